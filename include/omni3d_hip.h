@@ -1,0 +1,43 @@
+/* include/omni3d_hip.h -- C ABI of libomni3d_hip.so (gfx950 / MI355X).
+ *
+ * Every entry point takes raw DEVICE pointers, explicit sizes and a hipStream_t (passed as
+ * void*), returns an int status (0 = OMNI_OK, 1 = bad argument, 2 = launch failure), never
+ * allocates and never throws.  No torch types appear in any signature.  Each declaration cites
+ * the reference interface it replaces (paths relative to the facebookresearch/omni3d checkout).
+ * The reference itself has no FFI boundary (it is pure Python over detectron2 / torchvision /
+ * pytorch3d); INTEGRATION.md shows the ctypes stub a maintainer would add per entry point.
+ */
+#ifndef OMNI3D_HIP_H
+#define OMNI3D_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- IoU3D (evaluation) */
+
+/* pytorch3d._C.iou_box3d(boxes1, boxes2) as called at
+ * cubercnn/evaluation/omni3d_evaluation.py:155.  boxes1 (N,8,3), boxes2 (M,8,3) fp32 corner
+ * lists in the order documented at omni3d_evaluation.py:117-142.  Writes vol (N,M) [nullable]
+ * and iou (N,M).  valid1 [nullable] is an int32 (N) mask: rows with valid1[i]==0 are written as
+ * zeros without being computed (box3d_overlap, omni3d_evaluation.py:151-164).  overflow
+ * [nullable] is an int32 counter incremented when a pair exceeded the LDS triangle capacity. */
+int omni_iou_box3d(const float* boxes1, int N, const float* boxes2, int M, const int* valid1, float* vol,
+                   float* iou, int* overflow, void* stream);
+
+/* Paired / ragged form of the same computation, for the evaluator's per-(image, category)
+ * groups (Omni3Deval.computeIoU, omni3d_evaluation.py:1359-1431): pair p compares
+ * boxes1[idx1[p]] with boxes2[idx2[p]]; vol [nullable] and iou have npairs entries. */
+int omni_iou_box3d_pairs(const float* boxes1, const float* boxes2, const int* idx1, const int* idx2,
+                         long long npairs, const int* valid1, float* vol, float* iou, int* overflow,
+                         void* stream);
+
+/* _check_coplanar (omni3d_evaluation.py:65-86) and _check_nonzero (:89-104) fused:
+ * valid[i] = coplanar(i) && nonzero(i); counts [nullable, int32[2]] += {#non-coplanar, #zero}. */
+int omni_box3d_validity(const float* boxes, int N, float eps_coplanar, float eps_nonzero, int* valid,
+                        int* counts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNI3D_HIP_H */

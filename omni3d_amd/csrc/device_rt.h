@@ -1,0 +1,54 @@
+// device_rt.h -- gfx950 device/runtime prelude shared by every kernel translation unit.
+//
+// All kernels in omni3d_amd/csrc are written against plain HIP for CDNA4 (wave64, MFMA,
+// LDS).  This header only pulls in the HIP runtime and defines the small vector typedefs
+// and helpers the kernels share.  (tests/hipemu/ carries a host-side stand-in with the
+// same name that lets the *same kernel sources* run on the CPU of a GPU-less CI box; it
+// is test infrastructure and is never linked into the product library.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define OMNI_WAVE 64
+
+// status codes returned by every extern "C" entry point
+#define OMNI_OK 0
+#define OMNI_ERR_ARG 1
+#define OMNI_ERR_LAUNCH 2
+
+static inline int omni_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? OMNI_OK : OMNI_ERR_LAUNCH;
+}
+
+// wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// exact-f32 matrix cores (CDNA4): D = A(32x2) * B(2x32) + C, one f32 per lane for A and B.
+// lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
+// C/D: col j = l & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) for register r in [0,16).
+__device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// D = A(16x4) * B(4x16) + C.  lane l: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15];
+// C/D: col j = l & 15, row i = 4 * (l >> 4) + r, r in [0,4).
+__device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}

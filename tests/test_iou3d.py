@@ -1,0 +1,119 @@
+"""IoU3D kernel (omni3d_amd/csrc/iou_box3d.hip) against the C oracle.
+`not gpu`: the unmodified kernel source runs under the host fiber emulator (tests/hipemu).
+`gpu`: the gfx950 library through the C ABI, at oracle-sized and at BASELINE size (100k pairs)."""
+import numpy as np
+import pytest
+import torch
+
+import boxgen
+from test_iou3d_oracle import oracle_iou, oracle_overlap
+
+TOL = 1e-5  # fp32; north_star bar for IoU3D is 1e-4
+
+
+def _run_matrix(dev, b1, b2):
+    from omni3d_amd.kernels import iou3d
+    vol, iou = iou3d.iou_box3d(torch.from_numpy(b1).to(dev), torch.from_numpy(b2).to(dev))
+    return vol.cpu().numpy(), iou.cpu().numpy()
+
+
+def _suite(dev, oracle_lib, rng, n1, n2):
+    from omni3d_amd.kernels import iou3d
+    b1 = boxgen.random_boxes(rng, n1)
+    b2 = boxgen.random_boxes(rng, n2)
+    b2[0] = b1[0]                       # identical pair
+    b2[1] = b1[1] + np.float32(100.0)   # far apart
+    vol, iou = _run_matrix(dev, b1, b2)
+    vol_o, iou_o = oracle_iou(oracle_lib, b1, b2)
+    assert np.abs(iou - iou_o).max() < TOL
+    assert np.abs(vol - vol_o).max() < 1e-4
+    assert abs(iou[0, 0] - 1) < 1e-5 and iou[1, 1] == 0
+    # axis-aligned, face-sharing boxes exercise the coplanar epsilon branches identically
+    unit = (boxgen.UNIT + 0.5).astype(np.float32)
+    aa1 = np.stack([unit, unit * np.float32(2.0), unit + np.float32([1, 0, 0])])
+    aa2 = np.stack([unit + np.float32([0.5, 0, 0]), unit, unit + np.float32([0, 0.25, 0.25])])
+    vol, iou = _run_matrix(dev, aa1, aa2)
+    vol_o, iou_o = oracle_iou(oracle_lib, aa1, aa2)
+    assert np.abs(iou - iou_o).max() < TOL
+    # box3d_overlap with invalid detections (zero-area + skewed vertex)
+    dt, gt, deg = boxgen.omni3d_like_pairs(rng, 40, degenerate_frac=0.2)
+    got = iou3d.box3d_overlap(torch.from_numpy(dt).to(dev), torch.from_numpy(gt[:7]).to(dev), warn=False).cpu().numpy()
+    ref = oracle_overlap(oracle_lib, dt, gt[:7])
+    assert np.abs(got - ref).max() < TOL
+    assert deg.any() and (got[deg] == 0).all()
+    # ragged / paired form
+    idx1 = rng.integers(0, len(dt), 97).astype(np.int32)
+    idx2 = rng.integers(0, len(gt), 97).astype(np.int32)
+    _, ip = iou3d.iou_box3d_pairs(torch.from_numpy(dt).to(dev), torch.from_numpy(gt).to(dev),
+                                  torch.from_numpy(idx1).to(dev), torch.from_numpy(idx2).to(dev))
+    _, full = oracle_iou(oracle_lib, dt, gt)
+    assert np.abs(ip.cpu().numpy() - full[idx1, idx2]).max() < TOL
+    # empty inputs
+    e = torch.zeros((0, 8, 3), dtype=torch.float32, device=dev)
+    v0, i0 = iou3d.iou_box3d(e, torch.from_numpy(b2).to(dev))
+    assert i0.shape == (0, n2)
+    v0, i0 = iou3d.iou_box3d(torch.from_numpy(b1).to(dev), e)
+    assert i0.shape == (n1, 0)
+
+
+def test_iou3d_emulated(emu_lib, oracle_lib, rng):
+    _suite("cpu", oracle_lib, rng, 9, 8)
+
+
+def test_bad_arguments(emu_lib):
+    from omni3d_amd.kernels import iou3d
+    with pytest.raises(ValueError):
+        iou3d.iou_box3d(torch.zeros(3, 8, 2), torch.zeros(3, 8, 3))
+    with pytest.raises(ValueError):
+        iou3d.iou_box3d(torch.zeros(3, 8, 3, dtype=torch.float64), torch.zeros(3, 8, 3))
+
+
+def test_cpu_tensor_rejected_by_product_library():
+    """No CPU path: the product binding refuses CPU tensors (it is not the emulator)."""
+    from omni3d_amd import lib as L
+    from omni3d_amd.kernels import iou3d
+    import os
+    if not os.path.exists(L.LIB_PATH):
+        pytest.skip("product library not built")
+    prev = L._lib
+    L._install_for_tests(None)
+    try:
+        with pytest.raises(L.OmniHipError):
+            iou3d.iou_box3d(torch.zeros(1, 8, 3), torch.zeros(1, 8, 3))
+    finally:
+        L._install_for_tests(prev)
+
+
+@pytest.mark.gpu
+def test_iou3d_gpu(hip_lib, oracle_lib, rng):
+    _suite("cuda", oracle_lib, rng, 60, 50)
+
+
+@pytest.mark.gpu
+def test_iou3d_gpu_100k_pairs_properties(hip_lib, oracle_lib, rng):
+    """BASELINE config 5 size (100k pairs): size-independent properties + an oracle sample."""
+    from omni3d_amd.kernels import iou3d
+    dt, gt, deg = boxgen.omni3d_like_pairs(rng, 100_000)
+    d, g = torch.from_numpy(dt).cuda(), torch.from_numpy(gt).cuda()
+    ar = torch.arange(len(dt), dtype=torch.int32, device="cuda")
+    valid, counts = iou3d.box3d_validity(d)
+    vol, iou = iou3d.iou_box3d_pairs(d, g, ar, ar, valid1=valid)
+    iou = iou.cpu().numpy()
+    assert np.isfinite(iou).all() and (iou >= 0).all() and (iou <= 1 + 1e-5).all()
+    assert (iou[deg] == 0).all()
+    # self-IoU of every valid box is 1
+    _, self_iou = iou3d.iou_box3d_pairs(d, d, ar, ar, valid1=valid)
+    self_iou = self_iou.cpu().numpy()
+    assert np.abs(self_iou[~deg] - 1).max() < 1e-4
+    # swapping the operands leaves IoU unchanged up to rounding
+    _, swapped = iou3d.iou_box3d_pairs(g, d, ar, ar)
+    ok = ~deg
+    assert np.abs(swapped.cpu().numpy()[ok] - iou[ok]).max() < 1e-4
+    # rigid motion invariance: translate both boxes
+    shift = torch.tensor([3.0, -2.0, 5.0], device="cuda")
+    _, moved = iou3d.iou_box3d_pairs(d + shift, g + shift, ar, ar, valid1=valid)
+    assert np.abs(moved.cpu().numpy() - iou).max() < 2e-4
+    # oracle on a 2000-pair sample
+    sel = rng.choice(len(dt), 2000, replace=False)
+    ref = np.array([oracle_overlap(oracle_lib, dt[i:i + 1], gt[i:i + 1])[0, 0] for i in sel])
+    assert np.abs(iou[sel] - ref).max() < TOL
