@@ -1,0 +1,142 @@
+#!/usr/bin/env python
+"""bench.py -- measures the hot path on MI355X.  Contract: see the repo task statement.
+
+  python bench.py --gpus N --steps K --warmup W [--workload train|iou3d]
+
+Prints ONE JSON line on rank 0.  `train` (default once available) = images/sec of the
+cubercnn_DLA34_FPN training step, batch 4/GPU, synthetic 512x512 Omni3D-shaped inputs;
+`iou3d` = BASELINE config 5 (100k dt x gt box pairs through box3d_overlap).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
+
+
+def setup_dist(ngpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    return world, rank, local
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world):
+    if world == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def run_iou3d(args, world, rank):
+    """One step = one pass of box3d_overlap's work over 100k (dt, gt) pairs resident in HBM.
+    Pairs are independent, so ranks shard them with no collective (weak scaling)."""
+    import boxgen
+    from omni3d_amd.kernels import iou3d
+    P = 100_000
+    rng = np.random.default_rng(1000 + rank)
+    dt, gt, _ = boxgen.omni3d_like_pairs(rng, P)
+    d, g = torch.from_numpy(dt).cuda(), torch.from_numpy(gt).cuda()
+    ar = torch.arange(P, dtype=torch.int32, device="cuda")
+
+    def step():
+        valid, _ = iou3d.box3d_validity(d)
+        return iou3d.iou_box3d_pairs(d, g, ar, ar, valid1=valid)[1]
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for a, b in ev:
+        valid, _ = iou3d.box3d_validity(d)
+        a.record()
+        out = iou3d.iou_box3d_pairs(d, g, ar, ar, valid1=valid)[1]
+        b.record()
+    barrier_sync(world)
+    dt_s = max_over_ranks(time.perf_counter() - t0, world)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    alg_bytes = P * (192 + 4)
+    res = {
+        "metric": "IoU3D box pairs/sec (box3d_overlap, 100k dt x gt pairs)", "value": P * world * args.steps / dt_s,
+        "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt_s / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "iou3d: 100k Omni3D-shaped oriented box pairs (50% overlapping, 1% degenerate)",
+                   "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}, no collective"},
+        "roofline": {"bound": "hbm", "kernel": "iou_box3d_kernel<1>", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None, "kernel_ms": kern_ms,
+                     "note": "196 B/pair algorithmic I/O; the kernel is VALU/branch bound, not HBM bound"},
+    }
+    if rank == 0:
+        res["cpu_baseline"] = cpu_baseline_iou3d(dt, gt)
+    return res
+
+
+def cpu_baseline_iou3d(dt, gt, nsample=20000):
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    Pt = ctypes.c_void_p
+    out = np.zeros(nsample, np.float32)
+    a, b = np.ascontiguousarray(dt[:nsample]), np.ascontiguousarray(gt[:nsample])
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 10.0:
+        orc.iou_box3d_pairs_oracle(a.ctypes.data_as(Pt), b.ctypes.data_as(Pt), nsample, out.ctypes.data_as(Pt))
+        reps += 1
+    el = time.perf_counter() - t0
+    return {"value": nsample * reps / el, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x first {nsample} pairs of the same workload, oracle/iou_box3d_oracle.c, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None)
+    args = ap.parse_args()
+    world, rank, _ = setup_dist(args.gpus)
+    workload = args.workload or DEFAULT_WORKLOAD
+    if workload == "iou3d":
+        res = run_iou3d(args, world, rank)
+    else:
+        from omni3d_amd.bench_train import run_train
+        res = run_train(args, world, rank)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+DEFAULT_WORKLOAD = "iou3d"
+
+if __name__ == "__main__":
+    main()
