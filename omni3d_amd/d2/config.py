@@ -1,0 +1,373 @@
+"""yacs/detectron2-style config: ``CfgNode`` (attribute dict, ``_BASE_`` YAML chains,
+``merge_from_list``, ``freeze``), ``get_cfg()`` with the upstream detectron2 v0.6 defaults the
+reference reads (every key set in /root/reference/configs/Base.yaml:1-87
+must already exist), and the ``configurable`` decorator
+(/root/reference/cubercnn/modeling/proposal_generator/rpn.py:22, roi_heads.py:42)."""
+import copy
+import functools
+import inspect
+import os
+from ast import literal_eval
+
+import yaml
+
+BASE_KEY = "_BASE_"
+
+
+class CfgNode(dict):
+    IMMUTABLE = "__immutable__"
+    NEW_ALLOWED = "__new_allowed__"
+
+    def __init__(self, init_dict=None, new_allowed=False):
+        init_dict = {} if init_dict is None else init_dict
+        super().__init__()
+        self.__dict__[CfgNode.IMMUTABLE] = False
+        self.__dict__[CfgNode.NEW_ALLOWED] = new_allowed
+        for k, v in init_dict.items():
+            self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+    # attribute access
+    def __getattr__(self, name):
+        if name in self:
+            return self[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if self.is_frozen():
+            raise AttributeError(f"Attempted to set {name} to {value}, but CfgNode is immutable")
+        self[name] = value
+
+    def is_frozen(self):
+        return self.__dict__[CfgNode.IMMUTABLE]
+
+    def _set_immutable(self, flag):
+        self.__dict__[CfgNode.IMMUTABLE] = flag
+        for v in self.values():
+            if isinstance(v, CfgNode):
+                v._set_immutable(flag)
+
+    def freeze(self):
+        self._set_immutable(True)
+
+    def defrost(self):
+        self._set_immutable(False)
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    def __deepcopy__(self, memo):
+        out = CfgNode(new_allowed=self.__dict__[CfgNode.NEW_ALLOWED])
+        for k, v in self.items():
+            dict.__setitem__(out, k, copy.deepcopy(v, memo))
+        out.__dict__[CfgNode.IMMUTABLE] = self.__dict__[CfgNode.IMMUTABLE]
+        return out
+
+    def dump(self, **kwargs):
+        def conv(n):
+            if isinstance(n, CfgNode):
+                return {k: conv(v) for k, v in n.items()}
+            if isinstance(n, tuple):
+                return list(n)
+            return n
+        return yaml.safe_dump(conv(self), **kwargs)
+
+    # merging
+    @staticmethod
+    def load_yaml_with_base(filename):
+        with open(filename, "r") as f:
+            cfg = yaml.safe_load(f) or {}
+
+        def merge_a_into_b(a, b):
+            for k, v in a.items():
+                if isinstance(v, dict) and k in b and isinstance(b[k], dict):
+                    merge_a_into_b(v, b[k])
+                else:
+                    b[k] = v
+
+        if BASE_KEY in cfg:
+            base_file = cfg.pop(BASE_KEY)
+            if base_file.startswith("~"):
+                base_file = os.path.expanduser(base_file)
+            if not os.path.isabs(base_file):
+                base_file = os.path.join(os.path.dirname(filename), base_file)
+            base = CfgNode.load_yaml_with_base(base_file)
+            merge_a_into_b(cfg, base)
+            return base
+        return cfg
+
+    def merge_from_file(self, cfg_filename, allow_unsafe=False):
+        loaded = CfgNode.load_yaml_with_base(cfg_filename)
+        self.merge_from_other_cfg(CfgNode(loaded))
+
+    def merge_from_other_cfg(self, other):
+        _merge(other, self, self, [])
+
+    def merge_from_list(self, cfg_list):
+        assert len(cfg_list) % 2 == 0, f"Override list has odd length: {cfg_list}"
+        for full_key, v in zip(cfg_list[0::2], cfg_list[1::2]):
+            d = self
+            parts = full_key.split(".")
+            for sub in parts[:-1]:
+                assert sub in d, f"Non-existent key: {full_key}"
+                d = d[sub]
+            sub = parts[-1]
+            assert sub in d, f"Non-existent key: {full_key}"
+            value = _decode(v)
+            value = _coerce(value, d[sub], full_key)
+            d[sub] = value
+
+
+def _decode(v):
+    if not isinstance(v, str):
+        return v
+    try:
+        return literal_eval(v)
+    except (ValueError, SyntaxError):
+        return v
+
+
+def _coerce(replacement, original, full_key):
+    ot, rt = type(original), type(replacement)
+    if rt == ot or original is None or replacement is None:
+        return replacement
+    for a, b in ((list, tuple), (tuple, list)):
+        if rt == a and ot == b:
+            return b(replacement)
+    if ot == float and rt == int:
+        return float(replacement)
+    if ot == str and rt != str:
+        return str(replacement)
+    raise ValueError(f"Type mismatch ({ot} vs. {rt}) with values ({original} vs. {replacement}) for config key: {full_key}")
+
+
+def _merge(a, b, root, key_list):
+    for k, v_ in a.items():
+        full_key = ".".join(key_list + [k])
+        v = copy.deepcopy(v_)
+        v = _decode(v)
+        if k in b:
+            if isinstance(v, dict) and isinstance(b[k], CfgNode):
+                _merge(CfgNode(v) if not isinstance(v, CfgNode) else v, b[k], root, key_list + [k])
+            else:
+                b[k] = _coerce(v, b[k], full_key)
+        elif b.__dict__[CfgNode.NEW_ALLOWED]:
+            b[k] = CfgNode(v) if isinstance(v, dict) else v
+        else:
+            raise KeyError(f"Non-existent config key: {full_key}")
+
+
+CN = CfgNode
+
+
+def get_cfg():
+    """detectron2.config.get_cfg() defaults (v0.6), restricted to the keys this code path and the
+    reference's YAML/`get_cfg_defaults` touch.  [upstream values: SURVEY.md Appendix B]"""
+    _C = CN()
+    _C.VERSION = 2
+    _C.MODEL = CN()
+    _C.MODEL.LOAD_PROPOSALS = False
+    _C.MODEL.MASK_ON = False
+    _C.MODEL.KEYPOINT_ON = False
+    _C.MODEL.DEVICE = "cuda"
+    _C.MODEL.META_ARCHITECTURE = "GeneralizedRCNN"
+    _C.MODEL.WEIGHTS = ""
+    _C.MODEL.PIXEL_MEAN = [103.530, 116.280, 123.675]
+    _C.MODEL.PIXEL_STD = [1.0, 1.0, 1.0]
+
+    _C.INPUT = CN()
+    _C.INPUT.MIN_SIZE_TRAIN = (800,)
+    _C.INPUT.MIN_SIZE_TRAIN_SAMPLING = "choice"
+    _C.INPUT.MAX_SIZE_TRAIN = 1333
+    _C.INPUT.MIN_SIZE_TEST = 800
+    _C.INPUT.MAX_SIZE_TEST = 1333
+    _C.INPUT.RANDOM_FLIP = "horizontal"
+    _C.INPUT.FORMAT = "BGR"
+    _C.INPUT.MASK_FORMAT = "polygon"
+    _C.INPUT.CROP = CN({"ENABLED": False, "TYPE": "relative_range", "SIZE": [0.9, 0.9]})
+
+    _C.DATASETS = CN()
+    _C.DATASETS.TRAIN = ()
+    _C.DATASETS.TEST = ()
+    _C.DATASETS.PROPOSAL_FILES_TRAIN = ()
+    _C.DATASETS.PROPOSAL_FILES_TEST = ()
+
+    _C.DATALOADER = CN()
+    _C.DATALOADER.NUM_WORKERS = 4
+    _C.DATALOADER.ASPECT_RATIO_GROUPING = True
+    _C.DATALOADER.SAMPLER_TRAIN = "TrainingSampler"
+    _C.DATALOADER.REPEAT_THRESHOLD = 0.0
+    _C.DATALOADER.FILTER_EMPTY_ANNOTATIONS = True
+
+    _C.MODEL.BACKBONE = CN()
+    _C.MODEL.BACKBONE.NAME = "build_resnet_backbone"
+    _C.MODEL.BACKBONE.FREEZE_AT = 2
+
+    _C.MODEL.FPN = CN()
+    _C.MODEL.FPN.IN_FEATURES = []
+    _C.MODEL.FPN.OUT_CHANNELS = 256
+    _C.MODEL.FPN.NORM = ""
+    _C.MODEL.FPN.FUSE_TYPE = "sum"
+
+    _C.MODEL.PROPOSAL_GENERATOR = CN()
+    _C.MODEL.PROPOSAL_GENERATOR.NAME = "RPN"
+    _C.MODEL.PROPOSAL_GENERATOR.MIN_SIZE = 0
+
+    _C.MODEL.ANCHOR_GENERATOR = CN()
+    _C.MODEL.ANCHOR_GENERATOR.NAME = "DefaultAnchorGenerator"
+    _C.MODEL.ANCHOR_GENERATOR.SIZES = [[32, 64, 128, 256, 512]]
+    _C.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS = [[0.5, 1.0, 2.0]]
+    _C.MODEL.ANCHOR_GENERATOR.ANGLES = [[-90, 0, 90]]
+    _C.MODEL.ANCHOR_GENERATOR.OFFSET = 0.0
+
+    _C.MODEL.RPN = CN()
+    _C.MODEL.RPN.HEAD_NAME = "StandardRPNHead"
+    _C.MODEL.RPN.IN_FEATURES = ["res4"]
+    _C.MODEL.RPN.BOUNDARY_THRESH = -1
+    _C.MODEL.RPN.IOU_THRESHOLDS = [0.3, 0.7]
+    _C.MODEL.RPN.IOU_LABELS = [0, -1, 1]
+    _C.MODEL.RPN.BATCH_SIZE_PER_IMAGE = 256
+    _C.MODEL.RPN.POSITIVE_FRACTION = 0.5
+    _C.MODEL.RPN.BBOX_REG_LOSS_TYPE = "smooth_l1"
+    _C.MODEL.RPN.BBOX_REG_LOSS_WEIGHT = 1.0
+    _C.MODEL.RPN.BBOX_REG_WEIGHTS = (1.0, 1.0, 1.0, 1.0)
+    _C.MODEL.RPN.SMOOTH_L1_BETA = 0.0
+    _C.MODEL.RPN.LOSS_WEIGHT = 1.0
+    _C.MODEL.RPN.PRE_NMS_TOPK_TRAIN = 12000
+    _C.MODEL.RPN.PRE_NMS_TOPK_TEST = 6000
+    _C.MODEL.RPN.POST_NMS_TOPK_TRAIN = 2000
+    _C.MODEL.RPN.POST_NMS_TOPK_TEST = 1000
+    _C.MODEL.RPN.NMS_THRESH = 0.7
+    _C.MODEL.RPN.CONV_DIMS = [-1]
+
+    _C.MODEL.ROI_HEADS = CN()
+    _C.MODEL.ROI_HEADS.NAME = "Res5ROIHeads"
+    _C.MODEL.ROI_HEADS.NUM_CLASSES = 80
+    _C.MODEL.ROI_HEADS.IN_FEATURES = ["res4"]
+    _C.MODEL.ROI_HEADS.IOU_THRESHOLDS = [0.5]
+    _C.MODEL.ROI_HEADS.IOU_LABELS = [0, 1]
+    _C.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 512
+    _C.MODEL.ROI_HEADS.POSITIVE_FRACTION = 0.25
+    _C.MODEL.ROI_HEADS.SCORE_THRESH_TEST = 0.05
+    _C.MODEL.ROI_HEADS.NMS_THRESH_TEST = 0.5
+    _C.MODEL.ROI_HEADS.PROPOSAL_APPEND_GT = True
+
+    _C.MODEL.ROI_BOX_HEAD = CN()
+    _C.MODEL.ROI_BOX_HEAD.NAME = ""
+    _C.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE = "smooth_l1"
+    _C.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT = 1.0
+    _C.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS = (10.0, 10.0, 5.0, 5.0)
+    _C.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA = 0.0
+    _C.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION = 14
+    _C.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO = 0
+    _C.MODEL.ROI_BOX_HEAD.POOLER_TYPE = "ROIAlignV2"
+    _C.MODEL.ROI_BOX_HEAD.NUM_FC = 0
+    _C.MODEL.ROI_BOX_HEAD.FC_DIM = 1024
+    _C.MODEL.ROI_BOX_HEAD.NUM_CONV = 0
+    _C.MODEL.ROI_BOX_HEAD.CONV_DIM = 256
+    _C.MODEL.ROI_BOX_HEAD.NORM = ""
+    _C.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = False
+    _C.MODEL.ROI_BOX_HEAD.TRAIN_ON_PRED_BOXES = False
+
+    _C.MODEL.RESNETS = CN()
+    _C.MODEL.RESNETS.DEPTH = 50
+    _C.MODEL.RESNETS.OUT_FEATURES = ["res4"]
+    _C.MODEL.RESNETS.NUM_GROUPS = 1
+    _C.MODEL.RESNETS.NORM = "FrozenBN"
+    _C.MODEL.RESNETS.WIDTH_PER_GROUP = 64
+    _C.MODEL.RESNETS.STRIDE_IN_1X1 = True
+    _C.MODEL.RESNETS.RES5_DILATION = 1
+    _C.MODEL.RESNETS.RES2_OUT_CHANNELS = 256
+    _C.MODEL.RESNETS.STEM_OUT_CHANNELS = 64
+
+    _C.SOLVER = CN()
+    _C.SOLVER.LR_SCHEDULER_NAME = "WarmupMultiStepLR"
+    _C.SOLVER.MAX_ITER = 40000
+    _C.SOLVER.BASE_LR = 0.001
+    _C.SOLVER.MOMENTUM = 0.9
+    _C.SOLVER.NESTEROV = False
+    _C.SOLVER.WEIGHT_DECAY = 0.0001
+    _C.SOLVER.WEIGHT_DECAY_NORM = 0.0
+    _C.SOLVER.GAMMA = 0.1
+    _C.SOLVER.STEPS = (30000,)
+    _C.SOLVER.WARMUP_FACTOR = 1.0 / 1000
+    _C.SOLVER.WARMUP_ITERS = 1000
+    _C.SOLVER.WARMUP_METHOD = "linear"
+    _C.SOLVER.CHECKPOINT_PERIOD = 5000
+    _C.SOLVER.IMS_PER_BATCH = 16
+    _C.SOLVER.REFERENCE_WORLD_SIZE = 0
+    _C.SOLVER.BIAS_LR_FACTOR = 1.0
+    _C.SOLVER.WEIGHT_DECAY_BIAS = None
+    _C.SOLVER.CLIP_GRADIENTS = CN({"ENABLED": False, "CLIP_TYPE": "value", "CLIP_VALUE": 1.0, "NORM_TYPE": 2.0})
+    _C.SOLVER.AMP = CN({"ENABLED": False})
+
+    _C.TEST = CN()
+    _C.TEST.EXPECTED_RESULTS = []
+    _C.TEST.EVAL_PERIOD = 0
+    _C.TEST.DETECTIONS_PER_IMAGE = 100
+    _C.TEST.AUG = CN({"ENABLED": False})
+    _C.TEST.PRECISE_BN = CN({"ENABLED": False, "NUM_ITER": 200})
+
+    _C.OUTPUT_DIR = "./output"
+    _C.SEED = -1
+    _C.CUDNN_BENCHMARK = False
+    _C.VIS_PERIOD = 0
+    _C.GLOBAL = CN({"HACK": 1.0})
+    return _C
+
+
+def _called_with_cfg(*args, **kwargs):
+    if len(args) and isinstance(args[0], CfgNode):
+        return True
+    if isinstance(kwargs.get("cfg", None), CfgNode):
+        return True
+    return False
+
+
+def _get_args_from_config(from_config_func, *args, **kwargs):
+    sig = inspect.signature(from_config_func)
+    if list(sig.parameters.keys())[0] != "cfg":
+        raise TypeError(f"{from_config_func} must take 'cfg' as the first argument!")
+    support_var_arg = any(p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD) for p in sig.parameters.values())
+    if support_var_arg:
+        ret = from_config_func(*args, **kwargs)
+    else:
+        supported = set(sig.parameters.keys())
+        extra = {k: kwargs.pop(k) for k in list(kwargs.keys()) if k not in supported}
+        ret = from_config_func(*args, **kwargs)
+        ret.update(extra)
+    return ret
+
+
+def configurable(init_func=None, *, from_config=None):
+    """Decorate ``__init__`` so the class can be built either from explicit arguments or from a
+    ``cfg`` through its ``from_config`` classmethod (detectron2.config.configurable)."""
+    if init_func is not None:
+        assert inspect.isfunction(init_func) and from_config is None and init_func.__name__ == "__init__"
+
+        @functools.wraps(init_func)
+        def wrapped(self, *args, **kwargs):
+            try:
+                from_config_func = type(self).from_config
+            except AttributeError as e:
+                raise AttributeError("Class with @configurable must have a 'from_config' classmethod.") from e
+            if not inspect.ismethod(from_config_func):
+                raise TypeError("Class with @configurable must have a 'from_config' classmethod.")
+            if _called_with_cfg(*args, **kwargs):
+                explicit_args = _get_args_from_config(from_config_func, *args, **kwargs)
+                init_func(self, **explicit_args)
+            else:
+                init_func(self, *args, **kwargs)
+        return wrapped
+
+    assert from_config is not None
+
+    def wrapper(orig_func):
+        @functools.wraps(orig_func)
+        def wrapped(*args, **kwargs):
+            if _called_with_cfg(*args, **kwargs):
+                explicit_args = _get_args_from_config(from_config, *args, **kwargs)
+                return orig_func(**explicit_args)
+            return orig_func(*args, **kwargs)
+        wrapped.from_config = from_config
+        return wrapped
+    return wrapper

@@ -1,0 +1,32 @@
+"""fvcore.common.registry.Registry work-alike (used at e.g.
+/root/reference/cubercnn/modeling/roi_heads/cube_head.py:17-19, rcnn3d.py:25)."""
+
+
+class Registry:
+    def __init__(self, name):
+        self._name = name
+        self._obj_map = {}
+
+    def _do_register(self, name, obj):
+        assert name not in self._obj_map, f"An object named '{name}' was already registered in '{self._name}' registry!"
+        self._obj_map[name] = obj
+
+    def register(self, obj=None):
+        if obj is None:
+            def deco(func_or_class):
+                self._do_register(func_or_class.__name__, func_or_class)
+                return func_or_class
+            return deco
+        self._do_register(obj.__name__, obj)
+
+    def get(self, name):
+        ret = self._obj_map.get(name)
+        if ret is None:
+            raise KeyError(f"No object named '{name}' found in '{self._name}' registry!")
+        return ret
+
+    def __contains__(self, name):
+        return name in self._obj_map
+
+    def __iter__(self):
+        return iter(self._obj_map.items())

@@ -1,0 +1,84 @@
+"""Synthetic Omni3D-shaped training batches (BASELINE configs 1-4).
+
+Produces the batched-input schema of the reference's DatasetMapper3D
+(/root/reference/cubercnn/data/dataset_mapper.py:17-58,133-155): per image a dict with `image`
+uint8 (3,H,W) BGR, `height`, `width`, `K` 3x3, `image_id`, `dataset_id`, and `instances` carrying
+gt_classes int64 (-1 = ignore), gt_boxes (Boxes XYXY), gt_boxes3D (M,9) = [u, v, z, w, h, l, X, Y, Z]
+and gt_poses (M,3,3).  There is no network and no dataset here; benchmarks and parity tests use this
+generator (seeded, numpy only) on every side of a comparison.
+"""
+import numpy as np
+import torch
+
+from .d2.structures import Boxes, Instances
+
+
+def make_priors(num_classes=50, seed=0):
+    """`priors['priors_dims_per_cat']` (K,2,3): per-class mean / std of (w,h,l) in metres
+    (roi_heads.py:117-118).  Fixed table: mean U[.3,4], std = 0.2 * mean."""
+    rs = np.random.RandomState(1000 + seed)
+    mean = rs.uniform(0.3, 4.0, size=(num_classes, 3))
+    std = 0.2 * mean
+    return {"priors_dims_per_cat": np.stack([mean, std], axis=1).astype(np.float32).tolist(), "priors_bins": None}
+
+
+def _cuboid_corners(xyz, whl, R):
+    """8 corners in the order of math_util.get_cuboid_verts_faces (math_util.py:151-181)."""
+    w, h, l = whl
+    x = np.array([-l, l, l, -l, -l, l, l, -l]) / 2
+    y = np.array([-h, -h, h, h, -h, -h, h, h]) / 2
+    z = np.array([-w, -w, -w, -w, w, w, w, w]) / 2
+    v = R @ np.stack([x, y, z])
+    return (v + np.asarray(xyz)[:, None]).T
+
+
+def _euler_yxz(yaw, pitch, roll):
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+    return Ry @ Rx @ Rz
+
+
+def make_batch(num_images=2, height=512, width=512, num_gt=8, num_classes=50, seed=0, priors=None, focal=None,
+               num_ignore=1):
+    priors = priors or make_priors(num_classes)
+    prior_mean = np.asarray(priors["priors_dims_per_cat"])[:, 0, :]
+    rs = np.random.RandomState(seed)
+    f = float(focal if focal is not None else max(height, width))
+    K = [[f, 0.0, width / 2.0], [0.0, f, height / 2.0], [0.0, 0.0, 1.0]]
+    batch = []
+    for i in range(num_images):
+        image = torch.from_numpy(rs.randint(0, 256, size=(3, height, width)).astype(np.uint8))
+        classes, boxes2d, boxes3d, poses = [], [], [], []
+        for j in range(num_gt):
+            c = int(rs.randint(0, num_classes))
+            whl = prior_mean[c] * rs.uniform(0.8, 1.2, size=3)
+            z = rs.uniform(2.0, 40.0)
+            u = rs.uniform(0.15 * width, 0.85 * width)
+            v = rs.uniform(0.15 * height, 0.85 * height)
+            X = z * (u - K[0][2]) / f
+            Y = z * (v - K[1][2]) / f
+            R = _euler_yxz(rs.uniform(-np.pi, np.pi), rs.normal(scale=0.05), rs.normal(scale=0.05))
+            corners = _cuboid_corners((X, Y, z), whl, R)
+            zc = np.maximum(corners[:, 2], 0.1)
+            px = f * corners[:, 0] / zc + K[0][2]
+            py = f * corners[:, 1] / zc + K[1][2]
+            x1, y1 = max(px.min(), 0.0), max(py.min(), 0.0)
+            x2, y2 = min(px.max(), float(width)), min(py.max(), float(height))
+            if x2 - x1 < 2.0:
+                x1, x2 = max(u - 1.0, 0.0), min(u + 1.0, float(width))
+            if y2 - y1 < 2.0:
+                y1, y2 = max(v - 1.0, 0.0), min(v + 1.0, float(height))
+            classes.append(-1 if j >= num_gt - num_ignore else c)
+            boxes2d.append([x1, y1, x2, y2])
+            boxes3d.append([u, v, z, whl[0], whl[1], whl[2], X, Y, z])
+            poses.append(R)
+        inst = Instances((height, width))
+        inst.gt_classes = torch.tensor(classes, dtype=torch.int64)
+        inst.gt_boxes = Boxes(torch.tensor(np.asarray(boxes2d), dtype=torch.float32))
+        inst.gt_boxes3D = torch.tensor(np.asarray(boxes3d), dtype=torch.float32)
+        inst.gt_poses = torch.tensor(np.asarray(poses), dtype=torch.float32)
+        batch.append({"image": image, "height": height, "width": width, "K": K, "image_id": seed * 1000 + i,
+                      "dataset_id": 0, "instances": inst})
+    return batch
