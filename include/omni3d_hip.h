@@ -37,6 +37,26 @@ int omni_iou_box3d_pairs(const float* boxes1, const float* boxes2, const int* id
 int omni_box3d_validity(const float* boxes, int N, float eps_coplanar, float eps_nonzero, int* valid,
                         int* counts, void* stream);
 
+/* ------------------------------------------------- convolution / linear (fp32 MFMA, NHWC) */
+
+/* torch.nn.Conv2d forward as used by the DLA-34 bottom-up (cubercnn/modeling/backbone/dla.py:
+ * 43-51,159-161,241-245,291-295), detectron2 FPN (dla.py:500-506) and StandardRPNHead
+ * (configs/Base.yaml:49); and torch.nn.Linear (H=W=R=S=1: FastRCNNConvFCHead,
+ * cubercnn/modeling/roi_heads/cube_head.py:70,108-144).
+ * x is NHWC fp32 (N,H,W,C) with pixel pitch ldx floats, w is KRSC fp32, bias [nullable] (K),
+ * out NHWC (N,OH,OW,K) with pitch ldo.  C and ldx must be multiples of 4.  relu != 0 fuses ReLU. */
+int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C,
+                    int K, int R, int S, int stride, int pad, int ldx, int ldo, int relu, void* stream);
+
+/* grad wrt the input of the same convolution (autograd of the call sites above):
+ * dx (N,H,W,C) pitch lddx (=|+= when accumulate) from dy (N,OH,OW,K) pitch lddy. K % 4 == 0. */
+int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R,
+                      int S, int stride, int pad, int lddy, int lddx, int accumulate, void* stream);
+
+/* grad wrt the weights: dw (K,R,S,C) overwritten.  Split-K over output pixels, fp32 atomics. */
+int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R,
+                      int S, int stride, int pad, int ldx, int lddy, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

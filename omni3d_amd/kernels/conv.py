@@ -1,0 +1,96 @@
+"""Convolution / linear launchers over the implicit-GEMM kernels (csrc/conv_gemm.hip).
+
+Tensors cross this boundary in torch's channels_last memory format: logically (N,C,H,W) /
+(K,C,R,S) like the reference's nn.Conv2d, physically NHWC / KRSC, so `permute(0,2,3,1)` is a
+free contiguous view.  Channel counts must be multiples of 4 (16-byte loads); callers pad the
+3-channel image and the odd-sized prediction heads.
+"""
+import torch
+
+from .. import lib as _lib
+
+
+def _nhwc(t):
+    """logical NCHW channels_last tensor -> (N,H,W,C) contiguous view (no copy when already CL)."""
+    if t.dim() != 4:
+        raise ValueError("expected a 4-D tensor")
+    v = t.permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        v = v.contiguous()
+    return v
+
+
+def to_channels_last(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, relu=False):
+    """x (N,C,H,W) CL, w (K,C,R,S) CL -> y (N,K,OH,OW) CL."""
+    xv, wv = _nhwc(x), _nhwc(w)
+    N, H, W, C = xv.shape
+    K, R, S, C2 = wv.shape
+    assert C == C2, (C, C2)
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    L = _lib.check_device(xv, wv, bias)
+    out = torch.empty((N, OH, OW, K), dtype=torch.float32, device=x.device)
+    L.call("omni_conv2d_fwd", _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(bias), _lib.ptr(out), N, H, W, C, K, R, S, stride,
+           pad, C, K, int(relu), _lib.stream_of(x))
+    return out.permute(0, 3, 1, 2)
+
+
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0):
+    """dy (N,K,OH,OW) CL, w (K,C,R,S) CL -> dx (N,C,H,W) CL."""
+    dyv, wv = _nhwc(dy), _nhwc(w)
+    N, OH, OW, K = dyv.shape
+    K2, R, S, C = wv.shape
+    assert K == K2
+    H, W = in_hw
+    L = _lib.check_device(dyv, wv)
+    dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+    L.call("omni_conv2d_dgrad", _lib.ptr(dyv), _lib.ptr(wv), _lib.ptr(dx), N, H, W, C, K, R, S, stride, pad, K, C, 0,
+           _lib.stream_of(dy))
+    return dx.permute(0, 3, 1, 2)
+
+
+def conv2d_wgrad(x, dy, ksize, stride=1, pad=0):
+    """x (N,C,H,W) CL, dy (N,K,OH,OW) CL -> dw (K,C,R,S) CL."""
+    xv, dyv = _nhwc(x), _nhwc(dy)
+    N, H, W, C = xv.shape
+    K = dyv.shape[3]
+    R, S = ksize
+    L = _lib.check_device(xv, dyv)
+    dw = torch.empty((K, R, S, C), dtype=torch.float32, device=x.device)
+    L.call("omni_conv2d_wgrad", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, K, R, S, stride, pad, C, K,
+           _lib.stream_of(x))
+    return dw.permute(0, 3, 1, 2)
+
+
+def linear_fwd(x, w, bias=None, relu=False):
+    """x (M, Cin), w (Cout, Cin) -> (M, Cout): the 1x1 / H=W=1 case of the same kernel."""
+    M, C = x.shape
+    K = w.shape[0]
+    L = _lib.check_device(x, w, bias)
+    out = torch.empty((M, K), dtype=torch.float32, device=x.device)
+    L.call("omni_conv2d_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), M, 1, 1, C, K, 1, 1, 1, 0, C, K,
+           int(relu), _lib.stream_of(x))
+    return out
+
+
+def linear_dgrad(dy, w):
+    M, K = dy.shape
+    C = w.shape[1]
+    L = _lib.check_device(dy, w)
+    dx = torch.empty((M, C), dtype=torch.float32, device=dy.device)
+    L.call("omni_conv2d_dgrad", _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), M, 1, 1, C, K, 1, 1, 1, 0, K, C, 0,
+           _lib.stream_of(dy))
+    return dx
+
+
+def linear_wgrad(x, dy):
+    M, C = x.shape
+    K = dy.shape[1]
+    L = _lib.check_device(x, dy)
+    dw = torch.empty((K, C), dtype=torch.float32, device=x.device)
+    L.call("omni_conv2d_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), M, 1, 1, C, K, 1, 1, 1, 0, C, K,
+           _lib.stream_of(x))
+    return dw

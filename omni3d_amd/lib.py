@@ -16,13 +16,35 @@ LIB_PATH = os.path.join(_HERE, "libomni3d_hip.so")
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
 _CODES = {"p": _P, "i": _I, "l": _L, "f": _F}
 
-# name -> argument codes; every entry point returns int status (0 = ok).
-# Keep in sync with include/omni3d_hip.h (tests/test_abi.py checks both directions).
-SIGNATURES = {
-    "omni_iou_box3d": "pipippppp",
-    "omni_iou_box3d_pairs": "pppplppppp",
-    "omni_box3d_validity": "piffppp",
-}
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "omni3d_hip.h")
+
+
+def parse_header(path=HEADER_PATH):
+    """name -> argument codes ('p' pointer, 'i' int, 'l' long long, 'f' float) for every
+    `int omni_*(...)` declared in include/omni3d_hip.h -- the single source of truth of the ABI."""
+    import re
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\bint\s+(omni_\w+)\s*\(([^)]*)\)\s*;", text):
+        codes = ""
+        for arg in m.group(2).split(","):
+            a = " ".join(arg.replace("const", " ").split())
+            if "*" in a:
+                codes += "p"
+            elif a.startswith("long long"):
+                codes += "l"
+            elif a.startswith("float"):
+                codes += "f"
+            elif a.startswith("int"):
+                codes += "i"
+            else:
+                raise ValueError(f"unparsed argument {arg!r} in {m.group(1)}")
+        decls[m.group(1)] = codes
+    return decls
+
+
+SIGNATURES = parse_header()
 
 
 class OmniHipError(RuntimeError):

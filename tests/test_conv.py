@@ -1,0 +1,99 @@
+"""Implicit-GEMM conv / linear kernels (csrc/conv_gemm.hip) vs plain PyTorch fp32 on CPU.
+fp32 MFMA is an fmaf chain; the CPU reference sums in a different order, so the tolerance is
+relative to sum|a*b| (1e-5 of it), far inside the 1e-4 north-star bar."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+CASES = [
+    # N, H, W, C, K, R, stride, pad
+    (1, 8, 8, 16, 32, 3, 1, 1),     # 256x32 tile path (K<=32)
+    (2, 9, 7, 8, 48, 3, 2, 1),      # ragged M, 128x64 path, stride 2
+    (1, 6, 6, 32, 72, 1, 1, 0),     # 1x1, 128x128 path with ragged N
+    (1, 10, 10, 4, 16, 7, 1, 3),    # 7x7 stem shape (C padded to 4), Kd=196 (tail slab)
+]
+
+
+def _mk(dev, *shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(dev)
+
+
+def _check(a, b, scale):
+    err = (a.cpu() - b).abs().max().item()
+    assert err <= 2e-5 * scale + 1e-6, (err, scale)
+
+
+def _run_case(dev, case):
+    from omni3d_amd.kernels import conv
+    N, H, W, C, K, R, stride, pad = case
+    x = _mk(dev, N, C, H, W, seed=1).contiguous(memory_format=torch.channels_last)
+    w = (_mk(dev, K, C, R, R, seed=2) * 0.2).contiguous(memory_format=torch.channels_last)
+    b = _mk(dev, K, seed=3)
+    xc, wc, bc = x.cpu(), w.cpu(), b.cpu()
+    ref = F.conv2d(xc, wc, bc, stride=stride, padding=pad)
+    scale = float(F.conv2d(xc.abs(), wc.abs(), None, stride=stride, padding=pad).max())
+    y = conv.conv2d_fwd(x, w, b, stride, pad, relu=False)
+    assert y.shape == ref.shape
+    _check(y, ref, scale)
+    yr = conv.conv2d_fwd(x, w, b, stride, pad, relu=True)
+    _check(yr, ref.clamp(min=0), scale)
+    dy = _mk(dev, *ref.shape, seed=4).contiguous(memory_format=torch.channels_last)
+    dyc = dy.cpu()
+    dx_ref = torch.nn.grad.conv2d_input(xc.shape, wc, dyc, stride=stride, padding=pad)
+    dw_ref = torch.nn.grad.conv2d_weight(xc, wc.shape, dyc, stride=stride, padding=pad)
+    dx = conv.conv2d_dgrad(dy, w, (H, W), stride, pad)
+    _check(dx, dx_ref, float(dx_ref.abs().max()) * 4 + 1)
+    dw = conv.conv2d_wgrad(x, dy, (R, R), stride, pad)
+    _check(dw, dw_ref, float(dw_ref.abs().max()) * 4 + 1)
+
+
+def _run_linear(dev, M, C, K):
+    from omni3d_amd.kernels import conv
+    x, w, b = _mk(dev, M, C, seed=5), _mk(dev, K, C, seed=6) * 0.1, _mk(dev, K, seed=7)
+    ref = F.linear(x.cpu(), w.cpu(), b.cpu())
+    y = conv.linear_fwd(x, w, b, relu=True)
+    _check(y, ref.clamp(min=0), float(ref.abs().max()) * 4)
+    dy = _mk(dev, M, K, seed=8)
+    _check(conv.linear_dgrad(dy, w), dy.cpu() @ w.cpu(), float((dy.cpu() @ w.cpu()).abs().max()) * 4)
+    _check(conv.linear_wgrad(x, dy), dy.cpu().t() @ x.cpu(), float((dy.cpu().t() @ x.cpu()).abs().max()) * 4)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_emulated(emu_lib, case):
+    _run_case("cpu", case)
+
+
+def test_linear_emulated(emu_lib):
+    _run_linear("cpu", 70, 36, 20)
+
+
+def test_conv_rejects_unaligned_channels(emu_lib):
+    from omni3d_amd.kernels import conv
+    from omni3d_amd.lib import OmniHipError
+    x = torch.zeros(1, 3, 8, 8).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(8, 3, 3, 3).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(OmniHipError):
+        conv.conv2d_fwd(x, w, None, 1, 1)
+
+
+GPU_CASES = CASES + [
+    (4, 64, 64, 64, 64, 3, 1, 1),
+    (2, 32, 32, 128, 256, 3, 2, 1),
+    (2, 16, 16, 448, 128, 1, 1, 0),
+    (1, 128, 128, 16, 16, 3, 1, 1),
+    (2, 24, 40, 256, 16, 1, 1, 0),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GPU_CASES)
+def test_conv_gpu(hip_lib, case):
+    _run_case("cuda", case)
+
+
+@pytest.mark.gpu
+def test_linear_gpu(hip_lib):
+    _run_linear("cuda", 300, 12544, 1024)
+    _run_linear("cuda", 130, 1024, 256)
