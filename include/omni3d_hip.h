@@ -57,6 +57,46 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
 int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R,
                       int S, int stride, int pad, int ldx, int lddy, void* stream);
 
+/* ------------------------------------------------------- BatchNorm / pooling / FPN (NHWC) */
+
+/* nn.BatchNorm2d in training mode (+ fused ReLU and residual add): cubercnn/modeling/backbone/
+ * dla.py:46-66 (BasicBlock), :162-172 (Root), :214 (project), :244,294 (conv levels).
+ * x, y, residual [nullable]: NHWC fp32 with P = N*H*W pixels, C % 4 == 0, C <= 1024.
+ * running_mean/var [nullable] updated with `momentum` (unbiased var) like F.batch_norm.
+ * Outputs kept for backward: mean_rstd (2C), scale_shift (2C).  ws: >= 2C doubles scratch. */
+int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                float* running_mean, float* running_var, float* mean_rstd, float* scale_shift, double* ws,
+                int P, int C, float eps, float momentum, int relu, void* stream);
+
+/* eval-mode / frozen BatchNorm (solver/build.py:71-76 freeze_bn): y = relu?(x*scale+shift(+res)). */
+int omni_bn_apply(const float* x, const float* scale_shift, const float* residual, float* y, int P, int C,
+                  int relu, void* stream);
+
+/* backward of omni_bn_fwd.  dy = grad wrt y; dres [nullable] = grad wrt residual;
+ * ws >= 2C doubles, coef 3C floats scratch. */
+int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd,
+                float* dx, float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C,
+                int relu, void* stream);
+
+/* nn.MaxPool2d(2, stride=2) (dla.py:209) forward / backward, NHWC. */
+int omni_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int omni_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+
+/* F.max_pool2d(x, kernel_size=1, stride=2) (dla.py:474, resnet.py:55): y[n,oh,ow]=x[n,2oh,2ow]. */
+int omni_subsample2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int omni_subsample2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+
+/* detectron2 FPN top-down step: out = lateral + F.interpolate(top, 2.0, "nearest"); and the
+ * gradient wrt `top` (2x2 block sums). */
+int omni_upsample2_add(const float* lat, const float* top, float* out, int N, int H, int W, int C,
+                       void* stream);
+int omni_upsample2_bwd(const float* dout, float* dtop, int N, int H, int W, int C, void* stream);
+
+/* GeneralizedRCNN.preprocess_image (called at cubercnn/modeling/meta_arch/rcnn3d.py:46,87):
+ * uint8 planar (N,3,H,W) -> fp32 NHWC (N,PH,PW,4), (v-mean)/std, channel 3 and padding = 0. */
+int omni_preprocess(const unsigned char* img, float* out, int N, int H, int W, int PH, int PW, float m0,
+                    float m1, float m2, float s0, float s1, float s2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

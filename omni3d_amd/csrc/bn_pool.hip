@@ -1,0 +1,397 @@
+// bn_pool.hip -- HBM-bound NHWC kernels of the DLA-34 / FPN bottom-up: training-mode BatchNorm
+// (batch statistics, affine, running-stat update) fused with ReLU and the residual add, its
+// backward, 2x2 max-pool, the stride-2 subsample that makes p6, the FPN nearest-2x top-down add,
+// and image normalisation.
+//
+// Reference call sites:
+//   nn.BatchNorm2d + ReLU + `out += residual`   /root/reference/cubercnn/modeling/backbone/dla.py:46-66,162-172,214,244
+//   nn.MaxPool2d(2,2)                           dla.py:209      F.max_pool2d(k=1,s=2) dla.py:474
+//   FPN top-down `lateral + interpolate(prev, 2.0, "nearest")`   detectron2 FPN built at dla.py:500-506
+//   (img - PIXEL_MEAN) / PIXEL_STD + zero padding               GeneralizedRCNN.preprocess_image (rcnn3d.py:46)
+//
+// All of these move each byte once or twice and do a handful of flops per element: the roofline
+// is HBM (~6.3 TB/s achievable).  Layout is NHWC fp32, every lane moves 16 B (float4 = 4
+// channels), consecutive lanes walk the channel dimension first, so a wave reads 1 KiB contiguous.
+#include <device_rt.h>
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
+// (float4 + - * are the element-wise operators of HIP's vector types)
+__device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
+__device__ __forceinline__ float4 mask4(float4 g, float4 y) {
+    return make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
+}
+
+// ---- per-channel reductions over the P = N*H*W pixels of an NHWC tensor -------------------------
+// MODE 0: (sum x, sum x^2)                                  -> forward statistics
+// MODE 1: (sum dz, sum dz * xhat), dz = dy masked by y > 0  -> backward reductions
+// grid-stride over pixel rows; 256 threads = rows x C/4 column groups; LDS tree over rows; one
+// fp64 atomic per (block, channel, quantity).
+template <int MODE>
+__global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                                        int P, int C, int relu, double* __restrict__ acc) {
+    __shared__ float4 s0[256], s1[256];
+    const int C4 = C >> 2;
+    const int rows = 256 / C4;
+    const int t = threadIdx.x;
+    const int col = t % C4, row = t / C4;
+    const bool active = row < rows;
+    float4 a0 = f4(0.f), a1 = f4(0.f);
+    float4 mu = f4(0.f), rs = f4(0.f);
+    if (MODE == 1 && active) { mu = ld4(mean_rstd + 4 * col); rs = ld4(mean_rstd + C + 4 * col); }
+    if (active) {
+        for (long p = (long)blockIdx.x * rows + row; p < P; p += (long)gridDim.x * rows) {
+            const long off = p * C + 4 * col;
+            const float4 xv = ld4(x + off);
+            if (MODE == 0) {
+                a0 = a0 + xv;
+                a1 = a1 + xv * xv;
+            } else {
+                float4 g = ld4(dy + off);
+                if (relu) g = mask4(g, ld4(y + off));
+                a0 = a0 + g;
+                a1 = a1 + g * ((xv - mu) * rs);
+            }
+        }
+    }
+    s0[t] = a0;
+    s1[t] = a1;
+    __syncthreads();
+    if (t < C4) {
+        float4 r0 = s0[t], r1 = s1[t];
+        for (int r = 1; r < rows; ++r) { r0 = r0 + s0[r * C4 + t]; r1 = r1 + s1[r * C4 + t]; }
+        double* a = acc + 4 * t;
+        atomicAdd(a + 0, (double)r0.x); atomicAdd(a + 1, (double)r0.y); atomicAdd(a + 2, (double)r0.z); atomicAdd(a + 3, (double)r0.w);
+        double* b = acc + C + 4 * t;
+        atomicAdd(b + 0, (double)r1.x); atomicAdd(b + 1, (double)r1.y); atomicAdd(b + 2, (double)r1.z); atomicAdd(b + 3, (double)r1.w);
+    }
+}
+
+// forward finalize: mean, biased var -> rstd; scale/shift for the apply pass; running stats
+// (momentum m, unbiased variance) exactly like torch.nn.functional.batch_norm(training=True).
+__global__ void bn_finalize_fwd_kernel(const double* __restrict__ acc, int P, int C, float eps, float momentum,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ mean_rstd, float* __restrict__ scale_shift,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = acc[c] / P;
+    double var = acc[C + c] / P - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean_rstd[c] = (float)mean;
+    mean_rstd[C + c] = rstd;
+    const float sc = gamma[c] * rstd;
+    scale_shift[c] = sc;
+    scale_shift[C + c] = beta[c] - (float)mean * sc;
+    if (running_mean != nullptr) {
+        const double unbiased = P > 1 ? var * P / (P - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// y = relu?( x * scale + shift (+ residual) )
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale_shift,
+                                                       const float* __restrict__ residual, float* __restrict__ y,
+                                                       long total4, int C, int relu) {
+    const int C4 = C >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % C4);
+        float4 v = ld4(x + 4 * i) * ld4(scale_shift + 4 * col) + ld4(scale_shift + C + 4 * col);
+        if (residual != nullptr) v = v + ld4(residual + 4 * i);
+        if (relu) v = relu4(v);
+        st4(y + 4 * i, v);
+    }
+}
+
+// backward finalize: dgamma, dbeta out; coefficients for the apply pass:
+//   dx = g_rstd * (dz - a - xhat * b),  g_rstd = gamma*rstd, a = dbeta/P, b = dgamma/P
+__global__ void bn_finalize_bwd_kernel(const double* __restrict__ acc, int P, int C, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean_rstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double db = acc[c], dg = acc[C + c];
+    dbeta[c] = (float)db;
+    dgamma[c] = (float)dg;
+    coef[c] = gamma[c] * mean_rstd[C + c];
+    coef[C + c] = (float)(db / P);
+    coef[2 * C + c] = (float)(dg / P);
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                                           const float* __restrict__ coef, float* __restrict__ dx,
+                                                           float* __restrict__ dres, long total4, int C, int relu) {
+    const int C4 = C >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % C4);
+        float4 g = ld4(dy + 4 * i);
+        if (relu) g = mask4(g, ld4(y + 4 * i));
+        if (dres != nullptr) st4(dres + 4 * i, g);
+        const float4 xh = (ld4(x + 4 * i) - ld4(mean_rstd + 4 * col)) * ld4(mean_rstd + C + 4 * col);
+        const float4 v = ld4(coef + 4 * col) * (g - ld4(coef + C + 4 * col) - xh * ld4(coef + 2 * C + 4 * col));
+        st4(dx + 4 * i, v);
+    }
+}
+
+// ---- 2x2/s2 max-pool (NHWC); first maximum in window scan order wins, like ATen -----------------
+__global__ void __launch_bounds__(256) maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                           int H, int W, int C) {
+    const int C4 = C >> 2, OH = H >> 1, OW = W >> 1;
+    const long total = (long)N * OH * OW * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % C4);
+        long q = i / C4;
+        const int ow = (int)(q % OW); q /= OW;
+        const int oh = (int)(q % OH);
+        const int n = (int)(q / OH);
+        const float* b = x + (((long)n * H + 2 * oh) * W + 2 * ow) * C + 4 * col;
+        const float4 v00 = ld4(b), v01 = ld4(b + C), v10 = ld4(b + (long)W * C), v11 = ld4(b + (long)W * C + C);
+        float4 m;
+        m.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
+        m.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+        m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
+        m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+        st4(y + 4 * i, m);
+    }
+}
+
+__device__ __forceinline__ void route(float v00, float v01, float v10, float v11, float g, float& d00, float& d01,
+                                      float& d10, float& d11) {
+    int k = 0;
+    float m = v00;
+    if (v01 > m) { m = v01; k = 1; }
+    if (v10 > m) { m = v10; k = 2; }
+    if (v11 > m) { m = v11; k = 3; }
+    d00 = k == 0 ? g : 0.f; d01 = k == 1 ? g : 0.f; d10 = k == 2 ? g : 0.f; d11 = k == 3 ? g : 0.f;
+}
+
+__global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int N, int H, int W, int C) {
+    const int C4 = C >> 2, OH = H >> 1, OW = W >> 1;
+    const long total = (long)N * OH * OW * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % C4);
+        long q = i / C4;
+        const int ow = (int)(q % OW); q /= OW;
+        const int oh = (int)(q % OH);
+        const int n = (int)(q / OH);
+        const long o = (((long)n * H + 2 * oh) * W + 2 * ow) * C + 4 * col;
+        const float4 v00 = ld4(x + o), v01 = ld4(x + o + C), v10 = ld4(x + o + (long)W * C), v11 = ld4(x + o + (long)W * C + C);
+        const float4 g = ld4(dy + 4 * i);
+        float4 d00, d01, d10, d11;
+        route(v00.x, v01.x, v10.x, v11.x, g.x, d00.x, d01.x, d10.x, d11.x);
+        route(v00.y, v01.y, v10.y, v11.y, g.y, d00.y, d01.y, d10.y, d11.y);
+        route(v00.z, v01.z, v10.z, v11.z, g.z, d00.z, d01.z, d10.z, d11.z);
+        route(v00.w, v01.w, v10.w, v11.w, g.w, d00.w, d01.w, d10.w, d11.w);
+        st4(dx + o, d00); st4(dx + o + C, d01); st4(dx + o + (long)W * C, d10); st4(dx + o + (long)W * C + C, d11);
+    }
+}
+
+// ---- stride-2 subsample (max_pool2d kernel 1, stride 2): y[n,oh,ow] = x[n,2oh,2ow] ----------------
+// DIR 0: forward gather; DIR 1: backward scatter into a zero-initialised dx
+template <int DIR>
+__global__ void __launch_bounds__(256) subsample2_kernel(const float* __restrict__ src, float* __restrict__ dst, int N,
+                                                         int H, int W, int C) {
+    const int C4 = C >> 2, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long total = (long)N * OH * OW * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % C4);
+        long q = i / C4;
+        const int ow = (int)(q % OW); q /= OW;
+        const int oh = (int)(q % OH);
+        const int n = (int)(q / OH);
+        const long big = (((long)n * H + 2 * oh) * W + 2 * ow) * C + 4 * col;
+        if (DIR == 0) st4(dst + 4 * i, ld4(src + big));
+        else st4(dst + big, ld4(src + 4 * i));
+    }
+}
+
+// ---- FPN top-down: out = lateral + nearest_upsample_2x(top);  backward of the upsample ----------
+__global__ void __launch_bounds__(256) upsample2_add_kernel(const float* __restrict__ lat, const float* __restrict__ top,
+                                                            float* __restrict__ out, int N, int H, int W, int C) {
+    const int C4 = C >> 2, TH = H >> 1, TW = W >> 1;
+    const long total = (long)N * H * W * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % C4);
+        long q = i / C4;
+        const int w = (int)(q % W); q /= W;
+        const int h = (int)(q % H);
+        const int n = (int)(q / H);
+        const float4 t = ld4(top + (((long)n * TH + (h >> 1)) * TW + (w >> 1)) * C + 4 * col);
+        st4(out + 4 * i, ld4(lat + 4 * i) + t);
+    }
+}
+
+__global__ void __launch_bounds__(256) upsample2_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dtop,
+                                                            int N, int H, int W, int C) {
+    const int C4 = C >> 2, TH = H >> 1, TW = W >> 1;
+    const long total = (long)N * TH * TW * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % C4);
+        long q = i / C4;
+        const int tw = (int)(q % TW); q /= TW;
+        const int th = (int)(q % TH);
+        const int n = (int)(q / TH);
+        const long o = (((long)n * H + 2 * th) * W + 2 * tw) * C + 4 * col;
+        const float4 s = (ld4(dout + o) + ld4(dout + o + C)) + (ld4(dout + o + (long)W * C) + ld4(dout + o + (long)W * C + C));
+        st4(dtop + 4 * i, s);
+    }
+}
+
+// ---- image normalisation: uint8 planar (N,3,H,W) -> NHWC fp32 with 4 channels (4th = 0), the
+//      bottom/right padding up to (PH, PW) is zero AFTER normalisation (ImageList.from_tensors) ---
+__global__ void __launch_bounds__(256) preprocess_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
+                                                         int N, int H, int W, int PH, int PW, float m0, float m1,
+                                                         float m2, float s0, float s1, float s2) {
+    const long total = (long)N * PH * PW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % PW);
+        long q = i / PW;
+        const int h = (int)(q % PH);
+        const int n = (int)(q / PH);
+        float4 v = f4(0.f);
+        if (h < H && w < W) {
+            const unsigned char* b = img + ((long)n * 3 * H + h) * W + w;
+            v.x = ((float)b[0] - m0) / s0;
+            v.y = ((float)b[(long)H * W] - m1) / s1;
+            v.z = ((float)b[2L * H * W] - m2) / s2;
+        }
+        st4(out + 4 * i, v);
+    }
+}
+
+inline int ew_grid(long total) {
+    long g = (total + 255) / 256;
+    if (g > 256 * 8) g = 256 * 8;
+    return (int)(g < 1 ? 1 : g);
+}
+inline int red_grid(int P, int C) {
+    const int rows = 256 / (C >> 2);
+    long g = ((long)P + rows - 1) / rows;
+    if (g > 1024) g = 1024;
+    return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Training-mode BatchNorm forward on NHWC x (P = N*H*W pixels, C channels, C % 4 == 0, C <= 1024).
+// ws: >= 2*C doubles of scratch.  mean_rstd (2C) and scale_shift (2C) are outputs kept for backward.
+int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                float* running_mean, float* running_var, float* mean_rstd, float* scale_shift, double* ws, int P, int C,
+                float eps, float momentum, int relu, void* stream) {
+    if (P <= 0 || C <= 0 || (C & 3) || C > 1024) return OMNI_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(red_grid(P, C)), dim3(256), 0, st, x,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, P, C, 0, ws);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, P, C, eps,
+                       momentum, gamma, beta, mean_rstd, scale_shift, running_mean, running_var);
+    const long total4 = (long)P * (C >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, (const float*)scale_shift, residual, y,
+                       total4, C, relu);
+    return omni_launch_status();
+}
+
+// Inference / frozen BN: y = relu?(x*scale + shift (+res)) with caller-provided scale_shift (2C).
+int omni_bn_apply(const float* x, const float* scale_shift, const float* residual, float* y, int P, int C, int relu,
+                  void* stream) {
+    if (P <= 0 || C <= 0 || (C & 3)) return OMNI_ERR_ARG;
+    const long total4 = (long)P * (C >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, scale_shift, residual,
+                       y, total4, C, relu);
+    return omni_launch_status();
+}
+
+// Backward.  dy is the gradient wrt the (post-ReLU) output y; dres [nullable] receives the
+// gradient of the residual input.  ws: >= 2*C doubles, coef: 3*C floats of scratch.
+int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
+                float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C, int relu, void* stream) {
+    if (P <= 0 || C <= 0 || (C & 3) || C > 1024) return OMNI_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<1>), dim3(red_grid(P, C)), dim3(256), 0, st, x, dy, y, mean_rstd,
+                       P, C, relu, ws);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, P, C, gamma,
+                       mean_rstd, dgamma, dbeta, coef);
+    const long total4 = (long)P * (C >> 2);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, dy, y, mean_rstd,
+                       (const float*)coef, dx, dres, total4, C, relu);
+    return omni_launch_status();
+}
+
+int omni_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    if ((C & 3) || H < 2 || W < 2) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    if (total == 0) return OMNI_OK;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C);
+    return omni_launch_status();
+}
+
+int omni_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    if ((C & 3) || H < 2 || W < 2) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    if (total == 0) return OMNI_OK;
+    if ((H & 1) || (W & 1)) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * H * W * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C);
+    return omni_launch_status();
+}
+
+int omni_subsample2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    if (C & 3) return OMNI_ERR_ARG;
+    const long total = (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 4);
+    if (total == 0) return OMNI_OK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(subsample2_kernel<0>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x,
+                       y, N, H, W, C);
+    return omni_launch_status();
+}
+
+int omni_subsample2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    if (C & 3) return OMNI_ERR_ARG;
+    const long total = (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 4);
+    hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * H * W * C, (hipStream_t)stream);
+    if (total == 0) return OMNI_OK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(subsample2_kernel<1>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy,
+                       dx, N, H, W, C);
+    return omni_launch_status();
+}
+
+// out (N,H,W,C) = lat (N,H,W,C) + nearest-2x(top (N,H/2,W/2,C));  H, W even.
+int omni_upsample2_add(const float* lat, const float* top, float* out, int N, int H, int W, int C, void* stream) {
+    if ((C & 3) || (H & 1) || (W & 1)) return OMNI_ERR_ARG;
+    const long total = (long)N * H * W * (C / 4);
+    if (total == 0) return OMNI_OK;
+    hipLaunchKernelGGL(upsample2_add_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, lat, top, out, N, H,
+                       W, C);
+    return omni_launch_status();
+}
+
+// dtop (N,H/2,W/2,C) = 2x2 block sums of dout (N,H,W,C).
+int omni_upsample2_bwd(const float* dout, float* dtop, int N, int H, int W, int C, void* stream) {
+    if ((C & 3) || (H & 1) || (W & 1)) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    if (total == 0) return OMNI_OK;
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dout, dtop, N, H, W, C);
+    return omni_launch_status();
+}
+
+// img uint8 (N,3,H,W) -> out fp32 NHWC (N,PH,PW,4): (v - mean)/std per channel, zero padded.
+int omni_preprocess(const unsigned char* img, float* out, int N, int H, int W, int PH, int PW, float m0, float m1,
+                    float m2, float s0, float s1, float s2, void* stream) {
+    if (PH < H || PW < W) return OMNI_ERR_ARG;
+    const long total = (long)N * PH * PW;
+    if (total == 0) return OMNI_OK;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, img, out, N, H, W, PH,
+                       PW, m0, m1, m2, s0, s1, s2);
+    return omni_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+"""Launchers for csrc/bn_pool.hip.  All tensors are logical NCHW in channels_last memory
+(physically NHWC), fp32, C % 4 == 0."""
+import torch
+
+from .. import lib as _lib
+from .conv import _nhwc
+
+
+def _like_cl(shape_nhwc, ref):
+    return torch.empty(shape_nhwc, dtype=torch.float32, device=ref.device)
+
+
+def bn_fwd(x, gamma, beta, running_mean, running_var, residual=None, relu=False, eps=1e-5, momentum=0.1):
+    """-> (y CL, mean_rstd (2C), scale_shift (2C)); running stats updated in place."""
+    xv = _nhwc(x)
+    rv = _nhwc(residual) if residual is not None else None
+    N, H, W, C = xv.shape
+    L = _lib.check_device(xv, rv, gamma, beta, running_mean, running_var)
+    y = _like_cl((N, H, W, C), x)
+    mean_rstd = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    scale_shift = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    L.call("omni_bn_fwd", _lib.ptr(xv), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(rv), _lib.ptr(y),
+           _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), _lib.ptr(ws),
+           N * H * W, C, float(eps), float(momentum), int(relu), _lib.stream_of(x))
+    return y.permute(0, 3, 1, 2), mean_rstd, scale_shift
+
+
+def bn_apply(x, scale_shift, residual=None, relu=False):
+    xv = _nhwc(x)
+    rv = _nhwc(residual) if residual is not None else None
+    N, H, W, C = xv.shape
+    L = _lib.check_device(xv, rv, scale_shift)
+    y = _like_cl((N, H, W, C), x)
+    L.call("omni_bn_apply", _lib.ptr(xv), _lib.ptr(scale_shift), _lib.ptr(rv), _lib.ptr(y), N * H * W, C, int(relu),
+           _lib.stream_of(x))
+    return y.permute(0, 3, 1, 2)
+
+
+def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False):
+    """-> (dx CL, dres CL or None, dgamma, dbeta)."""
+    xv, dyv = _nhwc(x), _nhwc(dy)
+    yv = _nhwc(y) if relu else None
+    N, H, W, C = xv.shape
+    L = _lib.check_device(xv, dyv, yv, gamma, mean_rstd)
+    dx = _like_cl((N, H, W, C), x)
+    dres = _like_cl((N, H, W, C), x) if want_dres else None
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
+    L.call("omni_bn_bwd", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(dx),
+           _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, int(relu),
+           _lib.stream_of(x))
+    return dx.permute(0, 3, 1, 2), (dres.permute(0, 3, 1, 2) if want_dres else None), dgamma, dbeta
+
+
+def _simple(name, src, out_shape, dims, extra_in=()):
+    L = _lib.check_device(src, *extra_in)
+    out = torch.empty(out_shape, dtype=torch.float32, device=src.device)
+    L.call(name, *[_lib.ptr(t) for t in (src, *extra_in)], _lib.ptr(out), *dims, _lib.stream_of(src))
+    return out
+
+
+def maxpool2_fwd(x):
+    xv = _nhwc(x)
+    N, H, W, C = xv.shape
+    return _simple("omni_maxpool2_fwd", xv, (N, H // 2, W // 2, C), (N, H, W, C)).permute(0, 3, 1, 2)
+
+
+def maxpool2_bwd(x, dy):
+    xv, dyv = _nhwc(x), _nhwc(dy)
+    N, H, W, C = xv.shape
+    return _simple("omni_maxpool2_bwd", xv, (N, H, W, C), (N, H, W, C), extra_in=(dyv,)).permute(0, 3, 1, 2)
+
+
+def subsample2_fwd(x):
+    xv = _nhwc(x)
+    N, H, W, C = xv.shape
+    return _simple("omni_subsample2_fwd", xv, (N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), (N, H, W, C)).permute(0, 3, 1, 2)
+
+
+def subsample2_bwd(dy, in_hw):
+    dyv = _nhwc(dy)
+    N, _, _, C = dyv.shape
+    H, W = in_hw
+    return _simple("omni_subsample2_bwd", dyv, (N, H, W, C), (N, H, W, C)).permute(0, 3, 1, 2)
+
+
+def upsample2_add(lat, top):
+    lv, tv = _nhwc(lat), _nhwc(top)
+    N, H, W, C = lv.shape
+    assert tv.shape == (N, H // 2, W // 2, C), (tv.shape, lv.shape)
+    return _simple("omni_upsample2_add", lv, (N, H, W, C), (N, H, W, C), extra_in=(tv,)).permute(0, 3, 1, 2)
+
+
+def upsample2_bwd(dout):
+    dv = _nhwc(dout)
+    N, H, W, C = dv.shape
+    return _simple("omni_upsample2_bwd", dv, (N, H // 2, W // 2, C), (N, H, W, C)).permute(0, 3, 1, 2)
+
+
+def preprocess(images_u8, pixel_mean, pixel_std, size_divisibility=0):
+    """images (N,3,H,W) uint8 -> (N,4,PH,PW) CL fp32 normalised, zero padded (channel 3 = 0)."""
+    assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[1] == 3
+    images_u8 = images_u8.contiguous()
+    N, _, H, W = images_u8.shape
+    PH, PW = H, W
+    if size_divisibility > 1:
+        s = size_divisibility
+        PH, PW = (H + s - 1) // s * s, (W + s - 1) // s * s
+    L = _lib.check_device(images_u8)
+    out = torch.empty((N, PH, PW, 4), dtype=torch.float32, device=images_u8.device)
+    m, s = [float(v) for v in pixel_mean], [float(v) for v in pixel_std]
+    L.call("omni_preprocess", _lib.ptr(images_u8), _lib.ptr(out), N, H, W, PH, PW, m[0], m[1], m[2], s[0], s[1], s[2],
+           _lib.stream_of(images_u8))
+    return out.permute(0, 3, 1, 2)

@@ -46,6 +46,10 @@ struct alignas(16) float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
+// element-wise operators HIP's vector types provide natively
+static inline float4 operator+(float4 a, float4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+static inline float4 operator-(float4 a, float4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+static inline float4 operator*(float4 a, float4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
 static inline float2 make_float2(float x, float y) { return {x, y}; }
 static inline float3 make_float3(float x, float y, float z) { return {x, y, z}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }

@@ -1,0 +1,101 @@
+"""BatchNorm / pooling / FPN top-down / preprocess kernels (csrc/bn_pool.hip) vs PyTorch fp32 CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _run_bn(dev, N, C, H, W, relu, with_res):
+    from omni3d_amd.kernels import bnpool
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g) * 2 + 0.7
+    res = torch.randn(N, C, H, W, generator=g) if with_res else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    dy = torch.randn(N, C, H, W, generator=g)
+    # reference
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if with_res else None
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    if with_res:
+        z = z + rr
+    yr = F.relu(z) if relu else z
+    yr.backward(dy)
+    # kernel
+    rm_k, rv_k = rm.clone().to(dev), rv.clone().to(dev)
+    xk = _cl(x).to(dev)
+    y, mean_rstd, _ = bnpool.bn_fwd(xk, gamma.to(dev), beta.to(dev), rm_k, rv_k,
+                                    residual=_cl(res).to(dev) if with_res else None, relu=relu)
+    assert (y.cpu() - yr.detach()).abs().max() < 2e-5
+    assert (rm_k.cpu() - rm_ref).abs().max() < 1e-5 and (rv_k.cpu() - rv_ref).abs().max() < 1e-5
+    dx, dres, dgamma, dbeta = bnpool.bn_bwd(xk, _cl(dy).to(dev), y, gamma.to(dev), mean_rstd, relu=relu, want_dres=with_res)
+    assert (dx.cpu() - xr.grad).abs().max() < 5e-5
+    assert (dgamma.cpu() - gr.grad).abs().max() < 2e-4 * max(1.0, gr.grad.abs().max().item())
+    assert (dbeta.cpu() - br.grad).abs().max() < 2e-4 * max(1.0, br.grad.abs().max().item())
+    if with_res:
+        assert (dres.cpu() - rr.grad).abs().max() < 1e-6
+
+
+def _run_pool(dev):
+    from omni3d_amd.kernels import bnpool
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 6, 10, generator=g)
+    x[0, :, 0, 0] = x[0, :, 0, 1]  # a tie: first maximum must win
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    xk = _cl(x).to(dev)
+    assert torch.equal(bnpool.maxpool2_fwd(xk).cpu(), yr.detach())
+    assert torch.equal(bnpool.maxpool2_bwd(xk, _cl(dy).to(dev)).cpu(), xr.grad)
+    # stride-2 subsample, odd size
+    x = torch.randn(2, 4, 7, 5, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, kernel_size=1, stride=2, padding=0)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    assert torch.equal(bnpool.subsample2_fwd(_cl(x).to(dev)).cpu(), yr.detach())
+    assert torch.equal(bnpool.subsample2_bwd(_cl(dy).to(dev), (7, 5)).cpu(), xr.grad)
+    # FPN top-down
+    lat, top = torch.randn(2, 8, 6, 4, generator=g), torch.randn(2, 8, 3, 2, generator=g)
+    tr = top.clone().requires_grad_(True)
+    out = lat + F.interpolate(tr, scale_factor=2.0, mode="nearest")
+    dout = torch.randn_like(out)
+    out.backward(dout)
+    assert torch.equal(bnpool.upsample2_add(_cl(lat).to(dev), _cl(top).to(dev)).cpu(), out.detach())
+    assert (bnpool.upsample2_bwd(_cl(dout).to(dev)).cpu() - tr.grad).abs().max() < 1e-6
+    # preprocess
+    img = torch.randint(0, 256, (2, 3, 50, 70), generator=g, dtype=torch.uint8)
+    mean, std = [103.530, 116.280, 123.675], [57.375, 57.120, 58.395]
+    got = bnpool.preprocess(img.to(dev), mean, std, 64).cpu()
+    ref = (img.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    assert got.shape == (2, 4, 64, 128)
+    assert torch.equal(got[:, :3, :50, :70], ref)
+    assert got[:, 3].abs().max() == 0 and got[:, :, 50:].abs().max() == 0 and got[:, :, :, 70:].abs().max() == 0
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 5, 7, True, False), (1, 64, 4, 4, True, True), (3, 8, 3, 3, False, False),
+                                 (2, 512, 2, 2, False, True)])
+def test_bn_emulated(emu_lib, cfg):
+    _run_bn("cpu", *cfg)
+
+
+def test_pool_emulated(emu_lib):
+    _run_pool("cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(4, 16, 64, 64, True, False), (4, 128, 32, 32, True, True), (2, 512, 16, 16, False, False),
+                                 (2, 1024, 4, 4, True, True)])
+def test_bn_gpu(hip_lib, cfg):
+    _run_bn("cuda", *cfg)
+
+
+@pytest.mark.gpu
+def test_pool_gpu(hip_lib):
+    _run_pool("cuda")
