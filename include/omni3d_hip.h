@@ -97,6 +97,130 @@ int omni_upsample2_bwd(const float* dout, float* dtop, int N, int H, int W, int 
 int omni_preprocess(const unsigned char* img, float* out, int N, int H, int W, int PH, int PW, float m0,
                     float m1, float m2, float s0, float s1, float s2, void* stream);
 
+/* ----------------------------------------------------------- index-exact selection kernels */
+
+/* Row-wise sorted top-k (descending; equal keys -> lower index first).  Stands in for
+ * `logits.sort(descending=True)[:k]` of detectron2 find_top_rpn_proposals (RPN configured at
+ * configs/Base.yaml:49-54) and for torch.multinomial (== top-k of w / Exp(1)) at
+ * cubercnn/modeling/proposal_generator/rpn.py:318,322.  Element (r,i) = keys[r*pitch + i*estride].
+ * out_val / out_idx: (rows, k); slots >= min(k,n) hold -inf / -1.  k <= 2048. */
+int omni_topk_rows(const float* keys, int rows, int n, long long pitch, int estride, int k, float* out_val,
+                   int* out_idx, void* stream);
+
+/* Greedy NMS (torchvision.ops.nms semantics: suppress iff IoU > thr, areas (x2-x1)*(y2-y1)) for Q
+ * independent score-sorted problems; detectron2 batched_nms = one problem per (image, level) /
+ * (image, class): RPN [upstream], cubercnn/modeling/roi_heads/fast_rcnn.py:105.
+ * boxes (Q,nmax,4); counts [nullable] (Q); valid [nullable] (Q,nmax); keep (Q,nmax) int32 0/1;
+ * mask_ws: Q*nmax*ceil(nmax/64) 64-bit words scratch. nmax <= 8192. */
+int omni_nms_sorted(const float* boxes, const int* counts, const int* valid, int Q, int nmax, float iou_thr,
+                    unsigned long long* mask_ws, int* keep, void* stream);
+
+/* ---------------------------------------------- RPN / ROI-head box logic (index-exact parts) */
+
+/* detectron2 pairwise_iou (mode 0) / pairwise_ioa (mode 1): cubercnn/modeling/proposal_generator/
+ * rpn.py:62,100; roi_heads/roi_heads.py:881,892.  out (N, M). */
+int omni_pairwise_iou(const float* boxes1, int N, const float* boxes2, int M, int mode, float* out, void* stream);
+
+/* RPNWithIgnore.label_and_sample_anchors, matching half (rpn.py:62-75) = pairwise_iou + detectron2
+ * Matcher(thr, labels, allow_low_quality) + per-GT best anchor, for a batch of B images.
+ * anchors (A,4); gt: concatenated valid GT boxes (G,4) with gt_off (B+1); expo (B,A) Exp(1) variates.
+ * Outputs (B,A): matched_val, matched_idx (GT index inside the image), match_label int8,
+ * key_pos / key_neg = (iou+eps)/E for the positive / negative candidates (-inf elsewhere) whose
+ * top-k is the IoU-weighted multinomial of rpn.py:318,322; gt_best_idx (G); gt_best_bits (G) scratch. */
+int omni_rpn_match(const float* anchors, int A, const float* gt, const int* gt_off, int B, int G, float thr_lo,
+                   float thr_hi, int l0, int l1, int l2, int allow_low_quality, const float* expo, float eps,
+                   float* matched_val, int* matched_idx, signed char* match_label, int* gt_best_bits,
+                   int* gt_best_idx, float* key_pos, float* key_neg, void* stream);
+
+/* Second half (rpn.py:79-105): labels (B,A) int8 in {-1,0,1} from the sampled top-k lists, forced
+ * best-anchor positives and ignore regions (ign (Gi,4), ign_off (B+1)).  counts (B,2) [nullable]. */
+int omni_rpn_finalize_labels(const float* anchors, int A, int B, const int* gt_off, const float* ign,
+                             const int* ign_off, const signed char* match_label, const int* gt_best_idx,
+                             const float* pos_val, const int* pos_idx, const float* neg_val, const int* neg_idx,
+                             int kpos, int kneg, int batch_per_image, float ignore_thresh, signed char* labels,
+                             int* counts, void* stream);
+
+/* RPN head tensors: level_ptrs is a HOST array of nlev device pointers to (B, hw_l, 16) fp32
+ * [3 logits | 12 deltas | pad], level_hw a HOST int array.  Gathers the logits into (B, A). */
+int omni_rpn_gather_logits(const void* const* level_ptrs, const int* level_hw, int nlev, int B, float* logits,
+                           void* stream);
+
+/* RPNWithIgnore.losses with OBJECTNESS_UNCERTAINTY "IoUness" (rpn.py:129-204, 206-273): sums (6 doubles)
+ * = [sum BCE*t, sum L1*t, #pos, #neg, sum sigmoid(pos), sum sigmoid(non-pos)]. */
+int omni_rpn_loss_fwd(const void* const* level_ptrs, const int* level_hw, int nlev, int B, const float* anchors,
+                      const signed char* labels, const int* matched_idx, const float* gt, const int* gt_off,
+                      double* sums, void* stream);
+int omni_rpn_loss_bwd(const void* const* level_ptrs, const void* const* dlevel_ptrs, const int* level_hw, int nlev,
+                      int B, const float* anchors, const signed char* labels, const int* matched_idx,
+                      const float* gt, const int* gt_off, const float* g_cls, const float* g_loc, float inv_norm,
+                      void* stream);
+
+/* detectron2 RPN._decode_proposals + Boxes.clip + nonempty filter of find_top_rpn_proposals, applied
+ * to the selected per-level top-k anchors only.  slot_level (Ktot), idx (B,Ktot), image_hw (B,2) are
+ * device arrays; boxes (B,Ktot,4), valid (B,Ktot) out. */
+int omni_rpn_decode(const void* const* level_ptrs, const int* level_hw, int nlev, int B, int Ktot,
+                    const int* slot_level, const int* idx, const float* anchors, const int* image_hw,
+                    float scale_clamp, float min_size, float* boxes, int* valid, void* stream);
+
+/* ROIHeads3D.label_and_sample_proposals (roi_heads.py:862-929): append GT, Matcher(iou_thr), ignore
+ * regions, IoU-weighted sampling of <= nfg_max foreground + background up to batch_per_image.
+ * expo (B, 2048).  Outputs (B, batch_per_image): boxes, class (num_classes = bg, -2 = padding),
+ * global GT row, matched IoU; counts (B,2). */
+int omni_roi_sample(const float* prop_boxes, const int* prop_count, int B, int pmax, const float* gt,
+                    const int* gt_cls, const int* gt_off, const float* ign, const int* ign_off, const float* expo,
+                    float iou_thr, float ignore_thresh, float eps, int num_classes, int batch_per_image,
+                    int nfg_max, int append_gt, float* out_boxes, int* out_cls, int* out_gt, float* out_iou,
+                    int* out_counts, void* stream);
+
+/* ----------------------------------------------------------------------------- ROIAlign */
+
+/* detectron2 assign_boxes_to_levels (ROIPooler, canonical 224 / level 4). */
+int omni_roi_levels(const float* rois, int R, int min_level, int max_level, float canonical_size,
+                    int canonical_level, int* levels, void* stream);
+
+/* detectron2 ROIPooler + torchvision roi_align(aligned=True, sampling_ratio=0): box pooler
+ * (roi_heads.py:267) and cube pooler (roi_heads.py:166-171,362).  level_ptrs/level_hw/level_scale are
+ * HOST arrays; features (B,H_l,W_l,C) NHWC; out (R,P,P,C). */
+int omni_roi_align_fwd(const void* const* level_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                       const float* rois, const int* batch_idx, const int* levels, int R, int P, int C,
+                       float* out, void* stream);
+int omni_roi_align_bwd(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                       const float* rois, const int* batch_idx, const int* levels, int R, int P, int C,
+                       const float* dout, void* stream);
+
+/* ------------------------------------------------------------------- box-head / cube losses */
+
+/* FastRCNNOutputs.losses (cubercnn/modeling/roi_heads/fast_rcnn.py:145-260) on the fused prediction
+ * tensor pred (R, ldp) = [K+1 logits | 4K deltas].  sums (7 doubles). */
+int omni_box_loss_fwd(const float* pred, int ldp, int R, int K, const int* cls, const float* prop, const float* gt,
+                      const int* gt_row, float wx, float wy, float ww, float wh, double* sums, void* stream);
+int omni_box_loss_bwd(const float* pred, int ldp, int R, int K, const int* cls, const float* prop, const float* gt,
+                      const int* gt_row, float wx, float wy, float ww, float wh, const double* sums,
+                      const float* g_cls, const float* g_reg, float* dpred, void* stream);
+
+/* ROIHeads3D._forward_cube decode + disentangled losses (cubercnn/modeling/roi_heads/roi_heads.py:
+ * 374-768) on the fused cube-head outputs head (F, ldh) = [xy 2K | z K | dims 3K | pose 6K | uncert K]. */
+int omni_cube_loss_fwd(const float* head, int ldh, int F, int K, const float* boxes, const int* cls, const int* img,
+                       const float* Ks, const float* v2r, const float* priors, const float* gt3d,
+                       const float* gtpose, const int* gt_row, float* vals, float* jac, float* red, void* stream);
+int omni_cube_loss_bwd(const float* vals, const float* jac, const float* red, const float* gk, const int* cls, int F,
+                       int K, int ldh, float* dhead, void* stream);
+/* inference outputs (roi_heads.py:771-819): cube3d (F,9), pose (F,9), verts (F,24). */
+int omni_cube_decode(const float* head, int ldh, int F, int K, const float* boxes, const int* cls, const int* img,
+                     const float* Ks, const float* v2r, const float* ratio, const float* priors, float* cube3d,
+                     float* pose, float* verts, void* stream);
+/* util.get_cuboid_verts_faces (cubercnn/util/math_util.py:116-219): box3d (n,6), R (n,9) -> (n,24). */
+int omni_cuboid_corners(const float* box3d, const float* R, int n, float* verts, void* stream);
+
+/* ---------------------------------------------------------------------------- optimizer */
+
+/* torch.optim.SGD step (cubercnn/solver/build.py:49-56, tools/train_net.py:250) over a flat bucket. */
+int omni_sgd_step(float* param, const float* grad, float* momentum_buf, long long n, float lr, float momentum,
+                  float dampening, float weight_decay, int nesterov, int first_step, const float* skip_flag,
+                  void* stream);
+/* the isnan/isinf gradient scan of tools/train_net.py:222-233 as one pass; flag[0] = 1 if any. */
+int omni_nonfinite_any(const float* grad, long long n, float* flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,408 @@
+// cube_head.hip -- Cube R-CNN 3D head: per-class gather, decode (2D centre, virtual depth, dimension
+// priors, 6D pose -> rotation, allocentric -> egocentric), 8-corner cuboids and the disentangled
+// corner / chamfer losses with uncertainty weighting -- one fused kernel per direction.
+//
+// Reference (paths under /root/reference/cubercnn):
+//   CubeHead.forward (uncertainty clip, rotation_6d_to_matrix)      modeling/roi_heads/cube_head.py:147-197
+//   ROIHeads3D._forward_cube decode                                  modeling/roi_heads/roi_heads.py:374-525
+//   losses (disentangled z / xy / dims L1, chamfer pose, joint,      modeling/roi_heads/roi_heads.py:527-768
+//           sqrt(2)*exp(-u) weighting, safely_reduce_losses :932-940)
+//   util.get_cuboid_verts_faces                                      util/math_util.py:116-219
+//   util.R_from_allocentric (+ pytorch3d axis_angle_to_matrix)       util/math_util.py:651-705
+//   util.compute_virtual_scale_from_focal_spaces                     util/math_util.py:581-592
+//   inference outputs (cube_3D, pred_bbox3D ...)                     modeling/roi_heads/roi_heads.py:771-819
+//
+// The reference runs ~150 tiny ATen kernels plus 8 .item() syncs here.  The work per ROI is a few
+// hundred flops on 13 head outputs, so one LANE owns one ROI.  The backward pass needs d(loss_k)/d(13
+// inputs): the forward kernel evaluates the whole chain on forward-mode dual numbers (13 tangents) and
+// stores the 6 x 13 Jacobian per ROI; backward is a 6-term contraction + scatter into the head's
+// gradient rows.  min/abs/clip pick the active branch exactly like autograd (ties -> first).
+//
+// head (F, ldh): fused linear outputs, columns = [xy deltas K*2 | z K | dims K*3 | pose6 K*6 | uncert K].
+#include <device_rt.h>
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int NT = 13;  // tangent slots: dx dy | z | dw dh dl | p0..p5 | u
+
+struct D {            // dual number: value + 13 tangents
+    float v;
+    float d[NT];
+};
+__device__ __forceinline__ D cst(float v) { D r; r.v = v; for (int i = 0; i < NT; ++i) r.d[i] = 0.f; return r; }
+__device__ __forceinline__ D var(float v, int slot) { D r = cst(v); r.d[slot] = 1.f; return r; }
+__device__ __forceinline__ D operator+(const D& a, const D& b) { D r; r.v = a.v + b.v; for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ D operator-(const D& a, const D& b) { D r; r.v = a.v - b.v; for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ D operator*(const D& a, const D& b) { D r; r.v = a.v * b.v; for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ D operator/(const D& a, const D& b) {
+    D r; r.v = a.v / b.v;
+    const float inv = 1.f / b.v;
+    for (int i = 0; i < NT; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+__device__ __forceinline__ D operator*(const D& a, float s) { D r; r.v = a.v * s; for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] * s; return r; }
+__device__ __forceinline__ D operator+(const D& a, float s) { D r = a; r.v += s; return r; }
+__device__ __forceinline__ D neg(const D& a) { D r; r.v = -a.v; for (int i = 0; i < NT; ++i) r.d[i] = -a.d[i]; return r; }
+__device__ __forceinline__ D dsqrt(const D& a) {
+    D r; r.v = sqrtf(a.v);
+    const float k = 0.5f / r.v;
+    for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] * k;
+    return r;
+}
+__device__ __forceinline__ D dexp(const D& a) { D r; r.v = expf(a.v); for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] * r.v; return r; }
+__device__ __forceinline__ D dabs(const D& a) {
+    const float s = a.v > 0.f ? 1.f : (a.v < 0.f ? -1.f : 0.f);
+    D r; r.v = fabsf(a.v);
+    for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] * s;
+    return r;
+}
+__device__ __forceinline__ D clip_max(const D& a, float mx) { return a.v > mx ? cst(mx) : a; }   // grad 0 when clipped
+__device__ __forceinline__ D clip_min(const D& a, float mn) { return a.v < mn ? cst(mn) : a; }
+
+struct V3 { D x, y, z; };
+__device__ __forceinline__ D dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 normalize(const V3& a) {   // F.normalize: v / max(||v||, 1e-12)
+    D n = dsqrt(dot(a, a));
+    if (n.v < 1e-12f) n = cst(1e-12f);
+    V3 r; r.x = a.x / n; r.y = a.y / n; r.z = a.z / n;
+    return r;
+}
+
+struct Mat3 { D m[3][3]; };
+
+// pytorch3d rotation_6d_to_matrix: rows b1, b2, b3
+__device__ __forceinline__ Mat3 rot6d(const D (&p)[6]) {
+    V3 a1 = {p[0], p[1], p[2]}, a2 = {p[3], p[4], p[5]};
+    V3 b1 = normalize(a1);
+    D s = dot(b1, a2);
+    V3 t = {a2.x - s * b1.x, a2.y - s * b1.y, a2.z - s * b1.z};
+    V3 b2 = normalize(t);
+    V3 b3 = {b1.y * b2.z - b1.z * b2.y, b1.z * b2.x - b1.x * b2.z, b1.x * b2.y - b1.y * b2.x};
+    Mat3 R;
+    R.m[0][0] = b1.x; R.m[0][1] = b1.y; R.m[0][2] = b1.z;
+    R.m[1][0] = b2.x; R.m[1][1] = b2.y; R.m[1][2] = b2.z;
+    R.m[2][0] = b3.x; R.m[2][1] = b3.y; R.m[2][2] = b3.z;
+    return R;
+}
+
+// R_from_allocentric (math_util.py:651-679): M(u, v) is built from DETACHED u, v (roi_heads.py:489),
+// so it is a constant matrix; R = M @ R_view where the viewing-ray angle is > 0.
+__device__ __forceinline__ void allocentric_M(float fx, float fy, float sx, float sy, float u, float v, float (&M)[3][3],
+                                              bool& valid) {
+    float ox = (u - sx) / fx, oy = (v - sy) / fy, oz = 1.f;
+    const float on = sqrtf(ox * ox + oy * oy + oz * oz);
+    ox /= on; oy /= on; oz /= on;
+    const float angle = acosf(oz);
+    float ax = -oy, ay = ox;   // axis = (-ray_y, ray_x, 0)
+    const float an = sqrtf(ax * ax + ay * ay);
+    valid = angle > 0.f;
+    // axis_angle_to_matrix(angle * axis / |axis|) via quaternion (pytorch3d)
+    const float vx = angle * ax / an, vy = angle * ay / an, vz = 0.f;
+    const float ang = sqrtf(vx * vx + vy * vy + vz * vz), half = ang * 0.5f;
+    const float sh = fabsf(ang) < 1e-6f ? (0.5f - ang * ang / 48.f) : sinf(half) / ang;
+    const float r = cosf(half), i = vx * sh, j = vy * sh, k = vz * sh;
+    const float two_s = 2.f / (r * r + i * i + j * j + k * k);
+    M[0][0] = 1 - two_s * (j * j + k * k); M[0][1] = two_s * (i * j - k * r); M[0][2] = two_s * (i * k + j * r);
+    M[1][0] = two_s * (i * j + k * r); M[1][1] = 1 - two_s * (i * i + k * k); M[1][2] = two_s * (j * k - i * r);
+    M[2][0] = two_s * (i * k - j * r); M[2][1] = two_s * (j * k + i * r); M[2][2] = 1 - two_s * (i * i + j * j);
+}
+
+// get_cuboid_verts_faces (math_util.py:171-191): box = [X, Y, Z, W, H, L]; x = -+L/2 on {0,3,4,7}/{1,2,5,6},
+// y = -+H/2 on {0,1,4,5}/{2,3,6,7}, z = -+W/2 on {0..3}/{4..7}; verts = R @ v + centre.
+__device__ __forceinline__ void corners(const D& X, const D& Y, const D& Z, const D& Wd, const D& Hd, const D& Ld,
+                                        const Mat3& R, V3 (&out)[8]) {
+    const D hl = Ld * 0.5f, hh = Hd * 0.5f, hw = Wd * 0.5f;
+    const float sxs[8] = {-1, 1, 1, -1, -1, 1, 1, -1}, sys[8] = {-1, -1, 1, 1, -1, -1, 1, 1}, szs[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+    for (int i = 0; i < 8; ++i) {
+        const D vx = hl * sxs[i], vy = hh * sys[i], vz = hw * szs[i];
+        out[i].x = R.m[0][0] * vx + R.m[0][1] * vy + R.m[0][2] * vz + X;
+        out[i].y = R.m[1][0] * vx + R.m[1][1] * vy + R.m[1][2] * vz + Y;
+        out[i].z = R.m[2][0] * vx + R.m[2][1] * vy + R.m[2][2] * vz + Z;
+    }
+}
+__device__ __forceinline__ D l1_mean(const V3 (&a)[8], const V3 (&b)[8]) {
+    D s = cst(0.f);
+    for (int i = 0; i < 8; ++i) s = s + dabs(a[i].x - b[i].x) + dabs(a[i].y - b[i].y) + dabs(a[i].z - b[i].z);
+    return s * (1.f / 24.f);
+}
+// chamfer_loss (roi_heads.py:298-304): mean_j min_i d(i,j) + mean_i min_j d(i,j), d = L1 over xyz
+__device__ __forceinline__ D chamfer(const V3 (&a)[8], const V3 (&b)[8]) {
+    D dist[8][8];
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) dist[i][j] = dabs(a[i].x - b[j].x) + dabs(a[i].y - b[j].y) + dabs(a[i].z - b[j].z);
+    D s1 = cst(0.f), s2 = cst(0.f);
+    for (int j = 0; j < 8; ++j) {
+        int bi = 0;
+        for (int i = 1; i < 8; ++i) if (dist[i][j].v < dist[bi][j].v) bi = i;
+        s1 = s1 + dist[bi][j];
+    }
+    for (int i = 0; i < 8; ++i) {
+        int bj = 0;
+        for (int j = 1; j < 8; ++j) if (dist[i][j].v < dist[i][bj].v) bj = j;
+        s2 = s2 + dist[i][bj];
+    }
+    return s1 * 0.125f + s2 * 0.125f;
+}
+
+struct RoiIn {
+    float box[4];
+    int cls;
+    float K[4];        // fx, fy, cx, cy of the image intrinsics scaled to the network resolution
+    float v2r;         // virtual_to_real = (H_net * f_virtual... ) see host
+    float prior[3];    // prior mean dims of the class
+};
+
+// decode only (also used at inference): returns values + (optionally) duals
+struct Decoded {
+    D x, y, z, dims[3], u;
+    Mat3 pose;
+};
+__device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn& in) {
+    const int c = in.cls;
+    const float* pxy = hrow + 2 * c;
+    const float* pz = hrow + 2 * K + c;
+    const float* pd = hrow + 3 * K + 3 * c;
+    const float* pp = hrow + 6 * K + 6 * c;
+    const float* pu = hrow + 12 * K + c;
+    Decoded o;
+    const float sw = in.box[2] - in.box[0], sh = in.box[3] - in.box[1];
+    const float cx = in.box[0] + 0.5f * sw, cy = in.box[1] + 0.5f * sh;
+    o.x = var(pxy[0], 0) * sw + cx;                 // roi_heads.py:460-461
+    o.y = var(pxy[1], 1) * sh + cy;
+    o.z = var(pz[0], 2) * in.v2r;                   // z_type 'direct' + virtual depth (roi_heads.py:524-525)
+    for (int k = 0; k < 3; ++k) o.dims[k] = dexp(clip_max(var(pd[k], 3 + k), 5.f)) * in.prior[k];   // :479
+    D p6[6];
+    for (int k = 0; k < 6; ++k) p6[k] = var(pp[k], 6 + k);
+    const Mat3 Rv = rot6d(p6);                      // cube_head.py:176
+    float M[3][3];
+    bool valid;
+    allocentric_M(in.K[0], in.K[1], in.K[2], in.K[3], o.x.v, o.y.v, M, valid);
+    if (valid) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) o.pose.m[i][j] = Rv.m[0][j] * M[i][0] + Rv.m[1][j] * M[i][1] + Rv.m[2][j] * M[i][2];
+    } else {
+        o.pose = Rv;
+    }
+    o.u = clip_min(var(pu[0], 12), 0.01f);          // cube_head.py:163
+    return o;
+}
+
+// ---- training forward: per-ROI losses (6) + Jacobian (6 x 13) + logging terms -----------------------
+// vals (F, 12): [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, u,  total3d_report, z_err, dims_err(sum3), xy_err(sum2), conf, joint_valid]
+__global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restrict__ head, int ldh, int F, int K,
+                                                           const float* __restrict__ boxes, const int* __restrict__ cls,
+                                                           const int* __restrict__ img, const float* __restrict__ Ks,
+                                                           const float* __restrict__ v2r, const float* __restrict__ priors,
+                                                           const float* __restrict__ gt3d, const float* __restrict__ gtpose,
+                                                           const int* __restrict__ gt_row, float* __restrict__ vals,
+                                                           float* __restrict__ jac) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    RoiIn in;
+    for (int k = 0; k < 4; ++k) in.box[k] = boxes[4 * f + k];
+    in.cls = cls[f];
+    const int im = img[f];
+    for (int k = 0; k < 4; ++k) in.K[k] = Ks[4 * im + k];
+    in.v2r = v2r[im];
+    for (int k = 0; k < 3; ++k) in.prior[k] = priors[(in.cls * 2 + 0) * 3 + k];
+    const Decoded o = decode(head + (long)f * ldh, K, in);
+    const float* g = gt3d + 9 * gt_row[f];
+    const float* gp = gtpose + 9 * gt_row[f];
+    const float fx = in.K[0], fy = in.K[1], sx = in.K[2], sy = in.K[3];
+    const float gu = g[0], gv = g[1], gz = g[2];
+    const D gX = cst(gz * (gu - sx) / fx), gY = cst(gz * (gv - sy) / fy), gZ = cst(gz);
+    const D gW = cst(g[3]), gH = cst(g[4]), gL = cst(g[5]);
+    Mat3 Rg;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rg.m[i][j] = cst(gp[3 * i + j]);
+    V3 cgt[8], ctmp[8];
+    corners(gX, gY, gZ, gW, gH, gL, Rg, cgt);
+    // disentangled z / xy / pose / dims (roi_heads.py:574-600)
+    corners(o.z * ((gu - sx) / fx), o.z * ((gv - sy) / fy), o.z, gW, gH, gL, Rg, ctmp);
+    D loss_z = l1_mean(ctmp, cgt);
+    corners((o.x + (-sx)) * (gz / fx), (o.y + (-sy)) * (gz / fy), gZ, gW, gH, gL, Rg, ctmp);
+    D loss_xy = l1_mean(ctmp, cgt);
+    corners(gX, gY, gZ, gW, gH, gL, o.pose, ctmp);
+    D loss_pose = chamfer(ctmp, cgt);
+    corners(gX, gY, gZ, o.dims[0], o.dims[1], o.dims[2], Rg, ctmp);
+    D loss_dims = l1_mean(ctmp, cgt);
+    // joint (roi_heads.py:671-677)
+    corners(o.z * (o.x + (-sx)) * (1.f / fx), o.z * (o.y + (-sy)) * (1.f / fy), o.z, o.dims[0], o.dims[1], o.dims[2], o.pose, ctmp);
+    D loss_joint = chamfer(ctmp, cgt);
+    const float joint_valid = loss_joint.v < INFINITY ? 1.f : 0.f;
+    const float total = loss_dims.v + loss_pose.v + loss_xy.v + loss_z.v + loss_joint.v;
+    // uncertainty weighting (roi_heads.py:721-739)
+    const D sf = dexp(neg(o.u)) * 1.41421356f;
+    D L[6] = {loss_dims * sf, loss_xy * sf, loss_z * sf, loss_pose * sf, loss_joint * sf, o.u};
+    float* vo = vals + (long)f * 12;
+    for (int k = 0; k < 6; ++k) {
+        vo[k] = L[k].v;
+        for (int t = 0; t < NT; ++t) jac[((long)f * 6 + k) * NT + t] = L[k].d[t];
+    }
+    vo[6] = total;
+    vo[7] = fabsf(o.z.v - gz);
+    vo[8] = fabsf(o.dims[0].v - g[3]) + fabsf(o.dims[1].v - g[4]) + fabsf(o.dims[2].v - g[5]);
+    vo[9] = fabsf(o.x.v - gu) + fabsf(o.y.v - gv);
+    vo[10] = expf(-o.u.v);
+    vo[11] = joint_valid;
+}
+
+// safely_reduce_losses (roi_heads.py:932-940) for the 6 columns + logging sums.
+// red (24 floats): [0..5] reduced losses, [6..11] 1/n_finite (0 if none), [12] total3d mean(finite), [13] z_err mean,
+// [14] dims_err mean, [15] xy_err mean, [16] z_close mean, [17] conf mean, [18] F
+__global__ void __launch_bounds__(256) cube_reduce_kernel(const float* __restrict__ vals, int F, float* __restrict__ red) {
+    __shared__ double acc[20];
+    const int t = threadIdx.x;
+    if (t < 20) acc[t] = 0.0;
+    __syncthreads();
+    double s[6] = {0, 0, 0, 0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0}, tot = 0, totc = 0, ze = 0, de = 0, xe = 0, zc = 0, cf = 0;
+    for (int f = t; f < F; f += blockDim.x) {
+        const float* v = vals + (long)f * 12;
+        for (int k = 0; k < 6; ++k) {
+            bool ok = isfinite(v[k]);
+            if (k == 4) ok = ok && v[11] != 0.f;   // joint: `loss_joint[valid_joint]` then finite-only mean
+            if (ok) { s[k] += v[k]; c[k] += 1; }
+        }
+        if (isfinite(v[6])) { tot += v[6]; totc += 1; }
+        ze += v[7]; de += v[8]; xe += v[9]; zc += v[7] < 0.2f ? 1 : 0; cf += v[10];
+    }
+    for (int k = 0; k < 6; ++k) { atomicAdd(&acc[k], s[k]); atomicAdd(&acc[6 + k], c[k]); }
+    atomicAdd(&acc[12], tot); atomicAdd(&acc[13], totc); atomicAdd(&acc[14], ze); atomicAdd(&acc[15], de);
+    atomicAdd(&acc[16], xe); atomicAdd(&acc[17], zc); atomicAdd(&acc[18], cf);
+    __syncthreads();
+    if (t == 0) {
+        for (int k = 0; k < 6; ++k) {
+            const double n = acc[6 + k];
+            red[k] = n > 0 ? (float)(acc[k] / n) : 0.f;
+            red[6 + k] = n > 0 ? (float)(1.0 / n) : 0.f;
+        }
+        const double Fd = F > 0 ? (double)F : 1.0;
+        red[12] = acc[13] > 0 ? (float)(acc[12] / acc[13]) : 0.f;
+        red[13] = (float)(acc[14] / Fd);
+        red[14] = (float)(acc[15] / (3.0 * Fd));
+        red[15] = (float)(acc[16] / (2.0 * Fd));
+        red[16] = (float)(acc[17] / Fd);
+        red[17] = (float)(acc[18] / Fd);
+        red[18] = (float)F;
+    }
+}
+
+// dhead (F, ldh) = sum_k gk[k] * w_k(f) * J[f][k][:] scattered to the class columns; rest zero.
+__global__ void __launch_bounds__(64) cube_loss_bwd_kernel(const float* __restrict__ vals, const float* __restrict__ jac,
+                                                           const float* __restrict__ red, const float* __restrict__ gk,
+                                                           const int* __restrict__ cls, int F, int K, int ldh,
+                                                           float* __restrict__ dhead) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float* row = dhead + (long)f * ldh;
+    for (int j = 0; j < ldh; ++j) row[j] = 0.f;
+    float d[NT];
+    for (int t = 0; t < NT; ++t) d[t] = 0.f;
+    const float* v = vals + (long)f * 12;
+    for (int k = 0; k < 6; ++k) {
+        bool ok = isfinite(v[k]);
+        if (k == 4) ok = ok && v[11] != 0.f;
+        if (!ok) continue;
+        const float w = gk[k] * red[6 + k];
+        for (int t = 0; t < NT; ++t) d[t] += w * jac[((long)f * 6 + k) * NT + t];
+    }
+    const int c = cls[f];
+    row[2 * c + 0] = d[0]; row[2 * c + 1] = d[1];
+    row[2 * K + c] = d[2];
+    for (int k = 0; k < 3; ++k) row[3 * K + 3 * c + k] = d[3 + k];
+    for (int k = 0; k < 6; ++k) row[6 * K + 6 * c + k] = d[6 + k];
+    row[12 * K + c] = d[12];
+}
+
+// ---- inference / output decode (roi_heads.py:774-819): cube_3D (F, 9) = [X, Y, Z, w, h, l, u*s, v*s, conf],
+//      pose (F, 9), corners (F, 24) ----------------------------------------------------------------
+__global__ void __launch_bounds__(64) cube_decode_kernel(const float* __restrict__ head, int ldh, int F, int K,
+                                                         const float* __restrict__ boxes, const int* __restrict__ cls,
+                                                         const int* __restrict__ img, const float* __restrict__ Ks,
+                                                         const float* __restrict__ v2r, const float* __restrict__ ratio,
+                                                         const float* __restrict__ priors, float* __restrict__ cube3d,
+                                                         float* __restrict__ pose, float* __restrict__ verts) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    RoiIn in;
+    for (int k = 0; k < 4; ++k) in.box[k] = boxes[4 * f + k];
+    in.cls = cls[f];
+    const int im = img[f];
+    for (int k = 0; k < 4; ++k) in.K[k] = Ks[4 * im + k];
+    in.v2r = v2r[im];
+    for (int k = 0; k < 3; ++k) in.prior[k] = priors[(in.cls * 2 + 0) * 3 + k];
+    const Decoded o = decode(head + (long)f * ldh, K, in);
+    const float X = o.z.v * (o.x.v - in.K[2]) / in.K[0], Y = o.z.v * (o.y.v - in.K[3]) / in.K[1];
+    float* c3 = cube3d + 9 * f;
+    c3[0] = X; c3[1] = Y; c3[2] = o.z.v; c3[3] = o.dims[0].v; c3[4] = o.dims[1].v; c3[5] = o.dims[2].v;
+    c3[6] = o.x.v * ratio[im]; c3[7] = o.y.v * ratio[im]; c3[8] = expf(-o.u.v);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) pose[9 * f + 3 * i + j] = o.pose.m[i][j].v;
+    V3 cv[8];
+    corners(cst(X), cst(Y), cst(o.z.v), o.dims[0], o.dims[1], o.dims[2], o.pose, cv);
+    for (int i = 0; i < 8; ++i) { verts[24 * f + 3 * i] = cv[i].x.v; verts[24 * f + 3 * i + 1] = cv[i].y.v; verts[24 * f + 3 * i + 2] = cv[i].z.v; }
+}
+
+// plain cuboid corners: util.get_cuboid_verts_faces(box3d (n,6), R (n,3,3)) -> (n,8,3)
+__global__ void cuboid_corners_kernel(const float* __restrict__ box3d, const float* __restrict__ R, int n,
+                                      float* __restrict__ verts) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const float* b = box3d + 6 * f;
+    const float* r = R + 9 * f;
+    const float sxs[8] = {-1, 1, 1, -1, -1, 1, 1, -1}, sys[8] = {-1, -1, 1, 1, -1, -1, 1, 1}, szs[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+    for (int i = 0; i < 8; ++i) {
+        const float vx = sxs[i] * b[5] / 2, vy = sys[i] * b[4] / 2, vz = szs[i] * b[3] / 2;
+        verts[24 * f + 3 * i + 0] = r[0] * vx + r[1] * vy + r[2] * vz + b[0];
+        verts[24 * f + 3 * i + 1] = r[3] * vx + r[4] * vy + r[5] * vz + b[1];
+        verts[24 * f + 3 * i + 2] = r[6] * vx + r[7] * vy + r[8] * vz + b[2];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// head (F, ldh) fused cube-head outputs for the F foreground ROIs; boxes (F,4) proposal boxes; cls (F);
+// img (F) image index; Ks (B,4) = [fx, fy, cx, cy] scaled to network resolution; v2r (B) virtual->real depth
+// factor; priors (K,2,3); gt3d (G,9) gt_boxes3D rows; gtpose (G,9); gt_row (F).
+// vals (F,12), jac (F,6,13), red (24) outputs.
+int omni_cube_loss_fwd(const float* head, int ldh, int F, int K, const float* boxes, const int* cls, const int* img,
+                       const float* Ks, const float* v2r, const float* priors, const float* gt3d, const float* gtpose,
+                       const int* gt_row, float* vals, float* jac, float* red, void* stream) {
+    if (F < 0 || K <= 0 || ldh < 13 * K) return OMNI_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (F > 0)
+        hipLaunchKernelGGL(cube_loss_fwd_kernel, dim3((F + 63) / 64), dim3(64), 0, st, head, ldh, F, K, boxes, cls, img, Ks,
+                           v2r, priors, gt3d, gtpose, gt_row, vals, jac);
+    hipLaunchKernelGGL(cube_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)vals, F, red);
+    return omni_launch_status();
+}
+
+// gk (6) device floats: upstream gradients of [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert].
+int omni_cube_loss_bwd(const float* vals, const float* jac, const float* red, const float* gk, const int* cls, int F,
+                       int K, int ldh, float* dhead, void* stream) {
+    if (F < 0 || K <= 0 || ldh < 13 * K) return OMNI_ERR_ARG;
+    if (F == 0) return OMNI_OK;
+    hipLaunchKernelGGL(cube_loss_bwd_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, vals, jac, red, gk, cls,
+                       F, K, ldh, dhead);
+    return omni_launch_status();
+}
+
+int omni_cube_decode(const float* head, int ldh, int F, int K, const float* boxes, const int* cls, const int* img,
+                     const float* Ks, const float* v2r, const float* ratio, const float* priors, float* cube3d,
+                     float* pose, float* verts, void* stream) {
+    if (F < 0 || K <= 0 || ldh < 13 * K) return OMNI_ERR_ARG;
+    if (F == 0) return OMNI_OK;
+    hipLaunchKernelGGL(cube_decode_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, head, ldh, F, K, boxes,
+                       cls, img, Ks, v2r, ratio, priors, cube3d, pose, verts);
+    return omni_launch_status();
+}
+
+int omni_cuboid_corners(const float* box3d, const float* R, int n, float* verts, void* stream) {
+    if (n < 0) return OMNI_ERR_ARG;
+    if (n == 0) return OMNI_OK;
+    hipLaunchKernelGGL(cuboid_corners_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, box3d, R, n, verts);
+    return omni_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+// select_nms.hip -- index-exact selection kernels: row-wise sorted top-k and greedy NMS.
+//
+// Replaces (bit-exact on the selected indices):
+//   logits.sort(descending)[:k] per level            detectron2 find_top_rpn_proposals (RPN of
+//                                                     /root/reference/configs/Base.yaml:49-54)
+//   torch.multinomial(w, k) == topk(w / Exp(1), k)   /root/reference/cubercnn/modeling/proposal_generator/rpn.py:318,322
+//   torchvision.ops.nms via detectron2 batched_nms   rpn [upstream]; cubercnn/modeling/roi_heads/fast_rcnn.py:105
+//
+// Top-k: one 1024-thread workgroup per row.  Keys become order-preserving 64-bit integers
+// (float bits, then ~index so that equal scores resolve to the LOWER index = a stable descending
+// sort); an 8-pass MSB-first radix select finds the k-th largest key exactly, survivors are
+// compacted into LDS and bitonic-sorted there.  k <= 2048.
+//
+// NMS: boxes arrive sorted by descending score.  A 64x64-bit suppression matrix tile per
+// workgroup (strict IoU > thr, areas (x2-x1)*(y2-y1), no +1), then one wave per problem walks the
+// rows in 64-box chunks: intra-chunk resolution from the diagonal word, then the kept rows OR their
+// mask rows into the running `removed` words (one 64-bit word per lane).
+#include <device_rt.h>
+
+namespace {
+
+constexpr int TOPK_THREADS = 1024;
+constexpr int TOPK_MAXK = 2048;
+
+__device__ __forceinline__ unsigned long long make_key(float f, int idx) {
+    unsigned u = __float_as_uint(f);
+    if (f != f) u = 0u;  // NaN sorts last
+    else u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+}
+__device__ __forceinline__ float key_value(unsigned long long k) {
+    unsigned u = (unsigned)(k >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ int key_index(unsigned long long k) { return (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)); }
+
+// keys: (rows, n) with row pitch `pitch` and element stride `estride` (floats).
+__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __restrict__ keys, int n, long pitch,
+                                                                 int estride, int k, float* __restrict__ out_val,
+                                                                 int* __restrict__ out_idx) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long sel[TOPK_MAXK];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_need, s_count;
+    const int t = threadIdx.x;
+    const float* row = keys + (long)blockIdx.x * pitch;
+    const int kk = k < n ? k : n;
+    int kpad = 1;
+    while (kpad < kk) kpad <<= 1;
+    if (kpad < 2) kpad = 2;
+
+    unsigned long long thr = 0ull;  // keys >= thr are selected
+    if (kk < n) {
+        if (t == 0) { s_prefix = 0ull; s_need = kk; }
+        __syncthreads();
+        for (int pass = 7; pass >= 0; --pass) {
+            if (t < 256) hist[t] = 0u;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix;
+            const int shift = pass * 8;
+            for (int i = t; i < n; i += TOPK_THREADS) {
+                const unsigned long long key = make_key(row[(long)i * estride], i);
+                const bool match = (pass == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                if (match) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (t == 0) {
+                int need = s_need;
+                int d = 255;
+                for (; d > 0; --d) {
+                    const int c = (int)hist[d];
+                    if (c >= need) break;
+                    need -= c;
+                }
+                s_need = need;
+                s_prefix = prefix | ((unsigned long long)d << shift);
+            }
+            __syncthreads();
+        }
+        thr = s_prefix;  // keys are unique, so exactly kk keys are >= thr
+    }
+    if (t == 0) s_count = 0;
+    for (int i = t; i < kpad; i += TOPK_THREADS) sel[i] = 0ull;
+    __syncthreads();
+    for (int i = t; i < n; i += TOPK_THREADS) {
+        const unsigned long long key = make_key(row[(long)i * estride], i);
+        if (key >= thr) {
+            const int slot = atomicAdd(&s_count, 1);
+            if (slot < TOPK_MAXK) sel[slot] = key;
+        }
+    }
+    __syncthreads();
+    // bitonic sort, descending, kpad a power of two
+    for (int size = 2; size <= kpad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = t; i < (kpad >> 1); i += TOPK_THREADS) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = sel[lo], b = sel[hi];
+                if ((a < b) == desc) { sel[lo] = b; sel[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = t; i < k; i += TOPK_THREADS) {
+        const long o = (long)blockIdx.x * k + i;
+        if (i < kk) { out_val[o] = key_value(sel[i]); out_idx[o] = key_index(sel[i]); }
+        else { out_val[o] = -INFINITY; out_idx[o] = -1; }
+    }
+}
+
+// ---- NMS ---------------------------------------------------------------------------------------
+// problem q: boxes[q*nmax .. q*nmax + count[q]) sorted by descending score; valid[] == 0 marks boxes
+// that take no part (empty / non-finite).  mask: (Q, nmax, words) 64-bit, words = ceil(nmax/64).
+__global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
+                                                      int nmax, int words, float thr,
+                                                      unsigned long long* __restrict__ mask) {
+    const int q = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+    const int n = counts ? counts[q] : nmax;
+    if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+    __shared__ float cbx[64 * 4];
+    const int lane = threadIdx.x;
+    const float* B = boxes + (long)q * nmax * 4;
+    {
+        const int j = cb * 64 + lane;
+        if (j < n) {
+            cbx[lane * 4 + 0] = B[j * 4 + 0]; cbx[lane * 4 + 1] = B[j * 4 + 1];
+            cbx[lane * 4 + 2] = B[j * 4 + 2]; cbx[lane * 4 + 3] = B[j * 4 + 3];
+        }
+    }
+    __syncthreads();
+    const int i = rb * 64 + lane;
+    if (i >= n) return;
+    const float x1 = B[i * 4 + 0], y1 = B[i * 4 + 1], x2 = B[i * 4 + 2], y2 = B[i * 4 + 3];
+    const float ai = (x2 - x1) * (y2 - y1);
+    unsigned long long bits = 0ull;
+    const int jmax = (n - cb * 64) < 64 ? (n - cb * 64) : 64;
+    for (int jj = (rb == cb ? lane + 1 : 0); jj < jmax; ++jj) {
+        const float u1 = cbx[jj * 4 + 0], v1 = cbx[jj * 4 + 1], u2 = cbx[jj * 4 + 2], v2 = cbx[jj * 4 + 3];
+        const float w = fmaxf(fminf(x2, u2) - fmaxf(x1, u1), 0.f);
+        const float h = fmaxf(fminf(y2, v2) - fmaxf(y1, v1), 0.f);
+        const float inter = w * h;
+        const float aj = (u2 - u1) * (v2 - v1);
+        const float iou = inter / (ai + aj - inter);
+        if (iou > thr) bits |= (1ull << jj);
+    }
+    mask[((long)q * nmax + i) * words + cb] = bits;
+}
+
+__global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                      const int* __restrict__ counts, const int* __restrict__ valid,
+                                                      int nmax, int words, int* __restrict__ keep) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int n = counts ? counts[q] : nmax;
+    __shared__ unsigned long long s_alive;
+    // removed word w is owned by lane w % 64 (words <= 64 * WPL)
+    constexpr int WPL = 2;  // up to 128 words = 8192 boxes
+    unsigned long long removed[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) removed[w] = 0ull;
+    const int nchunks = (n + 63) / 64;
+    for (int c = 0; c < nchunks; ++c) {
+        const int i = c * 64 + lane;
+        const bool in = i < n;
+        // start state of this chunk: not removed by earlier keeps, and a valid box
+        unsigned long long rem_c = 0ull;
+#pragma unroll
+        for (int w = 0; w < WPL; ++w) {
+            const unsigned long long v = __shfl(removed[w], c & 63, 64);
+            if ((c >> 6) == w) rem_c = v;
+        }
+        const bool ok = in && (valid == nullptr || valid[(long)q * nmax + i] != 0);
+        unsigned long long alive = __ballot(ok) & ~rem_c;
+        const unsigned long long diag = in ? mask[((long)q * nmax + i) * words + c] : 0ull;
+        // intra-chunk greedy resolution (lane 0 walks the 64 rows; rows arrive via shuffles)
+        for (int r = 0; r < 64; ++r) {
+            const unsigned long long d = __shfl(diag, r, 64);
+            if ((alive >> r) & 1ull) alive &= ~d;
+        }
+        if (in) keep[(long)q * nmax + i] = (int)((alive >> lane) & 1ull);
+        if (lane == 0) s_alive = alive;
+        __syncthreads();
+        alive = s_alive;
+        // kept rows suppress later chunks
+        for (int r = 0; r < 64; ++r) {
+            if (!((alive >> r) & 1ull)) continue;
+            const long rowbase = ((long)q * nmax + c * 64 + r) * words;
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) {
+                const int word = w * 64 + lane;
+                if (word > c && word < words && word * 64 < n) removed[w] |= mask[rowbase + word];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Sorted (descending, ties -> lower index) top-k of each row.  keys element (r, i) lives at
+// keys[r*pitch + i*estride].  out_val/out_idx are (rows, k); slots beyond min(k, n) hold -inf / -1.
+int omni_topk_rows(const float* keys, int rows, int n, long long pitch, int estride, int k, float* out_val, int* out_idx,
+                   void* stream) {
+    if (rows < 0 || n < 0 || k <= 0 || k > TOPK_MAXK || estride <= 0) return OMNI_ERR_ARG;
+    if (rows == 0) return OMNI_OK;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TOPK_THREADS), 0, (hipStream_t)stream, keys, n, (long)pitch,
+                       estride, k, out_val, out_idx);
+    return omni_launch_status();
+}
+
+// Greedy NMS for Q independent problems of up to nmax score-sorted boxes each ((Q, nmax, 4) XYXY).
+// counts [nullable] (Q) active boxes per problem; valid [nullable] (Q, nmax) 0 = box takes no part.
+// mask_ws: Q * nmax * ceil(nmax/64) 64-bit words of scratch.  keep (Q, nmax) int32 out (0/1).
+int omni_nms_sorted(const float* boxes, const int* counts, const int* valid, int Q, int nmax, float iou_thr,
+                    unsigned long long* mask_ws, int* keep, void* stream) {
+    if (Q < 0 || nmax < 0 || nmax > 8192) return OMNI_ERR_ARG;
+    if (Q == 0 || nmax == 0) return OMNI_OK;
+    const int words = (nmax + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(mask_ws, 0, sizeof(unsigned long long) * (size_t)Q * nmax * words, st);
+    hipMemsetAsync(keep, 0, sizeof(int) * (size_t)Q * nmax, st);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, Q), dim3(64), 0, st, boxes, counts, nmax, words, iou_thr,
+                       mask_ws);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(Q), dim3(64), 0, st, (const unsigned long long*)mask_ws, counts, valid, nmax,
+                       words, keep);
+    return omni_launch_status();
+}
+
+}  // extern "C"

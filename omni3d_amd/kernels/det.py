@@ -1,0 +1,258 @@
+"""Launchers for the detection-logic kernels: csrc/rpn_roi.hip, roi_align.hip, box_loss.hip,
+cube_head.hip, optim.hip.  Thin: allocate outputs, pass raw pointers + the current stream."""
+import ctypes
+import math
+
+import torch
+
+from .. import lib as _lib
+
+_P = ctypes.c_void_p
+
+
+def _ptrs(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def _ints(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _floats(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def _cast(a):
+    return ctypes.cast(a, _P)
+
+
+def _dev(*ts):
+    return _lib.check_device(*ts)
+
+
+def _empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def pairwise_iou(boxes1, boxes2, mode="iou"):
+    boxes1, boxes2 = boxes1.contiguous().float(), boxes2.contiguous().float()
+    L = _dev(boxes1, boxes2)
+    N, M = boxes1.shape[0], boxes2.shape[0]
+    out = _empty((N, M), torch.float32, boxes1)
+    L.call("omni_pairwise_iou", _lib.ptr(boxes1), N, _lib.ptr(boxes2), M, 0 if mode == "iou" else 1, _lib.ptr(out),
+           _lib.stream_of(boxes1))
+    return out
+
+
+def rpn_match(anchors, gt, gt_off, expo, thresholds=(0.05, 0.05), labels=(0, -1, 1), allow_low_quality=True, eps=1e-4):
+    """-> dict(matched_val, matched_idx, match_label, gt_best_idx, key_pos, key_neg)."""
+    L = _dev(anchors, gt, gt_off, expo)
+    A, B, G = anchors.shape[0], expo.shape[0], gt.shape[0]
+    o = {
+        "matched_val": _empty((B, A), torch.float32, anchors), "matched_idx": _empty((B, A), torch.int32, anchors),
+        "match_label": _empty((B, A), torch.int8, anchors), "gt_best_idx": _empty((max(G, 1),), torch.int32, anchors),
+        "key_pos": _empty((B, A), torch.float32, anchors), "key_neg": _empty((B, A), torch.float32, anchors),
+    }
+    bits = _empty((max(G, 1),), torch.int32, anchors)
+    L.call("omni_rpn_match", _lib.ptr(anchors), A, _lib.ptr(gt), _lib.ptr(gt_off), B, G, float(thresholds[0]),
+           float(thresholds[1]), int(labels[0]), int(labels[1]), int(labels[2]), int(allow_low_quality), _lib.ptr(expo),
+           float(eps), _lib.ptr(o["matched_val"]), _lib.ptr(o["matched_idx"]), _lib.ptr(o["match_label"]), _lib.ptr(bits),
+           _lib.ptr(o["gt_best_idx"]), _lib.ptr(o["key_pos"]), _lib.ptr(o["key_neg"]), _lib.stream_of(anchors))
+    return o
+
+
+def rpn_finalize_labels(anchors, gt_off, ign, ign_off, match, pos_val, pos_idx, neg_val, neg_idx, batch_per_image,
+                        ignore_thresh):
+    L = _dev(anchors, gt_off, ign, ign_off, pos_val, pos_idx, neg_val, neg_idx)
+    A, B = anchors.shape[0], pos_val.shape[0]
+    labels = _empty((B, A), torch.int8, anchors)
+    counts = _empty((B, 2), torch.int32, anchors)
+    L.call("omni_rpn_finalize_labels", _lib.ptr(anchors), A, B, _lib.ptr(gt_off), _lib.ptr(ign), _lib.ptr(ign_off),
+           _lib.ptr(match["match_label"]), _lib.ptr(match["gt_best_idx"]), _lib.ptr(pos_val), _lib.ptr(pos_idx),
+           _lib.ptr(neg_val), _lib.ptr(neg_idx), pos_val.shape[1], neg_val.shape[1], int(batch_per_image),
+           float(ignore_thresh), _lib.ptr(labels), _lib.ptr(counts), _lib.stream_of(anchors))
+    return labels, counts
+
+
+class LevelPack:
+    """Host-side description of the per-level RPN head tensors (B, H, W, 16) NHWC."""
+
+    def __init__(self, tensors_nhwc):
+        self.tensors = [t for t in tensors_nhwc]
+        for t in self.tensors:
+            assert t.is_contiguous() and t.shape[-1] == 16
+        self.hw = [t.shape[1] * t.shape[2] for t in self.tensors]
+        self.B = self.tensors[0].shape[0]
+        self.A = 3 * sum(self.hw)
+
+    def args(self):
+        p, h = _ptrs(self.tensors), _ints(self.hw)
+        self._keep = (p, h)
+        return _cast(p), _cast(h), len(self.tensors)
+
+
+def rpn_gather_logits(pack):
+    L = _dev(*pack.tensors)
+    out = _empty((pack.B, pack.A), torch.float32, pack.tensors[0])
+    L.call("omni_rpn_gather_logits", *pack.args(), pack.B, _lib.ptr(out), _lib.stream_of(out))
+    return out
+
+
+def rpn_loss_fwd(pack, anchors, labels, matched_idx, gt, gt_off):
+    L = _dev(anchors, labels, matched_idx, gt, gt_off)
+    sums = _empty((6,), torch.float64, anchors)
+    L.call("omni_rpn_loss_fwd", *pack.args(), pack.B, _lib.ptr(anchors), _lib.ptr(labels), _lib.ptr(matched_idx),
+           _lib.ptr(gt), _lib.ptr(gt_off), _lib.ptr(sums), _lib.stream_of(anchors))
+    return sums
+
+
+def rpn_loss_bwd(pack, anchors, labels, matched_idx, gt, gt_off, g_cls, g_loc, inv_norm):
+    L = _dev(anchors, labels, matched_idx, gt, gt_off, g_cls, g_loc)
+    grads = [torch.empty_like(t) for t in pack.tensors]
+    dp = _ptrs(grads)
+    a = pack.args()
+    L.call("omni_rpn_loss_bwd", a[0], _cast(dp), a[1], a[2], pack.B, _lib.ptr(anchors), _lib.ptr(labels),
+           _lib.ptr(matched_idx), _lib.ptr(gt), _lib.ptr(gt_off), _lib.ptr(g_cls), _lib.ptr(g_loc), float(inv_norm),
+           _lib.stream_of(anchors))
+    return grads
+
+
+def rpn_decode(pack, slot_level, idx, anchors, image_hw, min_size=0.0):
+    L = _dev(slot_level, idx, anchors, image_hw)
+    B, Ktot = idx.shape
+    boxes = _empty((B, Ktot, 4), torch.float32, anchors)
+    valid = _empty((B, Ktot), torch.int32, anchors)
+    L.call("omni_rpn_decode", *pack.args(), B, Ktot, _lib.ptr(slot_level), _lib.ptr(idx), _lib.ptr(anchors),
+           _lib.ptr(image_hw), float(math.log(1000.0 / 16)), float(min_size), _lib.ptr(boxes), _lib.ptr(valid),
+           _lib.stream_of(anchors))
+    return boxes, valid
+
+
+ROI_MAXC = 2048
+
+
+def roi_sample(prop_boxes, prop_count, gt, gt_cls, gt_off, ign, ign_off, expo, iou_thr, ignore_thresh, num_classes,
+               batch_per_image, positive_fraction, append_gt=True, eps=1e-4):
+    L = _dev(prop_boxes, prop_count, gt, gt_cls, gt_off, ign, ign_off, expo)
+    B, pmax = prop_boxes.shape[0], prop_boxes.shape[1]
+    assert expo.shape == (B, ROI_MAXC)
+    o_boxes = _empty((B, batch_per_image, 4), torch.float32, prop_boxes)
+    o_cls = _empty((B, batch_per_image), torch.int32, prop_boxes)
+    o_gt = _empty((B, batch_per_image), torch.int32, prop_boxes)
+    o_iou = _empty((B, batch_per_image), torch.float32, prop_boxes)
+    o_cnt = _empty((B, 2), torch.int32, prop_boxes)
+    L.call("omni_roi_sample", _lib.ptr(prop_boxes), _lib.ptr(prop_count), B, pmax, _lib.ptr(gt), _lib.ptr(gt_cls),
+           _lib.ptr(gt_off), _lib.ptr(ign), _lib.ptr(ign_off), _lib.ptr(expo), float(iou_thr), float(ignore_thresh),
+           float(eps), int(num_classes), int(batch_per_image), int(batch_per_image * positive_fraction), int(append_gt),
+           _lib.ptr(o_boxes), _lib.ptr(o_cls), _lib.ptr(o_gt), _lib.ptr(o_iou), _lib.ptr(o_cnt), _lib.stream_of(prop_boxes))
+    return o_boxes, o_cls, o_gt, o_iou, o_cnt
+
+
+def roi_levels(rois, min_level=2, max_level=6, canonical_size=224.0, canonical_level=4):
+    L = _dev(rois)
+    R = rois.shape[0]
+    lv = _empty((R,), torch.int32, rois)
+    L.call("omni_roi_levels", _lib.ptr(rois), R, min_level, max_level, float(canonical_size), canonical_level, _lib.ptr(lv),
+           _lib.stream_of(rois))
+    return lv
+
+
+def _feat_args(feats_nhwc, scales):
+    p = _ptrs(feats_nhwc)
+    hw = _ints([v for t in feats_nhwc for v in (t.shape[1], t.shape[2])])
+    sc = _floats(scales)
+    return (p, hw, sc), (_cast(p), _cast(hw), _cast(sc), len(feats_nhwc))
+
+
+def roi_align_fwd(feats_nhwc, scales, rois, batch_idx, levels, P):
+    """feats: list of (B,H,W,C) contiguous; -> (R, P, P, C)."""
+    L = _dev(rois, batch_idx, levels, *feats_nhwc)
+    R, C = rois.shape[0], feats_nhwc[0].shape[3]
+    out = _empty((R, P, P, C), torch.float32, rois)
+    keep, a = _feat_args(feats_nhwc, scales)
+    L.call("omni_roi_align_fwd", *a, _lib.ptr(rois), _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, _lib.ptr(out),
+           _lib.stream_of(rois))
+    return out
+
+
+def roi_align_bwd(dfeats_nhwc, scales, rois, batch_idx, levels, P, dout):
+    """accumulates into dfeats (caller-zeroed or holding other gradients)."""
+    L = _dev(rois, batch_idx, levels, dout, *dfeats_nhwc)
+    R, C = rois.shape[0], dfeats_nhwc[0].shape[3]
+    keep, a = _feat_args(dfeats_nhwc, scales)
+    L.call("omni_roi_align_bwd", *a, _lib.ptr(rois), _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, _lib.ptr(dout),
+           _lib.stream_of(rois))
+
+
+def box_loss_fwd(pred, K, cls, prop, gt, gt_row, weights=(10.0, 10.0, 5.0, 5.0)):
+    L = _dev(pred, cls, prop, gt, gt_row)
+    R, ldp = pred.shape
+    sums = _empty((7,), torch.float64, pred)
+    L.call("omni_box_loss_fwd", _lib.ptr(pred), ldp, R, K, _lib.ptr(cls), _lib.ptr(prop), _lib.ptr(gt), _lib.ptr(gt_row),
+           *[float(w) for w in weights], _lib.ptr(sums), _lib.stream_of(pred))
+    return sums
+
+
+def box_loss_bwd(pred, K, cls, prop, gt, gt_row, sums, g_cls, g_reg, weights=(10.0, 10.0, 5.0, 5.0)):
+    L = _dev(pred, cls, prop, gt, gt_row, sums, g_cls, g_reg)
+    R, ldp = pred.shape
+    dpred = torch.empty_like(pred)
+    L.call("omni_box_loss_bwd", _lib.ptr(pred), ldp, R, K, _lib.ptr(cls), _lib.ptr(prop), _lib.ptr(gt), _lib.ptr(gt_row),
+           *[float(w) for w in weights], _lib.ptr(sums), _lib.ptr(g_cls), _lib.ptr(g_reg), _lib.ptr(dpred),
+           _lib.stream_of(pred))
+    return dpred
+
+
+def cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row):
+    L = _dev(head, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row)
+    F, ldh = head.shape
+    vals = _empty((max(F, 1), 12), torch.float32, head)
+    jac = _empty((max(F, 1), 6, 13), torch.float32, head)
+    red = _empty((24,), torch.float32, head)
+    L.call("omni_cube_loss_fwd", _lib.ptr(head), ldh, F, K, _lib.ptr(boxes), _lib.ptr(cls), _lib.ptr(img), _lib.ptr(Ks),
+           _lib.ptr(v2r), _lib.ptr(priors), _lib.ptr(gt3d), _lib.ptr(gtpose), _lib.ptr(gt_row), _lib.ptr(vals),
+           _lib.ptr(jac), _lib.ptr(red), _lib.stream_of(head))
+    return vals, jac, red
+
+
+def cube_loss_bwd(vals, jac, red, gk, cls, F, K, ldh):
+    L = _dev(vals, jac, red, gk, cls)
+    dhead = _empty((F, ldh), torch.float32, vals)
+    L.call("omni_cube_loss_bwd", _lib.ptr(vals), _lib.ptr(jac), _lib.ptr(red), _lib.ptr(gk), _lib.ptr(cls), F, K, ldh,
+           _lib.ptr(dhead), _lib.stream_of(vals))
+    return dhead
+
+
+def cube_decode(head, K, boxes, cls, img, Ks, v2r, ratio, priors):
+    L = _dev(head, boxes, cls, img, Ks, v2r, ratio, priors)
+    F, ldh = head.shape
+    cube3d = _empty((F, 9), torch.float32, head)
+    pose = _empty((F, 3, 3), torch.float32, head)
+    verts = _empty((F, 8, 3), torch.float32, head)
+    L.call("omni_cube_decode", _lib.ptr(head), ldh, F, K, _lib.ptr(boxes), _lib.ptr(cls), _lib.ptr(img), _lib.ptr(Ks),
+           _lib.ptr(v2r), _lib.ptr(ratio), _lib.ptr(priors), _lib.ptr(cube3d), _lib.ptr(pose), _lib.ptr(verts),
+           _lib.stream_of(head))
+    return cube3d, pose, verts
+
+
+def cuboid_corners(box3d, R):
+    box3d, R = box3d.contiguous().float(), R.contiguous().float()
+    L = _dev(box3d, R)
+    n = box3d.shape[0]
+    verts = _empty((n, 8, 3), torch.float32, box3d)
+    L.call("omni_cuboid_corners", _lib.ptr(box3d), _lib.ptr(R), n, _lib.ptr(verts), _lib.stream_of(box3d))
+    return verts
+
+
+def sgd_step(param, grad, buf, lr, momentum=0.9, dampening=0.0, weight_decay=0.0, nesterov=False, first_step=False,
+             skip_flag=None):
+    L = _dev(param, grad, buf, skip_flag)
+    L.call("omni_sgd_step", _lib.ptr(param), _lib.ptr(grad), _lib.ptr(buf), param.numel(), float(lr), float(momentum),
+           float(dampening), float(weight_decay), int(nesterov), int(first_step), _lib.ptr(skip_flag),
+           _lib.stream_of(param))
+
+
+def nonfinite_any(grad, flag):
+    L = _dev(grad, flag)
+    L.call("omni_nonfinite_any", _lib.ptr(grad), grad.numel(), _lib.ptr(flag), _lib.stream_of(grad))

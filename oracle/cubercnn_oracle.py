@@ -1,0 +1,257 @@
+"""oracle/cubercnn_oracle.py -- TEST INFRASTRUCTURE (CPU oracle).  Never imported by the product.
+
+Plain-PyTorch (CPU fp32, autograd) restatement of the reference's OWN hot-path arithmetic
+(/root/reference/cubercnn/modeling/...), written functionally so that every random choice is an
+explicit input: `torch.multinomial(w, n)` (rpn.py:318,322) is `topk(w / E, n)` with E ~ Exp(1) --
+exactly torch's algorithm for sampling without replacement -- and E is injected by the caller, so
+the HIP kernels and this oracle can be driven by the same variates.
+
+It travels to the GPU box (the reference checkout does not).  In the build container
+tests/test_reference_pin.py checks these functions against the reference files themselves run
+under oracle/ref_harness.py; tests/golden/ holds the resulting fixtures.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import upstream as U
+from omni3d_amd.d2.structures import Boxes
+
+SQRT_2 = 1.41421356
+
+
+# ---------------------------------------------------------------------------------------------------
+# proposal_generator/rpn.py
+# ---------------------------------------------------------------------------------------------------
+
+def subsample_labels_E(labels, num_samples, positive_fraction, bg_label, matched_ious, E, eps=1e-4):
+    """rpn.py:275-328 with the multinomial's exponential variates E (same length as labels) injected."""
+    positive = U.nonzero_tuple((labels != -1) & (labels != bg_label))[0]
+    negative = U.nonzero_tuple(labels == bg_label)[0]
+    num_pos = min(positive.numel(), int(num_samples * positive_fraction))
+    num_neg = min(negative.numel(), num_samples - num_pos)
+    perm1 = ((matched_ious[positive] + eps) / E[positive]).topk(num_pos)[1] if num_pos > 0 else positive.new_zeros(0)
+    perm2 = ((matched_ious[negative] + eps) / E[negative]).topk(num_neg)[1] if num_neg > 0 else negative.new_zeros(0)
+    return positive[perm1], negative[perm2]
+
+
+def rpn_label_and_sample(anchors, gt_boxes, ign_boxes, E, thresholds=(0.05, 0.05), match_labels=(0, -1, 1),
+                         batch_size_per_image=256, positive_fraction=1.0, ignore_thresh=0.5):
+    """RPNWithIgnore.label_and_sample_anchors for ONE image (rpn.py:56-108).
+    anchors (A,4), gt_boxes (M,4) valid GT, ign_boxes (Mi,4) -> labels (A,) int8 in {-1,0,1},
+    matched_idxs (A,), matched_ious (A,)."""
+    matcher = U.Matcher(list(thresholds), list(match_labels), allow_low_quality_matches=True)
+    mqm = U.pairwise_iou(Boxes(gt_boxes), Boxes(anchors))
+    matched_idxs, gt_labels_i = matcher(mqm)
+    matched_ious = mqm[matched_idxs, torch.arange(mqm.shape[1])]
+    _, best_ious_gt_ind = mqm.max(dim=1)
+    best_inds = torch.tensor(sorted(set(best_ious_gt_ind.tolist()) & set((gt_labels_i == 1).nonzero().squeeze(1).tolist())),
+                             dtype=torch.int64)
+    pos_idx, neg_idx = subsample_labels_E(gt_labels_i, batch_size_per_image, positive_fraction, 0, matched_ious, E)
+    labels = torch.full_like(gt_labels_i, -1)
+    labels[pos_idx] = 1
+    labels[neg_idx] = 0
+    if best_inds.numel() > 0:
+        labels[best_inds] = 1
+    if len(ign_boxes) > 0:
+        background_inds = (labels == 0).nonzero().squeeze()
+        if background_inds.numel() > 1:
+            ioa = U.pairwise_ioa(Boxes(ign_boxes), Boxes(anchors[background_inds]))
+            labels[background_inds[ioa.max(0)[0] >= ignore_thresh]] = -1
+    return labels, matched_idxs, matched_ious, (pos_idx, neg_idx)
+
+
+def matched_pairwise_iou(b1, b2):
+    """rpn.py:330-353"""
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt = torch.max(b1[:, :2], b2[:, :2])
+    rb = torch.min(b1[:, 2:], b2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, 0] * wh[:, 1]
+    return inter / (a1 + a2 - inter)
+
+
+def rpn_losses_iouness(anchors, logits, deltas, labels, matched_gt_boxes, batch_size_per_image=256):
+    """RPNWithIgnore.losses + _dense_box_regression_loss_with_uncertainty (rpn.py:129-273), 'IoUness'.
+    anchors (A,4); logits (N,A); deltas (N,A,4); labels (N,A); matched_gt_boxes (N,A,4).
+    -> {'rpn/cls','rpn/loc'}, stats dict."""
+    N = logits.shape[0]
+    fg = labels == 1
+    b2b = U.Box2BoxTransform(weights=(1.0, 1.0, 1.0, 1.0))
+    boxes_fg = anchors.unsqueeze(0).repeat(N, 1, 1)[fg]
+    gt_fg = matched_gt_boxes[fg].detach()
+    t = matched_pairwise_iou(boxes_fg, gt_fg).detach()
+    loss_conf = (F.binary_cross_entropy_with_logits(logits[fg], t, reduction="none") * t).sum()
+    gt_deltas = torch.stack([b2b.get_deltas(anchors, k) for k in matched_gt_boxes])
+    loss_reg = (U.smooth_l1_loss(deltas[fg], gt_deltas[fg], beta=0.0, reduction="none").sum(dim=1) * t).sum()
+    normalizer = batch_size_per_image * N
+    stats = {"rpn/num_pos_anchors": fg.sum().item() / N, "rpn/num_neg_anchors": (labels == 0).sum().item() / N,
+             "rpn/conf_pos_anchors": torch.sigmoid(logits[fg]).mean().item(),
+             "rpn/conf_neg_anchors": torch.sigmoid(logits[~fg]).mean().item()}
+    return {"rpn/cls": loss_conf / normalizer, "rpn/loc": loss_reg / normalizer}, stats
+
+
+# ---------------------------------------------------------------------------------------------------
+# roi_heads/roi_heads.py: label_and_sample_proposals
+# ---------------------------------------------------------------------------------------------------
+
+def roi_label_and_sample(prop_boxes, gt_boxes, gt_classes, ign_boxes, E, num_classes=50, iou_thr=0.5,
+                         batch_size_per_image=512, positive_fraction=0.25, ignore_thresh=0.5, append_gt=True):
+    """ROIHeads3D.label_and_sample_proposals for ONE image (roi_heads.py:862-929).
+    -> (boxes of sampled, classes, matched gt idx, sampled candidate indices)."""
+    cand = torch.cat([prop_boxes, gt_boxes], dim=0) if append_gt else prop_boxes
+    has_gt = len(gt_boxes) > 0
+    mqm = U.pairwise_iou(Boxes(gt_boxes), Boxes(cand))
+    matcher = U.Matcher([iou_thr], [0, 1], allow_low_quality_matches=False)
+    matched_idxs, matched_labels = matcher(mqm)
+    if len(ign_boxes) > 0:
+        background_inds = (matched_labels == 0).nonzero().squeeze()
+        if background_inds.numel() > 1:
+            ioa = U.pairwise_ioa(Boxes(ign_boxes), Boxes(cand[background_inds]))
+            matched_labels[background_inds[ioa.max(0)[0] >= ignore_thresh]] = -1
+    if has_gt:
+        matched_ious = mqm[matched_idxs, torch.arange(mqm.shape[1])]
+        cls = gt_classes[matched_idxs].clone()
+        cls[matched_labels == 0] = num_classes
+        cls[matched_labels == -1] = -1
+    else:
+        matched_ious = torch.zeros(len(cand))
+        cls = torch.zeros_like(matched_idxs) + num_classes
+    fg_idx, bg_idx = subsample_labels_E(cls, batch_size_per_image, positive_fraction, num_classes, matched_ious, E[: len(cand)])
+    sampled = torch.cat([fg_idx, bg_idx], dim=0)
+    return cand[sampled], cls[sampled], matched_idxs[sampled], sampled
+
+
+# ---------------------------------------------------------------------------------------------------
+# roi_heads/fast_rcnn.py: FastRCNNOutputs.losses
+# ---------------------------------------------------------------------------------------------------
+
+def fast_rcnn_losses(scores, deltas, gt_classes, proposal_boxes, gt_boxes, num_classes, weights=(10.0, 10.0, 5.0, 5.0)):
+    """fast_rcnn.py:145-194: CE mean + L1 on GT-class deltas of the foreground / #ROIs."""
+    b2b = U.Box2BoxTransform(weights=weights)
+    n = max(gt_classes.numel(), 1.0)
+    loss_cls = U.cross_entropy(scores, gt_classes, reduction="mean")
+    fg = U.nonzero_tuple((gt_classes >= 0) & (gt_classes < num_classes))[0]
+    fg_pred = deltas.view(-1, num_classes, 4)[fg, gt_classes[fg]]
+    gt_d = b2b.get_deltas(proposal_boxes[fg], gt_boxes[fg])
+    loss_reg = U.smooth_l1_loss(fg_pred, gt_d, 0.0, reduction="none").sum() / n
+    return {"BoxHead/loss_cls": loss_cls, "BoxHead/loss_box_reg": loss_reg}
+
+
+# ---------------------------------------------------------------------------------------------------
+# util/math_util.py pieces + roi_heads/cube_head.py + roi_heads.py:_forward_cube
+# ---------------------------------------------------------------------------------------------------
+
+def get_cuboid_verts(box3d, R):
+    """math_util.py:116-219 (vertices only): box3d (n,6)=[X,Y,Z,W,H,L], R (n,3,3) -> (n,8,3)."""
+    n = len(box3d)
+    x3d, y3d, z3d, w3d, h3d, l3d = [box3d[:, i].unsqueeze(1) for i in range(6)]
+    sx = torch.tensor([-1, 1, 1, -1, -1, 1, 1, -1.0])
+    sy = torch.tensor([-1, -1, 1, 1, -1, -1, 1, 1.0])
+    sz = torch.tensor([-1, -1, -1, -1, 1, 1, 1, 1.0])
+    verts = torch.stack([l3d / 2 * sx, h3d / 2 * sy, w3d / 2 * sz], dim=1)      # (n,3,8)
+    verts = R @ verts
+    verts = verts + torch.stack([x3d, y3d, z3d], dim=1)
+    return verts.transpose(1, 2)
+
+
+def R_from_allocentric(K, R_view, u, v):
+    """math_util.py:651-679 (tensor branch)."""
+    fx, fy, sx, sy = K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]
+    oray = torch.stack(((u - sx) / fx, (v - sy) / fy, torch.ones_like(u))).T
+    oray = oray / torch.linalg.norm(oray, dim=1).unsqueeze(1)
+    angle = torch.acos(oray[:, -1])
+    axis = torch.zeros_like(oray)
+    axis[:, 0] = axis[:, 0] - oray[:, 1]
+    axis[:, 1] = axis[:, 1] + oray[:, 0]
+    norms = torch.linalg.norm(axis, dim=1)
+    valid_angle = angle > 0
+    M = U.axis_angle_to_matrix(angle.unsqueeze(1) * axis / norms.unsqueeze(1))
+    R = R_view.clone()
+    R[valid_angle] = torch.bmm(M[valid_angle], R_view[valid_angle])
+    return R
+
+
+def chamfer_loss(vals, target):
+    """roi_heads.py:298-304"""
+    B = vals.shape[0]
+    l1 = (vals.view(B, 8, 1, 3) - target.view(B, 1, 8, 3)).abs().sum(-1)
+    return l1.min(1).values.mean(-1) + l1.min(2).values.mean(-1)
+
+
+def safely_reduce(loss):
+    """roi_heads.py:932-940"""
+    valid = (~loss.isinf()) & (~loss.isnan())
+    return loss[valid].mean() if valid.any() else loss.mean() * 0.0
+
+
+def cube_head_outputs_to_fused(xy, z, dims, pose6, uncert):
+    """(n,K,2),(n,K,1),(n,K,3),(n,K,6),(n,K) -> (n, 13K) in the product's fused column order."""
+    n = xy.shape[0]
+    return torch.cat([xy.reshape(n, -1), z.reshape(n, -1), dims.reshape(n, -1), pose6.reshape(n, -1), uncert.reshape(n, -1)], 1)
+
+
+def cube_losses(head, num_classes, boxes, classes, Ks_scaled, virtual_to_real, prior_mean, gt_boxes3D, gt_poses):
+    """CubeHead.forward tail (cube_head.py:163,176,187-197) + ROIHeads3D._forward_cube training path
+    (roi_heads.py:410-768) for the default config (z 'direct', 6d pose, dims priors 'exp', virtual depth,
+    allocentric, disentangled + chamfer + joint, confidence).
+    head (n, 13K) raw fused linear outputs in the column order of cube_head_outputs_to_fused;
+    boxes (n,4) proposal boxes; classes (n,); Ks_scaled (n,3,3); virtual_to_real (n,); prior_mean (n,3);
+    gt_boxes3D (n,9); gt_poses (n,3,3).  -> (losses dict, stats dict)."""
+    K = num_classes
+    n = head.shape[0]
+    ar = torch.arange(n)
+    box_2d_deltas = head[:, : 2 * K].view(n, K, 2)
+    box_z = head[:, 2 * K: 3 * K].view(n, K, 1)
+    box_dims = head[:, 3 * K: 6 * K].view(n, K, 3)
+    box_pose = U.rotation_6d_to_matrix(head[:, 6 * K: 12 * K].reshape(-1, 6)).view(n, K, 3, 3)
+    box_uncert = head[:, 12 * K: 13 * K].clip(0.01)
+    cube_z = box_z[ar, classes, :]
+    cube_dims = box_dims[ar, classes, :]
+    cube_pose = box_pose[ar, classes, :, :]
+    cube_uncert = box_uncert[ar, classes]
+    cube_2d_deltas = box_2d_deltas[ar, classes, :]
+    src_w = boxes[:, 2] - boxes[:, 0]
+    src_h = boxes[:, 3] - boxes[:, 1]
+    src_cx = boxes[:, 0] + 0.5 * src_w
+    src_cy = boxes[:, 1] + 0.5 * src_h
+    cube_x = src_cx + src_w * cube_2d_deltas[:, 0]
+    cube_y = src_cy + src_h * cube_2d_deltas[:, 1]
+    cube_xy = torch.stack((cube_x, cube_y), dim=1)
+    cube_dims = torch.exp(cube_dims.clip(max=5)) * prior_mean
+    cube_pose = R_from_allocentric(Ks_scaled, cube_pose, u=cube_x.detach(), v=cube_y.detach())
+    cube_z = cube_z.squeeze(1) * virtual_to_real
+    fx, fy, sx, sy = Ks_scaled[:, 0, 0], Ks_scaled[:, 1, 1], Ks_scaled[:, 0, 2], Ks_scaled[:, 1, 2]
+    gt_2d, gt_z, gt_dims = gt_boxes3D[:, :2], gt_boxes3D[:, 2], gt_boxes3D[:, 3:6]
+    gt_x3d = gt_z * (gt_2d[:, 0] - sx) / fx
+    gt_y3d = gt_z * (gt_2d[:, 1] - sy) / fy
+    gt_3d = torch.stack((gt_x3d, gt_y3d, gt_z)).T
+    gt_box3d = torch.cat((gt_3d, gt_dims), dim=1)
+    gt_corners = get_cuboid_verts(gt_box3d, gt_poses)
+    l1 = lambda a, b: F.smooth_l1_loss(a, b, reduction="none", beta=0.0)  # noqa: E731
+    dis_z = torch.cat((torch.stack((cube_z * (gt_2d[:, 0] - sx) / fx, cube_z * (gt_2d[:, 1] - sy) / fy, cube_z)).T, gt_dims), dim=1)
+    loss_z = l1(get_cuboid_verts(dis_z, gt_poses), gt_corners).contiguous().view(n, -1).mean(dim=1)
+    dis_xy = torch.cat((torch.stack((gt_z * (cube_x - sx) / fx, gt_z * (cube_y - sy) / fy, gt_z)).T, gt_dims), dim=1)
+    loss_xy = l1(get_cuboid_verts(dis_xy, gt_poses), gt_corners).contiguous().view(n, -1).mean(dim=1)
+    loss_pose = chamfer_loss(get_cuboid_verts(gt_box3d, cube_pose), gt_corners)
+    loss_dims = l1(get_cuboid_verts(torch.cat((gt_3d, cube_dims), dim=1), gt_poses), gt_corners).contiguous().view(n, -1).mean(dim=1)
+    total = (loss_dims + loss_pose + loss_xy + loss_z).detach()
+    joint = torch.cat((torch.stack((cube_z * (cube_x - sx) / fx, cube_z * (cube_y - sy) / fy, cube_z)).T, cube_dims), dim=1)
+    loss_joint = chamfer_loss(get_cuboid_verts(joint, cube_pose), gt_corners)
+    valid_joint = loss_joint < float("inf")
+    total = total + loss_joint.detach()
+    z_error = (cube_z - gt_z).detach().abs()
+    stats = {"Cube/z_error": z_error.mean().item(), "Cube/dims_error": (cube_dims - gt_dims).detach().abs().mean().item(),
+             "Cube/xy_error": (cube_xy - gt_2d).detach().abs().mean().item(), "Cube/z_close": (z_error < 0.20).float().mean().item(),
+             "Cube/total_3D_loss": safely_reduce(total).item(), "Cube/conf": torch.exp(-cube_uncert).mean().item()}
+    sf = SQRT_2 * torch.exp(-cube_uncert)
+    losses = {"Cube/uncert": safely_reduce(cube_uncert.clone()), "Cube/loss_dims": safely_reduce(loss_dims * sf),
+              "Cube/loss_xy": safely_reduce(loss_xy * sf), "Cube/loss_z": safely_reduce(loss_z * sf),
+              "Cube/loss_pose": safely_reduce(loss_pose * sf)}
+    if valid_joint.any():
+        losses["Cube/loss_joint"] = safely_reduce((loss_joint * sf)[valid_joint])
+    extras = {"cube_x": cube_x, "cube_y": cube_y, "cube_z": cube_z, "cube_dims": cube_dims, "cube_pose": cube_pose,
+              "cube_uncert": cube_uncert}
+    return losses, stats, extras

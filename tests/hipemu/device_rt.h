@@ -18,6 +18,8 @@
 #include <functional>
 
 #define OMNI_HIPEMU 1
+using std::min;
+using std::max;
 #define OMNI_WAVE 64
 #define OMNI_OK 0
 #define OMNI_ERR_ARG 1

@@ -1,0 +1,321 @@
+"""RPN / ROI / ROIAlign / loss / cube / optimizer kernels vs the CPU oracle
+(oracle/upstream.py + oracle/cubercnn_oracle.py).  Integer outputs are compared exactly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cubercnn_oracle as O
+from oracle import upstream as U
+from omni3d_amd.d2.structures import Boxes
+
+
+def _anchors(sizes, strides, hw):
+    gen = U.DefaultAnchorGenerator(sizes=[[s] for s in sizes], aspect_ratios=[[0.5, 1.0, 2.0]], strides=strides, offset=0.0)
+    feats = [torch.zeros(1, 1, h, w) for h, w in hw]
+    return torch.cat([b.tensor for b in gen(feats)])
+
+
+def _rand_boxes(g, n, W, H, smin=8, smax=80):
+    cx, cy = torch.rand(n, generator=g) * W, torch.rand(n, generator=g) * H
+    w, h = smin + torch.rand(n, generator=g) * (smax - smin), smin + torch.rand(n, generator=g) * (smax - smin)
+    b = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    b[:, 0::2] = b[:, 0::2].clamp(0, W)
+    b[:, 1::2] = b[:, 1::2].clamp(0, H)
+    return b
+
+
+def _rpn_setup(dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    hw, strides, sizes = [(16, 16), (8, 8), (4, 4)], [4, 8, 16], [16, 32, 64]
+    anchors = _anchors(sizes, strides, hw)
+    B = 2
+    gts = [_rand_boxes(g, 5, 64, 64), _rand_boxes(g, 3, 64, 64)]
+    igns = [_rand_boxes(g, 1, 64, 64, 30, 60), torch.zeros(0, 4)]
+    E = torch.empty(B, anchors.shape[0]).exponential_(generator=g)
+    return anchors, gts, igns, E, hw
+
+
+def _offsets(lst):
+    return torch.tensor(np.concatenate([[0], np.cumsum([len(x) for x in lst])]), dtype=torch.int32)
+
+
+def _run_rpn_labels(dev, batch_per_image, pos_frac, seed):
+    from omni3d_amd.kernels import det, select
+    anchors, gts, igns, E, hw = _rpn_setup(dev, seed)
+    A, B = anchors.shape[0], len(gts)
+    gt, ign = torch.cat(gts), torch.cat(igns)
+    gt_off, ign_off = _offsets(gts), _offsets(igns)
+    m = det.rpn_match(anchors.to(dev), gt.to(dev), gt_off.to(dev), E.to(dev))
+    kpos = int(batch_per_image * pos_frac)
+    pv, pi = select.topk_rows(m["key_pos"], max(kpos, 1))
+    nv, ni = select.topk_rows(m["key_neg"], batch_per_image)
+    labels, counts = det.rpn_finalize_labels(anchors.to(dev), gt_off.to(dev), ign.to(dev) if len(ign) else torch.zeros(1, 4).to(dev),
+                                             ign_off.to(dev), m, pv, pi, nv, ni, batch_per_image, 0.5)
+    for n in range(B):
+        ref_labels, ref_midx, ref_miou, _ = O.rpn_label_and_sample(anchors, gts[n], igns[n], E[n], batch_size_per_image=batch_per_image,
+                                                                  positive_fraction=pos_frac)
+        assert torch.equal(labels[n].cpu(), ref_labels), n
+        assert torch.equal(m["matched_idx"][n].cpu().long(), ref_midx)
+        assert torch.equal(m["matched_val"][n].cpu(), ref_miou)
+    return anchors, gts, labels, m, hw
+
+
+def _run_rpn_loss(dev):
+    from omni3d_amd.kernels import det
+    anchors, gts, labels, m, hw = _run_rpn_labels(dev, 64, 1.0, 3)
+    B, A = labels.shape
+    g = torch.Generator().manual_seed(11)
+    levels = [torch.randn(B, h, w, 16, generator=g) for h, w in hw]
+    pack = det.LevelPack([t.to(dev) for t in levels])
+    # oracle views: logits (B,A), deltas (B,A,4)
+    logits = torch.cat([t[..., :3].reshape(B, -1) for t in levels], 1).requires_grad_(True)
+    deltas = torch.cat([t[..., 3:15].reshape(B, -1, 4) for t in levels], 1).requires_grad_(True)
+    assert torch.equal(det.rpn_gather_logits(pack).cpu(), logits.detach())
+    gt = torch.cat(gts)
+    gt_off = _offsets(gts)
+    midx = m["matched_idx"].cpu().long()
+    mgt = torch.stack([gts[n][midx[n]] for n in range(B)])
+    ref, stats = O.rpn_losses_iouness(anchors, logits, deltas, labels.cpu(), mgt, batch_size_per_image=64)
+    sums = det.rpn_loss_fwd(pack, anchors.to(dev), labels, m["matched_idx"], gt.to(dev), gt_off.to(dev)).cpu()
+    norm = 64 * B
+    assert abs(sums[0].item() / norm - ref["rpn/cls"].item()) < 1e-5
+    assert abs(sums[1].item() / norm - ref["rpn/loc"].item()) < 1e-4
+    assert sums[2].item() / B == stats["rpn/num_pos_anchors"] and sums[3].item() / B == stats["rpn/num_neg_anchors"]
+    assert abs(sums[4].item() / sums[2].item() - stats["rpn/conf_pos_anchors"]) < 1e-5
+    (2.0 * ref["rpn/cls"] + 0.5 * ref["rpn/loc"]).backward()
+    grads = det.rpn_loss_bwd(pack, anchors.to(dev), labels, m["matched_idx"], gt.to(dev), gt_off.to(dev),
+                             torch.tensor([2.0]).to(dev), torch.tensor([0.5]).to(dev), 1.0 / norm)
+    dlog = torch.cat([t[..., :3].reshape(B, -1) for t in grads], 1).cpu()
+    ddel = torch.cat([t[..., 3:15].reshape(B, -1, 4) for t in grads], 1).cpu()
+    assert (dlog - logits.grad).abs().max() < 1e-6 and (ddel - deltas.grad).abs().max() < 1e-6
+    assert all(t[..., 15].abs().max() == 0 for t in grads)
+    # decode of selected anchors == detectron2 apply_deltas + clip + nonempty
+    b2b = U.Box2BoxTransform((1.0, 1.0, 1.0, 1.0))
+    a_off = np.concatenate([[0], np.cumsum([h * w * 3 for h, w in hw])])
+    k = 20
+    slot_level = torch.tensor(sum([[l] * k for l in range(len(hw))], []), dtype=torch.int32)
+    idx = torch.stack([torch.cat([torch.randperm(hw[l][0] * hw[l][1] * 3, generator=g)[:k] for l in range(len(hw))]) for _ in range(B)]).int()
+    idx[0, 3] = -1
+    image_hw = torch.tensor([[64, 64], [60, 50]], dtype=torch.int32)
+    boxes, valid = det.rpn_decode(pack, slot_level.to(dev), idx.to(dev), anchors.to(dev), image_hw.to(dev))
+    for n in range(B):
+        for j in range(len(slot_level)):
+            if idx[n, j] < 0:
+                assert valid[n, j] == 0
+                continue
+            a = int(a_off[slot_level[j]] + idx[n, j])
+            pb = Boxes(b2b.apply_deltas(deltas[n, a].detach()[None], anchors[a][None]))
+            pb.clip(tuple(image_hw[n].tolist()))
+            assert torch.equal(boxes[n, j].cpu(), pb.tensor[0]), (n, j)
+            assert bool(valid[n, j]) == bool(pb.nonempty()[0])
+
+
+def _run_roi_sample(dev):
+    from omni3d_amd.kernels import det
+    g = torch.Generator().manual_seed(5)
+    B, pmax, Kc = 2, 300, 50
+    gts = [_rand_boxes(g, 6, 200, 200, 20, 90), _rand_boxes(g, 2, 200, 200, 20, 90)]
+    gcls = [torch.randint(0, Kc, (6,), generator=g), torch.randint(0, Kc, (2,), generator=g)]
+    igns = [_rand_boxes(g, 2, 200, 200, 60, 150), torch.zeros(0, 4)]
+    props = torch.stack([_rand_boxes(g, pmax, 200, 200, 10, 100) for _ in range(B)])
+    # make some proposals overlap GT strongly
+    for n in range(B):
+        for j in range(40):
+            props[n, j] = gts[n][j % len(gts[n])] + torch.randn(4, generator=g) * 2.0
+    pcount = torch.tensor([pmax, 250], dtype=torch.int32)
+    E = torch.empty(B, det.ROI_MAXC).exponential_(generator=g)
+    gt_off, ign_off = _offsets(gts), _offsets(igns)
+    ob, oc, og, oi, cnt = det.roi_sample(props.to(dev), pcount.to(dev), torch.cat(gts).to(dev), torch.cat(gcls).int().to(dev),
+                                         gt_off.to(dev), torch.cat(igns).to(dev), ign_off.to(dev), E.to(dev), 0.5, 0.5, Kc, 128, 0.25)
+    for n in range(B):
+        rb, rc, rm, rs = O.roi_label_and_sample(props[n, : pcount[n]], gts[n], gcls[n], igns[n], E[n], num_classes=Kc,
+                                                batch_size_per_image=128, positive_fraction=0.25)
+        ns = len(rs)
+        assert int(cnt[n].sum()) == ns
+        assert torch.equal(ob[n, :ns].cpu(), rb)
+        assert torch.equal(oc[n, :ns].cpu().long(), rc)
+        assert torch.equal(og[n, :ns].cpu().long() - int(gt_off[n]), rm)
+        assert (oc[n, ns:] == -2).all()
+
+
+def _run_roi_align(dev):
+    from omni3d_amd.kernels import det
+    g = torch.Generator().manual_seed(9)
+    B, C, P = 2, 8, 7
+    hw = [(32, 32), (16, 16), (8, 8)]
+    scales = [1 / 4, 1 / 8, 1 / 16]
+    feats = [torch.randn(B, C, h, w, generator=g) for h, w in hw]
+    rois = torch.cat([_rand_boxes(g, 30, 128, 128, 6, 120), torch.tensor([[-20.0, -20, 30, 30], [100, 100, 160, 170], [5, 5, 5.5, 5.2]])])
+    R = rois.shape[0]
+    bidx = torch.randint(0, B, (R,), generator=g).int()
+    box_lists = [Boxes(rois[bidx == b]) for b in range(B)]
+    order = torch.cat([torch.where(bidx == b)[0] for b in range(B)])
+    pool = U.ROIPooler(P, scales, 0, "ROIAlignV2", canonical_box_size=56, canonical_level=3)
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    ref = pool(fr, box_lists)                                                      # (R, C, P, P) in `order`
+    lv = det.roi_levels(rois.to(dev), 2, 4, 56.0, 3)
+    ref_lv = U.assign_boxes_to_levels([Boxes(rois)], 2, 4, 56, 3)
+    assert torch.equal(lv.cpu().long(), ref_lv)
+    fn = [f.permute(0, 2, 3, 1).contiguous().to(dev) for f in feats]
+    out = det.roi_align_fwd(fn, scales, rois.to(dev), bidx.to(dev), lv, P)         # (R, P, P, C)
+    got = out.cpu().permute(0, 3, 1, 2)[order]
+    assert (got - ref.detach()).abs().max() < 1e-5
+    dout = torch.randn(R, P, P, C, generator=g)
+    ref.backward(dout.permute(0, 3, 1, 2)[order])
+    dfe = [torch.zeros_like(f) for f in fn]
+    det.roi_align_bwd(dfe, scales, rois.to(dev), bidx.to(dev), lv, P, dout.to(dev))
+    for d, f in zip(dfe, fr):
+        fg = f.grad if f.grad is not None else torch.zeros_like(f)
+        assert (d.cpu().permute(0, 3, 1, 2) - fg).abs().max() < 2e-5
+
+
+def _run_box_loss(dev):
+    from omni3d_amd.kernels import det
+    g = torch.Generator().manual_seed(2)
+    R, K = 70, 50
+    pred = torch.randn(R, 256, generator=g)
+    cls = torch.randint(0, K + 1, (R,), generator=g)
+    cls[:10] = torch.randint(0, K, (10,), generator=g)
+    cls[-5:] = -2
+    prop = _rand_boxes(g, R, 300, 300)
+    gtb = _rand_boxes(g, 9, 300, 300)
+    gt_row = torch.randint(0, 9, (R,), generator=g)
+    val = cls >= 0
+    scores = pred[val, : K + 1].clone().requires_grad_(True)
+    deltas = pred[val, K + 1: K + 1 + 4 * K].clone().requires_grad_(True)
+    ref = O.fast_rcnn_losses(scores, deltas, cls[val], prop[val], gtb[gt_row[val]], K)
+    args = (pred.to(dev), K, cls.int().to(dev), prop.to(dev), gtb.to(dev), gt_row.int().to(dev))
+    sums = det.box_loss_fwd(*args)
+    n = sums[2].item()
+    assert n == val.sum().item()
+    assert abs(sums[0].item() / n - ref["BoxHead/loss_cls"].item()) < 1e-5
+    assert abs(sums[1].item() / n - ref["BoxHead/loss_box_reg"].item()) < 1e-5
+    pc = scores.detach().argmax(1)
+    assert sums[4].item() == (pc == cls[val]).sum().item()
+    (1.5 * ref["BoxHead/loss_cls"] + 0.25 * ref["BoxHead/loss_box_reg"]).backward()
+    dpred = det.box_loss_bwd(*args, sums, torch.tensor([1.5]).to(dev), torch.tensor([0.25]).to(dev)).cpu()
+    assert (dpred[val, : K + 1] - scores.grad).abs().max() < 1e-7
+    assert (dpred[val, K + 1: K + 1 + 4 * K] - deltas.grad).abs().max() < 1e-7
+    assert dpred[~val].abs().max() == 0 and dpred[:, 5 * K + 1:].abs().max() == 0
+
+
+def _rand_rot(g, n):
+    q = torch.randn(n, 4, generator=g)
+    return U.quaternion_to_matrix(q / q.norm(dim=1, keepdim=True))
+
+
+def _run_cube(dev):
+    from omni3d_amd.kernels import det
+    g = torch.Generator().manual_seed(4)
+    F_, K, B = 37, 50, 3
+    ldh = 656
+    head = torch.randn(F_, ldh, generator=g) * 0.5
+    head[:, 12 * K: 13 * K] += 1.0            # uncertainties around 1, some below the 0.01 clip
+    head[0, 3 * K: 6 * K] = 6.0               # dims logits above the clip(max=5)
+    boxes = _rand_boxes(g, F_, 512, 512, 20, 200)
+    cls = torch.randint(0, K, (F_,), generator=g)
+    img = torch.randint(0, B, (F_,), generator=g)
+    Ks = torch.tensor([[500.0, 510.0, 250.0, 260.0], [400.0, 400.0, 256.0, 256.0], [700.0, 690.0, 300.0, 200.0]])
+    v2r = torch.tensor([1.0, 0.8, 1.7])
+    priors = torch.rand(K, 2, 3, generator=g) * 2 + 0.5
+    G = 11
+    gt3d = torch.cat([torch.rand(G, 2, generator=g) * 512, torch.rand(G, 1, generator=g) * 30 + 2, torch.rand(G, 3, generator=g) * 3 + 0.3,
+                      torch.zeros(G, 3)], 1)
+    gtpose = _rand_rot(g, G)
+    gt_row = torch.randint(0, G, (F_,), generator=g)
+    hr = head[:, : 13 * K].clone().requires_grad_(True)
+    Kmat = torch.zeros(F_, 3, 3)
+    Kmat[:, 0, 0], Kmat[:, 1, 1], Kmat[:, 0, 2], Kmat[:, 1, 2], Kmat[:, 2, 2] = Ks[img, 0], Ks[img, 1], Ks[img, 2], Ks[img, 3], 1.0
+    ref, stats, ex = O.cube_losses(hr, K, boxes, cls, Kmat, v2r[img], priors[cls, 0], gt3d[gt_row], gtpose[gt_row])
+    args = [t.to(dev) for t in (head, boxes, cls.int(), img.int(), Ks, v2r, priors, gt3d, gtpose.reshape(G, 9), gt_row.int())]
+    vals, jac, red = det.cube_loss_fwd(args[0], K, *args[1:])
+    names = ["Cube/loss_dims", "Cube/loss_xy", "Cube/loss_z", "Cube/loss_pose", "Cube/loss_joint", "Cube/uncert"]
+    r = red.cpu()
+    for k, nm in enumerate(names):
+        assert abs(r[k].item() - ref[nm].item()) < 2e-5 * max(1.0, abs(ref[nm].item())), (nm, r[k].item(), ref[nm].item())
+    for k, nm in zip((12, 13, 14, 15, 16, 17), ("Cube/total_3D_loss", "Cube/z_error", "Cube/dims_error", "Cube/xy_error", "Cube/z_close", "Cube/conf")):
+        assert abs(r[k].item() - stats[nm]) < 2e-5 * max(1.0, abs(stats[nm])), nm
+    w = torch.tensor([1.0, 0.7, 1.3, 0.9, 1.1, 0.5])
+    sum(w[k] * ref[nm] for k, nm in enumerate(names)).backward()
+    dhead = det.cube_loss_bwd(vals, jac, red, w.to(dev), args[2], F_, K, ldh).cpu()
+    scale = hr.grad.abs().max().item()
+    assert (dhead[:, : 13 * K] - hr.grad).abs().max() < 2e-5 * max(1.0, scale)
+    assert dhead[:, 13 * K:].abs().max() == 0
+    # inference decode
+    ratio = torch.tensor([1.0, 2.0, 0.5])
+    c3, pose, verts = det.cube_decode(args[0], K, args[1], args[2], args[3], args[4], args[5], ratio.to(dev), args[6])
+    X = ex["cube_z"] * (ex["cube_x"] - Kmat[:, 0, 2]) / Kmat[:, 0, 0]
+    assert (c3[:, 0].cpu() - X.detach()).abs().max() < 1e-4
+    assert (c3[:, 3:6].cpu() - ex["cube_dims"].detach()).abs().max() < 1e-5
+    assert (pose.cpu() - ex["cube_pose"].detach()).abs().max() < 1e-5
+    assert (c3[:, 8].cpu() - torch.exp(-ex["cube_uncert"].detach())).abs().max() < 1e-6
+    cc = torch.cat([torch.stack((X, ex["cube_z"] * (ex["cube_y"] - Kmat[:, 1, 2]) / Kmat[:, 1, 1], ex["cube_z"]), 1), ex["cube_dims"]], 1).detach()
+    assert (verts.cpu() - O.get_cuboid_verts(cc, ex["cube_pose"].detach())).abs().max() < 1e-4
+    assert (det.cuboid_corners(cc.to(dev), ex["cube_pose"].detach().reshape(-1, 9).to(dev)).cpu() - O.get_cuboid_verts(cc, ex["cube_pose"].detach())).abs().max() < 1e-5
+
+
+def _run_sgd(dev):
+    from omni3d_amd.kernels import det
+    g = torch.Generator().manual_seed(8)
+    n = 1003
+    p0, g0 = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=0.1, momentum=0.9, weight_decay=1e-2)
+    p, buf = p0.clone().to(dev), torch.zeros(n).to(dev)
+    for it in range(3):
+        gr = g0 * (it + 1)
+        ref.grad = gr.clone()
+        opt.step()
+        det.sgd_step(p, gr.to(dev), buf, 0.1, 0.9, 0.0, 1e-2, False, first_step=(it == 0))
+        assert (p.cpu() - ref.detach()).abs().max() < 1e-6
+    flag = torch.zeros(1).to(dev)
+    det.nonfinite_any(p, flag)
+    assert flag.item() == 0
+    p[517] = float("nan")
+    det.nonfinite_any(p, flag)
+    assert flag.item() == 1
+    skip = torch.ones(1).to(dev)
+    q = p0.clone().to(dev)
+    det.sgd_step(q, g0.to(dev), buf, 0.1, skip_flag=skip)
+    assert torch.equal(q.cpu(), p0)
+
+
+def test_rpn_labels_emulated(emu_lib):
+    _run_rpn_labels("cpu", 64, 1.0, 0)
+    _run_rpn_labels("cpu", 512, 0.5, 1)      # not enough positives -> negatives get sampled, ignore path
+
+
+def test_rpn_loss_decode_emulated(emu_lib):
+    _run_rpn_loss("cpu")
+
+
+def test_roi_sample_emulated(emu_lib):
+    _run_roi_sample("cpu")
+
+
+def test_roi_align_emulated(emu_lib):
+    _run_roi_align("cpu")
+
+
+def test_box_loss_emulated(emu_lib):
+    _run_box_loss("cpu")
+
+
+def test_cube_emulated(emu_lib):
+    _run_cube("cpu")
+
+
+def test_sgd_emulated(emu_lib):
+    _run_sgd("cpu")
+
+
+@pytest.mark.gpu
+def test_det_kernels_gpu(hip_lib):
+    _run_rpn_labels("cuda", 64, 1.0, 0)
+    _run_rpn_labels("cuda", 512, 0.5, 1)
+    _run_rpn_loss("cuda")
+    _run_roi_sample("cuda")
+    _run_roi_align("cuda")
+    _run_box_loss("cuda")
+    _run_cube("cuda")
+    _run_sgd("cuda")
