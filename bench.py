@@ -136,7 +136,7 @@ def main():
         dist.destroy_process_group()
 
 
-DEFAULT_WORKLOAD = "iou3d"
+DEFAULT_WORKLOAD = "train"
 
 if __name__ == "__main__":
     main()

@@ -221,6 +221,11 @@ int omni_sgd_step(float* param, const float* grad, float* momentum_buf, long lon
 /* the isnan/isinf gradient scan of tools/train_net.py:222-233 as one pass; flag[0] = 1 if any. */
 int omni_nonfinite_any(const float* grad, long long n, float* flag, void* stream);
 
+/* backward of the ReLU fused into conv / linear epilogues, and the bias gradient (per-channel sum
+ * of dy over P pixels; ws 2C doubles scratch).  autograd of the nn.Conv2d / nn.Linear call sites. */
+int omni_relu_bwd(const float* dy, const float* y, float* dz, long long n, void* stream);
+int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -267,6 +267,18 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const unsigned char* __
     }
 }
 
+// dz = dy where y > 0 else 0 (backward of the ReLU fused into a conv / linear epilogue)
+__global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       float* __restrict__ dz, long total4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x)
+        st4(dz + 4 * i, mask4(ld4(dy + 4 * i), ld4(y + 4 * i)));
+}
+
+__global__ void cast_sum_kernel(const double* __restrict__ acc, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) out[c] = (float)acc[c];
+}
+
 inline int ew_grid(long total) {
     long g = (total + 255) / 256;
     if (g > 256 * 8) g = 256 * 8;
@@ -391,6 +403,25 @@ int omni_preprocess(const unsigned char* img, float* out, int N, int H, int W, i
     if (total == 0) return OMNI_OK;
     hipLaunchKernelGGL(preprocess_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, img, out, N, H, W, PH,
                        PW, m0, m1, m2, s0, s1, s2);
+    return omni_launch_status();
+}
+
+// dz = dy * (y > 0), n elements (n % 4 == 0).
+int omni_relu_bwd(const float* dy, const float* y, float* dz, long long n, void* stream) {
+    if (n < 0 || (n & 3)) return OMNI_ERR_ARG;
+    if (n == 0) return OMNI_OK;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, dy, y, dz, (long)(n >> 2));
+    return omni_launch_status();
+}
+
+// db[c] = sum over the P pixels of dy[p, c] (bias gradient of a conv / linear).  ws: 2*C doubles.
+int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, void* stream) {
+    if (P <= 0 || C <= 0 || (C & 3) || C > 1024) return OMNI_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(red_grid(P, C)), dim3(256), 0, st, dy,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, P, C, 0, ws);
+    hipLaunchKernelGGL(cast_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, C, db);
     return omni_launch_status();
 }
 

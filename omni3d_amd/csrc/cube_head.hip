@@ -189,7 +189,8 @@ __device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn&
 }
 
 // ---- training forward: per-ROI losses (6) + Jacobian (6 x 13) + logging terms -----------------------
-// vals (F, 12): [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, u,  total3d_report, z_err, dims_err(sum3), xy_err(sum2), conf, joint_valid]
+// vals (F, 13): [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, u,  total3d_report, z_err, dims_err(sum3), xy_err(sum2), conf, joint_valid, row_valid]
+// rows whose class is outside [0, K) (background / padding slots of the fixed-capacity ROI set) are skipped: row_valid = 0.
 __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restrict__ head, int ldh, int F, int K,
                                                            const float* __restrict__ boxes, const int* __restrict__ cls,
                                                            const int* __restrict__ img, const float* __restrict__ Ks,
@@ -202,6 +203,10 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
     RoiIn in;
     for (int k = 0; k < 4; ++k) in.box[k] = boxes[4 * f + k];
     in.cls = cls[f];
+    if (in.cls < 0 || in.cls >= K) {
+        for (int k = 0; k < 13; ++k) vals[(long)f * 13 + k] = 0.f;
+        return;
+    }
     const int im = img[f];
     for (int k = 0; k < 4; ++k) in.K[k] = Ks[4 * im + k];
     in.v2r = v2r[im];
@@ -234,7 +239,7 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
     // uncertainty weighting (roi_heads.py:721-739)
     const D sf = dexp(neg(o.u)) * 1.41421356f;
     D L[6] = {loss_dims * sf, loss_xy * sf, loss_z * sf, loss_pose * sf, loss_joint * sf, o.u};
-    float* vo = vals + (long)f * 12;
+    float* vo = vals + (long)f * 13;
     for (int k = 0; k < 6; ++k) {
         vo[k] = L[k].v;
         for (int t = 0; t < NT; ++t) jac[((long)f * 6 + k) * NT + t] = L[k].d[t];
@@ -245,6 +250,7 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
     vo[9] = fabsf(o.x.v - gu) + fabsf(o.y.v - gv);
     vo[10] = expf(-o.u.v);
     vo[11] = joint_valid;
+    vo[12] = 1.f;
 }
 
 // safely_reduce_losses (roi_heads.py:932-940) for the 6 columns + logging sums.
@@ -255,9 +261,11 @@ __global__ void __launch_bounds__(256) cube_reduce_kernel(const float* __restric
     const int t = threadIdx.x;
     if (t < 20) acc[t] = 0.0;
     __syncthreads();
-    double s[6] = {0, 0, 0, 0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0}, tot = 0, totc = 0, ze = 0, de = 0, xe = 0, zc = 0, cf = 0;
+    double s[6] = {0, 0, 0, 0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0}, tot = 0, totc = 0, ze = 0, de = 0, xe = 0, zc = 0, cf = 0, nv = 0;
     for (int f = t; f < F; f += blockDim.x) {
-        const float* v = vals + (long)f * 12;
+        const float* v = vals + (long)f * 13;
+        if (v[12] == 0.f) continue;
+        nv += 1;
         for (int k = 0; k < 6; ++k) {
             bool ok = isfinite(v[k]);
             if (k == 4) ok = ok && v[11] != 0.f;   // joint: `loss_joint[valid_joint]` then finite-only mean
@@ -268,7 +276,7 @@ __global__ void __launch_bounds__(256) cube_reduce_kernel(const float* __restric
     }
     for (int k = 0; k < 6; ++k) { atomicAdd(&acc[k], s[k]); atomicAdd(&acc[6 + k], c[k]); }
     atomicAdd(&acc[12], tot); atomicAdd(&acc[13], totc); atomicAdd(&acc[14], ze); atomicAdd(&acc[15], de);
-    atomicAdd(&acc[16], xe); atomicAdd(&acc[17], zc); atomicAdd(&acc[18], cf);
+    atomicAdd(&acc[16], xe); atomicAdd(&acc[17], zc); atomicAdd(&acc[18], cf); atomicAdd(&acc[19], nv);
     __syncthreads();
     if (t == 0) {
         for (int k = 0; k < 6; ++k) {
@@ -276,14 +284,14 @@ __global__ void __launch_bounds__(256) cube_reduce_kernel(const float* __restric
             red[k] = n > 0 ? (float)(acc[k] / n) : 0.f;
             red[6 + k] = n > 0 ? (float)(1.0 / n) : 0.f;
         }
-        const double Fd = F > 0 ? (double)F : 1.0;
+        const double Fd = acc[19] > 0 ? acc[19] : 1.0;
         red[12] = acc[13] > 0 ? (float)(acc[12] / acc[13]) : 0.f;
         red[13] = (float)(acc[14] / Fd);
         red[14] = (float)(acc[15] / (3.0 * Fd));
         red[15] = (float)(acc[16] / (2.0 * Fd));
         red[16] = (float)(acc[17] / Fd);
         red[17] = (float)(acc[18] / Fd);
-        red[18] = (float)F;
+        red[18] = (float)acc[19];
     }
 }
 
@@ -298,7 +306,8 @@ __global__ void __launch_bounds__(64) cube_loss_bwd_kernel(const float* __restri
     for (int j = 0; j < ldh; ++j) row[j] = 0.f;
     float d[NT];
     for (int t = 0; t < NT; ++t) d[t] = 0.f;
-    const float* v = vals + (long)f * 12;
+    const float* v = vals + (long)f * 13;
+    if (v[12] == 0.f) return;
     for (int k = 0; k < 6; ++k) {
         bool ok = isfinite(v[k]);
         if (k == 4) ok = ok && v[11] != 0.f;
@@ -365,7 +374,7 @@ extern "C" {
 // head (F, ldh) fused cube-head outputs for the F foreground ROIs; boxes (F,4) proposal boxes; cls (F);
 // img (F) image index; Ks (B,4) = [fx, fy, cx, cy] scaled to network resolution; v2r (B) virtual->real depth
 // factor; priors (K,2,3); gt3d (G,9) gt_boxes3D rows; gtpose (G,9); gt_row (F).
-// vals (F,12), jac (F,6,13), red (24) outputs.
+// vals (F,13), jac (F,6,13), red (24) outputs.  Rows with cls outside [0,K) are ignored.
 int omni_cube_loss_fwd(const float* head, int ldh, int F, int K, const float* boxes, const int* cls, const int* img,
                        const float* Ks, const float* v2r, const float* priors, const float* gt3d, const float* gtpose,
                        const int* gt_row, float* vals, float* jac, float* red, void* stream) {

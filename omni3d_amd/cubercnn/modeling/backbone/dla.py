@@ -1,0 +1,162 @@
+"""DLA-34 bottom-up + FPN builder (`build_dla_from_vision_fpn_backbone`).
+
+Same topology, module names (=> state-dict keys of SURVEY.md Appendix C) and initialisation as
+/root/reference/cubercnn/modeling/backbone/dla.py (BasicBlock :40-68, Root :156-174, Tree :177-230,
+DLA :233-297, dla34 :312-321, DLABackbone :417-482, builder :484-507), restricted to the dla34
+variant of BASELINE.json.  Every conv is the implicit-GEMM MFMA kernel, every BN(+ReLU)(+residual)
+one fused HBM-bound kernel pair; the image enters as NHWC with C padded 3 -> 4."""
+import math
+
+import torch
+from torch import nn
+
+from .... import functional as HF
+from ..layers import BatchNorm2d, Conv2d
+from ..registries import BACKBONE_REGISTRY
+from .fpn import FPN, Backbone
+
+
+class ConvBNReLU(nn.Sequential):
+    """nn.Sequential(conv, bn, relu) with the reference's child names '0','1','2'."""
+
+    def __init__(self, cin, cout, k, stride, pad):
+        super().__init__(Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=False), BatchNorm2d(cout),
+                         nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        conv, bn = self[0], self[1]
+        w = conv.weight
+        if x.shape[1] != w.shape[1]:   # 3-channel stem weight against the 4-channel padded image
+            w = torch.cat([w, w.new_zeros(w.shape[0], x.shape[1] - w.shape[1], w.shape[2], w.shape[3])], dim=1)
+        return bn(HF.conv2d(x, w, None, conv.stride[0], conv.padding[0]), relu=True)
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, inplanes, planes, stride=1, dilation=1):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(planes)
+        self.stride = stride
+
+    def forward(self, x, residual=None):
+        if residual is None:
+            residual = x
+        out = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(out), residual=residual, relu=True)
+
+
+class Root(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, residual):
+        super().__init__()
+        self.conv = Conv2d(in_channels, out_channels, 1, stride=1, bias=False, padding=(kernel_size - 1) // 2)
+        self.bn = BatchNorm2d(out_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self.residual = residual
+
+    def forward(self, *x):
+        y = self.conv(torch.cat(x, 1))
+        return self.bn(y, residual=x[0] if self.residual else None, relu=True)
+
+
+class Project(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__(Conv2d(cin, cout, kernel_size=1, stride=1, bias=False), BatchNorm2d(cout))
+
+    def forward(self, x):
+        return self[1](self[0](x))
+
+
+class Tree(nn.Module):
+    def __init__(self, levels, block, in_channels, out_channels, stride=1, level_root=False, root_dim=0,
+                 root_kernel_size=1, dilation=1, root_residual=False):
+        super().__init__()
+        if root_dim == 0:
+            root_dim = 2 * out_channels
+        if level_root:
+            root_dim += in_channels
+        if levels == 1:
+            self.tree1 = block(in_channels, out_channels, stride, dilation=dilation)
+            self.tree2 = block(out_channels, out_channels, 1, dilation=dilation)
+            self.root = Root(root_dim, out_channels, root_kernel_size, root_residual)
+        else:
+            self.tree1 = Tree(levels - 1, block, in_channels, out_channels, stride, root_dim=0,
+                              root_kernel_size=root_kernel_size, dilation=dilation, root_residual=root_residual)
+            self.tree2 = Tree(levels - 1, block, out_channels, out_channels, root_dim=root_dim + out_channels,
+                              root_kernel_size=root_kernel_size, dilation=dilation, root_residual=root_residual)
+        self.level_root = level_root
+        self.root_dim = root_dim
+        self.levels = levels
+        self.downsample = nn.MaxPool2d(stride, stride=stride) if stride > 1 else None
+        self.project = Project(in_channels, out_channels) if in_channels != out_channels else None
+
+    def forward(self, x, residual=None, children=None):
+        children = [] if children is None else children
+        bottom = HF.max_pool2(x) if self.downsample is not None else x
+        residual = self.project(bottom) if self.project is not None else bottom
+        if self.level_root:
+            children.append(bottom)
+        x1 = self.tree1(x, residual)
+        if self.levels == 1:
+            x2 = self.tree2(x1)
+            return self.root(x2, x1, *children)
+        children.append(x1)
+        return self.tree2(x1, children=children)
+
+
+class DLA(nn.Module):
+    def __init__(self, levels, channels, block=BasicBlock, residual_root=False):
+        super().__init__()
+        self.channels = channels
+        self.base_layer = ConvBNReLU(3, channels[0], 7, 1, 3)
+        self.level0 = ConvBNReLU(channels[0], channels[0], 3, 1, 1)
+        self.level1 = ConvBNReLU(channels[0], channels[1], 3, 2, 1)
+        self.level2 = Tree(levels[2], block, channels[1], channels[2], 2, level_root=False, root_residual=residual_root)
+        self.level3 = Tree(levels[3], block, channels[2], channels[3], 2, level_root=True, root_residual=residual_root)
+        self.level4 = Tree(levels[4], block, channels[3], channels[4], 2, level_root=True, root_residual=residual_root)
+        self.level5 = Tree(levels[5], block, channels[4], channels[5], 2, level_root=True, root_residual=residual_root)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+
+def dla34(pretrained=False, tricks=False):
+    if pretrained:
+        raise RuntimeError("ImageNet DLA weights are downloaded by the reference (dla.py:300-309); there is no network "
+                           "here -- set MODEL.WEIGHTS / MODEL.WEIGHTS_PRETRAIN or load a state dict")
+    return DLA([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], block=BasicBlock)
+
+
+class DLABackbone(Backbone):
+    def __init__(self, cfg, input_shape, pretrained=True):
+        super().__init__()
+        if cfg.MODEL.DLA.TYPE != "dla34":
+            raise ValueError(f"DLA type {cfg.MODEL.DLA.TYPE} is outside the MI355X hot path (dla34 only)")
+        base = dla34(pretrained=pretrained, tricks=cfg.MODEL.DLA.TRICKS)
+        self._out_feature_channels = {"p2": 64, "p3": 128, "p4": 256, "p5": 512, "p6": 512}
+        for name in ("base_layer", "level0", "level1", "level2", "level3", "level4", "level5"):
+            setattr(self, name, getattr(base, name))
+        self._out_feature_strides = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
+        self._out_features = ["p2", "p3", "p4", "p5", "p6"]
+
+    def forward(self, x):
+        x = self.level1(self.level0(self.base_layer(x)))
+        p2 = self.level2(x)
+        p3 = self.level3(p2)
+        p4 = self.level4(p3)
+        p5 = self.level5(p4)
+        return {"p2": p2, "p3": p3, "p4": p4, "p5": p5, "p6": HF.subsample2(p5)}
+
+
+@BACKBONE_REGISTRY.register()
+def build_dla_from_vision_fpn_backbone(cfg, input_shape, priors=None):
+    imagenet_pretrain = cfg.MODEL.WEIGHTS_PRETRAIN + cfg.MODEL.WEIGHTS == ""
+    bottom_up = DLABackbone(cfg, input_shape, pretrained=imagenet_pretrain)
+    return FPN(bottom_up=bottom_up, in_features=cfg.MODEL.FPN.IN_FEATURES, out_channels=cfg.MODEL.FPN.OUT_CHANNELS,
+               norm=cfg.MODEL.FPN.NORM, fuse_type=cfg.MODEL.FPN.FUSE_TYPE)

@@ -1,0 +1,79 @@
+"""nn.Module shells over the HIP kernels.  They subclass the torch modules so that parameter /
+buffer names (state-dict keys), `isinstance(m, nn.BatchNorm2d)` checks (solver/build.py:8-19,71-76
+of the reference) and `.to(device)` behave exactly like the reference's modules; only `forward`
+differs: it launches the gfx950 kernels through omni3d_amd.functional."""
+import torch
+from torch import nn
+
+from ... import functional as HF
+
+CL = torch.channels_last
+
+
+class Conv2d(nn.Conv2d):
+    """weight (K,C,R,S) held in channels_last memory (= KRSC)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        assert self.dilation == (1, 1) and self.groups == 1 and self.kernel_size[0] == self.kernel_size[1]
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+
+    def forward(self, x, relu=False):
+        return HF.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu)
+
+
+class Linear(nn.Linear):
+    def forward(self, x, relu=False):
+        return HF.linear(x, self.weight, self.bias, relu)
+
+
+class FlattenLinear(nn.Module):
+    """`flatten -> nn.Linear(C*P*P, out)` of FastRCNNConvFCHead / CubeHead fc1, computed as a PxP
+    valid convolution over the NHWC ROI features.  The parameter is kept (out, C, P, P) in
+    channels_last memory so the GEMM reduction index is contiguous; state dicts carry the
+    reference's (out, C*P*P) shape."""
+
+    def __init__(self, channels, size, out_features):
+        super().__init__()
+        self.channels, self.size, self.out_features = channels, size, out_features
+        w = torch.empty(out_features, channels, size, size)
+        nn.init.kaiming_uniform_(w, a=1)  # c2_xavier_fill
+        self.weight = nn.Parameter(w.contiguous(memory_format=CL))
+        self.bias = nn.Parameter(torch.zeros(out_features))
+        self._register_state_dict_hook(self._to_reference_shape)
+        self._register_load_state_dict_pre_hook(self._from_reference_shape)
+
+    @staticmethod
+    def _to_reference_shape(module, state_dict, prefix, local_metadata):
+        key = prefix + "weight"
+        state_dict[key] = state_dict[key].reshape(module.out_features, -1)
+
+    def _from_reference_shape(self, state_dict, prefix, *args):
+        key = prefix + "weight"
+        if key in state_dict and state_dict[key].dim() == 2:
+            state_dict[key] = state_dict[key].reshape(self.out_features, self.channels, self.size, self.size)
+
+    def forward(self, x, relu=False):
+        y = HF.conv2d(x, self.weight, self.bias, 1, 0, relu)     # (R, out, 1, 1)
+        return y.reshape(y.shape[0], self.out_features)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    def forward(self, x, residual=None, relu=False):
+        if self.training:
+            y = HF.batch_norm_train(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                    self.running_var if self.track_running_stats else None, residual, relu, self.eps,
+                                    self.momentum)
+            if self.track_running_stats and self.num_batches_tracked is not None:
+                self.num_batches_tracked += 1
+            return y
+        from ...kernels import bnpool
+        rstd = torch.rsqrt(self.running_var + self.eps)
+        scale = self.weight * rstd
+        scale_shift = torch.cat([scale, self.bias - self.running_mean * scale]).detach().contiguous()
+        return bnpool.bn_apply(x.contiguous(memory_format=CL), scale_shift,
+                               residual.contiguous(memory_format=CL) if residual is not None else None, relu)

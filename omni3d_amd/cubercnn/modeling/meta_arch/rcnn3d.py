@@ -1,0 +1,124 @@
+"""`RCNN3D` (META_ARCH_REGISTRY), `build_model`, `build_backbone`.
+
+Mirrors /root/reference/cubercnn/modeling/meta_arch/rcnn3d.py (:25-112, :247-272): constructor via
+`from_config(cfg, priors)`, `forward(batched_inputs)` returning the loss dict in training and
+`[{"instances": Instances}]` in eval, `.device`, `preprocess_image`.  The image batch is normalised,
+padded and converted to NHWC (C padded 3 -> 4) by one kernel; ground truth is packed once per step."""
+import torch
+from torch import nn
+
+from ....d2.config import configurable
+from ....d2.events import get_event_storage, has_event_storage
+from ....d2.layers import ShapeSpec
+from ....d2.structures import ImageList
+from ....kernels import bnpool
+from ..proposal_generator import build_proposal_generator
+from ..registries import BACKBONE_REGISTRY, META_ARCH_REGISTRY
+from ..roi_heads import build_roi_heads
+from ..targets import pack_targets
+
+
+@META_ARCH_REGISTRY.register()
+class RCNN3D(nn.Module):
+    @configurable
+    def __init__(self, *, backbone, proposal_generator, roi_heads, pixel_mean, pixel_std, input_format=None, vis_period=0):
+        super().__init__()
+        self.backbone = backbone
+        self.proposal_generator = proposal_generator
+        self.roi_heads = roi_heads
+        self.input_format = input_format
+        self.vis_period = vis_period
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std).view(-1, 1, 1), False)
+        self._mean, self._std = [float(v) for v in pixel_mean], [float(v) for v in pixel_std]
+
+    @classmethod
+    def from_config(cls, cfg, priors=None):
+        backbone = build_backbone(cfg, priors=priors)
+        return {
+            "backbone": backbone,
+            "proposal_generator": build_proposal_generator(cfg, backbone.output_shape()),
+            "roi_heads": build_roi_heads(cfg, backbone.output_shape(), priors=priors),
+            "input_format": cfg.INPUT.FORMAT, "vis_period": cfg.VIS_PERIOD,
+            "pixel_mean": cfg.MODEL.PIXEL_MEAN, "pixel_std": cfg.MODEL.PIXEL_STD,
+        }
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess_image(self, batched_inputs):
+        imgs = [x["image"] for x in batched_inputs]
+        sizes = [(im.shape[-2], im.shape[-1]) for im in imgs]
+        if len(set(sizes)) == 1:
+            batch = torch.stack(imgs).to(self.device, non_blocking=True)
+        else:   # ragged batch: pad the uint8 images on the host first (zero padding is re-zeroed after normalisation)
+            H, W = max(s[0] for s in sizes), max(s[1] for s in sizes)
+            batch = torch.zeros((len(imgs), 3, H, W), dtype=torch.uint8)
+            for b, im in zip(batch, imgs):
+                b[:, : im.shape[-2], : im.shape[-1]] = im
+            batch = batch.to(self.device, non_blocking=True)
+        x = bnpool.preprocess(batch, self._mean, self._std, self.backbone.size_divisibility)
+        if len(set(sizes)) != 1:
+            for n, (h, w) in enumerate(sizes):   # re-zero the region that was host padding
+                x[n, :, h:, :] = 0
+                x[n, :, :, w:] = 0
+        return ImageList(x, sizes)
+
+    def prepack(self, batched_inputs):
+        """Pack the ground truth / intrinsics of a batch once and keep them on the device (benchmarks
+        pre-stage their synthetic batches with this; the training loop calls it implicitly)."""
+        sizes = [(x["image"].shape[-2], x["image"].shape[-1]) for x in batched_inputs]
+        vf = getattr(self.roi_heads, "virtual_focal", 512.0)
+        return pack_targets(batched_inputs, sizes, vf, with_gt=True).to(self.device)
+
+    def forward(self, batched_inputs, packed=None):
+        if not self.training:
+            return self.inference(batched_inputs, packed=packed)
+        images = self.preprocess_image(batched_inputs)
+        if packed is None:
+            packed = self.prepack(batched_inputs)
+        features = self.backbone(images.tensor)
+        proposals, proposal_losses = self.proposal_generator(images, features, None, targets=packed)
+        _, detector_losses = self.roi_heads(images, features, proposals, None, None, None, packed=packed)
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        if has_event_storage():
+            self.flush_logs(get_event_storage())
+        return losses
+
+    def flush_logs(self, storage):
+        """One device->host readback for all logged scalars (the reference does ~16 .item() syncs)."""
+        self.proposal_generator.flush_logs(storage)
+        self.roi_heads.flush_logs(storage)
+
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True, packed=None):
+        assert not self.training
+        from ..roi_heads.inference import postprocess
+        images = self.preprocess_image(batched_inputs)
+        if packed is None:
+            sizes = images.image_sizes
+            packed = pack_targets(batched_inputs, sizes, getattr(self.roi_heads, "virtual_focal", 512.0), with_gt=False).to(self.device)
+        features = self.backbone(images.tensor)
+        proposals, _ = self.proposal_generator(images, features, None, targets=packed)
+        results, _ = self.roi_heads(images, features, proposals, None, None, None, packed=packed)
+        if do_postprocess:
+            return postprocess(results, batched_inputs, images.image_sizes)
+        return results
+
+
+def build_model(cfg, priors=None):
+    meta_arch = cfg.MODEL.META_ARCHITECTURE
+    model = META_ARCH_REGISTRY.get(meta_arch)(cfg, priors=priors)
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    return model
+
+
+def build_backbone(cfg, input_shape=None, priors=None):
+    if input_shape is None:
+        input_shape = ShapeSpec(channels=len(cfg.MODEL.PIXEL_MEAN))
+    backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, input_shape, priors)
+    from ..backbone.fpn import Backbone
+    assert isinstance(backbone, Backbone)
+    return backbone

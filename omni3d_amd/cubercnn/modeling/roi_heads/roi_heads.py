@@ -1,0 +1,217 @@
+"""`ROIHeads3D` (ROI_HEADS_REGISTRY) on the HIP kernels.
+
+Mirrors /root/reference/cubercnn/modeling/roi_heads/roi_heads.py: constructor / from_config keys
+(:42-204), `forward(images, features, proposals, Ks, im_scales_ratio, targets)` (:207-246),
+`label_and_sample_proposals` (:862-929), `_forward_box` (:249-293), `_forward_cube` (:326-824) with
+the same loss names, loss weights and logged scalars -- for the configuration of
+configs/Base.yaml (disentangled + chamfer + joint losses, virtual depth, allocentric 6D pose,
+dimension priors, confidence).
+
+Data layout: the sampled ROIs of a batch are a fixed-shape (B, batch_size_per_image) block with the
+foreground first in every row (the sampler's order), so the 2D box head runs on B*512 rows and the
+cube head on the first `fg_cap` = int(512 * positive_fraction) slots of every image; padding /
+background slots carry class -2 / K and are skipped inside the loss kernels.  No per-image Python
+loops, boolean-mask gathers or host syncs."""
+import torch
+from torch import nn
+
+from .... import functional as HF
+from ....d2.config import configurable
+from ....d2.layers import ShapeSpec
+from ....d2.structures import Boxes, Instances
+from ....kernels import det
+from ..layers import FlattenLinear, Linear
+from ..registries import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
+from .cube_head import build_cube_head
+from .fast_rcnn import FastRCNNOutputs
+
+
+def build_roi_heads(cfg, input_shape, priors=None):
+    return ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, input_shape, priors=priors)
+
+
+@ROI_BOX_HEAD_REGISTRY.register()
+class FastRCNNConvFCHead(nn.Module):
+    """detectron2 FastRCNNConvFCHead with NUM_CONV 0: flatten -> fc1 -> ReLU -> fc2 -> ReLU
+    (state-dict names `fc1`, `fc2`)."""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        b = cfg.MODEL.ROI_BOX_HEAD
+        if b.NUM_CONV != 0 or b.NUM_FC != 2 or b.NORM != "":
+            raise NotImplementedError("MI355X hot path: FastRCNNConvFCHead with NUM_CONV 0, NUM_FC 2 (Base.yaml:67-70)")
+        self.fc1 = FlattenLinear(input_shape.channels, input_shape.height, b.FC_DIM)
+        self.fc2 = Linear(b.FC_DIM, b.FC_DIM)
+        nn.init.kaiming_uniform_(self.fc2.weight, a=1)
+        nn.init.constant_(self.fc2.bias, 0)
+        self._fc_dim = b.FC_DIM
+
+    @property
+    def output_shape(self):
+        return ShapeSpec(channels=self._fc_dim)
+
+    def forward(self, x):
+        return self.fc2(self.fc1(x, relu=True), relu=True)
+
+
+class ROIPooler(nn.Module):
+    """detectron2 ROIPooler (ROIAlignV2, canonical size 224 / level 4) over packed ROI tensors."""
+
+    def __init__(self, output_size, scales, sampling_ratio, pooler_type, canonical_box_size=224, canonical_level=4):
+        super().__init__()
+        import math
+        if pooler_type != "ROIAlignV2" or sampling_ratio != 0:
+            raise NotImplementedError("MI355X hot path: ROIAlignV2 with adaptive sampling (POOLER_SAMPLING_RATIO 0)")
+        self.output_size = output_size if isinstance(output_size, int) else output_size[0]
+        self.scales = tuple(scales)
+        self.min_level = int(round(-math.log2(scales[0])))
+        self.max_level = int(round(-math.log2(scales[-1])))
+        self.canonical_box_size, self.canonical_level = canonical_box_size, canonical_level
+
+    def forward(self, feats, rois, batch_idx):
+        levels = det.roi_levels(rois, self.min_level, self.max_level, float(self.canonical_box_size), self.canonical_level)
+        return HF.roi_align(feats, self.scales, rois, batch_idx, levels, self.output_size)
+
+
+@ROI_HEADS_REGISTRY.register()
+class ROIHeads3D(nn.Module):
+    @configurable
+    def __init__(self, *, num_classes, batch_size_per_image, positive_fraction, proposal_iou_threshold, proposal_append_gt,
+                 box_in_features, box_pooler, box_head, box_predictor, ignore_thresh, cube_head, cube_pooler, loss_w_3d,
+                 loss_w_xy, loss_w_z, loss_w_dims, loss_w_pose, loss_w_joint, use_confidence, inverse_z_weight, z_type,
+                 pose_type, cluster_bins, priors=None, dims_priors_enabled=None, dims_priors_func=None, disentangled_loss=None,
+                 virtual_depth=None, virtual_focal=None, test_scale=None, allocentric_pose=None, chamfer_pose=None,
+                 scale_roi_boxes=None, train_on_pred_boxes=False):
+        super().__init__()
+        self.num_classes = num_classes
+        self.batch_size_per_image = batch_size_per_image
+        self.positive_fraction = positive_fraction
+        self.proposal_iou_threshold = proposal_iou_threshold
+        self.proposal_append_gt = proposal_append_gt
+        self.in_features = self.box_in_features = box_in_features
+        self.box_pooler, self.box_head, self.box_predictor = box_pooler, box_head, box_predictor
+        self.ignore_thresh = ignore_thresh
+        self.loss_w_3d, self.loss_w_xy, self.loss_w_z = loss_w_3d, loss_w_xy, loss_w_z
+        self.loss_w_dims, self.loss_w_pose, self.loss_w_joint = loss_w_dims, loss_w_pose, loss_w_joint
+        self.use_confidence, self.virtual_focal, self.test_scale = use_confidence, virtual_focal, test_scale
+        unsupported = (inverse_z_weight or z_type != "direct" or pose_type != "6d" or cluster_bins != 1 or not dims_priors_enabled
+                       or dims_priors_func != "exp" or not disentangled_loss or not virtual_depth or not allocentric_pose
+                       or not chamfer_pose or scale_roi_boxes or train_on_pred_boxes or loss_w_3d <= 0 or loss_w_joint <= 0
+                       or not use_confidence)
+        if unsupported:
+            raise NotImplementedError("MI355X hot path implements the ROI_CUBE_HEAD configuration of configs/Base.yaml")
+        self.cube_head, self.cube_pooler = cube_head, cube_pooler
+        if priors is not None:
+            self.priors_dims_per_cat = nn.Parameter(torch.FloatTensor(priors["priors_dims_per_cat"]).unsqueeze(0))
+        else:
+            self.priors_dims_per_cat = nn.Parameter(torch.ones(1, num_classes, 2, 3))
+        self.priors_z_scales = nn.Parameter(torch.ones(num_classes, cluster_bins))
+        self.pending_logs = {}
+        self.injected = None     # parity tests: {'E': (B, 2048) exponential variates}
+        self.fg_cap = int(batch_size_per_image * positive_fraction)
+
+    @classmethod
+    def from_config(cls, cfg, input_shape, priors=None):
+        in_features = cfg.MODEL.ROI_HEADS.IN_FEATURES
+        scales = tuple(1.0 / input_shape[k].stride for k in in_features)
+        channels = [input_shape[f].channels for f in in_features]
+        assert len(set(channels)) == 1, channels
+        bres = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        box_head = ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(cfg, ShapeSpec(channels=channels[0], height=bres, width=bres))
+        c = cfg.MODEL.ROI_CUBE_HEAD
+        cres = c.POOLER_RESOLUTION
+        assert len(cfg.MODEL.ROI_HEADS.IOU_THRESHOLDS) == 1
+        return {
+            "num_classes": cfg.MODEL.ROI_HEADS.NUM_CLASSES, "batch_size_per_image": cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE,
+            "positive_fraction": cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION, "proposal_iou_threshold": cfg.MODEL.ROI_HEADS.IOU_THRESHOLDS[0],
+            "proposal_append_gt": cfg.MODEL.ROI_HEADS.PROPOSAL_APPEND_GT, "train_on_pred_boxes": cfg.MODEL.ROI_BOX_HEAD.TRAIN_ON_PRED_BOXES,
+            "box_in_features": in_features,
+            "box_pooler": ROIPooler(bres, scales, cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO, cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE),
+            "box_head": box_head, "box_predictor": FastRCNNOutputs(cfg, box_head.output_shape),
+            "cube_pooler": ROIPooler(cres, scales, c.POOLER_SAMPLING_RATIO, c.POOLER_TYPE),
+            "cube_head": build_cube_head(cfg, ShapeSpec(channels=channels[0], width=cres, height=cres)),
+            "use_confidence": c.USE_CONFIDENCE, "inverse_z_weight": c.INVERSE_Z_WEIGHT, "loss_w_3d": c.LOSS_W_3D,
+            "loss_w_xy": c.LOSS_W_XY, "loss_w_z": c.LOSS_W_Z, "loss_w_dims": c.LOSS_W_DIMS, "loss_w_pose": c.LOSS_W_POSE,
+            "loss_w_joint": c.LOSS_W_JOINT, "z_type": c.Z_TYPE, "pose_type": c.POSE_TYPE,
+            "dims_priors_enabled": c.DIMS_PRIORS_ENABLED, "dims_priors_func": c.DIMS_PRIORS_FUNC,
+            "disentangled_loss": c.DISENTANGLED_LOSS, "virtual_depth": c.VIRTUAL_DEPTH, "virtual_focal": c.VIRTUAL_FOCAL,
+            "test_scale": cfg.INPUT.MIN_SIZE_TEST, "chamfer_pose": c.CHAMFER_POSE, "allocentric_pose": c.ALLOCENTRIC_POSE,
+            "cluster_bins": c.CLUSTER_BINS, "ignore_thresh": cfg.MODEL.RPN.IGNORE_THRESHOLD, "scale_roi_boxes": c.SCALE_ROI_BOXES,
+            "priors": priors,
+        }
+
+    # ---- roi_heads.py:862-929 --------------------------------------------------------------------
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals, targets):
+        boxes, count = proposals.boxes, proposals.count
+        B = boxes.shape[0]
+        if self.injected is not None and "E" in self.injected:
+            E = self.injected["E"].to(boxes.device).float().contiguous()
+        else:
+            E = torch.empty((B, det.ROI_MAXC), dtype=torch.float32, device=boxes.device).exponential_()
+        out = det.roi_sample(boxes, count, targets.gt, targets.gt_cls, targets.gt_off, targets.ign, targets.ign_off, E,
+                             self.proposal_iou_threshold, self.ignore_thresh, self.num_classes, self.batch_size_per_image,
+                             self.positive_fraction, self.proposal_append_gt)
+        self.pending_logs["roi_counts"] = out[4]
+        return out
+
+    def forward(self, images, features, proposals, Ks, im_scales_ratio, targets=None, packed=None):
+        feats = [features[f] for f in self.in_features]
+        if self.training:
+            assert packed is not None
+            sboxes, scls, sgt, siou, counts = self.label_and_sample_proposals(proposals, packed)
+            losses = self._forward_box_train(feats, sboxes, scls, sgt, packed)
+            losses.update(self._forward_cube_train(feats, sboxes, scls, sgt, packed))
+            return [], losses
+        from .inference import roi_heads_inference
+        return roi_heads_inference(self, images, feats, proposals, packed), {}
+
+    def _batch_index(self, B, per_image, device):
+        key = (B, per_image, str(device))
+        if getattr(self, "_bidx_key", None) != key:
+            self._bidx = torch.arange(B, dtype=torch.int32, device=device).repeat_interleave(per_image).contiguous()
+            self._bidx_key = key
+        return self._bidx
+
+    # ---- roi_heads.py:249-293 + fast_rcnn.py:145-194 ------------------------------------------------
+    def _forward_box_train(self, feats, sboxes, scls, sgt, packed):
+        B, S = scls.shape
+        rois = sboxes.reshape(B * S, 4)
+        x = self.box_pooler(feats, rois, self._batch_index(B, S, rois.device))
+        pred = self.box_predictor(self.box_head(x))
+        return self.box_predictor.losses(pred, scls.reshape(-1), rois, packed, sgt.reshape(-1).clamp(min=0))
+
+    # ---- roi_heads.py:326-768 (training path) ----------------------------------------------------
+    def _forward_cube_train(self, feats, sboxes, scls, sgt, packed):
+        B, S = scls.shape
+        Fc = self.fg_cap
+        rois = sboxes[:, :Fc].reshape(B * Fc, 4).contiguous()
+        cls = scls[:, :Fc].reshape(-1).contiguous()
+        gt_row = sgt[:, :Fc].reshape(-1).clamp(min=0).contiguous()
+        bidx = self._batch_index(B, Fc, rois.device)
+        x = self.cube_pooler(feats, rois, bidx)
+        head = self.cube_head(x)
+        priors = self.priors_dims_per_cat.detach().reshape(self.num_classes, 2, 3).contiguous()
+        red6, red = HF.cube_loss(head, self.num_classes, rois, cls, bidx, packed.Ks, packed.v2r, priors, packed.gt3d,
+                                 packed.gtpose, gt_row)
+        self.pending_logs["cube"] = red
+        w3 = self.loss_w_3d
+        p = "Cube/"
+        return {
+            p + "uncert": self.use_confidence * red6[5],
+            p + "loss_dims": red6[0] * self.loss_w_dims * w3, p + "loss_xy": red6[1] * self.loss_w_xy * w3,
+            p + "loss_z": red6[2] * self.loss_w_z * w3, p + "loss_pose": red6[3] * self.loss_w_pose * w3,
+            p + "loss_joint": red6[4] * self.loss_w_joint * w3,
+        }
+
+    def flush_logs(self, storage):
+        self.box_predictor.flush_logs(storage)
+        if "roi_counts" in self.pending_logs:
+            c = self.pending_logs.pop("roi_counts").float().mean(0).tolist()
+            storage.put_scalar("roi_head/num_fg_samples", c[0])
+            storage.put_scalar("roi_head/num_bg_samples", c[1])
+        if "cube" in self.pending_logs:
+            r = self.pending_logs.pop("cube").tolist()
+            for name, k in (("z_error", 13), ("dims_error", 14), ("xy_error", 15), ("z_close", 16), ("conf", 17)):
+                storage.put_scalar("Cube/" + name, r[k], smoothing_hint=False)
+            storage.put_scalar("Cube/total_3D_loss", self.loss_w_3d * r[12], smoothing_hint=False)

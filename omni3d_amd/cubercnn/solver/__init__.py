@@ -1,0 +1,2 @@
+from .build import FlatSGD, build_optimizer, freeze_bn  # noqa: F401
+from .checkpoint import PeriodicCheckpointerOnlyOne  # noqa: F401

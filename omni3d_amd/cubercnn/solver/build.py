@@ -1,0 +1,134 @@
+"""`build_optimizer(cfg, model)` / `freeze_bn` with the reference's parameter-group rules
+(/root/reference/cubercnn/solver/build.py:6-76): SGD momentum (cfg.SOLVER.MOMENTUM / NESTEROV), weight decay
+WEIGHT_DECAY except WEIGHT_DECAY_NORM for norm layers, WEIGHT_DECAY_BIAS / BIAS_LR_FACTOR for biases, 0 for the
+`priors_*` parameters.
+
+MI355X design: instead of ~230 per-tensor update kernels, every parameter is re-homed into ONE flat fp32
+bucket (grouped by weight decay so a group is a contiguous range), gradients accumulate into a matching flat
+bucket (`param.grad` are views, so the training script's per-parameter NaN scan at tools/train_net.py:226-233
+still works), and `step()` is one fused kernel per group.  The flat gradient bucket is also what the
+data-parallel all-reduce operates on (one RCCL call, no per-tensor launches), and a fused non-finite scan of
+it can gate the step on the device."""
+import torch
+
+from ...kernels import det
+
+CL = torch.channels_last
+
+
+def _param_groups(cfg, model):
+    norm_types = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.SyncBatchNorm, torch.nn.GroupNorm,
+                  torch.nn.InstanceNorm1d, torch.nn.InstanceNorm2d, torch.nn.InstanceNorm3d, torch.nn.LayerNorm,
+                  torch.nn.LocalResponseNorm)
+    groups, memo = [], set()
+    for module in model.modules():
+        for key, value in module.named_parameters(recurse=False):
+            if not value.requires_grad or value in memo:
+                continue
+            memo.add(value)
+            lr, wd = cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY
+            if isinstance(module, norm_types) and cfg.SOLVER.WEIGHT_DECAY_NORM is not None:
+                wd = cfg.SOLVER.WEIGHT_DECAY_NORM
+            elif key == "bias":
+                if cfg.SOLVER.BIAS_LR_FACTOR is not None:
+                    lr = cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR
+                if cfg.SOLVER.WEIGHT_DECAY_BIAS is not None:
+                    wd = cfg.SOLVER.WEIGHT_DECAY_BIAS
+            if key in ("priors_dims_per_cat", "priors_z_scales", "priors_z_stats"):
+                wd = 0.0
+            groups.append({"params": [value], "lr": lr, "weight_decay": wd})
+    return groups
+
+
+class FlatSGD(torch.optim.Optimizer):
+    """torch.optim.SGD semantics over flat buckets (see module docstring)."""
+
+    def __init__(self, params, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov)
+        super().__init__(params, defaults)
+        self._build_buckets()
+        self._steps = 0
+        self.skip_flag = None   # optional device float: != 0 skips the update inside the kernel
+
+    def _build_buckets(self):
+        plist = [(g, p) for g in self.param_groups for p in g["params"]]
+        if not plist:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = plist[0][1].device
+        # contiguous range per (lr / base lr, weight decay) class; 16-byte aligned segments
+        classes = {}
+        for g, p in plist:
+            classes.setdefault((float(g["lr"]), float(g["weight_decay"])), []).append((g, p))
+        total = sum(((p.numel() + 3) // 4) * 4 for _, p in plist)
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_mom = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.segments = []   # (start, end, representative group)
+        off = 0
+        for key, items in classes.items():
+            start = off
+            for g, p in items:
+                n = p.numel()
+                pv = self._view_like(self.flat_param[off:off + n], p)
+                pv.copy_(p.data)
+                p.data = pv
+                gv = self._view_like(self.flat_grad[off:off + n], p)
+                if p.grad is not None:
+                    gv.copy_(p.grad)
+                p.grad = gv
+                off += ((n + 3) // 4) * 4
+            self.segments.append((start, off, items[0][0]))
+
+    @staticmethod
+    def _view_like(flat, p):
+        if p.dim() == 4 and p.is_contiguous(memory_format=CL) and not p.is_contiguous():
+            K, C, R, S = p.shape
+            return flat.view(K, R, S, C).permute(0, 3, 1, 2)
+        return flat.view(p.shape)
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()    # param.grad stay views of the bucket
+
+    @torch.no_grad()
+    def check_nonfinite(self, flag):
+        """flag (1,) device float: set to 1 if any gradient element is NaN/Inf (tools/train_net.py:222-233)."""
+        det.nonfinite_any(self.flat_grad, flag)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        first = self._steps == 0
+        for start, end, g in self.segments:
+            det.sgd_step(self.flat_param[start:end], self.flat_grad[start:end], self.flat_mom[start:end], g["lr"],
+                         g["momentum"], g["dampening"], g["weight_decay"], g["nesterov"], first_step=first, skip_flag=self.skip_flag)
+        self._steps += 1
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["flat_momentum"] = self.flat_mom.clone()
+        sd["steps"] = self._steps
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        mom = sd.pop("flat_momentum", None)
+        self._steps = sd.pop("steps", 0)
+        super().load_state_dict(sd)
+        if mom is not None:
+            self.flat_mom.copy_(mom)
+
+
+def build_optimizer(cfg, model):
+    params = _param_groups(cfg, model)
+    if cfg.SOLVER.TYPE == "sgd":
+        return FlatSGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV,
+                       weight_decay=cfg.SOLVER.WEIGHT_DECAY)
+    if cfg.SOLVER.TYPE in ("adam", "adam+amsgrad", "adamw", "adamw+amsgrad"):
+        raise NotImplementedError("MI355X hot path: SOLVER.TYPE 'sgd' (configs/Base.yaml:2); Adam variants are not fused yet")
+    raise ValueError("{} is not supported as an optimizer.".format(cfg.SOLVER.TYPE))
+
+
+def freeze_bn(network):
+    for _, module in network.named_modules():
+        if isinstance(module, torch.nn.BatchNorm2d):
+            module.eval()
+            module.track_running_stats = False

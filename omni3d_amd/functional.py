@@ -1,0 +1,243 @@
+"""torch.autograd.Function wrappers around the C-ABI kernels.
+
+These are the only place where torch's autograd graph meets the HIP kernels: each Function calls
+the forward launcher, keeps what its hand-written backward kernel needs, and returns gradients
+computed by the backward kernels.  4-D activations / weights are logical NCHW / KCRS tensors in
+channels_last memory (physically NHWC / KRSC).
+"""
+import torch
+from torch.autograd import Function
+
+from .kernels import bnpool, conv, det
+
+CL = torch.channels_last
+
+
+def _cl(t):
+    return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
+
+
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, relu):
+        x, w = _cl(x), _cl(w)
+        y = conv.conv2d_fwd(x, w, bias, stride, pad, relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.cfg = (stride, pad, relu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, relu, has_bias = ctx.cfg
+        dy = _cl(dy)
+        if relu:   # elementwise on the NHWC views (same dense layout for dy and y)
+            dy = bnpool.relu_bwd(dy.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+        dx = conv.conv2d_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad) if ctx.needs_input_grad[0] else None
+        dw = conv.conv2d_wgrad(x, dy, (w.shape[2], w.shape[3]), stride, pad) if ctx.needs_input_grad[1] else None
+        db = None
+        if has_bias and ctx.needs_input_grad[2]:
+            db = bnpool.bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]))
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, relu=False):
+    return _Conv2d.apply(x, w, bias, stride, pad, relu)
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, relu):
+        x, w = x.contiguous(), w.contiguous()
+        y = conv.linear_fwd(x, w, bias, relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.cfg = (relu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        relu, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        if relu:
+            dy = bnpool.relu_bwd(dy, y)
+        dx = conv.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dw = conv.linear_wgrad(x, dy) if ctx.needs_input_grad[1] else None
+        db = bnpool.bias_grad(dy) if (has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+def linear(x, w, bias=None, relu=False):
+    return _Linear.apply(x, w, bias, relu)
+
+
+class _BatchNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, eps, momentum):
+        x = _cl(x)
+        res = _cl(residual) if residual is not None else None
+        y, mean_rstd, _ = bnpool.bn_fwd(x, gamma, beta, running_mean, running_var, res, relu, eps, momentum)
+        ctx.save_for_backward(x, gamma, mean_rstd, y if relu else None)
+        ctx.cfg = (relu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean_rstd, y = ctx.saved_tensors
+        relu, has_res = ctx.cfg
+        dx, dres, dgamma, dbeta = bnpool.bn_bwd(x, _cl(dy), y, gamma, mean_rstd, relu, want_dres=has_res and ctx.needs_input_grad[5])
+        return dx, dgamma, dbeta, None, None, dres, None, None, None
+
+
+def batch_norm_train(x, gamma, beta, running_mean, running_var, residual=None, relu=False, eps=1e-5, momentum=0.1):
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, residual, relu, eps, momentum)
+
+
+class _MaxPool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(x)
+        ctx.save_for_backward(x)
+        return bnpool.maxpool2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return bnpool.maxpool2_bwd(x, _cl(dy))
+
+
+class _Subsample2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(x)
+        ctx.hw = (x.shape[2], x.shape[3])
+        return bnpool.subsample2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return bnpool.subsample2_bwd(_cl(dy), ctx.hw)
+
+
+class _Upsample2Add(Function):
+    @staticmethod
+    def forward(ctx, lat, top):
+        return bnpool.upsample2_add(_cl(lat), _cl(top))
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _cl(dout)
+        return dout, bnpool.upsample2_bwd(dout)
+
+
+def max_pool2(x):
+    return _MaxPool2.apply(x)
+
+
+def subsample2(x):
+    return _Subsample2.apply(x)
+
+
+def upsample2_add(lat, top):
+    return _Upsample2Add.apply(lat, top)
+
+
+class _ROIAlign(Function):
+    """feats: logical (B,C,H,W) CL tensors of the FPN levels -> (R, C, P, P) CL (physically (R,P,P,C))."""
+
+    @staticmethod
+    def forward(ctx, rois, batch_idx, levels, scales, P, *feats):
+        feats = [_cl(f) for f in feats]
+        nhwc = [f.permute(0, 2, 3, 1) for f in feats]
+        out = det.roi_align_fwd(nhwc, scales, rois, batch_idx, levels, P)
+        ctx.save_for_backward(rois, batch_idx, levels)
+        ctx.meta = (scales, P, [tuple(f.shape) for f in nhwc])
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        rois, batch_idx, levels = ctx.saved_tensors
+        scales, P, shapes = ctx.meta
+        dfe = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
+        det.roi_align_bwd(dfe, scales, rois, batch_idx, levels, P, _cl(dout).permute(0, 2, 3, 1))
+        return (None, None, None, None, None) + tuple(d.permute(0, 3, 1, 2) for d in dfe)
+
+
+def roi_align(feats, scales, rois, batch_idx, levels, P):
+    return _ROIAlign.apply(rois, batch_idx, levels, tuple(scales), P, *feats)
+
+
+def _scalar(t):
+    return t.reshape(1).contiguous().float()
+
+
+class _RPNLoss(Function):
+    """-> (sum BCE*t, sum L1*t) un-normalised; level tensors are the fused head outputs (B,16,H,W) CL."""
+
+    @staticmethod
+    def forward(ctx, anchors, labels, matched_idx, gt, gt_off, inv_norm, *levels):
+        lv = [_cl(t).permute(0, 2, 3, 1) for t in levels]
+        pack = det.LevelPack(lv)
+        sums = det.rpn_loss_fwd(pack, anchors, labels, matched_idx, gt, gt_off)
+        ctx.pack = pack
+        ctx.save_for_backward(anchors, labels, matched_idx, gt, gt_off)
+        ctx.inv_norm = inv_norm
+        ctx.mark_non_differentiable(sums)
+        s = sums.float()
+        return s[0] * inv_norm, s[1] * inv_norm, sums
+
+    @staticmethod
+    def backward(ctx, g_cls, g_loc, _):
+        anchors, labels, matched_idx, gt, gt_off = ctx.saved_tensors
+        grads = det.rpn_loss_bwd(ctx.pack, anchors, labels, matched_idx, gt, gt_off, _scalar(g_cls), _scalar(g_loc), ctx.inv_norm)
+        return (None,) * 6 + tuple(g.permute(0, 3, 1, 2) for g in grads)
+
+
+def rpn_loss(levels, anchors, labels, matched_idx, gt, gt_off, inv_norm):
+    return _RPNLoss.apply(anchors, labels, matched_idx, gt, gt_off, inv_norm, *levels)
+
+
+class _BoxLoss(Function):
+    @staticmethod
+    def forward(ctx, pred, K, cls, prop, gt, gt_row, weights):
+        pred = pred.contiguous()
+        sums = det.box_loss_fwd(pred, K, cls, prop, gt, gt_row, weights)
+        ctx.save_for_backward(pred, cls, prop, gt, gt_row, sums)
+        ctx.meta = (K, weights)
+        ctx.mark_non_differentiable(sums)
+        s = sums.float()
+        n = s[2].clamp(min=1.0)
+        return s[0] / n, s[1] / n, sums
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg, _):
+        pred, cls, prop, gt, gt_row, sums = ctx.saved_tensors
+        K, weights = ctx.meta
+        return det.box_loss_bwd(pred, K, cls, prop, gt, gt_row, sums, _scalar(g_cls), _scalar(g_reg), weights), None, None, None, None, None, None
+
+
+def box_loss(pred, K, cls, prop, gt, gt_row, weights=(10.0, 10.0, 5.0, 5.0)):
+    return _BoxLoss.apply(pred, K, cls, prop, gt, gt_row, tuple(weights))
+
+
+class _CubeLoss(Function):
+    """-> (red[0:6] = loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert ; red (24) stats)."""
+
+    @staticmethod
+    def forward(ctx, head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row):
+        head = head.contiguous()
+        vals, jac, red = det.cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row)
+        ctx.save_for_backward(vals, jac, red, cls)
+        ctx.meta = (head.shape[0], K, head.shape[1])
+        ctx.mark_non_differentiable(red)
+        return red[:6].clone(), red
+
+    @staticmethod
+    def backward(ctx, g, _):
+        vals, jac, red, cls = ctx.saved_tensors
+        F_, K, ldh = ctx.meta
+        dhead = det.cube_loss_bwd(vals, jac, red, g.contiguous().float(), cls, F_, K, ldh)
+        return (dhead,) + (None,) * 10
+
+
+def cube_loss(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row):
+    return _CubeLoss.apply(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row)

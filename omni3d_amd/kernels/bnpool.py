@@ -115,3 +115,21 @@ def preprocess(images_u8, pixel_mean, pixel_std, size_divisibility=0):
     L.call("omni_preprocess", _lib.ptr(images_u8), _lib.ptr(out), N, H, W, PH, PW, m[0], m[1], m[2], s[0], s[1], s[2],
            _lib.stream_of(images_u8))
     return out.permute(0, 3, 1, 2)
+
+
+def relu_bwd(dy, y):
+    """dz = dy * (y > 0); same memory layout in and out."""
+    L = _lib.check_device(dy, y)
+    dz = torch.empty_like(dy)
+    L.call("omni_relu_bwd", _lib.ptr(dy), _lib.ptr(y), _lib.ptr(dz), dy.numel(), _lib.stream_of(dy))
+    return dz
+
+
+def bias_grad(dy2d):
+    """dy (P, C) contiguous -> (C,) column sums."""
+    P, C = dy2d.shape
+    L = _lib.check_device(dy2d)
+    db = torch.empty(C, dtype=torch.float32, device=dy2d.device)
+    ws = torch.empty(2 * C, dtype=torch.float64, device=dy2d.device)
+    L.call("omni_bias_grad", _lib.ptr(dy2d), P, C, _lib.ptr(db), _lib.ptr(ws), _lib.stream_of(dy2d))
+    return db

@@ -207,7 +207,7 @@ def box_loss_bwd(pred, K, cls, prop, gt, gt_row, sums, g_cls, g_reg, weights=(10
 def cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row):
     L = _dev(head, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row)
     F, ldh = head.shape
-    vals = _empty((max(F, 1), 12), torch.float32, head)
+    vals = _empty((max(F, 1), 13), torch.float32, head)
     jac = _empty((max(F, 1), 6, 13), torch.float32, head)
     red = _empty((24,), torch.float32, head)
     L.call("omni_cube_loss_fwd", _lib.ptr(head), ldh, F, K, _lib.ptr(boxes), _lib.ptr(cls), _lib.ptr(img), _lib.ptr(Ks),

@@ -1,0 +1,139 @@
+"""oracle/make_golden.py -- TEST INFRASTRUCTURE.  Generates tests/golden/*.pt by running the
+REFERENCE's own files (/root/reference/cubercnn, unchanged) on CPU under oracle/ref_harness.py.
+
+Only runnable in the build container (needs /root/reference).  The fixtures are small: weights are
+NOT stored -- both sides build them from the same CPU seed (the product model is initialised with
+torch.manual_seed(seed) and its state dict is loaded, strict, into the reference model).
+Randomness of the reference (`torch.multinomial` inside `subsample_labels`, rpn.py:318,322) is
+captured as data: `subsample_labels` is swapped for the injected-variates form
+(oracle/cubercnn_oracle.py:subsample_labels_E, same algorithm as torch's multinomial without
+replacement) so the HIP path can be driven by the same exponential variates.
+
+    python oracle/make_golden.py          # writes tests/golden/dla34_small.pt
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+from oracle import cubercnn_oracle as O
+from oracle import ref_harness as H
+from oracle.upstream import EventStorage
+from omni3d_amd import synthetic
+
+SMALL = dict(
+    name="dla34_small", seed=0, images=2, height=128, width=128, num_gt=5,
+    overrides=["MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 64, "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 64,
+               "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 300, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 100],
+)
+
+
+TINY = dict(
+    name="dla34_tiny", seed=3, images=1, height=64, width=64, num_gt=3,
+    overrides=["MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16, "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 16,
+               "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 100, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 30],
+)
+
+
+def product_cfg(overrides):
+    from omni3d_amd.cubercnn.config import get_cfg_defaults
+    from omni3d_amd.d2.config import get_cfg
+    cfg = get_cfg()
+    get_cfg_defaults(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cubercnn_DLA34_FPN.yaml"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "VIS_PERIOD", 0, "MODEL.WEIGHTS", "synthetic://random-init"] + list(overrides))
+    return cfg
+
+
+def build_product_model(cfg, priors, seed, device="cpu"):
+    import omni3d_amd.cubercnn.modeling.backbone  # noqa: F401
+    import omni3d_amd.cubercnn.modeling.proposal_generator  # noqa: F401
+    import omni3d_amd.cubercnn.modeling.roi_heads  # noqa: F401
+    from omni3d_amd.cubercnn.modeling.meta_arch import build_model
+    torch.manual_seed(seed)
+    model = build_model(cfg, priors)
+    # give BN affine / running stats and the zero-initialised biases non-trivial values
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and "priors" not in n:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+    return model.to(device)
+
+
+def variates(spec, A):
+    g = torch.Generator().manual_seed(spec["seed"] + 7)
+    B = spec["images"]
+    return {"rpn": torch.empty(B, A).exponential_(generator=g), "roi": torch.empty(B, 2048).exponential_(generator=g)}
+
+
+def main(spec=SMALL):
+    priors = synthetic.make_priors(50)
+    cfg_ref = H.reference_cfg("cubercnn_DLA34_FPN.yaml", spec["overrides"])
+    ref = H.build_reference_model(cfg_ref, priors)
+    prod = build_product_model(product_cfg(spec["overrides"]), priors, spec["seed"])
+    missing = ref.load_state_dict(prod.state_dict(), strict=True)
+    batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
+    A = 3 * sum((spec["height"] // s) * (spec["width"] // s) for s in (4, 8, 16, 32, 64))
+    E = variates(spec, A)
+    queue = [E["rpn"][n] for n in range(spec["images"])] + [E["roi"][n] for n in range(spec["images"])]
+    record = {"rpn_labels": [], "roi_classes": []}
+
+    def patched(labels, num_samples, positive_fraction, bg_label, matched_ious=None, eps=1e-4):
+        e = queue.pop(0)[: labels.numel()]
+        return O.subsample_labels_E(labels, num_samples, positive_fraction, bg_label, matched_ious, e, eps)
+
+    import cubercnn.modeling.proposal_generator.rpn as ref_rpn
+    import cubercnn.modeling.roi_heads.roi_heads as ref_roi
+    ref_rpn.subsample_labels = patched
+    ref_roi.subsample_labels = patched
+    orig_label = ref_rpn.RPNWithIgnore.label_and_sample_anchors
+
+    def rec_label(self, anchors, gt_instances):
+        out = orig_label(self, anchors, gt_instances)
+        record["rpn_labels"] = torch.stack([o.to(torch.int8) for o in out[0]])
+        return out
+    ref_rpn.RPNWithIgnore.label_and_sample_anchors = rec_label
+    orig_sample = ref_roi.ROIHeads3D.label_and_sample_proposals
+
+    def rec_sample(self, proposals, targets):
+        out = orig_sample(self, proposals, targets)
+        record["roi_classes"] = [o.gt_classes.clone() for o in out]
+        record["roi_boxes"] = [o.proposal_boxes.tensor.clone() for o in out]
+        return out
+    ref_roi.ROIHeads3D.label_and_sample_proposals = rec_sample
+
+    ref.train()
+    with EventStorage(0) as st:
+        losses = ref(batch)
+        total = sum(losses.values())
+        total.backward()
+        logs = {k: v[0] for k, v in st.latest().items()}
+    grads = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+    pick = ["backbone.bottom_up.base_layer.0.weight", "backbone.bottom_up.level2.tree1.conv1.weight",
+            "backbone.bottom_up.level5.root.bn.weight", "backbone.fpn_output2.weight", "backbone.fpn_lateral6.bias",
+            "proposal_generator.rpn_head.conv.weight", "proposal_generator.rpn_head.objectness_logits.bias",
+            "proposal_generator.rpn_head.anchor_deltas.weight", "roi_heads.box_head.fc1.bias", "roi_heads.box_head.fc2.weight",
+            "roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.bias",
+            "roi_heads.cube_head.feature_generator.fc2.bias", "roi_heads.cube_head.bbox_3D_pose.weight",
+            "roi_heads.cube_head.bbox_3D_uncertainty.bias", "roi_heads.cube_head.bbox_3D_center_depth.weight"]
+    out = {
+        "spec": spec, "losses": {k: float(v) for k, v in losses.items()}, "logs": logs,
+        "rpn_labels": record["rpn_labels"], "roi_classes": record["roi_classes"], "roi_boxes": record["roi_boxes"],
+        "grad_norm": {n: float(g.norm()) for n, g in grads.items()},
+        "grad_head": {n: grads[n].flatten()[:64].clone() for n in pick},
+        "torch_version": torch.__version__,
+    }
+    path = os.path.join(ROOT, "tests", "golden", spec["name"] + ".pt")
+    torch.save(out, path)
+    print("wrote", path, os.path.getsize(path), "bytes")
+    for k, v in out["losses"].items():
+        print(f"  {k:24s} {v:.6f}")
+    return out
+
+
+if __name__ == "__main__":
+    main(TINY if "--tiny" in sys.argv else SMALL)

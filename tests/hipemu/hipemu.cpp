@@ -1,11 +1,35 @@
 // tests/hipemu/hipemu.cpp -- fiber scheduler behind tests/hipemu/device_rt.h.
-// TEST INFRASTRUCTURE ONLY (see the header).  One ucontext fiber per workgroup thread;
-// workgroups run sequentially; barriers / wave rendezvous yield to the scheduler.
+// TEST INFRASTRUCTURE ONLY (see the header).  One fiber per workgroup thread (hand-rolled x86-64
+// context switch, no syscalls); workgroups run sequentially; barriers / wave rendezvous yield to
+// the scheduler.
 #include "device_rt.h"
-#include <ucontext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch,.-hipemu_switch
+)");
 
 namespace hipemu {
 
@@ -14,36 +38,46 @@ Ctx g;
 namespace {
 enum State { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
 struct Fiber {
-    ucontext_t uc;
+    void* sp = nullptr;
     char* stack = nullptr;
     State st = DONE;
     Ctx ctx;
 };
 constexpr size_t kStack = 256 * 1024;
 std::vector<Fiber*> pool;
-ucontext_t sched_uc;
+void* sched_sp = nullptr;
 Fiber* cur = nullptr;
 const std::function<void()>* body = nullptr;
 std::vector<char> smem;
-std::vector<char> wscratch;           // per-wave 64*64 bytes
+std::vector<char> wscratch;             // per-wave 2 x 64*64 bytes (ping-pong)
 std::vector<unsigned long long> wlive;  // per-wave live-lane mask
+std::vector<int> wparity;               // per-wave scratch parity
 
 void trampoline() {
     (*body)();
     cur->st = DONE;
-    swapcontext(&cur->uc, &sched_uc);
+    hipemu_switch(&cur->sp, sched_sp);
+    abort();
 }
 void yield(State s) {
     Fiber* f = cur;
     f->st = s;
-    swapcontext(&f->uc, &sched_uc);
+    hipemu_switch(&f->sp, sched_sp);
+}
+void prepare(Fiber* f) {
+    uintptr_t top = ((uintptr_t)(f->stack + kStack)) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                // fake return address of trampoline (keeps rsp % 16 == 8 at entry)
+    *--sp = (void*)&trampoline;     // `ret` target of the first switch
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;   // rbp rbx r12 r13 r14 r15
+    f->sp = (void*)sp;
 }
 }  // namespace
 
 void* dyn_smem() { return smem.data(); }
 void block_sync() { yield(WAIT_BLOCK); }
 void wave_sync() { yield(WAIT_WAVE); }
-void* wave_scratch() { return wscratch.data() + (size_t)g.wave * 64 * 64; }
+void* wave_scratch() { return wscratch.data() + ((size_t)g.wave * 2 + 0) * 64 * 64; }
 unsigned long long wave_live_mask() { return wlive[g.wave]; }
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& fn) {
@@ -57,7 +91,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& fn
         pool.push_back(f);
     }
     smem.assign(shmem + 64, 0);
-    wscratch.assign((size_t)nwave * 64 * 64, 0);
+    wscratch.assign((size_t)nwave * 2 * 64 * 64, 0);
     wlive.assign(nwave, 0);
     body = &fn;
     for (unsigned bz = 0; bz < grid.z; ++bz)
@@ -66,11 +100,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& fn
         for (int w = 0; w < nwave; ++w) wlive[w] = 0;
         for (int t = 0; t < nthr; ++t) {
             Fiber* f = pool[t];
-            getcontext(&f->uc);
-            f->uc.uc_stack.ss_sp = f->stack;
-            f->uc.uc_stack.ss_size = kStack;
-            f->uc.uc_link = &sched_uc;
-            makecontext(&f->uc, (void (*)())trampoline, 0);
+            prepare(f);
             f->st = READY;
             f->ctx.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
             f->ctx.bid = dim3(bx, by, bz);
@@ -90,14 +120,13 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& fn
                 ran = true;
                 cur = f;
                 g = f->ctx;
-                swapcontext(&sched_uc, &f->uc);
+                hipemu_switch(&sched_sp, f->sp);
                 cur = nullptr;
                 if (f->st == DONE) {
                     --live;
                     wlive[t >> 6] &= ~(1ull << (t & 63));
                 }
             }
-            // release wave rendezvous whose live lanes have all arrived
             bool released = false;
             for (int w = 0; w < nwave; ++w) {
                 int lo = w * 64, hi = std::min(nthr, lo + 64);
@@ -112,7 +141,6 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& fn
                     released = true;
                 }
             }
-            // release the workgroup barrier
             int nblock = 0;
             for (int t = 0; t < nthr; ++t)
                 if (pool[t]->st == WAIT_BLOCK) ++nblock;

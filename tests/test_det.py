@@ -106,7 +106,8 @@ def _run_rpn_loss(dev):
             a = int(a_off[slot_level[j]] + idx[n, j])
             pb = Boxes(b2b.apply_deltas(deltas[n, a].detach()[None], anchors[a][None]))
             pb.clip(tuple(image_hw[n].tolist()))
-            assert torch.equal(boxes[n, j].cpu(), pb.tensor[0]), (n, j)
+            # expf on the GPU and exp on the CPU differ in the last ulp: fp32 tolerance, not bit-exact
+            assert (boxes[n, j].cpu() - pb.tensor[0]).abs().max() < 1e-4, (n, j)
             assert bool(valid[n, j]) == bool(pb.nonempty()[0])
 
 
