@@ -63,7 +63,7 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
  * dla.py:46-66 (BasicBlock), :162-172 (Root), :214 (project), :244,294 (conv levels).
  * x, y, residual [nullable]: NHWC fp32 with P = N*H*W pixels, C % 4 == 0, C <= 1024.
  * running_mean/var [nullable] updated with `momentum` (unbiased var) like F.batch_norm.
- * Outputs kept for backward: mean_rstd (2C), scale_shift (2C).  ws: >= 2C doubles scratch. */
+ * Outputs kept for backward: mean_rstd (2C), scale_shift (2C).  ws: >= 2C*258 doubles scratch. */
 int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                 float* running_mean, float* running_var, float* mean_rstd, float* scale_shift, double* ws,
                 int P, int C, float eps, float momentum, int relu, void* stream);
@@ -73,7 +73,7 @@ int omni_bn_apply(const float* x, const float* scale_shift, const float* residua
                   int relu, void* stream);
 
 /* backward of omni_bn_fwd.  dy = grad wrt y; dres [nullable] = grad wrt residual;
- * ws >= 2C doubles, coef 3C floats scratch. */
+ * ws >= 2C*258 doubles, coef 3C floats scratch. */
 int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd,
                 float* dx, float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C,
                 int relu, void* stream);
@@ -222,7 +222,7 @@ int omni_sgd_step(float* param, const float* grad, float* momentum_buf, long lon
 int omni_nonfinite_any(const float* grad, long long n, float* flag, void* stream);
 
 /* backward of the ReLU fused into conv / linear epilogues, and the bias gradient (per-channel sum
- * of dy over P pixels; ws 2C doubles scratch).  autograd of the nn.Conv2d / nn.Linear call sites. */
+ * of dy over P pixels; ws 2C*258 doubles scratch).  autograd of the nn.Conv2d / nn.Linear call sites. */
 int omni_relu_bwd(const float* dy, const float* y, float* dz, long long n, void* stream);
 int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, void* stream);
 

@@ -64,11 +64,22 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
     if (t < C4) {
         float4 r0 = s0[t], r1 = s1[t];
         for (int r = 1; r < rows; ++r) { r0 = r0 + s0[r * C4 + t]; r1 = r1 + s1[r * C4 + t]; }
-        double* a = acc + 4 * t;
-        atomicAdd(a + 0, (double)r0.x); atomicAdd(a + 1, (double)r0.y); atomicAdd(a + 2, (double)r0.z); atomicAdd(a + 3, (double)r0.w);
-        double* b = acc + C + 4 * t;
-        atomicAdd(b + 0, (double)r1.x); atomicAdd(b + 1, (double)r1.y); atomicAdd(b + 2, (double)r1.z); atomicAdd(b + 3, (double)r1.w);
+        // per-block partials (no atomics: deterministic, and 1024 blocks hammering 2C addresses was the
+        // bottleneck of this kernel); reduced over blocks by bn_partial_sum_kernel
+        float* a = reinterpret_cast<float*>(acc) + (long)blockIdx.x * 2 * C;
+        st4(a + 4 * t, r0);
+        st4(a + C + 4 * t, r1);
     }
+}
+
+// acc[j] (double) = sum over blocks of partial[b][j], j < 2C
+__global__ void __launch_bounds__(256) bn_partial_sum_kernel(const float* __restrict__ partial, int nblk, int C2,
+                                                            double* __restrict__ acc) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= C2) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)partial[(long)b * C2 + j];
+    acc[j] = s;
 }
 
 // forward finalize: mean, biased var -> rstd; scale/shift for the apply pass; running stats
@@ -287,7 +298,7 @@ inline int ew_grid(long total) {
 inline int red_grid(int P, int C) {
     const int rows = 256 / (C >> 2);
     long g = ((long)P + rows - 1) / rows;
-    if (g > 1024) g = 1024;
+    if (g > 512) g = 512;
     return (int)(g < 1 ? 1 : g);
 }
 
@@ -296,15 +307,18 @@ inline int red_grid(int P, int C) {
 extern "C" {
 
 // Training-mode BatchNorm forward on NHWC x (P = N*H*W pixels, C channels, C % 4 == 0, C <= 1024).
-// ws: >= 2*C doubles of scratch.  mean_rstd (2C) and scale_shift (2C) are outputs kept for backward.
+// ws: >= 2*C*258 doubles of scratch (sums + per-block partials).  mean_rstd (2C), scale_shift (2C) kept for backward.
 int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                 float* running_mean, float* running_var, float* mean_rstd, float* scale_shift, double* ws, int P, int C,
                 float eps, float momentum, int relu, void* stream) {
     if (P <= 0 || C <= 0 || (C & 3) || C > 1024) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(red_grid(P, C)), dim3(256), 0, st, x,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, P, C, 0, ws);
+    const int nblk = red_grid(P, C);
+    float* partial = reinterpret_cast<float*>(ws + 2 * C);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, x, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial));
+    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, (const float*)partial, nblk,
+                       2 * C, ws);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, P, C, eps,
                        momentum, gamma, beta, mean_rstd, scale_shift, running_mean, running_var);
     const long total4 = (long)P * (C >> 2);
@@ -329,9 +343,12 @@ int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* ga
                 float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C, int relu, void* stream) {
     if (P <= 0 || C <= 0 || (C & 3) || C > 1024) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<1>), dim3(red_grid(P, C)), dim3(256), 0, st, x, dy, y, mean_rstd,
-                       P, C, relu, ws);
+    const int nblk = red_grid(P, C);
+    float* partial = reinterpret_cast<float*>(ws + 2 * C);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<1>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean_rstd, P, C, relu,
+                       reinterpret_cast<double*>(partial));
+    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, (const float*)partial, nblk,
+                       2 * C, ws);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, P, C, gamma,
                        mean_rstd, dgamma, dbeta, coef);
     const long total4 = (long)P * (C >> 2);
@@ -418,9 +435,12 @@ int omni_relu_bwd(const float* dy, const float* y, float* dz, long long n, void*
 int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, void* stream) {
     if (P <= 0 || C <= 0 || (C & 3) || C > 1024) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(red_grid(P, C)), dim3(256), 0, st, dy,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, P, C, 0, ws);
+    const int nblk = red_grid(P, C);
+    float* partial = reinterpret_cast<float*>(ws + 2 * C);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, dy, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial));
+    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, (const float*)partial, nblk,
+                       2 * C, ws);
     hipLaunchKernelGGL(cast_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, C, db);
     return omni_launch_status();
 }

@@ -415,9 +415,15 @@ int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* ou
     if (bad_geom(p) || (ldx & 3) || ldx < C || ldo < K) return OMNI_ERR_ARG;
     const long M = (long)N * p.OH * p.OW;
     if (M == 0) return OMNI_OK;
-    if (K > 64) {
-        const int tiles = (int)((M + 127) / 128) * ((K + 127) / 128);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<128, 128, 2, 2>), dim3(tiles), dim3(256), 0,
+    // tile choice: 128x128 when that already fills the 256 CUs, otherwise 64x64 tiles (4x the workgroups)
+    // so the deep, small-M layers (DLA level4/5, the FC heads) do not leave most of the chip idle
+    const long t128 = ((M + 127) / 128) * ((K + 127) / 128);
+    if (K > 64 && t128 >= 256) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<128, 128, 2, 2>), dim3((unsigned)t128), dim3(256), 0,
+                           (hipStream_t)stream, p);
+    } else if (K > 32 && (K > 64 || ((M + 127) / 128) < 256)) {
+        const long tiles = ((M + 63) / 64) * ((K + 63) / 64);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<64, 64, 2, 2>), dim3((unsigned)tiles), dim3(256), 0,
                            (hipStream_t)stream, p);
     } else if (K > 32) {
         const int tiles = (int)((M + 127) / 128) * ((K + 63) / 64);
@@ -439,9 +445,13 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
     if (bad_geom(p) || (K & 3) || (lddy & 3) || lddy < K || lddx < C) return OMNI_ERR_ARG;
     const long M = (long)N * H * W;
     if (M == 0) return OMNI_OK;
-    if (C > 64) {
-        const int tiles = (int)((M + 127) / 128) * ((C + 127) / 128);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<128, 128, 2, 2>), dim3(tiles), dim3(256), 0,
+    const long t128 = ((M + 127) / 128) * ((C + 127) / 128);
+    if (C > 64 && t128 >= 256) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<128, 128, 2, 2>), dim3((unsigned)t128), dim3(256), 0,
+                           (hipStream_t)stream, p);
+    } else if (C > 32 && (C > 64 || ((M + 127) / 128) < 256)) {
+        const long tiles = ((M + 63) / 64) * ((C + 63) / 64);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<64, 64, 2, 2>), dim3((unsigned)tiles), dim3(256), 0,
                            (hipStream_t)stream, p);
     } else if (C > 32) {
         const int tiles = (int)((M + 127) / 128) * ((C + 63) / 64);

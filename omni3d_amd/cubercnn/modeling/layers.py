@@ -58,8 +58,13 @@ class FlattenLinear(nn.Module):
             state_dict[key] = state_dict[key].reshape(self.out_features, self.channels, self.size, self.size)
 
     def forward(self, x, relu=False):
-        y = HF.conv2d(x, self.weight, self.bias, 1, 0, relu)     # (R, out, 1, 1)
-        return y.reshape(y.shape[0], self.out_features)
+        """x: (R, C, P, P) channels_last (physically (R, P, P, C)) -> (R, out).  With KRSC weights the
+        flattened (p, p, c) order is contiguous on both operands, so this is a plain GEMM (forward,
+        dgrad and wgrad) on 2-D views -- no im2col gather."""
+        R = x.shape[0]
+        x2 = x.permute(0, 2, 3, 1).reshape(R, -1)
+        w2 = self.weight.permute(0, 2, 3, 1).reshape(self.out_features, -1)
+        return HF.linear(x2, w2, self.bias, relu)
 
 
 class BatchNorm2d(nn.BatchNorm2d):

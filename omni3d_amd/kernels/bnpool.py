@@ -19,7 +19,7 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, residual=None, relu=False,
     y = _like_cl((N, H, W, C), x)
     mean_rstd = torch.empty(2 * C, dtype=torch.float32, device=x.device)
     scale_shift = torch.empty(2 * C, dtype=torch.float32, device=x.device)
-    ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
     L.call("omni_bn_fwd", _lib.ptr(xv), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(rv), _lib.ptr(y),
            _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), _lib.ptr(ws),
            N * H * W, C, float(eps), float(momentum), int(relu), _lib.stream_of(x))
@@ -47,7 +47,7 @@ def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False):
     dres = _like_cl((N, H, W, C), x) if want_dres else None
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-    ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
     coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
     L.call("omni_bn_bwd", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(dx),
            _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, int(relu),
@@ -130,6 +130,6 @@ def bias_grad(dy2d):
     P, C = dy2d.shape
     L = _lib.check_device(dy2d)
     db = torch.empty(C, dtype=torch.float32, device=dy2d.device)
-    ws = torch.empty(2 * C, dtype=torch.float64, device=dy2d.device)
+    ws = torch.empty(2 * C * 258, dtype=torch.float64, device=dy2d.device)
     L.call("omni_bias_grad", _lib.ptr(dy2d), P, C, _lib.ptr(db), _lib.ptr(ws), _lib.stream_of(dy2d))
     return db
