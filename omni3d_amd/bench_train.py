@@ -134,6 +134,8 @@ def dominant_kernel_roofline(iters=20):
 def cpu_baseline_train(priors):
     """The CPU oracle (plain-PyTorch port of the reference path, oracle/model_oracle.py) timed on the host
     cores on a bounded sample: batch 2, forward + losses + backward + SGD."""
+    if os.environ.get("OMNI_BENCH_SKIP_CPU") == "1":   # profiling runs: do not spend GPU-box minutes on the CPU leg
+        return {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": "skipped (OMNI_BENCH_SKIP_CPU=1)"}
     try:
         from oracle import model_oracle
     except Exception as e:  # noqa: BLE001

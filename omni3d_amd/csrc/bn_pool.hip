@@ -73,13 +73,22 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
 }
 
 // acc[j] (double) = sum over blocks of partial[b][j], j < 2C
+// One workgroup per 16 columns: 16 column lanes x 16 row groups, LDS tree over the row groups.
 __global__ void __launch_bounds__(256) bn_partial_sum_kernel(const float* __restrict__ partial, int nblk, int C2,
                                                             double* __restrict__ acc) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= C2) return;
+    __shared__ double sm[256];
+    const int t = threadIdx.x, cl = t & 15, rg = t >> 4;
+    const int j = blockIdx.x * 16 + cl;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[(long)b * C2 + j];
-    acc[j] = s;
+    if (j < C2)
+        for (int b = rg; b < nblk; b += 16) s += (double)partial[(long)b * C2 + j];
+    sm[t] = s;
+    __syncthreads();
+    if (t < 16 && j < C2) {
+        double r = 0.0;
+        for (int k = 0; k < 16; ++k) r += sm[k * 16 + t];
+        acc[j] = r;
+    }
 }
 
 // forward finalize: mean, biased var -> rstd; scale/shift for the apply pass; running stats
@@ -317,7 +326,7 @@ int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const flo
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial));
-    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, (const float*)partial, nblk,
+    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk,
                        2 * C, ws);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, P, C, eps,
                        momentum, gamma, beta, mean_rstd, scale_shift, running_mean, running_var);
@@ -347,7 +356,7 @@ int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* ga
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<1>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean_rstd, P, C, relu,
                        reinterpret_cast<double*>(partial));
-    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, (const float*)partial, nblk,
+    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk,
                        2 * C, ws);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, P, C, gamma,
                        mean_rstd, dgamma, dbeta, coef);
@@ -439,7 +448,7 @@ int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, void* s
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, dy, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial));
-    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, (const float*)partial, nblk,
+    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk,
                        2 * C, ws);
     hipLaunchKernelGGL(cast_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, C, db);
     return omni_launch_status();
