@@ -226,6 +226,9 @@ int omni_nonfinite_any(const float* grad, long long n, float* flag, void* stream
 int omni_relu_bwd(const float* dy, const float* y, float* dz, long long n, void* stream);
 int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, void* stream);
 
+/* tuning knob for A/B measurements of kernel variants (tools/bench_kernels.py); 0 = production. */
+int omni_debug_set_variant(int v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,12 +62,13 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, i
 
 // ---- fragment fetch + MFMA over one BK=16 slab -------------------------------------------------
 // A_KCONTIG: As[m][BKP] else As[k][LDA] (m contiguous).  B likewise.
-template <int WM, int WN, bool A_KCONTIG, bool B_KCONTIG, int LDA, int LDB>
+template <int WM, int WN, bool A_KCONTIG, bool B_KCONTIG, int LDA, int LDB, int BKX = 16>
 __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs, int a_row0,
                                          int b_row0, int lane, f32x16 (&acc)[WM][WN]) {
     const int l31 = lane & 31, h = lane >> 5;
+    constexpr int BKP = BKX + 4;
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
+    for (int kc = 0; kc < BKX / 8; ++kc) {
         float a[WM][4], b[WN][4];
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
@@ -112,10 +113,12 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[WM][WN]) {
 // forward:  out[m, n] = sum_{r,s,c} x[pix(m; r, s), c] * w[n, r, s, c] (+ bias[n]) (ReLU)
 //   GEMM M = N*OH*OW, N = K, reduction Kd = R*S*C.  A and B k-contiguous in LDS.
 // =================================================================================================
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKX = 16>
 __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
     constexpr int WM = BM / (32 * WAVES_M), WN = BN / (32 * WAVES_N);
-    constexpr int AI = BM / 64, BI = (BN + 63) / 64;  // float4 loads per thread per slab
+    constexpr int BKP = BKX + 4, KQ = BKX / 4;        // float4 columns per slab row
+    constexpr int RPP = 256 / KQ;                      // tile rows covered per pass of the 256 threads
+    constexpr int AI = (BM + RPP - 1) / RPP, BI = (BN + RPP - 1) / RPP;
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BKP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -123,61 +126,70 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
     int tile_m, tile_n;
     tile_coords((M + BM - 1) / BM, (p.K + BN - 1) / BN, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kq = tid & 3, lrow = tid >> 2;
+    const int kq = tid % KQ, lrow = tid / KQ;
 
-    int a_img[AI], a_ih[AI], a_iw[AI];
+    long a_base[AI];                                   // element offset of (img, ih0, iw0, 0)
+    int a_ih[AI], a_iw[AI];
     bool a_ok[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m0 + lrow + 64 * i;
-        a_ok[i] = m < M;
+        const int m = m0 + lrow + RPP * i;
+        a_ok[i] = (lrow + RPP * i < BM) && m < M;
         const int mm = a_ok[i] ? m : 0;
         const int img = mm / (p.OH * p.OW), rem = mm - img * (p.OH * p.OW);
         const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        a_img[i] = img;
         a_ih[i] = oh * p.stride - p.pad;
         a_iw[i] = ow * p.stride - p.pad;
+        a_base[i] = ((long)(img * p.H + a_ih[i]) * p.W + a_iw[i]) * p.ldx;
     }
+    // reduction cursor of this thread's float4 column: kd = (r*S + s)*C + c, advanced by BKX per slab
+    int kd = kq * 4;
+    int c_cur = kd % p.C, tap0 = kd / p.C;
+    int r_cur = tap0 / p.S, s_cur = tap0 - r_cur * p.S;
     float4 ra[AI], rb[BI];
-    auto load_slab = [&](int kt) {
-        const int kd = kt * BK + kq * 4;
+    auto load_slab = [&]() {
         const bool kok = kd < Kd;
-        const int tap = kok ? kd / p.C : 0;
-        const int c = kd - tap * p.C;
-        const int r = tap / p.S, s = tap - r * p.S;
+        const long tap_off = ((long)r_cur * p.W + s_cur) * p.ldx + c_cur;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int ih = a_ih[i] + r, iw = a_iw[i] + s;
-            const bool ok = a_ok[i] && kok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            ra[i] = ok ? ldg4(p.x + ((long)(a_img[i] * p.H + ih) * p.W + iw) * p.ldx + c) : zero4();
+            const int ih = a_ih[i] + r_cur, iw = a_iw[i] + s_cur;
+            const bool ok = a_ok[i] && kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            ra[i] = ok ? ldg4(p.x + a_base[i] + tap_off) : zero4();
         }
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
-            const int n = n0 + lrow + 64 * j;
-            rb[j] = (lrow + 64 * j < BN && n < p.K && kok) ? ldg4(p.w + (long)n * Kd + kd) : zero4();
+            const int n = n0 + lrow + RPP * j;
+            rb[j] = (lrow + RPP * j < BN && n < p.K && kok) ? ldg4(p.w + (long)n * Kd + kd) : zero4();
+        }
+        kd += BKX;
+        c_cur += BKX;
+        while (c_cur >= p.C) {
+            c_cur -= p.C;
+            if (++s_cur == p.S) { s_cur = 0; ++r_cur; }
         }
     };
     auto store_slab = [&](int buf) {
         float* As = smem + buf * (BM + BN) * BKP;
         float* Bs = As + BM * BKP;
 #pragma unroll
-        for (int i = 0; i < AI; ++i) *reinterpret_cast<float4*>(As + (lrow + 64 * i) * BKP + kq * 4) = ra[i];
+        for (int i = 0; i < AI; ++i)
+            if (lrow + RPP * i < BM) *reinterpret_cast<float4*>(As + (lrow + RPP * i) * BKP + kq * 4) = ra[i];
 #pragma unroll
         for (int j = 0; j < BI; ++j)
-            if (lrow + 64 * j < BN) *reinterpret_cast<float4*>(Bs + (lrow + 64 * j) * BKP + kq * 4) = rb[j];
+            if (lrow + RPP * j < BN) *reinterpret_cast<float4*>(Bs + (lrow + RPP * j) * BKP + kq * 4) = rb[j];
     };
 
     f32x16 acc[WM][WN];
     zero_acc<WM, WN>(acc);
-    const int nk = (Kd + BK - 1) / BK;
-    load_slab(0);
+    const int nk = (Kd + BKX - 1) / BKX;
+    load_slab();
     store_slab(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_slab(kt + 1);
+        if (kt + 1 < nk) load_slab();
         const float* As = smem + buf * (BM + BN) * BKP;
-        mma_slab<WM, WN, true, true, 0, 0>(As, As + BM * BKP, wm * WM * 32, wn * WN * 32, lane, acc);
+        mma_slab<WM, WN, true, true, 0, 0, BKX>(As, As + BM * BKP, wm * WM * 32, wn * WN * 32, lane, acc);
         if (kt + 1 < nk) store_slab(buf ^ 1);
         __syncthreads();
     }
@@ -397,6 +409,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
         }
 }
 
+int g_variant = 0;   // tuning knob for A/B runs (omni_debug_set_variant); 0 = production choice
+
 inline bool bad_geom(const ConvP& p) {
     return p.N < 0 || p.H <= 0 || p.W <= 0 || p.C <= 0 || p.K <= 0 || p.R <= 0 || p.S <= 0 || p.stride <= 0 ||
            p.pad < 0 || (p.C & 3) || p.OH != (p.H + 2 * p.pad - p.R) / p.stride + 1 ||
@@ -406,6 +420,12 @@ inline bool bad_geom(const ConvP& p) {
 }  // namespace
 
 extern "C" {
+
+// Tuning knob used by tools/bench_kernels.py for A/B runs of kernel variants (0 = production).
+int omni_debug_set_variant(int v) {
+    g_variant = v;
+    return OMNI_OK;
+}
 
 // out[N,OH,OW,K] = conv(x[N,H,W,C], w[K,R,S,C]) + bias, optional ReLU.  Pitches in floats.
 int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
@@ -418,9 +438,13 @@ int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* ou
     // tile choice: 128x128 when that already fills the 256 CUs, otherwise 64x64 tiles (4x the workgroups)
     // so the deep, small-M layers (DLA level4/5, the FC heads) do not leave most of the chip idle
     const long t128 = ((M + 127) / 128) * ((K + 127) / 128);
-    if (K > 64 && t128 >= 256) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<128, 128, 2, 2>), dim3((unsigned)t128), dim3(256), 0,
-                           (hipStream_t)stream, p);
+    if ((K > 64 && t128 >= 256) || g_variant >= 2) {
+        if (g_variant == 1 || g_variant == 3)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<128, 128, 2, 2, 32>), dim3((unsigned)t128), dim3(256), 0,
+                               (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<128, 128, 2, 2, 16>), dim3((unsigned)t128), dim3(256), 0,
+                               (hipStream_t)stream, p);
     } else if (K > 32 && (K > 64 || ((M + 127) / 128) < 256)) {
         const long tiles = ((M + 63) / 64) * ((K + 63) / 64);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<64, 64, 2, 2>), dim3((unsigned)tiles), dim3(256), 0,
@@ -446,7 +470,7 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
     const long M = (long)N * H * W;
     if (M == 0) return OMNI_OK;
     const long t128 = ((M + 127) / 128) * ((C + 127) / 128);
-    if (C > 64 && t128 >= 256) {
+    if ((C > 64 && t128 >= 256) || g_variant >= 2) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<128, 128, 2, 2>), dim3((unsigned)t128), dim3(256), 0,
                            (hipStream_t)stream, p);
     } else if (C > 32 && (C > 64 || ((M + 127) / 128) < 256)) {

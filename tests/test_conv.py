@@ -65,6 +65,17 @@ def test_conv_emulated(emu_lib, case):
     _run_case("cpu", case)
 
 
+@pytest.mark.parametrize("variant", [2, 3])
+def test_conv_128x128_tiles_emulated(emu_lib, variant):
+    """force the 128x128 tile kernels (BK 16 / BK 32) on a small shape"""
+    from omni3d_amd import lib as L
+    L.get().call("omni_debug_set_variant", variant)
+    try:
+        _run_case("cpu", (1, 12, 12, 16, 72, 3, 1, 1))
+    finally:
+        L.get().call("omni_debug_set_variant", 0)
+
+
 def test_linear_emulated(emu_lib):
     _run_linear("cpu", 70, 36, 20)
 
@@ -84,6 +95,7 @@ GPU_CASES = CASES + [
     (2, 16, 16, 448, 128, 1, 1, 0),
     (1, 128, 128, 16, 16, 3, 1, 1),
     (2, 24, 40, 256, 16, 1, 1, 0),
+    (4, 128, 128, 32, 128, 3, 1, 1),   # 512 tiles of 128x128
 ]
 
 

@@ -44,6 +44,10 @@ def timeit(fn, iters=10):
 
 
 def main():
+    from omni3d_amd import lib as L
+    variant = int(os.environ.get("OMNI_VARIANT", "0"))
+    L.get().call("omni_debug_set_variant", variant)
+    print("variant", variant)
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     print(f"{'layer':34s} {'GFLOP':>7s} | {'fwd ms':>7s} {'TF':>6s} | {'dgrad':>7s} {'TF':>6s} | {'wgrad':>7s} {'TF':>6s}")
     for name, H, C, K, R, st in CONVS:
