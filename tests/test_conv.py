@@ -12,6 +12,7 @@ CASES = [
     (2, 9, 7, 8, 48, 3, 2, 1),      # ragged M, 128x64 path, stride 2
     (1, 6, 6, 32, 72, 1, 1, 0),     # 1x1, 128x128 path with ragged N
     (1, 10, 10, 4, 16, 7, 1, 3),    # 7x7 stem shape (C padded to 4), Kd=196 (tail slab)
+    (1, 6, 6, 64, 64, 3, 1, 1),     # few tiles + deep reduction: split-K path with atomic epilogue (+bias, +ReLU)
 ]
 
 
