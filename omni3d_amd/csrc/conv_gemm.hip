@@ -512,7 +512,9 @@ int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* ou
     } else if (K > 32) {
         OMNI_FWD(128, 64, 2, 2, ((M + 127) / 128) * ((K + 63) / 64), 1);
     } else {
-        OMNI_FWD(256, 32, 4, 1, ((M + 255) / 256) * ((K + 31) / 32), 1);
+        // tiny channel counts (stem, level0/1, RPN 16-wide heads): slab depth 16 measured faster than 32 here
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<256, 32, 4, 1, 16>), dim3((unsigned)(((M + 255) / 256) * ((K + 31) / 32))),
+                           dim3(256), 0, st, p);
     }
 #undef OMNI_FWD
     return omni_launch_status();
@@ -549,7 +551,7 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<128, 64, 2, 2, 32>), dim3((unsigned)tiles), dim3(256), 0, st, p);
     } else {
         const long tiles = ((M + 255) / 256) * ((C + 31) / 32);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<256, 32, 4, 1, 32>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<256, 32, 4, 1, 16>), dim3((unsigned)tiles), dim3(256), 0, st, p);
     }
     return omni_launch_status();
 }
