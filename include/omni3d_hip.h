@@ -53,9 +53,10 @@ int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* ou
 int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R,
                       int S, int stride, int pad, int lddy, int lddx, int accumulate, void* stream);
 
-/* grad wrt the weights: dw (K,R,S,C) overwritten.  Split-K over output pixels, fp32 atomics. */
+/* grad wrt the weights: dw (K,R,S,C) overwritten, or atomically accumulated into when accumulate != 0 (weight
+ * gradients land directly in the flat gradient bucket).  Split-K over output pixels, fp32 atomics. */
 int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R,
-                      int S, int stride, int pad, int ldx, int lddy, void* stream);
+                      int S, int stride, int pad, int ldx, int lddy, int accumulate, void* stream);
 
 /* ------------------------------------------------------- BatchNorm / pooling / FPN (NHWC) */
 
@@ -76,7 +77,7 @@ int omni_bn_apply(const float* x, const float* scale_shift, const float* residua
  * ws >= 2C*258 doubles, coef 3C floats scratch. */
 int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd,
                 float* dx, float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C,
-                int relu, void* stream);
+                int relu, int accumulate_param_grads, void* stream);
 
 /* nn.MaxPool2d(2, stride=2) (dla.py:209) forward / backward, NHWC. */
 int omni_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
@@ -224,7 +225,7 @@ int omni_nonfinite_any(const float* grad, long long n, float* flag, void* stream
 /* backward of the ReLU fused into conv / linear epilogues, and the bias gradient (per-channel sum
  * of dy over P pixels; ws 2C*258 doubles scratch).  autograd of the nn.Conv2d / nn.Linear call sites. */
 int omni_relu_bwd(const float* dy, const float* y, float* dz, long long n, void* stream);
-int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, void* stream);
+int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, int accumulate, void* stream);
 
 /* tuning knob for A/B measurements of kernel variants (tools/bench_kernels.py); 0 = production. */
 int omni_debug_set_variant(int v);

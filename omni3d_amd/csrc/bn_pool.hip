@@ -72,35 +72,40 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
     }
 }
 
-// acc[j] (double) = sum over blocks of partial[b][j], j < 2C
-// One workgroup per 16 columns: 16 column lanes x 16 row groups, LDS tree over the row groups.
-__global__ void __launch_bounds__(256) bn_partial_sum_kernel(const float* __restrict__ partial, int nblk, int C2,
-                                                            double* __restrict__ acc) {
-    __shared__ double sm[256];
+// Sum the per-block partials of 16 channels (both quantities) in fp64: 16 column lanes x 16 row groups + LDS tree.
+// Returns (for threads t < 16, channel c0 + t) s0 = sum partial[b][c], s1 = sum partial[b][C + c].
+__device__ __forceinline__ void colsum16(const float* __restrict__ partial, int nblk, int C, int c0, double& s0, double& s1) {
+    __shared__ double sm0[256], sm1[256];
     const int t = threadIdx.x, cl = t & 15, rg = t >> 4;
-    const int j = blockIdx.x * 16 + cl;
-    double s = 0.0;
-    if (j < C2)
-        for (int b = rg; b < nblk; b += 16) s += (double)partial[(long)b * C2 + j];
-    sm[t] = s;
+    const int c = c0 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int blk = rg; blk < nblk; blk += 16) {
+            a += (double)partial[(long)blk * 2 * C + c];
+            b += (double)partial[(long)blk * 2 * C + C + c];
+        }
+    sm0[t] = a;
+    sm1[t] = b;
     __syncthreads();
-    if (t < 16 && j < C2) {
-        double r = 0.0;
-        for (int k = 0; k < 16; ++k) r += sm[k * 16 + t];
-        acc[j] = r;
-    }
+    s0 = 0.0;
+    s1 = 0.0;
+    if (t < 16)
+        for (int k = 0; k < 16; ++k) { s0 += sm0[k * 16 + t]; s1 += sm1[k * 16 + t]; }
 }
 
-// forward finalize: mean, biased var -> rstd; scale/shift for the apply pass; running stats
-// (momentum m, unbiased variance) exactly like torch.nn.functional.batch_norm(training=True).
-__global__ void bn_finalize_fwd_kernel(const double* __restrict__ acc, int P, int C, float eps, float momentum,
-                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       float* __restrict__ mean_rstd, float* __restrict__ scale_shift,
-                                       float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mean = acc[c] / P;
-    double var = acc[C + c] / P - mean * mean;
+// forward finalize (one workgroup per 16 channels): mean, biased var -> rstd; scale/shift for the apply pass;
+// running stats (momentum m, unbiased variance) exactly like torch.nn.functional.batch_norm(training=True).
+__global__ void __launch_bounds__(256) bn_finalize_fwd_kernel(const float* __restrict__ partial, int nblk, int P, int C,
+                                                              float eps, float momentum, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ mean_rstd,
+                                                              float* __restrict__ scale_shift, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var) {
+    double sx, sxx;
+    colsum16(partial, nblk, C, blockIdx.x * 16, sx, sxx);
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x >= 16 || c >= C) return;
+    const double mean = sx / P;
+    double var = sxx / P - mean * mean;
     if (var < 0) var = 0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     mean_rstd[c] = (float)mean;
@@ -129,16 +134,18 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
     }
 }
 
-// backward finalize: dgamma, dbeta out; coefficients for the apply pass:
+// backward finalize: dgamma, dbeta out (or accumulated); coefficients for the apply pass:
 //   dx = g_rstd * (dz - a - xhat * b),  g_rstd = gamma*rstd, a = dbeta/P, b = dgamma/P
-__global__ void bn_finalize_bwd_kernel(const double* __restrict__ acc, int P, int C, const float* __restrict__ gamma,
-                                       const float* __restrict__ mean_rstd, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double db = acc[c], dg = acc[C + c];
-    dbeta[c] = (float)db;
-    dgamma[c] = (float)dg;
+__global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(const float* __restrict__ partial, int nblk, int P, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef, int accumulate) {
+    double db, dg;
+    colsum16(partial, nblk, C, blockIdx.x * 16, db, dg);
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x >= 16 || c >= C) return;
+    dbeta[c] = accumulate ? dbeta[c] + (float)db : (float)db;
+    dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
     coef[c] = gamma[c] * mean_rstd[C + c];
     coef[C + c] = (float)(db / P);
     coef[2 * C + c] = (float)(dg / P);
@@ -294,9 +301,12 @@ __global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__
         st4(dz + 4 * i, mask4(ld4(dy + 4 * i), ld4(y + 4 * i)));
 }
 
-__global__ void cast_sum_kernel(const double* __restrict__ acc, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) out[c] = (float)acc[c];
+__global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                              float* __restrict__ out, int accumulate) {
+    double s0, s1;
+    colsum16(partial, nblk, C, blockIdx.x * 16, s0, s1);
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x < 16 && c < C) out[c] = accumulate ? out[c] + (float)s0 : (float)s0;
 }
 
 inline int ew_grid(long total) {
@@ -326,9 +336,7 @@ int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const flo
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial));
-    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk,
-                       2 * C, ws);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, P, C, eps,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk, P, C, eps,
                        momentum, gamma, beta, mean_rstd, scale_shift, running_mean, running_var);
     const long total4 = (long)P * (C >> 2);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, (const float*)scale_shift, residual, y,
@@ -349,17 +357,16 @@ int omni_bn_apply(const float* x, const float* scale_shift, const float* residua
 // Backward.  dy is the gradient wrt the (post-ReLU) output y; dres [nullable] receives the
 // gradient of the residual input.  ws: >= 2*C doubles, coef: 3*C floats of scratch.
 int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
-                float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C, int relu, void* stream) {
+                float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C, int relu,
+                int accumulate_param_grads, void* stream) {
     if (P <= 0 || C <= 0 || (C & 3) || C > 1024) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = red_grid(P, C);
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<1>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean_rstd, P, C, relu,
                        reinterpret_cast<double*>(partial));
-    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk,
-                       2 * C, ws);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, P, C, gamma,
-                       mean_rstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk, P, C, gamma,
+                       mean_rstd, dgamma, dbeta, coef, accumulate_param_grads);
     const long total4 = (long)P * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, dy, y, mean_rstd,
                        (const float*)coef, dx, dres, total4, C, relu);
@@ -441,16 +448,15 @@ int omni_relu_bwd(const float* dy, const float* y, float* dz, long long n, void*
 }
 
 // db[c] = sum over the P pixels of dy[p, c] (bias gradient of a conv / linear).  ws: 2*C doubles.
-int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, void* stream) {
+int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, int accumulate, void* stream) {
     if (P <= 0 || C <= 0 || (C & 3) || C > 1024) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = red_grid(P, C);
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, dy, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial));
-    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk,
-                       2 * C, ws);
-    hipLaunchKernelGGL(cast_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)ws, C, db);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk, C, db,
+                       accumulate);
     return omni_launch_status();
 }
 

@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
         __syncthreads();
     }
     const int l31 = lane & 31, h = lane >> 5;
-    const bool single = gridDim.y == 1;
+    const bool single = gridDim.y == 1 && !p.accumulate;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -556,16 +556,18 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
     return omni_launch_status();
 }
 
-// dw[K,R,S,C] = sum over output pixels of dy (x) x.  dw is overwritten (zeroed here when split).
+// dw[K,R,S,C] = sum over output pixels of dy (x) x.  accumulate == 0: dw is overwritten (zeroed here when the
+// reduction is split); accumulate != 0: the result is atomically ADDED to dw -- this is how weight gradients land
+// directly in the flat gradient bucket without an extra add kernel per parameter.
 int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
-                      int stride, int pad, int ldx, int lddy, void* stream) {
+                      int stride, int pad, int ldx, int lddy, int accumulate, void* stream) {
     ConvP p{x, dy, nullptr, dw, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
-            R, S, stride, pad, ldx, 0, lddy, 0, 0, 1};
+            R, S, stride, pad, ldx, 0, lddy, 0, accumulate, 1};
     if (bad_geom(p) || (K & 3) || (ldx & 3) || (lddy & 3) || ldx < C || lddy < K) return OMNI_ERR_ARG;
     const long P = (long)N * p.OH * p.OW;
     const int Nn = R * S * C;
     if (P == 0) {
-        hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
+        if (!accumulate) hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
         return OMNI_OK;
     }
     constexpr int WBK = 32;
@@ -580,7 +582,7 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
     int pps = (int)((P + splits - 1) / splits);
     pps = (pps + WBK - 1) / WBK * WBK;
     splits = (P + pps - 1) / pps;
-    if (splits > 1) hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
+    if (splits > 1 && !accumulate) hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
     if (wide)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<128, 64, 2, 2, WBK>), dim3(tiles, (unsigned)splits), dim3(256),
                            0, (hipStream_t)stream, p, pps);

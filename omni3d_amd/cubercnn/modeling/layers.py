@@ -64,7 +64,11 @@ class FlattenLinear(nn.Module):
         R = x.shape[0]
         x2 = x.permute(0, 2, 3, 1).reshape(R, -1)
         w2 = self.weight.permute(0, 2, 3, 1).reshape(self.out_features, -1)
-        return HF.linear(x2, w2, self.bias, relu)
+        gview = None
+        if getattr(self.weight, "_omni_direct_grad", False) and self.weight.grad is not None:
+            gview = self.weight.grad.permute(0, 2, 3, 1).reshape(self.out_features, -1)
+            w2 = w2.detach().requires_grad_(True) if False else w2
+        return HF.linear(x2, w2, self.bias, relu, gview)
 
 
 class BatchNorm2d(nn.BatchNorm2d):

@@ -149,28 +149,25 @@ class RPNWithIgnore(nn.Module):
         pack = det.LevelPack(lv)
         B = pack.B
         logits = det.rpn_gather_logits(pack)                                    # (B, A)
-        vals, idxs, slot_level, ks = [], [], [], []
+        # every level gets `kmax` slots (top-k pads with -inf / -1 when a level has fewer anchors), so the
+        # (B, L*kmax) block is L*B equally sized, score-sorted NMS problems: ONE decode, ONE NMS launch
+        L = len(hw_list)
+        kmax = min(pre, max(H * W * 3 for H, W in hw_list))
+        vals, idxs = [], []
         off = 0
         for l, (H, W) in enumerate(hw_list):
             n = H * W * 3
-            k = min(n, pre)
-            v, i = select.topk_rows(logits[:, off:off + n], k)
-            vals.append(v); idxs.append(i); ks.append(k)
-            slot_level += [l] * k
+            v, i = select.topk_rows(logits[:, off:off + n], kmax)
+            vals.append(v); idxs.append(i)
             off += n
         scores = torch.cat(vals, 1)
         idx = torch.cat(idxs, 1).contiguous()
-        key = (tuple(ks), str(idx.device))
+        key = (L, kmax, str(idx.device))
         if getattr(self, "_slot_key", None) != key:
-            self._slot_level = torch.tensor(slot_level, dtype=torch.int32, device=idx.device)
+            self._slot_level = torch.arange(L, dtype=torch.int32, device=idx.device).repeat_interleave(kmax).contiguous()
             self._slot_key = key
         boxes, valid = det.rpn_decode(pack, self._slot_level, idx, anchors, image_hw, self.min_box_size)
-        keep = torch.empty_like(valid)
-        o = 0
-        for k in ks:                                                             # per-level NMS (batched_nms by level)
-            kp = select.nms_sorted(boxes[:, o:o + k].contiguous(), self.nms_thresh, None, valid[:, o:o + k].contiguous())
-            keep[:, o:o + k] = kp
-            o += k
+        keep = select.nms_sorted(boxes.view(B * L, kmax, 4), self.nms_thresh, None, valid.view(B * L, kmax)).view(B, L * kmax)
         masked = torch.where(keep != 0, scores, torch.full_like(scores, float("-inf")))
         top_v, top_i = select.topk_rows(masked, post)                             # keep[:post_nms_topk], score order
         ok = top_v > float("-inf")

@@ -43,10 +43,13 @@ def _param_groups(cfg, model):
 class FlatSGD(torch.optim.Optimizer):
     """torch.optim.SGD semantics over flat buckets (see module docstring)."""
 
-    def __init__(self, params, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
+    def __init__(self, params, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, direct_accumulate=True):
         defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov)
         super().__init__(params, defaults)
         self._build_buckets()
+        # backward kernels add weight / bias / BN gradients straight into the bucket views (functional._direct_grad).
+        # Must be off under torch DistributedDataParallel, whose reducer needs autograd's accumulation hooks.
+        self.set_direct_accumulate(direct_accumulate)
         self._steps = 0
         self.skip_flag = None   # optional device float: != 0 skips the update inside the kernel
 
@@ -78,6 +81,11 @@ class FlatSGD(torch.optim.Optimizer):
                 p.grad = gv
                 off += ((n + 3) // 4) * 4
             self.segments.append((start, off, items[0][0]))
+
+    def set_direct_accumulate(self, flag):
+        for g in self.param_groups:
+            for p in g["params"]:
+                p._omni_direct_grad = bool(flag)
 
     @staticmethod
     def _view_like(flat, p):
@@ -120,8 +128,9 @@ class FlatSGD(torch.optim.Optimizer):
 def build_optimizer(cfg, model):
     params = _param_groups(cfg, model)
     if cfg.SOLVER.TYPE == "sgd":
+        under_ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)   # tools/train_net.py:449-454 wraps first
         return FlatSGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV,
-                       weight_decay=cfg.SOLVER.WEIGHT_DECAY)
+                       weight_decay=cfg.SOLVER.WEIGHT_DECAY, direct_accumulate=not under_ddp)
     if cfg.SOLVER.TYPE in ("adam", "adam+amsgrad", "adamw", "adamw+amsgrad"):
         raise NotImplementedError("MI355X hot path: SOLVER.TYPE 'sgd' (configs/Base.yaml:2); Adam variants are not fused yet")
     raise ValueError("{} is not supported as an optimizer.".format(cfg.SOLVER.TYPE))

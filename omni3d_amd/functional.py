@@ -17,9 +17,19 @@ def _cl(t):
     return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
 
 
+def _direct_grad(t):
+    """The parameter's view of the flat gradient bucket when the optimizer asked for direct accumulation
+    (FlatSGD): backward kernels then ADD into it and return no gradient, which saves one elementwise add kernel
+    per parameter per step (~220 launches).  None otherwise (plain autograd accumulation)."""
+    if t is not None and getattr(t, "_omni_direct_grad", False) and t.grad is not None and t.requires_grad:
+        return t.grad
+    return None
+
+
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, relu):
+        ctx.direct = (_direct_grad(w), _direct_grad(bias))
         x, w = _cl(x), _cl(w)
         y = conv.conv2d_fwd(x, w, bias, stride, pad, relu)
         ctx.save_for_backward(x, w, y if relu else None)
@@ -33,11 +43,14 @@ class _Conv2d(Function):
         dy = _cl(dy)
         if relu:   # elementwise on the NHWC views (same dense layout for dy and y)
             dy = bnpool.relu_bwd(dy.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+        gw, gb = ctx.direct
+        if gw is not None and not gw.is_contiguous(memory_format=CL):
+            gw = None
         dx = conv.conv2d_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad) if ctx.needs_input_grad[0] else None
-        dw = conv.conv2d_wgrad(x, dy, (w.shape[2], w.shape[3]), stride, pad) if ctx.needs_input_grad[1] else None
+        dw = conv.conv2d_wgrad(x, dy, (w.shape[2], w.shape[3]), stride, pad, accum_into=gw) if ctx.needs_input_grad[1] else None
         db = None
         if has_bias and ctx.needs_input_grad[2]:
-            db = bnpool.bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]))
+            db = bnpool.bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]), accum_into=gb)
         return dx, dw, db, None, None, None
 
 
@@ -47,7 +60,9 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False):
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, relu):
+    def forward(ctx, x, w, bias, relu, w_grad_view=None):
+        gw = _direct_grad(w) if w_grad_view is None else w_grad_view
+        ctx.direct = (gw if (gw is not None and gw.is_contiguous()) else None, _direct_grad(bias))
         x, w = x.contiguous(), w.contiguous()
         y = conv.linear_fwd(x, w, bias, relu)
         ctx.save_for_backward(x, w, y if relu else None)
@@ -61,19 +76,24 @@ class _Linear(Function):
         dy = dy.contiguous()
         if relu:
             dy = bnpool.relu_bwd(dy, y)
+        gw, gb = ctx.direct
         dx = conv.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = conv.linear_wgrad(x, dy) if ctx.needs_input_grad[1] else None
-        db = bnpool.bias_grad(dy) if (has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None
+        dw = conv.linear_wgrad(x, dy, accum_into=gw) if ctx.needs_input_grad[1] else None
+        db = bnpool.bias_grad(dy, accum_into=gb) if (has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None
 
 
-def linear(x, w, bias=None, relu=False):
-    return _Linear.apply(x, w, bias, relu)
+def linear(x, w, bias=None, relu=False, w_grad_view=None):
+    """w_grad_view: 2-D contiguous view of the gradient bucket for `w` when `w` itself is a view of a
+    parameter (FlattenLinear); enables direct accumulation."""
+    return _Linear.apply(x, w, bias, relu, w_grad_view)
 
 
 class _BatchNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, eps, momentum):
+        gg, gb = _direct_grad(gamma), _direct_grad(beta)
+        ctx.direct = (gg, gb) if (gg is not None and gb is not None) else None
         x = _cl(x)
         res = _cl(residual) if residual is not None else None
         y, mean_rstd, _ = bnpool.bn_fwd(x, gamma, beta, running_mean, running_var, res, relu, eps, momentum)
@@ -85,7 +105,8 @@ class _BatchNorm(Function):
     def backward(ctx, dy):
         x, gamma, mean_rstd, y = ctx.saved_tensors
         relu, has_res = ctx.cfg
-        dx, dres, dgamma, dbeta = bnpool.bn_bwd(x, _cl(dy), y, gamma, mean_rstd, relu, want_dres=has_res and ctx.needs_input_grad[5])
+        dx, dres, dgamma, dbeta = bnpool.bn_bwd(x, _cl(dy), y, gamma, mean_rstd, relu, want_dres=has_res and ctx.needs_input_grad[5],
+                                                accum_into=ctx.direct)
         return dx, dgamma, dbeta, None, None, dres, None, None, None
 
 

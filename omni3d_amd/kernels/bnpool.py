@@ -37,21 +37,28 @@ def bn_apply(x, scale_shift, residual=None, relu=False):
     return y.permute(0, 3, 1, 2)
 
 
-def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False):
-    """-> (dx CL, dres CL or None, dgamma, dbeta)."""
+def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=None):
+    """-> (dx CL, dres CL or None, dgamma, dbeta).  accum_into = (dgamma_buf, dbeta_buf): the parameter
+    gradients are added to those buffers instead (dgamma/dbeta returned as None)."""
     xv, dyv = _nhwc(x), _nhwc(dy)
     yv = _nhwc(y) if relu else None
     N, H, W, C = xv.shape
     L = _lib.check_device(xv, dyv, yv, gamma, mean_rstd)
     dx = _like_cl((N, H, W, C), x)
     dres = _like_cl((N, H, W, C), x) if want_dres else None
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    if accum_into is not None:
+        dgamma, dbeta = accum_into
+        assert dgamma.is_contiguous() and dbeta.is_contiguous()
+    else:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
     coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
     L.call("omni_bn_bwd", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(dx),
            _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, int(relu),
-           _lib.stream_of(x))
+           int(accum_into is not None), _lib.stream_of(x))
+    if accum_into is not None:
+        dgamma = dbeta = None
     return dx.permute(0, 3, 1, 2), (dres.permute(0, 3, 1, 2) if want_dres else None), dgamma, dbeta
 
 
@@ -125,11 +132,11 @@ def relu_bwd(dy, y):
     return dz
 
 
-def bias_grad(dy2d):
-    """dy (P, C) contiguous -> (C,) column sums."""
+def bias_grad(dy2d, accum_into=None):
+    """dy (P, C) contiguous -> (C,) column sums (or added to accum_into, returning None)."""
     P, C = dy2d.shape
     L = _lib.check_device(dy2d)
-    db = torch.empty(C, dtype=torch.float32, device=dy2d.device)
+    db = accum_into if accum_into is not None else torch.empty(C, dtype=torch.float32, device=dy2d.device)
     ws = torch.empty(2 * C * 258, dtype=torch.float64, device=dy2d.device)
-    L.call("omni_bias_grad", _lib.ptr(dy2d), P, C, _lib.ptr(db), _lib.ptr(ws), _lib.stream_of(dy2d))
-    return db
+    L.call("omni_bias_grad", _lib.ptr(dy2d), P, C, _lib.ptr(db), _lib.ptr(ws), int(accum_into is not None), _lib.stream_of(dy2d))
+    return None if accum_into is not None else db

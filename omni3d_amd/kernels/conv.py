@@ -52,15 +52,22 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0):
     return dx.permute(0, 3, 1, 2)
 
 
-def conv2d_wgrad(x, dy, ksize, stride=1, pad=0):
-    """x (N,C,H,W) CL, dy (N,K,OH,OW) CL -> dw (K,C,R,S) CL."""
+def conv2d_wgrad(x, dy, ksize, stride=1, pad=0, accum_into=None):
+    """x (N,C,H,W) CL, dy (N,K,OH,OW) CL -> dw (K,C,R,S) CL.  accum_into: a (K,C,R,S) CL tensor (e.g. the
+    parameter's view of the flat gradient bucket) that the result is atomically added to (returns None)."""
     xv, dyv = _nhwc(x), _nhwc(dy)
     N, H, W, C = xv.shape
     K = dyv.shape[3]
     R, S = ksize
     L = _lib.check_device(xv, dyv)
+    if accum_into is not None:
+        tgt = accum_into.permute(0, 2, 3, 1)
+        assert tgt.is_contiguous() and tgt.shape == (K, R, S, C)
+        L.call("omni_conv2d_wgrad", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(tgt), N, H, W, C, K, R, S, stride, pad, C, K, 1,
+               _lib.stream_of(x))
+        return None
     dw = torch.empty((K, R, S, C), dtype=torch.float32, device=x.device)
-    L.call("omni_conv2d_wgrad", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, K, R, S, stride, pad, C, K,
+    L.call("omni_conv2d_wgrad", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, K, R, S, stride, pad, C, K, 0,
            _lib.stream_of(x))
     return dw.permute(0, 3, 1, 2)
 
@@ -86,11 +93,16 @@ def linear_dgrad(dy, w):
     return dx
 
 
-def linear_wgrad(x, dy):
+def linear_wgrad(x, dy, accum_into=None):
     M, C = x.shape
     K = dy.shape[1]
     L = _lib.check_device(x, dy)
+    if accum_into is not None:
+        assert accum_into.is_contiguous() and accum_into.shape == (K, C)
+        L.call("omni_conv2d_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(accum_into), M, 1, 1, C, K, 1, 1, 1, 0, C, K, 1,
+               _lib.stream_of(x))
+        return None
     dw = torch.empty((K, C), dtype=torch.float32, device=x.device)
-    L.call("omni_conv2d_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), M, 1, 1, C, K, 1, 1, 1, 0, C, K,
+    L.call("omni_conv2d_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), M, 1, 1, C, K, 1, 1, 1, 0, C, K, 0,
            _lib.stream_of(x))
     return dw
