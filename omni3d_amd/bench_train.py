@@ -60,9 +60,7 @@ def run_train(args, world, rank):
         losses = model(batch, packed)
         total = sum(losses.values())
         total.backward()
-        if world > 1:
-            dist.all_reduce(opt.flat_grad)
-            opt.flat_grad.mul_(1.0 / world)
+        opt.all_reduce_grads()
         opt.check_nonfinite(flag)
         opt.step()
         loss_log.append(total.detach())

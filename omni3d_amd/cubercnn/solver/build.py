@@ -98,6 +98,15 @@ class FlatSGD(torch.optim.Optimizer):
         self.flat_grad.zero_()    # param.grad stay views of the bucket
 
     @torch.no_grad()
+    def all_reduce_grads(self, group=None):
+        """Data-parallel exchange step: ONE all-reduce (RCCL over xGMI on MI355X; gloo in the CPU tests) of the whole
+        flat gradient bucket, then the average -- replaces DDP's per-bucket reducer for the native path."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat_grad, group=group)
+            self.flat_grad.mul_(1.0 / dist.get_world_size(group))
+
+    @torch.no_grad()
     def check_nonfinite(self, flag):
         """flag (1,) device float: set to 1 if any gradient element is NaN/Inf (tools/train_net.py:222-233)."""
         det.nonfinite_any(self.flat_grad, flag)

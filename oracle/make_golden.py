@@ -135,5 +135,48 @@ def main(spec=SMALL):
     return out
 
 
+INFER = dict(
+    name="dla34_small_infer", seed=2, images=2, height=128, width=128, num_gt=5,
+    overrides=["MODEL.ROI_HEADS.SCORE_THRESH_TEST", 0.05, "MODEL.RPN.PRE_NMS_TOPK_TEST", 300, "MODEL.RPN.POST_NMS_TOPK_TEST", 100],
+)
+
+
+def sharpen(model):
+    """Random-init class logits are ~uniform (every (roi, class) pair would pass the score threshold); scale the
+    classifier so the eval fixture has a realistic, small set of detections.  Applied to both sides."""
+    with torch.no_grad():
+        model.roi_heads.box_predictor.cls_score.weight.mul_(40.0)
+    return model
+
+
+def main_infer(spec=INFER):
+    """eval-mode fixture: RCNN3D.inference (rcnn3d.py:79-112) of the reference on CPU."""
+    priors = synthetic.make_priors(50)
+    ref = H.build_reference_model(H.reference_cfg("cubercnn_DLA34_FPN.yaml", spec["overrides"]), priors)
+    prod = sharpen(build_product_model(product_cfg(spec["overrides"]), priors, spec["seed"]))
+    ref.load_state_dict(prod.state_dict(), strict=True)
+    batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
+    for b in batch:
+        b.pop("instances")
+        b["height"], b["width"] = 2 * spec["height"], 2 * spec["width"]      # exercise _postprocess rescaling + im_scales_ratio
+        b["K"] = [[2 * v for v in row] for row in b["K"][:2]] + [b["K"][2]]
+    ref.eval()
+    with torch.no_grad():
+        out = ref(batch)
+    res = []
+    for o in out:
+        i = o["instances"]
+        res.append({"pred_boxes": i.pred_boxes.tensor.clone(), "scores": i.scores.clone(), "pred_classes": i.pred_classes.clone(),
+                    "pred_bbox3D": i.pred_bbox3D.clone(), "pred_center_cam": i.pred_center_cam.clone(),
+                    "pred_center_2D": i.pred_center_2D.clone(), "pred_dimensions": i.pred_dimensions.clone(),
+                    "pred_pose": i.pred_pose.clone(), "scores_full": i.scores_full.clone()})
+    path = os.path.join(ROOT, "tests", "golden", spec["name"] + ".pt")
+    torch.save({"spec": spec, "results": res, "torch_version": torch.__version__}, path)
+    print("wrote", path, os.path.getsize(path), "bytes;", [len(r["scores"]) for r in res], "detections")
+
+
 if __name__ == "__main__":
-    main(TINY if "--tiny" in sys.argv else SMALL)
+    if "--infer" in sys.argv:
+        main_infer()
+    else:
+        main(TINY if "--tiny" in sys.argv else SMALL)

@@ -1,0 +1,51 @@
+"""Eval-mode parity (RCNN3D.inference, /root/reference/cubercnn/modeling/meta_arch/rcnn3d.py:79-112;
+fast_rcnn_inference_single_image fast_rcnn.py:57-116; cube eval branch roi_heads.py:353-357,771-824) against
+the fixture produced by the reference's own files (oracle/make_golden.py --infer)."""
+import os
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+GOLD = os.path.join(ROOT, "tests", "golden", "dla34_small_infer.pt")
+
+
+def _run(dev):
+    from oracle import make_golden as MG
+    from omni3d_amd import synthetic
+    gold = torch.load(GOLD, weights_only=False)
+    spec = gold["spec"]
+    priors = synthetic.make_priors(50)
+    model = MG.sharpen(MG.build_product_model(MG.product_cfg(spec["overrides"]), priors, spec["seed"])).to(dev)
+    batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
+    for b in batch:
+        b.pop("instances")
+        b["height"], b["width"] = 2 * spec["height"], 2 * spec["width"]
+        b["K"] = [[2 * v for v in row] for row in b["K"][:2]] + [b["K"][2]]
+    model.eval()
+    with torch.no_grad():
+        out = model(batch)
+    assert len(out) == len(gold["results"])
+    for o, ref in zip(out, gold["results"]):
+        i = o["instances"]
+        n = len(ref["scores"])
+        assert len(i) == n, (len(i), n)
+        assert torch.equal(i.pred_classes.cpu().long(), ref["pred_classes"])            # selection is index-exact
+        assert (i.scores.cpu() - ref["scores"]).abs().max() < 1e-4
+        assert (i.pred_boxes.tensor.cpu() - ref["pred_boxes"]).abs().max() < 2e-3        # pixels, boxes up to 256 px
+        assert (i.pred_dimensions.cpu() - ref["pred_dimensions"]).abs().max() < 1e-4
+        assert (i.pred_center_cam.cpu() - ref["pred_center_cam"]).abs().max() < 1e-3
+        assert (i.pred_center_2D.cpu() - ref["pred_center_2D"]).abs().max() < 2e-3
+        assert (i.pred_pose.cpu() - ref["pred_pose"]).abs().max() < 1e-4
+        assert (i.pred_bbox3D.cpu() - ref["pred_bbox3D"]).abs().max() < 1e-3
+
+
+@pytest.mark.skipif(os.environ.get("OMNI_SLOW") != "1", reason="minutes under the host emulator; set OMNI_SLOW=1 (the GPU variant is the gate)")
+def test_inference_matches_reference_emulated(emu_lib):
+    _run("cpu")
+
+
+@pytest.mark.gpu
+def test_inference_matches_reference_gpu(hip_lib):
+    _run("cuda")
