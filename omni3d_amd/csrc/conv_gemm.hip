@@ -146,9 +146,26 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
     const int sps = (nk_total + (int)gridDim.y - 1) / (int)gridDim.y;       // slabs per split
     const int kt_begin = (int)blockIdx.y * sps;
     const int nk = min(sps, nk_total - kt_begin);
-    int kd = kt_begin * BKX + kq * 4;
-    int c_cur = kd % p.C, tap0 = kd / p.C;
-    int r_cur = tap0 / p.S, s_cur = tap0 - r_cur * p.S;
+    // Slab order.  Default (r, s, c): kd runs through the KRSC weight row.  When C is a multiple of the slab depth
+    // the order is (c-chunk, r, s) instead: the R*S taps of one channel chunk are consecutive slabs, so the
+    // shifted re-reads of the same input pixels hit L1/L2 while they are hot (measured: FETCH_SIZE of the
+    // 3x3 256->256 @128x128 conv drops, see profiles/README.md).  Any order gives the same sum up to rounding.
+    const bool tap_inner = (p.C % BKX) == 0 && p.R * p.S > 1;
+    const int RS = p.R * p.S;
+    int kd, c_cur, r_cur, s_cur;
+    if (tap_inner) {
+        const int chunk = kt_begin / RS, tap0 = kt_begin - chunk * RS;
+        c_cur = chunk * BKX + kq * 4;
+        r_cur = tap0 / p.S;
+        s_cur = tap0 - r_cur * p.S;
+        kd = tap0 * p.C + c_cur;
+    } else {
+        kd = kt_begin * BKX + kq * 4;
+        const int tap0 = kd / p.C;
+        c_cur = kd - tap0 * p.C;
+        r_cur = tap0 / p.S;
+        s_cur = tap0 - r_cur * p.S;
+    }
     float4 ra[AI], rb[BI];
     auto load_slab = [&]() {
         const bool kok = kd < Kd;
@@ -164,11 +181,19 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
             const int n = n0 + lrow + RPP * j;
             rb[j] = (lrow + RPP * j < BN && n < p.K && kok) ? ldg4(p.w + (long)n * Kd + kd) : zero4();
         }
-        kd += BKX;
-        c_cur += BKX;
-        while (c_cur >= p.C) {
-            c_cur -= p.C;
-            if (++s_cur == p.S) { s_cur = 0; ++r_cur; }
+        if (tap_inner) {
+            kd += p.C;
+            if (++s_cur == p.S) {
+                s_cur = 0;
+                if (++r_cur == p.R) { r_cur = 0; c_cur += BKX; kd = c_cur; }
+            }
+        } else {
+            kd += BKX;
+            c_cur += BKX;
+            while (c_cur >= p.C) {
+                c_cur -= p.C;
+                if (++s_cur == p.S) { s_cur = 0; ++r_cur; }
+            }
         }
     };
     auto store_slab = [&](int buf) {

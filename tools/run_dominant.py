@@ -1,0 +1,20 @@
+#!/usr/bin/env python
+"""Runs only the dominant kernel of the training step (3x3 256->256 conv on the 128x128 map, batch 4) so that
+rocprofv3 --pmc passes can attribute HBM traffic counters to it (see profiles/README.md)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from omni3d_amd.kernels import conv
+
+x = torch.randn(4, 256, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+w = (torch.randn(256, 256, 3, 3, device="cuda") * 0.02).contiguous(memory_format=torch.channels_last)
+dy = torch.randn(4, 256, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+for _ in range(5):
+    conv.conv2d_fwd(x, w, None, 1, 1)
+    conv.conv2d_dgrad(dy, w, (128, 128), 1, 1)
+    conv.conv2d_wgrad(x, dy, (3, 3), 1, 1)
+torch.cuda.synchronize()
+print("done")
