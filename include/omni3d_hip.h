@@ -230,6 +230,11 @@ int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, int acc
 /* tuning knob for A/B measurements of kernel variants (tools/bench_kernels.py); 0 = production. */
 int omni_debug_set_variant(int v);
 
+/* nn.MaxPool2d(3, stride=2, padding=1) of the torchvision ResNet stem (cubercnn/modeling/backbone/resnet.py:34,52),
+ * NHWC forward / backward (gather form, deterministic). */
+int omni_maxpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int omni_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

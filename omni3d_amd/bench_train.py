@@ -14,6 +14,11 @@ TRAIN_GFLOP_PER_IMAGE = 307.8      # fwd 103.0 GFLOP, fwd+dgrad+
 IMS_PER_GPU = 4
 
 
+# BASELINE.json configs[1] by default; OMNI_BENCH_CONFIG=cubercnn_ResNet34_FPN.yaml selects configs[3]'s model
+CONFIG = os.environ.get("OMNI_BENCH_CONFIG", "cubercnn_DLA34_FPN.yaml")
+MODEL_NAME = CONFIG.replace("cubercnn_", "").replace(".yaml", "")
+
+
 def build(world, device="cuda", seed=0):
     from omni3d_amd import synthetic
     from omni3d_amd.cubercnn.config import get_cfg_defaults
@@ -23,7 +28,7 @@ def build(world, device="cuda", seed=0):
     from omni3d_amd.d2.config import get_cfg
     cfg = get_cfg()
     get_cfg_defaults(cfg)
-    cfg.merge_from_file(os.path.join(ROOT, "configs", "cubercnn_DLA34_FPN.yaml"))
+    cfg.merge_from_file(os.path.join(ROOT, "configs", CONFIG))
     ims = IMS_PER_GPU * world
     # README.md:123-132 scaling rule of the reference: lr scales with the batch (0.12 at 192 images)
     cfg.merge_from_list(["MODEL.DEVICE", device, "VIS_PERIOD", 0, "MODEL.WEIGHTS", "synthetic://random-init",
@@ -87,10 +92,10 @@ def run_train(args, world, rank):
     ims = IMS_PER_GPU * world * args.steps / dt
     step_tf = TRAIN_GFLOP_PER_IMAGE * 1e9 * IMS_PER_GPU * args.steps / dt / 1e12   # per GPU
     res = {
-        "metric": "images/sec train DLA34_FPN b=4/GPU", "value": ims, "unit": "images/s", "n_gpus": world,
+        "metric": f"images/sec train {MODEL_NAME} b=4/GPU", "value": ims, "unit": "images/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cubercnn_DLA34_FPN train step, batch 4/GPU, synthetic Omni3D 512x512 (8 GT/img), "
+        "config": {"workload": f"cubercnn_{MODEL_NAME} train step, batch 4/GPU, synthetic Omni3D 512x512 (8 GT/img), "
                                "fwd+10 losses+bwd+allreduce+SGD, random-init weights",
                    "global_batch": IMS_PER_GPU * world, "image": "512x512", "parallelism": f"dp{world} (flat-bucket RCCL all-reduce)"},
         "step_mfma_frac": step_tf / FP32_MFMA_PEAK_TF,

@@ -290,17 +290,34 @@ __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
     const int sps = (nk_total + (int)gridDim.y - 1) / (int)gridDim.y;
     const int kt_begin = (int)blockIdx.y * sps;
     const int nk = min(sps, nk_total - kt_begin);
-    // A cursor (this thread's float4 column): kd = (r*S + s)*K + k
-    int kd = kt_begin * BKX + kq * 4;
-    int k_cur = kd % p.K, tap0 = kd / p.K;
-    int r_cur = tap0 / p.S, s_cur = tap0 - r_cur * p.S;
-    // B cursors (this thread's BI weight rows): kdb = tap*K + k  ->  w[k][tap][c]
+    // Slab order: (k-chunk, r, s) when K is a multiple of the slab depth (same L2-reuse argument as the forward
+    // kernel: the R*S taps of one chunk of dy channels are consecutive slabs), else (r, s, k).
+    const bool tap_inner = (p.K % BKX) == 0 && p.R * p.S > 1;
+    const int RS = p.R * p.S;
+    // A cursor (this thread's float4 column)
+    int kd, k_cur, r_cur, s_cur;
+    // B cursors (this thread's BI weight rows): w[k][tap][c]
     int kdb[BI], kb[BI], tapb[BI];
+    if (tap_inner) {
+        const int chunk = kt_begin / RS, tap0 = kt_begin - chunk * RS;
+        k_cur = chunk * BKX + kq * 4;
+        r_cur = tap0 / p.S;
+        s_cur = tap0 - r_cur * p.S;
+        kd = 0;   // always in range in this mode (nk bounds the loop)
 #pragma unroll
-    for (int j = 0; j < BI; ++j) {
-        kdb[j] = kt_begin * BKX + brow + BROWS * j;
-        tapb[j] = kdb[j] / p.K;
-        kb[j] = kdb[j] - tapb[j] * p.K;
+        for (int j = 0; j < BI; ++j) { kb[j] = chunk * BKX + brow + BROWS * j; tapb[j] = tap0; kdb[j] = 0; }
+    } else {
+        kd = kt_begin * BKX + kq * 4;
+        const int tap0 = kd / p.K;
+        k_cur = kd - tap0 * p.K;
+        r_cur = tap0 / p.S;
+        s_cur = tap0 - r_cur * p.S;
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            kdb[j] = kt_begin * BKX + brow + BROWS * j;
+            tapb[j] = kdb[j] / p.K;
+            kb[j] = kdb[j] - tapb[j] * p.K;
+        }
     }
     const int cb = n0 + bn4 * 4;
     float4 ra[AI], rb[BI];
@@ -323,15 +340,26 @@ __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
         for (int j = 0; j < BI; ++j) {
             const bool ok = (brow + BROWS * j < BKX) && kdb[j] < Kd && cb < p.C;
             rb[j] = ok ? ldg4(p.w + (long)kb[j] * RSC + (long)tapb[j] * p.C + cb) : zero4();
-            kdb[j] += BKX;
-            kb[j] += BKX;
-            while (kb[j] >= p.K) { kb[j] -= p.K; ++tapb[j]; }
+            if (tap_inner) {
+                if (++tapb[j] == RS) { tapb[j] = 0; kb[j] += BKX; }
+            } else {
+                kdb[j] += BKX;
+                kb[j] += BKX;
+                while (kb[j] >= p.K) { kb[j] -= p.K; ++tapb[j]; }
+            }
         }
-        kd += BKX;
-        k_cur += BKX;
-        while (k_cur >= p.K) {
-            k_cur -= p.K;
-            if (++s_cur == p.S) { s_cur = 0; ++r_cur; }
+        if (tap_inner) {
+            if (++s_cur == p.S) {
+                s_cur = 0;
+                if (++r_cur == p.R) { r_cur = 0; k_cur += BKX; }
+            }
+        } else {
+            kd += BKX;
+            k_cur += BKX;
+            while (k_cur >= p.K) {
+                k_cur -= p.K;
+                if (++s_cur == p.S) { s_cur = 0; ++r_cur; }
+            }
         }
     };
     auto store_slab = [&](int buf) {

@@ -1,2 +1,3 @@
 from .dla import *  # noqa: F401,F403
-from .fpn import FPN, Backbone  # noqa: F401
+from .resnet import ResNet, build_resnet_from_vision_fpn_backbone  # noqa: F401
+from .fpn import FPN, Backbone, LastLevelMaxPool  # noqa: F401

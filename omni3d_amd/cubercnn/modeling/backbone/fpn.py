@@ -20,11 +20,24 @@ class Backbone(nn.Module):
                 for name in self._out_features}
 
 
+class LastLevelMaxPool(nn.Module):
+    """detectron2 top block: one extra level = max_pool2d(k=1, s=2) of (the bottom-up) p5
+    (used by /root/reference/cubercnn/modeling/backbone/resnet.py:92)."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_levels = 1
+        self.in_feature = "p5"
+
+    def forward(self, x):
+        return [HF.subsample2(x)]
+
+
 class FPN(Backbone):
     def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
         super().__init__()
-        if norm != "" or fuse_type != "sum" or top_block is not None:
-            raise NotImplementedError("only FPN(norm='', fuse_type='sum', top_block=None) is on the MI355X hot path")
+        if norm != "" or fuse_type != "sum":
+            raise NotImplementedError("only FPN(norm='', fuse_type='sum') is on the MI355X hot path")
         shapes = bottom_up.output_shape()
         strides = [shapes[f].stride for f in in_features]
         self._stages = []
@@ -42,6 +55,10 @@ class FPN(Backbone):
         self.in_features = tuple(in_features)
         self.bottom_up = bottom_up
         self._out_feature_strides = {f"p{int(math.log2(s))}": s for s in strides}
+        self.top_block = top_block
+        if top_block is not None:
+            for s in range(stage, stage + top_block.num_levels):
+                self._out_feature_strides[f"p{s + 1}"] = 2 ** (s + 1)
         self._out_features = list(self._out_feature_strides.keys())
         self._out_feature_channels = {k: out_channels for k in self._out_features}
         self._size_divisibility = strides[-1]
@@ -58,4 +75,8 @@ class FPN(Backbone):
             lat = getattr(self, f"fpn_lateral{stage}")(feats[f])
             prev = lat if prev is None else HF.upsample2_add(lat, prev)
             results[f"p{stage}"] = getattr(self, f"fpn_output{stage}")(prev)
+        if self.top_block is not None:
+            src = feats[self.top_block.in_feature] if self.top_block.in_feature in feats else results[self.top_block.in_feature]
+            for i, t in enumerate(self.top_block(src)):
+                results[f"p{self._stages[-1] + 1 + i}"] = t
         return {k: results[k] for k in self._out_features}

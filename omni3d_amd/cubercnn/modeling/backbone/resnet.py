@@ -1,0 +1,118 @@
+"""torchvision-style ResNet-18/34 bottom-up + FPN builder (`build_resnet_from_vision_fpn_backbone`).
+
+Mirrors /root/reference/cubercnn/modeling/backbone/resnet.py (ResNet wrapper :12-65, builder :68-96):
+the wrapper lifts conv1/bn1/maxpool/layer1..4 out of `torchvision.models.resnet{18,34}` (module names,
+hence state-dict keys, `layerL.B.{conv1,bn1,conv2,bn2,downsample.0,downsample.1}`), emits p2..p5 and
+p6 = max_pool2d(p5, k=1, s=2), and wraps it in FPN(top_block=LastLevelMaxPool()).  torchvision is not
+a dependency here: the BasicBlock topology / initialisation is restated on the HIP kernels (7x7/s2 stem
+conv and all 3x3 / 1x1 convs = implicit-GEMM MFMA kernel, BN+ReLU(+residual) fused, 3x3/s2 max-pool =
+csrc/pool3.hip).  Depth 50/101 (Bottleneck) are outside the hot path of BASELINE.json (configs[3] is
+ResNet-34)."""
+import torch
+from torch import nn
+
+from .... import functional as HF
+from ..layers import BatchNorm2d, Conv2d
+from ..registries import BACKBONE_REGISTRY
+from .fpn import FPN, Backbone, LastLevelMaxPool
+
+
+class Downsample(nn.Sequential):
+    def __init__(self, cin, cout, stride):
+        super().__init__(Conv2d(cin, cout, kernel_size=1, stride=stride, bias=False), BatchNorm2d(cout))
+
+    def forward(self, x):
+        return self[1](self[0](x))
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(out), residual=identity, relu=True)
+
+
+class TorchvisionResNet(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0], 1)
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = Downsample(self.inplanes, planes, stride)
+        layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+
+_DEPTHS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+
+
+class ResNet(Backbone):
+    def __init__(self, cfg, input_shape, pretrained=True):
+        super().__init__()
+        depth = cfg.MODEL.RESNETS.DEPTH
+        if depth not in _DEPTHS:
+            if depth in (50, 101):
+                raise ValueError(f"ResNet-{depth} (Bottleneck) is outside the MI355X hot path (BasicBlock depths 18 / 34 only)")
+            raise ValueError("No configuration currently supporting depth of {}".format(depth))
+        if pretrained:
+            raise RuntimeError("ImageNet ResNet weights are downloaded by the reference via torchvision (resnet.py:16-20); there is "
+                               "no network here -- set MODEL.WEIGHTS / MODEL.WEIGHTS_PRETRAIN or load a state dict")
+        base = TorchvisionResNet(_DEPTHS[depth])
+        self._out_feature_channels = {"p2": 64, "p3": 128, "p4": 256, "p5": 512, "p6": 512}
+        for name in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4"):
+            setattr(self, name, getattr(base, name))
+        self._out_feature_strides = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
+        self._out_features = ["p2", "p3", "p4", "p5", "p6"]
+
+    def forward(self, x):
+        w = self.conv1.weight
+        if x.shape[1] != w.shape[1]:   # 3-channel stem weight against the 4-channel padded image
+            w = torch.cat([w, w.new_zeros(w.shape[0], x.shape[1] - w.shape[1], w.shape[2], w.shape[3])], dim=1)
+        x = self.bn1(HF.conv2d(x, w, None, 2, 3), relu=True)
+        x = HF.max_pool3s2(x)
+        p2 = self.layer1(x)
+        p3 = self.layer2(p2)
+        p4 = self.layer3(p3)
+        p5 = self.layer4(p4)
+        return {"p2": p2, "p3": p3, "p4": p4, "p5": p5, "p6": HF.subsample2(p5)}
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_from_vision_fpn_backbone(cfg, input_shape, priors=None):
+    imagenet_pretrain = cfg.MODEL.WEIGHTS_PRETRAIN + cfg.MODEL.WEIGHTS == ""
+    if not cfg.MODEL.RESNETS.TORCHVISION:
+        raise NotImplementedError("MODEL.RESNETS.TORCHVISION False (detectron2 MSRA ResNet) is outside the MI355X hot path")
+    bottom_up = ResNet(cfg, input_shape, pretrained=imagenet_pretrain)
+    return FPN(bottom_up=bottom_up, in_features=cfg.MODEL.FPN.IN_FEATURES, out_channels=cfg.MODEL.FPN.OUT_CHANNELS,
+               norm=cfg.MODEL.FPN.NORM, top_block=LastLevelMaxPool(), fuse_type=cfg.MODEL.FPN.FUSE_TYPE)

@@ -262,3 +262,21 @@ class _CubeLoss(Function):
 
 def cube_loss(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row):
     return _CubeLoss.apply(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row)
+
+
+class _MaxPool3s2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(x)
+        ctx.save_for_backward(x)
+        return bnpool.maxpool3s2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return bnpool.maxpool3s2_bwd(x, _cl(dy))
+
+
+def max_pool3s2(x):
+    """nn.MaxPool2d(3, stride=2, padding=1)"""
+    return _MaxPool3s2.apply(x)

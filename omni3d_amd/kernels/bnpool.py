@@ -140,3 +140,15 @@ def bias_grad(dy2d, accum_into=None):
     ws = torch.empty(2 * C * 258, dtype=torch.float64, device=dy2d.device)
     L.call("omni_bias_grad", _lib.ptr(dy2d), P, C, _lib.ptr(db), _lib.ptr(ws), int(accum_into is not None), _lib.stream_of(dy2d))
     return None if accum_into is not None else db
+
+
+def maxpool3s2_fwd(x):
+    xv = _nhwc(x)
+    N, H, W, C = xv.shape
+    return _simple("omni_maxpool3s2_fwd", xv, (N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), (N, H, W, C)).permute(0, 3, 1, 2)
+
+
+def maxpool3s2_bwd(x, dy):
+    xv, dyv = _nhwc(x), _nhwc(dy)
+    N, H, W, C = xv.shape
+    return _simple("omni_maxpool3s2_bwd", xv, (N, H, W, C), (N, H, W, C), extra_in=(dyv,)).permute(0, 3, 1, 2)

@@ -38,12 +38,19 @@ TINY = dict(
 )
 
 
-def product_cfg(overrides):
+RESNET = dict(
+    name="resnet34_small", seed=4, images=2, height=128, width=128, num_gt=5, config="cubercnn_ResNet34_FPN.yaml",
+    overrides=["MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 64, "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 64,
+               "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 300, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 100],
+)
+
+
+def product_cfg(overrides, config="cubercnn_DLA34_FPN.yaml"):
     from omni3d_amd.cubercnn.config import get_cfg_defaults
     from omni3d_amd.d2.config import get_cfg
     cfg = get_cfg()
     get_cfg_defaults(cfg)
-    cfg.merge_from_file(os.path.join(ROOT, "configs", "cubercnn_DLA34_FPN.yaml"))
+    cfg.merge_from_file(os.path.join(ROOT, "configs", config))
     cfg.merge_from_list(["MODEL.DEVICE", "cpu", "VIS_PERIOD", 0, "MODEL.WEIGHTS", "synthetic://random-init"] + list(overrides))
     return cfg
 
@@ -72,9 +79,10 @@ def variates(spec, A):
 
 def main(spec=SMALL):
     priors = synthetic.make_priors(50)
-    cfg_ref = H.reference_cfg("cubercnn_DLA34_FPN.yaml", spec["overrides"])
+    config = spec.get("config", "cubercnn_DLA34_FPN.yaml")
+    cfg_ref = H.reference_cfg(config, spec["overrides"])
     ref = H.build_reference_model(cfg_ref, priors)
-    prod = build_product_model(product_cfg(spec["overrides"]), priors, spec["seed"])
+    prod = build_product_model(product_cfg(spec["overrides"], config), priors, spec["seed"])
     missing = ref.load_state_dict(prod.state_dict(), strict=True)
     batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
     A = 3 * sum((spec["height"] // s) * (spec["width"] // s) for s in (4, 8, 16, 32, 64))
@@ -113,8 +121,10 @@ def main(spec=SMALL):
         total.backward()
         logs = {k: v[0] for k, v in st.latest().items()}
     grads = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
-    pick = ["backbone.bottom_up.base_layer.0.weight", "backbone.bottom_up.level2.tree1.conv1.weight",
-            "backbone.bottom_up.level5.root.bn.weight", "backbone.fpn_output2.weight", "backbone.fpn_lateral6.bias",
+    bb = (["backbone.bottom_up.conv1.weight", "backbone.bottom_up.layer2.0.downsample.0.weight", "backbone.bottom_up.layer4.2.bn2.weight"]
+          if "ResNet" in config else
+          ["backbone.bottom_up.base_layer.0.weight", "backbone.bottom_up.level2.tree1.conv1.weight", "backbone.bottom_up.level5.root.bn.weight"])
+    pick = bb + ["backbone.fpn_output2.weight", "backbone.fpn_lateral6.bias",
             "proposal_generator.rpn_head.conv.weight", "proposal_generator.rpn_head.objectness_logits.bias",
             "proposal_generator.rpn_head.anchor_deltas.weight", "roi_heads.box_head.fc1.bias", "roi_heads.box_head.fc2.weight",
             "roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.bbox_pred.bias",
@@ -179,4 +189,4 @@ if __name__ == "__main__":
     if "--infer" in sys.argv:
         main_infer()
     else:
-        main(TINY if "--tiny" in sys.argv else SMALL)
+        main(TINY if "--tiny" in sys.argv else RESNET if "--resnet" in sys.argv else SMALL)

@@ -96,6 +96,27 @@ class DLA34(U.Backbone):
         return {"p2": p2, "p3": p3, "p4": p4, "p5": p5, "p6": F.max_pool2d(p5, kernel_size=1, stride=2, padding=0)}
 
 
+class ResNet34(U.Backbone):
+    """cubercnn/modeling/backbone/resnet.py:12-65 over the restated torchvision resnet34 (oracle/upstream.py)."""
+
+    def __init__(self):
+        super().__init__()
+        base = U.tv_resnet34(False)
+        for name in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4"):
+            setattr(self, name, getattr(base, name))
+        self._out_feature_channels = {"p2": 64, "p3": 128, "p4": 256, "p5": 512, "p6": 512}
+        self._out_feature_strides = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
+        self._out_features = ["p2", "p3", "p4", "p5", "p6"]
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        p2 = self.layer1(x)
+        p3 = self.layer2(p2)
+        p4 = self.layer3(p3)
+        p5 = self.layer4(p4)
+        return {"p2": p2, "p3": p3, "p4": p4, "p5": p5, "p6": F.max_pool2d(p5, kernel_size=1, stride=2, padding=0)}
+
+
 class _Seq(nn.Module):
     pass
 
@@ -103,11 +124,12 @@ class _Seq(nn.Module):
 class ModelOracle(nn.Module):
     """State-dict compatible with the reference's RCNN3D (cubercnn_DLA34_FPN)."""
 
-    def __init__(self, priors, num_classes=50, rpn_batch=256, roi_batch=512, pre_nms=2000, post_nms=1000):
+    def __init__(self, priors, num_classes=50, rpn_batch=256, roi_batch=512, pre_nms=2000, post_nms=1000, backbone="dla34"):
         super().__init__()
         self.K, self.rpn_batch, self.roi_batch, self.pre_nms, self.post_nms = num_classes, rpn_batch, roi_batch, pre_nms, post_nms
         names = ["p2", "p3", "p4", "p5", "p6"]
-        self.backbone = U.FPN(DLA34(), names, 256)
+        self.backbone = (U.FPN(ResNet34(), names, 256, top_block=U.LastLevelMaxPool()) if backbone == "resnet34"
+                         else U.FPN(DLA34(), names, 256))
         self.proposal_generator = _Seq()
         self.proposal_generator.rpn_head = U.StandardRPNHead(in_channels=256, num_anchors=3, box_dim=4)
         self.anchor_gen = U.DefaultAnchorGenerator(sizes=[[32], [64], [128], [256], [512]], aspect_ratios=[[0.5, 1.0, 2.0]],

@@ -14,6 +14,7 @@ import types
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFERENCE = os.environ.get("OMNI3D_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True   # the reference tree is read-only: never leave __pycache__ behind in it
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -111,6 +112,8 @@ def install():
     _mod("detectron2.modeling.backbone", Backbone=U.Backbone, BACKBONE_REGISTRY=U.BACKBONE_REGISTRY)
     _mod("detectron2.modeling.backbone.build", BACKBONE_REGISTRY=U.BACKBONE_REGISTRY)
     _mod("detectron2.modeling.backbone.fpn", FPN=U.FPN, LastLevelMaxPool=U.LastLevelMaxPool)
+    _mod("detectron2.modeling.backbone.resnet", build_resnet_backbone=U.build_resnet_backbone)
+    _mod("torchvision.models", resnet18=U.tv_resnet18, resnet34=U.tv_resnet34)
     _mod("detectron2.modeling.proposal_generator", RPN=U.RPN, build_proposal_generator=U.build_proposal_generator)
     _mod("detectron2.modeling.proposal_generator.proposal_utils", add_ground_truth_to_proposals=U.add_ground_truth_to_proposals)
     _mod("detectron2.modeling.box_regression", Box2BoxTransform=U.Box2BoxTransform,

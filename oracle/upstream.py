@@ -743,6 +743,87 @@ class FPN(Backbone):
 
 
 # ------------------------------------------------------------------------------------------------
+# torchvision.models.resnet18/34 (BasicBlock variants), the `base` of the reference's ResNet wrapper
+#   (cubercnn/modeling/backbone/resnet.py:2,16-20,30-37).  torchvision is a pip dependency that is
+#   absent from /root/reference and from this image; restated from its published architecture
+#   (He et al. 2016; torchvision/models/resnet.py: conv7x7/s2 - BN - ReLU - maxpool3x3/s2/p1 -
+#   [3,4,6,3] BasicBlocks, stride on conv1 of the first block of layer2..4 with a 1x1/s2 conv+BN
+#   `downsample`, conv weights kaiming_normal_(fan_out, relu), BN weight 1 / bias 0).
+# ------------------------------------------------------------------------------------------------
+
+
+class TVBasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class TVResNet(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0], 1)
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512, 1000)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        layers = [TVBasicBlock(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        layers += [TVBasicBlock(planes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+
+def _tv_resnet(layers, pretrained):
+    if pretrained:
+        raise RuntimeError("ImageNet weights are a network download (torchvision); set MODEL.WEIGHTS")
+    return TVResNet(layers)
+
+
+def tv_resnet18(pretrained=False):
+    return _tv_resnet([2, 2, 2, 2], pretrained)
+
+
+def tv_resnet34(pretrained=False):
+    return _tv_resnet([3, 4, 6, 3], pretrained)
+
+
+def build_resnet_backbone(cfg, input_shape):
+    raise NotImplementedError("MSRA ResNet (MODEL.RESNETS.TORCHVISION False) is outside the restated surface")
+
+
+# ------------------------------------------------------------------------------------------------
 # detectron2.modeling.roi_heads: ROIHeads / StandardROIHeads / box head / FastRCNNOutputLayers
 #   (base classes of ROIHeads3D roi_heads.py:17-19,40 and FastRCNNOutputs fast_rcnn.py:11-13,119)
 # ------------------------------------------------------------------------------------------------

@@ -99,3 +99,27 @@ def test_bn_gpu(hip_lib, cfg):
 @pytest.mark.gpu
 def test_pool_gpu(hip_lib):
     _run_pool("cuda")
+
+
+def _run_pool3(dev):
+    from omni3d_amd.kernels import bnpool
+    g = torch.Generator().manual_seed(12)
+    for shape in ((2, 8, 9, 12), (1, 4, 6, 6)):
+        x = torch.randn(*shape, generator=g)
+        x[0, :, 0, 0] = x[0, :, 1, 1] = 5.0      # tie inside the first window: first maximum wins
+        xr = x.clone().requires_grad_(True)
+        yr = F.max_pool2d(xr, 3, 2, 1)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        xk = _cl(x).to(dev)
+        assert torch.equal(bnpool.maxpool3s2_fwd(xk).cpu(), yr.detach())
+        assert (bnpool.maxpool3s2_bwd(xk, _cl(dy).to(dev)).cpu() - xr.grad).abs().max() < 1e-6
+
+
+def test_pool3_emulated(emu_lib):
+    _run_pool3("cpu")
+
+
+@pytest.mark.gpu
+def test_pool3_gpu(hip_lib):
+    _run_pool3("cuda")

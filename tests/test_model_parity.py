@@ -20,7 +20,7 @@ def _run(dev, name):
     gold = torch.load(_gold(name), weights_only=False)
     spec = gold["spec"]
     priors = synthetic.make_priors(50)
-    model = MG.build_product_model(MG.product_cfg(spec["overrides"]), priors, spec["seed"], device=dev)
+    model = MG.build_product_model(MG.product_cfg(spec["overrides"], spec.get("config", "cubercnn_DLA34_FPN.yaml")), priors, spec["seed"], device=dev)
     batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
     A = gold["rpn_labels"].shape[1]
     E = MG.variates(spec, A)
@@ -69,7 +69,7 @@ def test_training_step_matches_reference_emulated(emu_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["dla34_tiny", "dla34_small"])
+@pytest.mark.parametrize("name", ["dla34_tiny", "dla34_small", "resnet34_small"])
 def test_training_step_matches_reference_gpu(hip_lib, name):
     _run("cuda", name)
 
