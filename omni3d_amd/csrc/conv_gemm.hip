@@ -255,7 +255,13 @@ __global__ void __launch_bounds__(256) relu_inplace_kernel(float* __restrict__ y
 
 // =================================================================================================
 // data gradient:  dx[m_in, c] = sum_{r,s,k} dy[pix_out(m_in; r, s), k] * w[k, r, s, c]
-//   GEMM M = N*H*W, N = C, reduction Kd = R*S*K.  A k-contiguous, B n-contiguous in LDS.
+//   GEMM N = C, reduction over (tap, k).  A k-contiguous, B n-contiguous in LDS.
+//
+//   Strided convs are decomposed into stride^2 PARITY CLASSES (blockIdx.z): input pixels with
+//   (ih % stride, iw % stride) = (ph, pw) only ever meet the taps r = r0 + stride*jr, r0 = (ph + pad) % stride
+//   (same for s), so each class is a dense stride-1 correlation of the class' pixel sub-grid with its
+//   Rc x Sc tap subset: oh = ihc + oh_off - jr.  No MFMA work is spent on the structurally-zero taps
+//   (a 3x3/s2 dgrad does 9/4 taps per pixel instead of 9).  stride 1 is the single class (0, 0).
 // =================================================================================================
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BKX = 32>
 __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
@@ -266,99 +272,113 @@ __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM * BKP + BKX * BN)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int M = p.N * p.H * p.W, Kd = p.R * p.S * p.K, RSC = p.R * p.S * p.C;
+    const int st = p.stride;
+    const int ph = (int)blockIdx.z / st, pw = (int)blockIdx.z - ph * st;
+    const int Hc = (p.H - ph + st - 1) / st, Wc = (p.W - pw + st - 1) / st;      // class sub-grid
+    const int r0 = (ph + p.pad) % st, s0 = (pw + p.pad) % st;
+    const int Rc = r0 < p.R ? (p.R - r0 + st - 1) / st : 0, Sc = s0 < p.S ? (p.S - s0 + st - 1) / st : 0;
+    const int RSc = Rc * Sc;
+    const int oh_off = (ph + p.pad - r0) / st, ow_off = (pw + p.pad - s0) / st;
+    const int M = p.N * Hc * Wc, Kd = RSc * p.K, RSC = p.R * p.S * p.C;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (p.C + BN - 1) / BN;
+    if ((int)blockIdx.x >= tiles_m * tiles_n) return;      // grid.x is sized for the largest class (0, 0)
     int tile_m, tile_n;
-    tile_coords((M + BM - 1) / BM, (p.C + BN - 1) / BN, tile_m, tile_n);
+    tile_coords(tiles_m, tiles_n, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kq = tid % KQ, lrow = tid / KQ;
     const int bn4 = tid % BF4, brow = tid / BF4;
 
-    int a_img[AI], a_ih[AI], a_iw[AI];
+    long a_base[AI];
+    int a_oh[AI], a_ow[AI];
     bool a_ok[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const int m = m0 + lrow + RPP * i;
         a_ok[i] = (lrow + RPP * i < BM) && m < M;
         const int mm = a_ok[i] ? m : 0;
-        const int img = mm / (p.H * p.W), rem = mm - img * (p.H * p.W);
-        const int ih = rem / p.W, iw = rem - ih * p.W;
-        a_img[i] = img;
-        a_ih[i] = ih + p.pad;
-        a_iw[i] = iw + p.pad;
+        const int img = mm / (Hc * Wc), rem = mm - img * (Hc * Wc);
+        const int ihc = rem / Wc, iwc = rem - ihc * Wc;
+        a_oh[i] = ihc + oh_off;
+        a_ow[i] = iwc + ow_off;
+        a_base[i] = ((long)(img * p.OH + a_oh[i]) * p.OW + a_ow[i]) * p.ldx;
     }
     const int nk_total = (Kd + BKX - 1) / BKX;
     const int sps = (nk_total + (int)gridDim.y - 1) / (int)gridDim.y;
     const int kt_begin = (int)blockIdx.y * sps;
     const int nk = min(sps, nk_total - kt_begin);
-    // Slab order: (k-chunk, r, s) when K is a multiple of the slab depth (same L2-reuse argument as the forward
-    // kernel: the R*S taps of one chunk of dy channels are consecutive slabs), else (r, s, k).
-    const bool tap_inner = (p.K % BKX) == 0 && p.R * p.S > 1;
-    const int RS = p.R * p.S;
+    // Slab order: (k-chunk, jr, js) when K is a multiple of the slab depth (same L2-reuse argument as the forward
+    // kernel: the taps of one chunk of dy channels are consecutive slabs), else (jr, js, k).
+    const bool tap_inner = (p.K % BKX) == 0 && RSc > 1;
     // A cursor (this thread's float4 column)
-    int kd, k_cur, r_cur, s_cur;
+    int kd, k_cur, jr_cur, js_cur;
     // B cursors (this thread's BI weight rows): w[k][tap][c]
-    int kdb[BI], kb[BI], tapb[BI];
-    if (tap_inner) {
-        const int chunk = kt_begin / RS, tap0 = kt_begin - chunk * RS;
-        k_cur = chunk * BKX + kq * 4;
-        r_cur = tap0 / p.S;
-        s_cur = tap0 - r_cur * p.S;
-        kd = 0;   // always in range in this mode (nk bounds the loop)
+    int kdb[BI], kb[BI], jrb[BI], jsb[BI];
+    if (nk > 0) {
+        if (tap_inner) {
+            const int chunk = kt_begin / RSc, tap0 = kt_begin - chunk * RSc;
+            k_cur = chunk * BKX + kq * 4;
+            jr_cur = tap0 / Sc;
+            js_cur = tap0 - jr_cur * Sc;
+            kd = 0;   // always in range in this mode (nk bounds the loop)
 #pragma unroll
-        for (int j = 0; j < BI; ++j) { kb[j] = chunk * BKX + brow + BROWS * j; tapb[j] = tap0; kdb[j] = 0; }
-    } else {
-        kd = kt_begin * BKX + kq * 4;
-        const int tap0 = kd / p.K;
-        k_cur = kd - tap0 * p.K;
-        r_cur = tap0 / p.S;
-        s_cur = tap0 - r_cur * p.S;
+            for (int j = 0; j < BI; ++j) { kb[j] = chunk * BKX + brow + BROWS * j; jrb[j] = jr_cur; jsb[j] = js_cur; kdb[j] = 0; }
+        } else {
+            kd = kt_begin * BKX + kq * 4;
+            const int tap0 = kd / p.K;
+            k_cur = kd - tap0 * p.K;
+            jr_cur = tap0 / Sc;
+            js_cur = tap0 - jr_cur * Sc;
 #pragma unroll
-        for (int j = 0; j < BI; ++j) {
-            kdb[j] = kt_begin * BKX + brow + BROWS * j;
-            tapb[j] = kdb[j] / p.K;
-            kb[j] = kdb[j] - tapb[j] * p.K;
+            for (int j = 0; j < BI; ++j) {
+                kdb[j] = kt_begin * BKX + brow + BROWS * j;
+                const int t = kdb[j] / p.K;
+                kb[j] = kdb[j] - t * p.K;
+                jrb[j] = t / Sc;
+                jsb[j] = t - jrb[j] * Sc;
+            }
         }
     }
     const int cb = n0 + bn4 * 4;
     float4 ra[AI], rb[BI];
     auto load_slab = [&]() {
         const bool kok = kd < Kd;
+        const long tap_off = -((long)jr_cur * p.OW + js_cur) * p.ldx + k_cur;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int th = a_ih[i] - r_cur, tw = a_iw[i] - s_cur;
-            bool ok = a_ok[i] && kok && th >= 0 && tw >= 0;
-            int oh = th, ow = tw;
-            if (p.stride > 1) {
-                oh = th / p.stride;
-                ow = tw / p.stride;
-                ok = ok && (oh * p.stride == th) && (ow * p.stride == tw);
-            }
-            ok = ok && oh < p.OH && ow < p.OW;
-            ra[i] = ok ? ldg4(p.x + ((long)(a_img[i] * p.OH + oh) * p.OW + ow) * p.ldx + k_cur) : zero4();
+            const int oh = a_oh[i] - jr_cur, ow = a_ow[i] - js_cur;
+            const bool ok = a_ok[i] && kok && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
+            ra[i] = ok ? ldg4(p.x + a_base[i] + tap_off) : zero4();
         }
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
             const bool ok = (brow + BROWS * j < BKX) && kdb[j] < Kd && cb < p.C;
-            rb[j] = ok ? ldg4(p.w + (long)kb[j] * RSC + (long)tapb[j] * p.C + cb) : zero4();
+            const int tap = (r0 + st * jrb[j]) * p.S + s0 + st * jsb[j];
+            rb[j] = ok ? ldg4(p.w + (long)kb[j] * RSC + (long)tap * p.C + cb) : zero4();
             if (tap_inner) {
-                if (++tapb[j] == RS) { tapb[j] = 0; kb[j] += BKX; }
+                if (++jsb[j] == Sc) {
+                    jsb[j] = 0;
+                    if (++jrb[j] == Rc) { jrb[j] = 0; kb[j] += BKX; }
+                }
             } else {
                 kdb[j] += BKX;
                 kb[j] += BKX;
-                while (kb[j] >= p.K) { kb[j] -= p.K; ++tapb[j]; }
+                while (kb[j] >= p.K) {
+                    kb[j] -= p.K;
+                    if (++jsb[j] == Sc) { jsb[j] = 0; ++jrb[j]; }
+                }
             }
         }
         if (tap_inner) {
-            if (++s_cur == p.S) {
-                s_cur = 0;
-                if (++r_cur == p.R) { r_cur = 0; k_cur += BKX; }
+            if (++js_cur == Sc) {
+                js_cur = 0;
+                if (++jr_cur == Rc) { jr_cur = 0; k_cur += BKX; }
             }
         } else {
             kd += BKX;
             k_cur += BKX;
             while (k_cur >= p.K) {
                 k_cur -= p.K;
-                if (++s_cur == p.S) { s_cur = 0; ++r_cur; }
+                if (++js_cur == Sc) { js_cur = 0; ++jr_cur; }
             }
         }
     };
@@ -375,30 +395,42 @@ __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
 
     f32x16 acc[WM][WN];
     zero_acc<WM, WN>(acc);
-    if (nk <= 0) return;
-    load_slab();
-    store_slab(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_slab();
-        const float* As = smem + buf * (BM * BKP + BKX * BN);
-        mma_slab<WM, WN, true, false, 0, BN, BKX>(As, As + BM * BKP, wm * WM * 32, wn * WN * 32, lane, acc);
-        if (kt + 1 < nk) store_slab(buf ^ 1);
+    const bool split = gridDim.y > 1;
+    if (nk <= 0) {
+        // no taps for this split / class (e.g. the odd pixels of a 1x1/s2 conv): the gradient is zero there.
+        // A split launch pre-zeroes dx and an accumulating one adds nothing; otherwise fall through and store zeros.
+        if (split || p.accumulate) return;
+    } else {
+        load_slab();
+        store_slab(0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_slab();
+            const float* As = smem + buf * (BM * BKP + BKX * BN);
+            mma_slab<WM, WN, true, false, 0, BN, BKX>(As, As + BM * BKP, wm * WM * 32, wn * WN * 32, lane, acc);
+            if (kt + 1 < nk) store_slab(buf ^ 1);
+            __syncthreads();
+        }
     }
     const int l31 = lane & 31, h = lane >> 5;
-    const bool split = gridDim.y > 1;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int n = n0 + (wn * WN + j) * 32 + l31;
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= M) continue;
+            long row = m;
+            if (st > 1) {
+                const int img = m / (Hc * Wc), rem = m - img * (Hc * Wc);
+                const int ihc = rem / Wc, iwc = rem - ihc * Wc;
+                row = (long)(img * p.H + ihc * st + ph) * p.W + iwc * st + pw;
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < M && n < p.C) {
-                    float* o = p.out + (long)m * p.ldo + n;
+            for (int j = 0; j < WN; ++j) {
+                const int n = n0 + (wn * WN + j) * 32 + l31;
+                if (n < p.C) {
+                    float* o = p.out + row * p.ldo + n;
                     if (split) atomicAdd(o, acc[i][j][r]);
                     else *o = p.accumulate ? (*o + acc[i][j][r]) : acc[i][j][r];
                 }
@@ -410,13 +442,15 @@ __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
 // weight gradient:  dw[k, r, s, c] = sum_{pix} dy[pix, k] * x[pix_in(pix; r, s), c]
 //   GEMM M = K, N = R*S*C, reduction over P = N*OH*OW output pixels, split over grid.y.
 //   A (dy) and B (x) both have the reduction index as the slow dimension: LDS tiles [pix][m|n].
+//   Each thread owns one (tap, c) float4 column of B and walks its BI pixel rows with incremental
+//   (oh, ow, offset) cursors -- no integer division inside the slab loop.
 // =================================================================================================
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK = 32>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_split) {
     constexpr int WM = BM / (32 * WAVES_M), WN = BN / (32 * WAVES_N);
     constexpr int AF4 = BM / 4, AROWS = 256 / AF4, AI = BK / AROWS;
     constexpr int BF4 = BN / 4, BROWS = 256 / BF4, BI = BK / BROWS;
-    static_assert(AROWS * AI == BK && BROWS * BI == BK, "tile mapping");
+    static_assert(AROWS * AI == BK && BROWS * BI == BK && WAVES_M * WAVES_N == 4, "tile mapping");
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -432,27 +466,46 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
     const bool n_ok = nn < Nn;
     const int tap = n_ok ? nn / p.C : 0;
     const int bc = nn - tap * p.C;
-    const int br = tap / p.S, bs = tap - br * p.S;
+    const int br = tap / p.S - p.pad, bs = tap - (tap / p.S) * p.S - p.pad;   // tap offset minus padding
     const int am = m0 + am4 * 4;
     const bool m_ok = am < p.K;
 
-    float4 ra[AI], rb[BI];
-    auto load_slab = [&](int kt) {
+    // pixel cursors (img, oh, ow) of this thread's BI rows of the NEXT slab to load; one slab advances them by
+    // BK pixels = d_img images + d_oh rows + d_ow columns (precomputed, carries resolved with two compares)
+    int b_pix[BI], b_img[BI], b_oh[BI], b_ow[BI];
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int pix = p_begin + kt * BK + arow + AROWS * i;
-            ra[i] = (m_ok && pix < p_end) ? ldg4(p.w + (long)pix * p.ldw + am) : zero4();
-        }
+    for (int j = 0; j < BI; ++j) {
+        const int pix = p_begin + brow + BROWS * j;
+        const int pp = pix < P ? pix : 0;
+        const int img = pp / (p.OH * p.OW), rem = pp - img * (p.OH * p.OW);
+        b_pix[j] = pix;
+        b_img[j] = img;
+        b_oh[j] = rem / p.OW;
+        b_ow[j] = rem - b_oh[j] * p.OW;
+    }
+    const int d_img = BK / (p.OH * p.OW), d_rem = BK - d_img * (p.OH * p.OW);
+    const int d_oh = d_rem / p.OW, d_ow = d_rem - d_oh * p.OW;
+    const float* a_ptr = p.w + (long)(p_begin + arow) * p.ldw + am;
+    int a_pix = p_begin + arow;
+
+    float4 ra[AI], rb[BI];
+    auto load_slab = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            ra[i] = (m_ok && a_pix + AROWS * i < p_end) ? ldg4(a_ptr + (long)(AROWS * i) * p.ldw) : zero4();
+        a_ptr += (long)BK * p.ldw;
+        a_pix += BK;
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
-            const int pix = p_begin + kt * BK + brow + BROWS * j;
-            bool ok = n_ok && pix < p_end;
-            const int pp = ok ? pix : 0;
-            const int img = pp / (p.OH * p.OW), rem = pp - img * (p.OH * p.OW);
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;
-            const int ih = oh * p.stride - p.pad + br, iw = ow * p.stride - p.pad + bs;
-            ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            rb[j] = ok ? ldg4(p.x + ((long)(img * p.H + ih) * p.W + iw) * p.ldx + bc) : zero4();
+            const int ih = b_oh[j] * p.stride + br, iw = b_ow[j] * p.stride + bs;
+            const bool ok = n_ok && b_pix[j] < p_end && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            rb[j] = ok ? ldg4(p.x + ((long)(b_img[j] * p.H + ih) * p.W + iw) * p.ldx + bc) : zero4();
+            b_pix[j] += BK;
+            b_ow[j] += d_ow;
+            if (b_ow[j] >= p.OW) { b_ow[j] -= p.OW; ++b_oh[j]; }
+            b_oh[j] += d_oh;
+            if (b_oh[j] >= p.OH) { b_oh[j] -= p.OH; ++b_img[j]; }
+            b_img[j] += d_img;
         }
     };
     auto store_slab = [&](int buf) {
@@ -468,12 +521,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
     zero_acc<WM, WN>(acc);
     const int nk = (p_end - p_begin + BK - 1) / BK;
     if (nk <= 0) return;
-    load_slab(0);
+    load_slab();
     store_slab(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_slab(kt + 1);
+        if (kt + 1 < nk) load_slab();
         const float* As = smem + buf * BK * (BM + BN);
         mma_slab<WM, WN, false, false, BM, BN, BK>(As, As + BK * BM, wm * WM * 32, wn * WN * 32, lane, acc);
         if (kt + 1 < nk) store_slab(buf ^ 1);
@@ -579,32 +632,34 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
     ConvP p{dy, w, nullptr, dx, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
             R, S, stride, pad, lddy, lddx, 0, 0, accumulate, 1};
     if (bad_geom(p) || (K & 3) || (lddy & 3) || lddy < K || lddx < C) return OMNI_ERR_ARG;
-    const long M = (long)N * H * W;
-    if (M == 0) return OMNI_OK;
+    if ((long)N * H * W == 0) return OMNI_OK;
     hipStream_t st = (hipStream_t)stream;
-    const long Kd = (long)R * S * K;
+    // one launch covers the stride^2 parity classes (grid.z); tiles are sized for the largest class (0, 0)
+    const unsigned ncls = (unsigned)(stride * stride);
+    const long M = (long)N * ((H + stride - 1) / stride) * ((W + stride - 1) / stride);
+    const long Kd = (long)((R + stride - 1) / stride) * ((S + stride - 1) / stride) * K;
     const long t128 = ((M + 127) / 128) * ((C + 127) / 128);
-    if ((C > 64 && t128 >= 256) || g_variant == 2 || g_variant == 3) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<128, 128, 2, 2, 32>), dim3((unsigned)t128), dim3(256), 0, st, p);
-    } else if (C > 32 && (C > 64 || ((M + 127) / 128) < 256)) {
+    if ((C > 64 && t128 * ncls >= 256) || g_variant == 2 || g_variant == 3) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<128, 128, 2, 2, 32>), dim3((unsigned)t128, 1, ncls), dim3(256), 0, st, p);
+    } else if (C > 32 && (C > 64 || ((M + 127) / 128) * ncls < 256)) {
         const long tiles = ((M + 63) / 64) * ((C + 63) / 64);
         long splits = 1;
         const long nslab = (Kd + 31) / 32;
-        if (tiles < 192 && nslab >= 16 && lddx == C && !accumulate && g_variant != 5) {
-            splits = (512 + tiles - 1) / tiles;
+        if (tiles * ncls < 192 && nslab >= 16 && lddx == C && !accumulate && g_variant != 5) {
+            splits = (512 + tiles * ncls - 1) / (tiles * ncls);
             if (splits > nslab / 8) splits = nslab / 8;
             if (splits > 32) splits = 32;
             if (splits < 1) splits = 1;
         }
-        if (splits > 1) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * C, st);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<64, 64, 2, 2, 32>), dim3((unsigned)tiles, (unsigned)splits),
+        if (splits > 1) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * H * W * C, st);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<64, 64, 2, 2, 32>), dim3((unsigned)tiles, (unsigned)splits, ncls),
                            dim3(256), 0, st, p);
     } else if (C > 32) {
         const long tiles = ((M + 127) / 128) * ((C + 63) / 64);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<128, 64, 2, 2, 32>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<128, 64, 2, 2, 32>), dim3((unsigned)tiles, 1, ncls), dim3(256), 0, st, p);
     } else {
         const long tiles = ((M + 255) / 256) * ((C + 31) / 32);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<256, 32, 4, 1, 16>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<256, 32, 4, 1, 16>), dim3((unsigned)tiles, 1, ncls), dim3(256), 0, st, p);
     }
     return omni_launch_status();
 }
@@ -624,9 +679,13 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
         return OMNI_OK;
     }
     constexpr int WBK = 32;
-    const bool wide = K > 64;
-    const int bm = wide ? 128 : 64;
-    const int tiles = ((K + bm - 1) / bm) * ((Nn + 63) / 64);
+    // tile: 128x128 for wide layers, 128x64 when the (tap, c) extent is only 64 wide, 64x64 for K <= 64,
+    // 32x128 for the <= 32-channel stem layers (a 64-row tile would spend >= half its MFMAs on padding)
+    int bm, bn;
+    if (K > 64) { bm = 128; bn = (Nn > 64 && (P >= 32768 || g_variant == 7) && g_variant != 6) ? 128 : 64; }
+    else if (K > 32 || g_variant == 6) { bm = 64; bn = 64; }
+    else { bm = 32; bn = 128; }
+    const int tiles = ((K + bm - 1) / bm) * ((Nn + bn - 1) / bn);
     // aim at ~1024 workgroups, at least 256 pixels (8 slabs) per split
     long splits = (1024 + tiles - 1) / tiles;
     long max_splits = (P + 255) / 256;
@@ -636,12 +695,14 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
     pps = (pps + WBK - 1) / WBK * WBK;
     splits = (P + pps - 1) / pps;
     if (splits > 1 && !accumulate) hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
-    if (wide)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<128, 64, 2, 2, WBK>), dim3(tiles, (unsigned)splits), dim3(256),
-                           0, (hipStream_t)stream, p, pps);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<64, 64, 2, 2, WBK>), dim3(tiles, (unsigned)splits), dim3(256),
-                           0, (hipStream_t)stream, p, pps);
+#define OMNI_WGRAD(BM_, BN_, WM_, WN_)                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<BM_, BN_, WM_, WN_, WBK>), dim3(tiles, (unsigned)splits), dim3(256), 0, \
+                       (hipStream_t)stream, p, pps)
+    if (bm == 128 && bn == 128) OMNI_WGRAD(128, 128, 2, 2);
+    else if (bm == 128) OMNI_WGRAD(128, 64, 2, 2);
+    else if (bm == 64) OMNI_WGRAD(64, 64, 2, 2);
+    else OMNI_WGRAD(32, 128, 1, 4);
+#undef OMNI_WGRAD
     return omni_launch_status();
 }
 

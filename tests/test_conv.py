@@ -13,6 +13,10 @@ CASES = [
     (1, 6, 6, 32, 72, 1, 1, 0),     # 1x1, 128x128 path with ragged N
     (1, 10, 10, 4, 16, 7, 1, 3),    # 7x7 stem shape (C padded to 4), Kd=196 (tail slab)
     (1, 6, 6, 64, 64, 3, 1, 1),     # few tiles + deep reduction: split-K path with atomic epilogue (+bias, +ReLU)
+    (1, 7, 9, 32, 64, 3, 2, 1),     # stride-2 dgrad parity classes, odd extents, tap-inner (K % 32 == 0) + split-K
+    (1, 7, 6, 16, 24, 1, 2, 0),     # 1x1/s2 (ResNet downsample): three of the four dgrad classes have no taps -> zeros
+    (1, 12, 10, 4, 16, 7, 2, 3),    # 7x7/s2 ResNet stem
+    (2, 5, 6, 16, 72, 3, 1, 1),     # wgrad 128x128 tile (K > 64, R*S*C > 64), pixel cursor wrapping rows and images
 ]
 
 
@@ -66,9 +70,9 @@ def test_conv_emulated(emu_lib, case):
     _run_case("cpu", case)
 
 
-@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("variant", [2, 3, 7])
 def test_conv_128x128_tiles_emulated(emu_lib, variant):
-    """force the 128x128 tile kernels (BK 16 / BK 32) on a small shape"""
+    """force the 128x128 tile kernels (fwd/dgrad BK 16 / BK 32; 7 = wgrad 128x128) on a small shape"""
     from omni3d_amd import lib as L
     L.get().call("omni_debug_set_variant", variant)
     try:
@@ -97,6 +101,9 @@ GPU_CASES = CASES + [
     (1, 128, 128, 16, 16, 3, 1, 1),
     (2, 24, 40, 256, 16, 1, 1, 0),
     (4, 128, 128, 32, 128, 3, 1, 1),   # 512 tiles of 128x128
+    (2, 64, 64, 16, 32, 3, 2, 1),      # DLA level1 shape (stride-2 dgrad on the 256x32 tile)
+    (2, 32, 32, 64, 128, 1, 2, 0),     # ResNet downsample 1x1/s2
+    (4, 128, 128, 128, 256, 3, 2, 1),  # stride-2 dgrad on 128x128 tiles
 ]
 
 
