@@ -107,6 +107,11 @@ int omni_preprocess(const unsigned char* img, float* out, int N, int H, int W, i
  * out_val / out_idx: (rows, k); slots >= min(k,n) hold -inf / -1.  k <= 2048. */
 int omni_topk_rows(const float* keys, int rows, int n, long long pitch, int estride, int k, float* out_val,
                    int* out_idx, void* stream);
+/* The same for `nseg` (<= 8) column segments of every row in one launch: the per-FPN-level pre-NMS top-k of
+ * detectron2 find_top_rpn_proposals (one sort per level and image upstream).  seg_off / seg_n are HOST int arrays;
+ * out_val / out_idx: (rows, nseg, k), indices relative to the segment start. */
+int omni_topk_segments(const float* keys, int rows, long long pitch, int estride, int nseg, const int* seg_off,
+                       const int* seg_n, int k, float* out_val, int* out_idx, void* stream);
 
 /* Greedy NMS (torchvision.ops.nms semantics: suppress iff IoU > thr, areas (x2-x1)*(y2-y1)) for Q
  * independent score-sorted problems; detectron2 batched_nms = one problem per (image, level) /

@@ -79,11 +79,21 @@ __device__ __forceinline__ void colsum16(const float* __restrict__ partial, int 
     const int t = threadIdx.x, cl = t & 15, rg = t >> 4;
     const int c = c0 + cl;
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int blk = rg; blk < nblk; blk += 16) {
+    if (c < C) {
+        // 4 independent loads in flight per quantity: this loop is pure memory latency
+        int blk = rg;
+        for (; blk + 48 < nblk; blk += 64) {
+            const float* q = partial + (long)blk * 2 * C + c;
+            const float a0 = q[0], a1 = q[(long)32 * C], a2 = q[(long)64 * C], a3 = q[(long)96 * C];
+            const float b0 = q[C], b1 = q[(long)33 * C], b2 = q[(long)65 * C], b3 = q[(long)97 * C];
+            a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; blk < nblk; blk += 16) {
             a += (double)partial[(long)blk * 2 * C + c];
             b += (double)partial[(long)blk * 2 * C + C + c];
         }
+    }
     sm0[t] = a;
     sm1[t] = b;
     __syncthreads();
@@ -315,8 +325,9 @@ inline int ew_grid(long total) {
     return (int)(g < 1 ? 1 : g);
 }
 inline int red_grid(int P, int C) {
+    // >= 16 pixel rows per thread before another workgroup is worth its partial-sum row; <= 512 workgroups
     const int rows = 256 / (C >> 2);
-    long g = ((long)P + rows - 1) / rows;
+    long g = ((long)P + 16L * rows - 1) / (16L * rows);
     if (g > 512) g = 512;
     return (int)(g < 1 ? 1 : g);
 }

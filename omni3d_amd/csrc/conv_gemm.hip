@@ -601,8 +601,8 @@ int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* ou
         const long tiles = ((M + 63) / 64) * ((K + 63) / 64);
         long splits = 1;
         const long nslab = (Kd + 31) / 32;
-        if (tiles < 192 && nslab >= 16 && ldo == K && g_variant != 5) {
-            splits = (512 + tiles - 1) / tiles;
+        if (tiles < (g_variant == 8 ? 192 : 512) && nslab >= 16 && ldo == K && g_variant != 5) {
+            splits = ((g_variant == 8 ? 512 : 1024) + tiles - 1) / tiles;
             if (splits > nslab / 8) splits = nslab / 8;
             if (splits > 32) splits = 32;
             if (splits < 1) splits = 1;
@@ -645,8 +645,8 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
         const long tiles = ((M + 63) / 64) * ((C + 63) / 64);
         long splits = 1;
         const long nslab = (Kd + 31) / 32;
-        if (tiles * ncls < 192 && nslab >= 16 && lddx == C && !accumulate && g_variant != 5) {
-            splits = (512 + tiles * ncls - 1) / (tiles * ncls);
+        if (tiles * ncls < (g_variant == 8 ? 192 : 512) && nslab >= 16 && lddx == C && !accumulate && g_variant != 5) {
+            splits = ((g_variant == 8 ? 512 : 1024) + tiles * ncls - 1) / (tiles * ncls);
             if (splits > nslab / 8) splits = nslab / 8;
             if (splits > 32) splits = 32;
             if (splits < 1) splits = 1;

@@ -35,8 +35,15 @@ __device__ __forceinline__ float key_value(unsigned long long k) {
 }
 __device__ __forceinline__ int key_index(unsigned long long k) { return (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)); }
 
+// Column segments of a row: segment s covers elements [off[s], off[s] + n[s]); one workgroup per (row, segment).
+constexpr int TOPK_MAXSEG = 8;
+struct SegP {
+    int S;
+    int off[TOPK_MAXSEG], n[TOPK_MAXSEG];
+};
+
 // keys: (rows, n) with row pitch `pitch` and element stride `estride` (floats).
-__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __restrict__ keys, int n, long pitch,
+__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __restrict__ keys, SegP seg, long pitch,
                                                                  int estride, int k, float* __restrict__ out_val,
                                                                  int* __restrict__ out_idx) {
     __shared__ unsigned hist[256];
@@ -44,7 +51,9 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __
     __shared__ unsigned long long s_prefix;
     __shared__ int s_need, s_count;
     const int t = threadIdx.x;
-    const float* row = keys + (long)blockIdx.x * pitch;
+    const int rowid = (int)blockIdx.x / seg.S, sid = (int)blockIdx.x - rowid * seg.S;
+    const int n = seg.n[sid];
+    const float* row = keys + (long)rowid * pitch + (long)seg.off[sid] * estride;
     const int kk = k < n ? k : n;
     int kpad = 1;
     while (kpad < kk) kpad <<= 1;
@@ -149,49 +158,58 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ 
     mask[((long)q * nmax + i) * words + cb] = bits;
 }
 
-__global__ void __launch_bounds__(64) nms_scan_kernel(const unsigned long long* __restrict__ mask,
-                                                      const int* __restrict__ counts, const int* __restrict__ valid,
-                                                      int nmax, int words, int* __restrict__ keep) {
-    const int q = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                        const int* __restrict__ counts, const int* __restrict__ valid,
+                                                        int nmax, int words, int* __restrict__ keep) {
+    // One 16-wave workgroup per problem.  Per 64-box chunk: wave 0 resolves the chunk greedily (the only serial
+    // part: 64 shuffle steps), then the 16 waves OR the mask rows of the kept boxes (4 rows each -- the row loads
+    // are the latency that dominated the one-wave version) into per-wave partials, combined in LDS into the
+    // running `removed` words (<= 128 words = 8192 boxes).
+    constexpr int MAXW = 128;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = counts ? counts[q] : nmax;
     __shared__ unsigned long long s_alive;
-    // removed word w is owned by lane w % 64 (words <= 64 * WPL)
-    constexpr int WPL = 2;  // up to 128 words = 8192 boxes
-    unsigned long long removed[WPL];
-#pragma unroll
-    for (int w = 0; w < WPL; ++w) removed[w] = 0ull;
+    __shared__ unsigned long long s_removed[MAXW];
+    __shared__ unsigned long long s_part[16][MAXW];
+    if (tid < MAXW) s_removed[tid] = 0ull;
+    __syncthreads();
     const int nchunks = (n + 63) / 64;
     for (int c = 0; c < nchunks; ++c) {
-        const int i = c * 64 + lane;
-        const bool in = i < n;
-        // start state of this chunk: not removed by earlier keeps, and a valid box
-        unsigned long long rem_c = 0ull;
-#pragma unroll
-        for (int w = 0; w < WPL; ++w) {
-            const unsigned long long v = __shfl(removed[w], c & 63, 64);
-            if ((c >> 6) == w) rem_c = v;
-        }
-        const bool ok = in && (valid == nullptr || valid[(long)q * nmax + i] != 0);
-        unsigned long long alive = __ballot(ok) & ~rem_c;
-        const unsigned long long diag = in ? mask[((long)q * nmax + i) * words + c] : 0ull;
-        // intra-chunk greedy resolution (lane 0 walks the 64 rows; rows arrive via shuffles)
-        for (int r = 0; r < 64; ++r) {
-            const unsigned long long d = __shfl(diag, r, 64);
-            if ((alive >> r) & 1ull) alive &= ~d;
-        }
-        if (in) keep[(long)q * nmax + i] = (int)((alive >> lane) & 1ull);
-        if (lane == 0) s_alive = alive;
-        __syncthreads();
-        alive = s_alive;
-        // kept rows suppress later chunks
-        for (int r = 0; r < 64; ++r) {
-            if (!((alive >> r) & 1ull)) continue;
-            const long rowbase = ((long)q * nmax + c * 64 + r) * words;
-#pragma unroll
-            for (int w = 0; w < WPL; ++w) {
-                const int word = w * 64 + lane;
-                if (word > c && word < words && word * 64 < n) removed[w] |= mask[rowbase + word];
+        if (wave == 0) {
+            const int i = c * 64 + lane;
+            const bool in = i < n;
+            // start state of this chunk: not removed by earlier keeps, and a valid box
+            const bool ok = in && (valid == nullptr || valid[(long)q * nmax + i] != 0);
+            unsigned long long alive = __ballot(ok) & ~s_removed[c];
+            const unsigned long long diag = in ? mask[((long)q * nmax + i) * words + c] : 0ull;
+            for (int r = 0; r < 64; ++r) {
+                const unsigned long long d = __shfl(diag, r, 64);
+                if ((alive >> r) & 1ull) alive &= ~d;
             }
+            if (in) keep[(long)q * nmax + i] = (int)((alive >> lane) & 1ull);
+            if (lane == 0) s_alive = alive;
+        }
+        __syncthreads();
+        const unsigned long long alive = s_alive;
+        unsigned long long part0 = 0ull, part1 = 0ull;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            if ((alive >> r) & 1ull) {
+                const long rowbase = ((long)q * nmax + c * 64 + r) * words;
+                const int w0 = lane, w1 = 64 + lane;
+                if (w0 > c && w0 < words && w0 * 64 < n) part0 |= mask[rowbase + w0];
+                if (w1 > c && w1 < words && w1 * 64 < n) part1 |= mask[rowbase + w1];
+            }
+        }
+        s_part[wave][lane] = part0;
+        s_part[wave][64 + lane] = part1;
+        __syncthreads();
+        if (tid < MAXW) {
+            unsigned long long v = s_removed[tid];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v |= s_part[k][tid];
+            s_removed[tid] = v;
         }
         __syncthreads();
     }
@@ -207,7 +225,29 @@ int omni_topk_rows(const float* keys, int rows, int n, long long pitch, int estr
                    void* stream) {
     if (rows < 0 || n < 0 || k <= 0 || k > TOPK_MAXK || estride <= 0) return OMNI_ERR_ARG;
     if (rows == 0) return OMNI_OK;
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TOPK_THREADS), 0, (hipStream_t)stream, keys, n, (long)pitch,
+    SegP seg;
+    seg.S = 1;
+    for (int i = 0; i < TOPK_MAXSEG; ++i) { seg.off[i] = 0; seg.n[i] = n; }
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TOPK_THREADS), 0, (hipStream_t)stream, keys, seg, (long)pitch,
+                       estride, k, out_val, out_idx);
+    return omni_launch_status();
+}
+
+// Same, for `nseg` (<= 8) column segments of every row in ONE launch (the per-FPN-level pre-NMS top-k of
+// find_top_rpn_proposals): segment s covers elements [seg_off[s], seg_off[s] + seg_n[s]) (host int arrays).
+// out_val / out_idx: (rows, nseg, k); indices are relative to the segment start.
+int omni_topk_segments(const float* keys, int rows, long long pitch, int estride, int nseg, const int* seg_off,
+                       const int* seg_n, int k, float* out_val, int* out_idx, void* stream) {
+    if (rows < 0 || nseg <= 0 || nseg > TOPK_MAXSEG || k <= 0 || k > TOPK_MAXK || estride <= 0) return OMNI_ERR_ARG;
+    if (rows == 0) return OMNI_OK;
+    SegP seg;
+    seg.S = nseg;
+    for (int i = 0; i < TOPK_MAXSEG; ++i) {
+        seg.off[i] = i < nseg ? seg_off[i] : 0;
+        seg.n[i] = i < nseg ? seg_n[i] : 0;
+        if (seg.off[i] < 0 || seg.n[i] < 0) return OMNI_ERR_ARG;
+    }
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows * nseg), dim3(TOPK_THREADS), 0, (hipStream_t)stream, keys, seg, (long)pitch,
                        estride, k, out_val, out_idx);
     return omni_launch_status();
 }
@@ -225,7 +265,7 @@ int omni_nms_sorted(const float* boxes, const int* counts, const int* valid, int
     hipMemsetAsync(keep, 0, sizeof(int) * (size_t)Q * nmax, st);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, Q), dim3(64), 0, st, boxes, counts, nmax, words, iou_thr,
                        mask_ws);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(Q), dim3(64), 0, st, (const unsigned long long*)mask_ws, counts, valid, nmax,
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(Q), dim3(1024), 0, st, (const unsigned long long*)mask_ws, counts, valid, nmax,
                        words, keep);
     return omni_launch_status();
 }

@@ -116,8 +116,10 @@ class RPNWithIgnore(nn.Module):
         thr = self.anchor_thresholds
         m = det.rpn_match(anchors, targets.gt, targets.gt_off, E, (thr[0], thr[-1]), self.anchor_labels, True)
         kpos = max(int(self.batch_size_per_image * self.positive_fraction), 1)
-        pv, pi = select.topk_rows(m["key_pos"], kpos)
-        nv, ni = select.topk_rows(m["key_neg"], self.batch_size_per_image)
+        # one launch for both draws: rows [0, B) = positive keys, [B, 2B) = negative keys (sorted => prefix = top-kpos)
+        kv, ki = select.topk_rows(m["keys"], max(kpos, self.batch_size_per_image))
+        pv, pi = kv[:B, :kpos].contiguous(), ki[:B, :kpos].contiguous()
+        nv, ni = kv[B:, :self.batch_size_per_image].contiguous(), ki[B:, :self.batch_size_per_image].contiguous()
         labels, counts = det.rpn_finalize_labels(anchors, targets.gt_off, targets.ign, targets.ign_off, m, pv, pi, nv, ni,
                                                  self.batch_size_per_image, self.ignore_thresh)
         return labels, m["matched_idx"]
@@ -153,15 +155,10 @@ class RPNWithIgnore(nn.Module):
         # (B, L*kmax) block is L*B equally sized, score-sorted NMS problems: ONE decode, ONE NMS launch
         L = len(hw_list)
         kmax = min(pre, max(H * W * 3 for H, W in hw_list))
-        vals, idxs = [], []
-        off = 0
-        for l, (H, W) in enumerate(hw_list):
-            n = H * W * 3
-            v, i = select.topk_rows(logits[:, off:off + n], kmax)
-            vals.append(v); idxs.append(i)
-            off += n
-        scores = torch.cat(vals, 1)
-        idx = torch.cat(idxs, 1).contiguous()
+        seg_n = [H * W * 3 for H, W in hw_list]
+        seg_off = [sum(seg_n[:l]) for l in range(L)]
+        scores, idx = select.topk_segments(logits, seg_off, seg_n, kmax)         # all levels, one launch
+        scores, idx = scores.view(B, L * kmax), idx.view(B, L * kmax)
         key = (L, kmax, str(idx.device))
         if getattr(self, "_slot_key", None) != key:
             self._slot_level = torch.arange(L, dtype=torch.int32, device=idx.device).repeat_interleave(kmax).contiguous()

@@ -52,13 +52,14 @@ def rpn_match(anchors, gt, gt_off, expo, thresholds=(0.05, 0.05), labels=(0, -1,
     o = {
         "matched_val": _empty((B, A), torch.float32, anchors), "matched_idx": _empty((B, A), torch.int32, anchors),
         "match_label": _empty((B, A), torch.int8, anchors), "gt_best_idx": _empty((max(G, 1),), torch.int32, anchors),
-        "key_pos": _empty((B, A), torch.float32, anchors), "key_neg": _empty((B, A), torch.float32, anchors),
+        "keys": _empty((2 * B, A), torch.float32, anchors),   # rows [0, B) positive keys, [B, 2B) negative keys
     }
     bits = _empty((max(G, 1),), torch.int32, anchors)
     L.call("omni_rpn_match", _lib.ptr(anchors), A, _lib.ptr(gt), _lib.ptr(gt_off), B, G, float(thresholds[0]),
            float(thresholds[1]), int(labels[0]), int(labels[1]), int(labels[2]), int(allow_low_quality), _lib.ptr(expo),
            float(eps), _lib.ptr(o["matched_val"]), _lib.ptr(o["matched_idx"]), _lib.ptr(o["match_label"]), _lib.ptr(bits),
-           _lib.ptr(o["gt_best_idx"]), _lib.ptr(o["key_pos"]), _lib.ptr(o["key_neg"]), _lib.stream_of(anchors))
+           _lib.ptr(o["gt_best_idx"]), _lib.ptr(o["keys"][:B]), _lib.ptr(o["keys"][B:]), _lib.stream_of(anchors))
+    o["key_pos"], o["key_neg"] = o["keys"][:B], o["keys"][B:]
     return o
 
 

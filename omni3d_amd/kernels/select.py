@@ -23,6 +23,25 @@ def topk_rows(keys, k, n=None, pitch=None, estride=1):
     return vals, idx
 
 
+def topk_segments(keys, seg_off, seg_n, k):
+    """keys (rows, n) float32; -> (vals, idx) of shape (rows, nseg, k): the sorted top-k of every column segment
+    [seg_off[s], seg_off[s] + seg_n[s]) of every row, ONE launch; indices are relative to the segment start."""
+    import ctypes
+    rows = keys.shape[0]
+    L = _lib.get()
+    if not keys.is_cuda and not L.emulated:
+        raise _lib.OmniHipError("omni3d_amd ops run on the GPU only")
+    S = len(seg_off)
+    vals = torch.empty((rows, S, k), dtype=torch.float32, device=keys.device)
+    idx = torch.empty((rows, S, k), dtype=torch.int32, device=keys.device)
+    offs = (ctypes.c_int * S)(*[int(v) for v in seg_off])
+    ns = (ctypes.c_int * S)(*[int(v) for v in seg_n])
+    L.call("omni_topk_segments", _lib.ptr(keys), rows, keys.stride(0), keys.stride(1) if keys.shape[1] > 1 else 1, S,
+           ctypes.cast(offs, ctypes.c_void_p), ctypes.cast(ns, ctypes.c_void_p), k, _lib.ptr(vals), _lib.ptr(idx),
+           _lib.stream_of(keys))
+    return vals, idx
+
+
 def nms_sorted(boxes, iou_thr, counts=None, valid=None):
     """boxes (Q, nmax, 4) sorted by descending score -> keep (Q, nmax) int32."""
     boxes = boxes.contiguous()

@@ -80,7 +80,8 @@ def _run_pool(dev):
 
 
 @pytest.mark.parametrize("cfg", [(2, 16, 5, 7, True, False), (1, 64, 4, 4, True, True), (3, 8, 3, 3, False, False),
-                                 (2, 512, 2, 2, False, True)])
+                                 (2, 512, 2, 2, False, True),
+                                 (1, 8, 384, 384, True, False)])     # 72 partial blocks: the unrolled partial-sum loop
 def test_bn_emulated(emu_lib, cfg):
     _run_bn("cpu", *cfg)
 
@@ -91,7 +92,7 @@ def test_pool_emulated(emu_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(4, 16, 64, 64, True, False), (4, 128, 32, 32, True, True), (2, 512, 16, 16, False, False),
-                                 (2, 1024, 4, 4, True, True)])
+                                 (2, 1024, 4, 4, True, True), (4, 16, 512, 512, True, False), (4, 64, 128, 128, True, True)])
 def test_bn_gpu(hip_lib, cfg):
     _run_bn("cuda", *cfg)
 

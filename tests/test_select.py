@@ -60,6 +60,31 @@ def _nms_case(dev, Q, nmax, thr, seed):
         assert (keep[q, n:] == 0).all()
 
 
+def _segments_case(dev, rows, seg_n, k, seed):
+    """one launch over column segments == topk_rows on each slice (the per-FPN-level pre-NMS top-k)"""
+    from omni3d_amd.kernels import select
+    g = torch.Generator().manual_seed(seed)
+    n = sum(seg_n)
+    keys = torch.randn(rows, n, generator=g)
+    keys[:, ::7] = keys[:, 3:4]                       # ties across the row
+    keys = keys.to(dev)
+    off = [sum(seg_n[:i]) for i in range(len(seg_n))]
+    v, i = select.topk_segments(keys, off, seg_n, k)
+    assert v.shape == (rows, len(seg_n), k)
+    for s, (o, m) in enumerate(zip(off, seg_n)):
+        rv, ri = select.topk_rows(keys[:, o:o + m], k)
+        assert torch.equal(v[:, s], rv) and torch.equal(i[:, s], ri), s
+
+
+def test_topk_segments_emulated(emu_lib):
+    _segments_case("cpu", 2, [700, 190, 48, 12, 3], 64, 0)
+
+
+@pytest.mark.gpu
+def test_topk_segments_gpu(hip_lib):
+    _segments_case("cuda", 4, [49152, 12288, 3072, 768, 192], 2000, 1)
+
+
 def test_topk_emulated(emu_lib):
     _topk_case("cpu", 2, 5000, 300, 0)
     _topk_case("cpu", 2, 700, 2000, 1)            # k > n
