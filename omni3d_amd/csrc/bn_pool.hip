@@ -44,7 +44,28 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
     float4 mu = f4(0.f), rs = f4(0.f);
     if (MODE == 1 && active) { mu = ld4(mean_rstd + 4 * col); rs = ld4(mean_rstd + C + 4 * col); }
     if (active) {
-        for (long p = (long)blockIdx.x * rows + row; p < P; p += (long)gridDim.x * rows) {
+        const long step = (long)gridDim.x * rows;
+        long p = (long)blockIdx.x * rows + row;
+        // 4 pixel rows per trip: the loads of a trip are independent, so 4 (MODE 1: up to 12) are in flight per lane
+        for (; p + 3 * step < P; p += 4 * step) {
+            float4 xv[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xv[u] = ld4(x + (p + u * step) * C + 4 * col);
+            if (MODE == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a0 = a0 + xv[u]; a1 = a1 + xv[u] * xv[u]; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] = ld4(dy + (p + u * step) * C + 4 * col);
+                if (relu) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) g[u] = mask4(g[u], ld4(y + (p + u * step) * C + 4 * col));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a0 = a0 + g[u]; a1 = a1 + g[u] * ((xv[u] - mu) * rs); }
+            }
+        }
+        for (; p < P; p += step) {
             const long off = p * C + 4 * col;
             const float4 xv = ld4(x + off);
             if (MODE == 0) {

@@ -72,12 +72,15 @@ class FlattenLinear(nn.Module):
 
 
 class BatchNorm2d(nn.BatchNorm2d):
+    # RCNN3D sets this and bumps every `num_batches_tracked` of the model with ONE multi-tensor add per step
+    defer_counter = False
+
     def forward(self, x, residual=None, relu=False):
         if self.training:
             y = HF.batch_norm_train(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                     self.running_var if self.track_running_stats else None, residual, relu, self.eps,
                                     self.momentum)
-            if self.track_running_stats and self.num_batches_tracked is not None:
+            if self.track_running_stats and self.num_batches_tracked is not None and not self.defer_counter:
                 self.num_batches_tracked += 1
             return y
         from ...kernels import bnpool

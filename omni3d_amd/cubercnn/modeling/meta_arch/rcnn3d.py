@@ -79,6 +79,7 @@ class RCNN3D(nn.Module):
         if packed is None:
             packed = self.prepack(batched_inputs)
         features = self.backbone(images.tensor)
+        self._bump_bn_counters()
         proposals, proposal_losses = self.proposal_generator(images, features, None, targets=packed)
         _, detector_losses = self.roi_heads(images, features, proposals, None, None, None, packed=packed)
         losses = {}
@@ -87,6 +88,18 @@ class RCNN3D(nn.Module):
         if has_event_storage():
             self.flush_logs(get_event_storage())
         return losses
+
+    def _bump_bn_counters(self):
+        """`num_batches_tracked += 1` of every training-mode BatchNorm in one multi-tensor launch (39 adds otherwise)."""
+        from ..layers import BatchNorm2d
+        bns = self.__dict__.get("_bn_modules")
+        if bns is None:
+            bns = self.__dict__["_bn_modules"] = [m for m in self.modules() if isinstance(m, BatchNorm2d)]
+            for m in bns:
+                m.defer_counter = True
+        live = [m.num_batches_tracked for m in bns if m.training and m.track_running_stats and m.num_batches_tracked is not None]
+        if live:
+            torch._foreach_add_(live, 1)
 
     def flush_logs(self, storage):
         """One device->host readback for all logged scalars (the reference does ~16 .item() syncs)."""

@@ -170,6 +170,25 @@ def _run_roi_align(dev):
         assert (d.cpu().permute(0, 3, 1, 2) - fg).abs().max() < 2e-5
 
 
+def _run_roi_align_big(dev):
+    """a footprint wider than the separable kernel's LDS tables (144 px) takes the per-sample fallback"""
+    from omni3d_amd.kernels import det
+    g = torch.Generator().manual_seed(10)
+    C, P = 4, 7
+    feat = torch.randn(1, C, 150, 150, generator=g)
+    rois = torch.tensor([[2.0, 3.0, 149.0, 148.0], [10.0, 20.0, 40.0, 30.0]])
+    pool = U.ROIPooler(P, [1.0], 0, "ROIAlignV2", canonical_box_size=56, canonical_level=0)
+    fr = feat.clone().requires_grad_(True)
+    ref = pool([fr], [Boxes(rois)])
+    dout = torch.randn(2, P, P, C, generator=g)
+    ref.backward(dout.permute(0, 3, 1, 2))
+    lv = torch.zeros(2, dtype=torch.int32, device=dev)
+    bidx = torch.zeros(2, dtype=torch.int32, device=dev)
+    dfe = [torch.zeros(1, 150, 150, C, device=dev)]
+    det.roi_align_bwd(dfe, [1.0], rois.to(dev), bidx, lv, P, dout.to(dev))
+    assert (dfe[0].cpu().permute(0, 3, 1, 2) - fr.grad).abs().max() < 2e-5
+
+
 def _run_box_loss(dev):
     from omni3d_amd.kernels import det
     g = torch.Generator().manual_seed(2)
@@ -296,6 +315,7 @@ def test_roi_sample_emulated(emu_lib):
 
 def test_roi_align_emulated(emu_lib):
     _run_roi_align("cpu")
+    _run_roi_align_big("cpu")
 
 
 def test_box_loss_emulated(emu_lib):
@@ -317,6 +337,7 @@ def test_det_kernels_gpu(hip_lib):
     _run_rpn_loss("cuda")
     _run_roi_sample("cuda")
     _run_roi_align("cuda")
+    _run_roi_align_big("cuda")
     _run_box_loss("cuda")
     _run_cube("cuda")
     _run_sgd("cuda")
