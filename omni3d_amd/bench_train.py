@@ -59,7 +59,7 @@ def run_train(args, world, rank):
     opt.skip_flag = flag
     loss_log = []
 
-    def step():
+    def eager_step():
         opt.zero_grad()
         flag.zero_()
         losses = model(batch, packed)
@@ -70,6 +70,27 @@ def run_train(args, world, rank):
         opt.step()
         loss_log.append(total.detach())
 
+    # zero_grad + forward + losses + backward replayed as one hipGraph (OMNI_BENCH_GRAPH=0: eager launches);
+    # all-reduce / non-finite scan / SGD update stay eager (host-side learning rate)
+    graphed, graph_note = None, "eager (OMNI_BENCH_GRAPH=0)"
+    if os.environ.get("OMNI_BENCH_GRAPH", "1") != "0":
+        try:
+            from omni3d_amd.cubercnn.solver.graphed import GraphedForwardBackward
+            graphed = GraphedForwardBackward(model, opt, batch, packed)
+            graph_note = "hipGraph replay of zero_grad+fwd+losses+bwd"
+        except Exception as e:   # capture refused: report it, measure the eager path
+            graphed, graph_note = None, f"eager (capture failed: {type(e).__name__}: {str(e)[:200]})"
+
+    def graph_step():
+        flag.zero_()
+        _, total = graphed()
+        opt.all_reduce_grads()
+        opt.check_nonfinite(flag)
+        opt.step()
+        loss_log.append(total.clone())
+
+    step = graph_step if graphed is not None else eager_step
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -79,6 +100,7 @@ def run_train(args, world, rank):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enqueue = time.perf_counter() - t0       # host time to enqueue the K steps (diagnostic: < dt means GPU-bound)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -98,6 +120,8 @@ def run_train(args, world, rank):
         "config": {"workload": f"cubercnn_{MODEL_NAME} train step, batch 4/GPU, synthetic Omni3D 512x512 (8 GT/img), "
                                "fwd+10 losses+bwd+allreduce+SGD, random-init weights",
                    "global_batch": IMS_PER_GPU * world, "image": "512x512", "parallelism": f"dp{world} (flat-bucket RCCL all-reduce)"},
+        "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
+        "launch_mode": graph_note,
         "step_mfma_frac": step_tf / FP32_MFMA_PEAK_TF,
         "step_algorithmic_tflops_per_gpu": step_tf,
         "loss_first_last": [final_losses[0], final_losses[-1]],

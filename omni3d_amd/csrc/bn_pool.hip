@@ -417,7 +417,7 @@ int omni_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, 
     if ((C & 3) || H < 2 || W < 2) return OMNI_ERR_ARG;
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     if (total == 0) return OMNI_OK;
-    if ((H & 1) || (W & 1)) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * H * W * C, (hipStream_t)stream);
+    if ((H & 1) || (W & 1)) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, (hipStream_t)stream);
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C);
     return omni_launch_status();
 }
@@ -434,7 +434,7 @@ int omni_subsample2_fwd(const float* x, float* y, int N, int H, int W, int C, vo
 int omni_subsample2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
     if (C & 3) return OMNI_ERR_ARG;
     const long total = (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 4);
-    hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * H * W * C, (hipStream_t)stream);
+    omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, (hipStream_t)stream);
     if (total == 0) return OMNI_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(subsample2_kernel<1>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy,
                        dx, N, H, W, C);

@@ -99,7 +99,7 @@ extern "C" {
 int omni_box_loss_fwd(const float* pred, int ldp, int R, int K, const int* cls, const float* prop, const float* gt,
                       const int* gt_row, float wx, float wy, float ww, float wh, double* sums, void* stream) {
     if (R < 0 || K <= 0 || K + 1 > 128 || ldp < 5 * K + 1) return OMNI_ERR_ARG;
-    hipMemsetAsync(sums, 0, sizeof(double) * 7, (hipStream_t)stream);
+    omni_memset_async(sums, 0, sizeof(double) * 7, (hipStream_t)stream);
     if (R == 0) return OMNI_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(box_loss_kernel<0>), dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, pred, ldp,
                        R, K, cls, prop, gt, gt_row, wx, wy, ww, wh, sums, (const float*)nullptr, (const float*)nullptr,

@@ -607,7 +607,7 @@ int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* ou
             if (splits > 32) splits = 32;
             if (splits < 1) splits = 1;
         }
-        if (splits > 1) hipMemsetAsync(out, 0, sizeof(float) * (size_t)M * K, st);
+        if (splits > 1) omni_memset_async(out, 0, sizeof(float) * (size_t)M * K, st);
         OMNI_FWD(64, 64, 2, 2, tiles, splits);
         if (splits > 1 && relu) {
             const long n4 = M * K / 4;
@@ -651,7 +651,7 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
             if (splits > 32) splits = 32;
             if (splits < 1) splits = 1;
         }
-        if (splits > 1) hipMemsetAsync(dx, 0, sizeof(float) * (size_t)N * H * W * C, st);
+        if (splits > 1) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, st);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<64, 64, 2, 2, 32>), dim3((unsigned)tiles, (unsigned)splits, ncls),
                            dim3(256), 0, st, p);
     } else if (C > 32) {
@@ -675,7 +675,7 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
     const long P = (long)N * p.OH * p.OW;
     const int Nn = R * S * C;
     if (P == 0) {
-        if (!accumulate) hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
+        if (!accumulate) omni_memset_async(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
         return OMNI_OK;
     }
     constexpr int WBK = 32;
@@ -694,7 +694,7 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
     int pps = (int)((P + splits - 1) / splits);
     pps = (pps + WBK - 1) / WBK * WBK;
     splits = (P + pps - 1) / pps;
-    if (splits > 1 && !accumulate) hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
+    if (splits > 1 && !accumulate) omni_memset_async(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
 #define OMNI_WGRAD(BM_, BN_, WM_, WN_)                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<BM_, BN_, WM_, WN_, WBK>), dim3(tiles, (unsigned)splits), dim3(256), 0, \
                        (hipStream_t)stream, p, pps)

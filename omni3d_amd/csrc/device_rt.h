@@ -24,6 +24,31 @@ static inline int omni_launch_status() {
     return e == hipSuccess ? OMNI_OK : OMNI_ERR_LAUNCH;
 }
 
+// Byte fill as a KERNEL (not hipMemsetAsync): a kernel node is replayed faithfully when the training step is captured
+// into a hipGraph (cubercnn/solver/graphed.py); memset nodes were observed not to re-zero split-K / atomic
+// accumulators on replay on ROCm 7.2.
+static __global__ void __launch_bounds__(256) omni_fill_kernel(unsigned char* __restrict__ p, unsigned int pat4, size_t head,
+                                                               size_t n16, size_t n) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    uint4* body = reinterpret_cast<uint4*>(p + head);
+    const uint4 v = make_uint4(pat4, pat4, pat4, pat4);
+    for (size_t i = gid; i < n16; i += nthr) body[i] = v;
+    const unsigned char b = (unsigned char)(pat4 & 0xFFu);
+    for (size_t i = gid; i < head; i += nthr) p[i] = b;
+    for (size_t i = head + n16 * 16 + gid; i < n; i += nthr) p[i] = b;
+}
+static inline void omni_memset_async(void* ptr, int byte, size_t n, hipStream_t st) {
+    if (n == 0) return;
+    size_t head = (size_t)((16 - ((uintptr_t)ptr & 15)) & 15);
+    if (head > n) head = n;
+    const size_t n16 = (n - head) / 16;
+    const unsigned int b = (unsigned int)(byte & 0xFF), pat4 = b | (b << 8) | (b << 16) | (b << 24);
+    size_t g = (n16 + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(omni_fill_kernel, dim3((unsigned)g), dim3(256), 0, st, (unsigned char*)ptr, pat4, head, n16, n);
+}
+
 // wave-level reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -458,8 +458,8 @@ int omni_rpn_match(const float* anchors, int A, const float* gt, const int* gt_o
     if (A <= 0 || B <= 0 || G < 0) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (G > 0) {
-        hipMemsetAsync(gt_best_bits, 0, sizeof(int) * G, st);
-        hipMemsetAsync(gt_best_idx, 0x7f, sizeof(int) * G, st);
+        omni_memset_async(gt_best_bits, 0, sizeof(int) * G, st);
+        omni_memset_async(gt_best_idx, 0x7f, sizeof(int) * G, st);
     }
     dim3 grid((A + 255) / 256, B);
     hipLaunchKernelGGL(rpn_match1_kernel, grid, dim3(256), 0, st, anchors, A, gt, gt_off, matched_val, matched_idx,
@@ -477,7 +477,7 @@ int omni_rpn_finalize_labels(const float* anchors, int A, int B, const int* gt_o
                              int batch_per_image, float ignore_thresh, signed char* labels, int* counts, void* stream) {
     if (A <= 0 || B <= 0) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(labels, 0xFF, (size_t)A * B, st);
+    omni_memset_async(labels, 0xFF, (size_t)A * B, st);
     hipLaunchKernelGGL(rpn_finalize_kernel, dim3(B), dim3(256), 0, st, anchors, A, gt_off, ign, ign_off, match_label,
                        gt_best_idx, pos_val, pos_idx, neg_val, neg_idx, kpos, kneg, batch_per_image, ignore_thresh, labels,
                        counts);
@@ -504,7 +504,7 @@ int omni_rpn_loss_fwd(const void* const* level_ptrs, const int* level_hw, int nl
     Levels lv = make_levels(level_ptrs, level_hw, nlev);
     const int A = lv.a_off[nlev];
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(sums, 0, sizeof(double) * 6, st);
+    omni_memset_async(sums, 0, sizeof(double) * 6, st);
     const long tot = (long)B * A;
     if (tot == 0) return OMNI_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_kernel<0>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lv, lv,
@@ -524,7 +524,7 @@ int omni_rpn_loss_bwd(const void* const* level_ptrs, const void* const* dlevel_p
     const int A = lv.a_off[nlev];
     hipStream_t st = (hipStream_t)stream;
     for (int l = 0; l < nlev; ++l)
-        hipMemsetAsync(dlv.y[l], 0, sizeof(float) * (size_t)B * level_hw[l] * RPN_C, st);
+        omni_memset_async(dlv.y[l], 0, sizeof(float) * (size_t)B * level_hw[l] * RPN_C, st);
     const long tot = (long)B * A;
     if (tot == 0) return OMNI_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_kernel<1>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lv, dlv,

@@ -261,8 +261,8 @@ int omni_nms_sorted(const float* boxes, const int* counts, const int* valid, int
     if (Q == 0 || nmax == 0) return OMNI_OK;
     const int words = (nmax + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(mask_ws, 0, sizeof(unsigned long long) * (size_t)Q * nmax * words, st);
-    hipMemsetAsync(keep, 0, sizeof(int) * (size_t)Q * nmax, st);
+    omni_memset_async(mask_ws, 0, sizeof(unsigned long long) * (size_t)Q * nmax * words, st);
+    omni_memset_async(keep, 0, sizeof(int) * (size_t)Q * nmax, st);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, Q), dim3(64), 0, st, boxes, counts, nmax, words, iou_thr,
                        mask_ws);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(Q), dim3(1024), 0, st, (const unsigned long long*)mask_ws, counts, valid, nmax,
