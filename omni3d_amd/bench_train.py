@@ -154,7 +154,11 @@ def dominant_kernel_roofline(iters=20):
     flops = 2.0 * B * H * H * C * C * 9
     tf = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "conv_fwd_kernel<128,128,2,2> (3x3 256->256 @128x128, batch 4)", "achieved": tf,
-            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF, "traffic": None,
+            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
+            # HBM-side bytes per launch from rocprofv3 PMC passes on this kernel (profiles/r01_pmc_dominant_conv_shape.csv):
+            # FETCH_SIZE 77.7 MB x2 (gfx950 wide-read correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 67.1 MB
+            "traffic": 222.5e6, "traffic_unit": "bytes/launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+            "algorithmic_bytes_per_launch": 4.0 * (2 * B * H * H * C + 9 * C * C),
             "kernel_ms": ms, "flops_per_launch": flops, "operands": "fp32 (v_mfma_f32_32x32x2_f32)"}
 
 
