@@ -72,6 +72,15 @@ class ROIPooler(nn.Module):
         levels = det.roi_levels(rois, self.min_level, self.max_level, float(self.canonical_box_size), self.canonical_level)
         return HF.roi_align(feats, self.scales, rois, batch_idx, levels, self.output_size)
 
+    def same_as(self, other):
+        return (self.output_size, self.scales, self.canonical_box_size, self.canonical_level) == \
+            (other.output_size, other.scales, other.canonical_box_size, other.canonical_level)
+
+    def forward_shared(self, feats, rois, batch_idx, per_image, first):
+        """-> (pooled features of all ROIs, pooled features of the first `first` ROIs of every image), one kernel pass."""
+        levels = det.roi_levels(rois, self.min_level, self.max_level, float(self.canonical_box_size), self.canonical_level)
+        return HF.roi_align_shared(feats, self.scales, rois, batch_idx, levels, self.output_size, per_image, first)
+
 
 @ROI_HEADS_REGISTRY.register()
 class ROIHeads3D(nn.Module):
@@ -160,36 +169,43 @@ class ROIHeads3D(nn.Module):
         if self.training:
             assert packed is not None
             sboxes, scls, sgt, siou, counts = self.label_and_sample_proposals(proposals, packed)
-            losses = self._forward_box_train(feats, sboxes, scls, sgt, packed)
-            losses.update(self._forward_cube_train(feats, sboxes, scls, sgt, packed))
+            x_box = x_cube = None
+            if self.box_pooler.same_as(self.cube_pooler):   # every Cube R-CNN config: pool once for both heads
+                B, S = scls.shape
+                x_box, x_cube = self.box_pooler.forward_shared(feats, sboxes.reshape(B * S, 4), self._batch_index(B, S, sboxes.device),
+                                                               S, self.fg_cap)
+            losses = self._forward_box_train(feats, sboxes, scls, sgt, packed, x_box)
+            losses.update(self._forward_cube_train(feats, sboxes, scls, sgt, packed, x_cube))
             return [], losses
         from .inference import roi_heads_inference
         return roi_heads_inference(self, images, feats, proposals, packed), {}
 
     def _batch_index(self, B, per_image, device):
+        cache = self.__dict__.setdefault("_bidx_cache", {})
         key = (B, per_image, str(device))
-        if getattr(self, "_bidx_key", None) != key:
-            self._bidx = torch.arange(B, dtype=torch.int32, device=device).repeat_interleave(per_image).contiguous()
-            self._bidx_key = key
-        return self._bidx
+        if key not in cache:
+            cache[key] = torch.arange(B, dtype=torch.int32, device=device).repeat_interleave(per_image).contiguous()
+        return cache[key]
 
     # ---- roi_heads.py:249-293 + fast_rcnn.py:145-194 ------------------------------------------------
-    def _forward_box_train(self, feats, sboxes, scls, sgt, packed):
+    def _forward_box_train(self, feats, sboxes, scls, sgt, packed, x=None):
         B, S = scls.shape
         rois = sboxes.reshape(B * S, 4)
-        x = self.box_pooler(feats, rois, self._batch_index(B, S, rois.device))
+        if x is None:
+            x = self.box_pooler(feats, rois, self._batch_index(B, S, rois.device))
         pred = self.box_predictor(self.box_head(x))
         return self.box_predictor.losses(pred, scls.reshape(-1), rois, packed, sgt.reshape(-1).clamp(min=0))
 
     # ---- roi_heads.py:326-768 (training path) ----------------------------------------------------
-    def _forward_cube_train(self, feats, sboxes, scls, sgt, packed):
+    def _forward_cube_train(self, feats, sboxes, scls, sgt, packed, x=None):
         B, S = scls.shape
         Fc = self.fg_cap
         rois = sboxes[:, :Fc].reshape(B * Fc, 4).contiguous()
         cls = scls[:, :Fc].reshape(-1).contiguous()
         gt_row = sgt[:, :Fc].reshape(-1).clamp(min=0).contiguous()
         bidx = self._batch_index(B, Fc, rois.device)
-        x = self.cube_pooler(feats, rois, bidx)
+        if x is None:
+            x = self.cube_pooler(feats, rois, bidx)
         head = self.cube_head(x)
         priors = self.priors_dims_per_cat.detach().reshape(self.num_classes, 2, 3).contiguous()
         red6, red = HF.cube_loss(head, self.num_classes, rois, cls, bidx, packed.Ks, packed.v2r, priors, packed.gt3d,

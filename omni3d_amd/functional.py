@@ -187,6 +187,45 @@ def roi_align(feats, scales, rois, batch_idx, levels, P):
     return _ROIAlign.apply(rois, batch_idx, levels, tuple(scales), P, *feats)
 
 
+class _ROIAlignShared(Function):
+    """Training: the cube head pools the SAME sampled boxes as the box head with an identical pooler (the reference builds
+    two ROIPoolers with the same resolution / sampling ratio / type, roi_heads.py:166-171, and calls them on the same
+    `proposal_boxes`, :267 and :362), restricted to the first `first` slots of each image's block of `per_image` ROIs.
+    One ROIAlign forward serves both heads -> (x_all, x_first); backward folds d(x_first) into d(x_all) and runs ONE
+    ROIAlign backward (one zero-fill + one atomic pass per level instead of two, and no autograd adds of the per-level
+    feature gradients)."""
+
+    @staticmethod
+    def forward(ctx, rois, batch_idx, levels, scales, P, per_image, first, *feats):
+        feats = [_cl(f) for f in feats]
+        nhwc = [f.permute(0, 2, 3, 1) for f in feats]
+        out = det.roi_align_fwd(nhwc, scales, rois, batch_idx, levels, P)          # (R, P, P, C)
+        R, C = out.shape[0], out.shape[3]
+        sub = out.view(R // per_image, per_image, P, P, C)[:, :first].reshape(-1, P, P, C)
+        ctx.save_for_backward(rois, batch_idx, levels)
+        ctx.meta = (scales, P, per_image, first, [tuple(f.shape) for f in nhwc])
+        return out.permute(0, 3, 1, 2), sub.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, d_all, d_first):
+        rois, batch_idx, levels = ctx.saved_tensors
+        scales, P, per_image, first, shapes = ctx.meta
+        d = _cl(d_all).permute(0, 2, 3, 1).clone() if d_all is not None else None
+        if d_first is not None:
+            df = _cl(d_first).permute(0, 2, 3, 1)
+            if d is None:
+                d = torch.zeros((rois.shape[0], P, P, df.shape[3]), dtype=torch.float32, device=df.device)
+            C = d.shape[3]
+            d.view(-1, per_image, P, P, C)[:, :first] += df.reshape(-1, first, P, P, C)
+        dfe = [torch.zeros(s, dtype=torch.float32, device=d.device) for s in shapes]
+        det.roi_align_bwd(dfe, scales, rois, batch_idx, levels, P, d)
+        return (None,) * 7 + tuple(t.permute(0, 3, 1, 2) for t in dfe)
+
+
+def roi_align_shared(feats, scales, rois, batch_idx, levels, P, per_image, first):
+    return _ROIAlignShared.apply(rois, batch_idx, levels, tuple(scales), P, per_image, first, *feats)
+
+
 def _scalar(t):
     return t.reshape(1).contiguous().float()
 
