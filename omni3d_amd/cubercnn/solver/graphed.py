@@ -26,7 +26,9 @@ class GraphedForwardBackward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: RCCL's watchdog thread (N > 1) and the autograd worker may issue HIP calls while this thread
+        # captures; only this thread's own unsafe calls should abort the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.losses, self.total = self._body()
 
     def _body(self):
