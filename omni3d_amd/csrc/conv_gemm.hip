@@ -40,6 +40,7 @@ struct ConvP {
     int relu;
     int accumulate;   // dgrad: out += result
     int splits;       // fwd/dgrad: reduction split over gridDim.y (atomic epilogue into a zeroed output)
+    long xb, wb, ob;  // fwd/wgrad: element strides of x / w / out between the gridDim.z problems of a batched GEMM
 };
 
 
@@ -119,6 +120,9 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
     constexpr int RPP = 256 / KQ;                      // tile rows covered per pass of the 256 threads
     constexpr int AI = (BM + RPP - 1) / RPP, BI = (BN + RPP - 1) / RPP;
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BKP];
+    p.x += (long)blockIdx.z * p.xb;       // batched GEMM (Winograd): problem blockIdx.z
+    p.w += (long)blockIdx.z * p.wb;
+    p.out += (long)blockIdx.z * p.ob;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int M = p.N * p.OH * p.OW, Kd = p.R * p.S * p.C;
@@ -452,6 +456,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
     constexpr int BF4 = BN / 4, BROWS = 256 / BF4, BI = BK / BROWS;
     static_assert(AROWS * AI == BK && BROWS * BI == BK && WAVES_M * WAVES_N == 4, "tile mapping");
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    p.x += (long)blockIdx.z * p.xb;       // batched GEMM (Winograd): problem blockIdx.z
+    p.w += (long)blockIdx.z * p.wb;
+    p.out += (long)blockIdx.z * p.ob;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int P = p.N * p.OH * p.OW, Nn = p.R * p.S * p.C;
@@ -703,6 +710,53 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
     else if (bm == 64) OMNI_WGRAD(64, 64, 2, 2);
     else OMNI_WGRAD(32, 128, 1, 4);
 #undef OMNI_WGRAD
+    return omni_launch_status();
+}
+
+// ---- batched GEMMs of the Winograd path (csrc/winograd.hip): `batch` independent dense problems in one launch ----
+// out[b] (M x K) = x[b] (M x C) * w[b] (K x C)^T
+int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch, int M, int C, int K, void* stream) {
+    if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3)) return OMNI_ERR_ARG;
+    if (M == 0) return OMNI_OK;
+    ConvP p{x, w, nullptr, out, M, 1, 1, C, 1, 1, K, 1, 1, 1, 0, C, K, 0, 0, 0, 1, (long)M * C, (long)K * C, (long)M * K};
+    const long t128 = (((long)M + 127) / 128) * ((K + 127) / 128);
+    if (K > 64 && t128 * batch >= 256)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<128, 128, 2, 2, 32>), dim3((unsigned)t128, 1, (unsigned)batch), dim3(256), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<64, 64, 2, 2, 32>),
+                           dim3((unsigned)((((long)M + 63) / 64) * ((K + 63) / 64)), 1, (unsigned)batch), dim3(256), 0,
+                           (hipStream_t)stream, p);
+    return omni_launch_status();
+}
+
+// dw[b] (K x C) = dy[b] (M x K)^T * x[b] (M x C)      (overwrites dw)
+int omni_gemm_batched_wgrad(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, void* stream) {
+    if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3) || (K & 3)) return OMNI_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0) {
+        omni_memset_async(dw, 0, sizeof(float) * (size_t)batch * K * C, st);
+        return OMNI_OK;
+    }
+    ConvP p{x, dy, nullptr, dw, M, 1, 1, C, 1, 1, K, 1, 1, 1, 0, C, 0, K, 0, 0, 1, (long)M * C, (long)M * K, (long)K * C};
+    constexpr int WBK = 32;
+    const bool wide = K > 64 && C > 64;
+    const int bm = wide ? 128 : 64, bn = wide ? 128 : 64;
+    const int tiles = ((K + bm - 1) / bm) * ((C + bn - 1) / bn);
+    long splits = (1024 + (long)tiles * batch - 1) / ((long)tiles * batch);
+    const long max_splits = ((long)M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int pps = (int)(((long)M + splits - 1) / splits);
+    pps = (pps + WBK - 1) / WBK * WBK;
+    splits = ((long)M + pps - 1) / pps;
+    if (splits > 1) omni_memset_async(dw, 0, sizeof(float) * (size_t)batch * K * C, st);
+    if (wide)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<128, 128, 2, 2, WBK>), dim3(tiles, (unsigned)splits, (unsigned)batch),
+                           dim3(256), 0, st, p, pps);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<64, 64, 2, 2, WBK>), dim3(tiles, (unsigned)splits, (unsigned)batch),
+                           dim3(256), 0, st, p, pps);
     return omni_launch_status();
 }
 

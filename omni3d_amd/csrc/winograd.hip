@@ -1,0 +1,241 @@
+// winograd.hip -- Winograd F(2x2, 3x3) transforms for the 3x3 / stride-1 / pad-1 convolutions with wide channel
+// counts (FPN output convs and the shared RPN conv on p2 / p3: 38 % of the step's direct-convolution flops).
+//
+// Reference call sites: detectron2 FPN output convs (built at /root/reference/cubercnn/modeling/backbone/dla.py:500-506)
+// and StandardRPNHead.conv (configs/Base.yaml:49) -- plain nn.Conv2d(256, 256, 3, padding=1) upstream.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A       per 4x4 input tile d (stride 2), 3x3 filter g, 2x2 output tile Y
+// The element-wise product summed over channels is 16 independent GEMMs  M[xi] (T x K) = V[xi] (T x C) * U[xi]^T (K x C),
+// T = N * H/2 * W/2 tiles, run by the batched entry points of conv_gemm.hip on the fp32 MFMA path: 2.25x fewer MFMA
+// flops than the direct implicit GEMM.  The kernels here are the HBM-bound transforms around those GEMMs (float4 per
+// lane along the channel dimension, consecutive lanes = consecutive channels):
+//   wino_in_kernel   d (NHWC, zero padding 1)    -> V  [16][T][C]     (B^T d B)
+//   wino_out_kernel  M [16][T][K] (+bias, ReLU)   -> y (NHWC)          (A^T M A)
+//   wino_dy_kernel   dy (NHWC)                    -> dM [16][T][K]     (A dy A^T, the adjoint of wino_out)
+//   wino_w_kernel    g [K][3][3][C]               -> U  [16][K][C]     (G g G^T); flip: U'[16][C][K] of the 180-degree
+//                                                    rotated, channel-transposed filter (data gradient = the same conv)
+//   wino_dw_kernel   dU [16][K][C]                -> dg [K][3][3][C]   (G^T dU G, the adjoint of wino_w), = or +=
+// Backward: dx = Winograd conv of dy with U' (no overlap-add), dU[xi] = dM[xi]^T V[xi] (V kept from the forward).
+#include <device_rt.h>
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 z4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+inline int ew_grid(long total) {
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    return (int)(g < 1 ? 1 : g);
+}
+
+__global__ void __launch_bounds__(256) wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W,
+                                                      int C) {
+    const int C4 = C >> 2, TH = H >> 1, TW = W >> 1;
+    const long T = (long)N * TH * TW, total = T * C4, plane = T * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long t = i / C4;
+        const int tx = (int)(t % TW);
+        const int ty = (int)((t / TW) % TH);
+        const int n = (int)(t / ((long)TW * TH));
+        float4 d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ih = 2 * ty - 1 + r;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int iw = 2 * tx - 1 + s;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                d[r][s] = ok ? ld4(x + (((long)n * H + ih) * W + iw) * C + 4 * c4) : z4();
+            }
+        }
+        float4 u[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {       // B^T d
+            u[0][s] = d[0][s] - d[2][s];
+            u[1][s] = d[1][s] + d[2][s];
+            u[2][s] = d[2][s] - d[1][s];
+            u[3][s] = d[1][s] - d[3][s];
+        }
+        float* o = V + t * C + 4 * c4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {       // (.) B
+            st4(o + (long)(4 * r + 0) * plane, u[r][0] - u[r][2]);
+            st4(o + (long)(4 * r + 1) * plane, u[r][1] + u[r][2]);
+            st4(o + (long)(4 * r + 2) * plane, u[r][2] - u[r][1]);
+            st4(o + (long)(4 * r + 3) * plane, u[r][1] - u[r][3]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wino_out_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                       float* __restrict__ y, int N, int H, int W, int K, int relu) {
+    const int K4 = K >> 2, TH = H >> 1, TW = W >> 1;
+    const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i % K4);
+        const long t = i / K4;
+        const int tx = (int)(t % TW);
+        const int ty = (int)((t / TW) % TH);
+        const int n = (int)(t / ((long)TW * TH));
+        const float* m = M + t * K + 4 * k4;
+        float4 s[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {       // A^T M
+            const float4 m0 = ld4(m + (long)(0 + c) * plane), m1 = ld4(m + (long)(4 + c) * plane);
+            const float4 m2 = ld4(m + (long)(8 + c) * plane), m3 = ld4(m + (long)(12 + c) * plane);
+            s[0][c] = m0 + m1 + m2;
+            s[1][c] = m1 - m2 - m3;
+        }
+        const float4 b = bias != nullptr ? ld4(bias + 4 * k4) : z4();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {       // (.) A
+            float4 y0 = s[r][0] + s[r][1] + s[r][2] + b;
+            float4 y1 = s[r][1] - s[r][2] - s[r][3] + b;
+            if (relu) {
+                y0 = make_float4(fmaxf(y0.x, 0.f), fmaxf(y0.y, 0.f), fmaxf(y0.z, 0.f), fmaxf(y0.w, 0.f));
+                y1 = make_float4(fmaxf(y1.x, 0.f), fmaxf(y1.y, 0.f), fmaxf(y1.z, 0.f), fmaxf(y1.w, 0.f));
+            }
+            float* o = y + (((long)n * H + 2 * ty + r) * W + 2 * tx) * K + 4 * k4;
+            st4(o, y0);
+            st4(o + K, y1);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N, int H, int W,
+                                                      int K) {
+    const int K4 = K >> 2, TH = H >> 1, TW = W >> 1;
+    const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i % K4);
+        const long t = i / K4;
+        const int tx = (int)(t % TW);
+        const int ty = (int)((t / TW) % TH);
+        const int n = (int)(t / ((long)TW * TH));
+        const float* g = dy + (((long)n * H + 2 * ty) * W + 2 * tx) * K + 4 * k4;
+        const float4 g00 = ld4(g), g01 = ld4(g + K), g10 = ld4(g + (long)W * K), g11 = ld4(g + (long)W * K + K);
+        // u = A dy  (rows: dy0, dy0 + dy1, dy0 - dy1, -dy1)
+        float4 u[4][2];
+        u[0][0] = g00;        u[0][1] = g01;
+        u[1][0] = g00 + g10;  u[1][1] = g01 + g11;
+        u[2][0] = g00 - g10;  u[2][1] = g01 - g11;
+        u[3][0] = z4() - g10; u[3][1] = z4() - g11;
+        float* o = dM + t * K + 4 * k4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {       // (.) A^T
+            st4(o + (long)(4 * r + 0) * plane, u[r][0]);
+            st4(o + (long)(4 * r + 1) * plane, u[r][0] + u[r][1]);
+            st4(o + (long)(4 * r + 2) * plane, u[r][0] - u[r][1]);
+            st4(o + (long)(4 * r + 3) * plane, z4() - u[r][1]);
+        }
+    }
+}
+
+// one thread per (k, c)
+__global__ void __launch_bounds__(256) wino_w_kernel(const float* __restrict__ g, float* __restrict__ U, int K, int C, int flip) {
+    const long total = (long)K * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), k = (int)(i / C);
+        float w[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
+                w[r][s] = g[((long)k * 9 + rr * 3 + ss) * C + c];
+            }
+        float a[4][3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {       // G g
+            a[0][s] = w[0][s];
+            a[1][s] = 0.5f * (w[0][s] + w[1][s] + w[2][s]);
+            a[2][s] = 0.5f * (w[0][s] - w[1][s] + w[2][s]);
+            a[3][s] = w[2][s];
+        }
+        // flip: U'[xi][c][k] (rows = output channel of the data-gradient conv = c, reduction index k contiguous)
+        float* o = flip ? U + (long)c * K + k : U + (long)k * C + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {       // (.) G^T
+            o[(long)(4 * r + 0) * total] = a[r][0];
+            o[(long)(4 * r + 1) * total] = 0.5f * (a[r][0] + a[r][1] + a[r][2]);
+            o[(long)(4 * r + 2) * total] = 0.5f * (a[r][0] - a[r][1] + a[r][2]);
+            o[(long)(4 * r + 3) * total] = a[r][2];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dg, int K, int C,
+                                                      int accumulate) {
+    const long total = (long)K * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), k = (int)(i / C);
+        float u[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) u[r][s] = dU[(long)(4 * r + s) * total + i];
+        float e[3][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {       // G^T dU
+            e[0][s] = u[0][s] + 0.5f * (u[1][s] + u[2][s]);
+            e[1][s] = 0.5f * (u[1][s] - u[2][s]);
+            e[2][s] = 0.5f * (u[1][s] + u[2][s]) + u[3][s];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {       // (.) G
+            const float v0 = e[r][0] + 0.5f * (e[r][1] + e[r][2]);
+            const float v1 = 0.5f * (e[r][1] - e[r][2]);
+            const float v2 = 0.5f * (e[r][1] + e[r][2]) + e[r][3];
+            float* o = dg + ((long)k * 9 + r * 3) * C + c;
+            if (accumulate) { o[0] += v0; o[C] += v1; o[2 * (long)C] += v2; }
+            else { o[0] = v0; o[C] = v1; o[2 * (long)C] = v2; }
+        }
+    }
+}
+
+inline bool bad(int N, int H, int W, int C) { return N < 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (H & 1) || (W & 1); }
+
+}  // namespace
+
+extern "C" {
+
+int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, void* stream) {
+    if (bad(N, H, W, C)) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    if (total == 0) return OMNI_OK;
+    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C);
+    return omni_launch_status();
+}
+
+int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, void* stream) {
+    if (bad(N, H, W, K)) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / 2) * (W / 2) * (K / 4);
+    if (total == 0) return OMNI_OK;
+    hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu);
+    return omni_launch_status();
+}
+
+int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, void* stream) {
+    if (bad(N, H, W, K)) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / 2) * (W / 2) * (K / 4);
+    if (total == 0) return OMNI_OK;
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, N, H, W, K);
+    return omni_launch_status();
+}
+
+int omni_wino_weights(const float* g, float* U, int K, int C, int flip_transpose, void* stream) {
+    if (K <= 0 || C <= 0) return OMNI_ERR_ARG;
+    hipLaunchKernelGGL(wino_w_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, g, U, K, C, flip_transpose);
+    return omni_launch_status();
+}
+
+int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate, void* stream) {
+    if (K <= 0 || C <= 0) return OMNI_ERR_ARG;
+    hipLaunchKernelGGL(wino_dw_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, dU, dg, K, C, accumulate);
+    return omni_launch_status();
+}
+
+}  // extern "C"

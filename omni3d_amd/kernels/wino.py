@@ -1,0 +1,114 @@
+"""Launchers for csrc/winograd.hip + the batched GEMM entry points of csrc/conv_gemm.hip: Winograd F(2x2, 3x3)
+forward / data-gradient / weight-gradient of a 3x3, stride-1, pad-1 convolution on NHWC tensors."""
+import torch
+
+from .. import lib as _lib
+
+CL = torch.channels_last
+
+
+def eligible(x_shape, w_shape, stride, pad):
+    """Wide 3x3/s1/p1 layers on even maps with enough tiles to fill the chip (FPN output / RPN conv on p2, p3)."""
+    N, C, H, W = x_shape
+    K, _, R, S = w_shape
+    return (R == 3 and S == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0 and C % 32 == 0 and K % 32 == 0
+            and C >= 128 and K >= 128 and N * (H // 2) * (W // 2) >= 4096)
+
+
+def _nhwc(t):
+    assert t.is_contiguous(memory_format=CL), "expected a channels_last tensor"
+    return t.permute(0, 2, 3, 1)
+
+
+def transform_input(x):
+    """x (N,C,H,W) CL -> V (16, T, C)"""
+    xv = _nhwc(x)
+    N, H, W, C = xv.shape
+    L = _lib.check_device(xv)
+    V = torch.empty((16, N * (H // 2) * (W // 2), C), dtype=torch.float32, device=x.device)
+    L.call("omni_wino_in", _lib.ptr(xv), _lib.ptr(V), N, H, W, C, _lib.stream_of(x))
+    return V
+
+
+def transform_weights(w, flip_transpose=False):
+    """w (K,C,3,3) CL (KRSC) -> U (16,K,C); flip_transpose: U' (16,C,K) of the rotated, channel-transposed filter."""
+    K, C = w.shape[0], w.shape[1]
+    wv = w.permute(0, 2, 3, 1)
+    assert wv.is_contiguous()
+    L = _lib.check_device(wv)
+    U = torch.empty((16, C, K) if flip_transpose else (16, K, C), dtype=torch.float32, device=w.device)
+    L.call("omni_wino_weights", _lib.ptr(wv), _lib.ptr(U), K, C, int(flip_transpose), _lib.stream_of(w))
+    return U
+
+
+def gemm_batched(V, U):
+    """V (B,M,C), U (B,K,C) -> (B,M,K)"""
+    B, M, C = V.shape
+    K = U.shape[1]
+    L = _lib.check_device(V, U)
+    out = torch.empty((B, M, K), dtype=torch.float32, device=V.device)
+    L.call("omni_gemm_batched_fwd", _lib.ptr(V), _lib.ptr(U), _lib.ptr(out), B, M, C, K, _lib.stream_of(V))
+    return out
+
+
+def gemm_batched_wgrad(V, dM):
+    """V (B,M,C), dM (B,M,K) -> dU (B,K,C) = dM^T V"""
+    B, M, C = V.shape
+    K = dM.shape[2]
+    L = _lib.check_device(V, dM)
+    dU = torch.empty((B, K, C), dtype=torch.float32, device=V.device)
+    L.call("omni_gemm_batched_wgrad", _lib.ptr(V), _lib.ptr(dM), _lib.ptr(dU), B, M, C, K, _lib.stream_of(V))
+    return dU
+
+
+def transform_output(Mt, shape, bias=None, relu=False):
+    """Mt (16,T,K) -> y (N,K,H,W) CL; shape = (N, H, W)"""
+    N, H, W = shape
+    K = Mt.shape[2]
+    L = _lib.check_device(Mt, bias)
+    y = torch.empty((N, H, W, K), dtype=torch.float32, device=Mt.device)
+    L.call("omni_wino_out", _lib.ptr(Mt), _lib.ptr(bias), _lib.ptr(y), N, H, W, K, int(relu), _lib.stream_of(Mt))
+    return y.permute(0, 3, 1, 2)
+
+
+def transform_dy(dy):
+    """dy (N,K,H,W) CL -> dM (16,T,K)"""
+    dv = _nhwc(dy)
+    N, H, W, K = dv.shape
+    L = _lib.check_device(dv)
+    dM = torch.empty((16, N * (H // 2) * (W // 2), K), dtype=torch.float32, device=dy.device)
+    L.call("omni_wino_dy", _lib.ptr(dv), _lib.ptr(dM), N, H, W, K, _lib.stream_of(dy))
+    return dM
+
+
+def transform_dweights(dU, accum_into=None):
+    """dU (16,K,C) -> dw (K,C,3,3) CL; accum_into: KRSC-contiguous gradient view to ADD into (returns None)."""
+    _, K, C = dU.shape
+    L = _lib.check_device(dU)
+    if accum_into is not None:
+        gv = accum_into.permute(0, 2, 3, 1)
+        assert gv.is_contiguous()
+        L.call("omni_wino_dweights", _lib.ptr(dU), _lib.ptr(gv), K, C, 1, _lib.stream_of(dU))
+        return None
+    dw = torch.empty((K, 3, 3, C), dtype=torch.float32, device=dU.device)
+    L.call("omni_wino_dweights", _lib.ptr(dU), _lib.ptr(dw), K, C, 0, _lib.stream_of(dU))
+    return dw.permute(0, 3, 1, 2)
+
+
+def conv3x3_fwd(x, w, bias=None, relu=False):
+    """-> (y, V): V is kept by the caller for the weight gradient."""
+    N, _, H, W = x.shape
+    V = transform_input(x)
+    Mt = gemm_batched(V, transform_weights(w))
+    return transform_output(Mt, (N, H, W), bias, relu), V
+
+
+def conv3x3_dgrad(dy, w):
+    """dx = the same Winograd convolution applied to dy with the rotated / transposed filter."""
+    N, _, H, W = dy.shape
+    Mt = gemm_batched(transform_input(dy), transform_weights(w, flip_transpose=True))
+    return transform_output(Mt, (N, H, W))
+
+
+def conv3x3_wgrad(V, dy, accum_into=None):
+    return transform_dweights(gemm_batched_wgrad(V, transform_dy(dy)), accum_into)

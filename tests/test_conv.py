@@ -117,3 +117,50 @@ def test_conv_gpu(hip_lib, case):
 def test_linear_gpu(hip_lib):
     _run_linear("cuda", 300, 12544, 1024)
     _run_linear("cuda", 130, 1024, 256)
+
+
+# ---- Winograd F(2x2, 3x3) path ------------------------------------------------------------------------
+def _run_wino(dev, N, C, K, H, W, seed=3):
+    from omni3d_amd.kernels import wino
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(K, generator=g)
+    dy = torch.randn(N, K, H, W, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.relu(F.conv2d(xr, wr, br, padding=1))
+    ref.backward(dy)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last).to(dev)  # noqa: E731
+    xk, wk, dyk = cl(x), cl(w), cl(dy)
+    y, V = wino.conv3x3_fwd(xk, wk, b.to(dev), relu=True)
+    scale = float(F.conv2d(x.abs(), w.abs(), None, padding=1).max())
+    assert (y.cpu() - ref.detach()).abs().max() <= 2e-6 * scale
+    dz = dyk * (y > 0)
+    dx = wino.conv3x3_dgrad(cl(dz), wk)
+    assert (dx.cpu() - xr.grad).abs().max() <= 2e-6 * float(F.conv_transpose2d(dy.abs(), w.abs(), padding=1).max())
+    dw = wino.conv3x3_wgrad(V, cl(dz))
+    assert (dw.cpu() - wr.grad).abs().max() <= 1e-5 * max(1.0, float(wr.grad.abs().max()))
+    acc = torch.ones_like(wk)
+    wino.conv3x3_wgrad(V, cl(dz), accum_into=acc)
+    assert (acc.cpu() - 1.0 - wr.grad).abs().max() <= 1e-5 * max(1.0, float(wr.grad.abs().max()))
+
+
+def test_winograd_emulated(emu_lib):
+    _run_wino("cpu", 1, 8, 12, 6, 8)
+    _run_wino("cpu", 2, 4, 4, 4, 4, seed=5)
+
+
+def test_winograd_dispatch_rule():
+    from omni3d_amd.kernels import wino
+    assert wino.eligible((4, 256, 128, 128), (256, 256, 3, 3), 1, 1)
+    assert wino.eligible((4, 256, 64, 64), (256, 256, 3, 3), 1, 1)
+    assert not wino.eligible((4, 256, 32, 32), (256, 256, 3, 3), 1, 1)      # too few tiles
+    assert not wino.eligible((4, 64, 128, 128), (64, 64, 3, 3), 1, 1)        # narrow
+    assert not wino.eligible((4, 256, 128, 128), (256, 256, 3, 3), 2, 1)     # strided
+    assert not wino.eligible((4, 256, 127, 128), (256, 256, 3, 3), 1, 1)     # odd extent
+
+
+@pytest.mark.gpu
+def test_winograd_gpu(hip_lib):
+    _run_wino("cuda", 2, 128, 256, 64, 64)
+    _run_wino("cuda", 1, 32, 64, 10, 6)

@@ -63,6 +63,25 @@ def main():
         for k, t in zip(tot, (t1, t2, t3)):
             tot[k] += t
         print(f"{name:34s} {gf:7.2f} | {t1:7.3f} {gf / t1:6.1f} | {t2:7.3f} {gf / t2:6.1f} | {t3:7.3f} {gf / t3:6.1f}")
+    from omni3d_amd.kernels import wino
+    print("Winograd F(2x2,3x3) path (ms; TF on the DIRECT algorithmic flops)")
+    for name, H in (("wino 3x3 256->256 @128", 128), ("wino 3x3 256->256 @64", 64)):
+        x = torch.randn(B, 256, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(256, 256, 3, 3, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn_like(x)
+        gf = 2.0 * B * H * H * 256 * 256 * 9 / 1e9
+        _, V = wino.conv3x3_fwd(x, w)
+        t1 = timeit(lambda: wino.conv3x3_fwd(x, w))
+        t2 = timeit(lambda: wino.conv3x3_dgrad(dy, w))
+        t3 = timeit(lambda: wino.conv3x3_wgrad(V, dy))
+        print(f"{name:34s} {gf:7.2f} | {t1:7.3f} {gf / t1:6.1f} | {t2:7.3f} {gf / t2:6.1f} | {t3:7.3f} {gf / t3:6.1f}")
+        Vd, U = wino.transform_input(x), wino.transform_weights(w)
+        Mt = wino.gemm_batched(Vd, U)
+        dM = wino.transform_dy(dy)
+        parts = {"in": lambda: wino.transform_input(x), "w": lambda: wino.transform_weights(w), "gemm": lambda: wino.gemm_batched(Vd, U),
+                 "out": lambda: wino.transform_output(Mt, (B, H, H)), "dy": lambda: wino.transform_dy(dy),
+                 "gemm_wgrad": lambda: wino.gemm_batched_wgrad(Vd, dM)}
+        print("   parts:", {k: round(timeit(f), 3) for k, f in parts.items()})
     for name, M, C, K in LINEARS:
         x = torch.randn(M, C, device="cuda")
         w = torch.randn(K, C, device="cuda") * 0.02
