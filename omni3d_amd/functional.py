@@ -78,7 +78,9 @@ class _WinoConv3x3(Function):
         gw, gb = ctx.direct
         if gw is not None and not gw.is_contiguous(memory_format=CL):
             gw = None
-        dx = wino.conv3x3_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = wino.conv3x3_dgrad(dy, w) if wino.dgrad_eligible(dy.shape) else conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1)
         dw = wino.conv3x3_wgrad(V, dy, accum_into=gw) if ctx.needs_input_grad[1] else None
         db = None
         if has_bias and ctx.needs_input_grad[2]:

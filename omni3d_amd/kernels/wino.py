@@ -8,11 +8,18 @@ CL = torch.channels_last
 
 
 def eligible(x_shape, w_shape, stride, pad):
-    """Wide 3x3/s1/p1 layers on even maps with enough tiles to fill the chip (FPN output / RPN conv on p2, p3)."""
+    """Wide (>= 128 channel) 3x3/s1/p1 layers on even maps with >= 256 tiles: FPN output / RPN convs on p2..p5 and the
+    DLA level 3-5 blocks (measured per shape with tools/bench_kernels.py, profiles/README.md)."""
     N, C, H, W = x_shape
     K, _, R, S = w_shape
     return (R == 3 and S == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0 and C % 32 == 0 and K % 32 == 0
-            and C >= 128 and K >= 128 and N * (H // 2) * (W // 2) >= 4096)
+            and C >= 128 and K >= 128 and N * (H // 2) * (W // 2) >= 256)
+
+
+def dgrad_eligible(x_shape):
+    """Below ~1024 tiles the direct split-K data-gradient kernel is faster than transform + 16 GEMMs + transform."""
+    N, _, H, W = x_shape
+    return N * (H // 2) * (W // 2) >= 1024
 
 
 def _nhwc(t):

@@ -65,11 +65,12 @@ def main():
         print(f"{name:34s} {gf:7.2f} | {t1:7.3f} {gf / t1:6.1f} | {t2:7.3f} {gf / t2:6.1f} | {t3:7.3f} {gf / t3:6.1f}")
     from omni3d_amd.kernels import wino
     print("Winograd F(2x2,3x3) path (ms; TF on the DIRECT algorithmic flops)")
-    for name, H in (("wino 3x3 256->256 @128", 128), ("wino 3x3 256->256 @64", 64)):
-        x = torch.randn(B, 256, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
-        w = (torch.randn(256, 256, 3, 3, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+    for name, H, CH in (("wino 3x3 256->256 @128", 128, 256), ("wino 3x3 256->256 @64", 64, 256), ("wino 3x3 128->128 @64", 64, 128),
+                        ("wino 3x3 256->256 @32", 32, 256), ("wino 3x3 64->64 @128", 128, 64), ("wino 3x3 512->512 @16", 16, 512)):
+        x = torch.randn(B, CH, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(CH, CH, 3, 3, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
         dy = torch.randn_like(x)
-        gf = 2.0 * B * H * H * 256 * 256 * 9 / 1e9
+        gf = 2.0 * B * H * H * CH * CH * 9 / 1e9
         _, V = wino.conv3x3_fwd(x, w)
         t1 = timeit(lambda: wino.conv3x3_fwd(x, w))
         t2 = timeit(lambda: wino.conv3x3_dgrad(dy, w))
