@@ -56,8 +56,15 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, i
     const int xcd = id % 8, k = id / 8;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     id = (nwg >= 8) ? swz : id;
-    tm = id % tiles_m;
-    tn = id / tiles_m;
+    if (tiles_n <= 4) {
+        // few column tiles (K <= 512): walk them fastest, so the big row operand (activations) of an m-tile is fetched
+        // once and re-hit in this XCD's L2 by the next column tile (PMC: FETCH_SIZE halves, profiles/README.md)
+        tn = id % tiles_n;
+        tm = id / tiles_n;
+    } else {
+        tm = id % tiles_m;
+        tn = id / tiles_m;
+    }
 }
 
 // ---- fragment fetch + MFMA over one BK=16 slab -------------------------------------------------

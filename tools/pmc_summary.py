@@ -13,7 +13,7 @@ for f in files:
         n = r["Kernel_Name"]
         m = re.search(r"(conv_(?:fwd|dgrad|wgrad)_kernel<[^>]*>)", n)
         if m:
-            acc[(m.group(1), r["Counter_Name"])].append(float(r["Counter_Value"]))
+            acc[(m.group(1) + " grid=" + r["Grid_Size"], r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open(out, "w") as fh:
     fh.write("kernel,counter,launches,mean_value_KB,mean_MB\n")
     for (k, c), v in sorted(acc.items()):
