@@ -33,8 +33,16 @@ def setup_dist(ngpus):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # OMNI_BENCH_BACKEND=gloo + OMNI_BENCH_ONE_DEVICE=1: functional check of the N > 1 path on a 1-GPU box
+        # (all ranks share cuda:0, collectives go through the host); the measured configuration is RCCL, one GPU per rank
+        backend = os.environ.get("OMNI_BENCH_BACKEND", "nccl")
+        if os.environ.get("OMNI_BENCH_ONE_DEVICE") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     return world, rank, local

@@ -71,11 +71,24 @@ def run_train(args, world, rank):
         loss_log.append(total.detach())
 
     # zero_grad + forward + losses + backward replayed as one hipGraph (OMNI_BENCH_GRAPH=0: eager launches);
-    # all-reduce / non-finite scan / SGD update stay eager (host-side learning rate)
+    # all-reduce / non-finite scan / SGD update stay eager (host-side learning rate).  With more than one rank the
+    # backward is cut at the FPN features into two graphs so the all-reduce of the heads' gradients (61 % of the
+    # bytes) runs beside the backbone's backward (GraphedTwoPhase); the collective sequence is the same on every
+    # rank whether or not its capture succeeded.
+    use_graph = os.environ.get("OMNI_BENCH_GRAPH", "1") != "0"
+    two_phase = world > 1 or os.environ.get("OMNI_BENCH_TWO_PHASE") == "1"
     graphed, graph_note = None, "eager (OMNI_BENCH_GRAPH=0)"
-    if os.environ.get("OMNI_BENCH_GRAPH", "1") != "0":
+    from omni3d_amd.cubercnn.solver.graphed import GraphedForwardBackward, GraphedTwoPhase
+    if two_phase:
         try:
-            from omni3d_amd.cubercnn.solver.graphed import GraphedForwardBackward
+            graphed = GraphedTwoPhase(model, opt, batch, packed, graphs=use_graph)
+            graph_note = ("two hipGraphs (fwd+heads bwd | backbone bwd), all-reduce of the heads' gradients overlapped"
+                          if use_graph else "eager two-phase backward, all-reduce of the heads' gradients overlapped")
+        except Exception as e:   # capture refused: same sequence with eager launches
+            graphed = GraphedTwoPhase(model, opt, batch, packed, graphs=False)
+            graph_note = f"eager two-phase (capture failed: {type(e).__name__}: {str(e)[:160]})"
+    elif use_graph:
+        try:
             graphed = GraphedForwardBackward(model, opt, batch, packed)
             graph_note = "hipGraph replay of zero_grad+fwd+losses+bwd"
         except Exception as e:   # capture refused: report it, measure the eager path
@@ -83,8 +96,12 @@ def run_train(args, world, rank):
 
     def graph_step():
         flag.zero_()
-        _, total = graphed()
-        opt.all_reduce_grads()
+        if two_phase:
+            _, total, pending = graphed()
+            opt.all_reduce_finish(pending)
+        else:
+            _, total = graphed()
+            opt.all_reduce_grads()
         opt.check_nonfinite(flag)
         opt.step()
         loss_log.append(total.clone())

@@ -79,6 +79,8 @@ class RCNN3D(nn.Module):
         if packed is None:
             packed = self.prepack(batched_inputs)
         features = self.backbone(images.tensor)
+        if getattr(self, "feature_cut", None) is not None:   # data-parallel two-phase backward (solver/graphed.py)
+            features = self.feature_cut(features)
         self._bump_bn_counters()
         proposals, proposal_losses = self.proposal_generator(images, features, None, targets=packed)
         _, detector_losses = self.roi_heads(images, features, proposals, None, None, None, packed=packed)

@@ -50,6 +50,82 @@ def _install_emulator():
     L._install_for_tests(L.HipLibrary(os.path.join(ROOT, "tests", "hipemu", "libomni3d_emu.so"), emulated=True))
 
 
+def _make_cut_net():
+    """backbone (conv+bn) | heads (flatten-linear + linear) with the FeatureCut between them, like RCNN3D.forward"""
+    from omni3d_amd.cubercnn.modeling.layers import BatchNorm2d, Conv2d, FlattenLinear, Linear
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Module()
+            self.backbone.c = Conv2d(8, 16, 3, padding=1, bias=True)
+            self.backbone.bn = BatchNorm2d(16)
+            self.f = FlattenLinear(16, 4, 12)
+            self.l = Linear(12, 8)
+            self.feature_cut = None
+
+        def forward(self, x, packed=None):
+            feats = {"p": self.backbone.bn(self.backbone.c(x, relu=True), relu=True)}
+            if self.feature_cut is not None:
+                feats = self.feature_cut(feats)
+            return {"loss": self.l(self.f(feats["p"], relu=True)).square().mean()}
+    torch.manual_seed(0)
+    return Net()
+
+
+def _tag_early(net):
+    for n, p in net.named_parameters():
+        p._omni_early_grad = not n.startswith("backbone.")
+
+
+def _worker_two_phase(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_emulator()
+    from omni3d_amd.cubercnn.solver.build import FlatSGD
+    from omni3d_amd.cubercnn.solver.graphed import GraphedTwoPhase
+    net = _make_cut_net()
+    _tag_early(net)
+    opt = FlatSGD([{"params": [p], "weight_decay": 0.0 if p.dim() == 1 else 1e-3} for p in net.parameters()], lr=0.1, momentum=0.9)
+    assert opt.early_ranges and opt.late_ranges
+    stepper = GraphedTwoPhase(net, opt, _shard(rank), None, graphs=False)
+    for _ in range(2):
+        _, _, pending = stepper()
+        opt.all_reduce_finish(pending)
+        opt.step()
+    torch.save({n: p.detach().clone() for n, p in net.named_parameters()}, os.path.join(out, f"tp{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _worker_single_phase(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_emulator()
+    from omni3d_amd.cubercnn.solver.build import FlatSGD
+    net = _make_cut_net()
+    opt = FlatSGD([{"params": [p], "weight_decay": 0.0 if p.dim() == 1 else 1e-3} for p in net.parameters()], lr=0.1, momentum=0.9)
+    for _ in range(2):
+        opt.zero_grad()
+        net(_shard(rank))["loss"].backward()
+        opt.all_reduce_grads()
+        opt.step()
+    torch.save({n: p.detach().clone() for n, p in net.named_parameters()}, os.path.join(out, f"sp{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_phase_overlapped_exchange_world2(emu_lib, tmp_path):
+    """backward cut at the features + all-reduce of the heads' ranges started before the backbone's backward ==
+    plain backward + one exchange (same parameters after two SGD steps, on both ranks)"""
+    world = 2
+    mp.spawn(_worker_two_phase, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_single_phase, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    tp = [torch.load(os.path.join(tmp_path, f"tp{r}.pt")) for r in range(world)]
+    sp = [torch.load(os.path.join(tmp_path, f"sp{r}.pt")) for r in range(world)]
+    for n in tp[0]:
+        assert torch.equal(tp[0][n], tp[1][n]), n
+        assert (tp[0][n] - sp[0][n]).abs().max() <= 1e-6 * max(1.0, float(sp[0][n].abs().max())), n
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
