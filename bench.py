@@ -141,6 +141,7 @@ def main():
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
+        dist.barrier()      # rank 0 times the roofline kernels after the step loop: leave together
         dist.destroy_process_group()
 
 

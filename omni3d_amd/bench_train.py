@@ -146,7 +146,11 @@ def run_train(args, world, rank):
     }
     if rank == 0:
         res["roofline"] = dominant_kernel_roofline()
-        res["cpu_baseline"] = cpu_baseline_train(priors)
+        res["hbm_bound_kernels"] = hbm_bound_kernels(opt)
+        if world == 1:   # the CPU leg is reported at N = 1 only (a minute of host work the other ranks would wait on)
+            res["cpu_baseline"] = cpu_baseline_train(priors)
+        else:
+            res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": "reported at N=1 only"}
     return res
 
 
@@ -194,6 +198,27 @@ def dominant_kernel_roofline(iters=20):
                                         "frac": flops_direct / (ms_direct * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
                                         "traffic": 175.3e6, "algorithmic_bytes_per_launch": 4.0 * (2 * B * H * H * C + 9 * C * C)},
             "layer_ms_winograd_vs_direct": [ms_wino, ms_direct]}
+
+
+def hbm_bound_kernels(opt, iters=10):
+    """The HBM-bound side of the step, reported separately: algorithmic bytes / live HIP-event time."""
+    from omni3d_amd.kernels import bnpool, wino
+    out = []
+    n = opt.flat_param.numel()
+    ms = _time_launch(lambda: opt.step(), iters)          # p, g, m read; p, m written
+    out.append({"kernel": "sgd_kernel (flat bucket, 47.9 M params)", "bytes": 20.0 * n, "kernel_ms": ms})
+    x = torch.randn(IMS_PER_GPU, 16, 512, 512, device="cuda").contiguous(memory_format=torch.channels_last)
+    g, b = torch.ones(16, device="cuda"), torch.zeros(16, device="cuda")
+    ms = _time_launch(lambda: bnpool.bn_fwd(x, g, b, None, None, None, True, 1e-5, 0.1), iters)   # x read twice, y written
+    out.append({"kernel": "bn_reduce + bn_finalize_fwd + bn_apply (16 ch @512x512, batch 4)", "bytes": 12.0 * x.numel(), "kernel_ms": ms})
+    x = torch.randn(IMS_PER_GPU, 256, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+    ms = _time_launch(lambda: wino.transform_input(x), iters)                                    # x read, 4x written
+    out.append({"kernel": "wino_in_kernel (256 ch @128x128, batch 4)", "bytes": 20.0 * x.numel(), "kernel_ms": ms})
+    for o in out:
+        o["achieved"] = o["bytes"] / (o["kernel_ms"] * 1e-3) / 1e9
+        o["peak"], o["unit"] = 8000.0, "GB/s"
+        o["frac"] = o["achieved"] / 8000.0
+    return out
 
 
 def cpu_baseline_train(priors):
