@@ -177,7 +177,7 @@ def dominant_kernel_roofline(iters=20):
     B, C, H = IMS_PER_GPU, 256, 128
     x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
     w = (torch.randn(C, C, 3, 3, device="cuda") * 0.02).contiguous(memory_format=torch.channels_last)
-    V, U = wino.transform_input(x), wino.transform_weights(w)
+    V, U = wino.transform_input(x), wino.transform_weights(w)[0]
     T = V.shape[1]
     ms = _time_launch(lambda: wino.gemm_batched(V, U), iters)
     flops = 2.0 * 16 * T * C * C

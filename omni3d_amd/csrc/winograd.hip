@@ -12,7 +12,7 @@
 //   wino_in_kernel   d (NHWC, zero padding 1)    -> V  [16][T][C]     (B^T d B)
 //   wino_out_kernel  M [16][T][K] (+bias, ReLU)   -> y (NHWC)          (A^T M A)
 //   wino_dy_kernel   dy (NHWC)                    -> dM [16][T][K]     (A dy A^T, the adjoint of wino_out)
-//   wino_w_kernel    g [K][3][3][C]               -> U  [16][K][C]     (G g G^T); flip: U'[16][C][K] of the 180-degree
+//   wino_w_kernel    g [K][3][3][C]               -> U  [16][K][C]     (G g G^T) and/or U'[16][C][K] of the 180-degree
 //                                                    rotated, channel-transposed filter (data gradient = the same conv)
 //   wino_dw_kernel   dU [16][K][C]                -> dg [K][3][3][C]   (G^T dU G, the adjoint of wino_w), = or +=
 // Backward: dx = Winograd conv of dy with U' (no overlap-add), dU[xi] = dM[xi]^T V[xi] (V kept from the forward).
@@ -134,8 +134,11 @@ __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ 
     }
 }
 
-// one thread per (k, c)
-__global__ void __launch_bounds__(256) wino_w_kernel(const float* __restrict__ g, float* __restrict__ U, int K, int C, int flip) {
+// one thread per (k, c).  U[xi][k][c] = (G g G^T)[xi]; optionally also U'[xi][c][k], the transform of the 180-degree rotated,
+// channel-transposed filter (what the data gradient convolves dy with): rotating g permutes the rows of G g by
+// pi = (3, 1, 2, 0), so U'[4i + j][c][k] = U[4 pi(i) + pi(j)][k][c] -- no second pass over g.
+__global__ void __launch_bounds__(256) wino_w_kernel(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf,
+                                                     int K, int C) {
     const long total = (long)K * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C), k = (int)(i / C);
@@ -143,10 +146,7 @@ __global__ void __launch_bounds__(256) wino_w_kernel(const float* __restrict__ g
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
-                w[r][s] = g[((long)k * 9 + rr * 3 + ss) * C + c];
-            }
+            for (int s = 0; s < 3; ++s) w[r][s] = g[((long)k * 9 + r * 3 + s) * C + c];
         float a[4][3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {       // G g
@@ -155,14 +155,28 @@ __global__ void __launch_bounds__(256) wino_w_kernel(const float* __restrict__ g
             a[2][s] = 0.5f * (w[0][s] - w[1][s] + w[2][s]);
             a[3][s] = w[2][s];
         }
-        // flip: U'[xi][c][k] (rows = output channel of the data-gradient conv = c, reduction index k contiguous)
-        float* o = flip ? U + (long)c * K + k : U + (long)k * C + c;
+        float u[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {       // (.) G^T
-            o[(long)(4 * r + 0) * total] = a[r][0];
-            o[(long)(4 * r + 1) * total] = 0.5f * (a[r][0] + a[r][1] + a[r][2]);
-            o[(long)(4 * r + 2) * total] = 0.5f * (a[r][0] - a[r][1] + a[r][2]);
-            o[(long)(4 * r + 3) * total] = a[r][2];
+            u[r][0] = a[r][0];
+            u[r][1] = 0.5f * (a[r][0] + a[r][1] + a[r][2]);
+            u[r][2] = 0.5f * (a[r][0] - a[r][1] + a[r][2]);
+            u[r][3] = a[r][2];
+        }
+        if (U != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) U[(long)(4 * r + t) * total + (long)k * C + c] = u[r][t];
+        }
+        if (Uf != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int pr = (r == 0) ? 3 : (r == 3) ? 0 : r, pt = (t == 0) ? 3 : (t == 3) ? 0 : t;
+                    Uf[(long)(4 * r + t) * total + (long)c * K + k] = u[pr][pt];
+                }
         }
     }
 }
@@ -226,9 +240,9 @@ int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, void* s
     return omni_launch_status();
 }
 
-int omni_wino_weights(const float* g, float* U, int K, int C, int flip_transpose, void* stream) {
-    if (K <= 0 || C <= 0) return OMNI_ERR_ARG;
-    hipLaunchKernelGGL(wino_w_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, g, U, K, C, flip_transpose);
+int omni_wino_weights(const float* g, float* U, float* U_flip, int K, int C, void* stream) {
+    if (K <= 0 || C <= 0 || (U == nullptr && U_flip == nullptr)) return OMNI_ERR_ARG;
+    hipLaunchKernelGGL(wino_w_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
     return omni_launch_status();
 }
 

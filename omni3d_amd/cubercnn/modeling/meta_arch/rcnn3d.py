@@ -11,6 +11,7 @@ from ....d2.config import configurable
 from ....d2.events import get_event_storage, has_event_storage
 from ....d2.layers import ShapeSpec
 from ....d2.structures import ImageList
+from .... import functional as HF
 from ....kernels import bnpool
 from ..proposal_generator import build_proposal_generator
 from ..registries import BACKBONE_REGISTRY, META_ARCH_REGISTRY
@@ -73,6 +74,7 @@ class RCNN3D(nn.Module):
         return pack_targets(batched_inputs, sizes, vf, with_gt=True).to(self.device)
 
     def forward(self, batched_inputs, packed=None):
+        HF.wino_weight_cache.clear()      # weights may have changed since the previous forward
         if not self.training:
             return self.inference(batched_inputs, packed=packed)
         images = self.preprocess_image(batched_inputs)

@@ -63,14 +63,23 @@ class _WinoConv3x3(Function):
     def forward(ctx, x, w, bias, relu):
         ctx.direct = (_direct_grad(w), _direct_grad(bias))
         x, w = _cl(x), _cl(w)
-        y, V = wino.conv3x3_fwd(x, w, bias, relu)
-        ctx.save_for_backward(V, w, y if relu else None)
+        # one launch yields the forward transform U and (when the data gradient will also go through Winograd) U' of
+        # the rotated filter; a weight shared by several calls of one step (the RPN conv over the FPN levels) is
+        # transformed once (wino_weight_cache, cleared by the model at the start of every forward)
+        need_flip = x.requires_grad and wino.dgrad_eligible(x.shape)
+        key = id(w)
+        U, Uf = wino_weight_cache.get(key, (None, None))
+        if U is None or (need_flip and Uf is None):
+            U, Uf = wino.transform_weights(w, True, need_flip or Uf is not None)
+            wino_weight_cache[key] = (U, Uf)
+        y, V = wino.conv3x3_fwd(x, w, bias, relu, U=U)
+        ctx.save_for_backward(V, w, y if relu else None, Uf if need_flip else None)
         ctx.cfg = (relu, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        V, w, y = ctx.saved_tensors
+        V, w, y, Uf = ctx.saved_tensors
         relu, has_bias = ctx.cfg
         dy = _cl(dy)
         if relu:
@@ -80,12 +89,15 @@ class _WinoConv3x3(Function):
             gw = None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = wino.conv3x3_dgrad(dy, w) if wino.dgrad_eligible(dy.shape) else conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1)
+            dx = wino.conv3x3_dgrad(dy, w, U_flip=Uf) if wino.dgrad_eligible(dy.shape) else conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1)
         dw = wino.conv3x3_wgrad(V, dy, accum_into=gw) if ctx.needs_input_grad[1] else None
         db = None
         if has_bias and ctx.needs_input_grad[2]:
             db = bnpool.bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]), accum_into=gb)
         return dx, dw, db, None
+
+
+wino_weight_cache = {}     # id(weight) -> (U, U') of the current step
 
 
 import os as _os

@@ -37,15 +37,17 @@ def transform_input(x):
     return V
 
 
-def transform_weights(w, flip_transpose=False):
-    """w (K,C,3,3) CL (KRSC) -> U (16,K,C); flip_transpose: U' (16,C,K) of the rotated, channel-transposed filter."""
+def transform_weights(w, want_u=True, want_flip=False):
+    """w (K,C,3,3) CL (KRSC) -> (U (16,K,C) or None, U' (16,C,K) or None); U' = transform of the rotated, channel-transposed
+    filter (the data gradient's weights), produced by the same launch."""
     K, C = w.shape[0], w.shape[1]
     wv = w.permute(0, 2, 3, 1)
     assert wv.is_contiguous()
     L = _lib.check_device(wv)
-    U = torch.empty((16, C, K) if flip_transpose else (16, K, C), dtype=torch.float32, device=w.device)
-    L.call("omni_wino_weights", _lib.ptr(wv), _lib.ptr(U), K, C, int(flip_transpose), _lib.stream_of(w))
-    return U
+    U = torch.empty((16, K, C), dtype=torch.float32, device=w.device) if want_u else None
+    Uf = torch.empty((16, C, K), dtype=torch.float32, device=w.device) if want_flip else None
+    L.call("omni_wino_weights", _lib.ptr(wv), _lib.ptr(U), _lib.ptr(Uf), K, C, _lib.stream_of(w))
+    return U, Uf
 
 
 def gemm_batched(V, U):
@@ -102,18 +104,22 @@ def transform_dweights(dU, accum_into=None):
     return dw.permute(0, 3, 1, 2)
 
 
-def conv3x3_fwd(x, w, bias=None, relu=False):
-    """-> (y, V): V is kept by the caller for the weight gradient."""
+def conv3x3_fwd(x, w, bias=None, relu=False, U=None):
+    """-> (y, V): V is kept by the caller for the weight gradient.  U: precomputed transform_weights(w)[0]."""
     N, _, H, W = x.shape
     V = transform_input(x)
-    Mt = gemm_batched(V, transform_weights(w))
+    if U is None:
+        U = transform_weights(w)[0]
+    Mt = gemm_batched(V, U)
     return transform_output(Mt, (N, H, W), bias, relu), V
 
 
-def conv3x3_dgrad(dy, w):
+def conv3x3_dgrad(dy, w, U_flip=None):
     """dx = the same Winograd convolution applied to dy with the rotated / transposed filter."""
     N, _, H, W = dy.shape
-    Mt = gemm_batched(transform_input(dy), transform_weights(w, flip_transpose=True))
+    if U_flip is None:
+        U_flip = transform_weights(w, want_u=False, want_flip=True)[1]
+    Mt = gemm_batched(transform_input(dy), U_flip)
     return transform_output(Mt, (N, H, W))
 
 

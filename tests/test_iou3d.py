@@ -56,6 +56,35 @@ def _suite(dev, oracle_lib, rng, n1, n2):
     assert i0.shape == (n1, 0)
 
 
+def _groups_case(dev, oracle_lib, rng, G, max_dt, max_gt):
+    """evaluator-shaped ragged batch: every group equals the reference's per-group box3d_overlap (oracle)"""
+    from omni3d_amd.cubercnn.evaluation.omni3d_evaluation import box3d_overlap_groups
+    dt_sizes = rng.integers(0, max_dt + 1, G)
+    gt_sizes = rng.integers(0, max_gt + 1, G)
+    dt_sizes[0], gt_sizes[1] = 0, 0                       # empty detections / empty ground truth
+    n = int(max(dt_sizes.sum(), gt_sizes.sum(), 1))
+    dt_all, gt_all, _ = boxgen.omni3d_like_pairs(rng, n, degenerate_frac=0.05)
+    dt, gt = dt_all[: dt_sizes.sum()], gt_all[: gt_sizes.sum()]
+    out = box3d_overlap_groups(torch.from_numpy(dt).to(dev), torch.from_numpy(gt).to(dev), dt_sizes, gt_sizes)
+    assert len(out) == G
+    do, go = 0, 0
+    for g in range(G):
+        a, b = dt[do:do + dt_sizes[g]], gt[go:go + gt_sizes[g]]
+        do, go = do + dt_sizes[g], go + gt_sizes[g]
+        assert tuple(out[g].shape) == (len(a), len(b))
+        if len(a) and len(b):
+            assert np.abs(out[g].cpu().numpy() - oracle_overlap(oracle_lib, a, b)).max() < TOL, g
+
+
+def test_iou3d_groups_emulated(emu_lib, oracle_lib, rng):
+    _groups_case("cpu", oracle_lib, rng, 6, 4, 3)
+
+
+@pytest.mark.gpu
+def test_iou3d_groups_gpu(hip_lib, oracle_lib, rng):
+    _groups_case("cuda", oracle_lib, rng, 300, 40, 8)
+
+
 def test_iou3d_emulated(emu_lib, oracle_lib, rng):
     _suite("cpu", oracle_lib, rng, 9, 8)
 

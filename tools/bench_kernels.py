@@ -76,10 +76,10 @@ def main():
         t2 = timeit(lambda: wino.conv3x3_dgrad(dy, w))
         t3 = timeit(lambda: wino.conv3x3_wgrad(V, dy))
         print(f"{name:34s} {gf:7.2f} | {t1:7.3f} {gf / t1:6.1f} | {t2:7.3f} {gf / t2:6.1f} | {t3:7.3f} {gf / t3:6.1f}")
-        Vd, U = wino.transform_input(x), wino.transform_weights(w)
+        Vd, U = wino.transform_input(x), wino.transform_weights(w)[0]
         Mt = wino.gemm_batched(Vd, U)
         dM = wino.transform_dy(dy)
-        parts = {"in": lambda: wino.transform_input(x), "w": lambda: wino.transform_weights(w), "gemm": lambda: wino.gemm_batched(Vd, U),
+        parts = {"in": lambda: wino.transform_input(x), "w": lambda: wino.transform_weights(w, True, True), "gemm": lambda: wino.gemm_batched(Vd, U),
                  "out": lambda: wino.transform_output(Mt, (B, H, H)), "dy": lambda: wino.transform_dy(dy),
                  "gemm_wgrad": lambda: wino.gemm_batched_wgrad(Vd, dM)}
         print("   parts:", {k: round(timeit(f), 3) for k, f in parts.items()})

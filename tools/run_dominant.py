@@ -18,7 +18,7 @@ for _ in range(5):
     conv.conv2d_wgrad(x, dy, (3, 3), 1, 1)
 # the Winograd batched GEMM of the same layer (16 x [16384 x 256] * [256 x 256]^T): grid (256, 1, 16) of conv_fwd_kernel<128,128>
 from omni3d_amd.kernels import wino
-V, U = wino.transform_input(x), wino.transform_weights(w)
+V, U = wino.transform_input(x), wino.transform_weights(w)[0]
 dM = wino.transform_dy(dy)
 for _ in range(5):
     wino.gemm_batched(V, U)
