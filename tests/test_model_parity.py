@@ -74,11 +74,9 @@ def test_training_step_matches_reference_gpu(hip_lib, name):
     _run("cuda", name)
 
 
-@pytest.mark.gpu
-def test_training_step_fullsize_vs_cpu_oracle(hip_lib):
-    """BASELINE configs[0]/[1] shape: 2 synthetic 512x512 images, default cubercnn_DLA34_FPN config
-    (65 472 anchors, 2000/1000 proposals, 512 ROIs/img).  HIP path on the GPU vs the CPU oracle
-    (oracle/model_oracle.py, itself pinned to the reference by tests/test_oracle_pin.py)."""
+def _vs_cpu_oracle(batch, report=None):
+    """HIP path on the GPU vs the CPU oracle (oracle/model_oracle.py, itself pinned to the reference by
+    tests/test_oracle_pin.py) on the same batch, weights and injected sampling variates."""
     from oracle import make_golden as MG
     from oracle import model_oracle as MO
     from omni3d_amd import synthetic
@@ -87,10 +85,12 @@ def test_training_step_fullsize_vs_cpu_oracle(hip_lib):
     oracle = MO.ModelOracle(priors)
     oracle.load_state_dict(model.state_dict(), strict=True)
     model = model.to("cuda")
-    batch = synthetic.make_batch(2, 512, 512, num_gt=8, seed=21, priors=priors)
-    A = 3 * sum((512 // s) ** 2 for s in (4, 8, 16, 32, 64))
+    B = len(batch)
+    Hp = -(-max(b["image"].shape[1] for b in batch) // 64) * 64      # ImageList pads to the FPN size divisibility
+    Wp = -(-max(b["image"].shape[2] for b in batch) // 64) * 64
+    A = 3 * sum((Hp // s) * (Wp // s) for s in (4, 8, 16, 32, 64))
     g = torch.Generator().manual_seed(3)
-    E_rpn, E_roi = torch.empty(2, A).exponential_(generator=g), torch.empty(2, 2048).exponential_(generator=g)
+    E_rpn, E_roi = torch.empty(B, A).exponential_(generator=g), torch.empty(B, 2048).exponential_(generator=g)
     model.proposal_generator.injected = {"E": E_rpn}
     model.roi_heads.injected = {"E": E_roi}
     model.train()
@@ -114,8 +114,8 @@ def test_training_step_fullsize_vs_cpu_oracle(hip_lib):
         cos = float(torch.nn.functional.cosine_similarity(g.flatten(), og[n].grad.flatten(), dim=0))
         rows.append((abs(a - b) / max(b, 1e-12), cos, n, a, b))
     out = os.path.join(ROOT, "gpurun_out")
-    if os.path.isdir(out):
-        with open(os.path.join(out, "fullsize_grad_report.txt"), "w") as f:
+    if report and os.path.isdir(out):
+        with open(os.path.join(out, report), "w") as f:
             for r in sorted(rows, reverse=True):
                 f.write("%.3e cos=%.6f %s %.6g %.6g\n" % r)
     # The gradient of a random-init 60-layer BN network is ill-conditioned towards the stem (ReLU / max-pool /
@@ -126,3 +126,23 @@ def test_training_step_fullsize_vs_cpu_oracle(hip_lib):
         assert rel <= (2e-2 if tight else 1e-1) or abs(a - b) < 1e-6, (n, a, b)
         if b > 1e-6:
             assert cos > (0.999 if tight else 0.98), (n, cos)
+
+
+@pytest.mark.gpu
+def test_training_step_fullsize_vs_cpu_oracle(hip_lib):
+    """BASELINE configs[0]/[1] shape: 2 synthetic 512x512 images, default cubercnn_DLA34_FPN config
+    (65 472 anchors, 2000/1000 proposals, 512 ROIs/img)."""
+    from omni3d_amd import synthetic
+    priors = synthetic.make_priors(50)
+    _vs_cpu_oracle(synthetic.make_batch(2, 512, 512, num_gt=8, seed=21, priors=priors), report="fullsize_grad_report.txt")
+
+
+@pytest.mark.gpu
+def test_training_step_ragged_batch_vs_cpu_oracle(hip_lib):
+    """Ragged input: images of different sizes and GT counts in one batch (ImageList zero-pads to the per-batch maximum
+    rounded up to 64; anchors cover the padding, proposals are clipped to each image's own size)."""
+    from omni3d_amd import synthetic
+    priors = synthetic.make_priors(50)
+    batch = (synthetic.make_batch(1, 128, 192, num_gt=3, seed=31, priors=priors)
+             + synthetic.make_batch(1, 160, 100, num_gt=6, seed=32, priors=priors))
+    _vs_cpu_oracle(batch)
