@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __
     __shared__ unsigned hist[256];
     __shared__ unsigned long long sel[TOPK_MAXK];
     __shared__ unsigned long long s_prefix;
-    __shared__ int s_need, s_count;
+    __shared__ int s_need, s_count, s_done;
     const int t = threadIdx.x;
     const int rowid = (int)blockIdx.x / seg.S, sid = (int)blockIdx.x - rowid * seg.S;
     const int n = seg.n[sid];
@@ -68,10 +68,30 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __
             __syncthreads();
             const unsigned long long prefix = s_prefix;
             const int shift = pass * 8;
-            for (int i = t; i < n; i += TOPK_THREADS) {
-                const unsigned long long key = make_key(row[(long)i * estride], i);
-                const bool match = (pass == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-                if (match) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+            // uniform trip count: the wave-level aggregation below uses ballots / shuffles
+            for (int base = 0; base < n; base += TOPK_THREADS) {
+                const int i = base + t;
+                bool todo = false;
+                unsigned digit = 0u;
+                if (i < n) {
+                    const unsigned long long key = make_key(row[(long)i * estride], i);
+                    todo = (pass == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                    digit = (unsigned)(key >> shift) & 255u;
+                }
+                // Scores cluster (the sign/exponent byte of RPN logits takes 2-3 values), so plain LDS atomics would
+                // serialise tens of thousands of adds on one bin: each wave first folds its lanes that share the
+                // leader's digit into ONE add (4 rounds), the rest fall back to per-lane atomics.
+#pragma unroll
+                for (int round = 0; round < 4; ++round) {
+                    const unsigned long long pending = __ballot(todo);
+                    if (pending == 0ull) break;
+                    const int leader = __ffsll((long long)pending) - 1;
+                    const unsigned d = (unsigned)__shfl((int)digit, leader, 64);
+                    const unsigned long long same = __ballot(todo && digit == d);
+                    if ((t & 63) == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
+                    if (todo && digit == d) todo = false;
+                }
+                if (todo) atomicAdd(&hist[digit], 1u);
             }
             __syncthreads();
             if (t == 0) {
@@ -84,8 +104,13 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __
                 }
                 s_need = need;
                 s_prefix = prefix | ((unsigned long long)d << shift);
+                // all remaining candidates share the prefix and every one of them is needed: the lower bytes cannot
+                // separate anything any more (distinct scores settle after the 4 score bytes; the index bytes only
+                // matter when equal scores straddle the k-th place)
+                s_done = ((int)hist[d] == need) ? 1 : 0;
             }
             __syncthreads();
+            if (s_done) break;
         }
         thr = s_prefix;  // keys are unique, so exactly kk keys are >= thr
     }

@@ -146,3 +146,21 @@ def test_training_step_ragged_batch_vs_cpu_oracle(hip_lib):
     batch = (synthetic.make_batch(1, 128, 192, num_gt=3, seed=31, priors=priors)
              + synthetic.make_batch(1, 160, 100, num_gt=6, seed=32, priors=priors))
     _vs_cpu_oracle(batch)
+
+
+@pytest.mark.gpu
+def test_training_step_image_without_valid_gt(hip_lib):
+    """An image whose only annotation is an ignore region (the reference's Matcher indexing fails on it, SURVEY.md A.8;
+    real training filters such images): the HIP path must stay finite -- no foreground, RPN/box losses from background only."""
+    from oracle import make_golden as MG
+    from omni3d_amd import synthetic
+    priors = synthetic.make_priors(50)
+    model = MG.build_product_model(MG.product_cfg([]), priors, 5, device="cuda")
+    batch = synthetic.make_batch(1, 128, 128, num_gt=4, seed=41, priors=priors) + \
+        synthetic.make_batch(1, 128, 128, num_gt=1, num_ignore=1, seed=42, priors=priors)
+    model.train()
+    losses = model(batch)
+    total = sum(losses.values())
+    total.backward()
+    assert all(bool(torch.isfinite(v)) for v in losses.values()), {k: float(v) for k, v in losses.items()}
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
