@@ -67,7 +67,7 @@ class _WinoConv3x3(Function):
         # the rotated filter; a weight shared by several calls of one step (the RPN conv over the FPN levels) is
         # transformed once (wino_weight_cache, cleared by the model at the start of every forward)
         need_flip = x.requires_grad and wino.dgrad_eligible(x.shape)
-        key = id(w)
+        key = (w.data_ptr(), tuple(w.shape))     # parameters live at fixed addresses of the flat bucket
         U, Uf = wino_weight_cache.get(key, (None, None))
         if U is None or (need_flip and Uf is None):
             U, Uf = wino.transform_weights(w, True, need_flip or Uf is not None)
@@ -97,7 +97,7 @@ class _WinoConv3x3(Function):
         return dx, dw, db, None
 
 
-wino_weight_cache = {}     # id(weight) -> (U, U') of the current step
+wino_weight_cache = {}     # (weight address, shape) -> (U, U') of the current step
 
 
 import os as _os
