@@ -67,7 +67,9 @@ class _WinoConv3x3(Function):
         # the rotated filter; a weight shared by several calls of one step (the RPN conv over the FPN levels) is
         # transformed once (wino_weight_cache, cleared by the model at the start of every forward)
         need_flip = x.requires_grad and wino.dgrad_eligible(x.shape)
-        key = (w.data_ptr(), tuple(w.shape))     # parameters live at fixed addresses of the flat bucket
+        # fixed address in the flat bucket + torch's in-place version counter (load_state_dict, manual edits); the fused
+        # SGD kernel bypasses the counter, so FlatSGD.step() clears the cache itself
+        key = (w.data_ptr(), tuple(w.shape), w._version)
         U, Uf = wino_weight_cache.get(key, (None, None))
         if U is None or (need_flip and Uf is None):
             U, Uf = wino.transform_weights(w, True, need_flip or Uf is not None)
