@@ -565,6 +565,117 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
         }
 }
 
+// =================================================================================================
+// Persistent batched GEMM  out[b] (M x N) = A[b] (M x K) * B[b] (N x K)^T   (the 16 Winograd-point GEMMs, K = channels)
+//   The reduction is short (K = 256 -> 8 slabs), so with one workgroup per tile the pipeline fill (first global load ->
+//   LDS -> first MFMA) and the drain are a sizeable share of a tile's life.  Here 512 resident workgroups (2 per CU) walk
+//   the item list (b, tile_m, tile_n; n fastest, one contiguous chunk of items per XCD) and keep the register-staged
+//   prefetch running ACROSS items: the first slab of the next item is loaded while the last slab of the current one is
+//   in the MFMAs, and the accumulators are stored while the next item's LDS tile is already filled.
+// =================================================================================================
+struct GemmP {
+    const float* A;
+    const float* B;
+    float* out;
+    int batch, M, N, K;
+    int tiles_m, tiles_n;
+};
+
+__global__ void __launch_bounds__(256) gemm_nt_persistent_kernel(GemmP p) {
+    constexpr int BM = 128, BN = 128, BKX = 32, BKP = BKX + 4, KQ = BKX / 4, RPP = 256 / KQ, AI = BM / RPP, BI = BN / RPP;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BKP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kq = tid % KQ, lrow = tid / KQ;
+    const int per_batch = p.tiles_m * p.tiles_n;
+    const int items = p.batch * per_batch;
+    const int per_xcd = (items + 7) / 8;
+    const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, step = (int)gridDim.x >> 3;
+    const int end = min((xcd + 1) * per_xcd, items);
+    int cur = xcd * per_xcd + local;
+    if (cur >= end) return;
+    const int nk = p.K / BKX;
+
+    // load cursor (the item / slab the NEXT load_slab() fetches)
+    const float* a_ptr[AI];
+    const float* b_ptr[BI];
+    bool a_ok[AI], b_ok[BI];
+    auto point_at = [&](int item) {
+        const int b = item / per_batch, r = item - b * per_batch;
+        const int m0 = (r / p.tiles_n) * BM, n0 = (r % p.tiles_n) * BN;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int m = m0 + lrow + RPP * i;
+            a_ok[i] = m < p.M;
+            a_ptr[i] = p.A + ((long)b * p.M + (a_ok[i] ? m : 0)) * p.K + kq * 4;
+        }
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const int n = n0 + lrow + RPP * j;
+            b_ok[j] = n < p.N;
+            b_ptr[j] = p.B + ((long)b * p.N + (b_ok[j] ? n : 0)) * p.K + kq * 4;
+        }
+    };
+    float4 ra[AI], rb[BI];
+    auto load_slab = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) { ra[i] = a_ok[i] ? ldg4(a_ptr[i]) : zero4(); a_ptr[i] += BKX; }
+#pragma unroll
+        for (int j = 0; j < BI; ++j) { rb[j] = b_ok[j] ? ldg4(b_ptr[j]) : zero4(); b_ptr[j] += BKX; }
+    };
+    auto store_slab = [&](int buf) {
+        float* As = smem + buf * (BM + BN) * BKP;
+        float* Bs = As + BM * BKP;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<float4*>(As + (lrow + RPP * i) * BKP + kq * 4) = ra[i];
+#pragma unroll
+        for (int j = 0; j < BI; ++j) *reinterpret_cast<float4*>(Bs + (lrow + RPP * j) * BKP + kq * 4) = rb[j];
+    };
+
+    f32x16 acc[2][2];
+    zero_acc<2, 2>(acc);
+    point_at(cur);
+    load_slab();
+    store_slab(0);
+    __syncthreads();
+    int buf = 0;
+    const int l31 = lane & 31, h = lane >> 5;
+    for (;;) {
+        const bool more_items = cur + step < end;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool last = kt + 1 == nk;
+            const bool has_next = !last || more_items;
+            if (last && more_items) point_at(cur + step);
+            if (has_next) load_slab();
+            const float* As = smem + buf * (BM + BN) * BKP;
+            mma_slab<2, 2, true, true, 0, 0, BKX>(As, As + BM * BKP, wm * 64, wn * 64, lane, acc);
+            if (has_next) store_slab(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        {   // epilogue of item `cur`
+            const int b = cur / per_batch, r = cur - b * per_batch;
+            const int m0 = (r / p.tiles_n) * BM, n0 = (r % p.tiles_n) * BN;
+            float* o = p.out + (long)b * p.M * p.N;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + (wn * 2 + j) * 32 + l31;
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) {
+                        const int m = m0 + (wm * 2 + i) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+                        if (m < p.M && n < p.N) o[(long)m * p.N + n] = acc[i][j][rr];
+                        acc[i][j][rr] = 0.f;
+                    }
+                }
+        }
+        if (!more_items) break;
+        cur += step;
+    }
+}
+
+
 int g_variant = 0;   // tuning knob for A/B runs (omni_debug_set_variant); 0 = production choice
 
 inline bool bad_geom(const ConvP& p) {
@@ -727,6 +838,13 @@ int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch,
     if (M == 0) return OMNI_OK;
     ConvP p{x, w, nullptr, out, M, 1, 1, C, 1, 1, K, 1, 1, 1, 0, C, K, 0, 0, 0, 1, (long)M * C, (long)K * C, (long)M * K};
     const long t128 = (((long)M + 127) / 128) * ((K + 127) / 128);
+    if (K > 64 && (C % 32) == 0 && (t128 * batch >= 1024 || g_variant == 13) && g_variant != 12) {
+        // >= 2 items per resident workgroup: persistent kernel with the prefetch carried across items
+        // (variant 13: tests force it on small problems with 8 workgroups)
+        GemmP g{x, w, out, batch, M, K, C, (M + 127) / 128, (K + 127) / 128};
+        hipLaunchKernelGGL(gemm_nt_persistent_kernel, dim3(g_variant == 13 ? 8 : 512), dim3(256), 0, (hipStream_t)stream, g);
+        return omni_launch_status();
+    }
     if (K > 64 && t128 * batch >= 512)   // else 64x64 tiles: 4x the workgroups (measured on the 256ch @32x32 layers)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<128, 128, 2, 2, 32>), dim3((unsigned)t128, 1, (unsigned)batch), dim3(256), 0,
                            (hipStream_t)stream, p);

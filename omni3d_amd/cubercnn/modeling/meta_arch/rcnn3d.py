@@ -74,7 +74,10 @@ class RCNN3D(nn.Module):
         return pack_targets(batched_inputs, sizes, vf, with_gt=True).to(self.device)
 
     def forward(self, batched_inputs, packed=None):
-        HF.wino_weight_cache.clear()      # weights may have changed since the previous forward
+        with HF.wino_weight_scope():       # shared conv weights are Winograd-transformed once per pass
+            return self._forward(batched_inputs, packed)
+
+    def _forward(self, batched_inputs, packed=None):
         if not self.training:
             return self.inference(batched_inputs, packed=packed)
         images = self.preprocess_image(batched_inputs)

@@ -148,8 +148,6 @@ class FlatSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        from ... import functional as HF
-        HF.wino_weight_cache.clear()          # transformed Winograd weights of the parameters this call overwrites
         first = self._steps == 0
         for start, end, g in self.segments:
             det.sgd_step(self.flat_param[start:end], self.flat_grad[start:end], self.flat_mom[start:end], g["lr"],

@@ -65,15 +65,17 @@ class _WinoConv3x3(Function):
         x, w = _cl(x), _cl(w)
         # one launch yields the forward transform U and (when the data gradient will also go through Winograd) U' of
         # the rotated filter; a weight shared by several calls of one step (the RPN conv over the FPN levels) is
-        # transformed once (wino_weight_cache, cleared by the model at the start of every forward)
+        # transformed once (wino_weight_scope)
         need_flip = x.requires_grad and wino.dgrad_eligible(x.shape)
-        # fixed address in the flat bucket + torch's in-place version counter (load_state_dict, manual edits); the fused
-        # SGD kernel bypasses the counter, so FlatSGD.step() clears the cache itself
-        key = (w.data_ptr(), tuple(w.shape), w._version)
-        U, Uf = wino_weight_cache.get(key, (None, None))
+        # The cache only lives inside one model forward (RCNN3D.forward opens and closes it): nothing can change a weight
+        # in between, and no stale entry can outlive the tensor it was computed from.
+        key = (w.data_ptr(), tuple(w.shape))
+        cache = _wino_scope["cache"]
+        U, Uf = cache.get(key, (None, None)) if cache is not None else (None, None)
         if U is None or (need_flip and Uf is None):
             U, Uf = wino.transform_weights(w, True, need_flip or Uf is not None)
-            wino_weight_cache[key] = (U, Uf)
+            if cache is not None:
+                cache[key] = (U, Uf)
         y, V = wino.conv3x3_fwd(x, w, bias, relu, U=U)
         ctx.save_for_backward(V, w, y if relu else None, Uf if need_flip else None)
         ctx.cfg = (relu, bias is not None)
@@ -99,7 +101,20 @@ class _WinoConv3x3(Function):
         return dx, dw, db, None
 
 
-wino_weight_cache = {}     # (weight address, shape) -> (U, U') of the current step
+_wino_scope = {"cache": None}     # (weight address, shape) -> (U, U'), only while a model forward is running
+
+
+class wino_weight_scope:
+    """`with wino_weight_scope():` around one forward pass: a weight used by several convolutions of that pass (the RPN
+    conv over the FPN levels) is transformed once."""
+
+    def __enter__(self):
+        self.prev = _wino_scope["cache"]
+        _wino_scope["cache"] = {}
+
+    def __exit__(self, *exc):
+        _wino_scope["cache"] = self.prev
+        return False
 
 
 import os as _os

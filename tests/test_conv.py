@@ -165,3 +165,30 @@ def test_winograd_dispatch_rule():
 def test_winograd_gpu(hip_lib):
     _run_wino("cuda", 2, 128, 256, 64, 64)
     _run_wino("cuda", 1, 32, 64, 10, 6)
+
+
+def _run_persistent_gemm(dev):
+    """the persistent batched GEMM (prefetch carried across work items), forced onto a small problem: 16 x 2 items over
+    8 workgroups = 4 items each, ragged M and N tiles"""
+    from omni3d_amd import lib as L
+    from omni3d_amd.kernels import wino
+    g = torch.Generator().manual_seed(8)
+    V = torch.randn(16, 160, 64, generator=g).to(dev)
+    U = torch.randn(16, 72, 64, generator=g).to(dev)
+    L.get().call("omni_debug_set_variant", 13)
+    try:
+        out = wino.gemm_batched(V, U)
+    finally:
+        L.get().call("omni_debug_set_variant", 0)
+    ref = torch.einsum("bmc,bkc->bmk", V.cpu().double(), U.cpu().double())
+    assert (out.cpu().double() - ref).abs().max() <= 1e-4 * ref.abs().max()
+    assert torch.equal(out, wino.gemm_batched(V, U))       # bit-identical to the one-tile-per-workgroup kernel (same k order)
+
+
+def test_persistent_gemm_emulated(emu_lib):
+    _run_persistent_gemm("cpu")
+
+
+@pytest.mark.gpu
+def test_persistent_gemm_gpu(hip_lib):
+    _run_persistent_gemm("cuda")
