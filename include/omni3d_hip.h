@@ -254,6 +254,15 @@ int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate,
 int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch, int M, int C, int K, void* stream);
 int omni_gemm_batched_wgrad(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, void* stream);
 
+/* Direct convolution for the full-resolution, few-channel DLA-34 stem layers (cubercnn/modeling/backbone/dla.py:241-247):
+ * out (N,H,W,16) = conv(x (N,H,W,C), w (16,R,R,C)), stride 1, padding R/2; (C, R) = (4, 7) [base_layer, image padded
+ * 3 -> 4 channels] or (16, 3) [level0; also its data gradient with the rotated, channel-transposed filter]. */
+int omni_stem_conv_fwd(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
+                       void* stream);
+/* Its weight gradient: dw (16,R,R,C) = (accumulate == 0) or += sum over pixels of dy (N,H,W,16) (x) x (N,H,W,C). */
+int omni_stem_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
+                         int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,225 @@
+// stem_conv.hip -- direct convolution for the full-resolution, few-channel layers of the DLA-34 stem
+//   base_layer  7x7  3(4) -> 16 @512x512     /root/reference/cubercnn/modeling/backbone/dla.py:241-245
+//   level0      3x3 16    -> 16 @512x512     /root/reference/cubercnn/modeling/backbone/dla.py:246-247,279-289
+// (forward, and the data gradient of level0 = the same convolution with the rotated, channel-transposed filter).
+//
+// Why not the implicit GEMM of conv_gemm.hip: with C <= 16 a k-slab is one filter tap, so the im2col formulation
+// re-stages every input pixel R*S times through registers -> LDS and pads N = 16 output channels to 32; these layers
+// then run at 20-35 TFLOP/s while their HBM floor is ~30 us.  Here one workgroup owns a 4 x 64 output tile, stages its
+// input halo ((4+R-1) x (64+R-1) pixels) into LDS ONCE, keeps the whole filter in LDS, and every wave walks the taps with
+// v_mfma_f32_16x16x4_f32 (M = 16 pixels, N = 16 output channels exactly, k = 4):
+//   C = 16: one tap = 4 k-steps; a lane's ds_read_b128 holds channels 4g..4g+3 of its pixel and feeds MFMA t with channel
+//           4g+t (k index = lane group g), the filter fragment is read the same way -> 5 LDS reads per 16 MFMAs.
+//   C = 4 : a group of 4 horizontally adjacent taps = 4 k-steps; lane group g reads the pixel shifted by g taps, MFMA t
+//           takes channel t, i.e. its k dimension runs over the 4 taps (rows of 7 taps are zero-padded to 8 in LDS).
+// Any k order gives the same sum up to fp32 rounding.
+#include <device_rt.h>
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int C, int R>
+__global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ out, int N, int H, int W, int ldx, int ldo) {
+    constexpr int TH = 4, TW = 64, PAD = R / 2;
+    constexpr int HR = TH + R - 1, HC = TW + R - 1 + (C == 4 ? 1 : 0);   // C = 4: one spare column for the padded 8th tap
+    constexpr int PP = (C == 16) ? 20 : 4;                               // LDS floats per pixel (20: conflict-free b128 reads)
+    constexpr int SP = (C == 16) ? R : 8;                                // taps per filter row held in LDS
+    constexpr int KD = R * SP * C;                                       // LDS filter row length
+    constexpr int KP = KD + ((KD / 4) % 2 == 0 ? 4 : 8);                 // odd number of 16-byte chunks per row
+    __shared__ __attribute__((aligned(16))) float s_in[HR * HC * PP];
+    __shared__ __attribute__((aligned(16))) float s_w[16 * KP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int n = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    // ---- stage the input halo (zero outside the image) and the filter ----
+    constexpr int C4 = C / 4;
+    for (int i = tid; i < HR * HC * C4; i += 256) {
+        const int c4 = i % C4, col = (i / C4) % HC, row = i / (C4 * HC);
+        const int iy = oy0 - PAD + row, ix = ox0 - PAD + col;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x + (((long)n * H + iy) * W + ix) * ldx + 4 * c4);
+        *reinterpret_cast<float4*>(s_in + (row * HC + col) * PP + 4 * c4) = v;
+    }
+    for (int i = tid; i < 16 * R * SP * C4; i += 256) {
+        const int c4 = i % C4, s = (i / C4) % SP, r = (i / (C4 * SP)) % R, k = i / (C4 * SP * R);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < R) v = ld4(w + (((long)k * R + r) * R + s) * C + 4 * c4);
+        *reinterpret_cast<float4*>(s_w + k * KP + (r * SP + s) * C + 4 * c4) = v;
+    }
+    __syncthreads();
+
+    const int px = lane & 15, g = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (C == 16) {
+#pragma unroll 1
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                const float4 bw = *reinterpret_cast<const float4*>(s_w + px * KP + (r * SP + s) * C + 4 * g);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float4 a = *reinterpret_cast<const float4*>(s_in + ((wave + r) * HC + 16 * b + px + s) * PP + 4 * g);
+                    acc[b] = mfma_16x16x4(a.x, bw.x, acc[b]);
+                    acc[b] = mfma_16x16x4(a.y, bw.y, acc[b]);
+                    acc[b] = mfma_16x16x4(a.z, bw.z, acc[b]);
+                    acc[b] = mfma_16x16x4(a.w, bw.w, acc[b]);
+                }
+            }
+    } else {
+#pragma unroll 1
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int sg = 0; sg < SP / 4; ++sg) {
+                const float4 bw = *reinterpret_cast<const float4*>(s_w + px * KP + (r * SP + 4 * sg + g) * C);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float4 a = *reinterpret_cast<const float4*>(s_in + ((wave + r) * HC + 16 * b + px + 4 * sg + g) * PP);
+                    acc[b] = mfma_16x16x4(a.x, bw.x, acc[b]);
+                    acc[b] = mfma_16x16x4(a.y, bw.y, acc[b]);
+                    acc[b] = mfma_16x16x4(a.z, bw.z, acc[b]);
+                    acc[b] = mfma_16x16x4(a.w, bw.w, acc[b]);
+                }
+            }
+    }
+    // D[row = 4g + i][col = px]: output pixel ox0 + 16b + 4g + i of row oy0 + wave, channel px
+    const int oy = oy0 + wave;
+    if (oy >= H) return;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ox = ox0 + 16 * b + 4 * g + i;
+            if (ox < W) out[(((long)n * H + oy) * W + ox) * ldo + px] = acc[b][i];
+        }
+}
+
+
+// ---- weight gradient: dW[k][r][s][c] += sum over output pixels of dy[pix][k] * x[pix + (r, s) - pad][c] -----------------
+// MFMA 16x16x4 with M = the 16 output channels, N = 16 columns of (tap, c) and the k dimension running over 4 consecutive
+// output pixels of a row: A[k][j] = dy[pix0 + j][k], B[j][col] = x[pix0 + j + tap(col)][c(col)].
+//   C = 16: one N block per tap (9 accumulator blocks);  C = 4: one block per 4 horizontally adjacent taps (rows of 7 taps
+//   padded to 8: 14 blocks) -- in both cases the 16 lanes of a k group read 16 consecutive floats of the LDS halo.
+// Persistent workgroups loop over 4 x 64 pixel tiles and keep the accumulators in registers; every wave adds its partial
+// filter gradient to dW with fp32 atomics at the end (dW is the flat gradient bucket or a zeroed buffer).
+template <int C, int R>
+__global__ void __launch_bounds__(256) stem_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ dw, int N, int H, int W, int ldx, int lddy) {
+    constexpr int TH = 4, TW = 64, PAD = R / 2;
+    constexpr int HR = TH + R - 1, HC = TW + R - 1 + (C == 4 ? 1 : 0);
+    constexpr int NB = (C == 16) ? R * R : R * 2;            // accumulator blocks
+    __shared__ __attribute__((aligned(16))) float s_in[HR * HC * C];
+    __shared__ __attribute__((aligned(16))) float s_dy[TH * TW * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, g = lane >> 4;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int tiles = N * tiles_y * tiles_x;
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int C4 = C / 4;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int n = t / tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        __syncthreads();                                      // previous tile's LDS reads are done
+        for (int i = tid; i < HR * HC * C4; i += 256) {
+            const int c4 = i % C4, cc = (i / C4) % HC, row = i / (C4 * HC);
+            const int iy = oy0 - PAD + row, ix = ox0 - PAD + cc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x + (((long)n * H + iy) * W + ix) * ldx + 4 * c4);
+            *reinterpret_cast<float4*>(s_in + (row * HC + cc) * C + 4 * c4) = v;
+        }
+        for (int i = tid; i < TH * TW * 4; i += 256) {
+            const int k4 = i % 4, cc = (i / 4) % TW, row = i / (4 * TW);
+            const int oy = oy0 + row, ox = ox0 + cc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oy < H && ox < W) v = ld4(dy + (((long)n * H + oy) * W + ox) * lddy + 4 * k4);
+            *reinterpret_cast<float4*>(s_dy + (row * TW + cc) * 16 + 4 * k4) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int p0 = 0; p0 < TW; p0 += 4) {                  // 4 output pixels of row `wave` per k group
+            const float a = s_dy[(wave * TW + p0 + g) * 16 + col];
+            if (C == 16) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int sx = 0; sx < R; ++sx)
+                        acc[r * R + sx] = mfma_16x16x4(a, s_in[((wave + r) * HC + p0 + g + sx) * C + col], acc[r * R + sx]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk)
+                        acc[r * 2 + blk] = mfma_16x16x4(a, s_in[((wave + r) * HC + p0 + g + 4 * blk) * C + col], acc[r * 2 + blk]);
+            }
+        }
+    }
+    // D[row = 4g + i][col]: k = 4g + i;  C = 16: (tap = block, c = col);  C = 4: (s = 4 blk + col / 4, c = col % 4)
+    constexpr int KD = R * R * C;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        int off;
+        bool ok = true;
+        if (C == 16) {
+            off = b * C + col;
+        } else {
+            const int r = b >> 1, sx = 4 * (b & 1) + (col >> 2);
+            ok = sx < R;
+            off = (r * R + sx) * C + (col & 3);
+        }
+        if (!ok) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(dw + (long)(4 * g + i) * KD + off, acc[b][i]);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// out (N,H,W,16) = conv(x (N,H,W,C), w (16,R,R,C)), stride 1, padding R/2.  (C, R) in {(4, 7), (16, 3)}.
+int omni_stem_conv_fwd(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
+                       void* stream) {
+    if (N < 0 || H <= 0 || W <= 0 || K != 16 || ldx < C || ldo < K || (ldx & 3)) return OMNI_ERR_ARG;
+    if (!((C == 4 && R == 7) || (C == 16 && R == 3))) return OMNI_ERR_ARG;
+    if (N == 0) return OMNI_OK;
+    const long tiles = (long)N * ((H + 3) / 4) * ((W + 63) / 64);
+    if (C == 4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_fwd_kernel<4, 7>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w,
+                           out, N, H, W, ldx, ldo);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_fwd_kernel<16, 3>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w,
+                           out, N, H, W, ldx, ldo);
+    return omni_launch_status();
+}
+
+// dw (16,R,R,C) (+)= sum_pix dy (N,H,W,16) x (N,H,W,C); accumulate == 0 zeroes dw first (atomic accumulation either way).
+int omni_stem_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
+                         int accumulate, void* stream) {
+    if (N < 0 || H <= 0 || W <= 0 || K != 16 || ldx < C || lddy < K || (ldx & 3) || (lddy & 3)) return OMNI_ERR_ARG;
+    if (!((C == 4 && R == 7) || (C == 16 && R == 3))) return OMNI_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) omni_memset_async(dw, 0, sizeof(float) * (size_t)K * R * R * C, st);
+    if (N == 0) return OMNI_OK;
+    long tiles = (long)N * ((H + 3) / 4) * ((W + 63) / 64);
+    const unsigned grid = (unsigned)(tiles < 768 ? tiles : 768);        // 3 resident workgroups per CU
+    if (C == 4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<4, 7>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, ldx, lddy);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<16, 3>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, ldx, lddy);
+    return omni_launch_status();
+}
+
+}  // extern "C"

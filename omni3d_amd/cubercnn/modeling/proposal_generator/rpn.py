@@ -190,6 +190,14 @@ class RPNWithIgnore(nn.Module):
             [list(s) for s in images.image_sizes], dtype=torch.int32, device=anchors.device)
         prop, scores, count = self.predict_proposals(levels, anchors, hw_list, image_hw)
         self.last = {"boxes": prop, "scores": scores, "count": count}
+        if self.injected is not None and "proposals" in self.injected:
+            # stage-wise parity tests: the second stage runs on a given proposal list (list of (n_i, 4) boxes in score
+            # order), so that a last-bit flip in the first stage's ranking does not re-deal the sampling variates
+            given = self.injected["proposals"]
+            prop = torch.zeros_like(prop)
+            for n, b in enumerate(given):
+                prop[n, :b.shape[0]] = b.to(prop.device)
+            count = torch.tensor([b.shape[0] for b in given], dtype=torch.int32, device=prop.device)
         return _PackedProposals(prop, scores, count, images.image_sizes), losses
 
 

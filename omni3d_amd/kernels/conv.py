@@ -106,3 +106,36 @@ def linear_wgrad(x, dy, accum_into=None):
     L.call("omni_conv2d_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), M, 1, 1, C, K, 1, 1, 1, 0, C, K, 0,
            _lib.stream_of(x))
     return dw
+
+
+def stem_eligible(x_shape, w_shape, stride, pad):
+    """the full-resolution few-channel layers served by csrc/stem_conv.hip: (C, R) = (4, 7) or (16, 3), 16 outputs, stride 1"""
+    K, C, R, S = w_shape
+    return K == 16 and R == S and stride == 1 and pad == R // 2 and (C, R) in ((4, 7), (16, 3)) and x_shape[1] == C
+
+
+def stem_conv_fwd(x, w):
+    """x (N,C,H,W) CL, w (16,C,R,R) CL -> (N,16,H,W) CL"""
+    xv, wv = _nhwc(x), _nhwc(w)
+    N, H, W, C = xv.shape
+    K, R = wv.shape[0], wv.shape[1]
+    L = _lib.check_device(xv, wv)
+    out = torch.empty((N, H, W, K), dtype=torch.float32, device=x.device)
+    L.call("omni_stem_conv_fwd", _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(out), N, H, W, C, K, R, C, K, _lib.stream_of(x))
+    return out.permute(0, 3, 1, 2)
+
+
+def stem_conv_wgrad(x, dy, R, accum_into=None):
+    """x (N,C,H,W) CL, dy (N,16,H,W) CL -> dw (16,C,R,R) CL; accum_into: KRSC-contiguous gradient view to ADD into."""
+    xv, dv = _nhwc(x), _nhwc(dy)
+    N, H, W, C = xv.shape
+    K = dv.shape[3]
+    L = _lib.check_device(xv, dv)
+    if accum_into is not None:
+        gv = accum_into.permute(0, 2, 3, 1)
+        assert gv.is_contiguous() and tuple(gv.shape) == (K, R, R, C)
+        L.call("omni_stem_conv_wgrad", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(gv), N, H, W, C, K, R, C, K, 1, _lib.stream_of(x))
+        return None
+    dw = torch.empty((K, R, R, C), dtype=torch.float32, device=x.device)
+    L.call("omni_stem_conv_wgrad", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dw), N, H, W, C, K, R, C, K, 0, _lib.stream_of(x))
+    return dw.permute(0, 3, 1, 2)

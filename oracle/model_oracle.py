@@ -216,6 +216,8 @@ class ModelOracle(nn.Module):
                                      torch.cat([g[m] for g, m in zip(s3d, fg)]), torch.cat([p[m] for p, m in zip(spose, fg)]))
             losses.update(cl)
         self.last_labels = torch.stack(labels)
+        self.last_roi_boxes = [b.detach().clone() for b in sb]       # sampled ROI boxes per image (tests: set comparison)
+        self.last_proposals = [p.proposal_boxes.tensor.detach().clone() for p in props]
         return losses
 
 

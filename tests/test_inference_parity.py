@@ -44,7 +44,8 @@ def _run(dev):
         # format moves the same amount against itself (DESIGN.md "conditioning"), so the bar is 3e-4
         assert close(i.pred_dimensions, ref["pred_dimensions"], 3e-4)
         assert close(i.pred_center_cam, ref["pred_center_cam"], 3e-4)
-        assert (i.pred_center_2D.cpu() - ref["pred_center_2D"]).abs().max() < px
+        c2 = ref["pred_center_2D"]          # projected 3D centres, may lie far outside the image (|u| up to ~800 px here)
+        assert bool(((i.pred_center_2D.cpu() - c2).abs() <= 1e-4 * c2.abs().clamp(min=max(o["instances"].image_size)) + 0.01).all())
         # the Gram-Schmidt of a random-init 6D pose (|a| ~ 1e-2, a1 and a2 far from orthogonal) amplifies fp32
         # rounding of the head GEMMs: rotation entries and the corners built from them get a looser bar
         assert close(i.pred_pose, ref["pred_pose"], 2e-3)
@@ -57,5 +58,5 @@ def test_inference_matches_reference_emulated(emu_lib):
 
 
 @pytest.mark.gpu
-def test_inference_matches_reference_gpu(hip_lib):
+def test_inference_matches_reference_gpu(hip_lib, deterministic_forward):
     _run("cuda")

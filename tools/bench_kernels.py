@@ -63,6 +63,17 @@ def main():
         for k, t in zip(tot, (t1, t2, t3)):
             tot[k] += t
         print(f"{name:34s} {gf:7.2f} | {t1:7.3f} {gf / t1:6.1f} | {t2:7.3f} {gf / t2:6.1f} | {t3:7.3f} {gf / t3:6.1f}")
+    print("direct stem convolution (csrc/stem_conv.hip) vs the implicit GEMM, forward ms")
+    for name, C, R in (("base 7x7 4->16 @512", 4, 7), ("level0 3x3 16->16 @512", 16, 3)):
+        x = torch.randn(B, C, 512, 512, device="cuda").contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(16, C, R, R, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+        gf = 2.0 * B * 512 * 512 * 16 * C * R * R / 1e9
+        t1 = timeit(lambda: conv.stem_conv_fwd(x, w))
+        t0 = timeit(lambda: conv.conv2d_fwd(x, w, None, 1, R // 2))
+        dy = torch.randn(B, 16, 512, 512, device="cuda").contiguous(memory_format=torch.channels_last)
+        t2 = timeit(lambda: conv.stem_conv_wgrad(x, dy, R))
+        t3 = timeit(lambda: conv.conv2d_wgrad(x, dy, (R, R), 1, R // 2))
+        print(f"{name:34s} {gf:7.2f} | fwd stem {t1:7.3f} vs implicit GEMM {t0:7.3f} | wgrad stem {t2:7.3f} vs implicit GEMM {t3:7.3f}")
     from omni3d_amd.kernels import wino
     print("Winograd F(2x2,3x3) path (ms; TF on the DIRECT algorithmic flops)")
     for name, H, CH in (("wino 3x3 256->256 @128", 128, 256), ("wino 3x3 256->256 @64", 64, 256), ("wino 3x3 128->128 @64", 64, 128),
