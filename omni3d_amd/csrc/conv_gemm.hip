@@ -722,6 +722,19 @@ int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* ou
     } while (0)
     if ((K > 64 && t128 >= 256) || g_variant == 2 || g_variant == 3) {
         OMNI_FWD(128, 128, 2, 2, t128, 1);
+    } else if (K > 64 && t128 >= 64 && Kd >= 2048 && ldo == K && g_variant != 5 && g_variant != 14) {
+        // big GEMM with few 128x128 tiles but a deep reduction (fc1: 2048 x 12544 -> 1024): keep the large tile and split K
+        long splits = (512 + t128 - 1) / t128;
+        const long nslab = (Kd + 31) / 32;
+        if (splits > nslab / 8) splits = nslab / 8;
+        omni_memset_async(out, 0, sizeof(float) * (size_t)M * K, st);
+        OMNI_FWD(128, 128, 2, 2, t128, splits);
+        if (relu) {
+            const long n4 = M * K / 4;
+            long g = (n4 + 255) / 256;
+            if (g > 2048) g = 2048;
+            hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)g), dim3(256), 0, st, out, n4);
+        }
     } else if (K > 32 && (K > 64 || ((M + 127) / 128) < 256)) {
         const long tiles = ((M + 63) / 64) * ((K + 63) / 64);
         long splits = 1;

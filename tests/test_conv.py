@@ -117,6 +117,7 @@ def test_conv_gpu(hip_lib, case):
 def test_linear_gpu(hip_lib):
     _run_linear("cuda", 300, 12544, 1024)
     _run_linear("cuda", 130, 1024, 256)
+    _run_linear("cuda", 1024, 2560, 1024)     # few 128x128 tiles + deep reduction: large tile with split-K (the fc1 shape class)
 
 
 # ---- Winograd F(2x2, 3x3) path ------------------------------------------------------------------------
