@@ -4,3 +4,73 @@ Hand-written HIP kernels behind a C ABI (include/omni3d_hip.h, omni3d_amd/csrc) 
 host-side mirror of the reference's Detectron2 registry surface.  See DESIGN.md.
 """
 __version__ = "0.1.0"
+
+
+def install():
+    """Makes the reference's import paths resolve to this package: `import cubercnn...` -> `omni3d_amd.cubercnn...` and the
+    `detectron2.*` names the hot path uses -> `omni3d_amd.d2.*`, so code written against the reference (the step loop of
+    tools/train_net.py:176-313, demo code, tests) runs on the HIP path without edits.  Only the modules this package ships
+    resolve (data / evaluation bookkeeping / vis stay out of scope) and nothing is touched when a real
+    `detectron2` or `cubercnn` is importable."""
+    import importlib
+    import importlib.abc
+    import importlib.machinery
+    import importlib.util
+    import sys
+    import types
+
+    pkg = __name__
+    if any(isinstance(f, _AliasFinder) for f in sys.meta_path):
+        return
+    for root in ("cubercnn", "detectron2"):
+        if root not in sys.modules and importlib.util.find_spec(root) is not None:
+            raise RuntimeError(f"a real `{root}` package is importable; omni3d_amd.install() will not shadow it")
+    table = {
+        "detectron2.config": pkg + ".d2.config", "detectron2.layers": pkg + ".d2.layers",
+        "detectron2.structures": pkg + ".d2.structures", "detectron2.solver": pkg + ".d2.solver",
+        "detectron2.utils.events": pkg + ".d2.events", "detectron2.utils.comm": pkg + ".d2.comm",
+        "detectron2.utils.registry": pkg + ".d2.registry", "detectron2.modeling": pkg + ".cubercnn.modeling.registries",
+    }
+    sys.meta_path.insert(0, _AliasFinder(pkg, table))
+    for ns in ("detectron2", "detectron2.utils"):
+        m = types.ModuleType(ns)
+        m.__path__ = []
+        sys.modules.setdefault(ns, m)
+
+
+import importlib.abc as _abc
+import importlib.machinery as _machinery
+
+
+class _AliasLoader(_abc.Loader):
+    def __init__(self, target):
+        self.target = target
+
+    def create_module(self, spec):
+        import importlib
+        return importlib.import_module(self.target)      # the real module object, under its real name
+
+    def exec_module(self, module):
+        pass
+
+
+class _AliasFinder(_abc.MetaPathFinder):
+    """`cubercnn[.x]` -> `omni3d_amd.cubercnn[.x]`; a fixed table for the `detectron2.*` names."""
+
+    def __init__(self, pkg, table):
+        self.pkg, self.table = pkg, table
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname == "cubercnn" or fullname.startswith("cubercnn."):
+            real = self.pkg + "." + fullname
+        elif fullname in self.table:
+            real = self.table[fullname]
+        else:
+            return None
+        import importlib.util
+        try:
+            if importlib.util.find_spec(real) is None:
+                return None
+        except ModuleNotFoundError:
+            return None
+        return _machinery.ModuleSpec(fullname, _AliasLoader(real), is_package=True)
