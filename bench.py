@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- measures the hot path on MI355X.  Contract: see the repo task statement.
 
-  python bench.py --gpus N --steps K --warmup W [--workload train|iou3d]
+  python bench.py --gpus N --steps K --warmup W [--workload train|iou3d|infer]
 
 Prints ONE JSON line on rank 0.  `train` (default once available) = images/sec of the
 cubercnn_DLA34_FPN training step, batch 4/GPU, synthetic 512x512 Omni3D-shaped inputs;
@@ -135,6 +135,9 @@ def main():
     workload = args.workload or DEFAULT_WORKLOAD
     if workload == "iou3d":
         res = run_iou3d(args, world, rank)
+    elif workload == "infer":
+        from omni3d_amd.bench_train import run_infer
+        res = run_infer(args, world, rank)
     else:
         from omni3d_amd.bench_train import run_train
         res = run_train(args, world, rank)

@@ -154,6 +154,39 @@ def run_train(args, world, rank):
     return res
 
 
+def run_infer(args, world, rank):
+    """`--workload infer`: RCNN3D.inference (backbone, RPN, box head, per-class NMS, cube head decode) on the same staged batch;
+    not the BASELINE metric, reported for the inference half of the path.  Images shard across ranks, no collective."""
+    cfg, model, opt, priors = build(world)
+    batch, _ = stage_batch(model, priors, rank)
+    model.eval()
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            out = model(batch)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(batch)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"metric": f"images/sec inference {MODEL_NAME} b=4/GPU", "value": IMS_PER_GPU * world * args.steps / dt, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cubercnn_{MODEL_NAME} inference, batch 4/GPU, synthetic Omni3D 512x512, random-init weights "
+                                   "(score threshold 0.01 keeps ~all 100 detections/image)",
+                       "detections_first_image": int(len(out[0]["instances"]))}}
+
+
 def _time_launch(fn, iters):
     for _ in range(3):
         fn()
