@@ -263,6 +263,16 @@ int omni_stem_conv_fwd(const float* x, const float* w, float* out, int N, int H,
 int omni_stem_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
                          int accumulate, void* stream);
 
+/* Greedy detection <-> ground-truth matching of Omni3Deval.evaluateImg (cubercnn/evaluation/omni3d_evaluation.py:1433-1551,
+ * 3D mode) for all (image, category) groups x A depth ranges x T IoU thresholds.  ious: ragged (D_g, G_g) matrices at
+ * iou_off[g] (rows = detections in descending score order); dt_off / gt_off: (ngroups + 1) prefix offsets; max_gt <= 1024.
+ * Out: dt_match (A,T,sumD) matched gt index within the group (original order) or -1; gt_match (A,T,sumG) matched dt index or
+ * -1; dt_ignore (A,T,sumD); gt_order (A,sumG) the stable ignore-last order; gt_ig (A,sumG) `_ignore` per original gt. */
+int omni_eval_match(const float* ious, const long long* iou_off, const int* dt_off, const int* gt_off, const int* gt_ignore,
+                    const float* gt_range, const float* dt_range, const float* areas, const double* thrs, int ngroups, int A,
+                    int T, int sumD, int sumG, int max_gt, int* dt_match, int* gt_match, unsigned char* dt_ignore, int* gt_order,
+                    unsigned char* gt_ig, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

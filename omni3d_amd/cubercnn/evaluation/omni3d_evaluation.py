@@ -58,3 +58,38 @@ def box3d_overlap_groups(boxes_dt, boxes_gt, dt_sizes, gt_sizes, eps_coplanar: f
             if c[1] > 0:
                 print('Warning: skipping {:d} zero volume boxes at eval.'.format(int(c[1])))
     return [flat[pair_off[g]:pair_off[g + 1]].view(int(dt_sizes[g]), int(gt_sizes[g])) for g in range(len(counts))]
+
+
+def evaluate_groups(ious_flat, dt_sizes, gt_sizes, gt_ignore, gt_range, dt_range, area_ranges, iou_thrs):
+    """The greedy matching of `Omni3Deval.evaluateImg` (:1433-1551, 3D mode, eval_prox off) for every (image, category)
+    group x depth range x IoU threshold in one launch (the reference loops over them in Python, :1346-1351).
+
+    ious_flat: the concatenated (D_g, G_g) matrices (e.g. torch.cat of box3d_overlap_groups' views), detections in descending
+    score order and cut to maxDets; dt_sizes / gt_sizes: per-group counts; gt_ignore (sumG) int `ignore3D`; gt_range (sumG),
+    dt_range (sumD) float `depth`; area_ranges (A, 2); iou_thrs (T,).
+    -> dict of device tensors: dt_match (A,T,sumD) index of the matched gt inside its group (original order) or -1,
+       gt_match (A,T,sumG) index of the matched dt or -1, dt_ignore (A,T,sumD) uint8, gt_order (A,sumG) the stable
+       ignore-last order, gt_ignore (A,sumG) uint8 `_ignore` per original gt."""
+    L = iou3d._lib.get()
+    dev = ious_flat.device
+    dt_sizes, gt_sizes = np.asarray(dt_sizes, dtype=np.int64), np.asarray(gt_sizes, dtype=np.int64)
+    ng, sumD, sumG = len(dt_sizes), int(dt_sizes.sum()), int(gt_sizes.sum())
+    A, T = len(area_ranges), len(iou_thrs)
+    i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)      # noqa: E731
+    iou_off = torch.from_numpy(np.concatenate([[0], np.cumsum(dt_sizes * gt_sizes)])[:-1].astype(np.int64)).to(dev)
+    dt_off, gt_off = i32(np.concatenate([[0], np.cumsum(dt_sizes)])), i32(np.concatenate([[0], np.cumsum(gt_sizes)]))
+    areas = torch.tensor(np.asarray(area_ranges, dtype=np.float32)).to(dev).contiguous()
+    thrs = torch.tensor(np.asarray(iou_thrs, dtype=np.float64)).to(dev).contiguous()
+    out = {"dt_match": torch.empty((A, T, sumD), dtype=torch.int32, device=dev), "gt_match": torch.empty((A, T, sumG), dtype=torch.int32, device=dev),
+           "dt_ignore": torch.empty((A, T, sumD), dtype=torch.uint8, device=dev), "gt_order": torch.empty((A, sumG), dtype=torch.int32, device=dev),
+           "gt_ignore": torch.empty((A, sumG), dtype=torch.uint8, device=dev)}
+    if ng == 0:
+        return out
+    ious_flat = ious_flat.float().contiguous()
+    gt_ignore, gt_range, dt_range = gt_ignore.to(torch.int32).contiguous(), gt_range.float().contiguous(), dt_range.float().contiguous()
+    iou3d._lib.check_device(ious_flat, gt_ignore, gt_range, dt_range)
+    _p = iou3d._lib.ptr
+    L.call("omni_eval_match", _p(ious_flat), _p(iou_off), _p(dt_off), _p(gt_off), _p(gt_ignore), _p(gt_range), _p(dt_range), _p(areas),
+           _p(thrs), ng, A, T, sumD, sumG, int(gt_sizes.max()) if ng else 0, _p(out["dt_match"]), _p(out["gt_match"]),
+           _p(out["dt_ignore"]), _p(out["gt_order"]), _p(out["gt_ignore"]), iou3d._lib.stream_of(ious_flat))
+    return out

@@ -185,8 +185,49 @@ def main_infer(spec=INFER):
     print("wrote", path, os.path.getsize(path), "bytes;", [len(r["scores"]) for r in res], "detections")
 
 
+def main_eval(seed=11, groups=40):
+    """Greedy matching fixture: the reference's own `Omni3Deval.evaluateImg` (omni3d_evaluation.py:1433-1551) called on a
+    stand-in `self` for random (image, category) groups x the three depth ranges of the 3D protocol."""
+    import types
+    import numpy as np
+    H.install()
+    from cubercnn.evaluation.omni3d_evaluation import Omni3Deval
+    rs = np.random.RandomState(seed)
+    iou_thrs = np.linspace(0.05, 0.5, int(np.round((0.5 - 0.05) / 0.05)) + 1, endpoint=True)
+    area_rngs = [[0, 1e5], [0, 10], [10, 35], [35, 1e5]]
+    cases = []
+    for gi in range(groups):
+        D, G = int(rs.randint(0, 14)), int(rs.randint(0, 7))
+        if gi == 0:
+            D, G = 0, 3
+        if gi == 1:
+            D, G = 4, 0
+        ious = rs.uniform(0, 1, size=(D, G)).astype(np.float32)
+        ious[rs.uniform(size=(D, G)) < 0.4] = 0.0
+        if D > 2 and G > 1:
+            ious[1, :] = ious[0, :]                      # equal IoUs: later gt wins (>=), earlier dt takes it first
+            ious[2, 1] = ious[2, 0]
+        gt = [{"id": 1000 + g, "ignore3D": int(rs.uniform() < 0.25), "depth": float(rs.uniform(1, 60)), "_ignore": 0} for g in range(G)]
+        dt = [{"id": 5000 + d, "score": float(1.0 - 0.01 * d), "depth": float(rs.uniform(1, 60))} for d in range(D)]
+        outs = []
+        for a in area_rngs:
+            fake = types.SimpleNamespace(
+                params=types.SimpleNamespace(useCats=1, iouThrs=iou_thrs, catIds=[0]), mode="3D", eval_prox=False,
+                _gts={(0, 0): [dict(g) for g in gt]}, _dts={(0, 0): [dict(d) for d in dt]},
+                ious={(0, 0): (ious.astype(np.float64) if D and G else [], None)})
+            r = Omni3Deval.evaluateImg(fake, 0, 0, a, 100)
+            outs.append(None if r is None else {k: np.asarray(r[k]) for k in ("dtMatches", "gtMatches", "gtIgnore", "dtIgnore", "gtIds", "dtIds")})
+        cases.append({"ious": ious, "gt_ignore": np.array([g["ignore3D"] for g in gt]), "gt_range": np.array([g["depth"] for g in gt]),
+                      "dt_range": np.array([d["depth"] for d in dt]), "out": outs})
+    path = os.path.join(ROOT, "tests", "golden", "eval_match.pt")
+    torch.save({"iou_thrs": iou_thrs, "area_rngs": area_rngs, "cases": cases}, path)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    if "--infer" in sys.argv:
+    if "--eval" in sys.argv:
+        main_eval()
+    elif "--infer" in sys.argv:
         main_infer()
     else:
         main(TINY if "--tiny" in sys.argv else RESNET if "--resnet" in sys.argv else SMALL)
