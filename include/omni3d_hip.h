@@ -244,11 +244,13 @@ int omni_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int N, int H
  * (detectron2 FPN output convs built at cubercnn/modeling/backbone/dla.py:500-506 and StandardRPNHead.conv,
  * configs/Base.yaml:49 -- nn.Conv2d(256, 256, 3, padding=1) upstream).  H and W even, channels % 4 == 0.
  * T = N*H/2*W/2 tiles.  V / M / dM: [16][T][channels]; U: [16][K][C]; U' (rotated, channel-transposed filter): [16][C][K]. */
-int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, void* stream);
-int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, void* stream);
-int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, void* stream);
-int omni_wino_weights(const float* g, float* U /*nullable*/, float* U_flip /*nullable: U'*/, int K, int C, void* stream);
-int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate, void* stream);
+/* tile = 2: F(2x2,3x3), P = 16 points;  tile = 4: F(4x4,3x3), P = 36 points, H and W multiples of 4.  T = N*(H/tile)*(W/tile);
+ * the [16] above reads [P]. */
+int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile, void* stream);
+int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, void* stream);
+int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, int tile, void* stream);
+int omni_wino_weights(const float* g, float* U /*nullable*/, float* U_flip /*nullable: U'*/, int K, int C, int tile, void* stream);
+int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate, int tile, void* stream);
 /* `batch` independent dense GEMMs in one launch (the 16 Winograd points):
  * fwd: out[b](M,K) = x[b](M,C) * w[b](K,C)^T;  wgrad: dw[b](K,C) = dy[b](M,K)^T * x[b](M,C) (overwrites dw). */
 int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch, int M, int C, int K, void* stream);

@@ -210,45 +210,270 @@ __global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ 
     }
 }
 
-inline bool bad(int N, int H, int W, int C) { return N < 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (H & 1) || (W & 1); }
+// ================================================================================================================
+// F(4x4, 3x3): 6x6 input tiles (stride 4), 36 Winograd points, 2.25 multiplies per output instead of 4 (and 9 direct);
+// the transformed tensors are only 2.25x (not 4x) the size of the activations.  Lavin & Gray's matrices:
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// fp32 error of this variant is ~1e-6..1e-5 of the output magnitude (the transforms mix magnitudes up to 25x), inside the
+// 1e-4 parity bar; layers with < 256 tiles of 4x4 or extents not divisible by 4 keep F(2x2, 3x3).
+// ================================================================================================================
+template <typename V>
+__device__ __forceinline__ void bt6(const V (&d)[6], V (&t)[6]) {
+    t[0] = d[0] * 4.f - d[2] * 5.f + d[4];
+    t[1] = d[3] + d[4] - (d[1] + d[2]) * 4.f;
+    t[2] = (d[1] - d[2]) * 4.f - d[3] + d[4];
+    t[3] = (d[3] - d[1]) * 2.f - d[2] + d[4];
+    t[4] = (d[1] - d[3]) * 2.f - d[2] + d[4];
+    t[5] = d[1] * 4.f - d[3] * 5.f + d[5];
+}
+template <typename V>
+__device__ __forceinline__ void at6(const V (&m)[6], V (&y)[4]) {
+    y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    y[1] = m[1] - m[2] + (m[3] - m[4]) * 2.f;
+    y[2] = m[1] + m[2] + (m[3] + m[4]) * 4.f;
+    y[3] = m[1] - m[2] + (m[3] - m[4]) * 8.f + m[5];
+}
+template <typename V>
+__device__ __forceinline__ void a6(const V (&y)[4], V (&u)[6]) {      // u = A y (adjoint of at6)
+    u[0] = y[0];
+    u[1] = y[0] + y[1] + y[2] + y[3];
+    u[2] = y[0] - y[1] + y[2] - y[3];
+    u[3] = y[0] + y[1] * 2.f + y[2] * 4.f + y[3] * 8.f;
+    u[4] = y[0] - y[1] * 2.f + y[2] * 4.f - y[3] * 8.f;
+    u[5] = y[3];
+}
+
+__global__ void __launch_bounds__(256) wino4_in_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W,
+                                                       int C) {
+    const int C4 = C >> 2, TH = H >> 2, TW = W >> 2;
+    const long T = (long)N * TH * TW, total = T * C4, plane = T * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long t = i / C4;
+        const int tx = (int)(t % TW);
+        const int ty = (int)((t / TW) % TH);
+        const int n = (int)(t / ((long)TW * TH));
+        float4 u[6][6];     // u[r][s] = (B^T d) row r, column s -- built column by column
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int iw = 4 * tx - 1 + s;
+            float4 d[6], tcol[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int ih = 4 * ty - 1 + r;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                d[r] = ok ? ld4(x + (((long)n * H + ih) * W + iw) * C + 4 * c4) : z4();
+            }
+            bt6(d, tcol);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) u[r][s] = tcol[r];
+        }
+        float* o = V + t * C + 4 * c4;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            float4 v[6];
+            bt6(u[r], v);       // (.) B  ==  B^T applied along the row
+#pragma unroll
+            for (int s = 0; s < 6; ++s) st4(o + (long)(6 * r + s) * plane, v[s]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wino4_out_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                        float* __restrict__ y, int N, int H, int W, int K, int relu) {
+    const int K4 = K >> 2, TH = H >> 2, TW = W >> 2;
+    const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i % K4);
+        const long t = i / K4;
+        const int tx = (int)(t % TW);
+        const int ty = (int)((t / TW) % TH);
+        const int n = (int)(t / ((long)TW * TH));
+        const float* m = M + t * K + 4 * k4;
+        float4 s[4][6];     // A^T M
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            float4 col[6], o4[4];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) col[r] = ld4(m + (long)(6 * r + c) * plane);
+            at6(col, o4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r][c] = o4[r];
+        }
+        const float4 b = bias != nullptr ? ld4(bias + 4 * k4) : z4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 row[4];
+            at6(s[r], row);
+            float* o = y + (((long)n * H + 4 * ty + r) * W + 4 * tx) * K + 4 * k4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float4 v = row[c] + b;
+                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                st4(o + (long)c * K, v);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N, int H, int W,
+                                                       int K) {
+    const int K4 = K >> 2, TH = H >> 2, TW = W >> 2;
+    const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i % K4);
+        const long t = i / K4;
+        const int tx = (int)(t % TW);
+        const int ty = (int)((t / TW) % TH);
+        const int n = (int)(t / ((long)TW * TH));
+        const float* g = dy + (((long)n * H + 4 * ty) * W + 4 * tx) * K + 4 * k4;
+        float4 u[6][4];     // A dy
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 col[4], o6[6];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) col[r] = ld4(g + ((long)r * W + c) * K);
+            a6(col, o6);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) u[r][c] = o6[r];
+        }
+        float* o = dM + t * K + 4 * k4;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            float4 row[6];
+            a6(u[r], row);      // (.) A^T
+#pragma unroll
+            for (int c = 0; c < 6; ++c) st4(o + (long)(6 * r + c) * plane, row[c]);
+        }
+    }
+}
+
+__device__ __forceinline__ void g6(const float (&g)[3], float (&a)[6]) {
+    a[0] = g[0] * 0.25f;
+    a[1] = -(g[0] + g[1] + g[2]) * (1.f / 6.f);
+    a[2] = -(g[0] - g[1] + g[2]) * (1.f / 6.f);
+    a[3] = g[0] * (1.f / 24.f) + g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+    a[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+    a[5] = g[2];
+}
+__device__ __forceinline__ void gt6(const float (&u)[6], float (&e)[3]) {      // e = G^T u (adjoint of g6)
+    e[0] = u[0] * 0.25f - (u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 24.f);
+    e[1] = (u[2] - u[1]) * (1.f / 6.f) + (u[3] - u[4]) * (1.f / 12.f);
+    e[2] = -(u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 6.f) + u[5];
+}
+
+// one thread per (k, c): U[36][K][C] and / or U'[36][C][K] (rotated, channel-transposed filter)
+__global__ void __launch_bounds__(256) wino4_w_kernel(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf,
+                                                      int K, int C) {
+    const long total = (long)K * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), k = (int)(i / C);
+        float w[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) w[r][s] = g[((long)k * 9 + r * 3 + s) * C + c];
+#pragma unroll
+        for (int flip = 0; flip < 2; ++flip) {
+            float* dst = flip ? Uf : U;
+            if (dst == nullptr) continue;
+            float a[6][3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                float col[3], o6[6];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) col[r] = flip ? w[2 - r][2 - s] : w[r][s];
+                g6(col, o6);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) a[r][s] = o6[r];
+            }
+            float* o = flip ? dst + (long)c * K + k : dst + (long)k * C + c;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                float row[6];
+                g6(a[r], row);
+#pragma unroll
+                for (int s = 0; s < 6; ++s) o[(long)(6 * r + s) * total] = row[s];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dg, int K, int C,
+                                                       int accumulate) {
+    const long total = (long)K * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), k = (int)(i / C);
+        float e[3][6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            float col[6], o3[3];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) col[r] = dU[(long)(6 * r + s) * total + i];
+            gt6(col, o3);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) e[r][s] = o3[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float v[3];
+            gt6(e[r], v);
+            float* o = dg + ((long)k * 9 + r * 3) * C + c;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                if (accumulate) o[(long)s * C] += v[s];
+                else o[(long)s * C] = v[s];
+            }
+        }
+    }
+}
+
+inline bool bad(int N, int H, int W, int C) { return N < 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3); }
 
 }  // namespace
 
 extern "C" {
 
-int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, void* stream) {
-    if (bad(N, H, W, C)) return OMNI_ERR_ARG;
-    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile, void* stream) {
+    if (bad(N, H, W, C) || (tile != 2 && tile != 4) || (H % tile) || (W % tile)) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / tile) * (W / tile) * (C / 4);
     if (total == 0) return OMNI_OK;
-    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C);
+    if (tile == 2) hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C);
+    else hipLaunchKernelGGL(wino4_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C);
     return omni_launch_status();
 }
 
-int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, void* stream) {
-    if (bad(N, H, W, K)) return OMNI_ERR_ARG;
-    const long total = (long)N * (H / 2) * (W / 2) * (K / 4);
+int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, void* stream) {
+    if (bad(N, H, W, K) || (tile != 2 && tile != 4) || (H % tile) || (W % tile)) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / tile) * (W / tile) * (K / 4);
     if (total == 0) return OMNI_OK;
-    hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu);
+    if (tile == 2) hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu);
+    else hipLaunchKernelGGL(wino4_out_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu);
     return omni_launch_status();
 }
 
-int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, void* stream) {
-    if (bad(N, H, W, K)) return OMNI_ERR_ARG;
-    const long total = (long)N * (H / 2) * (W / 2) * (K / 4);
+int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, int tile, void* stream) {
+    if (bad(N, H, W, K) || (tile != 2 && tile != 4) || (H % tile) || (W % tile)) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / tile) * (W / tile) * (K / 4);
     if (total == 0) return OMNI_OK;
-    hipLaunchKernelGGL(wino_dy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, N, H, W, K);
+    if (tile == 2) hipLaunchKernelGGL(wino_dy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, N, H, W, K);
+    else hipLaunchKernelGGL(wino4_dy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, N, H, W, K);
     return omni_launch_status();
 }
 
-int omni_wino_weights(const float* g, float* U, float* U_flip, int K, int C, void* stream) {
-    if (K <= 0 || C <= 0 || (U == nullptr && U_flip == nullptr)) return OMNI_ERR_ARG;
-    hipLaunchKernelGGL(wino_w_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
+int omni_wino_weights(const float* g, float* U, float* U_flip, int K, int C, int tile, void* stream) {
+    if (K <= 0 || C <= 0 || (U == nullptr && U_flip == nullptr) || (tile != 2 && tile != 4)) return OMNI_ERR_ARG;
+    if (tile == 2) hipLaunchKernelGGL(wino_w_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
+    else hipLaunchKernelGGL(wino4_w_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
     return omni_launch_status();
 }
 
-int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate, void* stream) {
-    if (K <= 0 || C <= 0) return OMNI_ERR_ARG;
-    hipLaunchKernelGGL(wino_dw_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, dU, dg, K, C, accumulate);
+int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate, int tile, void* stream) {
+    if (K <= 0 || C <= 0 || (tile != 2 && tile != 4)) return OMNI_ERR_ARG;
+    if (tile == 2) hipLaunchKernelGGL(wino_dw_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, dU, dg, K, C, accumulate);
+    else hipLaunchKernelGGL(wino4_dw_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, dU, dg, K, C, accumulate);
     return omni_launch_status();
 }
 

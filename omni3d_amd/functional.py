@@ -81,16 +81,17 @@ class _WinoConv3x3(Function):
         # the rotated filter; a weight shared by several calls of one step (the RPN conv over the FPN levels) is
         # transformed once (wino_weight_scope)
         need_flip = x.requires_grad and wino.dgrad_eligible(x.shape)
+        tile = wino.tile_size(x.shape)
         # The cache only lives inside one model forward (RCNN3D.forward opens and closes it): nothing can change a weight
         # in between, and no stale entry can outlive the tensor it was computed from.
-        key = (w.data_ptr(), tuple(w.shape))
+        key = (w.data_ptr(), tuple(w.shape), tile)
         cache = _wino_scope["cache"]
         U, Uf = cache.get(key, (None, None)) if cache is not None else (None, None)
         if U is None or (need_flip and Uf is None):
-            U, Uf = wino.transform_weights(w, True, need_flip or Uf is not None)
+            U, Uf = wino.transform_weights(w, True, need_flip or Uf is not None, tile)
             if cache is not None:
                 cache[key] = (U, Uf)
-        y, V = wino.conv3x3_fwd(x, w, bias, relu, U=U)
+        y, V = wino.conv3x3_fwd(x, w, bias, relu, U=U, tile=tile)
         ctx.save_for_backward(V, w, y if relu else None, Uf if need_flip else None)
         ctx.cfg = (relu, bias is not None)
         return y
@@ -107,7 +108,8 @@ class _WinoConv3x3(Function):
             gw = None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = wino.conv3x3_dgrad(dy, w, U_flip=Uf) if wino.dgrad_eligible(dy.shape) else conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1)
+            dx = (wino.conv3x3_dgrad(dy, w, U_flip=Uf, tile=2 if V.shape[0] == 16 else 4) if wino.dgrad_eligible(dy.shape)
+                  else conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1))
         dw = wino.conv3x3_wgrad(V, dy, accum_into=gw) if ctx.needs_input_grad[1] else None
         db = None
         if has_bias and ctx.needs_input_grad[2]:

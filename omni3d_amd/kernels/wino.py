@@ -7,13 +7,29 @@ from .. import lib as _lib
 CL = torch.channels_last
 
 
+import os as _os
+
+_F43 = _os.environ.get("OMNI_WINOGRAD_F43", "1") != "0"
+
+
 def eligible(x_shape, w_shape, stride, pad):
     """Wide (>= 128 channel) 3x3/s1/p1 layers on even maps with >= 256 tiles: FPN output / RPN convs on p2..p5 and the
     DLA level 3-5 blocks (measured per shape with tools/bench_kernels.py, profiles/README.md)."""
     N, C, H, W = x_shape
     K, _, R, S = w_shape
-    return (R == 3 and S == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0 and C % 32 == 0 and K % 32 == 0
-            and C >= 128 and K >= 128 and N * (H // 2) * (W // 2) >= 256)
+    if not (R == 3 and S == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0 and C % 32 == 0 and K % 32 == 0):
+        return False
+    if C >= 128 and K >= 128 and N * (H // 2) * (W // 2) >= 256:
+        return True
+    # 64-channel layers (DLA level 2, ResNet layer1) only pay off with the 36-point transform on large maps
+    return C >= 64 and K >= 64 and tile_size(x_shape) == 4 and N * (H // 4) * (W // 4) >= 4096
+
+
+def tile_size(x_shape):
+    """4 = F(4x4,3x3) (36 points, 2.25 multiplies per output) when the map divides into >= 1024 tiles of 4x4, else 2 =
+    F(2x2,3x3) (16 points, 4 multiplies per output)."""
+    N, _, H, W = x_shape
+    return 4 if (_F43 and H % 4 == 0 and W % 4 == 0 and N * (H // 4) * (W // 4) >= 1024) else 2
 
 
 def dgrad_eligible(x_shape):
@@ -27,26 +43,30 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1)
 
 
-def transform_input(x):
-    """x (N,C,H,W) CL -> V (16, T, C)"""
+def _points(tile):
+    return (tile + 2) ** 2
+
+
+def transform_input(x, tile=2):
+    """x (N,C,H,W) CL -> V (P, T, C), P = (tile + 2)^2 Winograd points, T = N * H/tile * W/tile"""
     xv = _nhwc(x)
     N, H, W, C = xv.shape
     L = _lib.check_device(xv)
-    V = torch.empty((16, N * (H // 2) * (W // 2), C), dtype=torch.float32, device=x.device)
-    L.call("omni_wino_in", _lib.ptr(xv), _lib.ptr(V), N, H, W, C, _lib.stream_of(x))
+    V = torch.empty((_points(tile), N * (H // tile) * (W // tile), C), dtype=torch.float32, device=x.device)
+    L.call("omni_wino_in", _lib.ptr(xv), _lib.ptr(V), N, H, W, C, tile, _lib.stream_of(x))
     return V
 
 
-def transform_weights(w, want_u=True, want_flip=False):
+def transform_weights(w, want_u=True, want_flip=False, tile=2):
     """w (K,C,3,3) CL (KRSC) -> (U (16,K,C) or None, U' (16,C,K) or None); U' = transform of the rotated, channel-transposed
     filter (the data gradient's weights), produced by the same launch."""
     K, C = w.shape[0], w.shape[1]
     wv = w.permute(0, 2, 3, 1)
     assert wv.is_contiguous()
     L = _lib.check_device(wv)
-    U = torch.empty((16, K, C), dtype=torch.float32, device=w.device) if want_u else None
-    Uf = torch.empty((16, C, K), dtype=torch.float32, device=w.device) if want_flip else None
-    L.call("omni_wino_weights", _lib.ptr(wv), _lib.ptr(U), _lib.ptr(Uf), K, C, _lib.stream_of(w))
+    U = torch.empty((_points(tile), K, C), dtype=torch.float32, device=w.device) if want_u else None
+    Uf = torch.empty((_points(tile), C, K), dtype=torch.float32, device=w.device) if want_flip else None
+    L.call("omni_wino_weights", _lib.ptr(wv), _lib.ptr(U), _lib.ptr(Uf), K, C, tile, _lib.stream_of(w))
     return U, Uf
 
 
@@ -71,57 +91,59 @@ def gemm_batched_wgrad(V, dM):
 
 
 def transform_output(Mt, shape, bias=None, relu=False):
-    """Mt (16,T,K) -> y (N,K,H,W) CL; shape = (N, H, W)"""
+    """Mt (P,T,K) -> y (N,K,H,W) CL; shape = (N, H, W); the tile size follows from P"""
+    tile = 2 if Mt.shape[0] == 16 else 4
     N, H, W = shape
     K = Mt.shape[2]
     L = _lib.check_device(Mt, bias)
     y = torch.empty((N, H, W, K), dtype=torch.float32, device=Mt.device)
-    L.call("omni_wino_out", _lib.ptr(Mt), _lib.ptr(bias), _lib.ptr(y), N, H, W, K, int(relu), _lib.stream_of(Mt))
+    L.call("omni_wino_out", _lib.ptr(Mt), _lib.ptr(bias), _lib.ptr(y), N, H, W, K, int(relu), tile, _lib.stream_of(Mt))
     return y.permute(0, 3, 1, 2)
 
 
-def transform_dy(dy):
-    """dy (N,K,H,W) CL -> dM (16,T,K)"""
+def transform_dy(dy, tile=2):
+    """dy (N,K,H,W) CL -> dM (P,T,K)"""
     dv = _nhwc(dy)
     N, H, W, K = dv.shape
     L = _lib.check_device(dv)
-    dM = torch.empty((16, N * (H // 2) * (W // 2), K), dtype=torch.float32, device=dy.device)
-    L.call("omni_wino_dy", _lib.ptr(dv), _lib.ptr(dM), N, H, W, K, _lib.stream_of(dy))
+    dM = torch.empty((_points(tile), N * (H // tile) * (W // tile), K), dtype=torch.float32, device=dy.device)
+    L.call("omni_wino_dy", _lib.ptr(dv), _lib.ptr(dM), N, H, W, K, tile, _lib.stream_of(dy))
     return dM
 
 
 def transform_dweights(dU, accum_into=None):
-    """dU (16,K,C) -> dw (K,C,3,3) CL; accum_into: KRSC-contiguous gradient view to ADD into (returns None)."""
-    _, K, C = dU.shape
+    """dU (P,K,C) -> dw (K,C,3,3) CL; accum_into: KRSC-contiguous gradient view to ADD into (returns None)."""
+    P, K, C = dU.shape
+    tile = 2 if P == 16 else 4
     L = _lib.check_device(dU)
     if accum_into is not None:
         gv = accum_into.permute(0, 2, 3, 1)
         assert gv.is_contiguous()
-        L.call("omni_wino_dweights", _lib.ptr(dU), _lib.ptr(gv), K, C, 1, _lib.stream_of(dU))
+        L.call("omni_wino_dweights", _lib.ptr(dU), _lib.ptr(gv), K, C, 1, tile, _lib.stream_of(dU))
         return None
     dw = torch.empty((K, 3, 3, C), dtype=torch.float32, device=dU.device)
-    L.call("omni_wino_dweights", _lib.ptr(dU), _lib.ptr(dw), K, C, 0, _lib.stream_of(dU))
+    L.call("omni_wino_dweights", _lib.ptr(dU), _lib.ptr(dw), K, C, 0, tile, _lib.stream_of(dU))
     return dw.permute(0, 3, 1, 2)
 
 
-def conv3x3_fwd(x, w, bias=None, relu=False, U=None):
-    """-> (y, V): V is kept by the caller for the weight gradient.  U: precomputed transform_weights(w)[0]."""
+def conv3x3_fwd(x, w, bias=None, relu=False, U=None, tile=2):
+    """-> (y, V): V is kept by the caller for the weight gradient.  U: precomputed transform_weights(w, tile=tile)[0]."""
     N, _, H, W = x.shape
-    V = transform_input(x)
+    V = transform_input(x, tile)
     if U is None:
-        U = transform_weights(w)[0]
+        U = transform_weights(w, tile=tile)[0]
     Mt = gemm_batched(V, U)
     return transform_output(Mt, (N, H, W), bias, relu), V
 
 
-def conv3x3_dgrad(dy, w, U_flip=None):
+def conv3x3_dgrad(dy, w, U_flip=None, tile=2):
     """dx = the same Winograd convolution applied to dy with the rotated / transposed filter."""
     N, _, H, W = dy.shape
     if U_flip is None:
-        U_flip = transform_weights(w, want_u=False, want_flip=True)[1]
-    Mt = gemm_batched(transform_input(dy), U_flip)
+        U_flip = transform_weights(w, want_u=False, want_flip=True, tile=tile)[1]
+    Mt = gemm_batched(transform_input(dy, tile), U_flip)
     return transform_output(Mt, (N, H, W))
 
 
 def conv3x3_wgrad(V, dy, accum_into=None):
-    return transform_dweights(gemm_batched_wgrad(V, transform_dy(dy)), accum_into)
+    return transform_dweights(gemm_batched_wgrad(V, transform_dy(dy, 2 if V.shape[0] == 16 else 4)), accum_into)

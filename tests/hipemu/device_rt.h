@@ -52,6 +52,8 @@ struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline float4 operator+(float4 a, float4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 static inline float4 operator-(float4 a, float4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
 static inline float4 operator*(float4 a, float4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+static inline float4 operator*(float4 a, float b) { return {a.x * b, a.y * b, a.z * b, a.w * b}; }
+static inline float4 operator*(float a, float4 b) { return {a * b.x, a * b.y, a * b.z, a * b.w}; }
 static inline float2 make_float2(float x, float y) { return {x, y}; }
 static inline float3 make_float3(float x, float y, float z) { return {x, y, z}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }

@@ -82,18 +82,21 @@ def main():
         w = (torch.randn(CH, CH, 3, 3, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
         dy = torch.randn_like(x)
         gf = 2.0 * B * H * H * CH * CH * 9 / 1e9
-        _, V = wino.conv3x3_fwd(x, w)
-        t1 = timeit(lambda: wino.conv3x3_fwd(x, w))
-        t2 = timeit(lambda: wino.conv3x3_dgrad(dy, w))
-        t3 = timeit(lambda: wino.conv3x3_wgrad(V, dy))
-        print(f"{name:34s} {gf:7.2f} | {t1:7.3f} {gf / t1:6.1f} | {t2:7.3f} {gf / t2:6.1f} | {t3:7.3f} {gf / t3:6.1f}")
-        Vd, U = wino.transform_input(x), wino.transform_weights(w)[0]
-        Mt = wino.gemm_batched(Vd, U)
-        dM = wino.transform_dy(dy)
-        parts = {"in": lambda: wino.transform_input(x), "w": lambda: wino.transform_weights(w, True, True), "gemm": lambda: wino.gemm_batched(Vd, U),
-                 "out": lambda: wino.transform_output(Mt, (B, H, H)), "dy": lambda: wino.transform_dy(dy),
-                 "gemm_wgrad": lambda: wino.gemm_batched_wgrad(Vd, dM)}
-        print("   parts:", {k: round(timeit(f), 3) for k, f in parts.items()})
+        for tile in (2, 4):
+            if H % tile or B * (H // tile) ** 2 < 64:
+                continue
+            _, V = wino.conv3x3_fwd(x, w, tile=tile)
+            t1 = timeit(lambda: wino.conv3x3_fwd(x, w, tile=tile))
+            t2 = timeit(lambda: wino.conv3x3_dgrad(dy, w, tile=tile))
+            t3 = timeit(lambda: wino.conv3x3_wgrad(V, dy))
+            print(f"{name + ' F(%dx%d)' % (tile, tile):34s} {gf:7.2f} | {t1:7.3f} {gf / t1:6.1f} | {t2:7.3f} {gf / t2:6.1f} | {t3:7.3f} {gf / t3:6.1f}")
+            Vd, U = wino.transform_input(x, tile), wino.transform_weights(w, tile=tile)[0]
+            Mt = wino.gemm_batched(Vd, U)
+            dM = wino.transform_dy(dy, tile)
+            parts = {"in": lambda: wino.transform_input(x, tile), "w": lambda: wino.transform_weights(w, True, True, tile),
+                     "gemm": lambda: wino.gemm_batched(Vd, U), "out": lambda: wino.transform_output(Mt, (B, H, H)),
+                     "dy": lambda: wino.transform_dy(dy, tile), "gemm_wgrad": lambda: wino.gemm_batched_wgrad(Vd, dM)}
+            print("   parts:", {k: round(timeit(f), 3) for k, f in parts.items()})
     for name, M, C, K in LINEARS:
         x = torch.randn(M, C, device="cuda")
         w = torch.randn(K, C, device="cuda") * 0.02
