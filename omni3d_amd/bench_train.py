@@ -203,28 +203,28 @@ def _time_launch(fn, iters):
 def dominant_kernel_roofline(iters=20):
     """Dominant kernel of the step = the batched GEMM of the Winograd path (gemm_nt_persistent_kernel: fp32 MFMA, 128x128
     tiles, prefetch carried across work items).  Its largest launch serves the 3x3 256->256 convs on the 128x128 map (FPN
-    output p2 and the RPN conv on p2, forward and data gradient): 16 x [16384 x 256] * [256 x 256]^T at batch 4, 34.4 GFLOP
-    and 541 MB of algorithmic traffic per launch (V 268.4 + U 4.2 read, M 268.4 written).  Timed live with HIP events on
-    the launch stream; the direct implicit-GEMM kernel of the same layer is reported next to it."""
+    output p2 and the RPN conv on p2, forward and data gradient) through F(4x4,3x3): 36 x [4096 x 256] * [256 x 256]^T at
+    batch 4, 19.3 GFLOP and 312 MB of algorithmic traffic per launch (V 151.0 + U 9.4 read, M 151.0 written).  Timed live
+    with HIP events on the launch stream; the direct implicit-GEMM kernel of the same layer is reported next to it."""
     from omni3d_amd.kernels import conv, wino
     B, C, H = IMS_PER_GPU, 256, 128
     x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
     w = (torch.randn(C, C, 3, 3, device="cuda") * 0.02).contiguous(memory_format=torch.channels_last)
-    V, U = wino.transform_input(x), wino.transform_weights(w)[0]
-    T = V.shape[1]
+    V, U = wino.transform_input(x, 4), wino.transform_weights(w, tile=4)[0]
+    P, T = V.shape[0], V.shape[1]
     ms = _time_launch(lambda: wino.gemm_batched(V, U), iters)
-    flops = 2.0 * 16 * T * C * C
+    flops = 2.0 * P * T * C * C
     tf = flops / (ms * 1e-3) / 1e12
     ms_direct = _time_launch(lambda: conv.conv2d_fwd(x, w, None, 1, 1), iters)
     flops_direct = 2.0 * B * H * H * C * C * 9
-    ms_wino = _time_launch(lambda: wino.conv3x3_fwd(x, w), iters)
-    return {"bound": "mfma", "kernel": "gemm_nt_persistent_kernel: Winograd batched GEMM 16x[16384x256]x[256x256]^T "
+    ms_wino = _time_launch(lambda: wino.conv3x3_fwd(x, w, tile=4), iters)
+    return {"bound": "mfma", "kernel": "gemm_nt_persistent_kernel: Winograd F(4x4,3x3) batched GEMM 36x[4096x256]x[256x256]^T "
                                        "(3x3 256->256 @128x128, batch 4)",
             "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
-            # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_persistent_gemm.csv): FETCH_SIZE 141.6 MB x2
-            # (gfx950 wide-read correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 268.4 MB
-            "traffic": 551.6e6, "traffic_unit": "bytes/launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
-            "algorithmic_bytes_per_launch": 4.0 * (2 * 16 * T * C + 16 * C * C),
+            # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_persistent_gemm_f43.csv): FETCH_SIZE 82.3 MB x2
+            # (gfx950 wide-read correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 151.0 MB
+            "traffic": 315.6e6, "traffic_unit": "bytes/launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+            "algorithmic_bytes_per_launch": 4.0 * (2 * P * T * C + P * C * C),
             "kernel_ms": ms, "flops_per_launch": flops, "operands": "fp32 (v_mfma_f32_32x32x2_f32)",
             "direct_conv_same_layer": {"kernel": "conv_fwd_kernel<128,128,2,2,32>", "shape": "3x3 256->256 @128x128 batch 4 implicit GEMM",
                                        "kernel_ms": ms_direct,

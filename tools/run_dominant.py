@@ -16,10 +16,10 @@ for _ in range(5):
     conv.conv2d_fwd(x, w, None, 1, 1)
     conv.conv2d_dgrad(dy, w, (128, 128), 1, 1)
     conv.conv2d_wgrad(x, dy, (3, 3), 1, 1)
-# the Winograd batched GEMM of the same layer (16 x [16384 x 256] * [256 x 256]^T): grid (256, 1, 16) of conv_fwd_kernel<128,128>
+# the Winograd batched GEMM of the same layer (gemm_nt_persistent_kernel)
 from omni3d_amd.kernels import wino
-V, U = wino.transform_input(x), wino.transform_weights(w)[0]
-dM = wino.transform_dy(dy)
+V, U = wino.transform_input(x, 4), wino.transform_weights(w, tile=4)[0]     # F(4x4,3x3): 36 x [4096 x 256] * [256 x 256]^T
+dM = wino.transform_dy(dy, 4)
 for _ in range(5):
     wino.gemm_batched(V, U)
     wino.gemm_batched_wgrad(V, dM)
