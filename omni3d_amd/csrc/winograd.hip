@@ -134,49 +134,60 @@ __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ 
     }
 }
 
-// one thread per (k, c).  U[xi][k][c] = (G g G^T)[xi]; optionally also U'[xi][c][k], the transform of the 180-degree rotated,
-// channel-transposed filter (what the data gradient convolves dy with): rotating g permutes the rows of G g by
-// pi = (3, 1, 2, 0), so U'[4i + j][c][k] = U[4 pi(i) + pi(j)][k][c] -- no second pass over g.
+// U[xi][k][c] = (G g G^T)[xi]; optionally also U'[xi][c][k], the transform of the 180-degree rotated, channel-transposed filter
+// (what the data gradient convolves dy with): rotating g permutes the rows of G g by pi = (3, 1, 2, 0), so
+// U'[4i + j][c][k] = U[4 pi(i) + pi(j)][k][c] -- no second pass over g.
 __global__ void __launch_bounds__(256) wino_w_kernel(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf,
                                                      int K, int C) {
+    // one 16 (k) x 16 (c) tile per block; U' goes through an LDS transpose so that its rows (k contiguous) are written
+    // in 64-byte runs instead of 4-byte scatters
+    __shared__ float s_t[16][16][17];
     const long total = (long)K * C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C), k = (int)(i / C);
-        float w[3][3];
+    const int tiles_c = (C + 15) / 16;
+    const int k0 = ((int)blockIdx.x / tiles_c) * 16, c0 = ((int)blockIdx.x % tiles_c) * 16;
+    const int kk = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    const int k = k0 + kk, c = c0 + cc;
+    const bool ok = k < K && c < C;
+    float w[3][3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) w[r][s] = g[((long)k * 9 + r * 3 + s) * C + c];
-        float a[4][3];
+        for (int s = 0; s < 3; ++s) w[r][s] = ok ? g[((long)k * 9 + r * 3 + s) * C + c] : 0.f;
+    float a[4][3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {       // G g
-            a[0][s] = w[0][s];
-            a[1][s] = 0.5f * (w[0][s] + w[1][s] + w[2][s]);
-            a[2][s] = 0.5f * (w[0][s] - w[1][s] + w[2][s]);
-            a[3][s] = w[2][s];
-        }
-        float u[4][4];
+    for (int s = 0; s < 3; ++s) {       // G g
+        a[0][s] = w[0][s];
+        a[1][s] = 0.5f * (w[0][s] + w[1][s] + w[2][s]);
+        a[2][s] = 0.5f * (w[0][s] - w[1][s] + w[2][s]);
+        a[3][s] = w[2][s];
+    }
+    float u[4][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {       // (.) G^T
-            u[r][0] = a[r][0];
-            u[r][1] = 0.5f * (a[r][0] + a[r][1] + a[r][2]);
-            u[r][2] = 0.5f * (a[r][0] - a[r][1] + a[r][2]);
-            u[r][3] = a[r][2];
-        }
-        if (U != nullptr) {
+    for (int r = 0; r < 4; ++r) {       // (.) G^T
+        u[r][0] = a[r][0];
+        u[r][1] = 0.5f * (a[r][0] + a[r][1] + a[r][2]);
+        u[r][2] = 0.5f * (a[r][0] - a[r][1] + a[r][2]);
+        u[r][3] = a[r][2];
+    }
+    if (U != nullptr && ok) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) U[(long)(4 * r + t) * total + (long)k * C + c] = u[r][t];
-        }
-        if (Uf != nullptr) {
+            for (int t = 0; t < 4; ++t) U[(long)(4 * r + t) * total + (long)k * C + c] = u[r][t];
+    }
+    if (Uf != nullptr) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int pr = (r == 0) ? 3 : (r == 3) ? 0 : r, pt = (t == 0) ? 3 : (t == 3) ? 0 : t;
-                    Uf[(long)(4 * r + t) * total + (long)c * K + k] = u[pr][pt];
-                }
+            for (int t = 0; t < 4; ++t) {
+                const int pr = (r == 0) ? 3 : (r == 3) ? 0 : r, pt = (t == 0) ? 3 : (t == 3) ? 0 : t;
+                s_t[4 * r + t][cc][kk] = u[pr][pt];
+            }
+        __syncthreads();
+        const int oc = c0 + kk, okk = k0 + cc;       // this thread now writes (c = c0 + kk, k = k0 + cc)
+        if (oc < C && okk < K) {
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) Uf[(long)xi * total + (long)oc * K + okk] = s_t[xi][kk][cc];
         }
     }
 }
@@ -364,38 +375,52 @@ __device__ __forceinline__ void gt6(const float (&u)[6], float (&e)[3]) {      /
     e[2] = -(u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 6.f) + u[5];
 }
 
-// one thread per (k, c): U[36][K][C] and / or U'[36][C][K] (rotated, channel-transposed filter)
+// U[36][K][C] and / or U'[36][C][K] (rotated, channel-transposed filter); 16 x 16 (k, c) tile per block, U' through an LDS
+// transpose (as wino_w_kernel)
 __global__ void __launch_bounds__(256) wino4_w_kernel(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf,
                                                       int K, int C) {
+    __shared__ float s_t[36][16][17];
     const long total = (long)K * C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C), k = (int)(i / C);
-        float w[3][3];
+    const int tiles_c = (C + 15) / 16;
+    const int k0 = ((int)blockIdx.x / tiles_c) * 16, c0 = ((int)blockIdx.x % tiles_c) * 16;
+    const int kk = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    const int k = k0 + kk, c = c0 + cc;
+    const bool ok = k < K && c < C;
+    float w[3][3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) w[r][s] = g[((long)k * 9 + r * 3 + s) * C + c];
+        for (int s = 0; s < 3; ++s) w[r][s] = ok ? g[((long)k * 9 + r * 3 + s) * C + c] : 0.f;
 #pragma unroll
-        for (int flip = 0; flip < 2; ++flip) {
-            float* dst = flip ? Uf : U;
-            if (dst == nullptr) continue;
-            float a[6][3];
+    for (int flip = 0; flip < 2; ++flip) {
+        float* dst = flip ? Uf : U;
+        if (dst == nullptr) continue;            // uniform
+        float a[6][3];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                float col[3], o6[6];
+        for (int s = 0; s < 3; ++s) {
+            float col[3], o6[6];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) col[r] = flip ? w[2 - r][2 - s] : w[r][s];
-                g6(col, o6);
+            for (int r = 0; r < 3; ++r) col[r] = flip ? w[2 - r][2 - s] : w[r][s];
+            g6(col, o6);
 #pragma unroll
-                for (int r = 0; r < 6; ++r) a[r][s] = o6[r];
+            for (int r = 0; r < 6; ++r) a[r][s] = o6[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            float row[6];
+            g6(a[r], row);
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                if (!flip) { if (ok) dst[(long)(6 * r + s) * total + (long)k * C + c] = row[s]; }
+                else s_t[6 * r + s][cc][kk] = row[s];
             }
-            float* o = flip ? dst + (long)c * K + k : dst + (long)k * C + c;
+        }
+        if (flip) {
+            __syncthreads();
+            const int oc = c0 + kk, okk = k0 + cc;
+            if (oc < C && okk < K) {
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                float row[6];
-                g6(a[r], row);
-#pragma unroll
-                for (int s = 0; s < 6; ++s) o[(long)(6 * r + s) * total] = row[s];
+                for (int xi = 0; xi < 36; ++xi) dst[(long)xi * total + (long)oc * K + okk] = s_t[xi][kk][cc];
             }
         }
     }
@@ -465,8 +490,9 @@ int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, int til
 
 int omni_wino_weights(const float* g, float* U, float* U_flip, int K, int C, int tile, void* stream) {
     if (K <= 0 || C <= 0 || (U == nullptr && U_flip == nullptr) || (tile != 2 && tile != 4)) return OMNI_ERR_ARG;
-    if (tile == 2) hipLaunchKernelGGL(wino_w_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
-    else hipLaunchKernelGGL(wino4_w_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
+    const unsigned wt = (unsigned)(((K + 15) / 16) * ((C + 15) / 16));       // one 16 x 16 (k, c) tile per workgroup
+    if (tile == 2) hipLaunchKernelGGL(wino_w_kernel, dim3(wt), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
+    else hipLaunchKernelGGL(wino4_w_kernel, dim3(wt), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
     return omni_launch_status();
 }
 
