@@ -76,6 +76,14 @@ class CfgNode(dict):
     def load_yaml_with_base(filename):
         with open(filename, "r") as f:
             cfg = yaml.safe_load(f) or {}
+        # this package's own presets are written as flat dotted keys ("MODEL.RPN.HEAD_NAME: ..."); nested YAML (the
+        # reference's configs/*.yaml) loads exactly as in yacs
+        flat = [k for k in cfg if isinstance(k, str) and "." in k]
+        for k in flat:
+            node, parts = cfg, k.split(".")
+            for sub in parts[:-1]:
+                node = node.setdefault(sub, {})
+            node[parts[-1]] = cfg.pop(k)
 
         def merge_a_into_b(a, b):
             for k, v in a.items():
