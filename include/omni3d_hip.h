@@ -249,6 +249,8 @@ int omni_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int N, int H
 int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile, void* stream);
 int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, void* stream);
 int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, int tile, void* stream);
+/* backward: dM (as omni_wino_dy) and V_dy (as omni_wino_in of dy) from one read of dy */
+int omni_wino_dy_in(const float* dy, float* dM, float* Vd, int N, int H, int W, int K, int tile, void* stream);
 int omni_wino_weights(const float* g, float* U /*nullable*/, float* U_flip /*nullable: U'*/, int K, int C, int tile, void* stream);
 int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate, int tile, void* stream);
 /* `batch` independent dense GEMMs in one launch (the 16 Winograd points):

@@ -455,6 +455,129 @@ __global__ void __launch_bounds__(256) wino4_dw_kernel(const float* __restrict__
     }
 }
 
+// ---- backward: both transforms of dy in one pass ---------------------------------------------------------------------
+// The data gradient needs V_dy = B^T dy B (the (tile+2)^2 window, like wino_in) and the weight gradient needs
+// dM = A dy A^T (the central tile x tile block of the same window): one kernel reads the window once and writes both.
+__global__ void __launch_bounds__(256) wino_dy_in_kernel(const float* __restrict__ dy, float* __restrict__ dM, float* __restrict__ Vd,
+                                                         int N, int H, int W, int K) {
+    const int K4 = K >> 2, TH = H >> 1, TW = W >> 1;
+    const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i % K4);
+        const long t = i / K4;
+        const int tx = (int)(t % TW);
+        const int ty = (int)((t / TW) % TH);
+        const int n = (int)(t / ((long)TW * TH));
+        float4 d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ih = 2 * ty - 1 + r;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int iw = 2 * tx - 1 + s;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                d[r][s] = ok ? ld4(dy + (((long)n * H + ih) * W + iw) * K + 4 * k4) : z4();
+            }
+        }
+        const long o = t * K + 4 * k4;
+        {   // V_dy = B^T d B
+            float4 u[4][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                u[0][s] = d[0][s] - d[2][s];
+                u[1][s] = d[1][s] + d[2][s];
+                u[2][s] = d[2][s] - d[1][s];
+                u[3][s] = d[1][s] - d[3][s];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st4(Vd + o + (long)(4 * r + 0) * plane, u[r][0] - u[r][2]);
+                st4(Vd + o + (long)(4 * r + 1) * plane, u[r][1] + u[r][2]);
+                st4(Vd + o + (long)(4 * r + 2) * plane, u[r][2] - u[r][1]);
+                st4(Vd + o + (long)(4 * r + 3) * plane, u[r][1] - u[r][3]);
+            }
+        }
+        {   // dM = A g A^T of the central 2x2 block
+            const float4 g00 = d[1][1], g01 = d[1][2], g10 = d[2][1], g11 = d[2][2];
+            float4 u[4][2];
+            u[0][0] = g00;        u[0][1] = g01;
+            u[1][0] = g00 + g10;  u[1][1] = g01 + g11;
+            u[2][0] = g00 - g10;  u[2][1] = g01 - g11;
+            u[3][0] = z4() - g10; u[3][1] = z4() - g11;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st4(dM + o + (long)(4 * r + 0) * plane, u[r][0]);
+                st4(dM + o + (long)(4 * r + 1) * plane, u[r][0] + u[r][1]);
+                st4(dM + o + (long)(4 * r + 2) * plane, u[r][0] - u[r][1]);
+                st4(dM + o + (long)(4 * r + 3) * plane, z4() - u[r][1]);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wino4_dy_in_kernel(const float* __restrict__ dy, float* __restrict__ dM, float* __restrict__ Vd,
+                                                          int N, int H, int W, int K) {
+    const int K4 = K >> 2, TH = H >> 2, TW = W >> 2;
+    const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i % K4);
+        const long t = i / K4;
+        const int tx = (int)(t % TW);
+        const int ty = (int)((t / TW) % TH);
+        const int n = (int)(t / ((long)TW * TH));
+        float4 d[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int ih = 4 * ty - 1 + r;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const int iw = 4 * tx - 1 + s;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                d[r][s] = ok ? ld4(dy + (((long)n * H + ih) * W + iw) * K + 4 * k4) : z4();
+            }
+        }
+        const long o = t * K + 4 * k4;
+        {   // dM = A g A^T of the central 4x4 block
+            float4 u[6][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float4 col[4], o6[6];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) col[r] = d[1 + r][1 + c];
+                a6(col, o6);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) u[r][c] = o6[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                float4 row[6];
+                a6(u[r], row);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) st4(dM + o + (long)(6 * r + c) * plane, row[c]);
+            }
+        }
+        {   // V_dy = B^T d B
+            float4 u[6][6];
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                float4 col[6], tcol[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) col[r] = d[r][s];
+                bt6(col, tcol);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) u[r][s] = tcol[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                float4 v[6];
+                bt6(u[r], v);
+#pragma unroll
+                for (int s = 0; s < 6; ++s) st4(Vd + o + (long)(6 * r + s) * plane, v[s]);
+            }
+        }
+    }
+}
+
 inline bool bad(int N, int H, int W, int C) { return N < 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3); }
 
 }  // namespace
@@ -485,6 +608,15 @@ int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, int til
     if (total == 0) return OMNI_OK;
     if (tile == 2) hipLaunchKernelGGL(wino_dy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, N, H, W, K);
     else hipLaunchKernelGGL(wino4_dy_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, N, H, W, K);
+    return omni_launch_status();
+}
+
+int omni_wino_dy_in(const float* dy, float* dM, float* Vd, int N, int H, int W, int K, int tile, void* stream) {
+    if (bad(N, H, W, K) || (tile != 2 && tile != 4) || (H % tile) || (W % tile)) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / tile) * (W / tile) * (K / 4);
+    if (total == 0) return OMNI_OK;
+    if (tile == 2) hipLaunchKernelGGL(wino_dy_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, Vd, N, H, W, K);
+    else hipLaunchKernelGGL(wino4_dy_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, Vd, N, H, W, K);
     return omni_launch_status();
 }
 

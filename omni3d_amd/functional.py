@@ -106,11 +106,15 @@ class _WinoConv3x3(Function):
         gw, gb = ctx.direct
         if gw is not None and not gw.is_contiguous(memory_format=CL):
             gw = None
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = (wino.conv3x3_dgrad(dy, w, U_flip=Uf, tile=2 if V.shape[0] == 16 else 4) if wino.dgrad_eligible(dy.shape)
-                  else conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1))
-        dw = wino.conv3x3_wgrad(V, dy, accum_into=gw) if ctx.needs_input_grad[1] else None
+        dx = dw = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and wino.dgrad_eligible(dy.shape):
+            dx, dw = wino.conv3x3_backward(V, dy, w, Uf, accum_into=gw)          # both transforms of dy in one pass
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = (wino.conv3x3_dgrad(dy, w, U_flip=Uf, tile=2 if V.shape[0] == 16 else 4) if wino.dgrad_eligible(dy.shape)
+                      else conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1))
+            if ctx.needs_input_grad[1]:
+                dw = wino.conv3x3_wgrad(V, dy, accum_into=gw)
         db = None
         if has_bias and ctx.needs_input_grad[2]:
             db = bnpool.bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]), accum_into=gb)

@@ -111,6 +111,18 @@ def transform_dy(dy, tile=2):
     return dM
 
 
+def transform_dy_both(dy, tile=2):
+    """dy (N,K,H,W) CL -> (dM (P,T,K), V_dy (P,T,K)): the weight-gradient and data-gradient transforms of dy in one pass"""
+    dv = _nhwc(dy)
+    N, H, W, K = dv.shape
+    L = _lib.check_device(dv)
+    shape = (_points(tile), N * (H // tile) * (W // tile), K)
+    dM = torch.empty(shape, dtype=torch.float32, device=dy.device)
+    Vd = torch.empty(shape, dtype=torch.float32, device=dy.device)
+    L.call("omni_wino_dy_in", _lib.ptr(dv), _lib.ptr(dM), _lib.ptr(Vd), N, H, W, K, tile, _lib.stream_of(dy))
+    return dM, Vd
+
+
 def transform_dweights(dU, accum_into=None):
     """dU (P,K,C) -> dw (K,C,3,3) CL; accum_into: KRSC-contiguous gradient view to ADD into (returns None)."""
     P, K, C = dU.shape
@@ -143,6 +155,17 @@ def conv3x3_dgrad(dy, w, U_flip=None, tile=2):
         U_flip = transform_weights(w, want_u=False, want_flip=True, tile=tile)[1]
     Mt = gemm_batched(transform_input(dy, tile), U_flip)
     return transform_output(Mt, (N, H, W))
+
+
+def conv3x3_backward(V, dy, w, U_flip, accum_into=None):
+    """data gradient + weight gradient through Winograd with ONE pass over dy -> (dx, dw or None when accumulated)"""
+    N, _, H, W = dy.shape
+    tile = 2 if V.shape[0] == 16 else 4
+    dM, Vd = transform_dy_both(dy, tile)
+    if U_flip is None:
+        U_flip = transform_weights(w, want_u=False, want_flip=True, tile=tile)[1]
+    dx = transform_output(gemm_batched(Vd, U_flip), (N, H, W))
+    return dx, transform_dweights(gemm_batched_wgrad(V, dM), accum_into)
 
 
 def conv3x3_wgrad(V, dy, accum_into=None):

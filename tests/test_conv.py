@@ -143,6 +143,10 @@ def _run_wino(dev, N, C, K, H, W, seed=3, tile=2):
     assert (dx.cpu() - xr.grad).abs().max() <= tol * float(F.conv_transpose2d(dy.abs(), w.abs(), padding=1).max())
     dw = wino.conv3x3_wgrad(V, cl(dz))
     assert (dw.cpu() - wr.grad).abs().max() <= 5 * tol * max(1.0, float(wr.grad.abs().max()))
+    dx2, dw2 = wino.conv3x3_backward(V, cl(dz), wk, None)                       # fused dy transforms: same results
+    # same arithmetic, separately compiled kernels (fp contraction may differ on the GPU) / split-K atomics for dw
+    assert (dx2 - dx).abs().max() <= 1e-5 * max(1.0, float(dx.abs().max()))
+    assert (dw2 - dw).abs().max() <= 1e-5 * max(1.0, float(dw.abs().max()))
     acc = torch.ones_like(wk)
     wino.conv3x3_wgrad(V, cl(dz), accum_into=acc)
     assert (acc.cpu() - 1.0 - wr.grad).abs().max() <= 5 * tol * max(1.0, float(wr.grad.abs().max()))
