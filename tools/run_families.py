@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Runs one representative layer of every MFMA kernel family of the cubercnn_DLA34_FPN training step (batch 4, 512x512)
+through the PRODUCTION dispatch (omni3d_amd.functional: Winograd where the model uses it, direct implicit GEMM elsewhere),
+forward + data gradient + weight gradient, so that `rocprofv3 --pmc` passes (tools/pmc_run.py) can attribute MFMA / HBM
+counters to each (kernel, grid).  Shapes: SURVEY.md 8(a)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from omni3d_amd import functional as F
+
+B = 4
+CONVS = [  # name, H, C, K, R, stride
+    ("fpn/rpn 3x3 256->256 @128", 128, 256, 256, 3, 1),
+    ("fpn/rpn 3x3 256->256 @64", 64, 256, 256, 3, 1),
+    ("l2 3x3 64->64 @128", 128, 64, 64, 3, 1),
+    ("l3 3x3 128->128 @64", 64, 128, 128, 3, 1),
+    ("l4 3x3 256->256 @32", 32, 256, 256, 3, 1),
+    ("l5 3x3 512->512 @16", 16, 512, 512, 3, 1),
+    ("l3 3x3s2 64->128 @128", 128, 64, 128, 3, 2),
+    ("l3 root 1x1 448->128 @64", 64, 448, 128, 1, 1),
+    ("l4 root 1x1 896->256 @32", 32, 896, 256, 1, 1),
+    ("fpn lat 1x1 64->256 @128", 128, 64, 256, 1, 1),
+]
+LINEARS = [("fc1 2048x12544->1024", 2048, 12544, 1024), ("fc2 2048x1024->1024", 2048, 1024, 1024),
+           ("cube fc1 512x12544->1024", 512, 12544, 1024)]
+reps = int(os.environ.get("REPS", "3"))
+for name, H, C, K, R, st in CONVS:
+    x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(K, C, R, R, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    for _ in range(reps):
+        with F.wino_weight_scope():
+            y = F.conv2d(x, w, None, st, R // 2)
+        y.backward(torch.randn_like(y))
+for name, M, C, K in LINEARS:
+    x = torch.randn(M, C, device="cuda", requires_grad=True)
+    w = (torch.randn(K, C, device="cuda") * 0.02).requires_grad_(True)
+    for _ in range(reps):
+        y = F.linear(x, w, None)
+        y.backward(torch.randn_like(y))
+torch.cuda.synchronize()
+print("done")
