@@ -58,6 +58,21 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
 int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R,
                       int S, int stride, int pad, int ldx, int lddy, int accumulate, void* stream);
 
+/* The same three operations with the ALGORITHM chosen by the caller instead of by the launcher's shape heuristics
+ * (cuDNN's "algo" argument; the reference reaches it through torch.backends.cudnn.benchmark, tools/train_net.py sets
+ * nothing and takes the default).  tile: 0 = automatic | 1 = 128x128 | 2 = 64x64 | 3 = 128x64 | 4 = 256x32 (fwd/dgrad) or
+ * 32x128 (wgrad).  splits: 0 = automatic | >= 1 = reduction splits (> 1 ends with fp32 atomics into a zeroed, dense output).
+ * omni_conv2d_fwd/dgrad/wgrad == the _algo form with tile = splits = 0.  Used by tools/bench_kernels.py and by tests that
+ * exercise a given tile shape on a small problem; there is no process-global tuning state. */
+int omni_conv2d_fwd_algo(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C,
+                         int K, int R, int S, int stride, int pad, int ldx, int ldo, int relu, int tile, int splits,
+                         void* stream);
+int omni_conv2d_dgrad_algo(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R,
+                           int S, int stride, int pad, int lddy, int lddx, int accumulate, int tile, int splits,
+                           void* stream);
+int omni_conv2d_wgrad_algo(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R,
+                           int S, int stride, int pad, int ldx, int lddy, int accumulate, int tile, void* stream);
+
 /* ------------------------------------------------------- BatchNorm / pooling / FPN (NHWC) */
 
 /* nn.BatchNorm2d in training mode (+ fused ReLU and residual add): cubercnn/modeling/backbone/
@@ -232,9 +247,6 @@ int omni_nonfinite_any(const float* grad, long long n, float* flag, void* stream
 int omni_relu_bwd(const float* dy, const float* y, float* dz, long long n, void* stream);
 int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, int accumulate, void* stream);
 
-/* tuning knob for A/B measurements of kernel variants (tools/bench_kernels.py); 0 = production. */
-int omni_debug_set_variant(int v);
-
 /* nn.MaxPool2d(3, stride=2, padding=1) of the torchvision ResNet stem (cubercnn/modeling/backbone/resnet.py:34,52),
  * NHWC forward / backward (gather form, deterministic). */
 int omni_maxpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
@@ -256,6 +268,10 @@ int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate,
 /* `batch` independent dense GEMMs in one launch (the 16 Winograd points):
  * fwd: out[b](M,K) = x[b](M,C) * w[b](K,C)^T;  wgrad: dw[b](K,C) = dy[b](M,K)^T * x[b](M,C) (overwrites dw). */
 int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch, int M, int C, int K, void* stream);
+/* algo: 0 = automatic | 1 = persistent workgroups walking the (problem, tile) list (`workgroups` of them, multiple of 8,
+ * 0 = default; C % 32 == 0) | 2 = one 128x128 tile per workgroup | 3 = one 64x64 tile per workgroup */
+int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int batch, int M, int C, int K, int algo,
+                               int workgroups, void* stream);
 int omni_gemm_batched_wgrad(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, void* stream);
 
 /* Direct convolution for the full-resolution, few-channel DLA-34 stem layers (cubercnn/modeling/backbone/dla.py:241-247):

@@ -676,8 +676,6 @@ __global__ void __launch_bounds__(256) gemm_nt_persistent_kernel(GemmP p) {
 }
 
 
-int g_variant = 0;   // tuning knob for A/B runs (omni_debug_set_variant); 0 = production choice
-
 inline bool bad_geom(const ConvP& p) {
     return p.N < 0 || p.H <= 0 || p.W <= 0 || p.C <= 0 || p.K <= 0 || p.R <= 0 || p.S <= 0 || p.stride <= 0 ||
            p.pad < 0 || (p.C & 3) || p.OH != (p.H + 2 * p.pad - p.R) / p.stride + 1 ||
@@ -688,125 +686,139 @@ inline bool bad_geom(const ConvP& p) {
 
 extern "C" {
 
-// Tuning knob used by tools/bench_kernels.py for A/B runs of kernel variants (0 = production).
-int omni_debug_set_variant(int v) {
-    g_variant = v;
-    return OMNI_OK;
-}
-
 // out[N,OH,OW,K] = conv(x[N,H,W,C], w[K,R,S,C]) + bias, optional ReLU.  Pitches in floats.
 //
 // Tile choice: 128x128 when that already fills the 256 CUs, otherwise 64x64 (4x the workgroups); when even
 // that leaves CUs idle and the reduction is deep (DLA level 4/5, FC heads with few rows) the reduction is
 // split over gridDim.y with an atomic epilogue into a zeroed output.  Slab depth 32 (one barrier per 64
 // MFMAs per wave) measured +23 % over 16 on the 3x3 256->256 @128x128 shape (96 -> 119 TFLOP/s).
-int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
-                    int R, int S, int stride, int pad, int ldx, int ldo, int relu, void* stream) {
+// `tile` / `splits` select the algorithm explicitly (0 = the launcher's own choice, which is what omni_conv2d_fwd uses):
+//   tile 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 256x32 (BM x BN output-pixel x output-channel tile); splits >= 1 = number of
+//   reduction splits (atomic epilogue into a zeroed output when > 1; needs ldo == K).  Used by tools/bench_kernels.py for A/B
+//   measurements and by tests that want a given tile on a small problem.
+int omni_conv2d_fwd_algo(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
+                         int R, int S, int stride, int pad, int ldx, int ldo, int relu, int tile, int splits_req, void* stream) {
     ConvP p{x, w, bias, out, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
             R, S, stride, pad, ldx, ldo, 0, relu, 0, 1};
-    if (bad_geom(p) || (ldx & 3) || ldx < C || ldo < K) return OMNI_ERR_ARG;
+    if (bad_geom(p) || (ldx & 3) || ldx < C || ldo < K || tile < 0 || tile > 4 || splits_req < 0) return OMNI_ERR_ARG;
+    if (splits_req > 1 && ldo != K) return OMNI_ERR_ARG;
     const long M = (long)N * p.OH * p.OW;
     if (M == 0) return OMNI_OK;
     hipStream_t st = (hipStream_t)stream;
     const long Kd = (long)R * S * C;
+    const long nslab = (Kd + 31) / 32;
     const long t128 = ((M + 127) / 128) * ((K + 127) / 128);
-    const bool bk16 = (g_variant == 4);
-#define OMNI_FWD(BM_, BN_, WM_, WN_, tiles_, splits_)                                                                   \
-    do {                                                                                                                \
-        if (bk16)                                                                                                       \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<BM_, BN_, WM_, WN_, 16>), dim3((unsigned)(tiles_), (unsigned)(splits_)), \
-                               dim3(256), 0, st, p);                                                                    \
-        else                                                                                                            \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<BM_, BN_, WM_, WN_, 32>), dim3((unsigned)(tiles_), (unsigned)(splits_)), \
-                               dim3(256), 0, st, p);                                                                    \
-    } while (0)
-    if ((K > 64 && t128 >= 256) || g_variant == 2 || g_variant == 3) {
-        OMNI_FWD(128, 128, 2, 2, t128, 1);
-    } else if (K > 64 && t128 >= 64 && Kd >= 2048 && ldo == K && g_variant != 5 && g_variant != 14) {
-        // big GEMM with few 128x128 tiles but a deep reduction (fc1: 2048 x 12544 -> 1024): keep the large tile and split K
-        long splits = (512 + t128 - 1) / t128;
-        const long nslab = (Kd + 31) / 32;
-        if (splits > nslab / 8) splits = nslab / 8;
-        omni_memset_async(out, 0, sizeof(float) * (size_t)M * K, st);
-        OMNI_FWD(128, 128, 2, 2, t128, splits);
-        if (relu) {
-            const long n4 = M * K / 4;
-            long g = (n4 + 255) / 256;
-            if (g > 2048) g = 2048;
-            hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)g), dim3(256), 0, st, out, n4);
-        }
-    } else if (K > 32 && (K > 64 || ((M + 127) / 128) < 256)) {
-        const long tiles = ((M + 63) / 64) * ((K + 63) / 64);
-        long splits = 1;
-        const long nslab = (Kd + 31) / 32;
-        if (tiles < (g_variant == 8 ? 192 : 512) && nslab >= 16 && ldo == K && g_variant != 5) {
-            splits = ((g_variant == 8 ? 512 : 1024) + tiles - 1) / tiles;
+    const long t64 = ((M + 63) / 64) * ((K + 63) / 64);
+    long splits = 1;
+    if (tile == 0) {
+        if (K > 64 && t128 >= 256) {
+            tile = 1;
+        } else if (K > 64 && t128 >= 64 && Kd >= 2048 && ldo == K) {
+            // big GEMM with few 128x128 tiles but a deep reduction (fc1: 2048 x 12544 -> 1024): keep the large tile and split K
+            tile = 1;
+            splits = (512 + t128 - 1) / t128;
             if (splits > nslab / 8) splits = nslab / 8;
-            if (splits > 32) splits = 32;
-            if (splits < 1) splits = 1;
+        } else if (K > 32 && (K > 64 || ((M + 127) / 128) < 256)) {
+            tile = 2;
+            if (t64 < 512 && nslab >= 16 && ldo == K) {
+                splits = (1024 + t64 - 1) / t64;
+                if (splits > nslab / 8) splits = nslab / 8;
+                if (splits > 32) splits = 32;
+            }
+        } else {
+            tile = K > 32 ? 3 : 4;
         }
-        if (splits > 1) omni_memset_async(out, 0, sizeof(float) * (size_t)M * K, st);
-        OMNI_FWD(64, 64, 2, 2, tiles, splits);
-        if (splits > 1 && relu) {
-            const long n4 = M * K / 4;
-            long g = (n4 + 255) / 256;
-            if (g > 2048) g = 2048;
-            hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)g), dim3(256), 0, st, out, n4);
-        }
-    } else if (K > 32) {
-        OMNI_FWD(128, 64, 2, 2, ((M + 127) / 128) * ((K + 63) / 64), 1);
-    } else {
-        // tiny channel counts (stem, level0/1, RPN 16-wide heads): slab depth 16 measured faster than 32 here
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<256, 32, 4, 1, 16>), dim3((unsigned)(((M + 255) / 256) * ((K + 31) / 32))),
-                           dim3(256), 0, st, p);
+        if (splits < 1) splits = 1;
     }
+    if (splits_req >= 1) splits = splits_req;
+    if (splits > nslab) splits = nslab;
+    if (splits > 1) omni_memset_async(out, 0, sizeof(float) * (size_t)M * K, st);
+#define OMNI_FWD(BM_, BN_, WM_, WN_, BK_)                                                                                \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<BM_, BN_, WM_, WN_, BK_>),                                          \
+                       dim3((unsigned)(((M + BM_ - 1) / BM_) * ((K + BN_ - 1) / BN_)), (unsigned)splits), dim3(256), 0, st, p)
+    if (tile == 1) OMNI_FWD(128, 128, 2, 2, 32);
+    else if (tile == 2) OMNI_FWD(64, 64, 2, 2, 32);
+    else if (tile == 3) OMNI_FWD(128, 64, 2, 2, 32);
+    else OMNI_FWD(256, 32, 4, 1, 16);   // tiny channel counts (stem, level0/1, RPN 16-wide heads): slab depth 16 measured faster
 #undef OMNI_FWD
+    if (splits > 1 && relu) {
+        const long n4 = M * K / 4;
+        long g = (n4 + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)g), dim3(256), 0, st, out, n4);
+    }
     return omni_launch_status();
 }
 
-// dx[N,H,W,C] (=|+= when accumulate) = conv_transpose(dy[N,OH,OW,K], w[K,R,S,C]).
-int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S,
-                      int stride, int pad, int lddy, int lddx, int accumulate, void* stream) {
+// Tile choice: 128x128 when that already fills the 256 CUs, otherwise 64x64 (4x the workgroups); when even
+// that leaves CUs idle and the reduction is deep (DLA level 4/5, FC heads with few rows) the reduction is
+// split over gridDim.y with an atomic epilogue into a zeroed output.  Slab depth 32 (one barrier per 64
+// MFMAs per wave) measured +23 % over 16 on the 3x3 256->256 @128x128 shape (96 -> 119 TFLOP/s).
+int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
+                    int R, int S, int stride, int pad, int ldx, int ldo, int relu, void* stream) {
+    return omni_conv2d_fwd_algo(x, w, bias, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, relu, 0, 0, stream);
+}
+
+// tile: 0 auto | 1 = 128x128 | 2 = 64x64 | 3 = 128x64 | 4 = 256x32; splits: 0 auto | >= 1 explicit (> 1 needs lddx == C and
+// accumulate == 0: atomic epilogue into a zeroed dx)
+int omni_conv2d_dgrad_algo(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S,
+                           int stride, int pad, int lddy, int lddx, int accumulate, int tile, int splits_req, void* stream) {
     ConvP p{dy, w, nullptr, dx, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
             R, S, stride, pad, lddy, lddx, 0, 0, accumulate, 1};
-    if (bad_geom(p) || (K & 3) || (lddy & 3) || lddy < K || lddx < C) return OMNI_ERR_ARG;
+    if (bad_geom(p) || (K & 3) || (lddy & 3) || lddy < K || lddx < C || tile < 0 || tile > 4 || splits_req < 0) return OMNI_ERR_ARG;
+    if (splits_req > 1 && (lddx != C || accumulate)) return OMNI_ERR_ARG;
     if ((long)N * H * W == 0) return OMNI_OK;
     hipStream_t st = (hipStream_t)stream;
     // one launch covers the stride^2 parity classes (grid.z); tiles are sized for the largest class (0, 0)
     const unsigned ncls = (unsigned)(stride * stride);
     const long M = (long)N * ((H + stride - 1) / stride) * ((W + stride - 1) / stride);
     const long Kd = (long)((R + stride - 1) / stride) * ((S + stride - 1) / stride) * K;
+    const long nslab = (Kd + 31) / 32;
     const long t128 = ((M + 127) / 128) * ((C + 127) / 128);
-    if ((C > 64 && t128 * ncls >= 256) || g_variant == 2 || g_variant == 3) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<128, 128, 2, 2, 32>), dim3((unsigned)t128, 1, ncls), dim3(256), 0, st, p);
-    } else if (C > 32 && (C > 64 || ((M + 127) / 128) * ncls < 256)) {
-        const long tiles = ((M + 63) / 64) * ((C + 63) / 64);
-        long splits = 1;
-        const long nslab = (Kd + 31) / 32;
-        if (tiles * ncls < (g_variant == 8 ? 192 : 512) && nslab >= 16 && lddx == C && !accumulate && g_variant != 5) {
-            splits = ((g_variant == 8 ? 512 : 1024) + tiles * ncls - 1) / (tiles * ncls);
-            if (splits > nslab / 8) splits = nslab / 8;
-            if (splits > 32) splits = 32;
-            if (splits < 1) splits = 1;
+    const long t64 = ((M + 63) / 64) * ((C + 63) / 64);
+    long splits = 1;
+    if (tile == 0) {
+        if (C > 64 && t128 * ncls >= 256) {
+            tile = 1;
+        } else if (C > 32 && (C > 64 || ((M + 127) / 128) * ncls < 256)) {
+            tile = 2;
+            if (t64 * ncls < 512 && nslab >= 16 && lddx == C && !accumulate) {
+                splits = (1024 + t64 * ncls - 1) / (t64 * ncls);
+                if (splits > nslab / 8) splits = nslab / 8;
+                if (splits > 32) splits = 32;
+                if (splits < 1) splits = 1;
+            }
+        } else {
+            tile = C > 32 ? 3 : 4;
         }
-        if (splits > 1) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, st);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<64, 64, 2, 2, 32>), dim3((unsigned)tiles, (unsigned)splits, ncls),
-                           dim3(256), 0, st, p);
-    } else if (C > 32) {
-        const long tiles = ((M + 127) / 128) * ((C + 63) / 64);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<128, 64, 2, 2, 32>), dim3((unsigned)tiles, 1, ncls), dim3(256), 0, st, p);
-    } else {
-        const long tiles = ((M + 255) / 256) * ((C + 31) / 32);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<256, 32, 4, 1, 16>), dim3((unsigned)tiles, 1, ncls), dim3(256), 0, st, p);
     }
+    if (splits_req >= 1) splits = splits_req;
+    if (splits > nslab) splits = nslab;
+    if (splits > 1) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, st);
+#define OMNI_DGRAD(BM_, BN_, WM_, WN_, BK_)                                                                              \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<BM_, BN_, WM_, WN_, BK_>),                                        \
+                       dim3((unsigned)(((M + BM_ - 1) / BM_) * ((C + BN_ - 1) / BN_)), (unsigned)splits, ncls), dim3(256), 0, st, p)
+    if (tile == 1) OMNI_DGRAD(128, 128, 2, 2, 32);
+    else if (tile == 2) OMNI_DGRAD(64, 64, 2, 2, 32);
+    else if (tile == 3) OMNI_DGRAD(128, 64, 2, 2, 32);
+    else OMNI_DGRAD(256, 32, 4, 1, 16);
+#undef OMNI_DGRAD
     return omni_launch_status();
+}
+
+// dx[N,H,W,C] (=|+= when accumulate) = conv_transpose(dy[N,OH,OW,K], w[K,R,S,C]).
+int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S,
+                      int stride, int pad, int lddy, int lddx, int accumulate, void* stream) {
+    return omni_conv2d_dgrad_algo(dy, w, dx, N, H, W, C, K, R, S, stride, pad, lddy, lddx, accumulate, 0, 0, stream);
 }
 
 // dw[K,R,S,C] = sum over output pixels of dy (x) x.  accumulate == 0: dw is overwritten (zeroed here when the
 // reduction is split); accumulate != 0: the result is atomically ADDED to dw -- this is how weight gradients land
 // directly in the flat gradient bucket without an extra add kernel per parameter.
-int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
-                      int stride, int pad, int ldx, int lddy, int accumulate, void* stream) {
+// tile: 0 auto | 1 = 128x128 | 2 = 64x64 | 3 = 128x64 | 4 = 32x128 (BM over K, BN over the (r, s, c) extent)
+int omni_conv2d_wgrad_algo(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                           int stride, int pad, int ldx, int lddy, int accumulate, int tile, void* stream) {
+    if (tile < 0 || tile > 4) return OMNI_ERR_ARG;
     ConvP p{x, dy, nullptr, dw, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
             R, S, stride, pad, ldx, 0, lddy, 0, accumulate, 1};
     if (bad_geom(p) || (K & 3) || (ldx & 3) || (lddy & 3) || ldx < C || lddy < K) return OMNI_ERR_ARG;
@@ -820,8 +832,12 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
     // tile: 128x128 for wide layers, 128x64 when the (tap, c) extent is only 64 wide, 64x64 for K <= 64,
     // 32x128 for the <= 32-channel stem layers (a 64-row tile would spend >= half its MFMAs on padding)
     int bm, bn;
-    if (K > 64) { bm = 128; bn = (Nn > 64 && (P >= 32768 || g_variant == 7) && g_variant != 6) ? 128 : 64; }
-    else if (K > 32 || g_variant == 6) { bm = 64; bn = 64; }
+    if (tile == 1) { bm = 128; bn = 128; }
+    else if (tile == 2) { bm = 64; bn = 64; }
+    else if (tile == 3) { bm = 128; bn = 64; }
+    else if (tile == 4) { bm = 32; bn = 128; }
+    else if (K > 64) { bm = 128; bn = (Nn > 64 && P >= 32768) ? 128 : 64; }
+    else if (K > 32) { bm = 64; bn = 64; }
     else { bm = 32; bn = 128; }
     const int tiles = ((K + bm - 1) / bm) * ((Nn + bn - 1) / bn);
     // aim at ~1024 workgroups, at least 256 pixels (8 slabs) per split
@@ -844,21 +860,30 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
     return omni_launch_status();
 }
 
+int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                      int stride, int pad, int ldx, int lddy, int accumulate, void* stream) {
+    return omni_conv2d_wgrad_algo(x, dy, dw, N, H, W, C, K, R, S, stride, pad, ldx, lddy, accumulate, 0, stream);
+}
+
 // ---- batched GEMMs of the Winograd path (csrc/winograd.hip): `batch` independent dense problems in one launch ----
 // out[b] (M x K) = x[b] (M x C) * w[b] (K x C)^T
-int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch, int M, int C, int K, void* stream) {
-    if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3)) return OMNI_ERR_ARG;
+// algo: 0 auto | 1 = persistent 128x128 workgroups walking the (problem, tile) list (`workgroups` of them, 0 = 512; needs
+// C % 32 == 0) | 2 = one 128x128 tile per workgroup | 3 = one 64x64 tile per workgroup
+int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int batch, int M, int C, int K, int algo, int workgroups,
+                               void* stream) {
+    if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3) || algo < 0 || algo > 3 || workgroups < 0) return OMNI_ERR_ARG;
+    if (algo == 1 && ((C % 32) != 0 || (workgroups & 7))) return OMNI_ERR_ARG;
     if (M == 0) return OMNI_OK;
     ConvP p{x, w, nullptr, out, M, 1, 1, C, 1, 1, K, 1, 1, 1, 0, C, K, 0, 0, 0, 1, (long)M * C, (long)K * C, (long)M * K};
     const long t128 = (((long)M + 127) / 128) * ((K + 127) / 128);
-    if (K > 64 && (C % 32) == 0 && (t128 * batch >= 1024 || g_variant == 13) && g_variant != 12) {
+    if (algo == 0) algo = (K > 64 && (C % 32) == 0 && t128 * batch >= 1024) ? 1 : (K > 64 && t128 * batch >= 512) ? 2 : 3;
+    if (algo == 1) {
         // >= 2 items per resident workgroup: persistent kernel with the prefetch carried across items
-        // (variant 13: tests force it on small problems with 8 workgroups)
         GemmP g{x, w, out, batch, M, K, C, (M + 127) / 128, (K + 127) / 128};
-        hipLaunchKernelGGL(gemm_nt_persistent_kernel, dim3(g_variant == 13 ? 8 : 512), dim3(256), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(gemm_nt_persistent_kernel, dim3(workgroups ? workgroups : 512), dim3(256), 0, (hipStream_t)stream, g);
         return omni_launch_status();
     }
-    if (K > 64 && t128 * batch >= 512)   // else 64x64 tiles: 4x the workgroups (measured on the 256ch @32x32 layers)
+    if (algo == 2)   // else 64x64 tiles: 4x the workgroups (measured on the 256ch @32x32 layers)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<128, 128, 2, 2, 32>), dim3((unsigned)t128, 1, (unsigned)batch), dim3(256), 0,
                            (hipStream_t)stream, p);
     else
@@ -866,6 +891,10 @@ int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch,
                            dim3((unsigned)((((long)M + 63) / 64) * ((K + 63) / 64)), 1, (unsigned)batch), dim3(256), 0,
                            (hipStream_t)stream, p);
     return omni_launch_status();
+}
+
+int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch, int M, int C, int K, void* stream) {
+    return omni_gemm_batched_fwd_algo(x, w, out, batch, M, C, K, 0, 0, stream);
 }
 
 // dw[b] (K x C) = dy[b] (M x K)^T * x[b] (M x C)      (overwrites dw)

@@ -24,8 +24,8 @@ def to_channels_last(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
-def conv2d_fwd(x, w, bias=None, stride=1, pad=0, relu=False):
-    """x (N,C,H,W) CL, w (K,C,R,S) CL -> y (N,K,OH,OW) CL."""
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, relu=False, tile=0, splits=0):
+    """x (N,C,H,W) CL, w (K,C,R,S) CL -> y (N,K,OH,OW) CL.  tile/splits: explicit algorithm (0 = the launcher's choice)."""
     xv, wv = _nhwc(x), _nhwc(w)
     N, H, W, C = xv.shape
     K, R, S, C2 = wv.shape
@@ -33,12 +33,12 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, relu=False):
     OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
     L = _lib.check_device(xv, wv, bias)
     out = torch.empty((N, OH, OW, K), dtype=torch.float32, device=x.device)
-    L.call("omni_conv2d_fwd", _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(bias), _lib.ptr(out), N, H, W, C, K, R, S, stride,
-           pad, C, K, int(relu), _lib.stream_of(x))
+    L.call("omni_conv2d_fwd_algo", _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(bias), _lib.ptr(out), N, H, W, C, K, R, S, stride,
+           pad, C, K, int(relu), tile, splits, _lib.stream_of(x))
     return out.permute(0, 3, 1, 2)
 
 
-def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0):
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, tile=0, splits=0):
     """dy (N,K,OH,OW) CL, w (K,C,R,S) CL -> dx (N,C,H,W) CL."""
     dyv, wv = _nhwc(dy), _nhwc(w)
     N, OH, OW, K = dyv.shape
@@ -47,12 +47,12 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0):
     H, W = in_hw
     L = _lib.check_device(dyv, wv)
     dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
-    L.call("omni_conv2d_dgrad", _lib.ptr(dyv), _lib.ptr(wv), _lib.ptr(dx), N, H, W, C, K, R, S, stride, pad, K, C, 0,
-           _lib.stream_of(dy))
+    L.call("omni_conv2d_dgrad_algo", _lib.ptr(dyv), _lib.ptr(wv), _lib.ptr(dx), N, H, W, C, K, R, S, stride, pad, K, C, 0,
+           tile, splits, _lib.stream_of(dy))
     return dx.permute(0, 3, 1, 2)
 
 
-def conv2d_wgrad(x, dy, ksize, stride=1, pad=0, accum_into=None):
+def conv2d_wgrad(x, dy, ksize, stride=1, pad=0, accum_into=None, tile=0):
     """x (N,C,H,W) CL, dy (N,K,OH,OW) CL -> dw (K,C,R,S) CL.  accum_into: a (K,C,R,S) CL tensor (e.g. the
     parameter's view of the flat gradient bucket) that the result is atomically added to (returns None)."""
     xv, dyv = _nhwc(x), _nhwc(dy)
@@ -63,12 +63,12 @@ def conv2d_wgrad(x, dy, ksize, stride=1, pad=0, accum_into=None):
     if accum_into is not None:
         tgt = accum_into.permute(0, 2, 3, 1)
         assert tgt.is_contiguous() and tgt.shape == (K, R, S, C)
-        L.call("omni_conv2d_wgrad", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(tgt), N, H, W, C, K, R, S, stride, pad, C, K, 1,
-               _lib.stream_of(x))
+        L.call("omni_conv2d_wgrad_algo", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(tgt), N, H, W, C, K, R, S, stride, pad, C, K, 1,
+               tile, _lib.stream_of(x))
         return None
     dw = torch.empty((K, R, S, C), dtype=torch.float32, device=x.device)
-    L.call("omni_conv2d_wgrad", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, K, R, S, stride, pad, C, K, 0,
-           _lib.stream_of(x))
+    L.call("omni_conv2d_wgrad_algo", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, K, R, S, stride, pad, C, K, 0,
+           tile, _lib.stream_of(x))
     return dw.permute(0, 3, 1, 2)
 
 

@@ -70,13 +70,13 @@ def transform_weights(w, want_u=True, want_flip=False, tile=2):
     return U, Uf
 
 
-def gemm_batched(V, U):
-    """V (B,M,C), U (B,K,C) -> (B,M,K)"""
+def gemm_batched(V, U, algo=0, workgroups=0):
+    """V (B,M,C), U (B,K,C) -> (B,M,K).  algo / workgroups: see omni_gemm_batched_fwd_algo (0 = the launcher's choice)."""
     B, M, C = V.shape
     K = U.shape[1]
     L = _lib.check_device(V, U)
     out = torch.empty((B, M, K), dtype=torch.float32, device=V.device)
-    L.call("omni_gemm_batched_fwd", _lib.ptr(V), _lib.ptr(U), _lib.ptr(out), B, M, C, K, _lib.stream_of(V))
+    L.call("omni_gemm_batched_fwd_algo", _lib.ptr(V), _lib.ptr(U), _lib.ptr(out), B, M, C, K, algo, workgroups, _lib.stream_of(V))
     return out
 
 

@@ -113,6 +113,13 @@ def main(spec=SMALL):
         record["roi_boxes"] = [o.proposal_boxes.tensor.clone() for o in out]
         return out
     ref_roi.ROIHeads3D.label_and_sample_proposals = rec_sample
+    orig_rpn_fwd = ref_rpn.RPNWithIgnore.forward
+
+    def rec_rpn_fwd(self, images, features, gt_instances=None):
+        out = orig_rpn_fwd(self, images, features, gt_instances)
+        record["proposals"] = [p.proposal_boxes.tensor.detach().clone() for p in out[0]]
+        return out
+    ref_rpn.RPNWithIgnore.forward = rec_rpn_fwd
 
     ref.train()
     with EventStorage(0) as st:
@@ -121,6 +128,9 @@ def main(spec=SMALL):
         total.backward()
         logs = {k: v[0] for k, v in st.latest().items()}
     grads = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+    ref_rpn.RPNWithIgnore.label_and_sample_anchors = orig_label
+    ref_roi.ROIHeads3D.label_and_sample_proposals = orig_sample
+    ref_rpn.RPNWithIgnore.forward = orig_rpn_fwd
     bb = (["backbone.bottom_up.conv1.weight", "backbone.bottom_up.layer2.0.downsample.0.weight", "backbone.bottom_up.layer4.2.bn2.weight"]
           if "ResNet" in config else
           ["backbone.bottom_up.base_layer.0.weight", "backbone.bottom_up.level2.tree1.conv1.weight", "backbone.bottom_up.level5.root.bn.weight"])
@@ -133,6 +143,7 @@ def main(spec=SMALL):
     out = {
         "spec": spec, "losses": {k: float(v) for k, v in losses.items()}, "logs": logs,
         "rpn_labels": record["rpn_labels"], "roi_classes": record["roi_classes"], "roi_boxes": record["roi_boxes"],
+        "proposals": record["proposals"],      # the reference's own first-stage output (injected into the second stage)
         "grad_norm": {n: float(g.norm()) for n, g in grads.items()},
         "grad_head": {n: grads[n].flatten()[:64].clone() for n in pick},
         "torch_version": torch.__version__,
@@ -143,6 +154,11 @@ def main(spec=SMALL):
     for k, v in out["losses"].items():
         print(f"  {k:24s} {v:.6f}")
     return out
+
+
+FULL = dict(name="dla34_full", seed=6, images=4, height=512, width=512, num_gt=8, overrides=[])       # BASELINE configs[1]
+RESNET_FULL = dict(name="resnet34_full", seed=8, images=2, height=512, width=512, num_gt=8, overrides=[],
+                   config="cubercnn_ResNet34_FPN.yaml")                                                  # BASELINE configs[3] model
 
 
 INFER = dict(
@@ -180,6 +196,29 @@ def main_infer(spec=INFER):
                     "pred_bbox3D": i.pred_bbox3D.clone(), "pred_center_cam": i.pred_center_cam.clone(),
                     "pred_center_2D": i.pred_center_2D.clone(), "pred_dimensions": i.pred_dimensions.clone(),
                     "pred_pose": i.pred_pose.clone(), "scores_full": i.scores_full.clone()})
+    # float64 yardstick: the same reference files evaluated in double precision (model.double(), default dtype float64);
+    # detections are matched to the fp32 list by (class, nearest box) because near-tied scores may order differently
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref64 = ref.double()
+        b64 = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
+        for b in b64:
+            b.pop("instances")
+            b["height"], b["width"] = 2 * spec["height"], 2 * spec["width"]
+            b["K"] = [[2 * v for v in row] for row in b["K"][:2]] + [b["K"][2]]
+        with torch.no_grad():
+            out64 = ref64(b64)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    for r, o in zip(res, out64):
+        j = o["instances"]
+        bi, bj = r["pred_boxes"].double(), j.pred_boxes.tensor.double()
+        d = (bi[:, None] - bj[None]).abs().amax(2) + 1e6 * (r["pred_classes"][:, None] != j.pred_classes[None])
+        m = d.argmin(1)
+        assert float(d.min(1).values.max()) < 0.5, "fp64 run produced a different detection set"
+        r["fp64"] = {"pred_boxes": bj[m], "scores": j.scores.double()[m], "pred_bbox3D": j.pred_bbox3D.double()[m],
+                     "pred_center_cam": j.pred_center_cam.double()[m], "pred_center_2D": j.pred_center_2D.double()[m],
+                     "pred_dimensions": j.pred_dimensions.double()[m], "pred_pose": j.pred_pose.double()[m]}
     path = os.path.join(ROOT, "tests", "golden", spec["name"] + ".pt")
     torch.save({"spec": spec, "results": res, "torch_version": torch.__version__}, path)
     print("wrote", path, os.path.getsize(path), "bytes;", [len(r["scores"]) for r in res], "detections")
@@ -230,4 +269,5 @@ if __name__ == "__main__":
     elif "--infer" in sys.argv:
         main_infer()
     else:
-        main(TINY if "--tiny" in sys.argv else RESNET if "--resnet" in sys.argv else SMALL)
+        main(TINY if "--tiny" in sys.argv else RESNET if "--resnet" in sys.argv else FULL if "--full" in sys.argv
+             else RESNET_FULL if "--resnet-full" in sys.argv else SMALL)

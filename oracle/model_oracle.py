@@ -152,7 +152,10 @@ class ModelOracle(nn.Module):
         self.register_buffer("pixel_std", torch.tensor([57.375, 57.120, 58.395]).view(-1, 1, 1), False)
         self.b2b = U.Box2BoxTransform((1.0, 1.0, 1.0, 1.0))
 
-    def forward(self, batch, E_rpn, E_roi, virtual_focal=512.0):
+    def forward(self, batch, E_rpn, E_roi, virtual_focal=512.0, proposals=None):
+        """proposals: optional list of (P_n, 4) boxes that REPLACE the first stage's own proposal list in the second stage
+        (stage-wise comparison: near-tied objectness scores can swap under any change of fp32 summation order or precision,
+        so a second stage is only comparable across implementations / precisions on one fixed proposal list)."""
         B = len(batch)
         images = ImageList.from_tensors([(x["image"].float() - self.pixel_mean) / self.pixel_std for x in batch], 64)
         feats = self.backbone(images.tensor)
@@ -180,6 +183,15 @@ class ModelOracle(nn.Module):
             dec = self.b2b.apply_deltas(deltas.detach().reshape(-1, 4), anchors.unsqueeze(0).expand(B, -1, -1).reshape(-1, 4)).view(B, -1, 4)
             props = U.find_top_rpn_proposals([dec[:, o:o + n] for o, n in per_level], [logits.detach()[:, o:o + n] for o, n in per_level],
                                              images.image_sizes, 0.7, self.pre_nms, self.post_nms, 0.0, True)
+        self.last_proposals = [p.proposal_boxes.tensor.detach().clone() for p in props]
+        if proposals is not None:
+            from omni3d_amd.d2.structures import Instances
+            inj = []
+            for n, bx in enumerate(proposals):
+                inst = Instances(images.image_sizes[n])
+                inst.proposal_boxes = Boxes(bx.to(anchors.dtype))
+                inj.append(inst)
+            props = inj
         # ROI heads
         sb, sc, sgb, s3d, spose, simg = [], [], [], [], [], []
         for n, g in enumerate(gts):
@@ -206,10 +218,10 @@ class ModelOracle(nn.Module):
             for n, (info, k) in enumerate(zip(batch, nfg)):
                 h_net = images.image_sizes[n][0]
                 r = info["height"] / h_net
-                Kt = torch.tensor(info["K"], dtype=torch.float32) / r
+                Kt = torch.tensor(info["K"], dtype=anchors.dtype) / r
                 Kt[2, 2] = 1
                 Km.append(Kt.unsqueeze(0).repeat(k, 1, 1))
-                v2r.append(torch.full((k,), (h_net * info["K"][1][1]) / (virtual_focal * (h_net * r))))
+                v2r.append(torch.full((k,), (h_net * info["K"][1][1]) / (virtual_focal * (h_net * r)), dtype=anchors.dtype))
             fcls = torch.cat([c[m] for c, m in zip(sc, fg)])
             prior_mean = rh.priors_dims_per_cat.detach()[0, fcls, 0, :]
             cl, _, _ = O.cube_losses(head, self.K, torch.cat(fb), fcls, torch.cat(Km), torch.cat(v2r), prior_mean,
@@ -217,8 +229,40 @@ class ModelOracle(nn.Module):
             losses.update(cl)
         self.last_labels = torch.stack(labels)
         self.last_roi_boxes = [b.detach().clone() for b in sb]       # sampled ROI boxes per image (tests: set comparison)
-        self.last_proposals = [p.proposal_boxes.tensor.detach().clone() for p in props]
         return losses
+
+
+def to_double(batch):
+    """deep copy of a batch with every floating-point ground-truth tensor in float64 (for the fp64 run of the oracle)"""
+    import copy
+    out = copy.deepcopy(batch)
+    for b in out:
+        inst = b.get("instances")
+        if inst is None:
+            continue
+        for k, v in list(inst._fields.items()):
+            if torch.is_tensor(v) and v.is_floating_point():
+                inst._fields[k] = v.double()
+            elif hasattr(v, "tensor"):
+                v.tensor = v.tensor.double()
+    return out
+
+
+def run_fp64(priors, state_dict, batch, E_rpn, E_roi, proposals, backbone="dla34", **kw):
+    """The same oracle evaluated in float64 on the same weights / variates / proposal list: the yardstick that separates
+    fp32 rounding (of the CPU oracle AND of the HIP path) from real differences.  -> (losses, {name: grad}, oracle)"""
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        o = ModelOracle(priors, backbone=backbone, **kw)
+        o.load_state_dict(state_dict, strict=True)
+        o = o.double()
+        o.train()
+        losses = o(to_double(batch), E_rpn.double(), E_roi.double(), proposals=[p.double() for p in proposals])
+        sum(losses.values()).backward()
+    finally:
+        torch.set_default_dtype(prev)
+    return ({k: float(v.detach()) for k, v in losses.items()}, {n: p.grad for n, p in o.named_parameters() if p.grad is not None}, o)
 
 
 def time_training(priors, images=2, size=512, iters=4):

@@ -30,7 +30,7 @@ def _check(a, b, scale):
     assert err <= 2e-5 * scale + 1e-6, (err, scale)
 
 
-def _run_case(dev, case):
+def _run_case(dev, case, tile=0, splits=0):
     from omni3d_amd.kernels import conv
     N, H, W, C, K, R, stride, pad = case
     x = _mk(dev, N, C, H, W, seed=1).contiguous(memory_format=torch.channels_last)
@@ -39,18 +39,18 @@ def _run_case(dev, case):
     xc, wc, bc = x.cpu(), w.cpu(), b.cpu()
     ref = F.conv2d(xc, wc, bc, stride=stride, padding=pad)
     scale = float(F.conv2d(xc.abs(), wc.abs(), None, stride=stride, padding=pad).max())
-    y = conv.conv2d_fwd(x, w, b, stride, pad, relu=False)
+    y = conv.conv2d_fwd(x, w, b, stride, pad, relu=False, tile=tile, splits=splits)
     assert y.shape == ref.shape
     _check(y, ref, scale)
-    yr = conv.conv2d_fwd(x, w, b, stride, pad, relu=True)
+    yr = conv.conv2d_fwd(x, w, b, stride, pad, relu=True, tile=tile, splits=splits)
     _check(yr, ref.clamp(min=0), scale)
     dy = _mk(dev, *ref.shape, seed=4).contiguous(memory_format=torch.channels_last)
     dyc = dy.cpu()
     dx_ref = torch.nn.grad.conv2d_input(xc.shape, wc, dyc, stride=stride, padding=pad)
     dw_ref = torch.nn.grad.conv2d_weight(xc, wc.shape, dyc, stride=stride, padding=pad)
-    dx = conv.conv2d_dgrad(dy, w, (H, W), stride, pad)
+    dx = conv.conv2d_dgrad(dy, w, (H, W), stride, pad, tile=tile, splits=splits)
     _check(dx, dx_ref, float(dx_ref.abs().max()) * 4 + 1)
-    dw = conv.conv2d_wgrad(x, dy, (R, R), stride, pad)
+    dw = conv.conv2d_wgrad(x, dy, (R, R), stride, pad, tile=tile)
     _check(dw, dw_ref, float(dw_ref.abs().max()) * 4 + 1)
 
 
@@ -70,15 +70,20 @@ def test_conv_emulated(emu_lib, case):
     _run_case("cpu", case)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 7])
-def test_conv_128x128_tiles_emulated(emu_lib, variant):
-    """force the 128x128 tile kernels (fwd/dgrad BK 16 / BK 32; 7 = wgrad 128x128) on a small shape"""
-    from omni3d_amd import lib as L
-    L.get().call("omni_debug_set_variant", variant)
-    try:
-        _run_case("cpu", (1, 12, 12, 16, 72, 3, 1, 1))
-    finally:
-        L.get().call("omni_debug_set_variant", 0)
+@pytest.mark.parametrize("tile,splits", [(1, 1), (1, 2), (2, 3), (3, 1), (4, 1)])
+def test_conv_explicit_algo_emulated(emu_lib, tile, splits):
+    """every tile shape of the fwd / dgrad / wgrad kernels, with and without a split reduction, requested explicitly through
+    the *_algo entry points on a small shape (the automatic choice would never pick 128x128 here)"""
+    _run_case("cpu", (1, 12, 12, 16, 72, 3, 1, 1), tile=tile, splits=splits)
+
+
+def test_conv_algo_rejects_bad_arguments(emu_lib):
+    from omni3d_amd.kernels import conv
+    from omni3d_amd.lib import OmniHipError
+    x = torch.zeros(1, 16, 8, 8).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(8, 16, 3, 3).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(OmniHipError):
+        conv.conv2d_fwd(x, w, None, 1, 1, tile=9)
 
 
 def test_linear_emulated(emu_lib):
@@ -188,11 +193,7 @@ def _run_persistent_gemm(dev):
     g = torch.Generator().manual_seed(8)
     V = torch.randn(16, 160, 64, generator=g).to(dev)
     U = torch.randn(16, 72, 64, generator=g).to(dev)
-    L.get().call("omni_debug_set_variant", 13)
-    try:
-        out = wino.gemm_batched(V, U)
-    finally:
-        L.get().call("omni_debug_set_variant", 0)
+    out = wino.gemm_batched(V, U, algo=1, workgroups=8)
     ref = torch.einsum("bmc,bkc->bmk", V.cpu().double(), U.cpu().double())
     assert (out.cpu().double() - ref).abs().max() <= 1e-4 * ref.abs().max()
     assert torch.equal(out, wino.gemm_batched(V, U))       # bit-identical to the one-tile-per-workgroup kernel (same k order)

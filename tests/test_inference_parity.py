@@ -27,29 +27,38 @@ def _run(dev):
     with torch.no_grad():
         out = model(batch)
     assert len(out) == len(gold["results"])
+    report = []
     for o, ref in zip(out, gold["results"]):
         i = o["instances"]
         n = len(ref["scores"])
         assert len(i) == n, (len(i), n)
         assert torch.equal(i.pred_classes.cpu().long(), ref["pred_classes"])            # selection is index-exact
-        def close(a, b, tol):   # fp32 bar of the north star (1e-4), relative for values above 1
-            err = float(((a.cpu() - b).abs() / (1.0 + b.abs())).max()) if b.numel() else 0.0
-            assert err <= tol, (err, tol)
-            return True
-        assert close(i.scores, ref["scores"], 1e-4)
-        px = 1e-4 * max(o["instances"].image_size)     # pixel quantities: 1e-4 of the image extent
-        assert (i.pred_boxes.tensor.cpu() - ref["pred_boxes"]).abs().max() < px
-        # dims = prior * exp(logit), z = exp-style depth decode: the fp32 summation order of ~60 conv layers + two 12544-long
-        # GEMM reductions (MFMA k-slab order vs the CPU's) shows up as 1.3e-4 relative here; CPU fp32 in a different memory
-        # format moves the same amount against itself (DESIGN.md "conditioning"), so the bar is 3e-4
-        assert close(i.pred_dimensions, ref["pred_dimensions"], 3e-4)
-        assert close(i.pred_center_cam, ref["pred_center_cam"], 3e-4)
-        c2 = ref["pred_center_2D"]          # projected 3D centres, may lie far outside the image (|u| up to ~800 px here)
-        assert bool(((i.pred_center_2D.cpu() - c2).abs() <= 1e-4 * c2.abs().clamp(min=max(o["instances"].image_size)) + 0.01).all())
-        # the Gram-Schmidt of a random-init 6D pose (|a| ~ 1e-2, a1 and a2 far from orthogonal) amplifies fp32
-        # rounding of the head GEMMs: rotation entries and the corners built from them get a looser bar
-        assert close(i.pred_pose, ref["pred_pose"], 2e-3)
-        assert close(i.pred_bbox3D, ref["pred_bbox3D"], 2e-3)
+        r64 = ref["fp64"]                                                               # the reference files in float64
+
+        def bounded(name, got, cap, scale=None):
+            """|HIP - fp64| <= cap (north_star: 1e-4, relative for values above 1) AND <= 2 x the reference's own fp32
+            distance to the fp64 value (+ an fp32 rounding floor): conditioning is measured, not asserted."""
+            got, r32, r_64 = got.double().cpu(), ref[name].double(), r64[name].double()
+            den = (1.0 + r_64.abs()) if scale is None else scale
+            e_hip, e_ref = float(((got - r_64).abs() / den).max()), float(((r32 - r_64).abs() / den).max())
+            report.append("%-16s |hip-fp64| %.2e  |ref32-fp64| %.2e  cap %.0e" % (name, e_hip, e_ref, cap))
+            assert e_hip <= cap and e_hip <= max(2.0 * e_ref, 2e-6), report[-1]
+
+        ext = float(max(o["instances"].image_size))
+        bounded("scores", i.scores, 1e-4)
+        bounded("pred_boxes", i.pred_boxes.tensor, 1e-4, scale=ext)          # pixel quantities: 1e-4 of the image extent
+        bounded("pred_dimensions", i.pred_dimensions, 1e-4)
+        bounded("pred_center_cam", i.pred_center_cam, 1e-4)
+        # projected 3D centres may lie far outside the image (|u| up to ~800 px here)
+        bounded("pred_center_2D", i.pred_center_2D, 1e-4 * 4, scale=r64["pred_center_2D"].abs().clamp(min=ext))
+        # the Gram-Schmidt of a random-init 6D pose amplifies fp32 rounding of the head GEMMs: the REFERENCE in fp32 is
+        # itself 2e-4 .. 3.5e-4 from its float64 evaluation here, so the cap is 1e-3 and the 2x rule is the real bar
+        bounded("pred_pose", i.pred_pose, 1e-3)
+        bounded("pred_bbox3D", i.pred_bbox3D, 1e-3)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir) and dev == "cuda":
+        with open(os.path.join(out_dir, "inference_fp64_report.txt"), "w") as f:
+            f.write("\n".join(report) + "\n")
 
 
 @pytest.mark.skipif(os.environ.get("OMNI_SLOW") != "1", reason="minutes under the host emulator; set OMNI_SLOW=1 (the GPU variant is the gate)")
@@ -58,5 +67,5 @@ def test_inference_matches_reference_emulated(emu_lib):
 
 
 @pytest.mark.gpu
-def test_inference_matches_reference_gpu(hip_lib, deterministic_forward):
+def test_inference_matches_reference_gpu(hip_lib):
     _run("cuda")

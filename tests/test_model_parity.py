@@ -24,7 +24,9 @@ def _run(dev, name):
     batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
     A = gold["rpn_labels"].shape[1]
     E = MG.variates(spec, A)
-    model.proposal_generator.injected = {"E": E["rpn"]}
+    # stage-wise (see _vs_cpu_oracle): the second stage runs on the REFERENCE's own proposal list, the first stage's own
+    # list is compared with it as a set.  Kernels run in their production configuration (split-K atomics included).
+    model.proposal_generator.injected = {"E": E["rpn"], "proposals": gold["proposals"]}
     model.roi_heads.injected = {"E": E["roi"]}
     model.train()
     with EventStorage(0) as st:
@@ -35,13 +37,26 @@ def _run(dev, name):
     assert torch.equal(model.proposal_generator.last_labels.cpu(), gold["rpn_labels"])
     for name in ("rpn/num_pos_anchors", "rpn/num_neg_anchors", "roi_head/num_fg_samples", "roi_head/num_bg_samples"):
         assert abs(logs[name] - gold["logs"][name]) < 1e-6, name
-    # losses: fp32 tolerance (north star: 1e-4 on box params; losses are O(1))
+    own, cnt = model.proposal_generator.last["boxes"].cpu(), model.proposal_generator.last["count"].tolist()
+    for n, want in enumerate(gold["proposals"]):
+        got = own[n, :cnt[n]]
+        assert abs(len(got) - len(want)) <= 2, (len(got), len(want))
+        d = (got[:, None, :] - want[None, :, :]).abs().amax(dim=2)
+        assert int((d.min(dim=0).values > 1e-2).sum()) <= 0.01 * len(want) + 2
+        assert int((d.min(dim=1).values > 1e-2).sum()) <= 0.01 * len(got) + 2
+    for got, cls, want in zip(model.roi_heads.last_sampled_boxes.cpu(), model.roi_heads.last_sampled_classes.cpu(), gold["roi_boxes"]):
+        got = got[cls >= 0]
+        assert len(got) == len(want)
+        d = (got[:, None, :] - want[None, :, :]).abs().amax(dim=2)
+        assert float(d.min(dim=1).values.max()) <= 1e-3 and float(d.min(dim=0).values.max()) <= 1e-3     # the reference's sampled ROI set
+    # losses: north_star's fp32 bar, 1e-4 (relative for values above 1)
     for k, v in gold["losses"].items():
         got = float(losses[k])
-        assert abs(got - v) <= 2e-4 * max(1.0, abs(v)), (k, got, v)
+        assert abs(got - v) <= 1e-4 * max(1.0, abs(v)), (k, got, v)
     for name in ("Cube/z_error", "Cube/dims_error", "Cube/xy_error", "Cube/conf", "Cube/total_3D_loss", "fast_rcnn/cls_accuracy"):
-        assert abs(logs[name] - gold["logs"][name]) <= 2e-4 * max(1.0, abs(gold["logs"][name])), name
-    # gradients
+        assert abs(logs[name] - gold["logs"][name]) <= 1e-4 * max(1.0, abs(gold["logs"][name])), name
+    # gradients: heads / FPN 0.5 %, bottom-up 3 % (how much of that is fp32 conditioning is MEASURED against a float64 run
+    # in the full-size tests below)
     grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     worst = 0.0
     for n, ref_norm in gold["grad_norm"].items():
@@ -49,8 +64,7 @@ def _run(dev, name):
         got = float(grads[n].float().norm())
         rel = abs(got - ref_norm) / max(ref_norm, 1e-6)
         worst = max(worst, rel)
-        # fp32 with a different summation order (MFMA k-order, atomics) through ~60 BN layers of a random-init net
-        tol = 1e-2 if (n.startswith('roi_heads') or n.startswith('proposal_generator') or 'fpn' in n) else 1e-1
+        tol = GRAD_CAP_HEADS if _is_head(n) else GRAD_CAP_BACKBONE
         assert rel < tol or abs(got - ref_norm) < 1e-6, (n, got, ref_norm)
     for n, head in gold["grad_head"].items():
         g = grads[n]
@@ -58,7 +72,7 @@ def _run(dev, name):
             g = g.contiguous(memory_format=torch.contiguous_format)
         got = g.reshape(g.shape[0], -1).flatten()[:64].cpu() if g.dim() > 1 else g.flatten()[:64].cpu()
         scale = max(head.abs().max().item(), 1e-6)
-        tol = 1e-2 if (n.startswith('roi_heads') or n.startswith('proposal_generator') or 'fpn' in n) else 1e-1
+        tol = GRAD_CAP_HEADS if _is_head(n) else GRAD_CAP_BACKBONE
         assert (got - head).abs().max().item() <= tol * scale + 1e-7, (n, (got - head).abs().max().item(), scale)
     return worst
 
@@ -69,21 +83,41 @@ def test_training_step_matches_reference_emulated(emu_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["dla34_tiny", "dla34_small", "resnet34_small"])
-def test_training_step_matches_reference_gpu(hip_lib, deterministic_forward, name):
+@pytest.mark.parametrize("name", ["dla34_tiny", "dla34_small", "resnet34_small", "dla34_full", "resnet34_full"])
+def test_training_step_matches_reference_gpu(hip_lib, name):
+    """tiny/small: plumbing-sized; *_full: BASELINE configs[1] (4 x 512x512, default config) and the configs[3] model at
+    2 x 512x512 -- fixtures written by the reference's OWN files (oracle/make_golden.py --full / --resnet-full)."""
     _run("cuda", name)
 
 
-def _vs_cpu_oracle(batch, report=None):
+# ---- fp64-bounded three-way comparison --------------------------------------------------------------------------------
+# north_star bar: fp32 outputs within 1e-4.  Gradients of a random-init 60-layer BatchNorm network are ill-conditioned, and
+# instead of asserting that, these tests MEASURE it: the same CPU oracle is evaluated a second time in float64 (same weights,
+# variates and proposal list) and every output of the HIP path must be no further from the float64 value than TWICE the CPU
+# oracle's own fp32 distance to it (plus an fp32-rounding floor), on top of absolute caps.
+LOSS_ABS = 1e-4          # |HIP - fp64| <= 1e-4 * max(1, |fp64|) for every loss (north_star)
+LOSS_FLOOR = 2e-6        # rounding floor of the "<= 2 x CPU error" rule for losses (relative to max(1, |v|))
+GRAD_FLOOR = 5e-4        # rounding floor of the rule for gradients (relative L2 per parameter tensor)
+GRAD_CAP_HEADS = 5e-3    # absolute caps on the relative L2 error per parameter tensor: heads / FPN 0.5 %, bottom-up 3 %
+GRAD_CAP_BACKBONE = 3e-2
+
+
+def _is_head(n):
+    return n.startswith("roi_heads") or n.startswith("proposal_generator") or "fpn" in n
+
+
+def _vs_cpu_oracle(batch, report=None, config="cubercnn_DLA34_FPN.yaml", backbone="dla34"):
     """HIP path on the GPU vs the CPU oracle (oracle/model_oracle.py, itself pinned to the reference by
-    tests/test_oracle_pin.py) on the same batch, weights and injected sampling variates."""
+    tests/test_oracle_pin.py) in fp32 AND in fp64, on the same batch, weights and injected sampling variates.  The kernels
+    run in their PRODUCTION configuration (split-K, Winograd, persistent GEMM: whatever the launchers pick for the shape)."""
     from oracle import make_golden as MG
     from oracle import model_oracle as MO
     from omni3d_amd import synthetic
     priors = synthetic.make_priors(50)
-    model = MG.build_product_model(MG.product_cfg([]), priors, 5, device="cpu")
-    oracle = MO.ModelOracle(priors)
+    model = MG.build_product_model(MG.product_cfg([], config), priors, 5, device="cpu")
+    oracle = MO.ModelOracle(priors, backbone=backbone)
     oracle.load_state_dict(model.state_dict(), strict=True)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to("cuda")
     B = len(batch)
     Hp = -(-max(b["image"].shape[1] for b in batch) // 64) * 64      # ImageList pads to the FPN size divisibility
@@ -95,11 +129,14 @@ def _vs_cpu_oracle(batch, report=None):
     oracle.train()
     ref = oracle(batch, E_rpn, E_roi)
     sum(ref.values()).backward()
+    # the float64 yardstick, second stage on the fp32 oracle's proposal list
+    l64, g64, o64 = MO.run_fp64(priors, state, batch, E_rpn, E_roi, oracle.last_proposals, backbone=backbone)
+    assert torch.equal(o64.last_labels, oracle.last_labels)
     # Stage-wise comparison.  Proposal scores of a random-init RPN are nearly tied, so a last-bit difference in one logit
     # (any change of fp32 summation order) can swap two proposals; as the sampling variates are dealt per proposal INDEX,
     # one swap re-deals every later draw and dozens of (equally valid) background ROIs change.  So: (1) the first stage's
     # own proposal list must agree with the oracle's up to a few such swaps, (2) the second stage runs on the oracle's
-    # list and must then reproduce the oracle's sampled ROI set exactly and all ten losses to 3e-4.
+    # list and must then reproduce the oracle's sampled ROI set exactly.
     model.proposal_generator.injected = {"E": E_rpn, "proposals": oracle.last_proposals}
     model.roi_heads.injected = {"E": E_roi}
     losses = model(batch)
@@ -113,58 +150,75 @@ def _vs_cpu_oracle(batch, report=None):
         assert int((d.min(dim=0).values > 1e-2).sum()) <= 0.01 * len(want) + 2      # membership
         assert int((d.min(dim=1).values > 1e-2).sum()) <= 0.01 * len(got) + 2       # (both directions; clipped proposals of the
                                                                                       # padded area coincide, so ranks are not compared)
-    for got, cls, want in zip(model.roi_heads.last_sampled_boxes.cpu(), model.roi_heads.last_sampled_classes.cpu(), oracle.last_roi_boxes):
+    for got, cls, want, want64 in zip(model.roi_heads.last_sampled_boxes.cpu(), model.roi_heads.last_sampled_classes.cpu(),
+                                      oracle.last_roi_boxes, o64.last_roi_boxes):
         got = got[cls >= 0]                                  # unused slots of the fixed 512-block carry class < 0
-        assert len(got) == len(want)
+        assert len(got) == len(want) == len(want64)
+        assert float((want - want64.float()).abs().max()) == 0.0           # fp32 and fp64 oracle sampled the same ROIs
         d = (got[:, None, :] - want[None, :, :]).abs().amax(dim=2)
         assert float(d.min(dim=1).values.max()) <= 1e-3 and float(d.min(dim=0).values.max()) <= 1e-3     # same ROI set
-    for k, v in ref.items():
-        assert abs(float(losses[k].detach()) - float(v.detach())) <= 3e-4 * max(1.0, abs(float(v))), (k, float(losses[k]), float(v))
+    lines, bad = [], []
+    for k, v64 in l64.items():
+        hip, cpu = float(losses[k].detach()), float(ref[k].detach())
+        scale = max(1.0, abs(v64))
+        e_hip, e_cpu = abs(hip - v64) / scale, abs(cpu - v64) / scale
+        lines.append("loss %-24s fp64 %.9g  |hip-fp64| %.2e  |cpu32-fp64| %.2e" % (k, v64, e_hip, e_cpu))
+        if not (e_hip <= LOSS_ABS and e_hip <= max(2 * e_cpu, LOSS_FLOOR)):
+            bad.append(lines[-1])
     og = dict(oracle.named_parameters())
     rows = []
     for n, p in model.named_parameters():
-        if p.grad is None or og[n].grad is None:
+        if p.grad is None or n not in g64:
             continue
-        a, b = float(p.grad.float().norm()), float(og[n].grad.norm())
-        g = p.grad.float().cpu()
-        if g.dim() == 4:
-            g = g.contiguous(memory_format=torch.contiguous_format)
-        cos = float(torch.nn.functional.cosine_similarity(g.flatten(), og[n].grad.flatten(), dim=0))
-        rows.append((abs(a - b) / max(b, 1e-12), cos, n, a, b))
+        gh = p.grad.double().cpu()
+        if gh.dim() == 4:
+            gh = gh.contiguous(memory_format=torch.contiguous_format)
+        gh = gh.reshape(g64[n].shape)
+        den = float(g64[n].norm().clamp(min=1e-30))
+        e_hip, e_cpu = float((gh - g64[n]).norm()) / den, float((og[n].grad.double() - g64[n]).norm()) / den
+        rows.append((e_hip, e_cpu, n, den))
+    for e_hip, e_cpu, n, den in sorted(rows, reverse=True):
+        lines.append("grad %.3e (cpu32 %.3e, ratio %.2f) |g64| %.3e %s" % (e_hip, e_cpu, e_hip / max(e_cpu, 1e-30), den, n))
+        if den < 1e-12:
+            continue
+        cap = GRAD_CAP_HEADS if _is_head(n) else GRAD_CAP_BACKBONE
+        if not (e_hip <= cap and e_hip <= max(2 * e_cpu, GRAD_FLOOR)):
+            bad.append(lines[-1])
     out = os.path.join(ROOT, "gpurun_out")
     if report and os.path.isdir(out):
         with open(os.path.join(out, report), "w") as f:
-            for r in sorted(rows, reverse=True):
-                f.write("%.3e cos=%.6f %s %.6g %.6g\n" % r)
-    # The gradient of a random-init 60-layer BN network is ill-conditioned towards the stem (ReLU / max-pool /
-    # chamfer-argmin decisions flip under 1e-7 perturbations), so the bar tightens with depth: heads 2 %,
-    # everything 10 % in norm and direction (cosine) -- the losses above are the fp32 1e-4-class check.
-    for rel, cos, n, a, b in rows:
-        tight = n.startswith("roi_heads") or n.startswith("proposal_generator") or "fpn" in n
-        assert rel <= (2e-2 if tight else 1e-1) or abs(a - b) < 1e-6, (n, a, b)
-        if b > 1e-6:
-            assert cos > (0.999 if tight else 0.98), (n, cos)
+            f.write("\n".join(lines) + "\n")
+    assert not bad, "\n".join(bad[:20])
 
 
 @pytest.mark.gpu
-def test_training_step_fullsize_vs_cpu_oracle(hip_lib, deterministic_forward):
+def test_training_step_fullsize_vs_cpu_oracle(hip_lib):
     """BASELINE configs[1] exactly: 4 synthetic 512x512 images, default cubercnn_DLA34_FPN config (65 472 anchors, 2000/1000
-    proposals, 512 ROIs/img) -- the benchmarked shape, so every kernel choice the bench makes (Winograd F(4x4,3x3) on p2/p3,
-    DLA level 2/3, stem kernels, split-K, persistent GEMM) is the one compared with the CPU oracle here."""
+    proposals, 512 ROIs/img) -- the benchmarked shape in the benchmarked kernel configuration (no debug knob exists any
+    more): Winograd F(4x4,3x3) on p2/p3, DLA level 2/3, stem kernels, split-K, persistent GEMM."""
     from omni3d_amd import synthetic
     priors = synthetic.make_priors(50)
-    _vs_cpu_oracle(synthetic.make_batch(4, 512, 512, num_gt=8, seed=21, priors=priors), report="fullsize_grad_report.txt")
+    _vs_cpu_oracle(synthetic.make_batch(4, 512, 512, num_gt=8, seed=21, priors=priors), report="fullsize_fp64_report.txt")
 
 
 @pytest.mark.gpu
-def test_training_step_ragged_batch_vs_cpu_oracle(hip_lib, deterministic_forward):
+def test_training_step_ragged_batch_vs_cpu_oracle(hip_lib):
     """Ragged input: images of different sizes and GT counts in one batch (ImageList zero-pads to the per-batch maximum
     rounded up to 64; anchors cover the padding, proposals are clipped to each image's own size)."""
     from omni3d_amd import synthetic
     priors = synthetic.make_priors(50)
     batch = (synthetic.make_batch(1, 128, 192, num_gt=3, seed=31, priors=priors)
              + synthetic.make_batch(1, 160, 100, num_gt=6, seed=32, priors=priors))
-    _vs_cpu_oracle(batch)
+    _vs_cpu_oracle(batch, report="ragged_fp64_report.txt")
+
+
+@pytest.mark.gpu
+def test_training_step_fullsize_resnet34_vs_cpu_oracle(hip_lib):
+    """BASELINE configs[3] model at full size: cubercnn_ResNet34_FPN, 2 x 512x512."""
+    from omni3d_amd import synthetic
+    priors = synthetic.make_priors(50)
+    _vs_cpu_oracle(synthetic.make_batch(2, 512, 512, num_gt=8, seed=23, priors=priors), report="resnet34_fp64_report.txt",
+                   config="cubercnn_ResNet34_FPN.yaml", backbone="resnet34")
 
 
 @pytest.mark.gpu

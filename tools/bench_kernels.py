@@ -44,10 +44,9 @@ def timeit(fn, iters=10):
 
 
 def main():
-    from omni3d_amd import lib as L
-    variant = int(os.environ.get("OMNI_VARIANT", "0"))
-    L.get().call("omni_debug_set_variant", variant)
-    print("variant", variant)
+    # A/B runs: OMNI_TILE / OMNI_SPLITS select the algorithm explicitly through the *_algo entry points (0 = automatic)
+    tile, splits = int(os.environ.get("OMNI_TILE", "0")), int(os.environ.get("OMNI_SPLITS", "0"))
+    print("tile", tile, "splits", splits)
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     print(f"{'layer':34s} {'GFLOP':>7s} | {'fwd ms':>7s} {'TF':>6s} | {'dgrad':>7s} {'TF':>6s} | {'wgrad':>7s} {'TF':>6s}")
     for name, H, C, K, R, st in CONVS:
@@ -57,9 +56,9 @@ def main():
         y = conv.conv2d_fwd(x, w, None, st, pad)
         dy = torch.randn_like(y)
         gf = 2.0 * B * y.shape[2] * y.shape[3] * K * C * R * R / 1e9
-        t1 = timeit(lambda: conv.conv2d_fwd(x, w, None, st, pad))
-        t2 = timeit(lambda: conv.conv2d_dgrad(dy, w, (H, H), st, pad))
-        t3 = timeit(lambda: conv.conv2d_wgrad(x, dy, (R, R), st, pad))
+        t1 = timeit(lambda: conv.conv2d_fwd(x, w, None, st, pad, tile=tile, splits=splits))
+        t2 = timeit(lambda: conv.conv2d_dgrad(dy, w, (H, H), st, pad, tile=tile, splits=splits))
+        t3 = timeit(lambda: conv.conv2d_wgrad(x, dy, (R, R), st, pad, tile=tile))
         for k, t in zip(tot, (t1, t2, t3)):
             tot[k] += t
         print(f"{name:34s} {gf:7.2f} | {t1:7.3f} {gf / t1:6.1f} | {t2:7.3f} {gf / t2:6.1f} | {t3:7.3f} {gf / t3:6.1f}")
