@@ -87,14 +87,25 @@ class RCNN3D(nn.Module):
         if getattr(self, "feature_cut", None) is not None:   # data-parallel two-phase backward (solver/graphed.py)
             features = self.feature_cut(features)
         self._bump_bn_counters()
-        proposals, proposal_losses = self.proposal_generator(images, features, None, targets=packed)
-        _, detector_losses = self.roi_heads(images, features, proposals, None, None, None, packed=packed)
+        # the reference's call contracts (rcnn3d.py:50-70): list[Instances] ground truth, per-image intrinsics and scale
+        # ratios.  This package's own components additionally take the packed device copy (`accepts_packed`), so the
+        # ground truth crosses PCIe once; a reference-style component registered under the same registry gets the lists.
+        gt_instances = [x["instances"].to(self.device) for x in batched_inputs] if not self._all_packed() else None
+        Ks = [torch.FloatTensor(x["K"]) for x in batched_inputs]
+        im_scales_ratio = [x["height"] / im[0] for x, im in zip(batched_inputs, images.image_sizes)]
+        pk = {"targets": packed} if getattr(self.proposal_generator, "accepts_packed", False) else {}
+        proposals, proposal_losses = self.proposal_generator(images, features, gt_instances, **pk)
+        pk = {"packed": packed} if getattr(self.roi_heads, "accepts_packed", False) else {}
+        _, detector_losses = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, gt_instances, **pk)
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)
         if has_event_storage():
             self.flush_logs(get_event_storage())
         return losses
+
+    def _all_packed(self):
+        return getattr(self.proposal_generator, "accepts_packed", False) and getattr(self.roi_heads, "accepts_packed", False)
 
     def _bump_bn_counters(self):
         """`num_batches_tracked += 1` of every training-mode BatchNorm in one multi-tensor launch (39 adds otherwise)."""
@@ -110,8 +121,9 @@ class RCNN3D(nn.Module):
 
     def flush_logs(self, storage):
         """One device->host readback for all logged scalars (the reference does ~16 .item() syncs)."""
-        self.proposal_generator.flush_logs(storage)
-        self.roi_heads.flush_logs(storage)
+        for m in (self.proposal_generator, self.roi_heads):
+            if hasattr(m, "flush_logs"):       # (a reference-style component logs its scalars itself)
+                m.flush_logs(storage)
 
     def inference(self, batched_inputs, detected_instances=None, do_postprocess=True, packed=None):
         assert not self.training
@@ -121,8 +133,12 @@ class RCNN3D(nn.Module):
             sizes = images.image_sizes
             packed = pack_targets(batched_inputs, sizes, getattr(self.roi_heads, "virtual_focal", 512.0), with_gt=False).to(self.device)
         features = self.backbone(images.tensor)
-        proposals, _ = self.proposal_generator(images, features, None, targets=packed)
-        results, _ = self.roi_heads(images, features, proposals, None, None, None, packed=packed)
+        Ks = [torch.FloatTensor(x["K"]) for x in batched_inputs]
+        im_scales_ratio = [x["height"] / im[0] for x, im in zip(batched_inputs, images.image_sizes)]
+        pk = {"targets": packed} if getattr(self.proposal_generator, "accepts_packed", False) else {}
+        proposals, _ = self.proposal_generator(images, features, None, **pk)
+        pk = {"packed": packed} if getattr(self.roi_heads, "accepts_packed", False) else {}
+        results, _ = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, None, **pk)
         if do_postprocess:
             return postprocess(results, batched_inputs, images.image_sizes)
         return results

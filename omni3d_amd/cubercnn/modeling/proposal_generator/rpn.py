@@ -62,6 +62,7 @@ def build_rpn_head(cfg, input_shape):
 
 @PROPOSAL_GENERATOR_REGISTRY.register()
 class RPNWithIgnore(nn.Module):
+    accepts_packed = True     # forward() also takes the ground truth pre-packed on the device (RCNN3D.prepack)
     @configurable
     def __init__(self, *, in_features, head, anchor_generator, anchor_thresholds, anchor_labels, batch_size_per_image,
                  positive_fraction, pre_nms_topk, post_nms_topk, nms_thresh=0.7, min_box_size=0.0, loss_weight=1.0,
@@ -174,6 +175,12 @@ class RPNWithIgnore(nn.Module):
         return prop.contiguous(), top_v, count
 
     def forward(self, images, features, gt_instances=None, targets=None):
+        """Reference contract (rpn.py / detectron2 RPN.forward): `gt_instances` = list[Instances] with gt_boxes / gt_classes
+        (class -1 = ignore region).  `targets` = the same ground truth already packed by RCNN3D.prepack (this package's
+        own meta-architecture passes it so the ROI heads reuse the device copy); either form works."""
+        if targets is None and gt_instances is not None:
+            from ..targets import pack_instances_cached
+            targets = pack_instances_cached(gt_instances, images.image_sizes, device=images.tensor.device)
         feats = [features[f] for f in self.in_features]
         hw_list = [(f.shape[2], f.shape[3]) for f in feats]
         anchors = self.anchor_generator.grid(hw_list, feats[0].device)

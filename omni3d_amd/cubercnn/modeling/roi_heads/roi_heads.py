@@ -24,6 +24,7 @@ from ..layers import FlattenLinear, Linear
 from ..registries import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
 from .cube_head import build_cube_head
 from .fast_rcnn import FastRCNNOutputs
+from ..targets import MAX_GT_PER_IMAGE
 
 
 def build_roi_heads(cfg, input_shape, priors=None):
@@ -82,8 +83,25 @@ class ROIPooler(nn.Module):
         return HF.roi_align_shared(feats, self.scales, rois, batch_idx, levels, self.output_size, per_image, first)
 
 
+def _pack_proposal_list(proposals, image_sizes, device):
+    """list[Instances] (proposal_boxes[, objectness_logits], score order) -> the packed (B, P, 4) + count form"""
+    from ..proposal_generator.rpn import _PackedProposals
+    P = max([len(p) for p in proposals] + [1])
+    boxes = torch.zeros((len(proposals), P, 4), dtype=torch.float32, device=device)
+    scores = torch.full((len(proposals), P), float("-inf"), dtype=torch.float32, device=device)
+    for n, p in enumerate(proposals):
+        k = len(p)
+        if k:
+            boxes[n, :k] = p.proposal_boxes.tensor.to(device)
+            if p.has("objectness_logits"):
+                scores[n, :k] = p.objectness_logits.to(device)
+    count = torch.tensor([len(p) for p in proposals], dtype=torch.int32, device=device)
+    return _PackedProposals(boxes, scores, count, image_sizes)
+
+
 @ROI_HEADS_REGISTRY.register()
 class ROIHeads3D(nn.Module):
+    accepts_packed = True     # forward() also takes the ground truth pre-packed on the device (RCNN3D.prepack)
     @configurable
     def __init__(self, *, num_classes, batch_size_per_image, positive_fraction, proposal_iou_threshold, proposal_append_gt,
                  box_in_features, box_pooler, box_head, box_predictor, ignore_thresh, cube_head, cube_pooler, loss_w_3d,
@@ -154,6 +172,9 @@ class ROIHeads3D(nn.Module):
     def label_and_sample_proposals(self, proposals, targets):
         boxes, count = proposals.boxes, proposals.count
         B = boxes.shape[0]
+        if boxes.shape[1] + MAX_GT_PER_IMAGE > det.ROI_MAXC and self.proposal_append_gt:
+            raise ValueError(f"{boxes.shape[1]} proposals + up to {MAX_GT_PER_IMAGE} appended GT boxes exceed the sampler's "
+                             f"capacity of {det.ROI_MAXC} candidates per image (csrc/rpn_roi.hip ROI_MAXC)")
         if self.injected is not None and "E" in self.injected:
             E = self.injected["E"].to(boxes.device).float().contiguous()
         else:
@@ -166,9 +187,20 @@ class ROIHeads3D(nn.Module):
         return out
 
     def forward(self, images, features, proposals, Ks, im_scales_ratio, targets=None, packed=None):
+        """Reference contract (roi_heads.py:207): proposals = list[Instances] (proposal_boxes), Ks = per-image 3x3 intrinsics
+        of the original image, im_scales_ratio = original height / network height, targets = list[Instances] ground truth.
+        `packed` = all of that already on the device (RCNN3D.prepack); this package's RCNN3D passes it and None for the
+        rest.  Proposals may be this package's packed list or any list[Instances] (e.g. from a reference RPN)."""
         feats = [features[f] for f in self.in_features]
+        if packed is None:
+            from ..targets import pack_instances_cached
+            assert Ks is not None and im_scales_ratio is not None, "ROIHeads3D needs Ks and im_scales_ratio (roi_heads.py:207)"
+            packed = pack_instances_cached(targets if targets is not None else [None] * len(images.image_sizes), images.image_sizes,
+                                           Ks, im_scales_ratio, self.virtual_focal, device=images.tensor.device)
+        if not hasattr(proposals, "boxes"):
+            proposals = _pack_proposal_list(proposals, images.image_sizes, images.tensor.device)
         if self.training:
-            assert packed is not None
+            assert packed.num_gt >= 0
             sboxes, scls, sgt, siou, counts = self.label_and_sample_proposals(proposals, packed)
             x_box = x_cube = None
             if self.box_pooler.same_as(self.cube_pooler):   # every Cube R-CNN config: pool once for both heads

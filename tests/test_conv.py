@@ -123,6 +123,11 @@ def test_linear_gpu(hip_lib):
     _run_linear("cuda", 300, 12544, 1024)
     _run_linear("cuda", 130, 1024, 256)
     _run_linear("cuda", 1024, 2560, 1024)     # few 128x128 tiles + deep reduction: large tile with split-K (the fc1 shape class)
+    # the head GEMMs at the benchmarked batch (4 images): cube head on 4 x 128 ROIs, box head on 4 x 512
+    _run_linear("cuda", 512, 1024, 656)       # fused cube prediction heads (2+1+3+6+1) x 50 = 650 -> 656
+    _run_linear("cuda", 512, 1024, 1024)      # cube fc2
+    _run_linear("cuda", 512, 12544, 1024)     # cube fc1
+    _run_linear("cuda", 2048, 1024, 256)      # fused box predictor 51 + 200 -> 256
 
 
 # ---- Winograd F(2x2, 3x3) path ------------------------------------------------------------------------

@@ -37,12 +37,12 @@ def _run(dev):
 
         def bounded(name, got, cap, scale=None):
             """|HIP - fp64| <= cap (north_star: 1e-4, relative for values above 1) AND <= 2 x the reference's own fp32
-            distance to the fp64 value (+ an fp32 rounding floor): conditioning is measured, not asserted."""
+            distance to the fp64 value (or within a fifth of the cap): conditioning is measured, not asserted."""
             got, r32, r_64 = got.double().cpu(), ref[name].double(), r64[name].double()
             den = (1.0 + r_64.abs()) if scale is None else scale
             e_hip, e_ref = float(((got - r_64).abs() / den).max()), float(((r32 - r_64).abs() / den).max())
             report.append("%-16s |hip-fp64| %.2e  |ref32-fp64| %.2e  cap %.0e" % (name, e_hip, e_ref, cap))
-            assert e_hip <= cap and e_hip <= max(2.0 * e_ref, 2e-6), report[-1]
+            assert e_hip <= cap and e_hip <= max(2.0 * e_ref, cap / 5), report[-1]
 
         ext = float(max(o["instances"].image_size))
         bounded("scores", i.scores, 1e-4)

@@ -120,7 +120,7 @@ def test_iou3d_gpu(hip_lib, oracle_lib, rng):
 
 @pytest.mark.gpu
 def test_iou3d_gpu_100k_pairs_properties(hip_lib, oracle_lib, rng):
-    """BASELINE config 5 size (100k pairs): size-independent properties + an oracle sample."""
+    """BASELINE config 5 size (100k pairs): size-independent properties + every pair against the C oracle."""
     from omni3d_amd.kernels import iou3d
     dt, gt, deg = boxgen.omni3d_like_pairs(rng, 100_000)
     d, g = torch.from_numpy(dt).cuda(), torch.from_numpy(gt).cuda()
@@ -146,7 +146,15 @@ def test_iou3d_gpu_100k_pairs_properties(hip_lib, oracle_lib, rng):
     _, moved = iou3d.iou_box3d_pairs(d + shift, g + shift, ar, ar, valid1=valid)
     frac = (np.abs(moved.cpu().numpy() - iou) > 2e-4).mean()
     assert frac < 0.03, frac
-    # oracle on a 2000-pair sample
-    sel = rng.choice(len(dt), 2000, replace=False)
-    ref = np.array([oracle_overlap(oracle_lib, dt[i:i + 1], gt[i:i + 1])[0, 0] for i in sel])
-    assert np.abs(iou[sel] - ref).max() < TOL
+    # EVERY one of the 100k pairs against the C oracle (~4.4e4 pairs/s single-thread: a few seconds); north_star bar 1e-4.
+    # (box3d_overlap's validity rule zeroes the degenerate rows, omni3d_evaluation.py:151-164; the pair oracle is the raw
+    # _C.iou_box3d restatement, so compare the valid rows and require exact zeros on the others.)
+    import ctypes
+    P = ctypes.c_void_p
+    ref = np.zeros(len(dt), np.float32)
+    a, b = np.ascontiguousarray(dt), np.ascontiguousarray(gt)
+    oracle_lib.iou_box3d_pairs_oracle(a.ctypes.data_as(P), b.ctypes.data_as(P), len(dt), ref.ctypes.data_as(P))
+    v = valid.cpu().numpy().astype(bool)
+    err = np.abs(iou[v] - ref[v])
+    assert err.max() < TOL, (float(err.max()), int(err.argmax()))
+    assert (iou[~v] == 0).all()
