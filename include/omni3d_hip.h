@@ -233,12 +233,23 @@ int omni_cube_decode(const float* head, int ldh, int F, int K, const float* boxe
 /* util.get_cuboid_verts_faces (cubercnn/util/math_util.py:116-219): box3d (n,6), R (n,9) -> (n,24). */
 int omni_cuboid_corners(const float* box3d, const float* R, int n, float* verts, void* stream);
 
+/* ------------------------------------------------------------------ input pipeline
+ * detectron2 T.ResizeShortestEdge -> ResizeTransform.apply_image = PIL Image.resize(BILINEAR) on the uint8 image, and
+ * RandomFlip (horizontal), as configured by cubercnn/data/dataset_mapper.py:25-27 + configs/Base.yaml:10-13.  Bit-exact
+ * with Pillow's 8-bit resampling: the fixed-point coefficient rows are built by the caller (omni3d_amd/kernels/resize.py,
+ * the arithmetic of Pillow's precompute_coeffs) -- bounds (n_out, 2) = [first source index, count], kk (n_out, ksize) int32.
+ * src (planes, H, W) -> dst (planes, HO, WO), tmp = planes*H*WO bytes scratch; flip != 0 mirrors the output columns. */
+int omni_resize_bilinear_u8(const unsigned char* src, unsigned char* dst, unsigned char* tmp, int planes, int H, int W,
+                            int HO, int WO, const int* bounds_h, const int* kk_h, int ksize_h, const int* bounds_v,
+                            const int* kk_v, int ksize_v, int flip, void* stream);
+
 /* ---------------------------------------------------------------------------- optimizer */
 
-/* torch.optim.SGD step (cubercnn/solver/build.py:49-56, tools/train_net.py:250) over a flat bucket. */
+/* torch.optim.SGD step (cubercnn/solver/build.py:49-56, tools/train_net.py:250) over a flat bucket; the gradient is
+ * read as grad * grad_scale (1/world after a summing all-reduce: DDP's averaging, tools/train_net.py:449-454). */
 int omni_sgd_step(float* param, const float* grad, float* momentum_buf, long long n, float lr, float momentum,
-                  float dampening, float weight_decay, int nesterov, int first_step, const float* skip_flag,
-                  void* stream);
+                  float dampening, float weight_decay, int nesterov, int first_step, float grad_scale,
+                  const float* skip_flag, void* stream);
 /* the isnan/isinf gradient scan of tools/train_net.py:222-233 as one pass; flag[0] = 1 if any. */
 int omni_nonfinite_any(const float* grad, long long n, float* flag, void* stream);
 
@@ -292,6 +303,15 @@ int omni_eval_match(const float* ious, const long long* iou_off, const int* dt_o
                     const float* gt_range, const float* dt_range, const float* areas, const double* thrs, int ngroups, int A,
                     int T, int sumD, int sumG, int max_gt, int* dt_match, int* gt_match, unsigned char* dt_ignore, int* gt_order,
                     unsigned char* gt_ig, void* stream);
+
+/* Omni3Deval.accumulate (omni3d_evaluation.py:1172-1313).  order (N): all detections sorted by (category, descending score)
+ * (stable); cat_off (K+1); rank (sumD): position of a detection in its image's score-sorted list; dt_match / dt_ignore:
+ * outputs of omni_eval_match; npig (K,A) non-ignored ground truths; has_e (K); rec_thrs (R); max_dets (M).
+ * precision / scores (T,R,K,A,M) and recall (T,K,A,M): doubles, pre-filled with -1 by the caller. */
+int omni_eval_accumulate(const int* order, const int* cat_off, const int* rank, const double* score, const int* dt_match,
+                         const unsigned char* dt_ignore, const int* npig, const int* has_e, const double* rec_thrs,
+                         const int* max_dets, int K, int A, int M, int T, int R, int sumD, double* precision, double* recall,
+                         double* scores, void* stream);
 
 #ifdef __cplusplus
 }

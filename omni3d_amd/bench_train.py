@@ -55,20 +55,30 @@ def run_train(args, world, rank):
     if world > 1:
         dist.broadcast(opt.flat_param, src=0)
     batch, packed = stage_batch(model, priors, rank)
-    flag = torch.zeros(1, device="cuda")
-    opt.skip_flag = flag
-    loss_log = []
+    # the loop's safety logic (tools/train_net.py:157-285): rolling-loss divergence test, NaN/Inf gradient scan, skip / retry
+    # decisions -- device-side state + ONE 12-float all-reduce per step (cubercnn/solver/guard.py); the fused SGD kernel
+    # reads the skip flag on the device, the host only looks at it after the timed region
+    from omni3d_amd.cubercnn.solver.guard import StepGuard
+    LOSS_NAMES = ["BoxHead/loss_cls", "BoxHead/loss_box_reg", "Cube/uncert", "Cube/loss_dims", "Cube/loss_xy", "Cube/loss_z",
+                  "Cube/loss_pose", "Cube/loss_joint", "rpn/cls", "rpn/loc"]
+    guard = StepGuard(LOSS_NAMES, cfg.MODEL.STABILIZE, cfg.SOLVER.CHECKPOINT_PERIOD, "cuda")
+    opt.skip_flag = guard.skip
+    loss_log, skipped_log = [], []
+
+    def finish(losses, total):
+        opt.check_nonfinite(guard.nonfinite_flag)
+        guard.update(losses, sync=False)
+        opt.step()
+        loss_log.append(total.clone())
+        skipped_log.append(guard.skip.clone())
 
     def eager_step():
         opt.zero_grad()
-        flag.zero_()
         losses = model(batch, packed)
         total = sum(losses.values())
         total.backward()
-        opt.all_reduce_grads()
-        opt.check_nonfinite(flag)
-        opt.step()
-        loss_log.append(total.detach())
+        opt.all_reduce_finish(opt.all_reduce_begin("early") + opt.all_reduce_begin("late"), defer_scale=True)
+        finish(losses, total.detach())
 
     # zero_grad + forward + losses + backward replayed as one hipGraph (OMNI_BENCH_GRAPH=0: eager launches);
     # all-reduce / non-finite scan / SGD update stay eager (host-side learning rate).  With more than one rank the
@@ -95,16 +105,13 @@ def run_train(args, world, rank):
             graphed, graph_note = None, f"eager (capture failed: {type(e).__name__}: {str(e)[:200]})"
 
     def graph_step():
-        flag.zero_()
         if two_phase:
-            _, total, pending = graphed()
-            opt.all_reduce_finish(pending)
+            losses, total, pending = graphed()
+            opt.all_reduce_finish(pending, defer_scale=True)       # 1/world is folded into the SGD kernel
         else:
-            _, total = graphed()
-            opt.all_reduce_grads()
-        opt.check_nonfinite(flag)
-        opt.step()
-        loss_log.append(total.clone())
+            losses, total = graphed()
+            opt.all_reduce_finish(opt.all_reduce_begin("early") + opt.all_reduce_begin("late"), defer_scale=True)
+        finish(losses, total)
 
     step = graph_step if graphed is not None else eager_step
 
@@ -135,14 +142,15 @@ def run_train(args, world, rank):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"cubercnn_{MODEL_NAME} train step, batch 4/GPU, synthetic Omni3D 512x512 (8 GT/img), "
-                               "fwd+10 losses+bwd+allreduce+SGD, random-init weights",
+                               "fwd+10 losses+bwd+allreduce+divergence guard+SGD, random-init weights",
                    "global_batch": IMS_PER_GPU * world, "image": "512x512", "parallelism": f"dp{world} (flat-bucket RCCL all-reduce)"},
         "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
         "launch_mode": graph_note,
         "step_mfma_frac": step_tf / FP32_MFMA_PEAK_TF,
         "step_algorithmic_tflops_per_gpu": step_tf,
         "loss_first_last": [final_losses[0], final_losses[-1]],
-        "skipped_steps_flag": float(flag.item()),
+        "skipped_steps": int(torch.stack(skipped_log[-args.steps:]).sum().item()),
+        "guard": "rolling-loss divergence test + NaN/Inf gradient scan + retry decision on the device, one 12-float all-reduce/step",
     }
     if rank == 0:
         res["roofline"] = dominant_kernel_roofline()

@@ -3,6 +3,9 @@ form the evaluator needs: `Omni3Deval.evaluate` calls `computeIoU` once per (ima
 comprehension (:1339-1343, :1357-1431), i.e. thousands of tiny `box3d_overlap` calls; `box3d_overlap_groups` takes all
 groups at once -- one validity launch + one ragged pairs launch + one readback.  The COCO-style greedy matching /
 accumulation around it (evaluateImg / accumulate) stays SURVEY.md 8(f) "next"."""
+import copy
+import datetime
+
 import numpy as np
 import torch
 
@@ -93,3 +96,359 @@ def evaluate_groups(ious_flat, dt_sizes, gt_sizes, gt_ignore, gt_range, dt_range
            _p(thrs), ng, A, T, sumD, sumG, int(gt_sizes.max()) if ng else 0, _p(out["dt_match"]), _p(out["gt_match"]),
            _p(out["dt_ignore"]), _p(out["gt_order"]), _p(out["gt_ignore"]), iou3d._lib.stream_of(ious_flat))
     return out
+
+
+# =====================================================================================================================
+# Omni3Deval: evaluate -> accumulate -> summarize on the device (reference :1019-1704)
+# =====================================================================================================================
+class Omni3DParams:
+    """omni3d_evaluation.py:1019-1088"""
+
+    def setDet2DParams(self):
+        self.imgIds, self.catIds = [], []
+        self.iouThrs = np.linspace(0.5, 0.95, int(np.round((0.95 - 0.5) / 0.05)) + 1, endpoint=True)
+        self.recThrs = np.linspace(0.0, 1.00, int(np.round((1.00 - 0.0) / 0.01)) + 1, endpoint=True)
+        self.maxDets = [1, 10, 100]
+        self.areaRng = [[0 ** 2, 1e5 ** 2], [0 ** 2, 32 ** 2], [32 ** 2, 96 ** 2], [96 ** 2, 1e5 ** 2]]
+        self.areaRngLbl = ["all", "small", "medium", "large"]
+        self.useCats = 1
+
+    def setDet3DParams(self):
+        self.imgIds, self.catIds = [], []
+        self.iouThrs = np.linspace(0.05, 0.5, int(np.round((0.5 - 0.05) / 0.05)) + 1, endpoint=True)
+        self.recThrs = np.linspace(0.0, 1.00, int(np.round((1.00 - 0.0) / 0.01)) + 1, endpoint=True)
+        self.maxDets = [1, 10, 100]
+        self.areaRng = [[0, 1e5], [0, 10], [10, 35], [35, 1e5]]
+        self.areaRngLbl = ["all", "near", "medium", "far"]
+        self.useCats = 1
+
+    def __init__(self, mode="2D"):
+        if mode == "2D":
+            self.setDet2DParams()
+        elif mode == "3D":
+            self.setDet3DParams()
+        else:
+            raise Exception("mode %s not supported" % (mode))
+        self.iouType = "bbox"
+        self.mode = mode
+        self.proximity_thresh = 0.3
+
+
+class AnnotationIndex:
+    """The four COCO-API calls Omni3Deval makes (getImgIds / getCatIds / getAnnIds / loadAnns) over a plain list of
+    annotation dicts -- pycocotools is not needed for the scoped path."""
+
+    def __init__(self, anns, img_ids=None, cat_ids=None):
+        self.anns = {}
+        for i, a in enumerate(anns):
+            a.setdefault("id", i + 1)
+            self.anns[a["id"]] = a
+        self._imgs = sorted(set(img_ids) if img_ids is not None else {a["image_id"] for a in anns})
+        self._cats = sorted(set(cat_ids) if cat_ids is not None else {a["category_id"] for a in anns})
+
+    def getImgIds(self):
+        return list(self._imgs)
+
+    def getCatIds(self):
+        return list(self._cats)
+
+    def getAnnIds(self, imgIds=(), catIds=()):
+        imgs, cats = set(imgIds), set(catIds)
+        return [i for i, a in self.anns.items() if (not imgs or a["image_id"] in imgs) and (not cats or a["category_id"] in cats)]
+
+    def loadAnns(self, ids):
+        return [self.anns[i] for i in ids]
+
+
+def _ragged_pairs(dt_sizes, gt_sizes):
+    counts = dt_sizes * gt_sizes
+    pair_off = np.concatenate([[0], np.cumsum(counts)])
+    P = int(pair_off[-1])
+    gid = np.repeat(np.arange(len(counts)), counts)
+    local = np.arange(P) - pair_off[gid]
+    ng = np.maximum(gt_sizes[gid], 1)
+    dt_off = np.concatenate([[0], np.cumsum(dt_sizes)])[:-1]
+    gt_off = np.concatenate([[0], np.cumsum(gt_sizes)])[:-1]
+    return (dt_off[gid] + local // ng).astype(np.int64), (gt_off[gid] + local % ng).astype(np.int64), pair_off
+
+
+class Omni3Deval:
+    """`Omni3Deval(cocoGt, cocoDt, mode=...)` with the reference's evaluate() / accumulate() / summarize() and result layout
+    (`eval['precision']` [T,R,K,A,M], `eval['recall']` [T,K,A,M], `eval['scores']`, `stats` (13,)).
+
+    evaluate(): all (image, category) groups at once -- one IoU pass (`box3d_overlap_groups` in 3D, a vectorised box IoU in
+    2D) and one greedy-matching launch for every group x range x threshold (`evaluate_groups`, csrc/eval_match.hip);
+    accumulate(): one launch for every (category, range, maxDets, threshold) (`omni_eval_accumulate`).  The reference runs
+    these as Python loops over dict-of-list structures (:1339-1351, :1230-1301).  eval_prox (proximity evaluation for
+    non-exhaustively annotated datasets, :1419-1429) is not built."""
+
+    def __init__(self, cocoGt=None, cocoDt=None, iouType="bbox", mode="2D", eval_prox=False):
+        if mode not in ["2D", "3D"]:
+            raise Exception("mode %s not supported" % (mode))
+        if eval_prox:
+            raise NotImplementedError("proximity evaluation (eval_prox) is not built on the device path")
+        self.mode, self.eval_prox = mode, eval_prox
+        self.cocoGt, self.cocoDt = cocoGt, cocoDt
+        self.params = Omni3DParams(mode)
+        self.eval, self.stats, self._dev = {}, [], None
+        if cocoGt is not None:
+            self.params.imgIds = sorted(cocoGt.getImgIds())
+            self.params.catIds = sorted(cocoGt.getCatIds())
+
+    # ---- evaluate (:1315-1357 + computeIoU :1359-1431 + evaluateImg :1433-1551) ----------------------------------------
+    def evaluate(self, device=None):
+        p = self.params
+        p.imgIds = list(np.unique(p.imgIds))
+        p.catIds = list(np.unique(p.catIds)) if p.useCats else p.catIds
+        p.maxDets = sorted(p.maxDets)
+        if not p.useCats:
+            raise NotImplementedError("useCats = 0 is not built on the device path")
+        gts = self.cocoGt.loadAnns(self.cocoGt.getAnnIds(imgIds=p.imgIds, catIds=p.catIds))
+        dts = self.cocoDt.loadAnns(self.cocoDt.getAnnIds(imgIds=p.imgIds, catIds=p.catIds))
+        flag = "ignore2D" if self.mode == "2D" else "ignore3D"
+        g_by, d_by = {}, {}
+        for g in gts:
+            g[flag] = g[flag] if flag in g else 0
+            g_by.setdefault((g["image_id"], g["category_id"]), []).append(g)
+        for d in dts:
+            d_by.setdefault((d["image_id"], d["category_id"]), []).append(d)
+        maxDet = p.maxDets[-1]
+        # group table in (category, image) order = the order evalImgs / accumulate walk (:1346-1351, :1230-1241)
+        groups = []
+        for ki, cat in enumerate(p.catIds):
+            for ii, img in enumerate(p.imgIds):
+                g, d = g_by.get((img, cat), []), d_by.get((img, cat), [])
+                if not g and not d:
+                    continue
+                order = np.argsort([-x["score"] for x in d], kind="mergesort")
+                groups.append((ki, ii, g, [d[i] for i in order[:maxDet]]))
+        key = "bbox" if self.mode == "2D" else "bbox3D"
+        rng_key = "area" if self.mode == "2D" else "depth"
+        dt_sizes = np.array([len(gr[3]) for gr in groups], dtype=np.int64)
+        gt_sizes = np.array([len(gr[2]) for gr in groups], dtype=np.int64)
+        all_d = [x for gr in groups for x in gr[3]]
+        all_g = [x for gr in groups for x in gr[2]]
+        if device is None:
+            device = torch.device("cpu") if iou3d._lib.get().emulated else torch.device("cuda")
+        f32 = lambda v, shape: torch.tensor(np.asarray(v, dtype=np.float32).reshape(shape)).to(device)      # noqa: E731
+        if self.mode == "3D":
+            mats = box3d_overlap_groups(f32([x[key] for x in all_d], (-1, 8, 3)), f32([x[key] for x in all_g], (-1, 8, 3)), dt_sizes, gt_sizes)
+            flat = torch.cat([m.reshape(-1) for m in mats]) if mats else torch.zeros(0, device=device)
+        else:
+            i1, i2, _ = _ragged_pairs(dt_sizes, gt_sizes)
+            bd, bg = f32([x[key] for x in all_d], (-1, 4))[torch.from_numpy(i1).to(device)], f32([x[key] for x in all_g], (-1, 4))[torch.from_numpy(i2).to(device)]
+            iw = (torch.min(bd[:, 0] + bd[:, 2], bg[:, 0] + bg[:, 2]) - torch.max(bd[:, 0], bg[:, 0])).clamp(min=0)
+            ih = (torch.min(bd[:, 1] + bd[:, 3], bg[:, 1] + bg[:, 3]) - torch.max(bd[:, 1], bg[:, 1])).clamp(min=0)
+            inter = iw * ih
+            flat = inter / (bd[:, 2] * bd[:, 3] + bg[:, 2] * bg[:, 3] - inter)                  # pycocotools bbIou, iscrowd = 0
+        m = evaluate_groups(flat, dt_sizes, gt_sizes, torch.tensor([int(x[flag]) for x in all_g], dtype=torch.int32, device=device),
+                            f32([x[rng_key] for x in all_g], (-1,)), f32([x[rng_key] for x in all_d], (-1,)), p.areaRng, p.iouThrs)
+        self._dev = {"groups": groups, "dt_sizes": dt_sizes, "gt_sizes": gt_sizes, "match": m, "device": device,
+                     "scores": np.array([x["score"] for x in all_d], dtype=np.float64),
+                     "dt_ids": np.array([x.get("id", 0) for x in all_d]), "gt_ids": np.array([x.get("id", 0) for x in all_g])}
+        self._paramsEval = copy.deepcopy(self.params)
+        self._evalImgs = None
+
+    @property
+    def evalImgs(self):
+        """the reference's per-(category, range, image) list of dicts (:1541-1551), materialised on demand from the device
+        results -- accumulate() does not need it"""
+        if self._evalImgs is None and self._dev is not None:
+            p, d = self._paramsEval, self._dev
+            m = {k: v.cpu().numpy() for k, v in d["match"].items()}
+            doff, goff = np.concatenate([[0], np.cumsum(d["dt_sizes"])]), np.concatenate([[0], np.cumsum(d["gt_sizes"])])
+            where = {(ki, ii): n for n, (ki, ii, _, _) in enumerate(d["groups"])}
+            out = []
+            for ki, cat in enumerate(p.catIds):
+                for ai, aRng in enumerate(p.areaRng):
+                    for ii, img in enumerate(p.imgIds):
+                        n = where.get((ki, ii))
+                        if n is None:
+                            out.append(None)
+                            continue
+                        ds, gs = slice(doff[n], doff[n + 1]), slice(goff[n], goff[n + 1])
+                        order = m["gt_order"][ai, gs]
+                        gids, dids = d["gt_ids"][gs], d["dt_ids"][ds]
+                        dtm = m["dt_match"][ai][:, ds]
+                        gtm = m["gt_match"][ai][:, gs][:, order]
+                        out.append({"image_id": img, "category_id": cat, "aRng": aRng, "maxDet": p.maxDets[-1],
+                                    "dtIds": list(dids), "gtIds": list(gids[order]),
+                                    "dtMatches": np.where(dtm >= 0, gids[np.clip(dtm, 0, None)] if len(gids) else 0, 0).astype(np.float64),
+                                    "gtMatches": np.where(gtm >= 0, dids[np.clip(gtm, 0, None)] if len(dids) else 0, 0).astype(np.float64),
+                                    "dtScores": list(d["scores"][ds]), "gtIgnore": m["gt_ignore"][ai, gs][order].astype(np.float64),
+                                    "dtIgnore": m["dt_ignore"][ai][:, ds].astype(bool)})
+            self._evalImgs = out
+        return self._evalImgs
+
+    # ---- accumulate (:1172-1313) --------------------------------------------------------------------------------------
+    def accumulate(self, p=None):
+        assert self._dev is not None, "Please run evaluate() first"
+        if p is None:
+            p = self.params
+        pe, d = self._paramsEval, self._dev
+        if list(p.catIds) != list(pe.catIds) or list(map(tuple, p.areaRng)) != list(map(tuple, pe.areaRng)) or list(p.maxDets) != list(pe.maxDets) \
+                or list(p.imgIds) != list(pe.imgIds):
+            raise NotImplementedError("accumulate() with parameters other than evaluate()'s is not built on the device path")
+        T, R, K, A, M = len(p.iouThrs), len(p.recThrs), len(p.catIds), len(p.areaRng), len(p.maxDets)
+        dev = d["device"]
+        groups, dt_sizes, gt_sizes = d["groups"], d["dt_sizes"], d["gt_sizes"]
+        sumD = int(dt_sizes.sum())
+        cat_of_group = np.array([g[0] for g in groups], dtype=np.int64)
+        det_cat = np.repeat(cat_of_group, dt_sizes)
+        det_rank = np.concatenate([np.arange(n) for n in dt_sizes]).astype(np.int32) if len(groups) else np.zeros(0, np.int32)
+        # merge order: stable by -score inside a category, categories ascending; ties keep (image, in-image) order (:1250-1253)
+        order = np.lexsort((np.arange(sumD), -d["scores"], det_cat)).astype(np.int32) if sumD else np.zeros(0, np.int32)
+        cat_off = np.concatenate([[0], np.cumsum(np.bincount(det_cat, minlength=K))]).astype(np.int32)
+        gt_ig = d["match"]["gt_ignore"].cpu().numpy()                                   # (A, sumG)
+        gcat = np.repeat(cat_of_group, gt_sizes)
+        npig = np.zeros((K, A), np.int32)
+        for a in range(A):
+            npig[:, a] = np.bincount(gcat[gt_ig[a] == 0], minlength=K)
+        has_e = np.bincount(cat_of_group, minlength=K).astype(np.int32).clip(max=1)
+        tod = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)               # noqa: E731
+        prec = torch.full((T, R, K, A, M), -1.0, dtype=torch.float64, device=dev)
+        rec = torch.full((T, K, A, M), -1.0, dtype=torch.float64, device=dev)
+        scr = torch.full((T, R, K, A, M), -1.0, dtype=torch.float64, device=dev)
+        L = iou3d._lib.get()
+        _p = iou3d._lib.ptr
+        t_order, t_off, t_rank, t_sc = tod(order), tod(cat_off), tod(det_rank), tod(d["scores"])
+        t_npig, t_has, t_thr, t_md = tod(npig), tod(has_e), tod(np.asarray(p.recThrs, dtype=np.float64)), tod(np.asarray(p.maxDets, dtype=np.int32))
+        dm, dg = d["match"]["dt_match"].contiguous(), d["match"]["dt_ignore"].contiguous()
+        L.call("omni_eval_accumulate", _p(t_order), _p(t_off), _p(t_rank), _p(t_sc), _p(dm), _p(dg), _p(t_npig), _p(t_has), _p(t_thr),
+               _p(t_md), K, A, M, T, R, sumD, _p(prec), _p(rec), _p(scr), iou3d._lib.stream_of(prec))
+        self.eval = {"params": p, "counts": [T, R, K, A, M], "date": datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S"),
+                     "precision": prec.cpu().numpy(), "recall": rec.cpu().numpy(), "scores": scr.cpu().numpy()}
+
+    # ---- summarize (:1553-1704) ---------------------------------------------------------------------------------------
+    def summarize(self):
+        if not self.eval:
+            raise Exception("Please run accumulate() first")
+        p, ev, mode = self.params, self.eval, self.mode
+        lines = []
+
+        def one(ap=1, iouThr=None, areaRng="all", maxDets=100):
+            fmt = (" {:<18} {} @[ IoU={:<9} | area={:>6s} | maxDets={:>3d} ] = {:0.3f}" if mode == "2D"
+                   else " {:<18} {} @[ IoU={:<9} | depth={:>6s} | maxDets={:>3d} ] = {:0.3f}")
+            iouStr = "{:0.2f}:{:0.2f}".format(p.iouThrs[0], p.iouThrs[-1]) if iouThr is None else "{:0.2f}".format(iouThr)
+            aind = [i for i, a in enumerate(p.areaRngLbl) if a == areaRng]
+            mind = [i for i, m in enumerate(p.maxDets) if m == maxDets]
+            if ap == 1:
+                s = ev["precision"]
+                if iouThr is not None:
+                    s = s[np.where(np.isclose(iouThr, p.iouThrs.astype(float)))[0]]
+                s = s[:, :, :, aind, mind]
+            else:
+                s = ev["recall"]
+                if iouThr is not None:
+                    s = s[np.where(iouThr == p.iouThrs)[0]]
+                s = s[:, :, aind, mind]
+            mean_s = -1 if len(s[s > -1]) == 0 else np.mean(s[s > -1])
+            lines.append("mode={} ".format(mode) + fmt.format("Average Precision" if ap == 1 else "Average Recall", "(AP)" if ap == 1 else "(AR)",
+                                                             iouStr, areaRng, maxDets, mean_s))
+            return mean_s
+
+        thres = [0.5, 0.75, 0.95] if mode == "2D" else [0.15, 0.25, 0.50]
+        L, md = p.areaRngLbl, p.maxDets
+        stats = np.zeros((13,))
+        stats[0] = one(1)
+        for i in range(3):
+            stats[1 + i] = one(1, iouThr=thres[i], maxDets=md[2])
+        for i in range(3):
+            stats[4 + i] = one(1, areaRng=L[1 + i], maxDets=md[2])
+        for i in range(3):
+            stats[7 + i] = one(0, maxDets=md[i])
+        for i in range(3):
+            stats[10 + i] = one(0, areaRng=L[1 + i], maxDets=md[2])
+        self.stats = stats
+        return "\n".join(lines)
+
+    def __str__(self):
+        self.summarize()
+
+
+# =====================================================================================================================
+# prediction plumbing around it (f-3): instances -> COCO-style records, the inference loop, the evaluator object
+# =====================================================================================================================
+def instances_to_coco_json(instances, img_id):
+    """omni3d_evaluation.py:970-1013.  The reference converts each field with its own `.tolist()` after a per-field device
+    copy and averages the corner depths one box at a time in numpy; here one host copy per field and a vectorised depth."""
+    n = len(instances)
+    if n == 0:
+        return []
+    cpu = instances.to("cpu") if instances.pred_boxes.tensor.is_cuda else instances
+    xyxy = cpu.pred_boxes.tensor.numpy()
+    boxes = np.concatenate([xyxy[:, :2], xyxy[:, 2:] - xyxy[:, :2]], axis=1).tolist()          # XYXY_ABS -> XYWH_ABS
+    scores, classes = cpu.scores.tolist(), cpu.pred_classes.tolist()
+    if cpu.has("pred_bbox3D"):
+        b3 = cpu.pred_bbox3D.numpy()
+        depth = b3[:, :, 2].mean(axis=1).tolist()
+        bbox3D, center_cam, center_2D = b3.tolist(), cpu.pred_center_cam.tolist(), cpu.pred_center_2D.tolist()
+        dimensions, pose = cpu.pred_dimensions.tolist(), cpu.pred_pose.tolist()
+    else:
+        bbox3D, center_cam, center_2D = np.ones([n, 8, 3]).tolist(), np.ones([n, 3]).tolist(), np.ones([n, 2]).tolist()
+        dimensions, pose, depth = np.ones([n, 3]).tolist(), np.ones([n, 3, 3]).tolist(), [1.0] * n
+    return [{"image_id": img_id, "category_id": classes[k], "bbox": boxes[k], "score": scores[k], "depth": depth[k], "bbox3D": bbox3D[k],
+             "center_cam": center_cam[k], "center_2D": center_2D[k], "dimensions": dimensions[k], "pose": pose[k]} for k in range(n)]
+
+
+def inference_on_dataset(model, data_loader):
+    """omni3d_evaluation.py:522-640 without the timing / logging: model in eval mode over the loader -> list of
+    {'image_id', 'K', 'width', 'height', 'instances': [COCO-style records]}"""
+    was_training = model.training
+    model.eval()
+    out = []
+    with torch.no_grad():
+        for inputs in data_loader:
+            outputs = model(inputs)
+            for inp, o in zip(inputs, outputs):
+                out.append({"image_id": inp["image_id"], "K": inp["K"], "width": inp["width"], "height": inp["height"],
+                            "instances": instances_to_coco_json(o["instances"], inp["image_id"])})
+    model.train(was_training)
+    return out
+
+
+class Omni3DEvaluator:
+    """reset() / process(inputs, outputs) / evaluate() around Omni3Deval (reference :643-935, reduced to the metric path:
+    AP2D / AP3D tables from in-memory ground truth; JSON dumps, per-category tables and visualisation are host bookkeeping)."""
+
+    def __init__(self, gt_annotations, img_ids=None, cat_ids=None, only_2d=False):
+        self._gt = gt_annotations
+        self._img_ids, self._cat_ids, self._only_2d = img_ids, cat_ids, only_2d
+        self.reset()
+
+    def reset(self):
+        self._predictions = []
+
+    def process(self, inputs, outputs):
+        for inp, o in zip(inputs, outputs):
+            self._predictions.extend(instances_to_coco_json(o["instances"], inp["image_id"]))
+
+    def evaluate(self):
+        res = {}
+        for mode in (["2D"] if self._only_2d else ["2D", "3D"]):
+            ev = Omni3Deval(AnnotationIndex(copy.deepcopy(self._gt), self._img_ids, self._cat_ids),
+                            AnnotationIndex(copy.deepcopy(self._predictions), self._img_ids, self._cat_ids), mode=mode)
+            ev.evaluate()
+            ev.accumulate()
+            ev.summarize()
+            res["AP" + mode] = float(ev.stats[0] * 100)
+            res["omni_eval_" + mode] = ev
+        return {"bbox": res}
+
+
+class Omni3DEvaluationHelper:
+    """omni3d_evaluation.py:168-520 aggregates per-dataset evaluators, JSON files and printed tables on the host; only the
+    container part is kept"""
+
+    def __init__(self, dataset_names=(), filter_settings=None, output_folder=None, iter_label="-", only_2d=False):
+        self.dataset_names, self.output_folder, self.iter_label, self.only_2d = list(dataset_names), output_folder, iter_label, only_2d
+        self.evaluators, self.results = {}, {}
+
+    def add_predictions(self, dataset_name, predictions):
+        self.evaluators.setdefault(dataset_name, []).extend(predictions)
+
+    def evaluate(self, dataset_name):
+        raise NotImplementedError("per-dataset JSON / table bookkeeping is host-side and out of the hot-path scope; use Omni3DEvaluator")
+
+    def summarize_all(self):
+        return self.results

@@ -52,6 +52,7 @@ class FlatSGD(torch.optim.Optimizer):
         self.set_direct_accumulate(direct_accumulate)
         self._steps = 0
         self.skip_flag = None   # optional device float: != 0 skips the update inside the kernel
+        self._grad_scale = 1.0  # consumed by the next step(): 1/world when the all-reduce left SUMS in the bucket
 
     def _build_buckets(self):
         plist = [(g, p) for g in self.param_groups for p in g["params"]]
@@ -67,6 +68,7 @@ class FlatSGD(torch.optim.Optimizer):
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_mom = torch.zeros(total, dtype=torch.float32, device=dev)
         self.segments = []   # (start, end, representative group)
+        self._slot = {}      # id(param) -> (offset, numel) inside the flat buckets
         off = 0
         # Inside a class, parameters whose gradients complete EARLY in backward (the heads: everything that is not the
         # backbone, tagged `_omni_early_grad` by build_optimizer) sit behind the late ones, so each class is
@@ -89,6 +91,7 @@ class FlatSGD(torch.optim.Optimizer):
                 if p.grad is not None:
                     gv.copy_(p.grad)
                 p.grad = gv
+                self._slot[id(p)] = (off, n)
                 off += ((n + 3) // 4) * 4
             if mid is None:
                 mid = off
@@ -99,6 +102,7 @@ class FlatSGD(torch.optim.Optimizer):
             self.segments.append((start, off, items[0][0]))
 
     def set_direct_accumulate(self, flag):
+        self._direct = bool(flag)
         for g in self.param_groups:
             for p in g["params"]:
                 p._omni_direct_grad = bool(flag)
@@ -111,7 +115,33 @@ class FlatSGD(torch.optim.Optimizer):
         return flat.view(p.shape)
 
     def zero_grad(self, set_to_none=False):
-        self.flat_grad.zero_()    # param.grad stay views of the bucket
+        """param.grad stay views of the flat bucket (set_to_none is ignored: the views ARE the storage the fused step and
+        the all-reduce operate on)."""
+        self.flat_grad.zero_()
+
+    @torch.no_grad()
+    def _rebind_grads(self):
+        """`nn.Module.zero_grad()` (set_to_none=True by default), `p.grad = None` or `model.to()` detach a parameter's grad
+        from the bucket; autograd then accumulates into a fresh tensor the fused step would never see.  Before every step:
+        a stray gradient is copied into its bucket slot and re-bound; a missing one (None) means "no gradient this step",
+        so its slot is cleared.  Costs one pointer compare per parameter."""
+        fixed = 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                off, n = self._slot[id(p)]
+                want = self.flat_grad[off:off + n]
+                if p.grad is not None and p.grad.data_ptr() == want.data_ptr():
+                    continue
+                gv = self._view_like(want, p)
+                if p.grad is None:
+                    gv.zero_()
+                else:
+                    gv.copy_(p.grad)
+                p.grad = gv
+                fixed += 1
+        if fixed:
+            self.set_direct_accumulate(self._direct)
+        return fixed
 
     @torch.no_grad()
     def all_reduce_grads(self, group=None):
@@ -131,15 +161,20 @@ class FlatSGD(torch.optim.Optimizer):
         ranges = self.early_ranges if which == "early" else self.late_ranges
         return [(dist.all_reduce(self.flat_grad[s:e], group=group, async_op=True), s, e) for s, e in ranges]
 
-    def all_reduce_finish(self, pending, group=None):
-        """Waits for the handles of all_reduce_begin (stream-ordered for RCCL) and averages."""
+    def all_reduce_finish(self, pending, group=None, defer_scale=False):
+        """Waits for the handles of all_reduce_begin (stream-ordered for RCCL) and averages.  defer_scale=True leaves the
+        SUMS in the bucket and folds 1/world into the next step()'s kernel (saves one pass over the 191.6 MB bucket; the
+        per-parameter `.grad` views then hold sums until the step -- the training loop only scans them for NaN/Inf)."""
         import torch.distributed as dist
         if not pending:
             return
         scale = 1.0 / dist.get_world_size(group)
         for work, s, e in pending:
             work.wait()
-            self.flat_grad[s:e].mul_(scale)
+            if not defer_scale:
+                self.flat_grad[s:e].mul_(scale)
+        if defer_scale:
+            self._grad_scale = scale
 
     @torch.no_grad()
     def check_nonfinite(self, flag):
@@ -148,25 +183,59 @@ class FlatSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        self._rebind_grads()
         first = self._steps == 0
         for start, end, g in self.segments:
             det.sgd_step(self.flat_param[start:end], self.flat_grad[start:end], self.flat_mom[start:end], g["lr"],
-                         g["momentum"], g["dampening"], g["weight_decay"], g["nesterov"], first_step=first, skip_flag=self.skip_flag)
+                         g["momentum"], g["dampening"], g["weight_decay"], g["nesterov"], first_step=first, skip_flag=self.skip_flag,
+                         grad_scale=self._grad_scale)
+        self._grad_scale = 1.0
         self._steps += 1
 
+    # ---- checkpoint format: torch.optim.SGD's (per-parameter `momentum_buffer`), so optimizer states written by the
+    # reference's DetectionCheckpointer (tools/train_net.py:128) load here and vice versa ----------------------------------
+    def _ordered_params(self):
+        return [p for g in self.param_groups for p in g["params"]]
+
     def state_dict(self):
-        sd = super().state_dict()
-        sd["flat_momentum"] = self.flat_mom.clone()
-        sd["steps"] = self._steps
+        sd = super().state_dict()          # param_groups with params packed as 0..N-1 in group order, like torch.optim.SGD
+        state = {}
+        if self._steps > 0:
+            for idx, p in enumerate(self._ordered_params()):
+                off, n = self._slot[id(p)]
+                state[idx] = {"momentum_buffer": self._view_like(self.flat_mom[off:off + n], p).detach().clone()
+                              .contiguous(memory_format=torch.contiguous_format)}
+        sd["state"] = state
         return sd
 
     def load_state_dict(self, sd):
         sd = dict(sd)
-        mom = sd.pop("flat_momentum", None)
-        self._steps = sd.pop("steps", 0)
-        super().load_state_dict(sd)
-        if mom is not None:
-            self.flat_mom.copy_(mom)
+        legacy = sd.pop("flat_momentum", None)           # round-1 layout-dependent format, still readable
+        steps = sd.pop("steps", None)
+        state = sd.get("state", {})
+        params = self._ordered_params()
+        sd["state"] = {}
+        super().load_state_dict(sd)                      # learning rates, momentum, weight decay of the groups
+        self.flat_mom.zero_()
+        loaded = 0
+        for idx, st in state.items():
+            buf = st.get("momentum_buffer") if isinstance(st, dict) else None
+            if buf is None:
+                continue
+            p = params[int(idx)]
+            off, n = self._slot[id(p)]
+            if buf.numel() != n:
+                raise ValueError(f"momentum_buffer {idx}: {buf.numel()} elements, the parameter has {n}")
+            self._view_like(self.flat_mom[off:off + n], p).copy_(buf.reshape(p.shape).to(self.flat_mom.device))
+            loaded += 1
+        if legacy is not None and loaded == 0:
+            self.flat_mom.copy_(legacy)
+            loaded = len(params)
+        if loaded not in (0, len(params)) :
+            raise ValueError(f"optimizer state holds momentum for {loaded} of {len(params)} parameters")
+        if loaded == 0 and any(g["momentum"] != 0 for g in self.param_groups) and (steps or 0) > 0:
+            raise ValueError("optimizer state has no momentum buffers although momentum != 0 and steps > 0")
+        self._steps = int(steps) if steps is not None else (1 if loaded else 0)
 
 
 def build_optimizer(cfg, model):

@@ -1,0 +1,93 @@
+"""The training loop's safety logic of the reference (tools/train_net.py:157-285, 471-498) as device-side state plus ONE
+small all-reduce per step.
+
+Reference per iteration: `allreduce_dict(loss_dict)` + ten `.item()` (:186), `comm.synchronize()` (:190), the rolling-loss
+divergence test (:198-215), the per-parameter NaN/Inf scan (:222-233), an all-reduce of the "diverging" flag (:237-243),
+skip or step (:245-253), the retry decision and an all-reduce of it (:258-270) -- three collectives, three barriers and a
+dozen host syncs.  Here:
+
+  * one 12-float vector per rank [10 losses | sum | non-finite-gradient flag] is all-reduced ONCE (sum);
+  * the divergence test, the rolling mean, the success / explode counters and the retry decision are evaluated from the
+    reduced vector by a handful of tiny device ops, identically on every rank (same inputs => same decision, so the flags
+    need no second collective), and `skip` lands in the device float the fused SGD kernel reads (`FlatSGD.skip_flag`);
+  * the host reads (skipped, retry, 10 reduced losses) back in one copy -- every step (`sync=True`, the reference's
+    semantics: it logs the scalars and may return False to restart) or only when it wants to look (`sync=False`).
+
+The clipped-loss trick of the reference (`losses.clip(0, 1)` before backward when diverging, then zero_grad and no step)
+only exists to keep that iteration's backward finite; its net effect -- no update -- is what the skip flag does."""
+import torch
+import torch.distributed as dist
+
+TOLERANCE = 4.0      # tools/train_net.py:163
+GAMMA = 0.02         # :165
+
+
+class StepGuard:
+    def __init__(self, loss_names, stabilize, checkpoint_period, device, group=None):
+        self.names = sorted(loss_names)                      # allreduce_dict sorts the keys (:486)
+        self.stabilize = float(stabilize)                    # cfg.MODEL.STABILIZE
+        self.half_period = 0.5 * float(checkpoint_period)    # :259
+        self.group = group
+        n = len(self.names)
+        self.vec = torch.zeros(n + 2, dtype=torch.float32, device=device)       # [losses | total | nonfinite]
+        self.recent = torch.full((), float("nan"), dtype=torch.float32, device=device)   # NaN = "None" (:166)
+        self.counts = torch.zeros(2, dtype=torch.float32, device=device)        # [success, explode]
+        self.skip = torch.zeros(1, dtype=torch.float32, device=device)          # -> FlatSGD.skip_flag
+        self.out = torch.zeros(n + 3, dtype=torch.float32, device=device)       # [skipped, retry, total, losses...]
+
+    @property
+    def nonfinite_flag(self):
+        """(1,) view the fused gradient scan writes into (FlatSGD.check_nonfinite)"""
+        return self.vec[-1:]
+
+    def world(self):
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    @torch.no_grad()
+    def update(self, loss_dict, sync=True):
+        """Call after backward + all-reduce of the gradients + check_nonfinite(self.nonfinite_flag), before optimizer.step().
+        -> (skipped, retry, {name: reduced loss}) as host values when sync, else None."""
+        n = len(self.names)
+        self.vec[:n] = torch.stack([loss_dict[k].detach().float().reshape(()) for k in self.names])
+        self.vec[n] = self.vec[:n].sum()
+        w = self.world()
+        if w > 1:
+            dist.all_reduce(self.vec, group=self.group)          # the ONE collective of the guard
+            self.vec[: n + 1] /= w                               # allreduce_dict(average=True)
+        total, bad_grad = self.vec[n], self.vec[n + 1] > 0
+        first = torch.isnan(self.recent)
+        recent = torch.where(first, total * 2.0, self.recent)                     # :194-196
+        loss_div = ~torch.isfinite(total) | (total > recent * TOLERANCE)          # :199-201
+        if not self.stabilize > 0:
+            loss_div = bad_grad = torch.zeros_like(loss_div)                      # guard off: the reference always steps
+        # the rolling mean moves whenever the LOSS was sane, also when the gradient scan then fails (:205-215 precede :222)
+        self.recent = torch.where(loss_div, recent, recent * (1 - GAMMA) + total * GAMMA)
+        diverging = loss_div | bad_grad
+        self.skip[0] = diverging.float()
+        self.counts += torch.stack([1.0 - self.skip[0], self.skip[0]])
+        tot = self.counts.sum()
+        retry = ((self.counts[1] / tot) >= self.stabilize) & (tot > self.half_period) & (self.stabilize > 0)     # :258-259
+        self.out[0], self.out[1], self.out[2] = self.skip[0], retry.float(), total
+        self.out[3:] = self.vec[:n]
+        self.nonfinite_flag.zero_()
+        if not sync:
+            return None
+        return self.read()
+
+    def read(self):
+        v = self.out.tolist()                                                     # one device->host copy
+        return bool(v[0]), bool(v[1]), dict(zip(self.names, v[3:]), total_loss=v[2])
+
+
+def allreduce_dict(input_dict, average=True, group=None):
+    """tools/train_net.py:471-498: every value a 0-d tensor; one stacked all-reduce in sorted-key order."""
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world < 2:
+        return input_dict
+    with torch.no_grad():
+        names = sorted(input_dict.keys())
+        values = torch.stack([input_dict[k] for k in names], dim=0)
+        dist.all_reduce(values, group=group)
+        if average:
+            values /= world
+        return {k: v for k, v in zip(names, values)}

@@ -247,10 +247,10 @@ def cuboid_corners(box3d, R):
 
 
 def sgd_step(param, grad, buf, lr, momentum=0.9, dampening=0.0, weight_decay=0.0, nesterov=False, first_step=False,
-             skip_flag=None):
+             skip_flag=None, grad_scale=1.0):
     L = _dev(param, grad, buf, skip_flag)
     L.call("omni_sgd_step", _lib.ptr(param), _lib.ptr(grad), _lib.ptr(buf), param.numel(), float(lr), float(momentum),
-           float(dampening), float(weight_decay), int(nesterov), int(first_step), _lib.ptr(skip_flag),
+           float(dampening), float(weight_decay), int(nesterov), int(first_step), float(grad_scale), _lib.ptr(skip_flag),
            _lib.stream_of(param))
 
 

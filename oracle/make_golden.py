@@ -263,8 +263,53 @@ def main_eval(seed=11, groups=40):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def main_evalfull(seed=5, images=40, cats=3):
+    """Whole-evaluator fixture: the reference's own `Omni3Deval` (3D mode) -- evaluate() (computeIoU + evaluateImg loops)
+    and accumulate() (omni3d_evaluation.py:1172-1357) -- on a random set of ground truths / detections with score ties,
+    ignored ground truths, empty groups and a category without any ground truth.  -> tests/golden/eval_full.npz"""
+    import json
+    import numpy as np
+    H.install()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import boxgen
+    from cubercnn.evaluation.omni3d_evaluation import Omni3Deval
+    from omni3d_amd.cubercnn.evaluation import AnnotationIndex          # duck-typed COCO API (4 methods), no arithmetic
+    np.float = float                                                     # the reference still uses the alias numpy 2 removed (:1265)
+    rs = np.random.default_rng(seed)
+    gts, dts = [], []
+    for img in range(images):
+        for cat in range(cats):
+            ng = int(rs.integers(0, 4)) if cat < cats - 1 else 0         # the last category never has ground truth
+            nd = int(rs.integers(0, 7))
+            if img == 0 and cat == 0:
+                ng, nd = 3, 0                                            # gts without detections
+            if ng + nd == 0:
+                continue
+            d_boxes, g_boxes, _ = boxgen.omni3d_like_pairs(rs, max(ng, nd, 1), overlap_frac=0.9, degenerate_frac=0.0)
+            for j in range(ng):
+                b = g_boxes[j]
+                gts.append({"image_id": img, "category_id": cat, "bbox3D": b.tolist(), "depth": float(b[:, 2].mean()),
+                            "ignore3D": int(rs.uniform() < 0.2), "bbox": [0, 0, 1, 1], "area": 1.0})
+            for j in range(nd):
+                b = d_boxes[j] if j < ng else d_boxes[j] + rs.normal(scale=2.0, size=(1, 3)).astype(np.float32)
+                score = float(np.round(rs.uniform(0.05, 1.0), 1 if rs.uniform() < 0.5 else 6))      # coarse rounding => score ties
+                dts.append({"image_id": img, "category_id": cat, "bbox3D": b.tolist(), "depth": float(b[:, 2].mean()), "score": score,
+                            "bbox": [0, 0, 1, 1], "area": 1.0})
+    ev = Omni3Deval(AnnotationIndex([dict(g) for g in gts], range(images), range(cats)),
+                    AnnotationIndex([dict(d) for d in dts], range(images), range(cats)), mode="3D")
+    ev.evaluate()
+    ev.accumulate()
+    ev.summarize()
+    path = os.path.join(ROOT, "tests", "golden", "eval_full.npz")
+    np.savez_compressed(path, precision=ev.eval["precision"], recall=ev.eval["recall"], scores=ev.eval["scores"], stats=np.asarray(ev.stats),
+                        annotations=np.frombuffer(json.dumps({"gts": gts, "dts": dts, "images": images, "cats": cats}).encode(), dtype=np.uint8))
+    print("wrote", path, os.path.getsize(path), "bytes; stats", np.round(ev.stats, 4).tolist())
+
+
 if __name__ == "__main__":
-    if "--eval" in sys.argv:
+    if "--evalfull" in sys.argv:
+        main_evalfull()
+    elif "--eval" in sys.argv:
         main_eval()
     elif "--infer" in sys.argv:
         main_infer()

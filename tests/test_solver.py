@@ -1,0 +1,183 @@
+"""FlatSGD checkpoint interchange with torch.optim.SGD (the format the reference's DetectionCheckpointer writes,
+tools/train_net.py:128), robustness against re-bound .grad tensors, and the StepGuard (tools/train_net.py:157-285)."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+from torch import nn
+
+from conftest import ROOT  # noqa: F401
+
+
+def _nets():
+    torch.manual_seed(0)
+    a = nn.Sequential(nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 3))
+    b = nn.Sequential(nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 3))
+    b.load_state_dict(a.state_dict())
+    return a, b
+
+
+def _loss(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(7, 6, generator=g)
+    return (net(x) ** 2).mean()
+
+
+def _flat(net, **kw):
+    from omni3d_amd.cubercnn.solver.build import FlatSGD
+    return FlatSGD([{"params": [p], "lr": 0.1, "weight_decay": wd} for p, wd in zip(net.parameters(), (1e-2, 0.0, 1e-2, 0.0))],
+                   0.1, momentum=0.9, direct_accumulate=False, **kw)
+
+
+def _torch(net):
+    return torch.optim.SGD([{"params": [p], "lr": 0.1, "weight_decay": wd} for p, wd in zip(net.parameters(), (1e-2, 0.0, 1e-2, 0.0))],
+                           0.1, momentum=0.9)
+
+
+def _same(a, b, tol=1e-6):
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert (p - q).abs().max() <= tol, float((p - q).abs().max())
+
+
+def test_flat_sgd_state_dict_is_torch_sgd_format(emu_lib):
+    a, b = _nets()
+    fo, to = _flat(a), _torch(b)
+    for it in range(2):
+        for net, opt in ((a, fo), (b, to)):
+            opt.zero_grad()
+            _loss(net, it).backward()
+            opt.step()
+    _same(a, b)
+    sd = fo.state_dict()
+    assert set(sd) == {"state", "param_groups"}
+    assert all("momentum_buffer" in v for v in sd["state"].values()) and len(sd["state"]) == 4
+    ref = to.state_dict()
+    for k in ref["state"]:
+        assert (sd["state"][k]["momentum_buffer"] - ref["state"][k]["momentum_buffer"]).abs().max() <= 1e-6
+    # FlatSGD -> torch.optim.SGD and torch.optim.SGD -> FlatSGD, then one more step each: all four agree
+    a2, b2 = _nets()
+    a2.load_state_dict(a.state_dict()); b2.load_state_dict(b.state_dict())
+    fo2, to2 = _flat(a2), _torch(b2)
+    fo2.load_state_dict(to.state_dict())           # reference-format state into the flat optimizer (momentum must arrive)
+    to2.load_state_dict(sd)                        # flat optimizer's state into torch SGD
+    assert float(fo2.flat_mom.abs().sum()) > 0 and fo2._steps > 0
+    for net, opt in ((a, fo), (b, to), (a2, fo2), (b2, to2)):
+        opt.zero_grad()
+        _loss(net, 9).backward()
+        opt.step()
+    _same(a, b); _same(a, a2); _same(a, b2)
+
+
+def test_flat_sgd_rejects_partial_momentum_state(emu_lib):
+    a, b = _nets()
+    fo, to = _flat(a), _torch(b)
+    to.zero_grad(); _loss(b, 0).backward(); to.step()
+    sd = to.state_dict()
+    sd["state"].pop(0)
+    with pytest.raises(ValueError):
+        fo.load_state_dict(sd)
+
+
+def test_flat_sgd_survives_module_zero_grad(emu_lib):
+    """nn.Module.zero_grad() sets .grad to None (torch >= 2): autograd then builds fresh gradient tensors outside the bucket.
+    step() must pick them up instead of silently applying only weight decay and momentum."""
+    a, b = _nets()
+    fo, to = _flat(a), _torch(b)
+    for it in range(3):
+        a.zero_grad()               # NOT optimizer.zero_grad()
+        b.zero_grad()
+        _loss(a, it).backward()
+        _loss(b, it).backward()
+        fo.step(); to.step()
+    _same(a, b)
+    assert all(p.grad.data_ptr() == fo.flat_grad[fo._slot[id(p)][0]:].data_ptr() for p in a.parameters())
+
+
+def test_flat_sgd_deferred_world_scale(emu_lib):
+    a, b = _nets()
+    fo, to = _flat(a), _torch(b)
+    fo.zero_grad(); to.zero_grad()
+    (2 * _loss(a, 0)).backward()        # "sum over 2 ranks"
+    _loss(b, 0).backward()
+    fo._grad_scale = 0.5                # what all_reduce_finish(defer_scale=True) leaves for the step kernel
+    fo.step(); to.step()
+    _same(a, b)
+    assert fo._grad_scale == 1.0
+
+
+def _reference_guard(seq, stabilize, period):
+    """tools/train_net.py:157-285 restated on host floats: seq = [(total_loss, grads_nonfinite)] -> [(skipped, retry)]"""
+    success = explode = 0
+    recent = None
+    out = []
+    for total, bad in seq:
+        if recent is None:
+            recent = total * 2.0
+        div = stabilize > 0 and (total > recent * 4.0 or not math.isfinite(total))
+        if not div:
+            recent = recent * (1 - 0.02) + total * 0.02
+            if stabilize > 0 and bad:
+                div = True
+        if div:
+            explode += 1
+        else:
+            success += 1
+        tot = success + explode
+        retry = (explode / tot) >= stabilize and tot > period * 0.5
+        out.append((bool(div), bool(retry) and stabilize > 0))
+    return out
+
+
+@pytest.mark.parametrize("stabilize", [0.02, 0.5, 0.0])
+def test_step_guard_matches_the_reference_logic(stabilize):
+    from omni3d_amd.cubercnn.solver.guard import StepGuard
+    seq = [(6.0, 0), (5.5, 0), (30.0, 0), (5.0, 1), (float("nan"), 0), (4.8, 0), (100.0, 0), (4.7, 0), (float("inf"), 0), (4.5, 0)]
+    want = _reference_guard(seq, stabilize, 6)
+    g = StepGuard(["b", "a"], stabilize, 6, "cpu")
+    for (total, bad), (skip_w, retry_w) in zip(seq, want):
+        g.nonfinite_flag[0] = float(bad)
+        skipped, retry, red = g.update({"a": torch.tensor(total * 0.25), "b": torch.tensor(total * 0.75)})
+        assert (skipped, retry) == (skip_w, retry_w), (total, bad, skipped, retry, skip_w, retry_w)
+        assert float(g.skip) == float(skip_w)
+        if math.isfinite(total):
+            assert abs(red["total_loss"] - total) < 1e-5 and abs(red["a"] - total * 0.25) < 1e-5
+
+
+def _guard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from omni3d_amd.cubercnn.solver.guard import StepGuard, allreduce_dict
+    g = StepGuard(["x", "y"], 0.5, 2, "cpu")
+    res = []
+    # step 0: sane; step 1: rank 1 alone sees non-finite gradients; step 2: rank 0 alone has a huge loss
+    for step, (lx, bad) in enumerate([((1.0, 3.0), (0, 0)), ((1.0, 3.0), (0, 1)), ((400.0, 2.0), (0, 0))]):
+        g.nonfinite_flag[0] = float(bad[rank])
+        skipped, retry, red = g.update({"x": torch.tensor(lx[rank]), "y": torch.tensor(2.0)})
+        res.append((skipped, retry, round(red["x"], 4), round(red["total_loss"], 4)))
+    d = allreduce_dict({"k": torch.tensor(float(rank + 1)), "j": torch.tensor(10.0 * (rank + 1))})
+    res.append((float(d["k"]), float(d["j"])))
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_step_guard_one_collective_keeps_ranks_in_agreement():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 400
+    ps = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(30)
+    assert out[0] == out[1]                                   # identical decisions and reduced scalars on both ranks
+    steps = out[0]
+    assert steps[0][:2] == (False, False) and steps[0][2] == 2.0            # mean of x over ranks (1, 3)
+    assert steps[1][0] is True                                # one rank's bad gradients skip the step everywhere
+    assert steps[2][0] is True and steps[2][1] is True        # 2 of 3 exploded >= 0.5 and 3 > period / 2: retry
+    assert steps[3] == (1.5, 15.0)                            # allreduce_dict average

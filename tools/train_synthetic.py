@@ -67,8 +67,8 @@ def main():
     if cfg.MODEL.DEVICE == "cpu":
         print("built on the CPU (dry run: the kernels need the GPU)")
         return
-    flag = torch.zeros(1, device="cuda")
-    optimizer.skip_flag = flag                       # non-finite gradients skip the update on the device (:222-246)
+    from cubercnn.solver import StepGuard
+    guard = None
     pool = [synthetic.make_batch(args.batch, args.size, args.size, num_gt=8, seed=s, priors=priors) for s in range(4)]
     t0 = time.perf_counter()
     with EventStorage(0) as storage:
@@ -77,18 +77,27 @@ def main():
             data = pool[it % len(pool)]
             loss_dict = model(data)
             losses = sum(loss_dict.values())
+            if guard is None:                            # :157-170 state; the skip flag is read by the fused SGD kernel
+                guard = StepGuard(list(loss_dict), cfg.MODEL.STABILIZE, cfg.SOLVER.CHECKPOINT_PERIOD, losses.device)
+                optimizer.skip_flag = guard.skip
             optimizer.zero_grad()
             losses.backward()
-            flag.zero_()
-            optimizer.check_nonfinite(flag)
-            optimizer.step()
-            storage.put_scalar("lr", optimizer.param_groups[0]["lr"], smoothing_hint=False)
+            optimizer.all_reduce_grads()
+            optimizer.check_nonfinite(guard.nonfinite_flag)                       # :222-233 as one pass
+            skipped, retry, reduced = guard.update(loss_dict)                       # :186-215, :237-270: ONE small all-reduce
+            storage.put_scalars(**{k.replace("/", "_"): v for k, v in reduced.items()})
+            optimizer.step()                                                        # skipped on the device when diverging
+            if not skipped:
+                storage.put_scalar("lr", optimizer.param_groups[0]["lr"], smoothing_hint=False)
+            if retry:
+                print(f"!! restart requested at iteration {it} (exploding loss) !!")   # :272-285 returns False here
+                return False
             scheduler.step()
-            ckpt.step(it)
+            if not skipped:
+                ckpt.step(it)
             if it % 10 == 0 or it == cfg.SOLVER.MAX_ITER - 1:
-                vals = {k: float(v) for k, v in loss_dict.items()}
-                print(f"iter {it:4d}  total {float(losses):8.4f}  lr {optimizer.param_groups[0]['lr']:.6f}  skipped {int(flag.item())}  "
-                      + "  ".join(f"{k.split('/')[-1]} {v:.3f}" for k, v in vals.items()), flush=True)
+                print(f"iter {it:4d}  total {reduced['total_loss']:8.4f}  lr {optimizer.param_groups[0]['lr']:.6f}  skipped {int(skipped)}  "
+                      + "  ".join(f"{k.split('/')[-1]} {v:.3f}" for k, v in reduced.items() if k != "total_loss"), flush=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"done: {cfg.SOLVER.MAX_ITER} iterations, {cfg.SOLVER.MAX_ITER * args.batch / dt:.1f} images/s including host-side batch packing "
