@@ -119,7 +119,7 @@ int omni_preprocess(const unsigned char* img, float* out, int N, int H, int W, i
  * `logits.sort(descending=True)[:k]` of detectron2 find_top_rpn_proposals (RPN configured at
  * configs/Base.yaml:49-54) and for torch.multinomial (== top-k of w / Exp(1)) at
  * cubercnn/modeling/proposal_generator/rpn.py:318,322.  Element (r,i) = keys[r*pitch + i*estride].
- * out_val / out_idx: (rows, k); slots >= min(k,n) hold -inf / -1.  k <= 2048. */
+ * out_val / out_idx: (rows, k); slots >= min(k,n) hold -inf / -1.  k <= 8192. */
 int omni_topk_rows(const float* keys, int rows, int n, long long pitch, int estride, int k, float* out_val,
                    int* out_idx, void* stream);
 /* The same for `nseg` (<= 8) column segments of every row in one launch: the per-FPN-level pre-NMS top-k of
@@ -232,6 +232,24 @@ int omni_cube_decode(const float* head, int ldh, int F, int K, const float* boxe
                      float* pose, float* verts, void* stream);
 /* util.get_cuboid_verts_faces (cubercnn/util/math_util.py:116-219): box3d (n,6), R (n,9) -> (n,24). */
 int omni_cuboid_corners(const float* box3d, const float* R, int n, float* verts, void* stream);
+
+/* ---------------------------------------------------------------- batched inference
+ * fast_rcnn_inference / fast_rcnn_inference_single_image (cubercnn/modeling/roi_heads/fast_rcnn.py:33-116) for all images
+ * of a batch with fixed shapes.  pred (B*P, ld) = [K+1 logits | 4K deltas]; rois (B*P,4); count (B); image_hw (B,2).
+ *  omni_det_scores: probs (B*P,K) softmax, boxes (B*P,K,4) decoded (Box2BoxTransform weights wx..wh) and clipped,
+ *    scores (B, P*K) = prob where the row is valid (finite, p < count) and prob > score_thresh, else -inf;
+ *  [omni_topk_rows over scores -> vals / idx (B, cap), stable descending]
+ *  omni_det_nms_boxes: candidate boxes + class * (max coordinate + 1) (detectron2 batched_nms) -> nms_boxes (B,cap,4), valid;
+ *  [omni_nms_sorted -> keep (B, cap)]
+ *  omni_det_compact: the first topk kept candidates per image -> out_box (B,topk,4), out_score, out_cls, out_roi, out_count. */
+int omni_det_scores(const float* pred, int ld, const float* rois, const int* count, const int* image_hw, int B, int P, int K,
+                    float wx, float wy, float ww, float wh, float score_thresh, float* scores, float* probs, float* boxes,
+                    void* stream);
+int omni_det_nms_boxes(const float* boxes, const float* vals, const int* idx, int B, int PK, int K, int cap, float* nms_boxes,
+                       int* valid, void* stream);
+int omni_det_compact(const int* keep, const int* valid, const float* vals, const int* idx, const float* boxes, int B, int PK,
+                     int K, int cap, int topk, float* out_box, float* out_score, int* out_cls, int* out_roi, int* out_count,
+                     void* stream);
 
 /* ------------------------------------------------------------------ input pipeline
  * detectron2 T.ResizeShortestEdge -> ResizeTransform.apply_image = PIL Image.resize(BILINEAR) on the uint8 image, and

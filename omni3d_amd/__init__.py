@@ -30,6 +30,9 @@ def install():
         "detectron2.structures": pkg + ".d2.structures", "detectron2.solver": pkg + ".d2.solver",
         "detectron2.utils.events": pkg + ".d2.events", "detectron2.utils.comm": pkg + ".d2.comm",
         "detectron2.utils.registry": pkg + ".d2.registry", "detectron2.modeling": pkg + ".cubercnn.modeling.registries",
+        # the names tools/train_net.py itself imports (:11-23)
+        "detectron2.checkpoint": pkg + ".d2.checkpoint", "detectron2.data": pkg + ".d2.data", "detectron2.engine": pkg + ".d2.engine",
+        "detectron2.utils.logger": pkg + ".d2.logger",
     }
     sys.meta_path.insert(0, _AliasFinder(pkg, table))
     for ns in ("detectron2", "detectron2.utils"):

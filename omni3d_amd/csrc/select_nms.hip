@@ -9,7 +9,7 @@
 // Top-k: one 1024-thread workgroup per row.  Keys become order-preserving 64-bit integers
 // (float bits, then ~index so that equal scores resolve to the LOWER index = a stable descending
 // sort); an 8-pass MSB-first radix select finds the k-th largest key exactly, survivors are
-// compacted into LDS and bitonic-sorted there.  k <= 2048.
+// compacted into LDS and bitonic-sorted there.  k <= 8192.
 //
 // NMS: boxes arrive sorted by descending score.  A 64x64-bit suppression matrix tile per
 // workgroup (strict IoU > thr, areas (x2-x1)*(y2-y1), no +1), then one wave per problem walks the
@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int TOPK_THREADS = 1024;
-constexpr int TOPK_MAXK = 2048;
+constexpr int TOPK_MAXK = 8192;      // 64 KB of LDS keys; the batched-inference candidate sort uses the full size
 
 __device__ __forceinline__ unsigned long long make_key(float f, int idx) {
     unsigned u = __float_as_uint(f);

@@ -7,6 +7,7 @@ per step, drawn by a seeded shuffling sampler sharded over ranks (detectron2 Tra
 import itertools
 
 import numpy as np
+import torch
 
 from ...d2 import comm
 from ...d2.data import DatasetCatalog
@@ -26,17 +27,47 @@ def get_detection_dataset_dicts(names, filter_empty=True, **kwargs):
     return dicts
 
 
+def repeat_factors_from_category_frequency(dataset_dicts, repeat_thresh):
+    """build.py:127-172 (LVIS repeat-factor sampling): r(I) = max_{c in I} max(1, sqrt(t / f(c)))"""
+    import math
+    from collections import defaultdict
+    freq = defaultdict(int)
+    for d in dataset_dicts:
+        for c in {a["category_id"] for a in d["annotations"]}:
+            if c >= 0:
+                freq[c] += 1
+    n = len(dataset_dicts)
+    rep = {c: max(1.0, math.sqrt(repeat_thresh / (v / n))) for c, v in freq.items()}
+    out = [max({rep[c] for c in {a["category_id"] for a in d["annotations"]} if c >= 0}, default=1.0) for d in dataset_dicts]
+    return torch.tensor(out, dtype=torch.float32)
+
+
 class _TrainLoader:
-    def __init__(self, dataset, mapper, batch, seed=0):
+    """endless batches; index stream = detectron2 TrainingSampler (shuffled epochs) or RepeatFactorTrainingSampler (each epoch
+    repeats image i floor(r_i) times plus once more with probability frac(r_i), then shuffles), one shared seeded stream
+    sharded over ranks by position"""
+
+    def __init__(self, dataset, mapper, batch, seed=0, repeat_factors=None):
         self.dataset, self.mapper, self.batch = dataset, mapper, batch
         self.seed, self.rank, self.world = seed, comm.get_rank(), comm.get_world_size()
+        self.repeat_factors = repeat_factors
+
+    def _epoch(self, g):
+        if self.repeat_factors is None:
+            return torch.randperm(len(self.dataset), generator=g).tolist()
+        ip, fp = torch.trunc(self.repeat_factors), self.repeat_factors - torch.trunc(self.repeat_factors)
+        reps = ip + (torch.rand(len(fp), generator=g) < fp).float()
+        idx = torch.repeat_interleave(torch.arange(len(reps)), reps.long())
+        return idx[torch.randperm(len(idx), generator=g)].tolist()
 
     def __iter__(self):
-        rs = np.random.RandomState(self.seed)
+        g = torch.Generator()
+        g.manual_seed(self.seed)
+
         def stream():
             while True:
-                yield from rs.permutation(len(self.dataset)).tolist()
-        mine = itertools.islice(stream(), self.rank, None, self.world)          # TrainingSampler: one shared permutation stream
+                yield from self._epoch(g)
+        mine = itertools.islice(stream(), self.rank, None, self.world)
         while True:
             yield [self.mapper(self.dataset[i]) for i in itertools.islice(mine, self.batch)]
 
@@ -48,12 +79,20 @@ def build_detection_train_loader(cfg, mapper=None, *, dataset=None, sampler=None
     if mapper is None:
         from .dataset_mapper import DatasetMapper3D
         mapper = DatasetMapper3D(cfg, True)
-    if cfg.DATALOADER.SAMPLER_TRAIN != "TrainingSampler" or getattr(cfg.DATALOADER, "BALANCE_DATASETS", False):
-        raise NotImplementedError("MI355X hot path: TrainingSampler without dataset balancing (host-side sampling variants are out of scope)")
+    name = cfg.DATALOADER.SAMPLER_TRAIN
+    if getattr(cfg.DATALOADER, "BALANCE_DATASETS", False):
+        raise NotImplementedError("DATALOADER.BALANCE_DATASETS (per-source re-weighting, build.py:66-91) is host-side sampling, not built")
+    if name == "TrainingSampler":
+        rf = None
+    elif name == "RepeatFactorTrainingSampler":
+        rf = repeat_factors_from_category_frequency(dataset, cfg.DATALOADER.REPEAT_THRESHOLD)
+    else:
+        raise ValueError("Unknown training sampler: {}".format(name))
     total = cfg.SOLVER.IMS_PER_BATCH if total_batch_size is None else total_batch_size
     world = comm.get_world_size()
     assert total > 0 and total % world == 0, "Total batch size ({}) must be divisible by the number of gpus ({}).".format(total, world)
-    return _TrainLoader(dataset, mapper, total // world, seed=int(getattr(cfg, "SEED", 0) if getattr(cfg, "SEED", -1) >= 0 else 0))
+    return _TrainLoader(dataset, mapper, total // world, seed=int(getattr(cfg, "SEED", 0) if getattr(cfg, "SEED", -1) >= 0 else 0),
+                        repeat_factors=rf)
 
 
 class _TestLoader(list):

@@ -257,3 +257,40 @@ def sgd_step(param, grad, buf, lr, momentum=0.9, dampening=0.0, weight_decay=0.0
 def nonfinite_any(grad, flag):
     L = _dev(grad, flag)
     L.call("omni_nonfinite_any", _lib.ptr(grad), grad.numel(), _lib.ptr(flag), _lib.stream_of(grad))
+
+
+# ---- batched inference (csrc/infer.hip) ---------------------------------------------------------------------------------
+DET_MAX_CANDIDATES = 8192      # candidates per image that enter NMS (the top-k / NMS kernels' capacity).  The reference has no cap;
+                               # with trained weights a few hundred (roi, class) pairs pass SCORE_THRESH_TEST
+
+
+def det_scores(pred, rois, count, image_hw, B, P, K, weights, score_thresh):
+    L = _dev(pred, rois, count, image_hw)
+    scores = _empty((B, P * K), torch.float32, pred)
+    probs = _empty((B * P, K), torch.float32, pred)
+    boxes = _empty((B * P * K, 4), torch.float32, pred)
+    wx, wy, ww, wh = [float(v) for v in weights]
+    L.call("omni_det_scores", _lib.ptr(pred), pred.shape[1], _lib.ptr(rois), _lib.ptr(count), _lib.ptr(image_hw), B, P, K, wx, wy, ww, wh,
+           float(score_thresh), _lib.ptr(scores), _lib.ptr(probs), _lib.ptr(boxes), _lib.stream_of(pred))
+    return scores, probs, boxes
+
+
+def det_nms_boxes(boxes, vals, idx, B, PK, K, cap):
+    L = _dev(boxes, vals, idx)
+    out = _empty((B, cap, 4), torch.float32, boxes)
+    valid = _empty((B, cap), torch.int32, boxes)
+    L.call("omni_det_nms_boxes", _lib.ptr(boxes), _lib.ptr(vals), _lib.ptr(idx), B, PK, K, cap, _lib.ptr(out), _lib.ptr(valid),
+           _lib.stream_of(boxes))
+    return out, valid
+
+
+def det_compact(keep, valid, vals, idx, boxes, B, PK, K, cap, topk):
+    L = _dev(keep, valid, vals, idx, boxes)
+    obox = _empty((B, topk, 4), torch.float32, boxes)
+    oscore = _empty((B, topk), torch.float32, boxes)
+    ocls = _empty((B, topk), torch.int32, boxes)
+    oroi = _empty((B, topk), torch.int32, boxes)
+    ocount = _empty((B,), torch.int32, boxes)
+    L.call("omni_det_compact", _lib.ptr(keep), _lib.ptr(valid), _lib.ptr(vals), _lib.ptr(idx), _lib.ptr(boxes), B, PK, K, cap, topk,
+           _lib.ptr(obox), _lib.ptr(oscore), _lib.ptr(ocls), _lib.ptr(oroi), _lib.ptr(ocount), _lib.stream_of(boxes))
+    return obox, oscore, ocls, oroi, ocount

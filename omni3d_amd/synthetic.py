@@ -82,3 +82,34 @@ def make_batch(num_images=2, height=512, width=512, num_gt=8, num_classes=50, se
         batch.append({"image": image, "height": height, "width": width, "K": K, "image_id": seed * 1000 + i,
                       "dataset_id": 0, "instances": inst})
     return batch
+
+
+def make_dataset_dicts(num_images=8, height=96, width=128, num_gt=4, num_classes=50, seed=0, priors=None):
+    """The same synthetic scenes as `make_batch`, in the DATASET-dict schema the reference's loader feeds to DatasetMapper3D
+    (cubercnn/data/datasets.py:230-330): file-level fields + `annotations` with bbox (XYXY_ABS), category_id, center_cam,
+    dimensions, pose / R_cam, bbox3D_cam (8 corners), ignore, iscrowd.  Pixels travel in memory (`image_array`, HWC BGR)."""
+    from .d2.structures import BoxMode
+    out = []
+    for i, b in enumerate(make_batch(num_images, height, width, num_gt, num_classes, seed, priors)):
+        inst = b["instances"]
+        annos = []
+        for j in range(len(inst)):
+            c = int(inst.gt_classes[j])
+            g = inst.gt_boxes3D[j].tolist()
+            R = inst.gt_poses[j].numpy().astype(np.float64)
+            annos.append({"bbox": inst.gt_boxes.tensor[j].tolist(), "bbox_mode": BoxMode.XYXY_ABS, "category_id": max(c, 0),
+                          "center_cam": g[6:9], "dimensions": g[3:6], "pose": R.tolist(), "R_cam": R.tolist(),
+                          "bbox3D_cam": _cuboid_corners(g[6:9], g[3:6], R).tolist(), "ignore": c < 0, "iscrowd": 0,
+                          "category_name": f"class{max(c, 0)}"})
+        out.append({"image_array": np.ascontiguousarray(b["image"].numpy().transpose(1, 2, 0)), "height": height, "width": width,
+                    "K": b["K"], "image_id": b["image_id"], "dataset_id": 0, "annotations": annos, "file_name": f"synthetic://{seed}/{i}"})
+    return out
+
+
+def register_synthetic_dataset(name, **kw):
+    from .d2.data import DatasetCatalog
+    dicts = make_dataset_dicts(**kw)
+    if name in DatasetCatalog:
+        DatasetCatalog.remove(name)
+    DatasetCatalog.register(name, lambda: dicts)
+    return dicts

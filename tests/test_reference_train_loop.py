@@ -1,0 +1,70 @@
+""""tools/train_net.py drops in unchanged" -- the REFERENCE's own `do_train` (tools/train_net.py:117-316,
+loaded from /root/reference as a file, not restated) drives this package's model / optimizer / scheduler / checkpointer /
+mapper / loader through `omni3d_amd.install()`.  Only runnable where the reference checkout exists (the build container);
+the kernels run under the host emulator there, so the model is the tiny 64x64 configuration and the test is slow-gated.
+(`.cuda()` is hard-coded in the script at :237,:263; the emulated run maps it to a no-op.)"""
+import importlib.util
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+REF = "/root/reference/tools/train_net.py"
+
+
+def _load_reference_script():
+    import omni3d_amd
+    omni3d_amd.install()
+    spec = importlib.util.spec_from_file_location("reference_train_net", REF)
+    mod = importlib.util.module_from_spec(spec)
+    cwd = os.getcwd()
+    try:
+        spec.loader.exec_module(mod)          # executes the reference file's own imports against this package
+    finally:
+        os.chdir(cwd)
+    return mod
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="needs the reference checkout (build container only)")
+def test_reference_train_net_imports_resolve():
+    mod = _load_reference_script()
+    for name in ("do_train", "do_test", "setup", "main", "allreduce_dict"):
+        assert hasattr(mod, name)
+    import omni3d_amd.cubercnn.solver as S
+    assert mod.build_optimizer is S.build_optimizer            # the script's names ARE this package's objects
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="needs the reference checkout (build container only)")
+@pytest.mark.skipif(os.environ.get("OMNI_SLOW") != "1", reason="several minutes under the host emulator; set OMNI_SLOW=1")
+def test_reference_do_train_runs_on_the_product(emu_lib, tmp_path, monkeypatch):
+    mod = _load_reference_script()
+    from omni3d_amd import synthetic
+    from omni3d_amd.cubercnn.config import get_cfg_defaults
+    from omni3d_amd.d2.config import get_cfg
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    priors = synthetic.make_priors(50)
+    synthetic.register_synthetic_dataset("synthetic_train", num_images=4, height=64, width=64, num_gt=3, seed=7, priors=priors)
+    cfg = get_cfg()
+    get_cfg_defaults(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "cubercnn_DLA34_FPN.yaml"))
+    iters = int(os.environ.get("OMNI_DO_TRAIN_ITERS", "2"))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "VIS_PERIOD", 0, "MODEL.WEIGHTS", "synthetic://random-init", "MODEL.WEIGHTS_PRETRAIN", "", "OUTPUT_DIR", str(tmp_path),
+                         "DATASETS.TRAIN", ("synthetic_train",), "SOLVER.IMS_PER_BATCH", 1, "SOLVER.MAX_ITER", iters, "SOLVER.BASE_LR", 0.001,
+                         "SOLVER.STEPS", (), "SOLVER.WARMUP_ITERS", 1, "SOLVER.CHECKPOINT_PERIOD", 1, "TEST.EVAL_PERIOD", 0,
+                         "INPUT.MIN_SIZE_TRAIN", (64,), "INPUT.MAX_SIZE_TRAIN", 64, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 16,
+                         "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 16, "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 100, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 30])
+    torch.manual_seed(0)
+    model = mod.build_model(cfg, priors=priors)
+    before = {k: v.clone() for k, v in model.state_dict().items() if "fc2.weight" in k}
+    ok = mod.do_train(cfg, model, dataset_id_to_unknown_cats={0: set()}, dataset_id_to_src={0: "synthetic"}, resume=False)
+    assert ok is True                                                           # ran to max_iter without a restart request
+    after = model.state_dict()
+    assert any(float((after[k] - v).abs().max()) > 0 for k, v in before.items())         # the optimizer stepped
+    files = sorted(os.listdir(tmp_path))
+    assert "model_final.pth" in files and "model_recent.pth" in files and "last_checkpoint" in files       # PeriodicCheckpointerOnlyOne
+    ck = torch.load(os.path.join(tmp_path, "model_final.pth"), weights_only=False)
+    assert {"model", "optimizer", "scheduler", "iteration"} <= set(ck) and ck["iteration"] == iters - 1
+    assert all("momentum_buffer" in s for s in ck["optimizer"]["state"].values())                        # torch-SGD format
