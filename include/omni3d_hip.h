@@ -233,6 +233,18 @@ int omni_cube_decode(const float* head, int ldh, int F, int K, const float* boxe
 /* util.get_cuboid_verts_faces (cubercnn/util/math_util.py:116-219): box3d (n,6), R (n,9) -> (n,24). */
 int omni_cuboid_corners(const float* box3d, const float* R, int n, float* verts, void* stream);
 
+/* ---------------------------------------------------------------- GEMM engine (csrc/gemm_engine.hip)
+ * The cuBLAS calls behind nn.Linear (detectron2 FastRCNNConvFCHead; cubercnn/modeling/roi_heads/cube_head.py:70,108-163),
+ * behind 1x1 nn.Conv2d (FPN laterals, DLA roots / projections, cubercnn/modeling/backbone/dla.py:159-161,214) and the point
+ * GEMMs of the Winograd path, forward / data gradient / weight gradient:
+ *   form 0 "NT": C = A (M x K) * B (N x K)^T     form 1 "NN": C = A (M x K) * B (K x N)     form 2 "TN": C = A (K x M)^T * B (K x N)
+ * batch problems at element strides stride_a/b/c; pitches lda/ldb/ldc; splits > 1 or accumulate != 0 => fp32 atomics into C
+ * (zeroed by the caller unless accumulating); bias (N) / ReLU on the direct-store path.  tile: 1 = 256x128, 2 = 128x128.
+ * workgroups: persistent workgroups walking the (problem, tile, split) list (0 = one per CU). */
+int omni_gemm_engine(const float* A, const float* B, float* C, const float* bias, int form, int batch, int M, int N, int K,
+                     int lda, int ldb, int ldc, long long stride_a, long long stride_b, long long stride_c, int splits,
+                     int relu, int accumulate, int tile, int workgroups, void* stream);
+
 /* ---------------------------------------------------------------- batched inference
  * fast_rcnn_inference / fast_rcnn_inference_single_image (cubercnn/modeling/roi_heads/fast_rcnn.py:33-116) for all images
  * of a batch with fixed shapes.  pred (B*P, ld) = [K+1 logits | 4K deltas]; rois (B*P,4); count (B); image_hw (B,2).

@@ -77,3 +77,24 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
 __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// ---- LDS-DMA / scheduling primitives used by csrc/gemm_engine.hip --------------------------------------------------------
+// buffer resource over [p, p + bytes): loads through it return 0 for offsets outside the range (no branches for tile tails)
+typedef __amdgpu_buffer_rsrc_t omni_rsrc_t;
+__device__ __forceinline__ omni_rsrc_t omni_make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// `buffer_load_dwordx4 ... lds`: every lane moves 16 bytes from base + voffset + soffset (bytes) straight into LDS at
+// lds_wave_base + lane * 16 (wave-uniform base, lane-linear destination: 1 KiB per wave instruction); no VGPR round trip
+#define OMNI_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
+__device__ __forceinline__ void omni_dma16(omni_rsrc_t r, float* lds_wave_base, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, OMNI_LDSP(lds_wave_base), 16, voffset, soffset, 0, 0);
+}
+#define OMNI_OOB ((int)0x80000000)            /* voffset that is out of range for every resource (tensors are < 2 GiB) */
+#define OMNI_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+__device__ __forceinline__ void omni_barrier() {          // s_barrier WITHOUT the vmcnt(0) drain __syncthreads() implies
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#define OMNI_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)      /* 0x8 MFMA, 0x20 VMEM read, 0x100 DS read */
+#define OMNI_SETPRIO(n) __builtin_amdgcn_s_setprio(n)

@@ -1,0 +1,336 @@
+// gemm_engine.hip -- the fp32-MFMA GEMM main loop of round 2: LDS-DMA ring, fragment prefetch carried across barriers
+// and work items, 256x128 / 128x128 tiles, persistent workgroups.
+//
+// Serves the GEMM-shaped launches of the Cube R-CNN step (the reference reaches them as cuBLAS / cuDNN calls through
+// nn.Linear / nn.Conv2d): FC layers of the box and cube heads (detectron2 FastRCNNConvFCHead; cube_head.py:70,108-163),
+// 1x1 convolutions (FPN laterals, DLA roots / projections, dla.py:159-161,214), and the batched GEMMs of the Winograd path
+// (csrc/winograd.hip) -- forward  C = A * B^T ("NT"), data gradient  C = A * B ("NN"), weight gradient  C = A^T * B ("TN").
+//
+// What changed against the round-1 tile engine (csrc/conv_gemm.hip), each measured in tools/exp/gemm_exp.hip:
+//   * operands go global -> LDS by `buffer_load_dwordx4 ... lds` (1 KiB per wave instruction, no VGPR staging, no
+//     ds_write pass); tile tails come back as zeros from the buffer resource's range check, so the slab body has NO
+//     branches and is one basic block the scheduler can interleave;
+//   * unpadded 128-byte LDS rows with the 16-byte chunks XOR-swizzled by (row & 7) on the SOURCE address (the DMA
+//     destination is lane-linear), fragments still one ds_read_b128 per operand row;
+//   * three LDS stages, each its own __shared__ object (hipcc then proves a fragment read of one stage cannot alias the
+//     DMA in flight into another and does not drain vmcnt before it), ONE barrier per 32-deep slab; at barrier t the
+//     slab t+1 has already landed, so its first fragments are fetched under the last MFMAs of slab t and the MFMA stream
+//     never waits for LDS after a barrier; the ring keeps running ACROSS work items of a persistent workgroup;
+//   * DMA issues and fragment reads are pinned between pairs of MFMAs (sched_group_barrier) instead of being issued in
+//     a block (an LDS-DMA issue costs 60-180 cycles of the issuing wave; one wave per SIMD must hide it under an MFMA);
+//   * 256x128 tiles: 8 accumulators per wave halve the operand traffic per MFMA (power, not bandwidth, is what keeps
+//     random-data fp32 MFMA kernels below the 157 TFLOP/s peak).
+//   Measured (tools/exp, MI355X): [65536x256x2304] 115 -> 133 TFLOP/s, fc1-like 4x[2048x1024x3136] 115 -> 129.
+#include <device_rt.h>
+
+namespace {
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;      // nullable, length N (added by split 0 only)
+    int batch, M, N, K;
+    int lda, ldb, ldc;      // KC operand: floats between consecutive rows; MC operand: floats between consecutive k
+    long sa, sb, sc;        // batch strides (floats)
+    int splits;             // reduction splits; > 1 or accumulate: atomic epilogue
+    int relu, accumulate;
+    int tiles_m, tiles_n, items;
+};
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return mfma_32x32x2(a, b, c); }
+
+// Compile-time description of one k-chunk's issue order for the scheduler: SLOTS pairs of MFMAs, after each pair either one
+// DMA piece (slots 2, 5, 8, ... until the ND pieces of the chunk are placed) or the next few of the NR fragment reads.
+template <int U, int SLOTS, int NR, int ND>
+__device__ __forceinline__ void sched_pin() {
+    if constexpr (U < SLOTS) {
+        OMNI_SCHED_GROUP(0x008, 2);
+        constexpr bool dma = (U % 3 == 2) && (U / 3 < ND);
+        if constexpr (dma) {
+            OMNI_SCHED_GROUP(0x020, 1);
+        } else {
+            constexpr int dma_before = (U / 3 < ND) ? U / 3 : ND;
+            constexpr int RPS = (NR + (SLOTS - ND) - 1) / (SLOTS - ND);
+            constexpr int left = NR - RPS * (U - dma_before);
+            constexpr int n = left <= 0 ? 0 : (left < RPS ? left : RPS);
+            if constexpr (n > 0) OMNI_SCHED_GROUP(0x100, n);
+        }
+        sched_pin<U + 1, SLOTS, NR, ND>();
+    }
+}
+
+// LA / LB: 0 = "KC" operand stored [rows][K] (k contiguous), 1 = "MC" operand stored [K][rows] (rows contiguous).
+//   NT (forward):         A KC (M x K),  B KC (N x K)
+//   NN (data gradient):   A KC (M x K),  B MC (K x N)
+//   TN (weight gradient): A MC (K x M),  B MC (K x N)
+template <int LA, int LB, int BM, int BN>
+__global__ void __launch_bounds__(256) gemm_engine_kernel(GemmArgs p) {
+    constexpr int BK = 32, STAGE = (BM + BN) * BK, WM = BM / 64, WN = BN / 64, PA = BM / 32, PB = BN / 32, NP = PA + PB;
+    static_assert(NP % 4 == 0, "pieces are spread over the four k-chunks of a slab");
+    __shared__ __attribute__((aligned(1024))) float st0[STAGE];
+    __shared__ __attribute__((aligned(1024))) float st1[STAGE];
+    __shared__ __attribute__((aligned(1024))) float st2[STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    // ---- work list: contiguous chunk of items per XCD (blocks round-robin over the 8 XCDs), strided inside it
+    const int per_xcd = (p.items + 7) / 8;
+    const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, stride = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int end = min((xcd + 1) * per_xcd, p.items);
+    const int first = xcd * per_xcd + local;
+    if (first >= end) return;
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int sps = (nk_total + p.splits - 1) / p.splits;                      // slabs per split
+    const bool ktail = (p.K % BK) != 0 || LA == 1 || LB == 1;                  // MC rows are checked against K slab by slab
+
+    // ---- issue cursor: the item / slab the NEXT DMA pieces belong to
+    int i_item = first, i_kt = 0, i_nk = 0, i_k0 = 0;
+    omni_rsrc_t ra, rb;
+    int voa[PA], vob[PB];
+    auto decode = [&](int item, int& b, int& tm, int& tn, int& split) {
+        int r = item;
+        tn = r % p.tiles_n; r /= p.tiles_n;
+        tm = r % p.tiles_m; r /= p.tiles_m;
+        b = r % p.batch;
+        split = r / p.batch;
+    };
+    auto setup_issue = [&](int item) {
+        int b, tm, tn, split;
+        decode(item, b, tm, tn, split);
+        i_k0 = split * sps;
+        i_nk = min(sps, nk_total - i_k0);
+        i_kt = 0;
+        const int m0 = tm * BM, n0 = tn * BN;
+        ra = omni_make_rsrc(p.A + (long)b * p.sa, (unsigned)((LA == 0 ? (long)p.M * p.lda : (long)p.K * p.lda) * 4));
+        rb = omni_make_rsrc(p.B + (long)b * p.sb, (unsigned)((LB == 0 ? (long)p.N * p.ldb : (long)p.K * p.ldb) * 4));
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int piece = wave * PA + i;
+            if (LA == 0) {                      // 8 rows x 128 B; lane -> (row, swizzled 16-byte chunk)
+                const int dr = lane >> 3, row = m0 + piece * 8 + dr, ch = (lane & 7) ^ dr;
+                voa[i] = row < p.M ? (row * p.lda + ch * 4) * 4 : OMNI_OOB;
+            } else {                            // 256 consecutive floats of the [32][BM] tile
+                constexpr int RPP = 256 / BM, LPR = BM / 4;
+                const int kk = piece * RPP + lane / LPR, col = m0 + (lane % LPR) * 4;
+                voa[i] = col < p.M ? (kk * p.lda + col) * 4 : OMNI_OOB;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int piece = wave * PB + i;
+            if (LB == 0) {
+                const int dr = lane >> 3, row = n0 + piece * 8 + dr, ch = (lane & 7) ^ dr;
+                vob[i] = row < p.N ? (row * p.ldb + ch * 4) * 4 : OMNI_OOB;
+            } else {
+                constexpr int RPP = 256 / BN, LPR = BN / 4;
+                const int kk = piece * RPP + lane / LPR, col = n0 + (lane % LPR) * 4;
+                vob[i] = col < p.N ? (kk * p.ldb + col) * 4 : OMNI_OOB;
+            }
+        }
+    };
+    // k index (inside the slab) this lane's piece q covers, for the K-tail check
+    auto piece_k = [&](int q) -> int {
+        if (q < PA) {
+            if (LA == 0) return ((lane & 7) ^ (lane >> 3)) * 4;
+            return (wave * PA + q) * (256 / BM) + lane / (BM / 4);
+        }
+        if (LB == 0) return ((lane & 7) ^ (lane >> 3)) * 4;
+        return (wave * PB + (q - PA)) * (256 / BN) + lane / (BN / 4);
+    };
+    bool i_live = true;                        // false once every slab of every item has been issued
+    auto piece = [&](float* st, int q) {       // q in [0, NP): PA pieces of A then PB pieces of B, of slab (i_item, i_kt)
+        const int kbase = (i_k0 + i_kt) * BK;
+        int vo = q < PA ? voa[q < PA ? q : 0] : vob[q < PA ? 0 : q - PA];
+        if (ktail && kbase + piece_k(q) >= p.K) vo = OMNI_OOB;
+        if (!i_live) vo = OMNI_OOB;            // past the end: still issued (zeros into a stage nobody reads), no branch
+        float* dst = q < PA ? st + (wave * PA + q) * 256 : st + BM * BK + (wave * PB + (q - PA)) * 256;
+        const int so = q < PA ? (LA == 0 ? kbase * 4 : kbase * p.lda * 4) : (LB == 0 ? kbase * 4 : kbase * p.ldb * 4);
+        omni_dma16(q < PA ? ra : rb, dst, vo, so);
+    };
+    auto advance_issue = [&]() {               // after the NP pieces of one slab
+        if (++i_kt == i_nk) {
+            if (i_item + stride < end) { i_item += stride; setup_issue(i_item); }
+            else i_live = false;
+        }
+    };
+
+    // ---- fragment addressing
+    int fa[WM], fb[WN], sw[4];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) fa[i] = LA == 0 ? (wm * (BM / 2) + 32 * i + l31) * BK : wm * (BM / 2) + 32 * i + l31;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) fb[j] = BM * BK + (LB == 0 ? (wn * (BN / 2) + 32 * j + l31) * BK : wn * (BN / 2) + 32 * j + l31);
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) sw[kc] = (((2 * kc + h) ^ (l31 & 7)) << 2);
+    float a[2][WM][4], bf[2][WN][4];
+    auto ldfrag = [&](const float* S, int buf, int kc) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            if (LA == 0) {
+                const float4 v = *reinterpret_cast<const float4*>(S + fa[i] + sw[kc]);
+                a[buf][i][0] = v.x; a[buf][i][1] = v.y; a[buf][i][2] = v.z; a[buf][i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[buf][i][t] = S[(8 * kc + 4 * h + t) * BM + fa[i]];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            if (LB == 0) {
+                const float4 v = *reinterpret_cast<const float4*>(S + fb[j] + sw[kc]);
+                bf[buf][j][0] = v.x; bf[buf][j][1] = v.y; bf[buf][j][2] = v.z; bf[buf][j][3] = v.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bf[buf][j][t] = S[(8 * kc + 4 * h + t) * BN + fb[j]];
+            }
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- compute cursor
+    int c_item = first, c_kt = 0, c_nk;
+    {
+        int b, tm, tn, split;
+        decode(c_item, b, tm, tn, split);
+        c_nk = min(sps, nk_total - split * sps);
+    }
+    auto epilogue = [&]() {
+        int b, tm, tn, split;
+        decode(c_item, b, tm, tn, split);
+        const int m0 = tm * BM, n0 = tn * BN;
+        float* o = p.C + (long)b * p.sc;
+        const bool atomic = p.splits > 1 || p.accumulate;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+                const float bv = (p.bias != nullptr && n < p.N && split == 0) ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+                    if (m < p.M && n < p.N) {
+                        float v = acc[i][j][rr] + bv;
+                        if (atomic) atomicAdd(o + (long)m * p.ldc + n, v);
+                        else o[(long)m * p.ldc + n] = p.relu ? fmaxf(v, 0.f) : v;
+                    }
+                    acc[i][j][rr] = 0.f;
+                }
+            }
+    };
+
+    // ---- prologue: two slabs in flight, first fragments in registers
+    setup_issue(first);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) piece(st0, q);
+    advance_issue();
+#pragma unroll
+    for (int q = 0; q < NP; ++q) piece(st1, q);
+    advance_issue();
+    if (NP == 8) OMNI_WAIT_VMCNT(8); else OMNI_WAIT_VMCNT(12);
+    omni_barrier();
+    ldfrag(st0, 0, 0);
+
+    bool done = false;
+    auto step = [&](const float* rd, const float* nx, float* wr) {
+        OMNI_WAIT_VMCNT(0);                    // this wave's pieces of the NEXT slab (issued a whole slab ago)
+        omni_barrier();                        // => the next slab has landed everywhere; nobody still reads `wr`
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int cur = kc & 1;
+            if (kc < 3) ldfrag(rd, cur ^ 1, kc + 1);
+            else ldfrag(nx, cur ^ 1, 0);       // first fragments of the next slab (possibly of the next item)
+#pragma unroll
+            for (int q = 0; q < NP / 4; ++q) piece(wr, (NP / 4) * kc + q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = mfma(a[cur][i][t], bf[cur][j][t], acc[i][j]);
+            // pin the interleave: fragment reads and DMA pieces between pairs of MFMAs
+            sched_pin<0, WM * WN * 2 - 1, WM * (LA ? 4 : 1) + WN * (LB ? 4 : 1), NP / 4>();
+            OMNI_SCHED_GROUP(0x008, 2);
+        }
+        advance_issue();
+        if (++c_kt == c_nk) {                  // item finished: store, move the compute cursor
+            epilogue();
+            if (c_item + stride < end) {
+                c_item += stride;
+                c_kt = 0;
+                int b, tm, tn, split;
+                decode(c_item, b, tm, tn, split);
+                c_nk = min(sps, nk_total - split * sps);
+            } else {
+                done = true;
+            }
+        }
+    };
+    while (!done) {
+        step(st0, st1, st2);
+        if (done) break;
+        step(st1, st2, st0);
+        if (done) break;
+        step(st2, st0, st1);
+    }
+    OMNI_WAIT_VMCNT(0);                        // the out-of-range pieces issued past the end
+}
+
+template <int LA, int LB, int BM, int BN>
+int launch_engine(GemmArgs p, int workgroups, hipStream_t st) {
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int nk_total = (p.K + 31) / 32;
+    if (p.splits < 1) p.splits = 1;
+    if (p.splits > nk_total) p.splits = nk_total;
+    const int sps = (nk_total + p.splits - 1) / p.splits;
+    p.splits = (nk_total + sps - 1) / sps;                                      // no empty split
+    const long items = (long)p.tiles_m * p.tiles_n * p.batch * p.splits;
+    if (items <= 0 || items > 0x7fffffff) return items == 0 ? OMNI_OK : OMNI_ERR_ARG;
+    p.items = (int)items;
+    long wg = workgroups > 0 ? workgroups : 256;                                // one workgroup per CU (96 / 144 KB of LDS)
+    if (wg > items) wg = items;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_engine_kernel<LA, LB, BM, BN>), dim3((unsigned)wg), dim3(256), 0, st, p);
+    return omni_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+// C[b] (M x N, row pitch ldc) (=, or += when accumulate / splits > 1) op(A[b]) * op(B[b]) (+ bias) (ReLU)
+//   form 0 "NT": A (M x K, pitch lda), B (N x K, pitch ldb)            forward of Linear / 1x1 conv / Winograd point GEMMs
+//   form 1 "NN": A (M x K, pitch lda), B (K x N, pitch ldb)            data gradient (B = weights [K_out][C_in])
+//   form 2 "TN": A (K x M, pitch lda), B (K x N, pitch ldb)            weight gradient (A = dy [pixels][K_out], B = x [pixels][C_in])
+// tile: 1 = 256x128, 2 = 128x128.  workgroups: persistent workgroups (0 = one per CU, never more than work items).
+// splits > 1 or accumulate != 0: fp32 atomics into C (the caller zeroes C when it is not accumulating); bias / ReLU are
+// applied only on the non-atomic path (bias also on split 0 of an atomic one).  All leading dimensions, M (MC operands), N
+// (MC operands) and K offsets in multiples of 4 floats; tensors < 2 GiB.
+int omni_gemm_engine(const float* A, const float* B, float* C, const float* bias, int form, int batch, int M, int N, int K,
+                     int lda, int ldb, int ldc, long long stride_a, long long stride_b, long long stride_c, int splits, int relu,
+                     int accumulate, int tile, int workgroups, void* stream) {
+    if (form < 0 || form > 2 || batch <= 0 || M < 0 || N < 0 || K <= 0 || (lda & 3) || (ldb & 3) || tile < 1 || tile > 2 || splits < 0 ||
+        workgroups < 0)
+        return OMNI_ERR_ARG;
+    if (form == 2 && ((M & 3) || (N & 3))) return OMNI_ERR_ARG;
+    if (form == 1 && (N & 3)) return OMNI_ERR_ARG;
+    if (form != 2 && (K & 3)) return OMNI_ERR_ARG;
+    if (M == 0 || N == 0) return OMNI_OK;
+    GemmArgs p{A, B, C, bias, batch, M, N, K, lda, ldb, ldc, (long)stride_a, (long)stride_b, (long)stride_c, splits ? splits : 1, relu, accumulate, 0, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+#define OMNI_ENGINE(LA_, LB_)                                                                                         \
+    return tile == 1 ? launch_engine<LA_, LB_, 256, 128>(p, workgroups, st) : launch_engine<LA_, LB_, 128, 128>(p, workgroups, st)
+    if (form == 0) { OMNI_ENGINE(0, 0); }
+    if (form == 1) { OMNI_ENGINE(0, 1); }
+    OMNI_ENGINE(1, 1);
+#undef OMNI_ENGINE
+}
+
+}  // extern "C"

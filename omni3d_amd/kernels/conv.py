@@ -72,11 +72,24 @@ def conv2d_wgrad(x, dy, ksize, stride=1, pad=0, accum_into=None, tile=0):
     return dw.permute(0, 3, 1, 2)
 
 
+def _engine_eligible(M, C, K):
+    """The round-2 GEMM engine (csrc/gemm_engine.hip) wins where one workgroup per CU gets a long reduction to stream: the
+    fc1-class layers (2048 x 12544 -> 1024: 124 vs 102 TFLOP/s forward, tools/bench_engine.py).  Everything shorter or narrower
+    stays on the 64x64 / 128x128 tile kernels, whose 2-4 workgroups per CU hide the per-tile prologue better."""
+    return M >= 1024 and C >= 4096 and K >= 512 and (C % 32) == 0
+
+
 def linear_fwd(x, w, bias=None, relu=False):
     """x (M, Cin), w (Cout, Cin) -> (M, Cout): the 1x1 / H=W=1 case of the same kernel."""
     M, C = x.shape
     K = w.shape[0]
     L = _lib.check_device(x, w, bias)
+    if _engine_eligible(M, C, K):
+        from . import gemm as _gemm
+        if relu:            # split reduction ends in atomics: bias rides on split 0, the ReLU needs the complete sum
+            out = _gemm.gemm(x, w, _gemm.NT, bias=bias, tile=2, splits=2)
+            return out.clamp_(min=0)
+        return _gemm.gemm(x, w, _gemm.NT, bias=bias, tile=2, splits=2)
     out = torch.empty((M, K), dtype=torch.float32, device=x.device)
     L.call("omni_conv2d_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), M, 1, 1, C, K, 1, 1, 1, 0, C, K,
            int(relu), _lib.stream_of(x))

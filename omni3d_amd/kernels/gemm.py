@@ -1,0 +1,43 @@
+"""Launcher of csrc/gemm_engine.hip (the round-2 fp32-MFMA GEMM main loop): NT / NN / TN, batched, split-K, persistent."""
+import torch
+
+from .. import lib as _lib
+
+NT, NN, TN = 0, 1, 2
+
+
+def gemm(A, B, form=NT, bias=None, relu=False, out=None, accumulate=False, splits=1, tile=1, workgroups=0):
+    """A, B: 2-D or 3-D (batched) contiguous fp32 tensors.
+       NT: A (b, M, K), B (b, N, K) -> (b, M, N)      NN: A (b, M, K), B (b, K, N)      TN: A (b, K, M), B (b, K, N) -> (b, M, N)
+    out: optional preallocated result (accumulate=True adds into it with fp32 atomics); splits > 1 zeroes `out` first unless
+    accumulating."""
+    squeeze = A.dim() == 2
+    A3, B3 = (A.unsqueeze(0), B.unsqueeze(0)) if squeeze else (A, B)
+    assert A3.is_contiguous() and B3.is_contiguous() and A3.shape[0] == B3.shape[0]
+    b = A3.shape[0]
+    if form == NT:
+        M, K = A3.shape[1:]
+        N = B3.shape[1]
+        assert B3.shape[2] == K
+        lda, ldb = K, K
+    elif form == NN:
+        M, K = A3.shape[1:]
+        N = B3.shape[2]
+        assert B3.shape[1] == K
+        lda, ldb = K, N
+    else:
+        K, M = A3.shape[1:]
+        N = B3.shape[2]
+        assert B3.shape[1] == K
+        lda, ldb = M, N
+    L = _lib.check_device(A3, B3, bias, out)
+    if out is None:
+        out3 = torch.empty((b, M, N), dtype=torch.float32, device=A.device)
+    else:
+        out3 = out.unsqueeze(0) if out.dim() == 2 else out
+        assert out3.is_contiguous() and tuple(out3.shape) == (b, M, N)
+    if splits > 1 and not accumulate:
+        out3.zero_()
+    L.call("omni_gemm_engine", _lib.ptr(A3), _lib.ptr(B3), _lib.ptr(out3), _lib.ptr(bias), form, b, M, N, K, lda, ldb, N,
+           A3.stride(0), B3.stride(0), M * N, splits, int(relu), int(accumulate), tile, workgroups, _lib.stream_of(A))
+    return out3[0] if squeeze else out3

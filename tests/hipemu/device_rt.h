@@ -212,3 +212,21 @@ static inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     hipemu::wave_sync();
     return d;
 }
+
+// ---- LDS-DMA / scheduling primitives of csrc/gemm_engine.hip, emulated synchronously -----------------------------------
+struct omni_rsrc_t { const char* base; unsigned bytes; };
+static inline omni_rsrc_t omni_make_rsrc(const void* p, unsigned bytes) { return {(const char*)p, bytes}; }
+#define OMNI_LDSP(p) (p)
+static inline void omni_dma16(omni_rsrc_t r, float* lds_wave_base, int voffset, int soffset) {
+    char* dst = (char*)lds_wave_base + 16 * hipemu::g.lane;
+    const unsigned vo = (unsigned)voffset;                       // range check on the vector offset, like a raw buffer
+    if ((unsigned long long)vo + 16ull <= (unsigned long long)r.bytes && (long long)vo + soffset + 16 <= (long long)r.bytes)
+        memcpy(dst, r.base + vo + soffset, 16);
+    else
+        memset(dst, 0, 16);
+}
+#define OMNI_OOB ((int)0x80000000)
+#define OMNI_WAIT_VMCNT(n) do { } while (0)
+static inline void omni_barrier() { hipemu::block_sync(); }
+#define OMNI_SCHED_GROUP(mask, n) do { } while (0)
+#define OMNI_SETPRIO(n) do { } while (0)
