@@ -220,10 +220,12 @@ int omni_box_loss_bwd(const float* pred, int ldp, int R, int K, const int* cls, 
                       const float* g_cls, const float* g_reg, float* dpred, void* stream);
 
 /* ROIHeads3D._forward_cube decode + disentangled losses (cubercnn/modeling/roi_heads/roi_heads.py:
- * 374-768) on the fused cube-head outputs head (F, ldh) = [xy 2K | z K | dims 3K | pose 6K | uncert K]. */
+ * 374-768) on the fused cube-head outputs head (F, ldh) = [xy 2K | z K | dims 3K | pose 6K | uncert K].
+ * w_*: MODEL.ROI_CUBE_HEAD.LOSS_W_{DIMS,POSE,XY,Z,JOINT}, used for the logged `Cube/total_3D_loss` (:651-695). */
 int omni_cube_loss_fwd(const float* head, int ldh, int F, int K, const float* boxes, const int* cls, const int* img,
                        const float* Ks, const float* v2r, const float* priors, const float* gt3d,
-                       const float* gtpose, const int* gt_row, float* vals, float* jac, float* red, void* stream);
+                       const float* gtpose, const int* gt_row, float w_dims, float w_pose, float w_xy, float w_z, float w_joint,
+                       float* vals, float* jac, float* red, void* stream);
 int omni_cube_loss_bwd(const float* vals, const float* jac, const float* red, const float* gk, const int* cls, int F,
                        int K, int ldh, float* dhead, void* stream);
 /* inference outputs (roi_heads.py:771-819): cube3d (F,9), pose (F,9), verts (F,24). */
@@ -232,6 +234,22 @@ int omni_cube_decode(const float* head, int ldh, int F, int K, const float* boxe
                      float* pose, float* verts, void* stream);
 /* util.get_cuboid_verts_faces (cubercnn/util/math_util.py:116-219): box3d (n,6), R (n,9) -> (n,24). */
 int omni_cuboid_corners(const float* box3d, const float* R, int n, float* verts, void* stream);
+
+/* ------------------------------------------- BatchNorm statistics from the producing kernel's epilogue
+ * The conv -> BatchNorm pairs of the bottom-up (cubercnn/modeling/backbone/dla.py:46-66,162-172,214,244; torchvision
+ * BasicBlock via resnet.py:17-27): the convolution / Winograd output transform / stem kernel also writes per-workgroup
+ * partial sums and sums of squares of its output, stats [rows][2][K] floats, so training-mode BatchNorm skips its own
+ * statistics pass (omni_bn_fwd_partials = finalize + apply).  *nblk_out = partial rows written; 0 means "not produced"
+ * (split reduction chosen, buffer too small, unsupported channel count) and the caller uses omni_bn_fwd. */
+int omni_conv2d_fwd_stats(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int S,
+                          int stride, int pad, int ldx, int ldo, float* stats, int stats_rows, int* nblk_out, void* stream);
+int omni_wino_out_stats(const float* M, float* y, int N, int H, int W, int K, int tile, float* stats, int stats_rows,
+                        int* nblk_out, void* stream);
+int omni_stem_conv_fwd_stats(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx,
+                             int ldo, float* stats, int stats_rows, int* nblk_out, void* stream);
+int omni_bn_fwd_partials(const float* x, const float* partial, int nblk, const float* gamma, const float* beta,
+                         const float* residual, float* y, float* running_mean, float* running_var, float* mean_rstd,
+                         float* scale_shift, int P, int C, float eps, float momentum, int relu, void* stream);
 
 /* ---------------------------------------------------------------- GEMM engine (csrc/gemm_engine.hip)
  * The cuBLAS calls behind nn.Linear (detectron2 FastRCNNConvFCHead; cubercnn/modeling/roi_heads/cube_head.py:70,108-163),
@@ -280,6 +298,14 @@ int omni_resize_bilinear_u8(const unsigned char* src, unsigned char* dst, unsign
 int omni_sgd_step(float* param, const float* grad, float* momentum_buf, long long n, float lr, float momentum,
                   float dampening, float weight_decay, int nesterov, int first_step, float grad_scale,
                   const float* skip_flag, void* stream);
+/* The loop's divergence guard (tools/train_net.py:157-285: allreduce_dict :186, rolling-loss test :194-215, skip / step
+ * :245-253, retry decision :258-270) around ONE small all-reduce.  vec (n + 2): [n loss scalars | sum | non-finite-gradient flag];
+ * omni_guard_pre writes the sum, the caller all-reduces vec over the ranks (sum), omni_guard_post averages by `world`, updates
+ * state (3) = [rolling loss (NaN = unset), iterations_success, iterations_explode], writes skip (1) for omni_sgd_step and
+ * out (n + 3) = [skipped, retry, total, n reduced losses], and clears the flag. */
+int omni_guard_pre(float* vec, int n, void* stream);
+int omni_guard_post(float* vec, int n, int world, float stabilize, float half_period, float tolerance, float gamma, float* state,
+                    float* skip, float* out, void* stream);
 /* the isnan/isinf gradient scan of tools/train_net.py:222-233 as one pass; flag[0] = 1 if any. */
 int omni_nonfinite_any(const float* grad, long long n, float* flag, void* stream);
 

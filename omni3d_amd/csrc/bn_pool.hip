@@ -376,6 +376,20 @@ int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const flo
     return omni_launch_status();
 }
 
+// The same forward with the statistics pass already done by the PRODUCER of x (conv / Winograd / stem epilogues):
+// partial [nblk][2][C] floats = per-block sums and sums of squares.
+int omni_bn_fwd_partials(const float* x, const float* partial, int nblk, const float* gamma, const float* beta, const float* residual,
+                         float* y, float* running_mean, float* running_var, float* mean_rstd, float* scale_shift, int P, int C,
+                         float eps, float momentum, int relu, void* stream) {
+    if (P <= 0 || C <= 0 || (C & 3) || C > 1024 || nblk <= 0) return OMNI_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, st, partial, nblk, P, C, eps, momentum, gamma, beta,
+                       mean_rstd, scale_shift, running_mean, running_var);
+    const long total4 = (long)P * (C >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, (const float*)scale_shift, residual, y, total4, C, relu);
+    return omni_launch_status();
+}
+
 // Inference / frozen BN: y = relu?(x*scale + shift (+res)) with caller-provided scale_shift (2C).
 int omni_bn_apply(const float* x, const float* scale_shift, const float* residual, float* y, int P, int C, int relu,
                   void* stream) {

@@ -41,6 +41,7 @@ struct ConvP {
     int accumulate;   // dgrad: out += result
     int splits;       // fwd/dgrad: reduction split over gridDim.y (atomic epilogue into a zeroed output)
     long xb, wb, ob;  // fwd/wgrad: element strides of x / w / out between the gridDim.z problems of a batched GEMM
+    float* stats;     // fwd, nullable: per-m-tile column sums [tiles_m][2][K] of the output (BatchNorm statistics, see omni_conv2d_fwd_stats)
 };
 
 
@@ -234,6 +235,40 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
     }
     const int l31 = lane & 31, h = lane >> 5;
     const bool split = gridDim.y > 1;
+    if (p.stats != nullptr && !split) {
+        // BatchNorm batch statistics from the accumulators (the conv -> BN pairs of the bottom-up, dla.py:46-66): per-channel
+        // sum and sum of squares over this tile's rows; [tile_m][2][K] partials, summed over tiles in fp64 by bn_finalize.
+        // Saves the statistics pass (one full read of the activation) of every BN layer behind a non-split convolution.
+        __syncthreads();
+        float* red = smem;                                   // [WAVES_M][2][BN]
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            float sv = 0.f, sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = m < M ? acc[i][j][r] : 0.f;
+                    sv += v;
+                    sq += v * v;
+                }
+            sv += __shfl_xor(sv, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (h == 0) {
+                red[(wm * 2 + 0) * BN + (wn * WN + j) * 32 + l31] = sv;
+                red[(wm * 2 + 1) * BN + (wn * WN + j) * 32 + l31] = sq;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * BN; idx += 256) {
+            const int which = idx / BN, nl = idx - which * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int wq = 0; wq < WAVES_M; ++wq) t += red[(wq * 2 + which) * BN + nl];
+            if (n0 + nl < p.K) p.stats[((long)tile_m * 2 + which) * p.K + n0 + nl] = t;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -696,10 +731,13 @@ extern "C" {
 //   tile 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 256x32 (BM x BN output-pixel x output-channel tile); splits >= 1 = number of
 //   reduction splits (atomic epilogue into a zeroed output when > 1; needs ldo == K).  Used by tools/bench_kernels.py for A/B
 //   measurements and by tests that want a given tile on a small problem.
-int omni_conv2d_fwd_algo(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
-                         int R, int S, int stride, int pad, int ldx, int ldo, int relu, int tile, int splits_req, void* stream) {
+static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
+                           int R, int S, int stride, int pad, int ldx, int ldo, int relu, int tile, int splits_req, float* stats,
+                           int stats_rows, int* nblk_out, void* stream) {
     ConvP p{x, w, bias, out, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
             R, S, stride, pad, ldx, ldo, 0, relu, 0, 1};
+    p.stats = nullptr;
+    if (nblk_out) *nblk_out = 0;
     if (bad_geom(p) || (ldx & 3) || ldx < C || ldo < K || tile < 0 || tile > 4 || splits_req < 0) return OMNI_ERR_ARG;
     if (splits_req > 1 && ldo != K) return OMNI_ERR_ARG;
     const long M = (long)N * p.OH * p.OW;
@@ -733,6 +771,14 @@ int omni_conv2d_fwd_algo(const float* x, const float* w, const float* bias, floa
     if (splits_req >= 1) splits = splits_req;
     if (splits > nslab) splits = nslab;
     if (splits > 1) omni_memset_async(out, 0, sizeof(float) * (size_t)M * K, st);
+    if (stats != nullptr && splits == 1 && bias == nullptr && !relu) {      // statistics only from complete, raw outputs
+        const int bm = tile == 1 ? 128 : tile == 2 ? 64 : tile == 3 ? 128 : 256;
+        const long rows = (M + bm - 1) / bm;
+        if (rows <= stats_rows) {
+            p.stats = stats;
+            if (nblk_out) *nblk_out = (int)rows;
+        }
+    }
 #define OMNI_FWD(BM_, BN_, WM_, WN_, BK_)                                                                                \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<BM_, BN_, WM_, WN_, BK_>),                                          \
                        dim3((unsigned)(((M + BM_ - 1) / BM_) * ((K + BN_ - 1) / BN_)), (unsigned)splits), dim3(256), 0, st, p)
@@ -748,6 +794,19 @@ int omni_conv2d_fwd_algo(const float* x, const float* w, const float* bias, floa
         hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)g), dim3(256), 0, st, out, n4);
     }
     return omni_launch_status();
+}
+
+int omni_conv2d_fwd_algo(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
+                         int R, int S, int stride, int pad, int ldx, int ldo, int relu, int tile, int splits_req, void* stream) {
+    return conv2d_fwd_impl(x, w, bias, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, relu, tile, splits_req, nullptr, 0, nullptr, stream);
+}
+
+// Forward convolution (no bias, no ReLU) that ALSO emits the BatchNorm batch statistics of its output: stats
+// [stats_rows][2][K] floats receives per-m-tile partial sums / sums of squares; *nblk_out = number of partial rows written
+// (0: the launcher chose a split reduction or the buffer is too small -- the caller then runs the separate statistics pass).
+int omni_conv2d_fwd_stats(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int S, int stride,
+                          int pad, int ldx, int ldo, float* stats, int stats_rows, int* nblk_out, void* stream) {
+    return conv2d_fwd_impl(x, w, nullptr, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, 0, 0, 0, stats, stats_rows, nblk_out, stream);
 }
 
 // Tile choice: 128x128 when that already fills the 256 CUs, otherwise 64x64 (4x the workgroups); when even

@@ -12,11 +12,15 @@
 //   util.compute_virtual_scale_from_focal_spaces                     util/math_util.py:581-592
 //   inference outputs (cube_3D, pred_bbox3D ...)                     modeling/roi_heads/roi_heads.py:771-819
 //
-// The reference runs ~150 tiny ATen kernels plus 8 .item() syncs here.  The work per ROI is a few
-// hundred flops on 13 head outputs, so one LANE owns one ROI.  The backward pass needs d(loss_k)/d(13
-// inputs): the forward kernel evaluates the whole chain on forward-mode dual numbers (13 tangents) and
-// stores the 6 x 13 Jacobian per ROI; backward is a 6-term contraction + scatter into the head's
-// gradient rows.  min/abs/clip pick the active branch exactly like autograd (ties -> first).
+// The reference runs ~150 tiny ATen kernels plus 8 .item() syncs here.  The backward pass needs d(loss_k)/d(13
+// inputs): the forward kernel evaluates the whole chain on forward-mode dual numbers and stores the 6 x 13
+// Jacobian per ROI; backward is a 6-term contraction + scatter into the head's gradient rows.  min/abs/clip pick
+// the active branch exactly like autograd (ties -> first).
+// Mapping (round 2): 16 lanes per ROI, 4 ROIs per wave.  Every lane carries the VALUE of each intermediate and ONE of
+// the 13 tangents (lane t of the group = tangent slot t), so a dual number is 2 registers instead of 14 and the
+// 8-corner / 8x8 chamfer intermediates stay in VGPRs (round 1: one lane per ROI with 13 tangents each = 512 VGPRs,
+// 93 spilled, 6.7 KB of scratch per lane, 8 waves on the whole chip).  Branch decisions depend on values only, so the
+// 16 lanes of a ROI never diverge.
 //
 // head (F, ldh): fused linear outputs, columns = [xy deltas K*2 | z K | dims K*3 | pose6 K*6 | uncert K].
 #include <device_rt.h>
@@ -24,37 +28,37 @@
 
 namespace {
 
-constexpr int NT = 13;  // tangent slots: dx dy | z | dw dh dl | p0..p5 | u
+constexpr int NT = 13;  // tangent slots: dx dy | z | dw dh dl | p0..p5 | u   (lane t of a ROI's 16-lane group carries slot t)
 
-struct D {            // dual number: value + 13 tangents
+struct D {            // dual number: value + THIS LANE's tangent
     float v;
-    float d[NT];
+    float d;
 };
-__device__ __forceinline__ D cst(float v) { D r; r.v = v; for (int i = 0; i < NT; ++i) r.d[i] = 0.f; return r; }
-__device__ __forceinline__ D var(float v, int slot) { D r = cst(v); r.d[slot] = 1.f; return r; }
-__device__ __forceinline__ D operator+(const D& a, const D& b) { D r; r.v = a.v + b.v; for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
-__device__ __forceinline__ D operator-(const D& a, const D& b) { D r; r.v = a.v - b.v; for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
-__device__ __forceinline__ D operator*(const D& a, const D& b) { D r; r.v = a.v * b.v; for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ D cst(float v) { D r; r.v = v; r.d = 0.f; return r; }
+// tl = the tangent slot this lane carries (-1: values only, e.g. the inference decode)
+__device__ __forceinline__ D var(float v, int slot, int tl) { D r; r.v = v; r.d = (slot == tl) ? 1.f : 0.f; return r; }
+__device__ __forceinline__ D operator+(const D& a, const D& b) { D r; r.v = a.v + b.v; r.d = a.d + b.d; return r; }
+__device__ __forceinline__ D operator-(const D& a, const D& b) { D r; r.v = a.v - b.v; r.d = a.d - b.d; return r; }
+__device__ __forceinline__ D operator*(const D& a, const D& b) { D r; r.v = a.v * b.v; r.d = a.d * b.v + a.v * b.d; return r; }
 __device__ __forceinline__ D operator/(const D& a, const D& b) {
     D r; r.v = a.v / b.v;
     const float inv = 1.f / b.v;
-    for (int i = 0; i < NT; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    r.d = (a.d - r.v * b.d) * inv;
     return r;
 }
-__device__ __forceinline__ D operator*(const D& a, float s) { D r; r.v = a.v * s; for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] * s; return r; }
+__device__ __forceinline__ D operator*(const D& a, float s) { D r; r.v = a.v * s; r.d = a.d * s; return r; }
 __device__ __forceinline__ D operator+(const D& a, float s) { D r = a; r.v += s; return r; }
-__device__ __forceinline__ D neg(const D& a) { D r; r.v = -a.v; for (int i = 0; i < NT; ++i) r.d[i] = -a.d[i]; return r; }
+__device__ __forceinline__ D neg(const D& a) { D r; r.v = -a.v; r.d = -a.d; return r; }
 __device__ __forceinline__ D dsqrt(const D& a) {
     D r; r.v = sqrtf(a.v);
-    const float k = 0.5f / r.v;
-    for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] * k;
+    r.d = a.d * (0.5f / r.v);
     return r;
 }
-__device__ __forceinline__ D dexp(const D& a) { D r; r.v = expf(a.v); for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] * r.v; return r; }
+__device__ __forceinline__ D dexp(const D& a) { D r; r.v = expf(a.v); r.d = a.d * r.v; return r; }
 __device__ __forceinline__ D dabs(const D& a) {
     const float s = a.v > 0.f ? 1.f : (a.v < 0.f ? -1.f : 0.f);
     D r; r.v = fabsf(a.v);
-    for (int i = 0; i < NT; ++i) r.d[i] = a.d[i] * s;
+    r.d = a.d * s;
     return r;
 }
 __device__ __forceinline__ D clip_max(const D& a, float mx) { return a.v > mx ? cst(mx) : a; }   // grad 0 when clipped
@@ -127,20 +131,28 @@ __device__ __forceinline__ D l1_mean(const V3 (&a)[8], const V3 (&b)[8]) {
     return s * (1.f / 24.f);
 }
 // chamfer_loss (roi_heads.py:298-304): mean_j min_i d(i,j) + mean_i min_j d(i,j), d = L1 over xyz
+__device__ __forceinline__ D l1_dist(const V3& a, const V3& b) { return dabs(a.x - b.x) + dabs(a.y - b.y) + dabs(a.z - b.z); }
 __device__ __forceinline__ D chamfer(const V3 (&a)[8], const V3 (&b)[8]) {
-    D dist[8][8];
-    for (int i = 0; i < 8; ++i)
-        for (int j = 0; j < 8; ++j) dist[i][j] = dabs(a[i].x - b[j].x) + dabs(a[i].y - b[j].y) + dabs(a[i].z - b[j].z);
+    // the 8 x 8 distance table is evaluated twice (row minima, column minima) instead of being kept: 64 dual numbers
+    // would not fit the register file next to the corner arrays
     D s1 = cst(0.f), s2 = cst(0.f);
+#pragma unroll 1
     for (int j = 0; j < 8; ++j) {
-        int bi = 0;
-        for (int i = 1; i < 8; ++i) if (dist[i][j].v < dist[bi][j].v) bi = i;
-        s1 = s1 + dist[bi][j];
+        D best = l1_dist(a[0], b[j]);
+        for (int i = 1; i < 8; ++i) {
+            const D d = l1_dist(a[i], b[j]);
+            if (d.v < best.v) best = d;         // first minimum wins (torch.min over dim)
+        }
+        s1 = s1 + best;
     }
+#pragma unroll 1
     for (int i = 0; i < 8; ++i) {
-        int bj = 0;
-        for (int j = 1; j < 8; ++j) if (dist[i][j].v < dist[i][bj].v) bj = j;
-        s2 = s2 + dist[i][bj];
+        D best = l1_dist(a[i], b[0]);
+        for (int j = 1; j < 8; ++j) {
+            const D d = l1_dist(a[i], b[j]);
+            if (d.v < best.v) best = d;
+        }
+        s2 = s2 + best;
     }
     return s1 * 0.125f + s2 * 0.125f;
 }
@@ -158,7 +170,7 @@ struct Decoded {
     D x, y, z, dims[3], u;
     Mat3 pose;
 };
-__device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn& in) {
+__device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn& in, int tl) {
     const int c = in.cls;
     const float* pxy = hrow + 2 * c;
     const float* pz = hrow + 2 * K + c;
@@ -168,12 +180,12 @@ __device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn&
     Decoded o;
     const float sw = in.box[2] - in.box[0], sh = in.box[3] - in.box[1];
     const float cx = in.box[0] + 0.5f * sw, cy = in.box[1] + 0.5f * sh;
-    o.x = var(pxy[0], 0) * sw + cx;                 // roi_heads.py:460-461
-    o.y = var(pxy[1], 1) * sh + cy;
-    o.z = var(pz[0], 2) * in.v2r;                   // z_type 'direct' + virtual depth (roi_heads.py:524-525)
-    for (int k = 0; k < 3; ++k) o.dims[k] = dexp(clip_max(var(pd[k], 3 + k), 5.f)) * in.prior[k];   // :479
+    o.x = var(pxy[0], 0, tl) * sw + cx;                 // roi_heads.py:460-461
+    o.y = var(pxy[1], 1, tl) * sh + cy;
+    o.z = var(pz[0], 2, tl) * in.v2r;                   // z_type 'direct' + virtual depth (roi_heads.py:524-525)
+    for (int k = 0; k < 3; ++k) o.dims[k] = dexp(clip_max(var(pd[k], 3 + k, tl), 5.f)) * in.prior[k];   // :479
     D p6[6];
-    for (int k = 0; k < 6; ++k) p6[k] = var(pp[k], 6 + k);
+    for (int k = 0; k < 6; ++k) p6[k] = var(pp[k], 6 + k, tl);
     const Mat3 Rv = rot6d(p6);                      // cube_head.py:176
     float M[3][3];
     bool valid;
@@ -184,7 +196,7 @@ __device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn&
     } else {
         o.pose = Rv;
     }
-    o.u = clip_min(var(pu[0], 12), 0.01f);          // cube_head.py:163
+    o.u = clip_min(var(pu[0], 12, tl), 0.01f);          // cube_head.py:163
     return o;
 }
 
@@ -196,22 +208,22 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
                                                            const int* __restrict__ img, const float* __restrict__ Ks,
                                                            const float* __restrict__ v2r, const float* __restrict__ priors,
                                                            const float* __restrict__ gt3d, const float* __restrict__ gtpose,
-                                                           const int* __restrict__ gt_row, float* __restrict__ vals,
-                                                           float* __restrict__ jac) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+                                                           const int* __restrict__ gt_row, float wd, float wp, float wxy,
+                                                           float wz, float wj, float* __restrict__ vals, float* __restrict__ jac) {
+    const int f = blockIdx.x * 4 + ((int)threadIdx.x >> 4), tl = (int)threadIdx.x & 15;   // ROI of this 16-lane group, tangent slot
     if (f >= F) return;
     RoiIn in;
     for (int k = 0; k < 4; ++k) in.box[k] = boxes[4 * f + k];
     in.cls = cls[f];
     if (in.cls < 0 || in.cls >= K) {
-        for (int k = 0; k < 13; ++k) vals[(long)f * 13 + k] = 0.f;
+        if (tl < 13) vals[(long)f * 13 + tl] = 0.f;
         return;
     }
     const int im = img[f];
     for (int k = 0; k < 4; ++k) in.K[k] = Ks[4 * im + k];
     in.v2r = v2r[im];
     for (int k = 0; k < 3; ++k) in.prior[k] = priors[(in.cls * 2 + 0) * 3 + k];
-    const Decoded o = decode(head + (long)f * ldh, K, in);
+    const Decoded o = decode(head + (long)f * ldh, K, in, tl);
     const float* g = gt3d + 9 * gt_row[f];
     const float* gp = gtpose + 9 * gt_row[f];
     const float fx = in.K[0], fy = in.K[1], sx = in.K[2], sy = in.K[3];
@@ -235,22 +247,24 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
     corners(o.z * (o.x + (-sx)) * (1.f / fx), o.z * (o.y + (-sy)) * (1.f / fy), o.z, o.dims[0], o.dims[1], o.dims[2], o.pose, ctmp);
     D loss_joint = chamfer(ctmp, cgt);
     const float joint_valid = loss_joint.v < INFINITY ? 1.f : 0.f;
-    const float total = loss_dims.v + loss_pose.v + loss_xy.v + loss_z.v + loss_joint.v;
+    // total_3D_loss_for_reporting (roi_heads.py:651-683): the WEIGHTED sum of the raw per-ROI terms
+    const float total = wd * loss_dims.v + wp * loss_pose.v + wxy * loss_xy.v + wz * loss_z.v + wj * loss_joint.v;
     // uncertainty weighting (roi_heads.py:721-739)
     const D sf = dexp(neg(o.u)) * 1.41421356f;
     D L[6] = {loss_dims * sf, loss_xy * sf, loss_z * sf, loss_pose * sf, loss_joint * sf, o.u};
     float* vo = vals + (long)f * 13;
-    for (int k = 0; k < 6; ++k) {
-        vo[k] = L[k].v;
-        for (int t = 0; t < NT; ++t) jac[((long)f * 6 + k) * NT + t] = L[k].d[t];
+    if (tl < NT)
+        for (int k = 0; k < 6; ++k) jac[((long)f * 6 + k) * NT + tl] = L[k].d;      // lane t stores tangent t of the six losses
+    if (tl == 0) {
+        for (int k = 0; k < 6; ++k) vo[k] = L[k].v;
+        vo[6] = total;
+        vo[7] = fabsf(o.z.v - gz);
+        vo[8] = fabsf(o.dims[0].v - g[3]) + fabsf(o.dims[1].v - g[4]) + fabsf(o.dims[2].v - g[5]);
+        vo[9] = fabsf(o.x.v - gu) + fabsf(o.y.v - gv);
+        vo[10] = expf(-o.u.v);
+        vo[11] = joint_valid;
+        vo[12] = 1.f;
     }
-    vo[6] = total;
-    vo[7] = fabsf(o.z.v - gz);
-    vo[8] = fabsf(o.dims[0].v - g[3]) + fabsf(o.dims[1].v - g[4]) + fabsf(o.dims[2].v - g[5]);
-    vo[9] = fabsf(o.x.v - gu) + fabsf(o.y.v - gv);
-    vo[10] = expf(-o.u.v);
-    vo[11] = joint_valid;
-    vo[12] = 1.f;
 }
 
 // safely_reduce_losses (roi_heads.py:932-940) for the 6 columns + logging sums.
@@ -340,7 +354,7 @@ __global__ void __launch_bounds__(64) cube_decode_kernel(const float* __restrict
     for (int k = 0; k < 4; ++k) in.K[k] = Ks[4 * im + k];
     in.v2r = v2r[im];
     for (int k = 0; k < 3; ++k) in.prior[k] = priors[(in.cls * 2 + 0) * 3 + k];
-    const Decoded o = decode(head + (long)f * ldh, K, in);
+    const Decoded o = decode(head + (long)f * ldh, K, in, -1);
     const float X = o.z.v * (o.x.v - in.K[2]) / in.K[0], Y = o.z.v * (o.y.v - in.K[3]) / in.K[1];
     float* c3 = cube3d + 9 * f;
     c3[0] = X; c3[1] = Y; c3[2] = o.z.v; c3[3] = o.dims[0].v; c3[4] = o.dims[1].v; c3[5] = o.dims[2].v;
@@ -377,12 +391,13 @@ extern "C" {
 // vals (F,13), jac (F,6,13), red (24) outputs.  Rows with cls outside [0,K) are ignored.
 int omni_cube_loss_fwd(const float* head, int ldh, int F, int K, const float* boxes, const int* cls, const int* img,
                        const float* Ks, const float* v2r, const float* priors, const float* gt3d, const float* gtpose,
-                       const int* gt_row, float* vals, float* jac, float* red, void* stream) {
+                       const int* gt_row, float w_dims, float w_pose, float w_xy, float w_z, float w_joint, float* vals, float* jac,
+                       float* red, void* stream) {
     if (F < 0 || K <= 0 || ldh < 13 * K) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (F > 0)
-        hipLaunchKernelGGL(cube_loss_fwd_kernel, dim3((F + 63) / 64), dim3(64), 0, st, head, ldh, F, K, boxes, cls, img, Ks,
-                           v2r, priors, gt3d, gtpose, gt_row, vals, jac);
+    if (F > 0)      // 16 lanes per ROI (one tangent each), 4 ROIs per wave
+        hipLaunchKernelGGL(cube_loss_fwd_kernel, dim3((F + 3) / 4), dim3(64), 0, st, head, ldh, F, K, boxes, cls, img, Ks,
+                           v2r, priors, gt3d, gtpose, gt_row, w_dims, w_pose, w_xy, w_z, w_joint, vals, jac);
     hipLaunchKernelGGL(cube_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)vals, F, red);
     return omni_launch_status();
 }

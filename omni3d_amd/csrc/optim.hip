@@ -52,6 +52,44 @@ __global__ void __launch_bounds__(256) nonfinite_kernel(const float* __restrict_
     if (__any(bad) && (threadIdx.x & 63) == 0) flag[0] = 1.f;
 }
 
+// The training loop's safety logic (tools/train_net.py:157-285) as two one-wave kernels around the ONE small all-reduce:
+//   guard_pre:  vec[n] = sum of the n losses (vec[n+1] already holds the non-finite-gradient flag of this rank)
+//   guard_post: averages over `world`, rolling-loss divergence test (:194-215), success / explode counters, retry decision
+//               (:258-259), writes the skip flag the fused SGD kernel reads and the record the host may read back.
+// state (3): [recent loss (NaN = unset), iterations_success, iterations_explode]
+__global__ void guard_pre_kernel(float* __restrict__ vec, int n) {
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += vec[i];
+        vec[n] = s;
+    }
+}
+
+__global__ void guard_post_kernel(float* __restrict__ vec, int n, float inv_world, float stabilize, float half_period, float tolerance,
+                                  float gamma, float* __restrict__ state, float* __restrict__ skip, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i <= n; ++i) vec[i] *= inv_world;                    // allreduce_dict(average=True), :496
+    const float total = vec[n];
+    bool bad_grad = vec[n + 1] > 0.f;
+    float recent = state[0];
+    if (recent != recent) recent = total * 2.0f;                         // :194-196
+    bool loss_div = !(fabsf(total) <= 3.402823466e+38f) || total > recent * tolerance;
+    if (!(stabilize > 0.f)) { loss_div = false; bad_grad = false; }
+    if (!loss_div) recent = recent * (1.f - gamma) + total * gamma;      // :205-215 (before the gradient scan of :222)
+    const bool diverging = loss_div || bad_grad;
+    state[0] = recent;
+    state[1] += diverging ? 0.f : 1.f;
+    state[2] += diverging ? 1.f : 0.f;
+    const float tot = state[1] + state[2];
+    const bool retry = stabilize > 0.f && (state[2] / tot) >= stabilize && tot > half_period;
+    skip[0] = diverging ? 1.f : 0.f;
+    out[0] = skip[0];
+    out[1] = retry ? 1.f : 0.f;
+    out[2] = total;
+    for (int i = 0; i < n; ++i) out[3 + i] = vec[i];
+    vec[n + 1] = 0.f;                                                    // re-arm the gradient scan's flag
+}
+
 inline int grid_for(long n) {
     long b = (n / 4 + 255) / 256;
     if (b > 2048) b = 2048;
@@ -81,6 +119,23 @@ int omni_nonfinite_any(const float* grad, long long n, float* flag, void* stream
     if (n < 0) return OMNI_ERR_ARG;
     if (n == 0) return OMNI_OK;
     hipLaunchKernelGGL(nonfinite_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, grad, (long)n, flag);
+    return omni_launch_status();
+}
+
+
+// vec (n + 2 floats): [n losses | their sum | non-finite-gradient flag].  omni_guard_pre fills the sum; the caller all-reduces
+// vec (sum) when world > 1; omni_guard_post decides (see guard_post_kernel).  state (3), skip (1), out (n + 3).
+int omni_guard_pre(float* vec, int n, void* stream) {
+    if (n <= 0) return OMNI_ERR_ARG;
+    hipLaunchKernelGGL(guard_pre_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vec, n);
+    return omni_launch_status();
+}
+
+int omni_guard_post(float* vec, int n, int world, float stabilize, float half_period, float tolerance, float gamma, float* state,
+                    float* skip, float* out, void* stream) {
+    if (n <= 0 || world <= 0) return OMNI_ERR_ARG;
+    hipLaunchKernelGGL(guard_post_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vec, n, 1.f / (float)world, stabilize, half_period,
+                       tolerance, gamma, state, skip, out);
     return omni_launch_status();
 }
 

@@ -21,7 +21,8 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 
 template <int C, int R>
 __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            float* __restrict__ out, int N, int H, int W, int ldx, int ldo) {
+                                                            float* __restrict__ out, int N, int H, int W, int ldx, int ldo,
+                                                            float* __restrict__ stats) {
     constexpr int TH = 4, TW = 64, PAD = R / 2;
     constexpr int HR = TH + R - 1, HC = TW + R - 1 + (C == 4 ? 1 : 0);   // C = 4: one spare column for the padded 8th tap
     constexpr int PP = (C == 16) ? 20 : 4;                               // LDS floats per pixel (20: conflict-free b128 reads)
@@ -92,14 +93,28 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
     }
     // D[row = 4g + i][col = px]: output pixel ox0 + 16b + 4g + i of row oy0 + wave, channel px
     const int oy = oy0 + wave;
-    if (oy >= H) return;
+    float sv = 0.f, sq = 0.f;
+    if (oy < H) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ox = ox0 + 16 * b + 4 * g + i;
-            if (ox < W) out[(((long)n * H + oy) * W + ox) * ldo + px] = acc[b][i];
-        }
+            for (int i = 0; i < 4; ++i) {
+                const int ox = ox0 + 16 * b + 4 * g + i;
+                if (ox < W) {
+                    out[(((long)n * H + oy) * W + ox) * ldo + px] = acc[b][i];
+                    sv += acc[b][i];
+                    sq += acc[b][i] * acc[b][i];
+                }
+            }
+    }
+    if (stats != nullptr) {     // BatchNorm statistics of the 16 output channels over this 4 x 64 tile -> stats[blockIdx][2][16]
+        sv += __shfl_xor(sv, 16, 64); sq += __shfl_xor(sq, 16, 64);
+        sv += __shfl_xor(sv, 32, 64); sq += __shfl_xor(sq, 32, 64);
+        __syncthreads();                                   // s_in is free now
+        if (lane < 16) { s_in[wave * 32 + lane] = sv; s_in[wave * 32 + 16 + lane] = sq; }
+        __syncthreads();
+        if (tid < 32) stats[(long)blockIdx.x * 32 + tid] = s_in[tid] + s_in[32 + tid] + s_in[64 + tid] + s_in[96 + tid];
+    }
 }
 
 
@@ -190,19 +205,33 @@ __global__ void __launch_bounds__(256) stem_conv_wgrad_kernel(const float* __res
 extern "C" {
 
 // out (N,H,W,16) = conv(x (N,H,W,C), w (16,R,R,C)), stride 1, padding R/2.  (C, R) in {(4, 7), (16, 3)}.
-int omni_stem_conv_fwd(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
-                       void* stream) {
+static int stem_fwd_impl(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
+                         float* stats, int stats_rows, int* nblk_out, void* stream) {
+    if (nblk_out) *nblk_out = 0;
     if (N < 0 || H <= 0 || W <= 0 || K != 16 || ldx < C || ldo < K || (ldx & 3)) return OMNI_ERR_ARG;
     if (!((C == 4 && R == 7) || (C == 16 && R == 3))) return OMNI_ERR_ARG;
     if (N == 0) return OMNI_OK;
     const long tiles = (long)N * ((H + 3) / 4) * ((W + 63) / 64);
+    float* sp = (stats != nullptr && tiles <= stats_rows) ? stats : nullptr;
+    if (sp && nblk_out) *nblk_out = (int)tiles;
     if (C == 4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_fwd_kernel<4, 7>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w,
-                           out, N, H, W, ldx, ldo);
+                           out, N, H, W, ldx, ldo, sp);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_fwd_kernel<16, 3>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w,
-                           out, N, H, W, ldx, ldo);
+                           out, N, H, W, ldx, ldo, sp);
     return omni_launch_status();
+}
+
+int omni_stem_conv_fwd(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
+                       void* stream) {
+    return stem_fwd_impl(x, w, out, N, H, W, C, K, R, ldx, ldo, nullptr, 0, nullptr, stream);
+}
+
+// the same with BatchNorm partial statistics stats[rows][2][16] of the output (one row per 4 x 64 tile); *nblk_out = rows (0 = none)
+int omni_stem_conv_fwd_stats(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
+                             float* stats, int stats_rows, int* nblk_out, void* stream) {
+    return stem_fwd_impl(x, w, out, N, H, W, C, K, R, ldx, ldo, stats, stats_rows, nblk_out, stream);
 }
 
 // dw (16,R,R,C) (+)= sum_pix dy (N,H,W,16) x (N,H,W,C); accumulate == 0 zeroes dw first (atomic accumulation either way).

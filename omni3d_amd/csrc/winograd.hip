@@ -70,10 +70,34 @@ __global__ void __launch_bounds__(256) wino_in_kernel(const float* __restrict__ 
     }
 }
 
+// Per-channel sum / sum of squares of everything a workgroup wrote (BatchNorm statistics of the Winograd layers,
+// cf. the conv_fwd epilogue in conv_gemm.hip): every thread keeps ONE channel group for its whole grid-stride walk
+// (256 % K4 == 0), so it accumulates privately and the 256 / K4 threads of a group meet once in LDS at the end.
+__device__ __forceinline__ void block_channel_stats(float4 sv, float4 sq, int K, float* __restrict__ stats) {
+    __shared__ float4 r0[256], r1[256];
+    const int K4 = K >> 2, t = threadIdx.x;
+    r0[t] = sv;
+    r1[t] = sq;
+    __syncthreads();
+    if (t < K4) {
+        float4 a = r0[t], b = r1[t];
+        for (int q = t + K4; q < 256; q += K4) {
+            a = make_float4(a.x + r0[q].x, a.y + r0[q].y, a.z + r0[q].z, a.w + r0[q].w);
+            b = make_float4(b.x + r1[q].x, b.y + r1[q].y, b.z + r1[q].z, b.w + r1[q].w);
+        }
+        st4(stats + (long)blockIdx.x * 2 * K + 4 * t, a);
+        st4(stats + (long)blockIdx.x * 2 * K + K + 4 * t, b);
+    }
+}
+#define OMNI_ACC_STATS(v) do { sv = make_float4(sv.x + (v).x, sv.y + (v).y, sv.z + (v).z, sv.w + (v).w); \
+                               sq = make_float4(sq.x + (v).x * (v).x, sq.y + (v).y * (v).y, sq.z + (v).z * (v).z, sq.w + (v).w * (v).w); } while (0)
+
 __global__ void __launch_bounds__(256) wino_out_kernel(const float* __restrict__ M, const float* __restrict__ bias,
-                                                       float* __restrict__ y, int N, int H, int W, int K, int relu) {
+                                                       float* __restrict__ y, int N, int H, int W, int K, int relu,
+                                                       float* __restrict__ stats) {
     const int K4 = K >> 2, TH = H >> 1, TW = W >> 1;
     const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    float4 sv = z4(), sq = z4();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k4 = (int)(i % K4);
         const long t = i / K4;
@@ -101,8 +125,11 @@ __global__ void __launch_bounds__(256) wino_out_kernel(const float* __restrict__
             float* o = y + (((long)n * H + 2 * ty + r) * W + 2 * tx) * K + 4 * k4;
             st4(o, y0);
             st4(o + K, y1);
+            OMNI_ACC_STATS(y0);
+            OMNI_ACC_STATS(y1);
         }
     }
+    if (stats != nullptr) block_channel_stats(sv, sq, K, stats);
 }
 
 __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N, int H, int W,
@@ -293,9 +320,11 @@ __global__ void __launch_bounds__(256) wino4_in_kernel(const float* __restrict__
 }
 
 __global__ void __launch_bounds__(256) wino4_out_kernel(const float* __restrict__ M, const float* __restrict__ bias,
-                                                        float* __restrict__ y, int N, int H, int W, int K, int relu) {
+                                                        float* __restrict__ y, int N, int H, int W, int K, int relu,
+                                                        float* __restrict__ stats) {
     const int K4 = K >> 2, TH = H >> 2, TW = W >> 2;
     const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    float4 sv = z4(), sq = z4();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k4 = (int)(i % K4);
         const long t = i / K4;
@@ -324,9 +353,11 @@ __global__ void __launch_bounds__(256) wino4_out_kernel(const float* __restrict_
                 float4 v = row[c] + b;
                 if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                 st4(o + (long)c * K, v);
+                OMNI_ACC_STATS(v);
             }
         }
     }
+    if (stats != nullptr) block_channel_stats(sv, sq, K, stats);
 }
 
 __global__ void __launch_bounds__(256) wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N, int H, int W,
@@ -593,13 +624,33 @@ int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile,
     return omni_launch_status();
 }
 
-int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, void* stream) {
+static int wino_out_impl(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, float* stats,
+                         int stats_rows, int* nblk_out, void* stream) {
+    if (nblk_out) *nblk_out = 0;
     if (bad(N, H, W, K) || (tile != 2 && tile != 4) || (H % tile) || (W % tile)) return OMNI_ERR_ARG;
     const long total = (long)N * (H / tile) * (W / tile) * (K / 4);
     if (total == 0) return OMNI_OK;
-    if (tile == 2) hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu);
-    else hipLaunchKernelGGL(wino4_out_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu);
+    int grid = ew_grid(total);
+    // statistics: one partial row per workgroup; needs a fixed channel group per thread (256 % (K/4) == 0), raw outputs
+    float* st_ptr = nullptr;
+    if (stats != nullptr && bias == nullptr && !relu && K >= 4 && (256 % (K / 4)) == 0) {
+        if (grid > stats_rows) grid = stats_rows;           // fewer, longer-running workgroups rather than no fusion
+        if (grid >= 1) { st_ptr = stats; if (nblk_out) *nblk_out = grid; }
+        else grid = ew_grid(total);
+    }
+    if (tile == 2) hipLaunchKernelGGL(wino_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu, st_ptr);
+    else hipLaunchKernelGGL(wino4_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu, st_ptr);
     return omni_launch_status();
+}
+
+int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, void* stream) {
+    return wino_out_impl(M, bias, y, N, H, W, K, relu, tile, nullptr, 0, nullptr, stream);
+}
+
+// Output transform (no bias, no ReLU) that also emits BatchNorm partial statistics [rows][2][K]; *nblk_out = rows written (0 = none)
+int omni_wino_out_stats(const float* M, float* y, int N, int H, int W, int K, int tile, float* stats, int stats_rows, int* nblk_out,
+                        void* stream) {
+    return wino_out_impl(M, nullptr, y, N, H, W, K, 0, tile, stats, stats_rows, nblk_out, stream);
 }
 
 int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, int tile, void* stream) {

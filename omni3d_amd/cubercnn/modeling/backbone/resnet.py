@@ -99,7 +99,7 @@ class ResNet(Backbone):
         w = self.conv1.weight
         if x.shape[1] != w.shape[1]:   # 3-channel stem weight against the 4-channel padded image
             w = torch.cat([w, w.new_zeros(w.shape[0], x.shape[1] - w.shape[1], w.shape[2], w.shape[3])], dim=1)
-        x = self.bn1(HF.conv2d(x, w, None, 2, 3), relu=True)
+        x = self.bn1(HF.conv2d(x, w, None, 2, 3, False, self.bn1.training and torch.is_grad_enabled()), relu=True)
         x = HF.max_pool3s2(x)
         p2 = self.layer1(x)
         p3 = self.layer2(p2)

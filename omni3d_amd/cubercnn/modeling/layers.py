@@ -23,7 +23,10 @@ class Conv2d(nn.Conv2d):
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
 
     def forward(self, x, relu=False):
-        return HF.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu)
+        # a bias-free convolution in training mode is the conv half of a conv -> BatchNorm pair (every one in the DLA / ResNet
+        # bottom-up): let the kernel emit the batch statistics with its output
+        want_stats = self.bias is None and self.training and not relu and torch.is_grad_enabled()
+        return HF.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu, want_stats)
 
 
 class Linear(nn.Linear):

@@ -242,7 +242,7 @@ class ROIHeads3D(nn.Module):
         head = self.cube_head(x)
         priors = self.priors_dims_per_cat.detach().reshape(self.num_classes, 2, 3).contiguous()
         red6, red = HF.cube_loss(head, self.num_classes, rois, cls, bidx, packed.Ks, packed.v2r, priors, packed.gt3d,
-                                 packed.gtpose, gt_row)
+                                 packed.gtpose, gt_row, (self.loss_w_dims, self.loss_w_pose, self.loss_w_xy, self.loss_w_z, self.loss_w_joint))
         self.pending_logs["cube"] = red
         w3 = self.loss_w_3d
         p = "Cube/"

@@ -8,7 +8,7 @@ dozen host syncs.  Here:
 
   * one 12-float vector per rank [10 losses | sum | non-finite-gradient flag] is all-reduced ONCE (sum);
   * the divergence test, the rolling mean, the success / explode counters and the retry decision are evaluated from the
-    reduced vector by a handful of tiny device ops, identically on every rank (same inputs => same decision, so the flags
+    reduced vector by one one-wave kernel (csrc/optim.hip guard_post_kernel), identically on every rank (same inputs => same decision, so the flags
     need no second collective), and `skip` lands in the device float the fused SGD kernel reads (`FlatSGD.skip_flag`);
   * the host reads (skipped, retry, 10 reduced losses) back in one copy -- every step (`sync=True`, the reference's
     semantics: it logs the scalars and may return False to restart) or only when it wants to look (`sync=False`).
@@ -30,8 +30,7 @@ class StepGuard:
         self.group = group
         n = len(self.names)
         self.vec = torch.zeros(n + 2, dtype=torch.float32, device=device)       # [losses | total | nonfinite]
-        self.recent = torch.full((), float("nan"), dtype=torch.float32, device=device)   # NaN = "None" (:166)
-        self.counts = torch.zeros(2, dtype=torch.float32, device=device)        # [success, explode]
+        self.state = torch.tensor([float("nan"), 0.0, 0.0], dtype=torch.float32, device=device)   # [recent (NaN = None, :166), success, explode]
         self.skip = torch.zeros(1, dtype=torch.float32, device=device)          # -> FlatSGD.skip_flag
         self.out = torch.zeros(n + 3, dtype=torch.float32, device=device)       # [skipped, retry, total, losses...]
 
@@ -47,29 +46,15 @@ class StepGuard:
     def update(self, loss_dict, sync=True):
         """Call after backward + all-reduce of the gradients + check_nonfinite(self.nonfinite_flag), before optimizer.step().
         -> (skipped, retry, {name: reduced loss}) as host values when sync, else None."""
+        from ...kernels import det
         n = len(self.names)
-        self.vec[:n] = torch.stack([loss_dict[k].detach().float().reshape(()) for k in self.names])
-        self.vec[n] = self.vec[:n].sum()
+        torch.stack([loss_dict[k].detach().float().reshape(()) for k in self.names], out=self.vec[:n])
+        det.guard_pre(self.vec, n)                                   # vec[n] = sum of the losses
         w = self.world()
         if w > 1:
-            dist.all_reduce(self.vec, group=self.group)          # the ONE collective of the guard
-            self.vec[: n + 1] /= w                               # allreduce_dict(average=True)
-        total, bad_grad = self.vec[n], self.vec[n + 1] > 0
-        first = torch.isnan(self.recent)
-        recent = torch.where(first, total * 2.0, self.recent)                     # :194-196
-        loss_div = ~torch.isfinite(total) | (total > recent * TOLERANCE)          # :199-201
-        if not self.stabilize > 0:
-            loss_div = bad_grad = torch.zeros_like(loss_div)                      # guard off: the reference always steps
-        # the rolling mean moves whenever the LOSS was sane, also when the gradient scan then fails (:205-215 precede :222)
-        self.recent = torch.where(loss_div, recent, recent * (1 - GAMMA) + total * GAMMA)
-        diverging = loss_div | bad_grad
-        self.skip[0] = diverging.float()
-        self.counts += torch.stack([1.0 - self.skip[0], self.skip[0]])
-        tot = self.counts.sum()
-        retry = ((self.counts[1] / tot) >= self.stabilize) & (tot > self.half_period) & (self.stabilize > 0)     # :258-259
-        self.out[0], self.out[1], self.out[2] = self.skip[0], retry.float(), total
-        self.out[3:] = self.vec[:n]
-        self.nonfinite_flag.zero_()
+            dist.all_reduce(self.vec, group=self.group)              # the ONE collective of the guard
+        # average, divergence test (:194-215), counters, retry (:258-259), skip flag, host record -- one one-wave kernel
+        det.guard_post(self.vec, n, w, self.stabilize, self.half_period, TOLERANCE, GAMMA, self.state, self.skip, self.out)
         if not sync:
             return None
         return self.read()

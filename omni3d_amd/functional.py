@@ -26,20 +26,31 @@ def _direct_grad(t):
     return None
 
 
+def _parts_out(parts, like):
+    """BatchNorm partial statistics as a second (non-differentiable) output; a 0-row tensor stands for "not produced" """
+    return parts if parts is not None else like.new_zeros((0, 1))
+
+
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, relu):
+    def forward(ctx, x, w, bias, stride, pad, relu, want_stats=False):
         ctx.direct = (_direct_grad(w), _direct_grad(bias))
         x, w = _cl(x), _cl(w)
         # full-resolution few-channel stem layers: direct convolution with the input halo staged once in LDS
         ctx.stem = bias is None and not relu and conv.stem_eligible(x.shape, w.shape, stride, pad)
-        y = conv.stem_conv_fwd(x, w) if ctx.stem else conv.conv2d_fwd(x, w, bias, stride, pad, relu)
+        parts = None
+        if want_stats and bias is None and not relu:     # conv -> BatchNorm: statistics from the epilogue (saves a pass over y)
+            y, parts = conv.stem_conv_fwd_stats(x, w) if ctx.stem else conv.conv2d_fwd_stats(x, w, stride, pad)
+        else:
+            y = conv.stem_conv_fwd(x, w) if ctx.stem else conv.conv2d_fwd(x, w, bias, stride, pad, relu)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.cfg = (stride, pad, relu, bias is not None)
-        return y
+        parts = _parts_out(parts, y)
+        ctx.mark_non_differentiable(parts)
+        return y, parts
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _parts_grad=None):
         x, w, y = ctx.saved_tensors
         stride, pad, relu, has_bias = ctx.cfg
         dy = _cl(dy)
@@ -65,7 +76,7 @@ class _Conv2d(Function):
         db = None
         if has_bias and ctx.needs_input_grad[2]:
             db = bnpool.bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]), accum_into=gb)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _WinoConv3x3(Function):
@@ -74,7 +85,7 @@ class _WinoConv3x3(Function):
     input) each run 16 batched fp32-MFMA GEMMs with 2.25x fewer flops than the direct implicit GEMM."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, relu):
+    def forward(ctx, x, w, bias, relu, want_stats=False):
         ctx.direct = (_direct_grad(w), _direct_grad(bias))
         x, w = _cl(x), _cl(w)
         # one launch yields the forward transform U and (when the data gradient will also go through Winograd) U' of
@@ -91,13 +102,19 @@ class _WinoConv3x3(Function):
             U, Uf = wino.transform_weights(w, True, need_flip or Uf is not None, tile)
             if cache is not None:
                 cache[key] = (U, Uf)
-        y, V = wino.conv3x3_fwd(x, w, bias, relu, U=U, tile=tile)
+        parts = None
+        if want_stats and bias is None and not relu:
+            y, V, parts = wino.conv3x3_fwd(x, w, None, False, U=U, tile=tile, want_stats=True)
+        else:
+            y, V = wino.conv3x3_fwd(x, w, bias, relu, U=U, tile=tile)
         ctx.save_for_backward(V, w, y if relu else None, Uf if need_flip else None)
         ctx.cfg = (relu, bias is not None)
-        return y
+        parts = _parts_out(parts, y)
+        ctx.mark_non_differentiable(parts)
+        return y, parts
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _parts_grad=None):
         V, w, y, Uf = ctx.saved_tensors
         relu, has_bias = ctx.cfg
         dy = _cl(dy)
@@ -118,7 +135,7 @@ class _WinoConv3x3(Function):
         db = None
         if has_bias and ctx.needs_input_grad[2]:
             db = bnpool.bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]), accum_into=gb)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 _wino_scope = {"cache": None}     # (weight address, shape) -> (U, U'), only while a model forward is running
@@ -142,10 +159,16 @@ import os as _os
 _WINOGRAD = _os.environ.get("OMNI_WINOGRAD", "1") != "0"
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, relu=False):
+def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, want_stats=False):
+    """want_stats: the caller is a conv -> BatchNorm pair in training mode; the result then carries `_omni_bn_partials`
+    (per-workgroup sums / sums of squares written by the kernel that produced it) when the chosen kernel could emit them."""
     if _WINOGRAD and wino.eligible(x.shape, w.shape, stride, pad):
-        return _WinoConv3x3.apply(x, w, bias, relu)
-    return _Conv2d.apply(x, w, bias, stride, pad, relu)
+        y, parts = _WinoConv3x3.apply(x, w, bias, relu, want_stats)
+    else:
+        y, parts = _Conv2d.apply(x, w, bias, stride, pad, relu, want_stats)
+    if parts.shape[0] > 0:
+        y._omni_bn_partials = parts
+    return y
 
 
 class _Linear(Function):
@@ -181,12 +204,12 @@ def linear(x, w, bias=None, relu=False, w_grad_view=None):
 
 class _BatchNorm(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, eps, momentum):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, eps, momentum, partials=None):
         gg, gb = _direct_grad(gamma), _direct_grad(beta)
         ctx.direct = (gg, gb) if (gg is not None and gb is not None) else None
         x = _cl(x)
         res = _cl(residual) if residual is not None else None
-        y, mean_rstd, _ = bnpool.bn_fwd(x, gamma, beta, running_mean, running_var, res, relu, eps, momentum)
+        y, mean_rstd, _ = bnpool.bn_fwd(x, gamma, beta, running_mean, running_var, res, relu, eps, momentum, partials)
         ctx.save_for_backward(x, gamma, mean_rstd, y if relu else None)
         ctx.cfg = (relu, residual is not None)
         return y
@@ -197,11 +220,12 @@ class _BatchNorm(Function):
         relu, has_res = ctx.cfg
         dx, dres, dgamma, dbeta = bnpool.bn_bwd(x, _cl(dy), y, gamma, mean_rstd, relu, want_dres=has_res and ctx.needs_input_grad[5],
                                                 accum_into=ctx.direct)
-        return dx, dgamma, dbeta, None, None, dres, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 
 def batch_norm_train(x, gamma, beta, running_mean, running_var, residual=None, relu=False, eps=1e-5, momentum=0.1):
-    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, residual, relu, eps, momentum)
+    """statistics: taken from `x._omni_bn_partials` when the producer of x emitted them (functional.conv2d(want_stats=True))"""
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, residual, relu, eps, momentum, getattr(x, "_omni_bn_partials", None))
 
 
 class _MaxPool2(Function):
@@ -373,9 +397,9 @@ class _CubeLoss(Function):
     """-> (red[0:6] = loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert ; red (24) stats)."""
 
     @staticmethod
-    def forward(ctx, head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row):
+    def forward(ctx, head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w):
         head = head.contiguous()
-        vals, jac, red = det.cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row)
+        vals, jac, red = det.cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w)
         ctx.save_for_backward(vals, jac, red, cls)
         ctx.meta = (head.shape[0], K, head.shape[1])
         ctx.mark_non_differentiable(red)
@@ -386,11 +410,11 @@ class _CubeLoss(Function):
         vals, jac, red, cls = ctx.saved_tensors
         F_, K, ldh = ctx.meta
         dhead = det.cube_loss_bwd(vals, jac, red, g.contiguous().float(), cls, F_, K, ldh)
-        return (dhead,) + (None,) * 10
+        return (dhead,) + (None,) * 11
 
 
-def cube_loss(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row):
-    return _CubeLoss.apply(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row)
+def cube_loss(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0)):
+    return _CubeLoss.apply(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, tuple(loss_w))
 
 
 class _MaxPool3s2(Function):

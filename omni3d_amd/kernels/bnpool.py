@@ -10,8 +10,9 @@ def _like_cl(shape_nhwc, ref):
     return torch.empty(shape_nhwc, dtype=torch.float32, device=ref.device)
 
 
-def bn_fwd(x, gamma, beta, running_mean, running_var, residual=None, relu=False, eps=1e-5, momentum=0.1):
-    """-> (y CL, mean_rstd (2C), scale_shift (2C)); running stats updated in place."""
+def bn_fwd(x, gamma, beta, running_mean, running_var, residual=None, relu=False, eps=1e-5, momentum=0.1, partials=None):
+    """-> (y CL, mean_rstd (2C), scale_shift (2C)); running stats updated in place.  partials (nblk, 2C): per-block sums / sums
+    of squares of x already produced by the kernel that wrote x (conv / Winograd / stem epilogue): skips the statistics pass."""
     xv = _nhwc(x)
     rv = _nhwc(residual) if residual is not None else None
     N, H, W, C = xv.shape
@@ -19,6 +20,12 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, residual=None, relu=False,
     y = _like_cl((N, H, W, C), x)
     mean_rstd = torch.empty(2 * C, dtype=torch.float32, device=x.device)
     scale_shift = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    if partials is not None:
+        assert partials.is_contiguous() and partials.shape[1] == 2 * C
+        L.call("omni_bn_fwd_partials", _lib.ptr(xv), _lib.ptr(partials), partials.shape[0], _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(rv),
+               _lib.ptr(y), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), N * H * W, C,
+               float(eps), float(momentum), int(relu), _lib.stream_of(x))
+        return y.permute(0, 3, 1, 2), mean_rstd, scale_shift
     ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
     L.call("omni_bn_fwd", _lib.ptr(xv), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(rv), _lib.ptr(y),
            _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), _lib.ptr(ws),

@@ -38,6 +38,47 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, relu=False, tile=0, splits=0):
     return out.permute(0, 3, 1, 2)
 
 
+STATS_ROWS = 4096       # capacity (partial rows) of the BatchNorm statistics buffer a producing kernel may fill
+
+
+def _stats_buf(K, device):
+    return torch.empty((STATS_ROWS, 2 * K), dtype=torch.float32, device=device)
+
+
+def _nblk_cell():
+    import ctypes
+    cell = ctypes.c_int(0)
+    return cell, ctypes.addressof(cell)
+
+
+def conv2d_fwd_stats(x, w, stride=1, pad=0):
+    """conv2d_fwd (no bias, no ReLU) + BatchNorm partial statistics from the epilogue -> (y, partial (nblk, 2K) or None)"""
+    xv, wv = _nhwc(x), _nhwc(w)
+    N, H, W, C = xv.shape
+    K, R, S, _ = wv.shape
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    L = _lib.check_device(xv, wv)
+    out = torch.empty((N, OH, OW, K), dtype=torch.float32, device=x.device)
+    stats = _stats_buf(K, x.device)
+    cell, addr = _nblk_cell()
+    L.call("omni_conv2d_fwd_stats", _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(out), N, H, W, C, K, R, S, stride, pad, C, K, _lib.ptr(stats),
+           STATS_ROWS, addr, _lib.stream_of(x))
+    return out.permute(0, 3, 1, 2), (stats[:cell.value] if cell.value > 0 else None)
+
+
+def stem_conv_fwd_stats(x, w):
+    xv, wv = _nhwc(x), _nhwc(w)
+    N, H, W, C = xv.shape
+    K, R = wv.shape[0], wv.shape[1]
+    L = _lib.check_device(xv, wv)
+    out = torch.empty((N, H, W, K), dtype=torch.float32, device=x.device)
+    stats = _stats_buf(K, x.device)
+    cell, addr = _nblk_cell()
+    L.call("omni_stem_conv_fwd_stats", _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(out), N, H, W, C, K, R, C, K, _lib.ptr(stats), STATS_ROWS, addr,
+           _lib.stream_of(x))
+    return out.permute(0, 3, 1, 2), (stats[:cell.value] if cell.value > 0 else None)
+
+
 def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, tile=0, splits=0):
     """dy (N,K,OH,OW) CL, w (K,C,R,S) CL -> dx (N,C,H,W) CL."""
     dyv, wv = _nhwc(dy), _nhwc(w)

@@ -205,15 +205,16 @@ def box_loss_bwd(pred, K, cls, prop, gt, gt_row, sums, g_cls, g_reg, weights=(10
     return dpred
 
 
-def cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row):
+def cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0)):
+    """loss_w = (w_dims, w_pose, w_xy, w_z, w_joint): only the logged total uses them (the loss terms are weighted by the caller)"""
     L = _dev(head, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row)
     F, ldh = head.shape
     vals = _empty((max(F, 1), 13), torch.float32, head)
     jac = _empty((max(F, 1), 6, 13), torch.float32, head)
     red = _empty((24,), torch.float32, head)
     L.call("omni_cube_loss_fwd", _lib.ptr(head), ldh, F, K, _lib.ptr(boxes), _lib.ptr(cls), _lib.ptr(img), _lib.ptr(Ks),
-           _lib.ptr(v2r), _lib.ptr(priors), _lib.ptr(gt3d), _lib.ptr(gtpose), _lib.ptr(gt_row), _lib.ptr(vals),
-           _lib.ptr(jac), _lib.ptr(red), _lib.stream_of(head))
+           _lib.ptr(v2r), _lib.ptr(priors), _lib.ptr(gt3d), _lib.ptr(gtpose), _lib.ptr(gt_row), *[float(w) for w in loss_w],
+           _lib.ptr(vals), _lib.ptr(jac), _lib.ptr(red), _lib.stream_of(head))
     return vals, jac, red
 
 
@@ -294,3 +295,14 @@ def det_compact(keep, valid, vals, idx, boxes, B, PK, K, cap, topk):
     L.call("omni_det_compact", _lib.ptr(keep), _lib.ptr(valid), _lib.ptr(vals), _lib.ptr(idx), _lib.ptr(boxes), B, PK, K, cap, topk,
            _lib.ptr(obox), _lib.ptr(oscore), _lib.ptr(ocls), _lib.ptr(oroi), _lib.ptr(ocount), _lib.stream_of(boxes))
     return obox, oscore, ocls, oroi, ocount
+
+
+def guard_pre(vec, n):
+    L = _dev(vec)
+    L.call("omni_guard_pre", _lib.ptr(vec), n, _lib.stream_of(vec))
+
+
+def guard_post(vec, n, world, stabilize, half_period, tolerance, gamma, state, skip, out):
+    L = _dev(vec, state, skip, out)
+    L.call("omni_guard_post", _lib.ptr(vec), n, world, float(stabilize), float(half_period), float(tolerance), float(gamma), _lib.ptr(state),
+           _lib.ptr(skip), _lib.ptr(out), _lib.stream_of(vec))

@@ -101,6 +101,20 @@ def transform_output(Mt, shape, bias=None, relu=False):
     return y.permute(0, 3, 1, 2)
 
 
+def transform_output_stats(Mt, shape):
+    """transform_output (no bias / ReLU) + BatchNorm partial statistics -> (y, partial (nblk, 2K) or None)"""
+    from .conv import STATS_ROWS, _nblk_cell, _stats_buf
+    tile = 2 if Mt.shape[0] == 16 else 4
+    N, H, W = shape
+    K = Mt.shape[2]
+    L = _lib.check_device(Mt)
+    y = torch.empty((N, H, W, K), dtype=torch.float32, device=Mt.device)
+    stats = _stats_buf(K, Mt.device)
+    cell, addr = _nblk_cell()
+    L.call("omni_wino_out_stats", _lib.ptr(Mt), _lib.ptr(y), N, H, W, K, tile, _lib.ptr(stats), STATS_ROWS, addr, _lib.stream_of(Mt))
+    return y.permute(0, 3, 1, 2), (stats[:cell.value] if cell.value > 0 else None)
+
+
 def transform_dy(dy, tile=2):
     """dy (N,K,H,W) CL -> dM (P,T,K)"""
     dv = _nhwc(dy)
@@ -138,13 +152,17 @@ def transform_dweights(dU, accum_into=None):
     return dw.permute(0, 3, 1, 2)
 
 
-def conv3x3_fwd(x, w, bias=None, relu=False, U=None, tile=2):
-    """-> (y, V): V is kept by the caller for the weight gradient.  U: precomputed transform_weights(w, tile=tile)[0]."""
+def conv3x3_fwd(x, w, bias=None, relu=False, U=None, tile=2, want_stats=False):
+    """-> (y, V): V is kept by the caller for the weight gradient.  U: precomputed transform_weights(w, tile=tile)[0].
+    want_stats (no bias, no ReLU): -> (y, V, BatchNorm partial statistics or None)"""
     N, _, H, W = x.shape
     V = transform_input(x, tile)
     if U is None:
         U = transform_weights(w, tile=tile)[0]
     Mt = gemm_batched(V, U)
+    if want_stats:
+        y, parts = transform_output_stats(Mt, (N, H, W))
+        return y, V, parts
     return transform_output(Mt, (N, H, W), bias, relu), V
 
 

@@ -124,3 +124,50 @@ def test_pool3_emulated(emu_lib):
 @pytest.mark.gpu
 def test_pool3_gpu(hip_lib):
     _run_pool3("cuda")
+
+
+# ---- BatchNorm statistics emitted by the producing kernel's epilogue (conv / Winograd / stem) ----------------------------
+def _bn_with_and_without_partials(dev, x_shape, w_shape, stride, pad):
+    """conv -> training BatchNorm through omni3d_amd.functional with the fused statistics vs the separate statistics pass"""
+    import omni3d_amd.functional as HF
+    from omni3d_amd.kernels import bnpool
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*x_shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(*w_shape, generator=g) * 0.2).to(dev).contiguous(memory_format=torch.channels_last)
+    C = w_shape[0]
+    gamma, beta = torch.rand(C, generator=g).to(dev) + 0.5, torch.randn(C, generator=g).to(dev)
+    y = HF.conv2d(x, w, None, stride, pad, False, True)
+    parts = getattr(y, "_omni_bn_partials", None)
+    rm1, rv1, rm2, rv2 = [torch.zeros(C, device=dev) if i % 2 == 0 else torch.ones(C, device=dev) for i in range(4)]
+    a, ms_a, _ = bnpool.bn_fwd(y, gamma, beta, rm1, rv1, None, True, 1e-5, 0.1, parts)
+    b, ms_b, _ = bnpool.bn_fwd(y, gamma, beta, rm2, rv2, None, True, 1e-5, 0.1, None)
+    return parts, (a - b).abs().max().item(), (ms_a - ms_b).abs().max().item() / ms_b.abs().max().item(), (rv1 - rv2).abs().max().item()
+
+
+STATS_CASES = [
+    ((2, 16, 24, 20), (32, 16, 3, 3), 1, 1, True),      # direct conv, 256x32 tile (K <= 32), ragged last m-tile
+    ((2, 32, 20, 20), (72, 32, 1, 1), 1, 0, True),      # 1x1, 64x64 / 128x128 tiles with a ragged channel tile
+    ((1, 8, 18, 14), (48, 8, 3, 3), 2, 1, True),        # stride 2
+    ((1, 64, 6, 6), (64, 64, 3, 3), 1, 1, False),       # few tiles + deep reduction: split-K chosen -> no statistics, fallback
+    ((1, 4, 12, 70), (16, 4, 7, 7), 1, 3, True),        # stem kernel 7x7 4 -> 16
+    ((1, 16, 9, 66), (16, 16, 3, 3), 1, 1, True),       # stem kernel 3x3 16 -> 16
+    ((1, 128, 32, 32), (128, 128, 3, 3), 1, 1, True),   # Winograd F(2x2,3x3) output transform (256 tiles)
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES)
+def test_bn_statistics_from_producer_epilogue_emulated(emu_lib, case):
+    xs, ws, st, pad, expect = case
+    parts, dy, dms, drv = _bn_with_and_without_partials("cpu", xs, ws, st, pad)
+    assert (parts is not None) == expect
+    if parts is not None:
+        assert dy <= 2e-5 and dms <= 1e-5 and drv <= 1e-5, (dy, dms, drv)
+
+
+@pytest.mark.gpu
+def test_bn_statistics_from_producer_epilogue_gpu(hip_lib):
+    for xs, ws, st, pad, _ in STATS_CASES + [((4, 256, 128, 128), (256, 256, 3, 3), 1, 1, True), ((4, 16, 512, 512), (16, 16, 3, 3), 1, 1, True),
+                                             ((4, 64, 128, 128), (128, 64, 3, 3), 2, 1, True)]:
+        parts, dy, dms, drv = _bn_with_and_without_partials("cuda", xs, ws, st, pad)
+        if parts is not None:
+            assert dy <= 5e-5 and dms <= 1e-5 and drv <= 1e-5, (xs, ws, dy, dms, drv)

@@ -131,7 +131,7 @@ def _reference_guard(seq, stabilize, period):
 
 
 @pytest.mark.parametrize("stabilize", [0.02, 0.5, 0.0])
-def test_step_guard_matches_the_reference_logic(stabilize):
+def test_step_guard_matches_the_reference_logic(emu_lib, stabilize):
     from omni3d_amd.cubercnn.solver.guard import StepGuard
     seq = [(6.0, 0), (5.5, 0), (30.0, 0), (5.0, 1), (float("nan"), 0), (4.8, 0), (100.0, 0), (4.7, 0), (float("inf"), 0), (4.5, 0)]
     want = _reference_guard(seq, stabilize, 6)
@@ -150,6 +150,8 @@ def _guard_worker(rank, world, port, q):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from omni3d_amd import lib as L
+    L._install_for_tests(L.HipLibrary(os.path.join(ROOT, "tests", "hipemu", "libomni3d_emu.so"), emulated=True))   # host-emulated kernels
     from omni3d_amd.cubercnn.solver.guard import StepGuard, allreduce_dict
     g = StepGuard(["x", "y"], 0.5, 2, "cpu")
     res = []
@@ -164,7 +166,7 @@ def _guard_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_step_guard_one_collective_keeps_ranks_in_agreement():
+def test_step_guard_one_collective_keeps_ranks_in_agreement(emu_lib):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
