@@ -115,6 +115,12 @@ def run_train(args, world, rank):
 
     step = graph_step if graphed is not None else eager_step
 
+    # executed (Winograd-aware) flops of one step: count the multiply-adds of every MFMA launch during one eager step
+    from omni3d_amd.profile_io import ExecutedFlops
+    with ExecutedFlops() as counter:
+        eager_step()
+    executed_flops = counter.flops
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -148,6 +154,11 @@ def run_train(args, world, rank):
         "launch_mode": graph_note,
         "step_mfma_frac": step_tf / FP32_MFMA_PEAK_TF,
         "step_algorithmic_tflops_per_gpu": step_tf,
+        # the flops the MFMA kernels really execute (Winograd layers at the size of their point GEMMs: 2.25x / 4x fewer than the
+        # direct-convolution count above) -- this, not the algorithmic figure, is the hardware's MFMA utilisation over the whole step
+        "step_executed_gflop": executed_flops / 1e9,
+        "step_executed_tflops_per_gpu": executed_flops * args.steps / dt / 1e12,
+        "step_executed_mfma_frac": executed_flops * args.steps / dt / 1e12 / FP32_MFMA_PEAK_TF,
         "loss_first_last": [final_losses[0], final_losses[-1]],
         "skipped_steps": int(torch.stack(skipped_log[-args.steps:]).sum().item()),
         "guard": "rolling-loss divergence test + NaN/Inf gradient scan + retry decision on the device, one 12-float all-reduce/step",
@@ -209,12 +220,15 @@ def _time_launch(fn, iters):
 
 
 def dominant_kernel_roofline(iters=20):
-    """Dominant kernel of the step = the batched GEMM of the Winograd path (gemm_nt_persistent_kernel: fp32 MFMA, 128x128
-    tiles, prefetch carried across work items).  Its largest launch serves the 3x3 256->256 convs on the 128x128 map (FPN
-    output p2 and the RPN conv on p2, forward and data gradient) through F(4x4,3x3): 36 x [4096 x 256] * [256 x 256]^T at
-    batch 4, 19.3 GFLOP and 312 MB of algorithmic traffic per launch (V 151.0 + U 9.4 read, M 151.0 written).  Timed live
-    with HIP events on the launch stream; the direct implicit-GEMM kernel of the same layer is reported next to it."""
-    from omni3d_amd.kernels import conv, wino
+    """`roofline`: the launch that contributes most to the step among single shapes -- the batched GEMM of the Winograd path on the
+    128x128 map (`gemm_nt_persistent_kernel`, F(4x4,3x3): 36 x [4096 x 256] * [256 x 256]^T at batch 4, 19.3 GFLOP and 312 MB of
+    algorithmic traffic per launch; FPN output p2 + RPN conv p2, forward and data gradient = 1.3 ms of the step) -- timed live with
+    HIP events on the launch stream.  HBM traffic and the cycle-based MFMA utilisation come from the committed PMC summary
+    (`traffic_source`).  `families`: every MFMA kernel family of the rocprof table (profiles/r02_train_final_kernel_stats.csv) with
+    one representative launch timed the same way, so the per-family distance to the 157.3 TFLOP/s fp32-MFMA peak is in the line."""
+    from omni3d_amd.kernels import conv, gemm as G, wino
+    from omni3d_amd.profile_io import profile_counters
+    PMC = "r02_pmc_families.csv"
     B, C, H = IMS_PER_GPU, 256, 128
     x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
     w = (torch.randn(C, C, 3, 3, device="cuda") * 0.02).contiguous(memory_format=torch.channels_last)
@@ -223,23 +237,58 @@ def dominant_kernel_roofline(iters=20):
     ms = _time_launch(lambda: wino.gemm_batched(V, U), iters)
     flops = 2.0 * P * T * C * C
     tf = flops / (ms * 1e-3) / 1e12
+    pmc = profile_counters(PMC, "gemm_nt_persistent_kernel")
+    traffic = (pmc["FETCH_SIZE_x2_MB"] + pmc["WRITE_SIZE_MB"]) * 1e6 if pmc and pmc.get("FETCH_SIZE_x2_MB") and pmc.get("WRITE_SIZE_MB") else None
     ms_direct = _time_launch(lambda: conv.conv2d_fwd(x, w, None, 1, 1), iters)
     flops_direct = 2.0 * B * H * H * C * C * 9
     ms_wino = _time_launch(lambda: wino.conv3x3_fwd(x, w, tile=4), iters)
+
+    def fam(name, kernel, shape, fl, fn, pmc_key=None, grid=None):
+        t = _time_launch(fn, max(iters // 2, 5))
+        r = {"family": name, "kernel": kernel, "shape": shape, "gflop": fl / 1e9, "kernel_ms": t, "tflops": fl / (t * 1e-3) / 1e12,
+             "frac": fl / (t * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF}
+        c = profile_counters(PMC, pmc_key or kernel.split("<")[0], grid)
+        if c and c.get("mfma_busy_frac"):
+            r["pmc_mfma_busy_frac"], r["pmc_source"] = c["mfma_busy_frac"], f"{c['source']} sha256:{c['sha256_16']} grid {c['grid']}"
+        return r
+    dM = torch.randn(P, T, C, device="cuda")
+    x1, w1 = torch.randn(2048, 12544, device="cuda"), torch.randn(1024, 12544, device="cuda") * 0.02
+    dy1 = torch.randn(2048, 1024, device="cuda")
+    xs = torch.randn(B, 64, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+    ws = (torch.randn(128, 64, 3, 3, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+    dys = torch.randn(B, 128, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    x3 = torch.randn(B, 128, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    w3 = (torch.randn(128, 128, 3, 3, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+    families = [
+        fam("Winograd point GEMMs", "gemm_nt_persistent_kernel", "36x[4096x256]x[256x256]^T (3x3 256->256 @128x128)", flops, lambda: wino.gemm_batched(V, U)),
+        fam("Winograd weight-gradient GEMMs", "conv_wgrad_kernel<128, 128, 2, 2, 32>", "36x[256x4096]x[4096x256] (same layer)", flops,
+            lambda: wino.gemm_batched_wgrad(V, dM), grid=294912),
+        fam("FC forward (fc1-class)", "gemm_engine_kernel<0, 0, 128, 128>", "[2048x12544]x[1024x12544]^T box-head fc1", 2.0 * 2048 * 12544 * 1024,
+            lambda: conv.linear_fwd(x1, w1, None)),
+        fam("FC data gradient", "conv_dgrad_kernel<128, 128, 2, 2, 32>", "[2048x1024]x[1024x12544] box-head fc1", 2.0 * 2048 * 12544 * 1024,
+            lambda: conv.linear_dgrad(dy1, w1), grid=401408),
+        fam("FC weight gradient", "conv_wgrad_kernel<128, 64, 2, 2, 32>", "[1024x2048]x[2048x12544] box-head fc1", 2.0 * 2048 * 12544 * 1024,
+            lambda: conv.linear_wgrad(x1, dy1), grid=401408),
+        fam("direct conv 64x64 tiles", "conv_fwd_kernel<64, 64, 2, 2, 32>", "3x3/s2 64->128 @128x128 (DLA level 3 entry)", 2.0 * B * 64 * 64 * 128 * 64 * 9,
+            lambda: conv.conv2d_fwd(xs, ws, None, 2, 1)),
+        fam("direct dgrad 64x64 tiles", "conv_dgrad_kernel<64, 64, 2, 2, 32>", "3x3/s2 64->128 @128x128", 2.0 * B * 64 * 64 * 128 * 64 * 9,
+            lambda: conv.conv2d_dgrad(dys, ws, (128, 128), 2, 1)),
+        fam("direct conv 128x128 tiles", "conv_fwd_kernel<128, 128, 2, 2, 32>", "3x3 256->256 @128x128 (the same layer WITHOUT Winograd)", flops_direct,
+            lambda: conv.conv2d_fwd(x, w, None, 1, 1)),
+        fam("direct conv mid layers", "conv_fwd_kernel<64, 64, 2, 2, 32>", "3x3 128->128 @64x64 (DLA level 3 block, direct)", 2.0 * B * 64 * 64 * 128 * 128 * 9,
+            lambda: conv.conv2d_fwd(x3, w3, None, 1, 1)),
+    ]
     return {"bound": "mfma", "kernel": "gemm_nt_persistent_kernel: Winograd F(4x4,3x3) batched GEMM 36x[4096x256]x[256x256]^T "
                                        "(3x3 256->256 @128x128, batch 4)",
             "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
-            # HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_persistent_gemm_f43.csv): FETCH_SIZE 82.3 MB x2
-            # (gfx950 wide-read correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 151.0 MB
-            "traffic": 315.6e6, "traffic_unit": "bytes/launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+            "traffic": traffic,
+            "traffic_source": (f"{pmc['source']} sha256:{pmc['sha256_16']} (rocprofv3 --pmc passes of tools/run_families.py: 2 x FETCH_SIZE + WRITE_SIZE, "
+                               "gfx950 wide-read correction of MI355X_MICROARCH.md)") if pmc else None,
+            "pmc_mfma_busy_frac": pmc.get("mfma_busy_frac") if pmc else None,
             "algorithmic_bytes_per_launch": 4.0 * (2 * P * T * C + P * C * C),
             "kernel_ms": ms, "flops_per_launch": flops, "operands": "fp32 (v_mfma_f32_32x32x2_f32)",
-            "direct_conv_same_layer": {"kernel": "conv_fwd_kernel<128,128,2,2,32>", "shape": "3x3 256->256 @128x128 batch 4 implicit GEMM",
-                                       "kernel_ms": ms_direct,
-                                        "achieved": flops_direct / (ms_direct * 1e-3) / 1e12,
-                                        "frac": flops_direct / (ms_direct * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
-                                        "traffic": 175.3e6, "algorithmic_bytes_per_launch": 4.0 * (2 * B * H * H * C + 9 * C * C)},
-            "layer_ms_winograd_vs_direct": [ms_wino, ms_direct]}
+            "layer_ms_winograd_vs_direct": [ms_wino, ms_direct],
+            "families": families}
 
 
 def hbm_bound_kernels(opt, iters=10):

@@ -206,7 +206,7 @@ static void box_planes(const float* b, face_t* out) {
 }
 /* BoxIntersections: clip `tris` (12) successively by the six planes; returns count */
 static int box_intersections(const tri_t* tris, const face_t* planes, v3 center, tri_t* out) {
-    static tri_t bufA[ORACLE_MAX_TRIS], bufB[ORACLE_MAX_TRIS];
+    static _Thread_local tri_t bufA[ORACLE_MAX_TRIS], bufB[ORACLE_MAX_TRIS];      /* per thread: the OpenMP baseline calls this concurrently */
     tri_t* cur = bufA; tri_t* nxt = bufB;
     int n = 12;
     memcpy(cur, tris, 12 * sizeof(tri_t));
@@ -228,7 +228,7 @@ static int box_intersections(const tri_t* tris, const face_t* planes, v3 center,
 
 /* pytorch3d _C.iou_box3d (iou_box3d_cpu.cpp): boxes1 (N,8,3), boxes2 (M,8,3) -> vol, iou (N,M) */
 void iou_box3d_oracle(const float* boxes1, int N, const float* boxes2, int M, float* vol_out, float* iou_out) {
-    static tri_t i1[2 * ORACLE_MAX_TRIS], i2[ORACLE_MAX_TRIS];
+    static _Thread_local tri_t i1[2 * ORACLE_MAX_TRIS], i2[ORACLE_MAX_TRIS];
     for (int a = 0; a < N; ++a) {
         const float* b1 = boxes1 + 24 * a;
         tri_t t1[12]; face_t p1[6];
@@ -314,3 +314,15 @@ void iou_box3d_pairs_oracle(const float* dt, const float* gt, int P, float* iou_
         iou_out[p] = iou;
     }
 }
+
+/* all-cores form of the paired loop (SURVEY.md 8d CPU baseline): pairs are independent; `g_max_tris_seen` is a debugging
+ * high-water mark updated without synchronisation, irrelevant for the result */
+void iou_box3d_pairs_oracle_omp(const float* dt, const float* gt, int P, float* iou_out) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int p = 0; p < P; ++p) {
+        float vol, iou;
+        iou_box3d_oracle(dt + 24 * p, 1, gt + 24 * p, 1, &vol, &iou);
+        iou_out[p] = iou;
+    }
+}
+

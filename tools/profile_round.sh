@@ -19,5 +19,9 @@ find $OUT/${TAG}_prof -name '*kernel_trace.csv' -delete
 timeout 900 python tools/pmc_run.py $OUT/${TAG}_pmc $OUT/${TAG}_pmc_families.csv -- python $REPO/tools/run_families.py > $OUT/${TAG}_pmc.log 2>&1
 tail -60 $OUT/${TAG}_pmc.log | cut -c1-400
 find $OUT/${TAG}_pmc -name '*kernel_trace.csv' -delete
+timeout 600 python tools/pmc_run.py $OUT/${TAG}_pmc_iou3d $OUT/${TAG}_pmc_iou3d.csv --filter "iou_box3d|box3d_validity" -- python $REPO/bench.py --workload iou3d --steps 3 --warmup 1 > $OUT/${TAG}_pmc_iou3d.log 2>&1
+tail -8 $OUT/${TAG}_pmc_iou3d.log | cut -c1-400
+find $OUT/${TAG}_pmc_iou3d -name '*kernel_trace.csv' -delete
 timeout 600 python tools/bench_kernels.py > $OUT/${TAG}_microbench.log 2>&1
-cat $OUT/${TAG}_microbench.log
+tail -40 $OUT/${TAG}_microbench.log
+python bench.py --workload iou3d > $OUT/${TAG}_bench_iou3d.log 2>/dev/null; tail -c 2500 $OUT/${TAG}_bench_iou3d.log
