@@ -22,9 +22,32 @@
 // 93 spilled, 6.7 KB of scratch per lane, 8 waves on the whole chip).  Branch decisions depend on values only, so the
 // 16 lanes of a ROI never diverge.
 //
-// head (F, ldh): fused linear outputs, columns = [xy deltas K*2 | z K | dims K*3 | pose6 K*6 | uncert K].
+// head (F, ldh): fused linear outputs, columns = [xy deltas K*2 | z K | dims K*3 | pose K*Pn | uncert K (if confidence)],
+// Pn = 6 / 4 / 3 for POSE_TYPE 6d / quaternion / euler.
+//
+// Head configuration (MODEL.ROI_CUBE_HEAD.*, roi_heads.py:426-768, cube_head.py:147-197) packed into `mode` by the host
+// (kernels/det.py:cube_mode):
+//   bits 0-1 Z_TYPE (0 direct, 1 sigmoid, 2 log)      bits 2-3 dims (0 priors 'exp', 1 priors 'sigmoid', 2 priors disabled)
+//   bits 4-5 POSE_TYPE (0 6d, 1 quaternion, 2 euler)  bit 6 ALLOCENTRIC_POSE   bit 7 VIRTUAL_DEPTH   bit 8 CHAMFER_POSE
+//   bit 9 INVERSE_Z_WEIGHT   bit 10 USE_CONFIDENCE > 0   bit 11 LOSS_W_JOINT > 0
+// The kernels are instantiated once with the configs/Base.yaml mode as a compile-time constant (every branch folds) and
+// once with the mode read at run time.  Z_TYPE 'clusters' / CLUSTER_BINS > 1 and DISENTANGLED_LOSS False are not built.
 #include <device_rt.h>
 #pragma clang fp contract(off)
+
+#define M_Z(m) ((m) & 3)
+#define M_DIMS(m) (((m) >> 2) & 3)
+#define M_POSE(m) (((m) >> 4) & 3)
+#define M_ALLOC(m) (((m) >> 6) & 1)
+#define M_VDEPTH(m) (((m) >> 7) & 1)
+#define M_CHAMFER(m) (((m) >> 8) & 1)
+#define M_INVZ(m) (((m) >> 9) & 1)
+#define M_CONF(m) (((m) >> 10) & 1)
+#define M_JOINT(m) (((m) >> 11) & 1)
+#define M_POSE_WIDTH(m) (M_POSE(m) == 0 ? 6 : (M_POSE(m) == 1 ? 4 : 3))
+#define M_HEAD_WIDTH(m) (6 + M_POSE_WIDTH(m) + M_CONF(m))
+#define MODE_BASE ((1 << 6) | (1 << 7) | (1 << 8) | (1 << 10) | (1 << 11))
+#define MODE_VALID(m) ((m) >= 0 && (m) < 4096 && M_Z(m) < 3 && M_DIMS(m) < 3 && M_POSE(m) < 3)
 
 namespace {
 
@@ -55,6 +78,13 @@ __device__ __forceinline__ D dsqrt(const D& a) {
     return r;
 }
 __device__ __forceinline__ D dexp(const D& a) { D r; r.v = expf(a.v); r.d = a.d * r.v; return r; }
+__device__ __forceinline__ D dsigmoid(const D& a) {
+    D r; r.v = 1.f / (1.f + expf(-a.v));
+    r.d = a.d * (r.v * (1.f - r.v));
+    return r;
+}
+__device__ __forceinline__ D dsin(const D& a) { D r; r.v = sinf(a.v); r.d = a.d * cosf(a.v); return r; }
+__device__ __forceinline__ D dcos(const D& a) { D r; r.v = cosf(a.v); r.d = -a.d * sinf(a.v); return r; }
 __device__ __forceinline__ D dabs(const D& a) {
     const float s = a.v > 0.f ? 1.f : (a.v < 0.f ? -1.f : 0.f);
     D r; r.v = fabsf(a.v);
@@ -87,6 +117,31 @@ __device__ __forceinline__ Mat3 rot6d(const D (&p)[6]) {
     R.m[0][0] = b1.x; R.m[0][1] = b1.y; R.m[0][2] = b1.z;
     R.m[1][0] = b2.x; R.m[1][1] = b2.y; R.m[1][2] = b2.z;
     R.m[2][0] = b3.x; R.m[2][1] = b3.y; R.m[2][2] = b3.z;
+    return R;
+}
+
+// cube_head.py:178-182: q / copysign(|q|, q[0]) then pytorch3d quaternion_to_matrix
+__device__ __forceinline__ Mat3 rot_quat(const D (&p)[4]) {
+    D n = dsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
+    if (p[0].v < 0.f) n = neg(n);
+    const D r = p[0] / n, i = p[1] / n, j = p[2] / n, k = p[3] / n;
+    const D two_s = cst(2.f) / (r * r + i * i + j * j + k * k);
+    const D one = cst(1.f);
+    Mat3 R;
+    R.m[0][0] = one - two_s * (j * j + k * k); R.m[0][1] = two_s * (i * j - k * r); R.m[0][2] = two_s * (i * k + j * r);
+    R.m[1][0] = two_s * (i * j + k * r); R.m[1][1] = one - two_s * (i * i + k * k); R.m[1][2] = two_s * (j * k - i * r);
+    R.m[2][0] = two_s * (i * k - j * r); R.m[2][1] = two_s * (j * k + i * r); R.m[2][2] = one - two_s * (i * i + j * j);
+    return R;
+}
+// pytorch3d euler_angles_to_matrix(angles, 'XYZ') = Rx(a) @ Ry(b) @ Rz(c)   (cube_head.py:184-185)
+__device__ __forceinline__ Mat3 rot_euler(const D (&p)[3]) {
+    const D ca = dcos(p[0]), sa = dsin(p[0]), cb = dcos(p[1]), sb = dsin(p[1]), cc = dcos(p[2]), sc = dsin(p[2]);
+    // Rx @ Ry = [[cb, 0, sb], [sa sb, ca, -sa cb], [-ca sb, sa, ca cb]]
+    const D xy10 = sa * sb, xy12 = neg(sa * cb), xy20 = neg(ca * sb), xy22 = ca * cb;
+    Mat3 R;
+    R.m[0][0] = cb * cc;               R.m[0][1] = neg(cb * sc);           R.m[0][2] = sb;
+    R.m[1][0] = xy10 * cc + ca * sc;   R.m[1][1] = ca * cc - xy10 * sc;    R.m[1][2] = xy12;
+    R.m[2][0] = xy20 * cc + sa * sc;   R.m[2][1] = sa * cc - xy20 * sc;    R.m[2][2] = xy22;
     return R;
 }
 
@@ -163,6 +218,7 @@ struct RoiIn {
     float K[4];        // fx, fy, cx, cy of the image intrinsics scaled to the network resolution
     float v2r;         // virtual_to_real = (H_net * f_virtual... ) see host
     float prior[3];    // prior mean dims of the class
+    float pstd[3];     // prior std of the class (DIMS_PRIORS_FUNC 'sigmoid')
 };
 
 // decode only (also used at inference): returns values + (optionally) duals
@@ -170,40 +226,62 @@ struct Decoded {
     D x, y, z, dims[3], u;
     Mat3 pose;
 };
-__device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn& in, int tl) {
-    const int c = in.cls;
+__device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn& in, int tl, const int mode) {
+    const int c = in.cls, Pn = M_POSE_WIDTH(mode);
     const float* pxy = hrow + 2 * c;
     const float* pz = hrow + 2 * K + c;
     const float* pd = hrow + 3 * K + 3 * c;
-    const float* pp = hrow + 6 * K + 6 * c;
-    const float* pu = hrow + 12 * K + c;
+    const float* pp = hrow + 6 * K + Pn * c;
     Decoded o;
     const float sw = in.box[2] - in.box[0], sh = in.box[3] - in.box[1];
     const float cx = in.box[0] + 0.5f * sw, cy = in.box[1] + 0.5f * sh;
     o.x = var(pxy[0], 0, tl) * sw + cx;                 // roi_heads.py:460-461
     o.y = var(pxy[1], 1, tl) * sh + cy;
-    o.z = var(pz[0], 2, tl) * in.v2r;                   // z_type 'direct' + virtual depth (roi_heads.py:524-525)
-    for (int k = 0; k < 3; ++k) o.dims[k] = dexp(clip_max(var(pd[k], 3 + k, tl), 5.f)) * in.prior[k];   // :479
-    D p6[6];
-    for (int k = 0; k < 6; ++k) p6[k] = var(pp[k], 6 + k, tl);
-    const Mat3 Rv = rot6d(p6);                      // cube_head.py:176
-    float M[3][3];
-    bool valid;
-    allocentric_M(in.K[0], in.K[1], in.K[2], in.K[3], o.x.v, o.y.v, M, valid);
-    if (valid) {
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) o.pose.m[i][j] = Rv.m[0][j] * M[i][0] + Rv.m[1][j] * M[i][1] + Rv.m[2][j] * M[i][2];
-    } else {
-        o.pose = Rv;
+    D z = var(pz[0], 2, tl);                            // Z_TYPE (roi_heads.py:493-500)
+    if (M_Z(mode) == 1) z = dsigmoid(z) * 100.f;
+    else if (M_Z(mode) == 2) z = dexp(z);
+    o.z = M_VDEPTH(mode) ? z * in.v2r : z;              // virtual depth (roi_heads.py:524-525)
+    for (int k = 0; k < 3; ++k) {                       // roi_heads.py:467-484
+        const D d = var(pd[k], 3 + k, tl);
+        if (M_DIMS(mode) == 0) o.dims[k] = dexp(clip_max(d, 5.f)) * in.prior[k];
+        else if (M_DIMS(mode) == 1) {                   // util.scaled_sigmoid(d, min = (mean - 3 std).clip(0), max = mean + 3 std)
+            const float mn = fmaxf(in.prior[k] - 3.f * in.pstd[k], 0.f), mx = in.prior[k] + 3.f * in.pstd[k];
+            o.dims[k] = dsigmoid(d) * (mx - mn) + mn;
+        } else o.dims[k] = dexp(clip_max(d, 5.f));
     }
-    o.u = clip_min(var(pu[0], 12, tl), 0.01f);          // cube_head.py:163
+    Mat3 Rv;
+    if (M_POSE(mode) == 0) {
+        D p6[6];
+        for (int k = 0; k < 6; ++k) p6[k] = var(pp[k], 6 + k, tl);
+        Rv = rot6d(p6);                                 // cube_head.py:176
+    } else if (M_POSE(mode) == 1) {
+        D q[4];
+        for (int k = 0; k < 4; ++k) q[k] = var(pp[k], 6 + k, tl);
+        Rv = rot_quat(q);
+    } else {
+        D e[3];
+        for (int k = 0; k < 3; ++k) e[k] = var(pp[k], 6 + k, tl);
+        Rv = rot_euler(e);
+    }
+    o.pose = Rv;
+    if (M_ALLOC(mode)) {
+        float M[3][3];
+        bool valid;
+        allocentric_M(in.K[0], in.K[1], in.K[2], in.K[3], o.x.v, o.y.v, M, valid);
+        if (valid)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) o.pose.m[i][j] = Rv.m[0][j] * M[i][0] + Rv.m[1][j] * M[i][1] + Rv.m[2][j] * M[i][2];
+    }
+    if (M_CONF(mode)) o.u = clip_min(var(hrow[(6 + Pn) * K + c], 12, tl), 0.01f);          // cube_head.py:163
+    else o.u = cst(0.f);
     return o;
 }
 
 // ---- training forward: per-ROI losses (6) + Jacobian (6 x 13) + logging terms -----------------------
 // vals (F, 13): [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, u,  total3d_report, z_err, dims_err(sum3), xy_err(sum2), conf, joint_valid, row_valid]
 // rows whose class is outside [0, K) (background / padding slots of the fixed-capacity ROI set) are skipped: row_valid = 0.
-__global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restrict__ head, int ldh, int F, int K,
+template <int FIXED>
+__global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restrict__ head, int ldh, int F, int K, int mode_rt,
                                                            const float* __restrict__ boxes, const int* __restrict__ cls,
                                                            const int* __restrict__ img, const float* __restrict__ Ks,
                                                            const float* __restrict__ v2r, const float* __restrict__ priors,
@@ -211,6 +289,7 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
                                                            const int* __restrict__ gt_row, float wd, float wp, float wxy,
                                                            float wz, float wj, float* __restrict__ vals, float* __restrict__ jac) {
     const int f = blockIdx.x * 4 + ((int)threadIdx.x >> 4), tl = (int)threadIdx.x & 15;   // ROI of this 16-lane group, tangent slot
+    const int mode = FIXED >= 0 ? FIXED : mode_rt;
     if (f >= F) return;
     RoiIn in;
     for (int k = 0; k < 4; ++k) in.box[k] = boxes[4 * f + k];
@@ -222,8 +301,8 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
     const int im = img[f];
     for (int k = 0; k < 4; ++k) in.K[k] = Ks[4 * im + k];
     in.v2r = v2r[im];
-    for (int k = 0; k < 3; ++k) in.prior[k] = priors[(in.cls * 2 + 0) * 3 + k];
-    const Decoded o = decode(head + (long)f * ldh, K, in, tl);
+    for (int k = 0; k < 3; ++k) { in.prior[k] = priors[(in.cls * 2 + 0) * 3 + k]; in.pstd[k] = priors[(in.cls * 2 + 1) * 3 + k]; }
+    const Decoded o = decode(head + (long)f * ldh, K, in, tl, mode);
     const float* g = gt3d + 9 * gt_row[f];
     const float* gp = gtpose + 9 * gt_row[f];
     const float fx = in.K[0], fy = in.K[1], sx = in.K[2], sy = in.K[3];
@@ -240,17 +319,25 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
     corners((o.x + (-sx)) * (gz / fx), (o.y + (-sy)) * (gz / fy), gZ, gW, gH, gL, Rg, ctmp);
     D loss_xy = l1_mean(ctmp, cgt);
     corners(gX, gY, gZ, gW, gH, gL, o.pose, ctmp);
-    D loss_pose = chamfer(ctmp, cgt);
+    D loss_pose = M_CHAMFER(mode) ? chamfer(ctmp, cgt) : l1_mean(ctmp, cgt);        // roi_heads.py:597-601
     corners(gX, gY, gZ, o.dims[0], o.dims[1], o.dims[2], Rg, ctmp);
     D loss_dims = l1_mean(ctmp, cgt);
-    // joint (roi_heads.py:671-677)
-    corners(o.z * (o.x + (-sx)) * (1.f / fx), o.z * (o.y + (-sy)) * (1.f / fy), o.z, o.dims[0], o.dims[1], o.dims[2], o.pose, ctmp);
-    D loss_joint = chamfer(ctmp, cgt);
-    const float joint_valid = loss_joint.v < INFINITY ? 1.f : 0.f;
-    // total_3D_loss_for_reporting (roi_heads.py:651-683): the WEIGHTED sum of the raw per-ROI terms
-    const float total = wd * loss_dims.v + wp * loss_pose.v + wxy * loss_xy.v + wz * loss_z.v + wj * loss_joint.v;
+    // joint (roi_heads.py:664-683), only when LOSS_W_JOINT > 0
+    D loss_joint = cst(0.f);
+    float joint_valid = 0.f;
+    float total = wd * loss_dims.v + wp * loss_pose.v + wxy * loss_xy.v + wz * loss_z.v;   // total_3D_loss_for_reporting (:651-683)
+    if (M_JOINT(mode)) {
+        corners(o.z * (o.x + (-sx)) * (1.f / fx), o.z * (o.y + (-sy)) * (1.f / fy), o.z, o.dims[0], o.dims[1], o.dims[2], o.pose, ctmp);
+        loss_joint = M_CHAMFER(mode) ? chamfer(ctmp, cgt) : l1_mean(ctmp, cgt);
+        joint_valid = loss_joint.v < INFINITY ? 1.f : 0.f;
+        total += wj * loss_joint.v;
+    }
+    if (M_INVZ(mode)) {                                  // roi_heads.py:697-719: 1 / log(clip(gt_z, e))
+        const float iz = 1.f / logf(fmaxf(gz, 2.71828183f));
+        loss_dims = loss_dims * iz; loss_xy = loss_xy * iz; loss_z = loss_z * iz; loss_pose = loss_pose * iz; loss_joint = loss_joint * iz;
+    }
     // uncertainty weighting (roi_heads.py:721-739)
-    const D sf = dexp(neg(o.u)) * 1.41421356f;
+    const D sf = M_CONF(mode) ? dexp(neg(o.u)) * 1.41421356f : cst(1.f);
     D L[6] = {loss_dims * sf, loss_xy * sf, loss_z * sf, loss_pose * sf, loss_joint * sf, o.u};
     float* vo = vals + (long)f * 13;
     if (tl < NT)
@@ -261,7 +348,7 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
         vo[7] = fabsf(o.z.v - gz);
         vo[8] = fabsf(o.dims[0].v - g[3]) + fabsf(o.dims[1].v - g[4]) + fabsf(o.dims[2].v - g[5]);
         vo[9] = fabsf(o.x.v - gu) + fabsf(o.y.v - gv);
-        vo[10] = expf(-o.u.v);
+        vo[10] = M_CONF(mode) ? expf(-o.u.v) : 0.f;
         vo[11] = joint_valid;
         vo[12] = 1.f;
     }
@@ -312,7 +399,7 @@ __global__ void __launch_bounds__(256) cube_reduce_kernel(const float* __restric
 // dhead (F, ldh) = sum_k gk[k] * w_k(f) * J[f][k][:] scattered to the class columns; rest zero.
 __global__ void __launch_bounds__(64) cube_loss_bwd_kernel(const float* __restrict__ vals, const float* __restrict__ jac,
                                                            const float* __restrict__ red, const float* __restrict__ gk,
-                                                           const int* __restrict__ cls, int F, int K, int ldh,
+                                                           const int* __restrict__ cls, int F, int K, int mode, int ldh,
                                                            float* __restrict__ dhead) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
@@ -333,19 +420,22 @@ __global__ void __launch_bounds__(64) cube_loss_bwd_kernel(const float* __restri
     row[2 * c + 0] = d[0]; row[2 * c + 1] = d[1];
     row[2 * K + c] = d[2];
     for (int k = 0; k < 3; ++k) row[3 * K + 3 * c + k] = d[3 + k];
-    for (int k = 0; k < 6; ++k) row[6 * K + 6 * c + k] = d[6 + k];
-    row[12 * K + c] = d[12];
+    const int Pn = M_POSE_WIDTH(mode);
+    for (int k = 0; k < Pn; ++k) row[6 * K + Pn * c + k] = d[6 + k];
+    if (M_CONF(mode)) row[(6 + Pn) * K + c] = d[12];
 }
 
 // ---- inference / output decode (roi_heads.py:774-819): cube_3D (F, 9) = [X, Y, Z, w, h, l, u*s, v*s, conf],
 //      pose (F, 9), corners (F, 24) ----------------------------------------------------------------
-__global__ void __launch_bounds__(64) cube_decode_kernel(const float* __restrict__ head, int ldh, int F, int K,
+template <int FIXED>
+__global__ void __launch_bounds__(64) cube_decode_kernel(const float* __restrict__ head, int ldh, int F, int K, int mode_rt,
                                                          const float* __restrict__ boxes, const int* __restrict__ cls,
                                                          const int* __restrict__ img, const float* __restrict__ Ks,
                                                          const float* __restrict__ v2r, const float* __restrict__ ratio,
                                                          const float* __restrict__ priors, float* __restrict__ cube3d,
                                                          float* __restrict__ pose, float* __restrict__ verts) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int mode = FIXED >= 0 ? FIXED : mode_rt;
     if (f >= F) return;
     RoiIn in;
     for (int k = 0; k < 4; ++k) in.box[k] = boxes[4 * f + k];
@@ -353,12 +443,15 @@ __global__ void __launch_bounds__(64) cube_decode_kernel(const float* __restrict
     const int im = img[f];
     for (int k = 0; k < 4; ++k) in.K[k] = Ks[4 * im + k];
     in.v2r = v2r[im];
-    for (int k = 0; k < 3; ++k) in.prior[k] = priors[(in.cls * 2 + 0) * 3 + k];
-    const Decoded o = decode(head + (long)f * ldh, K, in, -1);
+    for (int k = 0; k < 3; ++k) { in.prior[k] = priors[(in.cls * 2 + 0) * 3 + k]; in.pstd[k] = priors[(in.cls * 2 + 1) * 3 + k]; }
+    const Decoded o = decode(head + (long)f * ldh, K, in, -1, mode);
     const float X = o.z.v * (o.x.v - in.K[2]) / in.K[0], Y = o.z.v * (o.y.v - in.K[3]) / in.K[1];
     float* c3 = cube3d + 9 * f;
     c3[0] = X; c3[1] = Y; c3[2] = o.z.v; c3[3] = o.dims[0].v; c3[4] = o.dims[1].v; c3[5] = o.dims[2].v;
-    c3[6] = o.x.v * ratio[im]; c3[7] = o.y.v * ratio[im]; c3[8] = expf(-o.u.v);
+    c3[6] = o.x.v * ratio[im]; c3[7] = o.y.v * ratio[im];
+    // without USE_CONFIDENCE the reference's cube_3D has 8 columns and its score merge reads `cube_3D_i[:, -1]`, i.e. the
+    // scaled v coordinate (roi_heads.py:781-803); the 9th column carries exactly that so the host code stays mode-free
+    c3[8] = M_CONF(mode) ? expf(-o.u.v) : c3[7];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) pose[9 * f + 3 * i + j] = o.pose.m[i][j].v;
     V3 cv[8];
     corners(cst(X), cst(Y), cst(o.z.v), o.dims[0], o.dims[1], o.dims[2], o.pose, cv);
@@ -389,36 +482,45 @@ extern "C" {
 // img (F) image index; Ks (B,4) = [fx, fy, cx, cy] scaled to network resolution; v2r (B) virtual->real depth
 // factor; priors (K,2,3); gt3d (G,9) gt_boxes3D rows; gtpose (G,9); gt_row (F).
 // vals (F,13), jac (F,6,13), red (24) outputs.  Rows with cls outside [0,K) are ignored.
-int omni_cube_loss_fwd(const float* head, int ldh, int F, int K, const float* boxes, const int* cls, const int* img,
+int omni_cube_loss_fwd(const float* head, int ldh, int F, int K, int mode, const float* boxes, const int* cls, const int* img,
                        const float* Ks, const float* v2r, const float* priors, const float* gt3d, const float* gtpose,
                        const int* gt_row, float w_dims, float w_pose, float w_xy, float w_z, float w_joint, float* vals, float* jac,
                        float* red, void* stream) {
-    if (F < 0 || K <= 0 || ldh < 13 * K) return OMNI_ERR_ARG;
+    if (F < 0 || K <= 0 || !MODE_VALID(mode) || ldh < M_HEAD_WIDTH(mode) * K) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (F > 0)      // 16 lanes per ROI (one tangent each), 4 ROIs per wave
-        hipLaunchKernelGGL(cube_loss_fwd_kernel, dim3((F + 3) / 4), dim3(64), 0, st, head, ldh, F, K, boxes, cls, img, Ks,
-                           v2r, priors, gt3d, gtpose, gt_row, w_dims, w_pose, w_xy, w_z, w_joint, vals, jac);
+    if (F > 0) {    // 16 lanes per ROI (one tangent each), 4 ROIs per wave
+        if (mode == MODE_BASE)
+            hipLaunchKernelGGL(cube_loss_fwd_kernel<MODE_BASE>, dim3((F + 3) / 4), dim3(64), 0, st, head, ldh, F, K, mode, boxes, cls,
+                               img, Ks, v2r, priors, gt3d, gtpose, gt_row, w_dims, w_pose, w_xy, w_z, w_joint, vals, jac);
+        else
+            hipLaunchKernelGGL(cube_loss_fwd_kernel<-1>, dim3((F + 3) / 4), dim3(64), 0, st, head, ldh, F, K, mode, boxes, cls,
+                               img, Ks, v2r, priors, gt3d, gtpose, gt_row, w_dims, w_pose, w_xy, w_z, w_joint, vals, jac);
+    }
     hipLaunchKernelGGL(cube_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)vals, F, red);
     return omni_launch_status();
 }
 
 // gk (6) device floats: upstream gradients of [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert].
 int omni_cube_loss_bwd(const float* vals, const float* jac, const float* red, const float* gk, const int* cls, int F,
-                       int K, int ldh, float* dhead, void* stream) {
-    if (F < 0 || K <= 0 || ldh < 13 * K) return OMNI_ERR_ARG;
+                       int K, int mode, int ldh, float* dhead, void* stream) {
+    if (F < 0 || K <= 0 || !MODE_VALID(mode) || ldh < M_HEAD_WIDTH(mode) * K) return OMNI_ERR_ARG;
     if (F == 0) return OMNI_OK;
     hipLaunchKernelGGL(cube_loss_bwd_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, vals, jac, red, gk, cls,
-                       F, K, ldh, dhead);
+                       F, K, mode, ldh, dhead);
     return omni_launch_status();
 }
 
-int omni_cube_decode(const float* head, int ldh, int F, int K, const float* boxes, const int* cls, const int* img,
+int omni_cube_decode(const float* head, int ldh, int F, int K, int mode, const float* boxes, const int* cls, const int* img,
                      const float* Ks, const float* v2r, const float* ratio, const float* priors, float* cube3d,
                      float* pose, float* verts, void* stream) {
-    if (F < 0 || K <= 0 || ldh < 13 * K) return OMNI_ERR_ARG;
+    if (F < 0 || K <= 0 || !MODE_VALID(mode) || ldh < M_HEAD_WIDTH(mode) * K) return OMNI_ERR_ARG;
     if (F == 0) return OMNI_OK;
-    hipLaunchKernelGGL(cube_decode_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, head, ldh, F, K, boxes,
-                       cls, img, Ks, v2r, ratio, priors, cube3d, pose, verts);
+    if (mode == MODE_BASE)
+        hipLaunchKernelGGL(cube_decode_kernel<MODE_BASE>, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, head, ldh, F, K,
+                           mode, boxes, cls, img, Ks, v2r, ratio, priors, cube3d, pose, verts);
+    else
+        hipLaunchKernelGGL(cube_decode_kernel<-1>, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, head, ldh, F, K,
+                           mode, boxes, cls, img, Ks, v2r, ratio, priors, cube3d, pose, verts);
     return omni_launch_status();
 }
 

@@ -1,32 +1,42 @@
-"""`CubeHead` (own ROI_CUBE_HEAD_REGISTRY), default configuration of the reference
-(/root/reference/cubercnn/modeling/roi_heads/cube_head.py:19-197): shared fc1/fc2 + ReLU
-(`feature_generator.fc1/fc2`), five linear heads `bbox_3D_dims` (3K), `bbox_3D_center_deltas` (2K),
-`bbox_3D_pose` (6K), `bbox_3D_center_depth` (K), `bbox_3D_uncertainty` (K, bias 5).
+"""`CubeHead` (own ROI_CUBE_HEAD_REGISTRY) of the reference (/root/reference/cubercnn/modeling/roi_heads/cube_head.py:19-197):
+FC feature generator(s) + ReLU -- one shared `feature_generator.fc1..fcN` (SHARED_FC, configs/Base.yaml) or one per output
+group (`feature_generator_{XY,dims,pose,Z,conf}`) -- and the linear heads `bbox_3D_dims` (3K), `bbox_3D_center_deltas` (2K),
+`bbox_3D_pose` (6K / 4K / 3K for POSE_TYPE 6d / quaternion / euler), `bbox_3D_center_depth` (K) and, with USE_CONFIDENCE,
+`bbox_3D_uncertainty` (K, bias 5).  Parameter names equal the reference's, so its checkpoints load.
 
-The reference evaluates rotation_6d_to_matrix for ALL K classes of every ROI and gathers the GT class
-afterwards (cube_head.py:176, roi_heads.py:447-457).  Here the five heads are ONE fused GEMM
-(1024 -> 13K, padded to a multiple of 16) whose raw output goes to the fused decode / loss kernel,
-which gathers the class first."""
+The reference evaluates the rotation for ALL K classes of every ROI and gathers the GT class afterwards (cube_head.py:175-185,
+roi_heads.py:447-457).  Here the heads are ONE fused GEMM (fc_dim -> width*K, padded to a multiple of 16) whose raw output goes
+to the fused decode / loss kernel (csrc/cube_head.hip), which gathers the class first and applies the pose / depth /
+dimension parameterisation named by `self.mode`.  Z_TYPE 'clusters' (CLUSTER_BINS > 1) is not built."""
 import torch
 from torch import nn
 
 from .... import functional as HF
 from ....d2.registry import Registry
+from ....kernels import det
 from ..layers import FlattenLinear, Linear
 
 ROI_CUBE_HEAD_REGISTRY = Registry("ROI_CUBE_HEAD")
 
 
 class _FeatureGenerator(nn.Module):
-    def __init__(self, channels, size, fc_dim):
+    """fc1 (on the flattened ROI feature) .. fcN, each followed by ReLU (cube_head.py:63-103)"""
+
+    def __init__(self, channels, size, fc_dim, num_fc=2):
         super().__init__()
+        self.num_fc = num_fc
         self.fc1 = FlattenLinear(channels, size, fc_dim)
-        self.fc2 = Linear(fc_dim, fc_dim)
-        nn.init.kaiming_uniform_(self.fc2.weight, a=1)
-        nn.init.constant_(self.fc2.bias, 0)
+        for k in range(2, num_fc + 1):
+            fc = Linear(fc_dim, fc_dim)
+            nn.init.kaiming_uniform_(fc.weight, a=1)
+            nn.init.constant_(fc.bias, 0)
+            setattr(self, f"fc{k}", fc)
 
     def forward(self, x):
-        return self.fc2(self.fc1(x, relu=True), relu=True)
+        x = self.fc1(x, relu=True)
+        for k in range(2, self.num_fc + 1):
+            x = getattr(self, f"fc{k}")(x, relu=True)
+        return x
 
 
 @ROI_CUBE_HEAD_REGISTRY.register()
@@ -34,41 +44,72 @@ class CubeHead(nn.Module):
     def __init__(self, cfg, input_shape):
         super().__init__()
         c = cfg.MODEL.ROI_CUBE_HEAD
-        self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
-        if not (c.SHARED_FC and c.Z_TYPE == "direct" and c.POSE_TYPE == "6d" and c.CLUSTER_BINS == 1 and c.NUM_CONV == 0
-                and c.NUM_FC == 2 and c.USE_CONFIDENCE):
-            if c.POSE_TYPE not in ("6d", "quaternion", "euler"):
-                raise ValueError("Cuboid pose type {} is not recognized".format(c.POSE_TYPE))
-            raise NotImplementedError("MI355X hot path implements the Base.yaml cube head (shared FC, z direct, 6d pose, confidence)")
-        K = self.num_classes
-        self.feature_generator = _FeatureGenerator(input_shape.channels, input_shape.height, c.FC_DIM)
+        self.num_classes = K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        if c.POSE_TYPE not in det.POSE_WIDTH:
+            raise ValueError("Cuboid pose type {} is not recognized".format(c.POSE_TYPE))
+        if c.CLUSTER_BINS != 1 or c.Z_TYPE == "clusters":
+            raise NotImplementedError("MI355X hot path: Z_TYPE 'clusters' / CLUSTER_BINS > 1 is not built (direct, sigmoid, log are)")
+        if c.NUM_FC < 1:
+            raise NotImplementedError("CubeHead needs NUM_FC >= 1 (the reference builds no conv layers either, cube_head.py:49-103)")
+        self.use_conf, self.shared_fc, self.pose_type = bool(c.USE_CONFIDENCE), bool(c.SHARED_FC), c.POSE_TYPE
+        gen = lambda: _FeatureGenerator(input_shape.channels, input_shape.height, c.FC_DIM, c.NUM_FC)   # noqa: E731
+        if self.shared_fc:
+            self.feature_generator = gen()
+        else:
+            self.feature_generator_XY, self.feature_generator_dims = gen(), gen()
+            self.feature_generator_pose, self.feature_generator_Z = gen(), gen()
+            if self.use_conf:
+                self.feature_generator_conf = gen()
         self.bbox_3D_dims = Linear(c.FC_DIM, K * 3)
         self.bbox_3D_center_deltas = Linear(c.FC_DIM, K * 2)
-        self.bbox_3D_pose = Linear(c.FC_DIM, K * 6)
+        self.bbox_3D_pose = Linear(c.FC_DIM, K * det.POSE_WIDTH[c.POSE_TYPE])
         self.bbox_3D_center_depth = Linear(c.FC_DIM, K)
-        self.bbox_3D_uncertainty = Linear(c.FC_DIM, K)
-        for m in (self.bbox_3D_dims, self.bbox_3D_center_deltas, self.bbox_3D_pose, self.bbox_3D_center_depth,
-                  self.bbox_3D_uncertainty):
+        heads = [self.bbox_3D_dims, self.bbox_3D_center_deltas, self.bbox_3D_pose, self.bbox_3D_center_depth]
+        if self.use_conf:
+            self.bbox_3D_uncertainty = Linear(c.FC_DIM, K)
+            heads.append(self.bbox_3D_uncertainty)
+        for m in heads:
             nn.init.normal_(m.weight, std=0.001)
             nn.init.constant_(m.bias, 0)
-        nn.init.constant_(self.bbox_3D_uncertainty.bias, 5)
-        self.fused_dim = (13 * K + 15) // 16 * 16
+        if self.use_conf:
+            nn.init.constant_(self.bbox_3D_uncertainty.bias, 5)
+        self.width = 6 + det.POSE_WIDTH[c.POSE_TYPE] + int(self.use_conf)      # columns per class of the fused output
+        self.fused_dim = (self.width * K + 15) // 16 * 16
+
+    def _parts(self):
+        """the linear heads in the column order of the fused decode kernel: [center_deltas 2K | center_depth K | dims 3K | pose | uncertainty K]"""
+        parts = [self.bbox_3D_center_deltas, self.bbox_3D_center_depth, self.bbox_3D_dims, self.bbox_3D_pose]
+        return parts + ([self.bbox_3D_uncertainty] if self.use_conf else [])
 
     def fused_parameters(self):
-        """(13K_pad, 1024) weight and bias in the column order of the fused decode kernel:
-        [center_deltas 2K | center_depth K | dims 3K | pose 6K | uncertainty K | zero pad]."""
-        parts = (self.bbox_3D_center_deltas, self.bbox_3D_center_depth, self.bbox_3D_dims, self.bbox_3D_pose,
-                 self.bbox_3D_uncertainty)
-        pad = self.fused_dim - 13 * self.num_classes
+        """(width*K padded, fc_dim) weight and bias of the one GEMM that replaces the separate heads (shared FC only)."""
+        parts = self._parts()
+        pad = self.fused_dim - self.width * self.num_classes
         w = torch.cat([m.weight for m in parts] + [parts[0].weight.new_zeros(pad, parts[0].weight.shape[1])], dim=0)
         b = torch.cat([m.bias for m in parts] + [parts[0].bias.new_zeros(pad)], dim=0)
         return w, b
 
     def forward(self, x):
-        """x (n, C, 7, 7) ROI features -> raw fused head outputs (n, 13K_pad)."""
-        feats = self.feature_generator(x)
-        w, b = self.fused_parameters()
-        return HF.linear(feats, w, b)
+        """x (n, C, 7, 7) ROI features -> raw fused head outputs (n, width*K padded)."""
+        if self.shared_fc:
+            feats = self.feature_generator(x)
+            w, b = self.fused_parameters()
+            return HF.linear(feats, w, b)
+        # SHARED_FC False (cube_head.py:165-173): every output group has its own FC stack
+        gens = [self.feature_generator_XY, self.feature_generator_Z, self.feature_generator_dims, self.feature_generator_pose]
+        if self.use_conf:
+            gens.append(self.feature_generator_conf)
+        outs = []
+        for g, m in zip(gens, self._parts()):
+            n = m.weight.shape[0]
+            p4 = (n + 15) // 16 * 16 - n              # the GEMM kernels want an output width that is a multiple of 4
+            w = torch.cat([m.weight, m.weight.new_zeros(p4, m.weight.shape[1])], 0) if p4 else m.weight
+            b = torch.cat([m.bias, m.bias.new_zeros(p4)], 0) if p4 else m.bias
+            outs.append(HF.linear(g(x), w, b)[:, :n])
+        pad = self.fused_dim - self.width * self.num_classes
+        if pad:
+            outs.append(outs[0].new_zeros(outs[0].shape[0], pad))
+        return torch.cat(outs, dim=1).contiguous()
 
 
 def build_cube_head(cfg, input_shape):

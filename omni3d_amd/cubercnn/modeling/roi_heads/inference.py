@@ -35,7 +35,8 @@ def roi_heads_inference(heads, images, feats, proposals, packed):
     xc = heads.cube_pooler(feats, dboxes, dimg)
     head = heads.cube_head(xc)
     priors = heads.priors_dims_per_cat.detach().reshape(K, 2, 3).contiguous()
-    cube3d, pose, verts = det.cube_decode(head.contiguous(), K, dboxes, dcl, dimg, packed.Ks, packed.v2r, packed.ratio, priors)
+    cube3d, pose, verts = det.cube_decode(head.contiguous(), K, dboxes, dcl, dimg, packed.Ks, packed.v2r, packed.ratio, priors,
+                                           heads.cube_mode)
     final = (dscore.view(-1) * cube3d[:, 8]) ** 0.5                                               # roi_heads.py:800-801
     full = torch.gather(probs.view(B, P, K), 1, droi.long()[:, :, None].expand(-1, -1, K))        # scores of all classes per kept roi
     counts = dcount.tolist()                                                                      # the one host sync

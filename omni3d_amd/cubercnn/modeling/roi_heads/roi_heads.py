@@ -121,12 +121,18 @@ class ROIHeads3D(nn.Module):
         self.loss_w_3d, self.loss_w_xy, self.loss_w_z = loss_w_3d, loss_w_xy, loss_w_z
         self.loss_w_dims, self.loss_w_pose, self.loss_w_joint = loss_w_dims, loss_w_pose, loss_w_joint
         self.use_confidence, self.virtual_focal, self.test_scale = use_confidence, virtual_focal, test_scale
-        unsupported = (inverse_z_weight or z_type != "direct" or pose_type != "6d" or cluster_bins != 1 or not dims_priors_enabled
-                       or dims_priors_func != "exp" or not disentangled_loss or not virtual_depth or not allocentric_pose
-                       or not chamfer_pose or scale_roi_boxes or train_on_pred_boxes or loss_w_3d <= 0 or loss_w_joint <= 0
-                       or not use_confidence)
-        if unsupported:
-            raise NotImplementedError("MI355X hot path implements the ROI_CUBE_HEAD configuration of configs/Base.yaml")
+        if cluster_bins != 1 or z_type == "clusters":
+            raise NotImplementedError("MI355X hot path: Z_TYPE 'clusters' / CLUSTER_BINS > 1 is not built (direct, sigmoid, log are)")
+        if not disentangled_loss:
+            raise NotImplementedError("MI355X hot path: DISENTANGLED_LOSS False (so3_relative_angle / normalised-space losses, "
+                                      "roi_heads.py:603-649) is not built; every released config trains disentangled")
+        if scale_roi_boxes or train_on_pred_boxes:
+            raise NotImplementedError("MI355X hot path: SCALE_ROI_BOXES / TRAIN_ON_PRED_BOXES are not built (0.0 / False in every config)")
+        if loss_w_3d <= 0:
+            raise NotImplementedError("MI355X hot path: LOSS_W_3D <= 0 (2D-only training) is not built")
+        # head parameterisation + loss switches for csrc/cube_head.hip (bit layout: include/omni3d_hip.h)
+        self.cube_mode = det.cube_mode(z_type, dims_priors_enabled, dims_priors_func, pose_type, allocentric_pose, virtual_depth,
+                                       chamfer_pose, inverse_z_weight, use_confidence > 0, loss_w_joint > 0)
         self.cube_head, self.cube_pooler = cube_head, cube_pooler
         if priors is not None:
             self.priors_dims_per_cat = nn.Parameter(torch.FloatTensor(priors["priors_dims_per_cat"]).unsqueeze(0))
@@ -242,16 +248,22 @@ class ROIHeads3D(nn.Module):
         head = self.cube_head(x)
         priors = self.priors_dims_per_cat.detach().reshape(self.num_classes, 2, 3).contiguous()
         red6, red = HF.cube_loss(head, self.num_classes, rois, cls, bidx, packed.Ks, packed.v2r, priors, packed.gt3d,
-                                 packed.gtpose, gt_row, (self.loss_w_dims, self.loss_w_pose, self.loss_w_xy, self.loss_w_z, self.loss_w_joint))
+                                 packed.gtpose, gt_row, (self.loss_w_dims, self.loss_w_pose, self.loss_w_xy, self.loss_w_z, self.loss_w_joint),
+                                 self.cube_mode)
         self.pending_logs["cube"] = red
         w3 = self.loss_w_3d
         p = "Cube/"
-        return {
-            p + "uncert": self.use_confidence * red6[5],
-            p + "loss_dims": red6[0] * self.loss_w_dims * w3, p + "loss_xy": red6[1] * self.loss_w_xy * w3,
-            p + "loss_z": red6[2] * self.loss_w_z * w3, p + "loss_pose": red6[3] * self.loss_w_pose * w3,
-            p + "loss_joint": red6[4] * self.loss_w_joint * w3,
-        }
+        losses = {}
+        if self.use_confidence > 0:                                   # roi_heads.py:721-740
+            losses[p + "uncert"] = self.use_confidence * red6[5]
+        if self.loss_w_dims > 0:                                      # roi_heads.py:745-748
+            losses[p + "loss_dims"] = red6[0] * self.loss_w_dims * w3
+        losses[p + "loss_xy"] = red6[1] * self.loss_w_xy * w3
+        losses[p + "loss_z"] = red6[2] * self.loss_w_z * w3
+        losses[p + "loss_pose"] = red6[3] * self.loss_w_pose * w3
+        if self.loss_w_joint > 0:                                     # roi_heads.py:766-768
+            losses[p + "loss_joint"] = red6[4] * self.loss_w_joint * w3
+        return losses
 
     def flush_logs(self, storage):
         self.box_predictor.flush_logs(storage)
@@ -262,5 +274,7 @@ class ROIHeads3D(nn.Module):
         if "cube" in self.pending_logs:
             r = self.pending_logs.pop("cube").tolist()
             for name, k in (("z_error", 13), ("dims_error", 14), ("xy_error", 15), ("z_close", 16), ("conf", 17)):
+                if name == "conf" and not self.use_confidence > 0:
+                    continue
                 storage.put_scalar("Cube/" + name, r[k], smoothing_hint=False)
             storage.put_scalar("Cube/total_3D_loss", self.loss_w_3d * r[12], smoothing_hint=False)

@@ -397,24 +397,24 @@ class _CubeLoss(Function):
     """-> (red[0:6] = loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert ; red (24) stats)."""
 
     @staticmethod
-    def forward(ctx, head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w):
+    def forward(ctx, head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w, mode):
         head = head.contiguous()
-        vals, jac, red = det.cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w)
+        vals, jac, red = det.cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w, mode)
         ctx.save_for_backward(vals, jac, red, cls)
-        ctx.meta = (head.shape[0], K, head.shape[1])
+        ctx.meta = (head.shape[0], K, head.shape[1], mode)
         ctx.mark_non_differentiable(red)
         return red[:6].clone(), red
 
     @staticmethod
     def backward(ctx, g, _):
         vals, jac, red, cls = ctx.saved_tensors
-        F_, K, ldh = ctx.meta
-        dhead = det.cube_loss_bwd(vals, jac, red, g.contiguous().float(), cls, F_, K, ldh)
-        return (dhead,) + (None,) * 11
+        F_, K, ldh, mode = ctx.meta
+        dhead = det.cube_loss_bwd(vals, jac, red, g.contiguous().float(), cls, F_, K, ldh, mode)
+        return (dhead,) + (None,) * 12
 
 
-def cube_loss(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0)):
-    return _CubeLoss.apply(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, tuple(loss_w))
+def cube_loss(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0), mode=det.CUBE_MODE_BASE):
+    return _CubeLoss.apply(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, tuple(loss_w), int(mode))
 
 
 class _MaxPool3s2(Function):

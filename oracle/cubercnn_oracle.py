@@ -193,25 +193,43 @@ def cube_head_outputs_to_fused(xy, z, dims, pose6, uncert):
     return torch.cat([xy.reshape(n, -1), z.reshape(n, -1), dims.reshape(n, -1), pose6.reshape(n, -1), uncert.reshape(n, -1)], 1)
 
 
-def cube_losses(head, num_classes, boxes, classes, Ks_scaled, virtual_to_real, prior_mean, gt_boxes3D, gt_poses):
-    """CubeHead.forward tail (cube_head.py:163,176,187-197) + ROIHeads3D._forward_cube training path
-    (roi_heads.py:410-768) for the default config (z 'direct', 6d pose, dims priors 'exp', virtual depth,
-    allocentric, disentangled + chamfer + joint, confidence).
-    head (n, 13K) raw fused linear outputs in the column order of cube_head_outputs_to_fused;
-    boxes (n,4) proposal boxes; classes (n,); Ks_scaled (n,3,3); virtual_to_real (n,); prior_mean (n,3);
-    gt_boxes3D (n,9); gt_poses (n,3,3).  -> (losses dict, stats dict)."""
+E_CONSTANT = 2.71828183        # roi_heads.py:28
+POSE_WIDTH = {"6d": 6, "quaternion": 4, "euler": 3}
+
+
+def cube_losses(head, num_classes, boxes, classes, Ks_scaled, virtual_to_real, prior_mean, gt_boxes3D, gt_poses, *,
+                prior_std=None, z_type="direct", dims_priors_enabled=True, dims_priors_func="exp", pose_type="6d",
+                allocentric_pose=True, virtual_depth=True, chamfer_pose=True, inverse_z_weight=False, use_confidence=True,
+                joint=True, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0)):
+    """CubeHead.forward tail (cube_head.py:163,175-197) + ROIHeads3D._forward_cube training path (roi_heads.py:410-768) with
+    DISENTANGLED_LOSS (every released config).  Defaults = configs/Base.yaml (z 'direct', 6d pose, dims priors 'exp', virtual
+    depth, allocentric, chamfer + joint, confidence); the keyword switches follow MODEL.ROI_CUBE_HEAD.{Z_TYPE, DIMS_PRIORS_*,
+    POSE_TYPE, ALLOCENTRIC_POSE, VIRTUAL_DEPTH, CHAMFER_POSE, INVERSE_Z_WEIGHT, USE_CONFIDENCE, LOSS_W_JOINT > 0}.
+    head (n, width*K) raw fused linear outputs [xy 2K | z K | dims 3K | pose Pn*K | uncert K if confidence];
+    boxes (n,4) proposal boxes; classes (n,); Ks_scaled (n,3,3); virtual_to_real (n,); prior_mean / prior_std (n,3);
+    gt_boxes3D (n,9); gt_poses (n,3,3); loss_w = (dims, pose, xy, z, joint) for the logged total.
+    -> (losses dict (unweighted means), stats dict, extras)."""
     K = num_classes
     n = head.shape[0]
     ar = torch.arange(n)
+    Pn = POSE_WIDTH[pose_type]
     box_2d_deltas = head[:, : 2 * K].view(n, K, 2)
     box_z = head[:, 2 * K: 3 * K].view(n, K, 1)
     box_dims = head[:, 3 * K: 6 * K].view(n, K, 3)
-    box_pose = U.rotation_6d_to_matrix(head[:, 6 * K: 12 * K].reshape(-1, 6)).view(n, K, 3, 3)
-    box_uncert = head[:, 12 * K: 13 * K].clip(0.01)
+    raw_pose = head[:, 6 * K: (6 + Pn) * K]
+    if pose_type == "6d":                                                     # cube_head.py:175-176
+        box_pose = U.rotation_6d_to_matrix(raw_pose.reshape(-1, 6))
+    elif pose_type == "quaternion":                                           # cube_head.py:178-182
+        quats = raw_pose.reshape(-1, 4)
+        quats = quats / U._copysign(torch.sqrt((quats * quats).sum(1)), quats[:, 0])[:, None]
+        box_pose = U.quaternion_to_matrix(quats)
+    else:                                                                     # cube_head.py:184-185
+        box_pose = U.euler_angles_to_matrix(raw_pose.reshape(-1, 3), "XYZ")
+    box_pose = box_pose.view(n, K, 3, 3)
     cube_z = box_z[ar, classes, :]
     cube_dims = box_dims[ar, classes, :]
     cube_pose = box_pose[ar, classes, :, :]
-    cube_uncert = box_uncert[ar, classes]
+    cube_uncert = head[:, (6 + Pn) * K: (7 + Pn) * K].clip(0.01)[ar, classes] if use_confidence else None
     cube_2d_deltas = box_2d_deltas[ar, classes, :]
     src_w = boxes[:, 2] - boxes[:, 0]
     src_h = boxes[:, 3] - boxes[:, 1]
@@ -220,9 +238,23 @@ def cube_losses(head, num_classes, boxes, classes, Ks_scaled, virtual_to_real, p
     cube_x = src_cx + src_w * cube_2d_deltas[:, 0]
     cube_y = src_cy + src_h * cube_2d_deltas[:, 1]
     cube_xy = torch.stack((cube_x, cube_y), dim=1)
-    cube_dims = torch.exp(cube_dims.clip(max=5)) * prior_mean
-    cube_pose = R_from_allocentric(Ks_scaled, cube_pose, u=cube_x.detach(), v=cube_y.detach())
-    cube_z = cube_z.squeeze(1) * virtual_to_real
+    if dims_priors_enabled:                                                   # roi_heads.py:467-484
+        if dims_priors_func == "sigmoid":
+            mn, mx = (prior_mean - 3 * prior_std).clip(0.0), prior_mean + 3 * prior_std
+            cube_dims = mn + (mx - mn) * torch.sigmoid(cube_dims)             # util.scaled_sigmoid (math_util.py:969-978)
+        else:
+            cube_dims = torch.exp(cube_dims.clip(max=5)) * prior_mean
+    else:
+        cube_dims = torch.exp(cube_dims.clip(max=5))
+    if allocentric_pose:                                                      # roi_heads.py:486-490
+        cube_pose = R_from_allocentric(Ks_scaled, cube_pose, u=cube_x.detach(), v=cube_y.detach())
+    cube_z = cube_z.squeeze(1)
+    if z_type == "sigmoid":                                                   # roi_heads.py:493-500
+        cube_z = torch.sigmoid(cube_z) * 100
+    elif z_type == "log":
+        cube_z = torch.exp(cube_z)
+    if virtual_depth:                                                         # roi_heads.py:524-525
+        cube_z = cube_z * virtual_to_real
     fx, fy, sx, sy = Ks_scaled[:, 0, 0], Ks_scaled[:, 1, 1], Ks_scaled[:, 0, 2], Ks_scaled[:, 1, 2]
     gt_2d, gt_z, gt_dims = gt_boxes3D[:, :2], gt_boxes3D[:, 2], gt_boxes3D[:, 3:6]
     gt_x3d = gt_z * (gt_2d[:, 0] - sx) / fx
@@ -230,27 +262,37 @@ def cube_losses(head, num_classes, boxes, classes, Ks_scaled, virtual_to_real, p
     gt_3d = torch.stack((gt_x3d, gt_y3d, gt_z)).T
     gt_box3d = torch.cat((gt_3d, gt_dims), dim=1)
     gt_corners = get_cuboid_verts(gt_box3d, gt_poses)
-    l1 = lambda a, b: F.smooth_l1_loss(a, b, reduction="none", beta=0.0)  # noqa: E731
+    l1 = lambda a, b: F.smooth_l1_loss(a, b, reduction="none", beta=0.0).contiguous().view(n, -1).mean(dim=1)  # noqa: E731
     dis_z = torch.cat((torch.stack((cube_z * (gt_2d[:, 0] - sx) / fx, cube_z * (gt_2d[:, 1] - sy) / fy, cube_z)).T, gt_dims), dim=1)
-    loss_z = l1(get_cuboid_verts(dis_z, gt_poses), gt_corners).contiguous().view(n, -1).mean(dim=1)
+    loss_z = l1(get_cuboid_verts(dis_z, gt_poses), gt_corners)
     dis_xy = torch.cat((torch.stack((gt_z * (cube_x - sx) / fx, gt_z * (cube_y - sy) / fy, gt_z)).T, gt_dims), dim=1)
-    loss_xy = l1(get_cuboid_verts(dis_xy, gt_poses), gt_corners).contiguous().view(n, -1).mean(dim=1)
-    loss_pose = chamfer_loss(get_cuboid_verts(gt_box3d, cube_pose), gt_corners)
-    loss_dims = l1(get_cuboid_verts(torch.cat((gt_3d, cube_dims), dim=1), gt_poses), gt_corners).contiguous().view(n, -1).mean(dim=1)
-    total = (loss_dims + loss_pose + loss_xy + loss_z).detach()
-    joint = torch.cat((torch.stack((cube_z * (cube_x - sx) / fx, cube_z * (cube_y - sy) / fy, cube_z)).T, cube_dims), dim=1)
-    loss_joint = chamfer_loss(get_cuboid_verts(joint, cube_pose), gt_corners)
-    valid_joint = loss_joint < float("inf")
-    total = total + loss_joint.detach()
+    loss_xy = l1(get_cuboid_verts(dis_xy, gt_poses), gt_corners)
+    pose_corners = get_cuboid_verts(gt_box3d, cube_pose)
+    loss_pose = chamfer_loss(pose_corners, gt_corners) if chamfer_pose else l1(pose_corners, gt_corners)      # roi_heads.py:597-601
+    loss_dims = l1(get_cuboid_verts(torch.cat((gt_3d, cube_dims), dim=1), gt_poses), gt_corners)
+    wd, wp, wxy, wz, wj = loss_w
+    total = (loss_dims * wd + loss_pose * wp + loss_xy * wxy + loss_z * wz).detach()                            # roi_heads.py:651-662
+    if joint:                                                                 # roi_heads.py:664-683
+        jb = torch.cat((torch.stack((cube_z * (cube_x - sx) / fx, cube_z * (cube_y - sy) / fy, cube_z)).T, cube_dims), dim=1)
+        jc = get_cuboid_verts(jb, cube_pose)
+        loss_joint = chamfer_loss(jc, gt_corners) if chamfer_pose else l1(jc, gt_corners)
+        valid_joint = loss_joint < float("inf")
+        total = total + (loss_joint * wj).detach()
     z_error = (cube_z - gt_z).detach().abs()
     stats = {"Cube/z_error": z_error.mean().item(), "Cube/dims_error": (cube_dims - gt_dims).detach().abs().mean().item(),
              "Cube/xy_error": (cube_xy - gt_2d).detach().abs().mean().item(), "Cube/z_close": (z_error < 0.20).float().mean().item(),
-             "Cube/total_3D_loss": safely_reduce(total).item(), "Cube/conf": torch.exp(-cube_uncert).mean().item()}
-    sf = SQRT_2 * torch.exp(-cube_uncert)
-    losses = {"Cube/uncert": safely_reduce(cube_uncert.clone()), "Cube/loss_dims": safely_reduce(loss_dims * sf),
-              "Cube/loss_xy": safely_reduce(loss_xy * sf), "Cube/loss_z": safely_reduce(loss_z * sf),
-              "Cube/loss_pose": safely_reduce(loss_pose * sf)}
-    if valid_joint.any():
+             "Cube/total_3D_loss": safely_reduce(total).item()}
+    sf = torch.ones_like(loss_dims)
+    if inverse_z_weight:                                                      # roi_heads.py:697-719
+        sf = sf * (1 / torch.log(gt_z.clip(E_CONSTANT)))
+    losses = {}
+    if use_confidence:                                                        # roi_heads.py:721-740
+        sf = sf * (SQRT_2 * torch.exp(-cube_uncert))
+        losses["Cube/uncert"] = safely_reduce(cube_uncert.clone())
+        stats["Cube/conf"] = torch.exp(-cube_uncert).mean().item()
+    losses.update({"Cube/loss_dims": safely_reduce(loss_dims * sf), "Cube/loss_xy": safely_reduce(loss_xy * sf),
+                   "Cube/loss_z": safely_reduce(loss_z * sf), "Cube/loss_pose": safely_reduce(loss_pose * sf)})
+    if joint and valid_joint.any():
         losses["Cube/loss_joint"] = safely_reduce((loss_joint * sf)[valid_joint])
     extras = {"cube_x": cube_x, "cube_y": cube_y, "cube_z": cube_z, "cube_dims": cube_dims, "cube_pose": cube_pose,
               "cube_uncert": cube_uncert}

@@ -145,7 +145,7 @@ def main(spec=SMALL):
         "rpn_labels": record["rpn_labels"], "roi_classes": record["roi_classes"], "roi_boxes": record["roi_boxes"],
         "proposals": record["proposals"],      # the reference's own first-stage output (injected into the second stage)
         "grad_norm": {n: float(g.norm()) for n, g in grads.items()},
-        "grad_head": {n: grads[n].flatten()[:64].clone() for n in pick},
+        "grad_head": {n: grads[n].flatten()[:64].clone() for n in pick if n in grads},
         "torch_version": torch.__version__,
     }
     path = os.path.join(ROOT, "tests", "golden", spec["name"] + ".pt")
@@ -154,6 +154,23 @@ def main(spec=SMALL):
     for k, v in out["losses"].items():
         print(f"  {k:24s} {v:.6f}")
     return out
+
+
+# non-default cube-head parameterisations: every MODEL.ROI_CUBE_HEAD switch the HIP head kernel implements, flipped
+# at least once, on the tiny spec
+_T = TINY["overrides"]
+HEAD_QUAT = dict(TINY, name="dla34_tiny_head_quat", seed=13, overrides=_T + [
+    "MODEL.ROI_CUBE_HEAD.Z_TYPE", "sigmoid", "MODEL.ROI_CUBE_HEAD.DIMS_PRIORS_FUNC", "sigmoid", "MODEL.ROI_CUBE_HEAD.POSE_TYPE", "quaternion",
+    "MODEL.ROI_CUBE_HEAD.ALLOCENTRIC_POSE", False, "MODEL.ROI_CUBE_HEAD.CHAMFER_POSE", False, "MODEL.ROI_CUBE_HEAD.SHARED_FC", False])
+HEAD_EULER = dict(TINY, name="dla34_tiny_head_euler", seed=14, overrides=_T + [
+    "MODEL.ROI_CUBE_HEAD.Z_TYPE", "log", "MODEL.ROI_CUBE_HEAD.DIMS_PRIORS_ENABLED", False, "MODEL.ROI_CUBE_HEAD.POSE_TYPE", "euler",
+    "MODEL.ROI_CUBE_HEAD.VIRTUAL_DEPTH", False, "MODEL.ROI_CUBE_HEAD.INVERSE_Z_WEIGHT", True, "MODEL.ROI_CUBE_HEAD.USE_CONFIDENCE", 0.0,
+    "MODEL.ROI_CUBE_HEAD.LOSS_W_JOINT", 0.0])
+HEAD_MIXED = dict(TINY, name="dla34_tiny_head_mixed", seed=15, overrides=_T + [
+    "MODEL.ROI_CUBE_HEAD.Z_TYPE", "log", "MODEL.ROI_CUBE_HEAD.POSE_TYPE", "quaternion", "MODEL.ROI_CUBE_HEAD.INVERSE_Z_WEIGHT", True,
+    "MODEL.ROI_CUBE_HEAD.LOSS_W_POSE", 0.7, "MODEL.ROI_CUBE_HEAD.LOSS_W_JOINT", 0.5, "MODEL.ROI_CUBE_HEAD.LOSS_W_3D", 1.5,
+    "MODEL.ROI_CUBE_HEAD.NUM_FC", 1])
+HEAD_MODES = (HEAD_QUAT, HEAD_EULER, HEAD_MIXED)
 
 
 FULL = dict(name="dla34_full", seed=6, images=4, height=512, width=512, num_gt=8, overrides=[])       # BASELINE configs[1]
@@ -313,6 +330,9 @@ if __name__ == "__main__":
         main_eval()
     elif "--infer" in sys.argv:
         main_infer()
+    elif "--head-modes" in sys.argv:
+        for spec in HEAD_MODES:
+            main(spec)
     else:
         main(TINY if "--tiny" in sys.argv else RESNET if "--resnet" in sys.argv else FULL if "--full" in sys.argv
              else RESNET_FULL if "--resnet-full" in sys.argv else SMALL)

@@ -129,7 +129,7 @@ def install():
     _mod("fvcore.nn.weight_init", c2_xavier_fill=U.c2_xavier_fill, c2_msra_fill=U.c2_msra_fill)
     _mod("pytorch3d", _C=U._C)
     _mod("pytorch3d.transforms", rotation_6d_to_matrix=U.rotation_6d_to_matrix, axis_angle_to_matrix=U.axis_angle_to_matrix,
-         quaternion_to_matrix=U.quaternion_to_matrix)
+         quaternion_to_matrix=U.quaternion_to_matrix, euler_angles_to_matrix=U.euler_angles_to_matrix)
     _mod("pytorch3d.transforms.rotation_conversions", _copysign=U._copysign)
     _mod("pytorch3d.ops.iou_box3d", _box_planes=U._box_planes, _box_triangles=U._box_triangles)
     sys.meta_path.append(_StubFinder())

@@ -1131,6 +1131,31 @@ def axis_angle_to_matrix(axis_angle: torch.Tensor) -> torch.Tensor:
     return quaternion_to_matrix(axis_angle_to_quaternion(axis_angle))
 
 
+def _axis_angle_rotation(axis: str, angle: torch.Tensor) -> torch.Tensor:
+    """pytorch3d.transforms.rotation_conversions._axis_angle_rotation (published algorithm)"""
+    cos, sin = torch.cos(angle), torch.sin(angle)
+    one, zero = torch.ones_like(angle), torch.zeros_like(angle)
+    if axis == "X":
+        flat = (one, zero, zero, zero, cos, -sin, zero, sin, cos)
+    elif axis == "Y":
+        flat = (cos, zero, sin, zero, one, zero, -sin, zero, cos)
+    elif axis == "Z":
+        flat = (cos, -sin, zero, sin, cos, zero, zero, zero, one)
+    else:
+        raise ValueError("letter must be either X, Y or Z.")
+    return torch.stack(flat, -1).reshape(angle.shape + (3, 3))
+
+
+def euler_angles_to_matrix(euler_angles: torch.Tensor, convention: str) -> torch.Tensor:
+    """pytorch3d.transforms.euler_angles_to_matrix: product of the three axis rotations in convention order (cube_head.py:184-185)"""
+    if euler_angles.dim() == 0 or euler_angles.shape[-1] != 3:
+        raise ValueError("Invalid input euler angles.")
+    if len(convention) != 3:
+        raise ValueError("Convention must have 3 letters.")
+    mats = [_axis_angle_rotation(c, e) for c, e in zip(convention, torch.unbind(euler_angles, -1))]
+    return torch.matmul(torch.matmul(mats[0], mats[1]), mats[2])
+
+
 def _copysign(a, b):
     signs_differ = (a < 0) != (b < 0)
     return torch.where(signs_differ, -a, a)

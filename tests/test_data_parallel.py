@@ -161,3 +161,82 @@ def test_flat_bucket_allreduce_world2(emu_lib, tmp_path):
             opts[r].flat_grad.copy_(avg)
             opts[r].step()
     assert (got[0] - opts[0].flat_param).abs().max() < 1e-6
+
+
+# ---- the REAL model: tiny cubercnn_DLA34_FPN step over gloo, world 2 (slow under the host emulator) ------------------------
+def _tiny_model_and_batch(rank):
+    from oracle import make_golden as MG
+    from omni3d_amd import synthetic
+    spec = MG.TINY
+    priors = synthetic.make_priors(50)
+    model = MG.build_product_model(MG.product_cfg(spec["overrides"]), priors, spec["seed"], device="cpu")     # same seed => same replica
+    batch = synthetic.make_batch(1, 64, 64, num_gt=3, seed=50 + rank, priors=priors)                         # a different shard per rank
+    A = 3 * sum((64 // s) ** 2 for s in (4, 8, 16, 32, 64))
+    g = torch.Generator().manual_seed(900 + rank)
+    model.proposal_generator.injected = {"E": torch.empty(1, A).exponential_(generator=g)}
+    model.roi_heads.injected = {"E": torch.empty(1, 2048).exponential_(generator=g)}
+    model.train()
+    return model, batch
+
+
+def _real_step(model, opt, batch, guard, two_phase):
+    from omni3d_amd.cubercnn.solver.graphed import GraphedTwoPhase
+    if two_phase:
+        stepper = GraphedTwoPhase(model, opt, batch, model.prepack(batch), graphs=False)
+        losses, _, pending = stepper()
+        opt.all_reduce_finish(pending, defer_scale=True)
+    else:
+        opt.zero_grad()
+        losses = model(batch)
+        sum(losses.values()).backward()
+        opt.all_reduce_grads()
+    opt.check_nonfinite(guard.nonfinite_flag)
+    skipped, retry, red = guard.update(losses)
+    opt.step()
+    return skipped, retry, red
+
+
+def _worker_real(rank, world, port, out, two_phase):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_emulator()
+    from oracle import make_golden as MG
+    from omni3d_amd.cubercnn.solver import StepGuard, build_optimizer
+    model, batch = _tiny_model_and_batch(rank)
+    opt = build_optimizer(MG.product_cfg(MG.TINY["overrides"]), model)
+    guard = StepGuard(["BoxHead/loss_cls", "BoxHead/loss_box_reg", "Cube/uncert", "Cube/loss_dims", "Cube/loss_xy", "Cube/loss_z",
+                       "Cube/loss_pose", "Cube/loss_joint", "rpn/cls", "rpn/loc"], 0.01, 100, "cpu")
+    opt.skip_flag = guard.skip
+    skipped, retry, red = _real_step(model, opt, batch, guard, two_phase)
+    torch.save({"param": opt.flat_param.clone(), "red": red, "skipped": skipped,
+                "bn": model.backbone.bottom_up.level2.tree1.bn1.running_mean.clone()}, os.path.join(out, f"real{int(two_phase)}_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(os.environ.get("OMNI_SLOW") != "1", reason="~20 min under the host emulator (four emulated model steps); set OMNI_SLOW=1")
+def test_real_model_data_parallel_step_world2(emu_lib, tmp_path):
+    """SURVEY.md 8(e) on the REAL model: two ranks, one image each, gradients all-reduced over gloo (two-phase overlapped and
+    single-phase), divergence guard with its one collective, 1/world folded into the SGD kernel.  Replicas stay bit-identical,
+    both exchange forms agree, per-rank BatchNorm statistics stay per-rank, and the result equals a single process that
+    averages the two shards' gradients by hand."""
+    world = 2
+    for two_phase in (True, False):
+        mp.spawn(_worker_real, args=(world, _free_port(), str(tmp_path), two_phase), nprocs=world, join=True)
+    tp = [torch.load(os.path.join(tmp_path, f"real1_{r}.pt"), weights_only=False) for r in range(world)]
+    sp = [torch.load(os.path.join(tmp_path, f"real0_{r}.pt"), weights_only=False) for r in range(world)]
+    assert torch.equal(tp[0]["param"], tp[1]["param"]) and torch.equal(sp[0]["param"], sp[1]["param"])      # identical replicas
+    assert (tp[0]["param"] - sp[0]["param"]).abs().max() <= 1e-6                                          # two-phase == single-phase
+    assert tp[0]["red"] == tp[1]["red"] and not tp[0]["skipped"]                                          # same reduced losses everywhere
+    assert not torch.equal(tp[0]["bn"], tp[1]["bn"])                                                      # BN running stats are per rank
+    # single process, two replicas, hand-averaged gradients
+    from oracle import make_golden as MG
+    from omni3d_amd.cubercnn.solver import build_optimizer
+    reps = [_tiny_model_and_batch(r) for r in range(world)]
+    opts = [build_optimizer(MG.product_cfg(MG.TINY["overrides"]), m) for m, _ in reps]
+    for (m, b), o in zip(reps, opts):
+        o.zero_grad()
+        sum(m(b).values()).backward()
+    avg = (opts[0].flat_grad + opts[1].flat_grad) / world
+    opts[0].flat_grad.copy_(avg)
+    opts[0].step()
+    assert (tp[0]["param"] - opts[0].flat_param).abs().max() <= 2e-6

@@ -224,54 +224,89 @@ def _rand_rot(g, n):
     return U.quaternion_to_matrix(q / q.norm(dim=1, keepdim=True))
 
 
-def _run_cube(dev):
+CUBE_CONFIGS = {
+    "base": {},
+    # every non-default switch at least once (MODEL.ROI_CUBE_HEAD.*; roi_heads.py:426-768, cube_head.py:175-185)
+    "quat_sigmoid": dict(z_type="sigmoid", dims_priors_func="sigmoid", pose_type="quaternion", allocentric_pose=False, chamfer_pose=False),
+    "euler_log": dict(z_type="log", dims_priors_enabled=False, pose_type="euler", virtual_depth=False, inverse_z_weight=True,
+                      use_confidence=False, joint=False),
+    "quat_log_invz": dict(z_type="log", pose_type="quaternion", inverse_z_weight=True),
+    "euler_sigmoid_l1": dict(z_type="sigmoid", pose_type="euler", chamfer_pose=False, use_confidence=False),
+}
+
+
+def _run_cube(dev, cfg_name="base"):
     from omni3d_amd.kernels import det
+    cfg = CUBE_CONFIGS[cfg_name]
+    mode = det.cube_mode(**cfg)
+    assert (mode == det.CUBE_MODE_BASE) == (cfg_name == "base")
+    conf, joint = cfg.get("use_confidence", True), cfg.get("joint", True)
     g = torch.Generator().manual_seed(4)
     F_, K, B = 37, 50, 3
-    ldh = 656
+    W = det.cube_head_width(mode)
+    Pn = W - 6 - int(conf)
+    ldh = (W * K + 15) // 16 * 16
     head = torch.randn(F_, ldh, generator=g) * 0.5
-    head[:, 12 * K: 13 * K] += 1.0            # uncertainties around 1, some below the 0.01 clip
+    if conf:
+        head[:, (6 + Pn) * K: W * K] += 1.0            # uncertainties around 1, some below the 0.01 clip
     head[0, 3 * K: 6 * K] = 6.0               # dims logits above the clip(max=5)
+    if cfg.get("z_type") == "log":
+        head[:, 2 * K: 3 * K] += 2.0          # depths around e^2
+    if cfg.get("pose_type") == "quaternion":
+        head[1, 6 * K: 6 * K + 4 * K: 4] = -0.7   # negative real part -> the copysign branch
     boxes = _rand_boxes(g, F_, 512, 512, 20, 200)
     cls = torch.randint(0, K, (F_,), generator=g)
     img = torch.randint(0, B, (F_,), generator=g)
     Ks = torch.tensor([[500.0, 510.0, 250.0, 260.0], [400.0, 400.0, 256.0, 256.0], [700.0, 690.0, 300.0, 200.0]])
     v2r = torch.tensor([1.0, 0.8, 1.7])
     priors = torch.rand(K, 2, 3, generator=g) * 2 + 0.5
+    priors[:, 1] *= 0.3                       # std: some classes with mean - 3 std < 0 (clipped), some above
     G = 11
     gt3d = torch.cat([torch.rand(G, 2, generator=g) * 512, torch.rand(G, 1, generator=g) * 30 + 2, torch.rand(G, 3, generator=g) * 3 + 0.3,
                       torch.zeros(G, 3)], 1)
+    gt3d[0, 2] = 1.5                          # below e: the clip of INVERSE_Z_WEIGHT
     gtpose = _rand_rot(g, G)
     gt_row = torch.randint(0, G, (F_,), generator=g)
-    hr = head[:, : 13 * K].clone().requires_grad_(True)
+    loss_w = (1.0, 0.8, 1.2, 0.9, 1.1)
+    hr = head[:, : W * K].clone().requires_grad_(True)
     Kmat = torch.zeros(F_, 3, 3)
     Kmat[:, 0, 0], Kmat[:, 1, 1], Kmat[:, 0, 2], Kmat[:, 1, 2], Kmat[:, 2, 2] = Ks[img, 0], Ks[img, 1], Ks[img, 2], Ks[img, 3], 1.0
-    ref, stats, ex = O.cube_losses(hr, K, boxes, cls, Kmat, v2r[img], priors[cls, 0], gt3d[gt_row], gtpose[gt_row])
+    ref, stats, ex = O.cube_losses(hr, K, boxes, cls, Kmat, v2r[img], priors[cls, 0], gt3d[gt_row], gtpose[gt_row],
+                                   prior_std=priors[cls, 1], loss_w=loss_w, **cfg)
     args = [t.to(dev) for t in (head, boxes, cls.int(), img.int(), Ks, v2r, priors, gt3d, gtpose.reshape(G, 9), gt_row.int())]
-    vals, jac, red = det.cube_loss_fwd(args[0], K, *args[1:])
+    vals, jac, red = det.cube_loss_fwd(args[0], K, *args[1:], loss_w=loss_w, mode=mode)
     names = ["Cube/loss_dims", "Cube/loss_xy", "Cube/loss_z", "Cube/loss_pose", "Cube/loss_joint", "Cube/uncert"]
+    assert ("Cube/loss_joint" in ref) == joint and ("Cube/uncert" in ref) == conf
     r = red.cpu()
     for k, nm in enumerate(names):
-        assert abs(r[k].item() - ref[nm].item()) < 2e-5 * max(1.0, abs(ref[nm].item())), (nm, r[k].item(), ref[nm].item())
+        if nm in ref:
+            assert abs(r[k].item() - ref[nm].item()) < 2e-5 * max(1.0, abs(ref[nm].item())), (nm, r[k].item(), ref[nm].item())
+        else:
+            assert r[k].item() == 0.0, nm
     for k, nm in zip((12, 13, 14, 15, 16, 17), ("Cube/total_3D_loss", "Cube/z_error", "Cube/dims_error", "Cube/xy_error", "Cube/z_close", "Cube/conf")):
-        assert abs(r[k].item() - stats[nm]) < 2e-5 * max(1.0, abs(stats[nm])), nm
+        if nm in stats:
+            assert abs(r[k].item() - stats[nm]) < 2e-5 * max(1.0, abs(stats[nm])), nm
     w = torch.tensor([1.0, 0.7, 1.3, 0.9, 1.1, 0.5])
-    sum(w[k] * ref[nm] for k, nm in enumerate(names)).backward()
-    dhead = det.cube_loss_bwd(vals, jac, red, w.to(dev), args[2], F_, K, ldh).cpu()
+    sum(w[k] * ref[nm] for k, nm in enumerate(names) if nm in ref).backward()
+    dhead = det.cube_loss_bwd(vals, jac, red, w.to(dev), args[2], F_, K, ldh, mode).cpu()
     scale = hr.grad.abs().max().item()
-    assert (dhead[:, : 13 * K] - hr.grad).abs().max() < 2e-5 * max(1.0, scale)
-    assert dhead[:, 13 * K:].abs().max() == 0
+    assert (dhead[:, : W * K] - hr.grad).abs().max() < 2e-5 * max(1.0, scale), (dhead[:, : W * K] - hr.grad).abs().max()
+    assert dhead[:, W * K:].abs().max() == 0
     # inference decode
     ratio = torch.tensor([1.0, 2.0, 0.5])
-    c3, pose, verts = det.cube_decode(args[0], K, args[1], args[2], args[3], args[4], args[5], ratio.to(dev), args[6])
+    c3, pose, verts = det.cube_decode(args[0], K, args[1], args[2], args[3], args[4], args[5], ratio.to(dev), args[6], mode)
     X = ex["cube_z"] * (ex["cube_x"] - Kmat[:, 0, 2]) / Kmat[:, 0, 0]
-    assert (c3[:, 0].cpu() - X.detach()).abs().max() < 1e-4
-    assert (c3[:, 3:6].cpu() - ex["cube_dims"].detach()).abs().max() < 1e-5
+    assert (c3[:, 0].cpu() - X.detach()).abs().max() < 1e-4 * max(1.0, X.detach().abs().max().item())
+    assert (c3[:, 3:6].cpu() - ex["cube_dims"].detach()).abs().max() < 1e-5 * max(1.0, ex["cube_dims"].detach().abs().max().item())
     assert (pose.cpu() - ex["cube_pose"].detach()).abs().max() < 1e-5
-    assert (c3[:, 8].cpu() - torch.exp(-ex["cube_uncert"].detach())).abs().max() < 1e-6
+    if conf:
+        assert (c3[:, 8].cpu() - torch.exp(-ex["cube_uncert"].detach())).abs().max() < 1e-6
+    else:       # the reference merges scores with `cube_3D[:, -1]`, the scaled v coordinate, when it has no confidence column
+        assert torch.equal(c3[:, 8], c3[:, 7]) and (c3[:, 7].cpu() - ex["cube_y"].detach() * ratio[img]).abs().max() < 1e-3
     cc = torch.cat([torch.stack((X, ex["cube_z"] * (ex["cube_y"] - Kmat[:, 1, 2]) / Kmat[:, 1, 1], ex["cube_z"]), 1), ex["cube_dims"]], 1).detach()
-    assert (verts.cpu() - O.get_cuboid_verts(cc, ex["cube_pose"].detach())).abs().max() < 1e-4
-    assert (det.cuboid_corners(cc.to(dev), ex["cube_pose"].detach().reshape(-1, 9).to(dev)).cpu() - O.get_cuboid_verts(cc, ex["cube_pose"].detach())).abs().max() < 1e-5
+    want = O.get_cuboid_verts(cc, ex["cube_pose"].detach())
+    assert (verts.cpu() - want).abs().max() < 1e-4 * max(1.0, want.abs().max().item())
+    assert (det.cuboid_corners(cc.to(dev), ex["cube_pose"].detach().reshape(-1, 9).to(dev)).cpu() - want).abs().max() < 1e-5 * max(1.0, want.abs().max().item())
 
 
 def _run_sgd(dev):
@@ -322,8 +357,9 @@ def test_box_loss_emulated(emu_lib):
     _run_box_loss("cpu")
 
 
-def test_cube_emulated(emu_lib):
-    _run_cube("cpu")
+@pytest.mark.parametrize("cfg_name", sorted(CUBE_CONFIGS))
+def test_cube_emulated(emu_lib, cfg_name):
+    _run_cube("cpu", cfg_name)
 
 
 def test_sgd_emulated(emu_lib):
@@ -339,5 +375,6 @@ def test_det_kernels_gpu(hip_lib):
     _run_roi_align("cuda")
     _run_roi_align_big("cuda")
     _run_box_loss("cuda")
-    _run_cube("cuda")
+    for cfg_name in sorted(CUBE_CONFIGS):
+        _run_cube("cuda", cfg_name)
     _run_sgd("cuda")
