@@ -8,6 +8,8 @@ import time
 import torch
 import torch.distributed as dist
 
+from .functional import total_loss
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FP32_MFMA_PEAK_TF = 157.3          # MI355X_MICROARCH.md: f32-input MFMA, dense
 TRAIN_GFLOP_PER_IMAGE = 307.8      # fwd 103.0 GFLOP, fwd+dgrad+wgrad 307.8 GFLOP
@@ -73,9 +75,13 @@ def run_train(args, world, rank):
         skipped_log.append(guard.skip.clone())
 
     def eager_step():
+        if getattr(model, "feature_cut", None) is not None and hasattr(graphed, "_eager"):    # staged backward installed
+            losses, total, pending = graphed._eager()
+            opt.all_reduce_finish(pending + opt.all_reduce_begin("late"), defer_scale=True)
+            return finish(losses, total)
         opt.zero_grad()
         losses = model(batch, packed)
-        total = sum(losses.values())
+        total = total_loss(losses)             # == sum(losses.values()), two launches
         total.backward()
         opt.all_reduce_finish(opt.all_reduce_begin("early") + opt.all_reduce_begin("late"), defer_scale=True)
         finish(losses, total.detach())
@@ -88,8 +94,19 @@ def run_train(args, world, rank):
     use_graph = os.environ.get("OMNI_BENCH_GRAPH", "1") != "0"
     two_phase = world > 1 or os.environ.get("OMNI_BENCH_TWO_PHASE") == "1"
     graphed, graph_note = None, "eager (OMNI_BENCH_GRAPH=0)"
-    from omni3d_amd.cubercnn.solver.graphed import GraphedForwardBackward, GraphedTwoPhase
-    if two_phase:
+    from omni3d_amd.cubercnn.solver.graphed import GraphedForwardBackward, GraphedPipelined, GraphedTwoPhase
+    pipelined = os.environ.get("OMNI_BENCH_PIPELINE", "1") != "0" and os.environ.get("OMNI_BENCH_TWO_PHASE") != "1"
+    if pipelined:
+        try:
+            graphed = GraphedPipelined(model, opt, batch, packed, graphs=use_graph)
+            graph_note = (f"{len(graphed.stages)} backward stages x (critical-path hipGraph on the main stream | weight-gradient hipGraph "
+                          "on a second stream), all-reduce of the heads' gradients behind stage 0" if use_graph
+                          else "eager staged backward, weight gradients on a second stream")
+        except Exception as e:   # capture refused: same sequence with eager launches
+            graphed = GraphedPipelined(model, opt, batch, packed, graphs=False)
+            graph_note = f"eager staged backward (capture failed: {type(e).__name__}: {str(e)[:160]})"
+        two_phase = True          # same call protocol: (losses, total, pending)
+    elif two_phase:
         try:
             graphed = GraphedTwoPhase(model, opt, batch, packed, graphs=use_graph)
             graph_note = ("two hipGraphs (fwd+heads bwd | backbone bwd), all-reduce of the heads' gradients overlapped"

@@ -31,9 +31,9 @@ __device__ __forceinline__ float4 mask4(float4 g, float4 y) {
 // grid-stride over pixel rows; 256 threads = rows x C/4 column groups; LDS tree over rows; one
 // fp64 atomic per (block, channel, quantity).
 template <int MODE>
-__global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                        const float* __restrict__ y, const float* __restrict__ mean_rstd,
-                                                        int P, int C, int relu, double* __restrict__ acc) {
+__device__ __forceinline__ void bn_reduce_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                               const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                               int P, int C, int relu, double* __restrict__ acc) {
     __shared__ float4 s0[256], s1[256];
     const int C4 = C >> 2;
     const int rows = 256 / C4;
@@ -92,6 +92,12 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
         st4(a + C + 4 * t, r1);
     }
 }
+template <int MODE>
+__global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                                        int P, int C, int relu, double* __restrict__ acc) {
+    bn_reduce_body<MODE>(x, dy, y, mean_rstd, P, C, relu, acc);
+}
 
 // Sum the per-block partials of 16 channels (both quantities) in fp64: 16 column lanes x 16 row groups + LDS tree.
 // Returns (for threads t < 16, channel c0 + t) s0 = sum partial[b][c], s1 = sum partial[b][C + c].
@@ -126,14 +132,14 @@ __device__ __forceinline__ void colsum16(const float* __restrict__ partial, int 
 
 // forward finalize (one workgroup per 16 channels): mean, biased var -> rstd; scale/shift for the apply pass;
 // running stats (momentum m, unbiased variance) exactly like torch.nn.functional.batch_norm(training=True).
-__global__ void __launch_bounds__(256) bn_finalize_fwd_kernel(const float* __restrict__ partial, int nblk, int P, int C,
-                                                              float eps, float momentum, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ mean_rstd,
-                                                              float* __restrict__ scale_shift, float* __restrict__ running_mean,
-                                                              float* __restrict__ running_var) {
+__device__ __forceinline__ void bn_finalize_fwd_group(int grp, const float* __restrict__ partial, int nblk, int P, int C,
+                                                      float eps, float momentum, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ mean_rstd,
+                                                      float* __restrict__ scale_shift, float* __restrict__ running_mean,
+                                                      float* __restrict__ running_var) {
     double sx, sxx;
-    colsum16(partial, nblk, C, blockIdx.x * 16, sx, sxx);
-    const int c = blockIdx.x * 16 + threadIdx.x;
+    colsum16(partial, nblk, C, grp * 16, sx, sxx);
+    const int c = grp * 16 + threadIdx.x;
     if (threadIdx.x >= 16 || c >= C) return;
     const double mean = sx / P;
     double var = sxx / P - mean * mean;
@@ -150,11 +156,18 @@ __global__ void __launch_bounds__(256) bn_finalize_fwd_kernel(const float* __res
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
 }
+__global__ void __launch_bounds__(256) bn_finalize_fwd_kernel(const float* __restrict__ partial, int nblk, int P, int C,
+                                                              float eps, float momentum, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ mean_rstd,
+                                                              float* __restrict__ scale_shift, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var) {
+    bn_finalize_fwd_group(blockIdx.x, partial, nblk, P, C, eps, momentum, gamma, beta, mean_rstd, scale_shift, running_mean, running_var);
+}
 
 // y = relu?( x * scale + shift (+ residual) )
-__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale_shift,
-                                                       const float* __restrict__ residual, float* __restrict__ y,
-                                                       long total4, int C, int relu) {
+__device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const float* __restrict__ scale_shift,
+                                              const float* __restrict__ residual, float* __restrict__ y,
+                                              long total4, int C, int relu) {
     const int C4 = C >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % C4);
@@ -164,16 +177,21 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
         st4(y + 4 * i, v);
     }
 }
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale_shift,
+                                                       const float* __restrict__ residual, float* __restrict__ y,
+                                                       long total4, int C, int relu) {
+    bn_apply_body(x, scale_shift, residual, y, total4, C, relu);
+}
 
 // backward finalize: dgamma, dbeta out (or accumulated); coefficients for the apply pass:
 //   dx = g_rstd * (dz - a - xhat * b),  g_rstd = gamma*rstd, a = dbeta/P, b = dgamma/P
-__global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(const float* __restrict__ partial, int nblk, int P, int C,
-                                                              const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ coef, int accumulate) {
+__device__ __forceinline__ void bn_finalize_bwd_group(int grp, const float* __restrict__ partial, int nblk, int P, int C,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      float* __restrict__ coef, int accumulate) {
     double db, dg;
-    colsum16(partial, nblk, C, blockIdx.x * 16, db, dg);
-    const int c = blockIdx.x * 16 + threadIdx.x;
+    colsum16(partial, nblk, C, grp * 16, db, dg);
+    const int c = grp * 16 + threadIdx.x;
     if (threadIdx.x >= 16 || c >= C) return;
     dbeta[c] = accumulate ? dbeta[c] + (float)db : (float)db;
     dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
@@ -181,11 +199,17 @@ __global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(const float* __res
     coef[C + c] = (float)(db / P);
     coef[2 * C + c] = (float)(dg / P);
 }
+__global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(const float* __restrict__ partial, int nblk, int P, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef, int accumulate) {
+    bn_finalize_bwd_group(blockIdx.x, partial, nblk, P, C, gamma, mean_rstd, dgamma, dbeta, coef, accumulate);
+}
 
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           const float* __restrict__ y, const float* __restrict__ mean_rstd,
-                                                           const float* __restrict__ coef, float* __restrict__ dx,
-                                                           float* __restrict__ dres, long total4, int C, int relu) {
+__device__ __forceinline__ void bn_bwd_apply_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                                  const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                                  const float* __restrict__ coef, float* __restrict__ dx,
+                                                  float* __restrict__ dres, long total4, int C, int relu) {
     const int C4 = C >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % C4);
@@ -197,6 +221,45 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
         st4(dx + 4 * i, v);
     }
 }
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                                           const float* __restrict__ coef, float* __restrict__ dx,
+                                                           float* __restrict__ dres, long total4, int C, int relu) {
+    bn_bwd_apply_body(x, dy, y, mean_rstd, coef, dx, dres, total4, C, relu);
+}
+
+#ifndef OMNI_HIPEMU
+// (A one-launch BatchNorm -- statistics, finalize and apply separated by grid-wide barriers built on agent-scope atomics -- was
+// built and measured in round 2: inside a hipGraph a dependent launch costs ~2.8 us on MI355X while a grid barrier across the
+// eight XCDs costs ~5 us with sc1 loads/stores and ~20 us with acquire/release fences (whole-L2 write-back + invalidate), so
+// three launches win: 8.5 vs 14.6 us forward, 10.6 vs 18.7 us backward at 4 x 512 x 16 x 16.  tools/bench_bn.py reproduces the
+// three-launch numbers.)
+// bias gradient in one launch: column sums per workgroup, then one float atomic per (workgroup, channel) into db, which
+// already holds the running gradient (accumulate) -- no partial rows, no finalize launch
+__global__ void __launch_bounds__(256) bias_grad_atomic_kernel(const float* __restrict__ dy, int P, int C, float* __restrict__ db) {
+    __shared__ float4 s0[256];
+    const int C4 = C >> 2, rows = 256 / C4, t = threadIdx.x, col = t % C4, row = t / C4;
+    float4 a = f4(0.f);
+    if (row < rows) {
+        const long step = (long)gridDim.x * rows;
+        long p = (long)blockIdx.x * rows + row;
+        for (; p + 3 * step < P; p += 4 * step) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ld4(dy + (p + u * step) * C + 4 * col);
+            a = a + ((v[0] + v[1]) + (v[2] + v[3]));
+        }
+        for (; p < P; p += step) a = a + ld4(dy + p * C + 4 * col);
+    }
+    s0[t] = a;
+    __syncthreads();
+    if (t < C4) {
+        float4 r = s0[t];
+        for (int k = 1; k < rows; ++k) r = r + s0[k * C4 + t];
+        atomicAdd(db + 4 * t + 0, r.x); atomicAdd(db + 4 * t + 1, r.y); atomicAdd(db + 4 * t + 2, r.z); atomicAdd(db + 4 * t + 3, r.w);
+    }
+}
+#endif
 
 // ---- 2x2/s2 max-pool (NHWC); first maximum in window scan order wins, like ATen -----------------
 __global__ void __launch_bounds__(256) maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
@@ -499,6 +562,12 @@ int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, int acc
     hipStream_t st = (hipStream_t)stream;
     const int nblk = red_grid(P, C);
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
+#ifndef OMNI_HIPEMU
+    if (accumulate && nblk <= 64) {     // small tensors: db already holds the running gradient, add this call's column sums
+        hipLaunchKernelGGL(bias_grad_atomic_kernel, dim3(nblk), dim3(256), 0, st, dy, P, C, db);   // with <= 64 float atomics per channel
+        return omni_launch_status();
+    }
+#endif
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, dy, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial));
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk, C, db,

@@ -145,12 +145,17 @@ class DLABackbone(Backbone):
         self._out_feature_strides = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
         self._out_features = ["p2", "p3", "p4", "p5", "p6"]
 
+    stage_cut = None      # solver/graphed.py GraphedPipelined: backward is cut between the levels (x -> detached copy of x)
+    stage_cut_at = ("p2", "p3")       # a cut at level k needs the cuts at all lower levels (see GraphedPipelined); measured optimum
+
     def forward(self, x):
+        on = self.stage_cut is not None and self.training and torch.is_grad_enabled()
+        cut = lambda name, t: self.stage_cut(t) if (on and name in self.stage_cut_at) else t      # noqa: E731
         x = self.level1(self.level0(self.base_layer(x)))
-        p2 = self.level2(x)
-        p3 = self.level3(p2)
-        p4 = self.level4(p3)
-        p5 = self.level5(p4)
+        p2 = cut("p2", self.level2(x))
+        p3 = cut("p3", self.level3(p2))
+        p4 = cut("p4", self.level4(p3))
+        p5 = cut("p5", self.level5(p4))
         return {"p2": p2, "p3": p3, "p4": p4, "p5": p5, "p6": HF.subsample2(p5)}
 
 

@@ -97,7 +97,7 @@ class RCNN3D(nn.Module):
         proposals, proposal_losses = self.proposal_generator(images, features, gt_instances, **pk)
         pk = {"packed": packed} if getattr(self.roi_heads, "accepts_packed", False) else {}
         _, detector_losses = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, gt_instances, **pk)
-        losses = {}
+        losses = HF.LossDict()
         losses.update(detector_losses)
         losses.update(proposal_losses)
         if has_event_storage():

@@ -128,10 +128,11 @@ class RPNWithIgnore(nn.Module):
     def losses(self, levels, anchors, labels, matched_idx, targets):
         B = targets.B
         inv_norm = 1.0 / (self.batch_size_per_image * B)          # rpn.py:198
-        cls, loc, sums = HF.rpn_loss(levels, anchors, labels, matched_idx, targets.gt, targets.gt_off, inv_norm)
+        names = ("rpn/cls", "rpn/loc")
+        w = tuple(self.loss_weight.get(k, 1.0) for k in names)                     # rpn.py:203 (names never match => 1.0)
+        vec, sums = HF.rpn_loss(levels, anchors, labels, matched_idx, targets.gt, targets.gt_off, inv_norm, w)
         self.pending_logs = {"rpn": (sums, B)}
-        losses = {"rpn/cls": cls, "rpn/loc": loc}
-        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}   # rpn.py:203 (names never match => 1.0)
+        return HF.LossDict({names[0]: vec[0], names[1]: vec[1]}, vectors=[(vec, names)])
 
     def flush_logs(self, storage):
         if "rpn" in self.pending_logs:

@@ -56,10 +56,11 @@ class FastRCNNOutputs(nn.Module):
 
     def losses(self, pred, cls, prop_boxes, targets, gt_row):
         """fast_rcnn.py:145-194; cls (R) int32 with -2 on padding rows."""
-        loss_cls, loss_reg, sums = HF.box_loss(pred, self.num_classes, cls, prop_boxes, targets.gt, gt_row, self.box2box_weights)
+        names = ("BoxHead/loss_cls", "BoxHead/loss_box_reg")
+        w = tuple(self.loss_weight.get(k, 1.0) for k in names)
+        vec, sums = HF.box_loss(pred, self.num_classes, cls, prop_boxes, targets.gt, gt_row, self.box2box_weights, w)
         self.pending_logs = {"fast_rcnn": sums}
-        losses = {"BoxHead/loss_cls": loss_cls, "BoxHead/loss_box_reg": loss_reg}
-        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+        return HF.LossDict({names[0]: vec[0], names[1]: vec[1]}, vectors=[(vec, names)])
 
     def flush_logs(self, storage):
         if "fast_rcnn" in self.pending_logs:

@@ -247,23 +247,20 @@ class ROIHeads3D(nn.Module):
             x = self.cube_pooler(feats, rois, bidx)
         head = self.cube_head(x)
         priors = self.priors_dims_per_cat.detach().reshape(self.num_classes, 2, 3).contiguous()
-        red6, red = HF.cube_loss(head, self.num_classes, rois, cls, bidx, packed.Ks, packed.v2r, priors, packed.gt3d,
-                                 packed.gtpose, gt_row, (self.loss_w_dims, self.loss_w_pose, self.loss_w_xy, self.loss_w_z, self.loss_w_joint),
-                                 self.cube_mode)
-        self.pending_logs["cube"] = red
         w3 = self.loss_w_3d
-        p = "Cube/"
-        losses = {}
-        if self.use_confidence > 0:                                   # roi_heads.py:721-740
-            losses[p + "uncert"] = self.use_confidence * red6[5]
-        if self.loss_w_dims > 0:                                      # roi_heads.py:745-748
-            losses[p + "loss_dims"] = red6[0] * self.loss_w_dims * w3
-        losses[p + "loss_xy"] = red6[1] * self.loss_w_xy * w3
-        losses[p + "loss_z"] = red6[2] * self.loss_w_z * w3
-        losses[p + "loss_pose"] = red6[3] * self.loss_w_pose * w3
-        if self.loss_w_joint > 0:                                     # roi_heads.py:766-768
-            losses[p + "loss_joint"] = red6[4] * self.loss_w_joint * w3
-        return losses
+        # what each reduced term is multiplied by on the way into the loss dict; 0 = not a loss in this configuration
+        coef = (self.loss_w_dims * w3 if self.loss_w_dims > 0 else 0.0,        # roi_heads.py:745-748
+                self.loss_w_xy * w3, self.loss_w_z * w3, self.loss_w_pose * w3,
+                self.loss_w_joint * w3 if self.loss_w_joint > 0 else 0.0,      # roi_heads.py:766-768
+                float(self.use_confidence) if self.use_confidence > 0 else 0.0)   # roi_heads.py:721-740
+        vec, red = HF.cube_loss(head, self.num_classes, rois, cls, bidx, packed.Ks, packed.v2r, priors, packed.gt3d,
+                                packed.gtpose, gt_row, (self.loss_w_dims, self.loss_w_pose, self.loss_w_xy, self.loss_w_z, self.loss_w_joint),
+                                self.cube_mode, coef)
+        self.pending_logs["cube"] = red
+        order = ("loss_dims", "loss_xy", "loss_z", "loss_pose", "loss_joint", "uncert")
+        keep = [k for k, name in enumerate(order) if coef[k] != 0.0 or name in ("loss_xy", "loss_z", "loss_pose")]
+        names = tuple("Cube/" + order[k] for k in keep)
+        return HF.LossDict({n: vec[k] for n, k in zip(names, keep)}, vectors=[(vec, names)])
 
     def flush_logs(self, storage):
         self.box_predictor.flush_logs(storage)

@@ -117,6 +117,8 @@ class FlatSGD(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         """param.grad stay views of the flat bucket (set_to_none is ignored: the views ARE the storage the fused step and
         the all-reduce operate on)."""
+        from ... import functional as HF
+        HF.side_join()            # weight-gradient stream (normally already joined by the end-of-backward callback)
         self.flat_grad.zero_()
 
     @torch.no_grad()
@@ -183,6 +185,8 @@ class FlatSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        from ... import functional as HF
+        HF.side_join()
         self._rebind_grads()
         first = self._steps == 0
         for start, end, g in self.segments:

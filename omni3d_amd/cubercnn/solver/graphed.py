@@ -12,6 +12,8 @@ The reference's loop is tools/train_net.py:do_train (:175-259); this object repl
 into the static tensors the graph was captured with (`static_batch` / `static_packed`)."""
 import torch
 
+from ...functional import total_loss
+
 
 class FeatureCut:
     """Splits backward at the FPN features: `cut(features)` hands detached copies to the heads (RPN, ROI heads), so
@@ -57,17 +59,23 @@ class GraphedTwoPhase:
                 self._phase_b()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-            self.losses, self.total = self._phase_a()
-        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
-            self._phase_b()
+        from ... import functional as HF
+        prev_mode = HF.side_mode()
+        HF.side_mode("inline")      # single-branch graphs: a captured fork / join would be replayed node by node from the host
+        try:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                self.losses, self.total = self._phase_a()
+            with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+                self._phase_b()
+        finally:
+            HF.side_mode(prev_mode)
         self.graph_a, self.graph_b = ga, gb
 
     def _phase_a(self):
         self.optimizer.zero_grad()
         losses = self.model(self.static_batch, self.static_packed)
-        total = sum(losses.values())
+        total = total_loss(losses)             # == sum(losses.values()), two launches
         total.backward()
         return losses, total.detach()
 
@@ -102,15 +110,21 @@ class GraphedForwardBackward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        from ... import functional as HF
+        prev_mode = HF.side_mode()
+        HF.side_mode("inline")      # single-branch graph: a captured fork / join would be replayed node by node from the host
         # thread_local: RCCL's watchdog thread (N > 1) and the autograd worker may issue HIP calls while this thread
         # captures; only this thread's own unsafe calls should abort the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.losses, self.total = self._body()
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.losses, self.total = self._body()
+        finally:
+            HF.side_mode(prev_mode)
 
     def _body(self):
         self.optimizer.zero_grad()
         losses = self.model(self.static_batch, self.static_packed)
-        total = sum(losses.values())
+        total = total_loss(losses)             # == sum(losses.values()), two launches
         total.backward()
         return losses, total.detach()
 
@@ -119,3 +133,175 @@ class GraphedForwardBackward:
         -> (loss dict, total) as static device tensors (overwritten by the next replay)."""
         self.graph.replay()
         return self.losses, self.total
+
+
+class StageCuts:
+    """Ordered cut points of one forward pass.  `cuts(x)` (a tensor or a dict of tensors) returns detached copies that the
+    rest of the forward consumes; backward then runs in stages: `total.backward()` stops at the most recent cut, every
+    `backward_last()` pushes the gradients that reached the newest remaining cut through the piece of the network in front of
+    it, down to the cut before.  Gradients from several consumers of a copy accumulate in its `.grad` as usual."""
+
+    def __init__(self):
+        self.cuts = []
+
+    def __len__(self):
+        return len(self.cuts)
+
+    def __call__(self, x):
+        if isinstance(x, dict):
+            dst = {k: v.detach().requires_grad_(True) for k, v in x.items()}
+        else:
+            dst = x.detach().requires_grad_(True)
+        self.cuts.append((x, dst))
+        return dst
+
+    def reset(self):
+        self.cuts.clear()
+
+    def backward_last(self):
+        src, dst = self.cuts.pop()
+        if isinstance(src, dict):
+            pairs = [(src[k], dst[k].grad) for k in src if dst[k].grad is not None]
+        else:
+            pairs = [(src, dst.grad)] if dst.grad is not None else []
+        del src, dst
+        if pairs:
+            torch.autograd.backward([p[0] for p in pairs], [p[1] for p in pairs])
+
+
+class GraphedPipelined:
+    """The training step as a software pipeline over two HIP streams.
+
+    Backward is cut into stages -- heads | FPN + DLA levels 5, 4 | level 3 | level 2 .. stem by default (`stage_cut_at` of the
+    bottom-up; two stages for a backbone without cut points).  A cut at level k is only valid together with the cuts at all
+    lower levels: an uncut p_j feeds both its FPN lateral and level j+1, and would be back-propagated through twice.
+    Stage k is recorded as TWO single-branch hipGraphs: M_k = everything on the critical path (data gradients, BatchNorm,
+    ROIAlign, losses; M_0 also holds zero_grad + forward) and W_k = the stage's weight-gradient launches, which the backward
+    functions queue instead of running (functional.side_mode("collect")).  Replay:
+
+        main:  M_0 | M_1 | M_2 | ... | M_last | wait for the side stream
+        side:        W_0 (after M_0) | W_1 (after M_1) | ... | W_last
+
+    so weight gradients, which nothing on the critical path waits for, fill the CUs the small data-gradient kernels of the
+    next stages leave idle.  Measured on MI355X (batch 4 x 512 x 512): 14.07 ms / step with 4 stages against 14.65 ms for the
+    single graph (6 stages 14.18, 3 stages 14.42, 2 stages 14.92: every M -> M boundary costs up to ~200 us of idle main
+    queue while the side queue starts, which bounds the useful number of stages).  A single graph with parallel branches is
+    no alternative: ROCm 7.2 replays such a graph node by node from the host, 12 ms per step instead of 0.7 ms; neither is a
+    high-priority main stream (graph replays on it run 2x slower).
+
+    Memory: M graphs share one pool, W graphs another, so a W graph's temporaries are never handed to a main-stream kernel.
+    The INPUTS of the W graphs (saved activations, output gradients) live in the M pool and stay referenced for as long as
+    the graphs exist, so no later M graph can be given their memory while a W graph may still be reading it (a few GB of the
+    288 GB).  Nothing allocated by a warm-up step may be released inside a capture (observed on ROCm 7.2 / torch 2.10: the
+    captured graph then replays garbage), hence the warm-up results are dropped before the first capture begins.
+    With more than one rank the all-reduce of the heads' gradient ranges is issued behind W_0 on the side stream and overlaps
+    the rest of backward; the remaining ranges follow W_last.  graphs=False runs the same stages eagerly (weight gradients
+    inline), which is what the CPU / gloo tests exercise.
+    `__call__` -> (loss dict, total, pending all-reduce handles)."""
+
+    def __init__(self, model, optimizer, batch, packed, warmup=3, graphs=True, group=None):
+        from ... import functional as HF
+        self.HF = HF
+        self.model, self.optimizer, self.group = model, optimizer, group
+        self.static_batch, self.static_packed = batch, packed
+        self.cuts = StageCuts()
+        model.feature_cut = self.cuts
+        bottom_up = getattr(getattr(model, "backbone", None), "bottom_up", None)
+        if bottom_up is not None and hasattr(type(bottom_up), "stage_cut"):
+            bottom_up.stage_cut = self.cuts
+            import os
+            if os.environ.get("OMNI_PIPE_CUTS") is not None:       # A/B knob: "" | "p2" | "p2,p3" | "p2,p3,p4" | "p2,p3,p4,p5"
+                bottom_up.stage_cut_at = tuple(x for x in os.environ["OMNI_PIPE_CUTS"].split(",") if x)
+        self.stages = None
+        if not graphs:
+            return
+        assert torch.cuda.is_available(), "hipGraph capture needs the GPU"
+        self.side = torch.cuda.Stream()
+        prev_mode = HF.side_mode()
+        HF.side_mode("inline")
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):       # warm-up off the capture: allocator pools, lazily built constants
+            for _ in range(warmup):
+                self._eager()               # (results dropped here: nothing of a warm-up step may die inside a capture)
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        HF.side_mode("collect")
+        try:
+            stages, pool_m, pool_w = [], None, None
+            self._held = []                 # closures + their inputs: kept for the lifetime of the graphs (see class docstring)
+            while True:
+                gm = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gm, pool=pool_m, capture_error_mode="thread_local"):
+                    if not stages:
+                        self.losses, self.total = self._stage0()
+                    else:
+                        self.cuts.backward_last()
+                pool_m = gm.pool()
+                fns, keep = HF.side_take()
+                gw = None
+                if fns:
+                    gw = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gw, pool=pool_w, capture_error_mode="thread_local"):
+                        for fn in fns:
+                            fn()
+                    pool_w = gw.pool()
+                self._held.append((fns, keep))
+                del fns, keep
+                stages.append((gm, gw))
+                if len(self.cuts) == 0:
+                    break
+            self.stages = stages
+        finally:
+            HF.side_take()
+            HF.side_mode(prev_mode)
+
+    def _stage0(self):
+        self.cuts.reset()
+        self.optimizer.zero_grad()
+        losses = self.model(self.static_batch, self.static_packed)
+        total = total_loss(losses)
+        total.backward()
+        return losses, total.detach()
+
+    def _eager(self):
+        """all stages with eager launches (weight gradients wherever functional.side_mode() puts them)
+        -> (loss dict, total, pending early all-reduce handles)"""
+        losses, total = self._stage0()
+        pending = self.optimizer.all_reduce_begin("early", self.group)
+        while len(self.cuts):
+            self.cuts.backward_last()
+        self.HF.side_join()
+        return losses, total, pending
+
+    def __call__(self):
+        if self.stages is None:
+            losses, total, pending = self._eager()
+            return losses, total, pending + self.optimizer.all_reduce_begin("late", self.group)
+        main, side = torch.cuda.current_stream(), self.side
+        pending, n = [], len(self.stages)
+        ends = [None] * n
+
+        def launch_w(k):                              # W_k starts when M_k has finished ...
+            gw = self.stages[k][1]
+            if gw is None and k > 0:
+                return []
+            side.wait_event(ends[k])
+            with torch.cuda.stream(side):
+                if gw is not None:
+                    gw.replay()
+                # the heads' gradients are final after W_0: their all-reduce rides behind it on the side stream
+                return self.optimizer.all_reduce_begin("early", self.group) if k == 0 else []
+
+        # host order M_0, M_1, W_0, M_2, W_1, ...: the next critical-path graph is always queued on the main stream before the
+        # side-stream launch that depends on an event (measured: a graph launch behind a cross-stream event delays every
+        # launch issued after it by ~150 us)
+        for k in range(n):
+            self.stages[k][0].replay()
+            ends[k] = torch.cuda.Event()
+            ends[k].record(main)
+            if k >= 1:
+                pending += launch_w(k - 1)
+        pending += launch_w(n - 1)
+        main.wait_stream(side)                        # ... and everything after the step waits for the last W
+        return self.losses, self.total, pending + self.optimizer.all_reduce_begin("late", self.group)

@@ -7,6 +7,9 @@ channels_last memory (physically NHWC / KRSC).
 """
 import torch
 from torch.autograd import Function
+from os import environ as _environ
+
+_os_environ_get = _environ.get
 
 from .kernels import bnpool, conv, det, wino
 
@@ -31,9 +34,94 @@ def _parts_out(parts, like):
     return parts if parts is not None else like.new_zeros((0, 1))
 
 
+# ---- weight gradients off the critical path ---------------------------------------------------------------------------------
+# In the backward pass of a convolution / linear layer the data gradient is on the critical path (the next layer down waits for
+# it) while the weight gradient is needed only by the optimizer, and most layers of this network launch too few workgroups to
+# fill 256 CUs by themselves.  The backward functions therefore hand their weight-gradient launch (a closure that accumulates
+# into the FlatSGD bucket in place and returns nothing) to `_side_run`, which does one of three things:
+#   mode "inline"  : runs it on the spot (CPU / emulator, OMNI_WGRAD_STREAM=0, or no in-place gradient bucket);
+#   mode "stream"  : eager steps -- queues it and launches every `batch` closures on a second HIP stream behind one
+#                    cross-stream dependency; the main stream waits for the side stream once, when the backward pass ends
+#                    (autograd engine callback), before anything reads the gradient bucket;
+#   mode "collect" : hipGraph capture (cubercnn/solver/graphed.py GraphedPipelined) -- only queues; the capturer takes the
+#                    closures of a backward stage and records them as a second graph that replays on the side stream next
+#                    to the NEXT stage's data-gradient graph.  (A single captured graph with parallel branches is no use:
+#                    ROCm 7.2 replays such a graph node by node from the host, 12 ms per step instead of 0.7 ms.)
+# Inputs of queued closures are kept referenced until they have run and been joined, so the caching allocator cannot hand
+# their memory to a main-stream kernel early.
+_side = {"mode": "stream" if _os_environ_get("OMNI_WGRAD_STREAM", "1") != "0" else "inline",
+         "batch": int(_os_environ_get("OMNI_WGRAD_BATCH", "8")), "streams": {}, "pending": [], "queue": [], "main": None}
+
+
+def side_mode(mode=None):
+    """-> current mode; sets it when given ("inline" | "stream" | "collect")"""
+    if mode is not None:
+        assert mode in ("inline", "stream", "collect")
+        side_join()
+        _side["mode"] = mode
+    return _side["mode"]
+
+
+def side_take():
+    """collect mode: -> (queued closures, the tensors they read) and forget them"""
+    q, keep = list(_side["queue"]), list(_side["pending"])
+    _side["queue"].clear()
+    _side["pending"].clear()
+    return q, keep
+
+
+def _side_flush():
+    """launch the queued weight-gradient closures on the side stream behind ONE wait on the main stream"""
+    if not _side["queue"]:
+        return
+    main, st = _side["main"]
+    st.wait_stream(main)
+    with torch.cuda.stream(st):
+        for fn in _side["queue"]:
+            fn()
+    _side["queue"].clear()
+
+
+def _side_run(fn, keepalive):
+    dev = keepalive[0].device
+    mode = _side["mode"]
+    if mode == "inline" or (dev.type != "cuda" and mode != "collect"):
+        return fn()
+    _side["queue"].append(fn)
+    _side["pending"].extend(keepalive)
+    if mode == "collect":
+        return None
+    if _side["main"] is None:
+        st = _side["streams"].get(dev.index)
+        if st is None:
+            st = _side["streams"][dev.index] = torch.cuda.Stream(device=dev)
+        _side["main"] = (torch.cuda.current_stream(dev), st)
+        torch.autograd.Variable._execution_engine.queue_callback(side_join)    # runs when this backward pass ends
+    if len(_side["queue"]) >= _side["batch"]:
+        _side_flush()
+    return None
+
+
+def side_join():
+    """stream mode: flush, then the main stream waits for the weight-gradient stream (idempotent; FlatSGD also calls it before
+    it touches the gradient bucket).  collect mode: nothing to do, the capturer owns the queue."""
+    if _side["mode"] == "collect":
+        return
+    if _side["main"] is not None:
+        _side_flush()
+        main, st = _side["main"]
+        main.wait_stream(st)
+        _side["main"] = None
+    for fn in _side["queue"]:      # (queued without a stream: cannot happen in stream mode, kept for safety)
+        fn()
+    _side["queue"].clear()
+    _side["pending"].clear()
+
+
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, relu, want_stats=False):
+        ctx.set_materialize_grads(False)      # no zero tensors for the non-differentiable side outputs
         ctx.direct = (_direct_grad(w), _direct_grad(bias))
         x, w = _cl(x), _cl(w)
         # full-resolution few-channel stem layers: direct convolution with the input halo staged once in LDS
@@ -71,8 +159,10 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[1]:
             # (measured: the stem weight-gradient kernel wins for the 16-channel layer, 0.13 vs 0.21 ms, not for the
             # 4-channel 7x7 layer, 0.26 vs 0.21 ms, which keeps the split-K implicit GEMM)
-            dw = (conv.stem_conv_wgrad(x, dy, w.shape[2], accum_into=gw) if (ctx.stem and w.shape[1] == 16)
-                  else conv.conv2d_wgrad(x, dy, (w.shape[2], w.shape[3]), stride, pad, accum_into=gw))
+            def wgrad():
+                return (conv.stem_conv_wgrad(x, dy, w.shape[2], accum_into=gw) if (ctx.stem and w.shape[1] == 16)
+                        else conv.conv2d_wgrad(x, dy, (w.shape[2], w.shape[3]), stride, pad, accum_into=gw))
+            dw = _side_run(wgrad, (x, dy)) if gw is not None else wgrad()
         db = None
         if has_bias and ctx.needs_input_grad[2]:
             db = bnpool.bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]), accum_into=gb)
@@ -86,6 +176,7 @@ class _WinoConv3x3(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, relu, want_stats=False):
+        ctx.set_materialize_grads(False)      # no zero tensors for the non-differentiable side outputs
         ctx.direct = (_direct_grad(w), _direct_grad(bias))
         x, w = _cl(x), _cl(w)
         # one launch yields the forward transform U and (when the data gradient will also go through Winograd) U' of
@@ -125,13 +216,13 @@ class _WinoConv3x3(Function):
             gw = None
         dx = dw = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and wino.dgrad_eligible(dy.shape):
-            dx, dw = wino.conv3x3_backward(V, dy, w, Uf, accum_into=gw)          # both transforms of dy in one pass
+            dx, dw = wino.conv3x3_backward(V, dy, w, Uf, accum_into=gw, side_run=_side_run)   # both transforms of dy in one pass
         else:
             if ctx.needs_input_grad[0]:
                 dx = (wino.conv3x3_dgrad(dy, w, U_flip=Uf, tile=2 if V.shape[0] == 16 else 4) if wino.dgrad_eligible(dy.shape)
                       else conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1))
             if ctx.needs_input_grad[1]:
-                dw = wino.conv3x3_wgrad(V, dy, accum_into=gw)
+                dw = _side_run(lambda: wino.conv3x3_wgrad(V, dy, accum_into=gw), (V, dy)) if gw is not None else wino.conv3x3_wgrad(V, dy)
         db = None
         if has_bias and ctx.needs_input_grad[2]:
             db = bnpool.bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]), accum_into=gb)
@@ -154,9 +245,8 @@ class wino_weight_scope:
         return False
 
 
-import os as _os
 
-_WINOGRAD = _os.environ.get("OMNI_WINOGRAD", "1") != "0"
+_WINOGRAD = _os_environ_get("OMNI_WINOGRAD", "1") != "0"
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, want_stats=False):
@@ -191,7 +281,9 @@ class _Linear(Function):
             dy = bnpool.relu_bwd(dy, y)
         gw, gb = ctx.direct
         dx = conv.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = conv.linear_wgrad(x, dy, accum_into=gw) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = _side_run(lambda: conv.linear_wgrad(x, dy, accum_into=gw), (x, dy)) if gw is not None else conv.linear_wgrad(x, dy)
         db = bnpool.bias_grad(dy, accum_into=gb) if (has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None, None
 
@@ -344,77 +436,131 @@ def _scalar(t):
     return t.reshape(1).contiguous().float()
 
 
+_coef_cache = {}
+
+
+def _coef(values, device):
+    """small constant vector on the device, built once (before any hipGraph capture: the warm-up steps run first)"""
+    key = (tuple(float(v) for v in values), str(device))
+    t = _coef_cache.get(key)
+    if t is None:
+        t = _coef_cache[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+    return t
+
+
+class LossDict(dict):
+    """The reference's loss dictionary (name -> 0-d tensor) that also remembers the small vectors its entries are views of.
+    `sum(d.values())` (tools/train_net.py:180) works as always; `total_loss(d)` computes the same sum from the vectors with
+    two launches instead of one add per entry in the forward and a zero-fill + copy + accumulate per entry in the backward."""
+
+    def __init__(self, *a, vectors=None, **kw):
+        super().__init__(*a, **kw)
+        self.vectors = list(vectors or [])          # [(vector tensor, names it contributes to this dict)]
+
+    def update(self, other=(), **kw):
+        super().update(other, **kw)
+        if isinstance(other, LossDict):
+            self.vectors += other.vectors
+
+
+def total_loss(losses):
+    """== sum(losses.values()) (up to fp32 summation order)"""
+    vecs = getattr(losses, "vectors", None)
+    if vecs and sorted(n for _, names in vecs for n in names) == sorted(losses.keys()):
+        return torch.cat([v for v, _ in vecs]).sum()
+    return sum(losses.values())
+
+
 class _RPNLoss(Function):
-    """-> (sum BCE*t, sum L1*t) un-normalised; level tensors are the fused head outputs (B,16,H,W) CL."""
+    """-> ((2,) = [sum BCE*t, sum L1*t] * inv_norm * loss weights, raw sums); level tensors are the fused head outputs (B,16,H,W) CL."""
 
     @staticmethod
-    def forward(ctx, anchors, labels, matched_idx, gt, gt_off, inv_norm, *levels):
+    def forward(ctx, anchors, labels, matched_idx, gt, gt_off, inv_norm, weights, *levels):
+        ctx.set_materialize_grads(False)      # no zero tensors for the non-differentiable side outputs
         lv = [_cl(t).permute(0, 2, 3, 1) for t in levels]
         pack = det.LevelPack(lv)
         sums = det.rpn_loss_fwd(pack, anchors, labels, matched_idx, gt, gt_off)
         ctx.pack = pack
         ctx.save_for_backward(anchors, labels, matched_idx, gt, gt_off)
-        ctx.inv_norm = inv_norm
+        ctx.inv_norm, ctx.weights = inv_norm, weights
         ctx.mark_non_differentiable(sums)
-        s = sums.float()
-        return s[0] * inv_norm, s[1] * inv_norm, sums
+        return sums[:2].float() * _coef((inv_norm * weights[0], inv_norm * weights[1]), sums.device), sums
 
     @staticmethod
-    def backward(ctx, g_cls, g_loc, _):
+    def backward(ctx, g, _):
         anchors, labels, matched_idx, gt, gt_off = ctx.saved_tensors
-        grads = det.rpn_loss_bwd(ctx.pack, anchors, labels, matched_idx, gt, gt_off, _scalar(g_cls), _scalar(g_loc), ctx.inv_norm)
-        return (None,) * 6 + tuple(g.permute(0, 3, 1, 2) for g in grads)
+        g = g.contiguous().float()
+        if ctx.weights != (1.0, 1.0):
+            g = g * _coef(ctx.weights, g.device)
+        grads = det.rpn_loss_bwd(ctx.pack, anchors, labels, matched_idx, gt, gt_off, g[0:1], g[1:2], ctx.inv_norm)
+        return (None,) * 7 + tuple(t.permute(0, 3, 1, 2) for t in grads)
 
 
-def rpn_loss(levels, anchors, labels, matched_idx, gt, gt_off, inv_norm):
-    return _RPNLoss.apply(anchors, labels, matched_idx, gt, gt_off, inv_norm, *levels)
+def rpn_loss(levels, anchors, labels, matched_idx, gt, gt_off, inv_norm, weights=(1.0, 1.0)):
+    """-> ((2,) [cls, loc] weighted losses, raw sums)"""
+    return _RPNLoss.apply(anchors, labels, matched_idx, gt, gt_off, inv_norm, tuple(float(w) for w in weights), *levels)
 
 
 class _BoxLoss(Function):
+    """-> ((2,) = [loss_cls, loss_box_reg] * loss weights, raw sums)"""
+
     @staticmethod
-    def forward(ctx, pred, K, cls, prop, gt, gt_row, weights):
+    def forward(ctx, pred, K, cls, prop, gt, gt_row, weights, loss_w):
+        ctx.set_materialize_grads(False)      # no zero tensors for the non-differentiable side outputs
         pred = pred.contiguous()
         sums = det.box_loss_fwd(pred, K, cls, prop, gt, gt_row, weights)
         ctx.save_for_backward(pred, cls, prop, gt, gt_row, sums)
-        ctx.meta = (K, weights)
+        ctx.meta = (K, weights, loss_w)
         ctx.mark_non_differentiable(sums)
-        s = sums.float()
-        n = s[2].clamp(min=1.0)
-        return s[0] / n, s[1] / n, sums
+        s = sums[:3].float()
+        vec = s[:2] / s[2:3].clamp(min=1.0)
+        if loss_w != (1.0, 1.0):
+            vec = vec * _coef(loss_w, vec.device)
+        return vec, sums
 
     @staticmethod
-    def backward(ctx, g_cls, g_reg, _):
+    def backward(ctx, g, _):
         pred, cls, prop, gt, gt_row, sums = ctx.saved_tensors
-        K, weights = ctx.meta
-        return det.box_loss_bwd(pred, K, cls, prop, gt, gt_row, sums, _scalar(g_cls), _scalar(g_reg), weights), None, None, None, None, None, None
+        K, weights, loss_w = ctx.meta
+        g = g.contiguous().float()
+        if loss_w != (1.0, 1.0):
+            g = g * _coef(loss_w, g.device)
+        return (det.box_loss_bwd(pred, K, cls, prop, gt, gt_row, sums, g[0:1], g[1:2], weights),) + (None,) * 7
 
 
-def box_loss(pred, K, cls, prop, gt, gt_row, weights=(10.0, 10.0, 5.0, 5.0)):
-    return _BoxLoss.apply(pred, K, cls, prop, gt, gt_row, tuple(weights))
+def box_loss(pred, K, cls, prop, gt, gt_row, weights=(10.0, 10.0, 5.0, 5.0), loss_w=(1.0, 1.0)):
+    """-> ((2,) [loss_cls, loss_box_reg] weighted, raw sums)"""
+    return _BoxLoss.apply(pred, K, cls, prop, gt, gt_row, tuple(weights), tuple(float(w) for w in loss_w))
 
 
 class _CubeLoss(Function):
-    """-> (red[0:6] = loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert ; red (24) stats)."""
+    """-> ((6,) = [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert] * coef ; red (24) raw reductions + logging stats)."""
 
     @staticmethod
-    def forward(ctx, head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w, mode):
+    def forward(ctx, head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w, mode, coef):
+        ctx.set_materialize_grads(False)      # no zero tensors for the non-differentiable side outputs
         head = head.contiguous()
         vals, jac, red = det.cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w, mode)
         ctx.save_for_backward(vals, jac, red, cls)
-        ctx.meta = (head.shape[0], K, head.shape[1], mode)
+        ctx.meta = (head.shape[0], K, head.shape[1], mode, coef)
         ctx.mark_non_differentiable(red)
-        return red[:6].clone(), red
+        return red[:6] * _coef(coef, red.device), red
 
     @staticmethod
     def backward(ctx, g, _):
         vals, jac, red, cls = ctx.saved_tensors
-        F_, K, ldh, mode = ctx.meta
-        dhead = det.cube_loss_bwd(vals, jac, red, g.contiguous().float(), cls, F_, K, ldh, mode)
-        return (dhead,) + (None,) * 12
+        F_, K, ldh, mode, coef = ctx.meta
+        gk = g.contiguous().float() * _coef(coef, g.device)
+        dhead = det.cube_loss_bwd(vals, jac, red, gk, cls, F_, K, ldh, mode)
+        return (dhead,) + (None,) * 13
 
 
-def cube_loss(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0), mode=det.CUBE_MODE_BASE):
-    return _CubeLoss.apply(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, tuple(loss_w), int(mode))
+def cube_loss(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0), mode=det.CUBE_MODE_BASE,
+              coef=(1.0, 1.0, 1.0, 1.0, 1.0, 1.0)):
+    """coef: what each of [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert] is multiplied by on the way out
+    -> ((6,) weighted losses, red (24))"""
+    return _CubeLoss.apply(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, tuple(loss_w), int(mode),
+                           tuple(float(c) for c in coef))
 
 
 class _MaxPool3s2(Function):

@@ -175,15 +175,23 @@ def conv3x3_dgrad(dy, w, U_flip=None, tile=2):
     return transform_output(Mt, (N, H, W))
 
 
-def conv3x3_backward(V, dy, w, U_flip, accum_into=None):
-    """data gradient + weight gradient through Winograd with ONE pass over dy -> (dx, dw or None when accumulated)"""
+def conv3x3_backward(V, dy, w, U_flip, accum_into=None, side_run=None):
+    """data gradient + weight gradient through Winograd with ONE pass over dy -> (dx, dw or None when accumulated).
+    side_run(fn, keepalive): runs the weight-gradient half (batched GEMM + transform back, accumulated in place) on the
+    weight-gradient stream (functional._side_run)."""
     N, _, H, W = dy.shape
     tile = 2 if V.shape[0] == 16 else 4
     dM, Vd = transform_dy_both(dy, tile)
+    if side_run is not None and accum_into is not None:
+        dw = side_run(lambda: transform_dweights(gemm_batched_wgrad(V, dM), accum_into), (V, dM))
+    else:
+        dw = None
     if U_flip is None:
         U_flip = transform_weights(w, want_u=False, want_flip=True, tile=tile)[1]
     dx = transform_output(gemm_batched(Vd, U_flip), (N, H, W))
-    return dx, transform_dweights(gemm_batched_wgrad(V, dM), accum_into)
+    if side_run is None or accum_into is None:
+        dw = transform_dweights(gemm_batched_wgrad(V, dM), accum_into)
+    return dx, dw
 
 
 def conv3x3_wgrad(V, dy, accum_into=None):

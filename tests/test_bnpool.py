@@ -171,3 +171,18 @@ def test_bn_statistics_from_producer_epilogue_gpu(hip_lib):
         parts, dy, dms, drv = _bn_with_and_without_partials("cuda", xs, ws, st, pad)
         if parts is not None:
             assert dy <= 5e-5 and dms <= 1e-5 and drv <= 1e-5, (xs, ws, dy, dms, drv)
+
+
+@pytest.mark.gpu
+def test_bias_grad_accumulates_with_atomics(hip_lib):
+    """small tensors: one launch, column sums added to the running gradient with float atomics (csrc/bn_pool.hip)"""
+    from omni3d_amd.kernels import bnpool
+    g = torch.Generator().manual_seed(1)
+    for shape in ((4, 128, 32, 32), (4, 256, 128, 128)):        # atomic path / partial rows + finalize
+        dy = _cl(torch.randn(*shape, generator=g)).cuda()
+        dy2 = dy.permute(0, 2, 3, 1).reshape(-1, shape[1])
+        acc = torch.zeros(shape[1], device="cuda")
+        for _ in range(3):
+            bnpool.bias_grad(dy2, accum_into=acc)
+        want = dy2.double().sum(0) * 3
+        assert (acc.double() - want).abs().max() < 1e-3 * max(1.0, want.abs().max().item())

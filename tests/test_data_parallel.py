@@ -78,17 +78,17 @@ def _tag_early(net):
         p._omni_early_grad = not n.startswith("backbone.")
 
 
-def _worker_two_phase(rank, world, port, out):
+def _worker_two_phase(rank, world, port, out, pipelined=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _install_emulator()
     from omni3d_amd.cubercnn.solver.build import FlatSGD
-    from omni3d_amd.cubercnn.solver.graphed import GraphedTwoPhase
+    from omni3d_amd.cubercnn.solver.graphed import GraphedPipelined, GraphedTwoPhase
     net = _make_cut_net()
     _tag_early(net)
     opt = FlatSGD([{"params": [p], "weight_decay": 0.0 if p.dim() == 1 else 1e-3} for p in net.parameters()], lr=0.1, momentum=0.9)
     assert opt.early_ranges and opt.late_ranges
-    stepper = GraphedTwoPhase(net, opt, _shard(rank), None, graphs=False)
+    stepper = (GraphedPipelined if pipelined else GraphedTwoPhase)(net, opt, _shard(rank), None, graphs=False)
     for _ in range(2):
         _, _, pending = stepper()
         opt.all_reduce_finish(pending)
@@ -113,11 +113,13 @@ def _worker_single_phase(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_phase_overlapped_exchange_world2(emu_lib, tmp_path):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_two_phase_overlapped_exchange_world2(emu_lib, tmp_path, pipelined):
     """backward cut at the features + all-reduce of the heads' ranges started before the backbone's backward ==
-    plain backward + one exchange (same parameters after two SGD steps, on both ranks)"""
+    plain backward + one exchange (same parameters after two SGD steps, on both ranks); GraphedTwoPhase and the staged
+    GraphedPipelined in their eager form"""
     world = 2
-    mp.spawn(_worker_two_phase, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_two_phase, args=(world, _free_port(), str(tmp_path), pipelined), nprocs=world, join=True)
     mp.spawn(_worker_single_phase, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     tp = [torch.load(os.path.join(tmp_path, f"tp{r}.pt")) for r in range(world)]
     sp = [torch.load(os.path.join(tmp_path, f"sp{r}.pt")) for r in range(world)]
