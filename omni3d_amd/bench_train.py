@@ -236,37 +236,57 @@ def _time_launch(fn, iters):
     return a.elapsed_time(b) / iters
 
 
+def _table_shares(csv_name="r02_train_final_kernel_stats.csv"):
+    """share of the summed kernel time per kernel symbol in the committed rocprofv3 table (+ its sha256) -> ({symbol: frac}, note)"""
+    import csv
+    import hashlib
+    path = os.path.join(ROOT, "profiles", csv_name)
+    if not os.path.exists(path):
+        return {}, None
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+    def short(n):       # "void (anonymous namespace)::conv_fwd_kernel<64, 64, 2, 2, 32>((anonymous namespace)::ConvP)" -> symbol
+        n = n[5:] if n.startswith("void ") else n
+        n = n[len("(anonymous namespace)::"):] if n.startswith("(anonymous namespace)::") else n
+        return n.split("(")[0].strip()
+    shares = {}
+    for r in rows:
+        shares[short(r["Name"])] = shares.get(short(r["Name"]), 0.0) + float(r["TotalDurationNs"]) / tot
+    return shares, f"profiles/{csv_name} sha256:{hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16]}"
+
+
 def dominant_kernel_roofline(iters=20):
-    """`roofline`: the launch that contributes most to the step among single shapes -- the batched GEMM of the Winograd path on the
-    128x128 map (`gemm_nt_persistent_kernel`, F(4x4,3x3): 36 x [4096 x 256] * [256 x 256]^T at batch 4, 19.3 GFLOP and 312 MB of
-    algorithmic traffic per launch; FPN output p2 + RPN conv p2, forward and data gradient = 1.3 ms of the step) -- timed live with
-    HIP events on the launch stream.  HBM traffic and the cycle-based MFMA utilisation come from the committed PMC summary
-    (`traffic_source`).  `families`: every MFMA kernel family of the rocprof table (profiles/r02_train_final_kernel_stats.csv) with
-    one representative launch timed the same way, so the per-family distance to the 157.3 TFLOP/s fp32-MFMA peak is in the line."""
-    from omni3d_amd.kernels import conv, gemm as G, wino
+    """`roofline`: the kernel symbol that tops the committed rocprofv3 table of this command (profiles/r02_train_final_kernel_stats.csv),
+    on the launch shape that accounts for most of that symbol's time, timed live with HIP events on the launch stream; HBM traffic and
+    the cycle-based MFMA utilisation come from the committed PMC summary (`traffic_source`).  `families`: every MFMA kernel family of
+    the table with one representative launch timed the same way and its share of the summed kernel time, so the per-family distance
+    to the 157.3 TFLOP/s fp32-MFMA peak is in the line (the step is a near tie between six MFMA symbols at 7-9 % each)."""
+    from omni3d_amd.kernels import conv, wino
     from omni3d_amd.profile_io import profile_counters
     PMC = "r02_pmc_families.csv"
+    shares, table = _table_shares()
     B, C, H = IMS_PER_GPU, 256, 128
     x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
     w = (torch.randn(C, C, 3, 3, device="cuda") * 0.02).contiguous(memory_format=torch.channels_last)
     V, U = wino.transform_input(x, 4), wino.transform_weights(w, tile=4)[0]
     P, T = V.shape[0], V.shape[1]
-    ms = _time_launch(lambda: wino.gemm_batched(V, U), iters)
     flops = 2.0 * P * T * C * C
-    tf = flops / (ms * 1e-3) / 1e12
-    pmc = profile_counters(PMC, "gemm_nt_persistent_kernel")
-    traffic = (pmc["FETCH_SIZE_x2_MB"] + pmc["WRITE_SIZE_MB"]) * 1e6 if pmc and pmc.get("FETCH_SIZE_x2_MB") and pmc.get("WRITE_SIZE_MB") else None
     ms_direct = _time_launch(lambda: conv.conv2d_fwd(x, w, None, 1, 1), iters)
     flops_direct = 2.0 * B * H * H * C * C * 9
     ms_wino = _time_launch(lambda: wino.conv3x3_fwd(x, w, tile=4), iters)
 
-    def fam(name, kernel, shape, fl, fn, pmc_key=None, grid=None):
+    def fam(name, kernel, shape, fl, fn, pmc_key=None, grid=None, alg_bytes=None):
         t = _time_launch(fn, max(iters // 2, 5))
+        sym = kernel.split("(")[0]
         r = {"family": name, "kernel": kernel, "shape": shape, "gflop": fl / 1e9, "kernel_ms": t, "tflops": fl / (t * 1e-3) / 1e12,
-             "frac": fl / (t * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF}
+             "frac": fl / (t * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "share_of_kernel_time_in_table": shares.get(sym)}
+        if alg_bytes is not None:
+            r["algorithmic_bytes_per_launch"] = alg_bytes
         c = profile_counters(PMC, pmc_key or kernel.split("<")[0], grid)
         if c and c.get("mfma_busy_frac"):
             r["pmc_mfma_busy_frac"], r["pmc_source"] = c["mfma_busy_frac"], f"{c['source']} sha256:{c['sha256_16']} grid {c['grid']}"
+        if c and c.get("FETCH_SIZE_x2_MB") and c.get("WRITE_SIZE_MB") and grid is not None:
+            r["pmc_traffic_bytes"] = (c["FETCH_SIZE_x2_MB"] + c["WRITE_SIZE_MB"]) * 1e6
         return r
     dM = torch.randn(P, T, C, device="cuda")
     x1, w1 = torch.randn(2048, 12544, device="cuda"), torch.randn(1024, 12544, device="cuda") * 0.02
@@ -276,12 +296,21 @@ def dominant_kernel_roofline(iters=20):
     dys = torch.randn(B, 128, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
     x3 = torch.randn(B, 128, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
     w3 = (torch.randn(128, 128, 3, 3, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+    V3, U3 = wino.transform_input(x3, 4), wino.transform_weights(w3, tile=4)[0]           # 36 x [1024 x 128], 36 x [128 x 128]
+    dM3 = torch.randn(36, 1024, 128, device="cuda")
+    fl3 = 2.0 * 36 * 1024 * 128 * 128
     families = [
-        fam("Winograd point GEMMs", "gemm_nt_persistent_kernel", "36x[4096x256]x[256x256]^T (3x3 256->256 @128x128)", flops, lambda: wino.gemm_batched(V, U)),
+        fam("Winograd point GEMMs, small maps (DLA level 3: 14 launches / step)", "conv_fwd_kernel<64, 64, 2, 2, 32>",
+            "36x[1024x128]x[128x128]^T (3x3 128->128 @64x64, F(4x4,3x3))", fl3, lambda: wino.gemm_batched(V3, U3), grid=294912,
+            alg_bytes=4.0 * (2 * 36 * 1024 * 128 + 36 * 128 * 128)),
+        fam("Winograd point GEMMs, 128x128 maps", "gemm_nt_persistent_kernel", "36x[4096x256]x[256x256]^T (3x3 256->256 @128x128)", flops,
+            lambda: wino.gemm_batched(V, U), grid=131072, alg_bytes=4.0 * (2 * P * T * C + P * C * C)),
         fam("Winograd weight-gradient GEMMs", "conv_wgrad_kernel<128, 128, 2, 2, 32>", "36x[256x4096]x[4096x256] (same layer)", flops,
             lambda: wino.gemm_batched_wgrad(V, dM), grid=294912),
+        fam("Winograd weight-gradient GEMMs, small maps", "conv_wgrad_kernel<128, 64, 2, 2, 32>", "36x[128x1024]x[1024x128] (DLA level 3)", fl3,
+            lambda: wino.gemm_batched_wgrad(V3, dM3)),
         fam("FC forward (fc1-class)", "gemm_engine_kernel<0, 0, 128, 128>", "[2048x12544]x[1024x12544]^T box-head fc1", 2.0 * 2048 * 12544 * 1024,
-            lambda: conv.linear_fwd(x1, w1, None)),
+            lambda: conv.linear_fwd(x1, w1, None), grid=65536),
         fam("FC data gradient", "conv_dgrad_kernel<128, 128, 2, 2, 32>", "[2048x1024]x[1024x12544] box-head fc1", 2.0 * 2048 * 12544 * 1024,
             lambda: conv.linear_dgrad(dy1, w1), grid=401408),
         fam("FC weight gradient", "conv_wgrad_kernel<128, 64, 2, 2, 32>", "[1024x2048]x[2048x12544] box-head fc1", 2.0 * 2048 * 12544 * 1024,
@@ -295,16 +324,21 @@ def dominant_kernel_roofline(iters=20):
         fam("direct conv mid layers", "conv_fwd_kernel<64, 64, 2, 2, 32>", "3x3 128->128 @64x64 (DLA level 3 block, direct)", 2.0 * B * 64 * 64 * 128 * 128 * 9,
             lambda: conv.conv2d_fwd(x3, w3, None, 1, 1)),
     ]
-    return {"bound": "mfma", "kernel": "gemm_nt_persistent_kernel: Winograd F(4x4,3x3) batched GEMM 36x[4096x256]x[256x256]^T "
-                                       "(3x3 256->256 @128x128, batch 4)",
-            "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
+    # headline = the family whose kernel symbol tops the committed table (first family of that symbol in the list above)
+    top = max(shares, key=shares.get) if shares else None
+    head = next((f for f in families if top is not None and f["kernel"].split("(")[0] == top), families[1])
+    traffic = head.get("pmc_traffic_bytes")
+    return {"bound": "mfma",
+            "kernel": f"{head['kernel']} on {head['shape']} [{head['family']}]"
+                      + (f" -- tops {table} with {shares[top]:.1%} of the summed kernel time" if top == head["kernel"].split("(")[0] else ""),
+            "achieved": head["tflops"], "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": head["frac"],
             "traffic": traffic,
-            "traffic_source": (f"{pmc['source']} sha256:{pmc['sha256_16']} (rocprofv3 --pmc passes of tools/run_families.py: 2 x FETCH_SIZE + WRITE_SIZE, "
-                               "gfx950 wide-read correction of MI355X_MICROARCH.md)") if pmc else None,
-            "pmc_mfma_busy_frac": pmc.get("mfma_busy_frac") if pmc else None,
-            "algorithmic_bytes_per_launch": 4.0 * (2 * P * T * C + P * C * C),
-            "kernel_ms": ms, "flops_per_launch": flops, "operands": "fp32 (v_mfma_f32_32x32x2_f32)",
-            "layer_ms_winograd_vs_direct": [ms_wino, ms_direct],
+            "traffic_source": head.get("pmc_source", None) and (head["pmc_source"] + " (rocprofv3 --pmc passes of tools/run_families.py: 2 x FETCH_SIZE "
+                                                                  "+ WRITE_SIZE, gfx950 wide-read correction of MI355X_MICROARCH.md)"),
+            "pmc_mfma_busy_frac": head.get("pmc_mfma_busy_frac"),
+            "algorithmic_bytes_per_launch": head.get("algorithmic_bytes_per_launch"),
+            "kernel_ms": head["kernel_ms"], "flops_per_launch": head["gflop"] * 1e9, "operands": "fp32 (v_mfma_f32_32x32x2_f32)",
+            "table": table, "layer_ms_winograd_vs_direct_3x3_256_at_128": [ms_wino, ms_direct],
             "families": families}
 
 

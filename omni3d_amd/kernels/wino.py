@@ -10,6 +10,7 @@ CL = torch.channels_last
 import os as _os
 
 _F43 = _os.environ.get("OMNI_WINOGRAD_F43", "1") != "0"
+_F43_MIN_TILES = int(_os.environ.get("OMNI_WINOGRAD_F43_MIN_TILES", "256"))     # measured: 1024 -> 14.18, 256 -> 14.02, 64 -> 14.05 ms / step
 
 
 def eligible(x_shape, w_shape, stride, pad):
@@ -26,10 +27,10 @@ def eligible(x_shape, w_shape, stride, pad):
 
 
 def tile_size(x_shape):
-    """4 = F(4x4,3x3) (36 points, 2.25 multiplies per output) when the map divides into >= 1024 tiles of 4x4, else 2 =
-    F(2x2,3x3) (16 points, 4 multiplies per output)."""
+    """4 = F(4x4,3x3) (36 points, 2.25 multiplies per output) when the map divides into >= 256 tiles of 4x4 (batch 4: maps of
+    32x32 and larger), else 2 = F(2x2,3x3) (16 points, 4 multiplies per output)."""
     N, _, H, W = x_shape
-    return 4 if (_F43 and H % 4 == 0 and W % 4 == 0 and N * (H // 4) * (W // 4) >= 1024) else 2
+    return 4 if (_F43 and H % 4 == 0 and W % 4 == 0 and N * (H // 4) * (W // 4) >= _F43_MIN_TILES) else 2
 
 
 def dgrad_eligible(x_shape):
