@@ -95,16 +95,21 @@ class ResNet(Backbone):
         self._out_feature_strides = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
         self._out_features = ["p2", "p3", "p4", "p5", "p6"]
 
+    stage_cut = None      # solver/graphed.py GraphedPipelined: backward is cut between the stages (x -> detached copy of x)
+    stage_cut_at = ("p2", "p3")
+
     def forward(self, x):
         w = self.conv1.weight
         if x.shape[1] != w.shape[1]:   # 3-channel stem weight against the 4-channel padded image
             w = torch.cat([w, w.new_zeros(w.shape[0], x.shape[1] - w.shape[1], w.shape[2], w.shape[3])], dim=1)
         x = self.bn1(HF.conv2d(x, w, None, 2, 3, False, self.bn1.training and torch.is_grad_enabled()), relu=True)
         x = HF.max_pool3s2(x)
-        p2 = self.layer1(x)
-        p3 = self.layer2(p2)
-        p4 = self.layer3(p3)
-        p5 = self.layer4(p4)
+        on = self.stage_cut is not None and self.training and torch.is_grad_enabled()
+        cut = lambda name, t: self.stage_cut(t) if (on and name in self.stage_cut_at) else t      # noqa: E731
+        p2 = cut("p2", self.layer1(x))
+        p3 = cut("p3", self.layer2(p2))
+        p4 = cut("p4", self.layer3(p3))
+        p5 = cut("p5", self.layer4(p4))
         return {"p2": p2, "p3": p3, "p4": p4, "p5": p5, "p6": HF.subsample2(p5)}
 
 
