@@ -935,7 +935,9 @@ int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int b
     if (M == 0) return OMNI_OK;
     ConvP p{x, w, nullptr, out, M, 1, 1, C, 1, 1, K, 1, 1, 1, 0, C, K, 0, 0, 0, 1, (long)M * C, (long)K * C, (long)M * K};
     const long t128 = (((long)M + 127) / 128) * ((K + 127) / 128);
-    if (algo == 0) algo = (K > 64 && (C % 32) == 0 && t128 * batch >= 1024) ? 1 : (K > 64 && t128 * batch >= 512) ? 2 : 3;
+    // measured per shape (tools/sweep_batched_gemm.py, hipGraph replay): the persistent kernel from 1024 128x128 tiles up, 64x64 tiles
+    // below (36x[1024x256]x[256x256]^T: 60 us against 76 us with one 128x128 tile per workgroup)
+    if (algo == 0) algo = (K > 64 && (C % 32) == 0 && t128 * batch >= 1024) ? 1 : 3;
     if (algo == 1) {
         // >= 2 items per resident workgroup: persistent kernel with the prefetch carried across items
         GemmP g{x, w, out, batch, M, K, C, (M + 127) / 128, (K + 127) / 128};
