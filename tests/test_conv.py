@@ -177,7 +177,8 @@ def test_winograd_dispatch_rule():
     assert not wino.eligible((4, 256, 8, 8), (256, 256, 3, 3), 1, 1)        # too few tiles
     assert wino.eligible((4, 64, 128, 128), (64, 64, 3, 3), 1, 1) and wino.tile_size((4, 64, 128, 128)) == 4
     assert not wino.eligible((4, 32, 128, 128), (32, 32, 3, 3), 1, 1)        # narrow
-    assert wino.tile_size((4, 256, 128, 128)) == 4 and wino.tile_size((4, 256, 32, 32)) == 2 and wino.tile_size((2, 256, 126, 128)) == 2
+    assert wino.tile_size((4, 256, 128, 128)) == 4 and wino.tile_size((4, 256, 32, 32)) == 4       # F(4x4,3x3) from 256 tiles up
+    assert wino.tile_size((4, 512, 16, 16)) == 2 and wino.tile_size((2, 256, 126, 128)) == 2
     assert not wino.eligible((4, 256, 128, 128), (256, 256, 3, 3), 2, 1)     # strided
     assert not wino.eligible((4, 256, 127, 128), (256, 256, 3, 3), 1, 1)     # odd extent
 
