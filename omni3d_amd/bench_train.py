@@ -299,7 +299,12 @@ def dominant_kernel_roofline(iters=20):
     V3, U3 = wino.transform_input(x3, 4), wino.transform_weights(w3, tile=4)[0]           # 36 x [1024 x 128], 36 x [128 x 128]
     dM3 = torch.randn(36, 1024, 128, device="cuda")
     fl3 = 2.0 * 36 * 1024 * 128 * 128
+    V4, U4 = torch.randn(36, 256, 256, device="cuda"), torch.randn(36, 256, 256, device="cuda")      # DLA level 4: 256 tiles of 4x4 at batch 4
+    fl4 = 2.0 * 36 * 256 * 256 * 256
     families = [
+        fam("Winograd point GEMMs, small maps (DLA level 4: 18 launches / step)", "conv_fwd_kernel<64, 64, 2, 2, 32>",
+            "36x[256x256]x[256x256]^T (3x3 256->256 @32x32, F(4x4,3x3))", fl4, lambda: wino.gemm_batched(V4, U4), grid=147456,
+            alg_bytes=4.0 * (2 * 36 * 256 * 256 + 36 * 256 * 256)),
         fam("Winograd point GEMMs, small maps (DLA level 3: 14 launches / step)", "conv_fwd_kernel<64, 64, 2, 2, 32>",
             "36x[1024x128]x[128x128]^T (3x3 128->128 @64x64, F(4x4,3x3))", fl3, lambda: wino.gemm_batched(V3, U3), grid=294912,
             alg_bytes=4.0 * (2 * 36 * 1024 * 128 + 36 * 128 * 128)),
