@@ -1,10 +1,14 @@
 """`box3d_overlap` (reference cubercnn/evaluation/omni3d_evaluation.py:106-166) on the IoU3D kernel, and the batched
 form the evaluator needs: `Omni3Deval.evaluate` calls `computeIoU` once per (image, category) group from a Python dict
 comprehension (:1339-1343, :1357-1431), i.e. thousands of tiny `box3d_overlap` calls; `box3d_overlap_groups` takes all
-groups at once -- one validity launch + one ragged pairs launch + one readback.  The COCO-style greedy matching /
-accumulation around it (evaluateImg / accumulate) stays SURVEY.md 8(f) "next"."""
+groups at once -- one validity launch + one ragged pairs launch + one readback.  `Omni3Deval` runs the COCO-style greedy
+matching and the precision / recall accumulation around it on the device as well; `Omni3DEvaluator` / `Omni3DEvaluationHelper`
+are the per-split drivers `tools/train_net.py:do_test` uses."""
 import copy
 import datetime
+import json
+import logging
+import os
 
 import numpy as np
 import torch
@@ -179,14 +183,16 @@ class Omni3Deval:
     evaluate(): all (image, category) groups at once -- one IoU pass (`box3d_overlap_groups` in 3D, a vectorised box IoU in
     2D) and one greedy-matching launch for every group x range x threshold (`evaluate_groups`, csrc/eval_match.hip);
     accumulate(): one launch for every (category, range, maxDets, threshold) (`omni_eval_accumulate`).  The reference runs
-    these as Python loops over dict-of-list structures (:1339-1351, :1230-1301).  eval_prox (proximity evaluation for
-    non-exhaustively annotated datasets, :1419-1429) is not built."""
+    these as Python loops over dict-of-list structures (:1339-1351, :1230-1301).
+
+    eval_prox (proximity evaluation for non-exhaustively annotated datasets, :1419-1429, :1499, :1534-1536): a detection may
+    only match ground truths whose 2D box overlaps its own by more than `params.proximity_thresh`, and a detection with no
+    ground truth in proximity is ignored.  True / False like the reference, or a collection of image ids (extension: the
+    helper evaluates the union of several datasets of which only some use proximity evaluation)."""
 
     def __init__(self, cocoGt=None, cocoDt=None, iouType="bbox", mode="2D", eval_prox=False):
         if mode not in ["2D", "3D"]:
             raise Exception("mode %s not supported" % (mode))
-        if eval_prox:
-            raise NotImplementedError("proximity evaluation (eval_prox) is not built on the device path")
         self.mode, self.eval_prox = mode, eval_prox
         self.cocoGt, self.cocoDt = cocoGt, cocoDt
         self.params = Omni3DParams(mode)
@@ -241,8 +247,33 @@ class Omni3Deval:
             ih = (torch.min(bd[:, 1] + bd[:, 3], bg[:, 1] + bg[:, 3]) - torch.max(bd[:, 1], bg[:, 1])).clamp(min=0)
             inter = iw * ih
             flat = inter / (bd[:, 2] * bd[:, 3] + bg[:, 2] * bg[:, 3] - inter)                  # pycocotools bbIou, iscrowd = 0
+        far = None
+        if self.eval_prox is not False and self.eval_prox is not None and len(all_d) and len(all_g):
+            i1, i2, _ = _ragged_pairs(dt_sizes, gt_sizes)
+            t1, t2 = torch.from_numpy(i1).to(device), torch.from_numpy(i2).to(device)
+            if self.mode == "2D":
+                iou2d = flat
+            else:
+                bd, bg = f32([x["bbox"] for x in all_d], (-1, 4))[t1], f32([x["bbox"] for x in all_g], (-1, 4))[t2]
+                iw = (torch.min(bd[:, 0] + bd[:, 2], bg[:, 0] + bg[:, 2]) - torch.max(bd[:, 0], bg[:, 0])).clamp(min=0)
+                ih = (torch.min(bd[:, 1] + bd[:, 3], bg[:, 1] + bg[:, 3]) - torch.max(bd[:, 1], bg[:, 1])).clamp(min=0)
+                iou2d = iw * ih / (bd[:, 2] * bd[:, 3] + bg[:, 2] * bg[:, 3] - iw * ih)
+            prox = iou2d > p.proximity_thresh
+            if self.eval_prox is not True:            # only the images named
+                chosen = set(self.eval_prox)
+                applies = np.repeat(np.array([p.imgIds[gr[1]] in chosen for gr in groups], dtype=bool), dt_sizes)
+                t_app = torch.from_numpy(applies).to(device)
+                prox = prox | ~t_app[t1]
+            else:
+                t_app = torch.ones(len(all_d), dtype=torch.bool, device=device)
+            flat = torch.where(prox, flat, torch.full_like(flat, -1.0))      # a pair out of proximity can never be a match
+            near = torch.zeros(len(all_d), dtype=torch.int32, device=device).index_add_(0, t1, prox.to(torch.int32)) > 0
+            has_gt = torch.from_numpy(np.repeat(gt_sizes > 0, dt_sizes)).to(device)
+            far = ~near & has_gt & t_app
         m = evaluate_groups(flat, dt_sizes, gt_sizes, torch.tensor([int(x[flag]) for x in all_g], dtype=torch.int32, device=device),
                             f32([x[rng_key] for x in all_g], (-1,)), f32([x[rng_key] for x in all_d], (-1,)), p.areaRng, p.iouThrs)
+        if far is not None:
+            m["dt_ignore"] = (m["dt_ignore"].bool() | far.view(1, 1, -1)).to(m["dt_ignore"].dtype)
         self._dev = {"groups": groups, "dt_sizes": dt_sizes, "gt_sizes": gt_sizes, "match": m, "device": device,
                      "scores": np.array([x["score"] for x in all_d], dtype=np.float64),
                      "dt_ids": np.array([x.get("id", 0) for x in all_d]), "gt_ids": np.array([x.get("id", 0) for x in all_g])}
@@ -407,23 +438,73 @@ def inference_on_dataset(model, data_loader):
     return out
 
 
-class Omni3DEvaluator:
-    """reset() / process(inputs, outputs) / evaluate() around Omni3Deval (reference :643-935, reduced to the metric path:
-    AP2D / AP3D tables from in-memory ground truth; JSON dumps, per-category tables and visualisation are host bookkeeping)."""
+_METRICS = {"2D": ["AP", "AP50", "AP75", "AP95", "APs", "APm", "APl"], "3D": ["AP", "AP15", "AP25", "AP50", "APn", "APm", "APf"]}
 
-    def __init__(self, gt_annotations, img_ids=None, cat_ids=None, only_2d=False):
-        self._gt = gt_annotations
-        self._img_ids, self._cat_ids, self._only_2d = img_ids, cat_ids, only_2d
+
+def _derive_results(ev, mode, class_names):
+    """omni3d_evaluation.py:765-846: the seven headline numbers (x100, NaN when undefined) + per-category AP ('AP-<name>': mean
+    of the precision table over thresholds and recall points at area 'all', maxDets 100)"""
+    res = {name: float(ev.stats[i] * 100 if ev.stats[i] >= 0 else "nan") for i, name in enumerate(_METRICS[mode])}
+    if class_names is None or len(class_names) <= 1:
+        return res
+    prec = ev.eval["precision"]
+    assert len(class_names) == prec.shape[2], (len(class_names), prec.shape)
+    for k, name in enumerate(class_names):
+        vals = prec[:, :, k, 0, -1]
+        vals = vals[vals > -1]
+        res["AP-" + name] = float(np.mean(vals) * 100) if vals.size else float("nan")
+    return res
+
+
+class Omni3DEvaluator:
+    """Per-dataset evaluator (reference :643-935, a detectron2 COCOEvaluator subclass).
+
+    Reference form: `Omni3DEvaluator(dataset_name, output_dir=..., filter_settings=..., only_2d=..., eval_prox=..., distributed=...)`
+    -- the ground truth is the dataset's registered annotation file read through `Omni3D([json_file], filter_settings)`;
+    predictions are per-image dicts {'image_id', 'K', 'width', 'height', 'instances': [records with CONTIGUOUS category ids]}.
+    `evaluate()` maps the categories back to dataset ids, keeps the dataset's own categories, writes
+    `omni_instances_results.json`, runs Omni3Deval in 2D (and 3D) and returns {'bbox_2D': {...}, 'bbox_3D': {...},
+    'log_str_2D', 'log_str_3D', 'bbox_*_merge'} ('*_merge' = what the helper needs to score the union of several datasets; the
+    reference caches per-image match tables under '*_evals_per_cat_area' for the same purpose).
+
+    Short form (in-memory ground truth): `Omni3DEvaluator(gt_annotations, img_ids, cat_ids, only_2d)` with
+    `process(inputs, outputs)` taking model outputs -> {'bbox': {'AP2D', 'AP3D', 'omni_eval_*'}}."""
+
+    def __init__(self, dataset_name, tasks=None, distributed=True, output_dir=None, *, max_dets_per_image=None, use_fast_impl=False,
+                 eval_prox=False, only_2d=False, filter_settings=None, img_ids=None, cat_ids=None):
+        self._only_2d, self._eval_prox, self._output_dir, self._distributed = only_2d, eval_prox, output_dir, distributed
+        if not isinstance(dataset_name, str):                   # short form: (gt_annotations, img_ids, cat_ids, only_2d)
+            self._gt, self._omni_api = dataset_name, None
+            self._img_ids = tasks if tasks is not None else img_ids
+            self._cat_ids = cat_ids if isinstance(distributed, bool) else distributed
+            if output_dir is not None and not isinstance(output_dir, str):
+                self._only_2d, self._output_dir = bool(output_dir), None
+            self.reset()
+            return
+        from ...d2.data import MetadataCatalog
+        from ..data.datasets import Omni3D
+        self._filter_settings = filter_settings if filter_settings is not None else {}
+        self._metadata = MetadataCatalog.get(dataset_name)
+        self._omni_api = Omni3D([self._metadata.json_file], self._filter_settings)
+        self._do_evaluation = "annotations" in self._omni_api.dataset
         self.reset()
 
     def reset(self):
         self._predictions = []
+        self._results = {}
 
     def process(self, inputs, outputs):
         for inp, o in zip(inputs, outputs):
-            self._predictions.extend(instances_to_coco_json(o["instances"], inp["image_id"]))
+            recs = o["instances"] if isinstance(o["instances"], list) else instances_to_coco_json(o["instances"], inp["image_id"])
+            if self._omni_api is None:
+                self._predictions.extend(recs)
+            else:
+                pred = {"image_id": inp["image_id"], "K": inp["K"], "width": inp["width"], "height": inp["height"], "instances": recs}
+                if "p2" in inp:
+                    pred["p2"] = inp["p2"]
+                self._predictions.append(pred)
 
-    def evaluate(self):
+    def _evaluate_short(self):
         res = {}
         for mode in (["2D"] if self._only_2d else ["2D", "3D"]):
             ev = Omni3Deval(AnnotationIndex(copy.deepcopy(self._gt), self._img_ids, self._cat_ids),
@@ -435,20 +516,186 @@ class Omni3DEvaluator:
             res["omni_eval_" + mode] = ev
         return {"bbox": res}
 
+    def evaluate(self, img_ids=None):
+        if self._omni_api is None:
+            return self._evaluate_short()
+        from ...d2.data import MetadataCatalog
+        predictions = self._predictions
+        if self._distributed:
+            from ...d2 import comm
+            comm.synchronize()
+            gathered = comm.gather(predictions, dst=0)
+            predictions = [x for part in gathered for x in part]
+            if not comm.is_main_process():
+                return {}
+        self._results = {}
+        if len(predictions) == 0:
+            logging.getLogger(__name__).warning("[Omni3DEvaluator] Did not receive valid predictions.")
+            return {}
+        if self._output_dir:
+            os.makedirs(self._output_dir, exist_ok=True)
+            torch.save(predictions, os.path.join(self._output_dir, "instances_predictions.pth"))
+        model_meta = MetadataCatalog.get("omni3d_model")
+        model_classes = model_meta.thing_classes
+        # the split's own tables are filled in when its dataset dicts are loaded (load_omni3d_json); without a loader run the
+        # model's id table and the categories of the annotation file stand in (they are what the loader would have stored)
+        id_map = self._metadata.get("thing_dataset_id_to_contiguous_id") or model_meta.thing_dataset_id_to_contiguous_id
+        split_classes = self._metadata.get("thing_classes") or [c["name"] for c in sorted(self._omni_api.dataset["categories"], key=lambda c: c["id"])]
+        to_dataset_id = {v: k for k, v in id_map.items()}
+        num_classes = len(to_dataset_id)
+        kept = []
+        for rec in (r for pred in predictions for r in pred["instances"]):
+            c = rec["category_id"]
+            assert c < num_classes, f"A prediction has class={c}, but the model only has {num_classes} classes"
+            if model_classes[c] in split_classes:                         # categories this dataset is annotated for
+                r = dict(rec)
+                r["category_id"] = to_dataset_id[c]
+                kept.append(r)
+        if self._output_dir:
+            with open(os.path.join(self._output_dir, "omni_instances_results.json"), "w") as f:
+                json.dump(kept, f)
+        if not self._do_evaluation or len(kept) == 0:
+            return copy.deepcopy(self._results)
+        omni_dt = self._omni_api.loadRes(kept)
+        for mode in (["2D"] if self._only_2d else ["2D", "3D"]):
+            ev = Omni3Deval(self._omni_api, omni_dt, mode=mode, eval_prox=self._eval_prox)
+            if img_ids is not None:
+                ev.params.imgIds = img_ids
+            ev.evaluate()
+            ev.accumulate()
+            self._results["log_str_" + mode] = ev.summarize()
+            self._results["bbox_" + mode] = _derive_results(ev, mode, split_classes)
+            self._results["bbox_" + mode + "_merge"] = {"gt": self._omni_api, "dt": kept, "eval_prox": self._eval_prox,
+                                                        "img_ids": list(ev.params.imgIds), "cat_ids": list(ev.params.catIds)}
+        return copy.deepcopy({k: v for k, v in self._results.items() if not k.endswith("_merge")}) | \
+            {k: v for k, v in self._results.items() if k.endswith("_merge")}
+
 
 class Omni3DEvaluationHelper:
-    """omni3d_evaluation.py:168-520 aggregates per-dataset evaluators, JSON files and printed tables on the host; only the
-    container part is kept"""
+    """omni3d_evaluation.py:168-520: one `Omni3DEvaluator` per test split, their printed tables, and `summarize_all()` = the
+    metrics of the union of all splits (<Concat>) plus the Omni3D / Omni3D_In / Omni3D_Out aggregates.  Needs
+    `MetadataCatalog.get('omni3d_model').{thing_classes, thing_dataset_id_to_contiguous_id}`.  The union is scored by one
+    evaluation over the concatenated ground truth and detections (images of different splits are disjoint, so this equals the
+    reference's concatenation of cached per-image match tables), with proximity evaluation applied to the images of the splits
+    that use it."""
 
-    def __init__(self, dataset_names=(), filter_settings=None, output_folder=None, iter_label="-", only_2d=False):
-        self.dataset_names, self.output_folder, self.iter_label, self.only_2d = list(dataset_names), output_folder, iter_label, only_2d
-        self.evaluators, self.results = {}, {}
+    def __init__(self, dataset_names, filter_settings, output_folder, iter_label="-", only_2d=False):
+        from collections import OrderedDict
+        from ...d2.data import MetadataCatalog
+        from ..data.datasets import simple_register
+        self.dataset_names, self.filter_settings, self.output_folder = list(dataset_names), filter_settings, output_folder
+        self.iter_label, self.only_2d = iter_label, only_2d
+        self.evaluators, self.results = OrderedDict(), OrderedDict()
+        self.results_analysis, self.results_omni3d = OrderedDict(), OrderedDict()
+        self.overall_imgIds, self.overall_catIds = set(), set()
+        self.output_folders = {n: os.path.join(output_folder, n) for n in self.dataset_names}
+        for name in self.dataset_names:
+            if MetadataCatalog.get(name).get("json_file") is None:
+                simple_register(name, filter_settings, filter_empty=False)
+            ev = Omni3DEvaluator(name, output_dir=self.output_folders[name], filter_settings=filter_settings, only_2d=only_2d,
+                                 eval_prox=("Objectron" in name or "SUNRGBD" in name), distributed=False)
+            ev.reset()
+            self.evaluators[name] = ev
+            self.overall_imgIds.update(ev._omni_api.getImgIds())
+            self.overall_catIds.update(ev._omni_api.getCatIds())
 
     def add_predictions(self, dataset_name, predictions):
-        self.evaluators.setdefault(dataset_name, []).extend(predictions)
+        self.evaluators[dataset_name]._predictions += predictions
+
+    def save_predictions(self, dataset_name):
+        os.makedirs(self.output_folders[dataset_name], exist_ok=True)
+        torch.save(self.evaluators[dataset_name]._predictions, os.path.join(self.output_folders[dataset_name], "instances_predictions.pth"))
+
+    @staticmethod
+    def _mean(values):
+        values = list(values)
+        return float(np.mean(values)) if values else float("nan")
+
+    def _aggregates(self, res2d, res3d, categories):
+        nan = float("nan")
+        out = {"AP2D": self._mean(res2d["AP-" + c] for c in categories), "AP3D": nan}
+        if not self.only_2d:
+            out["AP3D"] = self._mean(res3d["AP-" + c] for c in categories)
+        return out
 
     def evaluate(self, dataset_name):
-        raise NotImplementedError("per-dataset JSON / table bookkeeping is host-side and out of the hot-path scope; use Omni3DEvaluator")
+        from ..data.datasets import get_omni3d_categories
+        from ..vis import logperf
+        log = logging.getLogger(__name__)
+        if dataset_name not in self.results:
+            self.results[dataset_name] = self.evaluators[dataset_name].evaluate()
+        res = self.results[dataset_name]
+        tag = "{} iter={} mode=".format(dataset_name, self.iter_label)
+        log.info("\n" + res["log_str_2D"].replace("mode=2D", tag + "2D"))
+        if not self.only_2d:
+            log.info("\n" + res["log_str_3D"].replace("mode=3D", tag + "3D"))
+        names = self.filter_settings["category_names"]
+        r2, r3 = res["bbox_2D"], res.get("bbox_3D", {})
+        present = {c for c in names if "AP-" + c in r2}
+        general = self._aggregates(r2, r3, present)
+        omni = {"AP2D": float("nan"), "AP3D": float("nan")}
+        split_cats = get_omni3d_categories(dataset_name)
+        if len(split_cats - present) == 0:
+            omni = self._aggregates(r2, r3, split_cats)
+        self.results_omni3d[dataset_name] = {"iters": self.iter_label, **omni}
+        extras = {k: (r3[k] if not self.only_2d else float("nan")) for k in ("AP15", "AP25", "AP50", "APn", "APm", "APf")}
+        self.results_analysis[dataset_name] = {"iters": self.iter_label, "AP2D": general["AP2D"], "AP3D": general["AP3D"],
+                                               "AP3D@15": extras["AP15"], "AP3D@25": extras["AP25"], "AP3D@50": extras["AP50"],
+                                               "AP3D-N": extras["APn"], "AP3D-M": extras["APm"], "AP3D-F": extras["APf"]}
+        logperf.print_ap_category_histogram(dataset_name, self._per_category(r2, r3))
+
+    def _per_category(self, r2, r3):
+        from collections import OrderedDict
+        out = OrderedDict()
+        for c in self.filter_settings["category_names"]:
+            a2 = r2.get("AP-" + c, float("nan"))
+            a3 = r3.get("AP-" + c, float("nan")) if not self.only_2d else float("nan")
+            if not np.isnan(a2) or not np.isnan(a3):
+                out[c] = {"AP2D": a2, "AP3D": a3}
+        return out
 
     def summarize_all(self):
-        return self.results
+        from ...d2.data import MetadataCatalog
+        from ..data.datasets import get_omni3d_categories
+        from ..vis import logperf
+        for name in self.dataset_names:
+            if name not in self.results:
+                self.evaluate(name)
+        meta = MetadataCatalog.get("omni3d_model")
+        cat_ids = sorted(self.overall_catIds)
+        ordered = [meta.thing_classes[meta.thing_dataset_id_to_contiguous_id[c]] for c in cat_ids]
+        categories = set(ordered)
+        merged = {}
+        for mode in (["2D"] if self.only_2d else ["2D", "3D"]):
+            gts, dts, prox_imgs = [], [], set()
+            for name in self.dataset_names:
+                rec = self.results[name].get("bbox_" + mode + "_merge")
+                if rec is None:
+                    continue
+                gts += rec["gt"].loadAnns(rec["gt"].getAnnIds(imgIds=rec["img_ids"], catIds=rec["cat_ids"]))
+                dts += rec["dt"]
+                if rec["eval_prox"]:
+                    prox_imgs.update(rec["img_ids"])
+            ev = Omni3Deval(AnnotationIndex(copy.deepcopy(gts), self.overall_imgIds, cat_ids),
+                            AnnotationIndex(copy.deepcopy(dts), self.overall_imgIds, cat_ids), mode=mode,
+                            eval_prox=(prox_imgs if prox_imgs else False))
+            ev.evaluate()
+            ev.accumulate()
+            ev.summarize()
+            merged[mode] = _derive_results(ev, mode, ordered if len(ordered) > 1 else None)
+            if len(ordered) == 1:       # _derive_results skips the per-category part for a single class
+                merged[mode]["AP-" + ordered[0]] = merged[mode]["AP"]
+        r2, r3 = merged["2D"], merged.get("3D", {})
+        general = self._aggregates(r2, r3, categories)
+        extras = {k: (r3[k] if not self.only_2d else float("nan")) for k in ("AP15", "AP25", "AP50", "APn", "APm", "APf")}
+        self.results_analysis["<Concat>"] = {"iters": self.iter_label, "AP2D": general["AP2D"], "AP3D": general["AP3D"],
+                                             "AP3D@15": extras["AP15"], "AP3D@25": extras["AP25"], "AP3D@50": extras["AP50"],
+                                             "AP3D-N": extras["APn"], "AP3D-M": extras["APm"], "AP3D-F": extras["APf"]}
+        for label, key in (("Omni3D_Out", "omni3d_out"), ("Omni3D_In", "omni3d_in"), ("Omni3D", "omni3d")):
+            want = get_omni3d_categories(key)
+            agg = self._aggregates(r2, r3, want) if len(want - categories) == 0 else {"AP2D": float("nan"), "AP3D": float("nan")}
+            self.results_omni3d[label] = {"iters": self.iter_label, **agg}
+        logperf.print_ap_category_histogram("<Concat>", self._per_category(r2, r3))
+        logperf.print_ap_analysis_histogram(self.results_analysis)
+        logperf.print_ap_omni_histogram(self.results_omni3d)
+        return self.results_analysis, self.results_omni3d

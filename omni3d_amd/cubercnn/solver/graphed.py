@@ -222,8 +222,10 @@ class GraphedPipelined:
         warm = torch.cuda.Stream()
         warm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(warm):       # warm-up off the capture: allocator pools, lazily built constants
-            for _ in range(warmup):
-                self._eager()               # (results dropped here: nothing of a warm-up step may die inside a capture)
+            for _ in range(warmup):             # the same collective sequence as a real step (early, late), waited for
+                _, _, pending = self._eager()   # (results dropped here: nothing of a warm-up step may die inside a capture)
+                self.optimizer.all_reduce_finish(pending + self.optimizer.all_reduce_begin("late", self.group), self.group)
+                del pending
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
         HF.side_mode("collect")

@@ -38,14 +38,82 @@ class CubeRCNNHandler:
         return local
 
 
+def approx_eval_resolution(h, w, scale_min=0, scale_max=1e10):
+    """math_util.py:262-289: the resolution an h x w image is run at under ResizeShortestEdge(scale_min, scale_max)
+    -> (h, w, factor original -> network)"""
+    orig_h = h
+    sf = scale_min / min(h, w)
+    h, w = h * sf, w * sf
+    sf = min(scale_max / max(h, w), 1.0)
+    h, w = h * sf, w * sf
+    return h, w, h / orig_h
+
+
+def _mean_std(values):
+    """pandas Series.mean() / .std() (ddof 1; NaN for a single sample) without pandas"""
+    a = np.asarray(values, dtype=np.float64)
+    return float(a.mean()), (float(a.std(ddof=1)) if len(a) > 1 else float("nan"))
+
+
 def compute_priors(cfg, datasets, max_cluster_rounds=1000, min_points_for_std=5):
-    """math_util.py:292-470 computes per-category (w, h, l) mean / std from the Omni3D annotation index.  Here `datasets` is a
-    list of dataset dicts (synthetic / pre-registered); category ids index the table.  -> {'priors_dims_per_cat': K x 2 x 3,
-    'priors_bins': None} (CLUSTER_BINS 1, the hot-path configuration)."""
+    """math_util.py:292-493: per-category statistics of the training annotations.  `datasets`: the Omni3D annotation index
+    (`cubercnn.data.Omni3D`: getAnnIds / loadAnns / imgs) or, as an extension, a list of dataset dicts.  Non-ignored annotations
+    of the model's categories (`MetadataCatalog.get('omni3d_model').thing_classes`) contribute; -> {'priors_dims_per_cat'
+    (K x [mean (w,h,l), std (w,h,l)]), 'priors_z3d_per_cat', 'priors_y3d_per_cat', 'priors_z3d', 'priors_y3d', 'priors_bins'};
+    categories without samples get the reference's placeholders ([[1,1,1],[1,1,1]], [50,50], [1,10]).  Depth is expressed in
+    virtual units when MODEL.ROI_CUBE_HEAD.VIRTUAL_DEPTH (as the reference does for its z statistics).  CLUSTER_BINS > 1 (k-means
+    over the 2D scale for Z_TYPE 'clusters') is not built, like the head mode that would consume it."""
+    if isinstance(datasets, (list, tuple)):
+        return _priors_from_dicts(cfg, datasets, min_points_for_std)
+    if cfg.MODEL.ROI_CUBE_HEAD.CLUSTER_BINS > 1:
+        raise NotImplementedError("priors_bins (CLUSTER_BINS > 1, Z_TYPE 'clusters') are not built")
+    from ...d2.data import MetadataCatalog
+    from ...d2.structures import BoxMode
+    names = list(MetadataCatalog.get("omni3d_model").thing_classes)
+    c = cfg.MODEL.ROI_CUBE_HEAD
+    rows = {n: [] for n in names}          # name -> [(y3d, z3d, w3d, h3d, l3d)]
+    for ann in datasets.loadAnns(datasets.getAnnIds()):
+        name = ann["category_name"].lower()
+        im = datasets.imgs[ann["image_id"]]
+        fy, im_h, im_w = im["K"][1][1], im["height"], im["width"]
+        if cfg.DATASETS.MODAL_2D_BOXES and "bbox2D_tight" in ann and ann["bbox2D_tight"][0] != -1:
+            pass
+        elif cfg.DATASETS.TRUNC_2D_BOXES and "bbox2D_trunc" in ann and not all(v == -1 for v in ann["bbox2D_trunc"]):
+            pass
+        elif "bbox2D_proj" not in ann:
+            continue                            # no usable 2D box: the reference skips the annotation here as well
+        _, y3d, z3d = ann["center_cam"]
+        w3d, h3d, l3d = ann["dimensions"]
+        if c.VIRTUAL_DEPTH:
+            test_h, _, _ = approx_eval_resolution(im_h, im_w, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+            z3d = z3d * (c.VIRTUAL_FOCAL * im_h) / (test_h * fy)          # real -> virtual (math_util.py:581-592 inverted)
+        if not ann["ignore"] and name in rows:
+            rows[name].append((y3d, z3d, w3d, h3d, l3d))
+    everything = [r for n in names for r in rows[n]]
+    if everything:
+        arr = np.asarray(everything, dtype=np.float64)
+        priors_y3d, priors_z3d = list(_mean_std(arr[:, 0])), list(_mean_std(arr[:, 1]))
+    else:
+        priors_y3d, priors_z3d = [float("nan")] * 2, [float("nan")] * 2
+    dims, z_cat, y_cat = [], [], []
+    for n in names:
+        if rows[n]:
+            arr = np.asarray(rows[n], dtype=np.float64)
+            ms = [_mean_std(arr[:, k]) for k in range(5)]
+            dims.append([[ms[2][0], ms[3][0], ms[4][0]], [ms[2][1], ms[3][1], ms[4][1]]])
+            z_cat.append(list(ms[1]))
+            y_cat.append(list(ms[0]))
+        else:
+            dims.append([[1.0, 1.0, 1.0], [1.0, 1.0, 1.0]])
+            z_cat.append([50, 50])
+            y_cat.append([1, 10])
+    return {"priors_dims_per_cat": dims, "priors_z3d_per_cat": z_cat, "priors_y3d_per_cat": y_cat, "priors_bins": [],
+            "priors_y3d": priors_y3d, "priors_z3d": priors_z3d}
+
+
+def _priors_from_dicts(cfg, datasets, min_points_for_std=5):
+    """extension: the same per-category dimension statistics from a list of dataset dicts (synthetic / pre-registered data)"""
     K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
-    if not isinstance(datasets, (list, tuple)):
-        raise NotImplementedError("priors from the Omni3D annotation index (datasets.getAnnIds / loadAnns) are dataset plumbing, "
-                                  "out of the hot-path scope; pass the list of dataset dicts")
     dims = [[] for _ in range(K)]
     for d in datasets:
         for a in d.get("annotations", []):

@@ -25,10 +25,25 @@ class _DatasetCatalog(dict):
         self.pop(name)
 
 
+class Metadata(types.SimpleNamespace):
+    """detectron2.data.catalog.Metadata: attribute bag with `.set(**kw)` / `.get(key, default)`; unknown attributes raise."""
+
+    def set(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+        return self
+
+    def get(self, key, default=None):
+        return getattr(self, key, default)
+
+    def as_dict(self):
+        return dict(vars(self))
+
+
 class _MetadataCatalog(dict):
     def get(self, name):
         if name not in self:
-            self[name] = types.SimpleNamespace(name=name)
+            self[name] = Metadata(name=name)
         return self[name]
 
     def list(self):

@@ -113,3 +113,58 @@ def register_synthetic_dataset(name, **kw):
         DatasetCatalog.remove(name)
     DatasetCatalog.register(name, lambda: dicts)
     return dicts
+
+
+def write_omni3d_dataset(root, name, category_names, category_ids=None, num_images=4, height=96, width=128, num_gt=4, seed=0, dataset_id=0,
+                         source="synthetic", image_id_base=None):
+    """Writes a synthetic split in the Omni3D ON-DISK format (reference DATA.md:133-198) under `root`:
+    `root/datasets/Omni3D/<name>.json` + `root/datasets/<name>/images/*.png`, the layout `cubercnn.data.simple_register` and
+    tools/train_net.py:380 expect relative to the working directory.  Scenes are the ones of `make_batch` (boxes projected from
+    the 3D cuboids, so `bbox2D_proj` / `bbox2D_trunc` / `bbox3D_cam` / `center_cam` / `dimensions` / `R_cam` are consistent),
+    categories cycle through `category_names`.  -> path of the JSON file."""
+    import json
+    import os
+    from PIL import Image
+    category_ids = list(category_ids) if category_ids is not None else list(range(len(category_names)))
+    img_dir = os.path.join(root, "datasets", name, "images")
+    os.makedirs(img_dir, exist_ok=True)
+    os.makedirs(os.path.join(root, "datasets", "Omni3D"), exist_ok=True)
+    base = image_id_base if image_id_base is not None else (dataset_id + 1) * 100000
+    images, annos = [], []
+    for i, b in enumerate(make_batch(num_images, height, width, num_gt, len(category_names), seed, None)):
+        rel = os.path.join(name, "images", f"{i:06d}.png")
+        Image.fromarray(np.ascontiguousarray(b["image"].numpy().transpose(1, 2, 0)[:, :, ::-1])).save(os.path.join(root, "datasets", rel))   # BGR -> RGB file
+        img_id = base + i
+        images.append({"id": img_id, "dataset_id": dataset_id, "width": width, "height": height, "file_path": rel, "K": b["K"],
+                       "src_90_rotate": 0, "src_flagged": False})
+        inst = b["instances"]
+        for j in range(len(inst)):
+            k = (i * num_gt + j) % len(category_names)
+            g = inst.gt_boxes3D[j].tolist()
+            R = inst.gt_poses[j].numpy().astype(np.float64)
+            box = [float(v) for v in inst.gt_boxes.tensor[j].tolist()]
+            annos.append({"id": len(annos) + 1 + base * 100, "image_id": img_id, "dataset_id": dataset_id, "category_id": category_ids[k],
+                          "category_name": category_names[k], "valid3D": True, "bbox2D_tight": [-1, -1, -1, -1], "bbox2D_proj": box,
+                          "bbox2D_trunc": box, "bbox3D_cam": _cuboid_corners(g[6:9], g[3:6], R).tolist(), "center_cam": [float(v) for v in g[6:9]],
+                          "dimensions": [float(v) for v in g[3:6]], "R_cam": R.tolist(), "behind_camera": False, "visibility": 1.0,
+                          "truncation": 0.0, "segmentation_pts": -1, "lidar_pts": -1, "depth_error": -1})
+    data = {"info": {"id": dataset_id, "source": source, "name": name, "split": name.rpartition("_")[2], "version": "0.1", "url": ""},
+            "images": images, "categories": [{"id": cid, "name": n, "supercategory": "object"} for cid, n in zip(category_ids, category_names)],
+            "annotations": annos}
+    path = os.path.join(root, "datasets", "Omni3D", name + ".json")
+    with open(path, "w") as f:
+        json.dump(data, f)
+    return path
+
+
+def write_omni3d_stats(root, category_names, category_ids=None):
+    """`datasets/Omni3D/stats.json` with the fields `register_and_store_model_metadata` reads (`category_names`, `categories`)"""
+    import json
+    import os
+    category_ids = list(category_ids) if category_ids is not None else list(range(len(category_names)))
+    path = os.path.join(root, "datasets", "Omni3D", "stats.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump({"n_datasets": 1, "n_ims": 0, "n_anns": 0, "category_names": list(category_names),
+                   "categories": [{"id": cid, "name": n} for cid, n in zip(category_ids, category_names)]}, f)
+    return path

@@ -107,6 +107,15 @@ def install():
     sys.modules["detectron2.utils.comm"] = comm
     _mod("detectron2.utils").comm = comm
     _mod("detectron2.utils.memory", retry_if_cuda_oom=ident)
+    # dataset / evaluator plumbing of the reference (cubercnn/data/datasets.py, evaluation/omni3d_evaluation.py) as an oracle for
+    # omni3d_amd/cubercnn/data/datasets.py: the catalogs are the plain registries of omni3d_amd.d2.data (no arithmetic), the
+    # pycocotools / PathManager / Timer pieces are restated in oracle/upstream.py
+    from omni3d_amd.d2.data import DatasetCatalog, MetadataCatalog
+    _mod("detectron2.data", MetadataCatalog=MetadataCatalog, DatasetCatalog=DatasetCatalog)
+    _mod("pycocotools.coco", COCO=U.COCO)
+    _mod("pycocotools.mask", iou=U.coco_box_iou)
+    _mod("detectron2.utils.file_io", PathManager=U.PathManagerLocal)
+    _mod("fvcore.common.timer", Timer=U.Timer)
     _mod("detectron2.utils.logger", _log_api_usage=lambda *a, **k: None)
     _mod("detectron2.modeling", PROPOSAL_GENERATOR_REGISTRY=U.PROPOSAL_GENERATOR_REGISTRY)
     _mod("detectron2.modeling.backbone", Backbone=U.Backbone, BACKBONE_REGISTRY=U.BACKBONE_REGISTRY)

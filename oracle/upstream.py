@@ -1200,3 +1200,176 @@ def warmup_multistep_lr_factor(it, steps, gamma=0.1, warmup_iters=1000, warmup_f
             alpha = it / warmup_iters
             f *= warmup_factor * (1 - alpha) + alpha
     return f
+
+
+# ------------------------------------------------------------------------------------------------
+# pycocotools.coco.COCO / pycocotools.mask.iou (pycocotools 2.0, not installable here): the calls
+# cubercnn/data/datasets.py:140-448 and cubercnn/evaluation/omni3d_evaluation.py make, restated from
+# the published API so that the reference's OWN dataset / evaluator files can be run as the oracle
+# for omni3d_amd/cubercnn/data/datasets.py (tests/test_datasets_io.py).  TEST INFRASTRUCTURE.
+# ------------------------------------------------------------------------------------------------
+class COCO:
+    def __init__(self, annotation_file=None):
+        import json as _json
+        from collections import defaultdict as _dd
+        self.dataset, self.anns, self.cats, self.imgs = dict(), dict(), dict(), dict()
+        self.imgToAnns, self.catToImgs = _dd(list), _dd(list)
+        if annotation_file is not None:
+            with open(annotation_file, "r") as f:
+                dataset = _json.load(f)
+            assert type(dataset) == dict, "annotation file format {} not supported".format(type(dataset))
+            self.dataset = dataset
+            self.createIndex()
+
+    def createIndex(self):
+        from collections import defaultdict as _dd
+        anns, cats, imgs = {}, {}, {}
+        imgToAnns, catToImgs = _dd(list), _dd(list)
+        if "annotations" in self.dataset:
+            for ann in self.dataset["annotations"]:
+                imgToAnns[ann["image_id"]].append(ann)
+                anns[ann["id"]] = ann
+        if "images" in self.dataset:
+            for img in self.dataset["images"]:
+                imgs[img["id"]] = img
+        if "categories" in self.dataset:
+            for cat in self.dataset["categories"]:
+                cats[cat["id"]] = cat
+        if "annotations" in self.dataset and "categories" in self.dataset:
+            for ann in self.dataset["annotations"]:
+                catToImgs[ann["category_id"]].append(ann["image_id"])
+        self.anns, self.imgToAnns, self.catToImgs, self.imgs, self.cats = anns, imgToAnns, catToImgs, imgs, cats
+
+    @staticmethod
+    def _isArrayLike(obj):
+        return hasattr(obj, "__iter__") and hasattr(obj, "__len__")
+
+    def getAnnIds(self, imgIds=[], catIds=[], areaRng=[], iscrowd=None):
+        import itertools as _it
+        imgIds = imgIds if self._isArrayLike(imgIds) else [imgIds]
+        catIds = catIds if self._isArrayLike(catIds) else [catIds]
+        if len(imgIds) == len(catIds) == len(areaRng) == 0:
+            anns = self.dataset["annotations"]
+        else:
+            if not len(imgIds) == 0:
+                lists = [self.imgToAnns[imgId] for imgId in imgIds if imgId in self.imgToAnns]
+                anns = list(_it.chain.from_iterable(lists))
+            else:
+                anns = self.dataset["annotations"]
+            anns = anns if len(catIds) == 0 else [ann for ann in anns if ann["category_id"] in catIds]
+            anns = anns if len(areaRng) == 0 else [ann for ann in anns if ann["area"] > areaRng[0] and ann["area"] < areaRng[1]]
+        if iscrowd is not None:
+            return [ann["id"] for ann in anns if ann["iscrowd"] == iscrowd]
+        return [ann["id"] for ann in anns]
+
+    def getCatIds(self, catNms=[], supNms=[], catIds=[]):
+        catNms = catNms if self._isArrayLike(catNms) else [catNms]
+        supNms = supNms if self._isArrayLike(supNms) else [supNms]
+        catIds = catIds if self._isArrayLike(catIds) else [catIds]
+        if len(catNms) == len(supNms) == len(catIds) == 0:
+            cats = self.dataset["categories"]
+        else:
+            cats = self.dataset["categories"]
+            cats = cats if len(catNms) == 0 else [cat for cat in cats if cat["name"] in catNms]
+            cats = cats if len(supNms) == 0 else [cat for cat in cats if cat["supercategory"] in supNms]
+            cats = cats if len(catIds) == 0 else [cat for cat in cats if cat["id"] in catIds]
+        return [cat["id"] for cat in cats]
+
+    def getImgIds(self, imgIds=[], catIds=[]):
+        imgIds = imgIds if self._isArrayLike(imgIds) else [imgIds]
+        catIds = catIds if self._isArrayLike(catIds) else [catIds]
+        if len(imgIds) == len(catIds) == 0:
+            ids = self.imgs.keys()
+        else:
+            ids = set(imgIds)
+            for i, catId in enumerate(catIds):
+                if i == 0 and len(ids) == 0:
+                    ids = set(self.catToImgs[catId])
+                else:
+                    ids &= set(self.catToImgs[catId])
+        return list(ids)
+
+    def loadAnns(self, ids=[]):
+        return [self.anns[i] for i in ids] if self._isArrayLike(ids) else [self.anns[ids]]
+
+    def loadCats(self, ids=[]):
+        return [self.cats[i] for i in ids] if self._isArrayLike(ids) else [self.cats[ids]]
+
+    def loadImgs(self, ids=[]):
+        return [self.imgs[i] for i in ids] if self._isArrayLike(ids) else [self.imgs[ids]]
+
+    def loadRes(self, resFile):
+        import copy as _copy
+        res = COCO()
+        res.dataset["images"] = [img for img in self.dataset["images"]]
+        anns = resFile
+        assert type(anns) == list, "results in not an array of objects"
+        annsImgIds = [ann["image_id"] for ann in anns]
+        assert set(annsImgIds) == (set(annsImgIds) & set(self.getImgIds())), "Results do not correspond to current coco set"
+        if "bbox" in anns[0] and not anns[0]["bbox"] == []:
+            res.dataset["categories"] = _copy.deepcopy(self.dataset["categories"])
+            for id, ann in enumerate(anns):
+                bb = ann["bbox"]
+                ann["area"] = bb[2] * bb[3]
+                ann["id"] = id + 1
+                ann["iscrowd"] = 0
+        res.dataset["annotations"] = anns
+        res.createIndex()
+        return res
+
+
+def coco_box_iou(dt, gt, iscrowd):
+    """pycocotools.mask.iou for XYWH boxes: (D, G) array, [] when either list is empty (bbIou of maskApi.c)"""
+    import numpy as _np
+    if len(dt) == 0 or len(gt) == 0:
+        return []
+    d, g = _np.asarray(dt, dtype=_np.float64).reshape(-1, 4), _np.asarray(gt, dtype=_np.float64).reshape(-1, 4)
+    out = _np.zeros((len(d), len(g)))
+    for j in range(len(g)):
+        ga = g[j, 2] * g[j, 3]
+        for i in range(len(d)):
+            da = d[i, 2] * d[i, 3]
+            w = min(d[i, 0] + d[i, 2], g[j, 0] + g[j, 2]) - max(d[i, 0], g[j, 0])
+            h = min(d[i, 1] + d[i, 3], g[j, 1] + g[j, 3]) - max(d[i, 1], g[j, 1])
+            inter = max(w, 0) * max(h, 0)
+            u = da if iscrowd[j] else da + ga - inter
+            out[i, j] = inter / u if u > 0 else 0.0
+    return out
+
+
+class PathManagerLocal:
+    """detectron2.utils.file_io.PathManager for local paths"""
+
+    @staticmethod
+    def get_local_path(path):
+        return path
+
+    @staticmethod
+    def open(path, mode="r"):
+        return open(path, mode)
+
+    @staticmethod
+    def mkdirs(path):
+        import os as _os
+        _os.makedirs(path, exist_ok=True)
+
+    @staticmethod
+    def exists(path):
+        import os as _os
+        return _os.path.exists(path)
+
+    @staticmethod
+    def register_handler(handler):        # cubercnn/util/model_zoo.py:25 registers its `cubercnn://` handler at import time
+        pass
+
+
+class Timer:
+    """fvcore.common.timer.Timer (seconds() only)"""
+
+    def __init__(self):
+        import time as _time
+        self._t0 = _time.perf_counter()
+
+    def seconds(self):
+        import time as _time
+        return _time.perf_counter() - self._t0
