@@ -3,7 +3,8 @@
 The reference's loader is torch DataLoader workers around JPEG decoding -- host-side I/O, outside the MI355X hot path
 (SURVEY.md 8b).  What the training loop needs from it is kept: an endless iterator of `IMS_PER_BATCH / world` mapped dicts
 per step, drawn by a seeded shuffling sampler sharded over ranks (detectron2 TrainingSampler), from the dicts registered in
-`DatasetCatalog` under cfg.DATASETS.TRAIN.  Dataset balancing / repeat-factor sampling (build.py:60-112) are not built."""
+`DatasetCatalog` under cfg.DATASETS.TRAIN, with the reference's category repeat factors (RepeatFactorTrainingSampler) and
+per-source balancing (DATALOADER.BALANCE_DATASETS, build.py:60-121)."""
 import itertools
 
 import numpy as np
@@ -40,6 +41,24 @@ def repeat_factors_from_category_frequency(dataset_dicts, repeat_thresh):
     rep = {c: max(1.0, math.sqrt(repeat_thresh / (v / n))) for c, v in freq.items()}
     out = [max({rep[c] for c in {a["category_id"] for a in d["annotations"]} if c >= 0}, default=1.0) for d in dataset_dicts]
     return torch.tensor(out, dtype=torch.float32)
+
+
+def dataset_balance_weights(dataset_dicts, dataset_id_to_src):
+    """build.py:66-91 (DATALOADER.BALANCE_DATASETS): images of a source that contributes the fraction p of the training set get
+    the weight (1 - p) / min over sources of (1 - p); a single source gives all ones"""
+    assert dataset_id_to_src is not None, "Need dataset sources."
+    sources = sorted(set(dataset_id_to_src.values()), key=str)
+    src_of = np.array([sources.index(dataset_id_to_src[d["dataset_id"]]) for d in dataset_dicts])
+    present = np.unique(src_of)
+    if len(present) == 1:
+        return torch.ones(len(src_of), dtype=torch.float32)
+    counts = np.bincount(src_of, minlength=len(sources))[present].astype(np.float64)
+    w = 1.0 - counts / counts.sum()
+    w = w / w.min()
+    out = torch.zeros(len(src_of), dtype=torch.float32)
+    for s_id, wt in zip(present, w):
+        out[torch.from_numpy(src_of == s_id)] = float(wt)
+    return out
 
 
 class _TrainLoader:
@@ -80,14 +99,16 @@ def build_detection_train_loader(cfg, mapper=None, *, dataset=None, sampler=None
         from .dataset_mapper import DatasetMapper3D
         mapper = DatasetMapper3D(cfg, True)
     name = cfg.DATALOADER.SAMPLER_TRAIN
-    if getattr(cfg.DATALOADER, "BALANCE_DATASETS", False):
-        raise NotImplementedError("DATALOADER.BALANCE_DATASETS (per-source re-weighting, build.py:66-91) is host-side sampling, not built")
-    if name == "TrainingSampler":
-        rf = None
-    elif name == "RepeatFactorTrainingSampler":
-        rf = repeat_factors_from_category_frequency(dataset, cfg.DATALOADER.REPEAT_THRESHOLD)
-    else:
+    if name not in ("TrainingSampler", "RepeatFactorTrainingSampler"):
         raise ValueError("Unknown training sampler: {}".format(name))
+    rf = repeat_factors_from_category_frequency(dataset, cfg.DATALOADER.REPEAT_THRESHOLD) if name == "RepeatFactorTrainingSampler" else None
+    if getattr(cfg.DATALOADER, "BALANCE_DATASETS", False):
+        w = dataset_balance_weights(dataset, dataset_id_to_src)
+        if rf is None:                   # TrainingSampler + balancing = repeat factors equal to the source weights (build.py:104-105)
+            rf = w
+        else:                            # categories AND sources (build.py:115-121)
+            rf = rf * w
+            rf = rf / rf.min().item()
     total = cfg.SOLVER.IMS_PER_BATCH if total_batch_size is None else total_batch_size
     world = comm.get_world_size()
     assert total > 0 and total % world == 0, "Total batch size ({}) must be divisible by the number of gpus ({}).".format(total, world)
