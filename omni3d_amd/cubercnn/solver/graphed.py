@@ -184,8 +184,8 @@ class GraphedPipelined:
 
     so weight gradients, which nothing on the critical path waits for, fill the CUs the small data-gradient kernels of the
     next stages leave idle.  Measured on MI355X (batch 4 x 512 x 512): 14.07 ms / step with 4 stages against 14.65 ms for the
-    single graph (6 stages 14.18, 3 stages 14.42, 2 stages 14.92: every M -> M boundary costs up to ~200 us of idle main
-    queue while the side queue starts, which bounds the useful number of stages).  A single graph with parallel branches is
+    single graph (6 stages 14.18, 3 stages 14.42, 2 stages 14.92: when a weight-gradient graph starts, the critical-path
+    kernels wait up to ~200 us for CU slots, which bounds the useful number of stages).  A single graph with parallel branches is
     no alternative: ROCm 7.2 replays such a graph node by node from the host, 12 ms per step instead of 0.7 ms; neither is a
     high-priority main stream (graph replays on it run 2x slower).
 
