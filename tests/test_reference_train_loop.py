@@ -115,3 +115,32 @@ def test_reference_main_runs_literally(emu_lib, tmp_path, monkeypatch):
     inf = os.path.join(out, "inference", "iter_final", "KITTI_test")
     assert os.path.exists(os.path.join(inf, "instances_predictions.pth"))
     assert MetadataCatalog.get("omni3d_model").thing_classes == [n for _, n in sorted(zip(ids, names))]
+    first = torch.load(os.path.join(inf, "instances_predictions.pth"), weights_only=False)
+    # ---- the script's --eval-only path (:365-379, :432-438): categories from <config dir>/category_meta.json, weights through
+    # DetectionCheckpointer.resume_or_load, straight to do_test; same weights => same detections
+    import shutil
+    cfg_dir = os.path.join(root, "cfgdir")
+    os.makedirs(cfg_dir)
+    for f in os.listdir(os.path.join(ROOT, "configs")):
+        shutil.copy(os.path.join(ROOT, "configs", f), cfg_dir)
+    shutil.copy(os.path.join(out, "category_meta.json"), cfg_dir)
+    out2 = os.path.join(root, "output_eval")
+    opts = list(args.opts)
+    opts[opts.index("OUTPUT_DIR") + 1] = out2
+    opts[opts.index("MODEL.WEIGHTS") + 1] = os.path.join(out, "model_final.pth")
+    args2 = argparse.Namespace(**{**vars(args), "config_file": os.path.join(cfg_dir, "cubercnn_DLA34_FPN.yaml"), "eval_only": True, "opts": opts})
+    MetadataCatalog.pop("omni3d_model", None)
+    for n in ("KITTI_train", "KITTI_test"):
+        if n in DatasetCatalog:
+            DatasetCatalog.remove(n)
+        MetadataCatalog.pop(n, None)
+    os.chdir(root)
+    try:
+        mod.main(args2)
+    finally:
+        os.chdir(cwd)
+    second = torch.load(os.path.join(out2, "inference", "iter_final", "KITTI_test", "instances_predictions.pth"), weights_only=False)
+    assert [len(p["instances"]) for p in first] == [len(p["instances"]) for p in second]
+    for a, b in zip(first, second):
+        for x, y in zip(a["instances"], b["instances"]):
+            assert x["category_id"] == y["category_id"] and abs(x["score"] - y["score"]) < 1e-5
