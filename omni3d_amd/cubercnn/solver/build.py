@@ -53,6 +53,7 @@ class FlatSGD(torch.optim.Optimizer):
         self._steps = 0
         self.skip_flag = None   # optional device float: != 0 skips the update inside the kernel
         self._grad_scale = 1.0  # consumed by the next step(): 1/world when the all-reduce left SUMS in the bucket
+        self._exchanged = False  # did this step's gradients go through all_reduce_begin / all_reduce_finish?
 
     def _build_buckets(self):
         plist = [(g, p) for g in self.param_groups for p in g["params"]]
@@ -120,6 +121,7 @@ class FlatSGD(torch.optim.Optimizer):
         from ... import functional as HF
         HF.side_join()            # weight-gradient stream (normally already joined by the end-of-backward callback)
         self.flat_grad.zero_()
+        self._exchanged = False
 
     @torch.no_grad()
     def _rebind_grads(self):
@@ -160,6 +162,7 @@ class FlatSGD(torch.optim.Optimizer):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
             return []
+        self._exchanged = True
         ranges = self.early_ranges if which == "early" else self.late_ranges
         return [(dist.all_reduce(self.flat_grad[s:e], group=group, async_op=True), s, e) for s, e in ranges]
 
@@ -188,6 +191,14 @@ class FlatSGD(torch.optim.Optimizer):
         from ... import functional as HF
         HF.side_join()
         self._rebind_grads()
+        if not self._exchanged:
+            # Data-parallel safety net.  The reference's loop (tools/train_net.py:449-454) relies on DistributedDataParallel's
+            # autograd hooks for the gradient exchange; with direct accumulation the weight gradients never pass through
+            # autograd, so those hooks would see nothing.  If the process group has more than one rank and nobody called
+            # all_reduce_begin for this step, the bucket is averaged here (a no-op on values DDP already made identical).
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                self.all_reduce_grads()
         first = self._steps == 0
         for start, end, g in self.segments:
             det.sgd_step(self.flat_param[start:end], self.flat_grad[start:end], self.flat_mom[start:end], g["lr"],

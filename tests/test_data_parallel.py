@@ -128,7 +128,7 @@ def test_two_phase_overlapped_exchange_world2(emu_lib, tmp_path, pipelined):
         assert (tp[0][n] - sp[0][n]).abs().max() <= 1e-6 * max(1.0, float(sp[0][n].abs().max())), n
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, explicit=True):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _install_emulator()
@@ -138,15 +138,19 @@ def _worker(rank, world, port, out):
     for _ in range(2):
         opt.zero_grad()
         net(_shard(rank)).backward()
-        opt.all_reduce_grads()
-        opt.step()
+        if explicit:
+            opt.all_reduce_grads()
+        opt.step()          # not explicit: the loop of tools/train_net.py:245-253 -- step() exchanges the bucket itself
     torch.save(opt.flat_param.clone(), os.path.join(out, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_flat_bucket_allreduce_world2(emu_lib, tmp_path):
+@pytest.mark.parametrize("explicit", [True, False])
+def test_flat_bucket_allreduce_world2(emu_lib, tmp_path, explicit):
+    """explicit=False: a loop that never calls the exchange (the reference's relies on DDP hooks, which direct gradient
+    accumulation bypasses) still trains identical replicas -- FlatSGD.step() averages the bucket when nobody did"""
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), explicit), nprocs=world, join=True)
     got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
     assert torch.equal(got[0], got[1])                      # replicas stay identical
     # single-process reference: two replicas (per-shard BN statistics, like the reference's per-GPU BatchNorm),
