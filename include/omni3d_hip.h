@@ -219,22 +219,34 @@ int omni_box_loss_bwd(const float* pred, int ldp, int R, int K, const int* cls, 
                       const int* gt_row, float wx, float wy, float ww, float wh, const double* sums,
                       const float* g_cls, const float* g_reg, float* dpred, void* stream);
 
-/* ROIHeads3D._forward_cube decode + disentangled losses (cubercnn/modeling/roi_heads/roi_heads.py:
- * 374-768) on the fused cube-head outputs head (F, ldh) = [xy 2K | z K | dims 3K | pose Pn*K | uncert K (if confidence)],
- * Pn = 6 / 4 / 3 for POSE_TYPE 6d / quaternion / euler (cube_head.py:118-128,175-185).
- * mode = MODEL.ROI_CUBE_HEAD configuration: bits 0-1 Z_TYPE (0 direct, 1 sigmoid, 2 log), bits 2-3 dimensions (0 priors 'exp',
- * 1 priors 'sigmoid', 2 DIMS_PRIORS_ENABLED False), bits 4-5 POSE_TYPE (0 6d, 1 quaternion, 2 euler), bit 6 ALLOCENTRIC_POSE,
- * bit 7 VIRTUAL_DEPTH, bit 8 CHAMFER_POSE, bit 9 INVERSE_Z_WEIGHT, bit 10 USE_CONFIDENCE > 0, bit 11 LOSS_W_JOINT > 0
- * (configs/Base.yaml = 0xDC0).  DISENTANGLED_LOSS is always on; Z_TYPE 'clusters' is not built.
+/* FastRCNNOutputLayers.predict_boxes_for_gt_classes (detectron2), called at cubercnn/modeling/roi_heads/roi_heads.py:276-289
+ * (MODEL.ROI_BOX_HEAD.TRAIN_ON_PRED_BOXES): out (R,4) = Box2BoxTransform.apply_deltas of each row's GT-class deltas
+ * (class clamped to [0, K-1]; cls < 0 copies the proposal) on its proposal box, unclipped. */
+int omni_box_decode_gt_class(const float* pred, int ldp, int R, int K, const int* cls, const float* prop, float wx, float wy,
+                             float ww, float wh, float scale_clamp, float* out, void* stream);
+
+/* ROIHeads3D._forward_cube decode + losses (cubercnn/modeling/roi_heads/roi_heads.py:374-768) on the fused cube-head
+ * outputs head (F, ldh) = [xy 2K | z K*bins (bin*K + class) | dims 3K | pose Pn*K | uncert K (if confidence)],
+ * Pn = 6 / 4 / 3 for POSE_TYPE 6d / quaternion / euler (cube_head.py:118-136,175-192), bins = max(CLUSTER_BINS, 1).
+ * mode = MODEL.ROI_CUBE_HEAD configuration: bits 0-1 Z_TYPE (0 direct, 1 sigmoid, 2 log, 3 clusters), bits 2-3 dimensions
+ * (0 priors 'exp', 1 priors 'sigmoid', 2 DIMS_PRIORS_ENABLED False), bits 4-5 POSE_TYPE (0 6d, 1 quaternion, 2 euler),
+ * bit 6 ALLOCENTRIC_POSE, bit 7 VIRTUAL_DEPTH, bit 8 CHAMFER_POSE, bit 9 INVERSE_Z_WEIGHT, bit 10 USE_CONFIDENCE > 0,
+ * bit 11 LOSS_W_JOINT > 0, bit 12 DISENTANGLED_LOSS False (configs/Base.yaml = 0xDC0).
+ * zscales (K, bins): 2D-scale prior of every depth cluster (roi_heads.py:123-130), zstats (K, bins, 2): its depth mean / std
+ * (:133-143); null when bins == 1 / Z_TYPE is not 'clusters'.  Bit 12 needs dimensions = 2: the reference's own entangled
+ * dimension loss cannot be evaluated with priors (roi_heads.py:620-622 divides an (n,3) by an (n,2,3) tensor).
  * w_*: MODEL.ROI_CUBE_HEAD.LOSS_W_{DIMS,POSE,XY,Z,JOINT}, used for the logged `Cube/total_3D_loss` (:651-695). */
-int omni_cube_loss_fwd(const float* head, int ldh, int F, int K, int mode, const float* boxes, const int* cls, const int* img,
+int omni_cube_loss_fwd(const float* head, int ldh, int F, int K, int mode, int bins, const float* zscales, const float* zstats,
+                       const float* boxes, const int* cls, const int* img,
                        const float* Ks, const float* v2r, const float* priors, const float* gt3d,
                        const float* gtpose, const int* gt_row, float w_dims, float w_pose, float w_xy, float w_z, float w_joint,
                        float* vals, float* jac, float* red, void* stream);
-int omni_cube_loss_bwd(const float* vals, const float* jac, const float* red, const float* gk, const int* cls, int F,
-                       int K, int mode, int ldh, float* dhead, void* stream);
+int omni_cube_loss_bwd(const float* vals, const float* jac, const float* red, const float* gk, const int* cls,
+                       const float* boxes, int F, int K, int mode, int bins, const float* zscales, int ldh, float* dhead,
+                       void* stream);
 /* inference outputs (roi_heads.py:771-819): cube3d (F,9), pose (F,9), verts (F,24). */
-int omni_cube_decode(const float* head, int ldh, int F, int K, int mode, const float* boxes, const int* cls, const int* img,
+int omni_cube_decode(const float* head, int ldh, int F, int K, int mode, int bins, const float* zscales, const float* zstats,
+                     const float* boxes, const int* cls, const int* img,
                      const float* Ks, const float* v2r, const float* ratio, const float* priors, float* cube3d,
                      float* pose, float* verts, void* stream);
 /* util.get_cuboid_verts_faces (cubercnn/util/math_util.py:116-219): box3d (n,6), R (n,9) -> (n,24). */

@@ -91,6 +91,26 @@ __global__ void __launch_bounds__(256) box_loss_kernel(const float* __restrict__
     }
 }
 
+// FastRCNNOutputLayers.predict_boxes_for_gt_classes (detectron2; called at roi_heads.py:276-289): Box2BoxTransform.apply_deltas
+// of the deltas of each row's (clamped) GT class on its proposal box; no clipping.  Padding rows (cls < 0) copy the proposal.
+__global__ void __launch_bounds__(256) box_decode_gt_kernel(const float* __restrict__ pred, int ldp, int R, int K,
+                                                            const int* __restrict__ cls, const float* __restrict__ prop,
+                                                            float wx, float wy, float ww, float wh, float scale_clamp,
+                                                            float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* pb = prop + 4 * (long)r;
+    float* o = out + 4 * (long)r;
+    int c = cls[r];
+    if (c < 0) { o[0] = pb[0]; o[1] = pb[1]; o[2] = pb[2]; o[3] = pb[3]; return; }
+    c = c > K - 1 ? K - 1 : c;                              // gt_classes.clamp_(0, K - 1): background rows use the last class
+    const float* d = pred + (long)r * ldp + (K + 1) + 4 * c;
+    const float w = pb[2] - pb[0], h = pb[3] - pb[1], cx = pb[0] + 0.5f * w, cy = pb[1] + 0.5f * h;
+    const float dx = d[0] / wx, dy = d[1] / wy, dw = fminf(d[2] / ww, scale_clamp), dh = fminf(d[3] / wh, scale_clamp);
+    const float pcx = dx * w + cx, pcy = dy * h + cy, pw = expf(dw) * w, ph = expf(dh) * h;
+    o[0] = pcx - 0.5f * pw; o[1] = pcy - 0.5f * ph; o[2] = pcx + 0.5f * pw; o[3] = pcy + 0.5f * ph;
+}
+
 }  // namespace
 
 extern "C" {
@@ -115,6 +135,16 @@ int omni_box_loss_bwd(const float* pred, int ldp, int R, int K, const int* cls, 
     if (R == 0) return OMNI_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(box_loss_kernel<1>), dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, pred, ldp,
                        R, K, cls, prop, gt, gt_row, wx, wy, ww, wh, const_cast<double*>(sums), g_cls, g_reg, dpred);
+    return omni_launch_status();
+}
+
+// out (R, 4): the predicted box of each row's GT class (TRAIN_ON_PRED_BOXES, roi_heads.py:283-289).
+int omni_box_decode_gt_class(const float* pred, int ldp, int R, int K, const int* cls, const float* prop, float wx, float wy,
+                             float ww, float wh, float scale_clamp, float* out, void* stream) {
+    if (R < 0 || K <= 0 || ldp < 5 * K + 1) return OMNI_ERR_ARG;
+    if (R == 0) return OMNI_OK;
+    hipLaunchKernelGGL(box_decode_gt_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred, ldp, R, K, cls, prop,
+                       wx, wy, ww, wh, scale_clamp, out);
     return omni_launch_status();
 }
 

@@ -22,16 +22,19 @@
 // 93 spilled, 6.7 KB of scratch per lane, 8 waves on the whole chip).  Branch decisions depend on values only, so the
 // 16 lanes of a ROI never diverge.
 //
-// head (F, ldh): fused linear outputs, columns = [xy deltas K*2 | z K | dims K*3 | pose K*Pn | uncert K (if confidence)],
-// Pn = 6 / 4 / 3 for POSE_TYPE 6d / quaternion / euler.
+// head (F, ldh): fused linear outputs, columns = [xy deltas K*2 | z K*bins (bin-major: bin*K + class) | dims K*3 | pose K*Pn |
+// uncert K (if confidence)], Pn = 6 / 4 / 3 for POSE_TYPE 6d / quaternion / euler, bins = max(CLUSTER_BINS, 1).
 //
 // Head configuration (MODEL.ROI_CUBE_HEAD.*, roi_heads.py:426-768, cube_head.py:147-197) packed into `mode` by the host
 // (kernels/det.py:cube_mode):
-//   bits 0-1 Z_TYPE (0 direct, 1 sigmoid, 2 log)      bits 2-3 dims (0 priors 'exp', 1 priors 'sigmoid', 2 priors disabled)
+//   bits 0-1 Z_TYPE (0 direct, 1 sigmoid, 2 log, 3 clusters)   bits 2-3 dims (0 priors 'exp', 1 priors 'sigmoid', 2 priors disabled)
 //   bits 4-5 POSE_TYPE (0 6d, 1 quaternion, 2 euler)  bit 6 ALLOCENTRIC_POSE   bit 7 VIRTUAL_DEPTH   bit 8 CHAMFER_POSE
-//   bit 9 INVERSE_Z_WEIGHT   bit 10 USE_CONFIDENCE > 0   bit 11 LOSS_W_JOINT > 0
+//   bit 9 INVERSE_Z_WEIGHT   bit 10 USE_CONFIDENCE > 0   bit 11 LOSS_W_JOINT > 0   bit 12 DISENTANGLED_LOSS False
+// With bins > 1 the depth output of a ROI is the one of the cluster whose 2D scale prior `zscales` (K, bins) is nearest to the
+// proposal's diagonal (roi_heads.py:432-442); Z_TYPE 'clusters' maps it through a sigmoid scaled to mean +- 3 std of that
+// cluster's depth prior `zstats` (K, bins, 2) (roi_heads.py:501-522).
 // The kernels are instantiated once with the configs/Base.yaml mode as a compile-time constant (every branch folds) and
-// once with the mode read at run time.  Z_TYPE 'clusters' / CLUSTER_BINS > 1 and DISENTANGLED_LOSS False are not built.
+// once with the mode read at run time.
 #include <device_rt.h>
 #pragma clang fp contract(off)
 
@@ -44,10 +47,14 @@
 #define M_INVZ(m) (((m) >> 9) & 1)
 #define M_CONF(m) (((m) >> 10) & 1)
 #define M_JOINT(m) (((m) >> 11) & 1)
+#define M_ENTANGLED(m) (((m) >> 12) & 1)
 #define M_POSE_WIDTH(m) (M_POSE(m) == 0 ? 6 : (M_POSE(m) == 1 ? 4 : 3))
-#define M_HEAD_WIDTH(m) (6 + M_POSE_WIDTH(m) + M_CONF(m))
+#define M_HEAD_WIDTH(m, bins) (5 + (bins) + M_POSE_WIDTH(m) + M_CONF(m))
 #define MODE_BASE ((1 << 6) | (1 << 7) | (1 << 8) | (1 << 10) | (1 << 11))
-#define MODE_VALID(m) ((m) >= 0 && (m) < 4096 && M_Z(m) < 3 && M_DIMS(m) < 3 && M_POSE(m) < 3)
+// the reference's entangled dimension loss only evaluates without dimension priors (roi_heads.py:620-622 divides (n,3) by (n,2,3))
+#define MODE_VALID(m, bins, zs, zt) ((m) >= 0 && (m) < 8192 && M_DIMS(m) < 3 && M_POSE(m) < 3 && (bins) >= 1 && (bins) <= 64 && \
+                                     ((bins) == 1 || (zs) != nullptr) && (M_Z(m) != 3 || ((bins) > 1 && (zt) != nullptr)) && \
+                                     (!M_ENTANGLED(m) || M_DIMS(m) == 2))
 
 namespace {
 
@@ -219,30 +226,72 @@ struct RoiIn {
     float v2r;         // virtual_to_real = (H_net * f_virtual... ) see host
     float prior[3];    // prior mean dims of the class
     float pstd[3];     // prior std of the class (DIMS_PRIORS_FUNC 'sigmoid')
+    int bins, bin;     // CLUSTER_BINS and the cluster this ROI's depth output comes from
+    float zmean, zstd; // depth prior of that cluster (Z_TYPE 'clusters')
 };
+
+// roi_heads.py:432-439: nearest 2D-scale prior of the ROI's class (first minimum, like torch.argmin)
+__device__ __forceinline__ int cluster_of(const float* box, int c, int bins, const float* __restrict__ zscales) {
+    if (bins <= 1) return 0;
+    const float w = box[2] - box[0], h = box[3] - box[1];
+    const float scale = sqrtf(h * h + w * w);
+    int best = 0;
+    float bd = fabsf(zscales[c * bins] - scale);
+    for (int b = 1; b < bins; ++b) {
+        const float d = fabsf(zscales[c * bins + b] - scale);
+        if (d < bd) { bd = d; best = b; }
+    }
+    return best;
+}
+__device__ __forceinline__ void load_roi(RoiIn& in, int f, const float* __restrict__ boxes, const int* __restrict__ img,
+                                         const float* __restrict__ Ks, const float* __restrict__ v2r,
+                                         const float* __restrict__ priors, int bins, const float* __restrict__ zscales,
+                                         const float* __restrict__ zstats, int mode) {
+    for (int k = 0; k < 4; ++k) in.box[k] = boxes[4 * f + k];
+    const int im = img[f];
+    for (int k = 0; k < 4; ++k) in.K[k] = Ks[4 * im + k];
+    in.v2r = v2r[im];
+    for (int k = 0; k < 3; ++k) { in.prior[k] = priors[(in.cls * 2 + 0) * 3 + k]; in.pstd[k] = priors[(in.cls * 2 + 1) * 3 + k]; }
+    in.bins = bins;
+    in.bin = cluster_of(in.box, in.cls, bins, zscales);
+    in.zmean = in.zstd = 0.f;
+    if (M_Z(mode) == 3) { in.zmean = zstats[(in.cls * bins + in.bin) * 2]; in.zstd = zstats[(in.cls * bins + in.bin) * 2 + 1]; }
+}
 
 // decode only (also used at inference): returns values + (optionally) duals
 struct Decoded {
     D x, y, z, dims[3], u;
     Mat3 pose;
+    // the network-space quantities the entangled losses compare (roi_heads.py:613-649)
+    D dxy[2], zn, dn[3];
+    Mat3 pose_view;    // the head's rotation before R_from_allocentric
+    float M[3][3];     // allocentric -> egocentric rotation of this ROI (identity if ALLOCENTRIC_POSE is off / the ray is the axis)
 };
 __device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn& in, int tl, const int mode) {
-    const int c = in.cls, Pn = M_POSE_WIDTH(mode);
+    const int c = in.cls, Pn = M_POSE_WIDTH(mode), nb = in.bins;
     const float* pxy = hrow + 2 * c;
-    const float* pz = hrow + 2 * K + c;
-    const float* pd = hrow + 3 * K + 3 * c;
-    const float* pp = hrow + 6 * K + Pn * c;
+    const float* pz = hrow + 2 * K + in.bin * K + c;          // cube_head.py:191-192: (n, bins, K) view of the depth outputs
+    const float* pd = hrow + (2 + nb) * K + 3 * c;
+    const float* pp = hrow + (5 + nb) * K + Pn * c;
     Decoded o;
     const float sw = in.box[2] - in.box[0], sh = in.box[3] - in.box[1];
     const float cx = in.box[0] + 0.5f * sw, cy = in.box[1] + 0.5f * sh;
-    o.x = var(pxy[0], 0, tl) * sw + cx;                 // roi_heads.py:460-461
-    o.y = var(pxy[1], 1, tl) * sh + cy;
-    D z = var(pz[0], 2, tl);                            // Z_TYPE (roi_heads.py:493-500)
-    if (M_Z(mode) == 1) z = dsigmoid(z) * 100.f;
+    o.dxy[0] = var(pxy[0], 0, tl);
+    o.dxy[1] = var(pxy[1], 1, tl);
+    o.x = o.dxy[0] * sw + cx;                           // roi_heads.py:460-461
+    o.y = o.dxy[1] * sh + cy;
+    D z = var(pz[0], 2, tl);                            // Z_TYPE (roi_heads.py:493-522)
+    o.zn = z;
+    if (M_Z(mode) == 1) { o.zn = dsigmoid(z); z = o.zn * 100.f; }
     else if (M_Z(mode) == 2) z = dexp(z);
+    else if (M_Z(mode) == 3) {                          // util.scaled_sigmoid(z, (mean - 3 std).clip(0), mean + 3 std)
+        const float mn = fmaxf(in.zmean - 3.f * in.zstd, 0.f), mx = in.zmean + 3.f * in.zstd;
+        z = dsigmoid(z) * (mx - mn) + mn;
+    }
     o.z = M_VDEPTH(mode) ? z * in.v2r : z;              // virtual depth (roi_heads.py:524-525)
     for (int k = 0; k < 3; ++k) {                       // roi_heads.py:467-484
         const D d = var(pd[k], 3 + k, tl);
+        o.dn[k] = d;
         if (M_DIMS(mode) == 0) o.dims[k] = dexp(clip_max(d, 5.f)) * in.prior[k];
         else if (M_DIMS(mode) == 1) {                   // util.scaled_sigmoid(d, min = (mean - 3 std).clip(0), max = mean + 3 std)
             const float mn = fmaxf(in.prior[k] - 3.f * in.pstd[k], 0.f), mx = in.prior[k] + 3.f * in.pstd[k];
@@ -264,15 +313,20 @@ __device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn&
         Rv = rot_euler(e);
     }
     o.pose = Rv;
+    o.pose_view = Rv;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o.M[i][j] = i == j ? 1.f : 0.f;
     if (M_ALLOC(mode)) {
         float M[3][3];
         bool valid;
         allocentric_M(in.K[0], in.K[1], in.K[2], in.K[3], o.x.v, o.y.v, M, valid);
         if (valid)
             for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) o.pose.m[i][j] = Rv.m[0][j] * M[i][0] + Rv.m[1][j] * M[i][1] + Rv.m[2][j] * M[i][2];
+                for (int j = 0; j < 3; ++j) {
+                    o.pose.m[i][j] = Rv.m[0][j] * M[i][0] + Rv.m[1][j] * M[i][1] + Rv.m[2][j] * M[i][2];
+                    o.M[i][j] = M[i][j];
+                }
     }
-    if (M_CONF(mode)) o.u = clip_min(var(hrow[(6 + Pn) * K + c], 12, tl), 0.01f);          // cube_head.py:163
+    if (M_CONF(mode)) o.u = clip_min(var(hrow[(5 + nb + Pn) * K + c], 12, tl), 0.01f);     // cube_head.py:163
     else o.u = cst(0.f);
     return o;
 }
@@ -282,6 +336,8 @@ __device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn&
 // rows whose class is outside [0, K) (background / padding slots of the fixed-capacity ROI set) are skipped: row_valid = 0.
 template <int FIXED>
 __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restrict__ head, int ldh, int F, int K, int mode_rt,
+                                                           int bins, const float* __restrict__ zscales,
+                                                           const float* __restrict__ zstats,
                                                            const float* __restrict__ boxes, const int* __restrict__ cls,
                                                            const int* __restrict__ img, const float* __restrict__ Ks,
                                                            const float* __restrict__ v2r, const float* __restrict__ priors,
@@ -292,16 +348,12 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
     const int mode = FIXED >= 0 ? FIXED : mode_rt;
     if (f >= F) return;
     RoiIn in;
-    for (int k = 0; k < 4; ++k) in.box[k] = boxes[4 * f + k];
     in.cls = cls[f];
     if (in.cls < 0 || in.cls >= K) {
         if (tl < 13) vals[(long)f * 13 + tl] = 0.f;
         return;
     }
-    const int im = img[f];
-    for (int k = 0; k < 4; ++k) in.K[k] = Ks[4 * im + k];
-    in.v2r = v2r[im];
-    for (int k = 0; k < 3; ++k) { in.prior[k] = priors[(in.cls * 2 + 0) * 3 + k]; in.pstd[k] = priors[(in.cls * 2 + 1) * 3 + k]; }
+    load_roi(in, f, boxes, img, Ks, v2r, priors, FIXED >= 0 ? 1 : bins, zscales, zstats, mode);
     const Decoded o = decode(head + (long)f * ldh, K, in, tl, mode);
     const float* g = gt3d + 9 * gt_row[f];
     const float* gp = gtpose + 9 * gt_row[f];
@@ -313,22 +365,45 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rg.m[i][j] = cst(gp[3 * i + j]);
     V3 cgt[8], ctmp[8];
     corners(gX, gY, gZ, gW, gH, gL, Rg, cgt);
-    // disentangled z / xy / pose / dims (roi_heads.py:574-600)
-    corners(o.z * ((gu - sx) / fx), o.z * ((gv - sy) / fy), o.z, gW, gH, gL, Rg, ctmp);
-    D loss_z = l1_mean(ctmp, cgt);
-    corners((o.x + (-sx)) * (gz / fx), (o.y + (-sy)) * (gz / fy), gZ, gW, gH, gL, Rg, ctmp);
-    D loss_xy = l1_mean(ctmp, cgt);
-    corners(gX, gY, gZ, gW, gH, gL, o.pose, ctmp);
-    D loss_pose = M_CHAMFER(mode) ? chamfer(ctmp, cgt) : l1_mean(ctmp, cgt);        // roi_heads.py:597-601
-    corners(gX, gY, gZ, o.dims[0], o.dims[1], o.dims[2], Rg, ctmp);
-    D loss_dims = l1_mean(ctmp, cgt);
+    D loss_z, loss_xy, loss_pose, loss_dims;
+    if (!M_ENTANGLED(mode)) {
+        // disentangled z / xy / pose / dims (roi_heads.py:574-600)
+        corners(o.z * ((gu - sx) / fx), o.z * ((gv - sy) / fy), o.z, gW, gH, gL, Rg, ctmp);
+        loss_z = l1_mean(ctmp, cgt);
+        corners((o.x + (-sx)) * (gz / fx), (o.y + (-sy)) * (gz / fy), gZ, gW, gH, gL, Rg, ctmp);
+        loss_xy = l1_mean(ctmp, cgt);
+        corners(gX, gY, gZ, gW, gH, gL, o.pose, ctmp);
+        loss_pose = M_CHAMFER(mode) ? chamfer(ctmp, cgt) : l1_mean(ctmp, cgt);        // roi_heads.py:597-601
+        corners(gX, gY, gZ, o.dims[0], o.dims[1], o.dims[2], Rg, ctmp);
+        loss_dims = l1_mean(ctmp, cgt);
+    } else {
+        // DISENTANGLED_LOSS False (roi_heads.py:606-649): L1 in the network's own output spaces
+        const float sw = in.box[2] - in.box[0], sh = in.box[3] - in.box[1];
+        const float scx = in.box[0] + 0.5f * sw, scy = in.box[1] + 0.5f * sh;
+        loss_xy = (dabs(o.dxy[0] + (-((gu - scx) / sw))) + dabs(o.dxy[1] + (-((gv - scy) / sh)))) * 0.5f;       // :614-617
+        loss_dims = (dabs(o.dn[0] + (-logf(g[3]))) + dabs(o.dn[1] + (-logf(g[4]))) + dabs(o.dn[2] + (-logf(g[5])))) * (1.f / 3.f);  // :625
+        // 1 - cos of the relative angle = 1 - (trace(R_a R_b^T) - 1) / 2 (pytorch3d so3_relative_angle, cos_angle=True); with
+        // ALLOCENTRIC_POSE both sides are in the allocentric frame: R_b = M^T R_gt (util.R_to_allocentric, :629-633)
+        D tr = cst(0.f);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const float rb = M_ALLOC(mode) ? (o.M[0][i] * gp[j] + o.M[1][i] * gp[3 + j]) + o.M[2][i] * gp[6 + j] : gp[3 * i + j];
+                tr = tr + o.pose_view.m[i][j] * rb;
+            }
+        loss_pose = neg((tr + (-1.f)) * 0.5f) + 1.f;
+        const float r2v = M_VDEPTH(mode) ? 1.f / in.v2r : 1.f;                                                       // :404-407
+        if (M_Z(mode) == 0) loss_z = dabs(o.z + (-gz));                                                             // :639-649
+        else if (M_Z(mode) == 1) loss_z = dabs(o.zn + (-fminf(fmaxf(gz * r2v / 100.f, 0.f), 1.f)));
+        else if (M_Z(mode) == 2) loss_z = dabs(o.zn + (-logf(fmaxf(gz * r2v, 0.01f))));
+        else loss_z = dabs(o.zn + (-((gz * r2v - in.zmean) / in.zstd)));
+    }
     // joint (roi_heads.py:664-683), only when LOSS_W_JOINT > 0
     D loss_joint = cst(0.f);
     float joint_valid = 0.f;
     float total = wd * loss_dims.v + wp * loss_pose.v + wxy * loss_xy.v + wz * loss_z.v;   // total_3D_loss_for_reporting (:651-683)
     if (M_JOINT(mode)) {
         corners(o.z * (o.x + (-sx)) * (1.f / fx), o.z * (o.y + (-sy)) * (1.f / fy), o.z, o.dims[0], o.dims[1], o.dims[2], o.pose, ctmp);
-        loss_joint = M_CHAMFER(mode) ? chamfer(ctmp, cgt) : l1_mean(ctmp, cgt);
+        loss_joint = (M_CHAMFER(mode) && !M_ENTANGLED(mode)) ? chamfer(ctmp, cgt) : l1_mean(ctmp, cgt);        // :676-680
         joint_valid = loss_joint.v < INFINITY ? 1.f : 0.f;
         total += wj * loss_joint.v;
     }
@@ -399,7 +474,8 @@ __global__ void __launch_bounds__(256) cube_reduce_kernel(const float* __restric
 // dhead (F, ldh) = sum_k gk[k] * w_k(f) * J[f][k][:] scattered to the class columns; rest zero.
 __global__ void __launch_bounds__(64) cube_loss_bwd_kernel(const float* __restrict__ vals, const float* __restrict__ jac,
                                                            const float* __restrict__ red, const float* __restrict__ gk,
-                                                           const int* __restrict__ cls, int F, int K, int mode, int ldh,
+                                                           const int* __restrict__ cls, const float* __restrict__ boxes, int F,
+                                                           int K, int mode, int bins, const float* __restrict__ zscales, int ldh,
                                                            float* __restrict__ dhead) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
@@ -418,17 +494,19 @@ __global__ void __launch_bounds__(64) cube_loss_bwd_kernel(const float* __restri
     }
     const int c = cls[f];
     row[2 * c + 0] = d[0]; row[2 * c + 1] = d[1];
-    row[2 * K + c] = d[2];
-    for (int k = 0; k < 3; ++k) row[3 * K + 3 * c + k] = d[3 + k];
+    row[2 * K + cluster_of(boxes + 4 * f, c, bins, zscales) * K + c] = d[2];    // the other clusters' outputs get no gradient
+    for (int k = 0; k < 3; ++k) row[(2 + bins) * K + 3 * c + k] = d[3 + k];
     const int Pn = M_POSE_WIDTH(mode);
-    for (int k = 0; k < Pn; ++k) row[6 * K + Pn * c + k] = d[6 + k];
-    if (M_CONF(mode)) row[(6 + Pn) * K + c] = d[12];
+    for (int k = 0; k < Pn; ++k) row[(5 + bins) * K + Pn * c + k] = d[6 + k];
+    if (M_CONF(mode)) row[(5 + bins + Pn) * K + c] = d[12];
 }
 
 // ---- inference / output decode (roi_heads.py:774-819): cube_3D (F, 9) = [X, Y, Z, w, h, l, u*s, v*s, conf],
 //      pose (F, 9), corners (F, 24) ----------------------------------------------------------------
 template <int FIXED>
 __global__ void __launch_bounds__(64) cube_decode_kernel(const float* __restrict__ head, int ldh, int F, int K, int mode_rt,
+                                                         int bins, const float* __restrict__ zscales,
+                                                         const float* __restrict__ zstats,
                                                          const float* __restrict__ boxes, const int* __restrict__ cls,
                                                          const int* __restrict__ img, const float* __restrict__ Ks,
                                                          const float* __restrict__ v2r, const float* __restrict__ ratio,
@@ -438,12 +516,9 @@ __global__ void __launch_bounds__(64) cube_decode_kernel(const float* __restrict
     const int mode = FIXED >= 0 ? FIXED : mode_rt;
     if (f >= F) return;
     RoiIn in;
-    for (int k = 0; k < 4; ++k) in.box[k] = boxes[4 * f + k];
     in.cls = cls[f];
     const int im = img[f];
-    for (int k = 0; k < 4; ++k) in.K[k] = Ks[4 * im + k];
-    in.v2r = v2r[im];
-    for (int k = 0; k < 3; ++k) { in.prior[k] = priors[(in.cls * 2 + 0) * 3 + k]; in.pstd[k] = priors[(in.cls * 2 + 1) * 3 + k]; }
+    load_roi(in, f, boxes, img, Ks, v2r, priors, FIXED >= 0 ? 1 : bins, zscales, zstats, mode);
     const Decoded o = decode(head + (long)f * ldh, K, in, -1, mode);
     const float X = o.z.v * (o.x.v - in.K[2]) / in.K[0], Y = o.z.v * (o.y.v - in.K[3]) / in.K[1];
     float* c3 = cube3d + 9 * f;
@@ -478,49 +553,56 @@ __global__ void cuboid_corners_kernel(const float* __restrict__ box3d, const flo
 
 extern "C" {
 
-// head (F, ldh) fused cube-head outputs for the F foreground ROIs; boxes (F,4) proposal boxes; cls (F);
+// head (F, ldh) fused cube-head outputs for the F foreground ROIs; bins = max(CLUSTER_BINS, 1), zscales (K, bins) /
+// zstats (K, bins, 2) the cluster priors (null when unused); boxes (F,4) proposal boxes; cls (F);
 // img (F) image index; Ks (B,4) = [fx, fy, cx, cy] scaled to network resolution; v2r (B) virtual->real depth
 // factor; priors (K,2,3); gt3d (G,9) gt_boxes3D rows; gtpose (G,9); gt_row (F).
 // vals (F,13), jac (F,6,13), red (24) outputs.  Rows with cls outside [0,K) are ignored.
-int omni_cube_loss_fwd(const float* head, int ldh, int F, int K, int mode, const float* boxes, const int* cls, const int* img,
+int omni_cube_loss_fwd(const float* head, int ldh, int F, int K, int mode, int bins, const float* zscales, const float* zstats,
+                       const float* boxes, const int* cls, const int* img,
                        const float* Ks, const float* v2r, const float* priors, const float* gt3d, const float* gtpose,
                        const int* gt_row, float w_dims, float w_pose, float w_xy, float w_z, float w_joint, float* vals, float* jac,
                        float* red, void* stream) {
-    if (F < 0 || K <= 0 || !MODE_VALID(mode) || ldh < M_HEAD_WIDTH(mode) * K) return OMNI_ERR_ARG;
+    if (F < 0 || K <= 0 || !MODE_VALID(mode, bins, zscales, zstats) || ldh < M_HEAD_WIDTH(mode, bins) * K) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (F > 0) {    // 16 lanes per ROI (one tangent each), 4 ROIs per wave
-        if (mode == MODE_BASE)
-            hipLaunchKernelGGL(cube_loss_fwd_kernel<MODE_BASE>, dim3((F + 3) / 4), dim3(64), 0, st, head, ldh, F, K, mode, boxes, cls,
-                               img, Ks, v2r, priors, gt3d, gtpose, gt_row, w_dims, w_pose, w_xy, w_z, w_joint, vals, jac);
+        if (mode == MODE_BASE && bins == 1)
+            hipLaunchKernelGGL(cube_loss_fwd_kernel<MODE_BASE>, dim3((F + 3) / 4), dim3(64), 0, st, head, ldh, F, K, mode, bins,
+                               zscales, zstats, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, w_dims, w_pose, w_xy, w_z,
+                               w_joint, vals, jac);
         else
-            hipLaunchKernelGGL(cube_loss_fwd_kernel<-1>, dim3((F + 3) / 4), dim3(64), 0, st, head, ldh, F, K, mode, boxes, cls,
-                               img, Ks, v2r, priors, gt3d, gtpose, gt_row, w_dims, w_pose, w_xy, w_z, w_joint, vals, jac);
+            hipLaunchKernelGGL(cube_loss_fwd_kernel<-1>, dim3((F + 3) / 4), dim3(64), 0, st, head, ldh, F, K, mode, bins,
+                               zscales, zstats, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, w_dims, w_pose, w_xy, w_z,
+                               w_joint, vals, jac);
     }
     hipLaunchKernelGGL(cube_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)vals, F, red);
     return omni_launch_status();
 }
 
-// gk (6) device floats: upstream gradients of [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert].
-int omni_cube_loss_bwd(const float* vals, const float* jac, const float* red, const float* gk, const int* cls, int F,
-                       int K, int mode, int ldh, float* dhead, void* stream) {
-    if (F < 0 || K <= 0 || !MODE_VALID(mode) || ldh < M_HEAD_WIDTH(mode) * K) return OMNI_ERR_ARG;
+// gk (6) device floats: upstream gradients of [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert]; boxes / bins /
+// zscales as in the forward call (they pick the depth column that receives the gradient).
+int omni_cube_loss_bwd(const float* vals, const float* jac, const float* red, const float* gk, const int* cls,
+                       const float* boxes, int F, int K, int mode, int bins, const float* zscales, int ldh, float* dhead,
+                       void* stream) {
+    if (F < 0 || K <= 0 || !MODE_VALID(mode, bins, zscales, zscales) || ldh < M_HEAD_WIDTH(mode, bins) * K) return OMNI_ERR_ARG;
     if (F == 0) return OMNI_OK;
     hipLaunchKernelGGL(cube_loss_bwd_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, vals, jac, red, gk, cls,
-                       F, K, mode, ldh, dhead);
+                       boxes, F, K, mode, bins, zscales, ldh, dhead);
     return omni_launch_status();
 }
 
-int omni_cube_decode(const float* head, int ldh, int F, int K, int mode, const float* boxes, const int* cls, const int* img,
+int omni_cube_decode(const float* head, int ldh, int F, int K, int mode, int bins, const float* zscales, const float* zstats,
+                     const float* boxes, const int* cls, const int* img,
                      const float* Ks, const float* v2r, const float* ratio, const float* priors, float* cube3d,
                      float* pose, float* verts, void* stream) {
-    if (F < 0 || K <= 0 || !MODE_VALID(mode) || ldh < M_HEAD_WIDTH(mode) * K) return OMNI_ERR_ARG;
+    if (F < 0 || K <= 0 || !MODE_VALID(mode, bins, zscales, zstats) || ldh < M_HEAD_WIDTH(mode, bins) * K) return OMNI_ERR_ARG;
     if (F == 0) return OMNI_OK;
-    if (mode == MODE_BASE)
+    if (mode == MODE_BASE && bins == 1)
         hipLaunchKernelGGL(cube_decode_kernel<MODE_BASE>, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, head, ldh, F, K,
-                           mode, boxes, cls, img, Ks, v2r, ratio, priors, cube3d, pose, verts);
+                           mode, bins, zscales, zstats, boxes, cls, img, Ks, v2r, ratio, priors, cube3d, pose, verts);
     else
         hipLaunchKernelGGL(cube_decode_kernel<-1>, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, head, ldh, F, K,
-                           mode, boxes, cls, img, Ks, v2r, ratio, priors, cube3d, pose, verts);
+                           mode, bins, zscales, zstats, boxes, cls, img, Ks, v2r, ratio, priors, cube3d, pose, verts);
     return omni_launch_status();
 }
 

@@ -1,13 +1,13 @@
 """`CubeHead` (own ROI_CUBE_HEAD_REGISTRY) of the reference (/root/reference/cubercnn/modeling/roi_heads/cube_head.py:19-197):
 FC feature generator(s) + ReLU -- one shared `feature_generator.fc1..fcN` (SHARED_FC, configs/Base.yaml) or one per output
 group (`feature_generator_{XY,dims,pose,Z,conf}`) -- and the linear heads `bbox_3D_dims` (3K), `bbox_3D_center_deltas` (2K),
-`bbox_3D_pose` (6K / 4K / 3K for POSE_TYPE 6d / quaternion / euler), `bbox_3D_center_depth` (K) and, with USE_CONFIDENCE,
-`bbox_3D_uncertainty` (K, bias 5).  Parameter names equal the reference's, so its checkpoints load.
+`bbox_3D_pose` (6K / 4K / 3K for POSE_TYPE 6d / quaternion / euler), `bbox_3D_center_depth` (K x max(CLUSTER_BINS, 1), bin-major)
+and, with USE_CONFIDENCE, `bbox_3D_uncertainty` (K, bias 5).  Parameter names equal the reference's, so its checkpoints load.
 
 The reference evaluates the rotation for ALL K classes of every ROI and gathers the GT class afterwards (cube_head.py:175-185,
 roi_heads.py:447-457).  Here the heads are ONE fused GEMM (fc_dim -> width*K, padded to a multiple of 16) whose raw output goes
-to the fused decode / loss kernel (csrc/cube_head.hip), which gathers the class first and applies the pose / depth /
-dimension parameterisation named by `self.mode`.  Z_TYPE 'clusters' (CLUSTER_BINS > 1) is not built."""
+to the fused decode / loss kernel (csrc/cube_head.hip), which gathers the class (and, with CLUSTER_BINS > 1, the depth cluster)
+first and applies the pose / depth / dimension parameterisation named by the ROI heads' `cube_mode`."""
 import torch
 from torch import nn
 
@@ -47,8 +47,7 @@ class CubeHead(nn.Module):
         self.num_classes = K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
         if c.POSE_TYPE not in det.POSE_WIDTH:
             raise ValueError("Cuboid pose type {} is not recognized".format(c.POSE_TYPE))
-        if c.CLUSTER_BINS != 1 or c.Z_TYPE == "clusters":
-            raise NotImplementedError("MI355X hot path: Z_TYPE 'clusters' / CLUSTER_BINS > 1 is not built (direct, sigmoid, log are)")
+        self.cluster_bins = bins = c.CLUSTER_BINS if c.CLUSTER_BINS > 1 else 1                 # cube_head.py:112
         if c.NUM_FC < 1:
             raise NotImplementedError("CubeHead needs NUM_FC >= 1 (the reference builds no conv layers either, cube_head.py:49-103)")
         self.use_conf, self.shared_fc, self.pose_type = bool(c.USE_CONFIDENCE), bool(c.SHARED_FC), c.POSE_TYPE
@@ -63,7 +62,7 @@ class CubeHead(nn.Module):
         self.bbox_3D_dims = Linear(c.FC_DIM, K * 3)
         self.bbox_3D_center_deltas = Linear(c.FC_DIM, K * 2)
         self.bbox_3D_pose = Linear(c.FC_DIM, K * det.POSE_WIDTH[c.POSE_TYPE])
-        self.bbox_3D_center_depth = Linear(c.FC_DIM, K)
+        self.bbox_3D_center_depth = Linear(c.FC_DIM, K * bins)                                # cube_head.py:136, viewed (n, bins, K)
         heads = [self.bbox_3D_dims, self.bbox_3D_center_deltas, self.bbox_3D_pose, self.bbox_3D_center_depth]
         if self.use_conf:
             self.bbox_3D_uncertainty = Linear(c.FC_DIM, K)
@@ -73,11 +72,11 @@ class CubeHead(nn.Module):
             nn.init.constant_(m.bias, 0)
         if self.use_conf:
             nn.init.constant_(self.bbox_3D_uncertainty.bias, 5)
-        self.width = 6 + det.POSE_WIDTH[c.POSE_TYPE] + int(self.use_conf)      # columns per class of the fused output
+        self.width = 5 + bins + det.POSE_WIDTH[c.POSE_TYPE] + int(self.use_conf)      # columns per class of the fused output
         self.fused_dim = (self.width * K + 15) // 16 * 16
 
     def _parts(self):
-        """the linear heads in the column order of the fused decode kernel: [center_deltas 2K | center_depth K | dims 3K | pose | uncertainty K]"""
+        """the linear heads in the column order of the fused decode kernel: [center_deltas 2K | center_depth K*bins | dims 3K | pose | uncertainty K]"""
         parts = [self.bbox_3D_center_deltas, self.bbox_3D_center_depth, self.bbox_3D_dims, self.bbox_3D_pose]
         return parts + ([self.bbox_3D_uncertainty] if self.use_conf else [])
 

@@ -32,11 +32,11 @@ def roi_heads_inference(heads, images, feats, proposals, packed):
     # ---- cube head on the fixed (B, topk) slots (roi_heads.py:353-357, 771-819); unused slots hold a dummy box
     dboxes, dcl = dbox.view(B * topk, 4), dcls.view(-1)
     dimg = heads._batch_index(B, topk, dboxes.device)
-    xc = heads.cube_pooler(feats, dboxes, dimg)
+    xc = heads.cube_pooler(feats, heads.scale_proposals(dboxes), dimg)
     head = heads.cube_head(xc)
     priors = heads.priors_dims_per_cat.detach().reshape(K, 2, 3).contiguous()
     cube3d, pose, verts = det.cube_decode(head.contiguous(), K, dboxes, dcl, dimg, packed.Ks, packed.v2r, packed.ratio, priors,
-                                           heads.cube_mode)
+                                           heads.cube_mode, heads.clusters())
     final = (dscore.view(-1) * cube3d[:, 8]) ** 0.5                                               # roi_heads.py:800-801
     full = torch.gather(probs.view(B, P, K), 1, droi.long()[:, :, None].expand(-1, -1, K))        # scores of all classes per kept roi
     counts = dcount.tolist()                                                                      # the one host sync

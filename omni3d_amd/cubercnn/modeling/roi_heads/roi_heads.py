@@ -3,9 +3,10 @@
 Mirrors /root/reference/cubercnn/modeling/roi_heads/roi_heads.py: constructor / from_config keys
 (:42-204), `forward(images, features, proposals, Ks, im_scales_ratio, targets)` (:207-246),
 `label_and_sample_proposals` (:862-929), `_forward_box` (:249-293), `_forward_cube` (:326-824) with
-the same loss names, loss weights and logged scalars -- for the configuration of
-configs/Base.yaml (disentangled + chamfer + joint losses, virtual depth, allocentric 6D pose,
-dimension priors, confidence).
+the same loss names, loss weights and logged scalars -- for every MODEL.ROI_CUBE_HEAD switch the
+reference evaluates (configs/Base.yaml: disentangled + chamfer + joint losses, virtual depth, allocentric
+6D pose, dimension priors, confidence; and Z_TYPE / CLUSTER_BINS / POSE_TYPE / DISENTANGLED_LOSS /
+SCALE_ROI_BOXES / TRAIN_ON_PRED_BOXES variants).
 
 Data layout: the sampled ROIs of a batch are a fixed-shape (B, batch_size_per_image) block with the
 foreground first in every row (the sampler's order), so the 2D box head runs on B*512 rows and the
@@ -121,24 +122,33 @@ class ROIHeads3D(nn.Module):
         self.loss_w_3d, self.loss_w_xy, self.loss_w_z = loss_w_3d, loss_w_xy, loss_w_z
         self.loss_w_dims, self.loss_w_pose, self.loss_w_joint = loss_w_dims, loss_w_pose, loss_w_joint
         self.use_confidence, self.virtual_focal, self.test_scale = use_confidence, virtual_focal, test_scale
-        if cluster_bins != 1 or z_type == "clusters":
-            raise NotImplementedError("MI355X hot path: Z_TYPE 'clusters' / CLUSTER_BINS > 1 is not built (direct, sigmoid, log are)")
-        if not disentangled_loss:
-            raise NotImplementedError("MI355X hot path: DISENTANGLED_LOSS False (so3_relative_angle / normalised-space losses, "
-                                      "roi_heads.py:603-649) is not built; every released config trains disentangled")
-        if scale_roi_boxes or train_on_pred_boxes:
-            raise NotImplementedError("MI355X hot path: SCALE_ROI_BOXES / TRAIN_ON_PRED_BOXES are not built (0.0 / False in every config)")
+        self.cluster_bins, self.z_type = cluster_bins, z_type
+        self.scale_roi_boxes = float(scale_roi_boxes or 0.0)
+        self.train_on_pred_boxes = bool(train_on_pred_boxes)
         if loss_w_3d <= 0:
-            raise NotImplementedError("MI355X hot path: LOSS_W_3D <= 0 (2D-only training) is not built")
+            raise NotImplementedError("MI355X hot path: LOSS_W_3D <= 0 (no cube head) is not built; the reference's training branch "
+                                      "fails there as well (roi_heads.py:219-225 returns an unassigned `instances_3d`)")
         # head parameterisation + loss switches for csrc/cube_head.hip (bit layout: include/omni3d_hip.h)
         self.cube_mode = det.cube_mode(z_type, dims_priors_enabled, dims_priors_func, pose_type, allocentric_pose, virtual_depth,
-                                       chamfer_pose, inverse_z_weight, use_confidence > 0, loss_w_joint > 0)
+                                       chamfer_pose, inverse_z_weight, use_confidence > 0, loss_w_joint > 0,
+                                       disentangled=bool(disentangled_loss))
         self.cube_head, self.cube_pooler = cube_head, cube_pooler
         if priors is not None:
             self.priors_dims_per_cat = nn.Parameter(torch.FloatTensor(priors["priors_dims_per_cat"]).unsqueeze(0))
         else:
             self.priors_dims_per_cat = nn.Parameter(torch.ones(1, num_classes, 2, 3))
-        self.priors_z_scales = nn.Parameter(torch.ones(num_classes, cluster_bins))
+        # depth clusters over the 2D scale (roi_heads.py:122-143); priors['priors_bins'] = [(name, scales, [[z mean, z std]])]
+        bins_table = priors.get("priors_bins") if priors is not None else None
+        if cluster_bins > 1 and bins_table:
+            self.priors_z_scales = nn.Parameter(torch.stack([torch.FloatTensor(p[1]) for p in bins_table]))
+        else:
+            self.priors_z_scales = nn.Parameter(torch.ones(num_classes, cluster_bins))
+        if z_type == "clusters":
+            assert cluster_bins > 1, "To use z_type of priors, there must be more than 1 cluster bin"
+            if bins_table:
+                self.priors_z_stats = nn.Parameter(torch.cat([torch.FloatTensor(p[2]).unsqueeze(0) for p in bins_table]))
+            else:
+                self.priors_z_stats = nn.Parameter(torch.ones(num_classes, cluster_bins, 2).float())
         self.pending_logs = {}
         self.injected = None     # parity tests: {'E': (B, 2048) exponential variates}
         self.fg_cap = int(batch_size_per_image * positive_fraction)
@@ -209,12 +219,13 @@ class ROIHeads3D(nn.Module):
             assert packed.num_gt >= 0
             sboxes, scls, sgt, siou, counts = self.label_and_sample_proposals(proposals, packed)
             x_box = x_cube = None
-            if self.box_pooler.same_as(self.cube_pooler):   # every Cube R-CNN config: pool once for both heads
+            own_cube_rois = self.train_on_pred_boxes or self.scale_roi_boxes > 0
+            if self.box_pooler.same_as(self.cube_pooler) and not own_cube_rois:   # every released config: pool once for both heads
                 B, S = scls.shape
                 x_box, x_cube = self.box_pooler.forward_shared(feats, sboxes.reshape(B * S, 4), self._batch_index(B, S, sboxes.device),
                                                                S, self.fg_cap)
-            losses = self._forward_box_train(feats, sboxes, scls, sgt, packed, x_box)
-            losses.update(self._forward_cube_train(feats, sboxes, scls, sgt, packed, x_cube))
+            losses, cube_boxes = self._forward_box_train(feats, sboxes, scls, sgt, packed, x_box)
+            losses.update(self._forward_cube_train(feats, cube_boxes, scls, sgt, packed, x_cube))
             return [], losses
         from .inference import roi_heads_inference
         return roi_heads_inference(self, images, feats, proposals, packed), {}
@@ -233,7 +244,27 @@ class ROIHeads3D(nn.Module):
         if x is None:
             x = self.box_pooler(feats, rois, self._batch_index(B, S, rois.device))
         pred = self.box_predictor(self.box_head(x))
-        return self.box_predictor.losses(pred, scls.reshape(-1), rois, packed, sgt.reshape(-1).clamp(min=0))
+        losses = self.box_predictor.losses(pred, scls.reshape(-1), rois, packed, sgt.reshape(-1).clamp(min=0))
+        if self.train_on_pred_boxes:      # roi_heads.py:283-289: the 3D head trains on the (detached) 2D predictions of the GT classes
+            with torch.no_grad():
+                sboxes = det.box_decode_gt_class(pred.detach().contiguous(), self.num_classes, scls.reshape(-1).contiguous(), rois.contiguous(),
+                                                 self.box_predictor.box2box_weights).view(B, S, 4)
+        return losses, sboxes
+
+    def clusters(self):
+        """None, or (bins, 2D-scale priors (K, bins), depth priors (K, bins, 2) | None) for the cube kernels"""
+        if self.cluster_bins <= 1:
+            return None
+        stats = self.priors_z_stats.detach().contiguous() if self.z_type == "clusters" else None
+        return (self.cluster_bins, self.priors_z_scales.detach().contiguous(), stats)
+
+    def scale_proposals(self, rois):
+        """roi_heads.py:307-324: zoom the boxes the cube features are pooled from; both extents use the WIDTH, as the reference does"""
+        if not self.scale_roi_boxes > 0:
+            return rois
+        cx, cy = (rois[:, 0] + rois[:, 2]) / 2, (rois[:, 1] + rois[:, 3]) / 2
+        half = 0.5 * (rois[:, 2] - rois[:, 0]) * self.scale_roi_boxes
+        return torch.stack([cx - half, cy - half, cx + half, cy + half], dim=1).contiguous()
 
     # ---- roi_heads.py:326-768 (training path) ----------------------------------------------------
     def _forward_cube_train(self, feats, sboxes, scls, sgt, packed, x=None):
@@ -244,7 +275,7 @@ class ROIHeads3D(nn.Module):
         gt_row = sgt[:, :Fc].reshape(-1).clamp(min=0).contiguous()
         bidx = self._batch_index(B, Fc, rois.device)
         if x is None:
-            x = self.cube_pooler(feats, rois, bidx)
+            x = self.cube_pooler(feats, self.scale_proposals(rois), bidx)
         head = self.cube_head(x)
         priors = self.priors_dims_per_cat.detach().reshape(self.num_classes, 2, 3).contiguous()
         w3 = self.loss_w_3d
@@ -255,7 +286,7 @@ class ROIHeads3D(nn.Module):
                 float(self.use_confidence) if self.use_confidence > 0 else 0.0)   # roi_heads.py:721-740
         vec, red = HF.cube_loss(head, self.num_classes, rois, cls, bidx, packed.Ks, packed.v2r, priors, packed.gt3d,
                                 packed.gtpose, gt_row, (self.loss_w_dims, self.loss_w_pose, self.loss_w_xy, self.loss_w_z, self.loss_w_joint),
-                                self.cube_mode, coef)
+                                self.cube_mode, coef, self.clusters())
         self.pending_logs["cube"] = red
         order = ("loss_dims", "loss_xy", "loss_z", "loss_pose", "loss_joint", "uncert")
         keep = [k for k, name in enumerate(order) if coef[k] != 0.0 or name in ("loss_xy", "loss_z", "loss_pose")]

@@ -537,30 +537,31 @@ class _CubeLoss(Function):
     """-> ((6,) = [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert] * coef ; red (24) raw reductions + logging stats)."""
 
     @staticmethod
-    def forward(ctx, head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w, mode, coef):
+    def forward(ctx, head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w, mode, coef, clusters):
         ctx.set_materialize_grads(False)      # no zero tensors for the non-differentiable side outputs
         head = head.contiguous()
-        vals, jac, red = det.cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w, mode)
-        ctx.save_for_backward(vals, jac, red, cls)
-        ctx.meta = (head.shape[0], K, head.shape[1], mode, coef)
+        vals, jac, red = det.cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w, mode, clusters)
+        ctx.save_for_backward(vals, jac, red, cls, boxes)
+        ctx.meta = (head.shape[0], K, head.shape[1], mode, coef, clusters)
         ctx.mark_non_differentiable(red)
         return red[:6] * _coef(coef, red.device), red
 
     @staticmethod
     def backward(ctx, g, _):
-        vals, jac, red, cls = ctx.saved_tensors
-        F_, K, ldh, mode, coef = ctx.meta
+        vals, jac, red, cls, boxes = ctx.saved_tensors
+        F_, K, ldh, mode, coef, clusters = ctx.meta
         gk = g.contiguous().float() * _coef(coef, g.device)
-        dhead = det.cube_loss_bwd(vals, jac, red, gk, cls, F_, K, ldh, mode)
-        return (dhead,) + (None,) * 13
+        dhead = det.cube_loss_bwd(vals, jac, red, gk, cls, boxes, F_, K, ldh, mode, clusters)
+        return (dhead,) + (None,) * 14
 
 
 def cube_loss(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0), mode=det.CUBE_MODE_BASE,
-              coef=(1.0, 1.0, 1.0, 1.0, 1.0, 1.0)):
-    """coef: what each of [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert] is multiplied by on the way out
+              coef=(1.0, 1.0, 1.0, 1.0, 1.0, 1.0), clusters=None):
+    """coef: what each of [loss_dims, loss_xy, loss_z, loss_pose, loss_joint, uncert] is multiplied by on the way out;
+    clusters: None or (bins, zscales (K, bins), zstats (K, bins, 2) | None) for CLUSTER_BINS > 1
     -> ((6,) weighted losses, red (24))"""
     return _CubeLoss.apply(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, tuple(loss_w), int(mode),
-                           tuple(float(c) for c in coef))
+                           tuple(float(c) for c in coef), clusters)
 
 
 class _MaxPool3s2(Function):

@@ -205,59 +205,87 @@ def box_loss_bwd(pred, K, cls, prop, gt, gt_row, sums, g_cls, g_reg, weights=(10
     return dpred
 
 
+def box_decode_gt_class(pred, K, cls, prop, weights=(10.0, 10.0, 5.0, 5.0), scale_clamp=4.135166556742356):
+    """predict_boxes_for_gt_classes (detectron2 FastRCNNOutputLayers; roi_heads.py:276-289): (R,4) predicted box of each row's GT class"""
+    L = _dev(pred, cls, prop)
+    R, ldp = pred.shape
+    out = _empty((R, 4), torch.float32, pred)
+    L.call("omni_box_decode_gt_class", _lib.ptr(pred), ldp, R, K, _lib.ptr(cls), _lib.ptr(prop), *[float(w) for w in weights],
+           float(scale_clamp), _lib.ptr(out), _lib.stream_of(pred))
+    return out
+
+
 CUBE_MODE_BASE = 0xDC0      # configs/Base.yaml: z direct, dims priors 'exp', 6d pose, allocentric, virtual depth, chamfer, confidence, joint
-_Z_TYPES = {"direct": 0, "sigmoid": 1, "log": 2}
+_Z_TYPES = {"direct": 0, "sigmoid": 1, "log": 2, "clusters": 3}
 _POSE_TYPES = {"6d": 0, "quaternion": 1, "euler": 2}
 POSE_WIDTH = {"6d": 6, "quaternion": 4, "euler": 3}
 
 
 def cube_mode(z_type="direct", dims_priors_enabled=True, dims_priors_func="exp", pose_type="6d", allocentric_pose=True,
-              virtual_depth=True, chamfer_pose=True, inverse_z_weight=False, use_confidence=True, joint=True):
+              virtual_depth=True, chamfer_pose=True, inverse_z_weight=False, use_confidence=True, joint=True, disentangled=True):
     """MODEL.ROI_CUBE_HEAD.* -> the `mode` word of csrc/cube_head.hip (bit layout in include/omni3d_hip.h)."""
     if z_type not in _Z_TYPES:
-        raise NotImplementedError(f"MI355X hot path: Z_TYPE '{z_type}' (built: direct, sigmoid, log; 'clusters' / CLUSTER_BINS > 1 is not)")
+        raise ValueError(f"MODEL.ROI_CUBE_HEAD.Z_TYPE '{z_type}' is not one of {sorted(_Z_TYPES)}")
     if pose_type not in _POSE_TYPES:
         raise ValueError("Cuboid pose type {} is not recognized".format(pose_type))
     if dims_priors_enabled and dims_priors_func not in ("exp", "sigmoid"):
         raise NotImplementedError(f"DIMS_PRIORS_FUNC '{dims_priors_func}'")
+    if not disentangled and dims_priors_enabled:
+        raise ValueError("DISENTANGLED_LOSS False needs DIMS_PRIORS_ENABLED False: the reference's entangled dimension loss divides "
+                         "an (n,3) tensor by the (n,2,3) priors (roi_heads.py:620-622) and cannot be evaluated")
     dims = 2 if not dims_priors_enabled else (1 if dims_priors_func == "sigmoid" else 0)
     return (_Z_TYPES[z_type] | dims << 2 | _POSE_TYPES[pose_type] << 4 | bool(allocentric_pose) << 6 | bool(virtual_depth) << 7
-            | bool(chamfer_pose) << 8 | bool(inverse_z_weight) << 9 | bool(use_confidence) << 10 | bool(joint) << 11)
+            | bool(chamfer_pose) << 8 | bool(inverse_z_weight) << 9 | bool(use_confidence) << 10 | bool(joint) << 11
+            | (not disentangled) << 12)
 
 
-def cube_head_width(mode):
-    """columns per class of the fused head output: xy 2 + z 1 + dims 3 + pose 6/4/3 + uncertainty 0/1"""
-    return 6 + (6, 4, 3)[(mode >> 4) & 3] + ((mode >> 10) & 1)
+def cube_head_width(mode, bins=1):
+    """columns per class of the fused head output: xy 2 + z bins + dims 3 + pose 6/4/3 + uncertainty 0/1"""
+    return 5 + bins + (6, 4, 3)[(mode >> 4) & 3] + ((mode >> 10) & 1)
 
 
-def cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0), mode=CUBE_MODE_BASE):
+def _clusters(clusters):
+    """clusters = None or (bins, zscales (K, bins), zstats (K, bins, 2) or None) -> (bins, zscales, zstats)"""
+    if clusters is None:
+        return 1, None, None
+    bins, zscales, zstats = clusters
+    return int(bins), zscales, zstats
+
+
+def cube_loss_fwd(head, K, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0), mode=CUBE_MODE_BASE,
+                  clusters=None):
     """loss_w = (w_dims, w_pose, w_xy, w_z, w_joint): only the logged total uses them (the loss terms are weighted by the caller)"""
-    L = _dev(head, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row)
+    bins, zscales, zstats = _clusters(clusters)
+    L = _dev(head, boxes, cls, img, Ks, v2r, priors, gt3d, gtpose, gt_row, zscales, zstats)
     F, ldh = head.shape
     vals = _empty((max(F, 1), 13), torch.float32, head)
     jac = _empty((max(F, 1), 6, 13), torch.float32, head)
     red = _empty((24,), torch.float32, head)
-    L.call("omni_cube_loss_fwd", _lib.ptr(head), ldh, F, K, int(mode), _lib.ptr(boxes), _lib.ptr(cls), _lib.ptr(img), _lib.ptr(Ks),
+    L.call("omni_cube_loss_fwd", _lib.ptr(head), ldh, F, K, int(mode), bins, _lib.ptr(zscales), _lib.ptr(zstats), _lib.ptr(boxes),
+           _lib.ptr(cls), _lib.ptr(img), _lib.ptr(Ks),
            _lib.ptr(v2r), _lib.ptr(priors), _lib.ptr(gt3d), _lib.ptr(gtpose), _lib.ptr(gt_row), *[float(w) for w in loss_w],
            _lib.ptr(vals), _lib.ptr(jac), _lib.ptr(red), _lib.stream_of(head))
     return vals, jac, red
 
 
-def cube_loss_bwd(vals, jac, red, gk, cls, F, K, ldh, mode=CUBE_MODE_BASE):
-    L = _dev(vals, jac, red, gk, cls)
+def cube_loss_bwd(vals, jac, red, gk, cls, boxes, F, K, ldh, mode=CUBE_MODE_BASE, clusters=None):
+    bins, zscales, _ = _clusters(clusters)
+    L = _dev(vals, jac, red, gk, cls, boxes, zscales)
     dhead = _empty((F, ldh), torch.float32, vals)
-    L.call("omni_cube_loss_bwd", _lib.ptr(vals), _lib.ptr(jac), _lib.ptr(red), _lib.ptr(gk), _lib.ptr(cls), F, K, int(mode), ldh,
-           _lib.ptr(dhead), _lib.stream_of(vals))
+    L.call("omni_cube_loss_bwd", _lib.ptr(vals), _lib.ptr(jac), _lib.ptr(red), _lib.ptr(gk), _lib.ptr(cls), _lib.ptr(boxes), F, K,
+           int(mode), bins, _lib.ptr(zscales), ldh, _lib.ptr(dhead), _lib.stream_of(vals))
     return dhead
 
 
-def cube_decode(head, K, boxes, cls, img, Ks, v2r, ratio, priors, mode=CUBE_MODE_BASE):
-    L = _dev(head, boxes, cls, img, Ks, v2r, ratio, priors)
+def cube_decode(head, K, boxes, cls, img, Ks, v2r, ratio, priors, mode=CUBE_MODE_BASE, clusters=None):
+    bins, zscales, zstats = _clusters(clusters)
+    L = _dev(head, boxes, cls, img, Ks, v2r, ratio, priors, zscales, zstats)
     F, ldh = head.shape
     cube3d = _empty((F, 9), torch.float32, head)
     pose = _empty((F, 3, 3), torch.float32, head)
     verts = _empty((F, 8, 3), torch.float32, head)
-    L.call("omni_cube_decode", _lib.ptr(head), ldh, F, K, int(mode), _lib.ptr(boxes), _lib.ptr(cls), _lib.ptr(img), _lib.ptr(Ks),
+    L.call("omni_cube_decode", _lib.ptr(head), ldh, F, K, int(mode), bins, _lib.ptr(zscales), _lib.ptr(zstats), _lib.ptr(boxes),
+           _lib.ptr(cls), _lib.ptr(img), _lib.ptr(Ks),
            _lib.ptr(v2r), _lib.ptr(ratio), _lib.ptr(priors), _lib.ptr(cube3d), _lib.ptr(pose), _lib.ptr(verts),
            _lib.stream_of(head))
     return cube3d, pose, verts

@@ -13,13 +13,23 @@ import torch
 from .d2.structures import Boxes, Instances
 
 
-def make_priors(num_classes=50, seed=0):
+def make_priors(num_classes=50, seed=0, bins=0):
     """`priors['priors_dims_per_cat']` (K,2,3): per-class mean / std of (w,h,l) in metres
-    (roi_heads.py:117-118).  Fixed table: mean U[.3,4], std = 0.2 * mean."""
+    (roi_heads.py:117-118).  Fixed table: mean U[.3,4], std = 0.2 * mean.  bins > 1 adds `priors_bins` in the form
+    math_util.compute_priors emits for CLUSTER_BINS (:436,485): per class (name, [2D scale of each cluster], [[z mean, z std]])."""
     rs = np.random.RandomState(1000 + seed)
     mean = rs.uniform(0.3, 4.0, size=(num_classes, 3))
     std = 0.2 * mean
-    return {"priors_dims_per_cat": np.stack([mean, std], axis=1).astype(np.float32).tolist(), "priors_bins": None}
+    out = {"priors_dims_per_cat": np.stack([mean, std], axis=1).astype(np.float32).tolist(), "priors_bins": None}
+    if bins and bins > 1:
+        out["priors_bins"] = []
+        for c in range(num_classes):
+            scales = np.sort(rs.uniform(10.0, 200.0, size=bins))
+            zmean = np.sort(rs.uniform(3.0, 40.0, size=bins))[::-1]            # large on screen = close
+            zstd = rs.uniform(0.5, 8.0, size=bins)
+            out["priors_bins"].append((f"class{c}", scales.astype(np.float32).tolist(),
+                                       np.stack([zmean, zstd], axis=1).astype(np.float32).tolist()))
+    return out
 
 
 def _cuboid_corners(xyz, whl, R):

@@ -174,6 +174,23 @@ def R_from_allocentric(K, R_view, u, v):
     return R
 
 
+def R_to_allocentric(K, R, u, v):
+    """math_util.py:595-623 (tensor branch): the inverse view rotation, M^T @ R where the viewing-ray angle is > 0."""
+    fx, fy, sx, sy = K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]
+    oray = torch.stack(((u - sx) / fx, (v - sy) / fy, torch.ones_like(u))).T
+    oray = oray / torch.linalg.norm(oray, dim=1).unsqueeze(1)
+    angle = torch.acos(oray[:, -1])
+    axis = torch.zeros_like(oray)
+    axis[:, 0] = axis[:, 0] - oray[:, 1]
+    axis[:, 1] = axis[:, 1] + oray[:, 0]
+    norms = torch.linalg.norm(axis, dim=1)
+    valid_angle = angle > 0
+    M = U.axis_angle_to_matrix(angle.unsqueeze(1) * axis / norms.unsqueeze(1))
+    R_view = R.clone()
+    R_view[valid_angle] = torch.bmm(M[valid_angle].transpose(2, 1), R[valid_angle])
+    return R_view
+
+
 def chamfer_loss(vals, target):
     """roi_heads.py:298-304"""
     B = vals.shape[0]
@@ -200,12 +217,14 @@ POSE_WIDTH = {"6d": 6, "quaternion": 4, "euler": 3}
 def cube_losses(head, num_classes, boxes, classes, Ks_scaled, virtual_to_real, prior_mean, gt_boxes3D, gt_poses, *,
                 prior_std=None, z_type="direct", dims_priors_enabled=True, dims_priors_func="exp", pose_type="6d",
                 allocentric_pose=True, virtual_depth=True, chamfer_pose=True, inverse_z_weight=False, use_confidence=True,
-                joint=True, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0)):
+                joint=True, loss_w=(1.0, 1.0, 1.0, 1.0, 1.0), disentangled=True, cluster_bins=1, z_scales=None, z_stats=None):
     """CubeHead.forward tail (cube_head.py:163,175-197) + ROIHeads3D._forward_cube training path (roi_heads.py:410-768) with
     DISENTANGLED_LOSS (every released config).  Defaults = configs/Base.yaml (z 'direct', 6d pose, dims priors 'exp', virtual
     depth, allocentric, chamfer + joint, confidence); the keyword switches follow MODEL.ROI_CUBE_HEAD.{Z_TYPE, DIMS_PRIORS_*,
-    POSE_TYPE, ALLOCENTRIC_POSE, VIRTUAL_DEPTH, CHAMFER_POSE, INVERSE_Z_WEIGHT, USE_CONFIDENCE, LOSS_W_JOINT > 0}.
-    head (n, width*K) raw fused linear outputs [xy 2K | z K | dims 3K | pose Pn*K | uncert K if confidence];
+    POSE_TYPE, ALLOCENTRIC_POSE, VIRTUAL_DEPTH, CHAMFER_POSE, INVERSE_Z_WEIGHT, USE_CONFIDENCE, LOSS_W_JOINT > 0, DISENTANGLED_LOSS,
+    CLUSTER_BINS}; z_scales (K, bins) / z_stats (K, bins, 2) = ROIHeads3D.priors_z_scales / priors_z_stats (roi_heads.py:123-143).
+    head (n, width*K) raw fused linear outputs [xy 2K | z K*bins (bin-major, cube_head.py:191-192) | dims 3K | pose Pn*K |
+    uncert K if confidence];
     boxes (n,4) proposal boxes; classes (n,); Ks_scaled (n,3,3); virtual_to_real (n,); prior_mean / prior_std (n,3);
     gt_boxes3D (n,9); gt_poses (n,3,3); loss_w = (dims, pose, xy, z, joint) for the logged total.
     -> (losses dict (unweighted means), stats dict, extras)."""
@@ -213,10 +232,12 @@ def cube_losses(head, num_classes, boxes, classes, Ks_scaled, virtual_to_real, p
     n = head.shape[0]
     ar = torch.arange(n)
     Pn = POSE_WIDTH[pose_type]
+    nb = max(int(cluster_bins), 1)
+    o_d, o_p, o_u = (2 + nb) * K, (5 + nb) * K, (5 + nb + Pn) * K
     box_2d_deltas = head[:, : 2 * K].view(n, K, 2)
-    box_z = head[:, 2 * K: 3 * K].view(n, K, 1)
-    box_dims = head[:, 3 * K: 6 * K].view(n, K, 3)
-    raw_pose = head[:, 6 * K: (6 + Pn) * K]
+    box_z = head[:, 2 * K: o_d].view(n, nb, K, 1) if nb > 1 else head[:, 2 * K: o_d].view(n, K, 1)
+    box_dims = head[:, o_d: o_p].view(n, K, 3)
+    raw_pose = head[:, o_p: o_u]
     if pose_type == "6d":                                                     # cube_head.py:175-176
         box_pose = U.rotation_6d_to_matrix(raw_pose.reshape(-1, 6))
     elif pose_type == "quaternion":                                           # cube_head.py:178-182
@@ -226,18 +247,24 @@ def cube_losses(head, num_classes, boxes, classes, Ks_scaled, virtual_to_real, p
     else:                                                                     # cube_head.py:184-185
         box_pose = U.euler_angles_to_matrix(raw_pose.reshape(-1, 3), "XYZ")
     box_pose = box_pose.view(n, K, 3, 3)
-    cube_z = box_z[ar, classes, :]
-    cube_dims = box_dims[ar, classes, :]
-    cube_pose = box_pose[ar, classes, :, :]
-    cube_uncert = head[:, (6 + Pn) * K: (7 + Pn) * K].clip(0.01)[ar, classes] if use_confidence else None
-    cube_2d_deltas = box_2d_deltas[ar, classes, :]
     src_w = boxes[:, 2] - boxes[:, 0]
     src_h = boxes[:, 3] - boxes[:, 1]
+    if nb > 1:                                                                # roi_heads.py:432-442: nearest 2D-scale cluster
+        src_scales = (src_h ** 2 + src_w ** 2).sqrt()
+        assignments = (z_scales.detach().T.unsqueeze(0) - src_scales.unsqueeze(1).unsqueeze(2)).abs().argmin(1)      # (n, K)
+        cube_z = box_z[ar, :, classes, :][ar, assignments[ar, classes]]
+    else:
+        cube_z = box_z[ar, classes, :]
+    cube_dims = box_dims[ar, classes, :]
+    cube_pose = box_pose[ar, classes, :, :]
+    cube_uncert = head[:, o_u: o_u + K].clip(0.01)[ar, classes] if use_confidence else None
+    cube_2d_deltas = box_2d_deltas[ar, classes, :]
     src_cx = boxes[:, 0] + 0.5 * src_w
     src_cy = boxes[:, 1] + 0.5 * src_h
     cube_x = src_cx + src_w * cube_2d_deltas[:, 0]
     cube_y = src_cy + src_h * cube_2d_deltas[:, 1]
     cube_xy = torch.stack((cube_x, cube_y), dim=1)
+    cube_dims_norm = cube_dims
     if dims_priors_enabled:                                                   # roi_heads.py:467-484
         if dims_priors_func == "sigmoid":
             mn, mx = (prior_mean - 3 * prior_std).clip(0.0), prior_mean + 3 * prior_std
@@ -246,15 +273,26 @@ def cube_losses(head, num_classes, boxes, classes, Ks_scaled, virtual_to_real, p
             cube_dims = torch.exp(cube_dims.clip(max=5)) * prior_mean
     else:
         cube_dims = torch.exp(cube_dims.clip(max=5))
+    cube_pose_allocentric = cube_pose
     if allocentric_pose:                                                      # roi_heads.py:486-490
         cube_pose = R_from_allocentric(Ks_scaled, cube_pose, u=cube_x.detach(), v=cube_y.detach())
     cube_z = cube_z.squeeze(1)
+    cube_z_norm = cube_z
     if z_type == "sigmoid":                                                   # roi_heads.py:493-500
-        cube_z = torch.sigmoid(cube_z) * 100
+        cube_z_norm = torch.sigmoid(cube_z)
+        cube_z = cube_z_norm * 100
     elif z_type == "log":
         cube_z = torch.exp(cube_z)
-    if virtual_depth:                                                         # roi_heads.py:524-525
+    elif z_type == "clusters":                                                # roi_heads.py:501-522
+        z_means = torch.gather(z_stats[:, :, 0].T.unsqueeze(0).repeat([n, 1, 1]), 1, assignments.unsqueeze(1)).squeeze(1).detach()
+        z_stds = torch.gather(z_stats[:, :, 1].T.unsqueeze(0).repeat([n, 1, 1]), 1, assignments.unsqueeze(1)).squeeze(1).detach()
+        z_means, z_stds = z_means[ar, classes], z_stds[ar, classes]
+        z_mins, z_maxs = (z_means - 3 * z_stds).clip(0), z_means + 3 * z_stds
+        cube_z = z_mins + (z_maxs - z_mins) * torch.sigmoid(cube_z)           # util.scaled_sigmoid (math_util.py:969-978)
+    real_to_virtual = 1.0
+    if virtual_depth:                                                         # roi_heads.py:398-407, 524-525
         cube_z = cube_z * virtual_to_real
+        real_to_virtual = 1 / virtual_to_real
     fx, fy, sx, sy = Ks_scaled[:, 0, 0], Ks_scaled[:, 1, 1], Ks_scaled[:, 0, 2], Ks_scaled[:, 1, 2]
     gt_2d, gt_z, gt_dims = gt_boxes3D[:, :2], gt_boxes3D[:, 2], gt_boxes3D[:, 3:6]
     gt_x3d = gt_z * (gt_2d[:, 0] - sx) / fx
@@ -263,19 +301,40 @@ def cube_losses(head, num_classes, boxes, classes, Ks_scaled, virtual_to_real, p
     gt_box3d = torch.cat((gt_3d, gt_dims), dim=1)
     gt_corners = get_cuboid_verts(gt_box3d, gt_poses)
     l1 = lambda a, b: F.smooth_l1_loss(a, b, reduction="none", beta=0.0).contiguous().view(n, -1).mean(dim=1)  # noqa: E731
-    dis_z = torch.cat((torch.stack((cube_z * (gt_2d[:, 0] - sx) / fx, cube_z * (gt_2d[:, 1] - sy) / fy, cube_z)).T, gt_dims), dim=1)
-    loss_z = l1(get_cuboid_verts(dis_z, gt_poses), gt_corners)
-    dis_xy = torch.cat((torch.stack((gt_z * (cube_x - sx) / fx, gt_z * (cube_y - sy) / fy, gt_z)).T, gt_dims), dim=1)
-    loss_xy = l1(get_cuboid_verts(dis_xy, gt_poses), gt_corners)
-    pose_corners = get_cuboid_verts(gt_box3d, cube_pose)
-    loss_pose = chamfer_loss(pose_corners, gt_corners) if chamfer_pose else l1(pose_corners, gt_corners)      # roi_heads.py:597-601
-    loss_dims = l1(get_cuboid_verts(torch.cat((gt_3d, cube_dims), dim=1), gt_poses), gt_corners)
+    if disentangled:                                                          # roi_heads.py:567-603
+        dis_z = torch.cat((torch.stack((cube_z * (gt_2d[:, 0] - sx) / fx, cube_z * (gt_2d[:, 1] - sy) / fy, cube_z)).T, gt_dims), dim=1)
+        loss_z = l1(get_cuboid_verts(dis_z, gt_poses), gt_corners)
+        dis_xy = torch.cat((torch.stack((gt_z * (cube_x - sx) / fx, gt_z * (cube_y - sy) / fy, gt_z)).T, gt_dims), dim=1)
+        loss_xy = l1(get_cuboid_verts(dis_xy, gt_poses), gt_corners)
+        pose_corners = get_cuboid_verts(gt_box3d, cube_pose)
+        loss_pose = chamfer_loss(pose_corners, gt_corners) if chamfer_pose else l1(pose_corners, gt_corners)      # roi_heads.py:597-601
+        loss_dims = l1(get_cuboid_verts(torch.cat((gt_3d, cube_dims), dim=1), gt_poses), gt_corners)
+    else:                                                                     # roi_heads.py:606-649: losses in the network's output spaces
+        e1 = lambda a, b: F.smooth_l1_loss(a, b, reduction="none", beta=0.0)  # noqa: E731
+        gt_deltas = (gt_2d.clone() - torch.stack((src_cx, src_cy), dim=1)) / torch.stack((src_w, src_h), dim=1)
+        loss_xy = e1(cube_2d_deltas, gt_deltas).mean(1)
+        # with DIMS_PRIORS_ENABLED the reference divides (n,3) by the (n,2,3) priors (:620-622), which does not evaluate
+        assert not dims_priors_enabled, "roi_heads.py:620-622 cannot be evaluated (shape mismatch in the reference)"
+        loss_dims = e1(cube_dims_norm, torch.log(gt_dims)).mean(1)
+        if allocentric_pose:
+            gt_alloc = R_to_allocentric(Ks_scaled, gt_poses, u=cube_x.detach(), v=cube_y.detach())
+            loss_pose = 1 - U.so3_relative_angle(cube_pose_allocentric, gt_alloc, eps=0.1, cos_angle=True)
+        else:
+            loss_pose = 1 - U.so3_relative_angle(cube_pose, gt_poses, eps=0.1, cos_angle=True)
+        if z_type == "direct":
+            loss_z = e1(cube_z, gt_z)
+        elif z_type == "sigmoid":
+            loss_z = e1(cube_z_norm, (gt_z * real_to_virtual / 100).clip(0, 1))
+        elif z_type == "log":
+            loss_z = e1(cube_z_norm, torch.log((gt_z * real_to_virtual).clip(0.01)))
+        else:
+            loss_z = e1(cube_z_norm, ((gt_z * real_to_virtual) - z_means) / z_stds)
     wd, wp, wxy, wz, wj = loss_w
     total = (loss_dims * wd + loss_pose * wp + loss_xy * wxy + loss_z * wz).detach()                            # roi_heads.py:651-662
     if joint:                                                                 # roi_heads.py:664-683
         jb = torch.cat((torch.stack((cube_z * (cube_x - sx) / fx, cube_z * (cube_y - sy) / fy, cube_z)).T, cube_dims), dim=1)
         jc = get_cuboid_verts(jb, cube_pose)
-        loss_joint = chamfer_loss(jc, gt_corners) if chamfer_pose else l1(jc, gt_corners)
+        loss_joint = chamfer_loss(jc, gt_corners) if (chamfer_pose and disentangled) else l1(jc, gt_corners)      # roi_heads.py:676-680
         valid_joint = loss_joint < float("inf")
         total = total + (loss_joint * wj).detach()
     z_error = (cube_z - gt_z).detach().abs()

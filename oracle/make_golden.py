@@ -78,7 +78,7 @@ def variates(spec, A):
 
 
 def main(spec=SMALL):
-    priors = synthetic.make_priors(50)
+    priors = synthetic.make_priors(50, bins=spec.get("prior_bins", 0))
     config = spec.get("config", "cubercnn_DLA34_FPN.yaml")
     cfg_ref = H.reference_cfg(config, spec["overrides"])
     ref = H.build_reference_model(cfg_ref, priors)
@@ -170,7 +170,14 @@ HEAD_MIXED = dict(TINY, name="dla34_tiny_head_mixed", seed=15, overrides=_T + [
     "MODEL.ROI_CUBE_HEAD.Z_TYPE", "log", "MODEL.ROI_CUBE_HEAD.POSE_TYPE", "quaternion", "MODEL.ROI_CUBE_HEAD.INVERSE_Z_WEIGHT", True,
     "MODEL.ROI_CUBE_HEAD.LOSS_W_POSE", 0.7, "MODEL.ROI_CUBE_HEAD.LOSS_W_JOINT", 0.5, "MODEL.ROI_CUBE_HEAD.LOSS_W_3D", 1.5,
     "MODEL.ROI_CUBE_HEAD.NUM_FC", 1])
-HEAD_MODES = (HEAD_QUAT, HEAD_EULER, HEAD_MIXED)
+# depth clusters + zoomed cube ROIs; entangled losses + cube head trained on the box head's own predictions
+HEAD_CLUSTERS = dict(TINY, name="dla34_tiny_head_clusters", seed=16, prior_bins=4, overrides=_T + [
+    "MODEL.ROI_CUBE_HEAD.Z_TYPE", "clusters", "MODEL.ROI_CUBE_HEAD.CLUSTER_BINS", 4, "MODEL.ROI_CUBE_HEAD.SCALE_ROI_BOXES", 1.3,
+    "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32])
+HEAD_ENTANGLED = dict(TINY, name="dla34_tiny_head_entangled", seed=18, prior_bins=3, overrides=_T + [
+    "MODEL.ROI_CUBE_HEAD.DISENTANGLED_LOSS", False, "MODEL.ROI_CUBE_HEAD.DIMS_PRIORS_ENABLED", False, "MODEL.ROI_CUBE_HEAD.Z_TYPE", "log",
+    "MODEL.ROI_CUBE_HEAD.CLUSTER_BINS", 3, "MODEL.ROI_BOX_HEAD.TRAIN_ON_PRED_BOXES", True, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32])
+HEAD_MODES = (HEAD_QUAT, HEAD_EULER, HEAD_MIXED, HEAD_CLUSTERS, HEAD_ENTANGLED)
 
 
 FULL = dict(name="dla34_full", seed=6, images=4, height=512, width=512, num_gt=8, overrides=[])       # BASELINE configs[1]
@@ -184,6 +191,11 @@ INFER = dict(
 )
 
 
+# the cube head's inference branch with depth clusters and zoomed cube ROIs (roi_heads.py:307-324, 432-442, 501-522)
+INFER_CLUSTERS = dict(INFER, name="dla34_small_infer_clusters", seed=2, prior_bins=4, overrides=INFER["overrides"] + [
+    "MODEL.ROI_CUBE_HEAD.Z_TYPE", "clusters", "MODEL.ROI_CUBE_HEAD.CLUSTER_BINS", 4, "MODEL.ROI_CUBE_HEAD.SCALE_ROI_BOXES", 1.3])
+
+
 def sharpen(model):
     """Random-init class logits are ~uniform (every (roi, class) pair would pass the score threshold); scale the
     classifier so the eval fixture has a realistic, small set of detections.  Applied to both sides."""
@@ -194,7 +206,7 @@ def sharpen(model):
 
 def main_infer(spec=INFER):
     """eval-mode fixture: RCNN3D.inference (rcnn3d.py:79-112) of the reference on CPU."""
-    priors = synthetic.make_priors(50)
+    priors = synthetic.make_priors(50, bins=spec.get("prior_bins", 0))
     ref = H.build_reference_model(H.reference_cfg("cubercnn_DLA34_FPN.yaml", spec["overrides"]), priors)
     prod = sharpen(build_product_model(product_cfg(spec["overrides"]), priors, spec["seed"]))
     ref.load_state_dict(prod.state_dict(), strict=True)
@@ -323,16 +335,143 @@ def main_evalfull(seed=5, images=40, cats=3):
     print("wrote", path, os.path.getsize(path), "bytes; stats", np.round(ev.stats, 4).tolist())
 
 
+# MODEL.ROI_CUBE_HEAD switches x the reference's own ROIHeads3D._forward_cube, at unit scale
+_C = "MODEL.ROI_CUBE_HEAD."
+CUBE_MODES = {
+    "base": [],
+    "quat_sigmoid": [_C + "Z_TYPE", "sigmoid", _C + "DIMS_PRIORS_FUNC", "sigmoid", _C + "POSE_TYPE", "quaternion", _C + "ALLOCENTRIC_POSE", False,
+                     _C + "CHAMFER_POSE", False, _C + "LOSS_W_3D", 1.5, _C + "LOSS_W_POSE", 0.7],
+    "euler_log": [_C + "Z_TYPE", "log", _C + "DIMS_PRIORS_ENABLED", False, _C + "POSE_TYPE", "euler", _C + "VIRTUAL_DEPTH", False,
+                  _C + "INVERSE_Z_WEIGHT", True, _C + "USE_CONFIDENCE", 0.0, _C + "LOSS_W_JOINT", 0.0],
+    "bins_direct": [_C + "CLUSTER_BINS", 4],
+    "clusters": [_C + "Z_TYPE", "clusters", _C + "CLUSTER_BINS", 5, _C + "POSE_TYPE", "quaternion", _C + "LOSS_W_Z", 0.8],
+    "entangled_direct": [_C + "DISENTANGLED_LOSS", False, _C + "DIMS_PRIORS_ENABLED", False],
+    "entangled_sigmoid": [_C + "DISENTANGLED_LOSS", False, _C + "DIMS_PRIORS_ENABLED", False, _C + "Z_TYPE", "sigmoid", _C + "ALLOCENTRIC_POSE", False,
+                          _C + "POSE_TYPE", "euler", _C + "INVERSE_Z_WEIGHT", True, _C + "LOSS_W_XY", 1.3],
+    "entangled_log": [_C + "DISENTANGLED_LOSS", False, _C + "DIMS_PRIORS_ENABLED", False, _C + "Z_TYPE", "log", _C + "VIRTUAL_DEPTH", False,
+                      _C + "USE_CONFIDENCE", 0.0, _C + "LOSS_W_JOINT", 0.0],
+    "entangled_clusters": [_C + "DISENTANGLED_LOSS", False, _C + "DIMS_PRIORS_ENABLED", False, _C + "Z_TYPE", "clusters", _C + "CLUSTER_BINS", 3,
+                           _C + "POSE_TYPE", "quaternion", _C + "LOSS_W_DIMS", 0.6],
+}
+CUBE_MODE_SHAPE = dict(images=2, per_image=12, height=128, width=160, num_gt=5)
+
+
+def cube_mode_inputs(name, overrides, seed=17):
+    """The synthetic inputs of one cube-head fixture; regenerated (not stored) on the test side.  Raw outputs of the five
+    linear heads, proposal boxes, classes, ground truth, intrinsics of an image that was resized by a per-image ratio."""
+    sh = CUBE_MODE_SHAPE
+    ov = dict(zip(overrides[0::2], overrides[1::2]))
+    bins = int(ov.get(_C + "CLUSTER_BINS", 1))
+    pose_w = {"6d": 6, "quaternion": 4, "euler": 3}[ov.get(_C + "POSE_TYPE", "6d")]
+    g = torch.Generator().manual_seed(seed + sum(map(ord, name)))
+    K, n = 50, sh["images"] * sh["per_image"]
+    raw = {"bbox_3D_center_deltas": torch.randn(n, 2 * K, generator=g) * 0.3, "bbox_3D_center_depth": torch.randn(n, K * bins, generator=g) * 0.5,
+           "bbox_3D_dims": torch.randn(n, 3 * K, generator=g) * 0.4, "bbox_3D_pose": torch.randn(n, pose_w * K, generator=g),
+           "bbox_3D_uncertainty": torch.randn(n, K, generator=g) * 0.5 + 0.8}
+    zt = ov.get(_C + "Z_TYPE", "direct")
+    if zt == "direct":
+        raw["bbox_3D_center_depth"] = raw["bbox_3D_center_depth"].abs() * 20 + 1.0
+    elif zt == "log":
+        raw["bbox_3D_center_depth"] += 2.0
+    raw["bbox_3D_dims"][0] = 6.0                                   # above the clip(max=5)
+    if pose_w == 4:
+        raw["bbox_3D_pose"][1, 0::4] = -0.7                        # negative real part: the copysign branch
+    x1 = torch.rand(n, generator=g) * (sh["width"] - 60)
+    y1 = torch.rand(n, generator=g) * (sh["height"] - 60)
+    boxes = torch.stack([x1, y1, x1 + 8 + torch.rand(n, generator=g) * 50, y1 + 8 + torch.rand(n, generator=g) * 50], 1)
+    classes = torch.randint(0, K, (n,), generator=g)
+    G = sh["num_gt"]
+    gt3d, gtpose, gt_row = [], [], []
+    for i in range(sh["images"]):
+        b = torch.cat([torch.rand(G, 1, generator=g) * sh["width"], torch.rand(G, 1, generator=g) * sh["height"],
+                       torch.rand(G, 1, generator=g) * 30 + 2, torch.rand(G, 3, generator=g) * 3 + 0.3, torch.zeros(G, 3)], 1)
+        if i == 0:
+            b[0, 2] = 1.5                                          # below e: the clip of INVERSE_Z_WEIGHT
+        q = torch.randn(G, 4, generator=g)
+        gt3d.append(b)
+        gtpose.append(H_quat(q / q.norm(dim=1, keepdim=True)))
+        gt_row.append(torch.randint(0, G, (sh["per_image"],), generator=g))
+    Ks = [torch.tensor([[700.0, 0, 330.0], [0, 690.0, 250.0], [0, 0, 1]]), torch.tensor([[380.0, 0, 150.0], [0, 400.0, 120.0], [0, 0, 1]])]
+    ratios = [4.0, 1.6]                                            # original height / network height
+    return dict(raw=raw, boxes=boxes, classes=classes, gt3d=gt3d, gtpose=gtpose, gt_row=gt_row, Ks=Ks, ratios=ratios, bins=bins)
+
+
+def H_quat(q):
+    from oracle import upstream as U
+    return U.quaternion_to_matrix(q)
+
+
+def main_cube_modes():
+    """tests/golden/cube_head_modes.pt: the reference's ROIHeads3D._forward_cube (roi_heads.py:326-824), training and inference
+    branch, for every MODEL.ROI_CUBE_HEAD parameterisation it can evaluate.  The five linear heads' outputs are replaced (forward
+    hooks) by the synthetic raw tensors of `cube_mode_inputs`, so the fixture covers exactly what csrc/cube_head.hip fuses:
+    class / cluster gather, decode, losses, logged scalars and the gradient w.r.t. the raw head outputs."""
+    from oracle.upstream import Boxes, Instances
+    sh = CUBE_MODE_SHAPE
+    out = {}
+    for name, ov in CUBE_MODES.items():
+        inp = cube_mode_inputs(name, ov)
+        priors = synthetic.make_priors(50, bins=inp["bins"])
+        cfg = H.reference_cfg("cubercnn_DLA34_FPN.yaml", TINY["overrides"] + ov)
+        ref = H.build_reference_model(cfg, priors)
+        rh = ref.roi_heads
+        raw = {k: v.clone().requires_grad_(True) for k, v in inp["raw"].items()}
+        hooks = [getattr(rh.cube_head, k).register_forward_hook(lambda m, i, o, k=k: raw[k]) for k in raw if hasattr(rh.cube_head, k)]
+        feats = {f"p{l}": torch.zeros(sh["images"], 256, sh["height"] // 2 ** l, sh["width"] // 2 ** l) for l in range(2, 7)}
+        im_dims = [(sh["height"], sh["width"])] * sh["images"]
+        P = sh["per_image"]
+
+        def instances(train):
+            res = []
+            for i in range(sh["images"]):
+                inst = Instances(im_dims[i])
+                b = inp["boxes"][i * P:(i + 1) * P]
+                if train:
+                    inst.proposal_boxes, inst.pred_boxes = Boxes(b.clone()), Boxes(b.clone())
+                    inst.gt_classes = inp["classes"][i * P:(i + 1) * P].clone()
+                    inst.gt_boxes3D = inp["gt3d"][i][inp["gt_row"][i]].clone()
+                    inst.gt_poses = inp["gtpose"][i][inp["gt_row"][i]].clone()
+                else:
+                    inst.pred_boxes = Boxes(b.clone())
+                    inst.pred_classes = inp["classes"][i * P:(i + 1) * P].clone()
+                    inst.scores = torch.full((P,), 0.64)
+                res.append(inst)
+            return res
+        rh.train()
+        with EventStorage(0) as st:
+            _, losses = rh._forward_cube(feats, instances(True), inp["Ks"], im_dims, inp["ratios"])
+            sum(losses.values()).backward()
+            logs = {k: v[0] for k, v in st.latest().items()}
+        grads = {k: v.grad.clone() for k, v in raw.items() if v.grad is not None}
+        rh.eval()
+        with torch.no_grad():
+            pred = rh._forward_cube(feats, instances(False), inp["Ks"], im_dims, inp["ratios"])
+        ev = [{k: getattr(p, k).clone() for k in ("scores", "pred_bbox3D", "pred_center_cam", "pred_center_2D", "pred_dimensions", "pred_pose")}
+              for p in pred]
+        for h in hooks:
+            h.remove()
+        out[name] = {"overrides": ov, "losses": {k: float(v) for k, v in losses.items()}, "logs": logs, "grads": grads, "eval": ev}
+        print(name, {k: round(float(v), 5) for k, v in losses.items()})
+    path = os.path.join(ROOT, "tests", "golden", "cube_head_modes.pt")
+    torch.save({"shape": CUBE_MODE_SHAPE, "modes": out, "torch_version": torch.__version__}, path)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    if "--evalfull" in sys.argv:
+    if "--cube-modes" in sys.argv:
+        main_cube_modes()
+    elif "--evalfull" in sys.argv:
         main_evalfull()
     elif "--eval" in sys.argv:
         main_eval()
+    elif "--infer-clusters" in sys.argv:
+        main_infer(INFER_CLUSTERS)
     elif "--infer" in sys.argv:
         main_infer()
     elif "--head-modes" in sys.argv:
         for spec in HEAD_MODES:
-            main(spec)
+            if "--new-only" not in sys.argv or not os.path.exists(os.path.join(ROOT, "tests", "golden", spec["name"] + ".pt")):
+                main(spec)
     else:
         main(TINY if "--tiny" in sys.argv else RESNET if "--resnet" in sys.argv else FULL if "--full" in sys.argv
              else RESNET_FULL if "--resnet-full" in sys.argv else SMALL)

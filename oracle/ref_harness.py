@@ -140,6 +140,7 @@ def install():
     _mod("pytorch3d.transforms", rotation_6d_to_matrix=U.rotation_6d_to_matrix, axis_angle_to_matrix=U.axis_angle_to_matrix,
          quaternion_to_matrix=U.quaternion_to_matrix, euler_angles_to_matrix=U.euler_angles_to_matrix)
     _mod("pytorch3d.transforms.rotation_conversions", _copysign=U._copysign)
+    _mod("pytorch3d.transforms.so3", so3_relative_angle=U.so3_relative_angle)
     _mod("pytorch3d.ops.iou_box3d", _box_planes=U._box_planes, _box_triangles=U._box_triangles)
     sys.meta_path.append(_StubFinder())
     if REFERENCE not in sys.path:

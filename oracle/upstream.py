@@ -1156,6 +1156,19 @@ def euler_angles_to_matrix(euler_angles: torch.Tensor, convention: str) -> torch
     return torch.matmul(torch.matmul(mats[0], mats[1]), mats[2])
 
 
+def so3_relative_angle(R1, R2, cos_angle: bool = False, cos_bound: float = 1e-4, eps: float = 1e-4):
+    """pytorch3d.transforms.so3.so3_relative_angle / so3_rotation_angle (published algorithm): the angle of R1 R2^T from its
+    trace; raises when a trace leaves [-1 - eps, 3 + eps].  The reference only uses cos_angle=True (roi_heads.py:631-633)."""
+    R12 = torch.bmm(R1, R2.permute(0, 2, 1))
+    rot_trace = R12[:, 0, 0] + R12[:, 1, 1] + R12[:, 2, 2]
+    if ((rot_trace < -1.0 - eps) + (rot_trace > 3.0 + eps)).any():
+        raise ValueError("A matrix has trace outside valid range [-1-eps,3+eps].")
+    phi_cos = (rot_trace - 1.0) * 0.5
+    if cos_angle:
+        return phi_cos
+    return torch.acos(phi_cos.clamp(-1.0 + cos_bound, 1.0 - cos_bound))
+
+
 def _copysign(a, b):
     signs_differ = (a < 0) != (b < 0)
     return torch.where(signs_differ, -a, a)

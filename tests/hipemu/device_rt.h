@@ -131,7 +131,9 @@ template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
     if (src < 0 || (src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
     return hipemu_exchange(v, src);
 }
-static inline unsigned long long __ballot(int pred) {
+// `live_out`: the live-lane mask the vote was taken over, sampled between the two rendezvous (a lane that has left the
+// second one may run to the end of the kernel and retire before its neighbours compare their result)
+static inline unsigned long long hipemu_ballot(int pred, unsigned long long* live_out) {
     unsigned long long* s = (unsigned long long*)hipemu::wave_scratch();
     int lane = hipemu::g.lane;
     s[lane * 8] = pred ? 1ull : 0ull;
@@ -140,10 +142,15 @@ static inline unsigned long long __ballot(int pred) {
     for (int l = 0; l < 64; ++l)
         if (((live >> l) & 1ull) && s[l * 8]) m |= (1ull << l);
     hipemu::wave_sync();
+    if (live_out) *live_out = live;
     return m;
 }
+static inline unsigned long long __ballot(int pred) { return hipemu_ballot(pred, nullptr); }
 static inline int __any(int pred) { return __ballot(pred) != 0; }
-static inline int __all(int pred) { return __ballot(pred) == hipemu::wave_live_mask(); }
+static inline int __all(int pred) {
+    unsigned long long live;
+    return hipemu_ballot(pred, &live) == live;
+}
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }

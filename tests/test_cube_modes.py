@@ -1,0 +1,185 @@
+"""Every MODEL.ROI_CUBE_HEAD parameterisation the reference can evaluate -- Z_TYPE direct / sigmoid / log / clusters,
+CLUSTER_BINS > 1, DIMS_PRIORS_*, POSE_TYPE, ALLOCENTRIC_POSE, VIRTUAL_DEPTH, CHAMFER_POSE, INVERSE_Z_WEIGHT, USE_CONFIDENCE,
+LOSS_W_*, DISENTANGLED_LOSS False -- against tests/golden/cube_head_modes.pt, written by the REFERENCE's own
+ROIHeads3D._forward_cube (oracle/make_golden.py --cube-modes; roi_heads.py:326-824): the weighted loss dict, the logged scalars,
+the gradient w.r.t. the raw outputs of the five linear heads and the inference outputs.
+
+  * CPU: the oracle restatement (oracle/cubercnn_oracle.py:cube_losses) is pinned to the fixture,
+  * emulated + GPU: the product's ROIHeads3D host code (loss names, weights, cluster priors) over csrc/cube_head.hip."""
+import os
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+GOLD = os.path.join(ROOT, "tests", "golden", "cube_head_modes.pt")
+HEADS = ("bbox_3D_center_deltas", "bbox_3D_center_depth", "bbox_3D_dims", "bbox_3D_pose", "bbox_3D_uncertainty")     # fused column order
+_C = "MODEL.ROI_CUBE_HEAD."
+
+
+def _gold():
+    return torch.load(GOLD, weights_only=False)
+
+
+MODES = sorted(_gold()["modes"])
+
+
+def _cfg(overrides):
+    from oracle import make_golden as MG
+    cfg = MG.product_cfg(MG.TINY["overrides"] + list(overrides) + ["MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 48])      # fg_cap = 12 = ROIs per image
+    return cfg
+
+
+def _fused(inp, conf):
+    parts = [inp["raw"][k] for k in HEADS if conf or k != "bbox_3D_uncertainty"]
+    w = sum(p.shape[1] for p in parts)
+    pad = (w + 15) // 16 * 16 - w
+    return torch.cat(parts + [torch.zeros(parts[0].shape[0], pad)], 1), [p.shape[1] for p in parts]
+
+
+def _close(a, b, tol=1e-4):
+    return abs(a - b) <= tol * max(1.0, abs(b))
+
+
+@pytest.mark.parametrize("name", MODES)
+def test_oracle_matches_reference_cube_modes(name):
+    """pins oracle/cubercnn_oracle.py:cube_losses (all keyword switches) to the reference's own outputs"""
+    from oracle import cubercnn_oracle as O
+    from oracle import make_golden as MG
+    from omni3d_amd import synthetic
+    gold = _gold()
+    g, sh = gold["modes"][name], gold["shape"]
+    inp = MG.cube_mode_inputs(name, g["overrides"])
+    cfg = _cfg(g["overrides"]).MODEL.ROI_CUBE_HEAD
+    priors = synthetic.make_priors(50, bins=inp["bins"])
+    conf = cfg.USE_CONFIDENCE > 0
+    head, widths = _fused(inp, conf)
+    hr = head[:, : sum(widths)].clone().requires_grad_(True)
+    P, n = sh["per_image"], sh["images"] * sh["per_image"]
+    img = torch.arange(sh["images"]).repeat_interleave(P)
+    Kmat = torch.stack([inp["Ks"][i] / inp["ratios"][i] for i in range(sh["images"])])
+    Kmat[:, 2, 2] = 1
+    v2r = torch.tensor([(sh["height"] * float(inp["Ks"][i][1, 1])) / (cfg.VIRTUAL_FOCAL * (sh["height"] * inp["ratios"][i])) for i in range(sh["images"])])
+    pd = torch.tensor(priors["priors_dims_per_cat"])
+    if not cfg.DIMS_PRIORS_ENABLED:
+        pd = torch.ones_like(pd)
+    gt3d = torch.cat([inp["gt3d"][i][inp["gt_row"][i]] for i in range(sh["images"])])
+    gtpose = torch.cat([inp["gtpose"][i][inp["gt_row"][i]] for i in range(sh["images"])])
+    zs = zt = None
+    if inp["bins"] > 1:
+        zs = torch.tensor([p[1] for p in priors["priors_bins"]])
+        zt = torch.tensor([p[2] for p in priors["priors_bins"]])
+    lw = (cfg.LOSS_W_DIMS, cfg.LOSS_W_POSE, cfg.LOSS_W_XY, cfg.LOSS_W_Z, cfg.LOSS_W_JOINT)
+    losses, stats, _ = O.cube_losses(hr, 50, inp["boxes"], inp["classes"], Kmat[img], v2r[img], pd[inp["classes"], 0], gt3d, gtpose,
+                                     prior_std=pd[inp["classes"], 1], z_type=cfg.Z_TYPE, dims_priors_enabled=cfg.DIMS_PRIORS_ENABLED,
+                                     dims_priors_func=cfg.DIMS_PRIORS_FUNC, pose_type=cfg.POSE_TYPE, allocentric_pose=cfg.ALLOCENTRIC_POSE,
+                                     virtual_depth=cfg.VIRTUAL_DEPTH, chamfer_pose=cfg.CHAMFER_POSE, inverse_z_weight=cfg.INVERSE_Z_WEIGHT,
+                                     use_confidence=conf, joint=cfg.LOSS_W_JOINT > 0, loss_w=lw, disentangled=cfg.DISENTANGLED_LOSS,
+                                     cluster_bins=inp["bins"], z_scales=zs, z_stats=zt)
+    w3 = cfg.LOSS_W_3D
+    weight = {"Cube/loss_dims": cfg.LOSS_W_DIMS * w3, "Cube/loss_xy": cfg.LOSS_W_XY * w3, "Cube/loss_z": cfg.LOSS_W_Z * w3,
+              "Cube/loss_pose": cfg.LOSS_W_POSE * w3, "Cube/loss_joint": cfg.LOSS_W_JOINT * w3, "Cube/uncert": cfg.USE_CONFIDENCE}
+    assert set(losses) == set(g["losses"])
+    total = 0
+    for k, v in g["losses"].items():
+        assert _close(float(losses[k].detach()) * weight[k], v, 2e-5), (k, float(losses[k].detach()) * weight[k], v)
+        total = total + losses[k] * weight[k]
+    for k in ("Cube/z_error", "Cube/dims_error", "Cube/xy_error", "Cube/z_close"):
+        assert _close(stats[k], g["logs"][k], 2e-5), k
+    assert _close(stats["Cube/total_3D_loss"] * w3, g["logs"]["Cube/total_3D_loss"], 2e-5)
+    total.backward()
+    off = 0
+    for k, w in zip([h for h in HEADS if conf or h != "bbox_3D_uncertainty"], widths):
+        want = g["grads"][k]
+        assert (hr.grad[:, off:off + w] - want).abs().max() <= 2e-5 * max(1.0, want.abs().max().item()), k
+        off += w
+
+
+def _run_product(dev, name):
+    from oracle import make_golden as MG
+    from omni3d_amd import synthetic
+    from omni3d_amd.cubercnn.modeling.roi_heads import build_roi_heads
+    from omni3d_amd.cubercnn.modeling.targets import pack_instances
+    from omni3d_amd.d2.events import EventStorage
+    from omni3d_amd.d2.layers import ShapeSpec
+    from omni3d_amd.d2.structures import Boxes, Instances
+    from omni3d_amd.kernels import det
+    gold = _gold()
+    g, sh = gold["modes"][name], gold["shape"]
+    inp = MG.cube_mode_inputs(name, g["overrides"])
+    cfg = _cfg(g["overrides"])
+    priors = synthetic.make_priors(50, bins=inp["bins"])
+    heads = build_roi_heads(cfg, {f"p{l}": ShapeSpec(channels=256, stride=2 ** l) for l in range(2, 7)}, priors=priors).to(dev)
+    conf = cfg.MODEL.ROI_CUBE_HEAD.USE_CONFIDENCE > 0
+    head, widths = _fused(inp, conf)
+    assert head.shape[1] == heads.cube_head.fused_dim
+    fused = head.to(dev).requires_grad_(True)
+
+    class Stub(torch.nn.Module):                         # the linear heads' outputs are the fixture's inputs
+        def forward(self, x):
+            return fused
+    heads.cube_head = Stub()
+    B, P, S = sh["images"], sh["per_image"], 48
+    assert heads.fg_cap == P
+    insts, goff = [], [0]
+    for i in range(B):
+        inst = Instances((sh["height"], sh["width"]))
+        G = len(inp["gt3d"][i])
+        inst.gt_classes, inst.gt_boxes = torch.zeros(G, dtype=torch.long), Boxes(torch.tensor([[0.0, 0.0, 8.0, 8.0]]).repeat(G, 1))
+        inst.gt_boxes3D, inst.gt_poses = inp["gt3d"][i], inp["gtpose"][i]
+        insts.append(inst)
+        goff.append(goff[-1] + G)
+    image_sizes = [(sh["height"], sh["width"])] * B
+    packed = pack_instances(insts, image_sizes, inp["Ks"], inp["ratios"], heads.virtual_focal).to(dev)
+    sboxes = torch.zeros(B, S, 4)
+    scls = torch.full((B, S), -2, dtype=torch.int32)
+    sgt = torch.full((B, S), -1, dtype=torch.int32)
+    for i in range(B):
+        sboxes[i, :P] = inp["boxes"][i * P:(i + 1) * P]
+        scls[i, :P] = inp["classes"][i * P:(i + 1) * P].int()
+        sgt[i, :P] = (inp["gt_row"][i] + goff[i]).int()
+    heads.train()
+    with EventStorage(0) as st:
+        losses = heads._forward_cube_train(None, sboxes.to(dev), scls.to(dev), sgt.to(dev), packed, x=torch.zeros(1))
+        sum(losses.values()).backward()
+        heads.flush_logs(st)
+        logs = {k: v[0] for k, v in st.latest().items()}
+    assert set(losses) == set(g["losses"]), (sorted(losses), sorted(g["losses"]))
+    for k, v in g["losses"].items():
+        assert _close(float(losses[k].detach()), v), (k, float(losses[k].detach()), v)
+    for k in ("Cube/z_error", "Cube/dims_error", "Cube/xy_error", "Cube/z_close", "Cube/total_3D_loss", "Cube/conf"):
+        if k in g["logs"]:
+            assert _close(logs[k], g["logs"][k]), (k, logs[k], g["logs"][k])
+        else:
+            assert k not in logs
+    off, grad = 0, fused.grad.cpu()
+    for k, w in zip([h for h in HEADS if conf or h != "bbox_3D_uncertainty"], widths):
+        want = g["grads"][k]
+        err = (grad[:, off:off + w] - want).abs().max().item()
+        assert err <= 1e-4 * max(1.0, want.abs().max().item()), (k, err)
+        off += w
+    assert off == sum(widths) and (off == grad.shape[1] or grad[:, off:].abs().max() == 0)
+    # inference branch (roi_heads.py:353-357, 771-819)
+    img = torch.arange(B, dtype=torch.int32).repeat_interleave(P).to(dev)
+    pr = heads.priors_dims_per_cat.detach().reshape(50, 2, 3).contiguous()
+    c3, pose, verts = det.cube_decode(fused.detach(), 50, inp["boxes"].to(dev), inp["classes"].int().to(dev), img, packed.Ks, packed.v2r,
+                                      packed.ratio, pr, heads.cube_mode, heads.clusters())
+    c3, pose, verts = c3.cpu(), pose.cpu(), verts.cpu()
+    for i, ev in enumerate(g["eval"]):
+        r = slice(i * P, (i + 1) * P)
+        for got, key, tol in ((c3[r, :3], "pred_center_cam", 1e-4), (c3[r, 3:6], "pred_dimensions", 1e-4), (c3[r, 6:8], "pred_center_2D", 1e-4),
+                              (pose[r], "pred_pose", 1e-5), (verts[r], "pred_bbox3D", 1e-4), ((0.64 * c3[r, 8]) ** 0.5, "scores", 1e-5)):
+            want = ev[key]
+            assert (got - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), (key, (got - want).abs().max().item())
+
+
+@pytest.mark.parametrize("name", MODES)
+def test_product_cube_modes_emulated(emu_lib, name):
+    _run_product("cpu", name)
+
+
+@pytest.mark.gpu
+def test_product_cube_modes_gpu(hip_lib):
+    for name in MODES:
+        _run_product("cuda", name)

@@ -138,6 +138,25 @@ def test_dataset_plumbing_matches_the_reference_files(in_tmp_cwd):
     for k in pb:
         np.testing.assert_allclose(np.asarray(pa[k], dtype=np.float64), np.asarray(pb[k], dtype=np.float64), rtol=1e-12, atol=0, equal_nan=True, err_msg=k)
     assert MetadataCatalog.get("KITTI_train").thing_classes == sorted(KITTI, key=lambda n: IDS[KITTI.index(n)])
+    # CLUSTER_BINS > 1: the 1-D k-means over the 2D scale and the per-cluster depth statistics (math_util.py:401-485)
+    from omni3d_amd import synthetic
+    big = synthetic.write_omni3d_dataset(root, "KITTI_big", KITTI[:4], IDS[:4], num_images=24, height=96, width=128, num_gt=5, seed=9, dataset_id=2)
+    populated = 0
+    for nbins in (2, 3, 5):           # the fifth category has no samples: the anchor-range placeholders
+        cfg.defrost()
+        cfg.MODEL.ROI_CUBE_HEAD.CLUSTER_BINS = nbins
+        pa = util.compute_priors(cfg, data.Omni3D([big], filter_settings=copy.deepcopy(fs)))
+        pb = RM.compute_priors(cfg, RD.Omni3D([big], filter_settings=copy.deepcopy(fs)))
+        assert len(pa["priors_bins"]) == len(pb["priors_bins"]) == len(KITTI)
+        for (na, sa, za), (nb, sb, zb) in zip(pa["priors_bins"], pb["priors_bins"]):
+            assert na == nb and len(sa) == len(sb) == nbins
+            np.testing.assert_allclose(sa, sb, rtol=1e-6)
+            np.testing.assert_allclose(np.asarray(za, dtype=np.float64), np.asarray(zb, dtype=np.float64), rtol=1e-9, equal_nan=True)
+            populated += int(len({round(v, 3) for v in sa}) == nbins and sa[0] != 32)
+        for k in pb:
+            if k != "priors_bins":
+                np.testing.assert_allclose(np.asarray(pa[k], dtype=np.float64), np.asarray(pb[k], dtype=np.float64), rtol=1e-12, equal_nan=True)
+    assert populated > 0, "no category had enough samples to exercise the clustering itself"
 
 
 def test_evaluation_helper_scores_perfect_predictions(emu_lib, in_tmp_cwd):

@@ -232,29 +232,46 @@ CUBE_CONFIGS = {
                       use_confidence=False, joint=False),
     "quat_log_invz": dict(z_type="log", pose_type="quaternion", inverse_z_weight=True),
     "euler_sigmoid_l1": dict(z_type="sigmoid", pose_type="euler", chamfer_pose=False, use_confidence=False),
+    # CLUSTER_BINS > 1 (roi_heads.py:432-442) with the plain depth types and Z_TYPE 'clusters' (:501-522)
+    "bins_direct": dict(cluster_bins=4),
+    "clusters": dict(z_type="clusters", cluster_bins=5, pose_type="quaternion"),
+    # DISENTANGLED_LOSS False (roi_heads.py:606-649, 676-680); only evaluates without dimension priors in the reference
+    "entangled_direct": dict(disentangled=False, dims_priors_enabled=False),
+    "entangled_sigmoid": dict(disentangled=False, dims_priors_enabled=False, z_type="sigmoid", allocentric_pose=False, pose_type="euler",
+                              inverse_z_weight=True),
+    "entangled_log": dict(disentangled=False, dims_priors_enabled=False, z_type="log", virtual_depth=False, use_confidence=False, joint=False),
+    "entangled_clusters": dict(disentangled=False, dims_priors_enabled=False, z_type="clusters", cluster_bins=3, pose_type="quaternion"),
 }
 
 
 def _run_cube(dev, cfg_name="base"):
     from omni3d_amd.kernels import det
-    cfg = CUBE_CONFIGS[cfg_name]
+    cfg = dict(CUBE_CONFIGS[cfg_name])
+    nb = cfg.pop("cluster_bins", 1)
     mode = det.cube_mode(**cfg)
-    assert (mode == det.CUBE_MODE_BASE) == (cfg_name == "base")
+    assert (mode == det.CUBE_MODE_BASE) == (cfg_name in ("base", "bins_direct"))
     conf, joint = cfg.get("use_confidence", True), cfg.get("joint", True)
     g = torch.Generator().manual_seed(4)
     F_, K, B = 37, 50, 3
-    W = det.cube_head_width(mode)
-    Pn = W - 6 - int(conf)
+    W = det.cube_head_width(mode, nb)
+    Pn = W - 5 - nb - int(conf)
     ldh = (W * K + 15) // 16 * 16
     head = torch.randn(F_, ldh, generator=g) * 0.5
     if conf:
-        head[:, (6 + Pn) * K: W * K] += 1.0            # uncertainties around 1, some below the 0.01 clip
-    head[0, 3 * K: 6 * K] = 6.0               # dims logits above the clip(max=5)
+        head[:, (5 + nb + Pn) * K: W * K] += 1.0       # uncertainties around 1, some below the 0.01 clip
+    head[0, (2 + nb) * K: (5 + nb) * K] = 6.0          # dims logits above the clip(max=5)
     if cfg.get("z_type") == "log":
         head[:, 2 * K: 3 * K] += 2.0          # depths around e^2
     if cfg.get("pose_type") == "quaternion":
-        head[1, 6 * K: 6 * K + 4 * K: 4] = -0.7   # negative real part -> the copysign branch
+        head[1, (5 + nb) * K: (5 + nb) * K + 4 * K: 4] = -0.7   # negative real part -> the copysign branch
     boxes = _rand_boxes(g, F_, 512, 512, 20, 200)
+    z_scales = z_stats = clusters = None
+    if nb > 1:
+        z_scales = torch.sort(torch.rand(K, nb, generator=g) * 250 + 20, dim=1).values
+        z_scales[3] = z_scales[3, 0]                                    # equal scale priors: argmin keeps the first
+        z_stats = torch.stack((torch.rand(K, nb, generator=g) * 30 + 3, torch.rand(K, nb, generator=g) * 6 + 0.5), dim=2)
+        z_stats[::7, :, 1] *= 4                                         # mean - 3 std < 0 -> the clip(0)
+        clusters = (nb, z_scales.to(dev), z_stats.to(dev) if cfg.get("z_type") == "clusters" else None)
     cls = torch.randint(0, K, (F_,), generator=g)
     img = torch.randint(0, B, (F_,), generator=g)
     Ks = torch.tensor([[500.0, 510.0, 250.0, 260.0], [400.0, 400.0, 256.0, 256.0], [700.0, 690.0, 300.0, 200.0]])
@@ -272,9 +289,9 @@ def _run_cube(dev, cfg_name="base"):
     Kmat = torch.zeros(F_, 3, 3)
     Kmat[:, 0, 0], Kmat[:, 1, 1], Kmat[:, 0, 2], Kmat[:, 1, 2], Kmat[:, 2, 2] = Ks[img, 0], Ks[img, 1], Ks[img, 2], Ks[img, 3], 1.0
     ref, stats, ex = O.cube_losses(hr, K, boxes, cls, Kmat, v2r[img], priors[cls, 0], gt3d[gt_row], gtpose[gt_row],
-                                   prior_std=priors[cls, 1], loss_w=loss_w, **cfg)
+                                   prior_std=priors[cls, 1], loss_w=loss_w, cluster_bins=nb, z_scales=z_scales, z_stats=z_stats, **cfg)
     args = [t.to(dev) for t in (head, boxes, cls.int(), img.int(), Ks, v2r, priors, gt3d, gtpose.reshape(G, 9), gt_row.int())]
-    vals, jac, red = det.cube_loss_fwd(args[0], K, *args[1:], loss_w=loss_w, mode=mode)
+    vals, jac, red = det.cube_loss_fwd(args[0], K, *args[1:], loss_w=loss_w, mode=mode, clusters=clusters)
     names = ["Cube/loss_dims", "Cube/loss_xy", "Cube/loss_z", "Cube/loss_pose", "Cube/loss_joint", "Cube/uncert"]
     assert ("Cube/loss_joint" in ref) == joint and ("Cube/uncert" in ref) == conf
     r = red.cpu()
@@ -288,13 +305,13 @@ def _run_cube(dev, cfg_name="base"):
             assert abs(r[k].item() - stats[nm]) < 2e-5 * max(1.0, abs(stats[nm])), nm
     w = torch.tensor([1.0, 0.7, 1.3, 0.9, 1.1, 0.5])
     sum(w[k] * ref[nm] for k, nm in enumerate(names) if nm in ref).backward()
-    dhead = det.cube_loss_bwd(vals, jac, red, w.to(dev), args[2], F_, K, ldh, mode).cpu()
+    dhead = det.cube_loss_bwd(vals, jac, red, w.to(dev), args[2], args[1], F_, K, ldh, mode, clusters).cpu()
     scale = hr.grad.abs().max().item()
     assert (dhead[:, : W * K] - hr.grad).abs().max() < 2e-5 * max(1.0, scale), (dhead[:, : W * K] - hr.grad).abs().max()
-    assert dhead[:, W * K:].abs().max() == 0
+    assert ldh == W * K or dhead[:, W * K:].abs().max() == 0
     # inference decode
     ratio = torch.tensor([1.0, 2.0, 0.5])
-    c3, pose, verts = det.cube_decode(args[0], K, args[1], args[2], args[3], args[4], args[5], ratio.to(dev), args[6], mode)
+    c3, pose, verts = det.cube_decode(args[0], K, args[1], args[2], args[3], args[4], args[5], ratio.to(dev), args[6], mode, clusters)
     X = ex["cube_z"] * (ex["cube_x"] - Kmat[:, 0, 2]) / Kmat[:, 0, 0]
     assert (c3[:, 0].cpu() - X.detach()).abs().max() < 1e-4 * max(1.0, X.detach().abs().max().item())
     assert (c3[:, 3:6].cpu() - ex["cube_dims"].detach()).abs().max() < 1e-5 * max(1.0, ex["cube_dims"].detach().abs().max().item())

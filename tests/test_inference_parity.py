@@ -8,15 +8,15 @@ import torch
 
 from conftest import ROOT
 
-GOLD = os.path.join(ROOT, "tests", "golden", "dla34_small_infer.pt")
+FIXTURES = ["dla34_small_infer", "dla34_small_infer_clusters"]     # default head; Z_TYPE clusters + CLUSTER_BINS 4 + SCALE_ROI_BOXES
 
 
-def _run(dev):
+def _run(dev, name="dla34_small_infer"):
     from oracle import make_golden as MG
     from omni3d_amd import synthetic
-    gold = torch.load(GOLD, weights_only=False)
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", name + ".pt"), weights_only=False)
     spec = gold["spec"]
-    priors = synthetic.make_priors(50)
+    priors = synthetic.make_priors(50, bins=spec.get("prior_bins", 0))
     model = MG.sharpen(MG.build_product_model(MG.product_cfg(spec["overrides"]), priors, spec["seed"])).to(dev)
     batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
     for b in batch:
@@ -60,15 +60,17 @@ def _run(dev):
         bounded("pred_bbox3D", i.pred_bbox3D, 1e-3)
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir) and dev == "cuda":
-        with open(os.path.join(out_dir, "inference_fp64_report.txt"), "w") as f:
+        with open(os.path.join(out_dir, "inference_fp64_report.txt" if name == "dla34_small_infer" else name + "_fp64_report.txt"), "w") as f:
             f.write("\n".join(report) + "\n")
 
 
 @pytest.mark.skipif(os.environ.get("OMNI_SLOW") != "1", reason="minutes under the host emulator; set OMNI_SLOW=1 (the GPU variant is the gate)")
-def test_inference_matches_reference_emulated(emu_lib):
-    _run("cpu")
+@pytest.mark.parametrize("name", FIXTURES)
+def test_inference_matches_reference_emulated(emu_lib, name):
+    _run("cpu", name)
 
 
 @pytest.mark.gpu
-def test_inference_matches_reference_gpu(hip_lib):
-    _run("cuda")
+@pytest.mark.parametrize("name", FIXTURES)
+def test_inference_matches_reference_gpu(hip_lib, name):
+    _run("cuda", name)

@@ -19,7 +19,7 @@ def _run(dev, name):
     from omni3d_amd.d2.events import EventStorage
     gold = torch.load(_gold(name), weights_only=False)
     spec = gold["spec"]
-    priors = synthetic.make_priors(50)
+    priors = synthetic.make_priors(50, bins=spec.get("prior_bins", 0))
     model = MG.build_product_model(MG.product_cfg(spec["overrides"], spec.get("config", "cubercnn_DLA34_FPN.yaml")), priors, spec["seed"], device=dev)
     batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
     A = gold["rpn_labels"].shape[1]
@@ -86,7 +86,8 @@ def test_training_step_matches_reference_emulated(emu_lib):
     _run("cpu", "dla34_tiny")     # 1 image 64x64: the whole step through the host-emulated kernels
 
 
-HEAD_MODE_FIXTURES = ["dla34_tiny_head_quat", "dla34_tiny_head_euler", "dla34_tiny_head_mixed"]
+HEAD_MODE_FIXTURES = ["dla34_tiny_head_quat", "dla34_tiny_head_euler", "dla34_tiny_head_mixed", "dla34_tiny_head_clusters",
+                      "dla34_tiny_head_entangled"]
 
 
 @pytest.mark.skipif(os.environ.get("OMNI_SLOW") != "1", reason="~5 min each under the host emulator; set OMNI_SLOW=1 (the GPU variant is the gate)")
@@ -102,7 +103,9 @@ def test_training_step_matches_reference_gpu(hip_lib, name):
     2 x 512x512 -- fixtures written by the reference's OWN files (oracle/make_golden.py --full / --resnet-full).
     *_head_*: the non-default MODEL.ROI_CUBE_HEAD parameterisations (oracle/make_golden.py --head-modes):
     quaternion / euler pose, sigmoid / log depth, sigmoid / disabled dimension priors, egocentric pose, no virtual depth,
-    L1 instead of chamfer, inverse-z weighting, no confidence, no joint loss, per-group FC stacks, NUM_FC 1."""
+    L1 instead of chamfer, inverse-z weighting, no confidence, no joint loss, per-group FC stacks, NUM_FC 1; *_clusters:
+    Z_TYPE 'clusters' with 4 depth clusters and SCALE_ROI_BOXES; *_entangled: DISENTANGLED_LOSS False, CLUSTER_BINS 3 with
+    log depth, TRAIN_ON_PRED_BOXES."""
     _run("cuda", name)
 
 
