@@ -27,7 +27,7 @@ def _run(dev, name="dla34_small_infer"):
     with torch.no_grad():
         out = model(batch)
     assert len(out) == len(gold["results"])
-    report = []
+    report, bad = [], []
     for o, ref in zip(out, gold["results"]):
         i = o["instances"]
         n = len(ref["scores"])
@@ -45,7 +45,8 @@ def _run(dev, name="dla34_small_infer"):
             den = (1.0 + r_64.abs()) if scale is None else scale
             e_hip, e_ref = float(((got - r_64).abs() / den).max()), float(((r32 - r_64).abs() / den).max())
             report.append("%-16s |hip-fp64| %.2e  |ref32-fp64| %.2e  cap %.0e" % (name, e_hip, e_ref, cap))
-            assert e_hip <= max(cap, 3.0 * e_ref) and e_hip <= 2.0 * cap, report[-1]
+            if not (e_hip <= max(cap, 3.0 * e_ref) and e_hip <= 2.0 * cap):
+                bad.append(report[-1])
 
         ext = float(max(o["instances"].image_size))
         bounded("scores", i.scores, 1e-4)
@@ -57,11 +58,14 @@ def _run(dev, name="dla34_small_infer"):
         # the Gram-Schmidt of a random-init 6D pose amplifies fp32 rounding of the head GEMMs: the REFERENCE in fp32 is
         # itself 2e-4 .. 3.5e-4 from its float64 evaluation here, so the cap is 1e-3 and the 2x rule is the real bar
         bounded("pred_pose", i.pred_pose, 1e-3)
-        bounded("pred_bbox3D", i.pred_bbox3D, 1e-3)
+        # corners = centre +- R dims / 2 cancel for the random-init head's cuboids of up to ~100 m around a centre a few metres
+        # away, so the error of a corner is measured against the extent of ITS cuboid, not against the corner coordinate
+        bounded("pred_bbox3D", i.pred_bbox3D, 1e-3, scale=1.0 + r64["pred_bbox3D"].double().abs().amax(dim=(1, 2), keepdim=True))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir) and dev == "cuda":
         with open(os.path.join(out_dir, "inference_fp64_report.txt" if name == "dla34_small_infer" else name + "_fp64_report.txt"), "w") as f:
             f.write("\n".join(report) + "\n")
+    assert not bad, "\n".join(bad)
 
 
 @pytest.mark.skipif(os.environ.get("OMNI_SLOW") != "1", reason="minutes under the host emulator; set OMNI_SLOW=1 (the GPU variant is the gate)")
