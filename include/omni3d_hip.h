@@ -315,6 +315,14 @@ int omni_resize_bilinear_u8(const unsigned char* src, unsigned char* dst, unsign
 int omni_sgd_step(float* param, const float* grad, float* momentum_buf, long long n, float lr, float momentum,
                   float dampening, float weight_decay, int nesterov, int first_step, float grad_scale,
                   const float* skip_flag, void* stream);
+/* torch.optim.Adam / AdamW (+ amsgrad) as built by cubercnn/solver/build.py:58-65 (eps 1e-2, betas (0.9, 0.999), the parameter
+ * groups' lr / weight decay), single-tensor form, over one group's range of the flat buckets.  decoupled: 0 Adam (L2 into the
+ * gradient), 1 AdamW (p *= 1 - lr wd).  max_exp_avg_sq: null or the amsgrad running maximum.  step: device float = number of this
+ * update (bias corrections); omni_adam_tick advances it once per optimizer step unless skip_flag is set. */
+int omni_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long long n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int decoupled, const float* step, float grad_scale,
+                   const float* skip_flag, void* stream);
+int omni_adam_tick(float* step, const float* skip_flag, void* stream);
 /* The loop's divergence guard (tools/train_net.py:157-285: allreduce_dict :186, rolling-loss test :194-215, skip / step
  * :245-253, retry decision :258-270) around ONE small all-reduce.  vec (n + 2): [n loss scalars | sum | non-finite-gradient flag];
  * omni_guard_pre writes the sum, the caller all-reduces vec over the ranks (sum), omni_guard_post averages by `world`, updates

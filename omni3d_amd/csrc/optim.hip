@@ -1,4 +1,4 @@
-// optim.hip -- fused SGD-with-momentum step over a flat fp32 parameter bucket and a fused
+// optim.hip -- fused SGD-with-momentum and Adam / AdamW (+ amsgrad) steps over a flat fp32 parameter bucket and a fused
 // non-finite scan of the flat gradient bucket.
 //
 // Reference: torch.optim.SGD built by /root/reference/cubercnn/solver/build.py:6-69 (momentum 0.9,
@@ -6,6 +6,9 @@
 // per-parameter isnan/isinf gradient scan of tools/train_net.py:222-233 (~230 params x 2 reductions
 // with a host sync each) which collapses into ONE pass over the flat bucket here.
 // HBM-bound: 4 streams (p, g, m read; p, m written) of 16 B per lane.
+// SOLVER.TYPE adam / adam+amsgrad / adamw / adamw+amsgrad (build.py:58-65: torch.optim.Adam / AdamW, eps 1e-2, betas (0.9, 0.999)):
+// one pass over p, g, exp_avg, exp_avg_sq (+ max_exp_avg_sq); the step count lives on the device because the divergence guard's
+// skip decision does (a skipped iteration must not advance the bias correction, as the reference never calls step() then).
 #include <device_rt.h>
 
 namespace {
@@ -41,6 +44,63 @@ __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const f
         }
         p[i] -= lr * d;
     }
+}
+
+// torch.optim.Adam / AdamW, single-tensor form (torch/optim/adam.py _single_tensor_adam, adamw.py): L2 decay into the gradient
+// (Adam) or p *= 1 - lr wd (AdamW); exp_avg.lerp_(g, 1 - b1); exp_avg_sq = b2 v + (1 - b2) g g; bias corrections from the step
+// count in double, like the Python scalars of the reference; denom = sqrt(v or max v) / sqrt(bc2) + eps; p -= lr / bc1 * m / denom.
+struct AdamCoef {
+    float beta2, eps, wd, w1, w2, shrink, step_size, bc2s, gscale;
+    int decoupled;
+};
+__device__ __forceinline__ void adam_elem(float& pv, float gv, float& mv, float& vv, float* vmax_elem, const AdamCoef& c) {
+    gv *= c.gscale;
+    if (c.wd != 0.f) {
+        if (c.decoupled) pv *= c.shrink;
+        else gv += c.wd * pv;
+    }
+    mv += (gv - mv) * c.w1;
+    vv = vv * c.beta2 + (c.w2 * gv) * gv;
+    float second = vv;
+    if (vmax_elem != nullptr) {
+        second = fmaxf(*vmax_elem, vv);
+        *vmax_elem = second;
+    }
+    pv -= c.step_size * (mv / (sqrtf(second) / c.bc2s + c.eps));
+}
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, float* __restrict__ vmax, long n, float lr, float beta1,
+                                                   float beta2, float eps, float wd, int decoupled, const float* __restrict__ step,
+                                                   float gscale, const float* __restrict__ skip_flag) {
+    if (skip_flag != nullptr && skip_flag[0] != 0.f) return;
+    const double t = (double)step[0];
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    AdamCoef c;
+    c.beta2 = beta2; c.eps = eps; c.wd = wd; c.w1 = 1.f - beta1; c.w2 = 1.f - beta2; c.shrink = 1.f - lr * wd;
+    c.step_size = (float)((double)lr / bc1); c.bc2s = (float)sqrt(bc2); c.gscale = gscale; c.decoupled = decoupled;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 pv = reinterpret_cast<float4*>(p)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 xv = vmax != nullptr ? reinterpret_cast<float4*>(vmax)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        adam_elem(pv.x, gv.x, mv.x, vv.x, vmax != nullptr ? &xv.x : nullptr, c);
+        adam_elem(pv.y, gv.y, mv.y, vv.y, vmax != nullptr ? &xv.y : nullptr, c);
+        adam_elem(pv.z, gv.z, mv.z, vv.z, vmax != nullptr ? &xv.z : nullptr, c);
+        adam_elem(pv.w, gv.w, mv.w, vv.w, vmax != nullptr ? &xv.w : nullptr, c);
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (vmax != nullptr) reinterpret_cast<float4*>(vmax)[i] = xv;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float pv = p[i], mv = m[i], vv = v[i];
+        adam_elem(pv, g[i], mv, vv, vmax != nullptr ? vmax + i : nullptr, c);
+        p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+}
+// step[0] += 1 unless the guard asked to skip this iteration
+__global__ void adam_tick_kernel(float* __restrict__ step, const float* __restrict__ skip_flag) {
+    if (threadIdx.x == 0 && !(skip_flag != nullptr && skip_flag[0] != 0.f)) step[0] += 1.f;
 }
 
 __global__ void __launch_bounds__(256) nonfinite_kernel(const float* __restrict__ g, long n, float* __restrict__ flag) {
@@ -111,6 +171,25 @@ int omni_sgd_step(float* param, const float* grad, float* momentum_buf, long lon
     if (n == 0) return OMNI_OK;
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, (long)n,
                        lr, momentum, dampening, weight_decay, nesterov, first_step, grad_scale, skip_flag);
+    return omni_launch_status();
+}
+
+// In-place Adam (decoupled = 0) / AdamW (decoupled = 1) step over n contiguous fp32 elements of one (lr, weight decay) group.
+// max_exp_avg_sq: null, or the amsgrad running maximum.  step: device float holding the number of this update (1 for the first;
+// advance it with omni_adam_tick once per optimizer step, before the groups).  grad_scale / skip_flag as in omni_sgd_step.
+int omni_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long long n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int decoupled, const float* step, float grad_scale,
+                   const float* skip_flag, void* stream) {
+    if (n < 0 || step == nullptr) return OMNI_ERR_ARG;
+    if (n == 0) return OMNI_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, max_exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, decoupled, step, grad_scale,
+                       skip_flag);
+    return omni_launch_status();
+}
+int omni_adam_tick(float* step, const float* skip_flag, void* stream) {
+    if (step == nullptr) return OMNI_ERR_ARG;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, skip_flag);
     return omni_launch_status();
 }
 

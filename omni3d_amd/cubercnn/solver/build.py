@@ -1,7 +1,7 @@
 """`build_optimizer(cfg, model)` / `freeze_bn` with the reference's parameter-group rules
-(/root/reference/cubercnn/solver/build.py:6-76): SGD momentum (cfg.SOLVER.MOMENTUM / NESTEROV), weight decay
-WEIGHT_DECAY except WEIGHT_DECAY_NORM for norm layers, WEIGHT_DECAY_BIAS / BIAS_LR_FACTOR for biases, 0 for the
-`priors_*` parameters.
+(/root/reference/cubercnn/solver/build.py:6-76): SGD momentum (cfg.SOLVER.MOMENTUM / NESTEROV) or Adam / AdamW with or without
+amsgrad (SOLVER.TYPE, eps 1e-2 as the reference passes), weight decay WEIGHT_DECAY except WEIGHT_DECAY_NORM for norm layers,
+WEIGHT_DECAY_BIAS / BIAS_LR_FACTOR for biases, 0 for the `priors_*` parameters.
 
 MI355X design: instead of ~230 per-tensor update kernels, every parameter is re-homed into ONE flat fp32
 bucket (grouped by weight decay so a group is a contiguous range), gradients accumulate into a matching flat
@@ -40,11 +40,13 @@ def _param_groups(cfg, model):
     return groups
 
 
-class FlatSGD(torch.optim.Optimizer):
-    """torch.optim.SGD semantics over flat buckets (see module docstring)."""
+class _FlatOptimizer(torch.optim.Optimizer):
+    """Flat parameter / gradient / state buckets, the data-parallel exchange over them and the re-binding of stray gradients:
+    everything the fused optimizers share.  Subclasses name their per-element state buckets in STATE and implement
+    `_step_segments()`."""
+    STATE = ()
 
-    def __init__(self, params, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, direct_accumulate=True):
-        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov)
+    def __init__(self, params, defaults, direct_accumulate=True):
         super().__init__(params, defaults)
         self._build_buckets()
         # backward kernels add weight / bias / BN gradients straight into the bucket views (functional._direct_grad).
@@ -67,7 +69,7 @@ class FlatSGD(torch.optim.Optimizer):
         total = sum(((p.numel() + 3) // 4) * 4 for _, p in plist)
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.flat_mom = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_state = {name: torch.zeros(total, dtype=torch.float32, device=dev) for name in self.STATE}
         self.segments = []   # (start, end, representative group)
         self._slot = {}      # id(param) -> (offset, numel) inside the flat buckets
         off = 0
@@ -199,19 +201,39 @@ class FlatSGD(torch.optim.Optimizer):
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 self.all_reduce_grads()
+        self._step_segments()
+        self._grad_scale = 1.0
+        self._steps += 1
+
+    def _ordered_params(self):
+        return [p for g in self.param_groups for p in g["params"]]
+
+    def _state_view(self, name, p):
+        off, n = self._slot[id(p)]
+        return self._view_like(self.flat_state[name][off:off + n], p)
+
+
+class FlatSGD(_FlatOptimizer):
+    """torch.optim.SGD semantics over flat buckets (see module docstring)."""
+    STATE = ("momentum_buffer",)
+
+    def __init__(self, params, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, direct_accumulate=True):
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov)
+        super().__init__(params, defaults, direct_accumulate)
+
+    @property
+    def flat_mom(self):
+        return self.flat_state["momentum_buffer"]
+
+    def _step_segments(self):
         first = self._steps == 0
         for start, end, g in self.segments:
             det.sgd_step(self.flat_param[start:end], self.flat_grad[start:end], self.flat_mom[start:end], g["lr"],
                          g["momentum"], g["dampening"], g["weight_decay"], g["nesterov"], first_step=first, skip_flag=self.skip_flag,
                          grad_scale=self._grad_scale)
-        self._grad_scale = 1.0
-        self._steps += 1
 
     # ---- checkpoint format: torch.optim.SGD's (per-parameter `momentum_buffer`), so optimizer states written by the
     # reference's DetectionCheckpointer (tools/train_net.py:128) load here and vice versa ----------------------------------
-    def _ordered_params(self):
-        return [p for g in self.param_groups for p in g["params"]]
-
     def state_dict(self):
         sd = super().state_dict()          # param_groups with params packed as 0..N-1 in group order, like torch.optim.SGD
         state = {}
@@ -253,6 +275,68 @@ class FlatSGD(torch.optim.Optimizer):
         self._steps = int(steps) if steps is not None else (1 if loaded else 0)
 
 
+class FlatAdam(_FlatOptimizer):
+    """torch.optim.Adam / AdamW (amsgrad optional) semantics over the flat buckets: one fused kernel per (lr, weight decay)
+    range reads p, g, exp_avg, exp_avg_sq (and max_exp_avg_sq) once.  The step count is a device scalar advanced by a one-lane
+    kernel that honours the divergence guard's skip flag, so a skipped iteration leaves the bias corrections where they were
+    (the reference does not call step() on such an iteration, tools/train_net.py:245-253)."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, decoupled=False, direct_accumulate=True):
+        self.STATE = ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if amsgrad else ())
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=bool(amsgrad))
+        self.decoupled = bool(decoupled)
+        super().__init__(params, defaults, direct_accumulate)
+        self.dev_step = torch.zeros(1, dtype=torch.float32, device=self.flat_param.device)
+
+    def _step_segments(self):
+        det.adam_tick(self.dev_step, self.skip_flag)
+        st = self.flat_state
+        for start, end, g in self.segments:
+            vmax = st["max_exp_avg_sq"][start:end] if g["amsgrad"] else None
+            det.adam_step(self.flat_param[start:end], self.flat_grad[start:end], st["exp_avg"][start:end], st["exp_avg_sq"][start:end],
+                          vmax, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.decoupled, self.dev_step,
+                          skip_flag=self.skip_flag, grad_scale=self._grad_scale)
+
+    # ---- checkpoint format: torch.optim.Adam's / AdamW's per-parameter {step, exp_avg, exp_avg_sq[, max_exp_avg_sq]} --------
+    def state_dict(self):
+        sd = super().state_dict()
+        state = {}
+        steps = float(self.dev_step.item())
+        if steps > 0:
+            for idx, p in enumerate(self._ordered_params()):
+                entry = {"step": torch.tensor(steps)}
+                for name in self.STATE:
+                    entry[name] = self._state_view(name, p).detach().clone().contiguous(memory_format=torch.contiguous_format)
+                state[idx] = entry
+        sd["state"] = state
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        state = sd.get("state", {})
+        params = self._ordered_params()
+        sd["state"] = {}
+        super().load_state_dict(sd)
+        for buf in self.flat_state.values():
+            buf.zero_()
+        steps = set()
+        for idx, st in state.items():
+            p = params[int(idx)]
+            steps.add(float(st["step"]))
+            for name in self.STATE:
+                if name not in st:
+                    raise ValueError(f"optimizer state of parameter {idx} has no '{name}' (amsgrad mismatch?)")
+                if st[name].numel() != p.numel():
+                    raise ValueError(f"{name} {idx}: {st[name].numel()} elements, the parameter has {p.numel()}")
+                self._state_view(name, p).copy_(st[name].reshape(p.shape).to(self.flat_param.device))
+        if len(state) not in (0, len(params)):
+            raise ValueError(f"optimizer state covers {len(state)} of {len(params)} parameters")
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}); the fused step keeps one count")
+        self.dev_step.fill_(steps.pop() if steps else 0.0)
+        self._steps = int(self.dev_step.item())
+
+
 def build_optimizer(cfg, model):
     params = _param_groups(cfg, model)
     # gradients of everything outside the backbone are complete before the backbone starts back-propagating
@@ -263,8 +347,12 @@ def build_optimizer(cfg, model):
         under_ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)   # tools/train_net.py:449-454 wraps first
         return FlatSGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV,
                        weight_decay=cfg.SOLVER.WEIGHT_DECAY, direct_accumulate=not under_ddp)
-    if cfg.SOLVER.TYPE in ("adam", "adam+amsgrad", "adamw", "adamw+amsgrad"):
-        raise NotImplementedError("MI355X hot path: SOLVER.TYPE 'sgd' (configs/Base.yaml:2); Adam variants are not fused yet")
+    if cfg.SOLVER.TYPE in ("adam", "adam+amsgrad", "adamw", "adamw+amsgrad"):     # build.py:58-65
+        under_ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)
+        adamw = cfg.SOLVER.TYPE.startswith("adamw")
+        # torch defaults behind the reference's calls: betas (0.9, 0.999); the groups carry their own weight decay
+        return FlatAdam(params, cfg.SOLVER.BASE_LR, eps=1e-02, weight_decay=1e-2 if adamw else 0.0, amsgrad=cfg.SOLVER.TYPE.endswith("+amsgrad"),
+                        decoupled=adamw, direct_accumulate=not under_ddp)
     raise ValueError("{} is not supported as an optimizer.".format(cfg.SOLVER.TYPE))
 
 

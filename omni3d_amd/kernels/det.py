@@ -308,6 +308,20 @@ def sgd_step(param, grad, buf, lr, momentum=0.9, dampening=0.0, weight_decay=0.0
            _lib.stream_of(param))
 
 
+def adam_step(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, lr, beta1, beta2, eps, weight_decay, decoupled, step, skip_flag=None,
+              grad_scale=1.0):
+    """torch.optim.Adam (decoupled False) / AdamW (True) over one contiguous range; step: device float, see adam_tick"""
+    L = _dev(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, step, skip_flag)
+    L.call("omni_adam_step", _lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(max_exp_avg_sq),
+           param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(decoupled), _lib.ptr(step),
+           float(grad_scale), _lib.ptr(skip_flag), _lib.stream_of(param))
+
+
+def adam_tick(step, skip_flag=None):
+    L = _dev(step, skip_flag)
+    L.call("omni_adam_tick", _lib.ptr(step), _lib.ptr(skip_flag), _lib.stream_of(step))
+
+
 def nonfinite_any(grad, flag):
     L = _dev(grad, flag)
     L.call("omni_nonfinite_any", _lib.ptr(grad), grad.numel(), _lib.ptr(flag), _lib.stream_of(grad))

@@ -183,3 +183,100 @@ def test_step_guard_one_collective_keeps_ranks_in_agreement(emu_lib):
     assert steps[1][0] is True                                # one rank's bad gradients skip the step everywhere
     assert steps[2][0] is True and steps[2][1] is True        # 2 of 3 exploded >= 0.5 and 3 > period / 2: retry
     assert steps[3] == (1.5, 15.0)                            # allreduce_dict average
+
+
+# ---- SOLVER.TYPE adam / adam+amsgrad / adamw / adamw+amsgrad (cubercnn/solver/build.py:58-65) ---------------------------------------
+ADAM_TYPES = ["adam", "adam+amsgrad", "adamw", "adamw+amsgrad"]
+_WD = (1e-2, 0.0, 3e-2, 0.0)
+
+
+def _adam_pair(kind, a, b, dev="cpu"):
+    from omni3d_amd.cubercnn.solver.build import FlatAdam
+    groups = lambda net: [{"params": [p], "lr": 0.05 if i % 2 else 0.02, "weight_decay": wd} for i, (p, wd) in enumerate(zip(net.parameters(), _WD))]  # noqa: E731
+    ams, adamw = kind.endswith("+amsgrad"), kind.startswith("adamw")
+    fo = FlatAdam(groups(a), 0.02, eps=1e-2, amsgrad=ams, decoupled=adamw, direct_accumulate=False)
+    to = (torch.optim.AdamW if adamw else torch.optim.Adam)(groups(b), 0.02, eps=1e-2, amsgrad=ams)      # as the reference builds them
+    return fo, to
+
+
+def _run_adam(kind, dev):
+    a, b = _nets()
+    a = a.to(dev)
+    fo, to = _adam_pair(kind, a, b, dev)
+    for it in range(6):
+        for net, opt, d in ((a, fo, dev), (b, to, "cpu")):
+            opt.zero_grad()
+            g = torch.Generator().manual_seed(it)
+            x = torch.randn(7, 6, generator=g).to(d)
+            ((net(x) ** 2).mean() * (10.0 if it == 3 else 1.0)).backward()
+            opt.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert (p.detach().cpu() - q.detach()).abs().max() <= 2e-6, (kind, float((p.detach().cpu() - q.detach()).abs().max()))
+    return a, b, fo, to
+
+
+@pytest.mark.parametrize("kind", ADAM_TYPES)
+def test_flat_adam_matches_torch(emu_lib, kind):
+    a, b, fo, to = _run_adam(kind, "cpu")
+    # checkpoint interchange in both directions, then one more step each
+    sd, ref = fo.state_dict(), to.state_dict()
+    assert set(sd["state"][0]) == set(ref["state"][0]) and float(sd["state"][0]["step"]) == float(ref["state"][0]["step"]) == 6.0
+    for k in ref["state"]:
+        for name in ref["state"][k]:
+            assert (sd["state"][k][name].float() - ref["state"][k][name].float()).abs().max() <= 2e-6, (k, name)
+    a2, b2 = _nets()
+    a2.load_state_dict(a.state_dict()); b2.load_state_dict(b.state_dict())
+    fo2, to2 = _adam_pair(kind, a2, b2)
+    fo2.load_state_dict(ref)
+    to2.load_state_dict(sd)
+    assert float(fo2.dev_step) == 6.0
+    for net, opt in ((a, fo), (b, to), (a2, fo2), (b2, to2)):
+        opt.zero_grad()
+        _loss(net, 9).backward()
+        opt.step()
+    _same(a, b, 2e-6); _same(a, a2, 2e-6); _same(a, b2, 2e-6)
+
+
+def test_flat_adam_skipped_step_keeps_the_bias_correction(emu_lib):
+    """the guard's skip flag: no update, no step-count advance (the reference does not call step() on such an iteration)"""
+    a, b = _nets()
+    fo, to = _adam_pair("adam", a, b)
+    fo.skip_flag = torch.zeros(1)
+    for it in range(4):
+        skip = it == 1
+        fo.skip_flag.fill_(1.0 if skip else 0.0)
+        for net, opt in ((a, fo), (b, to)):
+            opt.zero_grad()
+            _loss(net, it).backward()
+            if not (skip and opt is to):
+                opt.step()
+    assert float(fo.dev_step) == 3.0
+    _same(a, b, 2e-6)
+
+
+@pytest.mark.parametrize("kind", ADAM_TYPES + ["sgd", "lamb"])
+def test_build_optimizer_solver_types(emu_lib, kind):
+    from omni3d_amd.cubercnn.config import get_cfg_defaults
+    from omni3d_amd.cubercnn.solver import FlatAdam, FlatSGD, build_optimizer
+    from omni3d_amd.d2.config import get_cfg
+    cfg = get_cfg()
+    get_cfg_defaults(cfg)
+    cfg.SOLVER.TYPE = kind
+    net = nn.Sequential(nn.Conv2d(3, 4, 3), nn.BatchNorm2d(4))
+    if kind == "lamb":
+        with pytest.raises(ValueError, match="is not supported as an optimizer"):
+            build_optimizer(cfg, net)
+        return
+    opt = build_optimizer(cfg, net)
+    assert isinstance(opt, FlatSGD if kind == "sgd" else FlatAdam)
+    if kind != "sgd":
+        assert opt.decoupled == kind.startswith("adamw") and ("max_exp_avg_sq" in opt.flat_state) == kind.endswith("+amsgrad")
+        assert all(g["eps"] == 1e-2 and g["betas"] == (0.9, 0.999) for g in opt.param_groups)
+    wds = sorted({g["weight_decay"] for g in opt.param_groups})
+    assert wds == sorted({cfg.SOLVER.WEIGHT_DECAY, cfg.SOLVER.WEIGHT_DECAY_NORM, cfg.SOLVER.WEIGHT_DECAY_BIAS} - {None})
+
+
+@pytest.mark.gpu
+def test_flat_adam_matches_torch_gpu(hip_lib):
+    for kind in ADAM_TYPES:
+        _run_adam(kind, "cuda")
