@@ -98,6 +98,11 @@ int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* ga
 int omni_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int omni_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 
+/* nn.AvgPool2d(2, stride=2) of torchvision densenet121's transitions (cubercnn/modeling/backbone/densenet.py:14-15, 27-30)
+ * forward / backward, NHWC; dy (N, H/2, W/2, C) -> dx (N, H, W, C). */
+int omni_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int omni_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+
 /* F.max_pool2d(x, kernel_size=1, stride=2) (dla.py:474, resnet.py:55): y[n,oh,ow]=x[n,2oh,2ow]. */
 int omni_subsample2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int omni_subsample2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);

@@ -315,6 +315,34 @@ __global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const float* __restri
     }
 }
 
+// ---- 2x2/s2 average pool (nn.AvgPool2d(2, 2), torchvision densenet `_Transition.pool`): DIR 0 forward, DIR 1 backward (every
+//      input of a window gets dy / 4; an odd last row / column is outside every window and gets 0) ----------------------------
+template <int DIR>
+__global__ void __launch_bounds__(256) avgpool2_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int H, int W,
+                                                       int C) {
+    const int C4 = C >> 2, OH = H >> 1, OW = W >> 1;
+    const long total = (long)N * OH * OW * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % C4);
+        long q = i / C4;
+        const int ow = (int)(q % OW); q /= OW;
+        const int oh = (int)(q % OH);
+        const int n = (int)(q / OH);
+        const long o = (((long)n * H + 2 * oh) * W + 2 * ow) * C + 4 * col;
+        if (DIR == 0) {
+            const float4 a = ld4(src + o), b = ld4(src + o + C), c = ld4(src + o + (long)W * C), d = ld4(src + o + (long)W * C + C);
+            float4 m;
+            m.x = (a.x + b.x + c.x + d.x) * 0.25f; m.y = (a.y + b.y + c.y + d.y) * 0.25f;
+            m.z = (a.z + b.z + c.z + d.z) * 0.25f; m.w = (a.w + b.w + c.w + d.w) * 0.25f;
+            st4(dst + 4 * i, m);
+        } else {
+            float4 g = ld4(src + 4 * i);
+            g.x *= 0.25f; g.y *= 0.25f; g.z *= 0.25f; g.w *= 0.25f;
+            st4(dst + o, g); st4(dst + o + C, g); st4(dst + o + (long)W * C, g); st4(dst + o + (long)W * C + C, g);
+        }
+    }
+}
+
 // ---- stride-2 subsample (max_pool2d kernel 1, stride 2): y[n,oh,ow] = x[n,2oh,2ow] ----------------
 // DIR 0: forward gather; DIR 1: backward scatter into a zero-initialised dx
 template <int DIR>
@@ -496,6 +524,23 @@ int omni_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, 
     if (total == 0) return OMNI_OK;
     if ((H & 1) || (W & 1)) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, (hipStream_t)stream);
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C);
+    return omni_launch_status();
+}
+
+int omni_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    if ((C & 3) || H < 2 || W < 2) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    if (total == 0) return OMNI_OK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(avgpool2_kernel<0>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C);
+    return omni_launch_status();
+}
+
+int omni_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    if ((C & 3) || H < 2 || W < 2) return OMNI_ERR_ARG;
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    if (total == 0) return OMNI_OK;
+    if ((H & 1) || (W & 1)) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(avgpool2_kernel<1>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C);
     return omni_launch_status();
 }
 

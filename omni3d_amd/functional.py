@@ -333,6 +333,18 @@ class _MaxPool2(Function):
         return bnpool.maxpool2_bwd(x, _cl(dy))
 
 
+class _AvgPool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(x)
+        ctx.hw = (x.shape[2], x.shape[3])
+        return bnpool.avgpool2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return bnpool.avgpool2_bwd(_cl(dy), ctx.hw)
+
+
 class _Subsample2(Function):
     @staticmethod
     def forward(ctx, x):
@@ -358,6 +370,11 @@ class _Upsample2Add(Function):
 
 def max_pool2(x):
     return _MaxPool2.apply(x)
+
+
+def avg_pool2(x):
+    """nn.AvgPool2d(kernel_size=2, stride=2)"""
+    return _AvgPool2.apply(x)
 
 
 def subsample2(x):

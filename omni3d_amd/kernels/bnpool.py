@@ -88,6 +88,19 @@ def maxpool2_bwd(x, dy):
     return _simple("omni_maxpool2_bwd", xv, (N, H, W, C), (N, H, W, C), extra_in=(dyv,)).permute(0, 3, 1, 2)
 
 
+def avgpool2_fwd(x):
+    xv = _nhwc(x)
+    N, H, W, C = xv.shape
+    return _simple("omni_avgpool2_fwd", xv, (N, H // 2, W // 2, C), (N, H, W, C)).permute(0, 3, 1, 2)
+
+
+def avgpool2_bwd(dy, in_hw):
+    dyv = _nhwc(dy)
+    N, _, _, C = dyv.shape
+    H, W = in_hw
+    return _simple("omni_avgpool2_bwd", dyv, (N, H, W, C), (N, H, W, C)).permute(0, 3, 1, 2)
+
+
 def subsample2_fwd(x):
     xv = _nhwc(x)
     N, H, W, C = xv.shape

@@ -819,6 +819,81 @@ def tv_resnet34(pretrained=False):
     return _tv_resnet([3, 4, 6, 3], pretrained)
 
 
+# torchvision.models.densenet121 (cubercnn/modeling/backbone/densenet.py:2,14-15) -- un-vendored, restated from the published
+# architecture (Huang et al.; torchvision/models/densenet.py): growth 32, blocks (6, 12, 24, 16), bn_size 4, 64 stem features,
+# drop rate 0; `features` = conv0 7x7/s2, norm0, relu0, pool0 3x3/s2, denseblock1, transition1, ..., denseblock4, norm5.
+# PARITY UNPINNED: no torchvision binary or fixture exists here to check this restatement against.
+class TVDenseLayer(nn.Module):
+    def __init__(self, cin, growth, bn_size):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(cin)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(cin, bn_size * growth, kernel_size=1, stride=1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(bn_size * growth, growth, kernel_size=3, stride=1, padding=1, bias=False)
+
+    def forward(self, inputs):
+        prev = [inputs] if isinstance(inputs, torch.Tensor) else inputs
+        bottleneck = self.conv1(self.relu1(self.norm1(torch.cat(prev, 1))))
+        return self.conv2(self.relu2(self.norm2(bottleneck)))
+
+
+class TVDenseBlock(nn.ModuleDict):
+    def __init__(self, num_layers, cin, bn_size, growth):
+        super().__init__()
+        for i in range(num_layers):
+            self.add_module("denselayer%d" % (i + 1), TVDenseLayer(cin + i * growth, growth, bn_size))
+
+    def forward(self, init_features):
+        features = [init_features]
+        for _, layer in self.items():
+            features.append(layer(features))
+        return torch.cat(features, 1)
+
+
+class TVTransition(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("norm", nn.BatchNorm2d(cin))
+        self.add_module("relu", nn.ReLU(inplace=True))
+        self.add_module("conv", nn.Conv2d(cin, cout, kernel_size=1, stride=1, bias=False))
+        self.add_module("pool", nn.AvgPool2d(kernel_size=2, stride=2))
+
+
+class TVDenseNet(nn.Module):
+    def __init__(self, growth=32, block_config=(6, 12, 24, 16), init_features=64, bn_size=4, num_classes=1000):
+        super().__init__()
+        from collections import OrderedDict
+        self.features = nn.Sequential(OrderedDict([
+            ("conv0", nn.Conv2d(3, init_features, kernel_size=7, stride=2, padding=3, bias=False)),
+            ("norm0", nn.BatchNorm2d(init_features)), ("relu0", nn.ReLU(inplace=True)),
+            ("pool0", nn.MaxPool2d(kernel_size=3, stride=2, padding=1))]))
+        c = init_features
+        for i, n in enumerate(block_config):
+            self.features.add_module("denseblock%d" % (i + 1), TVDenseBlock(n, c, bn_size, growth))
+            c += n * growth
+            if i != len(block_config) - 1:
+                self.features.add_module("transition%d" % (i + 1), TVTransition(c, c // 2))
+                c //= 2
+        self.features.add_module("norm5", nn.BatchNorm2d(c))
+        self.classifier = nn.Linear(c, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.constant_(m.bias, 0)
+
+
+def tv_densenet121(pretrained=False):
+    if pretrained:
+        raise RuntimeError("ImageNet weights are a network download (torchvision); set MODEL.WEIGHTS")
+    return TVDenseNet()
+
+
 def build_resnet_backbone(cfg, input_shape):
     raise NotImplementedError("MSRA ResNet (MODEL.RESNETS.TORCHVISION False) is outside the restated surface")
 
