@@ -98,6 +98,13 @@ int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* ga
 int omni_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int omni_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 
+/* Depthwise convolution `nn.Conv2d(C, C, R, padding=pad, stride=stride, groups=C, bias=False)` of torchvision's mnasnet1_0
+ * (lifted by cubercnn/modeling/backbone/mnasnet.py:14-17): R in {3, 5}, stride in {1, 2}; x (N,H,W,C), w (R,R,C) tap-major,
+ * y / dy (N,OH,OW,C), dw (R,R,C) overwritten. */
+int omni_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int R, int stride, int pad, void* stream);
+int omni_dwconv_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int R, int stride, int pad, void* stream);
+int omni_dwconv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int R, int stride, int pad, void* stream);
+
 /* nn.AvgPool2d(2, stride=2) of torchvision densenet121's transitions (cubercnn/modeling/backbone/densenet.py:14-15, 27-30)
  * forward / backward, NHWC; dy (N, H/2, W/2, C) -> dx (N, H, W, C). */
 int omni_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);

@@ -30,15 +30,16 @@ __device__ __forceinline__ float4 mask4(float4 g, float4 y) {
 // MODE 1: (sum dz, sum dz * xhat), dz = dy masked by y > 0  -> backward reductions
 // grid-stride over pixel rows; 256 threads = rows x C/4 column groups; LDS tree over rows; one
 // fp64 atomic per (block, channel, quantity).
+// One tile = up to 256 channel quads starting at quad `cbase` (C <= 1024 is a single tile; wider tensors, e.g. the 1152-channel
+// expansions of MNASNet, take several).
 template <int MODE>
-__device__ __forceinline__ void bn_reduce_body(const float* __restrict__ x, const float* __restrict__ dy,
+__device__ __forceinline__ void bn_reduce_tile(const float* __restrict__ x, const float* __restrict__ dy,
                                                const float* __restrict__ y, const float* __restrict__ mean_rstd,
-                                               int P, int C, int relu, double* __restrict__ acc) {
-    __shared__ float4 s0[256], s1[256];
-    const int C4 = C >> 2;
+                                               int P, int C, int relu, double* __restrict__ acc, int cbase, int C4,
+                                               float4* __restrict__ s0, float4* __restrict__ s1) {
     const int rows = 256 / C4;
     const int t = threadIdx.x;
-    const int col = t % C4, row = t / C4;
+    const int col = cbase + t % C4, row = t / C4;
     const bool active = row < rows;
     float4 a0 = f4(0.f), a1 = f4(0.f);
     float4 mu = f4(0.f), rs = f4(0.f);
@@ -88,8 +89,20 @@ __device__ __forceinline__ void bn_reduce_body(const float* __restrict__ x, cons
         // per-block partials (no atomics: deterministic, and 1024 blocks hammering 2C addresses was the
         // bottleneck of this kernel); reduced over blocks by bn_partial_sum_kernel
         float* a = reinterpret_cast<float*>(acc) + (long)blockIdx.x * 2 * C;
-        st4(a + 4 * t, r0);
-        st4(a + C + 4 * t, r1);
+        st4(a + 4 * (cbase + t), r0);
+        st4(a + C + 4 * (cbase + t), r1);
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void bn_reduce_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                               const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                               int P, int C, int relu, double* __restrict__ acc) {
+    __shared__ float4 s0[256], s1[256];
+    const int C4 = C >> 2;
+    for (int cbase = 0; cbase < C4; cbase += 256) {
+        const int width = C4 - cbase < 256 ? C4 - cbase : 256;
+        bn_reduce_tile<MODE>(x, dy, y, mean_rstd, P, C, relu, acc, cbase, width, s0, s1);
+        if (cbase + 256 < C4) __syncthreads();
     }
 }
 template <int MODE>
@@ -438,7 +451,7 @@ inline int ew_grid(long total) {
 }
 inline int red_grid(int P, int C) {
     // >= 16 pixel rows per thread before another workgroup is worth its partial-sum row; <= 512 workgroups
-    const int rows = 256 / (C >> 2);
+    const int rows = (C >> 2) >= 256 ? 1 : 256 / (C >> 2);
     long g = ((long)P + 16L * rows - 1) / (16L * rows);
     if (g > 512) g = 512;
     return (int)(g < 1 ? 1 : g);
@@ -448,12 +461,12 @@ inline int red_grid(int P, int C) {
 
 extern "C" {
 
-// Training-mode BatchNorm forward on NHWC x (P = N*H*W pixels, C channels, C % 4 == 0, C <= 1024).
+// Training-mode BatchNorm forward on NHWC x (P = N*H*W pixels, C channels, C % 4 == 0, C <= 4096).
 // ws: >= 2*C*258 doubles of scratch (sums + per-block partials).  mean_rstd (2C), scale_shift (2C) kept for backward.
 int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                 float* running_mean, float* running_var, float* mean_rstd, float* scale_shift, double* ws, int P, int C,
                 float eps, float momentum, int relu, void* stream) {
-    if (P <= 0 || C <= 0 || (C & 3) || C > 1024) return OMNI_ERR_ARG;
+    if (P <= 0 || C <= 0 || (C & 3) || C > 4096) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = red_grid(P, C);
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
@@ -472,7 +485,7 @@ int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const flo
 int omni_bn_fwd_partials(const float* x, const float* partial, int nblk, const float* gamma, const float* beta, const float* residual,
                          float* y, float* running_mean, float* running_var, float* mean_rstd, float* scale_shift, int P, int C,
                          float eps, float momentum, int relu, void* stream) {
-    if (P <= 0 || C <= 0 || (C & 3) || C > 1024 || nblk <= 0) return OMNI_ERR_ARG;
+    if (P <= 0 || C <= 0 || (C & 3) || C > 4096 || nblk <= 0) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, st, partial, nblk, P, C, eps, momentum, gamma, beta,
                        mean_rstd, scale_shift, running_mean, running_var);
@@ -496,7 +509,7 @@ int omni_bn_apply(const float* x, const float* scale_shift, const float* residua
 int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
                 float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C, int relu,
                 int accumulate_param_grads, void* stream) {
-    if (P <= 0 || C <= 0 || (C & 3) || C > 1024) return OMNI_ERR_ARG;
+    if (P <= 0 || C <= 0 || (C & 3) || C > 4096) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = red_grid(P, C);
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
@@ -603,7 +616,7 @@ int omni_relu_bwd(const float* dy, const float* y, float* dz, long long n, void*
 
 // db[c] = sum over the P pixels of dy[p, c] (bias gradient of a conv / linear).  ws: 2*C doubles.
 int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, int accumulate, void* stream) {
-    if (P <= 0 || C <= 0 || (C & 3) || C > 1024) return OMNI_ERR_ARG;
+    if (P <= 0 || C <= 0 || (C & 3) || C > 4096) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = red_grid(P, C);
     float* partial = reinterpret_cast<float*>(ws + 2 * C);

@@ -29,6 +29,17 @@ class Conv2d(nn.Conv2d):
         return HF.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu, want_stats)
 
 
+class DepthwiseConv2d(nn.Conv2d):
+    """nn.Conv2d(C, C, k, groups=C, bias=False) (torchvision mnasnet) on csrc/depthwise.hip; weight (C, 1, k, k)"""
+
+    def __init__(self, channels, kernel_size, stride=1, padding=0):
+        super().__init__(channels, channels, kernel_size, stride=stride, padding=padding, groups=channels, bias=False)
+        assert kernel_size in (3, 5) and stride in (1, 2)
+
+    def forward(self, x):
+        return HF.depthwise_conv2d(x, self.weight, self.stride[0], self.padding[0])
+
+
 class Linear(nn.Linear):
     def forward(self, x, relu=False):
         return HF.linear(x, self.weight, self.bias, relu)

@@ -261,6 +261,29 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, want_stats=False):
     return y
 
 
+class _DepthwiseConv2d(Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        x = _cl(x)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad)
+        return conv.dwconv_fwd(x, w, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        dy = _cl(dy)
+        dx = conv.dwconv_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad) if ctx.needs_input_grad[0] else None
+        dw = conv.dwconv_wgrad(x, dy, w.shape[2], stride, pad).contiguous() if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+def depthwise_conv2d(x, w, stride=1, pad=1):
+    """nn.Conv2d(C, C, k, stride, pad, groups=C, bias=False): w (C, 1, k, k)"""
+    return _DepthwiseConv2d.apply(x, w, stride, pad)
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, bias, relu, w_grad_view=None):

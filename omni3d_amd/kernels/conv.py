@@ -193,3 +193,41 @@ def stem_conv_wgrad(x, dy, R, accum_into=None):
     dw = torch.empty((K, R, R, C), dtype=torch.float32, device=x.device)
     L.call("omni_stem_conv_wgrad", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dw), N, H, W, C, K, R, C, K, 0, _lib.stream_of(x))
     return dw.permute(0, 3, 1, 2)
+
+
+# ---- depthwise convolution (csrc/depthwise.hip); weights cross as (R, R, C) tap-major ----------------------------------------------
+def _taps(w):
+    """(C, 1, R, R) parameter -> (R, R, C) contiguous (a few KB)"""
+    C, _, R, S = w.shape
+    return w.reshape(C, R, S).permute(1, 2, 0).contiguous()
+
+
+def dwconv_fwd(x, w, stride=1, pad=1):
+    xv, wt = _nhwc(x), _taps(w)
+    N, H, W, C = xv.shape
+    R = wt.shape[0]
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    L = _lib.check_device(xv, wt)
+    out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
+    L.call("omni_dwconv_fwd", _lib.ptr(xv), _lib.ptr(wt), _lib.ptr(out), N, H, W, C, R, stride, pad, _lib.stream_of(x))
+    return out.permute(0, 3, 1, 2)
+
+
+def dwconv_dgrad(dy, w, in_hw, stride=1, pad=1):
+    dyv, wt = _nhwc(dy), _taps(w)
+    N, _, _, C = dyv.shape
+    H, W = in_hw
+    L = _lib.check_device(dyv, wt)
+    dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+    L.call("omni_dwconv_dgrad", _lib.ptr(dyv), _lib.ptr(wt), _lib.ptr(dx), N, H, W, C, wt.shape[0], stride, pad, _lib.stream_of(dy))
+    return dx.permute(0, 3, 1, 2)
+
+
+def dwconv_wgrad(x, dy, R, stride=1, pad=1):
+    """-> dw in the parameter's shape (C, 1, R, R)"""
+    xv, dyv = _nhwc(x), _nhwc(dy)
+    N, H, W, C = xv.shape
+    L = _lib.check_device(xv, dyv)
+    dw = torch.empty((R, R, C), dtype=torch.float32, device=x.device)
+    L.call("omni_dwconv_wgrad", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, R, stride, pad, _lib.stream_of(x))
+    return dw.permute(2, 0, 1).reshape(C, 1, R, R)

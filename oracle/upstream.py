@@ -894,6 +894,63 @@ def tv_densenet121(pretrained=False):
     return TVDenseNet()
 
 
+# torchvision.models.mnasnet1_0 (cubercnn/modeling/backbone/mnasnet.py:2,14-15) -- un-vendored, restated from the published
+# architecture (Tan et al.; torchvision/models/mnasnet.py): depths [32, 16, 24, 40, 80, 96, 192, 320], inverted-residual stacks
+# (k3 s2 x3 x3), (k5 s2 x3 x3), (k5 s2 x6 x3), (k3 s1 x6 x2), (k5 s2 x6 x4), (k3 s1 x6 x1), BN momentum 1 - 0.9997.
+# Its parameter count reproduces torchvision's published 4 383 312; beyond that PARITY UNPINNED (no torchvision binary here).
+_MNAS_BN_MOMENTUM = 1 - 0.9997
+
+
+class TVInvertedResidual(nn.Module):
+    def __init__(self, in_ch, out_ch, kernel_size, stride, expansion_factor, bn_momentum=0.1):
+        super().__init__()
+        mid_ch = in_ch * expansion_factor
+        self.apply_residual = in_ch == out_ch and stride == 1
+        self.layers = nn.Sequential(
+            nn.Conv2d(in_ch, mid_ch, 1, bias=False), nn.BatchNorm2d(mid_ch, momentum=bn_momentum), nn.ReLU(inplace=True),
+            nn.Conv2d(mid_ch, mid_ch, kernel_size, padding=kernel_size // 2, stride=stride, groups=mid_ch, bias=False),
+            nn.BatchNorm2d(mid_ch, momentum=bn_momentum), nn.ReLU(inplace=True),
+            nn.Conv2d(mid_ch, out_ch, 1, bias=False), nn.BatchNorm2d(out_ch, momentum=bn_momentum))
+
+    def forward(self, input):
+        return self.layers(input) + input if self.apply_residual else self.layers(input)
+
+
+def _tv_mnas_stack(in_ch, out_ch, kernel_size, stride, exp_factor, repeats, bn_momentum):
+    first = TVInvertedResidual(in_ch, out_ch, kernel_size, stride, exp_factor, bn_momentum=bn_momentum)
+    rest = [TVInvertedResidual(out_ch, out_ch, kernel_size, 1, exp_factor, bn_momentum=bn_momentum) for _ in range(1, repeats)]
+    return nn.Sequential(first, *rest)
+
+
+class TVMNASNet(nn.Module):
+    def __init__(self, num_classes=1000, dropout=0.2):
+        super().__init__()
+        d, m = [32, 16, 24, 40, 80, 96, 192, 320], _MNAS_BN_MOMENTUM
+        self.layers = nn.Sequential(
+            nn.Conv2d(3, d[0], 3, padding=1, stride=2, bias=False), nn.BatchNorm2d(d[0], momentum=m), nn.ReLU(inplace=True),
+            nn.Conv2d(d[0], d[0], 3, padding=1, stride=1, groups=d[0], bias=False), nn.BatchNorm2d(d[0], momentum=m), nn.ReLU(inplace=True),
+            nn.Conv2d(d[0], d[1], 1, padding=0, stride=1, bias=False), nn.BatchNorm2d(d[1], momentum=m),
+            _tv_mnas_stack(d[1], d[2], 3, 2, 3, 3, m), _tv_mnas_stack(d[2], d[3], 5, 2, 3, 3, m), _tv_mnas_stack(d[3], d[4], 5, 2, 6, 3, m),
+            _tv_mnas_stack(d[4], d[5], 3, 1, 6, 2, m), _tv_mnas_stack(d[5], d[6], 5, 2, 6, 4, m), _tv_mnas_stack(d[6], d[7], 3, 1, 6, 1, m),
+            nn.Conv2d(d[7], 1280, 1, padding=0, stride=1, bias=False), nn.BatchNorm2d(1280, momentum=m), nn.ReLU(inplace=True))
+        self.classifier = nn.Sequential(nn.Dropout(p=dropout, inplace=True), nn.Linear(1280, num_classes))
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(mod.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(mod, nn.BatchNorm2d):
+                nn.init.ones_(mod.weight)
+                nn.init.zeros_(mod.bias)
+            elif isinstance(mod, nn.Linear):
+                nn.init.kaiming_uniform_(mod.weight, mode="fan_out", nonlinearity="sigmoid")
+                nn.init.zeros_(mod.bias)
+
+
+def tv_mnasnet1_0(pretrained=False):
+    if pretrained:
+        raise RuntimeError("ImageNet weights are a network download (torchvision); set MODEL.WEIGHTS")
+    return TVMNASNet()
+
+
 def build_resnet_backbone(cfg, input_shape):
     raise NotImplementedError("MSRA ResNet (MODEL.RESNETS.TORCHVISION False) is outside the restated surface")
 
