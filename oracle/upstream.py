@@ -951,6 +951,60 @@ def tv_mnasnet1_0(pretrained=False):
     return TVMNASNet()
 
 
+# torchvision.models.shufflenet_v2_x1_0 (cubercnn/modeling/backbone/shufflenet.py:2,14-20) -- un-vendored, restated from the
+# published architecture (Ma et al.; torchvision/models/shufflenetv2.py): repeats [4, 8, 4], channels [24, 116, 232, 464, 1024],
+# PyTorch default initialisation.  Its parameter count reproduces torchvision's published 2 278 604; beyond that PARITY UNPINNED.
+def tv_channel_shuffle(x, groups):
+    batchsize, num_channels, height, width = x.size()
+    x = x.view(batchsize, groups, num_channels // groups, height, width)
+    x = torch.transpose(x, 1, 2).contiguous()
+    return x.view(batchsize, -1, height, width)
+
+
+class TVShuffleUnit(nn.Module):
+    def __init__(self, inp, oup, stride):
+        super().__init__()
+        self.stride = stride
+        bf = oup // 2
+        dw = lambda c, s: nn.Conv2d(c, c, 3, s, 1, bias=False, groups=c)      # noqa: E731
+        if stride > 1:
+            self.branch1 = nn.Sequential(dw(inp, stride), nn.BatchNorm2d(inp), nn.Conv2d(inp, bf, 1, 1, 0, bias=False), nn.BatchNorm2d(bf),
+                                         nn.ReLU(inplace=True))
+        else:
+            self.branch1 = nn.Sequential()
+        self.branch2 = nn.Sequential(nn.Conv2d(inp if stride > 1 else bf, bf, 1, 1, 0, bias=False), nn.BatchNorm2d(bf), nn.ReLU(inplace=True),
+                                     dw(bf, stride), nn.BatchNorm2d(bf), nn.Conv2d(bf, bf, 1, 1, 0, bias=False), nn.BatchNorm2d(bf),
+                                     nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        if self.stride == 1:
+            x1, x2 = x.chunk(2, dim=1)
+            out = torch.cat((x1, self.branch2(x2)), dim=1)
+        else:
+            out = torch.cat((self.branch1(x), self.branch2(x)), dim=1)
+        return tv_channel_shuffle(out, 2)
+
+
+class TVShuffleNetV2(nn.Module):
+    def __init__(self, stages_repeats=(4, 8, 4), stages_out_channels=(24, 116, 232, 464, 1024), num_classes=1000):
+        super().__init__()
+        c = stages_out_channels[0]
+        self.conv1 = nn.Sequential(nn.Conv2d(3, c, 3, 2, 1, bias=False), nn.BatchNorm2d(c), nn.ReLU(inplace=True))
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        for name, repeats, out in zip(("stage2", "stage3", "stage4"), stages_repeats, stages_out_channels[1:]):
+            setattr(self, name, nn.Sequential(TVShuffleUnit(c, out, 2), *[TVShuffleUnit(out, out, 1) for _ in range(repeats - 1)]))
+            c = out
+        out = stages_out_channels[-1]
+        self.conv5 = nn.Sequential(nn.Conv2d(c, out, 1, 1, 0, bias=False), nn.BatchNorm2d(out), nn.ReLU(inplace=True))
+        self.fc = nn.Linear(out, num_classes)
+
+
+def tv_shufflenet_v2_x1_0(pretrained=False):
+    if pretrained:
+        raise RuntimeError("ImageNet weights are a network download (torchvision); set MODEL.WEIGHTS")
+    return TVShuffleNetV2()
+
+
 def build_resnet_backbone(cfg, input_shape):
     raise NotImplementedError("MSRA ResNet (MODEL.RESNETS.TORCHVISION False) is outside the restated surface")
 
