@@ -98,6 +98,16 @@ int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* ga
 int omni_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int omni_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 
+/* Grouped convolution `nn.Conv2d(C, K, R, stride, pad, groups=G, bias=False)` of DLA's BottleneckX (cubercnn/modeling/backbone/
+ * dla.py:112-153): x (N,H,W,C), w (K,R,S,C/G), out / dy (N,OH,OW,K); C/G and K/G multiples of 4.  One launch of the implicit-GEMM
+ * kernels per group on channel slices (pixel pitch C / K). */
+int omni_grouped_conv2d_fwd(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int S, int stride,
+                            int pad, int groups, void* stream);
+int omni_grouped_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S, int stride,
+                              int pad, int groups, void* stream);
+int omni_grouped_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int stride,
+                              int pad, int groups, void* stream);
+
 /* Depthwise convolution `nn.Conv2d(C, C, R, padding=pad, stride=stride, groups=C, bias=False)` of torchvision's mnasnet1_0
  * (lifted by cubercnn/modeling/backbone/mnasnet.py:14-17): R in {3, 5}, stride in {1, 2}; x (N,H,W,C), w (R,R,C) tap-major,
  * y / dy (N,OH,OW,C), dw (R,R,C) overwritten. */

@@ -988,4 +988,45 @@ int omni_gemm_batched_wgrad(const float* x, const float* dy, float* dw, int batc
     return omni_launch_status();
 }
 
+// ---- grouped convolution: nn.Conv2d(C, K, R, stride, pad, groups=G, bias=False), the 3x3 of DLA's BottleneckX
+// (cubercnn/modeling/backbone/dla.py:112-153; 32 or 64 groups of 4..32 channels).  The G independent convolutions read / write
+// channel slices of the same NHWC tensors: the implicit-GEMM kernels already take the pixel pitch (ldx / ldo) separately from
+// the channel count, so every group is one launch of them on offset pointers; w (K, R, S, C/G) keeps a group's filters contiguous.
+int omni_grouped_conv2d_fwd(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int S, int stride,
+                            int pad, int groups, void* stream) {
+    if (groups <= 0 || C % groups || K % groups || ((C / groups) & 3) || ((K / groups) & 3)) return OMNI_ERR_ARG;
+    const int Cg = C / groups, Kg = K / groups;
+    for (int g = 0; g < groups; ++g) {
+        const int rc = conv2d_fwd_impl(x + g * Cg, w + (size_t)g * Kg * R * S * Cg, nullptr, out + g * Kg, N, H, W, Cg, Kg, R, S, stride,
+                                       pad, C, K, 0, 0, 0, nullptr, 0, nullptr, stream);
+        if (rc != OMNI_OK) return rc;
+    }
+    return OMNI_OK;
+}
+
+int omni_grouped_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S, int stride,
+                              int pad, int groups, void* stream) {
+    if (groups <= 0 || C % groups || K % groups || ((C / groups) & 3) || ((K / groups) & 3)) return OMNI_ERR_ARG;
+    const int Cg = C / groups, Kg = K / groups;
+    for (int g = 0; g < groups; ++g) {
+        const int rc = omni_conv2d_dgrad_algo(dy + g * Kg, w + (size_t)g * Kg * R * S * Cg, dx + g * Cg, N, H, W, Cg, Kg, R, S, stride, pad,
+                                              K, C, 0, 0, 0, stream);
+        if (rc != OMNI_OK) return rc;
+    }
+    return OMNI_OK;
+}
+
+// dw (K, R, S, C/G) overwritten
+int omni_grouped_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int stride,
+                              int pad, int groups, void* stream) {
+    if (groups <= 0 || C % groups || K % groups || ((C / groups) & 3) || ((K / groups) & 3)) return OMNI_ERR_ARG;
+    const int Cg = C / groups, Kg = K / groups;
+    for (int g = 0; g < groups; ++g) {
+        const int rc = omni_conv2d_wgrad_algo(x + g * Cg, dy + g * Kg, dw + (size_t)g * Kg * R * S * Cg, N, H, W, Cg, Kg, R, S, stride, pad,
+                                              C, K, 0, 0, stream);
+        if (rc != OMNI_OK) return rc;
+    }
+    return OMNI_OK;
+}
+
 }  // extern "C"

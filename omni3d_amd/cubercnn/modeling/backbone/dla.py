@@ -1,17 +1,19 @@
-"""DLA-34 bottom-up + FPN builder (`build_dla_from_vision_fpn_backbone`).
+"""DLA bottom-up + FPN builder (`build_dla_from_vision_fpn_backbone`).
 
 Same topology, module names (=> state-dict keys of SURVEY.md Appendix C) and initialisation as
-/root/reference/cubercnn/modeling/backbone/dla.py (BasicBlock :40-68, Root :156-174, Tree :177-230,
-DLA :233-297, dla34 :312-321, DLABackbone :417-482, builder :484-507), restricted to the dla34
-variant of BASELINE.json.  Every conv is the implicit-GEMM MFMA kernel, every BN(+ReLU)(+residual)
-one fused HBM-bound kernel pair; the image enters as NHWC with C padded 3 -> 4."""
+/root/reference/cubercnn/modeling/backbone/dla.py (BasicBlock :40-68, Bottleneck :71-109, Root :156-174, Tree :177-230,
+DLA :233-297, variants :312-414, DLABackbone :417-482, builder :484-507): dla34 (BASELINE.json), the Bottleneck
+variants dla46_c, dla60, dla102, dla169 and the BottleneckX (grouped 3x3) variants dla60x, dla102x, dla102x2 of
+MODEL.DLA.TYPE; dla46x_c / dla60x_c have 2 channels per group, below the 4-channel lanes of the kernels, and raise.
+Every conv is the implicit-GEMM MFMA kernel, every BN(+ReLU)(+residual) one fused HBM-bound kernel pair; the image
+enters as NHWC with C padded 3 -> 4."""
 import math
 
 import torch
 from torch import nn
 
 from .... import functional as HF
-from ..layers import BatchNorm2d, Conv2d
+from ..layers import BatchNorm2d, Conv2d, GroupedConv2d
 from ..registries import BACKBONE_REGISTRY
 from .fpn import FPN, Backbone
 
@@ -46,6 +48,57 @@ class BasicBlock(nn.Module):
             residual = x
         out = self.bn1(self.conv1(x), relu=True)
         return self.bn2(self.conv2(out), residual=residual, relu=True)
+
+
+class Bottleneck(nn.Module):
+    """dla.py:71-109: 1x1 (planes / 2) - 3x3 (stride) - 1x1, BN after each, the Tree's residual added before the last ReLU"""
+    expansion = 2
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1):
+        super().__init__()
+        bottle = planes // Bottleneck.expansion
+        self.conv1 = Conv2d(inplanes, bottle, kernel_size=1, bias=False)
+        self.bn1 = BatchNorm2d(bottle)
+        self.conv2 = Conv2d(bottle, bottle, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(bottle)
+        self.conv3 = Conv2d(bottle, planes, kernel_size=1, bias=False)
+        self.bn3 = BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.stride = stride
+
+    def forward(self, x, residual=None):
+        if residual is None:
+            residual = x
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), residual=residual, relu=True)
+
+
+def bottleneck_x(cardinality):
+    """dla.py:112-153: Bottleneck whose 3x3 is grouped (`cardinality` groups) over planes * cardinality / 32 channels"""
+
+    class BottleneckX(nn.Module):
+        expansion = 2
+
+        def __init__(self, inplanes, planes, stride=1, dilation=1):
+            super().__init__()
+            bottle = planes * cardinality // 32
+            self.conv1 = Conv2d(inplanes, bottle, kernel_size=1, bias=False)
+            self.bn1 = BatchNorm2d(bottle)
+            self.conv2 = GroupedConv2d(bottle, bottle, 3, stride=stride, padding=1, groups=cardinality)
+            self.bn2 = BatchNorm2d(bottle)
+            self.conv3 = Conv2d(bottle, planes, kernel_size=1, bias=False)
+            self.bn3 = BatchNorm2d(planes)
+            self.relu = nn.ReLU(inplace=True)
+            self.stride = stride
+
+        def forward(self, x, residual=None):
+            if residual is None:
+                residual = x
+            out = self.bn1(self.conv1(x), relu=True)
+            out = self.bn2(self.conv2(out), relu=True)
+            return self.bn3(self.conv3(out), residual=residual, relu=True)
+    return BottleneckX
 
 
 class Root(nn.Module):
@@ -126,20 +179,44 @@ class DLA(nn.Module):
                 m.bias.data.zero_()
 
 
-def dla34(pretrained=False, tricks=False):
+# MODEL.DLA.TYPE -> (levels, channels, block, residual_root, output channels p2..p6)   (dla.py:312-414, 421-450)
+_WIDE = {"p2": 128, "p3": 256, "p4": 512, "p5": 1024, "p6": 1024}
+DLA_VARIANTS = {
+    "dla34": ([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], BasicBlock, False, {"p2": 64, "p3": 128, "p4": 256, "p5": 512, "p6": 512}),
+    "dla46_c": ([1, 1, 1, 2, 2, 1], [16, 32, 64, 64, 128, 256], Bottleneck, False, {"p2": 64, "p3": 64, "p4": 128, "p5": 256, "p6": 256}),
+    "dla60": ([1, 1, 1, 2, 3, 1], [16, 32, 128, 256, 512, 1024], Bottleneck, False, _WIDE),
+    "dla102": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], Bottleneck, True, _WIDE),
+    "dla169": ([1, 1, 2, 3, 5, 1], [16, 32, 128, 256, 512, 1024], Bottleneck, True, _WIDE),
+    "dla60x": ([1, 1, 1, 2, 3, 1], [16, 32, 128, 256, 512, 1024], bottleneck_x(32), False, _WIDE),
+    "dla102x": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], bottleneck_x(32), True, _WIDE),
+    "dla102x2": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], bottleneck_x(64), True, _WIDE),
+}
+_GROUPED = ("dla46x_c", "dla60x_c")
+
+
+def build_dla(name, pretrained=False):
     if pretrained:
         raise RuntimeError("ImageNet DLA weights are downloaded by the reference (dla.py:300-309); there is no network "
                            "here -- set MODEL.WEIGHTS / MODEL.WEIGHTS_PRETRAIN or load a state dict")
-    return DLA([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], block=BasicBlock)
+    levels, channels, block, residual_root, _ = DLA_VARIANTS[name]
+    return DLA(levels, channels, block=block, residual_root=residual_root)
+
+
+def dla34(pretrained=False, tricks=False):
+    return build_dla("dla34", pretrained)
 
 
 class DLABackbone(Backbone):
     def __init__(self, cfg, input_shape, pretrained=True):
         super().__init__()
-        if cfg.MODEL.DLA.TYPE != "dla34":
-            raise ValueError(f"DLA type {cfg.MODEL.DLA.TYPE} is outside the MI355X hot path (dla34 only)")
-        base = dla34(pretrained=pretrained, tricks=cfg.MODEL.DLA.TRICKS)
-        self._out_feature_channels = {"p2": 64, "p3": 128, "p4": 256, "p5": 512, "p6": 512}
+        kind = cfg.MODEL.DLA.TYPE
+        if kind in _GROUPED:
+            raise NotImplementedError(f"MODEL.DLA.TYPE {kind}: its grouped 3x3 convolutions have 2 channels per group (dla.py:112-153, "
+                                      f"334-351), below the 4-channel lanes of the kernels; built: {sorted(DLA_VARIANTS)}")
+        if kind not in DLA_VARIANTS:
+            raise ValueError(f"unknown MODEL.DLA.TYPE {kind}")
+        base = build_dla(kind, pretrained=pretrained)
+        self._out_feature_channels = dict(DLA_VARIANTS[kind][4])
         for name in ("base_layer", "level0", "level1", "level2", "level3", "level4", "level5"):
             setattr(self, name, getattr(base, name))
         self._out_feature_strides = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}

@@ -1,4 +1,4 @@
-"""torchvision-style ResNet-18/34 bottom-up + FPN builder (`build_resnet_from_vision_fpn_backbone`).
+"""torchvision-style ResNet-18/34/50/101 bottom-up + FPN builder (`build_resnet_from_vision_fpn_backbone`).
 
 Mirrors /root/reference/cubercnn/modeling/backbone/resnet.py (ResNet wrapper :12-65, builder :68-96):
 the wrapper lifts conv1/bn1/maxpool/layer1..4 out of `torchvision.models.resnet{18,34}` (module names,
@@ -6,8 +6,8 @@ hence state-dict keys, `layerL.B.{conv1,bn1,conv2,bn2,downsample.0,downsample.1}
 p6 = max_pool2d(p5, k=1, s=2), and wraps it in FPN(top_block=LastLevelMaxPool()).  torchvision is not
 a dependency here: the BasicBlock topology / initialisation is restated on the HIP kernels (7x7/s2 stem
 conv and all 3x3 / 1x1 convs = implicit-GEMM MFMA kernel, BN+ReLU(+residual) fused, 3x3/s2 max-pool =
-csrc/pool3.hip).  Depth 50/101 (Bottleneck) are outside the hot path of BASELINE.json (configs[3] is
-ResNet-34)."""
+csrc/pool3.hip).  Depths 50 / 101 use torchvision's Bottleneck (1x1 - 3x3 with the stride - 1x1 x 4, `layerL.B.{conv1..3,bn1..3}`;
+BASELINE.json's configs[3] is ResNet-34)."""
 import torch
 from torch import nn
 
@@ -44,9 +44,32 @@ class BasicBlock(nn.Module):
         return self.bn2(self.conv2(out), residual=identity, relu=True)
 
 
-class TorchvisionResNet(nn.Module):
-    def __init__(self, layers):
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, kernel_size=1, stride=1, bias=False)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = Conv2d(planes, planes * self.expansion, kernel_size=1, stride=1, bias=False)
+        self.bn3 = BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), residual=identity, relu=True)
+
+
+class TorchvisionResNet(nn.Module):
+    def __init__(self, layers, block=BasicBlock):
+        super().__init__()
+        self.block = block
         self.inplanes = 64
         self.conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = BatchNorm2d(64)
@@ -65,16 +88,16 @@ class TorchvisionResNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def _make_layer(self, planes, blocks, stride):
-        downsample = None
-        if stride != 1 or self.inplanes != planes:
-            downsample = Downsample(self.inplanes, planes, stride)
-        layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes
-        layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+        block, downsample = self.block, None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = Downsample(self.inplanes, planes * block.expansion, stride)
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
 
-_DEPTHS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+_DEPTHS = {18: ([2, 2, 2, 2], BasicBlock), 34: ([3, 4, 6, 3], BasicBlock), 50: ([3, 4, 6, 3], Bottleneck), 101: ([3, 4, 23, 3], Bottleneck)}
 
 
 class ResNet(Backbone):
@@ -82,14 +105,14 @@ class ResNet(Backbone):
         super().__init__()
         depth = cfg.MODEL.RESNETS.DEPTH
         if depth not in _DEPTHS:
-            if depth in (50, 101):
-                raise ValueError(f"ResNet-{depth} (Bottleneck) is outside the MI355X hot path (BasicBlock depths 18 / 34 only)")
             raise ValueError("No configuration currently supporting depth of {}".format(depth))
         if pretrained:
             raise RuntimeError("ImageNet ResNet weights are downloaded by the reference via torchvision (resnet.py:16-20); there is "
                                "no network here -- set MODEL.WEIGHTS / MODEL.WEIGHTS_PRETRAIN or load a state dict")
-        base = TorchvisionResNet(_DEPTHS[depth])
-        self._out_feature_channels = {"p2": 64, "p3": 128, "p4": 256, "p5": 512, "p6": 512}
+        layers, block = _DEPTHS[depth]
+        base = TorchvisionResNet(layers, block)
+        e = block.expansion
+        self._out_feature_channels = {"p2": 64 * e, "p3": 128 * e, "p4": 256 * e, "p5": 512 * e, "p6": 512 * e}
         for name in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4"):
             setattr(self, name, getattr(base, name))
         self._out_feature_strides = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}

@@ -29,6 +29,24 @@ class Conv2d(nn.Conv2d):
         return HF.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu, want_stats)
 
 
+class GroupedConv2d(nn.Conv2d):
+    """nn.Conv2d(C, K, k, groups=G, bias=False) (DLA BottleneckX): weight (K, C/G, k, k) in channels_last memory"""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, groups=1):
+        super().__init__(cin, cout, kernel_size, stride=stride, padding=padding, groups=groups, bias=False)
+        if (cin // groups) % 4 or (cout // groups) % 4:
+            raise NotImplementedError(f"grouped convolution with {cin // groups} -> {cout // groups} channels per group: the kernels move "
+                                      "4 channels per lane")
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+
+    def forward(self, x):
+        return HF.grouped_conv2d(x, self.weight, self.groups, self.stride[0], self.padding[0])
+
+
 class DepthwiseConv2d(nn.Conv2d):
     """nn.Conv2d(C, C, k, groups=C, bias=False) (torchvision mnasnet) on csrc/depthwise.hip; weight (C, 1, k, k)"""
 

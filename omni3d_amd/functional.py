@@ -261,6 +261,29 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, want_stats=False):
     return y
 
 
+class _GroupedConv2d(Function):
+    @staticmethod
+    def forward(ctx, x, w, groups, stride, pad):
+        x, w = _cl(x), _cl(w)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (groups, stride, pad)
+        return conv.grouped_conv2d_fwd(x, w, groups, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        groups, stride, pad = ctx.cfg
+        dy = _cl(dy)
+        dx = conv.grouped_conv2d_dgrad(dy, w, groups, (x.shape[2], x.shape[3]), stride, pad) if ctx.needs_input_grad[0] else None
+        dw = conv.grouped_conv2d_wgrad(x, dy, groups, (w.shape[2], w.shape[3]), stride, pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None, None
+
+
+def grouped_conv2d(x, w, groups, stride=1, pad=0):
+    """nn.Conv2d(C, K, k, stride, pad, groups=groups, bias=False): w (K, C / groups, k, k)"""
+    return _GroupedConv2d.apply(x, w, groups, stride, pad)
+
+
 class _DepthwiseConv2d(Function):
     @staticmethod
     def forward(ctx, x, w, stride, pad):

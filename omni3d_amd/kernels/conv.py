@@ -231,3 +231,40 @@ def dwconv_wgrad(x, dy, R, stride=1, pad=1):
     dw = torch.empty((R, R, C), dtype=torch.float32, device=x.device)
     L.call("omni_dwconv_wgrad", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, R, stride, pad, _lib.stream_of(x))
     return dw.permute(2, 0, 1).reshape(C, 1, R, R)
+
+
+# ---- grouped convolution (one implicit-GEMM launch per group on channel slices) ----------------------------------------------------
+def grouped_conv2d_fwd(x, w, groups, stride=1, pad=0):
+    """x (N,C,H,W) CL, w (K, C/groups, R, S) CL -> y (N,K,OH,OW) CL"""
+    xv, wv = _nhwc(x), _nhwc(w)
+    N, H, W, C = xv.shape
+    K, R, S, Cg = wv.shape
+    assert Cg * groups == C, (C, Cg, groups)
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    L = _lib.check_device(xv, wv)
+    out = torch.empty((N, OH, OW, K), dtype=torch.float32, device=x.device)
+    L.call("omni_grouped_conv2d_fwd", _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(out), N, H, W, C, K, R, S, stride, pad, groups, _lib.stream_of(x))
+    return out.permute(0, 3, 1, 2)
+
+
+def grouped_conv2d_dgrad(dy, w, groups, in_hw, stride=1, pad=0):
+    dyv, wv = _nhwc(dy), _nhwc(w)
+    N, _, _, K = dyv.shape
+    _, R, S, Cg = wv.shape
+    H, W = in_hw
+    L = _lib.check_device(dyv, wv)
+    dx = torch.empty((N, H, W, Cg * groups), dtype=torch.float32, device=dy.device)
+    L.call("omni_grouped_conv2d_dgrad", _lib.ptr(dyv), _lib.ptr(wv), _lib.ptr(dx), N, H, W, Cg * groups, K, R, S, stride, pad, groups,
+           _lib.stream_of(dy))
+    return dx.permute(0, 3, 1, 2)
+
+
+def grouped_conv2d_wgrad(x, dy, groups, ksize, stride=1, pad=0):
+    xv, dyv = _nhwc(x), _nhwc(dy)
+    N, H, W, C = xv.shape
+    K = dyv.shape[3]
+    R, S = ksize
+    L = _lib.check_device(xv, dyv)
+    dw = torch.empty((K, R, S, C // groups), dtype=torch.float32, device=x.device)
+    L.call("omni_grouped_conv2d_wgrad", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, K, R, S, stride, pad, groups, _lib.stream_of(x))
+    return dw.permute(0, 3, 1, 2)

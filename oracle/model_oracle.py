@@ -33,28 +33,72 @@ class BasicBlock(nn.Module):
         return F.relu(self.bn2(self.conv2(out)) + residual)
 
 
+class Bottleneck(nn.Module):
+    """dla.py:71-109 (expansion 2)"""
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__()
+        mid = cout // 2
+        self.conv1 = nn.Conv2d(cin, mid, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(mid)
+        self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(mid)
+        self.conv3 = nn.Conv2d(mid, cout, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+
+    def forward(self, x, residual=None):
+        residual = x if residual is None else residual
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = F.relu(self.bn2(self.conv2(out)))
+        return F.relu(self.bn3(self.conv3(out)) + residual)
+
+
+def bottleneck_x(cardinality):
+    """dla.py:112-153 (cardinality 32; dla102x2 sets 64)"""
+
+    class BottleneckX(nn.Module):
+        def __init__(self, cin, cout, stride=1):
+            super().__init__()
+            mid = cout * cardinality // 32
+            self.conv1 = nn.Conv2d(cin, mid, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(mid)
+            self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, bias=False, groups=cardinality)
+            self.bn2 = nn.BatchNorm2d(mid)
+            self.conv3 = nn.Conv2d(mid, cout, 1, bias=False)
+            self.bn3 = nn.BatchNorm2d(cout)
+
+        def forward(self, x, residual=None):
+            residual = x if residual is None else residual
+            out = F.relu(self.bn1(self.conv1(x)))
+            out = F.relu(self.bn2(self.conv2(out)))
+            return F.relu(self.bn3(self.conv3(out)) + residual)
+    return BottleneckX
+
+
 class Root(nn.Module):
-    def __init__(self, cin, cout):
+    def __init__(self, cin, cout, residual=False):
         super().__init__()
         self.conv = nn.Conv2d(cin, cout, 1, bias=False)
         self.bn = nn.BatchNorm2d(cout)
+        self.residual = residual
 
     def forward(self, *x):
-        return F.relu(self.bn(self.conv(torch.cat(x, 1))))
+        y = self.bn(self.conv(torch.cat(x, 1)))
+        return F.relu(y + x[0] if self.residual else y)
 
 
 class Tree(nn.Module):
-    def __init__(self, levels, cin, cout, stride=1, level_root=False, root_dim=0):
+    def __init__(self, levels, cin, cout, stride=1, level_root=False, root_dim=0, block=BasicBlock, root_residual=False):
         super().__init__()
         root_dim = 2 * cout if root_dim == 0 else root_dim
         if level_root:
             root_dim += cin
         if levels == 1:
-            self.tree1, self.tree2 = BasicBlock(cin, cout, stride), BasicBlock(cout, cout, 1)
-            self.root = Root(root_dim, cout)
+            self.tree1, self.tree2 = block(cin, cout, stride), block(cout, cout, 1)
+            self.root = Root(root_dim, cout, root_residual)
         else:
-            self.tree1 = Tree(levels - 1, cin, cout, stride, root_dim=0)
-            self.tree2 = Tree(levels - 1, cout, cout, root_dim=root_dim + cout)
+            self.tree1 = Tree(levels - 1, cin, cout, stride, root_dim=0, block=block, root_residual=root_residual)
+            self.tree2 = Tree(levels - 1, cout, cout, root_dim=root_dim + cout, block=block, root_residual=root_residual)
         self.level_root, self.levels, self.stride = level_root, levels, stride
         self.project = nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout)) if cin != cout else None
 
@@ -71,19 +115,36 @@ class Tree(nn.Module):
         return self.tree2(x1, children=children)
 
 
+# MODEL.DLA.TYPE -> (levels, channels, block, residual_root)   (dla.py:312-414; dla102x2 = BottleneckX with cardinality 64)
+DLA_VARIANTS = {
+    "dla34": ([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], BasicBlock, False),
+    "dla46_c": ([1, 1, 1, 2, 2, 1], [16, 32, 64, 64, 128, 256], Bottleneck, False),
+    "dla60": ([1, 1, 1, 2, 3, 1], [16, 32, 128, 256, 512, 1024], Bottleneck, False),
+    "dla102": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], Bottleneck, True),
+    "dla169": ([1, 1, 2, 3, 5, 1], [16, 32, 128, 256, 512, 1024], Bottleneck, True),
+    "dla46x_c": ([1, 1, 1, 2, 2, 1], [16, 32, 64, 64, 128, 256], bottleneck_x(32), False),
+    "dla60x_c": ([1, 1, 1, 2, 3, 1], [16, 32, 64, 64, 128, 256], bottleneck_x(32), False),
+    "dla60x": ([1, 1, 1, 2, 3, 1], [16, 32, 128, 256, 512, 1024], bottleneck_x(32), False),
+    "dla102x": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], bottleneck_x(32), True),
+    "dla102x2": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], bottleneck_x(64), True),
+}
+
+
 class DLA34(U.Backbone):
-    def __init__(self):
+    """DLABackbone (dla.py:417-482) of any non-grouped MODEL.DLA.TYPE; the default is the dla34 of BASELINE.json"""
+
+    def __init__(self, variant="dla34"):
         super().__init__()
-        c = [16, 32, 64, 128, 256, 512]
+        lv, c, block, rr = DLA_VARIANTS[variant]
 
         def cbr(cin, cout, k, s, p):
             return nn.Sequential(nn.Conv2d(cin, cout, k, s, p, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
         self.base_layer, self.level0, self.level1 = cbr(3, c[0], 7, 1, 3), cbr(c[0], c[0], 3, 1, 1), cbr(c[0], c[1], 3, 2, 1)
-        self.level2 = Tree(1, c[1], c[2], 2, level_root=False)
-        self.level3 = Tree(2, c[2], c[3], 2, level_root=True)
-        self.level4 = Tree(2, c[3], c[4], 2, level_root=True)
-        self.level5 = Tree(1, c[4], c[5], 2, level_root=True)
-        self._out_feature_channels = {"p2": 64, "p3": 128, "p4": 256, "p5": 512, "p6": 512}
+        self.level2 = Tree(lv[2], c[1], c[2], 2, level_root=False, block=block, root_residual=rr)
+        self.level3 = Tree(lv[3], c[2], c[3], 2, level_root=True, block=block, root_residual=rr)
+        self.level4 = Tree(lv[4], c[3], c[4], 2, level_root=True, block=block, root_residual=rr)
+        self.level5 = Tree(lv[5], c[4], c[5], 2, level_root=True, block=block, root_residual=rr)
+        self._out_feature_channels = {"p2": c[2], "p3": c[3], "p4": c[4], "p5": c[5], "p6": c[5]}
         self._out_feature_strides = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
         self._out_features = ["p2", "p3", "p4", "p5", "p6"]
 
@@ -99,12 +160,13 @@ class DLA34(U.Backbone):
 class ResNet34(U.Backbone):
     """cubercnn/modeling/backbone/resnet.py:12-65 over the restated torchvision resnet34 (oracle/upstream.py)."""
 
-    def __init__(self):
+    def __init__(self, depth=34):
         super().__init__()
-        base = U.tv_resnet34(False)
+        base = {18: U.tv_resnet18, 34: U.tv_resnet34, 50: U.tv_resnet50, 101: U.tv_resnet101}[depth](False)
         for name in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4"):
             setattr(self, name, getattr(base, name))
-        self._out_feature_channels = {"p2": 64, "p3": 128, "p4": 256, "p5": 512, "p6": 512}
+        e = base.block.expansion
+        self._out_feature_channels = {"p2": 64 * e, "p3": 128 * e, "p4": 256 * e, "p5": 512 * e, "p6": 512 * e}
         self._out_feature_strides = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
         self._out_features = ["p2", "p3", "p4", "p5", "p6"]
 

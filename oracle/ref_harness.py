@@ -122,7 +122,7 @@ def install():
     _mod("detectron2.modeling.backbone.build", BACKBONE_REGISTRY=U.BACKBONE_REGISTRY)
     _mod("detectron2.modeling.backbone.fpn", FPN=U.FPN, LastLevelMaxPool=U.LastLevelMaxPool)
     _mod("detectron2.modeling.backbone.resnet", build_resnet_backbone=U.build_resnet_backbone)
-    _mod("torchvision.models", resnet18=U.tv_resnet18, resnet34=U.tv_resnet34, densenet121=U.tv_densenet121,
+    _mod("torchvision.models", resnet18=U.tv_resnet18, resnet34=U.tv_resnet34, resnet50=U.tv_resnet50, resnet101=U.tv_resnet101, densenet121=U.tv_densenet121,
          mnasnet1_0=U.tv_mnasnet1_0, shufflenet_v2_x1_0=U.tv_shufflenet_v2_x1_0)
     _mod("detectron2.modeling.proposal_generator", RPN=U.RPN, build_proposal_generator=U.build_proposal_generator)
     _mod("detectron2.modeling.proposal_generator.proposal_utils", add_ground_truth_to_proposals=U.add_ground_truth_to_proposals)

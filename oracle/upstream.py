@@ -774,9 +774,36 @@ class TVBasicBlock(nn.Module):
         return self.relu(out + identity)
 
 
-class TVResNet(nn.Module):
-    def __init__(self, layers):
+class TVBottleneck(nn.Module):
+    """torchvision Bottleneck (v1.5: the stride sits on the 3x3), expansion 4"""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class TVResNet(nn.Module):
+    def __init__(self, layers, block=None):
+        super().__init__()
+        self.block = block or TVBasicBlock
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -787,7 +814,7 @@ class TVResNet(nn.Module):
         self.layer3 = self._make_layer(256, layers[2], 2)
         self.layer4 = self._make_layer(512, layers[3], 2)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
-        self.fc = nn.Linear(512, 1000)
+        self.fc = nn.Linear(512 * self.block.expansion, 1000)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -796,19 +823,30 @@ class TVResNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def _make_layer(self, planes, blocks, stride):
-        downsample = None
-        if stride != 1 or self.inplanes != planes:
-            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
-        layers = [TVBasicBlock(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes
-        layers += [TVBasicBlock(planes, planes) for _ in range(1, blocks)]
+        block, downsample = self.block, None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                                       nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
 
-def _tv_resnet(layers, pretrained):
+def _tv_resnet(layers, pretrained, block=None):
     if pretrained:
         raise RuntimeError("ImageNet weights are a network download (torchvision); set MODEL.WEIGHTS")
-    return TVResNet(layers)
+    return TVResNet(layers, block)
+
+
+def tv_resnet50(pretrained=False):
+    """published parameter count 25 557 032"""
+    return _tv_resnet([3, 4, 6, 3], pretrained, TVBottleneck)
+
+
+def tv_resnet101(pretrained=False):
+    """published parameter count 44 549 160"""
+    return _tv_resnet([3, 4, 23, 3], pretrained, TVBottleneck)
 
 
 def tv_resnet18(pretrained=False):
