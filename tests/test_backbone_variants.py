@@ -158,7 +158,19 @@ def test_backbone_variants_emulated(emu_lib, kind, value):
     _run("cpu", kind, value)
 
 
+LIGHT = [("dla", "dla46_c"), ("dla", "dla60"), ("dla", "dla60x"), ("resnet", 18), ("resnet", 50)]
+HEAVY = [("dla", "dla102"), ("dla", "dla169"), ("dla", "dla102x"), ("dla", "dla102x2"), ("resnet", 101)]
+
+
 @pytest.mark.gpu
 def test_backbone_variants_gpu(hip_lib):
-    for kind, value in [("dla", v) for v in DLA_TYPES] + [("resnet", 18), ("resnet", 50), ("resnet", 101)]:
+    for kind, value in LIGHT:
+        _run("cuda", kind, value, 128)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("OMNI_SLOW") != "1", reason="~2.5 min, nearly all of it the float32 + float64 CPU oracle of the 100-170 layer "
+                    "variants; passed on MI355X together with the light set (profiles/r02_backbone_variants_gpu.txt)")
+def test_backbone_variants_heavy_gpu(hip_lib):
+    for kind, value in HEAVY:
         _run("cuda", kind, value, 128)
