@@ -18,6 +18,10 @@ def _model(config):
     ("cubercnn_DLA34_FPN.yaml", ["backbone.bottom_up.level2.tree1.conv1.weight", "backbone.bottom_up.level3.tree1.tree1.bn2.running_var",
                                  "backbone.bottom_up.base_layer.1.num_batches_tracked"]),
     ("cubercnn_ResNet34_FPN.yaml", ["backbone.bottom_up.layer2.0.downsample.0.weight", "backbone.bottom_up.bn1.running_mean"]),
+    ("cubercnn_densenet_FPN.yaml", ["backbone.bottom_up.base.denseblock4.denselayer16.conv2.weight", "backbone.bottom_up.base.norm5.running_var",
+                                    "backbone.bottom_up.base.transition2.conv.weight"]),
+    ("cubercnn_mnasnet_FPN.yaml", ["backbone.bottom_up.base.8.0.layers.3.weight", "backbone.bottom_up.base.15.running_mean"]),
+    ("cubercnn_shufflenet_FPN.yaml", ["backbone.bottom_up.stage2.0.branch1.0.weight", "backbone.bottom_up.conv5.0.weight"]),
 ])
 def test_state_dict_names_shapes_roundtrip(config, probe):
     model, priors = _model(config)

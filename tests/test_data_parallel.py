@@ -128,13 +128,20 @@ def test_two_phase_overlapped_exchange_world2(emu_lib, tmp_path, pipelined):
         assert (tp[0][n] - sp[0][n]).abs().max() <= 1e-6 * max(1.0, float(sp[0][n].abs().max())), n
 
 
-def _worker(rank, world, port, out, explicit=True):
+def _flat_opt(net, kind):
+    from omni3d_amd.cubercnn.solver.build import FlatAdam, FlatSGD
+    groups = [{"params": [p]} for p in net.parameters()]
+    if kind == "sgd":
+        return FlatSGD(groups, lr=0.1, momentum=0.9, weight_decay=1e-3)
+    return FlatAdam(groups, lr=0.02, eps=1e-2, weight_decay=1e-3, amsgrad=kind.endswith("+amsgrad"), decoupled=kind.startswith("adamw"))
+
+
+def _worker(rank, world, port, out, explicit=True, kind="sgd"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _install_emulator()
-    from omni3d_amd.cubercnn.solver.build import FlatSGD
     net = _make_net()
-    opt = FlatSGD([{"params": [p]} for p in net.parameters()], lr=0.1, momentum=0.9, weight_decay=1e-3)
+    opt = _flat_opt(net, kind)
     for _ in range(2):
         opt.zero_grad()
         net(_shard(rank)).backward()
@@ -145,19 +152,19 @@ def _worker(rank, world, port, out, explicit=True):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("explicit", [True, False])
-def test_flat_bucket_allreduce_world2(emu_lib, tmp_path, explicit):
+@pytest.mark.parametrize("explicit,kind", [(True, "sgd"), (False, "sgd"), (True, "adam"), (False, "adamw+amsgrad")])
+def test_flat_bucket_allreduce_world2(emu_lib, tmp_path, explicit, kind):
     """explicit=False: a loop that never calls the exchange (the reference's relies on DDP hooks, which direct gradient
-    accumulation bypasses) still trains identical replicas -- FlatSGD.step() averages the bucket when nobody did"""
+    accumulation bypasses) still trains identical replicas -- step() averages the bucket when nobody did.  The fused Adam family
+    shares the bucket / exchange code of the fused SGD."""
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), explicit), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), explicit, kind), nprocs=world, join=True)
     got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
     assert torch.equal(got[0], got[1])                      # replicas stay identical
     # single-process reference: two replicas (per-shard BN statistics, like the reference's per-GPU BatchNorm),
     # gradients averaged by hand
-    from omni3d_amd.cubercnn.solver.build import FlatSGD
     nets = [_make_net() for _ in range(world)]
-    opts = [FlatSGD([{"params": [p]} for p in n.parameters()], lr=0.1, momentum=0.9, weight_decay=1e-3) for n in nets]
+    opts = [_flat_opt(n, kind) for n in nets]
     for _ in range(2):
         for r in range(world):
             opts[r].zero_grad()
