@@ -180,6 +180,15 @@ HEAD_ENTANGLED = dict(TINY, name="dla34_tiny_head_entangled", seed=18, prior_bin
 HEAD_MODES = (HEAD_QUAT, HEAD_EULER, HEAD_MIXED, HEAD_CLUSTERS, HEAD_ENTANGLED)
 
 
+# the whole model over the other bottom-ups of the reference's configs (torchvision restated in oracle/upstream.py)
+BACKBONE_TINY = (dict(TINY, name="densenet_tiny", seed=21, config="cubercnn_densenet_FPN.yaml"),
+                 dict(TINY, name="mnasnet_tiny", seed=22, config="cubercnn_mnasnet_FPN.yaml"),
+                 dict(TINY, name="shufflenet_tiny", seed=23, config="cubercnn_shufflenet_FPN.yaml"))
+# 2 x 128 x 128: the deepest BatchNorms of the tiny spec see 4 samples per channel, too ill-conditioned for a GPU-vs-CPU comparison
+BACKBONE_SMALL = (dict(SMALL, name="mnasnet_small", seed=24, config="cubercnn_mnasnet_FPN.yaml"),
+                  dict(SMALL, name="shufflenet_small", seed=25, config="cubercnn_shufflenet_FPN.yaml"))
+
+
 FULL = dict(name="dla34_full", seed=6, images=4, height=512, width=512, num_gt=8, overrides=[])       # BASELINE configs[1]
 RESNET_FULL = dict(name="resnet34_full", seed=8, images=2, height=512, width=512, num_gt=8, overrides=[],
                    config="cubercnn_ResNet34_FPN.yaml")                                                  # BASELINE configs[3] model
@@ -468,6 +477,10 @@ if __name__ == "__main__":
         main_infer(INFER_CLUSTERS)
     elif "--infer" in sys.argv:
         main_infer()
+    elif "--backbones" in sys.argv:
+        for spec in BACKBONE_TINY + BACKBONE_SMALL:
+            if "--new-only" not in sys.argv or not os.path.exists(os.path.join(ROOT, "tests", "golden", spec["name"] + ".pt")):
+                main(spec)
     elif "--head-modes" in sys.argv:
         for spec in HEAD_MODES:
             if "--new-only" not in sys.argv or not os.path.exists(os.path.join(ROOT, "tests", "golden", spec["name"] + ".pt")):

@@ -13,8 +13,9 @@ def _gold(name):
     return os.path.join(ROOT, "tests", "golden", name + ".pt")
 
 
-def _run(dev, name):
+def _run(dev, name, head_cap=None):
     from oracle import make_golden as MG
+    head_cap = GRAD_CAP_HEADS if head_cap is None else head_cap
     from omni3d_amd import synthetic
     from omni3d_amd.d2.events import EventStorage
     gold = torch.load(_gold(name), weights_only=False)
@@ -63,20 +64,23 @@ def _run(dev, name):
     # in the full-size tests below)
     grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     worst = 0.0
+    # a BatchNorm bias that reaches the next BatchNorm through linear layers only (MNASNet's base.7, ShuffleNet's branch1.1) has an
+    # exactly-zero gradient in exact arithmetic: both sides hold rounding noise there, hence a floor relative to the largest gradient
+    floor = max(1e-6, 1e-7 * max(gold["grad_norm"].values()))
     for n, ref_norm in gold["grad_norm"].items():
         assert n in grads, n
         got = float(grads[n].float().norm())
         rel = abs(got - ref_norm) / max(ref_norm, 1e-6)
         worst = max(worst, rel)
-        tol = GRAD_CAP_HEADS if _is_head(n) else GRAD_CAP_BACKBONE
-        assert rel < tol or abs(got - ref_norm) < 1e-6, (n, got, ref_norm)
+        tol = head_cap if _is_head(n) else GRAD_CAP_BACKBONE
+        assert rel < tol or abs(got - ref_norm) < floor, (n, got, ref_norm, floor)
     for n, head in gold["grad_head"].items():
         g = grads[n]
         if g.dim() == 4:   # reference order is (K, C, R, S) row-major
             g = g.contiguous(memory_format=torch.contiguous_format)
         got = g.reshape(g.shape[0], -1).flatten()[:64].cpu() if g.dim() > 1 else g.flatten()[:64].cpu()
         scale = max(head.abs().max().item(), 1e-6)
-        tol = GRAD_CAP_HEADS if _is_head(n) else GRAD_CAP_BACKBONE
+        tol = head_cap if _is_head(n) else GRAD_CAP_BACKBONE
         assert (got - head).abs().max().item() <= tol * scale + 1e-7, (n, (got - head).abs().max().item(), scale)
     return worst
 
