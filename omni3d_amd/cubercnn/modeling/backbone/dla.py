@@ -3,8 +3,8 @@
 Same topology, module names (=> state-dict keys of SURVEY.md Appendix C) and initialisation as
 /root/reference/cubercnn/modeling/backbone/dla.py (BasicBlock :40-68, Bottleneck :71-109, Root :156-174, Tree :177-230,
 DLA :233-297, variants :312-414, DLABackbone :417-482, builder :484-507): dla34 (BASELINE.json), the Bottleneck
-variants dla46_c, dla60, dla102, dla169 and the BottleneckX (grouped 3x3) variants dla60x, dla102x, dla102x2 of
-MODEL.DLA.TYPE; dla46x_c / dla60x_c have 2 channels per group, below the 4-channel lanes of the kernels, and raise.
+variants dla46_c, dla60, dla102, dla169 and the BottleneckX (grouped 3x3) variants dla46x_c, dla60x_c, dla60x, dla102x,
+dla102x2 of MODEL.DLA.TYPE (the 2-channel groups of the *_c ones are zero-padded to the kernels' 4-channel lanes).
 Every conv is the implicit-GEMM MFMA kernel, every BN(+ReLU)(+residual) one fused HBM-bound kernel pair; the image
 enters as NHWC with C padded 3 -> 4."""
 import math
@@ -190,8 +190,9 @@ DLA_VARIANTS = {
     "dla60x": ([1, 1, 1, 2, 3, 1], [16, 32, 128, 256, 512, 1024], bottleneck_x(32), False, _WIDE),
     "dla102x": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], bottleneck_x(32), True, _WIDE),
     "dla102x2": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], bottleneck_x(64), True, _WIDE),
+    "dla46x_c": ([1, 1, 1, 2, 2, 1], [16, 32, 64, 64, 128, 256], bottleneck_x(32), False, {"p2": 64, "p3": 64, "p4": 128, "p5": 256, "p6": 256}),
+    "dla60x_c": ([1, 1, 1, 2, 3, 1], [16, 32, 64, 64, 128, 256], bottleneck_x(32), False, {"p2": 64, "p3": 64, "p4": 128, "p5": 256, "p6": 256}),
 }
-_GROUPED = ("dla46x_c", "dla60x_c")
 
 
 def build_dla(name, pretrained=False):
@@ -210,9 +211,6 @@ class DLABackbone(Backbone):
     def __init__(self, cfg, input_shape, pretrained=True):
         super().__init__()
         kind = cfg.MODEL.DLA.TYPE
-        if kind in _GROUPED:
-            raise NotImplementedError(f"MODEL.DLA.TYPE {kind}: its grouped 3x3 convolutions have 2 channels per group (dla.py:112-153, "
-                                      f"334-351), below the 4-channel lanes of the kernels; built: {sorted(DLA_VARIANTS)}")
         if kind not in DLA_VARIANTS:
             raise ValueError(f"unknown MODEL.DLA.TYPE {kind}")
         base = build_dla(kind, pretrained=pretrained)

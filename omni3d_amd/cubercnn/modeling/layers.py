@@ -30,13 +30,12 @@ class Conv2d(nn.Conv2d):
 
 
 class GroupedConv2d(nn.Conv2d):
-    """nn.Conv2d(C, K, k, groups=G, bias=False) (DLA BottleneckX): weight (K, C/G, k, k) in channels_last memory"""
+    """nn.Conv2d(C, K, k, groups=G, bias=False) (DLA BottleneckX): weight (K, C/G, k, k) in channels_last memory.  The kernels move
+    4 channels per lane: groups narrower than that (the 2 -> 2 channel groups of dla46x_c / dla60x_c) are zero-padded to 4 input and
+    4 output channels per group around the call (index permutations and pads in torch, the convolution itself on the same kernels)."""
 
     def __init__(self, cin, cout, kernel_size, stride=1, padding=0, groups=1):
         super().__init__(cin, cout, kernel_size, stride=stride, padding=padding, groups=groups, bias=False)
-        if (cin // groups) % 4 or (cout // groups) % 4:
-            raise NotImplementedError(f"grouped convolution with {cin // groups} -> {cout // groups} channels per group: the kernels move "
-                                      "4 channels per lane")
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
 
     def _load_from_state_dict(self, *a, **k):
@@ -44,7 +43,17 @@ class GroupedConv2d(nn.Conv2d):
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
 
     def forward(self, x):
-        return HF.grouped_conv2d(x, self.weight, self.groups, self.stride[0], self.padding[0])
+        G, cg, kg = self.groups, self.in_channels // self.groups, self.out_channels // self.groups
+        if cg % 4 == 0 and kg % 4 == 0:
+            return HF.grouped_conv2d(x, self.weight, G, self.stride[0], self.padding[0])
+        import torch.nn.functional as F
+        c4, k4 = (cg + 3) // 4 * 4, (kg + 3) // 4 * 4
+        n, _, h, w = x.shape
+        xp = F.pad(x.reshape(n, G, cg, h, w), (0, 0, 0, 0, 0, c4 - cg)).reshape(n, G * c4, h, w)
+        r = self.kernel_size[0]
+        wp = F.pad(self.weight.reshape(G, kg, cg, r, r), (0, 0, 0, 0, 0, c4 - cg, 0, k4 - kg)).reshape(G * k4, c4, r, r)
+        y = HF.grouped_conv2d(xp.contiguous(memory_format=CL), wp.contiguous(memory_format=CL), G, self.stride[0], self.padding[0])
+        return y.reshape(n, G, k4, y.shape[2], y.shape[3])[:, :, :kg].reshape(n, G * kg, y.shape[2], y.shape[3])
 
 
 class DepthwiseConv2d(nn.Conv2d):

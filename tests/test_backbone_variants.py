@@ -11,8 +11,8 @@ import torch
 
 REF = "/root/reference"
 needs_ref = pytest.mark.skipif(not os.path.exists(REF), reason="needs the reference checkout (build container only)")
-DLA_TYPES = ["dla46_c", "dla60", "dla102", "dla169", "dla60x", "dla102x", "dla102x2"]
-DLA_REF_ONLY = ["dla46x_c", "dla60x_c"]      # restated in the oracle, not built in the product (2 channels per group)
+DLA_TYPES = ["dla46_c", "dla60", "dla102", "dla169", "dla60x", "dla102x", "dla102x2", "dla46x_c", "dla60x_c"]
+DLA_REF_ONLY = []
 OV = ["MODEL.WEIGHTS", "synthetic://random-init"]
 
 
@@ -80,10 +80,9 @@ def test_product_dla_surface(variant):
     assert {k: (v.channels, v.stride) for k, v in prod.output_shape().items()} == {k: (v.channels, v.stride) for k, v in ora.output_shape().items()}
 
 
-def test_two_channel_group_variants_say_so():
-    for kind in DLA_REF_ONLY:
-        with pytest.raises(NotImplementedError, match="2 channels per group"):
-            _product("dla", kind)
+def test_unknown_dla_type_says_so():
+    with pytest.raises(ValueError, match="unknown MODEL.DLA.TYPE"):
+        _product("dla", "dla999")
 
 
 def _run_grouped(dev):
@@ -153,13 +152,13 @@ def _run(dev, kind, value, size=64):
 
 
 @pytest.mark.skipif(os.environ.get("OMNI_SLOW") != "1", reason="minutes under the host emulator; the GPU variant is the gate")
-@pytest.mark.parametrize("kind,value", [("dla", "dla46_c"), ("dla", "dla102"), ("dla", "dla60x"), ("resnet", 50)])
+@pytest.mark.parametrize("kind,value", [("dla", "dla46_c"), ("dla", "dla102"), ("dla", "dla60x"), ("dla", "dla46x_c"), ("resnet", 50)])
 def test_backbone_variants_emulated(emu_lib, kind, value):
     _run("cpu", kind, value)
 
 
 LIGHT = [("dla", "dla46_c"), ("dla", "dla60"), ("dla", "dla60x"), ("resnet", 18), ("resnet", 50)]
-HEAVY = [("dla", "dla102"), ("dla", "dla169"), ("dla", "dla102x"), ("dla", "dla102x2"), ("resnet", 101)]
+HEAVY = [("dla", "dla102"), ("dla", "dla169"), ("dla", "dla102x"), ("dla", "dla102x2"), ("resnet", 101), ("dla", "dla46x_c"), ("dla", "dla60x_c")]
 
 
 @pytest.mark.gpu
