@@ -135,8 +135,11 @@ class RCNN3D(nn.Module):
         features = self.backbone(images.tensor)
         Ks = [torch.FloatTensor(x["K"]) for x in batched_inputs]
         im_scales_ratio = [x["height"] / im[0] for x, im in zip(batched_inputs, images.image_sizes)]
-        pk = {"targets": packed} if getattr(self.proposal_generator, "accepts_packed", False) else {}
-        proposals, _ = self.proposal_generator(images, features, None, **pk)
+        if any("oracle2D" in b for b in batched_inputs):       # rcnn3d.py:98-101: oracle 2D boxes go straight to the ROI heads
+            proposals = [b["oracle2D"] for b in batched_inputs]
+        else:
+            pk = {"targets": packed} if getattr(self.proposal_generator, "accepts_packed", False) else {}
+            proposals, _ = self.proposal_generator(images, features, None, **pk)
         pk = {"packed": packed} if getattr(self.roi_heads, "accepts_packed", False) else {}
         results, _ = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, None, **pk)
         if do_postprocess:

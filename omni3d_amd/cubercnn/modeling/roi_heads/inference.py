@@ -57,6 +57,46 @@ def roi_heads_inference(heads, images, feats, proposals, packed):
     return per_image
 
 
+@torch.no_grad()
+def roi_heads_oracle2d(heads, images, feats, oracles, packed):
+    """The eval branch of ROIHeads3D.forward for given 2D boxes (roi_heads.py:228-240, then _forward_cube :353-357, 771-819):
+    `oracles` = per image {'gt_bbox2D': (n, 4) boxes at network resolution, 'gt_classes': (n,)}; the detections are those boxes with
+    score sqrt(1 * confidence) and the cube head's 3D outputs.  One fixed-shape pass for the whole batch."""
+    K = heads.num_classes
+    dev = images.tensor.device
+    B = len(oracles)
+    counts = [int(len(o["gt_classes"])) for o in oracles]
+    P = max(counts + [1])
+    boxes = torch.zeros((B, P, 4), dtype=torch.float32, device=dev)
+    boxes[:, :, 2:] = 1.0                                                # unused slots hold a dummy box
+    cls = torch.zeros((B, P), dtype=torch.int32, device=dev)
+    for n, o in enumerate(oracles):
+        if counts[n]:
+            boxes[n, :counts[n]] = torch.as_tensor(o["gt_bbox2D"], dtype=torch.float32).reshape(-1, 4).to(dev)
+            cls[n, :counts[n]] = torch.as_tensor(o["gt_classes"]).to(dev).int()
+    dboxes, dcl = boxes.view(B * P, 4), cls.view(-1)
+    dimg = heads._batch_index(B, P, dev)
+    head = heads.cube_head(heads.cube_pooler(feats, heads.scale_proposals(dboxes), dimg))
+    priors = heads.priors_dims_per_cat.detach().reshape(K, 2, 3).contiguous()
+    cube3d, pose, verts = det.cube_decode(head.contiguous(), K, dboxes, dcl, dimg, packed.Ks, packed.v2r, packed.ratio, priors,
+                                           heads.cube_mode, heads.clusters())
+    final = cube3d[:, 8] ** 0.5                                          # (ones * cube_3D[:, -1]) ** (1 / 2), roi_heads.py:239, 800-801
+    per_image = []
+    for n, o in enumerate(oracles):
+        k, s = counts[n], n * P
+        inst = Instances(tuple(images.image_sizes[n]))
+        inst.pred_boxes = Boxes(boxes[n, :k])
+        inst.pred_classes = torch.as_tensor(o["gt_classes"]).to(dev)
+        inst.scores = final[s:s + k]
+        inst.pred_bbox3D = verts[s:s + k]
+        inst.pred_center_cam = cube3d[s:s + k, :3]
+        inst.pred_center_2D = cube3d[s:s + k, 6:8]
+        inst.pred_dimensions = cube3d[s:s + k, 3:6]
+        inst.pred_pose = pose[s:s + k]
+        per_image.append(inst)
+    return per_image
+
+
 def postprocess(instances, batched_inputs, image_sizes):
     """detectron2 GeneralizedRCNN._postprocess / detector_postprocess: rescale 2D boxes to the original
     resolution, clip, drop empty boxes; 3D fields pass through."""

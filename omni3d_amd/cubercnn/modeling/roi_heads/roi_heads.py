@@ -213,6 +213,11 @@ class ROIHeads3D(nn.Module):
             assert Ks is not None and im_scales_ratio is not None, "ROIHeads3D needs Ks and im_scales_ratio (roi_heads.py:207)"
             packed = pack_instances_cached(targets if targets is not None else [None] * len(images.image_sizes), images.image_sizes,
                                            Ks, im_scales_ratio, self.virtual_focal, device=images.tensor.device)
+        if (not self.training and isinstance(proposals, list) and len(proposals) > 0
+                and not any(isinstance(p, Instances) for p in proposals)):
+            # oracle 2D boxes (rcnn3d.py:98-101, roi_heads.py:228-240): a list of {'gt_bbox2D', 'gt_classes'} bypasses RPN and box head
+            from .inference import roi_heads_oracle2d
+            return roi_heads_oracle2d(self, images, feats, proposals, packed), {}
         if not hasattr(proposals, "boxes"):
             proposals = _pack_proposal_list(proposals, images.image_sizes, images.tensor.device)
         if self.training:

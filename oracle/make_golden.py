@@ -205,6 +205,24 @@ INFER_CLUSTERS = dict(INFER, name="dla34_small_infer_clusters", seed=2, prior_bi
     "MODEL.ROI_CUBE_HEAD.Z_TYPE", "clusters", "MODEL.ROI_CUBE_HEAD.CLUSTER_BINS", 4, "MODEL.ROI_CUBE_HEAD.SCALE_ROI_BOXES", 1.3])
 
 
+# oracle 2D boxes: the ground-truth boxes / classes handed to RCNN3D.inference as `oracle2D` (rcnn3d.py:98-101, roi_heads.py:228-240)
+INFER_ORACLE2D = dict(INFER, name="dla34_small_infer_oracle2d", seed=6, oracle2d=True)
+
+
+def infer_batch(spec, priors, double=False):
+    """the eval batch of an inference fixture (also used by tests/test_inference_parity.py)"""
+    batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
+    for b in batch:
+        inst = b.pop("instances")
+        b["height"], b["width"] = 2 * spec["height"], 2 * spec["width"]      # exercise _postprocess rescaling + im_scales_ratio
+        b["K"] = [[2 * v for v in row] for row in b["K"][:2]] + [b["K"][2]]
+        if spec.get("oracle2d"):
+            keep = inst.gt_classes >= 0
+            boxes = inst.gt_boxes.tensor[keep].clone()
+            b["oracle2D"] = {"gt_bbox2D": boxes.double() if double else boxes, "gt_classes": inst.gt_classes[keep].clone()}
+    return batch
+
+
 def sharpen(model):
     """Random-init class logits are ~uniform (every (roi, class) pair would pass the score threshold); scale the
     classifier so the eval fixture has a realistic, small set of detections.  Applied to both sides."""
@@ -219,11 +237,7 @@ def main_infer(spec=INFER):
     ref = H.build_reference_model(H.reference_cfg("cubercnn_DLA34_FPN.yaml", spec["overrides"]), priors)
     prod = sharpen(build_product_model(product_cfg(spec["overrides"]), priors, spec["seed"]))
     ref.load_state_dict(prod.state_dict(), strict=True)
-    batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
-    for b in batch:
-        b.pop("instances")
-        b["height"], b["width"] = 2 * spec["height"], 2 * spec["width"]      # exercise _postprocess rescaling + im_scales_ratio
-        b["K"] = [[2 * v for v in row] for row in b["K"][:2]] + [b["K"][2]]
+    batch = infer_batch(spec, priors)
     ref.eval()
     with torch.no_grad():
         out = ref(batch)
@@ -233,17 +247,15 @@ def main_infer(spec=INFER):
         res.append({"pred_boxes": i.pred_boxes.tensor.clone(), "scores": i.scores.clone(), "pred_classes": i.pred_classes.clone(),
                     "pred_bbox3D": i.pred_bbox3D.clone(), "pred_center_cam": i.pred_center_cam.clone(),
                     "pred_center_2D": i.pred_center_2D.clone(), "pred_dimensions": i.pred_dimensions.clone(),
-                    "pred_pose": i.pred_pose.clone(), "scores_full": i.scores_full.clone()})
+                    "pred_pose": i.pred_pose.clone()})
+        if i.has("scores_full"):
+            res[-1]["scores_full"] = i.scores_full.clone()
     # float64 yardstick: the same reference files evaluated in double precision (model.double(), default dtype float64);
     # detections are matched to the fp32 list by (class, nearest box) because near-tied scores may order differently
     torch.set_default_dtype(torch.float64)
     try:
         ref64 = ref.double()
-        b64 = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
-        for b in b64:
-            b.pop("instances")
-            b["height"], b["width"] = 2 * spec["height"], 2 * spec["width"]
-            b["K"] = [[2 * v for v in row] for row in b["K"][:2]] + [b["K"][2]]
+        b64 = infer_batch(spec, priors, double=True)
         with torch.no_grad():
             out64 = ref64(b64)
     finally:
@@ -475,6 +487,8 @@ if __name__ == "__main__":
         main_eval()
     elif "--infer-clusters" in sys.argv:
         main_infer(INFER_CLUSTERS)
+    elif "--infer-oracle2d" in sys.argv:
+        main_infer(INFER_ORACLE2D)
     elif "--infer" in sys.argv:
         main_infer()
     elif "--backbones" in sys.argv:

@@ -8,7 +8,8 @@ import torch
 
 from conftest import ROOT
 
-FIXTURES = ["dla34_small_infer", "dla34_small_infer_clusters"]     # default head; Z_TYPE clusters + CLUSTER_BINS 4 + SCALE_ROI_BOXES
+# default head; Z_TYPE clusters + CLUSTER_BINS 4 + SCALE_ROI_BOXES; ground-truth 2D boxes handed in as `oracle2D` (no RPN / box head)
+FIXTURES = ["dla34_small_infer", "dla34_small_infer_clusters", "dla34_small_infer_oracle2d"]
 
 
 def _run(dev, name="dla34_small_infer"):
@@ -18,11 +19,7 @@ def _run(dev, name="dla34_small_infer"):
     spec = gold["spec"]
     priors = synthetic.make_priors(50, bins=spec.get("prior_bins", 0))
     model = MG.sharpen(MG.build_product_model(MG.product_cfg(spec["overrides"]), priors, spec["seed"])).to(dev)
-    batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
-    for b in batch:
-        b.pop("instances")
-        b["height"], b["width"] = 2 * spec["height"], 2 * spec["width"]
-        b["K"] = [[2 * v for v in row] for row in b["K"][:2]] + [b["K"][2]]
+    batch = MG.infer_batch(spec, priors)
     model.eval()
     with torch.no_grad():
         out = model(batch)
