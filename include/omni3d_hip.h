@@ -198,6 +198,16 @@ int omni_rpn_loss_bwd(const void* const* level_ptrs, const void* const* dlevel_p
                       const float* gt, const int* gt_off, const float* g_cls, const float* g_loc, float inv_norm,
                       void* stream);
 
+/* The same with OBJECTNESS_UNCERTAINTY "none" (rpn.py:181-195, detectron2's own RPN losses): objectness BCE against the 0 / 1
+ * labels over every sampled anchor, unweighted L1 on the foreground deltas; same sums layout. */
+int omni_rpn_loss_plain_fwd(const void* const* level_ptrs, const int* level_hw, int nlev, int B, const float* anchors,
+                            const signed char* labels, const int* matched_idx, const float* gt, const int* gt_off,
+                            double* sums, void* stream);
+int omni_rpn_loss_plain_bwd(const void* const* level_ptrs, const void* const* dlevel_ptrs, const int* level_hw, int nlev,
+                            int B, const float* anchors, const signed char* labels, const int* matched_idx,
+                            const float* gt, const int* gt_off, const float* g_cls, const float* g_loc, float inv_norm,
+                            void* stream);
+
 /* detectron2 RPN._decode_proposals + Boxes.clip + nonempty filter of find_top_rpn_proposals, applied
  * to the selected per-level top-k anchors only.  slot_level (Ktot), idx (B,Ktot), image_hw (B,2) are
  * device arrays; boxes (B,Ktot,4), valid (B,Ktot) out. */

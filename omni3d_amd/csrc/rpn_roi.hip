@@ -262,6 +262,56 @@ __global__ void __launch_bounds__(256) rpn_loss_kernel(Levels lv, Levels dlv, in
     }
 }
 
+// MODEL.RPN.OBJECTNESS_UNCERTAINTY 'none' (rpn.py:181-195, detectron2's RPN losses): objectness = BCE-with-logits against the 0 / 1
+// anchor labels over every sampled anchor, localisation = L1 on the foreground deltas without the IoU weight.  Same sums layout.
+template <int MODE>
+__global__ void __launch_bounds__(256) rpn_loss_plain_kernel(Levels lv, Levels dlv, int B, int A, const float* __restrict__ anchors,
+                                                             const signed char* __restrict__ labels, const int* __restrict__ midx,
+                                                             const float* __restrict__ gt, const int* __restrict__ gt_off,
+                                                             double* __restrict__ sums, const float* __restrict__ g_cls,
+                                                             const float* __restrict__ g_loc, float inv_norm) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < (long)B * A) {
+        const int n = (int)(i / A), a = (int)(i % A);
+        int l, loc, k;
+        anchor_to_level(lv, a, l, loc, k);
+        const long base = ((long)n * lv.hw[l] + loc) * RPN_C;
+        const float x = lv.y[l][base + k];
+        const int lab = labels[i];
+        const float sg = 1.f / (1.f + expf(-x));
+        if (lab >= 0) {                                    // valid_mask = gt_labels >= 0
+            const float t = lab == 1 ? 1.f : 0.f;
+            if (MODE == 0) s[0] = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+            else dlv.y[l][base + k] = (sg - t) * inv_norm * g_cls[0];
+        }
+        if (lab == 1) {
+            const float4 ab = ldbox(anchors + 4 * a);
+            const float4 gb = ldbox(gt + 4 * (gt_off[n] + midx[i]));
+            const float sw = ab.z - ab.x, sh = ab.w - ab.y, scx = ab.x + 0.5f * sw, scy = ab.y + 0.5f * sh;
+            const float tw = gb.z - gb.x, th = gb.w - gb.y, tcx = gb.x + 0.5f * tw, tcy = gb.y + 0.5f * th;
+            const float gd[4] = {(tcx - scx) / sw, (tcy - scy) / sh, logf(tw / sw), logf(th / sh)};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float df = lv.y[l][base + RPN_A + k * 4 + d] - gd[d];
+                if (MODE == 0) s[1] += fabsf(df);
+                else dlv.y[l][base + RPN_A + k * 4 + d] = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * inv_norm * g_loc[0];
+            }
+            if (MODE == 0) { s[2] = 1.f; s[4] = sg; }
+        } else if (MODE == 0) {
+            s[3] = lab == 0 ? 1.f : 0.f;
+            s[5] = sg;
+        }
+    }
+    if (MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float v = wave_sum(s[q]);
+            if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&sums[q], (double)v);
+        }
+    }
+}
+
 // ---- decode the selected anchors: Box2BoxTransform.apply_deltas + clip + validity -----------------
 // slot j of image n in level l: anchor a_off[l] + idx.  out boxes (B, Ktot, 4), valid (B, Ktot) = finite & w>0 & h>0.
 __global__ void rpn_decode_kernel(Levels lv, int B, int Ktot, const int* __restrict__ slot_level,
@@ -528,6 +578,39 @@ int omni_rpn_loss_bwd(const void* const* level_ptrs, const void* const* dlevel_p
     const long tot = (long)B * A;
     if (tot == 0) return OMNI_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_kernel<1>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lv, dlv,
+                       B, A, anchors, labels, matched_idx, gt, gt_off, (double*)nullptr, g_cls, g_loc, inv_norm);
+    return omni_launch_status();
+}
+
+// The same two entry points for MODEL.RPN.OBJECTNESS_UNCERTAINTY 'none' (plain 0 / 1 objectness targets, unweighted L1).
+int omni_rpn_loss_plain_fwd(const void* const* level_ptrs, const int* level_hw, int nlev, int B, const float* anchors,
+                            const signed char* labels, const int* matched_idx, const float* gt, const int* gt_off, double* sums,
+                            void* stream) {
+    if (nlev <= 0 || nlev > MAXL) return OMNI_ERR_ARG;
+    Levels lv = make_levels(level_ptrs, level_hw, nlev);
+    const int A = lv.a_off[nlev];
+    hipStream_t st = (hipStream_t)stream;
+    omni_memset_async(sums, 0, sizeof(double) * 6, st);
+    const long tot = (long)B * A;
+    if (tot == 0) return OMNI_OK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_plain_kernel<0>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lv, lv,
+                       B, A, anchors, labels, matched_idx, gt, gt_off, sums, (const float*)nullptr, (const float*)nullptr, 0.f);
+    return omni_launch_status();
+}
+
+int omni_rpn_loss_plain_bwd(const void* const* level_ptrs, const void* const* dlevel_ptrs, const int* level_hw, int nlev, int B,
+                            const float* anchors, const signed char* labels, const int* matched_idx, const float* gt,
+                            const int* gt_off, const float* g_cls, const float* g_loc, float inv_norm, void* stream) {
+    if (nlev <= 0 || nlev > MAXL) return OMNI_ERR_ARG;
+    Levels lv = make_levels(level_ptrs, level_hw, nlev);
+    Levels dlv = make_levels(dlevel_ptrs, level_hw, nlev);
+    const int A = lv.a_off[nlev];
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 0; l < nlev; ++l)
+        omni_memset_async(dlv.y[l], 0, sizeof(float) * (size_t)B * level_hw[l] * RPN_C, st);
+    const long tot = (long)B * A;
+    if (tot == 0) return OMNI_OK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_plain_kernel<1>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lv, dlv,
                        B, A, anchors, labels, matched_idx, gt, gt_off, (double*)nullptr, g_cls, g_loc, inv_norm);
     return omni_launch_status();
 }

@@ -81,8 +81,13 @@ class RPNWithIgnore(nn.Module):
         self.loss_weight = loss_weight if isinstance(loss_weight, dict) else {"loss_rpn_cls": loss_weight, "loss_rpn_loc": loss_weight}
         self.ignore_thresh = ignore_thresh
         self.objectness_uncertainty = objectness_uncertainty
-        if box_reg_loss_type != "smooth_l1" or smooth_l1_beta != 0.0 or objectness_uncertainty.lower() != "iouness":
-            raise NotImplementedError("MI355X hot path implements the reference configuration: IoUness + L1 (Base.yaml:55)")
+        if box_reg_loss_type != "smooth_l1" or smooth_l1_beta != 0.0:
+            raise NotImplementedError("MI355X hot path: L1 anchor regression (BBOX_REG_LOSS_TYPE smooth_l1, SMOOTH_L1_BETA 0: Base.yaml / "
+                                      "upstream defaults); the reference's IoUness losses only evaluate smooth_l1 as well (rpn.py:258-271)")
+        if objectness_uncertainty.lower() not in ("iouness", "none"):
+            # rpn.py:169-180 sends every other value down the same IoUness code path; only the two names that occur are accepted here
+            raise NotImplementedError(f"MODEL.RPN.OBJECTNESS_UNCERTAINTY '{objectness_uncertainty}': 'IoUness' (Base.yaml:55) and 'none'")
+        self.plain_objectness = objectness_uncertainty.lower() == "none"
         self.pending_logs = {}
         self.injected = None   # parity tests: dict with 'E' (B,A) exponential variates
         self.last = None
@@ -130,7 +135,7 @@ class RPNWithIgnore(nn.Module):
         inv_norm = 1.0 / (self.batch_size_per_image * B)          # rpn.py:198
         names = ("rpn/cls", "rpn/loc")
         w = tuple(self.loss_weight.get(k, 1.0) for k in names)                     # rpn.py:203 (names never match => 1.0)
-        vec, sums = HF.rpn_loss(levels, anchors, labels, matched_idx, targets.gt, targets.gt_off, inv_norm, w)
+        vec, sums = HF.rpn_loss(levels, anchors, labels, matched_idx, targets.gt, targets.gt_off, inv_norm, w, self.plain_objectness)
         self.pending_logs = {"rpn": (sums, B)}
         return HF.LossDict({names[0]: vec[0], names[1]: vec[1]}, vectors=[(vec, names)])
 
@@ -140,9 +145,10 @@ class RPNWithIgnore(nn.Module):
             s = sums.tolist()
             storage.put_scalar("rpn/num_pos_anchors", s[2] / B)
             storage.put_scalar("rpn/num_neg_anchors", s[3] / B)
-            storage.put_scalar("rpn/conf_pos_anchors", s[4] / max(s[2], 1.0))
-            n_other = B * self._num_anchors - s[2]
-            storage.put_scalar("rpn/conf_neg_anchors", s[5] / max(n_other, 1.0))
+            if not self.plain_objectness:        # logged by the IoUness loss only (rpn.py:252-255)
+                storage.put_scalar("rpn/conf_pos_anchors", s[4] / max(s[2], 1.0))
+                n_other = B * self._num_anchors - s[2]
+                storage.put_scalar("rpn/conf_neg_anchors", s[5] / max(n_other, 1.0))
 
     # ---- proposals (detectron2 predict_proposals / find_top_rpn_proposals) ---------------------
     @torch.no_grad()

@@ -538,14 +538,14 @@ class _RPNLoss(Function):
     """-> ((2,) = [sum BCE*t, sum L1*t] * inv_norm * loss weights, raw sums); level tensors are the fused head outputs (B,16,H,W) CL."""
 
     @staticmethod
-    def forward(ctx, anchors, labels, matched_idx, gt, gt_off, inv_norm, weights, *levels):
+    def forward(ctx, anchors, labels, matched_idx, gt, gt_off, inv_norm, weights, plain, *levels):
         ctx.set_materialize_grads(False)      # no zero tensors for the non-differentiable side outputs
         lv = [_cl(t).permute(0, 2, 3, 1) for t in levels]
         pack = det.LevelPack(lv)
-        sums = det.rpn_loss_fwd(pack, anchors, labels, matched_idx, gt, gt_off)
+        sums = det.rpn_loss_fwd(pack, anchors, labels, matched_idx, gt, gt_off, plain)
         ctx.pack = pack
         ctx.save_for_backward(anchors, labels, matched_idx, gt, gt_off)
-        ctx.inv_norm, ctx.weights = inv_norm, weights
+        ctx.inv_norm, ctx.weights, ctx.plain = inv_norm, weights, plain
         ctx.mark_non_differentiable(sums)
         return sums[:2].float() * _coef((inv_norm * weights[0], inv_norm * weights[1]), sums.device), sums
 
@@ -555,13 +555,13 @@ class _RPNLoss(Function):
         g = g.contiguous().float()
         if ctx.weights != (1.0, 1.0):
             g = g * _coef(ctx.weights, g.device)
-        grads = det.rpn_loss_bwd(ctx.pack, anchors, labels, matched_idx, gt, gt_off, g[0:1], g[1:2], ctx.inv_norm)
-        return (None,) * 7 + tuple(t.permute(0, 3, 1, 2) for t in grads)
+        grads = det.rpn_loss_bwd(ctx.pack, anchors, labels, matched_idx, gt, gt_off, g[0:1], g[1:2], ctx.inv_norm, ctx.plain)
+        return (None,) * 8 + tuple(t.permute(0, 3, 1, 2) for t in grads)
 
 
-def rpn_loss(levels, anchors, labels, matched_idx, gt, gt_off, inv_norm, weights=(1.0, 1.0)):
-    """-> ((2,) [cls, loc] weighted losses, raw sums)"""
-    return _RPNLoss.apply(anchors, labels, matched_idx, gt, gt_off, inv_norm, tuple(float(w) for w in weights), *levels)
+def rpn_loss(levels, anchors, labels, matched_idx, gt, gt_off, inv_norm, weights=(1.0, 1.0), plain=False):
+    """plain: OBJECTNESS_UNCERTAINTY 'none' instead of 'IoUness' -> ((2,) [cls, loc] weighted losses, raw sums)"""
+    return _RPNLoss.apply(anchors, labels, matched_idx, gt, gt_off, inv_norm, tuple(float(w) for w in weights), bool(plain), *levels)
 
 
 class _BoxLoss(Function):

@@ -100,20 +100,21 @@ def rpn_gather_logits(pack):
     return out
 
 
-def rpn_loss_fwd(pack, anchors, labels, matched_idx, gt, gt_off):
+def rpn_loss_fwd(pack, anchors, labels, matched_idx, gt, gt_off, plain=False):
+    """plain: MODEL.RPN.OBJECTNESS_UNCERTAINTY 'none' (0 / 1 objectness targets, unweighted L1) instead of 'IoUness'"""
     L = _dev(anchors, labels, matched_idx, gt, gt_off)
     sums = _empty((6,), torch.float64, anchors)
-    L.call("omni_rpn_loss_fwd", *pack.args(), pack.B, _lib.ptr(anchors), _lib.ptr(labels), _lib.ptr(matched_idx),
+    L.call("omni_rpn_loss_plain_fwd" if plain else "omni_rpn_loss_fwd", *pack.args(), pack.B, _lib.ptr(anchors), _lib.ptr(labels), _lib.ptr(matched_idx),
            _lib.ptr(gt), _lib.ptr(gt_off), _lib.ptr(sums), _lib.stream_of(anchors))
     return sums
 
 
-def rpn_loss_bwd(pack, anchors, labels, matched_idx, gt, gt_off, g_cls, g_loc, inv_norm):
+def rpn_loss_bwd(pack, anchors, labels, matched_idx, gt, gt_off, g_cls, g_loc, inv_norm, plain=False):
     L = _dev(anchors, labels, matched_idx, gt, gt_off, g_cls, g_loc)
     grads = [torch.empty_like(t) for t in pack.tensors]
     dp = _ptrs(grads)
     a = pack.args()
-    L.call("omni_rpn_loss_bwd", a[0], _cast(dp), a[1], a[2], pack.B, _lib.ptr(anchors), _lib.ptr(labels),
+    L.call("omni_rpn_loss_plain_bwd" if plain else "omni_rpn_loss_bwd", a[0], _cast(dp), a[1], a[2], pack.B, _lib.ptr(anchors), _lib.ptr(labels),
            _lib.ptr(matched_idx), _lib.ptr(gt), _lib.ptr(gt_off), _lib.ptr(g_cls), _lib.ptr(g_loc), float(inv_norm),
            _lib.stream_of(anchors))
     return grads

@@ -93,6 +93,20 @@ def rpn_losses_iouness(anchors, logits, deltas, labels, matched_gt_boxes, batch_
     return {"rpn/cls": loss_conf / normalizer, "rpn/loc": loss_reg / normalizer}, stats
 
 
+def rpn_losses_plain(anchors, logits, deltas, labels, matched_gt_boxes, batch_size_per_image=256):
+    """RPNWithIgnore.losses with OBJECTNESS_UNCERTAINTY 'none' (rpn.py:181-203): detectron2's `_dense_box_regression_loss`
+    (smooth_l1, beta 0, summed over the foreground) and BCE-with-logits against the 0 / 1 labels over the valid anchors."""
+    N = logits.shape[0]
+    fg = labels == 1
+    b2b = U.Box2BoxTransform(weights=(1.0, 1.0, 1.0, 1.0))
+    loss_reg = U._dense_box_regression_loss([anchors], b2b, [deltas], [k for k in matched_gt_boxes], fg, box_reg_loss_type="smooth_l1",
+                                            smooth_l1_beta=0.0)
+    valid = labels >= 0
+    loss_cls = F.binary_cross_entropy_with_logits(logits[valid], labels[valid].to(torch.float32), reduction="sum")
+    normalizer = batch_size_per_image * N
+    return {"rpn/cls": loss_cls / normalizer, "rpn/loc": loss_reg / normalizer}
+
+
 # ---------------------------------------------------------------------------------------------------
 # roi_heads/roi_heads.py: label_and_sample_proposals
 # ---------------------------------------------------------------------------------------------------

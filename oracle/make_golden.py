@@ -177,7 +177,9 @@ HEAD_CLUSTERS = dict(TINY, name="dla34_tiny_head_clusters", seed=16, prior_bins=
 HEAD_ENTANGLED = dict(TINY, name="dla34_tiny_head_entangled", seed=18, prior_bins=3, overrides=_T + [
     "MODEL.ROI_CUBE_HEAD.DISENTANGLED_LOSS", False, "MODEL.ROI_CUBE_HEAD.DIMS_PRIORS_ENABLED", False, "MODEL.ROI_CUBE_HEAD.Z_TYPE", "log",
     "MODEL.ROI_CUBE_HEAD.CLUSTER_BINS", 3, "MODEL.ROI_BOX_HEAD.TRAIN_ON_PRED_BOXES", True, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32])
-HEAD_MODES = (HEAD_QUAT, HEAD_EULER, HEAD_MIXED, HEAD_CLUSTERS, HEAD_ENTANGLED)
+# detectron2's own RPN losses instead of the IoUness ones (MODEL.RPN.OBJECTNESS_UNCERTAINTY 'none', rpn.py:169-195)
+RPN_PLAIN = dict(TINY, name="dla34_tiny_rpn_plain", seed=26, overrides=_T + ["MODEL.RPN.OBJECTNESS_UNCERTAINTY", "none"])
+HEAD_MODES = (HEAD_QUAT, HEAD_EULER, HEAD_MIXED, HEAD_CLUSTERS, HEAD_ENTANGLED, RPN_PLAIN)
 
 
 # the whole model over the other bottom-ups of the reference's configs (torchvision restated in oracle/upstream.py)

@@ -89,6 +89,20 @@ def _run_rpn_loss(dev):
     ddel = torch.cat([t[..., 3:15].reshape(B, -1, 4) for t in grads], 1).cpu()
     assert (dlog - logits.grad).abs().max() < 1e-6 and (ddel - deltas.grad).abs().max() < 1e-6
     assert all(t[..., 15].abs().max() == 0 for t in grads)
+    # MODEL.RPN.OBJECTNESS_UNCERTAINTY 'none': 0 / 1 objectness targets over every sampled anchor, unweighted L1 (rpn.py:181-195)
+    logits.grad = deltas.grad = None
+    refp = O.rpn_losses_plain(anchors, logits, deltas, labels.cpu(), mgt, batch_size_per_image=64)
+    sums = det.rpn_loss_fwd(pack, anchors.to(dev), labels, m["matched_idx"], gt.to(dev), gt_off.to(dev), plain=True).cpu()
+    assert abs(sums[0].item() / norm - refp["rpn/cls"].item()) < 1e-5 * max(1.0, refp["rpn/cls"].item())
+    assert abs(sums[1].item() / norm - refp["rpn/loc"].item()) < 1e-4 * max(1.0, refp["rpn/loc"].item())
+    assert sums[2].item() / B == stats["rpn/num_pos_anchors"] and sums[3].item() / B == stats["rpn/num_neg_anchors"]
+    (2.0 * refp["rpn/cls"] + 0.5 * refp["rpn/loc"]).backward()
+    grads = det.rpn_loss_bwd(pack, anchors.to(dev), labels, m["matched_idx"], gt.to(dev), gt_off.to(dev),
+                             torch.tensor([2.0]).to(dev), torch.tensor([0.5]).to(dev), 1.0 / norm, plain=True)
+    dlog = torch.cat([t[..., :3].reshape(B, -1) for t in grads], 1).cpu()
+    ddel = torch.cat([t[..., 3:15].reshape(B, -1, 4) for t in grads], 1).cpu()
+    assert (dlog - logits.grad).abs().max() < 1e-6 and (ddel - deltas.grad).abs().max() < 1e-6
+    assert all(t[..., 15].abs().max() == 0 for t in grads)
     # decode of selected anchors == detectron2 apply_deltas + clip + nonempty
     b2b = U.Box2BoxTransform((1.0, 1.0, 1.0, 1.0))
     a_off = np.concatenate([[0], np.cumsum([h * w * 3 for h, w in hw])])
