@@ -81,7 +81,8 @@ def _run_pool(dev):
 
 @pytest.mark.parametrize("cfg", [(2, 16, 5, 7, True, False), (1, 64, 4, 4, True, True), (3, 8, 3, 3, False, False),
                                  (2, 512, 2, 2, False, True),
-                                 (1, 8, 384, 384, True, False)])     # 72 partial blocks: the unrolled partial-sum loop
+                                 (1, 8, 384, 384, True, False),      # 72 partial blocks: the unrolled partial-sum loop
+                                 (2, 1152, 3, 3, True, True), (1, 2048, 2, 4, False, False)])   # > 1024 channels: several 256-quad tiles
 def test_bn_emulated(emu_lib, cfg):
     _run_bn("cpu", *cfg)
 
