@@ -2,6 +2,8 @@
 residual roots, deeper trees; cubercnn/modeling/backbone/dla.py:71-109, 324-414) and MODEL.RESNETS.DEPTH 18 / 50 / 101
 (resnet.py:16-29).
 
+(Named to run late: under `pytest -x` a flake in these long loops must not hide the results of the hot-path tests.)
+
   * the oracle's general DLA (oracle/model_oracle.py) is pinned to the REFERENCE's own dla.py for every variant (pure torch),
   * the product (HIP kernels) is compared with that oracle: forward, parameter gradients, running statistics."""
 import os
