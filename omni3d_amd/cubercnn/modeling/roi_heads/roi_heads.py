@@ -34,18 +34,21 @@ def build_roi_heads(cfg, input_shape, priors=None):
 
 @ROI_BOX_HEAD_REGISTRY.register()
 class FastRCNNConvFCHead(nn.Module):
-    """detectron2 FastRCNNConvFCHead with NUM_CONV 0: flatten -> fc1 -> ReLU -> fc2 -> ReLU
-    (state-dict names `fc1`, `fc2`)."""
+    """detectron2 FastRCNNConvFCHead with NUM_CONV 0: flatten -> fc1 -> ReLU [-> fc2 -> ReLU ...] (state-dict names `fc1` .. `fcN`;
+    configs/Base.yaml:67-70 uses two)."""
 
     def __init__(self, cfg, input_shape):
         super().__init__()
         b = cfg.MODEL.ROI_BOX_HEAD
-        if b.NUM_CONV != 0 or b.NUM_FC != 2 or b.NORM != "":
-            raise NotImplementedError("MI355X hot path: FastRCNNConvFCHead with NUM_CONV 0, NUM_FC 2 (Base.yaml:67-70)")
+        if b.NUM_CONV != 0 or b.NUM_FC < 1 or b.NORM != "":
+            raise NotImplementedError("MI355X hot path: FastRCNNConvFCHead with NUM_CONV 0, NUM_FC >= 1, no norm (Base.yaml:67-70 uses 2 FCs)")
+        self.num_fc = b.NUM_FC
         self.fc1 = FlattenLinear(input_shape.channels, input_shape.height, b.FC_DIM)
-        self.fc2 = Linear(b.FC_DIM, b.FC_DIM)
-        nn.init.kaiming_uniform_(self.fc2.weight, a=1)
-        nn.init.constant_(self.fc2.bias, 0)
+        for k in range(2, self.num_fc + 1):
+            fc = Linear(b.FC_DIM, b.FC_DIM)
+            nn.init.kaiming_uniform_(fc.weight, a=1)
+            nn.init.constant_(fc.bias, 0)
+            setattr(self, f"fc{k}", fc)
         self._fc_dim = b.FC_DIM
 
     @property
@@ -53,7 +56,10 @@ class FastRCNNConvFCHead(nn.Module):
         return ShapeSpec(channels=self._fc_dim)
 
     def forward(self, x):
-        return self.fc2(self.fc1(x, relu=True), relu=True)
+        x = self.fc1(x, relu=True)
+        for k in range(2, self.num_fc + 1):
+            x = getattr(self, f"fc{k}")(x, relu=True)
+        return x
 
 
 class ROIPooler(nn.Module):
