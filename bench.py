@@ -1,11 +1,18 @@
 #!/usr/bin/env python
 """bench.py -- measures the hot path on MI355X.  Contract: see the repo task statement.
 
-  python bench.py --gpus N --steps K --warmup W [--workload train|iou3d|infer]
+  python bench.py --gpus N --steps K --warmup W [--workload all|train|iou3d|infer]
 
-Prints ONE JSON line on rank 0.  `train` (default once available) = images/sec of the
-cubercnn_DLA34_FPN training step, batch 4/GPU, synthetic 512x512 Omni3D-shaped inputs;
-`iou3d` = BASELINE config 5 (100k dt x gt box pairs through box3d_overlap).
+Prints ONE JSON line on rank 0.  BASELINE.json's metric has two halves, and the default workload (`all`) measures both in one
+line: the top-level fields are images/sec of the cubercnn_DLA34_FPN training step (batch 4/GPU, synthetic 512x512 Omni3D-shaped
+inputs, configs[1] / configs[2]), the `iou3d` object is configs[4] (100k dt x gt box pairs per GPU through box3d_overlap) with
+its own roofline and CPU baseline.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself, one process per GPU, the way the
+reference's script does (tools/train_net.py:500-510 `launch(main, args.num_gpus, ...)`): bench.py re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`.  Launched under torchrun by somebody
+else (WORLD_SIZE set) it is one rank of that job.  Rank 0 reports `n_gpus` = the world size it observed, plus `ranks_observed`
+(an all-reduce of ones) and the device every rank ran on.
 """
 import argparse
 import ctypes
@@ -26,39 +33,88 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = 157.3 TFLOP/s dense
 
 
+# OMNI_BENCH_DEVICE=cpu exists for the GPU-less CI only (tests/test_bench_cli.py): the kernels then have to come from somewhere
+# else than libomni3d_hip.so -- the test environment installs the host-compiled build of the same kernel sources -- and the
+# line says "device": "cpu".  bench.py itself never installs anything: without that test seam every launcher refuses CPU tensors.
+DEVICE = os.environ.get("OMNI_BENCH_DEVICE", "cuda")
+ONE_DEVICE = os.environ.get("OMNI_BENCH_ONE_DEVICE") == "1"      # functional check of N > 1 on a 1-GPU box: all ranks on cuda:0
+
+
+def spawn_ranks(ngpus):
+    """--gpus N without a launcher: start N ranks of this script (one process per GPU over RCCL), hand their exit code back.
+    Counterpart of the reference's `launch(main, args.num_gpus, num_machines=1, dist_url=...)`, tools/train_net.py:500-510."""
+    import socket
+    import subprocess
+    if DEVICE == "cuda" and not ONE_DEVICE and torch.cuda.device_count() < ngpus:
+        sys.exit(f"bench.py --gpus {ngpus}: this node shows {torch.cuda.device_count()} GPU(s); one process per GPU is the measured "
+                 "configuration (OMNI_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0 over gloo as a functional check)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // ngpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def setup_dist(ngpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    info = {"backend": None, "device": DEVICE}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # OMNI_BENCH_BACKEND=gloo + OMNI_BENCH_ONE_DEVICE=1: functional check of the N > 1 path on a 1-GPU box
-        # (all ranks share cuda:0, collectives go through the host); the measured configuration is RCCL, one GPU per rank
-        backend = os.environ.get("OMNI_BENCH_BACKEND", "nccl")
-        if os.environ.get("OMNI_BENCH_ONE_DEVICE") == "1":
+        # the measured configuration is RCCL ("nccl"), one GPU per rank; ranks that share a device (OMNI_BENCH_ONE_DEVICE=1) or
+        # run on the host (OMNI_BENCH_DEVICE=cpu) exchange through gloo
+        backend = os.environ.get("OMNI_BENCH_BACKEND", "gloo" if (ONE_DEVICE or DEVICE != "cuda") else "nccl")
+        if ONE_DEVICE:
             local = 0
-        torch.cuda.set_device(local)
+        if DEVICE == "cuda":
+            torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    else:
+        info["backend"] = "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend
+    elif DEVICE == "cuda":
         torch.cuda.set_device(0)
-    return world, rank, local
+    if ngpus != world:
+        raise SystemExit(f"bench.py --gpus {ngpus} but the launcher started {world} rank(s)")
+    return world, rank, local, info
+
+
+def observe_ranks(world, local, info):
+    """what the job really was: number of ranks that answer an all-reduce of ones, and the device of each"""
+    if world == 1:
+        info.update(ranks_observed=1, devices=[f"{DEVICE}:0" if DEVICE == "cuda" else DEVICE])
+        return info
+    ones = torch.ones(1, device=DEVICE)
+    dist.all_reduce(ones)
+    devs = [None] * world
+    dist.all_gather_object(devs, f"cuda:{local}" if DEVICE == "cuda" else "cpu")
+    info.update(ranks_observed=int(ones.item()), devices=devs, one_gpu_per_rank=DEVICE == "cuda" and len(set(devs)) == world)
+    return info
+
+
+def dev_sync():
+    if DEVICE == "cuda":
+        torch.cuda.synchronize()
 
 
 def barrier_sync(world):
-    torch.cuda.synchronize()
+    dev_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
 
 
 def max_over_ranks(x, world):
     if world == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    t = torch.tensor([x], dtype=torch.float64, device=DEVICE)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -66,16 +122,41 @@ def max_over_ranks(x, world):
 from omni3d_amd.profile_io import profile_counters  # noqa: E402
 
 
+class _Timer:
+    """HIP events on torch's current stream (the stream the launchers use); host clock when the kernels run emulated on the CPU"""
+    def __init__(self):
+        self.cuda = DEVICE == "cuda"
+        self.a, self.b = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.cuda else (None, None)
+
+    def start(self):
+        if self.cuda:
+            self.a.record()
+        else:
+            self.t0 = time.perf_counter()
+
+    def stop(self):
+        if self.cuda:
+            self.b.record()
+        else:
+            self.t1 = time.perf_counter()
+
+    def ms(self):
+        return self.a.elapsed_time(self.b) if self.cuda else 1e3 * (self.t1 - self.t0)
+
+
+IOU_PAIRS = int(os.environ.get("OMNI_BENCH_IOU_PAIRS", "100000"))      # BASELINE configs[4]: 100k; smaller only for the emulated CI run
+
+
 def run_iou3d(args, world, rank):
     """One step = one pass of box3d_overlap's work over 100k (dt, gt) pairs resident in HBM.
     Pairs are independent, so ranks shard them with no collective (weak scaling)."""
     import boxgen
     from omni3d_amd.kernels import iou3d
-    P = 100_000
+    P = IOU_PAIRS
     rng = np.random.default_rng(1000 + rank)
     dt, gt, _ = boxgen.omni3d_like_pairs(rng, P)
-    d, g = torch.from_numpy(dt).cuda(), torch.from_numpy(gt).cuda()
-    ar = torch.arange(P, dtype=torch.int32, device="cuda")
+    d, g = torch.from_numpy(dt).to(DEVICE), torch.from_numpy(gt).to(DEVICE)
+    ar = torch.arange(P, dtype=torch.int32, device=DEVICE)
 
     def step():
         valid, _ = iou3d.box3d_validity(d)
@@ -83,44 +164,52 @@ def run_iou3d(args, world, rank):
 
     for _ in range(args.warmup):
         step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [_Timer() for _ in range(args.steps)]
     barrier_sync(world)
     t0 = time.perf_counter()
-    for a, b in ev:
+    for e in ev:
         valid, _ = iou3d.box3d_validity(d)
-        a.record()
+        e.start()
         out = iou3d.iou_box3d_pairs(d, g, ar, ar, valid1=valid)[1]
-        b.record()
+        e.stop()
     barrier_sync(world)
     dt_s = max_over_ranks(time.perf_counter() - t0, world)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = float(np.mean([e.ms() for e in ev]))
     alg_bytes = P * (192 + 4)
-    pmc = profile_counters("r02_pmc_iou3d.csv", "iou_box3d_kernel")
+    pmc = profile_counters(IOU_PMC, "iou_box3d_kernel") or profile_counters("r02_pmc_iou3d.csv", "iou_box3d_kernel")
     res = {
         "metric": "IoU3D box pairs/sec (box3d_overlap, 100k dt x gt pairs)", "value": P * world * args.steps / dt_s,
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt_s / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "iou3d: 100k Omni3D-shaped oriented box pairs (50% overlapping, 1% degenerate)",
+        "config": {"workload": f"iou3d: {P} Omni3D-shaped oriented box pairs per GPU (50% overlapping, 1% degenerate)",
                    "pairs_per_gpu": P, "parallelism": f"pairs sharded x{world}, no collective"},
         # IoU3D is neither HBM- nor MFMA-bound (196 B of I/O against ~1e4 branchy scalar flops per pair): the
         # required `roofline` object carries the HBM sanity bound, `valu` the issue-side utilisation from the committed PMC pass
-        "roofline": {"bound": "hbm", "kernel": "iou_box3d_kernel<1>", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "iou_box3d_kernel", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": (pmc["FETCH_SIZE_x2_MB"] + pmc["WRITE_SIZE_MB"]) * 1e6 if pmc and pmc.get("FETCH_SIZE_x2_MB") and pmc.get("WRITE_SIZE_MB") else None,
                      "kernel_ms": kern_ms, "pairs_per_s_kernel": P / (kern_ms * 1e-3),
-                     "note": "196 B/pair algorithmic I/O; the kernel is VALU / branch bound, not HBM bound",
+                     "note": "196 B/pair algorithmic I/O; the kernel is VALU / branch bound, not HBM bound: `valu` is the issue-side "
+                             "utilisation (VALU-active share of the wave cycles) from the committed PMC pass",
                      "valu": pmc},
     }
-    if rank == 0:
-        res["cpu_baseline"] = cpu_baseline_iou3d(dt, gt)
+    if rank == 0:       # the CPU leg is reported at N = 1 only (the other ranks would wait on it)
+        res["cpu_baseline"] = cpu_baseline_iou3d(dt, gt) if world == 1 else {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port",
+                                                                               "sample": "reported at N=1 only"}
     return res
+
+
+IOU_PMC = "r03_pmc_iou3d.csv"
 
 
 def cpu_baseline_iou3d(dt, gt, nsample=20000):
     """the restated pytorch3d algorithm (oracle/iou_box3d_oracle.c) single-thread, OpenMP on all host cores, and
     the PYTHON-LOOP form the reference really runs (omni3d_evaluation.py:1339-1343: one box3d_overlap call per (image, category)
     group from a dict comprehension) -- each on a bounded sample of the same pairs."""
+    if os.environ.get("OMNI_BENCH_SKIP_CPU") == "1":       # profiling runs: do not spend GPU-box minutes on the CPU leg
+        return {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "skipped (OMNI_BENCH_SKIP_CPU=1)"}
+    nsample = min(nsample, len(dt))
     cores = min(len(os.sched_getaffinity(0)), 64)          # OpenMP team of the all-cores leg (set before libgomp starts)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
@@ -171,9 +260,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None)
+    ap.add_argument("--workload", default=None, choices=[None, "all", "train", "iou3d", "infer"])
     args = ap.parse_args()
-    world, rank, _ = setup_dist(args.gpus)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    world, rank, local, info = setup_dist(args.gpus)
     workload = args.workload or DEFAULT_WORKLOAD
     if workload == "iou3d":
         res = run_iou3d(args, world, rank)
@@ -183,14 +274,26 @@ def main():
     else:
         from omni3d_amd.bench_train import run_train
         res = run_train(args, world, rank)
+        if workload == "all":
+            # second half of BASELINE.json's metric ("...; IoU3D boxes/sec", configs[4]) in the same driver-run line
+            io = run_iou3d(args, world, rank)
+            if rank == 0:
+                res["iou3d"] = {k: io[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype",
+                                                   "config", "roofline", "cpu_baseline")}
+    observe_ranks(world, local, info)
     if rank == 0:
+        res["n_gpus"] = world
+        res["launch"] = info
+        if DEVICE != "cuda" or (world > 1 and not info.get("one_gpu_per_rank")):
+            res["functional_check_only"] = ("ranks share a device or run host-compiled kernels: this line checks the N-rank code path, "
+                                            "its numbers are not measurements of the product")
         print(json.dumps(res))
     if world > 1:
         dist.barrier()      # rank 0 times the roofline kernels after the step loop: leave together
         dist.destroy_process_group()
 
 
-DEFAULT_WORKLOAD = "train"
+DEFAULT_WORKLOAD = "all"
 
 if __name__ == "__main__":
     main()

@@ -13,7 +13,17 @@ from .functional import total_loss
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FP32_MFMA_PEAK_TF = 157.3          # MI355X_MICROARCH.md: f32-input MFMA, dense
 TRAIN_GFLOP_PER_IMAGE = 307.8      # fwd 103.0 GFLOP, fwd+dgrad+wgrad 307.8 GFLOP
-IMS_PER_GPU = 4
+IMS_PER_GPU = int(os.environ.get("OMNI_BENCH_IMS", "4"))        # BASELINE: 4 images / GPU
+IMAGE_SIZE = int(os.environ.get("OMNI_BENCH_SIZE", "512"))       # BASELINE: 512 x 512
+DEVICE = os.environ.get("OMNI_BENCH_DEVICE", "cuda")             # "cpu" only in the GPU-less CI (tests/test_bench_cli.py), see bench.py
+# extra `KEY value ...` config overrides; like OMNI_BENCH_IMS / _SIZE they make the line a functional check (`nonstandard`)
+OVERRIDES = os.environ.get("OMNI_BENCH_OVERRIDES", "").split()
+NONSTANDARD = IMS_PER_GPU != 4 or IMAGE_SIZE != 512 or bool(OVERRIDES) or DEVICE != "cuda"
+
+
+def _sync():
+    if DEVICE == "cuda":
+        torch.cuda.synchronize()
 
 
 # BASELINE.json configs[1] by default; OMNI_BENCH_CONFIG=cubercnn_ResNet34_FPN.yaml selects configs[3]'s model
@@ -21,7 +31,7 @@ CONFIG = os.environ.get("OMNI_BENCH_CONFIG", "cubercnn_DLA34_FPN.yaml")
 MODEL_NAME = CONFIG.replace("cubercnn_", "").replace(".yaml", "")
 
 
-def build(world, device="cuda", seed=0):
+def build(world, device=DEVICE, seed=0):
     from omni3d_amd import synthetic
     from omni3d_amd.cubercnn.config import get_cfg_defaults
     from omni3d_amd.cubercnn.modeling import backbone, proposal_generator, roi_heads  # noqa: F401 (registrations)
@@ -35,6 +45,8 @@ def build(world, device="cuda", seed=0):
     # README.md:123-132 scaling rule of the reference: lr scales with the batch (0.12 at 192 images)
     cfg.merge_from_list(["MODEL.DEVICE", device, "VIS_PERIOD", 0, "MODEL.WEIGHTS", "synthetic://random-init",
                          "SOLVER.IMS_PER_BATCH", ims, "SOLVER.BASE_LR", 0.12 * ims / 192.0])
+    if OVERRIDES:
+        cfg.merge_from_list(OVERRIDES)
     priors = synthetic.make_priors(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
     torch.manual_seed(seed)
     model = build_model(cfg, priors)
@@ -43,7 +55,7 @@ def build(world, device="cuda", seed=0):
     return cfg, model, opt, priors
 
 
-def stage_batch(model, priors, rank, n=IMS_PER_GPU, size=512):
+def stage_batch(model, priors, rank, n=IMS_PER_GPU, size=IMAGE_SIZE):
     from omni3d_amd import synthetic
     batch = synthetic.make_batch(n, size, size, num_gt=8, seed=1000 + rank, priors=priors)
     packed = model.prepack(batch)
@@ -63,7 +75,7 @@ def run_train(args, world, rank):
     from omni3d_amd.cubercnn.solver.guard import StepGuard
     LOSS_NAMES = ["BoxHead/loss_cls", "BoxHead/loss_box_reg", "Cube/uncert", "Cube/loss_dims", "Cube/loss_xy", "Cube/loss_z",
                   "Cube/loss_pose", "Cube/loss_joint", "rpn/cls", "rpn/loc"]
-    guard = StepGuard(LOSS_NAMES, cfg.MODEL.STABILIZE, cfg.SOLVER.CHECKPOINT_PERIOD, "cuda")
+    guard = StepGuard(LOSS_NAMES, cfg.MODEL.STABILIZE, cfg.SOLVER.CHECKPOINT_PERIOD, DEVICE)
     opt.skip_flag = guard.skip
     loss_log, skipped_log = [], []
 
@@ -91,7 +103,7 @@ def run_train(args, world, rank):
     # backward is cut at the FPN features into two graphs so the all-reduce of the heads' gradients (61 % of the
     # bytes) runs beside the backbone's backward (GraphedTwoPhase); the collective sequence is the same on every
     # rank whether or not its capture succeeded.
-    use_graph = os.environ.get("OMNI_BENCH_GRAPH", "1") != "0"
+    use_graph = os.environ.get("OMNI_BENCH_GRAPH", "1") != "0" and DEVICE == "cuda"
     two_phase = world > 1 or os.environ.get("OMNI_BENCH_TWO_PHASE") == "1"
     graphed, graph_note = None, "eager (OMNI_BENCH_GRAPH=0)"
     from omni3d_amd.cubercnn.solver.graphed import GraphedForwardBackward, GraphedPipelined, GraphedTwoPhase
@@ -134,39 +146,42 @@ def run_train(args, world, rank):
 
     # executed (Winograd-aware) flops of one step: count the multiply-adds of every MFMA launch during one eager step
     from omni3d_amd.profile_io import ExecutedFlops
-    with ExecutedFlops() as counter:
-        eager_step()
-    executed_flops = counter.flops
+    executed_flops = 0.0
+    if DEVICE == "cuda":
+        with ExecutedFlops() as counter:
+            eager_step()
+        executed_flops = counter.flops
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    _sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     t_enqueue = time.perf_counter() - t0       # host time to enqueue the K steps (diagnostic: < dt means GPU-bound)
-    torch.cuda.synchronize()
+    _sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_losses = [float(v) for v in torch.stack(loss_log[-args.steps:]).cpu()]
     ims = IMS_PER_GPU * world * args.steps / dt
-    step_tf = TRAIN_GFLOP_PER_IMAGE * 1e9 * IMS_PER_GPU * args.steps / dt / 1e12   # per GPU
+    step_tf = TRAIN_GFLOP_PER_IMAGE * 1e9 * IMS_PER_GPU * args.steps / dt / 1e12   # per GPU (the per-image figure is for 512 x 512)
     res = {
-        "metric": f"images/sec train {MODEL_NAME} b=4/GPU", "value": ims, "unit": "images/s", "n_gpus": world,
+        "metric": f"images/sec train {MODEL_NAME} b={IMS_PER_GPU}/GPU", "value": ims, "unit": "images/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"cubercnn_{MODEL_NAME} train step, batch 4/GPU, synthetic Omni3D 512x512 (8 GT/img), "
+        "config": {"workload": f"cubercnn_{MODEL_NAME} train step, batch {IMS_PER_GPU}/GPU, synthetic Omni3D {IMAGE_SIZE}x{IMAGE_SIZE} (8 GT/img), "
                                "fwd+10 losses+bwd+allreduce+divergence guard+SGD, random-init weights",
-                   "global_batch": IMS_PER_GPU * world, "image": "512x512", "parallelism": f"dp{world} (flat-bucket RCCL all-reduce)"},
+                   "global_batch": IMS_PER_GPU * world, "image": f"{IMAGE_SIZE}x{IMAGE_SIZE}",
+                   "parallelism": f"dp{world} (flat-bucket RCCL all-reduce)"},
         "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
         "launch_mode": graph_note,
         "step_mfma_frac": step_tf / FP32_MFMA_PEAK_TF,
@@ -180,7 +195,12 @@ def run_train(args, world, rank):
         "skipped_steps": int(torch.stack(skipped_log[-args.steps:]).sum().item()),
         "guard": "rolling-loss divergence test + NaN/Inf gradient scan + retry decision on the device, one 12-float all-reduce/step",
     }
-    if rank == 0:
+    if NONSTANDARD:
+        res["nonstandard"] = {"ims_per_gpu": IMS_PER_GPU, "image_size": IMAGE_SIZE, "overrides": OVERRIDES, "device": DEVICE,
+                              "note": "not BASELINE.json's configuration: functional check only"}
+    if rank == 0 and DEVICE != "cuda":
+        res["roofline"], res["cpu_baseline"] = None, None
+    elif rank == 0:
         res["roofline"] = dominant_kernel_roofline()
         res["hbm_bound_kernels"] = hbm_bound_kernels(opt)
         if world == 1:   # the CPU leg is reported at N = 1 only (a minute of host work the other ranks would wait on)

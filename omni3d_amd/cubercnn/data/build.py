@@ -112,12 +112,52 @@ def build_detection_train_loader(cfg, mapper=None, *, dataset=None, sampler=None
     total = cfg.SOLVER.IMS_PER_BATCH if total_batch_size is None else total_batch_size
     world = comm.get_world_size()
     assert total > 0 and total % world == 0, "Total batch size ({}) must be divisible by the number of gpus ({}).".format(total, world)
-    return _TrainLoader(dataset, mapper, total // world, seed=int(getattr(cfg, "SEED", 0) if getattr(cfg, "SEED", -1) >= 0 else 0),
-                        repeat_factors=rf)
+    seed = int(getattr(cfg, "SEED", -1))
+    if seed < 0:          # detectron2 TrainingSampler: no configured seed = one random seed shared by all ranks
+        seed = comm.shared_random_seed()
+    return _TrainLoader(dataset, mapper, total // world, seed=seed, repeat_factors=rf)
 
 
-class _TestLoader(list):
-    pass
+class _TestLoader:
+    """Lazy batches over this rank's shard: a batch is decoded / resized when the evaluation loop asks for it (optionally one
+    batch of look-ahead in a helper thread; off by default because the mapper's resize launches device work on the caller's
+    stream), never the whole split up front -- Omni3D's test splits are tens of thousands of images.
+    Shards are detectron2 InferenceSampler's: contiguous ranges, the first `len % world` ranks one image longer, so the
+    gathered predictions keep the dataset order."""
+
+    def __init__(self, dataset, mapper, batch_size, rank, world, prefetch=False):
+        self.dataset, self.mapper, self.batch_size, self.prefetch = dataset, mapper, max(int(batch_size), 1), prefetch
+        n = len(dataset)
+        size, extra = n // world, n % world
+        self.begin = size * rank + min(rank, extra)
+        self.end = self.begin + size + (1 if rank < extra else 0)
+
+    def __len__(self):
+        return (self.end - self.begin + self.batch_size - 1) // self.batch_size
+
+    def _batch(self, k):
+        lo = self.begin + k * self.batch_size
+        return [self.mapper(self.dataset[i]) for i in range(lo, min(lo + self.batch_size, self.end))]
+
+    def __getitem__(self, k):
+        if not 0 <= k < len(self):
+            raise IndexError(k)
+        return self._batch(k)
+
+    def __iter__(self):
+        n = len(self)
+        if not self.prefetch or n <= 1:
+            for k in range(n):
+                yield self._batch(k)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(self._batch, 0)
+            for k in range(n):
+                cur = nxt.result()
+                if k + 1 < n:
+                    nxt = pool.submit(self._batch, k + 1)
+                yield cur
 
 
 def build_detection_test_loader(cfg=None, dataset_name=None, mapper=None, *, dataset=None, batch_size=1, num_workers=0):
@@ -126,8 +166,4 @@ def build_detection_test_loader(cfg=None, dataset_name=None, mapper=None, *, dat
     if mapper is None:
         from .dataset_mapper import DatasetMapper3D
         mapper = DatasetMapper3D(cfg, False)
-    rank, world = comm.get_rank(), comm.get_world_size()
-    shard = dataset[rank::world]                                                  # InferenceSampler shards contiguous-ish ranges
-    out = _TestLoader([[mapper(d) for d in shard[i:i + batch_size]] for i in range(0, len(shard), batch_size)])
-    out.dataset = dataset
-    return out
+    return _TestLoader(dataset, mapper, batch_size, comm.get_rank(), comm.get_world_size())

@@ -29,22 +29,45 @@ def pack_targets(batched_inputs, image_sizes, virtual_focal=512.0, with_gt=True)
     return pack_instances(insts, image_sizes, Ks, ratios, virtual_focal)
 
 
-_cache = {"key": None, "val": None}
+_cache = {"insts": None, "elems": [], "sizes": None, "Ks": None, "ratios": None, "val": None}
+
+
+def _same_scalars(a, b):
+    """Ks / ratios of two calls: equal values (they are a handful of floats per image; never trust identity here)"""
+    if a is None or b is None:
+        return a is None and b is None
+    if len(a) != len(b):
+        return False
+    for x, y in zip(a, b):
+        x = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x, dtype=np.float64)
+        y = y.detach().cpu().numpy() if isinstance(y, torch.Tensor) else np.asarray(y, dtype=np.float64)
+        if x.shape != y.shape or not np.array_equal(x, y):
+            return False
+    return True
 
 
 def pack_instances_cached(insts, image_sizes, Ks=None, ratios=None, virtual_focal=512.0, device=None):
-    """`pack_instances` memoised on the IDENTITY of the gt list: the reference's RCNN3D.forward hands the same
-    `gt_instances` list to the proposal generator (rcnn3d.py:65) and to the ROI heads (:70), so when this package's modules
-    are driven through the reference's contracts (list[Instances]) the ground truth is still packed / copied to the device
-    once per step.  The entry without intrinsics (RPN) is upgraded when the ROI heads supply Ks / ratios."""
-    key = (id(insts), len(insts), tuple(map(tuple, image_sizes)))
-    hit = _cache["val"] if _cache["key"] == key else None
-    if hit is not None and (Ks is None or hit.has_intrinsics):
-        return hit
+    """`pack_instances` memoised on the gt list OBJECT: the reference's RCNN3D.forward hands the same `gt_instances` list to the
+    proposal generator (rcnn3d.py:65) and to the ROI heads (:70), so when this package's modules are driven through the
+    reference's contracts (list[Instances]) the ground truth is still packed / copied to the device once per step.  The cache
+    keeps a strong reference to that list and compares with `is` (CPython recycles the address of a dead list at once, so an
+    id() key would hand the previous step's targets to a new list), every element must be the same object too (a caller may
+    refill a list in place), and an entry made with intrinsics is only reused for EQUAL intrinsics / ratios.  The entry without
+    intrinsics (RPN) is upgraded when the ROI heads supply Ks / ratios."""
+    sizes = tuple(map(tuple, image_sizes))
+    hit = None
+    if (insts is not None and _cache["insts"] is insts and _cache["sizes"] == sizes and len(insts) == len(_cache["elems"])
+            and all(a is b for a, b in zip(insts, _cache["elems"])) and any(a is not None for a in insts)):
+        hit = _cache["val"]
+    if hit is not None:
+        if Ks is None:
+            return hit
+        if hit.has_intrinsics and _same_scalars(Ks, _cache["Ks"]) and _same_scalars(ratios, _cache["ratios"]):
+            return hit
     t = pack_instances(insts, image_sizes, Ks, ratios, virtual_focal)
     if device is not None:
         t = t.to(device)
-    _cache["key"], _cache["val"] = key, t
+    _cache.update(insts=insts, elems=list(insts) if insts is not None else [], sizes=sizes, Ks=Ks, ratios=ratios, val=t)
     return t
 
 

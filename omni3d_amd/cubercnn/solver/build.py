@@ -56,6 +56,10 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.skip_flag = None   # optional device float: != 0 skips the update inside the kernel
         self._grad_scale = 1.0  # consumed by the next step(): 1/world when the all-reduce left SUMS in the bucket
         self._exchanged = False  # did this step's gradients go through all_reduce_begin / all_reduce_finish?
+        # step() averages the bucket itself when a process group with > 1 rank exists and nobody exchanged this step's
+        # gradients.  build_optimizer switches it off when somebody else owns the exchange (a DistributedDataParallel wrapper
+        # whose reducer already averaged the gradients: a second pass over the 191.6 MB bucket would only cost time)
+        self.exchange_in_step = True
 
     def _build_buckets(self):
         plist = [(g, p) for g in self.param_groups for p in g["params"]]
@@ -70,7 +74,9 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_state = {name: torch.zeros(total, dtype=torch.float32, device=dev) for name in self.STATE}
-        self.segments = []   # (start, end, representative group)
+        # (start, end, index of a representative group in self.param_groups).  An INDEX, not the dict: torch's
+        # Optimizer.load_state_dict replaces the group dicts, and the LR scheduler then writes to the new ones
+        self.segments = []
         self._slot = {}      # id(param) -> (offset, numel) inside the flat buckets
         off = 0
         # Inside a class, parameters whose gradients complete EARLY in backward (the heads: everything that is not the
@@ -102,7 +108,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 self.late_ranges.append((start, mid))
             if off > mid:
                 self.early_ranges.append((mid, off))
-            self.segments.append((start, off, items[0][0]))
+            self.segments.append((start, off, next(i for i, g in enumerate(self.param_groups) if g is items[0][0])))
 
     def set_direct_accumulate(self, flag):
         self._direct = bool(flag)
@@ -193,7 +199,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         from ... import functional as HF
         HF.side_join()
         self._rebind_grads()
-        if not self._exchanged:
+        if not self._exchanged and self.exchange_in_step:
             # Data-parallel safety net.  The reference's loop (tools/train_net.py:449-454) relies on DistributedDataParallel's
             # autograd hooks for the gradient exchange; with direct accumulation the weight gradients never pass through
             # autograd, so those hooks would see nothing.  If the process group has more than one rank and nobody called
@@ -227,7 +233,8 @@ class FlatSGD(_FlatOptimizer):
 
     def _step_segments(self):
         first = self._steps == 0
-        for start, end, g in self.segments:
+        for start, end, gi in self.segments:
+            g = self.param_groups[gi]          # looked up at step time: hyper-parameters are whatever the live groups say now
             det.sgd_step(self.flat_param[start:end], self.flat_grad[start:end], self.flat_mom[start:end], g["lr"],
                          g["momentum"], g["dampening"], g["weight_decay"], g["nesterov"], first_step=first, skip_flag=self.skip_flag,
                          grad_scale=self._grad_scale)
@@ -291,7 +298,8 @@ class FlatAdam(_FlatOptimizer):
     def _step_segments(self):
         det.adam_tick(self.dev_step, self.skip_flag)
         st = self.flat_state
-        for start, end, g in self.segments:
+        for start, end, gi in self.segments:
+            g = self.param_groups[gi]
             vmax = st["max_exp_avg_sq"][start:end] if g["amsgrad"] else None
             det.adam_step(self.flat_param[start:end], self.flat_grad[start:end], st["exp_avg"][start:end], st["exp_avg_sq"][start:end],
                           vmax, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.decoupled, self.dev_step,

@@ -70,6 +70,36 @@ def test_flat_sgd_state_dict_is_torch_sgd_format(emu_lib):
     _same(a, b); _same(a, a2); _same(a, b2)
 
 
+@pytest.mark.parametrize("kind", ["sgd", "adam"])
+def test_lr_schedule_reaches_the_kernel_after_load_state_dict(emu_lib, kind):
+    """torch's Optimizer.load_state_dict REPLACES the param_group dicts.  The fused step must read the live
+    groups, else a resumed run (tools/train_net.py:128 resume_or_load, the divergence retry) trains at the constructor's lr for
+    ever while the scheduler writes to dicts nobody reads."""
+    from omni3d_amd.cubercnn.solver.build import FlatAdam
+    a, b = _nets()
+    if kind == "sgd":
+        fo, to = _flat(a), _torch(b)
+    else:
+        groups = lambda net: [{"params": [p], "lr": 0.1, "weight_decay": wd} for p, wd in zip(net.parameters(), (1e-2, 0.0, 1e-2, 0.0))]  # noqa: E731
+        fo, to = FlatAdam(groups(a), 0.1, eps=1e-2, direct_accumulate=False), torch.optim.Adam(groups(b), 0.1, eps=1e-2)
+    for net, opt in ((a, fo), (b, to)):
+        opt.zero_grad(); _loss(net, 0).backward(); opt.step()
+    fo.load_state_dict(fo.state_dict())
+    to.load_state_dict(to.state_dict())
+    assert all(fo.param_groups[gi] is not None for _, _, gi in fo.segments)
+    sched_f = torch.optim.lr_scheduler.LambdaLR(fo, lambda it: 0.01)       # what build_lr_scheduler does after a resume
+    sched_t = torch.optim.lr_scheduler.LambdaLR(to, lambda it: 0.01)
+    assert abs(fo.param_groups[0]["lr"] - 1e-3) < 1e-12
+    before = [p.detach().clone() for p in a.parameters()]
+    for net, opt in ((a, fo), (b, to)):
+        opt.zero_grad(); _loss(net, 1).backward(); opt.step()
+    sched_f.step(); sched_t.step()
+    _same(a, b, 2e-6)
+    # and the step really was a small-lr step: two orders of magnitude below what lr 0.1 would have moved
+    moved = max(float((p - q).abs().max()) for p, q in zip(a.parameters(), before))
+    assert 0 < moved < 5e-3, moved
+
+
 def test_flat_sgd_rejects_partial_momentum_state(emu_lib):
     a, b = _nets()
     fo, to = _flat(a), _torch(b)
