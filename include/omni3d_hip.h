@@ -32,6 +32,13 @@ int omni_iou_box3d_pairs(const float* boxes1, const float* boxes2, const int* id
                          long long npairs, const int* valid1, float* vol, float* iou, int* overflow,
                          void* stream);
 
+/* The same with the number of lanes a pair occupies chosen by the caller: lanes_per_pair 64 | 32 | 16 = 1 | 2 | 4 pairs per
+ * wavefront (0 = the production choice, 32).  Every width computes the same per-pair algorithm (same triangle order, same
+ * epsilon decisions); used by the parity tests and by tools/bench_iou3d.py.  Replaces the same call site as above. */
+int omni_iou_box3d_pairs_algo(const float* boxes1, const float* boxes2, const int* idx1, const int* idx2,
+                              long long npairs, const int* valid1, float* vol, float* iou, int* overflow,
+                              int lanes_per_pair, void* stream);
+
 /* _check_coplanar (omni3d_evaluation.py:65-86) and _check_nonzero (:89-104) fused:
  * valid[i] = coplanar(i) && nonzero(i); counts [nullable, int32[2]] += {#non-coplanar, #zero}. */
 int omni_box3d_validity(const float* boxes, int N, float eps_coplanar, float eps_nonzero, int* valid,

@@ -397,4 +397,7 @@ def cpu_baseline_train(priors):
         from oracle import model_oracle
     except Exception as e:  # noqa: BLE001
         return {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
-    return model_oracle.time_training(priors)
+    try:
+        return model_oracle.time_training(priors)
+    except Exception as e:  # noqa: BLE001 -- a failing CPU leg must never take the measured line down with it
+        return {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {str(e)[:200]}"}

@@ -5,8 +5,8 @@
 // and the validity masks _check_coplanar (:65-86) / _check_nonzero (:89-104).
 //
 // MI355X mapping (NOT the upstream CUDA thread-per-pair + per-thread scratch design):
-//   * one 64-lane wavefront owns one (dt, gt) pair; workgroup = one wave, so the LDS region is
-//     private to the wave and __syncthreads() is a wave-local fence
+//   * a 32-lane half of a wavefront owns one (dt, gt) pair (two pairs per wave; 64 / 16 lanes per pair selectable);
+//     workgroup = one wave, so the LDS region is private to the wave and __syncthreads() is a wave-local fence
 //   * both clip directions (tris(box1) vs planes(box2) and tris(box2) vs planes(box1)) live in one
 //     LDS triangle list, lanes = triangles; every plane pass is clip -> ballot prefix -> stable
 //     compaction into the other LDS buffer, so triangle order equals the sequential algorithm
@@ -141,44 +141,71 @@ __device__ __forceinline__ int clip_tri(const V3* pv, V3 pc, V3 normal, const Tr
     return 1;
 }
 
-struct WaveLds {
+// LDS of ONE pair.  After the six plane passes the spare ping-pong buffer holds the dedupe phase's per-triangle unit normals
+// [CAP*3], areas [CAP] and box2 keep flags [CAP] (5 of its 9 floats per triangle).
+struct PairLds {
     float tri[2][CAP * 9];   // ping-pong triangle lists
-    float nrm[CAP * 3];      // per-triangle unit normals (dedupe phase)
-    float area[CAP];         // per-triangle areas (dedupe phase)
     float box[2][24];        // the two boxes' corners
     float pc[2][6][3];       // face-plane centres
     float pn[2][6][3];       // face-plane normals, pointing inside
     float vol[2];            // box volumes
-    int keep[CAP];           // box2-triangle keep flags
 };
 
-// MODE 0: matrix (pair p -> a = p / M, b = p % M); MODE 1: indexed pairs
-template <int MODE>
+// MODE 0: matrix (pair p -> a = p / M, b = p % M); MODE 1: indexed pairs.
+// SUB = lanes per pair: a wave works on G = 64 / SUB pairs side by side (round 3).  A pair's joint triangle list starts with 24
+// entries and rarely exceeds 40, so with one pair per wave at most ~40 of the 64 lanes ever had a triangle (PMC round 2: VALU
+// active 44 % of the wave cycles); sub-groups of 32 lanes run two pairs through the same instruction stream.  Every ballot is
+// taken over the wave and cut to the sub-group's bit range, loops that contain wave-level operations run to the maximum trip
+// count over the sub-groups, and each sub-group keeps its own LDS lists, so the per-pair algorithm -- including the order of
+// the triangles, which the epsilon rules depend on -- is unchanged.
+template <int MODE, int SUB>
 __global__ void __launch_bounds__(64) iou_box3d_kernel(const float* __restrict__ boxes1, const float* __restrict__ boxes2,
                                                        const int* __restrict__ idx1, const int* __restrict__ idx2,
                                                        const int* __restrict__ valid1, long long npairs, int M,
                                                        float* __restrict__ vol_out, float* __restrict__ iou_out,
                                                        int* __restrict__ overflow) {
-    __shared__ WaveLds L;
-    const int lane = threadIdx.x;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    constexpr int G = 64 / SUB;
+    __shared__ PairLds Lall[G];
+    const int lane = threadIdx.x, g = lane / SUB, sl = lane % SUB;
+    PairLds& L = Lall[g];
+    const int shift = g * SUB;
+    const unsigned long long sub_all = (SUB == 64) ? ~0ull : ((1ull << (SUB & 63)) - 1ull);
+    const unsigned long long sub_lt = (sl == 0) ? 0ull : (~0ull >> (64 - sl));      // sub-group lanes below this one
+    auto group_max = [&](int v) {                    // maximum over the wave's sub-groups (v is uniform inside a sub-group)
+#pragma unroll
+        for (int m = SUB; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m, 64));
+        return v;
+    };
+    auto group_sum = [&](float v) {                  // sum over the lanes of this sub-group
+#pragma unroll
+        for (int m = SUB / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    };
 
-    for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
-        int ia, ib;
-        if (MODE == 0) { ia = (int)(p / M); ib = (int)(p % M); }
-        else { ia = idx1[p]; ib = idx2[p]; }
-        if (valid1 != nullptr && valid1[ia] == 0) {
-            if (lane == 0) { if (vol_out) vol_out[p] = 0.f; iou_out[p] = 0.f; }
-            continue;
+    for (long long pbase = (long long)blockIdx.x * G; pbase < npairs; pbase += (long long)gridDim.x * G) {
+        const long long p = pbase + g;
+        bool act = p < npairs;
+        int ia = 0, ib = 0;
+        if (act) {
+            if (MODE == 0) { ia = (int)(p / M); ib = (int)(p % M); }
+            else { ia = idx1[p]; ib = idx2[p]; }
+            if (valid1 != nullptr && valid1[ia] == 0) {
+                if (sl == 0) { if (vol_out) vol_out[p] = 0.f; iou_out[p] = 0.f; }
+                act = false;
+            }
         }
-        __syncthreads();  // previous pair's LDS reads are done
-        if (lane < 24) L.box[0][lane] = boxes1[(size_t)ia * 24 + lane];
-        else if (lane < 48) L.box[1][lane - 24] = boxes2[(size_t)ib * 24 + (lane - 24)];
+        if (!__any(act)) continue;
+        __syncthreads();  // previous pairs' LDS reads are done
+        if (act)
+            for (int k = sl; k < 48; k += SUB) {
+                if (k < 24) L.box[0][k] = boxes1[(size_t)ia * 24 + k];
+                else L.box[1][k - 24] = boxes2[(size_t)ib * 24 + (k - 24)];
+            }
         __syncthreads();
 
-        // ---- per-box prologue: face planes (lanes 0..11), volumes (lanes 12,13), initial triangles
-        if (lane < 12) {
-            const int bx = lane / 6, f = lane % 6;
+        // ---- per-box prologue: face planes (sub-lanes 0..11), volumes (12, 13), initial triangles (all)
+        if (act && sl < 12) {
+            const int bx = sl / 6, f = sl % 6;
             const float* B = L.box[bx];
             V3 ctr = mk(0.f, 0.f, 0.f);
             for (int t = 0; t < 8; ++t) { ctr.x += B[3 * t]; ctr.y += B[3 * t + 1]; ctr.z += B[3 * t + 2]; }
@@ -200,8 +227,8 @@ __global__ void __launch_bounds__(64) iou_box3d_kernel(const float* __restrict__
             if (vdot(vsub(ctr, pc), n) < 0.0f) n = vscale(n, -1.0f);
             stv(L.pc[bx][f], pc);
             stv(L.pn[bx][f], n);
-        } else if (lane < 14) {
-            const int bx = lane - 12;
+        } else if (act && sl < 14) {
+            const int bx = sl - 12;
             const float* B = L.box[bx];
             V3 ctr = mk(0.f, 0.f, 0.f);
             for (int t = 0; t < 8; ++t) { ctr.x += B[3 * t]; ctr.y += B[3 * t + 1]; ctr.z += B[3 * t + 2]; }
@@ -214,25 +241,28 @@ __global__ void __launch_bounds__(64) iou_box3d_kernel(const float* __restrict__
                 vol += fabsf(vdot(a, vcross(b, c))) / 6.0f;
             }
             L.vol[bx] = vol;
-        } else if (lane >= 32 && lane < 56) {
-            const int t = lane - 32, bx = t / 12, tt = t % 12;
-            const float* B = L.box[bx];
-            float* dst = L.tri[0] + t * 9;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) stv(dst + 3 * k, ldv(B + 3 * c_box_tris[tt][k]));
         }
+        if (act)
+            for (int t = sl; t < 24; t += SUB) {
+                const int bx = t / 12, tt = t % 12;
+                const float* B = L.box[bx];
+                float* dst = L.tri[0] + t * 9;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) stv(dst + 3 * k, ldv(B + 3 * c_box_tris[tt][k]));
+            }
         __syncthreads();
 
         // ---- six plane passes over the joint list: entries [0,nA) are box1 triangles clipped by
         //      box2's planes, entries [nA,n) box2 triangles clipped by box1's planes
-        int n = 24, nA = 12, cur = 0;
+        int n = act ? 24 : 0, nA = act ? 12 : 0, cur = 0;
         bool over = false;
         for (int f = 0; f < 6; ++f) {
             const float* src = L.tri[cur];
             float* dst = L.tri[cur ^ 1];
             int base = 0, newA = 0;
-            for (int i0 = 0; i0 < n; i0 += 64) {
-                const int i = i0 + lane;
+            const int nmax = group_max(n);
+            for (int i0 = 0; i0 < nmax; i0 += SUB) {
+                const int i = i0 + sl;
                 int cnt = 0;
                 Tri o0, o1;
                 if (i < n) {
@@ -243,12 +273,12 @@ __global__ void __launch_bounds__(64) iou_box3d_kernel(const float* __restrict__
                     Tri t = ldtri(src + i * 9);
                     cnt = clip_tri(pv, ldv(L.pc[other][f]), ldv(L.pn[other][f]), t, o0, o1);
                 }
-                const unsigned long long b1 = __ballot(cnt >= 1), b2 = __ballot(cnt == 2);
-                const int off = base + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask);
+                const unsigned long long b1 = (__ballot(cnt >= 1) >> shift) & sub_all, b2 = (__ballot(cnt == 2) >> shift) & sub_all;
+                const int off = base + __popcll(b1 & sub_lt) + __popcll(b2 & sub_lt);
                 if (cnt >= 1) { if (off < CAP) sttri(dst + off * 9, o0); else over = true; }
                 if (cnt == 2) { if (off + 1 < CAP) sttri(dst + (off + 1) * 9, o1); else over = true; }
                 // outputs produced by box1-side entries of this round
-                int nAround = nA - i0; nAround = nAround < 0 ? 0 : (nAround > 64 ? 64 : nAround);
+                int nAround = nA - i0; nAround = nAround < 0 ? 0 : (nAround > SUB ? SUB : nAround);
                 const unsigned long long amask = (nAround >= 64) ? ~0ull : ((1ull << nAround) - 1ull);
                 newA += __popcll(b1 & amask) + __popcll(b2 & amask);
                 base += __popcll(b1) + __popcll(b2);
@@ -259,70 +289,70 @@ __global__ void __launch_bounds__(64) iou_box3d_kernel(const float* __restrict__
             __syncthreads();
         }
         const float* T = L.tri[cur];
-        float* O = L.tri[cur ^ 1];
+        float* aux = L.tri[cur ^ 1];                 // spare list: normals | areas | keep flags of the dedupe phase
+        float* nrm = aux;
+        float* area = aux + 3 * CAP;
+        int* keep = reinterpret_cast<int*>(aux + 4 * CAP);
         const int n1 = nA, n2 = n - nA;
 
         // ---- coplanar duplicate removal: box2 triangle q is dropped if coplanar with some box1
         //      triangle r whose area exceeds aEpsilon
-        for (int i = lane; i < n; i += 64) {
+        for (int i = sl; i < n; i += SUB) {
             Tri t = ldtri(T + i * 9);
-            stv(L.nrm + 3 * i, tri_normal(t));
-            L.area[i] = tri_area(t);
-            L.keep[i] = 1;
+            stv(nrm + 3 * i, tri_normal(t));
+            area[i] = tri_area(t);
+            keep[i] = 1;
         }
         __syncthreads();
         const int npair = n1 * n2;
-        for (int w = lane; w < npair; w += 64) {
+        for (int w = sl; w < npair; w += SUB) {
             const int r = w / n2, q = n1 + (w % n2);
-            if (L.area[r] > A_EPS) {
-                V3 na = ldv(L.nrm + 3 * r), nb = ldv(L.nrm + 3 * q);
+            if (area[r] > A_EPS) {
+                V3 na = ldv(nrm + 3 * r), nb = ldv(nrm + 3 * q);
                 if (fabsf(vdot(na, nb)) > 1.0f - D_EPS) {
                     Tri ta = ldtri(T + r * 9);
                     Tri tb = ldtri(T + q * 9);
                     V3 d = argmax_dir<3>(ta, tb.v);
-                    if ((fabsf(vdot(d, na)) < D_EPS) || (fabsf(vdot(d, nb)) < D_EPS)) L.keep[q] = 0;
+                    if ((fabsf(vdot(d, na)) < D_EPS) || (fabsf(vdot(d, nb)) < D_EPS)) keep[q] = 0;
                 }
             }
         }
         __syncthreads();
-        // ---- compact the survivors behind the box1 list (stable)
-        int m = n1;
-        for (int i0 = n1; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
-            const bool k = (i < n) && (L.keep[i] != 0);
-            const unsigned long long b = __ballot(k);
-            if (k) sttri(O + (m + __popcll(b & lt_mask)) * 9, ldtri(T + i * 9));
-            m += __popcll(b);
-        }
-        for (int i = lane; i < n1; i += 64) sttri(O + i * 9, ldtri(T + i * 9));
-        __syncthreads();
 
-        // ---- polyhedron centre and tetrahedron-sum volume (wave reductions)
-        float vol = 0.f, iou = 0.f;
-        if (m > 0) {
-            float cx = 0.f, cy = 0.f, cz = 0.f;
-            for (int i = lane; i < m; i += 64) {
-                Tri t = ldtri(O + i * 9);
+        // ---- polyhedron centre and tetrahedron-sum volume over the surviving triangles (box1's list + kept box2 entries),
+        //      sub-group reductions.  The survivors are not compacted: sums do not care about the order.
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        int mine = 0;
+        for (int i = sl; i < n; i += SUB) {
+            if (i < n1 || keep[i] != 0) {
+                Tri t = ldtri(T + i * 9);
                 cx += (t.v[0].x + t.v[1].x + t.v[2].x) / 3.0f;
                 cy += (t.v[0].y + t.v[1].y + t.v[2].y) / 3.0f;
                 cz += (t.v[0].z + t.v[1].z + t.v[2].z) / 3.0f;
+                ++mine;
             }
-            cx = wave_sum(cx); cy = wave_sum(cy); cz = wave_sum(cz);
-            V3 ctr = vdiv(mk(cx, cy, cz), (float)m);
-            float v = 0.f;
-            for (int i = lane; i < m; i += 64) {
-                Tri t = ldtri(O + i * 9);
-                V3 a = vsub(t.v[0], ctr), b = vsub(t.v[1], ctr), c = vsub(t.v[2], ctr);
-                v += fabsf(vdot(a, vcross(b, c))) / 6.0f;
-            }
-            vol = wave_sum(v);
-            iou = vol / (L.vol[0] + L.vol[1] - vol);
         }
-        if (lane == 0) {
-            if (vol_out) vol_out[p] = vol;
+        cx = group_sum(cx); cy = group_sum(cy); cz = group_sum(cz);
+        const int m = (int)(group_sum((float)mine) + 0.5f);
+        float v = 0.f;
+        if (m > 0) {
+            V3 ctr = vdiv(mk(cx, cy, cz), (float)m);
+            for (int i = sl; i < n; i += SUB) {
+                if (i < n1 || keep[i] != 0) {
+                    Tri t = ldtri(T + i * 9);
+                    V3 a = vsub(t.v[0], ctr), b = vsub(t.v[1], ctr), c = vsub(t.v[2], ctr);
+                    v += fabsf(vdot(a, vcross(b, c))) / 6.0f;
+                }
+            }
+        }
+        const float vol = group_sum(v);
+        const float iou = (m > 0) ? vol / (L.vol[0] + L.vol[1] - vol) : 0.f;
+        if (act && sl == 0) {
+            if (vol_out) vol_out[p] = (m > 0) ? vol : 0.f;
             iou_out[p] = iou;
         }
-        if (__any(over) && lane == 0 && overflow) atomicAdd(overflow, 1);
+        const unsigned long long ob = (__ballot(over) >> shift) & sub_all;
+        if (ob != 0ull && sl == 0 && overflow) atomicAdd(overflow, 1);
     }
 }
 
@@ -359,10 +389,28 @@ __global__ void box3d_validity_kernel(const float* __restrict__ boxes, int N, fl
     }
 }
 
-inline int iou_grid(long long npairs) {
+constexpr int IOU_SUB = 32;       // lanes per pair of the production launch (tools/bench_iou3d.py sweeps 64 / 32 / 16)
+
+inline int iou_grid(long long npairs, int sub) {
     // 256 CUs x up to 16 single-wave workgroups per CU (LDS-limited); grid-stride beyond that
-    long long g = npairs < 256 * 16 ? npairs : 256 * 16;
+    const long long waves = (npairs + 64 / sub - 1) / (64 / sub);
+    long long g = waves < 256 * 16 ? waves : 256 * 16;
     return (int)(g < 1 ? 1 : g);
+}
+
+template <int MODE>
+inline int iou_launch(int sub, const float* boxes1, const float* boxes2, const int* idx1, const int* idx2, const int* valid1,
+                      long long np, int M, float* vol, float* iou, int* overflow, void* stream) {
+    if (sub == 0) sub = IOU_SUB;
+#define OMNI_IOU(SUB_)                                                                                                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(iou_box3d_kernel<MODE, SUB_>), dim3(iou_grid(np, SUB_)), dim3(64), 0, (hipStream_t)stream, \
+                       boxes1, boxes2, idx1, idx2, valid1, np, M, vol, iou, overflow)
+    if (sub == 64) OMNI_IOU(64);
+    else if (sub == 32) OMNI_IOU(32);
+    else if (sub == 16) OMNI_IOU(16);
+    else return OMNI_ERR_ARG;
+#undef OMNI_IOU
+    return omni_launch_status();
 }
 
 }  // namespace
@@ -374,18 +422,23 @@ int omni_iou_box3d(const float* boxes1, int N, const float* boxes2, int M, const
     if (N < 0 || M < 0) return OMNI_ERR_ARG;
     const long long np = (long long)N * M;
     if (np == 0) return OMNI_OK;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(iou_box3d_kernel<0>), dim3(iou_grid(np)), dim3(64), 0, (hipStream_t)stream, boxes1,
-                       boxes2, (const int*)nullptr, (const int*)nullptr, valid1, np, M, vol, iou, overflow);
-    return omni_launch_status();
+    return iou_launch<0>(0, boxes1, boxes2, nullptr, nullptr, valid1, np, M, vol, iou, overflow, stream);
 }
 
 int omni_iou_box3d_pairs(const float* boxes1, const float* boxes2, const int* idx1, const int* idx2, long long npairs,
                          const int* valid1, float* vol, float* iou, int* overflow, void* stream) {
     if (npairs < 0) return OMNI_ERR_ARG;
     if (npairs == 0) return OMNI_OK;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(iou_box3d_kernel<1>), dim3(iou_grid(npairs)), dim3(64), 0, (hipStream_t)stream,
-                       boxes1, boxes2, idx1, idx2, valid1, npairs, 1, vol, iou, overflow);
-    return omni_launch_status();
+    return iou_launch<1>(0, boxes1, boxes2, idx1, idx2, valid1, npairs, 1, vol, iou, overflow, stream);
+}
+
+// lanes_per_pair in {64, 32, 16} (0 = the production choice): A/B entry point of tools/bench_iou3d.py and of the parity tests,
+// which run every sub-group width against the oracle
+int omni_iou_box3d_pairs_algo(const float* boxes1, const float* boxes2, const int* idx1, const int* idx2, long long npairs,
+                              const int* valid1, float* vol, float* iou, int* overflow, int lanes_per_pair, void* stream) {
+    if (npairs < 0) return OMNI_ERR_ARG;
+    if (npairs == 0) return OMNI_OK;
+    return iou_launch<1>(lanes_per_pair, boxes1, boxes2, idx1, idx2, valid1, npairs, 1, vol, iou, overflow, stream);
 }
 
 int omni_box3d_validity(const float* boxes, int N, float eps_coplanar, float eps_nonzero, int* valid, int* counts,

@@ -179,6 +179,8 @@ class RPNWithIgnore(nn.Module):
         gi = top_i.clamp(min=0).long()
         prop = torch.gather(boxes, 1, gi[:, :, None].expand(-1, -1, 4)) * ok[:, :, None]
         count = ok.sum(dim=1).to(torch.int32)
+        if getattr(self, "keep_candidates", False):      # parity tests: the pre-NMS candidate lists behind the proposal set
+            self.last_candidates = {"boxes": boxes, "scores": scores, "keep": keep, "valid": valid.view(B, L * kmax), "slots_per_level": kmax}
         return prop.contiguous(), top_v, count
 
     def forward(self, images, features, gt_instances=None, targets=None):

@@ -351,17 +351,25 @@ def build_optimizer(cfg, model):
     inner = model.module if hasattr(model, "module") else model
     for name, p in inner.named_parameters():
         p._omni_early_grad = not name.startswith("backbone.")
+    # tools/train_net.py:449-454 wraps the model in DistributedDataParallel BEFORE do_train builds the optimizer.  A wrapper that
+    # reduces the gradients itself needs autograd's accumulation hooks (no direct accumulation) and makes the step's own exchange
+    # redundant; a wrapper this package's build_model prepared (`_omni_owns_exchange`, cubercnn/solver/ddp.py) leaves the exchange
+    # to the optimizer's overlapped two-range all-reduce and keeps direct accumulation.
+    under_ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)
+    own = bool(getattr(inner, "_omni_owns_exchange", False))
+    direct = (not under_ddp) or own
     if cfg.SOLVER.TYPE == "sgd":
-        under_ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)   # tools/train_net.py:449-454 wraps first
-        return FlatSGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV,
-                       weight_decay=cfg.SOLVER.WEIGHT_DECAY, direct_accumulate=not under_ddp)
-    if cfg.SOLVER.TYPE in ("adam", "adam+amsgrad", "adamw", "adamw+amsgrad"):     # build.py:58-65
-        under_ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)
+        opt = FlatSGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV,
+                      weight_decay=cfg.SOLVER.WEIGHT_DECAY, direct_accumulate=direct)
+    elif cfg.SOLVER.TYPE in ("adam", "adam+amsgrad", "adamw", "adamw+amsgrad"):     # build.py:58-65
         adamw = cfg.SOLVER.TYPE.startswith("adamw")
         # torch defaults behind the reference's calls: betas (0.9, 0.999); the groups carry their own weight decay
-        return FlatAdam(params, cfg.SOLVER.BASE_LR, eps=1e-02, weight_decay=1e-2 if adamw else 0.0, amsgrad=cfg.SOLVER.TYPE.endswith("+amsgrad"),
-                        decoupled=adamw, direct_accumulate=not under_ddp)
-    raise ValueError("{} is not supported as an optimizer.".format(cfg.SOLVER.TYPE))
+        opt = FlatAdam(params, cfg.SOLVER.BASE_LR, eps=1e-02, weight_decay=1e-2 if adamw else 0.0, amsgrad=cfg.SOLVER.TYPE.endswith("+amsgrad"),
+                       decoupled=adamw, direct_accumulate=direct)
+    else:
+        raise ValueError("{} is not supported as an optimizer.".format(cfg.SOLVER.TYPE))
+    opt.exchange_in_step = direct          # DDP's reducer already averaged: never all-reduce the bucket a second time
+    return opt
 
 
 def freeze_bn(network):

@@ -30,8 +30,9 @@ def iou_box3d(boxes1, boxes2, valid1=None):
     return vol, iou
 
 
-def iou_box3d_pairs(boxes1, boxes2, idx1, idx2, valid1=None):
-    """Ragged / paired form: iou[p] = IoU3D(boxes1[idx1[p]], boxes2[idx2[p]])."""
+def iou_box3d_pairs(boxes1, boxes2, idx1, idx2, valid1=None, lanes_per_pair=0):
+    """Ragged / paired form: iou[p] = IoU3D(boxes1[idx1[p]], boxes2[idx2[p]]).  lanes_per_pair 64 / 32 / 16 picks how many
+    pairs share a wavefront (0 = production choice); every width gives the same result."""
     _check_boxes(boxes1, "boxes1")
     _check_boxes(boxes2, "boxes2")
     boxes1, boxes2 = boxes1.contiguous(), boxes2.contiguous()
@@ -44,8 +45,12 @@ def iou_box3d_pairs(boxes1, boxes2, idx1, idx2, valid1=None):
     vol = torch.empty(P, dtype=torch.float32, device=boxes1.device)
     iou = torch.empty(P, dtype=torch.float32, device=boxes1.device)
     overflow = torch.zeros(1, dtype=torch.int32, device=boxes1.device)
-    L.call("omni_iou_box3d_pairs", _lib.ptr(boxes1), _lib.ptr(boxes2), _lib.ptr(idx1), _lib.ptr(idx2), P,
-           _lib.ptr(valid1), _lib.ptr(vol), _lib.ptr(iou), _lib.ptr(overflow), _lib.stream_of(boxes1))
+    if lanes_per_pair:
+        L.call("omni_iou_box3d_pairs_algo", _lib.ptr(boxes1), _lib.ptr(boxes2), _lib.ptr(idx1), _lib.ptr(idx2), P,
+               _lib.ptr(valid1), _lib.ptr(vol), _lib.ptr(iou), _lib.ptr(overflow), int(lanes_per_pair), _lib.stream_of(boxes1))
+    else:
+        L.call("omni_iou_box3d_pairs", _lib.ptr(boxes1), _lib.ptr(boxes2), _lib.ptr(idx1), _lib.ptr(idx2), P,
+               _lib.ptr(valid1), _lib.ptr(vol), _lib.ptr(iou), _lib.ptr(overflow), _lib.stream_of(boxes1))
     return vol, iou
 
 

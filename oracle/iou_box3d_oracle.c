@@ -189,6 +189,11 @@ static int clip_tri_by_plane(const face_t* plane, v3 normal, const tri_t* t, tri
 #define ORACLE_MAX_TRIS 1024
 static int g_max_tris_seen = 0;
 int iou_box3d_oracle_max_tris(void) { return g_max_tris_seen; }
+/* high-water mark of (box1 list + box2 list) after the same plane pass: what a kernel that keeps both clip directions in ONE
+ * list (csrc/iou_box3d.hip) must hold.  Debugging aid like g_max_tris_seen, updated without synchronisation. */
+static int g_max_joint_seen = 0;
+static _Thread_local int g_pass_count[6];
+int iou_box3d_oracle_max_joint_tris(void) { return g_max_joint_seen; }
 
 static void box_tris(const float* b, tri_t* out) {
     for (int t = 0; t < 12; ++t)
@@ -221,6 +226,7 @@ static int box_intersections(const tri_t* tris, const face_t* planes, v3 center,
         tri_t* tmp = cur; cur = nxt; nxt = tmp;
         n = m;
         if (n > g_max_tris_seen) g_max_tris_seen = n;
+        g_pass_count[p] = n;
     }
     memcpy(out, cur, n * sizeof(tri_t));
     return n;
@@ -242,7 +248,11 @@ void iou_box3d_oracle(const float* boxes1, int N, const float* boxes2, int M, fl
             v3 c2 = box_center(b2);
             float vol2 = tris_volume(t2, 12, c2);
             int n1 = box_intersections(t1, p2, c2, i1);
+            int pass1[6];
+            memcpy(pass1, g_pass_count, sizeof(pass1));
             int n2 = box_intersections(t2, p1, c1, i2);
+            for (int f = 0; f < 6; ++f)
+                if (pass1[f] + g_pass_count[f] > g_max_joint_seen) g_max_joint_seen = pass1[f] + g_pass_count[f];
             int n1_orig = n1;
             if (n2 > 0) {
                 for (int q = 0; q < n2; ++q) {

@@ -179,7 +179,10 @@ HEAD_ENTANGLED = dict(TINY, name="dla34_tiny_head_entangled", seed=18, prior_bin
     "MODEL.ROI_CUBE_HEAD.CLUSTER_BINS", 3, "MODEL.ROI_BOX_HEAD.TRAIN_ON_PRED_BOXES", True, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32])
 # detectron2's own RPN losses instead of the IoUness ones (MODEL.RPN.OBJECTNESS_UNCERTAINTY 'none', rpn.py:169-195)
 RPN_PLAIN = dict(TINY, name="dla34_tiny_rpn_plain", seed=26, overrides=_T + ["MODEL.RPN.OBJECTNESS_UNCERTAINTY", "none"])
-HEAD_MODES = (HEAD_QUAT, HEAD_EULER, HEAD_MIXED, HEAD_CLUSTERS, HEAD_ENTANGLED, RPN_PLAIN)
+# ... and the same switch at 2 x 128 x 128: the 1 x 64 x 64 spec leaves 4 samples per channel in the deepest BatchNorms, too
+# ill-conditioned for a GPU-vs-CPU gradient comparison (round 2: stem BN weight gradient 3.46 % on MI355X against the 3 % cap)
+RPN_PLAIN_SMALL = dict(SMALL, name="dla34_small_rpn_plain", seed=27, overrides=SMALL["overrides"] + ["MODEL.RPN.OBJECTNESS_UNCERTAINTY", "none"])
+HEAD_MODES = (HEAD_QUAT, HEAD_EULER, HEAD_MIXED, HEAD_CLUSTERS, HEAD_ENTANGLED, RPN_PLAIN, RPN_PLAIN_SMALL)
 
 
 # the whole model over the other bottom-ups of the reference's configs (torchvision restated in oracle/upstream.py)
@@ -200,6 +203,11 @@ INFER = dict(
     name="dla34_small_infer", seed=2, images=2, height=128, width=128, num_gt=5,
     overrides=["MODEL.ROI_HEADS.SCORE_THRESH_TEST", 0.05, "MODEL.RPN.PRE_NMS_TOPK_TEST", 300, "MODEL.RPN.POST_NMS_TOPK_TEST", 100],
 )
+
+
+# the BENCHMARKED inference shape (bench.py --workload infer): 4 x 512 x 512, the configuration's own test-time settings
+# (1000 proposals per image, SCORE_THRESH_TEST / NMS_THRESH_TEST / DETECTIONS_PER_IMAGE of configs/Base.yaml)
+INFER_FULL = dict(name="dla34_full_infer", seed=12, images=4, height=512, width=512, num_gt=8, overrides=[], selection_may_differ=True)
 
 
 # the cube head's inference branch with depth clusters and zoomed cube ROIs (roi_heads.py:307-324, 432-442, 501-522)
@@ -267,10 +275,17 @@ def main_infer(spec=INFER):
         bi, bj = r["pred_boxes"].double(), j.pred_boxes.tensor.double()
         d = (bi[:, None] - bj[None]).abs().amax(2) + 1e6 * (r["pred_classes"][:, None] != j.pred_classes[None])
         m = d.argmin(1)
-        assert float(d.min(1).values.max()) < 0.5, "fp64 run produced a different detection set"
+        found = d.min(1).values < 0.5
+        # plumbing-sized fixtures: fp32 and fp64 select the same detections.  At the benchmarked size (1000 proposals x 50 classes
+        # per image, 100 detection slots) the REFERENCE's own fp32 run already differs from its fp64 run by a few near-tied
+        # detections at the NMS threshold / the top-100 cut; the fixture records which fp32 detections have an fp64 twin
+        # (`fp64_found`) and the tests compare values on those
+        assert bool(found.all()) or spec.get("selection_may_differ"), "fp64 run produced a different detection set"
+        r["fp64_found"] = found
         r["fp64"] = {"pred_boxes": bj[m], "scores": j.scores.double()[m], "pred_bbox3D": j.pred_bbox3D.double()[m],
                      "pred_center_cam": j.pred_center_cam.double()[m], "pred_center_2D": j.pred_center_2D.double()[m],
                      "pred_dimensions": j.pred_dimensions.double()[m], "pred_pose": j.pred_pose.double()[m]}
+        print("  fp32 detections:", len(found), " with an fp64 twin:", int(found.sum()), " fp64 detections:", len(j))
     path = os.path.join(ROOT, "tests", "golden", spec["name"] + ".pt")
     torch.save({"spec": spec, "results": res, "torch_version": torch.__version__}, path)
     print("wrote", path, os.path.getsize(path), "bytes;", [len(r["scores"]) for r in res], "detections")
@@ -491,6 +506,8 @@ if __name__ == "__main__":
         main_infer(INFER_CLUSTERS)
     elif "--infer-oracle2d" in sys.argv:
         main_infer(INFER_ORACLE2D)
+    elif "--infer-full" in sys.argv:
+        main_infer(INFER_FULL)
     elif "--infer" in sys.argv:
         main_infer()
     elif "--backbones" in sys.argv:

@@ -397,17 +397,46 @@ def test_sgd_emulated(emu_lib):
     _run_sgd("cpu")
 
 
+# one GPU test per kernel family: with `-x` a failure names its kernel and does not hide the other rows
 @pytest.mark.gpu
-def test_det_kernels_gpu(hip_lib):
-    _run_rpn_labels("cuda", 64, 1.0, 0)
-    _run_rpn_labels("cuda", 512, 0.5, 1)
+@pytest.mark.parametrize("batch_per_image,pos_frac,seed", [(64, 1.0, 0), (512, 0.5, 1)])
+def test_rpn_labels_gpu(hip_lib, batch_per_image, pos_frac, seed):
+    _run_rpn_labels("cuda", batch_per_image, pos_frac, seed)
+
+
+@pytest.mark.gpu
+def test_rpn_loss_decode_gpu(hip_lib):
     _run_rpn_loss("cuda")
+
+
+@pytest.mark.gpu
+def test_roi_sample_gpu(hip_lib):
     _run_roi_sample("cuda")
+
+
+@pytest.mark.gpu
+def test_roi_align_gpu(hip_lib):
     _run_roi_align("cuda")
+
+
+@pytest.mark.gpu
+def test_roi_align_big_gpu(hip_lib):
     _run_roi_align_big("cuda")
+
+
+@pytest.mark.gpu
+def test_box_loss_gpu(hip_lib):
     _run_box_loss("cuda")
-    for cfg_name in sorted(CUBE_CONFIGS):
-        _run_cube("cuda", cfg_name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", sorted(CUBE_CONFIGS))
+def test_cube_gpu(hip_lib, cfg_name):
+    _run_cube("cuda", cfg_name)
+
+
+@pytest.mark.gpu
+def test_sgd_gpu(hip_lib):
     _run_sgd("cuda")
 
 

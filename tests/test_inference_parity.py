@@ -10,6 +10,13 @@ from conftest import ROOT
 
 # default head; Z_TYPE clusters + CLUSTER_BINS 4 + SCALE_ROI_BOXES; ground-truth 2D boxes handed in as `oracle2D` (no RPN / box head)
 FIXTURES = ["dla34_small_infer", "dla34_small_infer_clusters", "dla34_small_infer_oracle2d"]
+# the BENCHMARKED inference shape (bench.py --workload infer): 4 x 512 x 512, 1000 proposals / image, the configuration's own test
+# settings.  At this size the reference's own fp32 run and its fp64 run agree on only 81 .. 94 of the 100 detections per image
+# (near-ties at the NMS threshold and at the top-100 cut between 50 000 (proposal, class) candidates of a random-init classifier),
+# so "the same detection list" is not defined to better than that: the fixture records which fp32 detections have an fp64 twin,
+# the test requires the HIP list to share at least as many detections with the fp32 reference (minus 10) and bounds every
+# value on the detections all three runs have in common.
+FULL_FIXTURES = ["dla34_full_infer"]
 
 
 def _run(dev, name="dla34_small_infer"):
@@ -25,12 +32,28 @@ def _run(dev, name="dla34_small_infer"):
         out = model(batch)
     assert len(out) == len(gold["results"])
     report, bad = [], []
+    loose = bool(spec.get("selection_may_differ"))
     for o, ref in zip(out, gold["results"]):
         i = o["instances"]
         n = len(ref["scores"])
         assert len(i) == n, (len(i), n)
-        assert torch.equal(i.pred_classes.cpu().long(), ref["pred_classes"])            # selection is index-exact
         r64 = ref["fp64"]                                                               # the reference files in float64
+        if not loose:
+            assert torch.equal(i.pred_classes.cpu().long(), ref["pred_classes"])        # selection is index-exact
+        else:
+            # twin of every reference detection in the HIP list: same class, same box to half a pixel
+            hb, hc = i.pred_boxes.tensor.cpu(), i.pred_classes.cpu().long()
+            d = (ref["pred_boxes"][:, None] - hb[None]).abs().amax(2) + 1e6 * (ref["pred_classes"][:, None] != hc[None])
+            m, found = d.argmin(1), d.min(1).values < 0.5
+            own = int(ref["fp64_found"].sum())
+            report.append("detections shared with the fp32 reference: %d of %d (the reference's own fp32 / fp64 runs share %d)" % (int(found.sum()), n, own))
+            assert int(found.sum()) >= own - 10, report[-1]
+            both = found & ref["fp64_found"]
+            sel = m[both]
+            # compare on the common detections: gather the HIP rows, restrict the reference rows
+            i = i[sel.to(i.pred_classes.device)]
+            ref = {k: (v[both] if torch.is_tensor(v) and v.shape[:1] == both.shape else v) for k, v in ref.items()}
+            r64 = {k: v[both] for k, v in r64.items()}
 
         def bounded(name, got, cap, scale=None):
             """|HIP - fp64| <= max(cap, 3 x the reference's own fp32 distance to the fp64 value), never above 2 x cap
@@ -72,6 +95,6 @@ def test_inference_matches_reference_emulated(emu_lib, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("name", FIXTURES + FULL_FIXTURES)
 def test_inference_matches_reference_gpu(hip_lib, name):
     _run("cuda", name)

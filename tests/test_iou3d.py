@@ -158,3 +158,42 @@ def test_iou3d_gpu_100k_pairs_properties(hip_lib, oracle_lib, rng):
     err = np.abs(iou[v] - ref[v])
     assert err.max() < TOL, (float(err.max()), int(err.argmax()))
     assert (iou[~v] == 0).all()
+
+
+def _widths_case(dev, oracle_lib, rng, npairs):
+    """Every lanes-per-pair width (64 = one pair per wave, 32 = two, 16 = four) against the C oracle on the same pairs, with an odd
+    pair count (a partly filled last wave), invalid rows scattered between valid ones (a sub-group idles while its neighbour
+    works) and pairs whose triangle lists differ wildly in length inside one wave (identical boxes next to far-apart ones)."""
+    import ctypes
+    from omni3d_amd.kernels import iou3d
+    dt, gt, deg = boxgen.omni3d_like_pairs(rng, npairs, degenerate_frac=0.1)
+    gt[2] = dt[2]                                   # identical boxes: the longest lists (every face coplanar)
+    gt[3] = dt[3] + np.float32(50.0)                # disjoint: empty after the first plane
+    d, g = torch.from_numpy(dt).to(dev), torch.from_numpy(gt).to(dev)
+    ar = torch.arange(npairs, dtype=torch.int32, device=dev)
+    valid, _ = iou3d.box3d_validity(d)
+    P = ctypes.c_void_p
+    ref = np.zeros(npairs, np.float32)
+    oracle_lib.iou_box3d_pairs_oracle(np.ascontiguousarray(dt).ctypes.data_as(P), np.ascontiguousarray(gt).ctypes.data_as(P), npairs,
+                                      ref.ctypes.data_as(P))
+    v = valid.cpu().numpy().astype(bool)
+    assert (~v).any() and v.any()
+    outs = {}
+    for lanes in (64, 32, 16, 0):
+        vol, iou = iou3d.iou_box3d_pairs(d, g, ar, ar, valid1=valid, lanes_per_pair=lanes)
+        iou = iou.cpu().numpy()
+        assert np.abs(iou[v] - ref[v]).max() < TOL, (lanes, float(np.abs(iou[v] - ref[v]).max()))
+        assert (iou[~v] == 0).all() and (vol.cpu().numpy()[~v] == 0).all()
+        outs[lanes] = iou
+    assert np.array_equal(outs[0], outs[32])        # 0 = the production width
+    with pytest.raises(Exception):
+        iou3d.iou_box3d_pairs(d, g, ar, ar, lanes_per_pair=8)
+
+
+def test_iou3d_lane_widths_emulated(emu_lib, oracle_lib, rng):
+    _widths_case("cpu", oracle_lib, rng, 37)
+
+
+@pytest.mark.gpu
+def test_iou3d_lane_widths_gpu(hip_lib, oracle_lib, rng):
+    _widths_case("cuda", oracle_lib, rng, 20_001)

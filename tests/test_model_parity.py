@@ -13,6 +13,60 @@ def _gold(name):
     return os.path.join(ROOT, "tests", "golden", name + ".pt")
 
 
+def _box_iou(a, b):
+    lt, rb = torch.max(a[:, None, :2], b[None, :, :2]), torch.min(a[:, None, 2:], b[None, :, 2:])
+    inter = (rb - lt).clamp(min=0).prod(2)
+    area = lambda x: (x[:, 2] - x[:, 0]) * (x[:, 3] - x[:, 1])      # noqa: E731
+    return inter / (area(a)[:, None] + area(b)[None, :] - inter).clamp(min=1e-12)
+
+
+def unexplained_proposal_mismatches(got, want, cand, n, nms_thresh, tol=4e-6, box_tol=1e-2):
+    """First-stage lists are compared as SETS because a last-bit difference in an objectness logit can re-order near-tied
+    candidates.  This checks that nothing else hides behind that slack: every proposal present on one side only must be
+    explained by (a) a ranking tie -- another candidate of the same image and level whose score differs by less than `tol`
+    (relative, a few fp32 ulps) --, (b) an NMS tie -- an IoU with a higher-scored candidate within 1e-5 of the threshold --,
+    (c) a tie at the post-NMS cut, or (d) being a consequence of such a flip: it overlaps (IoU > threshold - 1e-5) another
+    mismatched proposal.  -> list of unexplained boxes (empty = the slack was only ever used by ties).
+    got / want: (n, 4) proposal boxes of image n; cand: RPNWithIgnore.last_candidates."""
+    d = (got[:, None, :] - want[None, :, :]).abs().amax(dim=2) if len(got) and len(want) else torch.full((len(got), len(want)), 1e9)
+    only_got = got[d.min(dim=1).values > box_tol] if len(want) else got
+    only_want = want[d.min(dim=0).values > box_tol] if len(got) else want
+    mism = torch.cat([only_got, only_want])
+    if len(mism) == 0:
+        return []
+    cb, cs, ck = cand["boxes"][n].cpu(), cand["scores"][n].cpu(), cand["keep"][n].cpu() != 0
+    kmax = cand["slots_per_level"]
+    level = torch.arange(cb.shape[0]) // kmax
+    fin = torch.isfinite(cs)
+    kept_scores = cs[ck & fin]
+    cut = kept_scores.sort(descending=True).values[len(got) - 1] if 0 < len(got) <= len(kept_scores) else None
+    bad = []
+    for b in mism:
+        dist = (cb - b[None]).abs().amax(dim=1)
+        j = int(dist.argmin())
+        if float(dist[j]) > box_tol:
+            # a reference-only box the product never had among its pre-NMS candidates: only a tie at the per-level top-k cut can
+            # explain it, and the reference's score is not in the fixture -- count it as unexplained
+            bad.append(("not a candidate", b.tolist()))
+            continue
+        s, lv = float(cs[j]), int(level[j])
+        scale = tol * max(1.0, abs(s))
+        same = fin & (level == lv)
+        same[j] = False
+        if bool(((cs - s).abs() <= scale)[same].any()):
+            continue                                                            # (a) ranking tie
+        iou = _box_iou(b[None], cb[fin & (level == lv)])[0]
+        if bool(((iou - nms_thresh).abs() <= 1e-5).any()):
+            continue                                                            # (b) NMS threshold tie
+        if cut is not None and abs(s - float(cut)) <= scale:
+            continue                                                            # (c) post-NMS cut tie
+        others = mism[(mism - b[None]).abs().amax(dim=1) > box_tol]
+        if len(others) and float(_box_iou(b[None], others)[0].max()) > nms_thresh - 1e-5:
+            continue                                                            # (d) consequence of another flip
+        bad.append(("no tie", b.tolist(), s))
+    return bad
+
+
 def _run(dev, name, head_cap=None):
     from oracle import make_golden as MG
     head_cap = GRAD_CAP_HEADS if head_cap is None else head_cap
@@ -29,6 +83,7 @@ def _run(dev, name, head_cap=None):
     # list is compared with it as a set.  Kernels run in their production configuration (split-K atomics included).
     model.proposal_generator.injected = {"E": E["rpn"], "proposals": gold["proposals"]}
     model.roi_heads.injected = {"E": E["roi"]}
+    model.proposal_generator.keep_candidates = True
     model.train()
     with EventStorage(0) as st:
         losses = model(batch)
@@ -45,6 +100,9 @@ def _run(dev, name, head_cap=None):
         d = (got[:, None, :] - want[None, :, :]).abs().amax(dim=2)
         assert int((d.min(dim=0).values > 1e-2).sum()) <= 0.01 * len(want) + 2
         assert int((d.min(dim=1).values > 1e-2).sum()) <= 0.01 * len(got) + 2
+        # ... and that slack is only ever used by near-tied candidates
+        bad = unexplained_proposal_mismatches(got, want, model.proposal_generator.last_candidates, n, model.proposal_generator.nms_thresh)
+        assert not bad, (n, bad)
     for got, cls, want in zip(model.roi_heads.last_sampled_boxes.cpu(), model.roi_heads.last_sampled_classes.cpu(), gold["roi_boxes"]):
         got = got[cls >= 0]
         assert len(got) == len(want)
@@ -92,20 +150,21 @@ def test_training_step_matches_reference_emulated(emu_lib):
 
 HEAD_MODE_FIXTURES = ["dla34_tiny_head_quat", "dla34_tiny_head_euler", "dla34_tiny_head_mixed", "dla34_tiny_head_clusters",
                       "dla34_tiny_head_entangled"]
-# MODEL.RPN.OBJECTNESS_UNCERTAINTY 'none': whole-model parity under the emulator only.  On MI355X the plain RPN loss kernels are
-# checked against the oracle by tests/test_det.py (green); the 1 x 64 x 64 whole-model run there left ONE tensor, the stem BatchNorm
-# weight gradient, at 3.46 % against the 3 % cap (the tiny fixture's usual conditioning margin) when the round's GPU minutes ran out.
-EMULATED_ONLY_FIXTURES = ["dla34_tiny_rpn_plain"]
+# MODEL.RPN.OBJECTNESS_UNCERTAINTY 'none' (detectron2's own RPN losses).  The GPU gate is the 2 x 128 x 128 fixture
+# `dla34_small_rpn_plain`; the 1 x 64 x 64 one (4 samples per channel in the deepest BatchNorms: on MI355X its stem BatchNorm weight
+# gradient sat at 3.46 % against the 3 % cap in round 2) stays as the quick emulated plumbing check.
+RPN_PLAIN_TINY = ["dla34_tiny_rpn_plain"]
+RPN_PLAIN_GPU = ["dla34_small_rpn_plain"]
 
 
 @pytest.mark.skipif(os.environ.get("OMNI_SLOW") != "1", reason="~5 min each under the host emulator; set OMNI_SLOW=1 (the GPU variant is the gate)")
-@pytest.mark.parametrize("name", HEAD_MODE_FIXTURES + EMULATED_ONLY_FIXTURES)
+@pytest.mark.parametrize("name", HEAD_MODE_FIXTURES + RPN_PLAIN_TINY)
 def test_training_step_head_modes_emulated(emu_lib, name):
     _run("cpu", name)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["dla34_tiny", "dla34_small", "resnet34_small", "dla34_full", "resnet34_full"] + HEAD_MODE_FIXTURES)
+@pytest.mark.parametrize("name", ["dla34_tiny", "dla34_small", "resnet34_small", "dla34_full", "resnet34_full"] + HEAD_MODE_FIXTURES + RPN_PLAIN_GPU)
 def test_training_step_matches_reference_gpu(hip_lib, name):
     """tiny/small: plumbing-sized; *_full: BASELINE configs[1] (4 x 512x512, default config) and the configs[3] model at
     2 x 512x512 -- fixtures written by the reference's OWN files (oracle/make_golden.py --full / --resnet-full).
@@ -280,3 +339,22 @@ def test_training_step_image_without_valid_gt(hip_lib):
     total.backward()
     assert all(bool(torch.isfinite(v)) for v in losses.values()), {k: float(v) for k, v in losses.items()}
     assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+
+
+def test_proposal_mismatch_explainer_host():
+    """the tie explainer itself (host logic): a swap between two near-tied candidates is explained, a real loss is not"""
+    kmax = 4
+    boxes = torch.tensor([[[0, 0, 10, 10], [20, 20, 30, 30], [40, 40, 50, 50], [60, 60, 70, 70],          # level 0
+                           [0, 0, 20, 20], [100, 100, 140, 140], [0, 0, 0, 0], [0, 0, 0, 0]]], dtype=torch.float32)
+    scores = torch.tensor([[0.9, 0.5, 0.5 + 2e-8, 0.1, 0.8, 0.3, float("-inf"), float("-inf")]])
+    keep = torch.tensor([[1, 1, 1, 1, 1, 1, 0, 0]])
+    cand = {"boxes": boxes, "scores": scores, "keep": keep, "slots_per_level": kmax}
+    want = boxes[0, [0, 4, 1, 5]]                     # the reference kept candidate 1 ...
+    got_tie = boxes[0, [0, 4, 2, 5]]                  # ... the product its near-tied twin, candidate 2
+    assert unexplained_proposal_mismatches(got_tie, want, cand, 0, 0.7) == []
+    got_lost = boxes[0, [0, 4, 3, 5]]                 # candidate 3 (score 0.1) instead of candidate 1 (0.5): no tie explains it
+    bad = unexplained_proposal_mismatches(got_lost, want, cand, 0, 0.7)
+    assert len(bad) == 1 and bad[0][0] == "no tie" and abs(bad[0][2] - 0.1) < 1e-6
+    foreign = torch.tensor([[200.0, 200, 210, 210]])
+    assert unexplained_proposal_mismatches(torch.cat([want, foreign]), want, cand, 0, 0.7)[0][0] == "not a candidate"
+    assert unexplained_proposal_mismatches(want, want, cand, 0, 0.7) == []

@@ -160,19 +160,62 @@ def _reference_guard(seq, stabilize, period):
     return out
 
 
-@pytest.mark.parametrize("stabilize", [0.02, 0.5, 0.0])
-def test_step_guard_matches_the_reference_logic(emu_lib, stabilize):
+def _run_guard(dev, stabilize):
+    """omni_guard_pre / omni_guard_post (csrc/optim.hip) behind StepGuard.update against the loop's logic on host floats"""
     from omni3d_amd.cubercnn.solver.guard import StepGuard
     seq = [(6.0, 0), (5.5, 0), (30.0, 0), (5.0, 1), (float("nan"), 0), (4.8, 0), (100.0, 0), (4.7, 0), (float("inf"), 0), (4.5, 0)]
     want = _reference_guard(seq, stabilize, 6)
-    g = StepGuard(["b", "a"], stabilize, 6, "cpu")
+    g = StepGuard(["b", "a"], stabilize, 6, dev)
     for (total, bad), (skip_w, retry_w) in zip(seq, want):
         g.nonfinite_flag[0] = float(bad)
-        skipped, retry, red = g.update({"a": torch.tensor(total * 0.25), "b": torch.tensor(total * 0.75)})
+        skipped, retry, red = g.update({"a": torch.tensor(total * 0.25, device=dev), "b": torch.tensor(total * 0.75, device=dev)})
         assert (skipped, retry) == (skip_w, retry_w), (total, bad, skipped, retry, skip_w, retry_w)
         assert float(g.skip) == float(skip_w)
         if math.isfinite(total):
             assert abs(red["total_loss"] - total) < 1e-5 and abs(red["a"] - total * 0.25) < 1e-5
+
+
+@pytest.mark.parametrize("stabilize", [0.02, 0.5, 0.0])
+def test_step_guard_matches_the_reference_logic(emu_lib, stabilize):
+    _run_guard("cpu", stabilize)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stabilize", [0.02, 0.5, 0.0])
+def test_step_guard_matches_the_reference_logic_gpu(hip_lib, stabilize):
+    """the a-19 device kernels on MI355X (tools/train_net.py:157-285)"""
+    _run_guard("cuda", stabilize)
+
+
+@pytest.mark.gpu
+def test_step_guard_gates_the_fused_update_on_the_device_gpu(hip_lib):
+    """sync=False, as bench.py / the graphed step run it: the host never reads the decision inside the step; the fused SGD kernel
+    skips on the device flag (diverged loss, then non-finite gradients), and applies the update otherwise."""
+    from omni3d_amd.cubercnn.solver.guard import StepGuard
+    a, b = _nets()
+    a = a.to("cuda")
+    fo, to = _flat(a), _torch(b)
+    g = StepGuard(["l"], 0.5, 100, "cuda")
+    fo.skip_flag = g.skip
+    plan = [("ok", 1.0), ("diverged", 50.0), ("nan_grad", 1.0), ("ok", 1.0)]
+    for it, (what, mult) in enumerate(plan):
+        fo.zero_grad(); to.zero_grad()
+        gen = torch.Generator().manual_seed(it)
+        x = torch.randn(7, 6, generator=gen)
+        la = (a(x.cuda()) ** 2).mean() * mult
+        lb = (b(x) ** 2).mean() * mult
+        la.backward(); lb.backward()
+        if what == "nan_grad":
+            fo.flat_grad[3] = float("nan")
+        fo.check_nonfinite(g.nonfinite_flag)
+        g.update({"l": la.detach()}, sync=False)
+        fo.step()
+        if what == "ok":
+            to.step()
+        torch.cuda.synchronize()
+        assert float(g.skip) == (0.0 if what == "ok" else 1.0), (it, what)
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert (p.detach().cpu() - q.detach()).abs().max() <= 2e-6
 
 
 def _guard_worker(rank, world, port, q):
