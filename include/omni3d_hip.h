@@ -32,9 +32,11 @@ int omni_iou_box3d_pairs(const float* boxes1, const float* boxes2, const int* id
                          long long npairs, const int* valid1, float* vol, float* iou, int* overflow,
                          void* stream);
 
-/* The same with the number of lanes a pair occupies chosen by the caller: lanes_per_pair 64 | 32 | 16 = 1 | 2 | 4 pairs per
- * wavefront (0 = the production choice, 32).  Every width computes the same per-pair algorithm (same triangle order, same
- * epsilon decisions); used by the parity tests and by tools/bench_iou3d.py.  Replaces the same call site as above. */
+/* The same with the launch variant chosen by the caller: lanes_per_pair 64 | 32 | 16 = 1 | 2 | 4 pairs per wavefront over
+ * full-capacity (160-triangle) LDS lists; 1000 + lanes = first pass over 96-triangle lists (more waves resident per CU), pairs
+ * that outgrow them are marked and recomputed at full capacity by a second kernel of the same call; 0 = the production choice
+ * (1032).  Every variant computes the same per-pair algorithm (same triangle order, same epsilon decisions); used by the parity
+ * tests and by tools/bench_iou3d.py.  Replaces the same call site as above. */
 int omni_iou_box3d_pairs_algo(const float* boxes1, const float* boxes2, const int* idx1, const int* idx2,
                               long long npairs, const int* valid1, float* vol, float* iou, int* overflow,
                               int lanes_per_pair, void* stream);
@@ -400,10 +402,16 @@ int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate,
  * fwd: out[b](M,K) = x[b](M,C) * w[b](K,C)^T;  wgrad: dw[b](K,C) = dy[b](M,K)^T * x[b](M,C) (overwrites dw). */
 int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch, int M, int C, int K, void* stream);
 /* algo: 0 = automatic | 1 = persistent workgroups walking the (problem, tile) list (`workgroups` of them, multiple of 8,
- * 0 = default; C % 32 == 0) | 2 = one 128x128 tile per workgroup | 3 = one 64x64 tile per workgroup */
+ * 0 = default; C % 32 == 0) | 2 = one 128x128 tile per workgroup | 3 = one 64x64 tile per workgroup | 4 = 64x64 tiles with
+ * 2-4 slabs of buffer-load prefetch in flight (short reductions: the small-map point GEMMs; C % 64 == 0) */
 int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int batch, int M, int C, int K, int algo,
                                int workgroups, void* stream);
 int omni_gemm_batched_wgrad(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, void* stream);
+/* algo: 0 = automatic | 1 = the implicit-GEMM weight-gradient tiles (128x128 / 64x64) | 2 = 64x64 tiles with 4 slabs of
+ * buffer-load prefetch in flight (short reductions).  Same call site as omni_gemm_batched_wgrad (the Winograd-domain weight
+ * gradient of torch.nn.Conv2d's backward, dla.py:43-51). */
+int omni_gemm_batched_wgrad_algo(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, int algo,
+                                 void* stream);
 
 /* Direct convolution for the full-resolution, few-channel DLA-34 stem layers (cubercnn/modeling/backbone/dla.py:241-247):
  * out (N,H,W,16) = conv(x (N,H,W,C), w (16,R,R,C)), stride 1, padding R/2; (C, R) = (4, 7) [base_layer, image padded

@@ -121,7 +121,12 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[WM][WN]) {
 // forward:  out[m, n] = sum_{r,s,c} x[pix(m; r, s), c] * w[n, r, s, c] (+ bias[n]) (ReLU)
 //   GEMM M = N*OH*OW, N = K, reduction Kd = R*S*C.  A and B k-contiguous in LDS.
 // =================================================================================================
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKX = 16>
+// PF = register-staged prefetch depth: the global loads of slab kt + PF are issued while slab kt is in the MFMAs.  PF = 1 is the
+// classic double buffer (one MFMA phase per load in flight).  The small-map problems of this network (Winograd point GEMMs of DLA
+// levels 3-5, reduction depth 128-512 = 4-16 slabs, 64x64 tiles so that the launch has >= 2 workgroups per CU) are bound by that
+// dependency chain -- a 64x64 tile's MFMA phase is 0.43 us per wave against ~2 us of load latency -- so they run PF = 3: three
+// slabs (48 VGPRs) in flight per thread, LDS still double buffered.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKX = 16, int PF = 1>
 __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
     constexpr int WM = BM / (32 * WAVES_M), WN = BN / (32 * WAVES_N);
     constexpr int BKP = BKX + 4, KQ = BKX / 4;        // float4 columns per slab row
@@ -178,20 +183,20 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
         r_cur = tap0 / p.S;
         s_cur = tap0 - r_cur * p.S;
     }
-    float4 ra[AI], rb[BI];
-    auto load_slab = [&]() {
+    float4 ra[PF][AI], rb[PF][BI];
+    auto load_slab = [&](const int st) {
         const bool kok = kd < Kd;
         const long tap_off = ((long)r_cur * p.W + s_cur) * p.ldx + c_cur;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int ih = a_ih[i] + r_cur, iw = a_iw[i] + s_cur;
             const bool ok = a_ok[i] && kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            ra[i] = ok ? ldg4(p.x + a_base[i] + tap_off) : zero4();
+            ra[st][i] = ok ? ldg4(p.x + a_base[i] + tap_off) : zero4();
         }
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
             const int n = n0 + lrow + RPP * j;
-            rb[j] = (lrow + RPP * j < BN && n < p.K && kok) ? ldg4(p.w + (long)n * Kd + kd) : zero4();
+            rb[st][j] = (lrow + RPP * j < BN && n < p.K && kok) ? ldg4(p.w + (long)n * Kd + kd) : zero4();
         }
         if (tap_inner) {
             kd += p.C;
@@ -208,30 +213,56 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
             }
         }
     };
-    auto store_slab = [&](int buf) {
+    auto store_slab = [&](int buf, const int st) {
         float* As = smem + buf * (BM + BN) * BKP;
         float* Bs = As + BM * BKP;
 #pragma unroll
         for (int i = 0; i < AI; ++i)
-            if (lrow + RPP * i < BM) *reinterpret_cast<float4*>(As + (lrow + RPP * i) * BKP + kq * 4) = ra[i];
+            if (lrow + RPP * i < BM) *reinterpret_cast<float4*>(As + (lrow + RPP * i) * BKP + kq * 4) = ra[st][i];
 #pragma unroll
         for (int j = 0; j < BI; ++j)
-            if (lrow + RPP * j < BN) *reinterpret_cast<float4*>(Bs + (lrow + RPP * j) * BKP + kq * 4) = rb[j];
+            if (lrow + RPP * j < BN) *reinterpret_cast<float4*>(Bs + (lrow + RPP * j) * BKP + kq * 4) = rb[st][j];
     };
 
     f32x16 acc[WM][WN];
     zero_acc<WM, WN>(acc);
     if (nk <= 0) return;
-    load_slab();
-    store_slab(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_slab();
-        const float* As = smem + buf * (BM + BN) * BKP;
-        mma_slab<WM, WN, true, true, 0, 0, BKX>(As, As + BM * BKP, wm * WM * 32, wn * WN * 32, lane, acc);
-        if (kt + 1 < nk) store_slab(buf ^ 1);
+    if constexpr (PF == 1) {
+        load_slab(0);
+        store_slab(0, 0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_slab(0);
+            const float* As = smem + buf * (BM + BN) * BKP;
+            mma_slab<WM, WN, true, true, 0, 0, BKX>(As, As + BM * BKP, wm * WM * 32, wn * WN * 32, lane, acc);
+            if (kt + 1 < nk) store_slab(buf ^ 1, 0);
+            __syncthreads();
+        }
+    } else {
+        // stage s holds slab kt when kt % PF == s; the cursor of load_slab() runs PF slabs ahead of the MFMAs
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+            if (s < nk) load_slab(s);
+        store_slab(0, 0);
+        if (PF < nk) load_slab(0);
+        omni_barrier_lds();
+        for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int kt = kt0 + u;
+                if (kt < nk) {
+                    const int buf = kt & 1;
+                    if (kt + 1 < nk) {
+                        store_slab(buf ^ 1, (u + 1) % PF);                     // slab kt + 1: its loads were issued PF phases ago
+                        if (kt + 1 + PF < nk) load_slab((u + 1) % PF);         // refill the stage just drained
+                    }
+                    const float* As = smem + buf * (BM + BN) * BKP;
+                    mma_slab<WM, WN, true, true, 0, 0, BKX>(As, As + BM * BKP, wm * WM * 32, wn * WN * 32, lane, acc);
+                    omni_barrier_lds();       // not __syncthreads(): that would drain the loads in flight (vmcnt(0))
+                }
+            }
+        }
     }
     const int l31 = lane & 31, h = lane >> 5;
     const bool split = gridDim.y > 1;
@@ -711,6 +742,184 @@ __global__ void __launch_bounds__(256) gemm_nt_persistent_kernel(GemmP p) {
 }
 
 
+// =================================================================================================
+// Deep-prefetch tile GEMM (round 3)   out[b] (M x N) = A[b] (M x K) * B[b] (N x K)^T,  K % (32 * PF) == 0
+//   The small-map Winograd point GEMMs (DLA levels 3-5: 36 x [256..1024 x 128..512]) have a reduction of only 4-16 slabs and
+//   need 64x64 tiles to put >= 2 workgroups on every CU.  With the classic double buffer a wave's MFMA phase per slab is
+//   0.43 us against ~2 us of load latency: the launch is a chain of exposed latencies (round 2: 0.34 of peak, MFMA-busy 0.26).
+//   This kernel keeps PF slabs of global loads in flight per thread:
+//     * loads are `buffer_load_dwordx4` through a buffer resource sized to the problem, so rows past M / N and slabs past K
+//       return zeros WITHOUT a branch -- every iteration issues the same number of loads unconditionally, which is what lets
+//       the compiler's wait-count insertion use vmcnt(PF-1 slabs) instead of vmcnt(0) (a guarded load makes it drain everything);
+//     * the LDS hand-over uses s_barrier with an lgkmcnt-only wait (omni_barrier_lds): __syncthreads() would drain vmcnt too;
+//     * LDS stays double buffered (2 x 18 KB), stage registers: PF x 16 VGPRs.
+// =================================================================================================
+struct GemmTP {
+    const float* A;
+    const float* B;
+    float* out;
+    int M, N, K;
+    long ab, bb, ob;       // element strides between the gridDim.z problems
+};
+
+typedef unsigned omni_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 bufld4(omni_rsrc_t r, int voff) {
+#ifdef OMNI_HIPEMU
+    float4 v = zero4();
+    if ((unsigned)voff + 16u <= r.bytes) memcpy(&v, r.base + (unsigned)voff, 16);
+    return v;
+#else
+    const omni_u4 u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+#endif
+}
+
+template <int PF>
+__global__ void __launch_bounds__(256) gemm_nt_pf_kernel(GemmTP p) {
+    constexpr int BM = 64, BN = 64, BKX = 32, BKP = BKX + 4, KQ = BKX / 4, RPP = 256 / KQ, AI = BM / RPP, BI = BN / RPP;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BKP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kq = tid % KQ, lrow = tid / KQ;
+    const omni_rsrc_t ra_ = omni_make_rsrc(p.A + (long)blockIdx.z * p.ab, (unsigned)p.M * (unsigned)p.K * 4u);
+    const omni_rsrc_t rb_ = omni_make_rsrc(p.B + (long)blockIdx.z * p.bb, (unsigned)p.N * (unsigned)p.K * 4u);
+    float* out = p.out + (long)blockIdx.z * p.ob;
+    int tile_m, tile_n;
+    tile_coords((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // byte offsets of this thread's float4 column in its AI / BI rows; a row past the end lands past the resource -> zeros
+    int a_off[AI], b_off[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + lrow + RPP * i;
+        a_off[i] = m < p.M ? (m * p.K + kq * 4) * 4 : OMNI_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int n = n0 + lrow + RPP * j;
+        b_off[j] = n < p.N ? (n * p.K + kq * 4) * 4 : OMNI_OOB;
+    }
+    const int nk = p.K / BKX;                       // multiple of PF (launcher)
+    const int k_end = p.K * 4;                      // bytes per row: a slab past it must not run into the next row
+    int koff = 0;                                   // byte offset of the slab the NEXT load_slab() fetches
+    float4 ra[PF][AI], rb[PF][BI];
+    auto load_slab = [&](const int st) {
+        const bool kok = koff < k_end;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) ra[st][i] = bufld4(ra_, kok ? a_off[i] + koff : OMNI_OOB);
+#pragma unroll
+        for (int j = 0; j < BI; ++j) rb[st][j] = bufld4(rb_, kok ? b_off[j] + koff : OMNI_OOB);
+        koff += BKX * 4;
+    };
+    auto store_slab = [&](int buf, const int st) {
+        float* As = smem + buf * (BM + BN) * BKP;
+        float* Bs = As + BM * BKP;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<float4*>(As + (lrow + RPP * i) * BKP + kq * 4) = ra[st][i];
+#pragma unroll
+        for (int j = 0; j < BI; ++j) *reinterpret_cast<float4*>(Bs + (lrow + RPP * j) * BKP + kq * 4) = rb[st][j];
+    };
+    f32x16 acc[1][1];
+    zero_acc<1, 1>(acc);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) load_slab(s);       // slabs 0 .. PF-1
+    store_slab(0, 0);
+    load_slab(0);                                    // slab PF into the stage just drained
+    omni_barrier_lds();
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int buf = (kt0 + u) & 1;
+            store_slab(buf ^ 1, (u + 1) % PF);       // slab kt + 1 (zeros past the end: written, never read)
+            load_slab((u + 1) % PF);                 // slab kt + 1 + PF, unconditionally (see header)
+            const float* As = smem + buf * (BM + BN) * BKP;
+            mma_slab<1, 1, true, true, 0, 0, BKX>(As, As + BM * BKP, wm * 32, wn * 32, lane, acc);
+            omni_barrier_lds();
+        }
+    }
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n = n0 + wn * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.M && n < p.N) out[(long)m * p.N + n] = acc[0][0][r];
+    }
+}
+
+// TN twin of gemm_nt_pf_kernel: out[b] (Kc x C) (+)= A[b]^T B[b] with A (M x Kc), B (M x C), the reduction running over the M
+// rows (Winograd-domain weight gradient dU = dM^T V of the small maps).  gridDim.y splits the rows (`rows_per_split`, a multiple
+// of 32 * PF); a split launch adds its partial tile atomically into a zeroed output, a single split stores it.
+template <int PF>
+__global__ void __launch_bounds__(256) gemm_tn_pf_kernel(GemmTP p, int rows_per_split) {
+    constexpr int BM = 64, BN = 64, BK = 32, F4 = BM / 4, ROWS = 256 / F4, LI = BK / ROWS;      // 16 float4 per row, 16 rows per pass
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int c4 = tid % F4, lrow = tid / F4;
+    const omni_rsrc_t ra_ = omni_make_rsrc(p.A + (long)blockIdx.z * p.ab, (unsigned)p.M * (unsigned)p.N * 4u);   // p.N = Kc (A's width)
+    const omni_rsrc_t rb_ = omni_make_rsrc(p.B + (long)blockIdx.z * p.bb, (unsigned)p.M * (unsigned)p.K * 4u);   // p.K = C  (B's width)
+    float* out = p.out + (long)blockIdx.z * p.ob;
+    const int tiles_m = (p.N + BM - 1) / BM;
+    const int m0 = ((int)blockIdx.x % tiles_m) * BM, n0 = ((int)blockIdx.x / tiles_m) * BN;
+    const int r_begin = (int)blockIdx.y * rows_per_split;
+    const int r_end = min(r_begin + rows_per_split, p.M);
+    const int nk = (r_end - r_begin + BK - 1) / BK;
+    // this thread's float4 column in A / B (fixed) and its first row; out-of-range columns / rows read zeros through the resource
+    const int am = m0 + c4 * 4, bn = n0 + c4 * 4;
+    const bool a_ok = am < p.N, b_ok = bn < p.K;
+    int row = r_begin + lrow;                       // row of the NEXT load_slab()'s first pass
+    float4 ra[PF][LI], rb[PF][LI];
+    auto load_slab = [&](const int st) {
+#pragma unroll
+        for (int i = 0; i < LI; ++i) {
+            const int r = row + ROWS * i;
+            const bool ok = r < r_end;
+            ra[st][i] = bufld4(ra_, (ok && a_ok) ? (r * p.N + am) * 4 : OMNI_OOB);
+            rb[st][i] = bufld4(rb_, (ok && b_ok) ? (r * p.K + bn) * 4 : OMNI_OOB);
+        }
+        row += BK;
+    };
+    auto store_slab = [&](int buf, const int st) {
+        float* As = smem + buf * BK * (BM + BN);
+        float* Bs = As + BK * BM;
+#pragma unroll
+        for (int i = 0; i < LI; ++i) {
+            *reinterpret_cast<float4*>(As + (lrow + ROWS * i) * BM + c4 * 4) = ra[st][i];
+            *reinterpret_cast<float4*>(Bs + (lrow + ROWS * i) * BN + c4 * 4) = rb[st][i];
+        }
+    };
+    f32x16 acc[1][1];
+    zero_acc<1, 1>(acc);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) load_slab(s);
+    store_slab(0, 0);
+    load_slab(0);
+    omni_barrier_lds();
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int buf = (kt0 + u) & 1;
+            store_slab(buf ^ 1, (u + 1) % PF);
+            load_slab((u + 1) % PF);
+            const float* As = smem + buf * BK * (BM + BN);
+            mma_slab<1, 1, false, false, BM, BN, BK>(As, As + BK * BM, wm * 32, wn * 32, lane, acc);
+            omni_barrier_lds();
+        }
+    }
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n = n0 + wn * 32 + l31;
+    const bool single = gridDim.y == 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.N && n < p.K) {
+            float* o = out + (long)m * p.K + n;
+            if (single) *o = acc[0][0][r];
+            else atomicAdd(o, acc[0][0][r]);
+        }
+    }
+}
+
 inline bool bad_geom(const ConvP& p) {
     return p.N < 0 || p.H <= 0 || p.W <= 0 || p.C <= 0 || p.K <= 0 || p.R <= 0 || p.S <= 0 || p.stride <= 0 ||
            p.pad < 0 || (p.C & 3) || p.OH != (p.H + 2 * p.pad - p.R) / p.stride + 1 ||
@@ -728,9 +937,12 @@ extern "C" {
 // split over gridDim.y with an atomic epilogue into a zeroed output.  Slab depth 32 (one barrier per 64
 // MFMAs per wave) measured +23 % over 16 on the 3x3 256->256 @128x128 shape (96 -> 119 TFLOP/s).
 // `tile` / `splits` select the algorithm explicitly (0 = the launcher's own choice, which is what omni_conv2d_fwd uses):
-//   tile 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 256x32 (BM x BN output-pixel x output-channel tile); splits >= 1 = number of
+//   tile 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 256x32 (BM x BN output-pixel x output-channel tile), 5 = 64x64 with three
+//   slabs of register prefetch; splits >= 1 = number of
 //   reduction splits (atomic epilogue into a zeroed output when > 1; needs ldo == K).  Used by tools/bench_kernels.py for A/B
 //   measurements and by tests that want a given tile on a small problem.
+constexpr bool FWD64_DEEP_PREFETCH = true;    // batched GEMMs on 64x64 tiles: gemm_nt_pf_kernel (profiles/r03_sweep_batched_gemm.log: 17-27 % faster on every small-map shape)
+
 static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
                            int R, int S, int stride, int pad, int ldx, int ldo, int relu, int tile, int splits_req, float* stats,
                            int stats_rows, int* nblk_out, void* stream) {
@@ -738,7 +950,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
             R, S, stride, pad, ldx, ldo, 0, relu, 0, 1};
     p.stats = nullptr;
     if (nblk_out) *nblk_out = 0;
-    if (bad_geom(p) || (ldx & 3) || ldx < C || ldo < K || tile < 0 || tile > 4 || splits_req < 0) return OMNI_ERR_ARG;
+    if (bad_geom(p) || (ldx & 3) || ldx < C || ldo < K || tile < 0 || tile > 5 || splits_req < 0) return OMNI_ERR_ARG;
     if (splits_req > 1 && ldo != K) return OMNI_ERR_ARG;
     const long M = (long)N * p.OH * p.OW;
     if (M == 0) return OMNI_OK;
@@ -772,20 +984,21 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
     if (splits > nslab) splits = nslab;
     if (splits > 1) omni_memset_async(out, 0, sizeof(float) * (size_t)M * K, st);
     if (stats != nullptr && splits == 1 && bias == nullptr && !relu) {      // statistics only from complete, raw outputs
-        const int bm = tile == 1 ? 128 : tile == 2 ? 64 : tile == 3 ? 128 : 256;
+        const int bm = tile == 1 ? 128 : (tile == 2 || tile == 5) ? 64 : tile == 3 ? 128 : 256;
         const long rows = (M + bm - 1) / bm;
         if (rows <= stats_rows) {
             p.stats = stats;
             if (nblk_out) *nblk_out = (int)rows;
         }
     }
-#define OMNI_FWD(BM_, BN_, WM_, WN_, BK_)                                                                                \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<BM_, BN_, WM_, WN_, BK_>),                                          \
+#define OMNI_FWD(BM_, BN_, WM_, WN_, BK_, PF_)                                                                           \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<BM_, BN_, WM_, WN_, BK_, PF_>),                                     \
                        dim3((unsigned)(((M + BM_ - 1) / BM_) * ((K + BN_ - 1) / BN_)), (unsigned)splits), dim3(256), 0, st, p)
-    if (tile == 1) OMNI_FWD(128, 128, 2, 2, 32);
-    else if (tile == 2) OMNI_FWD(64, 64, 2, 2, 32);
-    else if (tile == 3) OMNI_FWD(128, 64, 2, 2, 32);
-    else OMNI_FWD(256, 32, 4, 1, 16);   // tiny channel counts (stem, level0/1, RPN 16-wide heads): slab depth 16 measured faster
+    if (tile == 1) OMNI_FWD(128, 128, 2, 2, 32, 1);
+    else if (tile == 2) OMNI_FWD(64, 64, 2, 2, 32, 1);
+    else if (tile == 5) OMNI_FWD(64, 64, 2, 2, 32, 3);
+    else if (tile == 3) OMNI_FWD(128, 64, 2, 2, 32, 1);
+    else OMNI_FWD(256, 32, 4, 1, 16, 1);   // tiny channel counts (stem, level0/1, RPN 16-wide heads): slab depth 16 measured faster
 #undef OMNI_FWD
     if (splits > 1 && relu) {
         const long n4 = M * K / 4;
@@ -927,10 +1140,11 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
 // ---- batched GEMMs of the Winograd path (csrc/winograd.hip): `batch` independent dense problems in one launch ----
 // out[b] (M x K) = x[b] (M x C) * w[b] (K x C)^T
 // algo: 0 auto | 1 = persistent 128x128 workgroups walking the (problem, tile) list (`workgroups` of them, 0 = 512; needs
-// C % 32 == 0) | 2 = one 128x128 tile per workgroup | 3 = one 64x64 tile per workgroup
+// C % 32 == 0) | 2 = one 128x128 tile per workgroup | 3 = one 64x64 tile per workgroup | 4 = 64x64 tiles with 2-4 slabs of
+// buffer-load prefetch in flight (gemm_nt_pf_kernel; needs C % 64 == 0)
 int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int batch, int M, int C, int K, int algo, int workgroups,
                                void* stream) {
-    if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3) || algo < 0 || algo > 3 || workgroups < 0) return OMNI_ERR_ARG;
+    if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3) || algo < 0 || algo > 4 || workgroups < 0) return OMNI_ERR_ARG;
     if (algo == 1 && ((C % 32) != 0 || (workgroups & 7))) return OMNI_ERR_ARG;
     if (M == 0) return OMNI_OK;
     ConvP p{x, w, nullptr, out, M, 1, 1, C, 1, 1, K, 1, 1, 1, 0, C, K, 0, 0, 0, 1, (long)M * C, (long)K * C, (long)M * K};
@@ -944,13 +1158,21 @@ int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int b
         hipLaunchKernelGGL(gemm_nt_persistent_kernel, dim3(workgroups ? workgroups : 512), dim3(256), 0, (hipStream_t)stream, g);
         return omni_launch_status();
     }
+    if (algo == 3 && FWD64_DEEP_PREFETCH && (C % 64) == 0 && (long)M * C * 4 < (1L << 31) && (long)K * C * 4 < (1L << 31)) algo = 4;
     if (algo == 2)   // else 64x64 tiles: 4x the workgroups (measured on the 256ch @32x32 layers)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<128, 128, 2, 2, 32>), dim3((unsigned)t128, 1, (unsigned)batch), dim3(256), 0,
                            (hipStream_t)stream, p);
-    else
+    else if (algo == 3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<64, 64, 2, 2, 32>),
                            dim3((unsigned)((((long)M + 63) / 64) * ((K + 63) / 64)), 1, (unsigned)batch), dim3(256), 0,
                            (hipStream_t)stream, p);
+    else {           // 64x64 tiles, PF slabs of buffer-load prefetch in flight (gemm_nt_pf_kernel)
+        if ((C % 64) != 0 || (long)M * C * 4 >= (1L << 31) || (long)K * C * 4 >= (1L << 31)) return OMNI_ERR_ARG;
+        GemmTP g{x, w, out, M, K, C, (long)M * C, (long)K * C, (long)M * K};
+        const dim3 grid((unsigned)((((long)M + 63) / 64) * ((K + 63) / 64)), 1, (unsigned)batch);
+        if ((C % 128) == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_nt_pf_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_nt_pf_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    }
     return omni_launch_status();
 }
 
@@ -959,12 +1181,34 @@ int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch,
 }
 
 // dw[b] (K x C) = dy[b] (M x K)^T * x[b] (M x C)      (overwrites dw)
-int omni_gemm_batched_wgrad(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, void* stream) {
-    if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3) || (K & 3)) return OMNI_ERR_ARG;
+// algo: 0 auto | 1 = the tile kernels of the implicit-GEMM weight gradient (128x128 / 64x64, one slab of prefetch) | 2 = 64x64 tiles
+// with 2-4 slabs of buffer-load prefetch in flight (gemm_tn_pf_kernel)
+constexpr bool WGRAD64_DEEP_PREFETCH = true;    // gemm_tn_pf_kernel (profiles/r03_sweep_batched_gemm.log: 3-66 % faster on every Winograd weight-gradient shape)
+
+int omni_gemm_batched_wgrad_algo(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, int algo, void* stream) {
+    if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3) || (K & 3) || algo < 0 || algo > 2) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (M == 0) {
         omni_memset_async(dw, 0, sizeof(float) * (size_t)batch * K * C, st);
         return OMNI_OK;
+    }
+    const bool fits = (long)M * C * 4 < (1L << 31) && (long)M * K * 4 < (1L << 31);
+    if (algo == 2 && !fits) return OMNI_ERR_ARG;
+    if (algo == 0) algo = (WGRAD64_DEEP_PREFETCH && fits) ? 2 : 1;
+    if (algo == 2) {
+        const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
+        // >= 8 slabs per split, aim at >= 512 workgroups
+        long splits = (512 + (long)tiles * batch - 1) / ((long)tiles * batch);
+        const long max_splits = ((long)M + 255) / 256;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        int rps = (int)(((long)M + splits - 1) / splits);
+        rps = (rps + 127) / 128 * 128;                                   // multiple of 32 * PF for PF = 4
+        splits = ((long)M + rps - 1) / rps;
+        if (splits > 1) omni_memset_async(dw, 0, sizeof(float) * (size_t)batch * K * C, st);
+        GemmTP g{dy, x, dw, M, K, C, (long)M * K, (long)M * C, (long)K * C};
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_tn_pf_kernel<4>), dim3(tiles, (unsigned)splits, (unsigned)batch), dim3(256), 0, st, g, rps);
+        return omni_launch_status();
     }
     ConvP p{x, dy, nullptr, dw, M, 1, 1, C, 1, 1, K, 1, 1, 1, 0, C, 0, K, 0, 0, 1, (long)M * C, (long)M * K, (long)K * C};
     constexpr int WBK = 32;
@@ -986,6 +1230,10 @@ int omni_gemm_batched_wgrad(const float* x, const float* dy, float* dw, int batc
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<64, 64, 2, 2, WBK>), dim3(tiles, (unsigned)splits, (unsigned)batch),
                            dim3(256), 0, st, p, pps);
     return omni_launch_status();
+}
+
+int omni_gemm_batched_wgrad(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, void* stream) {
+    return omni_gemm_batched_wgrad_algo(x, dy, dw, batch, M, C, K, 0, stream);
 }
 
 // ---- grouped convolution: nn.Conv2d(C, K, R, stride, pad, groups=G, bias=False), the 3x3 of DLA's BottleneckX

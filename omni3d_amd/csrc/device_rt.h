@@ -96,5 +96,14 @@ __device__ __forceinline__ void omni_barrier() {          // s_barrier WITHOUT t
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+// workgroup barrier for LDS hand-over with global loads still in flight: waits for this wave's LDS traffic only (lgkmcnt), not
+// for vmcnt -- __syncthreads() drains both, which serialises every register-staged prefetch deeper than one slab
+__device__ __forceinline__ void omni_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// register budget hint: ask the compiler to fit n waves per SIMD (512 / n VGPRs)
+#define OMNI_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
 #define OMNI_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)      /* 0x8 MFMA, 0x20 VMEM read, 0x100 DS read */
 #define OMNI_SETPRIO(n) __builtin_amdgcn_s_setprio(n)

@@ -142,32 +142,29 @@ __device__ __forceinline__ int clip_tri(const V3* pv, V3 pc, V3 normal, const Tr
 }
 
 // LDS of ONE pair.  After the six plane passes the spare ping-pong buffer holds the dedupe phase's per-triangle unit normals
-// [CAP*3], areas [CAP] and box2 keep flags [CAP] (5 of its 9 floats per triangle).
+// [CAPT*3], areas [CAPT] and box2 keep flags [CAPT] (5 of its 9 floats per triangle).
+template <int CAPT>
 struct PairLds {
-    float tri[2][CAP * 9];   // ping-pong triangle lists
+    float tri[2][CAPT * 9];  // ping-pong triangle lists
     float box[2][24];        // the two boxes' corners
     float pc[2][6][3];       // face-plane centres
     float pn[2][6][3];       // face-plane normals, pointing inside
     float vol[2];            // box volumes
 };
 
-// MODE 0: matrix (pair p -> a = p / M, b = p % M); MODE 1: indexed pairs.
-// SUB = lanes per pair: a wave works on G = 64 / SUB pairs side by side (round 3).  A pair's joint triangle list starts with 24
+constexpr float IOU_RETRY = -1.0f;   // first-pass marker: "this pair's triangle list outgrew the small LDS lists, recompute it"
+
+// One pair per SUB-lane sub-group (G = 64 / SUB pairs per wave side by side).  A pair's joint triangle list starts with 24
 // entries and rarely exceeds 40, so with one pair per wave at most ~40 of the 64 lanes ever had a triangle (PMC round 2: VALU
 // active 44 % of the wave cycles); sub-groups of 32 lanes run two pairs through the same instruction stream.  Every ballot is
 // taken over the wave and cut to the sub-group's bit range, loops that contain wave-level operations run to the maximum trip
 // count over the sub-groups, and each sub-group keeps its own LDS lists, so the per-pair algorithm -- including the order of
 // the triangles, which the epsilon rules depend on -- is unchanged.
-template <int MODE, int SUB>
-__global__ void __launch_bounds__(64) iou_box3d_kernel(const float* __restrict__ boxes1, const float* __restrict__ boxes2,
-                                                       const int* __restrict__ idx1, const int* __restrict__ idx2,
-                                                       const int* __restrict__ valid1, long long npairs, int M,
-                                                       float* __restrict__ vol_out, float* __restrict__ iou_out,
-                                                       int* __restrict__ overflow) {
-    constexpr int G = 64 / SUB;
-    __shared__ PairLds Lall[G];
-    const int lane = threadIdx.x, g = lane / SUB, sl = lane % SUB;
-    PairLds& L = Lall[g];
+// act: this sub-group has a pair (b1 / b2 = its boxes); -> vol, iou (sub-group uniform), over = a list hit CAPT.
+template <int SUB, int CAPT>
+__device__ __forceinline__ void iou_pair_body(PairLds<CAPT>& L, const bool act, const float* __restrict__ b1, const float* __restrict__ b2,
+                                              const int lane, float& vol_r, float& iou_r, bool& over_r) {
+    const int g = lane / SUB, sl = lane % SUB;
     const int shift = g * SUB;
     const unsigned long long sub_all = (SUB == 64) ? ~0ull : ((1ull << (SUB & 63)) - 1ull);
     const unsigned long long sub_lt = (sl == 0) ? 0ull : (~0ull >> (64 - sl));      // sub-group lanes below this one
@@ -181,178 +178,278 @@ __global__ void __launch_bounds__(64) iou_box3d_kernel(const float* __restrict__
         for (int m = SUB / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
         return v;
     };
-
-    for (long long pbase = (long long)blockIdx.x * G; pbase < npairs; pbase += (long long)gridDim.x * G) {
-        const long long p = pbase + g;
-        bool act = p < npairs;
-        int ia = 0, ib = 0;
-        if (act) {
-            if (MODE == 0) { ia = (int)(p / M); ib = (int)(p % M); }
-            else { ia = idx1[p]; ib = idx2[p]; }
-            if (valid1 != nullptr && valid1[ia] == 0) {
-                if (sl == 0) { if (vol_out) vol_out[p] = 0.f; iou_out[p] = 0.f; }
-                act = false;
-            }
+    __syncthreads();  // previous pairs' LDS reads are done
+    if (act)
+        for (int k = sl; k < 48; k += SUB) {
+            if (k < 24) L.box[0][k] = b1[k];
+            else L.box[1][k - 24] = b2[k - 24];
         }
-        if (!__any(act)) continue;
-        __syncthreads();  // previous pairs' LDS reads are done
-        if (act)
-            for (int k = sl; k < 48; k += SUB) {
-                if (k < 24) L.box[0][k] = boxes1[(size_t)ia * 24 + k];
-                else L.box[1][k - 24] = boxes2[(size_t)ib * 24 + (k - 24)];
-            }
-        __syncthreads();
+    __syncthreads();
 
-        // ---- per-box prologue: face planes (sub-lanes 0..11), volumes (12, 13), initial triangles (all)
-        if (act && sl < 12) {
-            const int bx = sl / 6, f = sl % 6;
+    // ---- per-box prologue: face planes (sub-lanes 0..11), volumes (12, 13), initial triangles (all)
+    if (act && sl < 12) {
+        const int bx = sl / 6, f = sl % 6;
+        const float* B = L.box[bx];
+        V3 ctr = mk(0.f, 0.f, 0.f);
+        for (int t = 0; t < 8; ++t) { ctr.x += B[3 * t]; ctr.y += B[3 * t + 1]; ctr.z += B[3 * t + 2]; }
+        ctr = vdiv(ctr, 8.0f);
+        V3 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = ldv(B + 3 * c_box_planes[f][k]);
+        V3 pc = vdiv(vadd(vadd(vadd(q[0], q[1]), q[2]), q[3]), 4.0f);
+        float best = -1.0f;
+        V3 n = mk(0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 4; ++j) {
+                V3 a = vsub(q[i], pc), b = vsub(q[j], pc);
+                float d = vnorm(vcross(a, b));
+                if (d > best) { best = d; n = get_normal(a, b); }
+            }
+        if (vdot(vsub(ctr, pc), n) < 0.0f) n = vscale(n, -1.0f);
+        stv(L.pc[bx][f], pc);
+        stv(L.pn[bx][f], n);
+    } else if (act && sl < 14) {
+        const int bx = sl - 12;
+        const float* B = L.box[bx];
+        V3 ctr = mk(0.f, 0.f, 0.f);
+        for (int t = 0; t < 8; ++t) { ctr.x += B[3 * t]; ctr.y += B[3 * t + 1]; ctr.z += B[3 * t + 2]; }
+        ctr = vdiv(ctr, 8.0f);
+        float vol = 0.f;
+        for (int t = 0; t < 12; ++t) {
+            V3 a = vsub(ldv(B + 3 * c_box_tris[t][0]), ctr);
+            V3 b = vsub(ldv(B + 3 * c_box_tris[t][1]), ctr);
+            V3 c = vsub(ldv(B + 3 * c_box_tris[t][2]), ctr);
+            vol += fabsf(vdot(a, vcross(b, c))) / 6.0f;
+        }
+        L.vol[bx] = vol;
+    }
+    if (act)
+        for (int t = sl; t < 24; t += SUB) {
+            const int bx = t / 12, tt = t % 12;
             const float* B = L.box[bx];
-            V3 ctr = mk(0.f, 0.f, 0.f);
-            for (int t = 0; t < 8; ++t) { ctr.x += B[3 * t]; ctr.y += B[3 * t + 1]; ctr.z += B[3 * t + 2]; }
-            ctr = vdiv(ctr, 8.0f);
-            V3 q[4];
+            float* dst = L.tri[0] + t * 9;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = ldv(B + 3 * c_box_planes[f][k]);
-            V3 pc = vdiv(vadd(vadd(vadd(q[0], q[1]), q[2]), q[3]), 4.0f);
-            float best = -1.0f;
-            V3 n = mk(0.f, 0.f, 0.f);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = i + 1; j < 4; ++j) {
-                    V3 a = vsub(q[i], pc), b = vsub(q[j], pc);
-                    float d = vnorm(vcross(a, b));
-                    if (d > best) { best = d; n = get_normal(a, b); }
-                }
-            if (vdot(vsub(ctr, pc), n) < 0.0f) n = vscale(n, -1.0f);
-            stv(L.pc[bx][f], pc);
-            stv(L.pn[bx][f], n);
-        } else if (act && sl < 14) {
-            const int bx = sl - 12;
-            const float* B = L.box[bx];
-            V3 ctr = mk(0.f, 0.f, 0.f);
-            for (int t = 0; t < 8; ++t) { ctr.x += B[3 * t]; ctr.y += B[3 * t + 1]; ctr.z += B[3 * t + 2]; }
-            ctr = vdiv(ctr, 8.0f);
-            float vol = 0.f;
-            for (int t = 0; t < 12; ++t) {
-                V3 a = vsub(ldv(B + 3 * c_box_tris[t][0]), ctr);
-                V3 b = vsub(ldv(B + 3 * c_box_tris[t][1]), ctr);
-                V3 c = vsub(ldv(B + 3 * c_box_tris[t][2]), ctr);
-                vol += fabsf(vdot(a, vcross(b, c))) / 6.0f;
-            }
-            L.vol[bx] = vol;
+            for (int k = 0; k < 3; ++k) stv(dst + 3 * k, ldv(B + 3 * c_box_tris[tt][k]));
         }
-        if (act)
-            for (int t = sl; t < 24; t += SUB) {
-                const int bx = t / 12, tt = t % 12;
-                const float* B = L.box[bx];
-                float* dst = L.tri[0] + t * 9;
+    __syncthreads();
+
+    // ---- six plane passes over the joint list: entries [0,nA) are box1 triangles clipped by
+    //      box2's planes, entries [nA,n) box2 triangles clipped by box1's planes
+    int n = act ? 24 : 0, nA = act ? 12 : 0, cur = 0;
+    bool over = false;
+    for (int f = 0; f < 6; ++f) {
+        const float* src = L.tri[cur];
+        float* dst = L.tri[cur ^ 1];
+        int base = 0, newA = 0;
+        const int nmax = group_max(n);
+        for (int i0 = 0; i0 < nmax; i0 += SUB) {
+            const int i = i0 + sl;
+            int cnt = 0;
+            Tri o0, o1;
+            if (i < n) {
+                const int other = (i < nA) ? 1 : 0;  // plane set of the other box
+                V3 pv[4];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) stv(dst + 3 * k, ldv(B + 3 * c_box_tris[tt][k]));
+                for (int k = 0; k < 4; ++k) pv[k] = ldv(L.box[other] + 3 * c_box_planes[f][k]);
+                Tri t = ldtri(src + i * 9);
+                cnt = clip_tri(pv, ldv(L.pc[other][f]), ldv(L.pn[other][f]), t, o0, o1);
             }
+            const unsigned long long b1m = (__ballot(cnt >= 1) >> shift) & sub_all, b2m = (__ballot(cnt == 2) >> shift) & sub_all;
+            const int off = base + __popcll(b1m & sub_lt) + __popcll(b2m & sub_lt);
+            if (cnt >= 1) { if (off < CAPT) sttri(dst + off * 9, o0); else over = true; }
+            if (cnt == 2) { if (off + 1 < CAPT) sttri(dst + (off + 1) * 9, o1); else over = true; }
+            // outputs produced by box1-side entries of this round
+            int nAround = nA - i0; nAround = nAround < 0 ? 0 : (nAround > SUB ? SUB : nAround);
+            const unsigned long long amask = (nAround >= 64) ? ~0ull : ((1ull << nAround) - 1ull);
+            newA += __popcll(b1m & amask) + __popcll(b2m & amask);
+            base += __popcll(b1m) + __popcll(b2m);
+        }
+        n = base < CAPT ? base : CAPT;
+        nA = newA < n ? newA : n;
+        cur ^= 1;
         __syncthreads();
+    }
+    const float* T = L.tri[cur];
+    float* aux = L.tri[cur ^ 1];                 // spare list: normals | areas | keep flags of the dedupe phase
+    float* nrm = aux;
+    float* area = aux + 3 * CAPT;
+    int* keep = reinterpret_cast<int*>(aux + 4 * CAPT);
+    const int n1 = nA, n2 = n - nA;
 
-        // ---- six plane passes over the joint list: entries [0,nA) are box1 triangles clipped by
-        //      box2's planes, entries [nA,n) box2 triangles clipped by box1's planes
-        int n = act ? 24 : 0, nA = act ? 12 : 0, cur = 0;
-        bool over = false;
-        for (int f = 0; f < 6; ++f) {
-            const float* src = L.tri[cur];
-            float* dst = L.tri[cur ^ 1];
-            int base = 0, newA = 0;
-            const int nmax = group_max(n);
-            for (int i0 = 0; i0 < nmax; i0 += SUB) {
-                const int i = i0 + sl;
-                int cnt = 0;
-                Tri o0, o1;
-                if (i < n) {
-                    const int other = (i < nA) ? 1 : 0;  // plane set of the other box
-                    V3 pv[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) pv[k] = ldv(L.box[other] + 3 * c_box_planes[f][k]);
-                    Tri t = ldtri(src + i * 9);
-                    cnt = clip_tri(pv, ldv(L.pc[other][f]), ldv(L.pn[other][f]), t, o0, o1);
-                }
-                const unsigned long long b1 = (__ballot(cnt >= 1) >> shift) & sub_all, b2 = (__ballot(cnt == 2) >> shift) & sub_all;
-                const int off = base + __popcll(b1 & sub_lt) + __popcll(b2 & sub_lt);
-                if (cnt >= 1) { if (off < CAP) sttri(dst + off * 9, o0); else over = true; }
-                if (cnt == 2) { if (off + 1 < CAP) sttri(dst + (off + 1) * 9, o1); else over = true; }
-                // outputs produced by box1-side entries of this round
-                int nAround = nA - i0; nAround = nAround < 0 ? 0 : (nAround > SUB ? SUB : nAround);
-                const unsigned long long amask = (nAround >= 64) ? ~0ull : ((1ull << nAround) - 1ull);
-                newA += __popcll(b1 & amask) + __popcll(b2 & amask);
-                base += __popcll(b1) + __popcll(b2);
+    // ---- coplanar duplicate removal: box2 triangle q is dropped if coplanar with some box1
+    //      triangle r whose area exceeds aEpsilon
+    for (int i = sl; i < n; i += SUB) {
+        Tri t = ldtri(T + i * 9);
+        stv(nrm + 3 * i, tri_normal(t));
+        area[i] = tri_area(t);
+        keep[i] = 1;
+    }
+    __syncthreads();
+    const int npair = n1 * n2;
+    for (int w = sl; w < npair; w += SUB) {
+        const int r = w / n2, q = n1 + (w % n2);
+        if (area[r] > A_EPS) {
+            V3 na = ldv(nrm + 3 * r), nb = ldv(nrm + 3 * q);
+            if (fabsf(vdot(na, nb)) > 1.0f - D_EPS) {
+                Tri ta = ldtri(T + r * 9);
+                Tri tb = ldtri(T + q * 9);
+                V3 d = argmax_dir<3>(ta, tb.v);
+                if ((fabsf(vdot(d, na)) < D_EPS) || (fabsf(vdot(d, nb)) < D_EPS)) keep[q] = 0;
             }
-            n = base < CAP ? base : CAP;
-            nA = newA < n ? newA : n;
-            cur ^= 1;
-            __syncthreads();
         }
-        const float* T = L.tri[cur];
-        float* aux = L.tri[cur ^ 1];                 // spare list: normals | areas | keep flags of the dedupe phase
-        float* nrm = aux;
-        float* area = aux + 3 * CAP;
-        int* keep = reinterpret_cast<int*>(aux + 4 * CAP);
-        const int n1 = nA, n2 = n - nA;
+    }
+    __syncthreads();
 
-        // ---- coplanar duplicate removal: box2 triangle q is dropped if coplanar with some box1
-        //      triangle r whose area exceeds aEpsilon
-        for (int i = sl; i < n; i += SUB) {
+    // ---- polyhedron centre and tetrahedron-sum volume over the surviving triangles (box1's list + kept box2 entries),
+    //      sub-group reductions.  The survivors are not compacted: sums do not care about the order.
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    int mine = 0;
+    for (int i = sl; i < n; i += SUB) {
+        if (i < n1 || keep[i] != 0) {
             Tri t = ldtri(T + i * 9);
-            stv(nrm + 3 * i, tri_normal(t));
-            area[i] = tri_area(t);
-            keep[i] = 1;
+            cx += (t.v[0].x + t.v[1].x + t.v[2].x) / 3.0f;
+            cy += (t.v[0].y + t.v[1].y + t.v[2].y) / 3.0f;
+            cz += (t.v[0].z + t.v[1].z + t.v[2].z) / 3.0f;
+            ++mine;
         }
-        __syncthreads();
-        const int npair = n1 * n2;
-        for (int w = sl; w < npair; w += SUB) {
-            const int r = w / n2, q = n1 + (w % n2);
-            if (area[r] > A_EPS) {
-                V3 na = ldv(nrm + 3 * r), nb = ldv(nrm + 3 * q);
-                if (fabsf(vdot(na, nb)) > 1.0f - D_EPS) {
-                    Tri ta = ldtri(T + r * 9);
-                    Tri tb = ldtri(T + q * 9);
-                    V3 d = argmax_dir<3>(ta, tb.v);
-                    if ((fabsf(vdot(d, na)) < D_EPS) || (fabsf(vdot(d, nb)) < D_EPS)) keep[q] = 0;
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- polyhedron centre and tetrahedron-sum volume over the surviving triangles (box1's list + kept box2 entries),
-        //      sub-group reductions.  The survivors are not compacted: sums do not care about the order.
-        float cx = 0.f, cy = 0.f, cz = 0.f;
-        int mine = 0;
+    }
+    cx = group_sum(cx); cy = group_sum(cy); cz = group_sum(cz);
+    const int m = (int)(group_sum((float)mine) + 0.5f);
+    float v = 0.f;
+    if (m > 0) {
+        V3 ctr = vdiv(mk(cx, cy, cz), (float)m);
         for (int i = sl; i < n; i += SUB) {
             if (i < n1 || keep[i] != 0) {
                 Tri t = ldtri(T + i * 9);
-                cx += (t.v[0].x + t.v[1].x + t.v[2].x) / 3.0f;
-                cy += (t.v[0].y + t.v[1].y + t.v[2].y) / 3.0f;
-                cz += (t.v[0].z + t.v[1].z + t.v[2].z) / 3.0f;
-                ++mine;
+                V3 a = vsub(t.v[0], ctr), b = vsub(t.v[1], ctr), c = vsub(t.v[2], ctr);
+                v += fabsf(vdot(a, vcross(b, c))) / 6.0f;
             }
         }
-        cx = group_sum(cx); cy = group_sum(cy); cz = group_sum(cz);
-        const int m = (int)(group_sum((float)mine) + 0.5f);
-        float v = 0.f;
-        if (m > 0) {
-            V3 ctr = vdiv(mk(cx, cy, cz), (float)m);
-            for (int i = sl; i < n; i += SUB) {
-                if (i < n1 || keep[i] != 0) {
-                    Tri t = ldtri(T + i * 9);
-                    V3 a = vsub(t.v[0], ctr), b = vsub(t.v[1], ctr), c = vsub(t.v[2], ctr);
-                    v += fabsf(vdot(a, vcross(b, c))) / 6.0f;
-                }
+    }
+    const float vol = group_sum(v);
+    vol_r = (m > 0) ? vol : 0.f;
+    iou_r = (m > 0 && act) ? vol / (L.vol[0] + L.vol[1] - vol) : 0.f;
+    over_r = ((__ballot(over) >> shift) & sub_all) != 0ull;
+}
+
+// Bounding-sphere rejection.  Two vertex sets whose bounding spheres (centre = vertex mean, radius = farthest vertex) are
+// disjoint cannot intersect, and the clipping algorithm then ends with empty triangle lists: a triangle of one box survives a
+// plane pass of the other only if it is inside that face's half-space or lies IN the face's plane (the coplanarity rule keeps
+// it "as is"), and to survive all six passes it would have to sit within the other box's extent along every face normal, i.e.
+// touch its bounding sphere.  The result is exactly vol = iou = 0, which is written without running the passes.  The margin
+// (1e-4 relative + 1e-4 absolute, three orders above the fp32 rounding of the distances involved) keeps touching spheres on
+// the slow path.  In an evaluation most (detection, ground truth) pairs of an image are far apart; in the bench workload ~50 %.
+__device__ __forceinline__ bool spheres_disjoint(const float* __restrict__ b1, const float* __restrict__ b2) {
+    float c[2][3], r2[2];
+#pragma unroll
+    for (int bx = 0; bx < 2; ++bx) {
+        const float* B = bx == 0 ? b1 : b2;
+        float v[24];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float4 q = *reinterpret_cast<const float4*>(B + 4 * k);      // 96-byte rows: 16-byte aligned
+            v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+        }
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { sx += v[3 * t]; sy += v[3 * t + 1]; sz += v[3 * t + 2]; }
+        c[bx][0] = sx / 8.0f; c[bx][1] = sy / 8.0f; c[bx][2] = sz / 8.0f;
+        float m = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float dx = v[3 * t] - c[bx][0], dy = v[3 * t + 1] - c[bx][1], dz = v[3 * t + 2] - c[bx][2];
+            m = fmaxf(m, dx * dx + dy * dy + dz * dz);
+        }
+        r2[bx] = m;
+    }
+    const float dx = c[0][0] - c[1][0], dy = c[0][1] - c[1][1], dz = c[0][2] - c[1][2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz), rs = sqrtf(r2[0]) + sqrtf(r2[1]);
+    return d > rs * 1.0001f + 1e-4f;        // false for NaN / Inf coordinates: those pairs take the full algorithm
+}
+
+// MODE 0: matrix (pair p -> a = p / M, b = p % M); MODE 1: indexed pairs.
+// First pass.  A wave takes 64 consecutive pairs: every lane screens one pair (validity mask, bounding spheres) and writes the
+// zeros of the rejected ones; the survivors are then worked off G = 64 / SUB at a time, SUB lanes per pair, lists of CAPT
+// triangles.  RETRY (CAPT below the full capacity): a pair whose list outgrows CAPT is marked with iou = IOU_RETRY for
+// iou_box3d_retry_kernel instead of being counted as an overflow.
+template <int MODE, int SUB, int CAPT, bool RETRY>
+__global__ void __launch_bounds__(64) OMNI_WAVES_PER_EU(4) iou_box3d_kernel(
+    const float* __restrict__ boxes1, const float* __restrict__ boxes2, const int* __restrict__ idx1, const int* __restrict__ idx2,
+    const int* __restrict__ valid1, long long npairs, int M, float* __restrict__ vol_out, float* __restrict__ iou_out,
+    int* __restrict__ overflow, int chunk) {
+    constexpr int G = 64 / SUB;
+    __shared__ PairLds<CAPT> Lall[G];
+    const int lane = threadIdx.x, g = lane / SUB, sl = lane % SUB;
+    // `chunk` (16 | 32 | 64) pairs are screened per round by the first `chunk` lanes: smaller chunks = more waves for the same
+    // problem (the launcher keeps >= ~4096 of them when the problem allows), the screening itself is cheap
+    for (long long c0 = (long long)blockIdx.x * chunk; c0 < npairs; c0 += (long long)gridDim.x * chunk) {
+        const long long q = c0 + lane;
+        int ia = 0, ib = 0;
+        bool live = false;
+        if (lane < chunk && q < npairs) {
+            if (MODE == 0) { ia = (int)(q / M); ib = (int)(q % M); }
+            else { ia = idx1[q]; ib = idx2[q]; }
+            live = !(valid1 != nullptr && valid1[ia] == 0) && !spheres_disjoint(boxes1 + (size_t)ia * 24, boxes2 + (size_t)ib * 24);
+            if (!live) { if (vol_out) vol_out[q] = 0.f; iou_out[q] = 0.f; }
+        }
+        unsigned long long todo = __ballot(live);
+        while (todo != 0ull) {
+            // sub-group g takes the (g+1)-th lowest survivor of this round
+            int j = -1;
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int f = todo != 0ull ? __ffsll(todo) - 1 : -1;
+                if (todo != 0ull) todo &= todo - 1ull;
+                if (k == g) j = f;
+            }
+            const bool act = j >= 0;
+            const int src = act ? j : 0;
+            const int pa = __shfl(ia, src, 64), pb = __shfl(ib, src, 64);
+            float vol, iou;
+            bool over;
+            iou_pair_body<SUB, CAPT>(Lall[g], act, boxes1 + (size_t)pa * 24, boxes2 + (size_t)pb * 24, lane, vol, iou, over);
+            if (act && sl == 0) {
+                const long long p = c0 + j;
+                if (RETRY && over) { vol = 0.f; iou = IOU_RETRY; }
+                if (vol_out) vol_out[p] = vol;
+                iou_out[p] = iou;
+                if (!RETRY && over && overflow) atomicAdd(overflow, 1);
             }
         }
-        const float vol = group_sum(v);
-        const float iou = (m > 0) ? vol / (L.vol[0] + L.vol[1] - vol) : 0.f;
-        if (act && sl == 0) {
-            if (vol_out) vol_out[p] = (m > 0) ? vol : 0.f;
-            iou_out[p] = iou;
+    }
+}
+
+// Second pass of a RETRY launch: every wave scans 64 results at a time for the marker and recomputes the marked pairs, one per
+// wave, with the full-capacity lists.  With no marked pair (the usual case: a joint list longer than 96 needs near-identical
+// boxes) this is one read of the result vector.
+template <int MODE>
+__global__ void __launch_bounds__(64) iou_box3d_retry_kernel(const float* __restrict__ boxes1, const float* __restrict__ boxes2,
+                                                             const int* __restrict__ idx1, const int* __restrict__ idx2, long long npairs,
+                                                             int M, float* __restrict__ vol_out, float* __restrict__ iou_out,
+                                                             int* __restrict__ overflow) {
+    __shared__ PairLds<CAP> L;
+    const int lane = threadIdx.x;
+    for (long long c0 = (long long)blockIdx.x * 64; c0 < npairs; c0 += (long long)gridDim.x * 64) {
+        const long long q = c0 + lane;
+        unsigned long long todo = __ballot(q < npairs && iou_out[q] == IOU_RETRY);
+        while (todo != 0ull) {
+            const int j = __ffsll(todo) - 1;
+            todo &= todo - 1ull;
+            const long long p = c0 + j;
+            int ia, ib;
+            if (MODE == 0) { ia = (int)(p / M); ib = (int)(p % M); }
+            else { ia = idx1[p]; ib = idx2[p]; }
+            float vol, iou;
+            bool over;
+            iou_pair_body<64, CAP>(L, true, boxes1 + (size_t)ia * 24, boxes2 + (size_t)ib * 24, lane, vol, iou, over);
+            if (lane == 0) {
+                if (vol_out) vol_out[p] = vol;
+                iou_out[p] = iou;
+                if (over && overflow) atomicAdd(overflow, 1);
+            }
         }
-        const unsigned long long ob = (__ballot(over) >> shift) & sub_all;
-        if (ob != 0ull && sl == 0 && overflow) atomicAdd(overflow, 1);
     }
 }
 
@@ -389,26 +486,45 @@ __global__ void box3d_validity_kernel(const float* __restrict__ boxes, int N, fl
     }
 }
 
-constexpr int IOU_SUB = 32;       // lanes per pair of the production launch (tools/bench_iou3d.py sweeps 64 / 32 / 16)
+// production launch: 32 lanes per pair over 96-triangle lists (7.4 KB of LDS per pair: 10 two-pair waves per CU instead of 6
+// with the full 160-triangle lists), marked pairs redone at full capacity by the retry pass
+constexpr int IOU_SUB = 32, IOU_CAP_SMALL = 96;
 
-inline int iou_grid(long long npairs, int sub) {
+inline int iou_chunk(long long npairs) { return npairs >= 262144 ? 64 : npairs >= 131072 ? 32 : 16; }
+
+inline int iou_grid(long long npairs) {
     // 256 CUs x up to 16 single-wave workgroups per CU (LDS-limited); grid-stride beyond that
-    const long long waves = (npairs + 64 / sub - 1) / (64 / sub);
+    const int chunk = iou_chunk(npairs);
+    const long long waves = (npairs + chunk - 1) / chunk;
     long long g = waves < 256 * 16 ? waves : 256 * 16;
     return (int)(g < 1 ? 1 : g);
 }
 
+// variant = lanes_per_pair (64 | 32 | 16) + 1000 when the first pass uses the small lists + retry pass; 0 = production
 template <int MODE>
-inline int iou_launch(int sub, const float* boxes1, const float* boxes2, const int* idx1, const int* idx2, const int* valid1,
+inline int iou_launch(int variant, const float* boxes1, const float* boxes2, const int* idx1, const int* idx2, const int* valid1,
                       long long np, int M, float* vol, float* iou, int* overflow, void* stream) {
-    if (sub == 0) sub = IOU_SUB;
-#define OMNI_IOU(SUB_)                                                                                                      \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(iou_box3d_kernel<MODE, SUB_>), dim3(iou_grid(np, SUB_)), dim3(64), 0, (hipStream_t)stream, \
-                       boxes1, boxes2, idx1, idx2, valid1, np, M, vol, iou, overflow)
-    if (sub == 64) OMNI_IOU(64);
-    else if (sub == 32) OMNI_IOU(32);
-    else if (sub == 16) OMNI_IOU(16);
-    else return OMNI_ERR_ARG;
+    if (variant == 0) variant = 1000 + IOU_SUB;
+    const bool small = variant >= 1000;
+    const int sub = small ? variant - 1000 : variant;
+    hipStream_t st = (hipStream_t)stream;
+#define OMNI_IOU(SUB_, CAP_, RETRY_)                                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(iou_box3d_kernel<MODE, SUB_, CAP_, RETRY_>), dim3(iou_grid(np)), dim3(64), 0, st,       \
+                       boxes1, boxes2, idx1, idx2, valid1, np, M, vol, iou, overflow, iou_chunk(np))
+    if (!small) {
+        if (sub == 64) OMNI_IOU(64, CAP, false);
+        else if (sub == 32) OMNI_IOU(32, CAP, false);
+        else if (sub == 16) OMNI_IOU(16, CAP, false);
+        else return OMNI_ERR_ARG;
+    } else {
+        if (sub == 64) OMNI_IOU(64, IOU_CAP_SMALL, true);
+        else if (sub == 32) OMNI_IOU(32, IOU_CAP_SMALL, true);
+        else if (sub == 16) OMNI_IOU(16, IOU_CAP_SMALL, true);
+        else return OMNI_ERR_ARG;
+        const long long chunks = (np + 63) / 64;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(iou_box3d_retry_kernel<MODE>), dim3((unsigned)(chunks < 2048 ? chunks : 2048)), dim3(64), 0, st,
+                           boxes1, boxes2, idx1, idx2, np, M, vol, iou, overflow);
+    }
 #undef OMNI_IOU
     return omni_launch_status();
 }
@@ -432,8 +548,9 @@ int omni_iou_box3d_pairs(const float* boxes1, const float* boxes2, const int* id
     return iou_launch<1>(0, boxes1, boxes2, idx1, idx2, valid1, npairs, 1, vol, iou, overflow, stream);
 }
 
-// lanes_per_pair in {64, 32, 16} (0 = the production choice): A/B entry point of tools/bench_iou3d.py and of the parity tests,
-// which run every sub-group width against the oracle
+// lanes_per_pair in {64, 32, 16}: one launch with the full-capacity triangle lists; 1000 + lanes: first pass over 96-triangle
+// lists + retry pass (0 = the production choice, 1032).  A/B entry point of tools/bench_iou3d.py and of the parity tests, which
+// run every variant against the oracle
 int omni_iou_box3d_pairs_algo(const float* boxes1, const float* boxes2, const int* idx1, const int* idx2, long long npairs,
                               const int* valid1, float* vol, float* iou, int* overflow, int lanes_per_pair, void* stream) {
     if (npairs < 0) return OMNI_ERR_ARG;

@@ -31,8 +31,9 @@ def iou_box3d(boxes1, boxes2, valid1=None):
 
 
 def iou_box3d_pairs(boxes1, boxes2, idx1, idx2, valid1=None, lanes_per_pair=0):
-    """Ragged / paired form: iou[p] = IoU3D(boxes1[idx1[p]], boxes2[idx2[p]]).  lanes_per_pair 64 / 32 / 16 picks how many
-    pairs share a wavefront (0 = production choice); every width gives the same result."""
+    """Ragged / paired form: iou[p] = IoU3D(boxes1[idx1[p]], boxes2[idx2[p]]).  lanes_per_pair: launch variant of
+    omni_iou_box3d_pairs_algo (64 / 32 / 16 lanes per pair, + 1000 = small LDS lists with a retry pass; 0 = production choice);
+    every variant gives the same result."""
     _check_boxes(boxes1, "boxes1")
     _check_boxes(boxes2, "boxes2")
     boxes1, boxes2 = boxes1.contiguous(), boxes2.contiguous()

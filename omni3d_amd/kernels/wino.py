@@ -81,13 +81,13 @@ def gemm_batched(V, U, algo=0, workgroups=0):
     return out
 
 
-def gemm_batched_wgrad(V, dM):
-    """V (B,M,C), dM (B,M,K) -> dU (B,K,C) = dM^T V"""
+def gemm_batched_wgrad(V, dM, algo=0):
+    """V (B,M,C), dM (B,M,K) -> dU (B,K,C) = dM^T V.  algo: see omni_gemm_batched_wgrad_algo (0 = the launcher's choice)."""
     B, M, C = V.shape
     K = dM.shape[2]
     L = _lib.check_device(V, dM)
     dU = torch.empty((B, K, C), dtype=torch.float32, device=V.device)
-    L.call("omni_gemm_batched_wgrad", _lib.ptr(V), _lib.ptr(dM), _lib.ptr(dU), B, M, C, K, _lib.stream_of(V))
+    L.call("omni_gemm_batched_wgrad_algo", _lib.ptr(V), _lib.ptr(dM), _lib.ptr(dU), B, M, C, K, algo, _lib.stream_of(V))
     return dU
 
 
@@ -126,10 +126,17 @@ def transform_dy(dy, tile=2):
     return dM
 
 
+# one-pass kernel writes 2 x P plane-strided streams per thread; from `_DY_SPLIT_PLANE_BYTES` per plane on, two passes (P streams
+# each, dy read twice) are used instead (A/B knob, 0 = never)
+_DY_SPLIT_PLANE_BYTES = int(_os.environ.get("OMNI_WINO_DY_SPLIT", "0"))
+
+
 def transform_dy_both(dy, tile=2):
     """dy (N,K,H,W) CL -> (dM (P,T,K), V_dy (P,T,K)): the weight-gradient and data-gradient transforms of dy in one pass"""
     dv = _nhwc(dy)
     N, H, W, K = dv.shape
+    if _DY_SPLIT_PLANE_BYTES and N * (H // tile) * (W // tile) * K * 4 >= _DY_SPLIT_PLANE_BYTES:
+        return transform_dy(dy, tile), transform_input(dy, tile)
     L = _lib.check_device(dv)
     shape = (_points(tile), N * (H // tile) * (W // tile), K)
     dM = torch.empty(shape, dtype=torch.float32, device=dy.device)

@@ -235,5 +235,7 @@ static inline void omni_dma16(omni_rsrc_t r, float* lds_wave_base, int voffset, 
 #define OMNI_OOB ((int)0x80000000)
 #define OMNI_WAIT_VMCNT(n) do { } while (0)
 static inline void omni_barrier() { hipemu::block_sync(); }
+static inline void omni_barrier_lds() { hipemu::block_sync(); }
 #define OMNI_SCHED_GROUP(mask, n) do { } while (0)
 #define OMNI_SETPRIO(n) do { } while (0)
+#define OMNI_WAVES_PER_EU(n)

@@ -205,8 +205,42 @@ def _run_persistent_gemm(dev):
     assert torch.equal(out, wino.gemm_batched(V, U))       # bit-identical to the one-tile-per-workgroup kernel (same k order)
 
 
+def _run_prefetch_gemm(dev):
+    """gemm_nt_pf_kernel (64x64 tiles, 2 / 4 slabs of buffer-load prefetch in flight): ragged M and N tiles, reduction depths of
+    exactly one round of the prefetch ring (K = 64 with PF 2, K = 128 with PF 4) and of several; bit-identical to the classic
+    double-buffered 64x64 kernel (same k order per accumulator)."""
+    from omni3d_amd.kernels import wino
+    g = torch.Generator().manual_seed(9)
+    for B, M, K, C in ((3, 150, 72, 64), (2, 70, 130, 128), (2, 129, 64, 192), (1, 64, 64, 512)):
+        V = torch.randn(B, M, C, generator=g).to(dev)
+        U = torch.randn(B, K, C, generator=g).to(dev)
+        out = wino.gemm_batched(V, U, algo=4)
+        ref = torch.einsum("bmc,bkc->bmk", V.cpu().double(), U.cpu().double())
+        assert (out.cpu().double() - ref).abs().max() <= 1e-4 * ref.abs().max(), (B, M, K, C)
+        assert torch.equal(out, wino.gemm_batched(V, U, algo=3)), (B, M, K, C)
+    with pytest.raises(Exception):
+        wino.gemm_batched(torch.randn(1, 64, 32).to(dev), torch.randn(1, 64, 32).to(dev), algo=4)     # C % 64 != 0: refused, not mangled
+    # TN twin (Winograd-domain weight gradient): ragged row counts (a last slab of 6 rows, a split that gets fewer rows), ragged tiles
+    for B, M, K, C in ((3, 70, 72, 64), (2, 300, 136, 68), (2, 1024, 64, 128), (1, 128, 64, 64)):
+        V = torch.randn(B, M, C, generator=g).to(dev)
+        dM = torch.randn(B, M, K, generator=g).to(dev)
+        dU = wino.gemm_batched_wgrad(V, dM, algo=2)
+        ref = torch.einsum("bmk,bmc->bkc", dM.cpu().double(), V.cpu().double())
+        assert (dU.cpu().double() - ref).abs().max() <= 1e-4 * ref.abs().max(), (B, M, K, C)
+        assert (dU - wino.gemm_batched_wgrad(V, dM, algo=1)).abs().max() <= 1e-5 * float(ref.abs().max())
+
+
 def test_persistent_gemm_emulated(emu_lib):
     _run_persistent_gemm("cpu")
+
+
+def test_prefetch_gemm_emulated(emu_lib):
+    _run_prefetch_gemm("cpu")
+
+
+@pytest.mark.gpu
+def test_prefetch_gemm_gpu(hip_lib):
+    _run_prefetch_gemm("cuda")
 
 
 @pytest.mark.gpu

@@ -19,7 +19,7 @@ d, g = torch.from_numpy(dt).cuda(), torch.from_numpy(gt).cuda()
 ar = torch.arange(P, dtype=torch.int32, device="cuda")
 valid, _ = iou3d.box3d_validity(d)
 ref = None
-for lanes in (64, 32, 16):
+for lanes in (64, 32, 16, 1064, 1032, 1016):
     for _ in range(3):
         out = iou3d.iou_box3d_pairs(d, g, ar, ar, valid1=valid, lanes_per_pair=lanes)[1]
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,4 +31,4 @@ for lanes in (64, 32, 16):
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 20
     ref = out if ref is None else ref
-    print(f"lanes_per_pair {lanes:2d}: {ms:.3f} ms / launch = {P / ms * 1e3:.3e} pairs/s   max|d| vs 64-lane {float((out - ref).abs().max()):.2e}")
+    print(f"variant {lanes:4d}: {ms:.3f} ms / launch = {P / ms * 1e3:.3e} pairs/s   max|d| vs 64-lane {float((out - ref).abs().max()):.2e}")

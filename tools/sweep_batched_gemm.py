@@ -27,14 +27,24 @@ def timeit(fn):
     return a.elapsed_time(b) / 200 * 1e3
 
 
+SHAPES += [(36, 64, 256, 256), (16, 256, 256, 256), (36, 5456, 256, 256)]
 for (P, M, C, K) in SHAPES:
     V, U = torch.randn(P, M, C, device="cuda"), torch.randn(P, K, C, device="cuda")
     gf = 2.0 * P * M * C * K / 1e9
     res = []
-    for algo, wg in ((0, 0), (1, 256), (1, 512), (1, 768), (2, 0), (3, 0)):
+    for algo, wg in ((0, 0), (1, 512), (2, 0), (3, 0), (4, 0)):
         try:
             t = timeit(lambda: wino.gemm_batched(V, U, algo, wg))
             res.append(f"a{algo}/{wg}: {t:6.1f}us {gf / t * 1e3:5.1f}TF")
         except Exception as e:
             res.append(f"a{algo}/{wg}: err")
     print(f"{str((P, M, C, K)):24s} {gf:6.2f} GF | " + " | ".join(res), flush=True)
+    dM = torch.randn(P, M, K, device="cuda")
+    res = []
+    for algo in (1, 2):
+        try:
+            t = timeit(lambda: wino.gemm_batched_wgrad(V, dM, algo))
+            res.append(f"wgrad a{algo}: {t:6.1f}us {gf / t * 1e3:5.1f}TF")
+        except Exception as e:
+            res.append(f"wgrad a{algo}: err {type(e).__name__}")
+    print(f"{'':24s} {'':9s} | " + " | ".join(res), flush=True)
