@@ -200,6 +200,8 @@ def run_train(args, world, rank):
                               "note": "not BASELINE.json's configuration: functional check only"}
     if rank == 0 and DEVICE != "cuda":
         res["roofline"], res["cpu_baseline"] = None, None
+    elif rank == 0 and os.environ.get("OMNI_BENCH_SKIP_ROOFLINE") == "1":      # A/B sweeps: the step time only
+        res["roofline"], res["cpu_baseline"] = None, None
     elif rank == 0:
         res["roofline"] = dominant_kernel_roofline()
         res["hbm_bound_kernels"] = hbm_bound_kernels(opt)

@@ -334,39 +334,65 @@ __device__ __forceinline__ void iou_pair_body(PairLds<CAPT>& L, const bool act, 
     over_r = ((__ballot(over) >> shift) & sub_all) != 0ull;
 }
 
-// Bounding-sphere rejection.  Two vertex sets whose bounding spheres (centre = vertex mean, radius = farthest vertex) are
+// Bounding-sphere rejection.  Two PROPER boxes whose bounding spheres (centre = vertex mean, radius = farthest vertex) are
 // disjoint cannot intersect, and the clipping algorithm then ends with empty triangle lists: a triangle of one box survives a
 // plane pass of the other only if it is inside that face's half-space or lies IN the face's plane (the coplanarity rule keeps
 // it "as is"), and to survive all six passes it would have to sit within the other box's extent along every face normal, i.e.
-// touch its bounding sphere.  The result is exactly vol = iou = 0, which is written without running the passes.  The margin
-// (1e-4 relative + 1e-4 absolute, three orders above the fp32 rounding of the distances involved) keeps touching spheres on
-// the slow path.  In an evaluation most (detection, ground truth) pairs of an image are far apart; in the bench workload ~50 %.
-__device__ __forceinline__ bool spheres_disjoint(const float* __restrict__ b1, const float* __restrict__ b2) {
-    float c[2][3], r2[2];
+// inside its convex hull (the intersection of the six half-spaces of a parallelepiped IS its hull), which the sphere contains.
+// The result is exactly vol = iou = 0, which is written without running the passes.
+// "Proper" matters: for a degenerate operand (a zero-thickness box has zero face normals, so EVERYTHING counts as inside; a
+// skewed vertex makes the half-space intersection larger than the hull) the reference algorithm returns garbage that does not
+// vanish with distance, and parity means reproducing that garbage.  So the shortcut is only taken when both vertex sets are
+// parallelepipeds in the documented corner order (omni3d_evaluation.py:117-142) -- the twelve edges equal e1 / e2 / e3 up to
+// 1e-3 of the shortest edge, shortest edge > 1e-3, |det(e1, e2, e3)| >= 1e-2 |e1||e2||e3| -- and the measured deviation is
+// added to the separation margin (1e-4 relative + 1e-4 absolute + 4 x deviation).  Everything else, NaN / Inf coordinates
+// included, takes the full algorithm.  In an evaluation most (detection, ground truth) pairs of an image are far apart; in the
+// bench workload ~50 %.
+__device__ __forceinline__ bool box_sphere(const float* __restrict__ B, float (&c)[3], float& radius, float& dev) {
+    float v[24];
 #pragma unroll
-    for (int bx = 0; bx < 2; ++bx) {
-        const float* B = bx == 0 ? b1 : b2;
-        float v[24];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const float4 q = *reinterpret_cast<const float4*>(B + 4 * k);      // 96-byte rows: 16-byte aligned
-            v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
-        }
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { sx += v[3 * t]; sy += v[3 * t + 1]; sz += v[3 * t + 2]; }
-        c[bx][0] = sx / 8.0f; c[bx][1] = sy / 8.0f; c[bx][2] = sz / 8.0f;
-        float m = 0.f;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float dx = v[3 * t] - c[bx][0], dy = v[3 * t + 1] - c[bx][1], dz = v[3 * t + 2] - c[bx][2];
-            m = fmaxf(m, dx * dx + dy * dy + dz * dz);
-        }
-        r2[bx] = m;
+    for (int k = 0; k < 6; ++k) {
+        const float4 q = *reinterpret_cast<const float4*>(B + 4 * k);      // 96-byte rows: 16-byte aligned
+        v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
     }
-    const float dx = c[0][0] - c[1][0], dy = c[0][1] - c[1][1], dz = c[0][2] - c[1][2];
-    const float d = sqrtf(dx * dx + dy * dy + dz * dz), rs = sqrtf(r2[0]) + sqrtf(r2[1]);
-    return d > rs * 1.0001f + 1e-4f;        // false for NaN / Inf coordinates: those pairs take the full algorithm
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { sx += v[3 * t]; sy += v[3 * t + 1]; sz += v[3 * t + 2]; }
+    c[0] = sx / 8.0f; c[1] = sy / 8.0f; c[2] = sz / 8.0f;
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float dx = v[3 * t] - c[0], dy = v[3 * t + 1] - c[1], dz = v[3 * t + 2] - c[2];
+        m = fmaxf(m, dx * dx + dy * dy + dz * dz);
+    }
+    radius = sqrtf(m);
+    // corner order: 0-1-2-3 and 4-5-6-7 are opposite quads, i and i + 4 are joined.  e1 = v1 - v0, e2 = v3 - v0, e3 = v4 - v0
+    float e[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e[0][k] = v[3 + k] - v[k]; e[1][k] = v[9 + k] - v[k]; e[2][k] = v[12 + k] - v[k]; }
+    constexpr int EDGES[9][3] = {{3, 2, 0}, {4, 5, 0}, {7, 6, 0}, {1, 2, 1}, {4, 7, 1}, {5, 6, 1}, {1, 5, 2}, {2, 6, 2}, {3, 7, 2}};
+    float d = 0.f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            d = fmaxf(d, fabsf((v[3 * EDGES[q][1] + k] - v[3 * EDGES[q][0] + k]) - e[EDGES[q][2]][k]));
+    dev = d;
+    float len[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) len[a] = sqrtf(e[a][0] * e[a][0] + e[a][1] * e[a][1] + e[a][2] * e[a][2]);
+    const float lmin = fminf(len[0], fminf(len[1], len[2]));
+    const float det = e[0][0] * (e[1][1] * e[2][2] - e[1][2] * e[2][1]) - e[0][1] * (e[1][0] * e[2][2] - e[1][2] * e[2][0]) +
+                      e[0][2] * (e[1][0] * e[2][1] - e[1][1] * e[2][0]);
+    return lmin > 1e-3f && d <= 1e-3f * lmin && fabsf(det) >= 1e-2f * len[0] * len[1] * len[2];      // false for NaN
+}
+
+__device__ __forceinline__ bool spheres_disjoint(const float* __restrict__ b1, const float* __restrict__ b2) {
+    float c1[3], c2[3], r1, r2, d1, d2;
+    const bool ok1 = box_sphere(b1, c1, r1, d1), ok2 = box_sphere(b2, c2, r2, d2);
+    const float dx = c1[0] - c2[0], dy = c1[1] - c2[1], dz = c1[2] - c2[2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz), rs = r1 + r2;
+    return ok1 && ok2 && d > rs * 1.0001f + 1e-4f + 4.0f * (d1 + d2);
 }
 
 // MODE 0: matrix (pair p -> a = p / M, b = p % M); MODE 1: indexed pairs.

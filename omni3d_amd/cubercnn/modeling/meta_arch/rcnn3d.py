@@ -80,6 +80,13 @@ class RCNN3D(nn.Module):
     def _forward(self, batched_inputs, packed=None):
         if not self.training:
             return self.inference(batched_inputs, packed=packed)
+        auto = self.__dict__.get("_omni_auto")
+        if auto is not None and packed is None and not auto.busy:
+            # the drop-in loop: once the batch signature repeats, model(data) replays the staged hipGraphs of the whole step
+            # (cubercnn/solver/autoreplay.py); callers that pre-stage their batch (bench.py, GraphedPipelined) pass `packed`
+            out = auto.forward(batched_inputs)
+            if out is not None:
+                return out
         images = self.preprocess_image(batched_inputs)
         if packed is None:
             packed = self.prepack(batched_inputs)

@@ -56,6 +56,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.skip_flag = None   # optional device float: != 0 skips the update inside the kernel
         self._grad_scale = 1.0  # consumed by the next step(): 1/world when the all-reduce left SUMS in the bucket
         self._exchanged = False  # did this step's gradients go through all_reduce_begin / all_reduce_finish?
+        self._replay_state = None  # set by AutoReplay.forward: {"pending": all-reduce handles, "zero_grads_seen": n}
         # step() averages the bucket itself when a process group with > 1 rank exists and nobody exchanged this step's
         # gradients.  build_optimizer switches it off when somebody else owns the exchange (a DistributedDataParallel wrapper
         # whose reducer already averaged the gradients: a second pass over the 191.6 MB bucket would only cost time)
@@ -126,10 +127,23 @@ class _FlatOptimizer(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         """param.grad stay views of the flat bucket (set_to_none is ignored: the views ARE the storage the fused step and
         the all-reduce operate on)."""
+        st = getattr(self, "_replay_state", None)
+        if st is not None:        # model(data) replayed the whole step (cubercnn/solver/autoreplay.py): the bucket holds THIS
+            st["zero_grads_seen"] += 1        # iteration's gradients; the loop's zero_grad() before backward() must not wipe them
+            if st["zero_grads_seen"] == 1:
+                return
+            self._finish_replay_exchange()    # a second zero_grad(): the loop drops the iteration (tools/train_net.py:245-247)
         from ... import functional as HF
         HF.side_join()            # weight-gradient stream (normally already joined by the end-of-backward callback)
         self.flat_grad.zero_()
         self._exchanged = False
+
+    def _finish_replay_exchange(self):
+        """pending all-reduce handles of a replayed step -> waited for, 1/world deferred into the update"""
+        st, self._replay_state = getattr(self, "_replay_state", None), None
+        if st is not None and st["pending"]:
+            self.all_reduce_finish(st["pending"], defer_scale=True)
+        return st is not None
 
     @torch.no_grad()
     def _rebind_grads(self):
@@ -160,6 +174,10 @@ class _FlatOptimizer(torch.optim.Optimizer):
         """Data-parallel exchange step, non-overlapped form: the early ranges then the late ranges (the same collective
         sequence as the overlapped form, so ranks may mix the two), then the average -- replaces DDP's per-bucket
         reducer for the native path (RCCL over xGMI on MI355X; gloo in the CPU tests)."""
+        if getattr(self, "_replay_state", None) is not None:     # a replayed step started its exchange itself
+            self._finish_replay_exchange()
+            self._replay_state = {"pending": [], "zero_grads_seen": 1}
+            return
         self.all_reduce_finish(self.all_reduce_begin("early", group) + self.all_reduce_begin("late", group), group)
 
     def all_reduce_begin(self, which, group=None):
@@ -199,6 +217,13 @@ class _FlatOptimizer(torch.optim.Optimizer):
         from ... import functional as HF
         HF.side_join()
         self._rebind_grads()
+        user_skip = self.skip_flag
+        if self._finish_replay_exchange():
+            auto = getattr(self, "_auto", None)
+            if auto is not None and auto.bad is not None:
+                # the fused update also skips when backward() saw a non-unit upstream gradient (autoreplay.py)
+                self.skip_flag = auto.bad if user_skip is None else torch.add(user_skip, auto.bad)
+                auto.arm_check()
         if not self._exchanged and self.exchange_in_step:
             # Data-parallel safety net.  The reference's loop (tools/train_net.py:449-454) relies on DistributedDataParallel's
             # autograd hooks for the gradient exchange; with direct accumulation the weight gradients never pass through
@@ -208,6 +233,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 self.all_reduce_grads()
         self._step_segments()
+        self.skip_flag = user_skip
         self._grad_scale = 1.0
         self._steps += 1
 
@@ -369,6 +395,9 @@ def build_optimizer(cfg, model):
     else:
         raise ValueError("{} is not supported as an optimizer.".format(cfg.SOLVER.TYPE))
     opt.exchange_in_step = direct          # DDP's reducer already averaged: never all-reduce the bucket a second time
+    if direct:
+        from .autoreplay import attach
+        attach(model, opt)                 # model(data) switches to staged-graph replay once the batch signature repeats
     return opt
 
 

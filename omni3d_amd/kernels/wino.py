@@ -13,6 +13,10 @@ _F43 = _os.environ.get("OMNI_WINOGRAD_F43", "1") != "0"
 _F43_MIN_TILES = int(_os.environ.get("OMNI_WINOGRAD_F43_MIN_TILES", "256"))     # measured: 1024 -> 14.18, 256 -> 14.02, 64 -> 14.05 ms / step
 
 
+_MIN_TILES = int(_os.environ.get("OMNI_WINO_MIN_TILES", "256"))                 # 2x2 tiles a map needs for the Winograd path at all
+_DGRAD_MIN_TILES = int(_os.environ.get("OMNI_WINO_DGRAD_MIN_TILES", "1024"))    # ... and for the Winograd data gradient
+
+
 def eligible(x_shape, w_shape, stride, pad):
     """Wide (>= 128 channel) 3x3/s1/p1 layers on even maps with >= 256 tiles: FPN output / RPN convs on p2..p5 and the
     DLA level 3-5 blocks (measured per shape with tools/bench_kernels.py, profiles/README.md)."""
@@ -20,7 +24,7 @@ def eligible(x_shape, w_shape, stride, pad):
     K, _, R, S = w_shape
     if not (R == 3 and S == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0 and C % 32 == 0 and K % 32 == 0):
         return False
-    if C >= 128 and K >= 128 and N * (H // 2) * (W // 2) >= 256:
+    if C >= 128 and K >= 128 and N * (H // 2) * (W // 2) >= _MIN_TILES:
         return True
     # 64-channel layers (DLA level 2, ResNet layer1) only pay off with the 36-point transform on large maps
     return C >= 64 and K >= 64 and tile_size(x_shape) == 4 and N * (H // 4) * (W // 4) >= 4096
@@ -36,7 +40,7 @@ def tile_size(x_shape):
 def dgrad_eligible(x_shape):
     """Below ~1024 tiles the direct split-K data-gradient kernel is faster than transform + 16 GEMMs + transform."""
     N, _, H, W = x_shape
-    return N * (H // 2) * (W // 2) >= 1024
+    return N * (H // 2) * (W // 2) >= _DGRAD_MIN_TILES
 
 
 def _nhwc(t):

@@ -203,3 +203,56 @@ def test_iou3d_lane_widths_emulated(emu_lib, oracle_lib, rng):
 @pytest.mark.gpu
 def test_iou3d_lane_widths_gpu(hip_lib, oracle_lib, rng):
     _widths_case("cuda", oracle_lib, rng, 20_001)
+
+
+def _degenerate_far_case(dev, oracle_lib, rng, n):
+    """Regression (round 3, first GPU run of the bounding-sphere screening): the reference algorithm returns garbage for
+    degenerate operands -- a zero-thickness box has zero face normals, so every triangle of the OTHER box counts as inside and
+    the "intersection" is that whole box, however far away it is -- and parity means reproducing it.  The screening may only
+    shortcut pairs of proper parallelepipeds: far-apart pairs with a flat, a skewed, a sheared-flat or a NaN operand must go
+    through the full algorithm and equal the oracle (no validity mask here: that is the raw _C.iou_box3d contract)."""
+    import ctypes
+    from omni3d_amd.kernels import iou3d
+    dt, gt, deg = boxgen.omni3d_like_pairs(rng, n, overlap_frac=0.0, degenerate_frac=0.5)      # zero-dimension / skewed-vertex dt boxes
+    perm = rng.permutation(n)
+    a, b = np.ascontiguousarray(dt), np.ascontiguousarray(gt[perm])                            # random partners: mostly far apart
+    b[::7] = a[::7][:, [0, 1, 2, 3, 0, 1, 2, 3]] + np.float32(25.0)                            # flat SECOND operands, far away
+    a[5::11, 2] = np.float32("nan")                                                            # a NaN coordinate
+    d, g = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    ar = torch.arange(n, dtype=torch.int32, device=dev)
+    ref, vref = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    P = ctypes.c_void_p
+    for i in range(n):      # pair by pair: the matrix entry point also returns the intersection volume
+        oracle_lib.iou_box3d_oracle(a[i].ctypes.data_as(P), 1, b[i].ctypes.data_as(P), 1, vref[i:].ctypes.data_as(P), ref[i:].ctypes.data_as(P))
+
+    def sphere(x):
+        c = x.mean(1)
+        return c, np.sqrt(((x - c[:, None]) ** 2).sum(2).max(1))
+    (c1, r1), (c2, r2) = sphere(a), sphere(b)
+    with np.errstate(invalid="ignore"):
+        far = np.linalg.norm(c1 - c2, axis=1) > (r1 + r2) * 1.0001 + 1e-4
+    garbage = far & (ref != 0)
+    assert garbage.sum() >= 1, "the case must contain far-apart pairs with a non-zero reference result"
+    # The garbage IoU of a degenerate pair is vol / (vol1 + vol2 - vol) with a denominator that may cancel to rounding noise, so
+    # the comparison is made on the intersection VOLUME (a sum of |tetrahedron| terms, well conditioned) for every pair, and on
+    # the IoU where the reference's own denominator is not a cancellation
+    for lanes in (0, 64):
+        vol, iou = iou3d.iou_box3d_pairs(d, g, ar, ar, lanes_per_pair=lanes)
+        vol, iou = vol.cpu().numpy(), iou.cpu().numpy()
+        with np.errstate(invalid="ignore"):
+            okv = (np.abs(vol - vref) <= 1e-4 * np.maximum(1.0, np.abs(vref))) | (np.isnan(vol) & np.isnan(vref))
+        assert okv.all(), (lanes, int((~okv).sum()), vol[~okv][:4], vref[~okv][:4])
+        assert (vol[garbage] != 0).all()                       # not screened out
+        with np.errstate(invalid="ignore", divide="ignore"):
+            sane = np.isfinite(ref) & (np.abs(ref) <= 1.0) & (np.abs(vref) > 1e-3 * np.abs(vref / np.where(ref == 0, 1, ref)))
+            oki = np.abs(iou - ref) <= 1e-4
+        assert oki[sane].all(), (lanes, iou[sane & ~oki][:4], ref[sane & ~oki][:4])
+
+
+def test_iou3d_degenerate_far_pairs_emulated(emu_lib, oracle_lib, rng):
+    _degenerate_far_case("cpu", oracle_lib, rng, 150)
+
+
+@pytest.mark.gpu
+def test_iou3d_degenerate_far_pairs_gpu(hip_lib, oracle_lib, rng):
+    _degenerate_far_case("cuda", oracle_lib, rng, 4000)
