@@ -205,11 +205,69 @@ def run_train(args, world, rank):
     elif rank == 0:
         res["roofline"] = dominant_kernel_roofline()
         res["hbm_bound_kernels"] = hbm_bound_kernels(opt)
+        if world == 1 and os.environ.get("OMNI_BENCH_SKIP_DROPIN") != "1":
+            # the drop-in loop (north_star: "tools/train_net.py drops in unchanged"): same step, reached from inside model(data)
+            try:
+                d1, d10 = dropin_loop(30, 1), dropin_loop(30, 10)
+                res["dropin_loop_ms_per_step"] = d1["ms_per_step"]
+                res["dropin_loop"] = {"loop": "tools/train_synthetic.py == tools/train_net.py:176-285 body, new batch (pool of 4) every iteration, "
+                                              "host-side target packing + H2D inside the timed region",
+                                      "losses_read_every_iteration": d1, "losses_read_every_10th": d10,
+                                      "vs_ms_per_step": d1["ms_per_step"] / (1e3 * dt / args.steps)}
+            except Exception as e:  # noqa: BLE001
+                res["dropin_loop_ms_per_step"] = None
+                res["dropin_loop"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         if world == 1:   # the CPU leg is reported at N = 1 only (a minute of host work the other ranks would wait on)
             res["cpu_baseline"] = cpu_baseline_train(priors)
         else:
             res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": "reported at N=1 only"}
     return res
+
+
+def dropin_loop(iters=30, sync_every=1):
+    """The reference's loop body (tools/train_net.py:176-285; tools/train_synthetic.py is the same loop as a script) on a FRESH model:
+    loss_dict = model(data) -> sum -> optimizer.zero_grad() -> backward() -> non-finite scan -> guard -> optimizer.step() ->
+    scheduler.step(), a new batch from a pool of four every iteration.  Nothing here knows about graphs: `model(data)` and the
+    optimizer switch to the staged-graph replay by themselves once the batch signature has repeated (cubercnn/solver/
+    autoreplay.py).  sync_every = 1 reads the reduced losses back on every iteration like the reference (:186); larger values
+    read them every n-th iteration.  -> ms per iteration over the replayed iterations, number of replayed iterations"""
+    from omni3d_amd import synthetic
+    from omni3d_amd.cubercnn.solver.guard import StepGuard
+    from omni3d_amd.d2.solver import build_lr_scheduler
+    cfg, model, opt, priors = build(1, seed=1)
+    sched = build_lr_scheduler(cfg, opt)
+    auto = model.__dict__.get("_omni_auto")
+    pool = [synthetic.make_batch(IMS_PER_GPU, IMAGE_SIZE, IMAGE_SIZE, num_gt=8, seed=2000 + s, priors=priors) for s in range(4)]
+    guard = None
+    warm = (auto.warm + 1) if auto is not None else 1
+
+    def iteration(it):
+        nonlocal guard
+        loss_dict = model(pool[it % len(pool)])
+        losses = sum(loss_dict.values())
+        if guard is None:
+            guard = StepGuard(list(loss_dict), cfg.MODEL.STABILIZE, cfg.SOLVER.CHECKPOINT_PERIOD, losses.device)
+            opt.skip_flag = guard.skip
+        opt.zero_grad()
+        losses.backward()
+        opt.all_reduce_grads()
+        opt.check_nonfinite(guard.nonfinite_flag)
+        guard.update(loss_dict, sync=(it % sync_every == 0))
+        opt.step()
+        sched.step()
+
+    for it in range(warm + 2):              # eager warm-up iterations, the capture, first replays
+        iteration(it)
+    _sync()
+    t0 = time.perf_counter()
+    for it in range(warm + 2, warm + 2 + iters):
+        iteration(it)
+    _sync()
+    dt = time.perf_counter() - t0
+    skipped, retry, red = guard.read()
+    return {"ms_per_step": 1e3 * dt / iters, "iterations": iters, "replayed_iterations": auto.replays if auto is not None else 0,
+            "capture": "ok" if (auto is not None and auto.failed is None and auto.stepper is not None) else f"not replaying: {getattr(auto, 'failed', 'disabled')}",
+            "losses_read_every": sync_every, "last_total_loss": red["total_loss"]}
 
 
 def run_infer(args, world, rank):

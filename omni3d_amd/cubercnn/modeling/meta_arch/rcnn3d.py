@@ -88,6 +88,7 @@ class RCNN3D(nn.Module):
             if out is not None:
                 return out
         images = self.preprocess_image(batched_inputs)
+        packed_given = packed
         if packed is None:
             packed = self.prepack(batched_inputs)
         features = self.backbone(images.tensor)
@@ -109,6 +110,9 @@ class RCNN3D(nn.Module):
         losses.update(proposal_losses)
         if has_event_storage():
             self.flush_logs(get_event_storage())
+        if packed_given is None and getattr(self, "_omni_owns_exchange", False):
+            from ...solver.ddp import tie_to_anchor     # loop-level call under the script's DDP wrapper (cubercnn/solver/ddp.py)
+            tie_to_anchor(self, losses)
         return losses
 
     def _all_packed(self):
@@ -158,6 +162,12 @@ def build_model(cfg, priors=None):
     meta_arch = cfg.MODEL.META_ARCHITECTURE
     model = META_ARCH_REGISTRY.get(meta_arch)(cfg, priors=priors)
     model.to(torch.device(cfg.MODEL.DEVICE))
+    import os
+    from ...solver import ddp
+    if ddp.world() > 1 and os.environ.get("OMNI_OWN_EXCHANGE", "1") != "0":
+        # the script will wrap this model in torch's DistributedDataParallel (tools/train_net.py:449-454): keep the gradient
+        # exchange with the optimizer's flat bucket instead of DDP's per-tensor reducer (cubercnn/solver/ddp.py)
+        ddp.prepare_for_ddp(model)
     return model
 
 

@@ -53,7 +53,8 @@ class _Replayed(Function):
     @staticmethod
     def backward(ctx, g):
         ctx.auto._on_backward(g)
-        return (None, None) + (None,) * ctx.n
+        # the anchor's (zero) gradient: under the script's DDP wrapper it is the one parameter whose hook must fire (solver/ddp.py)
+        return (torch.zeros_like(ctx.auto.anchor), None) + (None,) * ctx.n
 
 
 class AutoReplay:
@@ -156,7 +157,9 @@ class AutoReplay:
             with torch.no_grad():
                 for b, saved in bufs:
                     b.copy_(saved)
-        self.anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self.anchor = getattr(model, "_omni_ddp_anchor", None)
+        if self.anchor is None:
+            self.anchor = torch.zeros(1, device=dev, requires_grad=True)
         self.bad = torch.zeros(1, dtype=torch.float32, device=dev)
         # what the components would log this iteration (static tensors of the captured pass; flush_logs pops them)
         self._logs = [(m, dict(m.pending_logs)) for m in (model.proposal_generator, model.roi_heads) if hasattr(m, "pending_logs")]

@@ -23,7 +23,7 @@ def _param_groups(cfg, model):
     groups, memo = [], set()
     for module in model.modules():
         for key, value in module.named_parameters(recurse=False):
-            if not value.requires_grad or value in memo:
+            if not value.requires_grad or value in memo or key == "_omni_ddp_anchor":     # the anchor belongs to DDP (solver/ddp.py)
                 continue
             memo.add(value)
             lr, wd = cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY
@@ -398,6 +398,9 @@ def build_optimizer(cfg, model):
     if direct:
         from .autoreplay import attach
         attach(model, opt)                 # model(data) switches to staged-graph replay once the batch signature repeats
+    if under_ddp and own:
+        from .ddp import broadcast_replica
+        broadcast_replica(inner, opt)      # the initial parameter / buffer broadcast DDP's constructor skipped for ignored names
     return opt
 
 
