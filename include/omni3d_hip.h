@@ -321,6 +321,11 @@ int omni_gemm_engine(const float* A, const float* B, float* C, const float* bias
                      int lda, int ldb, int ldc, long long stride_a, long long stride_b, long long stride_c, int splits,
                      int relu, int accumulate, int tile, int workgroups, void* stream);
 
+/* dst (cols, rows) = src (rows, cols)^T, contiguous row-major fp32.  Brings the fc1-class weights (K_out x C_in) into the
+ * (C_in x K_out) layout the data gradient of torch.nn.Linear (FastRCNNConvFCHead fc1, cube_head.py:70) multiplies in the
+ * engine's fastest ("NT") form. */
+int omni_transpose2d(const float* src, float* dst, int rows, int cols, void* stream);
+
 /* ---------------------------------------------------------------- batched inference
  * fast_rcnn_inference / fast_rcnn_inference_single_image (cubercnn/modeling/roi_heads/fast_rcnn.py:33-116) for all images
  * of a batch with fixed shapes.  pred (B*P, ld) = [K+1 logits | 4K deltas]; rois (B*P,4); count (B); image_hw (B,2).

@@ -316,7 +316,7 @@ def _time_launch(fn, iters):
     return a.elapsed_time(b) / iters
 
 
-def _table_shares(csv_name="r02_train_final_kernel_stats.csv"):
+def _table_shares(csv_name="r03_train_final_kernel_stats.csv"):
     """share of the summed kernel time per kernel symbol in the committed rocprofv3 table (+ its sha256) -> ({symbol: frac}, note)"""
     import csv
     import hashlib
@@ -336,14 +336,14 @@ def _table_shares(csv_name="r02_train_final_kernel_stats.csv"):
 
 
 def dominant_kernel_roofline(iters=20):
-    """`roofline`: the kernel symbol that tops the committed rocprofv3 table of this command (profiles/r02_train_final_kernel_stats.csv),
+    """`roofline`: the kernel symbol that tops the committed rocprofv3 table of this command (profiles/r03_train_final_kernel_stats.csv),
     on the launch shape that accounts for most of that symbol's time, timed live with HIP events on the launch stream; HBM traffic and
     the cycle-based MFMA utilisation come from the committed PMC summary (`traffic_source`).  `families`: every MFMA kernel family of
     the table with one representative launch timed the same way and its share of the summed kernel time, so the per-family distance
     to the 157.3 TFLOP/s fp32-MFMA peak is in the line (the step is a near tie between six MFMA symbols at 7-9 % each)."""
     from omni3d_amd.kernels import conv, wino
     from omni3d_amd.profile_io import profile_counters
-    PMC = "r02_pmc_families.csv"
+    PMC = "r03_pmc_families.csv"
     shares, table = _table_shares()
     B, C, H = IMS_PER_GPU, 256, 128
     x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
@@ -380,38 +380,45 @@ def dominant_kernel_roofline(iters=20):
     dM3 = torch.randn(36, 1024, 128, device="cuda")
     fl3 = 2.0 * 36 * 1024 * 128 * 128
     V4, U4 = torch.randn(36, 256, 256, device="cuda"), torch.randn(36, 256, 256, device="cuda")      # DLA level 4: 256 tiles of 4x4 at batch 4
+    dM4 = torch.randn(36, 256, 256, device="cuda")
+    V5 = torch.randn(36, 1024, 256, device="cuda")                                                   # FPN output / RPN conv at p3
     fl4 = 2.0 * 36 * 256 * 256 * 256
     families = [
-        fam("Winograd point GEMMs, small maps (DLA level 4: 18 launches / step)", "conv_fwd_kernel<64, 64, 2, 2, 32>",
+        fam("Winograd point GEMMs, small maps (DLA level 4: 18 launches / step)", "gemm_nt_pf_kernel<4>",
             "36x[256x256]x[256x256]^T (3x3 256->256 @32x32, F(4x4,3x3))", fl4, lambda: wino.gemm_batched(V4, U4), grid=147456,
             alg_bytes=4.0 * (2 * 36 * 256 * 256 + 36 * 256 * 256)),
-        fam("Winograd point GEMMs, small maps (DLA level 3: 14 launches / step)", "conv_fwd_kernel<64, 64, 2, 2, 32>",
+        fam("Winograd point GEMMs, small maps (DLA level 3: 14 launches / step)", "gemm_nt_pf_kernel<4>",
             "36x[1024x128]x[128x128]^T (3x3 128->128 @64x64, F(4x4,3x3))", fl3, lambda: wino.gemm_batched(V3, U3), grid=294912,
             alg_bytes=4.0 * (2 * 36 * 1024 * 128 + 36 * 128 * 128)),
+        fam("Winograd point GEMMs, 64x64 maps (FPN / RPN p3)", "gemm_nt_pf_kernel<4>",
+            "36x[1024x256]x[256x256]^T (3x3 256->256 @64x64, F(4x4,3x3))", 2.0 * 36 * 1024 * 256 * 256,
+            lambda: wino.gemm_batched(V5, U4), grid=589824, alg_bytes=4.0 * (2 * 36 * 1024 * 256 + 36 * 256 * 256)),
         fam("Winograd point GEMMs, 128x128 maps", "gemm_nt_persistent_kernel", "36x[4096x256]x[256x256]^T (3x3 256->256 @128x128)", flops,
             lambda: wino.gemm_batched(V, U), grid=131072, alg_bytes=4.0 * (2 * P * T * C + P * C * C)),
-        fam("Winograd weight-gradient GEMMs", "conv_wgrad_kernel<128, 128, 2, 2, 32>", "36x[256x4096]x[4096x256] (same layer)", flops,
-            lambda: wino.gemm_batched_wgrad(V, dM), grid=294912),
+        fam("Winograd weight-gradient GEMMs", "gemm_tn_pf_kernel<4>", "36x[256x4096]x[4096x256] (same layer)", flops,
+            lambda: wino.gemm_batched_wgrad(V, dM)),
         fam("FC forward (fc1-class)", "gemm_engine_kernel<0, 0, 128, 128>", "[2048x12544]x[1024x12544]^T box-head fc1", 2.0 * 2048 * 12544 * 1024,
             lambda: conv.linear_fwd(x1, w1, None), grid=65536),
         fam("FC data gradient", "conv_dgrad_kernel<128, 128, 2, 2, 32>", "[2048x1024]x[1024x12544] box-head fc1", 2.0 * 2048 * 12544 * 1024,
             lambda: conv.linear_dgrad(dy1, w1), grid=401408),
         fam("FC weight gradient", "conv_wgrad_kernel<128, 64, 2, 2, 32>", "[1024x2048]x[2048x12544] box-head fc1", 2.0 * 2048 * 12544 * 1024,
             lambda: conv.linear_wgrad(x1, dy1), grid=401408),
-        fam("Winograd weight-gradient GEMMs, small maps", "conv_wgrad_kernel<128, 128, 2, 2, 32>", "36x[128x1024]x[1024x128] (DLA level 3)", fl3,
-            lambda: wino.gemm_batched_wgrad(V3, dM3), grid=36864),
-        fam("direct conv 64x64 tiles", "conv_fwd_kernel<64, 64, 2, 2, 32>", "3x3/s2 64->128 @128x128 (DLA level 3 entry)", 2.0 * B * 64 * 64 * 128 * 64 * 9,
+        fam("Winograd weight-gradient GEMMs, small maps", "gemm_tn_pf_kernel<4>", "36x[128x1024]x[1024x128] (DLA level 3)", fl3,
+            lambda: wino.gemm_batched_wgrad(V3, dM3)),
+        fam("Winograd weight-gradient GEMMs, small maps (DLA level 4)", "gemm_tn_pf_kernel<4>", "36x[256x256]x[256x256] (DLA level 4)", fl4,
+            lambda: wino.gemm_batched_wgrad(V4, dM4)),
+        fam("direct conv 64x64 tiles", "conv_fwd_kernel<64, 64, 2, 2, 32, 1>", "3x3/s2 64->128 @128x128 (DLA level 3 entry)", 2.0 * B * 64 * 64 * 128 * 64 * 9,
             lambda: conv.conv2d_fwd(xs, ws, None, 2, 1), grid=131072),
         fam("direct dgrad 64x64 tiles", "conv_dgrad_kernel<64, 64, 2, 2, 32>", "3x3/s2 64->128 @128x128", 2.0 * B * 64 * 64 * 128 * 64 * 9,
             lambda: conv.conv2d_dgrad(dys, ws, (128, 128), 2, 1), grid=131072),
-        fam("direct conv 128x128 tiles", "conv_fwd_kernel<128, 128, 2, 2, 32>", "3x3 256->256 @128x128 (the same layer WITHOUT Winograd)", flops_direct,
+        fam("direct conv 128x128 tiles", "conv_fwd_kernel<128, 128, 2, 2, 32, 1>", "3x3 256->256 @128x128 (the same layer WITHOUT Winograd)", flops_direct,
             lambda: conv.conv2d_fwd(x, w, None, 1, 1), pmc_key="(not in the production dispatch: no PMC row)"),
-        fam("direct conv mid layers", "conv_fwd_kernel<64, 64, 2, 2, 32>", "3x3 128->128 @64x64 (DLA level 3 block, direct)", 2.0 * B * 64 * 64 * 128 * 128 * 9,
+        fam("direct conv mid layers", "conv_fwd_kernel<64, 64, 2, 2, 32, 1>", "3x3 128->128 @64x64 (DLA level 3 block, direct)", 2.0 * B * 64 * 64 * 128 * 128 * 9,
             lambda: conv.conv2d_fwd(x3, w3, None, 1, 1), pmc_key="(not in the production dispatch: no PMC row)"),
     ]
     # headline = the family whose kernel symbol tops the committed table (first family of that symbol in the list above)
     top = max(shares, key=shares.get) if shares else None
-    head = next((f for f in families if top is not None and f["kernel"].split("(")[0] == top), families[1])
+    head = next((f for f in families if top is not None and f["kernel"].split("(")[0] == top), families[0])
     traffic = head.get("pmc_traffic_bytes")
     return {"bound": "mfma",
             "kernel": f"{head['kernel']} on {head['shape']} [{head['family']}]"

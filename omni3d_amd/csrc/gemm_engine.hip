@@ -283,6 +283,27 @@ __global__ void __launch_bounds__(256) gemm_engine_kernel(GemmArgs p) {
     OMNI_WAIT_VMCNT(0);                        // the out-of-range pieces issued past the end
 }
 
+// dst (cols x rows) = src (rows x cols)^T, 64 x 64 tiles through LDS: both the global reads and the global writes are
+// 256-byte row segments.  Used to bring the fc1 weight into the [N][K] layout of the NT form, the form the engine is fastest in
+// (row pitch 65: the transposed LDS reads are conflict free).
+__global__ void __launch_bounds__(256) transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    __shared__ float t[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int tiles_c = (cols + 63) / 64;
+    const int r0 = ((int)blockIdx.x / tiles_c) * 64, c0 = ((int)blockIdx.x % tiles_c) * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        t[ty + 4 * i][tx] = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(long)c * rows + r] = t[tx][ty + 4 * i];
+    }
+}
+
 template <int LA, int LB, int BM, int BN>
 int launch_engine(GemmArgs p, int workgroups, hipStream_t st) {
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -331,6 +352,16 @@ int omni_gemm_engine(const float* A, const float* B, float* C, const float* bias
     if (form == 1) { OMNI_ENGINE(0, 1); }
     OMNI_ENGINE(1, 1);
 #undef OMNI_ENGINE
+}
+
+// dst (cols, rows) = transpose of src (rows, cols), both row-major and contiguous.
+int omni_transpose2d(const float* src, float* dst, int rows, int cols, void* stream) {
+    if (rows < 0 || cols < 0) return OMNI_ERR_ARG;
+    if (rows == 0 || cols == 0) return OMNI_OK;
+    const long tiles = (long)((rows + 63) / 64) * ((cols + 63) / 64);
+    if (tiles > 0x7fffffff) return OMNI_ERR_ARG;
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols);
+    return omni_launch_status();
 }
 
 }  // extern "C"

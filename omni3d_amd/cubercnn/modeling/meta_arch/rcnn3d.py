@@ -110,6 +110,8 @@ class RCNN3D(nn.Module):
         losses.update(proposal_losses)
         if has_event_storage():
             self.flush_logs(get_event_storage())
+        if packed_given is None and auto is not None and not auto.busy:
+            losses = auto.wrap_eager(losses)            # the loop holds one releasable node, not the iteration's graph
         if packed_given is None and getattr(self, "_omni_owns_exchange", False):
             from ...solver.ddp import tie_to_anchor     # loop-level call under the script's DDP wrapper (cubercnn/solver/ddp.py)
             tie_to_anchor(self, losses)

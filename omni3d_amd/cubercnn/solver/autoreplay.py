@@ -57,6 +57,34 @@ class _Replayed(Function):
         return (torch.zeros_like(ctx.auto.anchor), None) + (None,) * ctx.n
 
 
+class _Boundary(Function):
+    """Loss dict of an EAGER iteration behind one autograd node that owns the iteration's real graph.  The training loop keeps
+    its `loss_dict` / `losses` variables alive into the next `model(data)` call; a live graph keeps the parameters' AccumulateGrad
+    nodes alive, and those are bound to the stream they were created on -- the default stream of an eager iteration.  A later
+    hipGraph capture that meets such a node makes the autograd engine synchronise the capture stream with the default stream,
+    which is illegal inside a capture (torch warns: "AccumulateGrad node's stream does not match ... may break CUDA graph capture";
+    on ROCm 7.2 capture_end segfaults: tools/debug/capture_matrix.py, profiles/r03_capture_matrix.txt).  With the boundary the loop
+    only ever holds this node; `release()` drops the inner graph before a capture, whatever the loop still references."""
+
+    @staticmethod
+    def forward(ctx, holder, anchor):
+        # the inner tensors travel in `holder`, not as inputs: the engine must not see an edge into the inner graph
+        ctx.holder = holder
+        return tuple(t.detach() for t in holder["inner"])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        inner = ctx.holder.get("inner")
+        if inner is None:
+            raise RuntimeError("omni3d_amd: backward() through a loss dict of an earlier iteration (its graph was released when the "
+                               "training step was captured)")
+        ctx.holder["inner"] = None
+        pairs = [(t, g) for t, g in zip(inner, grads) if g is not None and t.requires_grad]
+        if pairs:
+            torch.autograd.backward([p[0] for p in pairs], [p[1] for p in pairs])
+        return None, torch.zeros_like(ctx.holder["anchor"])
+
+
 class AutoReplay:
     def __init__(self, model, optimizer, warm=2, graphs=None):
         self.model, self.opt, self.warm = model, optimizer, warm
@@ -67,6 +95,8 @@ class AutoReplay:
         self.bad = None                          # device float: != 0 when backward saw a non-unit upstream gradient
         self.bad_host, self.bad_event, self.bad_armed = None, None, False
         self.replays = 0
+        self.holders = []                        # inner graphs of the eager iterations' loss dicts (see _Boundary)
+        self._eager_anchor = None
         self.busy = False                        # True while a capture drives the model itself
         optimizer._auto = self
 
@@ -118,6 +148,31 @@ class AutoReplay:
             self.model.flush_logs(get_event_storage())
         return HF.LossDict({k: out[i] for i, k in enumerate(names)})
 
+    def wrap_eager(self, losses):
+        """eager iteration: hand the loop a loss dict whose real graph this object can release (see _Boundary)"""
+        if not ENABLED or self.failed is not None or not losses:
+            return losses
+        names = list(losses.keys())
+        if not any(losses[k].requires_grad for k in names):
+            return losses
+        anchor = getattr(self.model, "_omni_ddp_anchor", None)
+        if anchor is None:
+            if self._eager_anchor is None:
+                self._eager_anchor = torch.zeros(1, device=losses[names[0]].device, requires_grad=True)
+            anchor = self._eager_anchor
+        holder = {"inner": tuple(losses[k] for k in names), "anchor": anchor}
+        self.holders = [h for h in self.holders if h.get("inner") is not None][-4:] + [holder]
+        out = _Boundary.apply(holder, anchor)
+        wrapped = HF.LossDict({k: o for k, o in zip(names, out)})
+        return wrapped
+
+    def release_eager_graphs(self):
+        import gc
+        for h in self.holders:
+            h["inner"] = None
+        self.holders = []
+        gc.collect()
+
     def _drop(self):
         if self.stepper is not None:
             self.model.feature_cut = None
@@ -138,8 +193,9 @@ class AutoReplay:
             if "instances" in b:
                 c["instances"] = b["instances"]
             sb.append(c)
+        self.release_eager_graphs()                      # no live eager graph (and its default-stream AccumulateGrad nodes) during capture
         packed = model.prepack(batch)
-        cap = B * MAX_GT_PER_IMAGE
+        cap = B * int(os.environ.get("OMNI_AUTO_REPLAY_ROWS", MAX_GT_PER_IMAGE))
         for f in ROW_FIELDS:                              # fixed capacity: any later batch's rows fit
             t = getattr(packed, f)
             pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)

@@ -5,6 +5,8 @@ Tensors cross this boundary in torch's channels_last memory format: logically (N
 free contiguous view.  Channel counts must be multiples of 4 (16-byte loads); callers pad the
 3-channel image and the odd-sized prediction heads.
 """
+import os
+
 import torch
 
 from .. import lib as _lib
@@ -137,10 +139,18 @@ def linear_fwd(x, w, bias=None, relu=False):
     return out
 
 
+_DGRAD_NT = os.environ.get("OMNI_FC_DGRAD_NT", "1") != "0"
+
+
 def linear_dgrad(dy, w):
     M, K = dy.shape
     C = w.shape[1]
     L = _lib.check_device(dy, w)
+    if _DGRAD_NT and M >= 512 and C >= 4096 and K >= 512 and (K % 32) == 0:
+        # fc1-class data gradient dX = dY W as the NT product dY (W^T)^T on the LDS-DMA engine: one pass over W to transpose it
+        # (51 MB for fc1) buys the engine's NT main loop (0.78 of the fp32-MFMA peak against 0.59 for the tile kernel's NN form)
+        from . import gemm as _gemm
+        return _gemm.gemm(dy, _gemm.transpose2d(w), _gemm.NT, tile=2)
     dx = torch.empty((M, C), dtype=torch.float32, device=dy.device)
     L.call("omni_conv2d_dgrad", _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), M, 1, 1, C, K, 1, 1, 1, 0, K, C, 0,
            _lib.stream_of(dy))

@@ -41,3 +41,12 @@ def gemm(A, B, form=NT, bias=None, relu=False, out=None, accumulate=False, split
     L.call("omni_gemm_engine", _lib.ptr(A3), _lib.ptr(B3), _lib.ptr(out3), _lib.ptr(bias), form, b, M, N, K, lda, ldb, N,
            A3.stride(0), B3.stride(0), M * N, splits, int(relu), int(accumulate), tile, workgroups, _lib.stream_of(A))
     return out3[0] if squeeze else out3
+
+
+def transpose2d(src):
+    """(rows, cols) contiguous -> (cols, rows) contiguous"""
+    assert src.dim() == 2 and src.is_contiguous() and src.dtype == torch.float32
+    L = _lib.check_device(src)
+    dst = torch.empty((src.shape[1], src.shape[0]), dtype=torch.float32, device=src.device)
+    L.call("omni_transpose2d", _lib.ptr(src), _lib.ptr(dst), src.shape[0], src.shape[1], _lib.stream_of(src))
+    return dst

@@ -86,8 +86,23 @@ def test_conv_algo_rejects_bad_arguments(emu_lib):
         conv.conv2d_fwd(x, w, None, 1, 1, tile=9)
 
 
+def _run_transposed_dgrad(dev, M, K, C):
+    """the fc1-class data gradient as dY (W^T)^T: the LDS-tiled transpose (ragged 64x64 tiles) + the engine's NT form, the way
+    conv.linear_dgrad runs it for M >= 512, C >= 4096, K >= 512"""
+    from omni3d_amd.kernels import gemm as G
+    g = torch.Generator().manual_seed(12)
+    w = (torch.randn(K, C, generator=g) * 0.1).to(dev)
+    dy = torch.randn(M, K, generator=g).to(dev)
+    wt = G.transpose2d(w)
+    assert wt.shape == (C, K) and torch.equal(wt.cpu(), w.cpu().t().contiguous())
+    dx = G.gemm(dy, wt, G.NT, tile=2)
+    ref = dy.cpu().double() @ w.cpu().double()
+    assert (dx.cpu().double() - ref).abs().max() <= 2e-6 * float((dy.cpu().abs() @ w.cpu().abs()).max())
+
+
 def test_linear_emulated(emu_lib):
     _run_linear("cpu", 70, 36, 20)
+    _run_transposed_dgrad("cpu", 70, 96, 200)
 
 
 def test_conv_rejects_unaligned_channels(emu_lib):
@@ -126,7 +141,9 @@ def test_linear_gpu(hip_lib):
     # the head GEMMs at the benchmarked batch (4 images): cube head on 4 x 128 ROIs, box head on 4 x 512
     _run_linear("cuda", 512, 1024, 656)       # fused cube prediction heads (2+1+3+6+1) x 50 = 650 -> 656
     _run_linear("cuda", 512, 1024, 1024)      # cube fc2
-    _run_linear("cuda", 512, 12544, 1024)     # cube fc1
+    _run_linear("cuda", 512, 12544, 1024)     # cube fc1 (data gradient: transposed weights + the engine's NT form)
+    _run_linear("cuda", 2048, 12544, 1024)    # box fc1
+    _run_transposed_dgrad("cuda", 130, 1000, 4100)
     _run_linear("cuda", 2048, 1024, 256)      # fused box predictor 51 + 200 -> 256
 
 
