@@ -450,9 +450,11 @@ inline int ew_grid(long total) {
     return (int)(g < 1 ? 1 : g);
 }
 inline int red_grid(int P, int C) {
-    // >= 16 pixel rows per thread before another workgroup is worth its partial-sum row; <= 512 workgroups
+    // >= 4 pixel rows per thread (one trip of the 4-deep load loop) before another workgroup is worth its partial-sum row;
+    // <= 512 workgroups (the partial rows live in the caller's workspace).  Round 3: 16 -> 4 rows.  With 16 the level-3 / level-4
+    // BatchNorms (8 / 4 MB tensors) ran their reductions on 128 / 64 workgroups at ~1.3 TB/s -- a latency chain, not a stream.
     const int rows = (C >> 2) >= 256 ? 1 : 256 / (C >> 2);
-    long g = ((long)P + 16L * rows - 1) / (16L * rows);
+    long g = ((long)P + 4L * rows - 1) / (4L * rows);
     if (g > 512) g = 512;
     return (int)(g < 1 ? 1 : g);
 }

@@ -762,6 +762,13 @@ struct GemmTP {
     long ab, bb, ob;       // element strides between the gridDim.z problems
 };
 
+// workgroup id -> position in a work sequence such that each XCD (ids round-robin over 8 of them) walks one contiguous chunk
+__device__ __forceinline__ int xcd_chunked(int id, int total) {
+    if (total < 8) return id;
+    const int q = total / 8, r = total % 8, xcd = id % 8, k = id / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 typedef unsigned omni_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 bufld4(omni_rsrc_t r, int voff) {
 #ifdef OMNI_HIPEMU
@@ -781,11 +788,17 @@ __global__ void __launch_bounds__(256) gemm_nt_pf_kernel(GemmTP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int kq = tid % KQ, lrow = tid / KQ;
-    const omni_rsrc_t ra_ = omni_make_rsrc(p.A + (long)blockIdx.z * p.ab, (unsigned)p.M * (unsigned)p.K * 4u);
-    const omni_rsrc_t rb_ = omni_make_rsrc(p.B + (long)blockIdx.z * p.bb, (unsigned)p.N * (unsigned)p.K * 4u);
-    float* out = p.out + (long)blockIdx.z * p.ob;
-    int tile_m, tile_n;
-    tile_coords((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, tile_m, tile_n);
+    // 1-D grid over (problem, tile) items, problem-major, one contiguous chunk of the sequence per XCD (workgroup ids round-robin
+    // over the 8 XCDs): all tiles of a problem -- which re-read the same A / B panels -- run on ONE XCD and share its L2.  With a
+    // (tiles, 1, batch) grid the 16 tiles of a 256 x 256 point problem were spread over all eight L2s: 66 MB fetched for 28 MB of
+    // operands (profiles/r03_pmc_families.csv).
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, per_problem = tiles_m * tiles_n;
+    const int item = xcd_chunked((int)blockIdx.x, (int)gridDim.x);
+    const int prob = item / per_problem, tix = item - prob * per_problem;
+    const omni_rsrc_t ra_ = omni_make_rsrc(p.A + (long)prob * p.ab, (unsigned)p.M * (unsigned)p.K * 4u);
+    const omni_rsrc_t rb_ = omni_make_rsrc(p.B + (long)prob * p.bb, (unsigned)p.N * (unsigned)p.K * 4u);
+    float* out = p.out + (long)prob * p.ob;
+    const int tile_m = tix / tiles_n, tile_n = tix - tile_m * tiles_n;      // n fastest: the A panel of a row of tiles stays hot
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     // byte offsets of this thread's float4 column in its AI / BI rows; a row past the end lands past the resource -> zeros
     int a_off[AI], b_off[BI];
@@ -850,18 +863,22 @@ __global__ void __launch_bounds__(256) gemm_nt_pf_kernel(GemmTP p) {
 // rows (Winograd-domain weight gradient dU = dM^T V of the small maps).  gridDim.y splits the rows (`rows_per_split`, a multiple
 // of 32 * PF); a split launch adds its partial tile atomically into a zeroed output, a single split stores it.
 template <int PF>
-__global__ void __launch_bounds__(256) gemm_tn_pf_kernel(GemmTP p, int rows_per_split) {
+__global__ void __launch_bounds__(256) gemm_tn_pf_kernel(GemmTP p, int rows_per_split, int splits) {
     constexpr int BM = 64, BN = 64, BK = 32, F4 = BM / 4, ROWS = 256 / F4, LI = BK / ROWS;      // 16 float4 per row, 16 rows per pass
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int c4 = tid % F4, lrow = tid / F4;
-    const omni_rsrc_t ra_ = omni_make_rsrc(p.A + (long)blockIdx.z * p.ab, (unsigned)p.M * (unsigned)p.N * 4u);   // p.N = Kc (A's width)
-    const omni_rsrc_t rb_ = omni_make_rsrc(p.B + (long)blockIdx.z * p.bb, (unsigned)p.M * (unsigned)p.K * 4u);   // p.K = C  (B's width)
-    float* out = p.out + (long)blockIdx.z * p.ob;
-    const int tiles_m = (p.N + BM - 1) / BM;
-    const int m0 = ((int)blockIdx.x % tiles_m) * BM, n0 = ((int)blockIdx.x / tiles_m) * BN;
-    const int r_begin = (int)blockIdx.y * rows_per_split;
+    // 1-D grid over (problem, split, tile) items, tile fastest, one contiguous chunk per XCD (see gemm_nt_pf_kernel)
+    const int tiles_m = (p.N + BM - 1) / BM, tiles = tiles_m * ((p.K + BN - 1) / BN);
+    const int item = xcd_chunked((int)blockIdx.x, (int)gridDim.x);
+    const int prob = item / (tiles * splits), rem = item - prob * (tiles * splits);
+    const int split = rem / tiles, tix = rem - split * tiles;
+    const omni_rsrc_t ra_ = omni_make_rsrc(p.A + (long)prob * p.ab, (unsigned)p.M * (unsigned)p.N * 4u);   // p.N = Kc (A's width)
+    const omni_rsrc_t rb_ = omni_make_rsrc(p.B + (long)prob * p.bb, (unsigned)p.M * (unsigned)p.K * 4u);   // p.K = C  (B's width)
+    float* out = p.out + (long)prob * p.ob;
+    const int m0 = (tix % tiles_m) * BM, n0 = (tix / tiles_m) * BN;
+    const int r_begin = split * rows_per_split;
     const int r_end = min(r_begin + rows_per_split, p.M);
     const int nk = (r_end - r_begin + BK - 1) / BK;
     // this thread's float4 column in A / B (fixed) and its first row; out-of-range columns / rows read zeros through the resource
@@ -908,7 +925,7 @@ __global__ void __launch_bounds__(256) gemm_tn_pf_kernel(GemmTP p, int rows_per_
     }
     const int l31 = lane & 31, h = lane >> 5;
     const int n = n0 + wn * 32 + l31;
-    const bool single = gridDim.y == 1;
+    const bool single = splits == 1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1151,7 +1168,7 @@ int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int b
     const long t128 = (((long)M + 127) / 128) * ((K + 127) / 128);
     // measured per shape (tools/sweep_batched_gemm.py, hipGraph replay): the persistent kernel from 1024 128x128 tiles up, 64x64 tiles
     // below (36x[1024x256]x[256x256]^T: 60 us against 76 us with one 128x128 tile per workgroup)
-    if (algo == 0) algo = (K > 64 && (C % 32) == 0 && t128 * batch >= 1024) ? 1 : 3;
+    if (algo == 0) algo = (K > 64 && (C % 32) == 0 && t128 * batch >= 1024 && !(FWD64_DEEP_PREFETCH && (C % 64) == 0)) ? 1 : 3;
     if (algo == 1) {
         // >= 2 items per resident workgroup: persistent kernel with the prefetch carried across items
         GemmP g{x, w, out, batch, M, K, C, (M + 127) / 128, (K + 127) / 128};
@@ -1169,7 +1186,9 @@ int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int b
     else {           // 64x64 tiles, PF slabs of buffer-load prefetch in flight (gemm_nt_pf_kernel)
         if ((C % 64) != 0 || (long)M * C * 4 >= (1L << 31) || (long)K * C * 4 >= (1L << 31)) return OMNI_ERR_ARG;
         GemmTP g{x, w, out, M, K, C, (long)M * C, (long)K * C, (long)M * K};
-        const dim3 grid((unsigned)((((long)M + 63) / 64) * ((K + 63) / 64)), 1, (unsigned)batch);
+        const long wgs = (((long)M + 63) / 64) * ((K + 63) / 64) * batch;
+        if (wgs > 0x7fffffff) return OMNI_ERR_ARG;
+        const dim3 grid((unsigned)wgs);
         if ((C % 128) == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_nt_pf_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, g);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_nt_pf_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, g);
     }
@@ -1207,7 +1226,9 @@ int omni_gemm_batched_wgrad_algo(const float* x, const float* dy, float* dw, int
         splits = ((long)M + rps - 1) / rps;
         if (splits > 1) omni_memset_async(dw, 0, sizeof(float) * (size_t)batch * K * C, st);
         GemmTP g{dy, x, dw, M, K, C, (long)M * K, (long)M * C, (long)K * C};
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_tn_pf_kernel<4>), dim3(tiles, (unsigned)splits, (unsigned)batch), dim3(256), 0, st, g, rps);
+        const long wgs = (long)tiles * splits * batch;
+        if (wgs > 0x7fffffff) return OMNI_ERR_ARG;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_tn_pf_kernel<4>), dim3((unsigned)wgs), dim3(256), 0, st, g, rps, (int)splits);
         return omni_launch_status();
     }
     ConvP p{x, dy, nullptr, dw, M, 1, 1, C, 1, 1, K, 1, 1, 1, 0, C, 0, K, 0, 0, 1, (long)M * C, (long)M * K, (long)K * C};

@@ -14,7 +14,8 @@ _F43_MIN_TILES = int(_os.environ.get("OMNI_WINOGRAD_F43_MIN_TILES", "256"))     
 
 
 _MIN_TILES = int(_os.environ.get("OMNI_WINO_MIN_TILES", "256"))                 # 2x2 tiles a map needs for the Winograd path at all
-_DGRAD_MIN_TILES = int(_os.environ.get("OMNI_WINO_DGRAD_MIN_TILES", "1024"))    # ... and for the Winograd data gradient
+_DGRAD_MIN_TILES = int(_os.environ.get("OMNI_WINO_DGRAD_MIN_TILES", "256"))     # ... and for the Winograd data gradient (round 3: 1024 -> 256,
+#   the deep-prefetch point GEMMs made the 16x16 maps pay: 13.60 -> 13.55 ms / step, profiles/r03_ab_thresholds.log)
 
 
 def eligible(x_shape, w_shape, stride, pad):
@@ -38,7 +39,7 @@ def tile_size(x_shape):
 
 
 def dgrad_eligible(x_shape):
-    """Below ~1024 tiles the direct split-K data-gradient kernel is faster than transform + 16 GEMMs + transform."""
+    """Below ~256 tiles the direct split-K data-gradient kernel is faster than transform + 16 GEMMs + transform."""
     N, _, H, W = x_shape
     return N * (H // 2) * (W // 2) >= _DGRAD_MIN_TILES
 

@@ -190,7 +190,7 @@ def test_winograd_dispatch_rule():
     from omni3d_amd.kernels import wino
     assert wino.eligible((4, 256, 128, 128), (256, 256, 3, 3), 1, 1)
     assert wino.eligible((4, 256, 64, 64), (256, 256, 3, 3), 1, 1)
-    assert wino.eligible((4, 512, 16, 16), (512, 512, 3, 3), 1, 1) and not wino.dgrad_eligible((4, 512, 16, 16))
+    assert wino.eligible((4, 512, 16, 16), (512, 512, 3, 3), 1, 1) and wino.dgrad_eligible((4, 512, 16, 16)) and not wino.dgrad_eligible((2, 512, 16, 16))
     assert not wino.eligible((4, 256, 8, 8), (256, 256, 3, 3), 1, 1)        # too few tiles
     assert wino.eligible((4, 64, 128, 128), (64, 64, 3, 3), 1, 1) and wino.tile_size((4, 64, 128, 128)) == 4
     assert not wino.eligible((4, 32, 128, 128), (32, 32, 3, 3), 1, 1)        # narrow

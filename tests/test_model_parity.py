@@ -20,13 +20,14 @@ def _box_iou(a, b):
     return inter / (area(a)[:, None] + area(b)[None, :] - inter).clamp(min=1e-12)
 
 
-def unexplained_proposal_mismatches(got, want, cand, n, nms_thresh, tol=4e-6, box_tol=1e-2):
+def unexplained_proposal_mismatches(got, want, cand, n, nms_thresh, tol=2e-5, iou_tol=1e-4, box_tol=1e-2):
     """First-stage lists are compared as SETS because a last-bit difference in an objectness logit can re-order near-tied
     candidates.  This checks that nothing else hides behind that slack: every proposal present on one side only must be
     explained by (a) a ranking tie -- another candidate of the same image and level whose score differs by less than `tol`
-    (relative, a few fp32 ulps) --, (b) an NMS tie -- an IoU with a higher-scored candidate within 1e-5 of the threshold --,
-    (c) a tie at the post-NMS cut, or (d) being a consequence of such a flip: it overlaps (IoU > threshold - 1e-5) another
-    mismatched proposal.  -> list of unexplained boxes (empty = the slack was only ever used by ties).
+    (relative; 2e-5 is the agreement of the objectness logits themselves after ~60 fp32 layers: the full-size fp64 reports put the
+    HIP and the CPU fp32 activations 1e-6 .. 1e-5 apart) --, (b) an NMS tie -- an IoU with another candidate within `iou_tol` of
+    the threshold (decoded boxes agree to ~1e-3 px, i.e. ~1e-4 in the IoU of a 50 px box) --, (c) a tie at the post-NMS cut, or
+    (d) being a consequence of such a flip: it overlaps (IoU > threshold - iou_tol) another mismatched proposal.  -> list of unexplained boxes (empty = the slack was only ever used by ties).
     got / want: (n, 4) proposal boxes of image n; cand: RPNWithIgnore.last_candidates."""
     d = (got[:, None, :] - want[None, :, :]).abs().amax(dim=2) if len(got) and len(want) else torch.full((len(got), len(want)), 1e9)
     only_got = got[d.min(dim=1).values > box_tol] if len(want) else got
@@ -56,12 +57,12 @@ def unexplained_proposal_mismatches(got, want, cand, n, nms_thresh, tol=4e-6, bo
         if bool(((cs - s).abs() <= scale)[same].any()):
             continue                                                            # (a) ranking tie
         iou = _box_iou(b[None], cb[fin & (level == lv)])[0]
-        if bool(((iou - nms_thresh).abs() <= 1e-5).any()):
+        if bool(((iou - nms_thresh).abs() <= iou_tol).any()):
             continue                                                            # (b) NMS threshold tie
         if cut is not None and abs(s - float(cut)) <= scale:
             continue                                                            # (c) post-NMS cut tie
         others = mism[(mism - b[None]).abs().amax(dim=1) > box_tol]
-        if len(others) and float(_box_iou(b[None], others)[0].max()) > nms_thresh - 1e-5:
+        if len(others) and float(_box_iou(b[None], others)[0].max()) > nms_thresh - iou_tol:
             continue                                                            # (d) consequence of another flip
         bad.append(("no tie", b.tolist(), s))
     return bad
@@ -346,7 +347,7 @@ def test_proposal_mismatch_explainer_host():
     kmax = 4
     boxes = torch.tensor([[[0, 0, 10, 10], [20, 20, 30, 30], [40, 40, 50, 50], [60, 60, 70, 70],          # level 0
                            [0, 0, 20, 20], [100, 100, 140, 140], [0, 0, 0, 0], [0, 0, 0, 0]]], dtype=torch.float32)
-    scores = torch.tensor([[0.9, 0.5, 0.5 + 2e-8, 0.1, 0.8, 0.3, float("-inf"), float("-inf")]])
+    scores = torch.tensor([[0.9, 0.5, 0.5 + 2e-8, 0.1, 0.8, 0.3, float("-inf"), float("-inf")]])     # candidates 1 and 2 tie
     keep = torch.tensor([[1, 1, 1, 1, 1, 1, 0, 0]])
     cand = {"boxes": boxes, "scores": scores, "keep": keep, "slots_per_level": kmax}
     want = boxes[0, [0, 4, 1, 5]]                     # the reference kept candidate 1 ...

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 timeout 900 python bench.py > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_bench.err
 tail -c 1500 $OUT/${TAG}_bench.log
 cd /tmp
-OMNI_BENCH_SKIP_CPU=1 OMNI_BENCH_SKIP_DROPIN=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o train -- python $REPO/bench.py --workload train --steps 10 --warmup 3 > $OUT/${TAG}_prof.log 2>&1
+OMNI_BENCH_SKIP_CPU=1 OMNI_BENCH_SKIP_ROOFLINE=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o train -- python $REPO/bench.py --workload train --steps 10 --warmup 3 > $OUT/${TAG}_prof.log 2>&1
 cd $REPO
 f=$(find $OUT/${TAG}_prof -name 'train_kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp $f $OUT/${TAG}_kernel_stats.csv && head -25 $OUT/${TAG}_kernel_stats.csv | cut -c1-170
