@@ -122,6 +122,9 @@ def _run(dev, name, head_cap=None):
     # gradients: heads / FPN 0.5 %, bottom-up 3 % (how much of that is fp32 conditioning is MEASURED against a float64 run
     # in the full-size tests below)
     grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    # bottom-up cap: 2 % (round 3; 3 % before the Winograd point change), 3 % only for the 1 x 64 x 64 plumbing fixtures whose
+    # deepest BatchNorms see 4 samples per channel
+    bb_cap = GRAD_CAP_BACKBONE_TINY if spec["images"] * spec["height"] * spec["width"] <= 64 * 64 else GRAD_CAP_BACKBONE
     worst = 0.0
     # a BatchNorm bias that reaches the next BatchNorm through linear layers only (MNASNet's base.7, ShuffleNet's branch1.1) has an
     # exactly-zero gradient in exact arithmetic: both sides hold rounding noise there, hence a floor relative to the largest gradient
@@ -131,7 +134,7 @@ def _run(dev, name, head_cap=None):
         got = float(grads[n].float().norm())
         rel = abs(got - ref_norm) / max(ref_norm, 1e-6)
         worst = max(worst, rel)
-        tol = head_cap if _is_head(n) else GRAD_CAP_BACKBONE
+        tol = head_cap if _is_head(n) else bb_cap
         assert rel < tol or abs(got - ref_norm) < floor, (n, got, ref_norm, floor)
     for n, head in gold["grad_head"].items():
         g = grads[n]
@@ -139,7 +142,7 @@ def _run(dev, name, head_cap=None):
             g = g.contiguous(memory_format=torch.contiguous_format)
         got = g.reshape(g.shape[0], -1).flatten()[:64].cpu() if g.dim() > 1 else g.flatten()[:64].cpu()
         scale = max(head.abs().max().item(), 1e-6)
-        tol = head_cap if _is_head(n) else GRAD_CAP_BACKBONE
+        tol = head_cap if _is_head(n) else bb_cap
         assert (got - head).abs().max().item() <= tol * scale + 1e-7, (n, (got - head).abs().max().item(), scale)
     return worst
 
@@ -185,19 +188,24 @@ def test_training_step_matches_reference_gpu(hip_lib, name):
 #
 # Measured on MI355X (profiles/r02_parity_fp64_*.txt): all ten losses of the HIP path sit within 1.2e-7 (relative) of the
 # float64 value, the same distance as the CPU fp32 oracle.  Gradients: the CPU fp32 oracle itself is 0.9 % .. 1.1 % (relative L2
-# per tensor) from float64 on the bottom-up parameters at 4 x 512 x 512 (0.5 % .. 0.6 % ResNet-34), the HIP path 1.5 % .. 2.2 %
-# (0.8 % .. 1.0 %): a steady 1.6x (Winograd F(4x4,3x3) + atomically split reductions).  Derivative discontinuities add isolated
+# per tensor) from float64 on the bottom-up parameters at 4 x 512 x 512 (0.5 % .. 0.6 % ResNet-34).  Round 2: the HIP path 1.5 % ..
+# 2.2 % (0.8 % .. 1.0 %), a steady 1.6x (Winograd F(4x4,3x3) + atomically split reductions).  Round 3 (F(4x4,3x3) on the points
+# {0, 1, -1, 1/2, -2}, profiles/r03_parity_fp64_fullsize.txt): 1.16 % .. 1.38 %, median ratio to the CPU fp32 oracle 1.19.  Derivative discontinuities add isolated
 # outliers: in the DLA run ONE of 44 foreground ROIs had a cube-head fc2 pre-activation within rounding of zero, its ReLU
 # mask flipped, and that ROI's gradient changed by 5 % (1/sqrt(#active units)) -- 0.4 % on the cube-head FC gradients and
 # 0.5 % .. 0.9 % on fpn_output4/5 downstream, with every head OUTPUT gradient of the same ROI still at 1e-4.  Hence: hard caps
 # for every tensor, and the "no worse than 3x the CPU oracle's own fp32 error" rule for at least 90 % of the tensors.
 LOSS_ABS = 1e-4          # |HIP - fp64| <= 1e-4 * max(1, |fp64|) for every loss (north_star)
 LOSS_FLOOR = LOSS_ABS / 5   # a loss within a fifth of the bar passes whatever the CPU oracle's own error happens to be
-GRAD_FLOOR = 1e-3        # same idea for gradients (relative L2 per parameter tensor)
+GRAD_FLOOR = 3e-3        # same idea for gradients (relative L2 per parameter tensor).  Round 3: 1e-3 -> 3e-3 together with the hard cap
+#   3 % -> 2 %: on the ragged batch the CPU fp32 oracle is itself only 0.07 % from fp64 while the HIP path sits at 0.2 .. 0.5 %
+#   (Winograd layers: 2.4x the rounding error of a direct fp32 convolution), so a 3x-ratio rule with a 0.1 % floor tested the
+#   run-to-run noise of the atomically split sums (133 .. 145 of 155 tensors over repeated runs), not the arithmetic
 GRAD_RULE_MULT = 3.0     # e_hip <= max(3 x e_cpu, GRAD_FLOOR) ...
 GRAD_RULE_FRACTION = 0.9    # ... for at least this fraction of the parameter tensors
 GRAD_CAP_HEADS = 1e-2    # hard caps on the relative L2 error of EVERY parameter tensor: heads / FPN 1 %, bottom-up 3 %
-GRAD_CAP_BACKBONE = 3e-2
+GRAD_CAP_BACKBONE = 2e-2         # round 3: measured worst 1.4 % at full size (profiles/r03_parity_fp64_*.txt); round 2: 3 % with 2.2 % measured
+GRAD_CAP_BACKBONE_TINY = 3e-2
 
 
 def _is_head(n):
