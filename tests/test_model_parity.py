@@ -200,7 +200,8 @@ LOSS_FLOOR = LOSS_ABS / 5   # a loss within a fifth of the bar passes whatever t
 GRAD_FLOOR = 3e-3        # same idea for gradients (relative L2 per parameter tensor).  Round 3: 1e-3 -> 3e-3 together with the hard cap
 #   3 % -> 2 %: on the ragged batch the CPU fp32 oracle is itself only 0.07 % from fp64 while the HIP path sits at 0.2 .. 0.5 %
 #   (Winograd layers: 2.4x the rounding error of a direct fp32 convolution), so a 3x-ratio rule with a 0.1 % floor tested the
-#   run-to-run noise of the atomically split sums (133 .. 145 of 155 tensors over repeated runs), not the arithmetic
+#   run-to-run noise of the atomically split sums (the test passed in three GPU runs of this round and failed in a fourth with
+#   133 of 155 tensors), not the arithmetic
 GRAD_RULE_MULT = 3.0     # e_hip <= max(3 x e_cpu, GRAD_FLOOR) ...
 GRAD_RULE_FRACTION = 0.9    # ... for at least this fraction of the parameter tensors
 GRAD_CAP_HEADS = 1e-2    # hard caps on the relative L2 error of EVERY parameter tensor: heads / FPN 1 %, bottom-up 3 %
