@@ -40,19 +40,39 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
     const int oy0 = ty * TH, ox0 = tx * TW;
 
     // ---- stage the input halo (zero outside the image) and the filter ----
+    // All global loads of a thread are issued before the first LDS store, explicitly (round 3; hipcc had already hoisted them out
+    // of the load -> store loop: 68 -> 66 us on the level0 shape, i.e. the staging phase is not what keeps this kernel at 0.47 of
+    // the fp32-MFMA peak against a ridge-point floor of ~31 us).
     constexpr int C4 = C / 4;
-    for (int i = tid; i < HR * HC * C4; i += 256) {
+    constexpr int NI = (HR * HC * C4 + 255) / 256, NW = (16 * R * SP * C4 + 255) / 256;
+    float4 vi[NI], vw[NW];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = tid + 256 * u;
         const int c4 = i % C4, col = (i / C4) % HC, row = i / (C4 * HC);
         const int iy = oy0 - PAD + row, ix = ox0 - PAD + col;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x + (((long)n * H + iy) * W + ix) * ldx + 4 * c4);
-        *reinterpret_cast<float4*>(s_in + (row * HC + col) * PP + 4 * c4) = v;
+        vi[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < HR * HC * C4 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            vi[u] = ld4(x + (((long)n * H + iy) * W + ix) * ldx + 4 * c4);
     }
-    for (int i = tid; i < 16 * R * SP * C4; i += 256) {
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+        const int i = tid + 256 * u;
         const int c4 = i % C4, s = (i / C4) % SP, r = (i / (C4 * SP)) % R, k = i / (C4 * SP * R);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < R) v = ld4(w + (((long)k * R + r) * R + s) * C + 4 * c4);
-        *reinterpret_cast<float4*>(s_w + k * KP + (r * SP + s) * C + 4 * c4) = v;
+        vw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < 16 * R * SP * C4 && s < R) vw[u] = ld4(w + (((long)k * R + r) * R + s) * C + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = tid + 256 * u;
+        const int c4 = i % C4, col = (i / C4) % HC, row = i / (C4 * HC);
+        if (i < HR * HC * C4) *reinterpret_cast<float4*>(s_in + (row * HC + col) * PP + 4 * c4) = vi[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+        const int i = tid + 256 * u;
+        const int c4 = i % C4, s = (i / C4) % SP, r = (i / (C4 * SP)) % R, k = i / (C4 * SP * R);
+        if (i < 16 * R * SP * C4) *reinterpret_cast<float4*>(s_w + k * KP + (r * SP + s) * C + 4 * c4) = vw[u];
     }
     __syncthreads();
 
@@ -147,20 +167,39 @@ __global__ void __launch_bounds__(256) stem_conv_wgrad_kernel(const float* __res
         const int ty = t % tiles_y;
         const int n = t / tiles_y;
         const int oy0 = ty * TH, ox0 = tx * TW;
-        __syncthreads();                                      // previous tile's LDS reads are done
-        for (int i = tid; i < HR * HC * C4; i += 256) {
+        // all global loads of the tile before the first LDS store (see stem_conv_fwd_kernel); they are issued BEFORE the barrier
+        // that frees the LDS tiles, so they fly while the other waves finish the previous tile's MFMAs
+        constexpr int NI = (HR * HC * C4 + 255) / 256, ND = (TH * TW * 4 + 255) / 256;
+        float4 vi[NI], vd[ND];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = tid + 256 * u;
             const int c4 = i % C4, cc = (i / C4) % HC, row = i / (C4 * HC);
             const int iy = oy0 - PAD + row, ix = ox0 - PAD + cc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x + (((long)n * H + iy) * W + ix) * ldx + 4 * c4);
-            *reinterpret_cast<float4*>(s_in + (row * HC + cc) * C + 4 * c4) = v;
+            vi[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < HR * HC * C4 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                vi[u] = ld4(x + (((long)n * H + iy) * W + ix) * ldx + 4 * c4);
         }
-        for (int i = tid; i < TH * TW * 4; i += 256) {
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int i = tid + 256 * u;
             const int k4 = i % 4, cc = (i / 4) % TW, row = i / (4 * TW);
             const int oy = oy0 + row, ox = ox0 + cc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oy < H && ox < W) v = ld4(dy + (((long)n * H + oy) * W + ox) * lddy + 4 * k4);
-            *reinterpret_cast<float4*>(s_dy + (row * TW + cc) * 16 + 4 * k4) = v;
+            vd[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < TH * TW * 4 && oy < H && ox < W) vd[u] = ld4(dy + (((long)n * H + oy) * W + ox) * lddy + 4 * k4);
+        }
+        __syncthreads();                                      // previous tile's LDS reads are done
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = tid + 256 * u;
+            const int c4 = i % C4, cc = (i / C4) % HC, row = i / (C4 * HC);
+            if (i < HR * HC * C4) *reinterpret_cast<float4*>(s_in + (row * HC + cc) * C + 4 * c4) = vi[u];
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int i = tid + 256 * u;
+            const int k4 = i % 4, cc = (i / 4) % TW, row = i / (4 * TW);
+            if (i < TH * TW * 4) *reinterpret_cast<float4*>(s_dy + (row * TW + cc) * 16 + 4 * k4) = vd[u];
         }
         __syncthreads();
 #pragma unroll 1
