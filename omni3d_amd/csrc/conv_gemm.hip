@@ -68,6 +68,13 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, i
     }
 }
 
+// workgroup id -> position in a work sequence such that each XCD (ids round-robin over 8 of them) walks one contiguous chunk
+__device__ __forceinline__ int xcd_chunked(int id, int total) {
+    if (total < 8) return id;
+    const int q = total / 8, r = total % 8, xcd = id % 8, k = id / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // ---- fragment fetch + MFMA over one BK=16 slab -------------------------------------------------
 // A_KCONTIG: As[m][BKP] else As[k][LDA] (m contiguous).  B likewise.
 template <int WM, int WN, bool A_KCONTIG, bool B_KCONTIG, int LDA, int LDB, int BKX = 16>
@@ -536,7 +543,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int P = p.N * p.OH * p.OW, Nn = p.R * p.S * p.C;
     const int tiles_m = (p.K + BM - 1) / BM;
-    const int m0 = (blockIdx.x % tiles_m) * BM, n0 = (blockIdx.x / tiles_m) * BN;
+    // p.relu (unused by a weight gradient) = XCD-contiguous tile order: the tiles_m workgroups that share an x panel run on ONE
+    // XCD instead of one on each (fc1: 8 tiles per 2048 x 64 panel, exactly one per XCD in the plain order)
+    const int bid = p.relu ? xcd_chunked((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int m0 = (bid % tiles_m) * BM, n0 = (bid / tiles_m) * BN;
     const int p_begin = blockIdx.y * pix_per_split;
     const int p_end = (p_begin + pix_per_split < P) ? p_begin + pix_per_split : P;
     const int am4 = tid % AF4, arow = tid / AF4;
@@ -762,13 +772,6 @@ struct GemmTP {
     long ab, bb, ob;       // element strides between the gridDim.z problems
 };
 
-// workgroup id -> position in a work sequence such that each XCD (ids round-robin over 8 of them) walks one contiguous chunk
-__device__ __forceinline__ int xcd_chunked(int id, int total) {
-    if (total < 8) return id;
-    const int q = total / 8, r = total % 8, xcd = id % 8, k = id / 8;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
 typedef unsigned omni_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 bufld4(omni_rsrc_t r, int voff) {
 #ifdef OMNI_HIPEMU
@@ -958,6 +961,7 @@ extern "C" {
 //   slabs of register prefetch; splits >= 1 = number of
 //   reduction splits (atomic epilogue into a zeroed output when > 1; needs ldo == K).  Used by tools/bench_kernels.py for A/B
 //   measurements and by tests that want a given tile on a small problem.
+constexpr bool WGRAD_XCD_ORDER_FC = true;     // fc-class weight gradients (one split): XCD-contiguous tile order (fc1: 615 -> 562 us, profiles/r03_fc_wgrad_xcd_order.log)
 constexpr bool FWD64_DEEP_PREFETCH = true;    // batched GEMMs on 64x64 tiles: gemm_nt_pf_kernel (profiles/r03_sweep_batched_gemm.log: 17-27 % faster on every small-map shape)
 
 static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
@@ -1107,6 +1111,10 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
 // tile: 0 auto | 1 = 128x128 | 2 = 64x64 | 3 = 128x64 | 4 = 32x128 (BM over K, BN over the (r, s, c) extent)
 int omni_conv2d_wgrad_algo(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
                            int stride, int pad, int ldx, int lddy, int accumulate, int tile, void* stream) {
+    // tile + 16: the same tile with the XCD-contiguous workgroup order; tile + 32: with the plain order; 0..4: the launcher decides
+    int xcd_order = -1;
+    if (tile >= 32) { xcd_order = 0; tile -= 32; }
+    else if (tile >= 16) { xcd_order = 1; tile -= 16; }
     if (tile < 0 || tile > 4) return OMNI_ERR_ARG;
     ConvP p{x, dy, nullptr, dw, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
             R, S, stride, pad, ldx, 0, lddy, 0, accumulate, 1};
@@ -1138,6 +1146,8 @@ int omni_conv2d_wgrad_algo(const float* x, const float* dy, float* dw, int N, in
     pps = (pps + WBK - 1) / WBK * WBK;
     splits = (P + pps - 1) / pps;
     if (splits > 1 && !accumulate) omni_memset_async(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
+    if (xcd_order < 0) xcd_order = (WGRAD_XCD_ORDER_FC && R == 1 && S == 1 && H == 1 && W == 1 && splits == 1) ? 1 : 0;
+    p.relu = xcd_order;
 #define OMNI_WGRAD(BM_, BN_, WM_, WN_)                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<BM_, BN_, WM_, WN_, WBK>), dim3(tiles, (unsigned)splits), dim3(256), 0, \
                        (hipStream_t)stream, p, pps)
