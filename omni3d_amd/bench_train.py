@@ -384,6 +384,8 @@ def dominant_kernel_roofline(iters=20):
     V5 = torch.randn(36, 1024, 256, device="cuda")                                                   # FPN output / RPN conv at p3
     fl4 = 2.0 * 36 * 256 * 256 * 256
     families = [
+        fam("Winograd point GEMMs, 128x128 maps (FPN output / RPN conv at p2: 4 launches / step, the heaviest shape of this symbol)", "gemm_nt_pf_kernel<4>", "36x[4096x256]x[256x256]^T (3x3 256->256 @128x128)", flops,
+            lambda: wino.gemm_batched(V, U), grid=2359296, alg_bytes=4.0 * (2 * P * T * C + P * C * C)),
         fam("Winograd point GEMMs, small maps (DLA level 4: 18 launches / step)", "gemm_nt_pf_kernel<4>",
             "36x[256x256]x[256x256]^T (3x3 256->256 @32x32, F(4x4,3x3))", fl4, lambda: wino.gemm_batched(V4, U4), grid=147456,
             alg_bytes=4.0 * (2 * 36 * 256 * 256 + 36 * 256 * 256)),
@@ -393,10 +395,9 @@ def dominant_kernel_roofline(iters=20):
         fam("Winograd point GEMMs, 64x64 maps (FPN / RPN p3)", "gemm_nt_pf_kernel<4>",
             "36x[1024x256]x[256x256]^T (3x3 256->256 @64x64, F(4x4,3x3))", 2.0 * 36 * 1024 * 256 * 256,
             lambda: wino.gemm_batched(V5, U4), grid=589824, alg_bytes=4.0 * (2 * 36 * 1024 * 256 + 36 * 256 * 256)),
-        fam("Winograd point GEMMs, 128x128 maps", "gemm_nt_persistent_kernel", "36x[4096x256]x[256x256]^T (3x3 256->256 @128x128)", flops,
-            lambda: wino.gemm_batched(V, U), grid=131072, alg_bytes=4.0 * (2 * P * T * C + P * C * C)),
         fam("Winograd weight-gradient GEMMs", "gemm_tn_pf_kernel<4>", "36x[256x4096]x[4096x256] (same layer)", flops,
-            lambda: wino.gemm_batched_wgrad(V, dM)),
+            lambda: wino.gemm_batched_wgrad(V, dM), grid=147456),      # (PMC: the three weight-gradient shapes share the geometry
+                                                                        #  576 workgroups -> one averaged row)
         fam("FC forward (fc1-class)", "gemm_engine_kernel<0, 0, 128, 128>", "[2048x12544]x[1024x12544]^T box-head fc1", 2.0 * 2048 * 12544 * 1024,
             lambda: conv.linear_fwd(x1, w1, None), grid=65536),
         fam("FC data gradient", "conv_dgrad_kernel<128, 128, 2, 2, 32>", "[2048x1024]x[1024x12544] box-head fc1", 2.0 * 2048 * 12544 * 1024,
@@ -404,9 +405,9 @@ def dominant_kernel_roofline(iters=20):
         fam("FC weight gradient", "conv_wgrad_kernel<128, 64, 2, 2, 32>", "[1024x2048]x[2048x12544] box-head fc1", 2.0 * 2048 * 12544 * 1024,
             lambda: conv.linear_wgrad(x1, dy1), grid=401408),
         fam("Winograd weight-gradient GEMMs, small maps", "gemm_tn_pf_kernel<4>", "36x[128x1024]x[1024x128] (DLA level 3)", fl3,
-            lambda: wino.gemm_batched_wgrad(V3, dM3)),
+            lambda: wino.gemm_batched_wgrad(V3, dM3), grid=147456),
         fam("Winograd weight-gradient GEMMs, small maps (DLA level 4)", "gemm_tn_pf_kernel<4>", "36x[256x256]x[256x256] (DLA level 4)", fl4,
-            lambda: wino.gemm_batched_wgrad(V4, dM4)),
+            lambda: wino.gemm_batched_wgrad(V4, dM4), grid=147456),
         fam("direct conv 64x64 tiles", "conv_fwd_kernel<64, 64, 2, 2, 32, 1>", "3x3/s2 64->128 @128x128 (DLA level 3 entry)", 2.0 * B * 64 * 64 * 128 * 64 * 9,
             lambda: conv.conv2d_fwd(xs, ws, None, 2, 1), grid=131072),
         fam("direct dgrad 64x64 tiles", "conv_dgrad_kernel<64, 64, 2, 2, 32>", "3x3/s2 64->128 @128x128", 2.0 * B * 64 * 64 * 128 * 64 * 9,
