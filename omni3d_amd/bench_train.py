@@ -400,8 +400,8 @@ def dominant_kernel_roofline(iters=20):
                                                                         #  576 workgroups -> one averaged row)
         fam("FC forward (fc1-class)", "gemm_engine_kernel<0, 0, 128, 128>", "[2048x12544]x[1024x12544]^T box-head fc1", 2.0 * 2048 * 12544 * 1024,
             lambda: conv.linear_fwd(x1, w1, None), grid=65536),
-        fam("FC data gradient", "conv_dgrad_kernel<128, 128, 2, 2, 32>", "[2048x1024]x[1024x12544] box-head fc1", 2.0 * 2048 * 12544 * 1024,
-            lambda: conv.linear_dgrad(dy1, w1), grid=401408),
+        fam("FC data gradient (transpose of W + the engine's NT form)", "gemm_engine_kernel<0, 0, 128, 128>", "[2048x1024]x[12544x1024]^T box-head fc1 (incl. the 51 MB transpose)",
+            2.0 * 2048 * 12544 * 1024, lambda: conv.linear_dgrad(dy1, w1), grid=65536),
         fam("FC weight gradient", "conv_wgrad_kernel<128, 64, 2, 2, 32>", "[1024x2048]x[2048x12544] box-head fc1", 2.0 * 2048 * 12544 * 1024,
             lambda: conv.linear_wgrad(x1, dy1), grid=401408),
         fam("Winograd weight-gradient GEMMs, small maps", "gemm_tn_pf_kernel<4>", "36x[128x1024]x[1024x128] (DLA level 3)", fl3,
