@@ -2,7 +2,9 @@
 """The step loop of the reference's tools/train_net.py:do_train (:176-313) on the HIP path, written against the REFERENCE's
 import paths (omni3d_amd.install()) and fed with synthetic Omni3D-shaped batches instead of the data pipeline (out of scope,
 SURVEY.md 8b): model(data) -> sum(losses).backward() -> non-finite check -> optimizer.step() -> scheduler.step(), EventStorage
-scalars, PeriodicCheckpointerOnlyOne.
+scalars, PeriodicCheckpointerOnlyOne.  Nothing in this loop knows about graphs: after two iterations with the same batch shape
+`model(data)` switches to the staged hipGraph replay by itself (cubercnn/solver/autoreplay.py; OMNI_AUTO_REPLAY=0 keeps eager
+launches).
 
     python tools/train_synthetic.py --iters 60 [--config cubercnn_ResNet34_FPN.yaml] [--out /tmp/run]
 """
@@ -100,8 +102,11 @@ def main():
                       + "  ".join(f"{k.split('/')[-1]} {v:.3f}" for k, v in reduced.items() if k != "total_loss"), flush=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"done: {cfg.SOLVER.MAX_ITER} iterations, {cfg.SOLVER.MAX_ITER * args.batch / dt:.1f} images/s including host-side batch packing "
-          f"and logging (eager launches)")
+    auto = getattr(model, "_omni_auto", None)
+    mode = (f"{auto.replays} of them replayed as staged hipGraphs from inside model(data)" if auto is not None and auto.replays
+            else "eager launches" + (f" ({auto.failed})" if auto is not None and auto.failed else ""))
+    print(f"done: {cfg.SOLVER.MAX_ITER} iterations, {cfg.SOLVER.MAX_ITER * args.batch / dt:.1f} images/s including the capture, host-side "
+          f"batch packing and logging; {mode}")
 
 
 if __name__ == "__main__":
