@@ -514,7 +514,7 @@ __global__ void box3d_validity_kernel(const float* __restrict__ boxes, int N, fl
 
 // production launch: 32 lanes per pair over 96-triangle lists (7.4 KB of LDS per pair: 10 two-pair waves per CU instead of 6
 // with the full 160-triangle lists), marked pairs redone at full capacity by the retry pass
-constexpr int IOU_SUB = 32, IOU_CAP_SMALL = 96;
+constexpr int IOU_VARIANT = 1032;      // (set from tools/bench_iou3d.py: profiles/r03_iou3d_variants*.log)
 
 inline int iou_chunk(long long npairs) { return npairs >= 262144 ? 64 : npairs >= 131072 ? 32 : 16; }
 
@@ -530,9 +530,10 @@ inline int iou_grid(long long npairs) {
 template <int MODE>
 inline int iou_launch(int variant, const float* boxes1, const float* boxes2, const int* idx1, const int* idx2, const int* valid1,
                       long long np, int M, float* vol, float* iou, int* overflow, void* stream) {
-    if (variant == 0) variant = 1000 + IOU_SUB;
+    if (variant == 0) variant = IOU_VARIANT;
     const bool small = variant >= 1000;
-    const int sub = small ? variant - 1000 : variant;
+    const int cap_code = variant / 1000;                 // 0: full lists | 1: 96 | 2: 64 | 3: 48 triangles in the first pass
+    const int sub = variant % 1000;
     hipStream_t st = (hipStream_t)stream;
 #define OMNI_IOU(SUB_, CAP_, RETRY_)                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(iou_box3d_kernel<MODE, SUB_, CAP_, RETRY_>), dim3(iou_grid(np)), dim3(64), 0, st,       \
@@ -543,9 +544,12 @@ inline int iou_launch(int variant, const float* boxes1, const float* boxes2, con
         else if (sub == 16) OMNI_IOU(16, CAP, false);
         else return OMNI_ERR_ARG;
     } else {
-        if (sub == 64) OMNI_IOU(64, IOU_CAP_SMALL, true);
-        else if (sub == 32) OMNI_IOU(32, IOU_CAP_SMALL, true);
-        else if (sub == 16) OMNI_IOU(16, IOU_CAP_SMALL, true);
+        if (cap_code == 1 && sub == 64) OMNI_IOU(64, 96, true);
+        else if (cap_code == 1 && sub == 32) OMNI_IOU(32, 96, true);
+        else if (cap_code == 1 && sub == 16) OMNI_IOU(16, 96, true);
+        else if (cap_code == 2 && sub == 32) OMNI_IOU(32, 64, true);
+        else if (cap_code == 2 && sub == 64) OMNI_IOU(64, 64, true);
+        else if (cap_code == 3 && sub == 32) OMNI_IOU(32, 48, true);
         else return OMNI_ERR_ARG;
         const long long chunks = (np + 63) / 64;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(iou_box3d_retry_kernel<MODE>), dim3((unsigned)(chunks < 2048 ? chunks : 2048)), dim3(64), 0, st,
@@ -574,8 +578,8 @@ int omni_iou_box3d_pairs(const float* boxes1, const float* boxes2, const int* id
     return iou_launch<1>(0, boxes1, boxes2, idx1, idx2, valid1, npairs, 1, vol, iou, overflow, stream);
 }
 
-// lanes_per_pair in {64, 32, 16}: one launch with the full-capacity triangle lists; 1000 + lanes: first pass over 96-triangle
-// lists + retry pass (0 = the production choice, 1032).  A/B entry point of tools/bench_iou3d.py and of the parity tests, which
+// lanes_per_pair in {64, 32, 16}: one launch with the full-capacity triangle lists; 1000 / 2000 / 3000 + lanes: first pass over
+// 96- / 64- / 48-triangle lists + retry pass (0 = the production choice).  A/B entry point of tools/bench_iou3d.py and of the parity tests, which
 // run every variant against the oracle
 int omni_iou_box3d_pairs_algo(const float* boxes1, const float* boxes2, const int* idx1, const int* idx2, long long npairs,
                               const int* valid1, float* vol, float* iou, int* overflow, int lanes_per_pair, void* stream) {
