@@ -112,24 +112,29 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict_
     bn_reduce_body<MODE>(x, dy, y, mean_rstd, P, C, relu, acc);
 }
 
-// Sum the per-block partials of 16 channels (both quantities) in fp64: 16 column lanes x 16 row groups + LDS tree.
-// Returns (for threads t < 16, channel c0 + t) s0 = sum partial[b][c], s1 = sum partial[b][C + c].
-__device__ __forceinline__ void colsum16(const float* __restrict__ partial, int nblk, int C, int c0, double& s0, double& s1) {
+// Sum the per-block partials of FIN_C channels (both quantities) in fp64: FIN_C column lanes x (256 / FIN_C) row groups + LDS
+// reduction.  Returns (for threads t < FIN_C, channel c0 + t) s0 = sum partial[b][c], s1 = sum partial[b][C + c].
+// Round 3: FIN_C 16 -> 4.  A finalize launch is pure latency on the critical path (56 of them per training step, 0.45 ms): with
+// 16 channels per workgroup a 128-channel layer ran on 8 workgroups whose threads each walked nblk / 16 partial rows (up to 32
+// dependent trips); with 4 it runs on 32 workgroups and a thread walks nblk / 64 rows.
+constexpr int FIN_C = 4, FIN_RG = 256 / FIN_C;
+__device__ __forceinline__ void colsum_fin(const float* __restrict__ partial, int nblk, int C, int c0, double& s0, double& s1) {
     __shared__ double sm0[256], sm1[256];
-    const int t = threadIdx.x, cl = t & 15, rg = t >> 4;
+    const int t = threadIdx.x, cl = t % FIN_C, rg = t / FIN_C;
     const int c = c0 + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
         // 4 independent loads in flight per quantity: this loop is pure memory latency
         int blk = rg;
-        for (; blk + 48 < nblk; blk += 64) {
+        for (; blk + 3 * FIN_RG < nblk; blk += 4 * FIN_RG) {
             const float* q = partial + (long)blk * 2 * C + c;
-            const float a0 = q[0], a1 = q[(long)32 * C], a2 = q[(long)64 * C], a3 = q[(long)96 * C];
-            const float b0 = q[C], b1 = q[(long)33 * C], b2 = q[(long)65 * C], b3 = q[(long)97 * C];
+            const long st = (long)FIN_RG * 2 * C;
+            const float a0 = q[0], a1 = q[st], a2 = q[2 * st], a3 = q[3 * st];
+            const float b0 = q[C], b1 = q[st + C], b2 = q[2 * st + C], b3 = q[3 * st + C];
             a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
             b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
         }
-        for (; blk < nblk; blk += 16) {
+        for (; blk < nblk; blk += FIN_RG) {
             a += (double)partial[(long)blk * 2 * C + c];
             b += (double)partial[(long)blk * 2 * C + C + c];
         }
@@ -137,13 +142,16 @@ __device__ __forceinline__ void colsum16(const float* __restrict__ partial, int 
     sm0[t] = a;
     sm1[t] = b;
     __syncthreads();
-    s0 = 0.0;
-    s1 = 0.0;
-    if (t < 16)
-        for (int k = 0; k < 16; ++k) { s0 += sm0[k * 16 + t]; s1 += sm1[k * 16 + t]; }
+    // tree over the row groups (fixed order: deterministic)
+    for (int half = FIN_RG / 2; half >= 1; half >>= 1) {
+        if (rg < half) { sm0[t] += sm0[t + half * FIN_C]; sm1[t] += sm1[t + half * FIN_C]; }
+        __syncthreads();
+    }
+    s0 = sm0[t % FIN_C];
+    s1 = sm1[t % FIN_C];
 }
 
-// forward finalize (one workgroup per 16 channels): mean, biased var -> rstd; scale/shift for the apply pass;
+// forward finalize (one workgroup per FIN_C channels): mean, biased var -> rstd; scale/shift for the apply pass;
 // running stats (momentum m, unbiased variance) exactly like torch.nn.functional.batch_norm(training=True).
 __device__ __forceinline__ void bn_finalize_fwd_group(int grp, const float* __restrict__ partial, int nblk, int P, int C,
                                                       float eps, float momentum, const float* __restrict__ gamma,
@@ -151,9 +159,9 @@ __device__ __forceinline__ void bn_finalize_fwd_group(int grp, const float* __re
                                                       float* __restrict__ scale_shift, float* __restrict__ running_mean,
                                                       float* __restrict__ running_var) {
     double sx, sxx;
-    colsum16(partial, nblk, C, grp * 16, sx, sxx);
-    const int c = grp * 16 + threadIdx.x;
-    if (threadIdx.x >= 16 || c >= C) return;
+    colsum_fin(partial, nblk, C, grp * FIN_C, sx, sxx);
+    const int c = grp * FIN_C + threadIdx.x;
+    if (threadIdx.x >= FIN_C || c >= C) return;
     const double mean = sx / P;
     double var = sxx / P - mean * mean;
     if (var < 0) var = 0;
@@ -203,9 +211,9 @@ __device__ __forceinline__ void bn_finalize_bwd_group(int grp, const float* __re
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                       float* __restrict__ coef, int accumulate) {
     double db, dg;
-    colsum16(partial, nblk, C, grp * 16, db, dg);
-    const int c = grp * 16 + threadIdx.x;
-    if (threadIdx.x >= 16 || c >= C) return;
+    colsum_fin(partial, nblk, C, grp * FIN_C, db, dg);
+    const int c = grp * FIN_C + threadIdx.x;
+    if (threadIdx.x >= FIN_C || c >= C) return;
     dbeta[c] = accumulate ? dbeta[c] + (float)db : (float)db;
     dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
     coef[c] = gamma[c] * mean_rstd[C + c];
@@ -439,9 +447,9 @@ __global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__
 __global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                               float* __restrict__ out, int accumulate) {
     double s0, s1;
-    colsum16(partial, nblk, C, blockIdx.x * 16, s0, s1);
-    const int c = blockIdx.x * 16 + threadIdx.x;
-    if (threadIdx.x < 16 && c < C) out[c] = accumulate ? out[c] + (float)s0 : (float)s0;
+    colsum_fin(partial, nblk, C, blockIdx.x * FIN_C, s0, s1);
+    const int c = blockIdx.x * FIN_C + threadIdx.x;
+    if (threadIdx.x < FIN_C && c < C) out[c] = accumulate ? out[c] + (float)s0 : (float)s0;
 }
 
 inline int ew_grid(long total) {
@@ -474,7 +482,7 @@ int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const flo
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial));
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk, P, C, eps,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, (const float*)partial, nblk, P, C, eps,
                        momentum, gamma, beta, mean_rstd, scale_shift, running_mean, running_var);
     const long total4 = (long)P * (C >> 2);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, (const float*)scale_shift, residual, y,
@@ -489,7 +497,7 @@ int omni_bn_fwd_partials(const float* x, const float* partial, int nblk, const f
                          float eps, float momentum, int relu, void* stream) {
     if (P <= 0 || C <= 0 || (C & 3) || C > 4096 || nblk <= 0) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, st, partial, nblk, P, C, eps, momentum, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, partial, nblk, P, C, eps, momentum, gamma, beta,
                        mean_rstd, scale_shift, running_mean, running_var);
     const long total4 = (long)P * (C >> 2);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, (const float*)scale_shift, residual, y, total4, C, relu);
@@ -517,7 +525,7 @@ int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* ga
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<1>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean_rstd, P, C, relu,
                        reinterpret_cast<double*>(partial));
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk, P, C, gamma,
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, (const float*)partial, nblk, P, C, gamma,
                        mean_rstd, dgamma, dbeta, coef, accumulate_param_grads);
     const long total4 = (long)P * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, dy, y, mean_rstd,
@@ -630,7 +638,7 @@ int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, int acc
 #endif
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, dy, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial));
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, nblk, C, db,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, (const float*)partial, nblk, C, db,
                        accumulate);
     return omni_launch_status();
 }
