@@ -90,6 +90,8 @@ __device__ __forceinline__ omni_rsrc_t omni_make_rsrc(const void* p, unsigned by
 __device__ __forceinline__ void omni_dma16(omni_rsrc_t r, float* lds_wave_base, int voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, OMNI_LDSP(lds_wave_base), 16, voffset, soffset, 0, 0);
 }
+// one dword through a buffer resource: out-of-range offsets come back as 0 without a branch
+__device__ __forceinline__ unsigned omni_bufld1(omni_rsrc_t r, int voffset) { return __builtin_amdgcn_raw_buffer_load_b32(r, voffset, 0, 0); }
 #define OMNI_OOB ((int)0x80000000)            /* voffset that is out of range for every resource (tensors are < 2 GiB) */
 #define OMNI_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 __device__ __forceinline__ void omni_barrier() {          // s_barrier WITHOUT the vmcnt(0) drain __syncthreads() implies
@@ -105,5 +107,8 @@ __device__ __forceinline__ void omni_barrier_lds() {
 }
 // register budget hint: ask the compiler to fit n waves per SIMD (512 / n VGPRs)
 #define OMNI_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#define OMNI_OPAQUE_V(x) asm volatile("" : "+v"(x))                                  /* the optimiser forgets what it knows about a VGPR value */
+#define OMNI_OPAQUE_S(x) asm volatile("" : "+s"(x))                                  /* same for a wave-uniform (SGPR) value */
+#define OMNI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)                            /* nothing is scheduled across this point */
 #define OMNI_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)      /* 0x8 MFMA, 0x20 VMEM read, 0x100 DS read */
 #define OMNI_SETPRIO(n) __builtin_amdgcn_s_setprio(n)

@@ -36,6 +36,9 @@ struct GemmArgs {
     int splits;             // reduction splits; > 1 or accumulate: atomic epilogue
     int relu, accumulate;
     int tiles_m, tiles_n, items;
+    // balanced mode (BAL): every workgroup owns bal_r whole tiles, the remaining tiles (fewer than workgroups) are cut along the
+    // reduction into bal_ts parts of bal_sps slabs, one part per workgroup (bal_tail_items of them)
+    int bal_r, bal_ts, bal_sps, bal_tail_items;
 };
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return mfma_32x32x2(a, b, c); }
@@ -64,7 +67,11 @@ __device__ __forceinline__ void sched_pin() {
 //   NT (forward):         A KC (M x K),  B KC (N x K)
 //   NN (data gradient):   A KC (M x K),  B MC (K x N)
 //   TN (weight gradient): A MC (K x M),  B MC (K x N)
-template <int LA, int LB, int BM, int BN>
+// BAL: tile-quantisation-free work split for launches whose tile count is not a multiple of the workgroup count (fc1's weight
+//   gradient: 784 tiles of 128x128 on 256 workgroups = 3.06 rounds, i.e. 4 rounds at 77 % occupancy): r = tiles / workgroups whole
+//   tiles per workgroup, and the tiles % workgroups left over are cut along K so that together they give every workgroup one
+//   more, short item; those parts meet in C through the atomic epilogue.
+template <int LA, int LB, int BM, int BN, bool BAL>
 __global__ void __launch_bounds__(256) gemm_engine_kernel(GemmArgs p) {
     constexpr int BK = 32, STAGE = (BM + BN) * BK, WM = BM / 64, WN = BN / 64, PA = BM / 32, PB = BN / 32, NP = PA + PB;
     static_assert(NP % 4 == 0, "pieces are spread over the four k-chunks of a slab");
@@ -78,27 +85,58 @@ __global__ void __launch_bounds__(256) gemm_engine_kernel(GemmArgs p) {
     const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3, stride = ((int)gridDim.x + 7 - xcd) >> 3;
     const int end = min((xcd + 1) * per_xcd, p.items);
     const int first = xcd * per_xcd + local;
-    if (first >= end) return;
+    const int W8 = (int)gridDim.x >> 3;                                        // BAL: workgroups per XCD (grid is a multiple of 8)
+    const int tail_q = xcd * W8 + local;                                       // BAL: this workgroup's part of the cut tiles
+    if (BAL) {
+        if (p.bal_r == 0 && tail_q >= p.bal_tail_items) return;
+    } else if (first >= end) {
+        return;
+    }
     const int nk_total = (p.K + BK - 1) / BK;
     const int sps = (nk_total + p.splits - 1) / p.splits;                      // slabs per split
     const bool ktail = (p.K % BK) != 0 || LA == 1 || LB == 1;                  // MC rows are checked against K slab by slab
 
-    // ---- issue cursor: the item / slab the NEXT DMA pieces belong to
-    int i_item = first, i_kt = 0, i_nk = 0, i_k0 = 0;
+    // ---- issue cursor: the item / slab the NEXT DMA pieces belong to.  Items are numbered s = 0, 1, ... per workgroup:
+    //      item first + s * stride of the launch-wide list, or (BAL) its s-th whole tile and then its part of a cut tile
+    int i_item = BAL ? 0 : first, i_kt = 0, i_nk = 0, i_k0 = 0;
     omni_rsrc_t ra, rb;
     int voa[PA], vob[PB];
-    auto decode = [&](int item, int& b, int& tm, int& tn, int& split) {
-        int r = item;
+    // -> tile coordinates, first slab and slab count of an item; `lead`: the part that adds the bias; `cut`: shares its tile
+    auto decode = [&](int item, int& b, int& tm, int& tn, int& k0, int& nk, bool& lead, bool& cut) {
+        int r;
+        if (BAL) {
+            if (item < p.bal_r) {
+                r = (xcd * p.bal_r + item) * W8 + local;
+                k0 = 0; nk = nk_total; lead = true; cut = false;
+            } else {
+                r = p.bal_r * (int)gridDim.x + tail_q / p.bal_ts;
+                const int part = tail_q % p.bal_ts;
+                k0 = part * p.bal_sps; nk = min(p.bal_sps, nk_total - k0); lead = part == 0; cut = p.bal_ts > 1;
+            }
+        } else {
+            r = item;
+        }
         tn = r % p.tiles_n; r /= p.tiles_n;
         tm = r % p.tiles_m; r /= p.tiles_m;
         b = r % p.batch;
-        split = r / p.batch;
+        if (!BAL) {
+            const int split = r / p.batch;
+            k0 = split * sps; nk = min(sps, nk_total - k0); lead = split == 0; cut = p.splits > 1;
+        }
+    };
+    // is there an item after `item` for this workgroup, and which
+    auto next_item = [&](int item, int& nxt) -> bool {
+        if (BAL) {
+            nxt = item + 1;
+            return nxt < p.bal_r + (tail_q < p.bal_tail_items ? 1 : 0);
+        }
+        nxt = item + stride;
+        return nxt < end;
     };
     auto setup_issue = [&](int item) {
-        int b, tm, tn, split;
-        decode(item, b, tm, tn, split);
-        i_k0 = split * sps;
-        i_nk = min(sps, nk_total - i_k0);
+        int b, tm, tn;
+        bool lead, cut;
+        decode(item, b, tm, tn, i_k0, i_nk, lead, cut);
         i_kt = 0;
         const int m0 = tm * BM, n0 = tn * BN;
         ra = omni_make_rsrc(p.A + (long)b * p.sa, (unsigned)((LA == 0 ? (long)p.M * p.lda : (long)p.K * p.lda) * 4));
@@ -149,7 +187,8 @@ __global__ void __launch_bounds__(256) gemm_engine_kernel(GemmArgs p) {
     };
     auto advance_issue = [&]() {               // after the NP pieces of one slab
         if (++i_kt == i_nk) {
-            if (i_item + stride < end) { i_item += stride; setup_issue(i_item); }
+            int nxt;
+            if (next_item(i_item, nxt)) { i_item = nxt; setup_issue(i_item); }
             else i_live = false;
         }
     };
@@ -195,24 +234,25 @@ __global__ void __launch_bounds__(256) gemm_engine_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // ---- compute cursor
-    int c_item = first, c_kt = 0, c_nk;
+    int c_item = BAL ? 0 : first, c_kt = 0, c_nk;
     {
-        int b, tm, tn, split;
-        decode(c_item, b, tm, tn, split);
-        c_nk = min(sps, nk_total - split * sps);
+        int b, tm, tn, k0;
+        bool lead, cut;
+        decode(c_item, b, tm, tn, k0, c_nk, lead, cut);
     }
     auto epilogue = [&]() {
-        int b, tm, tn, split;
-        decode(c_item, b, tm, tn, split);
+        int b, tm, tn, k0, nk;
+        bool lead, cut;
+        decode(c_item, b, tm, tn, k0, nk, lead, cut);
         const int m0 = tm * BM, n0 = tn * BN;
         float* o = p.C + (long)b * p.sc;
-        const bool atomic = p.splits > 1 || p.accumulate;
+        const bool atomic = cut || p.accumulate;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int n = n0 + wn * (BN / 2) + j * 32 + l31;
-                const float bv = (p.bias != nullptr && n < p.N && split == 0) ? p.bias[n] : 0.f;
+                const float bv = (p.bias != nullptr && n < p.N && lead) ? p.bias[n] : 0.f;
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) {
                     const int m = m0 + wm * (BM / 2) + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
@@ -227,7 +267,7 @@ __global__ void __launch_bounds__(256) gemm_engine_kernel(GemmArgs p) {
     };
 
     // ---- prologue: two slabs in flight, first fragments in registers
-    setup_issue(first);
+    setup_issue(i_item);
 #pragma unroll
     for (int q = 0; q < NP; ++q) piece(st0, q);
     advance_issue();
@@ -262,12 +302,13 @@ __global__ void __launch_bounds__(256) gemm_engine_kernel(GemmArgs p) {
         advance_issue();
         if (++c_kt == c_nk) {                  // item finished: store, move the compute cursor
             epilogue();
-            if (c_item + stride < end) {
-                c_item += stride;
+            int nxt;
+            if (next_item(c_item, nxt)) {
+                c_item = nxt;
                 c_kt = 0;
-                int b, tm, tn, split;
-                decode(c_item, b, tm, tn, split);
-                c_nk = min(sps, nk_total - split * sps);
+                int b, tm, tn, k0;
+                bool lead, cut;
+                decode(c_item, b, tm, tn, k0, c_nk, lead, cut);
             } else {
                 done = true;
             }
@@ -309,16 +350,36 @@ int launch_engine(GemmArgs p, int workgroups, hipStream_t st) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const int nk_total = (p.K + 31) / 32;
+    const long tiles = (long)p.tiles_m * p.tiles_n * p.batch;
+    if (p.splits == -1) {                                                       // balanced: whole tiles + one cut part per workgroup
+        const long W = workgroups > 0 ? workgroups : 256;
+        if ((W & 7) || tiles <= 0 || tiles > 0x7fffffff) return tiles == 0 ? OMNI_OK : OMNI_ERR_ARG;
+        const long left = tiles % W;
+        if (left != 0) {
+            p.bal_r = (int)(tiles / W);
+            long ts = W / left;
+            if (ts > nk_total) ts = nk_total;
+            p.bal_sps = (int)((nk_total + ts - 1) / ts);
+            p.bal_ts = (nk_total + p.bal_sps - 1) / p.bal_sps;                  // no empty part
+            p.bal_tail_items = (int)left * p.bal_ts;
+            if (p.bal_ts > 1 && p.relu) return OMNI_ERR_ARG;                    // cut tiles meet through atomics: no ReLU on them
+            p.splits = 1;
+            p.items = (int)tiles;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_engine_kernel<LA, LB, BM, BN, true>), dim3((unsigned)W), dim3(256), 0, st, p);
+            return omni_launch_status();
+        }
+        p.splits = 1;                                                           // already an exact number of rounds
+    }
     if (p.splits < 1) p.splits = 1;
     if (p.splits > nk_total) p.splits = nk_total;
     const int sps = (nk_total + p.splits - 1) / p.splits;
     p.splits = (nk_total + sps - 1) / sps;                                      // no empty split
-    const long items = (long)p.tiles_m * p.tiles_n * p.batch * p.splits;
+    const long items = tiles * p.splits;
     if (items <= 0 || items > 0x7fffffff) return items == 0 ? OMNI_OK : OMNI_ERR_ARG;
     p.items = (int)items;
     long wg = workgroups > 0 ? workgroups : 256;                                // one workgroup per CU (96 / 144 KB of LDS)
     if (wg > items) wg = items;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_engine_kernel<LA, LB, BM, BN>), dim3((unsigned)wg), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_engine_kernel<LA, LB, BM, BN, false>), dim3((unsigned)wg), dim3(256), 0, st, p);
     return omni_launch_status();
 }
 
@@ -332,19 +393,22 @@ extern "C" {
 //   form 2 "TN": A (K x M, pitch lda), B (K x N, pitch ldb)            weight gradient (A = dy [pixels][K_out], B = x [pixels][C_in])
 // tile: 1 = 256x128, 2 = 128x128.  workgroups: persistent workgroups (0 = one per CU, never more than work items).
 // splits > 1 or accumulate != 0: fp32 atomics into C (the caller zeroes C when it is not accumulating); bias / ReLU are
-// applied only on the non-atomic path (bias also on split 0 of an atomic one).  All leading dimensions, M (MC operands), N
+// applied only on the non-atomic path (bias also on split 0 of an atomic one).
+// splits == -1: balanced.  With T tiles and W workgroups (W a multiple of 8), every workgroup computes T / W whole tiles and the
+// last T % W tiles (tile order: batch, then tile row, then tile column) are cut along the reduction into floor(W / (T % W)) parts
+// that are ADDED into C with atomics: the caller zeroes those tiles (or all of C) unless accumulating; no ReLU when tiles are cut.  All leading dimensions, M (MC operands), N
 // (MC operands) and K offsets in multiples of 4 floats; tensors < 2 GiB.
 int omni_gemm_engine(const float* A, const float* B, float* C, const float* bias, int form, int batch, int M, int N, int K,
                      int lda, int ldb, int ldc, long long stride_a, long long stride_b, long long stride_c, int splits, int relu,
                      int accumulate, int tile, int workgroups, void* stream) {
-    if (form < 0 || form > 2 || batch <= 0 || M < 0 || N < 0 || K <= 0 || (lda & 3) || (ldb & 3) || tile < 1 || tile > 2 || splits < 0 ||
+    if (form < 0 || form > 2 || batch <= 0 || M < 0 || N < 0 || K <= 0 || (lda & 3) || (ldb & 3) || tile < 1 || tile > 2 || splits < -1 ||
         workgroups < 0)
         return OMNI_ERR_ARG;
     if (form == 2 && ((M & 3) || (N & 3))) return OMNI_ERR_ARG;
     if (form == 1 && (N & 3)) return OMNI_ERR_ARG;
     if (form != 2 && (K & 3)) return OMNI_ERR_ARG;
     if (M == 0 || N == 0) return OMNI_OK;
-    GemmArgs p{A, B, C, bias, batch, M, N, K, lda, ldb, ldc, (long)stride_a, (long)stride_b, (long)stride_c, splits ? splits : 1, relu, accumulate, 0, 0, 0};
+    GemmArgs p{A, B, C, bias, batch, M, N, K, lda, ldb, ldc, (long)stride_a, (long)stride_b, (long)stride_c, splits ? splits : 1, relu, accumulate, 0, 0, 0, 0, 1, 0, 0};
     hipStream_t st = (hipStream_t)stream;
 #define OMNI_ENGINE(LA_, LB_)                                                                                         \
     return tile == 1 ? launch_engine<LA_, LB_, 256, 128>(p, workgroups, st) : launch_engine<LA_, LB_, 128, 128>(p, workgroups, st)

@@ -203,9 +203,33 @@ __global__ void rpn_gather_logits_kernel(Levels lv, int B, int A, float* __restr
     logits[i] = lv.y[l][((long)n * lv.hw[l] + loc) * RPN_C + k];
 }
 
-// ---- IoUness losses.  MODE 0: forward sums; MODE 1: gradients into dY (pre-zeroed) ---------------
+// ---- IoUness losses.  MODE 0: forward sums; MODE 1: gradients into dY (every element written: no pre-zeroing) ----
 // sums[0] = sum BCE(x, t)*t, sums[1] = sum |dpred - dgt|_1 * t, sums[2] = #pos, sums[3] = #neg (label 0),
 // sums[4] = sum sigmoid(x) over pos, sums[5] = sum sigmoid(x) over non-pos.
+// Forward: grid-stride over the anchors, per-wave float sums, one fp64 combine per workgroup in LDS and at most 6 atomics per
+// workgroup (round 3: one atomic set per WAVE -- 4092 waves hitting the same 6 doubles -- was 84 us of serialised atomics).
+constexpr int RPN_LOSS_MAX_BLOCKS = 512;
+__device__ __forceinline__ void rpn_loss_flush(const float (&s)[6], double* __restrict__ sums) {
+    __shared__ double part[4][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const float v = wave_sum(s[q]);
+        if (lane == 0) part[wave][q] = (double)v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const double v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (v != 0.0) atomicAdd(&sums[threadIdx.x], v);
+    }
+}
+// zero the channels of one location that no anchor owns (the padding of the fused head output), by the anchor-0 thread
+__device__ __forceinline__ void rpn_zero_pad(float* __restrict__ d, long base, int k) {
+    if (k == 0) {
+#pragma unroll
+        for (int c = RPN_A * 5; c < RPN_C; ++c) d[base + c] = 0.f;
+    }
+}
 template <int MODE>
 __global__ void __launch_bounds__(256) rpn_loss_kernel(Levels lv, Levels dlv, int B, int A,
                                                        const float* __restrict__ anchors,
@@ -214,9 +238,9 @@ __global__ void __launch_bounds__(256) rpn_loss_kernel(Levels lv, Levels dlv, in
                                                        const int* __restrict__ gt_off, double* __restrict__ sums,
                                                        const float* __restrict__ g_cls, const float* __restrict__ g_loc,
                                                        float inv_norm) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (i < (long)B * A) {
+    const long tot = (long)B * A;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
         const int n = (int)(i / A), a = (int)(i % A);
         int l, loc, k;
         anchor_to_level(lv, a, l, loc, k);
@@ -224,6 +248,7 @@ __global__ void __launch_bounds__(256) rpn_loss_kernel(Levels lv, Levels dlv, in
         const float x = lv.y[l][base + k];
         const int lab = labels[i];
         const float sg = 1.f / (1.f + expf(-x));
+        float dcls = 0.f, dloc[4] = {0.f, 0.f, 0.f, 0.f};
         if (lab == 1) {
             const float4 ab = ldbox(anchors + 4 * a);
             const float4 gb = ldbox(gt + 4 * (gt_off[n] + midx[i]));
@@ -238,28 +263,29 @@ __global__ void __launch_bounds__(256) rpn_loss_kernel(Levels lv, Levels dlv, in
                 float l1 = 0.f;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) l1 += fabsf(lv.y[l][base + RPN_A + k * 4 + d] - gd[d]);
-                s[0] = bce * t; s[1] = l1 * t; s[2] = 1.f; s[4] = sg;
+                s[0] += bce * t; s[1] += l1 * t; s[2] += 1.f; s[4] += sg;
             } else {
-                dlv.y[l][base + k] = (sg - t) * t * inv_norm * g_cls[0];
+                dcls = (sg - t) * t * inv_norm * g_cls[0];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const float df = lv.y[l][base + RPN_A + k * 4 + d] - gd[d];
                     const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-                    dlv.y[l][base + RPN_A + k * 4 + d] = sgn * t * inv_norm * g_loc[0];
+                    dloc[d] = sgn * t * inv_norm * g_loc[0];
                 }
             }
         } else if (MODE == 0) {
-            s[3] = lab == 0 ? 1.f : 0.f;
-            s[5] = sg;
+            s[3] += lab == 0 ? 1.f : 0.f;
+            s[5] += sg;
         }
-    }
-    if (MODE == 0) {
+        if (MODE == 1) {
+            float* d = dlv.y[l];
+            d[base + k] = dcls;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const float v = wave_sum(s[q]);
-            if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&sums[q], (double)v);
+            for (int q = 0; q < 4; ++q) d[base + RPN_A + k * 4 + q] = dloc[q];
+            rpn_zero_pad(d, base, k);
         }
     }
+    if (MODE == 0) rpn_loss_flush(s, sums);
 }
 
 // MODEL.RPN.OBJECTNESS_UNCERTAINTY 'none' (rpn.py:181-195, detectron2's RPN losses): objectness = BCE-with-logits against the 0 / 1
@@ -270,9 +296,9 @@ __global__ void __launch_bounds__(256) rpn_loss_plain_kernel(Levels lv, Levels d
                                                              const float* __restrict__ gt, const int* __restrict__ gt_off,
                                                              double* __restrict__ sums, const float* __restrict__ g_cls,
                                                              const float* __restrict__ g_loc, float inv_norm) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (i < (long)B * A) {
+    const long tot = (long)B * A;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
         const int n = (int)(i / A), a = (int)(i % A);
         int l, loc, k;
         anchor_to_level(lv, a, l, loc, k);
@@ -280,10 +306,11 @@ __global__ void __launch_bounds__(256) rpn_loss_plain_kernel(Levels lv, Levels d
         const float x = lv.y[l][base + k];
         const int lab = labels[i];
         const float sg = 1.f / (1.f + expf(-x));
+        float dcls = 0.f, dloc[4] = {0.f, 0.f, 0.f, 0.f};
         if (lab >= 0) {                                    // valid_mask = gt_labels >= 0
             const float t = lab == 1 ? 1.f : 0.f;
-            if (MODE == 0) s[0] = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-            else dlv.y[l][base + k] = (sg - t) * inv_norm * g_cls[0];
+            if (MODE == 0) s[0] += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+            else dcls = (sg - t) * inv_norm * g_cls[0];
         }
         if (lab == 1) {
             const float4 ab = ldbox(anchors + 4 * a);
@@ -295,21 +322,22 @@ __global__ void __launch_bounds__(256) rpn_loss_plain_kernel(Levels lv, Levels d
             for (int d = 0; d < 4; ++d) {
                 const float df = lv.y[l][base + RPN_A + k * 4 + d] - gd[d];
                 if (MODE == 0) s[1] += fabsf(df);
-                else dlv.y[l][base + RPN_A + k * 4 + d] = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * inv_norm * g_loc[0];
+                else dloc[d] = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * inv_norm * g_loc[0];
             }
-            if (MODE == 0) { s[2] = 1.f; s[4] = sg; }
+            if (MODE == 0) { s[2] += 1.f; s[4] += sg; }
         } else if (MODE == 0) {
-            s[3] = lab == 0 ? 1.f : 0.f;
-            s[5] = sg;
+            s[3] += lab == 0 ? 1.f : 0.f;
+            s[5] += sg;
         }
-    }
-    if (MODE == 0) {
+        if (MODE == 1) {
+            float* d = dlv.y[l];
+            d[base + k] = dcls;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const float v = wave_sum(s[q]);
-            if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&sums[q], (double)v);
+            for (int q = 0; q < 4; ++q) d[base + RPN_A + k * 4 + q] = dloc[q];
+            rpn_zero_pad(d, base, k);
         }
     }
+    if (MODE == 0) rpn_loss_flush(s, sums);
 }
 
 // ---- decode the selected anchors: Box2BoxTransform.apply_deltas + clip + validity -----------------
@@ -486,6 +514,11 @@ Levels make_levels(const void* const* ptrs, const int* hw, int nlev) {
 
 }  // namespace
 
+static inline long rpn_loss_blocks(long tot) {
+    const long b = (tot + 255) / 256;
+    return b < RPN_LOSS_MAX_BLOCKS ? b : RPN_LOSS_MAX_BLOCKS;
+}
+
 extern "C" {
 
 // mode 0: IoU (detectron2 pairwise_iou), mode 1: IoA = inter / area(boxes2).  out (N, M).
@@ -557,14 +590,14 @@ int omni_rpn_loss_fwd(const void* const* level_ptrs, const int* level_hw, int nl
     omni_memset_async(sums, 0, sizeof(double) * 6, st);
     const long tot = (long)B * A;
     if (tot == 0) return OMNI_OK;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_kernel<0>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lv, lv,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_kernel<0>), dim3((unsigned)rpn_loss_blocks(tot)), dim3(256), 0, st, lv, lv,
                        B, A, anchors, labels, matched_idx, gt, gt_off, sums, (const float*)nullptr, (const float*)nullptr,
                        0.f);
     return omni_launch_status();
 }
 
 // grads of (g_cls * cls_sum + g_loc * loc_sum) * inv_norm wrt the level tensors, written into
-// dlevel_ptrs (same shapes; zeroed here).  g_cls / g_loc are device scalars.
+// dlevel_ptrs (same shapes; every element is written).  g_cls / g_loc are device scalars.
 int omni_rpn_loss_bwd(const void* const* level_ptrs, const void* const* dlevel_ptrs, const int* level_hw, int nlev, int B,
                       const float* anchors, const signed char* labels, const int* matched_idx, const float* gt,
                       const int* gt_off, const float* g_cls, const float* g_loc, float inv_norm, void* stream) {
@@ -573,9 +606,7 @@ int omni_rpn_loss_bwd(const void* const* level_ptrs, const void* const* dlevel_p
     Levels dlv = make_levels(dlevel_ptrs, level_hw, nlev);
     const int A = lv.a_off[nlev];
     hipStream_t st = (hipStream_t)stream;
-    for (int l = 0; l < nlev; ++l)
-        omni_memset_async(dlv.y[l], 0, sizeof(float) * (size_t)B * level_hw[l] * RPN_C, st);
-    const long tot = (long)B * A;
+    const long tot = (long)B * A;                   // one thread per anchor; together they write every element of the level tensors
     if (tot == 0) return OMNI_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_kernel<1>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lv, dlv,
                        B, A, anchors, labels, matched_idx, gt, gt_off, (double*)nullptr, g_cls, g_loc, inv_norm);
@@ -593,7 +624,7 @@ int omni_rpn_loss_plain_fwd(const void* const* level_ptrs, const int* level_hw, 
     omni_memset_async(sums, 0, sizeof(double) * 6, st);
     const long tot = (long)B * A;
     if (tot == 0) return OMNI_OK;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_plain_kernel<0>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lv, lv,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_plain_kernel<0>), dim3((unsigned)rpn_loss_blocks(tot)), dim3(256), 0, st, lv, lv,
                        B, A, anchors, labels, matched_idx, gt, gt_off, sums, (const float*)nullptr, (const float*)nullptr, 0.f);
     return omni_launch_status();
 }
@@ -606,9 +637,7 @@ int omni_rpn_loss_plain_bwd(const void* const* level_ptrs, const void* const* dl
     Levels dlv = make_levels(dlevel_ptrs, level_hw, nlev);
     const int A = lv.a_off[nlev];
     hipStream_t st = (hipStream_t)stream;
-    for (int l = 0; l < nlev; ++l)
-        omni_memset_async(dlv.y[l], 0, sizeof(float) * (size_t)B * level_hw[l] * RPN_C, st);
-    const long tot = (long)B * A;
+    const long tot = (long)B * A;                   // one thread per anchor; together they write every element of the level tensors
     if (tot == 0) return OMNI_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_plain_kernel<1>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lv, dlv,
                        B, A, anchors, labels, matched_idx, gt, gt_off, (double*)nullptr, g_cls, g_loc, inv_norm);

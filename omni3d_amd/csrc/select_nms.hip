@@ -9,7 +9,10 @@
 // Top-k: one 1024-thread workgroup per row.  Keys become order-preserving 64-bit integers
 // (float bits, then ~index so that equal scores resolve to the LOWER index = a stable descending
 // sort); an 8-pass MSB-first radix select finds the k-th largest key exactly, survivors are
-// compacted into LDS and bitonic-sorted there.  k <= 8192.
+// compacted into LDS and bitonic-sorted there.  k <= 8192.  Rows of up to 65536 elements (every row of the training step:
+// 49152 anchors of the finest level, 65472 sampling keys per image) are read from memory ONCE: each thread keeps the score bits
+// of its <= 64 elements in registers and the radix passes and the compaction run on those (round 3; the passes used to re-read
+// the row, up to 8 x 64 dependent L2 round trips per thread -- 132 / 118 / 48 us for the three launches of a step).
 //
 // NMS: boxes arrive sorted by descending score.  A 64x64-bit suppression matrix tile per
 // workgroup (strict IoU > thr, areas (x2-x1)*(y2-y1), no +1), then one wave per problem walks the
@@ -22,12 +25,16 @@ namespace {
 constexpr int TOPK_THREADS = 1024;
 constexpr int TOPK_MAXK = 8192;      // 64 KB of LDS keys; the batched-inference candidate sort uses the full size
 
-__device__ __forceinline__ unsigned long long make_key(float f, int idx) {
+__device__ __forceinline__ unsigned score_bits(float f) {
     unsigned u = __float_as_uint(f);
     if (f != f) u = 0u;  // NaN sorts last
     else u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return u;
+}
+__device__ __forceinline__ unsigned long long key_of_bits(unsigned u, int idx) {
     return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
 }
+__device__ __forceinline__ unsigned long long make_key(float f, int idx) { return key_of_bits(score_bits(f), idx); }
 __device__ __forceinline__ float key_value(unsigned long long k) {
     unsigned u = (unsigned)(k >> 32);
     u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
@@ -43,6 +50,9 @@ struct SegP {
 };
 
 // keys: (rows, n) with row pitch `pitch` and element stride `estride` (floats).
+// NPT > 0: every segment has at most NPT * 1024 elements and a thread caches its NPT score words in registers; 0: streamed.
+constexpr int TOPK_NPT = 64;
+template <int NPT>
 __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __restrict__ keys, SegP seg, long pitch,
                                                                  int estride, int k, float* __restrict__ out_val,
                                                                  int* __restrict__ out_idx) {
@@ -59,6 +69,37 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __
     while (kpad < kk) kpad <<= 1;
     if (kpad < 2) kpad = 2;
 
+    // element j of this thread is i = j * 1024 + t (the loops below have the same, workgroup-uniform, trip count for every thread:
+    // the wave-level aggregation uses ballots / shuffles)
+    unsigned ku[NPT > 0 ? NPT : 1];
+    if (NPT > 0) {
+        // all loads issued back to back through a buffer resource sized to the row (elements past n come back as zeros and are
+        // never looked at); a guarded global load is a branch + a full wait per element, 64 serial round trips
+        const omni_rsrc_t rr = omni_make_rsrc(row, n > 0 ? (unsigned)(((long)(n - 1) * estride + 1) * 4) : 0u);
+        int tt = t;
+        OMNI_OPAQUE_V(tt);                     // (a private copy of t per loop: see the note in the pass loop)
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int i = j * TOPK_THREADS + tt;
+            ku[j] = score_bits(__uint_as_float(omni_bufld1(rr, i < n ? i * estride * 4 : OMNI_OOB)));
+        }
+    }
+    auto count_digit = [&](bool todo, unsigned digit) {
+        // Scores cluster (the sign/exponent byte of RPN logits takes 2-3 values), so plain LDS atomics would
+        // serialise tens of thousands of adds on one bin: each wave first folds its lanes that share the
+        // leader's digit into ONE add (4 rounds), the rest fall back to per-lane atomics.
+#pragma unroll
+        for (int round = 0; round < 4; ++round) {
+            const unsigned long long pending = __ballot(todo);
+            if (pending == 0ull) break;
+            const int leader = __ffsll((long long)pending) - 1;
+            const unsigned d = (unsigned)__shfl((int)digit, leader, 64);
+            const unsigned long long same = __ballot(todo && digit == d);
+            if ((t & 63) == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
+            if (todo && digit == d) todo = false;
+        }
+        if (todo) atomicAdd(&hist[digit], 1u);
+    };
     unsigned long long thr = 0ull;  // keys >= thr are selected
     if (kk < n) {
         if (t == 0) { s_prefix = 0ull; s_need = kk; }
@@ -68,30 +109,40 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __
             __syncthreads();
             const unsigned long long prefix = s_prefix;
             const int shift = pass * 8;
-            // uniform trip count: the wave-level aggregation below uses ballots / shuffles
-            for (int base = 0; base < n; base += TOPK_THREADS) {
-                const int i = base + t;
-                bool todo = false;
-                unsigned digit = 0u;
-                if (i < n) {
-                    const unsigned long long key = make_key(row[(long)i * estride], i);
-                    todo = (pass == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-                    digit = (unsigned)(key >> shift) & 255u;
-                }
-                // Scores cluster (the sign/exponent byte of RPN logits takes 2-3 values), so plain LDS atomics would
-                // serialise tens of thousands of adds on one bin: each wave first folds its lanes that share the
-                // leader's digit into ONE add (4 rounds), the rest fall back to per-lane atomics.
+            if (NPT > 0) {
+                // 32-bit arithmetic on the cached score word / the index word (a 64-bit key per element would double the
+                // registers), and the element index and the trip count are re-derived from opaque copies in every pass:
+                // otherwise the 64 index words, range predicates and loop-exit conditions are hoisted out of the pass loop
+                // as loop invariants and spill.
+                int tt = t, nn = n;
+                OMNI_OPAQUE_V(tt);
+                OMNI_OPAQUE_S(nn);
+                const unsigned phi = (unsigned)(prefix >> 32), plo = (unsigned)prefix;
+                const bool hi = pass >= 4;
+                const int sh = hi ? shift - 32 : shift;                    // shift inside the word this pass looks at
 #pragma unroll
-                for (int round = 0; round < 4; ++round) {
-                    const unsigned long long pending = __ballot(todo);
-                    if (pending == 0ull) break;
-                    const int leader = __ffsll((long long)pending) - 1;
-                    const unsigned d = (unsigned)__shfl((int)digit, leader, 64);
-                    const unsigned long long same = __ballot(todo && digit == d);
-                    if ((t & 63) == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
-                    if (todo && digit == d) todo = false;
+                for (int j = 0; j < NPT; ++j) {
+                    if (j * TOPK_THREADS >= nn) break;
+                    const int i = j * TOPK_THREADS + tt;
+                    const unsigned w = hi ? ku[j] : (0xFFFFFFFFu - (unsigned)i), pw = hi ? phi : plo;
+                    // candidates: all bytes above this pass's byte equal the prefix
+                    bool todo = i < nn && (hi || ku[j] == phi);
+                    if (sh < 24) todo = todo && ((w >> (sh + 8)) == (pw >> (sh + 8)));
+                    const unsigned digit = (w >> sh) & 255u;
+                    count_digit(todo, digit);
                 }
-                if (todo) atomicAdd(&hist[digit], 1u);
+            } else {
+                for (int base = 0; base < n; base += TOPK_THREADS) {
+                    const int i = base + t;
+                    bool todo = false;
+                    unsigned digit = 0u;
+                    if (i < n) {
+                        const unsigned long long key = make_key(row[(long)i * estride], i);
+                        todo = (pass == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                        digit = (unsigned)(key >> shift) & 255u;
+                    }
+                    count_digit(todo, digit);
+                }
             }
             __syncthreads();
             if (t == 0) {
@@ -117,11 +168,26 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __
     if (t == 0) s_count = 0;
     for (int i = t; i < kpad; i += TOPK_THREADS) sel[i] = 0ull;
     __syncthreads();
-    for (int i = t; i < n; i += TOPK_THREADS) {
-        const unsigned long long key = make_key(row[(long)i * estride], i);
-        if (key >= thr) {
-            const int slot = atomicAdd(&s_count, 1);
-            if (slot < TOPK_MAXK) sel[slot] = key;
+    if (NPT > 0) {
+        int tt = t;
+        OMNI_OPAQUE_V(tt);
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            if (j * TOPK_THREADS >= n) break;
+            const int i = j * TOPK_THREADS + tt;
+            const unsigned long long key = key_of_bits(ku[j], i);
+            if (i < n && key >= thr) {
+                const int slot = atomicAdd(&s_count, 1);
+                if (slot < TOPK_MAXK) sel[slot] = key;
+            }
+        }
+    } else {
+        for (int i = t; i < n; i += TOPK_THREADS) {
+            const unsigned long long key = make_key(row[(long)i * estride], i);
+            if (key >= thr) {
+                const int slot = atomicAdd(&s_count, 1);
+                if (slot < TOPK_MAXK) sel[slot] = key;
+            }
         }
     }
     __syncthreads();
@@ -197,21 +263,41 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
     __shared__ unsigned long long s_removed[MAXW];
     __shared__ unsigned long long s_part[16][MAXW];
     if (tid < MAXW) s_removed[tid] = 0ull;
+    for (int i = n + tid; i < nmax; i += 1024) keep[(long)q * nmax + i] = 0;      // boxes beyond the count are never kept
     __syncthreads();
     const int nchunks = (n + 63) / 64;
+    // Round 3: the mask rows of a chunk are fetched BEFORE its greedy resolution decides which of them are needed (all 64 rows, 4 per
+    // wave, selected by the `alive` bits afterwards): the loads of chunk c+1 fly under the LDS combine of chunk c and the serial
+    // resolution of chunk c+1 instead of sitting between two barriers (32 chunks x ~2 us of exposed latency per 2000-box problem).
+    // Only entries the mask kernel wrote are ever selected (row < n, word > chunk, word * 64 < n), so the scratch needs no zeroing.
+    unsigned long long rw0[4], rw1[4], diag = 0ull;
+    int okv = 0;
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = c * 64 + wave * 4 + rr;
+            const long rowbase = ((long)q * nmax + row) * words;
+            const int w0 = lane, w1 = 64 + lane;
+            rw0[rr] = (row < n && w0 > c && w0 < words && w0 * 64 < n) ? mask[rowbase + w0] : 0ull;
+            rw1[rr] = (row < n && w1 > c && w1 < words && w1 * 64 < n) ? mask[rowbase + w1] : 0ull;
+        }
+        if (wave == 0) {
+            const int i = c * 64 + lane;
+            diag = i < n ? mask[((long)q * nmax + i) * words + c] : 0ull;
+            okv = (i < n && (valid == nullptr || valid[(long)q * nmax + i] != 0)) ? 1 : 0;
+        }
+    };
+    if (nchunks > 0) fetch(0);
     for (int c = 0; c < nchunks; ++c) {
         if (wave == 0) {
             const int i = c * 64 + lane;
-            const bool in = i < n;
             // start state of this chunk: not removed by earlier keeps, and a valid box
-            const bool ok = in && (valid == nullptr || valid[(long)q * nmax + i] != 0);
-            unsigned long long alive = __ballot(ok) & ~s_removed[c];
-            const unsigned long long diag = in ? mask[((long)q * nmax + i) * words + c] : 0ull;
+            unsigned long long alive = __ballot(okv != 0) & ~s_removed[c];
             for (int r = 0; r < 64; ++r) {
                 const unsigned long long d = __shfl(diag, r, 64);
                 if ((alive >> r) & 1ull) alive &= ~d;
             }
-            if (in) keep[(long)q * nmax + i] = (int)((alive >> lane) & 1ull);
+            if (i < n) keep[(long)q * nmax + i] = (int)((alive >> lane) & 1ull);
             if (lane == 0) s_alive = alive;
         }
         __syncthreads();
@@ -219,16 +305,11 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
         unsigned long long part0 = 0ull, part1 = 0ull;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int r = wave * 4 + rr;
-            if ((alive >> r) & 1ull) {
-                const long rowbase = ((long)q * nmax + c * 64 + r) * words;
-                const int w0 = lane, w1 = 64 + lane;
-                if (w0 > c && w0 < words && w0 * 64 < n) part0 |= mask[rowbase + w0];
-                if (w1 > c && w1 < words && w1 * 64 < n) part1 |= mask[rowbase + w1];
-            }
+            if ((alive >> (wave * 4 + rr)) & 1ull) { part0 |= rw0[rr]; part1 |= rw1[rr]; }
         }
         s_part[wave][lane] = part0;
         s_part[wave][64 + lane] = part1;
+        if (c + 1 < nchunks) fetch(c + 1);
         __syncthreads();
         if (tid < MAXW) {
             unsigned long long v = s_removed[tid];
@@ -238,6 +319,16 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
         }
         __syncthreads();
     }
+}
+
+inline void launch_topk(int blocks, int nmax, const float* keys, const SegP& seg, long pitch, int estride, int k, float* out_val,
+                        int* out_idx, hipStream_t st) {
+    if (nmax <= TOPK_NPT * TOPK_THREADS)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(topk_rows_kernel<TOPK_NPT>), dim3(blocks), dim3(TOPK_THREADS), 0, st, keys, seg, pitch, estride, k,
+                           out_val, out_idx);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(topk_rows_kernel<0>), dim3(blocks), dim3(TOPK_THREADS), 0, st, keys, seg, pitch, estride, k,
+                           out_val, out_idx);
 }
 
 }  // namespace
@@ -253,8 +344,7 @@ int omni_topk_rows(const float* keys, int rows, int n, long long pitch, int estr
     SegP seg;
     seg.S = 1;
     for (int i = 0; i < TOPK_MAXSEG; ++i) { seg.off[i] = 0; seg.n[i] = n; }
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TOPK_THREADS), 0, (hipStream_t)stream, keys, seg, (long)pitch,
-                       estride, k, out_val, out_idx);
+    launch_topk(rows, n, keys, seg, (long)pitch, estride, k, out_val, out_idx, (hipStream_t)stream);
     return omni_launch_status();
 }
 
@@ -272,22 +362,22 @@ int omni_topk_segments(const float* keys, int rows, long long pitch, int estride
         seg.n[i] = i < nseg ? seg_n[i] : 0;
         if (seg.off[i] < 0 || seg.n[i] < 0) return OMNI_ERR_ARG;
     }
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows * nseg), dim3(TOPK_THREADS), 0, (hipStream_t)stream, keys, seg, (long)pitch,
-                       estride, k, out_val, out_idx);
+    int nmax = 0;
+    for (int i = 0; i < nseg; ++i) nmax = seg.n[i] > nmax ? seg.n[i] : nmax;
+    launch_topk(rows * nseg, nmax, keys, seg, (long)pitch, estride, k, out_val, out_idx, (hipStream_t)stream);
     return omni_launch_status();
 }
 
 // Greedy NMS for Q independent problems of up to nmax score-sorted boxes each ((Q, nmax, 4) XYXY).
 // counts [nullable] (Q) active boxes per problem; valid [nullable] (Q, nmax) 0 = box takes no part.
-// mask_ws: Q * nmax * ceil(nmax/64) 64-bit words of scratch.  keep (Q, nmax) int32 out (0/1).
+// mask_ws: Q * nmax * ceil(nmax/64) 64-bit words of scratch (need not be zeroed: only entries the mask kernel writes are read).
+// keep (Q, nmax) int32 out (0/1), every element written.
 int omni_nms_sorted(const float* boxes, const int* counts, const int* valid, int Q, int nmax, float iou_thr,
                     unsigned long long* mask_ws, int* keep, void* stream) {
     if (Q < 0 || nmax < 0 || nmax > 8192) return OMNI_ERR_ARG;
     if (Q == 0 || nmax == 0) return OMNI_OK;
     const int words = (nmax + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-    omni_memset_async(mask_ws, 0, sizeof(unsigned long long) * (size_t)Q * nmax * words, st);
-    omni_memset_async(keep, 0, sizeof(int) * (size_t)Q * nmax, st);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, Q), dim3(64), 0, st, boxes, counts, nmax, words, iou_thr,
                        mask_ws);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(Q), dim3(1024), 0, st, (const unsigned long long*)mask_ws, counts, valid, nmax,

@@ -145,13 +145,19 @@ class Tree(nn.Module):
         self.downsample = nn.MaxPool2d(stride, stride=stride) if stride > 1 else None
         self.project = Project(in_channels, out_channels) if in_channels != out_channels else None
 
-    def forward(self, x, residual=None, children=None):
+    def forward(self, x, residual=None, children=None, bottom=None):
         children = [] if children is None else children
-        bottom = HF.max_pool2(x) if self.downsample is not None else x
+        if bottom is None:      # (a nested first subtree pools the same x with the same stride: the outer level passes its result)
+            bottom = HF.max_pool2(x) if self.downsample is not None else x
         residual = self.project(bottom) if self.project is not None else bottom
         if self.level_root:
             children.append(bottom)
-        x1 = self.tree1(x, residual)
+        if self.levels == 1:
+            x1 = self.tree1(x, residual)
+        else:
+            t1 = self.tree1
+            shared = bottom if (t1.downsample is None) == (self.downsample is None) else None
+            x1 = t1(x, residual, bottom=shared)
         if self.levels == 1:
             x2 = self.tree2(x1)
             return self.root(x2, x1, *children)

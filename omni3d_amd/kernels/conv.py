@@ -140,6 +140,8 @@ def linear_fwd(x, w, bias=None, relu=False):
 
 
 _DGRAD_NT = os.environ.get("OMNI_FC_DGRAD_NT", "1") != "0"
+_FC_BALANCED = os.environ.get("OMNI_FC_BALANCED", "1") != "0"
+_FC_WGRAD_ENGINE_MIN_ROWS = int(os.environ.get("OMNI_FC_WGRAD_ENGINE_MIN_ROWS", "1024"))
 
 
 def linear_dgrad(dy, w):
@@ -150,7 +152,7 @@ def linear_dgrad(dy, w):
         # fc1-class data gradient dX = dY W as the NT product dY (W^T)^T on the LDS-DMA engine: one pass over W to transpose it
         # (51 MB for fc1) buys the engine's NT main loop (0.78 of the fp32-MFMA peak against 0.59 for the tile kernel's NN form)
         from . import gemm as _gemm
-        return _gemm.gemm(dy, _gemm.transpose2d(w), _gemm.NT, tile=2)
+        return _gemm.gemm(dy, _gemm.transpose2d(w), _gemm.NT, tile=2, splits=_gemm.BALANCED if _FC_BALANCED else 1)
     dx = torch.empty((M, C), dtype=torch.float32, device=dy.device)
     L.call("omni_conv2d_dgrad", _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), M, 1, 1, C, K, 1, 1, 1, 0, K, C, 0,
            _lib.stream_of(dy))
@@ -163,6 +165,12 @@ def linear_wgrad(x, dy, accum_into=None):
     L = _lib.check_device(x, dy)
     if accum_into is not None:
         assert accum_into.is_contiguous() and accum_into.shape == (K, C)
+        if _FC_BALANCED and M >= _FC_WGRAD_ENGINE_MIN_ROWS and C >= 4096 and K >= 512 and (K % 4) == 0 and (C % 4) == 0:
+            # fc1-class weight gradient dW += dY^T X on the LDS-DMA engine's TN form with the balanced work split: 784 tiles of
+            # 128 x 128 are 3.06 rounds of 256 workgroups -- the plain launch pays 4 (csrc/gemm_engine.hip, BAL)
+            from . import gemm as _gemm
+            _gemm.gemm(dy, x, _gemm.TN, out=accum_into, accumulate=True, tile=2, splits=_gemm.BALANCED)
+            return None
         L.call("omni_conv2d_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(accum_into), M, 1, 1, C, K, 1, 1, 1, 0, C, K, 1,
                _lib.stream_of(x))
         return None

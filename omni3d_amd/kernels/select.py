@@ -42,14 +42,18 @@ def topk_segments(keys, seg_off, seg_n, k):
     return vals, idx
 
 
-def nms_sorted(boxes, iou_thr, counts=None, valid=None):
-    """boxes (Q, nmax, 4) sorted by descending score -> keep (Q, nmax) int32."""
+def nms_sorted(boxes, iou_thr, counts=None, valid=None, _poison=False):
+    """boxes (Q, nmax, 4) sorted by descending score -> keep (Q, nmax) int32.  (_poison: tests fill the scratch and the output
+    with garbage first -- the kernels must not depend on their previous contents.)"""
     boxes = boxes.contiguous()
     Q, nmax, _ = boxes.shape
     L = _lib.check_device(boxes, counts, valid)
     words = (nmax + 63) // 64
     ws = torch.empty(max(Q * nmax * words, 1), dtype=torch.int64, device=boxes.device)
     keep = torch.empty((Q, nmax), dtype=torch.int32, device=boxes.device)
+    if _poison:
+        ws.fill_(-1)
+        keep.fill_(7)
     L.call("omni_nms_sorted", _lib.ptr(boxes), _lib.ptr(counts), _lib.ptr(valid), Q, nmax, float(iou_thr), _lib.ptr(ws),
            _lib.ptr(keep), _lib.stream_of(boxes))
     return keep

@@ -232,10 +232,18 @@ static inline void omni_dma16(omni_rsrc_t r, float* lds_wave_base, int voffset, 
     else
         memset(dst, 0, 16);
 }
+static inline unsigned omni_bufld1(omni_rsrc_t r, int voffset) {
+    unsigned v = 0u;
+    if ((unsigned long long)(unsigned)voffset + 4ull <= (unsigned long long)r.bytes) memcpy(&v, r.base + (unsigned)voffset, 4);
+    return v;
+}
 #define OMNI_OOB ((int)0x80000000)
 #define OMNI_WAIT_VMCNT(n) do { } while (0)
 static inline void omni_barrier() { hipemu::block_sync(); }
 static inline void omni_barrier_lds() { hipemu::block_sync(); }
+#define OMNI_OPAQUE_V(x) do { } while (0)
+#define OMNI_OPAQUE_S(x) do { } while (0)
+#define OMNI_SCHED_FENCE() do { } while (0)
 #define OMNI_SCHED_GROUP(mask, n) do { } while (0)
 #define OMNI_SETPRIO(n) do { } while (0)
 #define OMNI_WAVES_PER_EU(n)

@@ -95,7 +95,23 @@ def _run_transposed_dgrad(dev, M, K, C):
     dy = torch.randn(M, K, generator=g).to(dev)
     wt = G.transpose2d(w)
     assert wt.shape == (C, K) and torch.equal(wt.cpu(), w.cpu().t().contiguous())
-    dx = G.gemm(dy, wt, G.NT, tile=2)
+    ref = dy.cpu().double() @ w.cpu().double()
+    for splits in (1, G.BALANCED):             # plain launch; whole tiles + parts of the left-over tiles (cut tiles pre-zeroed)
+        dx = G.gemm(dy, wt, G.NT, tile=2, splits=splits, workgroups=8 if dev == "cpu" else 0)
+        assert (dx.cpu().double() - ref).abs().max() <= 2e-6 * float((dy.cpu().abs() @ w.cpu().abs()).max()), splits
+
+
+def _run_fc1_class_gradients(dev, M=1024, C=4096, K=512):
+    """shapes that take the engine routes of conv.linear_dgrad / conv.linear_wgrad (accumulating form of the training step)"""
+    from omni3d_amd.kernels import conv
+    g = torch.Generator().manual_seed(3)
+    x, w, dy = torch.randn(M, C, generator=g).to(dev), (torch.randn(K, C, generator=g) * 0.05).to(dev), torch.randn(M, K, generator=g).to(dev)
+    base = torch.randn(K, C, generator=g)
+    acc = base.clone().to(dev)
+    assert conv.linear_wgrad(x, dy, accum_into=acc) is None
+    ref = base.double() + dy.cpu().double().t() @ x.cpu().double()
+    assert (acc.cpu().double() - ref).abs().max() <= 2e-6 * float((dy.cpu().abs().t() @ x.cpu().abs()).max())
+    dx = conv.linear_dgrad(dy, w)
     ref = dy.cpu().double() @ w.cpu().double()
     assert (dx.cpu().double() - ref).abs().max() <= 2e-6 * float((dy.cpu().abs() @ w.cpu().abs()).max())
 
@@ -103,6 +119,7 @@ def _run_transposed_dgrad(dev, M, K, C):
 def test_linear_emulated(emu_lib):
     _run_linear("cpu", 70, 36, 20)
     _run_transposed_dgrad("cpu", 70, 96, 200)
+    _run_transposed_dgrad("cpu", 300, 64, 520)      # 3 x 5 = 15 tiles on 8 workgroups: one whole tile each, 7 left over
 
 
 def test_conv_rejects_unaligned_channels(emu_lib):
@@ -144,6 +161,8 @@ def test_linear_gpu(hip_lib):
     _run_linear("cuda", 512, 12544, 1024)     # cube fc1 (data gradient: transposed weights + the engine's NT form)
     _run_linear("cuda", 2048, 12544, 1024)    # box fc1
     _run_transposed_dgrad("cuda", 130, 1000, 4100)
+    _run_fc1_class_gradients("cuda")                      # 8 x 32 = 256 tiles (dgrad), 4 x 32 = 128 tiles (wgrad): cut in 2
+    _run_fc1_class_gradients("cuda", 2048, 12544, 1024)   # box fc1: 784 wgrad tiles = 3 whole + 16 tiles cut in 16; 1568 dgrad tiles
     _run_linear("cuda", 2048, 1024, 256)      # fused box predictor 51 + 200 -> 256
 
 

@@ -13,6 +13,13 @@ CASES = [  # form, batch, M, N, K, tile, splits, workgroups
     ("NN", 2, 260, 132, 64, 1, 1, 8),
     ("TN", 1, 72, 136, 200, 2, 1, 0),       # weight-gradient form, reduction over 200 "pixels" (tail slab)
     ("TN", 2, 264, 68, 96, 1, 2, 8),
+    # balanced (-1): whole tiles + one part of the left-over tiles per workgroup
+    ("TN", 1, 520, 392, 200, 2, -1, 8),     # 5 x 4 = 20 tiles on 8 workgroups: 2 whole tiles each, 4 tiles cut in 2 (7 slabs -> 4 + 3)
+    ("NT", 2, 300, 200, 136, 2, -1, 16),    # 2 x 3 x 2 = 12 tiles on 16 workgroups: no whole tile, 12 parts (ts = 1), batched
+    ("NT", 1, 130, 72, 416, 2, -1, 8),      # 2 tiles on 8 workgroups: both cut in 4 (13 slabs -> 4 + 4 + 4 + 1)
+    ("NN", 1, 700, 260, 72, 1, -1, 8),      # 256x128 tiles: 3 x 3 = 9 on 8: one whole tile each, 1 tile cut in 3 (3 slabs)
+    ("NT", 1, 256, 256, 64, 2, -1, 8),      # 4 tiles on 8 workgroups, 2 slabs: cut in 2
+    ("TN", 1, 256, 512, 64, 2, -1, 8),      # 8 tiles on 8 workgroups: exact rounds, plain launch
 ]
 
 

@@ -49,7 +49,7 @@ def _nms_case(dev, Q, nmax, thr, seed):
     counts = torch.randint(max(nmax // 2, 1), nmax + 1, (Q,), generator=g).int()
     counts[0] = nmax
     valid = (torch.rand(Q, nmax, generator=g) > 0.1).int()
-    keep = select.nms_sorted(boxes.to(dev), thr, counts.to(dev), valid.to(dev)).cpu()
+    keep = select.nms_sorted(boxes.to(dev), thr, counts.to(dev), valid.to(dev), _poison=True).cpu()
     for q in range(Q):
         n = int(counts[q])
         sel = torch.where(valid[q, :n] != 0)[0]
@@ -89,6 +89,8 @@ def test_topk_emulated(emu_lib):
     _topk_case("cpu", 2, 5000, 300, 0)
     _topk_case("cpu", 2, 700, 2000, 1)            # k > n
     _topk_case("cpu", 3, 3000, 64, 2, ties=True)
+    _topk_case("cpu", 1, 66000, 100, 3, ties=True)    # > 65536 elements: the streamed variant (rows are not cached in registers)
+    _topk_case("cpu", 1, 65536, 40, 4)                # the largest cached row
     _strided_topk("cpu")
 
 
@@ -103,6 +105,8 @@ def test_topk_gpu(hip_lib):
     _topk_case("cuda", 4, 65472, 256, 1, ties=True)
     _topk_case("cuda", 4, 192, 2000, 2)
     _topk_case("cuda", 4, 6960, 1000, 3, ties=True)
+    _topk_case("cuda", 2, 70000, 300, 4, ties=True)   # streamed variant
+    _topk_case("cuda", 2, 65536, 8192, 5)
     _strided_topk("cuda")
 
 
