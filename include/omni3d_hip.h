@@ -98,7 +98,9 @@ int omni_bn_apply(const float* x, const float* scale_shift, const float* residua
                   int relu, void* stream);
 
 /* backward of omni_bn_fwd.  dy = grad wrt y; dres [nullable] = grad wrt residual;
- * ws >= 2C*258 doubles, coef 3C floats scratch. */
+ * ws >= 2C*258 doubles, coef 3C floats scratch.  relu: 0 = none; 1 = mask dy by y > 0, y = the forward output;
+ * 2 = layers without residual: `y` points at the forward pass's scale_shift (2C floats) and the mask is recomputed as
+ * x * scale + shift > 0, the output tensor is not read. */
 int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd,
                 float* dx, float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C,
                 int relu, int accumulate_param_grads, void* stream);

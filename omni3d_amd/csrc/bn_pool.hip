@@ -42,8 +42,11 @@ __device__ __forceinline__ void bn_reduce_tile(const float* __restrict__ x, cons
     const int col = cbase + t % C4, row = t / C4;
     const bool active = row < rows;
     float4 a0 = f4(0.f), a1 = f4(0.f);
-    float4 mu = f4(0.f), rs = f4(0.f);
+    float4 mu = f4(0.f), rs = f4(0.f), sc = f4(0.f), sh = f4(0.f);
     if (MODE == 1 && active) { mu = ld4(mean_rstd + 4 * col); rs = ld4(mean_rstd + C + 4 * col); }
+    // relu == 2: `y` holds the forward pass's (scale, shift) instead of the output -- the mask y > 0 of a layer without residual is
+    // recomputed as x * scale + shift > 0 with the expression of bn_apply_body, and the output tensor is not read at all
+    if (MODE == 1 && active && relu == 2) { sc = ld4(y + 4 * col); sh = ld4(y + C + 4 * col); }
     if (active) {
         const long step = (long)gridDim.x * rows;
         long p = (long)blockIdx.x * rows + row;
@@ -58,9 +61,12 @@ __device__ __forceinline__ void bn_reduce_tile(const float* __restrict__ x, cons
             } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) g[u] = ld4(dy + (p + u * step) * C + 4 * col);
-                if (relu) {
+                if (relu == 1) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) g[u] = mask4(g[u], ld4(y + (p + u * step) * C + 4 * col));
+                } else if (relu == 2) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) g[u] = mask4(g[u], xv[u] * sc + sh);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { a0 = a0 + g[u]; a1 = a1 + g[u] * ((xv[u] - mu) * rs); }
@@ -74,7 +80,8 @@ __device__ __forceinline__ void bn_reduce_tile(const float* __restrict__ x, cons
                 a1 = a1 + xv * xv;
             } else {
                 float4 g = ld4(dy + off);
-                if (relu) g = mask4(g, ld4(y + off));
+                if (relu == 1) g = mask4(g, ld4(y + off));
+                else if (relu == 2) g = mask4(g, xv * sc + sh);
                 a0 = a0 + g;
                 a1 = a1 + g * ((xv - mu) * rs);
             }
@@ -235,9 +242,11 @@ __device__ __forceinline__ void bn_bwd_apply_body(const float* __restrict__ x, c
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % C4);
         float4 g = ld4(dy + 4 * i);
-        if (relu) g = mask4(g, ld4(y + 4 * i));
+        const float4 xv = ld4(x + 4 * i);
+        if (relu == 1) g = mask4(g, ld4(y + 4 * i));
+        else if (relu == 2) g = mask4(g, xv * ld4(y + 4 * col) + ld4(y + C + 4 * col));      // y = (scale, shift): see bn_reduce_tile
         if (dres != nullptr) st4(dres + 4 * i, g);
-        const float4 xh = (ld4(x + 4 * i) - ld4(mean_rstd + 4 * col)) * ld4(mean_rstd + C + 4 * col);
+        const float4 xh = (xv - ld4(mean_rstd + 4 * col)) * ld4(mean_rstd + C + 4 * col);
         const float4 v = ld4(coef + 4 * col) * (g - ld4(coef + C + 4 * col) - xh * ld4(coef + 2 * C + 4 * col));
         st4(dx + 4 * i, v);
     }
@@ -519,7 +528,7 @@ int omni_bn_apply(const float* x, const float* scale_shift, const float* residua
 int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
                 float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C, int relu,
                 int accumulate_param_grads, void* stream) {
-    if (P <= 0 || C <= 0 || (C & 3) || C > 4096) return OMNI_ERR_ARG;
+    if (P <= 0 || C <= 0 || (C & 3) || C > 4096 || relu < 0 || relu > 2 || (relu && y == nullptr)) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = red_grid(P, C);
     float* partial = reinterpret_cast<float*>(ws + 2 * C);

@@ -8,6 +8,7 @@ dla102x2 of MODEL.DLA.TYPE (the 2-channel groups of the *_c ones are zero-padded
 Every conv is the implicit-GEMM MFMA kernel, every BN(+ReLU)(+residual) one fused HBM-bound kernel pair; the image
 enters as NHWC with C padded 3 -> 4."""
 import math
+import os
 
 import torch
 from torch import nn
@@ -16,6 +17,8 @@ from .... import functional as HF
 from ..layers import BatchNorm2d, Conv2d, GroupedConv2d
 from ..registries import BACKBONE_REGISTRY
 from .fpn import FPN, Backbone
+
+_SHARE_POOL = os.environ.get("OMNI_DLA_SHARE_POOL", "1") != "0"      # A/B knob: nested trees pool their common input once
 
 
 class ConvBNReLU(nn.Sequential):
@@ -156,7 +159,7 @@ class Tree(nn.Module):
             x1 = self.tree1(x, residual)
         else:
             t1 = self.tree1
-            shared = bottom if (t1.downsample is None) == (self.downsample is None) else None
+            shared = bottom if _SHARE_POOL and (t1.downsample is None) == (self.downsample is None) else None
             x1 = t1(x, residual, bottom=shared)
         if self.levels == 1:
             x2 = self.tree2(x1)

@@ -340,6 +340,9 @@ def linear(x, w, bias=None, relu=False, w_grad_view=None):
     return _Linear.apply(x, w, bias, relu, w_grad_view)
 
 
+_BN_REMASK = _os_environ_get("OMNI_BN_REMASK", "1") != "0"     # A/B knob
+
+
 class _BatchNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, eps, momentum, partials=None):
@@ -347,17 +350,20 @@ class _BatchNorm(Function):
         ctx.direct = (gg, gb) if (gg is not None and gb is not None) else None
         x = _cl(x)
         res = _cl(residual) if residual is not None else None
-        y, mean_rstd, _ = bnpool.bn_fwd(x, gamma, beta, running_mean, running_var, res, relu, eps, momentum, partials)
-        ctx.save_for_backward(x, gamma, mean_rstd, y if relu else None)
+        y, mean_rstd, scale_shift = bnpool.bn_fwd(x, gamma, beta, running_mean, running_var, res, relu, eps, momentum, partials)
+        # ReLU mask for the backward pass: the output y, or (no residual) the 2C-float (scale, shift) pair -- y > 0 is then
+        # recomputed from x, which the backward kernels read anyway, and y is not read again (bnpool.bn_bwd)
+        remask = relu and residual is None and _BN_REMASK
+        ctx.save_for_backward(x, gamma, mean_rstd, (y if relu and not remask else None), (scale_shift if remask else None))
         ctx.cfg = (relu, residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, mean_rstd, y = ctx.saved_tensors
+        x, gamma, mean_rstd, y, scale_shift = ctx.saved_tensors
         relu, has_res = ctx.cfg
         dx, dres, dgamma, dbeta = bnpool.bn_bwd(x, _cl(dy), y, gamma, mean_rstd, relu, want_dres=has_res and ctx.needs_input_grad[5],
-                                                accum_into=ctx.direct)
+                                                accum_into=ctx.direct, scale_shift=scale_shift)
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 

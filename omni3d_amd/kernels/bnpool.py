@@ -44,11 +44,17 @@ def bn_apply(x, scale_shift, residual=None, relu=False):
     return y.permute(0, 3, 1, 2)
 
 
-def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=None):
+def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=None, scale_shift=None):
     """-> (dx CL, dres CL or None, dgamma, dbeta).  accum_into = (dgamma_buf, dbeta_buf): the parameter
-    gradients are added to those buffers instead (dgamma/dbeta returned as None)."""
+    gradients are added to those buffers instead (dgamma/dbeta returned as None).  scale_shift (2C, from bn_fwd) instead of y:
+    the ReLU mask of a layer WITHOUT residual is recomputed from x (mode 2 of omni_bn_bwd), the output tensor is not read."""
     xv, dyv = _nhwc(x), _nhwc(dy)
-    yv = _nhwc(y) if relu else None
+    mode = int(bool(relu))
+    if relu and scale_shift is not None:
+        assert y is None and scale_shift.is_contiguous() and scale_shift.numel() == 2 * xv.shape[3]
+        yv, mode = scale_shift, 2
+    else:
+        yv = _nhwc(y) if relu else None
     N, H, W, C = xv.shape
     L = _lib.check_device(xv, dyv, yv, gamma, mean_rstd)
     dx = _like_cl((N, H, W, C), x)
@@ -62,7 +68,7 @@ def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=N
     ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
     coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
     L.call("omni_bn_bwd", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(dx),
-           _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, int(relu),
+           _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, mode,
            int(accum_into is not None), _lib.stream_of(x))
     if accum_into is not None:
         dgamma = dbeta = None

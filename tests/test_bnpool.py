@@ -29,8 +29,8 @@ def _run_bn(dev, N, C, H, W, relu, with_res):
     # kernel
     rm_k, rv_k = rm.clone().to(dev), rv.clone().to(dev)
     xk = _cl(x).to(dev)
-    y, mean_rstd, _ = bnpool.bn_fwd(xk, gamma.to(dev), beta.to(dev), rm_k, rv_k,
-                                    residual=_cl(res).to(dev) if with_res else None, relu=relu)
+    y, mean_rstd, scale_shift = bnpool.bn_fwd(xk, gamma.to(dev), beta.to(dev), rm_k, rv_k,
+                                              residual=_cl(res).to(dev) if with_res else None, relu=relu)
     assert (y.cpu() - yr.detach()).abs().max() < 2e-5
     assert (rm_k.cpu() - rm_ref).abs().max() < 1e-5 and (rv_k.cpu() - rv_ref).abs().max() < 1e-5
     dx, dres, dgamma, dbeta = bnpool.bn_bwd(xk, _cl(dy).to(dev), y, gamma.to(dev), mean_rstd, relu=relu, want_dres=with_res)
@@ -39,6 +39,10 @@ def _run_bn(dev, N, C, H, W, relu, with_res):
     assert (dbeta.cpu() - br.grad).abs().max() < 2e-4 * max(1.0, br.grad.abs().max().item())
     if with_res:
         assert (dres.cpu() - rr.grad).abs().max() < 1e-6
+    if relu and not with_res:
+        # the ReLU mask recomputed from x and the forward pass's (scale, shift) instead of read from y: the very same gradients
+        dx2, _, dgamma2, dbeta2 = bnpool.bn_bwd(xk, _cl(dy).to(dev), None, gamma.to(dev), mean_rstd, relu=True, scale_shift=scale_shift)
+        assert torch.equal(dx2, dx) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta)
 
 
 def _run_pool(dev):

@@ -124,7 +124,9 @@ def _run(dev, name, head_cap=None):
     grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     # bottom-up cap: 2 % (round 3; 3 % before the Winograd point change), 3 % only for the 1 x 64 x 64 plumbing fixtures whose
     # deepest BatchNorms see 4 samples per channel
-    bb_cap = GRAD_CAP_BACKBONE_TINY if spec["images"] * spec["height"] * spec["width"] <= 64 * 64 else GRAD_CAP_BACKBONE
+    tiny = spec["images"] * spec["height"] * spec["width"] <= 64 * 64
+    bb_cap = GRAD_CAP_BACKBONE_TINY if tiny else GRAD_CAP_BACKBONE
+    bb_elem_cap = GRAD_HEAD64_CAP_BACKBONE_TINY if tiny else GRAD_HEAD64_CAP_BACKBONE
     worst = 0.0
     # a BatchNorm bias that reaches the next BatchNorm through linear layers only (MNASNet's base.7, ShuffleNet's branch1.1) has an
     # exactly-zero gradient in exact arithmetic: both sides hold rounding noise there, hence a floor relative to the largest gradient
@@ -142,7 +144,7 @@ def _run(dev, name, head_cap=None):
             g = g.contiguous(memory_format=torch.contiguous_format)
         got = g.reshape(g.shape[0], -1).flatten()[:64].cpu() if g.dim() > 1 else g.flatten()[:64].cpu()
         scale = max(head.abs().max().item(), 1e-6)
-        tol = head_cap if _is_head(n) else bb_cap
+        tol = head_cap if _is_head(n) else bb_elem_cap
         assert (got - head).abs().max().item() <= tol * scale + 1e-7, (n, (got - head).abs().max().item(), scale)
     return worst
 
@@ -207,6 +209,17 @@ GRAD_RULE_FRACTION = 0.9    # ... for at least this fraction of the parameter te
 GRAD_CAP_HEADS = 1e-2    # hard caps on the relative L2 error of EVERY parameter tensor: heads / FPN 1 %, bottom-up 3 %
 GRAD_CAP_BACKBONE = 2e-2         # round 3: measured worst 1.4 % at full size (profiles/r03_parity_fp64_*.txt); round 2: 3 % with 2.2 % measured
 GRAD_CAP_BACKBONE_TINY = 3e-2
+GRAD_RUNS = 3            # the HIP step is repeated; caps apply to the median error per tensor ...
+GRAD_SINGLE_RUN_SLACK = 1.5     # ... and every single run stays within 1.5 x the cap (see _vs_cpu_oracle)
+# Element-wise check of the recorded 64-element gradient heads (max |HIP - reference| over the largest reference element): a far
+# noisier quantity than a tensor norm, and it is NOT the same from run to run -- the production kernels sum split-K / statistics
+# partials with atomics, and a last-bit difference in an activation flips ReLU / max-pool decisions further up.  Ten repetitions
+# of each fixture on MI355X (tools/debug/grad_repeat.py, profiles/r03_grad_run_to_run_spread.txt): dla34_full base_layer.0.weight
+# 1.38 .. 2.35 % (continuous), dla34_small 0.7 / 1.04 % (two modes), the 1 x 64 x 64 plumbing fixture dla34_tiny_head_entangled
+# 0.2 / 0.5 / 4.9 % (three modes: its deepest maps are 2 x 2, one flipped decision is a visible share of the gradient).  Caps:
+# 3 % (1.3 x the worst of the ten full-size runs), 6 % for the 1 x 64 x 64 fixtures; a wrong kernel is O(100 %) here.
+GRAD_HEAD64_CAP_BACKBONE = 3e-2
+GRAD_HEAD64_CAP_BACKBONE_TINY = 6e-2
 
 
 def _is_head(n):
@@ -273,25 +286,41 @@ def _vs_cpu_oracle(batch, report=None, config="cubercnn_DLA34_FPN.yaml", backbon
         if not (e_hip <= LOSS_ABS and e_hip <= max(2 * e_cpu, LOSS_FLOOR)):
             bad.append(lines[-1])
     og = dict(oracle.named_parameters())
+    # The production kernels sum split-K / statistics partials with atomics, and this random-init network amplifies a last-bit
+    # difference ~1e5 x on the way down (its fp32 CPU reference is itself ~1 % from float64 at the stem): whole gradient tensors
+    # of two GPU runs of the same step differ by 0.6 .. 1.3 % in relative L2 (tools/debug/grad_repeat.py,
+    # profiles/r03_grad_run_to_run_spread.txt).  The step is therefore run GRAD_RUNS times; the caps and the 3x rule apply to the
+    # MEDIAN error of each tensor, and every single run must stay within GRAD_SINGLE_RUN_SLACK x the cap.
+    hip_runs = [{n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}]
+    for _ in range(GRAD_RUNS - 1):
+        for p in model.parameters():
+            p.grad = None
+        sum(model(batch).values()).backward()
+        hip_runs.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
     rows = []
     for n, p in model.named_parameters():
         if p.grad is None or n not in g64:
             continue
-        gh = p.grad.double().cpu()
-        if gh.dim() == 4:
-            gh = gh.contiguous(memory_format=torch.contiguous_format)
-        gh = gh.reshape(g64[n].shape)
         den = float(g64[n].norm().clamp(min=1e-30))
-        e_hip, e_cpu = float((gh - g64[n]).norm()) / den, float((og[n].grad.double() - g64[n]).norm()) / den
-        rows.append((e_hip, e_cpu, n, den))
+        errs = []
+        for run in hip_runs:
+            gh = run[n].double().cpu()
+            if gh.dim() == 4:
+                gh = gh.contiguous(memory_format=torch.contiguous_format)
+            errs.append(float((gh.reshape(g64[n].shape) - g64[n]).norm()) / den)
+        errs.sort()
+        e_cpu = float((og[n].grad.double() - g64[n]).norm()) / den
+        rows.append((errs[len(errs) // 2], e_cpu, n, den, errs[0], errs[-1]))
     n_rule = n_all = 0
-    for e_hip, e_cpu, n, den in sorted(rows, reverse=True):
-        lines.append("grad %.3e (cpu32 %.3e, ratio %.2f) |g64| %.3e %s" % (e_hip, e_cpu, e_hip / max(e_cpu, 1e-30), den, n))
+    for e_hip, e_cpu, n, den, e_min, e_max in sorted(rows, reverse=True):
+        lines.append("grad %.3e [%.3e .. %.3e over %d runs] (cpu32 %.3e, ratio %.2f) |g64| %.3e %s"
+                     % (e_hip, e_min, e_max, GRAD_RUNS, e_cpu, e_hip / max(e_cpu, 1e-30), den, n))
         if den < 1e-12:
             continue
         n_all += 1
         n_rule += e_hip <= max(GRAD_RULE_MULT * e_cpu, GRAD_FLOOR)
-        if not e_hip <= (GRAD_CAP_HEADS if _is_head(n) else GRAD_CAP_BACKBONE):
+        cap = GRAD_CAP_HEADS if _is_head(n) else GRAD_CAP_BACKBONE
+        if not (e_hip <= cap and e_max <= GRAD_SINGLE_RUN_SLACK * cap):
             bad.append(lines[-1])
     lines.append("gradient tensors within max(%gx CPU-fp32 error, %g): %d of %d" % (GRAD_RULE_MULT, GRAD_FLOOR, n_rule, n_all))
     if n_rule < GRAD_RULE_FRACTION * n_all:
