@@ -450,9 +450,16 @@ __global__ void __launch_bounds__(256) cube_reduce_kernel(const float* __restric
         if (isfinite(v[6])) { tot += v[6]; totc += 1; }
         ze += v[7]; de += v[8]; xe += v[9]; zc += v[7] < 0.2f ? 1 : 0; cf += v[10];
     }
-    for (int k = 0; k < 6; ++k) { atomicAdd(&acc[k], s[k]); atomicAdd(&acc[6 + k], c[k]); }
-    atomicAdd(&acc[12], tot); atomicAdd(&acc[13], totc); atomicAdd(&acc[14], ze); atomicAdd(&acc[15], de);
-    atomicAdd(&acc[16], xe); atomicAdd(&acc[17], zc); atomicAdd(&acc[18], cf); atomicAdd(&acc[19], nv);
+    // wave reduction in registers, then one LDS atomic per (wave, quantity) (round 3: 20 fp64 LDS atomics per THREAD on the same
+    // 20 words were 45 us of serialisation for <= 512 rows)
+    double q[20] = {s[0], s[1], s[2], s[3], s[4], s[5], c[0], c[1], c[2], c[3], c[4], c[5], tot, totc, ze, de, xe, zc, cf, nv};
+#pragma unroll
+    for (int k = 0; k < 20; ++k) {
+        double v = q[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((t & 63) == 0) atomicAdd(&acc[k], v);
+    }
     __syncthreads();
     if (t == 0) {
         for (int k = 0; k < 6; ++k) {

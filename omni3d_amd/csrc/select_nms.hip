@@ -28,6 +28,7 @@ constexpr int TOPK_MAXK = 8192;      // 64 KB of LDS keys; the batched-inference
 __device__ __forceinline__ unsigned score_bits(float f) {
     unsigned u = __float_as_uint(f);
     if (f != f) u = 0u;  // NaN sorts last
+    else if (f == 0.f) u = 0x80000000u;  // -0.0 and +0.0 compare equal (torch.sort): one key, the index decides
     else u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return u;
 }
@@ -35,6 +36,18 @@ __device__ __forceinline__ unsigned long long key_of_bits(unsigned u, int idx) {
     return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
 }
 __device__ __forceinline__ unsigned long long make_key(float f, int idx) { return key_of_bits(score_bits(f), idx); }
+// key_of_bits(u, idx) >= thr, on the two 32-bit halves (cached rows keep ONE register per element: a 64-bit key per element that
+// lives across the passes doubles them)
+// sel[slot] = key_of_bits(u, idx) as two 32-bit stores: a 64-bit store makes the register allocator keep every cached score word
+// in the odd half of an aligned pair
+__device__ __forceinline__ void store_key(unsigned long long* sel, int slot, unsigned u, int idx) {
+    unsigned* w = reinterpret_cast<unsigned*>(sel + slot);
+    w[0] = 0xFFFFFFFFu - (unsigned)idx;
+    w[1] = u;
+}
+__device__ __forceinline__ bool key_ge(unsigned u, int idx, unsigned thi, unsigned tlo) {
+    return u > thi || (u == thi && (0xFFFFFFFFu - (unsigned)idx) >= tlo);
+}
 __device__ __forceinline__ float key_value(unsigned long long k) {
     unsigned u = (unsigned)(k >> 32);
     u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
@@ -49,17 +62,120 @@ struct SegP {
     int off[TOPK_MAXSEG], n[TOPK_MAXSEG];
 };
 
+// ---- radix selection machinery (one 1024-thread workgroup) ----------------------------------------------------------------
+// Scores cluster (the sign/exponent byte of RPN logits takes 2-3 values), so plain LDS atomics would serialise tens of thousands
+// of adds on one bin: each wave first folds its lanes that share the leader's digit into ONE add (4 rounds), the rest fall back
+// to per-lane atomics.  Must be called by whole waves (ballots / shuffles).
+__device__ __forceinline__ void count_digit(unsigned* hist, bool todo, unsigned digit) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        const unsigned long long pending = __ballot(todo);
+        if (pending == 0ull) break;
+        const int leader = __ffsll((long long)pending) - 1;
+        const unsigned d = (unsigned)__shfl((int)digit, leader, 64);
+        const unsigned long long same = __ballot(todo && digit == d);
+        if (lane == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
+        if (todo && digit == d) todo = false;
+    }
+    if (todo) atomicAdd(&hist[digit], 1u);
+}
+
+struct RadixShared {
+    unsigned hist[256];
+    unsigned wsum[4];
+    unsigned long long prefix;
+    int need, done;
+};
+
+// After a pass's histogram is complete (and a barrier): the bin that holds the `need`-th largest candidate, found by a suffix scan
+// of the 256 bins over 256 threads (round 3: thread 0 used to walk the bins one dependent LDS read at a time, ~3 us per pass).
+// Extends the prefix by that digit, lowers `need` by the candidates in the higher bins, sets `done` when every remaining candidate
+// is needed.  Contains one barrier; the caller adds one after it.
+__device__ __forceinline__ void radix_pick_bin(RadixShared& R, int shift) {
+    const int t = threadIdx.x;
+    const int need = R.need;                       // (read by everyone before the barrier below, written after it)
+    const unsigned long long prefix = R.prefix;
+    unsigned v = 0u, incl = 0u;
+    if (t < 256) {
+        v = R.hist[255 - t];                        // thread t looks at digit 255 - t: inclusive scan = candidates with digit >= d
+        incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(incl, o, 64);
+            if ((t & 63) >= o) incl += u;
+        }
+        if ((t & 63) == 63) R.wsum[t >> 6] = incl;
+    }
+    __syncthreads();
+    if (t < 256) {
+        for (int w = 0; w < (t >> 6); ++w) incl += R.wsum[w];
+        const unsigned above = incl - v;            // candidates in the bins above this one
+        // the first bin (from the top) whose cumulative count reaches `need`; digit 0 takes whatever is left
+        if (((int)incl >= need || t == 255) && (int)above < need) {
+            R.need = need - (int)above;
+            R.prefix = prefix | ((unsigned long long)(255 - t) << shift);
+            // all remaining candidates share the prefix and every one of them is needed: the lower bytes cannot separate
+            // anything any more (distinct scores settle after the 4 score bytes; the index bytes only matter when equal scores
+            // straddle the k-th place)
+            R.done = ((int)v == need - (int)above) ? 1 : 0;
+        }
+    }
+}
+
+// k-th largest (kth >= 1, at most the number of valid entries) of the 64-bit keys (eu[c] << 32 | el[c]) spread over the threads'
+// register lists; -> threshold: exactly kth keys are >= it (keys are unique).  Whole workgroup; barriers inside.
+template <int CNT>
+__device__ __forceinline__ unsigned long long radix_kth(RadixShared& R, const unsigned (&eu)[CNT], const unsigned (&el)[CNT],
+                                                        const bool (&ev)[CNT], int kth) {
+    const int t = threadIdx.x;
+    if (t == 0) { R.prefix = 0ull; R.need = kth; }
+    __syncthreads();
+    for (int pass = 7; pass >= 0; --pass) {
+        if (t < 256) R.hist[t] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = R.prefix;
+        const unsigned phi = (unsigned)(prefix >> 32), plo = (unsigned)prefix;
+        const bool hi = pass >= 4;
+        const int sh = hi ? pass * 8 - 32 : pass * 8;
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) {
+            const unsigned w = hi ? eu[c] : el[c], pw = hi ? phi : plo;
+            bool todo = ev[c] && (hi || eu[c] == phi);
+            if (sh < 24) todo = todo && ((w >> (sh + 8)) == (pw >> (sh + 8)));
+            count_digit(R.hist, todo, (w >> sh) & 255u);
+        }
+        __syncthreads();
+        radix_pick_bin(R, pass * 8);
+        __syncthreads();
+        if (R.done) break;
+    }
+    const unsigned long long thr = R.prefix;
+    __syncthreads();                                 // (the next selection resets the shared state)
+    return thr;
+}
+
 // keys: (rows, n) with row pitch `pitch` and element stride `estride` (floats).
 // NPT > 0: every segment has at most NPT * 1024 elements and a thread caches its NPT score words in registers; 0: streamed.
+//
+// Cached rows with k <= TOPK_PREFILTER_K take a two-level selection (round 3): every thread picks its own 4 largest elements in
+// registers; the k-th largest of those 4096 keys (a radix selection over 4 register entries per thread) is a LOWER bound of the
+// row's k-th largest key, and because the per-thread maxima are nearly the row's top 4096, only a few more than k elements pass
+// it (measured on RPN logits: ~2300 for k = 2000 of 49152).  Those are compacted into LDS and the exact k-th largest is selected
+// among them, again 4 entries per thread.  The radix passes therefore touch 4 entries per thread instead of 48-64, and the
+// selection is the same set -- the keys are unique 64-bit (score, index) words throughout.
 constexpr int TOPK_NPT = 64;
-template <int NPT>
+constexpr int TOPK_PREFILTER_K = 3072, TOPK_PREFILTER_CAND = 4096;
+// PREF (needs NPT > 0): the two-level selection; a segment it does not settle (k >= n, or more than TOPK_PREFILTER_CAND
+// survivors of the bound: adversarial ties) takes the streamed full selection, so that the cached words are dead after level 2
+// (both full selections compiled into one kernel keep them live everywhere and spill).
+template <int NPT, bool PREF>
 __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __restrict__ keys, SegP seg, long pitch,
                                                                  int estride, int k, float* __restrict__ out_val,
                                                                  int* __restrict__ out_idx) {
-    __shared__ unsigned hist[256];
+    __shared__ RadixShared R;
     __shared__ unsigned long long sel[TOPK_MAXK];
-    __shared__ unsigned long long s_prefix;
-    __shared__ int s_need, s_count, s_done;
+    __shared__ int s_count;
     const int t = threadIdx.x;
     const int rowid = (int)blockIdx.x / seg.S, sid = (int)blockIdx.x - rowid * seg.S;
     const int n = seg.n[sid];
@@ -84,109 +200,160 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __
             ku[j] = score_bits(__uint_as_float(omni_bufld1(rr, i < n ? i * estride * 4 : OMNI_OOB)));
         }
     }
-    auto count_digit = [&](bool todo, unsigned digit) {
-        // Scores cluster (the sign/exponent byte of RPN logits takes 2-3 values), so plain LDS atomics would
-        // serialise tens of thousands of adds on one bin: each wave first folds its lanes that share the
-        // leader's digit into ONE add (4 rounds), the rest fall back to per-lane atomics.
+
+    bool selected = false;                      // sel[0 .. kk) already holds the answer set (unsorted), sel[kk .. kpad) zeros
+    if (PREF && kk < n && kk <= TOPK_PREFILTER_K) {
+        // ---- level 1: per-thread top 4 (ties: the earlier element = lower index = larger key stays ahead) ----
+        unsigned bu[4] = {0u, 0u, 0u, 0u};
+        int bj[4] = {-1, -1, -1, -1};
+        {
+            int tt = t, nn = n;
+            OMNI_OPAQUE_V(tt);
+            OMNI_OPAQUE_S(nn);
 #pragma unroll
-        for (int round = 0; round < 4; ++round) {
-            const unsigned long long pending = __ballot(todo);
-            if (pending == 0ull) break;
-            const int leader = __ffsll((long long)pending) - 1;
-            const unsigned d = (unsigned)__shfl((int)digit, leader, 64);
-            const unsigned long long same = __ballot(todo && digit == d);
-            if ((t & 63) == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
-            if (todo && digit == d) todo = false;
-        }
-        if (todo) atomicAdd(&hist[digit], 1u);
-    };
-    unsigned long long thr = 0ull;  // keys >= thr are selected
-    if (kk < n) {
-        if (t == 0) { s_prefix = 0ull; s_need = kk; }
-        __syncthreads();
-        for (int pass = 7; pass >= 0; --pass) {
-            if (t < 256) hist[t] = 0u;
-            __syncthreads();
-            const unsigned long long prefix = s_prefix;
-            const int shift = pass * 8;
-            if (NPT > 0) {
-                // 32-bit arithmetic on the cached score word / the index word (a 64-bit key per element would double the
-                // registers), and the element index and the trip count are re-derived from opaque copies in every pass:
-                // otherwise the 64 index words, range predicates and loop-exit conditions are hoisted out of the pass loop
-                // as loop invariants and spill.
-                int tt = t, nn = n;
-                OMNI_OPAQUE_V(tt);
-                OMNI_OPAQUE_S(nn);
-                const unsigned phi = (unsigned)(prefix >> 32), plo = (unsigned)prefix;
-                const bool hi = pass >= 4;
-                const int sh = hi ? shift - 32 : shift;                    // shift inside the word this pass looks at
+            for (int j = 0; j < NPT; ++j) {
+                if (j * TOPK_THREADS >= nn) break;
+                if (j * TOPK_THREADS + tt < nn) {
+                    unsigned cu = ku[j];
+                    OMNI_OPAQUE_V(cu);          // a copy: otherwise (ku[j], j) become an aligned 64-bit pair for the swaps below
+                    int cj = j;
 #pragma unroll
-                for (int j = 0; j < NPT; ++j) {
-                    if (j * TOPK_THREADS >= nn) break;
-                    const int i = j * TOPK_THREADS + tt;
-                    const unsigned w = hi ? ku[j] : (0xFFFFFFFFu - (unsigned)i), pw = hi ? phi : plo;
-                    // candidates: all bytes above this pass's byte equal the prefix
-                    bool todo = i < nn && (hi || ku[j] == phi);
-                    if (sh < 24) todo = todo && ((w >> (sh + 8)) == (pw >> (sh + 8)));
-                    const unsigned digit = (w >> sh) & 255u;
-                    count_digit(todo, digit);
-                }
-            } else {
-                for (int base = 0; base < n; base += TOPK_THREADS) {
-                    const int i = base + t;
-                    bool todo = false;
-                    unsigned digit = 0u;
-                    if (i < n) {
-                        const unsigned long long key = make_key(row[(long)i * estride], i);
-                        todo = (pass == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-                        digit = (unsigned)(key >> shift) & 255u;
+                    for (int q = 0; q < 4; ++q) {
+                        if (cj >= 0 && (bj[q] < 0 || cu > bu[q])) {
+                            const unsigned su = bu[q]; const int sj = bj[q];
+                            bu[q] = cu; bj[q] = cj; cu = su; cj = sj;
+                        }
                     }
-                    count_digit(todo, digit);
                 }
             }
-            __syncthreads();
-            if (t == 0) {
-                int need = s_need;
-                int d = 255;
-                for (; d > 0; --d) {
-                    const int c = (int)hist[d];
-                    if (c >= need) break;
-                    need -= c;
-                }
-                s_need = need;
-                s_prefix = prefix | ((unsigned long long)d << shift);
-                // all remaining candidates share the prefix and every one of them is needed: the lower bytes cannot
-                // separate anything any more (distinct scores settle after the 4 score bytes; the index bytes only
-                // matter when equal scores straddle the k-th place)
-                s_done = ((int)hist[d] == need) ? 1 : 0;
-            }
-            __syncthreads();
-            if (s_done) break;
         }
-        thr = s_prefix;  // keys are unique, so exactly kk keys are >= thr
-    }
-    if (t == 0) s_count = 0;
-    for (int i = t; i < kpad; i += TOPK_THREADS) sel[i] = 0ull;
-    __syncthreads();
-    if (NPT > 0) {
-        int tt = t;
-        OMNI_OPAQUE_V(tt);
+        unsigned el[4];
+        bool ev[4];
 #pragma unroll
-        for (int j = 0; j < NPT; ++j) {
-            if (j * TOPK_THREADS >= n) break;
-            const int i = j * TOPK_THREADS + tt;
-            const unsigned long long key = key_of_bits(ku[j], i);
-            if (i < n && key >= thr) {
-                const int slot = atomicAdd(&s_count, 1);
-                if (slot < TOPK_MAXK) sel[slot] = key;
+        for (int q = 0; q < 4; ++q) { ev[q] = bj[q] >= 0; el[q] = 0xFFFFFFFFu - (unsigned)(bj[q] * TOPK_THREADS + t); }
+        const unsigned long long bound = radix_kth<4>(R, bu, el, ev, kk);      // at least kk elements of the row are >= bound
+        // ---- level 2: compact everything >= bound, select among the survivors ----
+        if (t == 0) s_count = 0;
+        __syncthreads();
+        {
+            int tt = t, nn = n;
+            OMNI_OPAQUE_V(tt);
+            OMNI_OPAQUE_S(nn);
+            const unsigned bhi = (unsigned)(bound >> 32), blo = (unsigned)bound;
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                if (j * TOPK_THREADS >= nn) break;
+                const int i = j * TOPK_THREADS + tt;
+                if (i < nn && key_ge(ku[j], i, bhi, blo)) {
+                    const int slot = atomicAdd(&s_count, 1);
+                    if (slot < TOPK_PREFILTER_CAND) store_key(sel, slot, ku[j], i);
+                }
             }
         }
-    } else {
-        for (int i = t; i < n; i += TOPK_THREADS) {
-            const unsigned long long key = make_key(row[(long)i * estride], i);
-            if (key >= thr) {
-                const int slot = atomicAdd(&s_count, 1);
-                if (slot < TOPK_MAXK) sel[slot] = key;
+        __syncthreads();
+        const int ncand = s_count;
+        if (ncand <= TOPK_PREFILTER_CAND) {              // (otherwise: the full selection below)
+            unsigned cu[4], cl[4];
+            bool cv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = q * TOPK_THREADS + t;
+                cv[q] = idx < ncand;
+                const unsigned long long key = cv[q] ? sel[idx] : 0ull;
+                cu[q] = (unsigned)(key >> 32);
+                cl[q] = (unsigned)key;
+            }
+            __syncthreads();                             // every candidate is in registers: sel can be rewritten
+            if (ncand > kk) {
+                const unsigned long long thr = radix_kth<4>(R, cu, cl, cv, kk);
+                if (t == 0) s_count = 0;
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned long long key = ((unsigned long long)cu[q] << 32) | cl[q];
+                    if (cv[q] && key >= thr) sel[atomicAdd(&s_count, 1)] = key;
+                }
+            }
+            for (int i = kk + t; i < kpad; i += TOPK_THREADS) sel[i] = 0ull;
+            selected = true;
+        }
+    }
+
+    if (!selected) {
+        unsigned long long thr = 0ull;  // keys >= thr are selected
+        if (kk < n) {
+            if (t == 0) { R.prefix = 0ull; R.need = kk; }
+            __syncthreads();
+            for (int pass = 7; pass >= 0; --pass) {
+                if (t < 256) R.hist[t] = 0u;
+                __syncthreads();
+                const unsigned long long prefix = R.prefix;
+                const int shift = pass * 8;
+                if (NPT > 0 && !PREF) {
+                    // 32-bit arithmetic on the cached score word / the index word (a 64-bit key per element would double the
+                    // registers), and the element index and the trip count are re-derived from opaque copies in every pass:
+                    // otherwise the 64 index words, range predicates and loop-exit conditions are hoisted out of the pass loop
+                    // as loop invariants and spill.
+                    int tt = t, nn = n;
+                    OMNI_OPAQUE_V(tt);
+                    OMNI_OPAQUE_S(nn);
+                    const unsigned phi = (unsigned)(prefix >> 32), plo = (unsigned)prefix;
+                    const bool hi = pass >= 4;
+                    const int sh = hi ? shift - 32 : shift;                    // shift inside the word this pass looks at
+#pragma unroll
+                    for (int j = 0; j < NPT; ++j) {
+                        if (j * TOPK_THREADS >= nn) break;
+                        const int i = j * TOPK_THREADS + tt;
+                        const unsigned w = hi ? ku[j] : (0xFFFFFFFFu - (unsigned)i), pw = hi ? phi : plo;
+                        // candidates: all bytes above this pass's byte equal the prefix
+                        bool todo = i < nn && (hi || ku[j] == phi);
+                        if (sh < 24) todo = todo && ((w >> (sh + 8)) == (pw >> (sh + 8)));
+                        count_digit(R.hist, todo, (w >> sh) & 255u);
+                    }
+                } else {
+                    // uniform trip count: the wave-level aggregation uses ballots / shuffles
+                    for (int base = 0; base < n; base += TOPK_THREADS) {
+                        const int i = base + t;
+                        bool todo = false;
+                        unsigned digit = 0u;
+                        if (i < n) {
+                            const unsigned long long key = make_key(row[(long)i * estride], i);
+                            todo = (pass == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                            digit = (unsigned)(key >> shift) & 255u;
+                        }
+                        count_digit(R.hist, todo, digit);
+                    }
+                }
+                __syncthreads();
+                radix_pick_bin(R, shift);
+                __syncthreads();
+                if (R.done) break;
+            }
+            thr = R.prefix;  // keys are unique, so exactly kk keys are >= thr
+        }
+        if (t == 0) s_count = 0;
+        for (int i = t; i < kpad; i += TOPK_THREADS) sel[i] = 0ull;
+        __syncthreads();
+        if (NPT > 0 && !PREF) {
+            int tt = t;
+            OMNI_OPAQUE_V(tt);
+            const unsigned thi = (unsigned)(thr >> 32), tlo = (unsigned)thr;
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                if (j * TOPK_THREADS >= n) break;
+                const int i = j * TOPK_THREADS + tt;
+                if (i < n && key_ge(ku[j], i, thi, tlo)) {
+                    const int slot = atomicAdd(&s_count, 1);
+                    if (slot < TOPK_MAXK) store_key(sel, slot, ku[j], i);
+                }
+            }
+        } else {
+            for (int i = t; i < n; i += TOPK_THREADS) {
+                const unsigned long long key = make_key(row[(long)i * estride], i);
+                if (key >= thr) {
+                    const int slot = atomicAdd(&s_count, 1);
+                    if (slot < TOPK_MAXK) sel[slot] = key;
+                }
             }
         }
     }
@@ -323,11 +490,14 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
 
 inline void launch_topk(int blocks, int nmax, const float* keys, const SegP& seg, long pitch, int estride, int k, float* out_val,
                         int* out_idx, hipStream_t st) {
-    if (nmax <= TOPK_NPT * TOPK_THREADS)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(topk_rows_kernel<TOPK_NPT>), dim3(blocks), dim3(TOPK_THREADS), 0, st, keys, seg, pitch, estride, k,
-                           out_val, out_idx);
+    if (nmax <= TOPK_NPT * TOPK_THREADS && k <= TOPK_PREFILTER_K)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(topk_rows_kernel<TOPK_NPT, true>), dim3(blocks), dim3(TOPK_THREADS), 0, st, keys, seg, pitch, estride,
+                           k, out_val, out_idx);
+    else if (nmax <= TOPK_NPT * TOPK_THREADS)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(topk_rows_kernel<TOPK_NPT, false>), dim3(blocks), dim3(TOPK_THREADS), 0, st, keys, seg, pitch, estride,
+                           k, out_val, out_idx);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(topk_rows_kernel<0>), dim3(blocks), dim3(TOPK_THREADS), 0, st, keys, seg, pitch, estride, k,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(topk_rows_kernel<0, false>), dim3(blocks), dim3(TOPK_THREADS), 0, st, keys, seg, pitch, estride, k,
                            out_val, out_idx);
 }
 

@@ -23,6 +23,21 @@ def _topk_case(dev, rows, n, k, seed, ties=False):
         assert (idx.cpu()[:, n:] == -1).all()
 
 
+def _topk_prefilter_overflow(dev):
+    """the two-level selection's bound comes from the per-thread top 4 (thread = index mod 1024); when 64 threads own ALL the large
+    values the bound is far too low, more than 4096 elements pass it and the segment must take the full selection instead"""
+    from omni3d_amd.kernels import select
+    g = torch.Generator().manual_seed(9)
+    n, k = 65536, 3000
+    keys = torch.rand(2, n, generator=g)
+    hot = (torch.arange(n) % 1024) < 64
+    keys[:, hot] += 10.0
+    keys[1, ::3] = keys[1, 5]                      # and ties
+    vals, idx = select.topk_rows(keys.to(dev), k)
+    sv, si = torch.sort(keys, dim=1, descending=True, stable=True)
+    assert torch.equal(idx.cpu().long(), si[:, :k]) and torch.equal(vals.cpu(), sv[:, :k])
+
+
 def _strided_topk(dev):
     from omni3d_amd.kernels import select
     g = torch.Generator().manual_seed(5)
@@ -91,6 +106,9 @@ def test_topk_emulated(emu_lib):
     _topk_case("cpu", 3, 3000, 64, 2, ties=True)
     _topk_case("cpu", 1, 66000, 100, 3, ties=True)    # > 65536 elements: the streamed variant (rows are not cached in registers)
     _topk_case("cpu", 1, 65536, 40, 4)                # the largest cached row
+    _topk_case("cpu", 1, 9000, 3072, 5, ties=True)    # the largest k of the two-level selection
+    _topk_case("cpu", 1, 9000, 3073, 6, ties=True)    # one more: cached full selection
+    _topk_prefilter_overflow("cpu")
     _strided_topk("cpu")
 
 
@@ -107,6 +125,8 @@ def test_topk_gpu(hip_lib):
     _topk_case("cuda", 4, 6960, 1000, 3, ties=True)
     _topk_case("cuda", 2, 70000, 300, 4, ties=True)   # streamed variant
     _topk_case("cuda", 2, 65536, 8192, 5)
+    _topk_case("cuda", 3, 30000, 3072, 6, ties=True)
+    _topk_prefilter_overflow("cuda")
     _strided_topk("cuda")
 
 
