@@ -226,6 +226,14 @@ int omni_rpn_decode(const void* const* level_ptrs, const int* level_hw, int nlev
                     const int* slot_level, const int* idx, const float* anchors, const int* image_hw,
                     float scale_clamp, float min_size, float* boxes, int* valid, void* stream);
 
+/* Post-NMS glue of find_top_rpn_proposals (detectron2; the `keep[:post_nms_topk]` step of the RPN configured in
+ * /root/reference/configs/Base.yaml:49-54).  omni_rpn_mask_scores: masked (n) = keep ? scores : -inf, the input of the
+ * post-NMS ranking.  omni_rpn_collect: boxes (B,N,4), top_v / top_i (B,P) = that ranking (sorted, -inf / -1 padded)
+ * -> prop (B,P,4) (zeros behind the real ones), count (B). */
+int omni_rpn_mask_scores(const float* scores, const int* keep, long long n, float* masked, void* stream);
+int omni_rpn_collect(const float* boxes, const float* top_v, const int* top_i, int B, int N, int P, float* prop,
+                     int* count, void* stream);
+
 /* ROIHeads3D.label_and_sample_proposals (roi_heads.py:862-929): append GT, Matcher(iou_thr), ignore
  * regions, IoU-weighted sampling of <= nfg_max foreground + background up to batch_per_image.
  * expo (B, 2048).  Outputs (B, batch_per_image): boxes, class (num_classes = bg, -2 = padding),
@@ -305,6 +313,16 @@ int omni_conv2d_fwd_stats(const float* x, const float* w, float* out, int N, int
                           int stride, int pad, int ldx, int ldo, float* stats, int stats_rows, int* nblk_out, void* stream);
 int omni_wino_out_stats(const float* M, float* y, int N, int H, int W, int K, int tile, float* stats, int stats_rows,
                         int* nblk_out, void* stream);
+/* The same idea in the backward pass: the Winograd data-gradient transform of the convolution ABOVE a BatchNorm(+ReLU) writes that
+ * BatchNorm's output gradient dy, and emits the per-workgroup partial sums (sum dz, sum dz * xhat) its backward pass starts with
+ * (dz = dy masked by x * scale + shift > 0 when scale_shift != NULL); omni_bn_bwd_partials = finalize + apply on those rows
+ * (arguments as omni_bn_bwd).  *nblk_out == 0: not produced, run omni_bn_bwd. */
+int omni_wino_out_bn_bwd_stats(const float* M, float* y, int N, int H, int W, int K, int tile, const float* bn_x,
+                               const float* mean_rstd, const float* scale_shift, float* stats, int stats_rows, int* nblk_out,
+                               void* stream);
+int omni_bn_bwd_partials(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd,
+                         const float* partial, int nblk, float* dx, float* dres, float* dgamma, float* dbeta, float* coef,
+                         int P, int C, int relu, int accumulate_param_grads, void* stream);
 int omni_stem_conv_fwd_stats(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx,
                              int ldo, float* stats, int stats_rows, int* nblk_out, void* stream);
 int omni_bn_fwd_partials(const float* x, const float* partial, int nblk, const float* gamma, const float* beta,

@@ -542,6 +542,20 @@ int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* ga
     return omni_launch_status();
 }
 
+// omni_bn_bwd with the reductions already done by the kernel that produced dy (omni_wino_out_bn_bwd_stats): finalize + apply.
+int omni_bn_bwd_partials(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd,
+                         const float* partial, int nblk, float* dx, float* dres, float* dgamma, float* dbeta, float* coef, int P,
+                         int C, int relu, int accumulate_param_grads, void* stream) {
+    if (P <= 0 || C <= 0 || (C & 3) || C > 4096 || nblk <= 0 || relu < 0 || relu > 2 || (relu && y == nullptr)) return OMNI_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, partial, nblk, P, C, gamma, mean_rstd,
+                       dgamma, dbeta, coef, accumulate_param_grads);
+    const long total4 = (long)P * (C >> 2);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, dy, y, mean_rstd, (const float*)coef, dx, dres,
+                       total4, C, relu);
+    return omni_launch_status();
+}
+
 int omni_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
     if ((C & 3) || H < 2 || W < 2) return OMNI_ERR_ARG;
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);

@@ -514,6 +514,39 @@ Levels make_levels(const void* const* ptrs, const int* hw, int nlev) {
 
 }  // namespace
 
+namespace {
+
+// ---- glue of find_top_rpn_proposals after NMS (detectron2; rpn.py call site): two launches instead of eleven element-wise ones ----
+// masked[i] = keep[i] ? scores[i] : -inf   (the suppressed / invalid candidates leave the post-NMS ranking)
+__global__ void rpn_mask_scores_kernel(const float* __restrict__ scores, const int* __restrict__ keep, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = keep[i] != 0 ? scores[i] : -INFINITY;
+}
+// proposals of image b: prop[b][p] = boxes[b][top_i[b][p]] where the p-th ranked score is a real one (> -inf), zeros after them;
+// count[b] = number of real ones.  One workgroup per image.
+__global__ void __launch_bounds__(256) rpn_collect_kernel(const float* __restrict__ boxes, const float* __restrict__ top_v,
+                                                          const int* __restrict__ top_i, int N, int P, float* __restrict__ prop,
+                                                          int* __restrict__ count) {
+    __shared__ int part[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    int c = 0;
+    for (int p = t; p < P; p += 256) {
+        const bool ok = top_v[(long)b * P + p] > -INFINITY;
+        int gi = top_i[(long)b * P + p];
+        gi = gi < 0 ? 0 : gi;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = ldbox(boxes + ((long)b * N + gi) * 4);
+        *reinterpret_cast<float4*>(prop + ((long)b * P + p) * 4) = v;
+        c += ok ? 1 : 0;
+    }
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((t & 63) == 0) part[t >> 6] = c;
+    __syncthreads();
+    if (t == 0) count[b] = part[0] + part[1] + part[2] + part[3];
+}
+
+}  // namespace
+
 static inline long rpn_loss_blocks(long tot) {
     const long b = (tot + 255) / 256;
     return b < RPN_LOSS_MAX_BLOCKS ? b : RPN_LOSS_MAX_BLOCKS;
@@ -641,6 +674,22 @@ int omni_rpn_loss_plain_bwd(const void* const* level_ptrs, const void* const* dl
     if (tot == 0) return OMNI_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_loss_plain_kernel<1>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lv, dlv,
                        B, A, anchors, labels, matched_idx, gt, gt_off, (double*)nullptr, g_cls, g_loc, inv_norm);
+    return omni_launch_status();
+}
+
+// masked (n) = keep ? scores : -inf
+int omni_rpn_mask_scores(const float* scores, const int* keep, long long n, float* masked, void* stream) {
+    if (n < 0) return OMNI_ERR_ARG;
+    if (n == 0) return OMNI_OK;
+    hipLaunchKernelGGL(rpn_mask_scores_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, keep, (long)n, masked);
+    return omni_launch_status();
+}
+
+// boxes (B, N, 4); top_v / top_i (B, P): the post-NMS ranking (sorted scores, -inf / -1 padded) -> prop (B, P, 4), count (B)
+int omni_rpn_collect(const float* boxes, const float* top_v, const int* top_i, int B, int N, int P, float* prop, int* count, void* stream) {
+    if (B < 0 || N < 0 || P < 0) return OMNI_ERR_ARG;
+    if (B == 0) return OMNI_OK;
+    hipLaunchKernelGGL(rpn_collect_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, boxes, top_v, top_i, N, P, prop, count);
     return omni_launch_status();
 }
 

@@ -381,16 +381,18 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __
 // ---- NMS ---------------------------------------------------------------------------------------
 // problem q: boxes[q*nmax .. q*nmax + count[q]) sorted by descending score; valid[] == 0 marks boxes
 // that take no part (empty / non-finite).  mask: (Q, nmax, words) 64-bit, words = ceil(nmax/64).
-__global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
-                                                      int nmax, int words, float thr,
-                                                      unsigned long long* __restrict__ mask) {
-    const int q = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+// One 4-wave workgroup = 4 row blocks x one column block (the 64 column boxes are staged in LDS once for the four); round 3:
+// one wave per workgroup before, 20 000 tiny workgroups for the 20 problems of a training step.
+__global__ void __launch_bounds__(256) nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
+                                                       int nmax, int words, float thr,
+                                                       unsigned long long* __restrict__ mask) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.z, rb = blockIdx.y * 4 + wave, cb = blockIdx.x;
     const int n = counts ? counts[q] : nmax;
-    if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+    if ((int)blockIdx.y * 4 > cb || cb * 64 >= n) return;            // (uniform) nothing above the diagonal / past the count here
     __shared__ float cbx[64 * 4];
-    const int lane = threadIdx.x;
     const float* B = boxes + (long)q * nmax * 4;
-    {
+    if (wave == 0) {
         const int j = cb * 64 + lane;
         if (j < n) {
             cbx[lane * 4 + 0] = B[j * 4 + 0]; cbx[lane * 4 + 1] = B[j * 4 + 1];
@@ -398,6 +400,7 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
+    if (cb < rb || rb * 64 >= n) return;
     const int i = rb * 64 + lane;
     if (i >= n) return;
     const float x1 = B[i * 4 + 0], y1 = B[i * 4 + 1], x2 = B[i * 4 + 2], y2 = B[i * 4 + 3];
@@ -416,33 +419,32 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ 
     mask[((long)q * nmax + i) * words + cb] = bits;
 }
 
-__global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long* __restrict__ mask,
-                                                        const int* __restrict__ counts, const int* __restrict__ valid,
-                                                        int nmax, int words, int* __restrict__ keep) {
-    // One 16-wave workgroup per problem.  Per 64-box chunk: wave 0 resolves the chunk greedily (the only serial
-    // part: 64 shuffle steps), then the 16 waves OR the mask rows of the kept boxes (4 rows each -- the row loads
-    // are the latency that dominated the one-wave version) into per-wave partials, combined in LDS into the
-    // running `removed` words (<= 128 words = 8192 boxes).
-    constexpr int MAXW = 128;
+constexpr int NMS_SCAN_WAVES = 4;
+__global__ void __launch_bounds__(64 * NMS_SCAN_WAVES) nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                                       const int* __restrict__ counts, const int* __restrict__ valid,
+                                                                       int nmax, int words, int* __restrict__ keep) {
+    // One 4-wave workgroup per problem.  Per 64-box chunk: wave 0 resolves the chunk greedily (64 shuffle steps), then every wave
+    // ORs the mask rows of the kept boxes among ITS 16 rows of the chunk into a running per-wave `removed` set that lives in
+    // registers (lane l holds words l and 64 + l: <= 128 words = 8192 boxes).  The only word anybody needs next is word c + 1, so
+    // each wave publishes that one word and wave 0 ORs the four -- two barriers per chunk.
+    // Round 3: (1) the mask rows of a chunk are fetched BEFORE its resolution decides which are needed (all 64, selected by the
+    // `alive` bits afterwards): the loads of chunk c + 1 fly under the work of chunk c instead of sitting between two barriers;
+    // (2) 4 waves and 2 barriers per chunk instead of 16 waves and 3 (the barriers of the 32 chunks of a 2000-box problem were
+    // most of the kernel).  Only entries the mask kernel wrote are ever selected (row < n, word > chunk, word * 64 < n), so the
+    // scratch needs no zeroing.
+    constexpr int RPW = 64 / NMS_SCAN_WAVES;            // rows of a chunk per wave
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = counts ? counts[q] : nmax;
     __shared__ unsigned long long s_alive;
-    __shared__ unsigned long long s_removed[MAXW];
-    __shared__ unsigned long long s_part[16][MAXW];
-    if (tid < MAXW) s_removed[tid] = 0ull;
-    for (int i = n + tid; i < nmax; i += 1024) keep[(long)q * nmax + i] = 0;      // boxes beyond the count are never kept
-    __syncthreads();
+    __shared__ unsigned long long s_next[NMS_SCAN_WAVES];
+    for (int i = n + tid; i < nmax; i += 64 * NMS_SCAN_WAVES) keep[(long)q * nmax + i] = 0;      // boxes beyond the count are never kept
     const int nchunks = (n + 63) / 64;
-    // Round 3: the mask rows of a chunk are fetched BEFORE its greedy resolution decides which of them are needed (all 64 rows, 4 per
-    // wave, selected by the `alive` bits afterwards): the loads of chunk c+1 fly under the LDS combine of chunk c and the serial
-    // resolution of chunk c+1 instead of sitting between two barriers (32 chunks x ~2 us of exposed latency per 2000-box problem).
-    // Only entries the mask kernel wrote are ever selected (row < n, word > chunk, word * 64 < n), so the scratch needs no zeroing.
-    unsigned long long rw0[4], rw1[4], diag = 0ull;
+    unsigned long long rw0[RPW], rw1[RPW], diag = 0ull, acc0 = 0ull, acc1 = 0ull, removed_c = 0ull;
     int okv = 0;
     auto fetch = [&](int c) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int row = c * 64 + wave * 4 + rr;
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int row = c * 64 + wave * RPW + rr;
             const long rowbase = ((long)q * nmax + row) * words;
             const int w0 = lane, w1 = 64 + lane;
             rw0[rr] = (row < n && w0 > c && w0 < words && w0 * 64 < n) ? mask[rowbase + w0] : 0ull;
@@ -459,7 +461,7 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
         if (wave == 0) {
             const int i = c * 64 + lane;
             // start state of this chunk: not removed by earlier keeps, and a valid box
-            unsigned long long alive = __ballot(okv != 0) & ~s_removed[c];
+            unsigned long long alive = __ballot(okv != 0) & ~removed_c;
             for (int r = 0; r < 64; ++r) {
                 const unsigned long long d = __shfl(diag, r, 64);
                 if ((alive >> r) & 1ull) alive &= ~d;
@@ -469,22 +471,21 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
         }
         __syncthreads();
         const unsigned long long alive = s_alive;
-        unsigned long long part0 = 0ull, part1 = 0ull;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            if ((alive >> (wave * 4 + rr)) & 1ull) { part0 |= rw0[rr]; part1 |= rw1[rr]; }
+        for (int rr = 0; rr < RPW; ++rr) {
+            if ((alive >> (wave * RPW + rr)) & 1ull) { acc0 |= rw0[rr]; acc1 |= rw1[rr]; }
         }
-        s_part[wave][lane] = part0;
-        s_part[wave][64 + lane] = part1;
+        // word c + 1 of this wave's removed set sits in lane (c + 1) % 64 of acc0 (c + 1 < 64) or acc1
+        const int nw = c + 1;
+        const unsigned long long mine = __shfl(nw < 64 ? acc0 : acc1, nw & 63, 64);
+        if (lane == 0) s_next[wave] = mine;
         if (c + 1 < nchunks) fetch(c + 1);
         __syncthreads();
-        if (tid < MAXW) {
-            unsigned long long v = s_removed[tid];
+        if (wave == 0) {
+            removed_c = 0ull;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v |= s_part[k][tid];
-            s_removed[tid] = v;
+            for (int k = 0; k < NMS_SCAN_WAVES; ++k) removed_c |= s_next[k];
         }
-        __syncthreads();
     }
 }
 
@@ -548,9 +549,9 @@ int omni_nms_sorted(const float* boxes, const int* counts, const int* valid, int
     if (Q == 0 || nmax == 0) return OMNI_OK;
     const int words = (nmax + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, Q), dim3(64), 0, st, boxes, counts, nmax, words, iou_thr,
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, (words + 3) / 4, Q), dim3(256), 0, st, boxes, counts, nmax, words, iou_thr,
                        mask_ws);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(Q), dim3(1024), 0, st, (const unsigned long long*)mask_ws, counts, valid, nmax,
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(Q), dim3(64 * NMS_SCAN_WAVES), 0, st, (const unsigned long long*)mask_ws, counts, valid, nmax,
                        words, keep);
     return omni_launch_status();
 }

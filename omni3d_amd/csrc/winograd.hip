@@ -325,12 +325,28 @@ __global__ void __launch_bounds__(256) wino4_in_kernel(const float* __restrict__
     }
 }
 
+// BatchNorm-BACKWARD statistics of the layer below a data-gradient transform (bnb.x != nullptr): the tensor written here is the
+// gradient dy of a BatchNorm(+ReLU) output, and that layer's backward pass starts with the per-channel sums of dz and dz * xhat
+// (dz = dy masked by the ReLU, xhat = (x - mean) * rstd of the BatchNorm INPUT x) -- bn_reduce_kernel<1>, one more pass over dy
+// and x.  Here every dy value is in a register already: the thread reads x at the same offset and accumulates both sums, one
+// partial row per workgroup like the forward statistics.
+struct BnBwdStats {
+    const float* x;             // BatchNorm input, same (N, H, W, K) layout as the tensor written here
+    const float* mean_rstd;     // 2K
+    const float* scale_shift;   // 2K, or nullptr: no ReLU on that layer
+};
 __global__ void __launch_bounds__(256) wino4_out_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                         float* __restrict__ y, int N, int H, int W, int K, int relu,
-                                                        float* __restrict__ stats) {
+                                                        float* __restrict__ stats, BnBwdStats bnb) {
     const int K4 = K >> 2, TH = H >> 2, TW = W >> 2;
     const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
     float4 sv = z4(), sq = z4();
+    float4 mu = z4(), rs = z4(), sc = z4(), sh = z4();
+    if (bnb.x != nullptr) {            // (the statistics modes keep ONE channel group per thread: 256 % K4 == 0)
+        const int kc = 4 * (int)(threadIdx.x % K4);
+        mu = ld4(bnb.mean_rstd + kc); rs = ld4(bnb.mean_rstd + K + kc);
+        if (bnb.scale_shift != nullptr) { sc = ld4(bnb.scale_shift + kc); sh = ld4(bnb.scale_shift + K + kc); }
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k4 = (int)(i % K4);
         const long t = i / K4;
@@ -353,13 +369,33 @@ __global__ void __launch_bounds__(256) wino4_out_kernel(const float* __restrict_
         for (int r = 0; r < 4; ++r) {
             float4 row[4];
             at6(s[r], row);
-            float* o = y + (((long)n * H + 4 * ty + r) * W + 4 * tx) * K + 4 * k4;
+            const long off = (((long)n * H + 4 * ty + r) * W + 4 * tx) * K + 4 * k4;
+            float* o = y + off;
+            if (bnb.x != nullptr) {
+                float4 xv[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float4 v = row[c] + b;
-                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                st4(o + (long)c * K, v);
-                OMNI_ACC_STATS(v);
+                for (int c = 0; c < 4; ++c) xv[c] = ld4(bnb.x + off + (long)c * K);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 v = row[c];
+                    st4(o + (long)c * K, v);
+                    float4 g = v;
+                    if (bnb.scale_shift != nullptr) {      // y > 0 of that layer, recomputed like bn_apply_body computes it
+                        const float4 yv = xv[c] * sc + sh;
+                        g = make_float4(yv.x > 0.f ? v.x : 0.f, yv.y > 0.f ? v.y : 0.f, yv.z > 0.f ? v.z : 0.f, yv.w > 0.f ? v.w : 0.f);
+                    }
+                    const float4 xh = (xv[c] - mu) * rs;
+                    sv = sv + g;
+                    sq = sq + g * xh;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float4 v = row[c] + b;
+                    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    st4(o + (long)c * K, v);
+                    OMNI_ACC_STATS(v);
+                }
             }
         }
     }
@@ -631,7 +667,7 @@ int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile,
 }
 
 static int wino_out_impl(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, float* stats,
-                         int stats_rows, int* nblk_out, void* stream) {
+                         int stats_rows, int* nblk_out, void* stream, BnBwdStats bnb = BnBwdStats{nullptr, nullptr, nullptr}) {
     if (nblk_out) *nblk_out = 0;
     if (bad(N, H, W, K) || (tile != 2 && tile != 4) || (H % tile) || (W % tile)) return OMNI_ERR_ARG;
     const long total = (long)N * (H / tile) * (W / tile) * (K / 4);
@@ -639,18 +675,28 @@ static int wino_out_impl(const float* M, const float* bias, float* y, int N, int
     int grid = ew_grid(total);
     // statistics: one partial row per workgroup; needs a fixed channel group per thread (256 % (K/4) == 0), raw outputs
     float* st_ptr = nullptr;
-    if (stats != nullptr && bias == nullptr && !relu && K >= 4 && (256 % (K / 4)) == 0) {
+    if (stats != nullptr && bias == nullptr && !relu && K >= 4 && (256 % (K / 4)) == 0 && (bnb.x == nullptr || tile == 4)) {
         if (grid > stats_rows) grid = stats_rows;           // fewer, longer-running workgroups rather than no fusion
         if (grid >= 1) { st_ptr = stats; if (nblk_out) *nblk_out = grid; }
         else grid = ew_grid(total);
     }
+    if (st_ptr == nullptr) bnb = BnBwdStats{nullptr, nullptr, nullptr};
     if (tile == 2) hipLaunchKernelGGL(wino_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu, st_ptr);
-    else hipLaunchKernelGGL(wino4_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu, st_ptr);
+    else hipLaunchKernelGGL(wino4_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu, st_ptr, bnb);
     return omni_launch_status();
 }
 
 int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, void* stream) {
     return wino_out_impl(M, bias, y, N, H, W, K, relu, tile, nullptr, 0, nullptr, stream);
+}
+
+// Data-gradient output transform that also emits the BACKWARD partial statistics of the BatchNorm whose output gradient it writes
+// (see BnBwdStats): stats [rows][2][K] = per-workgroup (sum dz, sum dz * xhat); *nblk_out = rows written, 0 = not produced (F(2x2)
+// tiles, channel count without a fixed group per thread) and the caller runs omni_bn_bwd.  scale_shift nullable (no ReLU).
+int omni_wino_out_bn_bwd_stats(const float* M, float* y, int N, int H, int W, int K, int tile, const float* bn_x, const float* mean_rstd,
+                               const float* scale_shift, float* stats, int stats_rows, int* nblk_out, void* stream) {
+    if (bn_x == nullptr || mean_rstd == nullptr) return OMNI_ERR_ARG;
+    return wino_out_impl(M, nullptr, y, N, H, W, K, 0, tile, stats, stats_rows, nblk_out, stream, BnBwdStats{bn_x, mean_rstd, scale_shift});
 }
 
 // Output transform (no bias, no ReLU) that also emits BatchNorm partial statistics [rows][2][K]; *nblk_out = rows written (0 = none)

@@ -173,15 +173,12 @@ class RPNWithIgnore(nn.Module):
             self._slot_key = key
         boxes, valid = det.rpn_decode(pack, self._slot_level, idx, anchors, image_hw, self.min_box_size)
         keep = select.nms_sorted(boxes.view(B * L, kmax, 4), self.nms_thresh, None, valid.view(B * L, kmax)).view(B, L * kmax)
-        masked = torch.where(keep != 0, scores, torch.full_like(scores, float("-inf")))
+        masked = det.rpn_mask_scores(scores.contiguous(), keep.contiguous())     # suppressed / invalid candidates -> -inf
         top_v, top_i = select.topk_rows(masked, post)                             # keep[:post_nms_topk], score order
-        ok = top_v > float("-inf")
-        gi = top_i.clamp(min=0).long()
-        prop = torch.gather(boxes, 1, gi[:, :, None].expand(-1, -1, 4)) * ok[:, :, None]
-        count = ok.sum(dim=1).to(torch.int32)
+        prop, count = det.rpn_collect(boxes, top_v, top_i)                        # boxes of the real entries, zeros behind; #real
         if getattr(self, "keep_candidates", False):      # parity tests: the pre-NMS candidate lists behind the proposal set
             self.last_candidates = {"boxes": boxes, "scores": scores, "keep": keep, "valid": valid.view(B, L * kmax), "slots_per_level": kmax}
-        return prop.contiguous(), top_v, count
+        return prop, top_v, count
 
     def forward(self, images, features, gt_instances=None, targets=None):
         """Reference contract (rpn.py / detectron2 RPN.forward): `gt_instances` = list[Instances] with gt_boxes / gt_classes

@@ -178,6 +178,7 @@ class _WinoConv3x3(Function):
     def forward(ctx, x, w, bias, relu, want_stats=False):
         ctx.set_materialize_grads(False)      # no zero tensors for the non-differentiable side outputs
         ctx.direct = (_direct_grad(w), _direct_grad(bias))
+        ctx.bn_below = getattr(x, "_omni_bn_below", None)      # x is the output of a BatchNorm(+ReLU) without residual
         x, w = _cl(x), _cl(w)
         # one launch yields the forward transform U and (when the data gradient will also go through Winograd) U' of
         # the rotated filter; a weight shared by several calls of one step (the RPN conv over the FPN levels) is
@@ -216,7 +217,7 @@ class _WinoConv3x3(Function):
             gw = None
         dx = dw = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and wino.dgrad_eligible(dy.shape):
-            dx, dw = wino.conv3x3_backward(V, dy, w, Uf, accum_into=gw, side_run=_side_run)   # both transforms of dy in one pass
+            dx, dw = wino.conv3x3_backward(V, dy, w, Uf, accum_into=gw, side_run=_side_run, bn_below=ctx.bn_below)   # both transforms of dy in one pass
         else:
             if ctx.needs_input_grad[0]:
                 dx = (wino.conv3x3_dgrad(dy, w, U_flip=Uf, tile=2 if V.shape[0] == 16 else 4) if wino.dgrad_eligible(dy.shape)
@@ -341,6 +342,7 @@ def linear(x, w, bias=None, relu=False, w_grad_view=None):
 
 
 _BN_REMASK = _os_environ_get("OMNI_BN_REMASK", "1") != "0"     # A/B knob
+_BN_BWD_FUSE = _os_environ_get("OMNI_BN_BWD_FUSE", "1") != "0"  # A/B knob: backward reductions from the data-gradient transform above
 
 
 class _BatchNorm(Function):
@@ -356,14 +358,20 @@ class _BatchNorm(Function):
         remask = relu and residual is None and _BN_REMASK
         ctx.save_for_backward(x, gamma, mean_rstd, (y if relu and not remask else None), (scale_shift if remask else None))
         ctx.cfg = (relu, residual is not None)
+        if _BN_BWD_FUSE and residual is None and (remask or not relu):
+            # what the convolution that consumes y needs to leave this layer's backward reductions behind (_WinoConv3x3.backward)
+            y._omni_bn_below = (x, mean_rstd, scale_shift if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean_rstd, y, scale_shift = ctx.saved_tensors
         relu, has_res = ctx.cfg
+        parts = getattr(dy, "_omni_bn_bwd_parts", None)
+        if parts is not None:       # made for THIS layer (same statistics tensor), and dy reached us unchanged
+            parts = parts[0] if parts[1].data_ptr() == mean_rstd.data_ptr() and dy.is_contiguous(memory_format=CL) else None
         dx, dres, dgamma, dbeta = bnpool.bn_bwd(x, _cl(dy), y, gamma, mean_rstd, relu, want_dres=has_res and ctx.needs_input_grad[5],
-                                                accum_into=ctx.direct, scale_shift=scale_shift)
+                                                accum_into=ctx.direct, scale_shift=scale_shift, partials=parts)
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 

@@ -44,10 +44,11 @@ def bn_apply(x, scale_shift, residual=None, relu=False):
     return y.permute(0, 3, 1, 2)
 
 
-def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=None, scale_shift=None):
+def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=None, scale_shift=None, partials=None):
     """-> (dx CL, dres CL or None, dgamma, dbeta).  accum_into = (dgamma_buf, dbeta_buf): the parameter
     gradients are added to those buffers instead (dgamma/dbeta returned as None).  scale_shift (2C, from bn_fwd) instead of y:
-    the ReLU mask of a layer WITHOUT residual is recomputed from x (mode 2 of omni_bn_bwd), the output tensor is not read."""
+    the ReLU mask of a layer WITHOUT residual is recomputed from x (mode 2 of omni_bn_bwd), the output tensor is not read.
+    partials (nblk, 2C): the reductions over dy already made by the kernel that produced dy (wino.transform_output_bn_bwd)."""
     xv, dyv = _nhwc(x), _nhwc(dy)
     mode = int(bool(relu))
     if relu and scale_shift is not None:
@@ -65,8 +66,16 @@ def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=N
     else:
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-    ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
     coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
+    if partials is not None:
+        assert partials.is_contiguous() and partials.shape[1] == 2 * C
+        L.call("omni_bn_bwd_partials", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(partials),
+               partials.shape[0], _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(coef), N * H * W, C, mode,
+               int(accum_into is not None), _lib.stream_of(x))
+        if accum_into is not None:
+            dgamma = dbeta = None
+        return dx.permute(0, 3, 1, 2), (dres.permute(0, 3, 1, 2) if want_dres else None), dgamma, dbeta
+    ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
     L.call("omni_bn_bwd", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(dx),
            _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, mode,
            int(accum_into is not None), _lib.stream_of(x))

@@ -131,6 +131,27 @@ def rpn_decode(pack, slot_level, idx, anchors, image_hw, min_size=0.0):
     return boxes, valid
 
 
+def rpn_mask_scores(scores, keep):
+    """-> scores where keep != 0 else -inf (same shape)"""
+    L = _dev(scores, keep)
+    assert scores.is_contiguous() and keep.is_contiguous() and keep.dtype == torch.int32 and scores.shape == keep.shape
+    out = _empty(tuple(scores.shape), torch.float32, scores)
+    L.call("omni_rpn_mask_scores", _lib.ptr(scores), _lib.ptr(keep), scores.numel(), _lib.ptr(out), _lib.stream_of(scores))
+    return out
+
+
+def rpn_collect(boxes, top_v, top_i):
+    """boxes (B, N, 4), top_v / top_i (B, P) -> (prop (B, P, 4), count (B) int32)"""
+    L = _dev(boxes, top_v, top_i)
+    B, N, _ = boxes.shape
+    P = top_v.shape[1]
+    assert boxes.is_contiguous() and top_v.is_contiguous() and top_i.is_contiguous() and top_i.dtype == torch.int32
+    prop = _empty((B, P, 4), torch.float32, boxes)
+    count = _empty((B,), torch.int32, boxes)
+    L.call("omni_rpn_collect", _lib.ptr(boxes), _lib.ptr(top_v), _lib.ptr(top_i), B, N, P, _lib.ptr(prop), _lib.ptr(count), _lib.stream_of(boxes))
+    return prop, count
+
+
 ROI_MAXC = 2048
 
 

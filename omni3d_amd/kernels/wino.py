@@ -121,6 +121,24 @@ def transform_output_stats(Mt, shape):
     return y.permute(0, 3, 1, 2), (stats[:cell.value] if cell.value > 0 else None)
 
 
+def transform_output_bn_bwd(Mt, shape, bn_x, mean_rstd, scale_shift):
+    """data-gradient transform_output that also emits the backward partial statistics of the BatchNorm whose output gradient it
+    writes (bn_x: that layer's input, (N,K,H,W) CL; scale_shift None = no ReLU) -> (dy, partial (nblk, 2K) or None)"""
+    from .conv import STATS_ROWS, _nblk_cell, _stats_buf
+    tile = 2 if Mt.shape[0] == 16 else 4
+    N, H, W = shape
+    K = Mt.shape[2]
+    xv = bn_x.permute(0, 2, 3, 1)
+    assert xv.is_contiguous() and tuple(xv.shape) == (N, H, W, K)
+    L = _lib.check_device(Mt, xv, mean_rstd, scale_shift)
+    y = torch.empty((N, H, W, K), dtype=torch.float32, device=Mt.device)
+    stats = _stats_buf(K, Mt.device)
+    cell, addr = _nblk_cell()
+    L.call("omni_wino_out_bn_bwd_stats", _lib.ptr(Mt), _lib.ptr(y), N, H, W, K, tile, _lib.ptr(xv), _lib.ptr(mean_rstd), _lib.ptr(scale_shift),
+           _lib.ptr(stats), STATS_ROWS, addr, _lib.stream_of(Mt))
+    return y.permute(0, 3, 1, 2), (stats[:cell.value] if cell.value > 0 else None)
+
+
 def transform_dy(dy, tile=2):
     """dy (N,K,H,W) CL -> dM (P,T,K)"""
     dv = _nhwc(dy)
@@ -188,7 +206,7 @@ def conv3x3_dgrad(dy, w, U_flip=None, tile=2):
     return transform_output(Mt, (N, H, W))
 
 
-def conv3x3_backward(V, dy, w, U_flip, accum_into=None, side_run=None):
+def conv3x3_backward(V, dy, w, U_flip, accum_into=None, side_run=None, bn_below=None):
     """data gradient + weight gradient through Winograd with ONE pass over dy -> (dx, dw or None when accumulated).
     side_run(fn, keepalive): runs the weight-gradient half (batched GEMM + transform back, accumulated in place) on the
     weight-gradient stream (functional._side_run)."""
@@ -201,7 +219,14 @@ def conv3x3_backward(V, dy, w, U_flip, accum_into=None, side_run=None):
         dw = None
     if U_flip is None:
         U_flip = transform_weights(w, want_u=False, want_flip=True, tile=tile)[1]
-    dx = transform_output(gemm_batched(Vd, U_flip), (N, H, W))
+    if bn_below is not None and tile == 4:
+        # the input of this convolution is the output of a BatchNorm(+ReLU): dx is that layer's dy, and the transform that writes
+        # it also leaves the partial sums the BatchNorm backward starts with (functional._BatchNorm.backward picks them up)
+        dx, parts = transform_output_bn_bwd(gemm_batched(Vd, U_flip), (N, H, W), *bn_below[:3])
+        if parts is not None:
+            dx._omni_bn_bwd_parts = (parts, bn_below[1])
+    else:
+        dx = transform_output(gemm_batched(Vd, U_flip), (N, H, W))
     if side_run is None or accum_into is None:
         dw = transform_dweights(gemm_batched_wgrad(V, dM), accum_into)
     return dx, dw

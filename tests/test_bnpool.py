@@ -191,3 +191,57 @@ def test_bias_grad_accumulates_with_atomics(hip_lib):
             bnpool.bias_grad(dy2, accum_into=acc)
         want = dy2.double().sum(0) * 3
         assert (acc.double() - want).abs().max() < 1e-3 * max(1.0, want.abs().max().item())
+
+
+def _run_bn_bwd_stats_from_dgrad(dev, relu):
+    """conv -> BatchNorm(+ReLU) -> 3x3 conv: the Winograd data-gradient transform of the second convolution leaves the BatchNorm's
+    backward reductions behind (functional._BatchNorm.backward must pick them up) -- same gradients as the three-kernel backward"""
+    from omni3d_amd import functional as HF
+    from omni3d_amd.kernels import bnpool, wino
+    g = torch.Generator().manual_seed(8)
+    N, C, H, W = 4, 128, 32, 32          # a DLA level-4-like block: 256 tiles of 4 x 4, Winograd F(4x4,3x3) forward and data gradient
+    x0 = torch.randn(N, C, H, W, generator=g).contiguous(memory_format=torch.channels_last).to(dev)
+    w1 = (torch.randn(C, C, 3, 3, generator=g) * 0.05).contiguous(memory_format=torch.channels_last).to(dev)
+    w2 = (torch.randn(C, C, 3, 3, generator=g) * 0.05).contiguous(memory_format=torch.channels_last).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    dout = torch.randn(N, C, H, W, generator=g).contiguous(memory_format=torch.channels_last).to(dev)
+    assert wino.eligible((N, C, H, W), (C, C, 3, 3), 1, 1) and wino.dgrad_eligible((N, C, H, W)) and wino.tile_size((N, C, H, W)) == 4
+    taken = []
+    real = bnpool.bn_bwd
+
+    def spy(*a, **kw):
+        taken.append(kw.get("partials") is not None)
+        return real(*a, **kw)
+
+    def run(fuse):
+        HF._BN_BWD_FUSE = fuse
+        xs = [t.clone().requires_grad_(True) for t in (x0, w1, w2, gamma, beta)]
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        y = HF.batch_norm_train(HF.conv2d(xs[0], xs[1], None, 1, 1, False, True), xs[3], xs[4], rm, rv, relu=relu)
+        out = HF.conv2d(y, xs[2], None, 1, 1)
+        bnpool.bn_bwd = spy
+        try:
+            (out * dout).sum().backward()
+        finally:
+            bnpool.bn_bwd = real
+        return [t.grad.clone() for t in xs]
+    try:
+        ga = run(True)
+        assert taken == [True], taken
+        gb = run(False)
+        assert taken == [True, False], taken
+    finally:
+        HF._BN_BWD_FUSE = True
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_backward_statistics_from_dgrad_emulated(emu_lib, relu):
+    _run_bn_bwd_stats_from_dgrad("cpu", relu)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_backward_statistics_from_dgrad_gpu(hip_lib, relu):
+    _run_bn_bwd_stats_from_dgrad("cuda", relu)

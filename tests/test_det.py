@@ -366,6 +366,36 @@ def _run_sgd(dev):
     assert torch.equal(q.cpu(), p0)
 
 
+def _run_rpn_post_nms_glue(dev):
+    """det.rpn_mask_scores / det.rpn_collect == the element-wise torch formulation of find_top_rpn_proposals' last step"""
+    from omni3d_amd.kernels import det, select
+    g = torch.Generator().manual_seed(4)
+    B, N, P = 3, 700, 300
+    boxes = (torch.rand(B, N, 4, generator=g) * 100).to(dev)
+    scores = torch.randn(B, N, generator=g).to(dev)
+    keep = (torch.rand(B, N, generator=g) > 0.7).int().to(dev)
+    keep[1] = 0                                                      # an image whose candidates are all suppressed
+    keep[2, :5] = 1
+    masked = det.rpn_mask_scores(scores, keep)
+    ref_masked = torch.where(keep != 0, scores, torch.full_like(scores, float("-inf")))
+    assert torch.equal(masked, ref_masked)
+    top_v, top_i = select.topk_rows(masked, P)
+    prop, count = det.rpn_collect(boxes, top_v, top_i)
+    ok = top_v > float("-inf")
+    ref = torch.gather(boxes, 1, top_i.clamp(min=0).long()[:, :, None].expand(-1, -1, 4)) * ok[:, :, None]
+    assert torch.equal(prop, ref) and torch.equal(count, ok.sum(dim=1).to(torch.int32))
+    assert int(count[1]) == 0 and float(prop[1].abs().max()) == 0.0
+
+
+def test_rpn_post_nms_glue_emulated(emu_lib):
+    _run_rpn_post_nms_glue("cpu")
+
+
+@pytest.mark.gpu
+def test_rpn_post_nms_glue_gpu(hip_lib):
+    _run_rpn_post_nms_glue("cuda")
+
+
 def test_rpn_labels_emulated(emu_lib):
     _run_rpn_labels("cpu", 64, 1.0, 0)
     _run_rpn_labels("cpu", 512, 0.5, 1)      # not enough positives -> negatives get sampled, ignore path

@@ -115,6 +115,8 @@ def test_topk_emulated(emu_lib):
 def test_nms_emulated(emu_lib):
     _nms_case("cpu", 2, 150, 0.5, 0)
     _nms_case("cpu", 1, 64, 0.7, 1)
+    _nms_case("cpu", 2, 700, 0.5, 2)              # 11 chunks: the per-wave removed sets across many chunks
+    _nms_case("cpu", 1, 4300, 0.6, 3)             # more than 64 words: the second register word of the removed set
 
 
 @pytest.mark.gpu
@@ -134,3 +136,4 @@ def test_topk_gpu(hip_lib):
 def test_nms_gpu(hip_lib):
     _nms_case("cuda", 20, 2000, 0.7, 0)
     _nms_case("cuda", 3, 777, 0.5, 1)
+    _nms_case("cuda", 2, 8192, 0.6, 2)            # the largest problem: 128 words
