@@ -19,6 +19,7 @@
 // rows in 64-box chunks: intra-chunk resolution from the diagonal word, then the kept rows OR their
 // mask rows into the running `removed` words (one 64-bit word per lane).
 #include <device_rt.h>
+#include <cstdlib>
 
 namespace {
 
@@ -419,19 +420,20 @@ __global__ void __launch_bounds__(256) nms_mask_kernel(const float* __restrict__
     mask[((long)q * nmax + i) * words + cb] = bits;
 }
 
-constexpr int NMS_SCAN_WAVES = 4;
+template <int NMS_SCAN_WAVES>
 __global__ void __launch_bounds__(64 * NMS_SCAN_WAVES) nms_scan_kernel(const unsigned long long* __restrict__ mask,
                                                                        const int* __restrict__ counts, const int* __restrict__ valid,
                                                                        int nmax, int words, int* __restrict__ keep) {
-    // One 4-wave workgroup per problem.  Per 64-box chunk: wave 0 resolves the chunk greedily (64 shuffle steps), then every wave
-    // ORs the mask rows of the kept boxes among ITS 16 rows of the chunk into a running per-wave `removed` set that lives in
-    // registers (lane l holds words l and 64 + l: <= 128 words = 8192 boxes).  The only word anybody needs next is word c + 1, so
-    // each wave publishes that one word and wave 0 ORs the four -- two barriers per chunk.
+    // One workgroup of NMS_SCAN_WAVES waves per problem.  Per 64-box chunk: wave 0 resolves the chunk greedily (64 shuffle steps),
+    // then every wave ORs the mask rows of the kept boxes among ITS 64 / NMS_SCAN_WAVES rows of the chunk into a running per-wave
+    // `removed` set that lives in registers (lane l holds words l and 64 + l: <= 128 words = 8192 boxes).  The only word anybody
+    // needs next is word c + 1, so each wave publishes that one word and wave 0 ORs them -- two barriers per chunk.
     // Round 3: (1) the mask rows of a chunk are fetched BEFORE its resolution decides which are needed (all 64, selected by the
     // `alive` bits afterwards): the loads of chunk c + 1 fly under the work of chunk c instead of sitting between two barriers;
-    // (2) 4 waves and 2 barriers per chunk instead of 16 waves and 3 (the barriers of the 32 chunks of a 2000-box problem were
-    // most of the kernel).  Only entries the mask kernel wrote are ever selected (row < n, word > chunk, word * 64 < n), so the
-    // scratch needs no zeroing.
+    // (2) 2 barriers per chunk instead of 3 and no LDS pass over the partial sets.  Measured for the 20 x 2000-box problems of a
+    // training step: 138 us before, 119 us with (1), 181 us with (1) + (2) on 4 waves (16 rows = 32 loads per lane and chunk queue up
+    // behind each other), 16 waves: see profiles/README.md.  Only entries the mask kernel wrote are ever selected (row < n, word >
+    // chunk, word * 64 < n), so the scratch needs no zeroing.
     constexpr int RPW = 64 / NMS_SCAN_WAVES;            // rows of a chunk per wave
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = counts ? counts[q] : nmax;
@@ -448,7 +450,7 @@ __global__ void __launch_bounds__(64 * NMS_SCAN_WAVES) nms_scan_kernel(const uns
             const long rowbase = ((long)q * nmax + row) * words;
             const int w0 = lane, w1 = 64 + lane;
             rw0[rr] = (row < n && w0 > c && w0 < words && w0 * 64 < n) ? mask[rowbase + w0] : 0ull;
-            rw1[rr] = (row < n && w1 > c && w1 < words && w1 * 64 < n) ? mask[rowbase + w1] : 0ull;
+            rw1[rr] = (words > 64 && row < n && w1 > c && w1 < words && w1 * 64 < n) ? mask[rowbase + w1] : 0ull;
         }
         if (wave == 0) {
             const int i = c * 64 + lane;
@@ -551,8 +553,16 @@ int omni_nms_sorted(const float* boxes, const int* counts, const int* valid, int
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, (words + 3) / 4, Q), dim3(256), 0, st, boxes, counts, nmax, words, iou_thr,
                        mask_ws);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(Q), dim3(64 * NMS_SCAN_WAVES), 0, st, (const unsigned long long*)mask_ws, counts, valid, nmax,
-                       words, keep);
+    static const int scan_waves = [] { const char* e = getenv("OMNI_NMS_SCAN_WAVES"); return e ? atoi(e) : 16; }();   // A/B knob
+    if (scan_waves == 4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(nms_scan_kernel<4>), dim3(Q), dim3(256), 0, st, (const unsigned long long*)mask_ws, counts, valid,
+                           nmax, words, keep);
+    else if (scan_waves == 8)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(nms_scan_kernel<8>), dim3(Q), dim3(512), 0, st, (const unsigned long long*)mask_ws, counts, valid,
+                           nmax, words, keep);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(nms_scan_kernel<16>), dim3(Q), dim3(1024), 0, st, (const unsigned long long*)mask_ws, counts, valid,
+                           nmax, words, keep);
     return omni_launch_status();
 }
 

@@ -342,7 +342,10 @@ def linear(x, w, bias=None, relu=False, w_grad_view=None):
 
 
 _BN_REMASK = _os_environ_get("OMNI_BN_REMASK", "1") != "0"     # A/B knob
-_BN_BWD_FUSE = _os_environ_get("OMNI_BN_BWD_FUSE", "1") != "0"  # A/B knob: backward reductions from the data-gradient transform above
+# backward reductions from the data-gradient transform above the layer (wino.transform_output_bn_bwd).  OFF by default: measured
+# neutral on the DLA-34 step (317.9 / 316.2 images/s with, 316.3 without): the transform of a 32x32 / 64x64 map runs on 128-256
+# workgroups and gets 2-3x longer with the extra x reads, which is what the saved reduction launch was worth
+_BN_BWD_FUSE = _os_environ_get("OMNI_BN_BWD_FUSE", "0") != "0"
 
 
 class _BatchNorm(Function):

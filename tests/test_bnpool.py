@@ -225,13 +225,14 @@ def _run_bn_bwd_stats_from_dgrad(dev, relu):
         finally:
             bnpool.bn_bwd = real
         return [t.grad.clone() for t in xs]
+    prev = HF._BN_BWD_FUSE
     try:
         ga = run(True)
         assert taken == [True], taken
         gb = run(False)
         assert taken == [True, False], taken
     finally:
-        HF._BN_BWD_FUSE = True
+        HF._BN_BWD_FUSE = prev
     for a, b in zip(ga, gb):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
 
