@@ -371,6 +371,7 @@ def dominant_kernel_roofline(iters=20):
     dM = torch.randn(P, T, C, device="cuda")
     x1, w1 = torch.randn(2048, 12544, device="cuda"), torch.randn(1024, 12544, device="cuda") * 0.02
     dy1 = torch.randn(2048, 1024, device="cuda")
+    gacc1 = torch.zeros(1024, 12544, device="cuda")
     xs = torch.randn(B, 64, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
     ws = (torch.randn(128, 64, 3, 3, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
     dys = torch.randn(B, 128, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
@@ -398,12 +399,14 @@ def dominant_kernel_roofline(iters=20):
         fam("Winograd weight-gradient GEMMs", "gemm_tn_pf_kernel<4>", "36x[256x4096]x[4096x256] (same layer)", flops,
             lambda: wino.gemm_batched_wgrad(V, dM), grid=147456),      # (PMC: the three weight-gradient shapes share the geometry
                                                                         #  576 workgroups -> one averaged row)
-        fam("FC forward (fc1-class)", "gemm_engine_kernel<0, 0, 128, 128>", "[2048x12544]x[1024x12544]^T box-head fc1", 2.0 * 2048 * 12544 * 1024,
-            lambda: conv.linear_fwd(x1, w1, None), grid=65536),
-        fam("FC data gradient (transpose of W + the engine's NT form)", "gemm_engine_kernel<0, 0, 128, 128>", "[2048x1024]x[12544x1024]^T box-head fc1 (incl. the 51 MB transpose)",
-            2.0 * 2048 * 12544 * 1024, lambda: conv.linear_dgrad(dy1, w1), grid=65536),
-        fam("FC weight gradient", "conv_wgrad_kernel<128, 64, 2, 2, 32>", "[1024x2048]x[2048x12544] box-head fc1", 2.0 * 2048 * 12544 * 1024,
-            lambda: conv.linear_wgrad(x1, dy1), grid=401408),
+        fam("FC forward (fc1-class)", "gemm_engine_kernel<0, 0, 128, 128, false>", "[2048x12544]x[1024x12544]^T box-head fc1 (128 tiles x 2 reduction halves = one round of 256 workgroups)",
+            2.0 * 2048 * 12544 * 1024, lambda: conv.linear_fwd(x1, w1, None), pmc_key="gemm_engine_kernel<0, 0, 128, 128, false>", grid=65536),
+        fam("FC data gradient (transpose of W + the engine's NT form, balanced work split)", "gemm_engine_kernel<0, 0, 128, 128, true>",
+            "[2048x1024]x[12544x1024]^T box-head fc1 (incl. the 51 MB transpose; 1568 tiles = 6 per workgroup + 32 tiles cut in 8)",
+            2.0 * 2048 * 12544 * 1024, lambda: conv.linear_dgrad(dy1, w1), pmc_key="gemm_engine_kernel<0, 0, 128, 128, true>", grid=65536),
+        fam("FC weight gradient (engine TN form, balanced work split, accumulated into the gradient bucket)", "gemm_engine_kernel<1, 1, 128, 128, true>",
+            "[1024x2048]x[2048x12544] box-head fc1 (784 tiles = 3 per workgroup + 16 tiles cut in 16)", 2.0 * 2048 * 12544 * 1024,
+            lambda: conv.linear_wgrad(x1, dy1, accum_into=gacc1), pmc_key="gemm_engine_kernel<1, 1, 128, 128, true>", grid=65536),
         fam("Winograd weight-gradient GEMMs, small maps", "gemm_tn_pf_kernel<4>", "36x[128x1024]x[1024x128] (DLA level 3)", fl3,
             lambda: wino.gemm_batched_wgrad(V3, dM3), grid=147456),
         fam("Winograd weight-gradient GEMMs, small maps (DLA level 4)", "gemm_tn_pf_kernel<4>", "36x[256x256]x[256x256] (DLA level 4)", fl4,

@@ -37,6 +37,10 @@ for name, H, C, K, R, st in CONVS:
 for name, M, C, K in LINEARS:
     x = torch.randn(M, C, device="cuda", requires_grad=True)
     w = (torch.randn(K, C, device="cuda") * 0.02).requires_grad_(True)
+    # the training step's form: the weight gradient is ADDED into the optimizer's flat bucket by the kernel itself (FlatSGD's direct
+    # accumulation) -- for fc1 that is the GEMM engine's TN form with the balanced work split
+    w.grad = torch.zeros_like(w)
+    w._omni_direct_grad = True
     for _ in range(reps):
         y = F.linear(x, w, None)
         y.backward(torch.randn_like(y))
