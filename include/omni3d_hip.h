@@ -259,6 +259,11 @@ int omni_roi_align_fwd(const void* const* level_ptrs, const int* level_hw, const
 int omni_roi_align_bwd(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
                        const float* rois, const int* batch_idx, const int* levels, int R, int P, int C,
                        const float* dout, void* stream);
+/* The same with two gradient tensors (P == 7): dout (R,7,7,C) [nullable] and dout2 ((R / per_image) * first, 7, 7, C) [nullable] for
+ * the first `first` ROIs of every block of `per_image` (the cube head's ROIs are a prefix of the box head's in one shared pass). */
+int omni_roi_align_bwd2(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                        const float* rois, const int* batch_idx, const int* levels, int R, int P, int C,
+                        const float* dout, const float* dout2, int per_image, int first, void* stream);
 
 /* ------------------------------------------------------------------- box-head / cube losses */
 

@@ -147,7 +147,11 @@ template <int PP>
 __global__ void __launch_bounds__(256) roi_align_bwd_sep_kernel(FeatLevels fl, const float* __restrict__ rois,
                                                                 const int* __restrict__ batch_idx,
                                                                 const int* __restrict__ levels, int R, int C,
-                                                                const float* __restrict__ dout) {
+                                                                const float* __restrict__ dout, const float* __restrict__ dout2,
+                                                                int per_image, int first) {
+    // dout (R, PP, PP, C) [nullable]; dout2 [nullable]: a second gradient for the first `first` ROIs of every block of `per_image`
+    // (the cube head pools a prefix of the box head's ROIs from the same ROIAlign pass): added on the fly instead of being merged
+    // into a copy of dout first
     __shared__ __attribute__((aligned(16))) float s_w[4][2][SEP_MAXF][8];    // [wave][y|x][pixel][bin]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int CG = (C + 63) / 64;
@@ -201,13 +205,23 @@ __global__ void __launch_bounds__(256) roi_align_bwd_sep_kernel(FeatLevels fl, c
     __syncthreads();
     if (!any || c >= C) return;
     const float inv_count = 1.f / (float)(gh * gw);
-    const float* o = dout + (long)r * PP * PP * C + c;
+    const float* o = dout != nullptr ? dout + (long)r * PP * PP * C + c : nullptr;
+    const float* o2 = nullptr;
+    if (dout2 != nullptr) {
+        const int img = r / per_image, k = r - img * per_image;
+        if (k < first) o2 = dout2 + ((long)img * first + k) * PP * PP * C + c;
+    }
+    auto gval = [&](int bin) -> float {
+        float v = o != nullptr ? o[(long)bin * C] : 0.f;
+        if (o2 != nullptr) v += o2[(long)bin * C];
+        return v * inv_count;
+    };
     if (sep) {
         float g[PP][PP];
 #pragma unroll
         for (int ph = 0; ph < PP; ++ph)
 #pragma unroll
-            for (int pw = 0; pw < PP; ++pw) g[ph][pw] = o[(long)(ph * PP + pw) * C] * inv_count;
+            for (int pw = 0; pw < PP; ++pw) g[ph][pw] = gval(ph * PP + pw);
         for (int yy = 0; yy < fh; ++yy) {
             float rowT[PP];
 #pragma unroll
@@ -240,7 +254,7 @@ __global__ void __launch_bounds__(256) roi_align_bwd_sep_kernel(FeatLevels fl, c
     // footprint larger than the tables: per-sample scatter (same arithmetic as the forward pass)
     for (int bin = 0; bin < PP * PP; ++bin) {
         const int ph = bin / PP, pw = bin % PP;
-        const float gv = o[(long)bin * C] * inv_count;
+        const float gv = gval(bin);
         for (int iy = 0; iy < gh; ++iy) {
             const float y = sh + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
             for (int ix = 0; ix < gw; ++ix) {
@@ -293,22 +307,40 @@ int omni_roi_align_fwd(const void* const* level_ptrs, const int* level_hw, const
 }
 
 // dlevel_ptrs[l] (same shapes as the features) are ACCUMULATED into with fp32 atomics (caller zeroes).
-int omni_roi_align_bwd(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
-                       const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, const float* dout,
-                       void* stream) {
-    if (nlev <= 0 || nlev > MAXL || (C & 3) || P <= 0) return OMNI_ERR_ARG;
+static int roi_align_bwd_impl(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                              const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, const float* dout,
+                              const float* dout2, int per_image, int first, void* stream) {
+    if (nlev <= 0 || nlev > MAXL || (C & 3) || P <= 0 || (dout == nullptr && dout2 == nullptr)) return OMNI_ERR_ARG;
+    if (dout2 != nullptr && (per_image <= 0 || first < 0 || first > per_image || R % per_image != 0)) return OMNI_ERR_ARG;
     if (R == 0) return OMNI_OK;
     FeatLevels fl = make_feat(dlevel_ptrs, level_hw, level_scale, nlev);
     if (P == 7) {   // the pooler resolution of every Cube R-CNN config: separable, one atomic per footprint pixel
         const long jobs = (long)R * ((C + 63) / 64);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_bwd_sep_kernel<7>), dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
-                           (hipStream_t)stream, fl, rois, batch_idx, levels, R, C, dout);
+                           (hipStream_t)stream, fl, rois, batch_idx, levels, R, C, dout, dout2, per_image, first);
         return omni_launch_status();
     }
+    if (dout == nullptr || dout2 != nullptr) return OMNI_ERR_ARG;          // the general-P kernel takes one gradient
     const long jobs = (long)R * P * P;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_kernel<1>), dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, fl, rois, batch_idx, levels, R, P, C, const_cast<float*>(dout));
     return omni_launch_status();
+}
+
+int omni_roi_align_bwd(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                       const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, const float* dout,
+                       void* stream) {
+    return roi_align_bwd_impl(dlevel_ptrs, level_hw, level_scale, nlev, rois, batch_idx, levels, R, P, C, dout, nullptr, 0, 0, stream);
+}
+
+// The same with two gradient tensors (P == 7): dout (R, 7, 7, C) [nullable] and dout2 ((R / per_image) * first, 7, 7, C) [nullable]
+// for the first `first` ROIs of every block of `per_image` -- the box head's and the cube head's gradients of one shared ROIAlign
+// pass (roi_heads.py:249-357 pools the cube head's ROIs separately; here they are a prefix of the box head's).
+int omni_roi_align_bwd2(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                        const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, const float* dout,
+                        const float* dout2, int per_image, int first, void* stream) {
+    return roi_align_bwd_impl(dlevel_ptrs, level_hw, level_scale, nlev, rois, batch_idx, levels, R, P, C, dout, dout2, per_image, first,
+                              stream);
 }
 
 }  // extern "C"

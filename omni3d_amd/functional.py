@@ -496,15 +496,28 @@ class _ROIAlignShared(Function):
     def backward(ctx, d_all, d_first):
         rois, batch_idx, levels = ctx.saved_tensors
         scales, P, per_image, first, shapes = ctx.meta
-        d = _cl(d_all).permute(0, 2, 3, 1).clone() if d_all is not None else None
-        if d_first is not None:
-            df = _cl(d_first).permute(0, 2, 3, 1)
-            if d is None:
-                d = torch.zeros((rois.shape[0], P, P, df.shape[3]), dtype=torch.float32, device=df.device)
-            C = d.shape[3]
-            d.view(-1, per_image, P, P, C)[:, :first] += df.reshape(-1, first, P, P, C)
-        dfe = [torch.zeros(s, dtype=torch.float32, device=d.device) for s in shapes]
-        det.roi_align_bwd(dfe, scales, rois, batch_idx, levels, P, d)
+        d = _cl(d_all).permute(0, 2, 3, 1) if d_all is not None else None
+        df = _cl(d_first).permute(0, 2, 3, 1) if d_first is not None else None
+        ref = d if d is not None else df
+        # the five level gradients are views of ONE zero-filled slab (one fill launch), and the kernel adds the cube head's gradient
+        # to the box head's on the fly (round 3: a 103 MB clone of d, a strided add and five fills before)
+        sizes = [s[0] * s[1] * s[2] * s[3] for s in shapes]
+        slab = torch.zeros(sum(sizes), dtype=torch.float32, device=ref.device)
+        dfe, off = [], 0
+        for shp, n in zip(shapes, sizes):
+            dfe.append(slab[off:off + n].view(shp))
+            off += n
+        if df is not None and P == 7:
+            det.roi_align_bwd(dfe, scales, rois, batch_idx, levels, P, d, dout2=df.contiguous(), per_image=per_image, first=first)
+        else:
+            if df is not None:            # (general pooler resolution: merge on the host side as before)
+                if d is None:
+                    d = torch.zeros((rois.shape[0], P, P, df.shape[3]), dtype=torch.float32, device=df.device)
+                else:
+                    d = d.clone()
+                C = d.shape[3]
+                d.view(-1, per_image, P, P, C)[:, :first] += df.reshape(-1, first, P, P, C)
+            det.roi_align_bwd(dfe, scales, rois, batch_idx, levels, P, d)
         return (None,) * 7 + tuple(t.permute(0, 3, 1, 2) for t in dfe)
 
 

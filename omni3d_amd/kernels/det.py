@@ -199,13 +199,19 @@ def roi_align_fwd(feats_nhwc, scales, rois, batch_idx, levels, P):
     return out
 
 
-def roi_align_bwd(dfeats_nhwc, scales, rois, batch_idx, levels, P, dout):
-    """accumulates into dfeats (caller-zeroed or holding other gradients)."""
-    L = _dev(rois, batch_idx, levels, dout, *dfeats_nhwc)
+def roi_align_bwd(dfeats_nhwc, scales, rois, batch_idx, levels, P, dout, dout2=None, per_image=0, first=0):
+    """accumulates into dfeats (caller-zeroed or holding other gradients).  dout2 ((R / per_image) * first, P, P, C): a second gradient
+    for the first `first` ROIs of every block of `per_image`, added on the fly (P == 7); dout may then be None."""
+    L = _dev(rois, batch_idx, levels, dout, dout2, *dfeats_nhwc)
     R, C = rois.shape[0], dfeats_nhwc[0].shape[3]
     keep, a = _feat_args(dfeats_nhwc, scales)
-    L.call("omni_roi_align_bwd", *a, _lib.ptr(rois), _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, _lib.ptr(dout),
-           _lib.stream_of(rois))
+    if dout2 is None:
+        L.call("omni_roi_align_bwd", *a, _lib.ptr(rois), _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, _lib.ptr(dout),
+               _lib.stream_of(rois))
+        return
+    assert dout2.is_contiguous() and (dout is None or dout.is_contiguous())
+    L.call("omni_roi_align_bwd2", *a, _lib.ptr(rois), _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, _lib.ptr(dout), _lib.ptr(dout2),
+           int(per_image), int(first), _lib.stream_of(rois))
 
 
 def box_loss_fwd(pred, K, cls, prop, gt, gt_row, weights=(10.0, 10.0, 5.0, 5.0)):

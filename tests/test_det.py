@@ -182,6 +182,23 @@ def _run_roi_align(dev):
     for d, f in zip(dfe, fr):
         fg = f.grad if f.grad is not None else torch.zeros_like(f)
         assert (d.cpu().permute(0, 3, 1, 2) - fg).abs().max() < 2e-5
+    # two gradient tensors in one pass (the box head's for every ROI + the cube head's for the first `first` of every `per_image`)
+    # == one pass over their sum; also with the first one absent
+    per_image, first = 11, 4                                   # 33 ROIs = 3 blocks
+    assert R == 3 * per_image
+    d2 = torch.randn((R // per_image) * first, P, P, C, generator=g)
+    merged = dout.clone()
+    merged.view(-1, per_image, P, P, C)[:, :first] += d2.view(-1, first, P, P, C)
+    only2 = torch.zeros_like(dout)
+    only2.view(-1, per_image, P, P, C)[:, :first] += d2.view(-1, first, P, P, C)
+    for first_grad, want_src in ((dout, merged), (None, only2)):
+        want = [torch.zeros_like(f) for f in fn]
+        det.roi_align_bwd(want, scales, rois.to(dev), bidx.to(dev), lv, P, want_src.to(dev))
+        got2 = [torch.zeros_like(f) for f in fn]
+        det.roi_align_bwd(got2, scales, rois.to(dev), bidx.to(dev), lv, P, None if first_grad is None else first_grad.to(dev),
+                          dout2=d2.to(dev), per_image=per_image, first=first)
+        for a, b in zip(got2, want):
+            assert (a - b).abs().max() <= 1e-5 * max(1.0, float(b.abs().max()))     # (atomics: summation order differs)
 
 
 def _run_roi_align_big(dev):
