@@ -70,7 +70,8 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
 /* The same three operations with the ALGORITHM chosen by the caller instead of by the launcher's shape heuristics
  * (cuDNN's "algo" argument; the reference reaches it through torch.backends.cudnn.benchmark, tools/train_net.py sets
  * nothing and takes the default).  tile: 0 = automatic | 1 = 128x128 | 2 = 64x64 | 3 = 128x64 | 4 = 256x32 (fwd/dgrad) or
- * 32x128 (wgrad).  splits: 0 = automatic | >= 1 = reduction splits (> 1 ends with fp32 atomics into a zeroed, dense output).
+ * 32x128 (wgrad).  splits: 0 = automatic | >= 1 = reduction splits (> 1 ends with fp32 atomics into a zeroed, dense output;
+ * dgrad with accumulate != 0: on top of dx's content, any pitch -- the gradient fan-in target of functional.fanout).
  * omni_conv2d_fwd/dgrad/wgrad == the _algo form with tile = splits = 0.  Used by tools/bench_kernels.py and by tests that
  * exercise a given tile shape on a small problem; there is no process-global tuning state. */
 int omni_conv2d_fwd_algo(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C,
@@ -140,6 +141,27 @@ int omni_subsample2_bwd(const float* dy, float* dx, int N, int H, int W, int C, 
 int omni_upsample2_add(const float* lat, const float* top, float* out, int N, int H, int W, int C,
                        void* stream);
 int omni_upsample2_bwd(const float* dout, float* dtop, int N, int H, int W, int C, void* stream);
+
+/* Gradient fan-in ("carry") forms of four backward kernels.  An activation with several consumers -- the input of a DLA Tree
+ * (max-pool + first block, cubercnn/modeling/backbone/dla.py:204-222), a block output that is the next block's input, its residual
+ * and a Root child (:60-66, :171-173), an FPN top-down map (detectron2 FPN.forward, built at dla.py:500-506), an FPN output read
+ * by the RPN head and by ROIAlign (cubercnn/modeling/roi_heads/roi_heads.py:267,362) -- has a gradient that is the SUM of its
+ * consumers' gradients; autograd forms that sum with one elementwise add kernel per extra consumer.  Here the consumer that runs
+ * later reads what the earlier ones produced (`carry`: NHWC, same extent as the output, pixel pitch ldc floats -- a whole tensor or a
+ * channel slice of the Root's concatenated gradient; ldc >= channels, ldc % 4 == 0, 16-byte aligned) and writes the sum:
+ *   omni_wino_out_carry      y = A^T M A + carry                 (Winograd data gradient, tile as omni_wino_out)
+ *   omni_bn_bwd_carry        dres = masked dy + res_carry        (res_carry nullable: then == omni_bn_bwd)
+ *   omni_maxpool2_bwd_carry  dx = routed dy + carry              (carry nullable; H, W even when given)
+ *   omni_upsample2_bwd_carry dtop = 2x2 block sums + carry       (carry nullable)
+ * The implicit-GEMM data gradient takes the same role through omni_conv2d_dgrad(accumulate = 1, lddx = the carry's pitch). */
+int omni_wino_out_carry(const float* M, const float* carry, long long ldc, float* y, int N, int H, int W, int K, int tile, void* stream);
+int omni_bn_bwd_carry(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
+                      float* dres, const float* res_carry, long long ldc, float* dgamma, float* dbeta, double* ws, float* coef,
+                      int P, int C, int relu, int accumulate_param_grads, void* stream);
+int omni_maxpool2_bwd_carry(const float* x, const float* dy, const float* carry, long long ldc, float* dx, int N, int H, int W,
+                            int C, void* stream);
+int omni_upsample2_bwd_carry(const float* dout, const float* carry, long long ldc, float* dtop, int N, int H, int W, int C,
+                             void* stream);
 
 /* GeneralizedRCNN.preprocess_image (called at cubercnn/modeling/meta_arch/rcnn3d.py:46,87):
  * uint8 planar (N,3,H,W) -> fp32 NHWC (N,PH,PW,4), (v-mean)/std, channel 3 and padding = 0. */

@@ -237,7 +237,8 @@ __global__ void __launch_bounds__(256) bn_finalize_bwd_kernel(const float* __res
 __device__ __forceinline__ void bn_bwd_apply_body(const float* __restrict__ x, const float* __restrict__ dy,
                                                   const float* __restrict__ y, const float* __restrict__ mean_rstd,
                                                   const float* __restrict__ coef, float* __restrict__ dx,
-                                                  float* __restrict__ dres, long total4, int C, int relu) {
+                                                  float* __restrict__ dres, long total4, int C, int relu,
+                                                  const float* __restrict__ res_carry = nullptr, long ldc = 0) {
     const int C4 = C >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % C4);
@@ -245,7 +246,8 @@ __device__ __forceinline__ void bn_bwd_apply_body(const float* __restrict__ x, c
         const float4 xv = ld4(x + 4 * i);
         if (relu == 1) g = mask4(g, ld4(y + 4 * i));
         else if (relu == 2) g = mask4(g, xv * ld4(y + 4 * col) + ld4(y + C + 4 * col));      // y = (scale, shift): see bn_reduce_tile
-        if (dres != nullptr) st4(dres + 4 * i, g);
+        // residual gradient (+ what other consumers of the residual tensor already contributed: gradient fan-in, pixel pitch ldc)
+        if (dres != nullptr) st4(dres + 4 * i, res_carry != nullptr ? g + ld4(res_carry + (i / C4) * ldc + 4 * col) : g);
         const float4 xh = (xv - ld4(mean_rstd + 4 * col)) * ld4(mean_rstd + C + 4 * col);
         const float4 v = ld4(coef + 4 * col) * (g - ld4(coef + C + 4 * col) - xh * ld4(coef + 2 * C + 4 * col));
         st4(dx + 4 * i, v);
@@ -254,8 +256,9 @@ __device__ __forceinline__ void bn_bwd_apply_body(const float* __restrict__ x, c
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ y, const float* __restrict__ mean_rstd,
                                                            const float* __restrict__ coef, float* __restrict__ dx,
-                                                           float* __restrict__ dres, long total4, int C, int relu) {
-    bn_bwd_apply_body(x, dy, y, mean_rstd, coef, dx, dres, total4, C, relu);
+                                                           float* __restrict__ dres, long total4, int C, int relu,
+                                                           const float* __restrict__ res_carry, long ldc) {
+    bn_bwd_apply_body(x, dy, y, mean_rstd, coef, dx, dres, total4, C, relu, res_carry, ldc);
 }
 
 #ifndef OMNI_HIPEMU
@@ -324,7 +327,8 @@ __device__ __forceinline__ void route(float v00, float v01, float v10, float v11
 }
 
 __global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           float* __restrict__ dx, int N, int H, int W, int C) {
+                                                           float* __restrict__ dx, int N, int H, int W, int C,
+                                                           const float* __restrict__ carry, long ldc) {
     const int C4 = C >> 2, OH = H >> 1, OW = W >> 1;
     const long total = (long)N * OH * OW * C4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -341,6 +345,11 @@ __global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const float* __restri
         route(v00.y, v01.y, v10.y, v11.y, g.y, d00.y, d01.y, d10.y, d11.y);
         route(v00.z, v01.z, v10.z, v11.z, g.z, d00.z, d01.z, d10.z, d11.z);
         route(v00.w, v01.w, v10.w, v11.w, g.w, d00.w, d01.w, d10.w, d11.w);
+        if (carry != nullptr) {     // gradient fan-in: dx = routed dy + what the other consumers of x contributed (pixel pitch ldc)
+            const long pc = (((long)n * H + 2 * oh) * W + 2 * ow) * ldc + 4 * col;
+            d00 = d00 + ld4(carry + pc); d01 = d01 + ld4(carry + pc + ldc);
+            d10 = d10 + ld4(carry + pc + (long)W * ldc); d11 = d11 + ld4(carry + pc + (long)W * ldc + ldc);
+        }
         st4(dx + o, d00); st4(dx + o + C, d01); st4(dx + o + (long)W * C, d10); st4(dx + o + (long)W * C + C, d11);
     }
 }
@@ -409,7 +418,7 @@ __global__ void __launch_bounds__(256) upsample2_add_kernel(const float* __restr
 }
 
 __global__ void __launch_bounds__(256) upsample2_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dtop,
-                                                            int N, int H, int W, int C) {
+                                                            int N, int H, int W, int C, const float* __restrict__ carry, long ldc) {
     const int C4 = C >> 2, TH = H >> 1, TW = W >> 1;
     const long total = (long)N * TH * TW * C4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -419,7 +428,8 @@ __global__ void __launch_bounds__(256) upsample2_bwd_kernel(const float* __restr
         const int th = (int)(q % TH);
         const int n = (int)(q / TH);
         const long o = (((long)n * H + 2 * th) * W + 2 * tw) * C + 4 * col;
-        const float4 s = (ld4(dout + o) + ld4(dout + o + C)) + (ld4(dout + o + (long)W * C) + ld4(dout + o + (long)W * C + C));
+        float4 s = (ld4(dout + o) + ld4(dout + o + C)) + (ld4(dout + o + (long)W * C) + ld4(dout + o + (long)W * C + C));
+        if (carry != nullptr) s = s + ld4(carry + (i / C4) * ldc + 4 * col);      // gradient fan-in (pixel pitch ldc)
         st4(dtop + 4 * i, s);
     }
 }
@@ -525,10 +535,17 @@ int omni_bn_apply(const float* x, const float* scale_shift, const float* residua
 
 // Backward.  dy is the gradient wrt the (post-ReLU) output y; dres [nullable] receives the
 // gradient of the residual input.  ws: >= 2*C doubles, coef: 3*C floats of scratch.
-int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
-                float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C, int relu,
-                int accumulate_param_grads, void* stream) {
+static int bad_carry(const float* carry, long long ldc, int C) {
+    return carry != nullptr && (ldc < C || (ldc & 3) || (((unsigned long long)carry) & 15));
+}
+
+// omni_bn_bwd with gradient fan-in on the residual: dres = (masked dy) + res_carry, res_carry [nullable] an NHWC tensor of the
+// same extent with pixel pitch ldc floats (what the other consumers of the residual tensor already contributed to its gradient).
+int omni_bn_bwd_carry(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
+                      float* dres, const float* res_carry, long long ldc, float* dgamma, float* dbeta, double* ws, float* coef, int P,
+                      int C, int relu, int accumulate_param_grads, void* stream) {
     if (P <= 0 || C <= 0 || (C & 3) || C > 4096 || relu < 0 || relu > 2 || (relu && y == nullptr)) return OMNI_ERR_ARG;
+    if (bad_carry(res_carry, ldc, C) || (res_carry != nullptr && dres == nullptr)) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = red_grid(P, C);
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
@@ -538,8 +555,15 @@ int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* ga
                        mean_rstd, dgamma, dbeta, coef, accumulate_param_grads);
     const long total4 = (long)P * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, dy, y, mean_rstd,
-                       (const float*)coef, dx, dres, total4, C, relu);
+                       (const float*)coef, dx, dres, total4, C, relu, res_carry, (long)ldc);
     return omni_launch_status();
+}
+
+int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
+                float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C, int relu,
+                int accumulate_param_grads, void* stream) {
+    return omni_bn_bwd_carry(x, dy, y, gamma, mean_rstd, dx, dres, nullptr, 0, dgamma, dbeta, ws, coef, P, C, relu, accumulate_param_grads,
+                             stream);
 }
 
 // omni_bn_bwd with the reductions already done by the kernel that produced dy (omni_wino_out_bn_bwd_stats): finalize + apply.
@@ -552,7 +576,7 @@ int omni_bn_bwd_partials(const float* x, const float* dy, const float* y, const 
                        dgamma, dbeta, coef, accumulate_param_grads);
     const long total4 = (long)P * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, dy, y, mean_rstd, (const float*)coef, dx, dres,
-                       total4, C, relu);
+                       total4, C, relu, (const float*)nullptr, 0L);
     return omni_launch_status();
 }
 
@@ -564,13 +588,19 @@ int omni_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void
     return omni_launch_status();
 }
 
-int omni_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
-    if ((C & 3) || H < 2 || W < 2) return OMNI_ERR_ARG;
+// carry [nullable]: gradient fan-in, dx = routed dy + carry (NHWC, pixel pitch ldc floats; H and W even when given)
+int omni_maxpool2_bwd_carry(const float* x, const float* dy, const float* carry, long long ldc, float* dx, int N, int H, int W, int C,
+                            void* stream) {
+    if ((C & 3) || H < 2 || W < 2 || bad_carry(carry, ldc, C) || (carry != nullptr && ((H & 1) || (W & 1)))) return OMNI_ERR_ARG;
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     if (total == 0) return OMNI_OK;
     if ((H & 1) || (W & 1)) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, (hipStream_t)stream);
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C, carry, (long)ldc);
     return omni_launch_status();
+}
+
+int omni_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    return omni_maxpool2_bwd_carry(x, dy, nullptr, 0, dx, N, H, W, C, stream);
 }
 
 int omni_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
@@ -620,12 +650,17 @@ int omni_upsample2_add(const float* lat, const float* top, float* out, int N, in
 }
 
 // dtop (N,H/2,W/2,C) = 2x2 block sums of dout (N,H,W,C).
-int omni_upsample2_bwd(const float* dout, float* dtop, int N, int H, int W, int C, void* stream) {
-    if ((C & 3) || (H & 1) || (W & 1)) return OMNI_ERR_ARG;
+// carry [nullable]: gradient fan-in, dtop = block sums + carry (N,H/2,W/2,C with pixel pitch ldc floats)
+int omni_upsample2_bwd_carry(const float* dout, const float* carry, long long ldc, float* dtop, int N, int H, int W, int C, void* stream) {
+    if ((C & 3) || (H & 1) || (W & 1) || bad_carry(carry, ldc, C)) return OMNI_ERR_ARG;
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     if (total == 0) return OMNI_OK;
-    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dout, dtop, N, H, W, C);
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dout, dtop, N, H, W, C, carry, (long)ldc);
     return omni_launch_status();
+}
+
+int omni_upsample2_bwd(const float* dout, float* dtop, int N, int H, int W, int C, void* stream) {
+    return omni_upsample2_bwd_carry(dout, nullptr, 0, dtop, N, H, W, C, stream);
 }
 
 // img uint8 (N,3,H,W) -> out fp32 NHWC (N,PH,PW,4): (v - mean)/std per channel, zero padded.

@@ -1052,14 +1052,15 @@ int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* ou
     return omni_conv2d_fwd_algo(x, w, bias, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, relu, 0, 0, stream);
 }
 
-// tile: 0 auto | 1 = 128x128 | 2 = 64x64 | 3 = 128x64 | 4 = 256x32; splits: 0 auto | >= 1 explicit (> 1 needs lddx == C and
-// accumulate == 0: atomic epilogue into a zeroed dx)
+// tile: 0 auto | 1 = 128x128 | 2 = 64x64 | 3 = 128x64 | 4 = 256x32; splits: 0 auto | >= 1 explicit (> 1: atomic epilogue; into
+// a dx zeroed here when accumulate == 0, which needs lddx == C, or on top of dx's content when accumulate != 0 -- a gradient
+// fan-in target, see functional.fanout: neither a zero-fill nor a separate add kernel)
 int omni_conv2d_dgrad_algo(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S,
                            int stride, int pad, int lddy, int lddx, int accumulate, int tile, int splits_req, void* stream) {
     ConvP p{dy, w, nullptr, dx, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
             R, S, stride, pad, lddy, lddx, 0, 0, accumulate, 1};
     if (bad_geom(p) || (K & 3) || (lddy & 3) || lddy < K || lddx < C || tile < 0 || tile > 4 || splits_req < 0) return OMNI_ERR_ARG;
-    if (splits_req > 1 && (lddx != C || accumulate)) return OMNI_ERR_ARG;
+    if (splits_req > 1 && lddx != C && !accumulate) return OMNI_ERR_ARG;
     if ((long)N * H * W == 0) return OMNI_OK;
     hipStream_t st = (hipStream_t)stream;
     // one launch covers the stride^2 parity classes (grid.z); tiles are sized for the largest class (0, 0)
@@ -1075,7 +1076,7 @@ int omni_conv2d_dgrad_algo(const float* dy, const float* w, float* dx, int N, in
             tile = 1;
         } else if (C > 32 && (C > 64 || ((M + 127) / 128) * ncls < 256)) {
             tile = 2;
-            if (t64 * ncls < 512 && nslab >= 16 && lddx == C && !accumulate) {
+            if (t64 * ncls < 512 && nslab >= 16 && (lddx == C || accumulate)) {
                 splits = (1024 + t64 * ncls - 1) / (t64 * ncls);
                 if (splits > nslab / 8) splits = nslab / 8;
                 if (splits > 32) splits = 32;
@@ -1087,7 +1088,7 @@ int omni_conv2d_dgrad_algo(const float* dy, const float* w, float* dx, int N, in
     }
     if (splits_req >= 1) splits = splits_req;
     if (splits > nslab) splits = nslab;
-    if (splits > 1) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, st);
+    if (splits > 1 && !accumulate) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, st);
 #define OMNI_DGRAD(BM_, BN_, WM_, WN_, BK_)                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<BM_, BN_, WM_, WN_, BK_>),                                        \
                        dim3((unsigned)(((M + BM_ - 1) / BM_) * ((C + BN_ - 1) / BN_)), (unsigned)splits, ncls), dim3(256), 0, st, p)

@@ -94,7 +94,7 @@ __device__ __forceinline__ void block_channel_stats(float4 sv, float4 sq, int K,
 
 __global__ void __launch_bounds__(256) wino_out_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                        float* __restrict__ y, int N, int H, int W, int K, int relu,
-                                                       float* __restrict__ stats) {
+                                                       float* __restrict__ stats, const float* __restrict__ carry, long ldc) {
     const int K4 = K >> 2, TH = H >> 1, TW = W >> 1;
     const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
     float4 sv = z4(), sq = z4();
@@ -122,7 +122,12 @@ __global__ void __launch_bounds__(256) wino_out_kernel(const float* __restrict__
                 y0 = make_float4(fmaxf(y0.x, 0.f), fmaxf(y0.y, 0.f), fmaxf(y0.z, 0.f), fmaxf(y0.w, 0.f));
                 y1 = make_float4(fmaxf(y1.x, 0.f), fmaxf(y1.y, 0.f), fmaxf(y1.z, 0.f), fmaxf(y1.w, 0.f));
             }
-            float* o = y + (((long)n * H + 2 * ty + r) * W + 2 * tx) * K + 4 * k4;
+            const long pix = ((long)n * H + 2 * ty + r) * W + 2 * tx;
+            if (carry != nullptr) {     // gradient fan-in: what other consumers of this tensor already contributed (pixel pitch ldc)
+                y0 = y0 + ld4(carry + pix * ldc + 4 * k4);
+                y1 = y1 + ld4(carry + (pix + 1) * ldc + 4 * k4);
+            }
+            float* o = y + pix * K + 4 * k4;
             st4(o, y0);
             st4(o + K, y1);
             OMNI_ACC_STATS(y0);
@@ -337,7 +342,8 @@ struct BnBwdStats {
 };
 __global__ void __launch_bounds__(256) wino4_out_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                         float* __restrict__ y, int N, int H, int W, int K, int relu,
-                                                        float* __restrict__ stats, BnBwdStats bnb) {
+                                                        float* __restrict__ stats, BnBwdStats bnb,
+                                                        const float* __restrict__ carry, long ldc) {
     const int K4 = K >> 2, TH = H >> 2, TW = W >> 2;
     const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
     float4 sv = z4(), sq = z4();
@@ -369,9 +375,16 @@ __global__ void __launch_bounds__(256) wino4_out_kernel(const float* __restrict_
         for (int r = 0; r < 4; ++r) {
             float4 row[4];
             at6(s[r], row);
-            const long off = (((long)n * H + 4 * ty + r) * W + 4 * tx) * K + 4 * k4;
+            const long pix = ((long)n * H + 4 * ty + r) * W + 4 * tx;
+            const long off = pix * K + 4 * k4;
             float* o = y + off;
-            if (bnb.x != nullptr) {
+            if (carry != nullptr) {     // gradient fan-in (see wino_out_kernel); never combined with bias / ReLU / statistics
+                float4 cv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cv[c] = ld4(carry + (pix + c) * ldc + 4 * k4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) st4(o + (long)c * K, row[c] + cv[c]);
+            } else if (bnb.x != nullptr) {
                 float4 xv[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) xv[c] = ld4(bnb.x + off + (long)c * K);
@@ -667,7 +680,8 @@ int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile,
 }
 
 static int wino_out_impl(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, float* stats,
-                         int stats_rows, int* nblk_out, void* stream, BnBwdStats bnb = BnBwdStats{nullptr, nullptr, nullptr}) {
+                         int stats_rows, int* nblk_out, void* stream, BnBwdStats bnb = BnBwdStats{nullptr, nullptr, nullptr},
+                         const float* carry = nullptr, long ldc = 0) {
     if (nblk_out) *nblk_out = 0;
     if (bad(N, H, W, K) || (tile != 2 && tile != 4) || (H % tile) || (W % tile)) return OMNI_ERR_ARG;
     const long total = (long)N * (H / tile) * (W / tile) * (K / 4);
@@ -681,13 +695,24 @@ static int wino_out_impl(const float* M, const float* bias, float* y, int N, int
         else grid = ew_grid(total);
     }
     if (st_ptr == nullptr) bnb = BnBwdStats{nullptr, nullptr, nullptr};
-    if (tile == 2) hipLaunchKernelGGL(wino_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu, st_ptr);
-    else hipLaunchKernelGGL(wino4_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu, st_ptr, bnb);
+    if (tile == 2) hipLaunchKernelGGL(wino_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu, st_ptr,
+                                      carry, ldc);
+    else hipLaunchKernelGGL(wino4_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu, st_ptr, bnb,
+                            carry, ldc);
     return omni_launch_status();
 }
 
 int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, void* stream) {
     return wino_out_impl(M, bias, y, N, H, W, K, relu, tile, nullptr, 0, nullptr, stream);
+}
+
+// Data-gradient output transform with gradient fan-in: y = A^T M A + carry, carry an NHWC tensor of the same extent whose pixels
+// are ldc floats apart (ldc >= K, ldc % 4 == 0, 16-byte aligned: a whole tensor, or a channel slice of a wider one).  The tensor this
+// convolution's input gradient is added to (another consumer's gradient of the same activation) is read here instead of by a
+// separate add kernel.  carry may alias nothing that is written (y is a different buffer).
+int omni_wino_out_carry(const float* M, const float* carry, long long ldc, float* y, int N, int H, int W, int K, int tile, void* stream) {
+    if (carry == nullptr || ldc < K || (ldc & 3) || (((unsigned long long)carry) & 15)) return OMNI_ERR_ARG;
+    return wino_out_impl(M, nullptr, y, N, H, W, K, 0, tile, nullptr, 0, nullptr, stream, BnBwdStats{nullptr, nullptr, nullptr}, carry, (long)ldc);
 }
 
 // Data-gradient output transform that also emits the BACKWARD partial statistics of the BatchNorm whose output gradient it writes

@@ -113,7 +113,8 @@ class Root(nn.Module):
         self.residual = residual
 
     def forward(self, *x):
-        y = self.conv(torch.cat(x, 1))
+        # (the concatenation hands each child its slice of the gradient through the child's fan-in slot, see functional.fanout)
+        y = self.conv(HF.cat_channels(x) if (self.training and torch.is_grad_enabled()) else torch.cat(x, 1))
         return self.bn(y, residual=x[0] if self.residual else None, relu=True)
 
 
@@ -150,9 +151,20 @@ class Tree(nn.Module):
 
     def forward(self, x, residual=None, children=None, bottom=None):
         children = [] if children is None else children
+        # x, bottom and x1 below each have several consumers (max-pool + first block | projection, Root child, nested subtree |
+        # next block, its residual, Root child): their gradients are summed inside the consumers' backward kernels
+        HF.fanout(x)
         if bottom is None:      # (a nested first subtree pools the same x with the same stride: the outer level passes its result)
             bottom = HF.max_pool2(x) if self.downsample is not None else x
-        residual = self.project(bottom) if self.project is not None else bottom
+        HF.fanout(bottom)
+        if self.levels > 1 and self.project is not None:
+            # a nested Tree recomputes `residual` from its own projection and drops this one (dla.py:208-213 of the reference):
+            # run it for its BatchNorm's running statistics only -- no autograd graph, no saved activations
+            with torch.no_grad():
+                self.project(bottom.detach())
+            residual = None
+        else:
+            residual = self.project(bottom) if self.project is not None else bottom
         if self.level_root:
             children.append(bottom)
         if self.levels == 1:
@@ -161,6 +173,7 @@ class Tree(nn.Module):
             t1 = self.tree1
             shared = bottom if _SHARE_POOL and (t1.downsample is None) == (self.downsample is None) else None
             x1 = t1(x, residual, bottom=shared)
+        HF.fanout(x1)
         if self.levels == 1:
             x2 = self.tree2(x1)
             return self.root(x2, x1, *children)
@@ -239,7 +252,7 @@ class DLABackbone(Backbone):
         p2 = cut("p2", self.level2(x))
         p3 = cut("p3", self.level3(p2))
         p4 = cut("p4", self.level4(p3))
-        p5 = cut("p5", self.level5(p4))
+        p5 = HF.fanout(cut("p5", self.level5(p4)))        # (FPN lateral + the p6 subsampling; p2..p4 are marked by the next Tree)
         return {"p2": p2, "p3": p3, "p4": p4, "p5": p5, "p6": HF.subsample2(p5)}
 
 

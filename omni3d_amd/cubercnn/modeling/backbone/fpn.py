@@ -74,7 +74,8 @@ class FPN(Backbone):
         for f, stage in zip(reversed(self.in_features), reversed(self._stages)):
             lat = getattr(self, f"fpn_lateral{stage}")(feats[f])
             prev = lat if prev is None else HF.upsample2_add(lat, prev)
-            results[f"p{stage}"] = getattr(self, f"fpn_output{stage}")(prev)
+            HF.fanout(prev)       # read by its output convolution and by the next finer level's top-down sum
+            results[f"p{stage}"] = HF.fanout(getattr(self, f"fpn_output{stage}")(prev))      # ... by the RPN head and by ROIAlign
         if self.top_block is not None:
             src = feats[self.top_block.in_feature] if self.top_block.in_feature in feats else results[self.top_block.in_feature]
             for i, t in enumerate(self.top_block(src)):

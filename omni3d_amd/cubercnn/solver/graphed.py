@@ -15,6 +15,15 @@ import torch
 from ...functional import total_loss
 
 
+def _leaf_grad(t):
+    """gradient of a cut's detached copy: .grad plus whatever its fan-in slot still withholds (functional.fanout)"""
+    from ...functional import fanout_leftover
+    left = fanout_leftover(t)
+    if left is None:
+        return t.grad
+    return left if t.grad is None else t.grad + left
+
+
 class FeatureCut:
     """Splits backward at the FPN features: `cut(features)` hands detached copies to the heads (RPN, ROI heads), so
     `total.backward()` stops there with the heads' parameter gradients complete; `cut.backward()` then pushes the
@@ -25,12 +34,14 @@ class FeatureCut:
         self.src, self.dst = None, None
 
     def __call__(self, features):
+        from ...functional import fanout
         self.src = features
-        self.dst = {k: v.detach().requires_grad_(True) for k, v in features.items()}
+        self.dst = {k: fanout(v.detach().requires_grad_(True)) for k, v in features.items()}
         return self.dst
 
     def backward(self):
-        pairs = [(self.src[k], self.dst[k].grad) for k in self.src if self.dst[k].grad is not None]
+        pairs = [(self.src[k], _leaf_grad(self.dst[k])) for k in self.src]
+        pairs = [p for p in pairs if p[1] is not None]
         self.src, self.dst = None, None
         if pairs:
             torch.autograd.backward([p[0] for p in pairs], [p[1] for p in pairs])
@@ -148,10 +159,13 @@ class StageCuts:
         return len(self.cuts)
 
     def __call__(self, x):
+        # (the copies are read by several consumers -- RPN head + ROIAlign, FPN lateral + the next DLA level --, possibly in
+        # different backward stages: functional.fanout sums their gradients inside the consumers' kernels)
+        from ...functional import fanout
         if isinstance(x, dict):
-            dst = {k: v.detach().requires_grad_(True) for k, v in x.items()}
+            dst = {k: fanout(v.detach().requires_grad_(True)) for k, v in x.items()}
         else:
-            dst = x.detach().requires_grad_(True)
+            dst = fanout(x.detach().requires_grad_(True))
         self.cuts.append((x, dst))
         return dst
 
@@ -161,9 +175,10 @@ class StageCuts:
     def backward_last(self):
         src, dst = self.cuts.pop()
         if isinstance(src, dict):
-            pairs = [(src[k], dst[k].grad) for k in src if dst[k].grad is not None]
+            pairs = [(src[k], _leaf_grad(dst[k])) for k in src]
         else:
-            pairs = [(src, dst.grad)] if dst.grad is not None else []
+            pairs = [(src, _leaf_grad(dst))]
+        pairs = [p for p in pairs if p[1] is not None]
         del src, dst
         if pairs:
             torch.autograd.backward([p[0] for p in pairs], [p[1] for p in pairs])

@@ -34,6 +34,102 @@ def _parts_out(parts, like):
     return parts if parts is not None else like.new_zeros((0, 1))
 
 
+# ---- gradient fan-in ---------------------------------------------------------------------------------------------------------
+# An activation with several consumers (the input of a DLA Tree: max-pool + first block; a block output that is the next block's
+# input, its residual and a Root child; an FPN top-down map; an FPN output read by the RPN head and by ROIAlign) has a gradient that
+# is the SUM of its consumers' gradients, and the autograd engine forms that sum with one elementwise add kernel per extra
+# consumer: ~80 launches and ~0.5 ms of a 12.6 ms DLA-34 step (profiles/r03_trace_table_final.txt).  `fanout(t)` hangs a slot on
+# such a tensor; every backward function of this file that consumes it registers in its forward, and in backward
+#   * reads what the consumers that ran before it left in the slot (`carry`) INSIDE its own kernel's epilogue (the *_carry entry
+#     points of include/omni3d_hip.h, omni_conv2d_dgrad(accumulate = 1)) -- no separate add kernel, two reads and one write less;
+#   * returns None to the engine unless it is the last registered consumer, which returns the complete sum.
+# Consumers without a slot-aware kernel (ATen ops, anything outside this file) are unaffected: their gradient reaches the producer
+# through the engine's own accumulation, on top of the one defined gradient the slot hands over.  A registered consumer whose
+# backward never runs (its output does not reach the loss -- the projection a nested DLA Tree computes and drops, dla.py:208)
+# would leave the sum withheld: a pre-hook on the producer's autograd node hands over whatever a slot still holds when the producer
+# is about to run.  A leaf's consumers (the detached copies of solver/graphed.py's stage cuts) may run in different backward
+# calls: the slot keeps the partial sum in between, and the cut adds `fanout_leftover` when it reads the leaf's gradient.
+_FANOUT = _os_environ_get("OMNI_FANOUT", "1") != "0"          # A/B knob
+
+
+class _GradSlot:
+    __slots__ = ("buf", "remaining")
+
+    def __init__(self):
+        self.buf, self.remaining = None, 0
+
+
+def fanout(t):
+    """marks a tensor that several slot-aware consumers read (idempotent; a no-op outside training) -> t"""
+    if _FANOUT and t.requires_grad and torch.is_grad_enabled() and getattr(t, "_omni_slot", None) is None:
+        slot = t._omni_slot = _GradSlot()
+        if t.grad_fn is not None:
+            nr = t.output_nr
+
+            def hand_over(grads):       # the producer is about to run: every consumer that will ever run has run
+                left = fanout_leftover(slot)
+                if left is None:
+                    return None
+                if grads[nr] is None:       # (autograd does not let a hook turn an undefined gradient into a defined one)
+                    raise RuntimeError(f"omni3d_amd.functional.fanout: a consumer of a {tuple(left.shape)} activation registered with its "
+                                       "gradient fan-in slot in forward but never ran in backward (its output does not reach the loss), and "
+                                       "no other gradient arrived that the withheld sum could be added to.  Feed that consumer a detached "
+                                       "input, or set OMNI_FANOUT=0.")
+                grads = list(grads)
+                grads[nr] = grads[nr] + left
+                return tuple(grads)
+            t.grad_fn.register_prehook(hand_over)
+    return t
+
+
+def fanout_leftover(t_or_slot):
+    """-> the partial gradient sum a slot still withholds (a registered consumer never ran), or None; clears the slot"""
+    slot = t_or_slot if isinstance(t_or_slot, _GradSlot) else getattr(t_or_slot, "_omni_slot", None)
+    if slot is None or slot.buf is None:
+        return None
+    left, slot.buf, slot.remaining = slot.buf, None, 0
+    return left
+
+
+def _slot_enter(t, needs_grad):
+    """forward of a consumer: register with the slot of input `t` (None: `t` has no slot / needs no gradient)"""
+    slot = getattr(t, "_omni_slot", None) if (needs_grad and t is not None) else None
+    if slot is not None:
+        slot.remaining += 1
+    return slot
+
+
+def _slot_deliver(slot, compute):
+    """backward of a consumer: compute(carry) -> this consumer's gradient PLUS carry (carry None: nothing to add).
+    -> what the backward function returns for that input."""
+    if slot is None:
+        return compute(None)
+    out = compute(slot.buf)
+    slot.remaining -= 1
+    if slot.remaining <= 0:
+        slot.buf = None
+        return out
+    slot.buf = out
+    return None
+
+
+def _add_carry(out, carry):
+    """consumers without a fan-in epilogue"""
+    return out if carry is None else out + carry
+
+
+def _carry_pitch(c):
+    """-> pixel pitch (floats) of a logical (N,C,H,W) tensor that is NHWC in memory with channel stride 1 -- a whole channels_last
+    tensor or a channel slice of a wider one --, or None when the kernels cannot read it as a carry"""
+    N, C, H, W = c.shape
+    sn, sc, sh, sw = c.stride()
+    if c.dtype != torch.float32 or sc != 1 or sw < C or (sw & 3) or (c.data_ptr() & 15) or (c.storage_offset() & 3):
+        return None
+    if (H > 1 and sh != W * sw) or (N > 1 and sn != H * W * sw):
+        return None
+    return sw
+
+
 # ---- weight gradients off the critical path ---------------------------------------------------------------------------------
 # In the backward pass of a convolution / linear layer the data gradient is on the critical path (the next layer down waits for
 # it) while the weight gradient is needed only by the optimizer, and most layers of this network launch too few workgroups to
@@ -123,6 +219,7 @@ class _Conv2d(Function):
     def forward(ctx, x, w, bias, stride, pad, relu, want_stats=False):
         ctx.set_materialize_grads(False)      # no zero tensors for the non-differentiable side outputs
         ctx.direct = (_direct_grad(w), _direct_grad(bias))
+        ctx.slot = _slot_enter(x, ctx.needs_input_grad[0])
         x, w = _cl(x), _cl(w)
         # full-resolution few-channel stem layers: direct convolution with the input halo staged once in LDS
         ctx.stem = bias is None and not relu and conv.stem_eligible(x.shape, w.shape, stride, pad)
@@ -149,12 +246,15 @@ class _Conv2d(Function):
             gw = None
         dx = None
         if ctx.needs_input_grad[0]:
-            if ctx.stem and w.shape[1] == 16:
-                # data gradient of a stride-1 "same" convolution = the same convolution of dy with the 180-degree rotated,
-                # channel-transposed filter (a 9 KB tensor)
-                dx = conv.stem_conv_fwd(dy, _cl(w.flip(2, 3).transpose(0, 1)))
-            else:
-                dx = conv.conv2d_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad)
+            def dgrad(carry):
+                if ctx.stem and w.shape[1] == 16:
+                    # data gradient of a stride-1 "same" convolution = the same convolution of dy with the 180-degree rotated,
+                    # channel-transposed filter (a 9 KB tensor)
+                    return _add_carry(conv.stem_conv_fwd(dy, _cl(w.flip(2, 3).transpose(0, 1))), carry)
+                if carry is not None and _carry_pitch(carry) is not None:
+                    return conv.conv2d_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad, accum_into=carry)
+                return _add_carry(conv.conv2d_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad), carry)
+            dx = _slot_deliver(ctx.slot, dgrad)
         dw = None
         if ctx.needs_input_grad[1]:
             # (measured: the stem weight-gradient kernel wins for the 16-channel layer, 0.13 vs 0.21 ms, not for the
@@ -179,6 +279,7 @@ class _WinoConv3x3(Function):
         ctx.set_materialize_grads(False)      # no zero tensors for the non-differentiable side outputs
         ctx.direct = (_direct_grad(w), _direct_grad(bias))
         ctx.bn_below = getattr(x, "_omni_bn_below", None)      # x is the output of a BatchNorm(+ReLU) without residual
+        ctx.slot = _slot_enter(x, ctx.needs_input_grad[0])
         x, w = _cl(x), _cl(w)
         # one launch yields the forward transform U and (when the data gradient will also go through Winograd) U' of
         # the rotated filter; a weight shared by several calls of one step (the RPN conv over the FPN levels) is
@@ -216,12 +317,30 @@ class _WinoConv3x3(Function):
         if gw is not None and not gw.is_contiguous(memory_format=CL):
             gw = None
         dx = dw = None
+        slot, box = ctx.slot, []
+
+        def fused(carry):       # carry: read by the output transform of the data gradient (omni_wino_out_carry)
+            ok = carry is not None and _carry_pitch(carry) is not None
+            dx_, dw_ = wino.conv3x3_backward(V, dy, w, Uf, accum_into=gw, side_run=_side_run, bn_below=ctx.bn_below if carry is None else None,
+                                             carry=carry if ok else None)   # both transforms of dy in one pass
+            box.append(dw_)
+            return dx_ if (ok or carry is None) else dx_ + carry
+
+        def dgrad_only(carry):
+            if wino.dgrad_eligible(dy.shape):
+                ok = carry is not None and _carry_pitch(carry) is not None
+                dx_ = wino.conv3x3_dgrad(dy, w, U_flip=Uf, tile=2 if V.shape[0] == 16 else 4, carry=carry if ok else None)
+                return dx_ if (ok or carry is None) else dx_ + carry
+            if carry is not None and _carry_pitch(carry) is not None:
+                return conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1, accum_into=carry)
+            return _add_carry(conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1), carry)
+
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and wino.dgrad_eligible(dy.shape):
-            dx, dw = wino.conv3x3_backward(V, dy, w, Uf, accum_into=gw, side_run=_side_run, bn_below=ctx.bn_below)   # both transforms of dy in one pass
+            dx = _slot_deliver(slot, fused)
+            dw = box[0]
         else:
             if ctx.needs_input_grad[0]:
-                dx = (wino.conv3x3_dgrad(dy, w, U_flip=Uf, tile=2 if V.shape[0] == 16 else 4) if wino.dgrad_eligible(dy.shape)
-                      else conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1))
+                dx = _slot_deliver(slot, dgrad_only)
             if ctx.needs_input_grad[1]:
                 dw = _side_run(lambda: wino.conv3x3_wgrad(V, dy, accum_into=gw), (V, dy)) if gw is not None else wino.conv3x3_wgrad(V, dy)
         db = None
@@ -353,6 +472,7 @@ class _BatchNorm(Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, eps, momentum, partials=None):
         gg, gb = _direct_grad(gamma), _direct_grad(beta)
         ctx.direct = (gg, gb) if (gg is not None and gb is not None) else None
+        ctx.res_slot = _slot_enter(residual, residual is not None and ctx.needs_input_grad[5])
         x = _cl(x)
         res = _cl(residual) if residual is not None else None
         y, mean_rstd, scale_shift = bnpool.bn_fwd(x, gamma, beta, running_mean, running_var, res, relu, eps, momentum, partials)
@@ -373,8 +493,18 @@ class _BatchNorm(Function):
         parts = getattr(dy, "_omni_bn_bwd_parts", None)
         if parts is not None:       # made for THIS layer (same statistics tensor), and dy reached us unchanged
             parts = parts[0] if parts[1].data_ptr() == mean_rstd.data_ptr() and dy.is_contiguous(memory_format=CL) else None
-        dx, dres, dgamma, dbeta = bnpool.bn_bwd(x, _cl(dy), y, gamma, mean_rstd, relu, want_dres=has_res and ctx.needs_input_grad[5],
-                                                accum_into=ctx.direct, scale_shift=scale_shift, partials=parts)
+        want_dres = has_res and ctx.needs_input_grad[5]
+        box = []
+
+        def run(carry):     # carry: what the other consumers of the residual tensor contributed, added where dres is written
+            ok = carry is not None and parts is None and _carry_pitch(carry) is not None
+            dx_, dres_, dgamma_, dbeta_ = bnpool.bn_bwd(x, _cl(dy), y, gamma, mean_rstd, relu, want_dres=want_dres, accum_into=ctx.direct,
+                                                        scale_shift=scale_shift, partials=parts, res_carry=carry if ok else None)
+            box.append((dx_, dgamma_, dbeta_))
+            return dres_ if (ok or carry is None) else dres_ + carry
+
+        dres = _slot_deliver(ctx.res_slot, run) if want_dres else run(None)
+        dx, dgamma, dbeta = box[0]
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 
@@ -386,6 +516,7 @@ def batch_norm_train(x, gamma, beta, running_mean, running_var, residual=None, r
 class _MaxPool2(Function):
     @staticmethod
     def forward(ctx, x):
+        ctx.slot = _slot_enter(x, ctx.needs_input_grad[0])
         x = _cl(x)
         ctx.save_for_backward(x)
         return bnpool.maxpool2_fwd(x)
@@ -393,7 +524,12 @@ class _MaxPool2(Function):
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return bnpool.maxpool2_bwd(x, _cl(dy))
+
+        def run(carry):
+            if carry is not None and (_carry_pitch(carry) is None or (x.shape[2] | x.shape[3]) & 1):
+                return bnpool.maxpool2_bwd(x, _cl(dy)) + carry
+            return bnpool.maxpool2_bwd(x, _cl(dy), carry=carry)
+        return _slot_deliver(ctx.slot, run)
 
 
 class _AvgPool2(Function):
@@ -411,24 +547,56 @@ class _AvgPool2(Function):
 class _Subsample2(Function):
     @staticmethod
     def forward(ctx, x):
+        ctx.slot = _slot_enter(x, ctx.needs_input_grad[0])
         x = _cl(x)
         ctx.hw = (x.shape[2], x.shape[3])
         return bnpool.subsample2_fwd(x)
 
     @staticmethod
     def backward(ctx, dy):
-        return bnpool.subsample2_bwd(_cl(dy), ctx.hw)
+        return _slot_deliver(ctx.slot, lambda carry: _add_carry(bnpool.subsample2_bwd(_cl(dy), ctx.hw), carry))
 
 
 class _Upsample2Add(Function):
     @staticmethod
     def forward(ctx, lat, top):
+        ctx.slot = _slot_enter(top, ctx.needs_input_grad[1])
         return bnpool.upsample2_add(_cl(lat), _cl(top))
 
     @staticmethod
     def backward(ctx, dout):
         dout = _cl(dout)
-        return dout, bnpool.upsample2_bwd(dout)
+
+        def run(carry):
+            if carry is not None and _carry_pitch(carry) is None:
+                return bnpool.upsample2_bwd(dout) + carry
+            return bnpool.upsample2_bwd(dout, carry=carry)
+        return dout, _slot_deliver(ctx.slot, run)
+
+
+class _CatChannels(Function):
+    """torch.cat(xs, dim=1) of the DLA Root (dla.py:171) whose backward hands each input its channel slice of the gradient THROUGH
+    the input's fan-in slot: the slice -- a strided view, nothing is copied -- becomes the carry the input's other consumers add
+    their gradients to."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.slots = [_slot_enter(x, ctx.needs_input_grad[i]) for i, x in enumerate(xs)]
+        ctx.sizes = [x.shape[1] for x in xs]
+        return torch.cat(xs, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for i, (slot, c) in enumerate(zip(ctx.slots, ctx.sizes)):
+            piece = g[:, off:off + c]
+            off += c
+            outs.append(_slot_deliver(slot, lambda carry, piece=piece: _add_carry(piece, carry)) if ctx.needs_input_grad[i] else None)
+        return tuple(outs)
+
+
+def cat_channels(xs):
+    return _CatChannels.apply(*xs)
 
 
 def max_pool2(x):
@@ -453,6 +621,7 @@ class _ROIAlign(Function):
 
     @staticmethod
     def forward(ctx, rois, batch_idx, levels, scales, P, *feats):
+        ctx.slots = [_slot_enter(f, ctx.needs_input_grad[5 + i]) for i, f in enumerate(feats)]
         feats = [_cl(f) for f in feats]
         nhwc = [f.permute(0, 2, 3, 1) for f in feats]
         out = det.roi_align_fwd(nhwc, scales, rois, batch_idx, levels, P)
@@ -466,7 +635,8 @@ class _ROIAlign(Function):
         scales, P, shapes = ctx.meta
         dfe = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
         det.roi_align_bwd(dfe, scales, rois, batch_idx, levels, P, _cl(dout).permute(0, 2, 3, 1))
-        return (None, None, None, None, None) + tuple(d.permute(0, 3, 1, 2) for d in dfe)
+        return (None, None, None, None, None) + tuple(_slot_deliver(slot, lambda carry, d=d: _add_carry(d.permute(0, 3, 1, 2), carry))
+                                                      for slot, d in zip(ctx.slots, dfe))
 
 
 def roi_align(feats, scales, rois, batch_idx, levels, P):
@@ -483,6 +653,7 @@ class _ROIAlignShared(Function):
 
     @staticmethod
     def forward(ctx, rois, batch_idx, levels, scales, P, per_image, first, *feats):
+        ctx.slots = [_slot_enter(f, ctx.needs_input_grad[7 + i]) for i, f in enumerate(feats)]
         feats = [_cl(f) for f in feats]
         nhwc = [f.permute(0, 2, 3, 1) for f in feats]
         out = det.roi_align_fwd(nhwc, scales, rois, batch_idx, levels, P)          # (R, P, P, C)
@@ -518,7 +689,10 @@ class _ROIAlignShared(Function):
                 C = d.shape[3]
                 d.view(-1, per_image, P, P, C)[:, :first] += df.reshape(-1, first, P, P, C)
             det.roi_align_bwd(dfe, scales, rois, batch_idx, levels, P, d)
-        return (None,) * 7 + tuple(t.permute(0, 3, 1, 2) for t in dfe)
+        # (each level's gradient goes through the feature's fan-in slot: the RPN head's data gradient, which runs later, reads it
+        # in its output transform instead of an add kernel over the whole map)
+        return (None,) * 7 + tuple(_slot_deliver(slot, lambda carry, t=t: _add_carry(t.permute(0, 3, 1, 2), carry))
+                                   for slot, t in zip(ctx.slots, dfe))
 
 
 def roi_align_shared(feats, scales, rois, batch_idx, levels, P, per_image, first):

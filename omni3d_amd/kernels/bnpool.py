@@ -44,11 +44,13 @@ def bn_apply(x, scale_shift, residual=None, relu=False):
     return y.permute(0, 3, 1, 2)
 
 
-def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=None, scale_shift=None, partials=None):
+def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=None, scale_shift=None, partials=None, res_carry=None):
     """-> (dx CL, dres CL or None, dgamma, dbeta).  accum_into = (dgamma_buf, dbeta_buf): the parameter
     gradients are added to those buffers instead (dgamma/dbeta returned as None).  scale_shift (2C, from bn_fwd) instead of y:
     the ReLU mask of a layer WITHOUT residual is recomputed from x (mode 2 of omni_bn_bwd), the output tensor is not read.
-    partials (nblk, 2C): the reductions over dy already made by the kernel that produced dy (wino.transform_output_bn_bwd)."""
+    partials (nblk, 2C): the reductions over dy already made by the kernel that produced dy (wino.transform_output_bn_bwd).
+    res_carry: gradient fan-in of the residual tensor (logical NCHW, NHWC memory, any pixel pitch: functional._carry_pitch), added
+    to dres where it is written."""
     xv, dyv = _nhwc(x), _nhwc(dy)
     mode = int(bool(relu))
     if relu and scale_shift is not None:
@@ -68,7 +70,7 @@ def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=N
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
     if partials is not None:
-        assert partials.is_contiguous() and partials.shape[1] == 2 * C
+        assert partials.is_contiguous() and partials.shape[1] == 2 * C and res_carry is None
         L.call("omni_bn_bwd_partials", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(partials),
                partials.shape[0], _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(coef), N * H * W, C, mode,
                int(accum_into is not None), _lib.stream_of(x))
@@ -76,9 +78,15 @@ def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=N
             dgamma = dbeta = None
         return dx.permute(0, 3, 1, 2), (dres.permute(0, 3, 1, 2) if want_dres else None), dgamma, dbeta
     ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
-    L.call("omni_bn_bwd", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(dx),
-           _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, mode,
-           int(accum_into is not None), _lib.stream_of(x))
+    if res_carry is not None:
+        assert want_dres and tuple(res_carry.shape) == tuple(x.shape)
+        L.call("omni_bn_bwd_carry", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(dx),
+               _lib.ptr(dres), res_carry.data_ptr(), res_carry.stride(3), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef),
+               N * H * W, C, mode, int(accum_into is not None), _lib.stream_of(x))
+    else:
+        L.call("omni_bn_bwd", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(dx),
+               _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, mode,
+               int(accum_into is not None), _lib.stream_of(x))
     if accum_into is not None:
         dgamma = dbeta = None
     return dx.permute(0, 3, 1, 2), (dres.permute(0, 3, 1, 2) if want_dres else None), dgamma, dbeta
@@ -97,10 +105,18 @@ def maxpool2_fwd(x):
     return _simple("omni_maxpool2_fwd", xv, (N, H // 2, W // 2, C), (N, H, W, C)).permute(0, 3, 1, 2)
 
 
-def maxpool2_bwd(x, dy):
+def maxpool2_bwd(x, dy, carry=None):
+    """carry: gradient fan-in of x (logical NCHW like x, NHWC memory, any pixel pitch), added to the routed gradient"""
     xv, dyv = _nhwc(x), _nhwc(dy)
     N, H, W, C = xv.shape
-    return _simple("omni_maxpool2_bwd", xv, (N, H, W, C), (N, H, W, C), extra_in=(dyv,)).permute(0, 3, 1, 2)
+    if carry is None:
+        return _simple("omni_maxpool2_bwd", xv, (N, H, W, C), (N, H, W, C), extra_in=(dyv,)).permute(0, 3, 1, 2)
+    assert tuple(carry.shape) == tuple(x.shape)
+    L = _lib.check_device(xv, dyv)
+    dx = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+    L.call("omni_maxpool2_bwd_carry", _lib.ptr(xv), _lib.ptr(dyv), carry.data_ptr(), carry.stride(3), _lib.ptr(dx), N, H, W, C,
+           _lib.stream_of(x))
+    return dx.permute(0, 3, 1, 2)
 
 
 def avgpool2_fwd(x):
@@ -136,10 +152,17 @@ def upsample2_add(lat, top):
     return _simple("omni_upsample2_add", lv, (N, H, W, C), (N, H, W, C), extra_in=(tv,)).permute(0, 3, 1, 2)
 
 
-def upsample2_bwd(dout):
+def upsample2_bwd(dout, carry=None):
+    """carry: gradient fan-in of the top-down input ((N,C,H/2,W/2) logical, NHWC memory, any pixel pitch)"""
     dv = _nhwc(dout)
     N, H, W, C = dv.shape
-    return _simple("omni_upsample2_bwd", dv, (N, H // 2, W // 2, C), (N, H, W, C)).permute(0, 3, 1, 2)
+    if carry is None:
+        return _simple("omni_upsample2_bwd", dv, (N, H // 2, W // 2, C), (N, H, W, C)).permute(0, 3, 1, 2)
+    assert tuple(carry.shape) == (N, C, H // 2, W // 2)
+    L = _lib.check_device(dv)
+    dtop = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=dout.device)
+    L.call("omni_upsample2_bwd_carry", _lib.ptr(dv), carry.data_ptr(), carry.stride(3), _lib.ptr(dtop), N, H, W, C, _lib.stream_of(dout))
+    return dtop.permute(0, 3, 1, 2)
 
 
 def preprocess(images_u8, pixel_mean, pixel_std, size_divisibility=0):

@@ -81,14 +81,21 @@ def stem_conv_fwd_stats(x, w):
     return out.permute(0, 3, 1, 2), (stats[:cell.value] if cell.value > 0 else None)
 
 
-def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, tile=0, splits=0):
-    """dy (N,K,OH,OW) CL, w (K,C,R,S) CL -> dx (N,C,H,W) CL."""
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, tile=0, splits=0, accum_into=None):
+    """dy (N,K,OH,OW) CL, w (K,C,R,S) CL -> dx (N,C,H,W) CL.
+    accum_into: gradient fan-in target (logical (N,C,H,W), NHWC memory with any pixel pitch -- functional._carry_pitch): the result
+    is ADDED to it in place (split reductions: atomics on top of its content, no zero-fill) and it is returned."""
     dyv, wv = _nhwc(dy), _nhwc(w)
     N, OH, OW, K = dyv.shape
     K2, R, S, C = wv.shape
     assert K == K2
     H, W = in_hw
     L = _lib.check_device(dyv, wv)
+    if accum_into is not None:
+        assert tuple(accum_into.shape) == (N, C, H, W) and accum_into.stride(1) == 1
+        L.call("omni_conv2d_dgrad_algo", _lib.ptr(dyv), _lib.ptr(wv), accum_into.data_ptr(), N, H, W, C, K, R, S, stride, pad, K,
+               accum_into.stride(3), 1, tile, splits, _lib.stream_of(dy))
+        return accum_into
     dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
     L.call("omni_conv2d_dgrad_algo", _lib.ptr(dyv), _lib.ptr(wv), _lib.ptr(dx), N, H, W, C, K, R, S, stride, pad, K, C, 0,
            tile, splits, _lib.stream_of(dy))

@@ -96,13 +96,18 @@ def gemm_batched_wgrad(V, dM, algo=0):
     return dU
 
 
-def transform_output(Mt, shape, bias=None, relu=False):
-    """Mt (P,T,K) -> y (N,K,H,W) CL; shape = (N, H, W); the tile size follows from P"""
+def transform_output(Mt, shape, bias=None, relu=False, carry=None):
+    """Mt (P,T,K) -> y (N,K,H,W) CL; shape = (N, H, W); the tile size follows from P.
+    carry (data gradients): gradient fan-in, a logical (N,K,H,W) tensor in NHWC memory with any pixel pitch, added to the result"""
     tile = 2 if Mt.shape[0] == 16 else 4
     N, H, W = shape
     K = Mt.shape[2]
     L = _lib.check_device(Mt, bias)
     y = torch.empty((N, H, W, K), dtype=torch.float32, device=Mt.device)
+    if carry is not None:
+        assert bias is None and not relu and tuple(carry.shape) == (N, K, H, W)
+        L.call("omni_wino_out_carry", _lib.ptr(Mt), carry.data_ptr(), carry.stride(3), _lib.ptr(y), N, H, W, K, tile, _lib.stream_of(Mt))
+        return y.permute(0, 3, 1, 2)
     L.call("omni_wino_out", _lib.ptr(Mt), _lib.ptr(bias), _lib.ptr(y), N, H, W, K, int(relu), tile, _lib.stream_of(Mt))
     return y.permute(0, 3, 1, 2)
 
@@ -197,16 +202,16 @@ def conv3x3_fwd(x, w, bias=None, relu=False, U=None, tile=2, want_stats=False):
     return transform_output(Mt, (N, H, W), bias, relu), V
 
 
-def conv3x3_dgrad(dy, w, U_flip=None, tile=2):
-    """dx = the same Winograd convolution applied to dy with the rotated / transposed filter."""
+def conv3x3_dgrad(dy, w, U_flip=None, tile=2, carry=None):
+    """dx = the same Winograd convolution applied to dy with the rotated / transposed filter (+ carry: see transform_output)."""
     N, _, H, W = dy.shape
     if U_flip is None:
         U_flip = transform_weights(w, want_u=False, want_flip=True, tile=tile)[1]
     Mt = gemm_batched(transform_input(dy, tile), U_flip)
-    return transform_output(Mt, (N, H, W))
+    return transform_output(Mt, (N, H, W), carry=carry)
 
 
-def conv3x3_backward(V, dy, w, U_flip, accum_into=None, side_run=None, bn_below=None):
+def conv3x3_backward(V, dy, w, U_flip, accum_into=None, side_run=None, bn_below=None, carry=None):
     """data gradient + weight gradient through Winograd with ONE pass over dy -> (dx, dw or None when accumulated).
     side_run(fn, keepalive): runs the weight-gradient half (batched GEMM + transform back, accumulated in place) on the
     weight-gradient stream (functional._side_run)."""
@@ -219,7 +224,9 @@ def conv3x3_backward(V, dy, w, U_flip, accum_into=None, side_run=None, bn_below=
         dw = None
     if U_flip is None:
         U_flip = transform_weights(w, want_u=False, want_flip=True, tile=tile)[1]
-    if bn_below is not None and tile == 4:
+    if carry is not None:       # gradient fan-in of the input tensor, read by the output transform (see transform_output)
+        dx = transform_output(gemm_batched(Vd, U_flip), (N, H, W), carry=carry)
+    elif bn_below is not None and tile == 4:
         # the input of this convolution is the output of a BatchNorm(+ReLU): dx is that layer's dy, and the transform that writes
         # it also leaves the partial sums the BatchNorm backward starts with (functional._BatchNorm.backward picks them up)
         dx, parts = transform_output_bn_bwd(gemm_batched(Vd, U_flip), (N, H, W), *bn_below[:3])
