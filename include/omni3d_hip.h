@@ -153,13 +153,17 @@ int omni_upsample2_bwd(const float* dout, float* dtop, int N, int H, int W, int 
  *   omni_bn_bwd_carry        dres = masked dy + res_carry        (res_carry nullable: then == omni_bn_bwd)
  *   omni_maxpool2_bwd_carry  dx = routed dy + carry              (carry nullable; H, W even when given)
  *   omni_upsample2_bwd_carry dtop = 2x2 block sums + carry       (carry nullable)
- * The implicit-GEMM data gradient takes the same role through omni_conv2d_dgrad(accumulate = 1, lddx = the carry's pitch). */
+ *   omni_subsample2_bwd_carry dx = carry + dy at the even pixels (the p6 = p5[::2, ::2] level; one pass instead of fill + scatter + add)
+ * The implicit-GEMM data gradient takes the same role through omni_conv2d_dgrad(accumulate = 1, lddx = the carry's pitch).
+ * omni_bn_bwd_carry / omni_maxpool2_bwd_carry also read their OUTPUT gradient dy with a pixel pitch lddy (same constraints): a
+ * Root child with no other consumer gets its slice of the concatenated gradient without a copy. */
 int omni_wino_out_carry(const float* M, const float* carry, long long ldc, float* y, int N, int H, int W, int K, int tile, void* stream);
-int omni_bn_bwd_carry(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
+int omni_bn_bwd_carry(const float* x, const float* dy, long long lddy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
                       float* dres, const float* res_carry, long long ldc, float* dgamma, float* dbeta, double* ws, float* coef,
                       int P, int C, int relu, int accumulate_param_grads, void* stream);
-int omni_maxpool2_bwd_carry(const float* x, const float* dy, const float* carry, long long ldc, float* dx, int N, int H, int W,
-                            int C, void* stream);
+int omni_maxpool2_bwd_carry(const float* x, const float* dy, long long lddy, const float* carry, long long ldc, float* dx, int N, int H,
+                            int W, int C, void* stream);
+int omni_subsample2_bwd_carry(const float* dy, const float* carry, long long ldc, float* dx, int N, int H, int W, int C, void* stream);
 int omni_upsample2_bwd_carry(const float* dout, const float* carry, long long ldc, float* dtop, int N, int H, int W, int C,
                              void* stream);
 

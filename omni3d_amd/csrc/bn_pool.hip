@@ -36,7 +36,7 @@ template <int MODE>
 __device__ __forceinline__ void bn_reduce_tile(const float* __restrict__ x, const float* __restrict__ dy,
                                                const float* __restrict__ y, const float* __restrict__ mean_rstd,
                                                int P, int C, int relu, double* __restrict__ acc, int cbase, int C4,
-                                               float4* __restrict__ s0, float4* __restrict__ s1) {
+                                               float4* __restrict__ s0, float4* __restrict__ s1, long lddy) {
     const int rows = 256 / C4;
     const int t = threadIdx.x;
     const int col = cbase + t % C4, row = t / C4;
@@ -60,7 +60,7 @@ __device__ __forceinline__ void bn_reduce_tile(const float* __restrict__ x, cons
                 for (int u = 0; u < 4; ++u) { a0 = a0 + xv[u]; a1 = a1 + xv[u] * xv[u]; }
             } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) g[u] = ld4(dy + (p + u * step) * C + 4 * col);
+                for (int u = 0; u < 4; ++u) g[u] = ld4(dy + (p + u * step) * lddy + 4 * col);
                 if (relu == 1) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) g[u] = mask4(g[u], ld4(y + (p + u * step) * C + 4 * col));
@@ -79,7 +79,7 @@ __device__ __forceinline__ void bn_reduce_tile(const float* __restrict__ x, cons
                 a0 = a0 + xv;
                 a1 = a1 + xv * xv;
             } else {
-                float4 g = ld4(dy + off);
+                float4 g = ld4(dy + p * lddy + 4 * col);
                 if (relu == 1) g = mask4(g, ld4(y + off));
                 else if (relu == 2) g = mask4(g, xv * sc + sh);
                 a0 = a0 + g;
@@ -103,20 +103,21 @@ __device__ __forceinline__ void bn_reduce_tile(const float* __restrict__ x, cons
 template <int MODE>
 __device__ __forceinline__ void bn_reduce_body(const float* __restrict__ x, const float* __restrict__ dy,
                                                const float* __restrict__ y, const float* __restrict__ mean_rstd,
-                                               int P, int C, int relu, double* __restrict__ acc) {
+                                               int P, int C, int relu, double* __restrict__ acc, long lddy = 0) {
     __shared__ float4 s0[256], s1[256];
+    if (lddy == 0) lddy = C;        // (dy: pixel pitch lddy floats -- a channel slice of a wider NHWC gradient is read in place)
     const int C4 = C >> 2;
     for (int cbase = 0; cbase < C4; cbase += 256) {
         const int width = C4 - cbase < 256 ? C4 - cbase : 256;
-        bn_reduce_tile<MODE>(x, dy, y, mean_rstd, P, C, relu, acc, cbase, width, s0, s1);
+        bn_reduce_tile<MODE>(x, dy, y, mean_rstd, P, C, relu, acc, cbase, width, s0, s1, lddy);
         if (cbase + 256 < C4) __syncthreads();
     }
 }
 template <int MODE>
 __global__ void __launch_bounds__(256) bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const float* __restrict__ y, const float* __restrict__ mean_rstd,
-                                                        int P, int C, int relu, double* __restrict__ acc) {
-    bn_reduce_body<MODE>(x, dy, y, mean_rstd, P, C, relu, acc);
+                                                        int P, int C, int relu, double* __restrict__ acc, long lddy) {
+    bn_reduce_body<MODE>(x, dy, y, mean_rstd, P, C, relu, acc, lddy);
 }
 
 // Sum the per-block partials of FIN_C channels (both quantities) in fp64: FIN_C column lanes x (256 / FIN_C) row groups + LDS
@@ -238,11 +239,12 @@ __device__ __forceinline__ void bn_bwd_apply_body(const float* __restrict__ x, c
                                                   const float* __restrict__ y, const float* __restrict__ mean_rstd,
                                                   const float* __restrict__ coef, float* __restrict__ dx,
                                                   float* __restrict__ dres, long total4, int C, int relu,
-                                                  const float* __restrict__ res_carry = nullptr, long ldc = 0) {
+                                                  const float* __restrict__ res_carry = nullptr, long ldc = 0, long lddy = 0) {
     const int C4 = C >> 2;
+    const bool dense_dy = lddy == 0 || lddy == C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % C4);
-        float4 g = ld4(dy + 4 * i);
+        float4 g = ld4(dense_dy ? dy + 4 * i : dy + (i / C4) * lddy + 4 * col);
         const float4 xv = ld4(x + 4 * i);
         if (relu == 1) g = mask4(g, ld4(y + 4 * i));
         else if (relu == 2) g = mask4(g, xv * ld4(y + 4 * col) + ld4(y + C + 4 * col));      // y = (scale, shift): see bn_reduce_tile
@@ -257,8 +259,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ y, const float* __restrict__ mean_rstd,
                                                            const float* __restrict__ coef, float* __restrict__ dx,
                                                            float* __restrict__ dres, long total4, int C, int relu,
-                                                           const float* __restrict__ res_carry, long ldc) {
-    bn_bwd_apply_body(x, dy, y, mean_rstd, coef, dx, dres, total4, C, relu, res_carry, ldc);
+                                                           const float* __restrict__ res_carry, long ldc, long lddy) {
+    bn_bwd_apply_body(x, dy, y, mean_rstd, coef, dx, dres, total4, C, relu, res_carry, ldc, lddy);
 }
 
 #ifndef OMNI_HIPEMU
@@ -328,7 +330,7 @@ __device__ __forceinline__ void route(float v00, float v01, float v10, float v11
 
 __global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dx, int N, int H, int W, int C,
-                                                           const float* __restrict__ carry, long ldc) {
+                                                           const float* __restrict__ carry, long ldc, long lddy) {
     const int C4 = C >> 2, OH = H >> 1, OW = W >> 1;
     const long total = (long)N * OH * OW * C4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -339,7 +341,7 @@ __global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const float* __restri
         const int n = (int)(q / OH);
         const long o = (((long)n * H + 2 * oh) * W + 2 * ow) * C + 4 * col;
         const float4 v00 = ld4(x + o), v01 = ld4(x + o + C), v10 = ld4(x + o + (long)W * C), v11 = ld4(x + o + (long)W * C + C);
-        const float4 g = ld4(dy + 4 * i);
+        const float4 g = ld4(dy + (i / C4) * lddy + 4 * col);
         float4 d00, d01, d10, d11;
         route(v00.x, v01.x, v10.x, v11.x, g.x, d00.x, d01.x, d10.x, d11.x);
         route(v00.y, v01.y, v10.y, v11.y, g.y, d00.y, d01.y, d10.y, d11.y);
@@ -384,6 +386,24 @@ __global__ void __launch_bounds__(256) avgpool2_kernel(const float* __restrict__
 
 // ---- stride-2 subsample (max_pool2d kernel 1, stride 2): y[n,oh,ow] = x[n,2oh,2ow] ----------------
 // DIR 0: forward gather; DIR 1: backward scatter into a zero-initialised dx
+// gradient fan-in form of the backward scatter: dx = carry everywhere (+ dy at the even pixels), one pass, no zero-fill
+__global__ void __launch_bounds__(256) subsample2_bwd_carry_kernel(const float* __restrict__ dy, const float* __restrict__ carry, long ldc,
+                                                                   float* __restrict__ dx, int N, int H, int W, int C) {
+    const int C4 = C >> 2, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long total = (long)N * H * W * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % C4);
+        long q = i / C4;
+        const long pix = q;
+        const int w = (int)(q % W); q /= W;
+        const int h = (int)(q % H);
+        const int n = (int)(q / H);
+        float4 v = ld4(carry + pix * ldc + 4 * col);
+        if (!((h | w) & 1)) v = v + ld4(dy + ((((long)n * OH + (h >> 1)) * OW + (w >> 1)) * C4 + col) * 4);
+        st4(dx + 4 * i, v);
+    }
+}
+
 template <int DIR>
 __global__ void __launch_bounds__(256) subsample2_kernel(const float* __restrict__ src, float* __restrict__ dst, int N,
                                                          int H, int W, int C) {
@@ -500,7 +520,7 @@ int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const flo
     const int nblk = red_grid(P, C);
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, x, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial));
+                       (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial), 0L);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, (const float*)partial, nblk, P, C, eps,
                        momentum, gamma, beta, mean_rstd, scale_shift, running_mean, running_var);
     const long total4 = (long)P * (C >> 2);
@@ -540,30 +560,31 @@ static int bad_carry(const float* carry, long long ldc, int C) {
 }
 
 // omni_bn_bwd with gradient fan-in on the residual: dres = (masked dy) + res_carry, res_carry [nullable] an NHWC tensor of the
-// same extent with pixel pitch ldc floats (what the other consumers of the residual tensor already contributed to its gradient).
-int omni_bn_bwd_carry(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
+// same extent with pixel pitch ldc floats (what the other consumers of the residual tensor already contributed to its gradient);
+// dy with pixel pitch lddy floats (a channel slice of the DLA Root's concatenated gradient is read where it lies).
+int omni_bn_bwd_carry(const float* x, const float* dy, long long lddy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
                       float* dres, const float* res_carry, long long ldc, float* dgamma, float* dbeta, double* ws, float* coef, int P,
                       int C, int relu, int accumulate_param_grads, void* stream) {
     if (P <= 0 || C <= 0 || (C & 3) || C > 4096 || relu < 0 || relu > 2 || (relu && y == nullptr)) return OMNI_ERR_ARG;
-    if (bad_carry(res_carry, ldc, C) || (res_carry != nullptr && dres == nullptr)) return OMNI_ERR_ARG;
+    if (bad_carry(res_carry, ldc, C) || (res_carry != nullptr && dres == nullptr) || bad_carry(dy, lddy, C)) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = red_grid(P, C);
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<1>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean_rstd, P, C, relu,
-                       reinterpret_cast<double*>(partial));
+                       reinterpret_cast<double*>(partial), (long)lddy);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, (const float*)partial, nblk, P, C, gamma,
                        mean_rstd, dgamma, dbeta, coef, accumulate_param_grads);
     const long total4 = (long)P * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, dy, y, mean_rstd,
-                       (const float*)coef, dx, dres, total4, C, relu, res_carry, (long)ldc);
+                       (const float*)coef, dx, dres, total4, C, relu, res_carry, (long)ldc, (long)lddy);
     return omni_launch_status();
 }
 
 int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
                 float* dres, float* dgamma, float* dbeta, double* ws, float* coef, int P, int C, int relu,
                 int accumulate_param_grads, void* stream) {
-    return omni_bn_bwd_carry(x, dy, y, gamma, mean_rstd, dx, dres, nullptr, 0, dgamma, dbeta, ws, coef, P, C, relu, accumulate_param_grads,
-                             stream);
+    return omni_bn_bwd_carry(x, dy, C, y, gamma, mean_rstd, dx, dres, nullptr, 0, dgamma, dbeta, ws, coef, P, C, relu,
+                             accumulate_param_grads, stream);
 }
 
 // omni_bn_bwd with the reductions already done by the kernel that produced dy (omni_wino_out_bn_bwd_stats): finalize + apply.
@@ -576,7 +597,7 @@ int omni_bn_bwd_partials(const float* x, const float* dy, const float* y, const 
                        dgamma, dbeta, coef, accumulate_param_grads);
     const long total4 = (long)P * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, dy, y, mean_rstd, (const float*)coef, dx, dres,
-                       total4, C, relu, (const float*)nullptr, 0L);
+                       total4, C, relu, (const float*)nullptr, 0L, 0L);
     return omni_launch_status();
 }
 
@@ -588,19 +609,22 @@ int omni_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void
     return omni_launch_status();
 }
 
-// carry [nullable]: gradient fan-in, dx = routed dy + carry (NHWC, pixel pitch ldc floats; H and W even when given)
-int omni_maxpool2_bwd_carry(const float* x, const float* dy, const float* carry, long long ldc, float* dx, int N, int H, int W, int C,
-                            void* stream) {
-    if ((C & 3) || H < 2 || W < 2 || bad_carry(carry, ldc, C) || (carry != nullptr && ((H & 1) || (W & 1)))) return OMNI_ERR_ARG;
+// carry [nullable]: gradient fan-in, dx = routed dy + carry (NHWC, pixel pitch ldc floats; H and W even when given); dy with pixel
+// pitch lddy floats
+int omni_maxpool2_bwd_carry(const float* x, const float* dy, long long lddy, const float* carry, long long ldc, float* dx, int N, int H,
+                            int W, int C, void* stream) {
+    if ((C & 3) || H < 2 || W < 2 || bad_carry(carry, ldc, C) || (carry != nullptr && ((H & 1) || (W & 1))) || bad_carry(dy, lddy, C))
+        return OMNI_ERR_ARG;
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     if (total == 0) return OMNI_OK;
     if ((H & 1) || (W & 1)) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, (hipStream_t)stream);
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C, carry, (long)ldc);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C, carry, (long)ldc,
+                       (long)lddy);
     return omni_launch_status();
 }
 
 int omni_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
-    return omni_maxpool2_bwd_carry(x, dy, nullptr, 0, dx, N, H, W, C, stream);
+    return omni_maxpool2_bwd_carry(x, dy, C, nullptr, 0, dx, N, H, W, C, stream);
 }
 
 int omni_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
@@ -636,6 +660,16 @@ int omni_subsample2_bwd(const float* dy, float* dx, int N, int H, int W, int C, 
     if (total == 0) return OMNI_OK;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(subsample2_kernel<1>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy,
                        dx, N, H, W, C);
+    return omni_launch_status();
+}
+
+// carry (required): gradient fan-in, dx = carry + scattered dy (NHWC (N,H,W,C), pixel pitch ldc floats)
+int omni_subsample2_bwd_carry(const float* dy, const float* carry, long long ldc, float* dx, int N, int H, int W, int C, void* stream) {
+    if ((C & 3) || carry == nullptr || bad_carry(carry, ldc, C)) return OMNI_ERR_ARG;
+    const long total = (long)N * H * W * (C / 4);
+    if (total == 0) return OMNI_OK;
+    hipLaunchKernelGGL(subsample2_bwd_carry_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, carry, (long)ldc, dx, N, H,
+                       W, C);
     return omni_launch_status();
 }
 
@@ -695,7 +729,7 @@ int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, int acc
     }
 #endif
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, dy, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial));
+                       (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial), 0L);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, (const float*)partial, nblk, C, db,
                        accumulate);
     return omni_launch_status();

@@ -496,9 +496,12 @@ class _BatchNorm(Function):
         want_dres = has_res and ctx.needs_input_grad[5]
         box = []
 
+        # (dy that is a channel slice of the Root's concatenated gradient is read where it lies)
+        dyk = dy if (parts is None and not dy.is_contiguous(memory_format=CL) and _carry_pitch(dy) is not None) else _cl(dy)
+
         def run(carry):     # carry: what the other consumers of the residual tensor contributed, added where dres is written
             ok = carry is not None and parts is None and _carry_pitch(carry) is not None
-            dx_, dres_, dgamma_, dbeta_ = bnpool.bn_bwd(x, _cl(dy), y, gamma, mean_rstd, relu, want_dres=want_dres, accum_into=ctx.direct,
+            dx_, dres_, dgamma_, dbeta_ = bnpool.bn_bwd(x, dyk, y, gamma, mean_rstd, relu, want_dres=want_dres, accum_into=ctx.direct,
                                                         scale_shift=scale_shift, partials=parts, res_carry=carry if ok else None)
             box.append((dx_, dgamma_, dbeta_))
             return dres_ if (ok or carry is None) else dres_ + carry
@@ -525,10 +528,12 @@ class _MaxPool2(Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
 
+        dyk = dy if (not dy.is_contiguous(memory_format=CL) and _carry_pitch(dy) is not None) else _cl(dy)
+
         def run(carry):
             if carry is not None and (_carry_pitch(carry) is None or (x.shape[2] | x.shape[3]) & 1):
-                return bnpool.maxpool2_bwd(x, _cl(dy)) + carry
-            return bnpool.maxpool2_bwd(x, _cl(dy), carry=carry)
+                return bnpool.maxpool2_bwd(x, dyk) + carry
+            return bnpool.maxpool2_bwd(x, dyk, carry=carry)
         return _slot_deliver(ctx.slot, run)
 
 
@@ -554,7 +559,11 @@ class _Subsample2(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        return _slot_deliver(ctx.slot, lambda carry: _add_carry(bnpool.subsample2_bwd(_cl(dy), ctx.hw), carry))
+        def run(carry):
+            if carry is not None and _carry_pitch(carry) is None:
+                return bnpool.subsample2_bwd(_cl(dy), ctx.hw) + carry
+            return bnpool.subsample2_bwd(_cl(dy), ctx.hw, carry=carry)
+        return _slot_deliver(ctx.slot, run)
 
 
 class _Upsample2Add(Function):

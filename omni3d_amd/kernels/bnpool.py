@@ -50,8 +50,10 @@ def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=N
     the ReLU mask of a layer WITHOUT residual is recomputed from x (mode 2 of omni_bn_bwd), the output tensor is not read.
     partials (nblk, 2C): the reductions over dy already made by the kernel that produced dy (wino.transform_output_bn_bwd).
     res_carry: gradient fan-in of the residual tensor (logical NCHW, NHWC memory, any pixel pitch: functional._carry_pitch), added
-    to dres where it is written."""
-    xv, dyv = _nhwc(x), _nhwc(dy)
+    to dres where it is written.  dy may be such a pitched tensor too (a channel slice of the Root's concatenated gradient)."""
+    xv = _nhwc(x)
+    dy_pitched = not dy.is_contiguous(memory_format=torch.channels_last)
+    dyv = None if dy_pitched else _nhwc(dy)
     mode = int(bool(relu))
     if relu and scale_shift is not None:
         assert y is None and scale_shift.is_contiguous() and scale_shift.numel() == 2 * xv.shape[3]
@@ -70,7 +72,7 @@ def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=N
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
     if partials is not None:
-        assert partials.is_contiguous() and partials.shape[1] == 2 * C and res_carry is None
+        assert partials.is_contiguous() and partials.shape[1] == 2 * C and res_carry is None and not dy_pitched
         L.call("omni_bn_bwd_partials", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(partials),
                partials.shape[0], _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(coef), N * H * W, C, mode,
                int(accum_into is not None), _lib.stream_of(x))
@@ -78,11 +80,13 @@ def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=N
             dgamma = dbeta = None
         return dx.permute(0, 3, 1, 2), (dres.permute(0, 3, 1, 2) if want_dres else None), dgamma, dbeta
     ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
-    if res_carry is not None:
-        assert want_dres and tuple(res_carry.shape) == tuple(x.shape)
-        L.call("omni_bn_bwd_carry", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(dx),
-               _lib.ptr(dres), res_carry.data_ptr(), res_carry.stride(3), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef),
-               N * H * W, C, mode, int(accum_into is not None), _lib.stream_of(x))
+    if res_carry is not None or dy_pitched:
+        assert tuple(dy.shape) == tuple(x.shape) and dy.stride(1) == 1
+        if res_carry is not None:
+            assert want_dres and tuple(res_carry.shape) == tuple(x.shape)
+        L.call("omni_bn_bwd_carry", _lib.ptr(xv), dy.data_ptr(), dy.stride(3), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd),
+               _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(res_carry), res_carry.stride(3) if res_carry is not None else 0, _lib.ptr(dgamma),
+               _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, mode, int(accum_into is not None), _lib.stream_of(x))
     else:
         L.call("omni_bn_bwd", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(dx),
                _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, mode,
@@ -106,16 +110,17 @@ def maxpool2_fwd(x):
 
 
 def maxpool2_bwd(x, dy, carry=None):
-    """carry: gradient fan-in of x (logical NCHW like x, NHWC memory, any pixel pitch), added to the routed gradient"""
-    xv, dyv = _nhwc(x), _nhwc(dy)
+    """carry: gradient fan-in of x (logical NCHW like x, NHWC memory, any pixel pitch), added to the routed gradient; dy may be
+    pitched the same way (functional._carry_pitch)"""
+    xv = _nhwc(x)
     N, H, W, C = xv.shape
-    if carry is None:
-        return _simple("omni_maxpool2_bwd", xv, (N, H, W, C), (N, H, W, C), extra_in=(dyv,)).permute(0, 3, 1, 2)
-    assert tuple(carry.shape) == tuple(x.shape)
-    L = _lib.check_device(xv, dyv)
+    if carry is None and dy.is_contiguous(memory_format=torch.channels_last):
+        return _simple("omni_maxpool2_bwd", xv, (N, H, W, C), (N, H, W, C), extra_in=(_nhwc(dy),)).permute(0, 3, 1, 2)
+    assert (carry is None or tuple(carry.shape) == tuple(x.shape)) and tuple(dy.shape) == (N, C, H // 2, W // 2) and dy.stride(1) == 1
+    L = _lib.check_device(xv)
     dx = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
-    L.call("omni_maxpool2_bwd_carry", _lib.ptr(xv), _lib.ptr(dyv), carry.data_ptr(), carry.stride(3), _lib.ptr(dx), N, H, W, C,
-           _lib.stream_of(x))
+    L.call("omni_maxpool2_bwd_carry", _lib.ptr(xv), dy.data_ptr(), dy.stride(3), _lib.ptr(carry), carry.stride(3) if carry is not None else 0,
+           _lib.ptr(dx), N, H, W, C, _lib.stream_of(x))
     return dx.permute(0, 3, 1, 2)
 
 
@@ -138,11 +143,18 @@ def subsample2_fwd(x):
     return _simple("omni_subsample2_fwd", xv, (N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), (N, H, W, C)).permute(0, 3, 1, 2)
 
 
-def subsample2_bwd(dy, in_hw):
+def subsample2_bwd(dy, in_hw, carry=None):
+    """carry: gradient fan-in of x ((N,C,H,W) logical, NHWC memory, any pixel pitch): dx = carry + scattered dy in one pass"""
     dyv = _nhwc(dy)
     N, _, _, C = dyv.shape
     H, W = in_hw
-    return _simple("omni_subsample2_bwd", dyv, (N, H, W, C), (N, H, W, C)).permute(0, 3, 1, 2)
+    if carry is None:
+        return _simple("omni_subsample2_bwd", dyv, (N, H, W, C), (N, H, W, C)).permute(0, 3, 1, 2)
+    assert tuple(carry.shape) == (N, C, H, W)
+    L = _lib.check_device(dyv)
+    dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+    L.call("omni_subsample2_bwd_carry", _lib.ptr(dyv), carry.data_ptr(), carry.stride(3), _lib.ptr(dx), N, H, W, C, _lib.stream_of(dy))
+    return dx.permute(0, 3, 1, 2)
 
 
 def upsample2_add(lat, top):
