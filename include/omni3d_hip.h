@@ -225,6 +225,22 @@ int omni_rpn_finalize_labels(const float* anchors, int A, int B, const int* gt_o
 int omni_rpn_gather_logits(const void* const* level_ptrs, const int* level_hw, int nlev, int B, float* logits,
                            void* stream);
 
+/* The two 1x1 convolutions of detectron2's StandardRPNHead (objectness_logits: nn.Conv2d(256, 3, 1), anchor_deltas:
+ * nn.Conv2d(256, 12, 1); configs/Base.yaml:49, reached from cubercnn/modeling/proposal_generator/rpn.py:129-135) over ALL FPN levels
+ * in one launch per direction, as one 16-wide product per pixel: y[p] = [3 logits | 12 deltas | 0] (the layout above).
+ * t / y / dy / dt: HOST arrays of nlev (<= 8) device pointers -- t_l (P_l, 256) fp32 NHWC = relu(conv(x_l)), y_l / dy_l (P_l, 16),
+ * dt_l (P_l, 256); pix: HOST array of P_l = B * H_l * W_l; w_obj (3, 256), w_del (12, 256), biases (3), (12).
+ *   fwd    y_l = t_l . [w_obj | w_del | 0]^T + [b_obj | b_del | 0]                 (fp32 MFMA 16x16x4, operands straight from HBM)
+ *   dgrad  dt_l = dy_l . [w_obj | w_del | 0], zeroed where t_l <= 0 when relu_mask != 0 (the ReLU backward of the shared conv)
+ *   wgrad  dw_obj, db_obj, dw_del, db_del [each nullable] = (accumulate == 0) or += the sums over every pixel of every level;
+ *          partial = scratch of partial_rows (>= 1; 512 fills the chip) * (15 * 256 + 16) floats; fixed summation order, no atomics. */
+int omni_rpn_head16_fwd(const void* const* t, const long long* pix, int nlev, const float* w_obj, const float* b_obj,
+                        const float* w_del, const float* b_del, const void* const* y, void* stream);
+int omni_rpn_head16_dgrad(const void* const* dy, const void* const* t, const long long* pix, int nlev, const float* w_obj,
+                          const float* w_del, int relu_mask, const void* const* dt, void* stream);
+int omni_rpn_head16_wgrad(const void* const* dy, const void* const* t, const long long* pix, int nlev, float* partial,
+                          int partial_rows, float* dw_obj, float* db_obj, float* dw_del, float* db_del, int accumulate, void* stream);
+
 /* RPNWithIgnore.losses with OBJECTNESS_UNCERTAINTY "IoUness" (rpn.py:129-204, 206-273): sums (6 doubles)
  * = [sum BCE*t, sum L1*t, #pos, #neg, sum sigmoid(pos), sum sigmoid(non-pos)]. */
 int omni_rpn_loss_fwd(const void* const* level_ptrs, const int* level_hw, int nlev, int B, const float* anchors,

@@ -66,6 +66,11 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
+// value of `v` in lane `lane` (a compile-time constant) as a wave-uniform scalar: v_readlane_b32
+__device__ __forceinline__ float omni_readlane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 // exact-f32 matrix cores (CDNA4): D = A(32x2) * B(2x32) + C, one f32 per lane for A and B.
 // lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
 // C/D: col j = l & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) for register r in [0,16).

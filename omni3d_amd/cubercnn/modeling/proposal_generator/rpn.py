@@ -20,6 +20,8 @@ from ..layers import Conv2d
 from ..registries import PROPOSAL_GENERATOR_REGISTRY, RPN_HEAD_REGISTRY
 
 CL = torch.channels_last
+import os as _os
+_FUSED_HEAD = _os.environ.get("OMNI_RPN_HEAD16", "1") != "0"      # A/B knob: the two 1x1 heads of all levels as one launch per direction
 
 
 @RPN_HEAD_REGISTRY.register()
@@ -51,6 +53,9 @@ class StandardRPNHead(nn.Module):
 
     def forward(self, features):
         wl, wd = self.objectness_logits.weight, self.anchor_deltas.weight
+        if _FUSED_HEAD and HF.rpn_head16_eligible(features, wl, wd):
+            # both 1x1 heads over every level: one HBM-bound launch per direction (csrc/rpn_head.hip)
+            return HF.rpn_head16([self.conv(x, relu=True) for x in features], wl, self.objectness_logits.bias, wd, self.anchor_deltas.bias)
         w16 = torch.cat([wl, wd, wl.new_zeros(1, wl.shape[1], 1, 1)], dim=0)
         b16 = torch.cat([self.objectness_logits.bias, self.anchor_deltas.bias, wl.new_zeros(1)])
         return [HF.conv2d(self.conv(x, relu=True), w16, b16, 1, 0) for x in features]   # (B,16,H,W) CL each

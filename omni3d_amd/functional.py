@@ -238,6 +238,7 @@ class _Conv2d(Function):
     def backward(ctx, dy, _parts_grad=None):
         x, w, y = ctx.saved_tensors
         stride, pad, relu, has_bias = ctx.cfg
+        relu = relu and not getattr(dy, "_omni_relu_masked", False)       # (the consumer's data-gradient kernel applied the mask)
         dy = _cl(dy)
         if relu:   # elementwise on the NHWC views (same dense layout for dy and y)
             dy = bnpool.relu_bwd(dy.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
@@ -310,6 +311,7 @@ class _WinoConv3x3(Function):
     def backward(ctx, dy, _parts_grad=None):
         V, w, y, Uf = ctx.saved_tensors
         relu, has_bias = ctx.cfg
+        relu = relu and not getattr(dy, "_omni_relu_masked", False)       # (the consumer's data-gradient kernel applied the mask)
         dy = _cl(dy)
         if relu:
             dy = bnpool.relu_bwd(dy.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
@@ -347,6 +349,56 @@ class _WinoConv3x3(Function):
         if has_bias and ctx.needs_input_grad[2]:
             db = bnpool.bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]), accum_into=gb)
         return dx, dw, db, None, None
+
+
+class _RPNHead16(Function):
+    """objectness_logits + anchor_deltas of detectron2's StandardRPNHead over all FPN levels (csrc/rpn_head.hip): ts = the per-level
+    ReLU outputs of the shared 3x3 convolution, (B, 256, H, W) CL -> per-level (B, 16, H, W) CL [3 logits | 12 deltas | 0].
+    One launch forward, one for the data gradients (which come back already masked by the ReLU of the convolution below), two for the
+    four parameter gradients, which land in the gradient bucket directly -- instead of, per level, a 16-wide implicit GEMM in each
+    direction, a ReLU backward, a bias gradient and the adds that sum the per-level parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, w_obj, b_obj, w_del, b_del, *ts):
+        ctx.direct = (_direct_grad(w_obj), _direct_grad(b_obj), _direct_grad(w_del), _direct_grad(b_del))
+        tn = [_cl(t).permute(0, 2, 3, 1) for t in ts]
+        w_obj, w_del = _cl(w_obj), _cl(w_del)          # (K, 256, 1, 1) CL == (K, 256) row-major
+        ys = det.head16_fwd(tn, w_obj, b_obj.contiguous(), w_del, b_del.contiguous())
+        ctx.save_for_backward(w_obj, w_del, *tn)
+        return tuple(y.permute(0, 3, 1, 2) for y in ys)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        w_obj, w_del, *tn = ctx.saved_tensors
+        dys = [(_cl(d).permute(0, 2, 3, 1) if d is not None else torch.zeros(t.shape[:3] + (16,), dtype=torch.float32, device=t.device))
+               for d, t in zip(douts, tn)]
+        dts = [None] * len(tn)
+        if any(ctx.needs_input_grad[4:]):
+            dts = []
+            for d in det.head16_dgrad(dys, tn, w_obj, w_del, relu_mask=True):
+                d = d.permute(0, 3, 1, 2)
+                d._omni_relu_masked = True           # read by _WinoConv3x3 / _Conv2d.backward: no second pass for the ReLU
+                dts.append(d)
+        grads = (None, None, None, None)
+        if any(ctx.needs_input_grad[:4]):
+            direct = ctx.direct
+            if all(g is not None for g in direct) and direct[0].is_contiguous(memory_format=CL) and direct[2].is_contiguous(memory_format=CL):
+                _side_run(lambda: det.head16_wgrad(dys, tn, accum_into=(direct[0].permute(0, 2, 3, 1), direct[1], direct[2].permute(0, 2, 3, 1),
+                                                                           direct[3])), tuple(dys) + tuple(tn))
+            else:
+                gw_o, gb_o, gw_d, gb_d = det.head16_wgrad(dys, tn)
+                grads = (gw_o.view(3, 1, 1, -1).permute(0, 3, 1, 2), gb_o, gw_d.view(12, 1, 1, -1).permute(0, 3, 1, 2), gb_d)
+        return grads + tuple(dts)
+
+
+def rpn_head16_eligible(ts, w_obj, w_del):
+    return (all(t.shape[1] == det.HEAD16_C and t.dtype == torch.float32 for t in ts) and tuple(w_obj.shape[:2]) == (3, det.HEAD16_C)
+            and tuple(w_del.shape[:2]) == (12, det.HEAD16_C) and tuple(w_obj.shape[2:]) == (1, 1) and len(ts) <= 8)
+
+
+def rpn_head16(ts, w_obj, b_obj, w_del, b_del):
+    """-> list of per-level (B, 16, H, W) CL head outputs"""
+    return list(_RPNHead16.apply(w_obj, b_obj, w_del, b_del, *ts))
 
 
 _wino_scope = {"cache": None}     # (weight address, shape) -> (U, U'), only while a model forward is running

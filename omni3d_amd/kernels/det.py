@@ -93,6 +93,54 @@ class LevelPack:
         return _cast(p), _cast(h), len(self.tensors)
 
 
+def _longs(vals):
+    return (ctypes.c_longlong * len(vals))(*[int(v) for v in vals])
+
+
+HEAD16_C = 256          # input width the fused RPN head kernels (csrc/rpn_head.hip) are written for
+_HEAD16_ROWS = 512
+
+
+def head16_fwd(ts, w_obj, b_obj, w_del, b_del):
+    """ts: per-level (B, H, W, 256) NHWC activations; w_obj (3, 256), w_del (12, 256) row-major -> per-level (B, H, W, 16)
+    [3 logits | 12 deltas | 0] of detectron2's StandardRPNHead, all levels in one launch"""
+    L = _dev(*ts, w_obj, b_obj, w_del, b_del)
+    ys = [_empty(t.shape[:3] + (16,), torch.float32, t) for t in ts]
+    tp, yp, px = _ptrs(ts), _ptrs(ys), _longs([t.shape[0] * t.shape[1] * t.shape[2] for t in ts])
+    L.call("omni_rpn_head16_fwd", _cast(tp), _cast(px), len(ts), _lib.ptr(w_obj), _lib.ptr(b_obj), _lib.ptr(w_del), _lib.ptr(b_del), _cast(yp),
+           _lib.stream_of(ts[0]))
+    return ys
+
+
+def head16_dgrad(dys, ts, w_obj, w_del, relu_mask=True):
+    """-> per-level gradients wrt ts, zeroed where ts <= 0 (relu_mask: ts are ReLU outputs and the gradient wrt the ReLU INPUT is wanted)"""
+    L = _dev(*dys, *ts, w_obj, w_del)
+    dts = [torch.empty_like(t) for t in ts]
+    dp, tp, op, px = _ptrs(dys), _ptrs(ts), _ptrs(dts), _longs([t.shape[0] * t.shape[1] * t.shape[2] for t in ts])
+    L.call("omni_rpn_head16_dgrad", _cast(dp), _cast(tp), _cast(px), len(ts), _lib.ptr(w_obj), _lib.ptr(w_del), int(bool(relu_mask)), _cast(op),
+           _lib.stream_of(ts[0]))
+    return dts
+
+
+def head16_wgrad(dys, ts, accum_into=None):
+    """-> (dw_obj (3, 256), db_obj (3), dw_del (12, 256), db_del (12)); accum_into: the same four as contiguous buffers (None entries
+    allowed) that the sums are ADDED to instead (returns None for those)"""
+    L = _dev(*dys, *ts)
+    ref = ts[0]
+    partial = _empty((_HEAD16_ROWS * (15 * HEAD16_C + 16),), torch.float32, ref)
+    fresh = [_empty(s, torch.float32, ref) for s in ((3, HEAD16_C), (3,), (12, HEAD16_C), (12,))]
+    dp, tp, px = _ptrs(dys), _ptrs(ts), _longs([t.shape[0] * t.shape[1] * t.shape[2] for t in ts])
+    if accum_into is not None and all(a is not None for a in accum_into):
+        for a in accum_into:
+            assert a.is_contiguous()
+        L.call("omni_rpn_head16_wgrad", _cast(dp), _cast(tp), _cast(px), len(ts), _lib.ptr(partial), _HEAD16_ROWS, *[_lib.ptr(a) for a in accum_into],
+               1, _lib.stream_of(ref))
+        return (None, None, None, None)
+    L.call("omni_rpn_head16_wgrad", _cast(dp), _cast(tp), _cast(px), len(ts), _lib.ptr(partial), _HEAD16_ROWS, *[_lib.ptr(a) for a in fresh], 0,
+           _lib.stream_of(ref))
+    return tuple(fresh)
+
+
 def rpn_gather_logits(pack):
     L = _dev(*pack.tensors)
     out = _empty((pack.B, pack.A), torch.float32, pack.tensors[0])

@@ -183,6 +183,8 @@ static inline int wave_sum_i(int v) {
     return v;
 }
 
+static inline float omni_readlane(float v, int lane) { return __shfl(v, lane, 64); }
+
 // MFMA emulation.  Bitwise model of v_mfma_f32_32x32x2_f32 per the CDNA4 guide: a k-ordered
 // fmaf chain, one rounding per product.
 static inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
