@@ -24,6 +24,40 @@ def _leaf_grad(t):
     return left if t.grad is None else t.grad + left
 
 
+def make_side_stream(device=None):
+    """The weight-gradient stream.  The critical path runs on the main stream and is ~92 % busy (rocprofv3 trace, queue 1: 11.4 of
+    12.4 ms); whatever the side stream runs beside it competes for the same CUs, and a PERSISTENT side kernel (the fc1-class weight
+    gradient on the GEMM engine: one workgroup per CU for 0.57 ms) stops every main-stream kernel that cannot co-reside with it
+    until it ends (a 50 us data gradient measured at 557 us).  Two knobs bound that:
+      OMNI_SIDE_CUS=n       the side stream's queue is created on n of the 256 CUs (hipExtStreamCreateWithCUMask; the mask bits are
+                            spread over the XCDs), so the critical path always finds 256 - n CUs free of weight-gradient work;
+      OMNI_SIDE_PRIORITY=p  stream priority of the side stream (torch: lower value = higher priority; 0 = default).
+    Defaults are the measured optimum (profiles/r03_ab_side_stream.log)."""
+    import ctypes
+    import os
+    n = int(os.environ.get("OMNI_SIDE_CUS", str(SIDE_CUS_DEFAULT)))
+    prio = int(os.environ.get("OMNI_SIDE_PRIORITY", "0"))
+    if 0 < n < 256:
+        hip = ctypes.CDLL("libamdhip64.so")
+        dev = torch.cuda.current_device() if device is None else torch.device(device).index
+        with torch.cuda.device(dev):
+            words = (ctypes.c_uint32 * 8)()
+            for bit in range(n):                # bits 0 .. n-1: KFD deals consecutive mask bits round-robin over the XCDs
+                words[bit // 32] |= 1 << (bit % 32)
+            st = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+            if rc == 0 and st.value:
+                _MASKED_STREAMS.append(st)      # (never destroyed: lives as long as the process, like torch's pooled streams)
+                return torch.cuda.ExternalStream(st.value, device=dev)
+    if prio != 0:
+        return torch.cuda.Stream(priority=prio)
+    return torch.cuda.Stream()
+
+
+SIDE_CUS_DEFAULT = 0            # 0 = no mask
+_MASKED_STREAMS = []
+
+
 class FeatureCut:
     """Splits backward at the FPN features: `cut(features)` hands detached copies to the heads (RPN, ROI heads), so
     `total.backward()` stops there with the heads' parameter gradients complete; `cut.backward()` then pushes the
@@ -231,7 +265,7 @@ class GraphedPipelined:
         if not graphs:
             return
         assert torch.cuda.is_available(), "hipGraph capture needs the GPU"
-        self.side = torch.cuda.Stream()
+        self.side = make_side_stream()
         prev_mode = HF.side_mode()
         HF.side_mode("inline")
         warm = torch.cuda.Stream()
