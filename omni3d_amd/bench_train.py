@@ -171,6 +171,10 @@ def run_train(args, world, rank):
         t = torch.tensor([dt], dtype=torch.float64, device=DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if os.environ.get("OMNI_PIPE_TIMING") == "1" and getattr(graphed, "_timing", None):
+        import sys
+        from omni3d_amd.cubercnn.solver.graphed import pipe_timing_report
+        print("pipe timing: " + pipe_timing_report(graphed), file=sys.stderr)
     final_losses = [float(v) for v in torch.stack(loss_log[-args.steps:]).cpu()]
     ims = IMS_PER_GPU * world * args.steps / dt
     step_tf = TRAIN_GFLOP_PER_IMAGE * 1e9 * IMS_PER_GPU * args.steps / dt / 1e12   # per GPU (the per-image figure is for 512 x 512)

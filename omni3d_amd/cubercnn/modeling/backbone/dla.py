@@ -243,12 +243,17 @@ class DLABackbone(Backbone):
         self._out_features = ["p2", "p3", "p4", "p5", "p6"]
 
     stage_cut = None      # solver/graphed.py GraphedPipelined: backward is cut between the levels (x -> detached copy of x)
-    stage_cut_at = ("p2", "p3")       # a cut at level k needs the cuts at all lower levels (see GraphedPipelined); measured optimum
+    # a cut at level k needs the cuts at all lower levels (see GraphedPipelined).  Measured optimum; "stem" (round 3): the main stream
+    # used to wait 0.39 ms for the last weight-gradient graph after its own last kernel, 0.20 ms with the first layer as its own stage
+    # (device timestamps of OMNI_PIPE_TIMING=1, profiles/r03_pipe_timing.log): 12.14 -> 12.06 ms / step
+    stage_cut_at = ("stem", "p2", "p3")
 
     def forward(self, x):
         on = self.stage_cut is not None and self.training and torch.is_grad_enabled()
         cut = lambda name, t: self.stage_cut(t) if (on and name in self.stage_cut_at) else t      # noqa: E731
-        x = self.level1(self.level0(self.base_layer(x)))
+        # ("stem": the first layer's backward -- a BatchNorm backward and a 0.33 ms weight gradient, nothing below it -- as a stage of
+        # its own, so the weight gradients of level 2 .. level 0 run beside it instead of after it)
+        x = self.level1(self.level0(cut("stem", self.base_layer(x))))
         p2 = cut("p2", self.level2(x))
         p3 = cut("p3", self.level3(p2))
         p4 = cut("p4", self.level4(p3))

@@ -55,6 +55,29 @@ def make_side_stream(device=None):
 
 
 SIDE_CUS_DEFAULT = 0            # 0 = no mask
+_PIPE_ORDER = __import__("os").environ.get("OMNI_PIPE_ORDER", "interleaved")
+_PIPE_TIMING = __import__("os").environ.get("OMNI_PIPE_TIMING", "0") == "1"
+
+
+def pipe_timing_report(graphed, last=10):
+    """OMNI_PIPE_TIMING=1: mean over the last steps of, per stage, when M_k / W_k ended on the device (ms after the step's first
+    launch) and how long the host spent inside each graph launch (us) -- without a profiler attached"""
+    torch.cuda.synchronize()
+    recs = graphed._timing[-last:]
+    if not recs:
+        return ""
+    n = len(recs[0]["m"])
+    out = []
+    for k in range(n):
+        m = sum(r["t0"].elapsed_time(r["m"][k]) for r in recs) / len(recs)
+        w = [r["t0"].elapsed_time(r["w"][k]) for r in recs if r["w"][k] is not None]
+        out.append("M%d end %.3f ms%s" % (k, m, (", W%d end %.3f ms" % (k, sum(w) / len(w))) if w else ""))
+    host = {}
+    for r in recs:
+        for name, us in r["host"]:
+            host.setdefault(name, []).append(us)
+    out.append("host us per launch: " + ", ".join("%s %.0f" % (k, sum(v) / len(v)) for k, v in host.items()))
+    return " | ".join(out)
 _MASKED_STREAMS = []
 
 
@@ -262,6 +285,7 @@ class GraphedPipelined:
             if os.environ.get("OMNI_PIPE_CUTS") is not None:       # A/B knob: "" | "p2" | "p2,p3" | "p2,p3,p4" | "p2,p3,p4,p5"
                 bottom_up.stage_cut_at = tuple(x for x in os.environ["OMNI_PIPE_CUTS"].split(",") if x)
         self.stages = None
+        self._timing = []
         if not graphs:
             return
         assert torch.cuda.is_available(), "hipGraph capture needs the GPU"
@@ -332,6 +356,12 @@ class GraphedPipelined:
         main, side = torch.cuda.current_stream(), self.side
         pending, n = [], len(self.stages)
         ends = [None] * n
+        timing = _PIPE_TIMING          # diagnostic (OMNI_PIPE_TIMING=1): device timestamps of every M_k / W_k end, see pipe_timing_report
+        if timing:
+            import time
+            rec = {"t0": torch.cuda.Event(enable_timing=True), "m": [], "w": [None] * n, "host": []}
+            rec["t0"].record(main)
+            self._timing.append(rec)
 
         def launch_w(k):                              # W_k starts when M_k has finished ...
             gw = self.stages[k][1]
@@ -340,19 +370,44 @@ class GraphedPipelined:
             side.wait_event(ends[k])
             with torch.cuda.stream(side):
                 if gw is not None:
+                    if timing:
+                        h0 = time.perf_counter()
                     gw.replay()
+                    if timing:
+                        rec["host"].append(("W%d" % k, (time.perf_counter() - h0) * 1e6))
+                        rec["w"][k] = torch.cuda.Event(enable_timing=True)
+                        rec["w"][k].record(side)
                 # the heads' gradients are final after W_0: their all-reduce rides behind it on the side stream
                 return self.optimizer.all_reduce_begin("early", self.group) if k == 0 else []
 
         # host order M_0, M_1, W_0, M_2, W_1, ...: the next critical-path graph is always queued on the main stream before the
         # side-stream launch that depends on an event (measured: a graph launch behind a cross-stream event delays every
         # launch issued after it by ~150 us)
-        for k in range(n):
-            self.stages[k][0].replay()
-            ends[k] = torch.cuda.Event()
-            ends[k].record(main)
-            if k >= 1:
-                pending += launch_w(k - 1)
-        pending += launch_w(n - 1)
+        if timing:
+            for k in range(n):
+                h0 = time.perf_counter()
+                self.stages[k][0].replay()
+                rec["host"].append(("M%d" % k, (time.perf_counter() - h0) * 1e6))
+                ends[k] = torch.cuda.Event(enable_timing=True)
+                ends[k].record(main)
+                rec["m"].append(ends[k])
+                if k >= 1:
+                    pending += launch_w(k - 1)
+            pending += launch_w(n - 1)
+        elif _PIPE_ORDER == "mfirst":               # A/B: every critical-path graph first, then the weight-gradient graphs behind their events
+            for k in range(n):
+                self.stages[k][0].replay()
+                ends[k] = torch.cuda.Event()
+                ends[k].record(main)
+            for k in range(n):
+                pending += launch_w(k)
+        else:
+            for k in range(n):
+                self.stages[k][0].replay()
+                ends[k] = torch.cuda.Event()
+                ends[k].record(main)
+                if k >= 1:
+                    pending += launch_w(k - 1)
+            pending += launch_w(n - 1)
         main.wait_stream(side)                        # ... and everything after the step waits for the last W
         return self.losses, self.total, pending + self.optimizer.all_reduce_begin("late", self.group)
