@@ -80,6 +80,15 @@ class CubeHead(nn.Module):
         parts = [self.bbox_3D_center_deltas, self.bbox_3D_center_depth, self.bbox_3D_dims, self.bbox_3D_pose]
         return parts + ([self.bbox_3D_uncertainty] if self.use_conf else [])
 
+    def fused_param_groups(self):
+        """read by solver/build.py tag_fused_groups (shared FC only: the heads are then ONE GEMM): the optimizer keeps these back to
+        back (+ zero padding) in its buckets, so the fused matrix and its gradient are views"""
+        if not self.shared_fc:
+            return []
+        parts = self._parts()
+        pad = self.fused_dim - self.width * self.num_classes
+        return [([m.weight for m in parts], pad * parts[0].weight.shape[1]), ([m.bias for m in parts], pad)]
+
     def fused_parameters(self):
         """(width*K padded, fc_dim) weight and bias of the one GEMM that replaces the separate heads (shared FC only)."""
         parts = self._parts()
@@ -91,9 +100,8 @@ class CubeHead(nn.Module):
     def forward(self, x):
         """x (n, C, 7, 7) ROI features -> raw fused head outputs (n, width*K padded)."""
         if self.shared_fc:
-            feats = self.feature_generator(x)
-            w, b = self.fused_parameters()
-            return HF.linear(feats, w, b)
+            parts = self._parts()
+            return HF.fused_linear(self.feature_generator(x), [m.weight for m in parts], [m.bias for m in parts], self.fused_dim)
         # SHARED_FC False (cube_head.py:165-173): every output group has its own FC stack
         gens = [self.feature_generator_XY, self.feature_generator_Z, self.feature_generator_dims, self.feature_generator_pose]
         if self.use_conf:

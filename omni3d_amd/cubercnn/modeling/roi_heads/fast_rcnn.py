@@ -49,10 +49,13 @@ class FastRCNNOutputs(nn.Module):
 
     def forward(self, x):
         """x (R, 1024) -> fused predictions (R, fused_dim) = [K+1 logits | 4K deltas | pad]."""
+        return HF.fused_linear(x, [self.cls_score.weight, self.bbox_pred.weight], [self.cls_score.bias, self.bbox_pred.bias], self.fused_dim)
+
+    def fused_param_groups(self):
+        """read by solver/build.py tag_fused_groups: the optimizer keeps these back to back (+ zero padding) in its buckets"""
         pad = self.fused_dim - (5 * self.num_classes + 1)
-        w = torch.cat([self.cls_score.weight, self.bbox_pred.weight, self.cls_score.weight.new_zeros(pad, x.shape[1])], 0)
-        b = torch.cat([self.cls_score.bias, self.bbox_pred.bias, self.cls_score.bias.new_zeros(pad)], 0)
-        return HF.linear(x, w, b)
+        return [([self.cls_score.weight, self.bbox_pred.weight], pad * self.cls_score.weight.shape[1]),
+                ([self.cls_score.bias, self.bbox_pred.bias], pad)]
 
     def losses(self, pred, cls, prop_boxes, targets, gt_row):
         """fast_rcnn.py:145-194; cls (R) int32 with -2 on padding rows."""

@@ -71,7 +71,35 @@ class _FlatOptimizer(torch.optim.Optimizer):
         classes = {}
         for g, p in plist:
             classes.setdefault((float(g["lr"]), float(g["weight_decay"])), []).append((g, p))
-        total = sum(((p.numel() + 3) // 4) * 4 for _, p in plist)
+        # Fused parameter groups (`tag_fused_groups`): parameters a module evaluates as ONE matrix -- cls_score + bbox_pred of the box
+        # predictor, the five bbox_3D_* heads of the cube head (+ zero rows up to the kernels' multiple of 16) -- sit back to back in
+        # that order, followed by their zero padding, so the fused matrix and its gradient are plain views of the buckets: no
+        # torch.cat per forward, one weight-gradient launch that accumulates in place, no per-member gradient adds.
+        layout = {}
+        total = 0
+        for key, items in classes.items():
+            items = sorted(items, key=lambda gp: bool(getattr(gp[1], "_omni_early_grad", False)))   # stable: [late | early]
+            ids = {id(p) for _, p in items}
+            entries, done = [], set()
+            for g, p in items:
+                if id(p) in done:
+                    continue
+                tag = getattr(p, "_omni_fuse", None)
+                members = tag["members"] if tag is not None else None
+                if members is not None and all(id(m) in ids for m in members) and not any(id(m) in done for m in members) and \
+                        len({bool(getattr(m, "_omni_early_grad", False)) for m in members}) == 1:
+                    gof = {id(pp): gg for gg, pp in items}
+                    for m in members:
+                        entries.append((gof[id(m)], m, m.numel(), tag))
+                        done.add(id(m))
+                    entries.append((None, None, int(tag["pad"]), tag))                      # zero padding behind the last member
+                    entries.append((None, None, (-sum(m.numel() for m in members) - int(tag["pad"])) % 4, None))   # re-align
+                else:
+                    entries.append((g, p, p.numel(), None))
+                    entries.append((None, None, (-p.numel()) % 4, None))
+                    done.add(id(p))
+            layout[key] = (items, entries)
+            total += sum(e[2] for e in entries)
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_state = {name: torch.zeros(total, dtype=torch.float32, device=dev) for name in self.STATE}
@@ -85,15 +113,22 @@ class _FlatOptimizer(torch.optim.Optimizer):
         # [late | early] and the data-parallel exchange can all-reduce the early ranges while the backbone is still
         # back-propagating (all_reduce_begin / all_reduce_finish).
         self.early_ranges, self.late_ranges = [], []
-        for key, items in classes.items():
+        for key, (items, entries) in layout.items():
             start = off
-            items = sorted(items, key=lambda gp: bool(getattr(gp[1], "_omni_early_grad", False)))   # stable
-            n_late = sum(not getattr(p, "_omni_early_grad", False) for _, p in items)
             mid = None
-            for idx, (g, p) in enumerate(items):
-                if idx == n_late:
+            fused_start = {}
+            for g, p, n, tag in entries:
+                if p is None:
+                    if tag is not None:              # the padding closes a fused group: hand its members the fused views
+                        o = fused_start.pop(id(tag))
+                        tag["members"][0]._omni_fused_view = (self.flat_param[o:off + n], self.flat_grad[o:off + n],
+                                                              tuple(m.data_ptr() for m in tag["members"]))
+                    off += n
+                    continue
+                if mid is None and getattr(p, "_omni_early_grad", False):
                     mid = off
-                n = p.numel()
+                if tag is not None and id(tag) not in fused_start:
+                    fused_start[id(tag)] = off
                 pv = self._view_like(self.flat_param[off:off + n], p)
                 pv.copy_(p.data)
                 p.data = pv
@@ -102,7 +137,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
                     gv.copy_(p.grad)
                 p.grad = gv
                 self._slot[id(p)] = (off, n)
-                off += ((n + 3) // 4) * 4
+                off += n
             if mid is None:
                 mid = off
             if mid > start:
@@ -371,8 +406,44 @@ class FlatAdam(_FlatOptimizer):
         self._steps = int(self.dev_step.item())
 
 
+def tag_fused_groups(model):
+    """modules that evaluate several parameters as one matrix name them (`fused_param_groups() -> [(members in fused order, zero
+    elements of padding behind them)]`); the tags are read by _FlatOptimizer._build_buckets"""
+    for m in model.modules():
+        groups = getattr(m, "fused_param_groups", None)
+        if groups is None:
+            continue
+        for members, pad in groups():
+            members = list(members)
+            for p in members:
+                p._omni_fuse = None
+            members[0]._omni_fuse = {"members": members, "pad": int(pad)}
+            for p in members[1:]:
+                p._omni_fuse = members[0]._omni_fuse
+
+
+def fused_view(members, training):
+    """-> (matrix storage, gradient storage or None) = flat views over `members` + their zero padding when the optimizer laid them out
+    back to back (tag_fused_groups) and nothing has moved them since; None -> the caller concatenates.  The gradient storage is only
+    handed out when the backward kernels may accumulate into the bucket directly (functional._direct_grad)."""
+    fv = getattr(members[0], "_omni_fused_view", None)
+    if fv is None:
+        return None
+    pflat, gflat, ptrs = fv
+    if any(m.data_ptr() != q for m, q in zip(members, ptrs)):
+        return None                                         # (model.to(), a re-assigned .data: the layout is gone)
+    if not training:
+        return pflat, None
+    if not all(getattr(m, "_omni_direct_grad", False) and m.requires_grad and m.grad is not None for m in members):
+        return None
+    if members[0].grad.data_ptr() != gflat.data_ptr():
+        return None
+    return pflat, gflat
+
+
 def build_optimizer(cfg, model):
     params = _param_groups(cfg, model)
+    tag_fused_groups(model.module if hasattr(model, "module") else model)
     # gradients of everything outside the backbone are complete before the backbone starts back-propagating
     inner = model.module if hasattr(model, "module") else model
     for name, p in inner.named_parameters():

@@ -481,9 +481,9 @@ def depthwise_conv2d(x, w, stride=1, pad=1):
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, relu, w_grad_view=None):
+    def forward(ctx, x, w, bias, relu, w_grad_view=None, b_grad_view=None):
         gw = _direct_grad(w) if w_grad_view is None else w_grad_view
-        ctx.direct = (gw if (gw is not None and gw.is_contiguous()) else None, _direct_grad(bias))
+        ctx.direct = (gw if (gw is not None and gw.is_contiguous()) else None, _direct_grad(bias) if b_grad_view is None else b_grad_view)
         x, w = x.contiguous(), w.contiguous()
         y = conv.linear_fwd(x, w, bias, relu)
         ctx.save_for_backward(x, w, y if relu else None)
@@ -503,13 +503,33 @@ class _Linear(Function):
         if ctx.needs_input_grad[1]:
             dw = _side_run(lambda: conv.linear_wgrad(x, dy, accum_into=gw), (x, dy)) if gw is not None else conv.linear_wgrad(x, dy)
         db = bnpool.bias_grad(dy, accum_into=gb) if (has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def linear(x, w, bias=None, relu=False, w_grad_view=None):
-    """w_grad_view: 2-D contiguous view of the gradient bucket for `w` when `w` itself is a view of a
-    parameter (FlattenLinear); enables direct accumulation."""
-    return _Linear.apply(x, w, bias, relu, w_grad_view)
+def linear(x, w, bias=None, relu=False, w_grad_view=None, b_grad_view=None):
+    """w_grad_view / b_grad_view: contiguous views of the gradient bucket for `w` / `bias` when those are not parameters themselves
+    (a view of one, FlattenLinear; the fused matrix of several, fused_linear); enables direct accumulation."""
+    return _Linear.apply(x, w, bias, relu, w_grad_view, b_grad_view)
+
+
+def fused_linear(x, weights, biases, rows, relu=False):
+    """y = x . [W_0; W_1; ...; 0]^T + [b_0; b_1; ...; 0]: several nn.Linear evaluated as one GEMM of `rows` (>= sum of the members',
+    zero padded) output columns.  When the optimizer laid the members out back to back (solver/build.py tag_fused_groups) the fused
+    matrix, bias and both gradients are views of its buckets: no concatenation, one accumulating weight-gradient launch, no
+    per-member gradient adds.  Otherwise the members are concatenated and autograd splits the gradient."""
+    from .cubercnn.solver.build import fused_view
+    cols = weights[0].shape[1]
+    training = torch.is_grad_enabled() and any(w.requires_grad for w in weights)
+    fw, fb = fused_view(weights, training), fused_view(biases, training)
+    if fw is not None and fb is not None and fw[0].numel() == rows * cols and fb[0].numel() == rows:
+        w, b = fw[0].view(rows, cols), fb[0]
+        if training:
+            return _Linear.apply(x, w.detach().requires_grad_(True), b.detach().requires_grad_(True), relu, fw[1].view(rows, cols), fb[1])
+        return _Linear.apply(x, w, b, relu, None, None)
+    pad = rows - sum(w.shape[0] for w in weights)
+    w = torch.cat(list(weights) + ([weights[0].new_zeros(pad, cols)] if pad else []), dim=0)
+    b = torch.cat(list(biases) + ([biases[0].new_zeros(pad)] if pad else []), dim=0)
+    return _Linear.apply(x, w, b, relu, None, None)
 
 
 _BN_REMASK = _os_environ_get("OMNI_BN_REMASK", "1") != "0"     # A/B knob

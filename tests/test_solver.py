@@ -353,3 +353,73 @@ def test_build_optimizer_solver_types(emu_lib, kind):
 def test_flat_adam_matches_torch_gpu(hip_lib):
     for kind in ADAM_TYPES:
         _run_adam(kind, "cuda")
+
+
+# ---- fused parameter groups: several nn.Linear evaluated as one GEMM, laid out back to back in the optimizer's buckets ----------------
+def _run_fused_groups(dev):
+    """box predictor (cls_score + bbox_pred) and cube head (five bbox_3D_* heads): with the optimizer's layout the fused matrix and its
+    gradient are bucket views -- same outputs, same parameter gradients and the same update as the concatenating path"""
+    import copy
+    from omni3d_amd import functional as HF
+    from omni3d_amd.cubercnn.modeling.roi_heads.fast_rcnn import FastRCNNOutputs
+    from omni3d_amd.cubercnn.solver.build import FlatSGD, fused_view, tag_fused_groups
+    torch.manual_seed(4)
+    head = FastRCNNOutputs(64, box2box_weights=(10.0, 10.0, 5.0, 5.0), num_classes=50).to(dev)
+    for p in head.parameters():
+        p.data.normal_(0, 0.1)
+    ref = copy.deepcopy(head)
+    x = torch.randn(96, 64, device=dev)
+    g = torch.randn(96, head.fused_dim, device=dev)
+    g[:, 5 * 50 + 1:] = 0.0                                   # the loss kernels write zeros into the padding columns
+    # reference: concatenation + autograd + torch SGD
+    yr = ref(x)
+    yr.backward(g)
+    opt_r = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3)
+    opt_r.step()
+    # product: tagged layout
+    tag_fused_groups(head)
+    opt = FlatSGD([{"params": [p]} for p in head.parameters()], lr=0.1, momentum=0.9, weight_decay=1e-3)
+    members = [head.cls_score.weight, head.bbox_pred.weight]
+    fw = fused_view(members, True)
+    assert fw is not None and fw[0].numel() == head.fused_dim * 64 and fw[0].data_ptr() == head.cls_score.weight.data_ptr()
+    assert head.bbox_pred.weight.data_ptr() == fw[0].data_ptr() + 4 * 51 * 64            # back to back, no alignment gap
+    assert float(fw[0][251 * 64:].abs().max()) == 0.0                                    # zero padding rows
+    fb = fused_view([head.cls_score.bias, head.bbox_pred.bias], True)
+    assert fb is not None and fb[0].numel() == head.fused_dim
+    opt.zero_grad()
+    y = head(x)
+    assert (y - yr.detach()).abs().max() < 1e-4
+    y.backward(g)
+    HF.side_join()
+    for (n, p), (_, q) in zip(head.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and (p.grad - q.grad).abs().max() < 1e-3 * max(1.0, float(q.grad.abs().max())), n
+    assert float(fw[1][251 * 64:].abs().max()) == 0.0                                    # nothing lands in the padding
+    opt.step()
+    for (n, p), (_, q) in zip(head.named_parameters(), ref.named_parameters()):
+        assert (p.data - q.data).abs().max() < 1e-5, n
+    # inference reads the fused matrix without gradient plumbing
+    with torch.no_grad():
+        assert (head(x) - ref(x)).abs().max() < 1e-4
+    # a parameter that moved (model.to(), re-assigned .data) silently falls back to the concatenating path
+    head.bbox_pred.weight.data = head.bbox_pred.weight.data.clone()
+    assert fused_view(members, True) is None
+    with torch.no_grad():
+        assert (head(x) - ref(x)).abs().max() < 1e-4
+    # without direct accumulation (a DistributedDataParallel reducer needs autograd's hooks) no gradient view is handed out
+    head2 = copy.deepcopy(ref)
+    tag_fused_groups(head2)
+    opt2 = FlatSGD([{"params": [p]} for p in head2.parameters()], lr=0.1, direct_accumulate=False)
+    assert fused_view([head2.cls_score.weight, head2.bbox_pred.weight], True) is None
+    assert fused_view([head2.cls_score.weight, head2.bbox_pred.weight], False) is not None
+    opt2.zero_grad()
+    head2(x).backward(g)
+    assert (head2.cls_score.weight.grad - (ref.cls_score.weight.grad)).abs().max() < 1e-3
+
+
+def test_fused_parameter_groups_emulated(emu_lib):
+    _run_fused_groups("cpu")
+
+
+@pytest.mark.gpu
+def test_fused_parameter_groups_gpu(hip_lib):
+    _run_fused_groups("cuda")
