@@ -466,6 +466,10 @@ int omni_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int N, int H
 int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile, void* stream);
 int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, void* stream);
 int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, int tile, void* stream);
+/* omni_wino_weights for n <= 48 filters in ONE launch (the weights are fixed during a step: every filter transform of the forward pass
+ * at once).  g / U / U_flip: HOST arrays of device pointers (U[i] / U_flip[i] nullable, not both); K / C / tile: HOST int arrays. */
+int omni_wino_weights_multi(const void* const* g, const void* const* U, const void* const* U_flip, const int* K, const int* C,
+                            const int* tile, int n, void* stream);
 /* backward: dM (as omni_wino_dy) and V_dy (as omni_wino_in of dy) from one read of dy */
 int omni_wino_dy_in(const float* dy, float* dM, float* Vd, int N, int H, int W, int K, int tile, void* stream);
 int omni_wino_weights(const float* g, float* U /*nullable*/, float* U_flip /*nullable: U'*/, int K, int C, int tile, void* stream);

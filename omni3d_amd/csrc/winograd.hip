@@ -169,14 +169,13 @@ __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ 
 // U[xi][k][c] = (G g G^T)[xi]; optionally also U'[xi][c][k], the transform of the 180-degree rotated, channel-transposed filter
 // (what the data gradient convolves dy with): rotating g permutes the rows of G g by pi = (3, 1, 2, 0), so
 // U'[4i + j][c][k] = U[4 pi(i) + pi(j)][k][c] -- no second pass over g.
-__global__ void __launch_bounds__(256) wino_w_kernel(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf,
-                                                     int K, int C) {
-    // one 16 (k) x 16 (c) tile per block; U' goes through an LDS transpose so that its rows (k contiguous) are written
-    // in 64-byte runs instead of 4-byte scatters
-    __shared__ float s_t[16][16][17];
+__device__ __forceinline__ void wino_w_body(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf, int K, int C,
+                                            int bid, float (*s_t)[16][17]) {
+    // one 16 (k) x 16 (c) tile per block (bid); U' goes through an LDS transpose (s_t: [16][16][17]) so that its rows (k contiguous)
+    // are written in 64-byte runs instead of 4-byte scatters
     const long total = (long)K * C;
     const int tiles_c = (C + 15) / 16;
-    const int k0 = ((int)blockIdx.x / tiles_c) * 16, c0 = ((int)blockIdx.x % tiles_c) * 16;
+    const int k0 = (bid / tiles_c) * 16, c0 = (bid % tiles_c) * 16;
     const int kk = threadIdx.x >> 4, cc = threadIdx.x & 15;
     const int k = k0 + kk, c = c0 + cc;
     const bool ok = k < K && c < C;
@@ -222,6 +221,11 @@ __global__ void __launch_bounds__(256) wino_w_kernel(const float* __restrict__ g
             for (int xi = 0; xi < 16; ++xi) Uf[(long)xi * total + (long)oc * K + okk] = s_t[xi][kk][cc];
         }
     }
+}
+__global__ void __launch_bounds__(256) wino_w_kernel(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf,
+                                                     int K, int C) {
+    __shared__ float s_t[16][16][17];
+    wino_w_body(g, U, Uf, K, C, (int)blockIdx.x, s_t);
 }
 
 __global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dg, int K, int C,
@@ -463,12 +467,11 @@ __device__ __forceinline__ void gt6(const float (&u)[6], float (&e)[3]) {      /
 
 // U[36][K][C] and / or U'[36][C][K] (rotated, channel-transposed filter); 16 x 16 (k, c) tile per block, U' through an LDS
 // transpose (as wino_w_kernel)
-__global__ void __launch_bounds__(256) wino4_w_kernel(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf,
-                                                      int K, int C) {
-    __shared__ float s_t[36][16][17];
+__device__ __forceinline__ void wino4_w_body(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf, int K, int C,
+                                             int bid, float (*s_t)[16][17]) {
     const long total = (long)K * C;
     const int tiles_c = (C + 15) / 16;
-    const int k0 = ((int)blockIdx.x / tiles_c) * 16, c0 = ((int)blockIdx.x % tiles_c) * 16;
+    const int k0 = (bid / tiles_c) * 16, c0 = (bid % tiles_c) * 16;
     const int kk = threadIdx.x >> 4, cc = threadIdx.x & 15;
     const int k = k0 + kk, c = c0 + cc;
     const bool ok = k < K && c < C;
@@ -510,6 +513,32 @@ __global__ void __launch_bounds__(256) wino4_w_kernel(const float* __restrict__ 
             }
         }
     }
+}
+__global__ void __launch_bounds__(256) wino4_w_kernel(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf,
+                                                      int K, int C) {
+    __shared__ float s_t[36][16][17];
+    wino4_w_body(g, U, Uf, K, C, (int)blockIdx.x, s_t);
+}
+
+// Every filter of a forward pass in ONE launch: the weights are fixed for the duration of a step, so the ~20 transform launches of
+// the DLA-34 + FPN + RPN forward (6 us each, latency-bound, on the un-overlapped forward path) collapse into one.  A workgroup finds
+// its (filter, 16 x 16 tile) by scanning the table's workgroup prefix.
+constexpr int WINO_MULTI_MAX = 48;
+struct WinoWTable {
+    const float* g[WINO_MULTI_MAX];
+    float* U[WINO_MULTI_MAX];
+    float* Uf[WINO_MULTI_MAX];
+    int K[WINO_MULTI_MAX], C[WINO_MULTI_MAX], tile[WINO_MULTI_MAX];
+    int wg0[WINO_MULTI_MAX + 1];
+    int n;
+};
+__global__ void __launch_bounds__(256) wino_w_multi_kernel(WinoWTable t) {
+    __shared__ float s_t[36][16][17];
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.wg0[e + 1]) ++e;
+    const int bid = (int)blockIdx.x - t.wg0[e];
+    if (t.tile[e] == 2) wino_w_body(t.g[e], t.U[e], t.Uf[e], t.K[e], t.C[e], bid, s_t);
+    else wino4_w_body(t.g[e], t.U[e], t.Uf[e], t.K[e], t.C[e], bid, s_t);
 }
 
 __global__ void __launch_bounds__(256) wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dg, int K, int C,
@@ -753,6 +782,27 @@ int omni_wino_weights(const float* g, float* U, float* U_flip, int K, int C, int
     const unsigned wt = (unsigned)(((K + 15) / 16) * ((C + 15) / 16));       // one 16 x 16 (k, c) tile per workgroup
     if (tile == 2) hipLaunchKernelGGL(wino_w_kernel, dim3(wt), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
     else hipLaunchKernelGGL(wino4_w_kernel, dim3(wt), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
+    return omni_launch_status();
+}
+
+// omni_wino_weights for n (<= 48) filters in one launch: g / U / U_flip are HOST arrays of device pointers (U[i], U_flip[i] nullable, not
+// both), K / C / tile HOST int arrays.
+int omni_wino_weights_multi(const void* const* g, const void* const* U, const void* const* U_flip, const int* K, const int* C,
+                            const int* tile, int n, void* stream) {
+    if (n <= 0 || n > WINO_MULTI_MAX || g == nullptr || U == nullptr || U_flip == nullptr) return OMNI_ERR_ARG;
+    WinoWTable t;
+    t.n = n;
+    t.wg0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (K[i] <= 0 || C[i] <= 0 || (U[i] == nullptr && U_flip[i] == nullptr) || (tile[i] != 2 && tile[i] != 4) || g[i] == nullptr)
+            return OMNI_ERR_ARG;
+        t.g[i] = (const float*)g[i];
+        t.U[i] = (float*)U[i];
+        t.Uf[i] = (float*)U_flip[i];
+        t.K[i] = K[i]; t.C[i] = C[i]; t.tile[i] = tile[i];
+        t.wg0[i + 1] = t.wg0[i] + ((K[i] + 15) / 16) * ((C[i] + 15) / 16);
+    }
+    hipLaunchKernelGGL(wino_w_multi_kernel, dim3((unsigned)t.wg0[n]), dim3(256), 0, (hipStream_t)stream, t);
     return omni_launch_status();
 }
 

@@ -74,7 +74,7 @@ class RCNN3D(nn.Module):
         return pack_targets(batched_inputs, sizes, vf, with_gt=True).to(self.device)
 
     def forward(self, batched_inputs, packed=None):
-        with HF.wino_weight_scope():       # shared conv weights are Winograd-transformed once per pass
+        with HF.wino_weight_scope(self):   # every Winograd filter of the pass is transformed by one launch at its start
             return self._forward(batched_inputs, packed)
 
     def _forward(self, batched_inputs, packed=None):

@@ -281,6 +281,7 @@ class _WinoConv3x3(Function):
         ctx.direct = (_direct_grad(w), _direct_grad(bias))
         ctx.bn_below = getattr(x, "_omni_bn_below", None)      # x is the output of a BatchNorm(+ReLU) without residual
         ctx.slot = _slot_enter(x, ctx.needs_input_grad[0])
+        w_given = w
         x, w = _cl(x), _cl(w)
         # one launch yields the forward transform U and (when the data gradient will also go through Winograd) U' of
         # the rotated filter; a weight shared by several calls of one step (the RPN conv over the FPN levels) is
@@ -296,6 +297,8 @@ class _WinoConv3x3(Function):
             U, Uf = wino.transform_weights(w, True, need_flip or Uf is not None, tile)
             if cache is not None:
                 cache[key] = (U, Uf)
+                if w is w_given:        # (a filter that had to be re-laid-out first is a temporary: nothing to remember)
+                    _wino_scope["record"].append((w, tile, bool(need_flip or Uf is not None)))      # -> next pass: one batched launch
         parts = None
         if want_stats and bias is None and not relu:
             y, V, parts = wino.conv3x3_fwd(x, w, None, False, U=U, tile=tile, want_stats=True)
@@ -401,19 +404,45 @@ def rpn_head16(ts, w_obj, b_obj, w_del, b_del):
     return list(_RPNHead16.apply(w_obj, b_obj, w_del, b_del, *ts))
 
 
-_wino_scope = {"cache": None}     # (weight address, shape) -> (U, U'), only while a model forward is running
+_wino_scope = {"cache": None, "record": []}     # (weight address, shape) -> (U, U'), only while a model forward is running
+_WINO_MULTI = _os_environ_get("OMNI_WINO_WEIGHTS_MULTI", "1") != "0"          # A/B knob
 
 
 class wino_weight_scope:
-    """`with wino_weight_scope():` around one forward pass: a weight used by several convolutions of that pass (the RPN
-    conv over the FPN levels) is transformed once."""
+    """`with wino_weight_scope(owner):` around one forward pass.  A weight used by several convolutions of that pass (the RPN conv
+    over the FPN levels) is transformed once; and the pass remembers on `owner` (the model) which filters it transformed, so the
+    NEXT pass of the same kind (training / inference) transforms all of them with one launch at its start (wino.transform_weights_multi:
+    the weights are fixed during a step) instead of one latency-bound launch in front of every convolution."""
+
+    def __init__(self, owner=None):
+        self.owner = owner
 
     def __enter__(self):
-        self.prev = _wino_scope["cache"]
-        _wino_scope["cache"] = {}
+        self.prev = (_wino_scope["cache"], _wino_scope["record"])
+        cache = _wino_scope["cache"] = {}
+        _wino_scope["record"] = []
+        self.kind = "_omni_wino_plan_train" if torch.is_grad_enabled() else "_omni_wino_plan_infer"
+        plan = getattr(self.owner, self.kind, None) if (self.owner is not None and _WINO_MULTI) else None
+        if plan:
+            items = [(w, True, flip, tile) for w, tile, flip in plan if w.is_contiguous(memory_format=CL)]
+            for k in range(0, len(items), wino.WEIGHTS_MULTI_MAX):
+                chunk = items[k:k + wino.WEIGHTS_MULTI_MAX]
+                for (w, _, _, tile), uu in zip(chunk, wino.transform_weights_multi(chunk)):
+                    cache[(w.data_ptr(), tuple(w.shape), tile)] = uu
 
     def __exit__(self, *exc):
-        _wino_scope["cache"] = self.prev
+        record = _wino_scope["record"]
+        if self.owner is not None and record and exc[0] is None:
+            # filters this pass still had to transform one by one (first pass, or a shape the plan did not know): extend the plan
+            plan = {(id(w), tile): (w, tile, flip) for w, tile, flip in (getattr(self.owner, self.kind, None) or [])}
+            for w, tile, flip in record:
+                old = plan.get((id(w), tile))
+                plan[(id(w), tile)] = (w, tile, flip or (old[2] if old else False))
+            try:
+                object.__setattr__(self.owner, self.kind, list(plan.values()))     # (not a module attribute: keeps state_dict / children clean)
+            except Exception:
+                pass
+        _wino_scope["cache"], _wino_scope["record"] = self.prev
         return False
 
 

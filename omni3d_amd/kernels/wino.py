@@ -76,6 +76,31 @@ def transform_weights(w, want_u=True, want_flip=False, tile=2):
     return U, Uf
 
 
+WEIGHTS_MULTI_MAX = 48
+
+
+def transform_weights_multi(items):
+    """items: [(w (K,C,3,3) CL, want_u, want_flip, tile)] (<= 48) -> [(U or None, U' or None)], every filter in ONE launch"""
+    import ctypes
+    assert 0 < len(items) <= WEIGHTS_MULTI_MAX
+    outs, gp, up, fp, Ks, Cs, Ts = [], [], [], [], [], [], []
+    for w, want_u, want_flip, tile in items:
+        K, C = w.shape[0], w.shape[1]
+        wv = w.permute(0, 2, 3, 1)
+        assert wv.is_contiguous() and (want_u or want_flip)
+        U = torch.empty((_points(tile), K, C), dtype=torch.float32, device=w.device) if want_u else None
+        Uf = torch.empty((_points(tile), C, K), dtype=torch.float32, device=w.device) if want_flip else None
+        outs.append((U, Uf))
+        gp.append(wv.data_ptr()); up.append(_lib.ptr(U)); fp.append(_lib.ptr(Uf)); Ks.append(K); Cs.append(C); Ts.append(tile)
+    L = _lib.check_device(items[0][0].permute(0, 2, 3, 1))
+    n = len(items)
+    P = ctypes.c_void_p
+    arr = lambda vals: ctypes.cast((P * n)(*vals), P)                     # noqa: E731
+    ints = lambda vals: ctypes.cast((ctypes.c_int * n)(*vals), P)         # noqa: E731
+    L.call("omni_wino_weights_multi", arr(gp), arr(up), arr(fp), ints(Ks), ints(Cs), ints(Ts), n, _lib.stream_of(items[0][0]))
+    return outs
+
+
 def gemm_batched(V, U, algo=0, workgroups=0):
     """V (B,M,C), U (B,K,C) -> (B,M,K).  algo / workgroups: see omni_gemm_batched_fwd_algo (0 = the launcher's choice)."""
     B, M, C = V.shape

@@ -335,3 +335,73 @@ def _run_stem_autograd(dev):
 
 def test_stem_conv_autograd_emulated(emu_lib):
     _run_stem_autograd("cpu")
+
+
+def _run_weights_multi(dev):
+    """every filter transform of a pass in one launch == the per-filter launches (both tile sizes, U and U' in any combination)"""
+    from omni3d_amd.kernels import wino
+    g = torch.Generator().manual_seed(9)
+    items = []
+    for (K, C, tile, want_u, want_flip) in ((32, 64, 2, True, True), (64, 32, 4, True, False), (48, 40, 4, True, True), (16, 16, 2, False, True),
+                                            (128, 64, 4, True, True)):
+        w = torch.randn(K, C, 3, 3, generator=g).contiguous(memory_format=torch.channels_last).to(dev)
+        items.append((w, want_u, want_flip, tile))
+    outs = wino.transform_weights_multi(items)
+    for (w, want_u, want_flip, tile), (U, Uf) in zip(items, outs):
+        U1, Uf1 = wino.transform_weights(w, want_u, want_flip, tile)
+        assert (U is None) == (not want_u) and (Uf is None) == (not want_flip)
+        if want_u:
+            assert torch.equal(U, U1)
+        if want_flip:
+            assert torch.equal(Uf, Uf1)
+
+
+def _run_weight_plan(dev):
+    """wino_weight_scope(owner): the second pass transforms the filters of the first with one launch and produces the same outputs"""
+    from omni3d_amd import functional as HF
+    from omni3d_amd.cubercnn.modeling.layers import Conv2d
+    torch.manual_seed(2)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = Conv2d(128, 128, kernel_size=3, padding=1), Conv2d(128, 128, kernel_size=3, padding=1)
+
+        def forward(self, x):
+            with HF.wino_weight_scope(self):
+                return self.b(self.a(x, relu=True)) + self.a(x)          # `a` is used twice: transformed once
+    net = Net().to(dev)
+    x = torch.randn(2, 128, 32, 32).contiguous(memory_format=torch.channels_last).to(dev).requires_grad_(True)
+    y1 = net(x)
+    plan = net._omni_wino_plan_train
+    assert len(plan) == 2 and all(flip for _, _, flip in plan)
+    y1.square().mean().backward()
+    g1 = [p.grad.clone() for p in net.parameters()] + [x.grad.clone()]
+    for p in net.parameters():
+        p.grad = None
+    x.grad = None
+    calls = []
+    real = HF.wino.transform_weights
+    HF.wino.transform_weights = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        y2 = net(x)
+    finally:
+        HF.wino.transform_weights = real
+    assert not calls and torch.equal(y1, y2)                 # no per-filter launch on the second pass
+    y2.square().mean().backward()
+    for a, b in zip(g1, [p.grad for p in net.parameters()] + [x.grad]):
+        assert (a - b).abs().max() <= 1e-5 * max(1.0, float(a.abs().max()))
+    with torch.no_grad():
+        net(x.detach())
+    assert len(net._omni_wino_plan_infer) == 2 and not any(flip for _, _, flip in net._omni_wino_plan_infer)
+
+
+def test_winograd_weights_multi_emulated(emu_lib):
+    _run_weights_multi("cpu")
+    _run_weight_plan("cpu")
+
+
+@pytest.mark.gpu
+def test_winograd_weights_multi_gpu(hip_lib):
+    _run_weights_multi("cuda")
+    _run_weight_plan("cuda")
