@@ -456,6 +456,18 @@ def hbm_bound_kernels(opt, iters=10):
     x = torch.randn(IMS_PER_GPU, 256, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
     ms = _time_launch(lambda: wino.transform_input(x), iters)                                    # x read, 4x written
     out.append({"kernel": "wino_in_kernel (256 ch @128x128, batch 4)", "bytes": 20.0 * x.numel(), "kernel_ms": ms})
+    # the fused RPN head over the five FPN levels of this workload (csrc/rpn_head.hip): forward reads t (256 ch) and writes 16 columns per
+    # pixel; the data gradient reads dy (16) + t (ReLU mask) and writes 256 channels
+    from omni3d_amd.kernels import det
+    tn = [torch.relu(torch.randn(IMS_PER_GPU, s, s, 256, device="cuda")) for s in (128, 64, 32, 16, 8)]
+    pix = sum(t.shape[0] * t.shape[1] * t.shape[2] for t in tn)
+    wo, wd = torch.randn(3, 256, device="cuda") * 0.05, torch.randn(12, 256, device="cuda") * 0.05
+    bo, bd = torch.zeros(3, device="cuda"), torch.zeros(12, device="cuda")
+    ms = _time_launch(lambda: det.head16_fwd(tn, wo, bo, wd, bd), iters)
+    out.append({"kernel": "head16_fwd_kernel (RPN objectness + deltas, p2..p6 in one launch)", "bytes": 4.0 * pix * (256 + 16), "kernel_ms": ms})
+    dys = [torch.randn(t.shape[:3] + (16,), device="cuda") for t in tn]
+    ms = _time_launch(lambda: det.head16_dgrad(dys, tn, wo, wd), iters)
+    out.append({"kernel": "head16_dgrad_kernel (+ ReLU mask, p2..p6 in one launch)", "bytes": 4.0 * pix * (16 + 256 + 256), "kernel_ms": ms})
     for o in out:
         o["achieved"] = o["bytes"] / (o["kernel_ms"] * 1e-3) / 1e9
         o["peak"], o["unit"] = 8000.0, "GB/s"

@@ -1,0 +1,27 @@
+#!/bin/bash
+# usage (on the GPU box, through gpurun): tools/profile_final.sh <tag>   -- the reduced end-of-session measurement set:
+#   <tag>_kernel_stats.csv / <tag>_trace_table.txt  rocprofv3 --kernel-trace --stats of `bench.py --workload train`
+#   <tag>_pmc_families.csv                          PMC passes over tools/run_families.py (tools/pmc_run.py)
+#   <tag>_bench.log                                 the default `python bench.py` line (train + iou3d + cpu baselines + drop-in loop);
+# the kernel table and the PMC summary are copied to the profiles/ names bench.py hashes BEFORE the bench line is taken, so the line's
+# sha256 references match the files committed afterwards.
+set -u
+TAG=${1:-rXX}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+OMNI_BENCH_SKIP_CPU=1 OMNI_BENCH_SKIP_ROOFLINE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o train -- python $REPO/bench.py --workload train --steps 10 --warmup 3 > $OUT/${TAG}_prof.log 2>&1
+cd $REPO
+f=$(find $OUT/${TAG}_prof -name 'train_kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp $f $OUT/${TAG}_kernel_stats.csv && cp $f profiles/r03_train_final_kernel_stats.csv && head -12 $f | cut -c1-150
+t=$(find $OUT/${TAG}_prof -name 'train_kernel_trace.csv' | head -1)
+[ -n "$t" ] && python tools/trace_table.py $t 17 140 > $OUT/${TAG}_trace_table.txt && head -3 $OUT/${TAG}_trace_table.txt
+find $OUT/${TAG}_prof -name '*kernel_trace.csv' -delete
+timeout 400 python tools/pmc_run.py $OUT/${TAG}_pmc $OUT/${TAG}_pmc_families.csv -- python $REPO/tools/run_families.py > $OUT/${TAG}_pmc.log 2>&1
+tail -3 $OUT/${TAG}_pmc.log | cut -c1-200
+[ -s $OUT/${TAG}_pmc_families.csv ] && cp $OUT/${TAG}_pmc_families.csv profiles/r03_pmc_families.csv
+find $OUT/${TAG}_pmc -name '*kernel_trace.csv' -delete; find $OUT/${TAG}_pmc -name '*counter_collection.csv' -delete
+timeout 900 python bench.py > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_bench.err
+tail -c 600 $OUT/${TAG}_bench.log

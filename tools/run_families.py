@@ -44,5 +44,13 @@ for name, M, C, K in LINEARS:
     for _ in range(reps):
         y = F.linear(x, w, None)
         y.backward(torch.randn_like(y))
+# the fused RPN head (csrc/rpn_head.hip): both 1x1 heads over the five FPN levels of the benchmark, one launch per direction (HBM-bound)
+ts = [torch.relu(torch.randn(B, 256, s, s, device="cuda")).contiguous(memory_format=torch.channels_last).requires_grad_(True) for s in (128, 64, 32, 16, 8)]
+wo = (torch.randn(3, 256, 1, 1, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+wd = (torch.randn(12, 256, 1, 1, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+bo, bd = torch.zeros(3, device="cuda", requires_grad=True), torch.zeros(12, device="cuda", requires_grad=True)
+for _ in range(reps):
+    ys = F.rpn_head16(ts, wo, bo, wd, bd)
+    torch.autograd.backward(ys, [torch.randn_like(y) for y in ys])
 torch.cuda.synchronize()
 print("done")
