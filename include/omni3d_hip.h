@@ -464,6 +464,14 @@ int omni_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int N, int H
 /* tile = 2: F(2x2,3x3), P = 16 points;  tile = 4: F(4x4,3x3), P = 36 points, H and W multiples of 4.  T = N*(H/tile)*(W/tile);
  * the [16] above reads [P]. */
 int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile, void* stream);
+/* conv -> BatchNorm(+ReLU) -> 3x3 conv (the inside of every DLA / torchvision BasicBlock, dla.py:60-66): omni_bn_finalize_fwd turns the
+ * first convolution's epilogue statistics into (scale, shift) and omni_wino_in_affine applies them (+ ReLU) while it loads the input
+ * tiles of the second -- affine = [scale (C) | shift (C)], zero padding outside the image as for the normalised tensor, which is
+ * never stored.  affine NULL == omni_wino_in. */
+int omni_wino_in_affine(const float* x, const float* affine, int relu, float* V, int N, int H, int W, int C, int tile, void* stream);
+int omni_bn_finalize_fwd(const float* partial, int nblk, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* mean_rstd, float* scale_shift, int P, int C, float eps, float momentum,
+                         void* stream);
 int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, void* stream);
 int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, int tile, void* stream);
 /* omni_wino_weights for n <= 48 filters in ONE launch (the weights are fixed during a step: every filter transform of the forward pass

@@ -543,6 +543,17 @@ int omni_bn_fwd_partials(const float* x, const float* partial, int nblk, const f
     return omni_launch_status();
 }
 
+// The finalize half of omni_bn_fwd_partials alone: batch statistics -> mean_rstd (2C), scale_shift (2C), running statistics updated.
+// For a BatchNorm(+ReLU) whose only consumer is a Winograd convolution: that layer's input transform applies (scale, shift) on load
+// (omni_wino_in_affine) and the normalised tensor is never materialised.
+int omni_bn_finalize_fwd(const float* partial, int nblk, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float* mean_rstd, float* scale_shift, int P, int C, float eps, float momentum, void* stream) {
+    if (P <= 0 || C <= 0 || (C & 3) || C > 4096 || nblk <= 0) return OMNI_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, (hipStream_t)stream, partial, nblk, P, C, eps,
+                       momentum, gamma, beta, mean_rstd, scale_shift, running_mean, running_var);
+    return omni_launch_status();
+}
+
 // Inference / frozen BN: y = relu?(x*scale + shift (+res)) with caller-provided scale_shift (2C).
 int omni_bn_apply(const float* x, const float* scale_shift, const float* residual, float* y, int P, int C, int relu,
                   void* stream) {

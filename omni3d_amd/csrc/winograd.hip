@@ -30,9 +30,23 @@ inline int ew_grid(long total) {
     return (int)(g < 1 ? 1 : g);
 }
 
+// affine != nullptr: the input is the RAW output of the convolution below and the BatchNorm(+ReLU) between the two layers is applied
+// on load -- d = relu?(x * scale + shift) with (scale, shift) = affine[0:C], affine[C:2C], zero outside the image like the padding of
+// the normalised tensor -- so that tensor is never written or read (the expression of bn_apply_body).
+__device__ __forceinline__ float4 wino_ld(const float* __restrict__ p, bool ok, bool aff, float4 sc, float4 sh, int relu) {
+    if (!ok) return z4();
+    float4 v = ld4(p);
+    if (aff) {
+        v = v * sc + sh;
+        if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    }
+    return v;
+}
+
 __global__ void __launch_bounds__(256) wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W,
-                                                      int C) {
+                                                      int C, const float* __restrict__ affine, int relu) {
     const int C4 = C >> 2, TH = H >> 1, TW = W >> 1;
+    const bool aff = affine != nullptr;
     const long T = (long)N * TH * TW, total = T * C4, plane = T * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
@@ -40,6 +54,7 @@ __global__ void __launch_bounds__(256) wino_in_kernel(const float* __restrict__ 
         const int tx = (int)(t % TW);
         const int ty = (int)((t / TW) % TH);
         const int n = (int)(t / ((long)TW * TH));
+        const float4 sc = aff ? ld4(affine + 4 * c4) : z4(), sh = aff ? ld4(affine + C + 4 * c4) : z4();
         float4 d[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -48,7 +63,7 @@ __global__ void __launch_bounds__(256) wino_in_kernel(const float* __restrict__ 
             for (int s = 0; s < 4; ++s) {
                 const int iw = 2 * tx - 1 + s;
                 const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-                d[r][s] = ok ? ld4(x + (((long)n * H + ih) * W + iw) * C + 4 * c4) : z4();
+                d[r][s] = wino_ld(x + (((long)n * H + ih) * W + iw) * C + 4 * c4, ok, aff, sc, sh, relu);
             }
         }
         float4 u[4][4];
@@ -299,8 +314,9 @@ __device__ __forceinline__ void a6(const V (&y)[4], V (&u)[6]) {      // u = A y
 }
 
 __global__ void __launch_bounds__(256) wino4_in_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W,
-                                                       int C) {
+                                                       int C, const float* __restrict__ affine, int relu) {
     const int C4 = C >> 2, TH = H >> 2, TW = W >> 2;
+    const bool aff = affine != nullptr;
     const long T = (long)N * TH * TW, total = T * C4, plane = T * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
@@ -308,6 +324,7 @@ __global__ void __launch_bounds__(256) wino4_in_kernel(const float* __restrict__
         const int tx = (int)(t % TW);
         const int ty = (int)((t / TW) % TH);
         const int n = (int)(t / ((long)TW * TH));
+        const float4 sc = aff ? ld4(affine + 4 * c4) : z4(), sh = aff ? ld4(affine + C + 4 * c4) : z4();
         float4 u[6][6];     // u[r][s] = (B^T d) row r, column s -- built column by column
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
@@ -317,7 +334,7 @@ __global__ void __launch_bounds__(256) wino4_in_kernel(const float* __restrict__
             for (int r = 0; r < 6; ++r) {
                 const int ih = 4 * ty - 1 + r;
                 const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-                d[r] = ok ? ld4(x + (((long)n * H + ih) * W + iw) * C + 4 * c4) : z4();
+                d[r] = wino_ld(x + (((long)n * H + ih) * W + iw) * C + 4 * c4, ok, aff, sc, sh, relu);
             }
             bt6(d, tcol);
 #pragma unroll
@@ -699,13 +716,19 @@ inline bool bad(int N, int H, int W, int C) { return N < 0 || H <= 0 || W <= 0 |
 
 extern "C" {
 
-int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile, void* stream) {
+// omni_wino_in of relu?(x * scale + shift): affine = [scale (C) | shift (C)] of the BatchNorm between the convolution that wrote x and
+// this one (nullable: plain omni_wino_in) -- the normalised activation is consumed without ever being stored.
+int omni_wino_in_affine(const float* x, const float* affine, int relu, float* V, int N, int H, int W, int C, int tile, void* stream) {
     if (bad(N, H, W, C) || (tile != 2 && tile != 4) || (H % tile) || (W % tile)) return OMNI_ERR_ARG;
     const long total = (long)N * (H / tile) * (W / tile) * (C / 4);
     if (total == 0) return OMNI_OK;
-    if (tile == 2) hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C);
-    else hipLaunchKernelGGL(wino4_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C);
+    if (tile == 2) hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C, affine, relu);
+    else hipLaunchKernelGGL(wino4_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C, affine, relu);
     return omni_launch_status();
+}
+
+int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile, void* stream) {
+    return omni_wino_in_affine(x, nullptr, 0, V, N, H, W, C, tile, stream);
 }
 
 static int wino_out_impl(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, float* stats,

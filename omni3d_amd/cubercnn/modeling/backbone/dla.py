@@ -49,8 +49,9 @@ class BasicBlock(nn.Module):
     def forward(self, x, residual=None):
         if residual is None:
             residual = x
-        out = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(out), residual=residual, relu=True)
+        # (bn1 + ReLU are applied inside conv2's Winograd input transform when it takes that path: functional.bn_relu_conv3x3)
+        out = HF.bn_relu_conv3x3(self.conv1(x), self.bn1, self.conv2, want_stats=self.training and torch.is_grad_enabled())
+        return self.bn2(out, residual=residual, relu=True)
 
 
 class Bottleneck(nn.Module):

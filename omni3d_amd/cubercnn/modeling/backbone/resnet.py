@@ -41,8 +41,9 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         HF.fanout(x)        # read by conv1 and by the shortcut: the two gradients are summed inside the consumers' kernels
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(out), residual=identity, relu=True)
+        # (bn1 + ReLU are applied inside conv2's Winograd input transform when it takes that path: functional.bn_relu_conv3x3)
+        out = HF.bn_relu_conv3x3(self.conv1(x), self.bn1, self.conv2, want_stats=self.training and torch.is_grad_enabled())
+        return self.bn2(out, residual=identity, relu=True)
 
 
 class Bottleneck(nn.Module):

@@ -561,6 +561,89 @@ def fused_linear(x, weights, biases, rows, relu=False):
     return _Linear.apply(x, w, b, relu, None, None)
 
 
+def _wino_weights(w, tile, need_flip):
+    """(U, U') of filter `w` through the pass's cache (wino_weight_scope), recording a miss for the next pass's batched launch"""
+    key = (w.data_ptr(), tuple(w.shape), tile)
+    cache = _wino_scope["cache"]
+    U, Uf = cache.get(key, (None, None)) if cache is not None else (None, None)
+    if U is None or (need_flip and Uf is None):
+        U, Uf = wino.transform_weights(w, True, need_flip or Uf is not None, tile)
+        if cache is not None:
+            cache[key] = (U, Uf)
+            _wino_scope["record"].append((w, tile, bool(need_flip or Uf is not None)))
+    return U, Uf
+
+
+class _BNReLUWinoConv(Function):
+    """conv -> BatchNorm -> ReLU -> 3x3 convolution with the normalised activation never materialised (the inside of every DLA /
+    torchvision BasicBlock, /root/reference/cubercnn/modeling/backbone/dla.py:60-66): x is the RAW output of the first convolution with
+    its epilogue statistics; BatchNorm's finalize turns them into (scale, shift), and the Winograd input transform of the second
+    convolution applies scale / shift / ReLU while it loads its tiles (omni_wino_in_affine).  Saves the write and the read of the
+    normalised tensor and one launch per block; the backward pass is the two layers' usual kernels (the BatchNorm's ReLU mask is
+    recomputed from x, so nothing needed the normalised tensor anyway)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, partials, w, want_stats):
+        ctx.set_materialize_grads(False)
+        gg, gb = _direct_grad(gamma), _direct_grad(beta)
+        ctx.bn_direct = (gg, gb) if (gg is not None and gb is not None) else None
+        ctx.w_direct = _direct_grad(w)
+        x, w = _cl(x), _cl(w)
+        mean_rstd, scale_shift = bnpool.bn_finalize_fwd(x, gamma, beta, running_mean, running_var, partials, eps, momentum)
+        tile = wino.tile_size(x.shape)
+        need_flip = wino.dgrad_eligible(x.shape)
+        U, Uf = _wino_weights(w, tile, need_flip)
+        parts = None
+        if want_stats:
+            y, V, parts = wino.conv3x3_fwd(x, w, None, False, U=U, tile=tile, want_stats=True, in_affine=scale_shift, in_relu=True)
+        else:
+            y, V = wino.conv3x3_fwd(x, w, None, False, U=U, tile=tile, in_affine=scale_shift, in_relu=True)
+        ctx.save_for_backward(x, gamma, mean_rstd, scale_shift, V, w, Uf if need_flip else None)
+        parts = _parts_out(parts, y)
+        ctx.mark_non_differentiable(parts)
+        return y, parts
+
+    @staticmethod
+    def backward(ctx, dy, _parts_grad=None):
+        x, gamma, mean_rstd, scale_shift, V, w, Uf = ctx.saved_tensors
+        dy = _cl(dy)
+        gw = ctx.w_direct
+        if gw is not None and not gw.is_contiguous(memory_format=CL):
+            gw = None
+        # the second convolution: data gradient (= the gradient of the normalised activation) and weight gradient
+        if wino.dgrad_eligible(dy.shape):
+            dmid, dw = wino.conv3x3_backward(V, dy, w, Uf, accum_into=gw, side_run=_side_run)
+        else:
+            dmid = conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 1)
+            dw = _side_run(lambda: wino.conv3x3_wgrad(V, dy, accum_into=gw), (V, dy)) if gw is not None else wino.conv3x3_wgrad(V, dy)
+        # the BatchNorm + ReLU: mask recomputed from x and (scale, shift)
+        dx, _, dgamma, dbeta = bnpool.bn_bwd(x, dmid, None, gamma, mean_rstd, True, want_dres=False, accum_into=ctx.bn_direct,
+                                             scale_shift=scale_shift)
+        return dx, dgamma, dbeta, None, None, None, None, None, dw, None
+
+
+_BN_WINO_FUSE = _os_environ_get("OMNI_BN_WINO_FUSE", "1") != "0"      # A/B knob
+
+
+def bn_relu_conv3x3(x, bn, conv_mod, want_stats):
+    """`conv_mod(bn(x, relu=True))` for a 3x3 / stride 1 / pad 1 / bias-free `conv_mod` (layers.Conv2d) behind a training-mode
+    BatchNorm `bn` (layers.BatchNorm2d) whose input `x` carries its producer's epilogue statistics: fused when the convolution takes
+    the Winograd path, the plain two-module sequence otherwise."""
+    w = conv_mod.weight
+    parts = getattr(x, "_omni_bn_partials", None)
+    if (_BN_WINO_FUSE and _WINOGRAD and parts is not None and bn.training and torch.is_grad_enabled() and conv_mod.bias is None
+            and conv_mod.stride[0] == 1 and conv_mod.padding[0] == 1 and w.requires_grad and x.requires_grad
+            and wino.eligible(x.shape, w.shape, 1, 1) and _BN_REMASK and w.is_contiguous(memory_format=CL)):
+        y, p2 = _BNReLUWinoConv.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                      bn.running_var if bn.track_running_stats else None, bn.eps, bn.momentum, parts, w, bool(want_stats))
+        if bn.track_running_stats and bn.num_batches_tracked is not None and not bn.defer_counter:
+            bn.num_batches_tracked += 1
+        if p2.shape[0] > 0:
+            y._omni_bn_partials = p2
+        return y
+    return conv_mod(bn(x, relu=True))
+
+
 _BN_REMASK = _os_environ_get("OMNI_BN_REMASK", "1") != "0"     # A/B knob
 # backward reductions from the data-gradient transform above the layer (wino.transform_output_bn_bwd).  OFF by default: measured
 # neutral on the DLA-34 step (317.9 / 316.2 images/s with, 316.3 without): the transform of a 32x32 / 64x64 map runs on 128-256

@@ -33,6 +33,20 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, residual=None, relu=False,
     return y.permute(0, 3, 1, 2), mean_rstd, scale_shift
 
 
+def bn_finalize_fwd(x, gamma, beta, running_mean, running_var, partials, eps=1e-5, momentum=0.1):
+    """the finalize half of bn_fwd alone (statistics from the producer's epilogue): -> (mean_rstd (2C), scale_shift (2C)); running
+    statistics updated.  x only gives the geometry: the normalised tensor is applied on load by its consumer (wino.transform_input)."""
+    xv = _nhwc(x)
+    N, H, W, C = xv.shape
+    assert partials is not None and partials.is_contiguous() and partials.shape[1] == 2 * C
+    L = _lib.check_device(xv, gamma, beta, running_mean, running_var, partials)
+    mean_rstd = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    scale_shift = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    L.call("omni_bn_finalize_fwd", _lib.ptr(partials), partials.shape[0], _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+           _lib.ptr(running_var), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), N * H * W, C, float(eps), float(momentum), _lib.stream_of(x))
+    return mean_rstd, scale_shift
+
+
 def bn_apply(x, scale_shift, residual=None, relu=False):
     xv = _nhwc(x)
     rv = _nhwc(residual) if residual is not None else None

@@ -53,13 +53,19 @@ def _points(tile):
     return (tile + 2) ** 2
 
 
-def transform_input(x, tile=2):
-    """x (N,C,H,W) CL -> V (P, T, C), P = (tile + 2)^2 Winograd points, T = N * H/tile * W/tile"""
+def transform_input(x, tile=2, affine=None, relu=False):
+    """x (N,C,H,W) CL -> V (P, T, C), P = (tile + 2)^2 Winograd points, T = N * H/tile * W/tile.
+    affine (2C) = [scale | shift]: the transform of relu?(x * scale + shift) -- the BatchNorm(+ReLU) between the convolution that wrote
+    x and this one, applied on load (zero padding as for the normalised tensor, which is never stored)"""
     xv = _nhwc(x)
     N, H, W, C = xv.shape
-    L = _lib.check_device(xv)
+    L = _lib.check_device(xv, affine)
     V = torch.empty((_points(tile), N * (H // tile) * (W // tile), C), dtype=torch.float32, device=x.device)
-    L.call("omni_wino_in", _lib.ptr(xv), _lib.ptr(V), N, H, W, C, tile, _lib.stream_of(x))
+    if affine is not None:
+        assert affine.numel() == 2 * C
+        L.call("omni_wino_in_affine", _lib.ptr(xv), _lib.ptr(affine), int(bool(relu)), _lib.ptr(V), N, H, W, C, tile, _lib.stream_of(x))
+    else:
+        L.call("omni_wino_in", _lib.ptr(xv), _lib.ptr(V), N, H, W, C, tile, _lib.stream_of(x))
     return V
 
 
@@ -213,11 +219,12 @@ def transform_dweights(dU, accum_into=None):
     return dw.permute(0, 3, 1, 2)
 
 
-def conv3x3_fwd(x, w, bias=None, relu=False, U=None, tile=2, want_stats=False):
+def conv3x3_fwd(x, w, bias=None, relu=False, U=None, tile=2, want_stats=False, in_affine=None, in_relu=False):
     """-> (y, V): V is kept by the caller for the weight gradient.  U: precomputed transform_weights(w, tile=tile)[0].
-    want_stats (no bias, no ReLU): -> (y, V, BatchNorm partial statistics or None)"""
+    want_stats (no bias, no ReLU): -> (y, V, BatchNorm partial statistics or None).
+    in_affine / in_relu: the convolution of relu?(x * scale + shift) (see transform_input)"""
     N, _, H, W = x.shape
-    V = transform_input(x, tile)
+    V = transform_input(x, tile, affine=in_affine, relu=in_relu)
     if U is None:
         U = transform_weights(w, tile=tile)[0]
     Mt = gemm_batched(V, U)

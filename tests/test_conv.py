@@ -405,3 +405,52 @@ def test_winograd_weights_multi_emulated(emu_lib):
 def test_winograd_weights_multi_gpu(hip_lib):
     _run_weights_multi("cuda")
     _run_weight_plan("cuda")
+
+
+def _run_bn_relu_wino_fusion(dev, shapes):
+    """BasicBlock (conv -> BN -> ReLU -> 3x3 conv -> BN + residual + ReLU) with bn1 + ReLU applied inside conv2's Winograd input
+    transform == the unfused sequence: outputs, input / parameter gradients, running statistics, batch counter"""
+    import copy
+    from omni3d_amd import functional as HF
+    from omni3d_amd.cubercnn.modeling.backbone.dla import BasicBlock
+    for (N, C, H, tile) in shapes:
+        torch.manual_seed(C + H)
+        blk = BasicBlock(C, C).to(dev).train()
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.3)
+        x0 = torch.randn(N, C, H, H).contiguous(memory_format=torch.channels_last).to(dev)
+        g = torch.randn(N, C, H, H).contiguous(memory_format=torch.channels_last).to(dev)
+        assert HF.wino.eligible(x0.shape, blk.conv2.weight.shape, 1, 1) and HF.wino.tile_size(x0.shape) == tile
+        res = {}
+        for fused in (True, False):
+            prev, HF._BN_WINO_FUSE = HF._BN_WINO_FUSE, fused
+            try:
+                b = copy.deepcopy(blk)
+                x = x0.clone().requires_grad_(True)
+                calls = []
+                real = HF.bnpool.bn_finalize_fwd
+                HF.bnpool.bn_finalize_fwd = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+                try:
+                    y = b(x)
+                finally:
+                    HF.bnpool.bn_finalize_fwd = real
+                assert bool(calls) == fused                      # the fused path really ran (or did not)
+                y.backward(g)
+                HF.side_join()
+                res[fused] = [y.detach(), x.grad] + [p.grad for p in b.parameters()] + [b.bn1.running_mean, b.bn1.running_var,
+                                                                                        b.bn1.num_batches_tracked.float()]
+            finally:
+                HF._BN_WINO_FUSE = prev
+        for i, (a, c) in enumerate(zip(res[True], res[False])):
+            assert (a - c).abs().max() <= 2e-5 * max(1.0, float(c.abs().max())), (C, H, i, float((a - c).abs().max()))
+
+
+def test_bn_relu_winograd_fusion_emulated(emu_lib):
+    _run_bn_relu_wino_fusion("cpu", [(4, 128, 16, 2), (1, 128, 64, 4)])
+
+
+@pytest.mark.gpu
+def test_bn_relu_winograd_fusion_gpu(hip_lib):
+    _run_bn_relu_wino_fusion("cuda", [(4, 128, 64, 4), (4, 256, 32, 4), (4, 512, 16, 2), (4, 64, 128, 4)])
