@@ -622,7 +622,10 @@ class _BNReLUWinoConv(Function):
         return dx, dgamma, dbeta, None, None, None, None, None, dw, None
 
 
-_BN_WINO_FUSE = _os_environ_get("OMNI_BN_WINO_FUSE", "1") != "0"      # A/B knob
+# OFF by default: measured SLOWER on the DLA-34 step (11.93 / 11.95 ms with, 11.89 without; profiles/r03_ab_bn_wino_fuse.log): the input
+# transform reads every activation 2.25 times (overlapping 6x6 windows) and now normalises it 2.25 times, with 8 more live registers
+# next to its 144-register tile -- that costs more than the 5 us bn_apply launch and the 2 x 4-17 MB it saves
+_BN_WINO_FUSE = _os_environ_get("OMNI_BN_WINO_FUSE", "0") != "0"      # A/B knob
 
 
 def bn_relu_conv3x3(x, bn, conv_mod, want_stats):
