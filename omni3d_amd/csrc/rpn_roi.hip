@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int MAXG = 256;   // GT boxes per image staged in LDS
+constexpr int MAXG = 1024;  // GT boxes per image staged in LDS (round 3: 256 -> 1024; the ROI sampler then holds 56 KB of LDS)
 constexpr int MAXL = 8;
 constexpr int RPN_A = 3;    // anchors per location
 constexpr int RPN_C = 16;   // channels of the fused RPN head output

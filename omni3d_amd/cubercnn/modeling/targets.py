@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 
-MAX_GT_PER_IMAGE = 256      # csrc/rpn_roi.hip MAXG
+MAX_GT_PER_IMAGE = 1024     # csrc/rpn_roi.hip MAXG (with MODEL.RPN.POST_NMS_TOPK_TRAIN 1000 the sampler's 2048 candidate slots still hold proposals + appended GT)
 
 
 class PackedTargets:

@@ -24,12 +24,13 @@ def _rand_boxes(g, n, W, H, smin=8, smax=80):
     return b
 
 
-def _rpn_setup(dev, seed=0):
+def _rpn_setup(dev, seed=0, crowded=0):
     g = torch.Generator().manual_seed(seed)
     hw, strides, sizes = [(16, 16), (8, 8), (4, 4)], [4, 8, 16], [16, 32, 64]
     anchors = _anchors(sizes, strides, hw)
     B = 2
-    gts = [_rand_boxes(g, 5, 64, 64), _rand_boxes(g, 3, 64, 64)]
+    # crowded: one image with more ground-truth boxes than the kernels' LDS staging held before round 3 (256)
+    gts = [_rand_boxes(g, crowded or 5, 64, 64), _rand_boxes(g, 3, 64, 64)]
     igns = [_rand_boxes(g, 1, 64, 64, 30, 60), torch.zeros(0, 4)]
     E = torch.empty(B, anchors.shape[0]).exponential_(generator=g)
     return anchors, gts, igns, E, hw
@@ -39,9 +40,9 @@ def _offsets(lst):
     return torch.tensor(np.concatenate([[0], np.cumsum([len(x) for x in lst])]), dtype=torch.int32)
 
 
-def _run_rpn_labels(dev, batch_per_image, pos_frac, seed):
+def _run_rpn_labels(dev, batch_per_image, pos_frac, seed, crowded=0):
     from omni3d_amd.kernels import det, select
-    anchors, gts, igns, E, hw = _rpn_setup(dev, seed)
+    anchors, gts, igns, E, hw = _rpn_setup(dev, seed, crowded)
     A, B = anchors.shape[0], len(gts)
     gt, ign = torch.cat(gts), torch.cat(igns)
     gt_off, ign_off = _offsets(gts), _offsets(igns)
@@ -125,12 +126,13 @@ def _run_rpn_loss(dev):
             assert bool(valid[n, j]) == bool(pb.nonempty()[0])
 
 
-def _run_roi_sample(dev):
+def _run_roi_sample(dev, crowded=0):
     from omni3d_amd.kernels import det
     g = torch.Generator().manual_seed(5)
     B, pmax, Kc = 2, 300, 50
-    gts = [_rand_boxes(g, 6, 200, 200, 20, 90), _rand_boxes(g, 2, 200, 200, 20, 90)]
-    gcls = [torch.randint(0, Kc, (6,), generator=g), torch.randint(0, Kc, (2,), generator=g)]
+    n0 = crowded or 6          # crowded: more ground truth in one image than the kernels staged before round 3 (256), all appended
+    gts = [_rand_boxes(g, n0, 200, 200, 20, 90), _rand_boxes(g, 2, 200, 200, 20, 90)]
+    gcls = [torch.randint(0, Kc, (n0,), generator=g), torch.randint(0, Kc, (2,), generator=g)]
     igns = [_rand_boxes(g, 2, 200, 200, 60, 150), torch.zeros(0, 4)]
     props = torch.stack([_rand_boxes(g, pmax, 200, 200, 10, 100) for _ in range(B)])
     # make some proposals overlap GT strongly
@@ -420,6 +422,18 @@ def test_rpn_labels_emulated(emu_lib):
 
 def test_rpn_loss_decode_emulated(emu_lib):
     _run_rpn_loss("cpu")
+
+
+def test_crowded_image_labels_and_sampling_emulated(emu_lib):
+    """300 / 700 ground-truth boxes in one image (the LDS staging of csrc/rpn_roi.hip holds 1024; it held 256)"""
+    _run_rpn_labels("cpu", 64, 0.5, 3, crowded=300)
+    _run_roi_sample("cpu", crowded=700)
+
+
+@pytest.mark.gpu
+def test_crowded_image_labels_and_sampling_gpu(hip_lib):
+    _run_rpn_labels("cuda", 64, 0.5, 3, crowded=300)
+    _run_roi_sample("cuda", crowded=700)
 
 
 def test_roi_sample_emulated(emu_lib):
