@@ -66,7 +66,9 @@ def build_product_model(cfg, priors, seed, device="cpu"):
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for n, p in model.named_parameters():
-            if p.dim() == 1 and "priors" not in n:
+            # (`_omni_ddp_anchor` only exists when a process group with more than one rank is up at build time, solver/ddp.py: it must
+            # not shift the random stream, or a replica built inside a rank differs from the same seed built outside one)
+            if p.dim() == 1 and "priors" not in n and "_omni_ddp_anchor" not in n:
                 p.add_(torch.randn(p.shape, generator=g) * 0.05)
     return model.to(device)
 
