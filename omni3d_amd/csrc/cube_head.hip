@@ -60,67 +60,89 @@ namespace {
 
 constexpr int NT = 13;  // tangent slots: dx dy | z | dw dh dl | p0..p5 | u   (lane t of a ROI's 16-lane group carries slot t)
 
-struct D {            // dual number: value + THIS LANE's tangent
-    float v;
-    float d;
+// scalar maths on the working type T: float for the training kernels (the reference's own precision; losses and Jacobians are
+// parity-green at 1e-7), double for the inference decode (round 4: the Gram-Schmidt of the 6D pose, the allocentric viewing-ray
+// rotation and R d / 2 of up to ~100 m cuboids lose 2-3 digits in fp32; the decode kernel is latency-bound, fp64 costs nothing)
+__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float m_exp(float x) { return expf(x); }
+__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ float m_sin(float x) { return sinf(x); }
+__device__ __forceinline__ double m_sin(double x) { return sin(x); }
+__device__ __forceinline__ float m_cos(float x) { return cosf(x); }
+__device__ __forceinline__ double m_cos(double x) { return cos(x); }
+__device__ __forceinline__ float m_acos(float x) { return acosf(x); }
+__device__ __forceinline__ double m_acos(double x) { return acos(x); }
+__device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double m_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float m_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
+
+template <class T>
+struct Dual {         // dual number: value + THIS LANE's tangent
+    T v;
+    T d;
 };
-__device__ __forceinline__ D cst(float v) { D r; r.v = v; r.d = 0.f; return r; }
+template <class T> __device__ __forceinline__ Dual<T> cstT(T v) { Dual<T> r; r.v = v; r.d = T(0); return r; }
 // tl = the tangent slot this lane carries (-1: values only, e.g. the inference decode)
-__device__ __forceinline__ D var(float v, int slot, int tl) { D r; r.v = v; r.d = (slot == tl) ? 1.f : 0.f; return r; }
-__device__ __forceinline__ D operator+(const D& a, const D& b) { D r; r.v = a.v + b.v; r.d = a.d + b.d; return r; }
-__device__ __forceinline__ D operator-(const D& a, const D& b) { D r; r.v = a.v - b.v; r.d = a.d - b.d; return r; }
-__device__ __forceinline__ D operator*(const D& a, const D& b) { D r; r.v = a.v * b.v; r.d = a.d * b.v + a.v * b.d; return r; }
-__device__ __forceinline__ D operator/(const D& a, const D& b) {
-    D r; r.v = a.v / b.v;
-    const float inv = 1.f / b.v;
+template <class T> __device__ __forceinline__ Dual<T> varT(float v, int slot, int tl) { Dual<T> r; r.v = T(v); r.d = (slot == tl) ? T(1) : T(0); return r; }
+template <class T> __device__ __forceinline__ Dual<T> operator+(const Dual<T>& a, const Dual<T>& b) { Dual<T> r; r.v = a.v + b.v; r.d = a.d + b.d; return r; }
+template <class T> __device__ __forceinline__ Dual<T> operator-(const Dual<T>& a, const Dual<T>& b) { Dual<T> r; r.v = a.v - b.v; r.d = a.d - b.d; return r; }
+template <class T> __device__ __forceinline__ Dual<T> operator*(const Dual<T>& a, const Dual<T>& b) { Dual<T> r; r.v = a.v * b.v; r.d = a.d * b.v + a.v * b.d; return r; }
+template <class T> __device__ __forceinline__ Dual<T> operator/(const Dual<T>& a, const Dual<T>& b) {
+    Dual<T> r; r.v = a.v / b.v;
+    const T inv = T(1) / b.v;
     r.d = (a.d - r.v * b.d) * inv;
     return r;
 }
-__device__ __forceinline__ D operator*(const D& a, float s) { D r; r.v = a.v * s; r.d = a.d * s; return r; }
-__device__ __forceinline__ D operator+(const D& a, float s) { D r = a; r.v += s; return r; }
-__device__ __forceinline__ D neg(const D& a) { D r; r.v = -a.v; r.d = -a.d; return r; }
-__device__ __forceinline__ D dsqrt(const D& a) {
-    D r; r.v = sqrtf(a.v);
-    r.d = a.d * (0.5f / r.v);
+// scalar factors / offsets are exact in either working type (they are floats or float-valued)
+template <class T> __device__ __forceinline__ Dual<T> operator*(const Dual<T>& a, float s) { Dual<T> r; r.v = a.v * T(s); r.d = a.d * T(s); return r; }
+template <class T> __device__ __forceinline__ Dual<T> operator+(const Dual<T>& a, float s) { Dual<T> r = a; r.v += T(s); return r; }
+__device__ __forceinline__ Dual<double> operator*(const Dual<double>& a, double s) { Dual<double> r; r.v = a.v * s; r.d = a.d * s; return r; }
+__device__ __forceinline__ Dual<double> operator+(const Dual<double>& a, double s) { Dual<double> r = a; r.v += s; return r; }
+template <class T> __device__ __forceinline__ Dual<T> neg(const Dual<T>& a) { Dual<T> r; r.v = -a.v; r.d = -a.d; return r; }
+template <class T> __device__ __forceinline__ Dual<T> dsqrt(const Dual<T>& a) {
+    Dual<T> r; r.v = m_sqrt(a.v);
+    r.d = a.d * (T(0.5) / r.v);
     return r;
 }
-__device__ __forceinline__ D dexp(const D& a) { D r; r.v = expf(a.v); r.d = a.d * r.v; return r; }
-__device__ __forceinline__ D dsigmoid(const D& a) {
-    D r; r.v = 1.f / (1.f + expf(-a.v));
-    r.d = a.d * (r.v * (1.f - r.v));
+template <class T> __device__ __forceinline__ Dual<T> dexp(const Dual<T>& a) { Dual<T> r; r.v = m_exp(a.v); r.d = a.d * r.v; return r; }
+template <class T> __device__ __forceinline__ Dual<T> dsigmoid(const Dual<T>& a) {
+    Dual<T> r; r.v = T(1) / (T(1) + m_exp(-a.v));
+    r.d = a.d * (r.v * (T(1) - r.v));
     return r;
 }
-__device__ __forceinline__ D dsin(const D& a) { D r; r.v = sinf(a.v); r.d = a.d * cosf(a.v); return r; }
-__device__ __forceinline__ D dcos(const D& a) { D r; r.v = cosf(a.v); r.d = -a.d * sinf(a.v); return r; }
-__device__ __forceinline__ D dabs(const D& a) {
-    const float s = a.v > 0.f ? 1.f : (a.v < 0.f ? -1.f : 0.f);
-    D r; r.v = fabsf(a.v);
+template <class T> __device__ __forceinline__ Dual<T> dsin(const Dual<T>& a) { Dual<T> r; r.v = m_sin(a.v); r.d = a.d * m_cos(a.v); return r; }
+template <class T> __device__ __forceinline__ Dual<T> dcos(const Dual<T>& a) { Dual<T> r; r.v = m_cos(a.v); r.d = -a.d * m_sin(a.v); return r; }
+template <class T> __device__ __forceinline__ Dual<T> dabs(const Dual<T>& a) {
+    const T s = a.v > T(0) ? T(1) : (a.v < T(0) ? T(-1) : T(0));
+    Dual<T> r; r.v = m_abs(a.v);
     r.d = a.d * s;
     return r;
 }
-__device__ __forceinline__ D clip_max(const D& a, float mx) { return a.v > mx ? cst(mx) : a; }   // grad 0 when clipped
-__device__ __forceinline__ D clip_min(const D& a, float mn) { return a.v < mn ? cst(mn) : a; }
+template <class T> __device__ __forceinline__ Dual<T> clip_max(const Dual<T>& a, float mx) { return a.v > T(mx) ? cstT<T>(T(mx)) : a; }   // grad 0 when clipped
+template <class T> __device__ __forceinline__ Dual<T> clip_min(const Dual<T>& a, float mn) { return a.v < T(mn) ? cstT<T>(T(mn)) : a; }
 
-struct V3 { D x, y, z; };
-__device__ __forceinline__ D dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 normalize(const V3& a) {   // F.normalize: v / max(||v||, 1e-12)
-    D n = dsqrt(dot(a, a));
-    if (n.v < 1e-12f) n = cst(1e-12f);
-    V3 r; r.x = a.x / n; r.y = a.y / n; r.z = a.z / n;
+template <class T> struct Vec3 { Dual<T> x, y, z; };
+template <class T> __device__ __forceinline__ Dual<T> dot(const Vec3<T>& a, const Vec3<T>& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> __device__ __forceinline__ Vec3<T> normalize(const Vec3<T>& a) {   // F.normalize: v / max(||v||, 1e-12)
+    Dual<T> n = dsqrt(dot(a, a));
+    if (n.v < T(1e-12f)) n = cstT<T>(T(1e-12f));
+    Vec3<T> r; r.x = a.x / n; r.y = a.y / n; r.z = a.z / n;
     return r;
 }
 
-struct Mat3 { D m[3][3]; };
+template <class T> struct Mat3T { Dual<T> m[3][3]; };
 
 // pytorch3d rotation_6d_to_matrix: rows b1, b2, b3
-__device__ __forceinline__ Mat3 rot6d(const D (&p)[6]) {
-    V3 a1 = {p[0], p[1], p[2]}, a2 = {p[3], p[4], p[5]};
-    V3 b1 = normalize(a1);
-    D s = dot(b1, a2);
-    V3 t = {a2.x - s * b1.x, a2.y - s * b1.y, a2.z - s * b1.z};
-    V3 b2 = normalize(t);
-    V3 b3 = {b1.y * b2.z - b1.z * b2.y, b1.z * b2.x - b1.x * b2.z, b1.x * b2.y - b1.y * b2.x};
-    Mat3 R;
+template <class T> __device__ __forceinline__ Mat3T<T> rot6d(const Dual<T> (&p)[6]) {
+    Vec3<T> a1 = {p[0], p[1], p[2]}, a2 = {p[3], p[4], p[5]};
+    Vec3<T> b1 = normalize(a1);
+    Dual<T> s = dot(b1, a2);
+    Vec3<T> t = {a2.x - s * b1.x, a2.y - s * b1.y, a2.z - s * b1.z};
+    Vec3<T> b2 = normalize(t);
+    Vec3<T> b3 = {b1.y * b2.z - b1.z * b2.y, b1.z * b2.x - b1.x * b2.z, b1.x * b2.y - b1.y * b2.x};
+    Mat3T<T> R;
     R.m[0][0] = b1.x; R.m[0][1] = b1.y; R.m[0][2] = b1.z;
     R.m[1][0] = b2.x; R.m[1][1] = b2.y; R.m[1][2] = b2.z;
     R.m[2][0] = b3.x; R.m[2][1] = b3.y; R.m[2][2] = b3.z;
@@ -128,24 +150,24 @@ __device__ __forceinline__ Mat3 rot6d(const D (&p)[6]) {
 }
 
 // cube_head.py:178-182: q / copysign(|q|, q[0]) then pytorch3d quaternion_to_matrix
-__device__ __forceinline__ Mat3 rot_quat(const D (&p)[4]) {
-    D n = dsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
-    if (p[0].v < 0.f) n = neg(n);
-    const D r = p[0] / n, i = p[1] / n, j = p[2] / n, k = p[3] / n;
-    const D two_s = cst(2.f) / (r * r + i * i + j * j + k * k);
-    const D one = cst(1.f);
-    Mat3 R;
+template <class T> __device__ __forceinline__ Mat3T<T> rot_quat(const Dual<T> (&p)[4]) {
+    Dual<T> n = dsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
+    if (p[0].v < T(0)) n = neg(n);
+    const Dual<T> r = p[0] / n, i = p[1] / n, j = p[2] / n, k = p[3] / n;
+    const Dual<T> two_s = cstT<T>(T(2)) / (r * r + i * i + j * j + k * k);
+    const Dual<T> one = cstT<T>(T(1));
+    Mat3T<T> R;
     R.m[0][0] = one - two_s * (j * j + k * k); R.m[0][1] = two_s * (i * j - k * r); R.m[0][2] = two_s * (i * k + j * r);
     R.m[1][0] = two_s * (i * j + k * r); R.m[1][1] = one - two_s * (i * i + k * k); R.m[1][2] = two_s * (j * k - i * r);
     R.m[2][0] = two_s * (i * k - j * r); R.m[2][1] = two_s * (j * k + i * r); R.m[2][2] = one - two_s * (i * i + j * j);
     return R;
 }
 // pytorch3d euler_angles_to_matrix(angles, 'XYZ') = Rx(a) @ Ry(b) @ Rz(c)   (cube_head.py:184-185)
-__device__ __forceinline__ Mat3 rot_euler(const D (&p)[3]) {
-    const D ca = dcos(p[0]), sa = dsin(p[0]), cb = dcos(p[1]), sb = dsin(p[1]), cc = dcos(p[2]), sc = dsin(p[2]);
+template <class T> __device__ __forceinline__ Mat3T<T> rot_euler(const Dual<T> (&p)[3]) {
+    const Dual<T> ca = dcos(p[0]), sa = dsin(p[0]), cb = dcos(p[1]), sb = dsin(p[1]), cc = dcos(p[2]), sc = dsin(p[2]);
     // Rx @ Ry = [[cb, 0, sb], [sa sb, ca, -sa cb], [-ca sb, sa, ca cb]]
-    const D xy10 = sa * sb, xy12 = neg(sa * cb), xy20 = neg(ca * sb), xy22 = ca * cb;
-    Mat3 R;
+    const Dual<T> xy10 = sa * sb, xy12 = neg(sa * cb), xy20 = neg(ca * sb), xy22 = ca * cb;
+    Mat3T<T> R;
     R.m[0][0] = cb * cc;               R.m[0][1] = neg(cb * sc);           R.m[0][2] = sb;
     R.m[1][0] = xy10 * cc + ca * sc;   R.m[1][1] = ca * cc - xy10 * sc;    R.m[1][2] = xy12;
     R.m[2][0] = xy20 * cc + sa * sc;   R.m[2][1] = sa * cc - xy20 * sc;    R.m[2][2] = xy22;
@@ -154,21 +176,27 @@ __device__ __forceinline__ Mat3 rot_euler(const D (&p)[3]) {
 
 // R_from_allocentric (math_util.py:651-679): M(u, v) is built from DETACHED u, v (roi_heads.py:489),
 // so it is a constant matrix; R = M @ R_view where the viewing-ray angle is > 0.
-__device__ __forceinline__ void allocentric_M(float fx, float fy, float sx, float sy, float u, float v, float (&M)[3][3],
-                                              bool& valid) {
-    float ox = (u - sx) / fx, oy = (v - sy) / fy, oz = 1.f;
-    const float on = sqrtf(ox * ox + oy * oy + oz * oz);
+// The float instantiation follows the reference's operation order (acos of the normalised ray's z, axis_angle_to_matrix through
+// the quaternion).  The double instantiation takes the angle from atan2(|ray_xy|, 1) -- acos near 1 loses half the digits of its
+// argument -- which is the same real number.
+template <class T>
+__device__ __forceinline__ void allocentric_M(float fx, float fy, float sx, float sy, T u, T v, T (&M)[3][3], bool& valid) {
+    T ox = (u - T(sx)) / T(fx), oy = (v - T(sy)) / T(fy), oz = T(1);
+    const T rxy = m_sqrt(ox * ox + oy * oy);
+    const T on = m_sqrt(ox * ox + oy * oy + oz * oz);
     ox /= on; oy /= on; oz /= on;
-    const float angle = acosf(oz);
-    float ax = -oy, ay = ox;   // axis = (-ray_y, ray_x, 0)
-    const float an = sqrtf(ax * ax + ay * ay);
-    valid = angle > 0.f;
+    T angle;
+    if constexpr (sizeof(T) == 8) angle = atan2(rxy, T(1));
+    else angle = m_acos(oz);
+    T ax = -oy, ay = ox;   // axis = (-ray_y, ray_x, 0)
+    const T an = m_sqrt(ax * ax + ay * ay);
+    valid = angle > T(0);
     // axis_angle_to_matrix(angle * axis / |axis|) via quaternion (pytorch3d)
-    const float vx = angle * ax / an, vy = angle * ay / an, vz = 0.f;
-    const float ang = sqrtf(vx * vx + vy * vy + vz * vz), half = ang * 0.5f;
-    const float sh = fabsf(ang) < 1e-6f ? (0.5f - ang * ang / 48.f) : sinf(half) / ang;
-    const float r = cosf(half), i = vx * sh, j = vy * sh, k = vz * sh;
-    const float two_s = 2.f / (r * r + i * i + j * j + k * k);
+    const T vx = angle * ax / an, vy = angle * ay / an, vz = T(0);
+    const T ang = m_sqrt(vx * vx + vy * vy + vz * vz), half = ang * T(0.5);
+    const T sh = m_abs(ang) < T(1e-6f) ? (T(0.5) - ang * ang / T(48)) : m_sin(half) / ang;
+    const T r = m_cos(half), i = vx * sh, j = vy * sh, k = vz * sh;
+    const T two_s = T(2) / (r * r + i * i + j * j + k * k);
     M[0][0] = 1 - two_s * (j * j + k * k); M[0][1] = two_s * (i * j - k * r); M[0][2] = two_s * (i * k + j * r);
     M[1][0] = two_s * (i * j + k * r); M[1][1] = 1 - two_s * (i * i + k * k); M[1][2] = two_s * (j * k - i * r);
     M[2][0] = two_s * (i * k - j * r); M[2][1] = two_s * (j * k + i * r); M[2][2] = 1 - two_s * (i * i + j * j);
@@ -176,17 +204,25 @@ __device__ __forceinline__ void allocentric_M(float fx, float fy, float sx, floa
 
 // get_cuboid_verts_faces (math_util.py:171-191): box = [X, Y, Z, W, H, L]; x = -+L/2 on {0,3,4,7}/{1,2,5,6},
 // y = -+H/2 on {0,1,4,5}/{2,3,6,7}, z = -+W/2 on {0..3}/{4..7}; verts = R @ v + centre.
-__device__ __forceinline__ void corners(const D& X, const D& Y, const D& Z, const D& Wd, const D& Hd, const D& Ld,
-                                        const Mat3& R, V3 (&out)[8]) {
-    const D hl = Ld * 0.5f, hh = Hd * 0.5f, hw = Wd * 0.5f;
+template <class T>
+__device__ __forceinline__ void corners(const Dual<T>& X, const Dual<T>& Y, const Dual<T>& Z, const Dual<T>& Wd, const Dual<T>& Hd,
+                                        const Dual<T>& Ld, const Mat3T<T>& R, Vec3<T> (&out)[8]) {
+    const Dual<T> hl = Ld * 0.5f, hh = Hd * 0.5f, hw = Wd * 0.5f;
     const float sxs[8] = {-1, 1, 1, -1, -1, 1, 1, -1}, sys[8] = {-1, -1, 1, 1, -1, -1, 1, 1}, szs[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
     for (int i = 0; i < 8; ++i) {
-        const D vx = hl * sxs[i], vy = hh * sys[i], vz = hw * szs[i];
+        const Dual<T> vx = hl * sxs[i], vy = hh * sys[i], vz = hw * szs[i];
         out[i].x = R.m[0][0] * vx + R.m[0][1] * vy + R.m[0][2] * vz + X;
         out[i].y = R.m[1][0] * vx + R.m[1][1] * vy + R.m[1][2] * vz + Y;
         out[i].z = R.m[2][0] * vx + R.m[2][1] * vy + R.m[2][2] * vz + Z;
     }
 }
+
+// the training kernels' working types
+using D = Dual<float>;
+using V3 = Vec3<float>;
+using Mat3 = Mat3T<float>;
+__device__ __forceinline__ D cst(float v) { return cstT<float>(v); }
+
 __device__ __forceinline__ D l1_mean(const V3 (&a)[8], const V3 (&b)[8]) {
     D s = cst(0.f);
     for (int i = 0; i < 8; ++i) s = s + dabs(a[i].x - b[i].x) + dabs(a[i].y - b[i].y) + dabs(a[i].z - b[i].z);
@@ -259,66 +295,70 @@ __device__ __forceinline__ void load_roi(RoiIn& in, int f, const float* __restri
 }
 
 // decode only (also used at inference): returns values + (optionally) duals
-struct Decoded {
-    D x, y, z, dims[3], u;
-    Mat3 pose;
+template <class T>
+struct DecodedT {
+    Dual<T> x, y, z, dims[3], u;
+    Mat3T<T> pose;
     // the network-space quantities the entangled losses compare (roi_heads.py:613-649)
-    D dxy[2], zn, dn[3];
-    Mat3 pose_view;    // the head's rotation before R_from_allocentric
-    float M[3][3];     // allocentric -> egocentric rotation of this ROI (identity if ALLOCENTRIC_POSE is off / the ray is the axis)
+    Dual<T> dxy[2], zn, dn[3];
+    Mat3T<T> pose_view;    // the head's rotation before R_from_allocentric
+    T M[3][3];             // allocentric -> egocentric rotation of this ROI (identity if ALLOCENTRIC_POSE is off / the ray is the axis)
 };
-__device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn& in, int tl, const int mode) {
+using Decoded = DecodedT<float>;
+template <class T>
+__device__ __forceinline__ DecodedT<T> decode(const float* hrow, int K, const RoiIn& in, int tl, const int mode) {
+    using DT = Dual<T>;
     const int c = in.cls, Pn = M_POSE_WIDTH(mode), nb = in.bins;
     const float* pxy = hrow + 2 * c;
     const float* pz = hrow + 2 * K + in.bin * K + c;          // cube_head.py:191-192: (n, bins, K) view of the depth outputs
     const float* pd = hrow + (2 + nb) * K + 3 * c;
     const float* pp = hrow + (5 + nb) * K + Pn * c;
-    Decoded o;
-    const float sw = in.box[2] - in.box[0], sh = in.box[3] - in.box[1];
-    const float cx = in.box[0] + 0.5f * sw, cy = in.box[1] + 0.5f * sh;
-    o.dxy[0] = var(pxy[0], 0, tl);
-    o.dxy[1] = var(pxy[1], 1, tl);
+    DecodedT<T> o;
+    const T sw = T(in.box[2]) - T(in.box[0]), sh = T(in.box[3]) - T(in.box[1]);
+    const T cx = T(in.box[0]) + T(0.5) * sw, cy = T(in.box[1]) + T(0.5) * sh;
+    o.dxy[0] = varT<T>(pxy[0], 0, tl);
+    o.dxy[1] = varT<T>(pxy[1], 1, tl);
     o.x = o.dxy[0] * sw + cx;                           // roi_heads.py:460-461
     o.y = o.dxy[1] * sh + cy;
-    D z = var(pz[0], 2, tl);                            // Z_TYPE (roi_heads.py:493-522)
+    DT z = varT<T>(pz[0], 2, tl);                       // Z_TYPE (roi_heads.py:493-522)
     o.zn = z;
     if (M_Z(mode) == 1) { o.zn = dsigmoid(z); z = o.zn * 100.f; }
     else if (M_Z(mode) == 2) z = dexp(z);
     else if (M_Z(mode) == 3) {                          // util.scaled_sigmoid(z, (mean - 3 std).clip(0), mean + 3 std)
-        const float mn = fmaxf(in.zmean - 3.f * in.zstd, 0.f), mx = in.zmean + 3.f * in.zstd;
+        const T mn = m_max(T(in.zmean) - T(3) * T(in.zstd), T(0)), mx = T(in.zmean) + T(3) * T(in.zstd);
         z = dsigmoid(z) * (mx - mn) + mn;
     }
     o.z = M_VDEPTH(mode) ? z * in.v2r : z;              // virtual depth (roi_heads.py:524-525)
     for (int k = 0; k < 3; ++k) {                       // roi_heads.py:467-484
-        const D d = var(pd[k], 3 + k, tl);
+        const DT d = varT<T>(pd[k], 3 + k, tl);
         o.dn[k] = d;
         if (M_DIMS(mode) == 0) o.dims[k] = dexp(clip_max(d, 5.f)) * in.prior[k];
         else if (M_DIMS(mode) == 1) {                   // util.scaled_sigmoid(d, min = (mean - 3 std).clip(0), max = mean + 3 std)
-            const float mn = fmaxf(in.prior[k] - 3.f * in.pstd[k], 0.f), mx = in.prior[k] + 3.f * in.pstd[k];
+            const T mn = m_max(T(in.prior[k]) - T(3) * T(in.pstd[k]), T(0)), mx = T(in.prior[k]) + T(3) * T(in.pstd[k]);
             o.dims[k] = dsigmoid(d) * (mx - mn) + mn;
         } else o.dims[k] = dexp(clip_max(d, 5.f));
     }
-    Mat3 Rv;
+    Mat3T<T> Rv;
     if (M_POSE(mode) == 0) {
-        D p6[6];
-        for (int k = 0; k < 6; ++k) p6[k] = var(pp[k], 6 + k, tl);
+        DT p6[6];
+        for (int k = 0; k < 6; ++k) p6[k] = varT<T>(pp[k], 6 + k, tl);
         Rv = rot6d(p6);                                 // cube_head.py:176
     } else if (M_POSE(mode) == 1) {
-        D q[4];
-        for (int k = 0; k < 4; ++k) q[k] = var(pp[k], 6 + k, tl);
+        DT q[4];
+        for (int k = 0; k < 4; ++k) q[k] = varT<T>(pp[k], 6 + k, tl);
         Rv = rot_quat(q);
     } else {
-        D e[3];
-        for (int k = 0; k < 3; ++k) e[k] = var(pp[k], 6 + k, tl);
+        DT e[3];
+        for (int k = 0; k < 3; ++k) e[k] = varT<T>(pp[k], 6 + k, tl);
         Rv = rot_euler(e);
     }
     o.pose = Rv;
     o.pose_view = Rv;
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o.M[i][j] = i == j ? 1.f : 0.f;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o.M[i][j] = i == j ? T(1) : T(0);
     if (M_ALLOC(mode)) {
-        float M[3][3];
+        T M[3][3];
         bool valid;
-        allocentric_M(in.K[0], in.K[1], in.K[2], in.K[3], o.x.v, o.y.v, M, valid);
+        allocentric_M<T>(in.K[0], in.K[1], in.K[2], in.K[3], o.x.v, o.y.v, M, valid);
         if (valid)
             for (int i = 0; i < 3; ++i)
                 for (int j = 0; j < 3; ++j) {
@@ -326,8 +366,8 @@ __device__ __forceinline__ Decoded decode(const float* hrow, int K, const RoiIn&
                     o.M[i][j] = M[i][j];
                 }
     }
-    if (M_CONF(mode)) o.u = clip_min(var(hrow[(5 + nb + Pn) * K + c], 12, tl), 0.01f);     // cube_head.py:163
-    else o.u = cst(0.f);
+    if (M_CONF(mode)) o.u = clip_min(varT<T>(hrow[(5 + nb + Pn) * K + c], 12, tl), 0.01f);     // cube_head.py:163
+    else o.u = cstT<T>(T(0));
     return o;
 }
 
@@ -354,7 +394,7 @@ __global__ void __launch_bounds__(64) cube_loss_fwd_kernel(const float* __restri
         return;
     }
     load_roi(in, f, boxes, img, Ks, v2r, priors, FIXED >= 0 ? 1 : bins, zscales, zstats, mode);
-    const Decoded o = decode(head + (long)f * ldh, K, in, tl, mode);
+    const Decoded o = decode<float>(head + (long)f * ldh, K, in, tl, mode);
     const float* g = gt3d + 9 * gt_row[f];
     const float* gp = gtpose + 9 * gt_row[f];
     const float fx = in.K[0], fy = in.K[1], sx = in.K[2], sy = in.K[3];
@@ -526,18 +566,23 @@ __global__ void __launch_bounds__(64) cube_decode_kernel(const float* __restrict
     in.cls = cls[f];
     const int im = img[f];
     load_roi(in, f, boxes, img, Ks, v2r, priors, FIXED >= 0 ? 1 : bins, zscales, zstats, mode);
-    const Decoded o = decode(head + (long)f * ldh, K, in, -1, mode);
-    const float X = o.z.v * (o.x.v - in.K[2]) / in.K[0], Y = o.z.v * (o.y.v - in.K[3]) / in.K[1];
+    // values only, in double: the head row, box, intrinsics and priors are the fp32 quantities the network produced; every
+    // operation from there to the stored float is done once in fp64 (cube_head.py:176, math_util.py:651-705, :171-191)
+    const DecodedT<double> o = decode<double>(head + (long)f * ldh, K, in, -1, mode);
+    const double X = o.z.v * (o.x.v - (double)in.K[2]) / (double)in.K[0], Y = o.z.v * (o.y.v - (double)in.K[3]) / (double)in.K[1];
     float* c3 = cube3d + 9 * f;
-    c3[0] = X; c3[1] = Y; c3[2] = o.z.v; c3[3] = o.dims[0].v; c3[4] = o.dims[1].v; c3[5] = o.dims[2].v;
-    c3[6] = o.x.v * ratio[im]; c3[7] = o.y.v * ratio[im];
+    c3[0] = (float)X; c3[1] = (float)Y; c3[2] = (float)o.z.v;
+    c3[3] = (float)o.dims[0].v; c3[4] = (float)o.dims[1].v; c3[5] = (float)o.dims[2].v;
+    c3[6] = (float)(o.x.v * (double)ratio[im]); c3[7] = (float)(o.y.v * (double)ratio[im]);
     // without USE_CONFIDENCE the reference's cube_3D has 8 columns and its score merge reads `cube_3D_i[:, -1]`, i.e. the
     // scaled v coordinate (roi_heads.py:781-803); the 9th column carries exactly that so the host code stays mode-free
-    c3[8] = M_CONF(mode) ? expf(-o.u.v) : c3[7];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) pose[9 * f + 3 * i + j] = o.pose.m[i][j].v;
-    V3 cv[8];
-    corners(cst(X), cst(Y), cst(o.z.v), o.dims[0], o.dims[1], o.dims[2], o.pose, cv);
-    for (int i = 0; i < 8; ++i) { verts[24 * f + 3 * i] = cv[i].x.v; verts[24 * f + 3 * i + 1] = cv[i].y.v; verts[24 * f + 3 * i + 2] = cv[i].z.v; }
+    c3[8] = M_CONF(mode) ? (float)exp(-o.u.v) : c3[7];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) pose[9 * f + 3 * i + j] = (float)o.pose.m[i][j].v;
+    Vec3<double> cv[8];
+    corners<double>(cstT<double>(X), cstT<double>(Y), cstT<double>(o.z.v), o.dims[0], o.dims[1], o.dims[2], o.pose, cv);
+    for (int i = 0; i < 8; ++i) {
+        verts[24 * f + 3 * i] = (float)cv[i].x.v; verts[24 * f + 3 * i + 1] = (float)cv[i].y.v; verts[24 * f + 3 * i + 2] = (float)cv[i].z.v;
+    }
 }
 
 // plain cuboid corners: util.get_cuboid_verts_faces(box3d (n,6), R (n,3,3)) -> (n,8,3)

@@ -172,6 +172,9 @@ class _FlatOptimizer(torch.optim.Optimizer):
         HF.side_join()            # weight-gradient stream (normally already joined by the end-of-backward callback)
         self.flat_grad.zero_()
         self._exchanged = False
+        # the bucket is empty again: a 1/world left behind by an exchange whose step() never came (the dropped iteration of
+        # tools/train_net.py:245-247) must not scale the NEXT iteration's, separately averaged, gradients
+        self._grad_scale = 1.0
 
     def _finish_replay_exchange(self):
         """pending all-reduce handles of a replayed step -> waited for, 1/world deferred into the update"""
@@ -187,6 +190,10 @@ class _FlatOptimizer(torch.optim.Optimizer):
         a stray gradient is copied into its bucket slot and re-bound; a missing one (None) means "no gradient this step",
         so its slot is cleared.  Costs one pointer compare per parameter."""
         fixed = 0
+        # after a replayed model(data) the iteration's gradients exist ONLY in the bucket: a `model.zero_grad()` (set_to_none) between
+        # the replay and step() detached the views but must not cost the slot its content (ADVICE r3); only optimizer.zero_grad()
+        # called twice drops a replayed iteration
+        replayed = getattr(self, "_replay_state", None) is not None
         for g in self.param_groups:
             for p in g["params"]:
                 off, n = self._slot[id(p)]
@@ -195,7 +202,8 @@ class _FlatOptimizer(torch.optim.Optimizer):
                     continue
                 gv = self._view_like(want, p)
                 if p.grad is None:
-                    gv.zero_()
+                    if not replayed:
+                        gv.zero_()
                 else:
                     gv.copy_(p.grad)
                 p.grad = gv
@@ -221,6 +229,8 @@ class _FlatOptimizer(torch.optim.Optimizer):
         are final once the heads have back-propagated (cubercnn/solver/graphed.py runs the backbone's backward after
         this call), so RCCL moves ~61 % of the 191.6 MB while the backbone's dgrad/wgrad kernels run."""
         import torch.distributed as dist
+        if getattr(self, "_exchange_muted", False):        # warm-up passes of a staged-graph capture (graphed.py): rank-local
+            return []
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
             return []
         self._exchanged = True

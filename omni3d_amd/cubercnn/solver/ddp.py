@@ -61,6 +61,12 @@ def broadcast_replica(model, optimizer):
     if world() < 2:
         return
     dist.broadcast(optimizer.flat_param, src=0)
+    # parameters the optimizer does not hold (frozen before build_optimizer: requires_grad False) are in DDP's ignore list too, so
+    # nobody else synchronises them
+    slots = getattr(optimizer, "_slot", {})
+    for n, p in model.named_parameters():
+        if id(p) not in slots and n != ANCHOR and p.numel():
+            dist.broadcast(p.data, src=0)
     for b in model.buffers():
         if b.numel():
             dist.broadcast(b, src=0)

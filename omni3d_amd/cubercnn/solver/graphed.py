@@ -294,11 +294,21 @@ class GraphedPipelined:
         HF.side_mode("inline")
         warm = torch.cuda.Stream()
         warm.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(warm):       # warm-up off the capture: allocator pools, lazily built constants
-            for _ in range(warmup):             # the same collective sequence as a real step (early, late), waited for
-                _, _, pending = self._eager()   # (results dropped here: nothing of a warm-up step may die inside a capture)
-                self.optimizer.all_reduce_finish(pending + self.optimizer.all_reduce_begin("late", self.group), self.group)
-                del pending
+        # Warm-up off the capture: allocator pools, lazily built constants.  WITHOUT collectives: under the
+        # reference's loader every rank decides for itself when its batch signature has repeated often enough to capture
+        # (autoreplay.py), so a capture's warm-up steps on one rank would pair their all-reduces with another rank's real gradient
+        # exchange -- a hang or silently mixed gradients.  The warm-up gradients are thrown away anyway; nothing in a capture
+        # talks to another rank, and the replayed step's own exchange is the same (early, late) sequence as an eager step's.
+        muted = getattr(self.optimizer, "_exchange_muted", False)
+        self.optimizer._exchange_muted = True
+        try:
+            with torch.cuda.stream(warm):
+                for _ in range(warmup):
+                    _, _, pending = self._eager()   # (results dropped here: nothing of a warm-up step may die inside a capture)
+                    assert not pending
+                    del pending
+        finally:
+            self.optimizer._exchange_muted = muted
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
         HF.side_mode("collect")

@@ -169,7 +169,9 @@ def _run_product(dev, name):
     for i, ev in enumerate(g["eval"]):
         r = slice(i * P, (i + 1) * P)
         for got, key, tol in ((c3[r, :3], "pred_center_cam", 1e-4), (c3[r, 3:6], "pred_dimensions", 1e-4), (c3[r, 6:8], "pred_center_2D", 1e-4),
-                              (pose[r], "pred_pose", 1e-5), (verts[r], "pred_bbox3D", 1e-4), ((0.64 * c3[r, 8]) ** 0.5, "scores", 1e-5)):
+                              # pose: the fixture is the reference's fp32 evaluation, itself ~1e-5 from the exact rotation; the decode
+                              # kernel evaluates the same fp32 head outputs in float64 since round 4
+                              (pose[r], "pred_pose", 3e-5), (verts[r], "pred_bbox3D", 1e-4), ((0.64 * c3[r, 8]) ** 0.5, "scores", 1e-5)):
             want = ev[key]
             assert (got - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), (key, (got - want).abs().max().item())
 
