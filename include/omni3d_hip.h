@@ -83,6 +83,29 @@ int omni_conv2d_dgrad_algo(const float* dy, const float* w, float* dx, int N, in
 int omni_conv2d_wgrad_algo(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R,
                            int S, int stride, int pad, int ldx, int lddy, int accumulate, int tile, void* stream);
 
+/* Deterministic forms (round 4; csrc/split_reduce.h).  The reference's PyTorch-CPU path gives bit-identical results from run to
+ * run; a split reduction that meets in the output through fp32 atomics does not (the order of the adds follows the order in which
+ * workgroups finish).  These entry points are the three operations above with the reduction splits meeting in a caller-provided
+ * workspace instead: every split stores its partial tile to `ws` (ws_floats floats), arrives at one of `ctr`'s n_ctr unsigned
+ * counters (ZERO on entry, zero again on exit), and the tile's last-arriving workgroup adds the partial tiles in split order and
+ * runs the normal epilogue -- bias / ReLU (fwd), overwrite or add-to-carry (dgrad, accumulate != 0), overwrite or add to the
+ * gradient bucket (wgrad, accumulate != 0: plain read-modify-write, each element has one owner per launch).  No zero-fill, no
+ * follow-up ReLU pass, and omni_conv2d_fwd_det emits BatchNorm statistics (stats, see omni_conv2d_fwd_stats) from split launches too.
+ * plan != NULL: nothing is launched; plan[0..3] = {tile, reduction splits, counters needed (0 = not split), workspace floats
+ * needed} for exactly the launch the other arguments describe, so the caller sizes `ws` / `ctr` with the launcher's own heuristics
+ * (pass plan[0] / plan[1] back as tile / splits).  Replaces the same torch.nn.Conv2d / nn.Linear forward and backward calls as
+ * omni_conv2d_fwd / dgrad / wgrad (dla.py:43-51, cube_head.py:70,108-163). */
+int omni_conv2d_fwd_det(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
+                        int R, int S, int stride, int pad, int ldx, int ldo, int relu, int tile, int splits, float* stats,
+                        int stats_rows, int* nblk_out, float* ws, long long ws_floats, int* ctr, int n_ctr, long long* plan,
+                        void* stream);
+int omni_conv2d_dgrad_det(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S,
+                          int stride, int pad, int lddy, int lddx, int accumulate, int tile, int splits, float* ws,
+                          long long ws_floats, int* ctr, int n_ctr, long long* plan, void* stream);
+int omni_conv2d_wgrad_det(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                          int stride, int pad, int ldx, int lddy, int accumulate, int tile, float* ws, long long ws_floats,
+                          int* ctr, int n_ctr, long long* plan, void* stream);
+
 /* ------------------------------------------------------- BatchNorm / pooling / FPN (NHWC) */
 
 /* nn.BatchNorm2d in training mode (+ fused ReLU and residual add): cubercnn/modeling/backbone/
@@ -306,6 +329,16 @@ int omni_roi_align_bwd(const void* const* dlevel_ptrs, const int* level_hw, cons
 int omni_roi_align_bwd2(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
                         const float* rois, const int* batch_idx, const int* levels, int R, int P, int C,
                         const float* dout, const float* dout2, int per_image, int first, void* stream);
+/* Deterministic form (round 4; P == 7, R <= 4096, B = images): the OUTPUT owns the sum -- one wave per 8 x 8 pixel tile of a
+ * (level, image) and 64 channels adds the contributions of the ROIs that touch the tile in ascending ROI index and writes every
+ * element of dlevel_ptrs[l] exactly once (OVERWRITES: no zero-fill by the caller), no atomics: two runs are bit-identical.  A tile
+ * with a long ROI list is shared by up to 8 workgroups taking contiguous chunks of the list; their partial tiles meet in `ws`
+ * (ctr: zeroed arrival counters, left zeroed) and are added in chunk order.  C <= 256.  plan != NULL: plan[2] / plan[3] = counters /
+ * workspace floats needed, nothing is launched.  Same call site and gradient arguments as omni_roi_align_bwd2. */
+int omni_roi_align_bwd_det(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev, int B,
+                           const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, const float* dout,
+                           const float* dout2, int per_image, int first, float* ws, long long ws_floats, int* ctr, int n_ctr,
+                           long long* plan, void* stream);
 
 /* ------------------------------------------------------------------- box-head / cube losses */
 
@@ -387,6 +420,15 @@ int omni_bn_fwd_partials(const float* x, const float* partial, int nblk, const f
 int omni_gemm_engine(const float* A, const float* B, float* C, const float* bias, int form, int batch, int M, int N, int K,
                      int lda, int ldb, int ldc, long long stride_a, long long stride_b, long long stride_c, int splits,
                      int relu, int accumulate, int tile, int workgroups, void* stream);
+/* Deterministic form (round 4, csrc/split_reduce.h; same call sites): the parts of a cut tile -- splits > 1, or the left-over tiles
+ * of the balanced split (splits == -1) -- meet in `ws` (ws_floats floats) and are summed in part order by the tile's last-arriving
+ * workgroup (ctr: n_ctr zeroed unsigned counters, left zeroed), which applies bias / ReLU and overwrites C or, accumulate != 0,
+ * adds to it with a plain read-modify-write; the caller zeroes nothing.  plan != NULL: plan[0..3] = {0, parts per cut tile,
+ * counters needed, workspace floats needed}, nothing is launched. */
+int omni_gemm_engine_det(const float* A, const float* B, float* C, const float* bias, int form, int batch, int M, int N, int K,
+                         int lda, int ldb, int ldc, long long stride_a, long long stride_b, long long stride_c, int splits,
+                         int relu, int accumulate, int tile, int workgroups, float* ws, long long ws_floats, int* ctr, int n_ctr,
+                         long long* plan, void* stream);
 
 /* dst (cols, rows) = src (rows, cols)^T, contiguous row-major fp32.  Brings the fc1-class weights (K_out x C_in) into the
  * (C_in x K_out) layout the data gradient of torch.nn.Linear (FastRCNNConvFCHead fc1, cube_head.py:70) multiplies in the
@@ -448,7 +490,8 @@ int omni_guard_post(float* vec, int n, int world, float stabilize, float half_pe
 int omni_nonfinite_any(const float* grad, long long n, float* flag, void* stream);
 
 /* backward of the ReLU fused into conv / linear epilogues, and the bias gradient (per-channel sum
- * of dy over P pixels; ws 2C*258 doubles scratch).  autograd of the nn.Conv2d / nn.Linear call sites. */
+ * of dy over P pixels; ws 2C*258 doubles scratch).  autograd of the nn.Conv2d / nn.Linear call sites.  accumulate: 0 = overwrite | 1 = add (small tensors: fp32 atomics) | 3 = add
+ * deterministically (partial rows + fixed-order finalize, round 4). */
 int omni_relu_bwd(const float* dy, const float* y, float* dz, long long n, void* stream);
 int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, int accumulate, void* stream);
 
@@ -496,6 +539,9 @@ int omni_gemm_batched_wgrad(const float* x, const float* dy, float* dw, int batc
  * gradient of torch.nn.Conv2d's backward, dla.py:43-51). */
 int omni_gemm_batched_wgrad_algo(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, int algo,
                                  void* stream);
+/* deterministic form (see omni_conv2d_fwd_det): the row splits of the Winograd-domain weight gradient meet in `ws` in split order */
+int omni_gemm_batched_wgrad_det(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, int algo, float* ws,
+                                long long ws_floats, int* ctr, int n_ctr, long long* plan, void* stream);
 
 /* Direct convolution for the full-resolution, few-channel DLA-34 stem layers (cubercnn/modeling/backbone/dla.py:241-247):
  * out (N,H,W,16) = conv(x (N,H,W,C), w (16,R,R,C)), stride 1, padding R/2; (C, R) = (4, 7) [base_layer, image padded
@@ -505,6 +551,10 @@ int omni_stem_conv_fwd(const float* x, const float* w, float* out, int N, int H,
 /* Its weight gradient: dw (16,R,R,C) = (accumulate == 0) or += sum over pixels of dy (N,H,W,16) (x) x (N,H,W,C). */
 int omni_stem_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
                          int accumulate, void* stream);
+/* deterministic form (round 4): per-wave partial filter gradients in `ws` (plan != NULL: plan[3] = floats needed, nothing launched),
+ * added in a fixed order by a second launch; same call site as omni_stem_conv_wgrad */
+int omni_stem_conv_wgrad_det(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
+                             int accumulate, float* ws, long long ws_floats, long long* plan, void* stream);
 
 /* Greedy detection <-> ground-truth matching of Omni3Deval.evaluateImg (cubercnn/evaluation/omni3d_evaluation.py:1433-1551,
  * 3D mode) for all (image, category) groups x A depth ranges x T IoU thresholds.  ious: ragged (D_g, G_g) matrices at

@@ -728,13 +728,15 @@ int omni_relu_bwd(const float* dy, const float* y, float* dz, long long n, void*
 }
 
 // db[c] = sum over the P pixels of dy[p, c] (bias gradient of a conv / linear).  ws: 2*C doubles.
+// accumulate: 0 = overwrite db | 1 = add to db (small tensors: one launch with <= 64 fp32 atomics per channel) | 3 = add to db
+// deterministically (always partial rows + a fixed-order finalize)
 int omni_bias_grad(const float* dy, int P, int C, float* db, double* ws, int accumulate, void* stream) {
     if (P <= 0 || C <= 0 || (C & 3) || C > 4096) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = red_grid(P, C);
     float* partial = reinterpret_cast<float*>(ws + 2 * C);
 #ifndef OMNI_HIPEMU
-    if (accumulate && nblk <= 64) {     // small tensors: db already holds the running gradient, add this call's column sums
+    if (accumulate == 1 && nblk <= 64) {     // small tensors: db already holds the running gradient, add this call's column sums
         hipLaunchKernelGGL(bias_grad_atomic_kernel, dim3(nblk), dim3(256), 0, st, dy, P, C, db);   // with <= 64 float atomics per channel
         return omni_launch_status();
     }

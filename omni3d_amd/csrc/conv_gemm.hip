@@ -25,6 +25,7 @@
 //   * weight gradient: reduction over output pixels split across grid.z, partial tiles are
 //     accumulated with fp32 atomics into a zero-initialised dW.
 #include <device_rt.h>
+#include "split_reduce.h"
 
 namespace {
 
@@ -42,6 +43,11 @@ struct ConvP {
     int splits;       // fwd/dgrad: reduction split over gridDim.y (atomic epilogue into a zeroed output)
     long xb, wb, ob;  // fwd/wgrad: element strides of x / w / out between the gridDim.z problems of a batched GEMM
     float* stats;     // fwd, nullable: per-m-tile column sums [tiles_m][2][K] of the output (BatchNorm statistics, see omni_conv2d_fwd_stats)
+    // deterministic mode (round 4, split_reduce.h): ctr != nullptr asks for run-to-run identical sums -- a split reduction meets in
+    // the workspace `ws` and the last-arriving workgroup adds the partial tiles in split order; accumulating epilogues use plain
+    // read-modify-write (every output element has exactly one owner per launch) instead of atomics
+    float* ws;
+    unsigned* ctr;
 };
 
 
@@ -233,8 +239,10 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
 
     f32x16 acc[WM][WN];
     zero_acc<WM, WN>(acc);
-    if (nk <= 0) return;
-    if constexpr (PF == 1) {
+    const bool det = gridDim.y > 1 && p.ctr != nullptr;
+    if (nk <= 0 && !det) return;          // (a deterministic split with no slabs still has to arrive, with zeros)
+    if (nk <= 0) {
+    } else if constexpr (PF == 1) {
         load_slab(0);
         store_slab(0, 0);
         __syncthreads();
@@ -272,7 +280,11 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
         }
     }
     const int l31 = lane & 31, h = lane >> 5;
-    const bool split = gridDim.y > 1;
+    if (det) {
+        __syncthreads();                  // (the slab loop's last LDS reads are done before split_reduce reuses a shared word)
+        if (!omni_split_reduce<WM, WN>(p.ws, p.ctr, (long)blockIdx.z * gridDim.x + blockIdx.x, (int)blockIdx.y, (int)gridDim.y, acc)) return;
+    }
+    const bool split = gridDim.y > 1 && !det;      // atomic epilogue; a deterministic launch continues as if it had not been split
     if (p.stats != nullptr && !split) {
         // BatchNorm batch statistics from the accumulators (the conv -> BN pairs of the bottom-up, dla.py:46-66): per-channel
         // sum and sum of squares over this tile's rows; [tile_m][2][K] partials, summed over tiles in fp64 by bn_finalize.
@@ -312,7 +324,7 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int n = n0 + (wn * WN + j) * 32 + l31;
-            const float bv = (p.bias != nullptr && n < p.K && blockIdx.y == 0) ? p.bias[n] : 0.f;
+            const float bv = (p.bias != nullptr && n < p.K && (blockIdx.y == 0 || det)) ? p.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -479,11 +491,13 @@ __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
 
     f32x16 acc[WM][WN];
     zero_acc<WM, WN>(acc);
-    const bool split = gridDim.y > 1;
+    const bool det = gridDim.y > 1 && p.ctr != nullptr;
+    const bool split = gridDim.y > 1 && !det;
     if (nk <= 0) {
         // no taps for this split / class (e.g. the odd pixels of a 1x1/s2 conv): the gradient is zero there.
-        // A split launch pre-zeroes dx and an accumulating one adds nothing; otherwise fall through and store zeros.
-        if (split || p.accumulate) return;
+        // A split launch pre-zeroes dx and an accumulating one adds nothing; otherwise fall through and store zeros
+        // (a deterministic split arrives with its zeros: the last arrival writes the tile).
+        if (split || (p.accumulate && !det)) return;
     } else {
         load_slab();
         store_slab(0);
@@ -498,6 +512,10 @@ __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
         }
     }
     const int l31 = lane & 31, h = lane >> 5;
+    if (det) {
+        __syncthreads();
+        if (!omni_split_reduce<WM, WN>(p.ws, p.ctr, (long)blockIdx.z * gridDim.x + blockIdx.x, (int)blockIdx.y, (int)gridDim.y, acc)) return;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -610,10 +628,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
     f32x16 acc[WM][WN];
     zero_acc<WM, WN>(acc);
     const int nk = (p_end - p_begin + BK - 1) / BK;
-    if (nk <= 0) return;
-    load_slab();
-    store_slab(0);
-    __syncthreads();
+    const bool det = p.ctr != nullptr && gridDim.y > 1;
+    if (nk <= 0 && !det) return;
+    if (nk > 0) {
+        load_slab();
+        store_slab(0);
+        __syncthreads();
+    }
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_slab();
@@ -623,6 +644,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
         __syncthreads();
     }
     const int l31 = lane & 31, h = lane >> 5;
+    if (det && !omni_split_reduce<WM, WN>(p.ws, p.ctr, (long)blockIdx.z * gridDim.x + blockIdx.x, (int)blockIdx.y, (int)gridDim.y, acc))
+        return;
     const bool single = gridDim.y == 1 && !p.accumulate;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -634,7 +657,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
                 const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m < p.K && n < Nn) {
                     float* o = p.out + (long)m * Nn + n;
-                    if (single) *o = acc[i][j][r];
+                    // (an ordered split arrives here with the complete sum: ONE add per element and launch, whose result does
+                    // not depend on any order -- the atomic is only the cheapest way to issue a read-modify-write)
+                    if (single || (det && !p.accumulate)) *o = acc[i][j][r];
                     else atomicAdd(o, acc[i][j][r]);
                 }
             }
@@ -770,6 +795,8 @@ struct GemmTP {
     float* out;
     int M, N, K;
     long ab, bb, ob;       // element strides between the gridDim.z problems
+    float* ws;             // deterministic split reduction (split_reduce.h); ctr == nullptr: fp32 atomics
+    unsigned* ctr;
 };
 
 typedef unsigned omni_u4 __attribute__((ext_vector_type(4)));
@@ -928,7 +955,9 @@ __global__ void __launch_bounds__(256) gemm_tn_pf_kernel(GemmTP p, int rows_per_
     }
     const int l31 = lane & 31, h = lane >> 5;
     const int n = n0 + wn * 32 + l31;
-    const bool single = splits == 1;
+    const bool det = splits > 1 && p.ctr != nullptr;
+    if (det && !omni_split_reduce<1, 1>(p.ws, p.ctr, (long)prob * tiles + tix, split, splits, acc)) return;
+    const bool single = splits == 1 || det;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -964,12 +993,35 @@ extern "C" {
 constexpr bool WGRAD_XCD_ORDER_FC = true;     // fc-class weight gradients (one split): XCD-contiguous tile order (fc1: 615 -> 562 us, profiles/r03_fc_wgrad_xcd_order.log)
 constexpr bool FWD64_DEEP_PREFETCH = true;    // batched GEMMs on 64x64 tiles: gemm_nt_pf_kernel (profiles/r03_sweep_batched_gemm.log: 17-27 % faster on every small-map shape)
 
+// Deterministic-mode plumbing shared by the launchers below (split_reduce.h).  `ctr` != nullptr asks for run-to-run identical
+// results; `plan` != nullptr makes the launcher report what it WOULD launch -- plan[0] = tile, [1] = reduction splits, [2] = arrival
+// counters (unsigned, zeroed once by the caller; 0 when the launch is not split), [3] = workspace floats -- and return without
+// launching, so the caller can size the workspace with the launcher's own decision code.
+struct DetArgs {
+    float* ws;
+    long long ws_floats;
+    unsigned* ctr;
+    int n_ctr;
+    long long* plan;
+};
+static inline bool det_fits(const DetArgs& d, long tiles, long splits, long tile_elems) {
+    return d.ctr != nullptr && d.ws != nullptr && d.n_ctr >= omni_split_counters(tiles, splits) &&
+           d.ws_floats >= omni_split_ws_floats(tiles, splits, tile_elems);
+}
+static inline void det_plan(const DetArgs& d, long tile, long tiles, long splits, long tile_elems) {
+    d.plan[0] = tile; d.plan[1] = splits;
+    d.plan[2] = splits > 1 ? omni_split_counters(tiles, splits) : 0;
+    d.plan[3] = splits > 1 ? omni_split_ws_floats(tiles, splits, tile_elems) : 0;
+}
+
 static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
                            int R, int S, int stride, int pad, int ldx, int ldo, int relu, int tile, int splits_req, float* stats,
-                           int stats_rows, int* nblk_out, void* stream) {
+                           int stats_rows, int* nblk_out, void* stream, const DetArgs& det = DetArgs{nullptr, 0, nullptr, 0, nullptr}) {
     ConvP p{x, w, bias, out, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
             R, S, stride, pad, ldx, ldo, 0, relu, 0, 1};
     p.stats = nullptr;
+    p.ws = nullptr;
+    p.ctr = nullptr;
     if (nblk_out) *nblk_out = 0;
     if (bad_geom(p) || (ldx & 3) || ldx < C || ldo < K || tile < 0 || tile > 5 || splits_req < 0) return OMNI_ERR_ARG;
     if (splits_req > 1 && ldo != K) return OMNI_ERR_ARG;
@@ -1003,9 +1055,21 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
     }
     if (splits_req >= 1) splits = splits_req;
     if (splits > nslab) splits = nslab;
-    if (splits > 1) omni_memset_async(out, 0, sizeof(float) * (size_t)M * K, st);
-    if (stats != nullptr && splits == 1 && bias == nullptr && !relu) {      // statistics only from complete, raw outputs
-        const int bm = tile == 1 ? 128 : (tile == 2 || tile == 5) ? 64 : tile == 3 ? 128 : 256;
+    const int bm = tile == 1 ? 128 : (tile == 2 || tile == 5) ? 64 : tile == 3 ? 128 : 256;
+    const int bn = tile == 1 ? 128 : (tile == 2 || tile == 5) ? 64 : tile == 3 ? 64 : 32;
+    const long tiles = ((M + bm - 1) / bm) * ((K + bn - 1) / bn);
+    if (det.plan != nullptr) {
+        det_plan(det, tile, tiles, splits, (long)bm * bn);
+        return OMNI_OK;
+    }
+    const bool ordered = det.ctr != nullptr && splits > 1;      // split partials meet in the workspace, summed in split order
+    if (ordered) {
+        if (!det_fits(det, tiles, splits, (long)bm * bn)) return OMNI_ERR_ARG;
+        p.ws = det.ws;
+        p.ctr = det.ctr;
+    }
+    if (splits > 1 && !ordered) omni_memset_async(out, 0, sizeof(float) * (size_t)M * K, st);
+    if (stats != nullptr && (splits == 1 || ordered) && bias == nullptr && !relu) {      // statistics only from complete, raw outputs
         const long rows = (M + bm - 1) / bm;
         if (rows <= stats_rows) {
             p.stats = stats;
@@ -1021,7 +1085,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
     else if (tile == 3) OMNI_FWD(128, 64, 2, 2, 32, 1);
     else OMNI_FWD(256, 32, 4, 1, 16, 1);   // tiny channel counts (stem, level0/1, RPN 16-wide heads): slab depth 16 measured faster
 #undef OMNI_FWD
-    if (splits > 1 && relu) {
+    if (splits > 1 && relu && !ordered) {     // (an ordered split applies the ReLU in its last-arriving workgroup)
         const long n4 = M * K / 4;
         long g = (n4 + 255) / 256;
         if (g > 2048) g = 2048;
@@ -1043,6 +1107,17 @@ int omni_conv2d_fwd_stats(const float* x, const float* w, float* out, int N, int
     return conv2d_fwd_impl(x, w, nullptr, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, 0, 0, 0, stats, stats_rows, nblk_out, stream);
 }
 
+// Deterministic form of omni_conv2d_fwd_algo / omni_conv2d_fwd_stats (round 4): a split reduction meets in `ws` (ws_floats floats)
+// and is summed in split order by the tile's last-arriving workgroup (ctr: n_ctr zeroed unsigned counters, left zero), bias and ReLU
+// applied there; BatchNorm statistics (stats != nullptr) then also come from split launches.  plan != nullptr: report {tile, splits,
+// counters, workspace floats} of the launch the arguments describe and return without launching.
+int omni_conv2d_fwd_det(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K, int R, int S,
+                        int stride, int pad, int ldx, int ldo, int relu, int tile, int splits_req, float* stats, int stats_rows,
+                        int* nblk_out, float* ws, long long ws_floats, int* ctr, int n_ctr, long long* plan, void* stream) {
+    return conv2d_fwd_impl(x, w, bias, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, relu, tile, splits_req, stats, stats_rows, nblk_out,
+                           stream, DetArgs{ws, ws_floats, (unsigned*)ctr, n_ctr, plan});
+}
+
 // Tile choice: 128x128 when that already fills the 256 CUs, otherwise 64x64 (4x the workgroups); when even
 // that leaves CUs idle and the reduction is deep (DLA level 4/5, FC heads with few rows) the reduction is
 // split over gridDim.y with an atomic epilogue into a zeroed output.  Slab depth 32 (one barrier per 64
@@ -1055,10 +1130,14 @@ int omni_conv2d_fwd(const float* x, const float* w, const float* bias, float* ou
 // tile: 0 auto | 1 = 128x128 | 2 = 64x64 | 3 = 128x64 | 4 = 256x32; splits: 0 auto | >= 1 explicit (> 1: atomic epilogue; into
 // a dx zeroed here when accumulate == 0, which needs lddx == C, or on top of dx's content when accumulate != 0 -- a gradient
 // fan-in target, see functional.fanout: neither a zero-fill nor a separate add kernel)
-int omni_conv2d_dgrad_algo(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S,
-                           int stride, int pad, int lddy, int lddx, int accumulate, int tile, int splits_req, void* stream) {
+static int conv2d_dgrad_impl(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S,
+                             int stride, int pad, int lddy, int lddx, int accumulate, int tile, int splits_req, void* stream,
+                             const DetArgs& det) {
     ConvP p{dy, w, nullptr, dx, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
             R, S, stride, pad, lddy, lddx, 0, 0, accumulate, 1};
+    p.stats = nullptr;
+    p.ws = nullptr;
+    p.ctr = nullptr;
     if (bad_geom(p) || (K & 3) || (lddy & 3) || lddy < K || lddx < C || tile < 0 || tile > 4 || splits_req < 0) return OMNI_ERR_ARG;
     if (splits_req > 1 && lddx != C && !accumulate) return OMNI_ERR_ARG;
     if ((long)N * H * W == 0) return OMNI_OK;
@@ -1088,7 +1167,19 @@ int omni_conv2d_dgrad_algo(const float* dy, const float* w, float* dx, int N, in
     }
     if (splits_req >= 1) splits = splits_req;
     if (splits > nslab) splits = nslab;
-    if (splits > 1 && !accumulate) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, st);
+    const int bm = tile == 1 ? 128 : tile == 2 ? 64 : tile == 3 ? 128 : 256, bn = tile == 1 ? 128 : tile == 2 ? 64 : tile == 3 ? 64 : 32;
+    const long tiles = ((M + bm - 1) / bm) * ((C + bn - 1) / bn) * ncls;      // counter index: blockIdx.z * gridDim.x + blockIdx.x
+    if (det.plan != nullptr) {
+        det_plan(det, tile, tiles, splits, (long)bm * bn);
+        return OMNI_OK;
+    }
+    const bool ordered = det.ctr != nullptr && splits > 1;
+    if (ordered) {
+        if (!det_fits(det, tiles, splits, (long)bm * bn)) return OMNI_ERR_ARG;
+        p.ws = det.ws;
+        p.ctr = det.ctr;
+    }
+    if (splits > 1 && !accumulate && !ordered) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, st);
 #define OMNI_DGRAD(BM_, BN_, WM_, WN_, BK_)                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<BM_, BN_, WM_, WN_, BK_>),                                        \
                        dim3((unsigned)(((M + BM_ - 1) / BM_) * ((C + BN_ - 1) / BN_)), (unsigned)splits, ncls), dim3(256), 0, st, p)
@@ -1098,6 +1189,21 @@ int omni_conv2d_dgrad_algo(const float* dy, const float* w, float* dx, int N, in
     else OMNI_DGRAD(256, 32, 4, 1, 16);
 #undef OMNI_DGRAD
     return omni_launch_status();
+}
+
+int omni_conv2d_dgrad_algo(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S,
+                           int stride, int pad, int lddy, int lddx, int accumulate, int tile, int splits_req, void* stream) {
+    return conv2d_dgrad_impl(dy, w, dx, N, H, W, C, K, R, S, stride, pad, lddy, lddx, accumulate, tile, splits_req, stream,
+                             DetArgs{nullptr, 0, nullptr, 0, nullptr});
+}
+
+// deterministic form (see omni_conv2d_fwd_det): an ordered split writes dx (or dx + the carry when accumulate != 0) once, from the
+// last-arriving workgroup of each tile; no zero-fill, no atomics
+int omni_conv2d_dgrad_det(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                          int lddy, int lddx, int accumulate, int tile, int splits_req, float* ws, long long ws_floats, int* ctr, int n_ctr,
+                          long long* plan, void* stream) {
+    return conv2d_dgrad_impl(dy, w, dx, N, H, W, C, K, R, S, stride, pad, lddy, lddx, accumulate, tile, splits_req, stream,
+                             DetArgs{ws, ws_floats, (unsigned*)ctr, n_ctr, plan});
 }
 
 // dx[N,H,W,C] (=|+= when accumulate) = conv_transpose(dy[N,OH,OW,K], w[K,R,S,C]).
@@ -1110,8 +1216,8 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
 // reduction is split); accumulate != 0: the result is atomically ADDED to dw -- this is how weight gradients land
 // directly in the flat gradient bucket without an extra add kernel per parameter.
 // tile: 0 auto | 1 = 128x128 | 2 = 64x64 | 3 = 128x64 | 4 = 32x128 (BM over K, BN over the (r, s, c) extent)
-int omni_conv2d_wgrad_algo(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
-                           int stride, int pad, int ldx, int lddy, int accumulate, int tile, void* stream) {
+static int conv2d_wgrad_impl(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                             int stride, int pad, int ldx, int lddy, int accumulate, int tile, void* stream, const DetArgs& det) {
     // tile + 16: the same tile with the XCD-contiguous workgroup order; tile + 32: with the plain order; 0..4: the launcher decides
     int xcd_order = -1;
     if (tile >= 32) { xcd_order = 0; tile -= 32; }
@@ -1119,9 +1225,13 @@ int omni_conv2d_wgrad_algo(const float* x, const float* dy, float* dw, int N, in
     if (tile < 0 || tile > 4) return OMNI_ERR_ARG;
     ConvP p{x, dy, nullptr, dw, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
             R, S, stride, pad, ldx, 0, lddy, 0, accumulate, 1};
+    p.stats = nullptr;
+    p.ws = nullptr;
+    p.ctr = nullptr;
     if (bad_geom(p) || (K & 3) || (ldx & 3) || (lddy & 3) || ldx < C || lddy < K) return OMNI_ERR_ARG;
     const long P = (long)N * p.OH * p.OW;
     const int Nn = R * S * C;
+    if (P == 0 && det.plan != nullptr) { det.plan[0] = tile; det.plan[1] = 1; det.plan[2] = det.plan[3] = 0; return OMNI_OK; }
     if (P == 0) {
         if (!accumulate) omni_memset_async(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
         return OMNI_OK;
@@ -1146,7 +1256,17 @@ int omni_conv2d_wgrad_algo(const float* x, const float* dy, float* dw, int N, in
     int pps = (int)((P + splits - 1) / splits);
     pps = (pps + WBK - 1) / WBK * WBK;
     splits = (P + pps - 1) / pps;
-    if (splits > 1 && !accumulate) omni_memset_async(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
+    if (det.plan != nullptr) {
+        det_plan(det, tile, tiles, splits, (long)bm * bn);
+        return OMNI_OK;
+    }
+    const bool ordered = det.ctr != nullptr && splits > 1;
+    if (ordered && !det_fits(det, tiles, splits, (long)bm * bn)) return OMNI_ERR_ARG;
+    if (det.ctr != nullptr) {             // deterministic: ordered split sums, plain read-modify-write for accumulate
+        p.ws = det.ws;
+        p.ctr = det.ctr;
+    }
+    if (splits > 1 && !accumulate && !ordered) omni_memset_async(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
     if (xcd_order < 0) xcd_order = (WGRAD_XCD_ORDER_FC && R == 1 && S == 1 && H == 1 && W == 1 && splits == 1) ? 1 : 0;
     p.relu = xcd_order;
 #define OMNI_WGRAD(BM_, BN_, WM_, WN_)                                                                                  \
@@ -1158,6 +1278,20 @@ int omni_conv2d_wgrad_algo(const float* x, const float* dy, float* dw, int N, in
     else OMNI_WGRAD(32, 128, 1, 4);
 #undef OMNI_WGRAD
     return omni_launch_status();
+}
+
+int omni_conv2d_wgrad_algo(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                           int stride, int pad, int ldx, int lddy, int accumulate, int tile, void* stream) {
+    return conv2d_wgrad_impl(x, dy, dw, N, H, W, C, K, R, S, stride, pad, ldx, lddy, accumulate, tile, stream, DetArgs{nullptr, 0, nullptr, 0, nullptr});
+}
+
+// deterministic form: ctr must be non-null even for a launch that is not split (it selects the plain read-modify-write epilogue of an
+// accumulating launch; one counter is enough then)
+int omni_conv2d_wgrad_det(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                          int ldx, int lddy, int accumulate, int tile, float* ws, long long ws_floats, int* ctr, int n_ctr, long long* plan,
+                          void* stream) {
+    return conv2d_wgrad_impl(x, dy, dw, N, H, W, C, K, R, S, stride, pad, ldx, lddy, accumulate, tile, stream,
+                             DetArgs{ws, ws_floats, (unsigned*)ctr, n_ctr, plan});
 }
 
 int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
@@ -1196,7 +1330,7 @@ int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int b
                            (hipStream_t)stream, p);
     else {           // 64x64 tiles, PF slabs of buffer-load prefetch in flight (gemm_nt_pf_kernel)
         if ((C % 64) != 0 || (long)M * C * 4 >= (1L << 31) || (long)K * C * 4 >= (1L << 31)) return OMNI_ERR_ARG;
-        GemmTP g{x, w, out, M, K, C, (long)M * C, (long)K * C, (long)M * K};
+        GemmTP g{x, w, out, M, K, C, (long)M * C, (long)K * C, (long)M * K, nullptr, nullptr};
         const long wgs = (((long)M + 63) / 64) * ((K + 63) / 64) * batch;
         if (wgs > 0x7fffffff) return OMNI_ERR_ARG;
         const dim3 grid((unsigned)wgs);
@@ -1215,10 +1349,12 @@ int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch,
 // with 2-4 slabs of buffer-load prefetch in flight (gemm_tn_pf_kernel)
 constexpr bool WGRAD64_DEEP_PREFETCH = true;    // gemm_tn_pf_kernel (profiles/r03_sweep_batched_gemm.log: 3-66 % faster on every Winograd weight-gradient shape)
 
-int omni_gemm_batched_wgrad_algo(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, int algo, void* stream) {
+static int gemm_batched_wgrad_impl(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, int algo, void* stream,
+                                   const DetArgs& det) {
     if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3) || (K & 3) || algo < 0 || algo > 2) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (M == 0) {
+        if (det.plan != nullptr) { det.plan[0] = algo; det.plan[1] = 1; det.plan[2] = det.plan[3] = 0; return OMNI_OK; }
         omni_memset_async(dw, 0, sizeof(float) * (size_t)batch * K * C, st);
         return OMNI_OK;
     }
@@ -1235,8 +1371,14 @@ int omni_gemm_batched_wgrad_algo(const float* x, const float* dy, float* dw, int
         int rps = (int)(((long)M + splits - 1) / splits);
         rps = (rps + 127) / 128 * 128;                                   // multiple of 32 * PF for PF = 4
         splits = ((long)M + rps - 1) / rps;
-        if (splits > 1) omni_memset_async(dw, 0, sizeof(float) * (size_t)batch * K * C, st);
-        GemmTP g{dy, x, dw, M, K, C, (long)M * K, (long)M * C, (long)K * C};
+        if (det.plan != nullptr) {
+            det_plan(det, algo, (long)tiles * batch, splits, 64 * 64);
+            return OMNI_OK;
+        }
+        const bool ordered = det.ctr != nullptr && splits > 1;
+        if (ordered && !det_fits(det, (long)tiles * batch, splits, 64 * 64)) return OMNI_ERR_ARG;
+        if (splits > 1 && !ordered) omni_memset_async(dw, 0, sizeof(float) * (size_t)batch * K * C, st);
+        GemmTP g{dy, x, dw, M, K, C, (long)M * K, (long)M * C, (long)K * C, ordered ? det.ws : nullptr, ordered ? det.ctr : nullptr};
         const long wgs = (long)tiles * splits * batch;
         if (wgs > 0x7fffffff) return OMNI_ERR_ARG;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_tn_pf_kernel<4>), dim3((unsigned)wgs), dim3(256), 0, st, g, rps, (int)splits);
@@ -1254,7 +1396,20 @@ int omni_gemm_batched_wgrad_algo(const float* x, const float* dy, float* dw, int
     int pps = (int)(((long)M + splits - 1) / splits);
     pps = (pps + WBK - 1) / WBK * WBK;
     splits = ((long)M + pps - 1) / pps;
-    if (splits > 1) omni_memset_async(dw, 0, sizeof(float) * (size_t)batch * K * C, st);
+    p.stats = nullptr;
+    p.ws = nullptr;
+    p.ctr = nullptr;
+    if (det.plan != nullptr) {
+        det_plan(det, algo, (long)tiles * batch, splits, (long)bm * bn);
+        return OMNI_OK;
+    }
+    const bool ordered = det.ctr != nullptr && splits > 1;
+    if (ordered) {
+        if (!det_fits(det, (long)tiles * batch, splits, (long)bm * bn)) return OMNI_ERR_ARG;
+        p.ws = det.ws;
+        p.ctr = det.ctr;
+    }
+    if (splits > 1 && !ordered) omni_memset_async(dw, 0, sizeof(float) * (size_t)batch * K * C, st);
     if (wide)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<128, 128, 2, 2, WBK>), dim3(tiles, (unsigned)splits, (unsigned)batch),
                            dim3(256), 0, st, p, pps);
@@ -1262,6 +1417,15 @@ int omni_gemm_batched_wgrad_algo(const float* x, const float* dy, float* dw, int
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<64, 64, 2, 2, WBK>), dim3(tiles, (unsigned)splits, (unsigned)batch),
                            dim3(256), 0, st, p, pps);
     return omni_launch_status();
+}
+
+int omni_gemm_batched_wgrad_algo(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, int algo, void* stream) {
+    return gemm_batched_wgrad_impl(x, dy, dw, batch, M, C, K, algo, stream, DetArgs{nullptr, 0, nullptr, 0, nullptr});
+}
+
+int omni_gemm_batched_wgrad_det(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, int algo, float* ws,
+                                long long ws_floats, int* ctr, int n_ctr, long long* plan, void* stream) {
+    return gemm_batched_wgrad_impl(x, dy, dw, batch, M, C, K, algo, stream, DetArgs{ws, ws_floats, (unsigned*)ctr, n_ctr, plan});
 }
 
 int omni_gemm_batched_wgrad(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, void* stream) {

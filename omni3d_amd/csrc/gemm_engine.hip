@@ -39,6 +39,9 @@ struct GemmArgs {
     // balanced mode (BAL): every workgroup owns bal_r whole tiles, the remaining tiles (fewer than workgroups) are cut along the
     // reduction into bal_ts parts of bal_sps slabs, one part per workgroup (bal_tail_items of them)
     int bal_r, bal_ts, bal_sps, bal_tail_items;
+    // deterministic mode: ws != nullptr -> the parts of a cut tile are stored to `ws` and summed in part order by
+    // engine_cut_finalize_kernel (bias / ReLU / accumulate applied there)
+    float* ws;
 };
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return mfma_32x32x2(a, b, c); }
@@ -246,6 +249,29 @@ __global__ void __launch_bounds__(256) gemm_engine_kernel(GemmArgs p) {
         decode(c_item, b, tm, tn, k0, nk, lead, cut);
         const int m0 = tm * BM, n0 = tn * BN;
         float* o = p.C + (long)b * p.sc;
+        const bool det = p.ws != nullptr;
+        if (det && cut) {
+            // deterministic mode: the part's accumulators go to its workspace slot (cut tiles numbered from the first of them, parts
+            // in k order; element r * 256 + tid = register r of thread tid) and engine_cut_finalize_kernel, launched behind this
+            // kernel, adds the parts in order and runs the epilogue.  (An in-kernel last-arrival reduction -- what the tile kernels
+            // of conv_gemm.hip do -- is inlined three times into this kernel's ring and doubled its code size: the 15 k instruction
+            // kernel ran 60 % longer on I-cache misses alone.)
+            long slot_tile;
+            int part, parts;
+            if (BAL) { slot_tile = tail_q / p.bal_ts; part = tail_q % p.bal_ts; parts = p.bal_ts; }
+            else { slot_tile = ((long)b * p.tiles_m + tm) * p.tiles_n + tn; part = k0 / sps; parts = p.splits; }
+            float* slot = p.ws + (slot_tile * parts + part) * (long)(BM * BN) + tid;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) {
+                        slot[((i * WN + j) * 16 + rr) * 256] = acc[i][j][rr];
+                        acc[i][j][rr] = 0.f;
+                    }
+            return;
+        }
         const bool atomic = cut || p.accumulate;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -258,8 +284,9 @@ __global__ void __launch_bounds__(256) gemm_engine_kernel(GemmArgs p) {
                     const int m = m0 + wm * (BM / 2) + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
                     if (m < p.M && n < p.N) {
                         float v = acc[i][j][rr] + bv;
-                        if (atomic) atomicAdd(o + (long)m * p.ldc + n, v);
-                        else o[(long)m * p.ldc + n] = p.relu ? fmaxf(v, 0.f) : v;
+                        float* q = o + (long)m * p.ldc + n;
+                        if (atomic) atomicAdd(q, v);
+                        else *q = p.relu ? fmaxf(v, 0.f) : v;
                     }
                     acc[i][j][rr] = 0.f;
                 }
@@ -345,8 +372,70 @@ __global__ void __launch_bounds__(256) transpose2d_kernel(const float* __restric
     }
 }
 
+// Deterministic mode, second launch: C tile (=, or += when accumulate) sum over the parts of a cut tile in part order (+ bias)
+// (ReLU).  One workgroup per (cut tile, 8 accumulator registers): thread tid adds `parts` slot values per register, all loads of a
+// register independent.  first_tile: linear index (batch, tile row, tile column) of cut tile 0.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) engine_cut_finalize_kernel(const float* __restrict__ ws, int parts, long first_tile, int tiles_m,
+                                                                  int tiles_n, float* __restrict__ C, const float* __restrict__ bias, int M,
+                                                                  int N, int ldc, long sc, int relu, int accumulate) {
+    constexpr int WN = BN / 64, NACC = BM * BN / 256, CH = NACC / 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const long ct = (long)blockIdx.x / CH;
+    const int r0 = ((int)blockIdx.x % CH) * 8;
+    long r = first_tile + ct;
+    const int tn = (int)(r % tiles_n); r /= tiles_n;
+    const int tm = (int)(r % tiles_m);
+    const long b = r / tiles_m;
+    const float* slot = ws + ct * parts * (long)(BM * BN) + tid;
+    float* o = C + b * sc;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int reg = r0 + u, blk = reg >> 4, rr = reg & 15, i = blk / WN, j = blk % WN;
+        float v = 0.f;
+        for (int q = 0; q < parts; ++q) v += slot[((long)q * NACC + reg) * 256];
+        const int n = tn * BN + wn * (BN / 2) + j * 32 + l31;
+        const int m = tm * BM + wm * (BM / 2) + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+        if (m < M && n < N) {
+            if (bias != nullptr) v += bias[n];
+            float* q = o + (long)m * ldc + n;
+            if (accumulate) *q = *q + v;
+            else *q = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+struct EngineDet {
+    float* ws;
+    long long ws_floats;
+    unsigned* ctr;
+    int n_ctr;
+    long long* plan;        // != nullptr: report {0, parts of a cut tile, counters, workspace floats} and do not launch
+};
+
 template <int LA, int LB, int BM, int BN>
-int launch_engine(GemmArgs p, int workgroups, hipStream_t st) {
+int launch_engine(GemmArgs p, int workgroups, hipStream_t st, const EngineDet& det) {
+    p.ws = nullptr;
+    long fin_tiles = 0, fin_first = 0;
+    int fin_parts = 0;
+    auto bind = [&](long cut_tiles, long parts, long first) -> int {        // deterministic mode: slots for the cut tiles
+        if (det.plan != nullptr) {
+            det.plan[0] = 0; det.plan[1] = parts; det.plan[2] = 0;
+            det.plan[3] = parts > 1 ? cut_tiles * parts * (long)BM * BN : 0;
+            return 1;
+        }
+        if (det.ctr == nullptr || parts <= 1) return 0;
+        if (det.ws == nullptr || det.ws_floats < cut_tiles * parts * (long)BM * BN) return -1;
+        p.ws = det.ws;
+        fin_tiles = cut_tiles; fin_parts = (int)parts; fin_first = first;
+        return 0;
+    };
+    auto finalize = [&]() {
+        if (fin_tiles > 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(engine_cut_finalize_kernel<BM, BN>), dim3((unsigned)(fin_tiles * (BM * BN / 2048))), dim3(256), 0, st,
+                               (const float*)p.ws, fin_parts, fin_first, p.tiles_m, p.tiles_n, p.C, p.bias, p.M, p.N, p.ldc, p.sc, p.relu,
+                               p.accumulate);
+    };
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const int nk_total = (p.K + 31) / 32;
@@ -362,10 +451,13 @@ int launch_engine(GemmArgs p, int workgroups, hipStream_t st) {
             p.bal_sps = (int)((nk_total + ts - 1) / ts);
             p.bal_ts = (nk_total + p.bal_sps - 1) / p.bal_sps;                  // no empty part
             p.bal_tail_items = (int)left * p.bal_ts;
-            if (p.bal_ts > 1 && p.relu) return OMNI_ERR_ARG;                    // cut tiles meet through atomics: no ReLU on them
+            const int rc = bind(left, p.bal_ts, tiles - left);
+            if (rc != 0) return rc > 0 ? OMNI_OK : OMNI_ERR_ARG;
+            if (p.bal_ts > 1 && p.relu && p.ws == nullptr) return OMNI_ERR_ARG;    // cut tiles meet through atomics: no ReLU on them
             p.splits = 1;
             p.items = (int)tiles;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_engine_kernel<LA, LB, BM, BN, true>), dim3((unsigned)W), dim3(256), 0, st, p);
+            finalize();
             return omni_launch_status();
         }
         p.splits = 1;                                                           // already an exact number of rounds
@@ -374,12 +466,17 @@ int launch_engine(GemmArgs p, int workgroups, hipStream_t st) {
     if (p.splits > nk_total) p.splits = nk_total;
     const int sps = (nk_total + p.splits - 1) / p.splits;
     p.splits = (nk_total + sps - 1) / sps;                                      // no empty split
+    {
+        const int rc = bind(tiles, p.splits, 0);
+        if (rc != 0) return rc > 0 ? OMNI_OK : OMNI_ERR_ARG;
+    }
     const long items = tiles * p.splits;
     if (items <= 0 || items > 0x7fffffff) return items == 0 ? OMNI_OK : OMNI_ERR_ARG;
     p.items = (int)items;
     long wg = workgroups > 0 ? workgroups : 256;                                // one workgroup per CU (96 / 144 KB of LDS)
     if (wg > items) wg = items;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_engine_kernel<LA, LB, BM, BN, false>), dim3((unsigned)wg), dim3(256), 0, st, p);
+    finalize();
     return omni_launch_status();
 }
 
@@ -398,24 +495,46 @@ extern "C" {
 // last T % W tiles (tile order: batch, then tile row, then tile column) are cut along the reduction into floor(W / (T % W)) parts
 // that are ADDED into C with atomics: the caller zeroes those tiles (or all of C) unless accumulating; no ReLU when tiles are cut.  All leading dimensions, M (MC operands), N
 // (MC operands) and K offsets in multiples of 4 floats; tensors < 2 GiB.
-int omni_gemm_engine(const float* A, const float* B, float* C, const float* bias, int form, int batch, int M, int N, int K,
-                     int lda, int ldb, int ldc, long long stride_a, long long stride_b, long long stride_c, int splits, int relu,
-                     int accumulate, int tile, int workgroups, void* stream) {
+static int gemm_engine_impl(const float* A, const float* B, float* C, const float* bias, int form, int batch, int M, int N, int K,
+                            int lda, int ldb, int ldc, long long stride_a, long long stride_b, long long stride_c, int splits, int relu,
+                            int accumulate, int tile, int workgroups, void* stream, const EngineDet& det) {
     if (form < 0 || form > 2 || batch <= 0 || M < 0 || N < 0 || K <= 0 || (lda & 3) || (ldb & 3) || tile < 1 || tile > 2 || splits < -1 ||
         workgroups < 0)
         return OMNI_ERR_ARG;
     if (form == 2 && ((M & 3) || (N & 3))) return OMNI_ERR_ARG;
     if (form == 1 && (N & 3)) return OMNI_ERR_ARG;
     if (form != 2 && (K & 3)) return OMNI_ERR_ARG;
-    if (M == 0 || N == 0) return OMNI_OK;
+    if (M == 0 || N == 0) {
+        if (det.plan != nullptr) det.plan[0] = det.plan[1] = det.plan[2] = det.plan[3] = 0;
+        return OMNI_OK;
+    }
     GemmArgs p{A, B, C, bias, batch, M, N, K, lda, ldb, ldc, (long)stride_a, (long)stride_b, (long)stride_c, splits ? splits : 1, relu, accumulate, 0, 0, 0, 0, 1, 0, 0};
     hipStream_t st = (hipStream_t)stream;
 #define OMNI_ENGINE(LA_, LB_)                                                                                         \
-    return tile == 1 ? launch_engine<LA_, LB_, 256, 128>(p, workgroups, st) : launch_engine<LA_, LB_, 128, 128>(p, workgroups, st)
+    return tile == 1 ? launch_engine<LA_, LB_, 256, 128>(p, workgroups, st, det) : launch_engine<LA_, LB_, 128, 128>(p, workgroups, st, det)
     if (form == 0) { OMNI_ENGINE(0, 0); }
     if (form == 1) { OMNI_ENGINE(0, 1); }
     OMNI_ENGINE(1, 1);
 #undef OMNI_ENGINE
+}
+
+int omni_gemm_engine(const float* A, const float* B, float* C, const float* bias, int form, int batch, int M, int N, int K,
+                     int lda, int ldb, int ldc, long long stride_a, long long stride_b, long long stride_c, int splits, int relu,
+                     int accumulate, int tile, int workgroups, void* stream) {
+    return gemm_engine_impl(A, B, C, bias, form, batch, M, N, K, lda, ldb, ldc, stride_a, stride_b, stride_c, splits, relu, accumulate, tile,
+                            workgroups, stream, EngineDet{nullptr, 0, nullptr, 0, nullptr});
+}
+
+// Deterministic form: the parts of a cut tile (splits > 1, or the left-over tiles of the balanced split) are stored to `ws` and a
+// second launch adds them in part order, applies bias / ReLU (now allowed with cut tiles) and overwrites C or -- accumulate != 0 --
+// adds to it.  Nothing has to be zeroed by the caller.  ctr: any non-null pointer (selects the mode; this kernel family needs no
+// counters).  plan != NULL: report {0, parts per cut tile, 0, workspace floats}, no launch.
+int omni_gemm_engine_det(const float* A, const float* B, float* C, const float* bias, int form, int batch, int M, int N, int K,
+                         int lda, int ldb, int ldc, long long stride_a, long long stride_b, long long stride_c, int splits, int relu,
+                         int accumulate, int tile, int workgroups, float* ws, long long ws_floats, int* ctr, int n_ctr, long long* plan,
+                         void* stream) {
+    return gemm_engine_impl(A, B, C, bias, form, batch, M, N, K, lda, ldb, ldc, stride_a, stride_b, stride_c, splits, relu, accumulate, tile,
+                            workgroups, stream, EngineDet{ws, ws_floats, (unsigned*)ctr, n_ctr, plan});
 }
 
 // dst (cols, rows) = transpose of src (rows, cols), both row-major and contiguous.

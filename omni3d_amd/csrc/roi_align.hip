@@ -14,6 +14,7 @@
 // backward scatter is a coalesced run of fp32 atomics.  Output is (R, P, P, C): with KRSC weights the
 // following fc1 is a PxP "valid" convolution whose reduction index is contiguous on both operands.
 #include <device_rt.h>
+#include "split_reduce.h"
 #pragma clang fp contract(off)
 
 namespace {
@@ -270,6 +271,203 @@ __global__ void __launch_bounds__(256) roi_align_bwd_sep_kernel(FeatLevels fl, c
     }
 }
 
+// ---- deterministic backward (round 4): the OUTPUT owns the sum ------------------------------------------------------------
+// The scatter above is bound by ~1.2e8 fp32 atomics per step and the order in which they land -- hence the rounding of every
+// feature-gradient element that several ROIs touch -- changes from run to run.  Here one wave owns an 8 x 8 pixel tile of one
+// (level, image) and 64 channels (lane = channel, 64 accumulators in registers); the workgroup (4 waves = 4 channel groups of
+// the same tile) lists the ROIs of that image and level whose footprint meets the tile, IN ROI ORDER, and every wave adds their
+// contributions one after the other with the same separable arithmetic as the scatter kernel.  Each element of dfeat is written
+// exactly once (no zero-fill in front, no atomics), and the sum over ROIs always runs in ascending ROI index.
+struct GatherTiles {
+    int off[MAXL + 1];        // first tile of each level in the 1-D grid
+    int tx[MAXL], ty[MAXL];   // 8 x 8 tiles per image along x / y
+    int B;
+};
+constexpr int GT_TILE = 8, GT_MAXR = 4096;
+// GT_NSEG > 1: up to GT_NSEG workgroups share a tile with a long ROI list -- every one of them builds the same ordered list, takes a
+// contiguous chunk of it (>= GT_CHUNK ROIs each), and the partial tiles meet in a workspace slot per (tile, segment), summed in
+// segment order by the last arrival (the ordered-split scheme of split_reduce.h).  Measured on MI355X with 8 segments: 532 -> 1110 us
+// per step -- the kernel is bound by VALU issue (140 k (tile, ROI, channel group) jobs of ~1.7 k instructions), not by its tail, and
+// half of the tiles then pay 0.5 MB of slot traffic -- so the shipped configuration is one workgroup per tile.
+constexpr int GT_NSEG = 1, GT_CHUNK = 12;
+
+// per ROI, once: (image << 8 | level, or -1 for an empty sampling grid), footprint rows Y0 | Y1 << 16, columns X0 | X1 << 16 -- what
+// every tile's list building compares against (10 k workgroups each recomputing 2048 footprints was most of the first version's time)
+template <int PP>
+__global__ void roi_footprint_kernel(FeatLevels fl, const float* __restrict__ rois, const int* __restrict__ batch_idx,
+                                     const int* __restrict__ levels, int R, int4* __restrict__ fp, float4* __restrict__ par) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int l = levels[r];
+    const int H = fl.H[l], W = fl.W[l];
+    const float sc = fl.scale[l];
+    const float sw = rois[4 * r + 0] * sc - 0.5f, sh = rois[4 * r + 1] * sc - 0.5f;
+    const float rw = rois[4 * r + 2] * sc - 0.5f - sw, rh = rois[4 * r + 3] * sc - 0.5f - sh;
+    const float bin_h = rh / (float)PP, bin_w = rw / (float)PP;
+    const int gh = (int)ceilf(rh / (float)PP), gw = (int)ceilf(rw / (float)PP);
+    int4 o = make_int4(-1, 0, 0, 0);
+    if (gh > 0 && gw > 0) {
+        const int Y0 = make_tap1(sh + 0.5f * bin_h / (float)gh, H).lo, X0 = make_tap1(sw + 0.5f * bin_w / (float)gw, W).lo;
+        const int Y1 = make_tap1(sh + (float)(PP - 1) * bin_h + ((float)(gh - 1) + 0.5f) * bin_h / (float)gh, H).hi;
+        const int X1 = make_tap1(sw + (float)(PP - 1) * bin_w + ((float)(gw - 1) + 0.5f) * bin_w / (float)gw, W).hi;
+        o = make_int4((batch_idx[r] << 8) | l, Y0 | (Y1 << 16), X0 | (X1 << 16), gh | (gw << 16));
+    }
+    fp[r] = o;
+    par[2 * r] = make_float4(sw, sh, bin_w, bin_h);
+    par[2 * r + 1] = make_float4(gh > 0 ? bin_h / (float)gh : 0.f, gw > 0 ? bin_w / (float)gw : 0.f, (gh > 0 && gw > 0) ? 1.f / (float)(gh * gw) : 0.f, 0.f);
+}
+
+template <int PP>
+__global__ void __launch_bounds__(256) roi_align_bwd_gather_kernel(FeatLevels fl, GatherTiles gt, const float* __restrict__ rois,
+                                                                   const int* __restrict__ batch_idx, const int* __restrict__ levels,
+                                                                   int R, int C, const float* __restrict__ dout,
+                                                                   const float* __restrict__ dout2, int per_image, int first,
+                                                                   float* __restrict__ ws, unsigned* __restrict__ ctr,
+                                                                   const int4* __restrict__ fp, const float4* __restrict__ par) {
+    __shared__ unsigned char s_hit[GT_MAXR];
+    __shared__ unsigned short s_list[GT_MAXR];
+    __shared__ int s_count;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // coarsest level first: its few tiles carry the longest ROI lists and should not be the launch's tail
+    const int tile_id = gt.off[MAXL] - 1 - (int)blockIdx.x / GT_NSEG, seg = (int)blockIdx.x % GT_NSEG;
+    int l = 0;
+    while (l + 1 < fl.nlev && tile_id >= gt.off[l + 1]) ++l;
+    int t = tile_id - gt.off[l];
+    const int tix = t % gt.tx[l]; t /= gt.tx[l];
+    const int tiy = t % gt.ty[l];
+    const int n = t / gt.ty[l];
+    const int H = fl.H[l], W = fl.W[l];
+    const float sc = fl.scale[l];
+    const int ty0 = tiy * GT_TILE, tx0 = tix * GT_TILE;
+    // -- 1. which ROIs touch this tile (every thread tests R / 256 precomputed footprints)
+    const int key = (n << 8) | l;
+    for (int r = tid; r < R; r += 256) {
+        const int4 f = fp[r];
+        const int Y0 = f.y & 0xffff, Y1 = f.y >> 16, X0 = f.z & 0xffff, X1 = f.z >> 16;
+        s_hit[r] = (f.x == key && Y0 < ty0 + GT_TILE && Y1 >= ty0 && X0 < tx0 + GT_TILE && X1 >= tx0) ? 1 : 0;
+    }
+    __syncthreads();
+    if (wave == 0) {                                          // ordered compaction: ascending ROI index
+        int count = 0;
+        for (int base = 0; base < R; base += 64) {
+            const int r = base + lane;
+            const bool h = r < R && s_hit[r] != 0;
+            const unsigned long long m = __ballot(h);
+            if (h) s_list[count + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)r;
+            count += __popcll(m);
+        }
+        if (lane == 0) s_count = count;
+    }
+    __syncthreads();
+    const int total = s_count;
+    const int nseg = min(GT_NSEG, max(1, (total + GT_CHUNK - 1) / GT_CHUNK));
+    if (seg >= nseg) return;
+    const int q_begin = (int)((long)seg * total / nseg), count = (int)((long)(seg + 1) * total / nseg);
+    // From here on the four waves are independent (no workgroup barrier): each owns one 64-channel group of the tile.  The
+    // tile-local weight tables of a ROI live in two registers -- lane 8 * yy + ph holds WY[yy][ph], the summed y-weights of bin
+    // ph's samples on tile row yy (same for x) -- and reach the FMAs as wave-uniform scalars through v_readlane.
+    const int tr = lane >> 3, tb = lane & 7;                  // this lane's (tile row / column, bin) of the weight registers
+    {                                                         // wave = channel group (C <= 256; a wave past C idles but arrives)
+        const int c = wave * 64 + lane;
+        const bool cok = c < C;
+        float acc[GT_TILE * GT_TILE];
+#pragma unroll
+        for (int i = 0; i < GT_TILE * GT_TILE; ++i) acc[i] = 0.f;
+        for (int q = q_begin; q < count; ++q) {
+            const int r = s_list[q];
+            // the 49 bin gradients of this lane's channel first: their latency covers the weight arithmetic below
+            const float* o = (dout != nullptr && cok) ? dout + (long)r * PP * PP * C + c : nullptr;
+            const float* o2 = nullptr;
+            if (dout2 != nullptr && cok) {
+                const int img = r / per_image, k = r - img * per_image;
+                if (k < first) o2 = dout2 + ((long)img * first + k) * PP * PP * C + c;
+            }
+            float g[PP][PP];
+#pragma unroll
+            for (int ph = 0; ph < PP; ++ph)
+#pragma unroll
+                for (int pw = 0; pw < PP; ++pw) {
+                    float v = o != nullptr ? o[(long)(ph * PP + pw) * C] : 0.f;
+                    if (o2 != nullptr) v += o2[(long)(ph * PP + pw) * C];
+                    g[ph][pw] = v;
+                }
+            // per-ROI constants from roi_footprint_kernel (same expressions as the scatter kernel: sample positions are bit-equal)
+            const float4 pa = par[2 * r], pb = par[2 * r + 1];
+            const float sw = pa.x, sh = pa.y, bin_w = pa.z, bin_h = pa.w;
+            const int ghw = fp[r].w, gh = ghw & 0xffff, gw = ghw >> 16;
+            float wyv = 0.f, wxv = 0.f;
+            if (tb < PP) {
+                for (int iy = 0; iy < gh; ++iy) {             // samples in ascending order, like the scatter kernel's table build
+                    const Tap1 tp = make_tap1(sh + (float)tb * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh, H);
+                    if (!tp.ok) continue;
+                    if (tp.lo - ty0 == tr) wyv += tp.wlo;
+                    if (tp.hi - ty0 == tr) wyv += tp.whi;
+                }
+                for (int ix = 0; ix < gw; ++ix) {
+                    const Tap1 tp = make_tap1(sw + (float)tb * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw, W);
+                    if (!tp.ok) continue;
+                    if (tp.lo - tx0 == tr) wxv += tp.wlo;
+                    if (tp.hi - tx0 == tr) wxv += tp.whi;
+                }
+            }
+            const float inv_count = pb.z;
+            // rows / columns of the tile this ROI has any weight on (a ROI usually covers part of the tile): one scalar test each
+            // instead of a test per (row, bin); inside an active row the arithmetic is branch-free
+            const unsigned long long ymask = __ballot(wyv != 0.f), xmask = __ballot(wxv != 0.f);
+            float wxs[GT_TILE][PP];
+#pragma unroll
+            for (int xx = 0; xx < GT_TILE; ++xx)
+#pragma unroll
+                for (int pw = 0; pw < PP; ++pw) wxs[xx][pw] = omni_readlane(wxv, xx * 8 + pw);       // wave-uniform (SGPRs)
+            {
+#pragma clang fp contract(fast)
+#pragma unroll
+                for (int yy = 0; yy < GT_TILE; ++yy) {
+                    if (((ymask >> (8 * yy)) & 0x7fULL) == 0) continue;
+                    float rowT[PP];
+#pragma unroll
+                    for (int pw = 0; pw < PP; ++pw) rowT[pw] = 0.f;
+#pragma unroll
+                    for (int ph = 0; ph < PP; ++ph) {
+                        const float w = omni_readlane(wyv, yy * 8 + ph) * inv_count;
+#pragma unroll
+                        for (int pw = 0; pw < PP; ++pw) rowT[pw] += w * g[ph][pw];
+                    }
+#pragma unroll
+                    for (int xx = 0; xx < GT_TILE; ++xx) {
+                        if (((xmask >> (8 * xx)) & 0x7fULL) == 0) continue;
+                        float v = 0.f;
+#pragma unroll
+                        for (int pw = 0; pw < PP; ++pw) v += wxs[xx][pw] * rowT[pw];
+                        acc[yy * GT_TILE + xx] += v;
+                    }
+                }
+            }
+        }
+        if (nseg > 1) {
+            // partial tile of this segment -> slot (tile, segment); the last arrival adds the segments in order
+            float* slot = ws + ((long)tile_id * GT_NSEG) * (GT_TILE * GT_TILE * 256) + tid;
+#pragma unroll
+            for (int i = 0; i < GT_TILE * GT_TILE; ++i) OMNI_ST_AGENT(slot + ((long)seg * GT_TILE * GT_TILE + i) * 256, acc[i]);
+            if (!omni_split_arrive(ctr + tile_id, nseg)) return;
+#pragma unroll
+            for (int i = 0; i < GT_TILE * GT_TILE; ++i) acc[i] = 0.f;
+            for (int sg = 0; sg < nseg; ++sg) {
+#pragma unroll
+                for (int i = 0; i < GT_TILE * GT_TILE; ++i) acc[i] += OMNI_LD_AGENT(slot + ((long)sg * GT_TILE * GT_TILE + i) * 256);
+            }
+        }
+        if (cok) {
+            float* feat = fl.f[l] + (long)n * H * W * C + c;
+#pragma unroll
+            for (int yy = 0; yy < GT_TILE; ++yy)
+#pragma unroll
+                for (int xx = 0; xx < GT_TILE; ++xx)
+                    if (ty0 + yy < H && tx0 + xx < W) feat[((long)(ty0 + yy) * W + tx0 + xx) * C] = acc[yy * GT_TILE + xx];
+        }
+    }
+}
+
 FeatLevels make_feat(const void* const* ptrs, const int* hw, const float* scales, int nlev) {
     FeatLevels fl;
     for (int l = 0; l < MAXL; ++l) { fl.f[l] = nullptr; fl.H[l] = fl.W[l] = 0; fl.scale[l] = 0.f; }
@@ -324,6 +522,40 @@ static int roi_align_bwd_impl(const void* const* dlevel_ptrs, const int* level_h
     const long jobs = (long)R * P * P;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_kernel<1>), dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, fl, rois, batch_idx, levels, R, P, C, const_cast<float*>(dout));
+    return omni_launch_status();
+}
+
+// Deterministic form of omni_roi_align_bwd2 (P == 7, R <= 4096, C <= 256, B images): dlevel_ptrs[l] (B, H_l, W_l, C) are
+// OVERWRITTEN -- every element exactly once, by the wave that owns its 8 x 8 tile, which adds the contributions of the ROIs in
+// ascending ROI index (long ROI lists: in up to 8 contiguous chunks whose partial tiles meet in `ws` and are added in chunk order;
+// ctr: n_ctr zeroed counters, left zeroed).  No zero-fill by the caller, no atomics on the gradients; two runs give bit-identical
+// feature gradients.  plan != NULL: plan[2] = counters, plan[3] = workspace floats needed; nothing is launched.
+int omni_roi_align_bwd_det(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev, int B,
+                           const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, const float* dout,
+                           const float* dout2, int per_image, int first, float* ws, long long ws_floats, int* ctr, int n_ctr,
+                           long long* plan, void* stream) {
+    if (nlev <= 0 || nlev > MAXL || (C & 3) || C > 256 || P != 7 || B <= 0 || R < 0 || R > GT_MAXR || (dout == nullptr && dout2 == nullptr)) return OMNI_ERR_ARG;
+    if (dout2 != nullptr && (per_image <= 0 || first < 0 || first > per_image || R % per_image != 0)) return OMNI_ERR_ARG;
+    FeatLevels fl = make_feat(dlevel_ptrs, level_hw, level_scale, nlev);
+    GatherTiles gt;
+    int total = 0;
+    for (int l = 0; l < MAXL; ++l) { gt.off[l] = total; gt.tx[l] = gt.ty[l] = 1; if (l < nlev) { gt.tx[l] = (fl.W[l] + GT_TILE - 1) / GT_TILE; gt.ty[l] = (fl.H[l] + GT_TILE - 1) / GT_TILE; total += B * gt.tx[l] * gt.ty[l]; } }
+    gt.off[MAXL] = total;
+    for (int l = nlev; l <= MAXL; ++l) gt.off[l] = total;
+    gt.B = B;
+    const long long slots = (long long)total * GT_NSEG * GT_TILE * GT_TILE * 256;
+    const long long need = slots + 12LL * R;                  // + the per-ROI records: int4 footprint, 2 x float4 parameters
+    if (plan != nullptr) { plan[0] = plan[1] = 0; plan[2] = total; plan[3] = need; return OMNI_OK; }
+    if (total == 0) return OMNI_OK;
+    if (ws == nullptr || ctr == nullptr || ws_floats < need || n_ctr < total) return OMNI_ERR_ARG;
+    int4* fp = reinterpret_cast<int4*>(ws + slots);           // (slots is a multiple of 4 floats: 16-byte aligned like ws)
+    float4* par = reinterpret_cast<float4*>(ws + slots + 4LL * R);
+    if (R > 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_footprint_kernel<7>), dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, fl, rois, batch_idx,
+                           levels, R, fp, par);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_bwd_gather_kernel<7>), dim3((unsigned)total * GT_NSEG), dim3(256), 0, (hipStream_t)stream, fl,
+                       gt, rois, batch_idx, levels, R, C, dout, dout2, per_image, first, ws, (unsigned*)ctr, (const int4*)fp,
+                       (const float4*)par);
     return omni_launch_status();
 }
 

@@ -146,8 +146,11 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
 // Persistent workgroups loop over 4 x 64 pixel tiles and keep the accumulators in registers; every wave adds its partial
 // filter gradient to dW with fp32 atomics at the end (dW is the flat gradient bucket or a zeroed buffer).
 template <int C, int R>
+// part != nullptr (deterministic mode, round 4): every wave stores its partial filter gradient as row (4 * blockIdx.x + wave) of
+// part[4 * gridDim.x][16 * R * R * C] instead; stem_wgrad_finalize_kernel adds the rows in a fixed order.
 __global__ void __launch_bounds__(256) stem_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                              float* __restrict__ dw, int N, int H, int W, int ldx, int lddy) {
+                                                              float* __restrict__ dw, int N, int H, int W, int ldx, int lddy,
+                                                              float* __restrict__ part) {
     constexpr int TH = 4, TW = 64, PAD = R / 2;
     constexpr int HR = TH + R - 1, HC = TW + R - 1 + (C == 4 ? 1 : 0);
     constexpr int NB = (C == 16) ? R * R : R * 2;            // accumulator blocks
@@ -234,9 +237,34 @@ __global__ void __launch_bounds__(256) stem_conv_wgrad_kernel(const float* __res
             off = (r * R + sx) * C + (col & 3);
         }
         if (!ok) continue;
+        if (part != nullptr) {
+            float* row = part + ((long)blockIdx.x * 4 + wave) * (16 * KD);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(dw + (long)(4 * g + i) * KD + off, acc[b][i]);
+            for (int i = 0; i < 4; ++i) row[(4 * g + i) * KD + off] = acc[b][i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(dw + (long)(4 * g + i) * KD + off, acc[b][i]);
+        }
     }
+}
+
+// dw[e] (+)= sum over the `rows` partial rows of part[row][e], E elements: 4 elements per workgroup, 64 row groups per element,
+// every thread adds its rows in ascending order (fp64), the 64 group sums meet in LDS in a fixed tree -- run-to-run identical.
+__global__ void __launch_bounds__(256) stem_wgrad_finalize_kernel(const float* __restrict__ part, int rows, int E, float* __restrict__ dw,
+                                                                  int accumulate) {
+    __shared__ double sm[256];
+    const int t = threadIdx.x, el = t & 3, rg = t >> 2;
+    const int e = (int)blockIdx.x * 4 + el;
+    double a = 0.0;
+    if (e < E)
+        for (int r = rg; r < rows; r += 64) a += (double)part[(long)r * E + e];
+    sm[t] = a;
+    __syncthreads();
+    for (int s = 128; s >= 4; s >>= 1) {
+        if (t < s) sm[t] += sm[t + s];
+        __syncthreads();
+    }
+    if (t < 4 && e < E) dw[e] = accumulate ? dw[e] + (float)sm[t] : (float)sm[t];
 }
 
 }  // namespace
@@ -274,20 +302,39 @@ int omni_stem_conv_fwd_stats(const float* x, const float* w, float* out, int N, 
 }
 
 // dw (16,R,R,C) (+)= sum_pix dy (N,H,W,16) x (N,H,W,C); accumulate == 0 zeroes dw first (atomic accumulation either way).
-int omni_stem_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
-                         int accumulate, void* stream) {
+static int stem_wgrad_impl(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
+                           int accumulate, float* ws, long long ws_floats, long long* plan, bool det, void* stream) {
     if (N < 0 || H <= 0 || W <= 0 || K != 16 || ldx < C || lddy < K || (ldx & 3) || (lddy & 3)) return OMNI_ERR_ARG;
     if (!((C == 4 && R == 7) || (C == 16 && R == 3))) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (!accumulate) omni_memset_async(dw, 0, sizeof(float) * (size_t)K * R * R * C, st);
-    if (N == 0) return OMNI_OK;
     long tiles = (long)N * ((H + 3) / 4) * ((W + 63) / 64);
     const unsigned grid = (unsigned)(tiles < 768 ? tiles : 768);        // 3 resident workgroups per CU
+    const int E = K * R * R * C;
+    if (plan != nullptr) { plan[0] = plan[1] = plan[2] = 0; plan[3] = (long long)grid * 4 * E; return OMNI_OK; }
+    if (det && N > 0 && (ws == nullptr || ws_floats < (long long)grid * 4 * E)) return OMNI_ERR_ARG;
+    if (!accumulate && (!det || N == 0)) omni_memset_async(dw, 0, sizeof(float) * (size_t)E, st);
+    if (N == 0) return OMNI_OK;
+    float* part = det ? ws : nullptr;
     if (C == 4)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<4, 7>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, ldx, lddy);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<4, 7>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, ldx, lddy, part);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<16, 3>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, ldx, lddy);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<16, 3>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, ldx, lddy, part);
+    if (det)
+        hipLaunchKernelGGL(stem_wgrad_finalize_kernel, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, st, (const float*)part, (int)grid * 4, E, dw,
+                           accumulate);
     return omni_launch_status();
+}
+
+int omni_stem_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
+                         int accumulate, void* stream) {
+    return stem_wgrad_impl(x, dy, dw, N, H, W, C, K, R, ldx, lddy, accumulate, nullptr, 0, nullptr, false, stream);
+}
+
+// deterministic form: per-wave partial filter gradients go to `ws` (ws_floats floats; plan != NULL: plan[3] = floats needed, no
+// launch) and a second launch adds them in a fixed order into dw (overwritten, or added to when accumulate != 0); no atomics
+int omni_stem_conv_wgrad_det(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
+                             int accumulate, float* ws, long long ws_floats, long long* plan, void* stream) {
+    return stem_wgrad_impl(x, dy, dw, N, H, W, C, K, R, ldx, lddy, accumulate, ws, ws_floats, plan, true, stream);
 }
 
 }  // extern "C"

@@ -128,6 +128,8 @@ class GraphedTwoPhase:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         from ... import functional as HF
+        from ...kernels import detmode
+        detmode.prewarm(torch.cuda.current_device())
         prev_mode = HF.side_mode()
         HF.side_mode("inline")      # single-branch graphs: a captured fork / join would be replayed node by node from the host
         try:
@@ -179,6 +181,8 @@ class GraphedForwardBackward:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         from ... import functional as HF
+        from ...kernels import detmode
+        detmode.prewarm(torch.cuda.current_device())
         prev_mode = HF.side_mode()
         HF.side_mode("inline")      # single-branch graph: a captured fork / join would be replayed node by node from the host
         # thread_local: RCCL's watchdog thread (N > 1) and the autograd worker may issue HIP calls while this thread
@@ -312,12 +316,16 @@ class GraphedPipelined:
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
         HF.side_mode("collect")
+        # deterministic split reductions (kernels/detmode.py): the critical-path graphs and the weight-gradient graphs replay
+        # side by side, so each family gets its own block of arrival counters, allocated before the first capture starts
+        from ...kernels import detmode
+        detmode.prewarm(torch.cuda.current_device())
         try:
             stages, pool_m, pool_w = [], None, None
             self._held = []                 # closures + their inputs: kept for the lifetime of the graphs (see class docstring)
             while True:
                 gm = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gm, pool=pool_m, capture_error_mode="thread_local"):
+                with torch.cuda.graph(gm, pool=pool_m, capture_error_mode="thread_local"), detmode.domain("M"):
                     if not stages:
                         self.losses, self.total = self._stage0()
                     else:
@@ -327,7 +335,7 @@ class GraphedPipelined:
                 gw = None
                 if fns:
                     gw = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gw, pool=pool_w, capture_error_mode="thread_local"):
+                    with torch.cuda.graph(gw, pool=pool_w, capture_error_mode="thread_local"), detmode.domain("W"):
                         for fn in fns:
                             fn()
                     pool_w = gw.pool()

@@ -829,8 +829,12 @@ class _ROIAlign(Function):
     def backward(ctx, dout):
         rois, batch_idx, levels = ctx.saved_tensors
         scales, P, shapes = ctx.meta
-        dfe = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
-        det.roi_align_bwd(dfe, scales, rois, batch_idx, levels, P, _cl(dout).permute(0, 2, 3, 1))
+        if det.roi_align_bwd_deterministic(P, rois.shape[0], shapes[0][3]):
+            dfe = [torch.empty(s, dtype=torch.float32, device=dout.device) for s in shapes]      # every element written exactly once
+            det.roi_align_bwd_det(dfe, scales, rois, batch_idx, levels, P, _cl(dout).permute(0, 2, 3, 1).contiguous())
+        else:
+            dfe = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
+            det.roi_align_bwd(dfe, scales, rois, batch_idx, levels, P, _cl(dout).permute(0, 2, 3, 1))
         return (None, None, None, None, None) + tuple(_slot_deliver(slot, lambda carry, d=d: _add_carry(d.permute(0, 3, 1, 2), carry))
                                                       for slot, d in zip(ctx.slots, dfe))
 
@@ -869,12 +873,17 @@ class _ROIAlignShared(Function):
         # the five level gradients are views of ONE zero-filled slab (one fill launch), and the kernel adds the cube head's gradient
         # to the box head's on the fly (round 3: a 103 MB clone of d, a strided add and five fills before)
         sizes = [s[0] * s[1] * s[2] * s[3] for s in shapes]
-        slab = torch.zeros(sum(sizes), dtype=torch.float32, device=ref.device)
+        ordered = det.roi_align_bwd_deterministic(P, rois.shape[0], shapes[0][3])
+        slab = (torch.empty if ordered else torch.zeros)(sum(sizes), dtype=torch.float32, device=ref.device)
         dfe, off = [], 0
         for shp, n in zip(shapes, sizes):
             dfe.append(slab[off:off + n].view(shp))
             off += n
-        if df is not None and P == 7:
+        if ordered:
+            # owner-computes backward: one wave per 8 x 8 tile adds the ROIs' contributions in ROI order and writes each element once
+            det.roi_align_bwd_det(dfe, scales, rois, batch_idx, levels, P, d.contiguous() if d is not None else None,
+                                  dout2=df.contiguous() if df is not None else None, per_image=per_image, first=first)
+        elif df is not None and P == 7:
             det.roi_align_bwd(dfe, scales, rois, batch_idx, levels, P, d, dout2=df.contiguous(), per_image=per_image, first=first)
         else:
             if df is not None:            # (general pooler resolution: merge on the host side as before)

@@ -222,7 +222,9 @@ def bias_grad(dy2d, accum_into=None):
     L = _lib.check_device(dy2d)
     db = accum_into if accum_into is not None else torch.empty(C, dtype=torch.float32, device=dy2d.device)
     ws = torch.empty(2 * C * 258, dtype=torch.float64, device=dy2d.device)
-    L.call("omni_bias_grad", _lib.ptr(dy2d), P, C, _lib.ptr(db), _lib.ptr(ws), int(accum_into is not None), _lib.stream_of(dy2d))
+    from . import detmode as _det
+    acc = 0 if accum_into is None else (3 if _det.on() else 1)     # 3: add without atomics (fixed-order finalize)
+    L.call("omni_bias_grad", _lib.ptr(dy2d), P, C, _lib.ptr(db), _lib.ptr(ws), acc, _lib.stream_of(dy2d))
     return None if accum_into is not None else db
 
 

@@ -10,6 +10,7 @@ import os
 import torch
 
 from .. import lib as _lib
+from . import detmode as _det
 
 
 def _nhwc(t):
@@ -26,6 +27,48 @@ def to_channels_last(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
+def _fwd_launch(L, x, w, bias, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, relu, tile, splits, like, stats=None, stats_rows=0, nblk_addr=None):
+    """omni_conv2d_fwd_algo / _stats, or -- deterministic mode -- omni_conv2d_fwd_det with the workspace its own plan asks for"""
+    st = _lib.stream_of(like)
+    if not _det.on():
+        if stats is not None:
+            L.call("omni_conv2d_fwd_stats", x, w, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, _lib.ptr(stats), stats_rows, nblk_addr, st)
+        else:
+            L.call("omni_conv2d_fwd_algo", x, w, bias, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, int(relu), tile, splits, st)
+        return
+    plan, addr = _det.new_plan()
+    L.call("omni_conv2d_fwd_det", x, w, bias, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, int(relu), tile, splits, None, 0, None, None, 0,
+           None, 0, addr, st)
+    ws, wsf, ctr, nctr = _det.workspace(like, plan)
+    L.call("omni_conv2d_fwd_det", x, w, bias, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, int(relu), int(plan[0]), int(plan[1]),
+           _lib.ptr(stats), stats_rows, nblk_addr, _lib.ptr(ws), wsf, _lib.ptr(ctr), nctr, None, st)
+
+
+def _dgrad_launch(L, dy, w, dx, N, H, W, C, K, R, S, stride, pad, lddy, lddx, accumulate, tile, splits, like):
+    st = _lib.stream_of(like)
+    if not _det.on():
+        L.call("omni_conv2d_dgrad_algo", dy, w, dx, N, H, W, C, K, R, S, stride, pad, lddy, lddx, accumulate, tile, splits, st)
+        return
+    plan, addr = _det.new_plan()
+    L.call("omni_conv2d_dgrad_det", dy, w, dx, N, H, W, C, K, R, S, stride, pad, lddy, lddx, accumulate, tile, splits, None, 0, None, 0, addr, st)
+    ws, wsf, ctr, nctr = _det.workspace(like, plan)
+    L.call("omni_conv2d_dgrad_det", dy, w, dx, N, H, W, C, K, R, S, stride, pad, lddy, lddx, accumulate, int(plan[0]), int(plan[1]),
+           _lib.ptr(ws), wsf, _lib.ptr(ctr), nctr, None, st)
+
+
+def _wgrad_launch(L, x, dy, dw, N, H, W, C, K, R, S, stride, pad, ldx, lddy, accumulate, tile, like):
+    st = _lib.stream_of(like)
+    if not _det.on():
+        L.call("omni_conv2d_wgrad_algo", x, dy, dw, N, H, W, C, K, R, S, stride, pad, ldx, lddy, accumulate, tile, st)
+        return
+    plan, addr = _det.new_plan()
+    L.call("omni_conv2d_wgrad_det", x, dy, dw, N, H, W, C, K, R, S, stride, pad, ldx, lddy, accumulate, tile, None, 0, None, 0, addr, st)
+    ws, wsf, ctr, nctr = _det.workspace(like, plan)
+    # (the tile is passed back as the caller gave it: `tile` also carries the workgroup-order request, + 16 / + 32)
+    L.call("omni_conv2d_wgrad_det", x, dy, dw, N, H, W, C, K, R, S, stride, pad, ldx, lddy, accumulate, tile, _lib.ptr(ws), wsf, _lib.ptr(ctr),
+           nctr, None, st)
+
+
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, relu=False, tile=0, splits=0):
     """x (N,C,H,W) CL, w (K,C,R,S) CL -> y (N,K,OH,OW) CL.  tile/splits: explicit algorithm (0 = the launcher's choice)."""
     xv, wv = _nhwc(x), _nhwc(w)
@@ -35,8 +78,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, relu=False, tile=0, splits=0):
     OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
     L = _lib.check_device(xv, wv, bias)
     out = torch.empty((N, OH, OW, K), dtype=torch.float32, device=x.device)
-    L.call("omni_conv2d_fwd_algo", _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(bias), _lib.ptr(out), N, H, W, C, K, R, S, stride,
-           pad, C, K, int(relu), tile, splits, _lib.stream_of(x))
+    _fwd_launch(L, _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(bias), _lib.ptr(out), N, H, W, C, K, R, S, stride, pad, C, K, relu, tile, splits, x)
     return out.permute(0, 3, 1, 2)
 
 
@@ -63,8 +105,8 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0):
     out = torch.empty((N, OH, OW, K), dtype=torch.float32, device=x.device)
     stats = _stats_buf(K, x.device)
     cell, addr = _nblk_cell()
-    L.call("omni_conv2d_fwd_stats", _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(out), N, H, W, C, K, R, S, stride, pad, C, K, _lib.ptr(stats),
-           STATS_ROWS, addr, _lib.stream_of(x))
+    _fwd_launch(L, _lib.ptr(xv), _lib.ptr(wv), None, _lib.ptr(out), N, H, W, C, K, R, S, stride, pad, C, K, False, 0, 0, x, stats=stats,
+                stats_rows=STATS_ROWS, nblk_addr=addr)
     return out.permute(0, 3, 1, 2), (stats[:cell.value] if cell.value > 0 else None)
 
 
@@ -93,12 +135,11 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, tile=0, splits=0, accum_into=Non
     L = _lib.check_device(dyv, wv)
     if accum_into is not None:
         assert tuple(accum_into.shape) == (N, C, H, W) and accum_into.stride(1) == 1
-        L.call("omni_conv2d_dgrad_algo", _lib.ptr(dyv), _lib.ptr(wv), accum_into.data_ptr(), N, H, W, C, K, R, S, stride, pad, K,
-               accum_into.stride(3), 1, tile, splits, _lib.stream_of(dy))
+        _dgrad_launch(L, _lib.ptr(dyv), _lib.ptr(wv), accum_into.data_ptr(), N, H, W, C, K, R, S, stride, pad, K, accum_into.stride(3), 1,
+                      tile, splits, dy)
         return accum_into
     dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
-    L.call("omni_conv2d_dgrad_algo", _lib.ptr(dyv), _lib.ptr(wv), _lib.ptr(dx), N, H, W, C, K, R, S, stride, pad, K, C, 0,
-           tile, splits, _lib.stream_of(dy))
+    _dgrad_launch(L, _lib.ptr(dyv), _lib.ptr(wv), _lib.ptr(dx), N, H, W, C, K, R, S, stride, pad, K, C, 0, tile, splits, dy)
     return dx.permute(0, 3, 1, 2)
 
 
@@ -113,12 +154,10 @@ def conv2d_wgrad(x, dy, ksize, stride=1, pad=0, accum_into=None, tile=0):
     if accum_into is not None:
         tgt = accum_into.permute(0, 2, 3, 1)
         assert tgt.is_contiguous() and tgt.shape == (K, R, S, C)
-        L.call("omni_conv2d_wgrad_algo", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(tgt), N, H, W, C, K, R, S, stride, pad, C, K, 1,
-               tile, _lib.stream_of(x))
+        _wgrad_launch(L, _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(tgt), N, H, W, C, K, R, S, stride, pad, C, K, 1, tile, x)
         return None
     dw = torch.empty((K, R, S, C), dtype=torch.float32, device=x.device)
-    L.call("omni_conv2d_wgrad_algo", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, K, R, S, stride, pad, C, K, 0,
-           tile, _lib.stream_of(x))
+    _wgrad_launch(L, _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, K, R, S, stride, pad, C, K, 0, tile, x)
     return dw.permute(0, 3, 1, 2)
 
 
@@ -136,13 +175,14 @@ def linear_fwd(x, w, bias=None, relu=False):
     L = _lib.check_device(x, w, bias)
     if _engine_eligible(M, C, K):
         from . import gemm as _gemm
+        if relu and _det.on():      # ordered split: the last-arriving workgroup holds the complete sum, bias + ReLU there
+            return _gemm.gemm(x, w, _gemm.NT, bias=bias, relu=True, tile=2, splits=2)
         if relu:            # split reduction ends in atomics: bias rides on split 0, the ReLU needs the complete sum
             out = _gemm.gemm(x, w, _gemm.NT, bias=bias, tile=2, splits=2)
             return out.clamp_(min=0)
         return _gemm.gemm(x, w, _gemm.NT, bias=bias, tile=2, splits=2)
     out = torch.empty((M, K), dtype=torch.float32, device=x.device)
-    L.call("omni_conv2d_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), M, 1, 1, C, K, 1, 1, 1, 0, C, K,
-           int(relu), _lib.stream_of(x))
+    _fwd_launch(L, _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), M, 1, 1, C, K, 1, 1, 1, 0, C, K, relu, 0, 0, x)
     return out
 
 
@@ -164,8 +204,7 @@ def linear_dgrad(dy, w):
         from . import gemm as _gemm
         return _gemm.gemm(dy, _gemm.transpose2d(w), _gemm.NT, tile=2, splits=_gemm.BALANCED if _FC_BALANCED else 1)
     dx = torch.empty((M, C), dtype=torch.float32, device=dy.device)
-    L.call("omni_conv2d_dgrad", _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), M, 1, 1, C, K, 1, 1, 1, 0, K, C, 0,
-           _lib.stream_of(dy))
+    _dgrad_launch(L, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), M, 1, 1, C, K, 1, 1, 1, 0, K, C, 0, 0, 0, dy)
     return dx
 
 
@@ -181,12 +220,10 @@ def linear_wgrad(x, dy, accum_into=None):
             from . import gemm as _gemm
             _gemm.gemm(dy, x, _gemm.TN, out=accum_into, accumulate=True, tile=2, splits=_gemm.BALANCED, workgroups=_FC_WGRAD_WGS)
             return None
-        L.call("omni_conv2d_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(accum_into), M, 1, 1, C, K, 1, 1, 1, 0, C, K, 1,
-               _lib.stream_of(x))
+        _wgrad_launch(L, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(accum_into), M, 1, 1, C, K, 1, 1, 1, 0, C, K, 1, 0, x)
         return None
     dw = torch.empty((K, C), dtype=torch.float32, device=x.device)
-    L.call("omni_conv2d_wgrad", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), M, 1, 1, C, K, 1, 1, 1, 0, C, K, 0,
-           _lib.stream_of(x))
+    _wgrad_launch(L, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), M, 1, 1, C, K, 1, 1, 1, 0, C, K, 0, 0, x)
     return dw
 
 
@@ -213,13 +250,22 @@ def stem_conv_wgrad(x, dy, R, accum_into=None):
     N, H, W, C = xv.shape
     K = dv.shape[3]
     L = _lib.check_device(xv, dv)
+    def launch(dst, acc):
+        if not _det.on():
+            L.call("omni_stem_conv_wgrad", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dst), N, H, W, C, K, R, C, K, acc, _lib.stream_of(x))
+            return
+        plan, addr = _det.new_plan()
+        L.call("omni_stem_conv_wgrad_det", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dst), N, H, W, C, K, R, C, K, acc, None, 0, addr, _lib.stream_of(x))
+        ws = torch.empty(max(int(plan[3]), 1), dtype=torch.float32, device=x.device)
+        L.call("omni_stem_conv_wgrad_det", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dst), N, H, W, C, K, R, C, K, acc, _lib.ptr(ws), int(plan[3]), None,
+               _lib.stream_of(x))
     if accum_into is not None:
         gv = accum_into.permute(0, 2, 3, 1)
         assert gv.is_contiguous() and tuple(gv.shape) == (K, R, R, C)
-        L.call("omni_stem_conv_wgrad", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(gv), N, H, W, C, K, R, C, K, 1, _lib.stream_of(x))
+        launch(gv, 1)
         return None
     dw = torch.empty((K, R, R, C), dtype=torch.float32, device=x.device)
-    L.call("omni_stem_conv_wgrad", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dw), N, H, W, C, K, R, C, K, 0, _lib.stream_of(x))
+    launch(dw, 0)
     return dw.permute(0, 3, 1, 2)
 
 

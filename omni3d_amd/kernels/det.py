@@ -247,6 +247,26 @@ def roi_align_fwd(feats_nhwc, scales, rois, batch_idx, levels, P):
     return out
 
 
+def roi_align_bwd_deterministic(P, R, C=256):
+    """the owner-computes backward (omni_roi_align_bwd_det) serves the pooler resolution and FPN width of every Cube R-CNN config"""
+    from . import detmode as _det
+    return _det.on() and P == 7 and R <= 4096 and C <= 256
+
+
+def roi_align_bwd_det(dfeats_nhwc, scales, rois, batch_idx, levels, P, dout, dout2=None, per_image=0, first=0):
+    """OVERWRITES dfeats (any content, e.g. torch.empty): every element written once, ROI contributions added in ROI order"""
+    L = _dev(rois, batch_idx, levels, dout, dout2, *dfeats_nhwc)
+    R, C, B = rois.shape[0], dfeats_nhwc[0].shape[3], dfeats_nhwc[0].shape[0]
+    keep, a = _feat_args(dfeats_nhwc, scales)
+    assert (dout is None or dout.is_contiguous()) and (dout2 is None or dout2.is_contiguous())
+    from . import detmode as _det
+    args = (*a, B, _lib.ptr(rois), _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, _lib.ptr(dout), _lib.ptr(dout2), int(per_image), int(first))
+    plan, addr = _det.new_plan()
+    L.call("omni_roi_align_bwd_det", *args, None, 0, None, 0, addr, _lib.stream_of(rois))
+    ws, wsf, ctr, nctr = _det.workspace(rois, plan)
+    L.call("omni_roi_align_bwd_det", *args, _lib.ptr(ws), wsf, _lib.ptr(ctr), nctr, None, _lib.stream_of(rois))
+
+
 def roi_align_bwd(dfeats_nhwc, scales, rois, batch_idx, levels, P, dout, dout2=None, per_image=0, first=0):
     """accumulates into dfeats (caller-zeroed or holding other gradients).  dout2 ((R / per_image) * first, P, P, C): a second gradient
     for the first `first` ROIs of every block of `per_image`, added on the fly (P == 7); dout may then be None."""

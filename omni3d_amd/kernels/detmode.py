@@ -1,0 +1,101 @@
+"""Deterministic mode of the split reductions (csrc/split_reduce.h): workspace + arrival-counter plumbing.
+
+The reference's PyTorch-CPU path is run-to-run identical; rounds 1-3 of this path were not (fp32 atomics where a reduction is cut
+over several workgroups).  With the switch on, every launcher that would split a reduction asks the C launcher for its plan
+(`plan` argument of the `*_det` entry points: the launcher's own tile / split decision, no duplicated heuristics here), takes a
+workspace for the partial tiles from torch's caching allocator (stream-ordered; inside a hipGraph capture from that graph's pool,
+so the critical-path graphs and the weight-gradient graphs that replay beside them never share one) and hands over a block of
+arrival counters that the kernels leave zeroed.
+
+Counters are persistent per *domain*: launches that can run concurrently must not share them.  Eager launches are keyed by the
+stream they go to; captured launches by the graph family they belong to (`domain("W")` around the capture of a weight-gradient
+graph, "M" otherwise) -- graphs of one family replay on one stream, one after another.
+
+OMNI_DETERMINISTIC=0 returns to the atomic epilogues (A/B switch; the `-m gpu` tests and bench.py run with the default)."""
+import ctypes
+import os
+
+import torch
+
+_ON = os.environ.get("OMNI_DETERMINISTIC", "1") != "0"
+_CTR_CAP = 1 << 16
+_domain = None
+_counters = {}
+
+
+def on():
+    return _ON
+
+
+def set_enabled(flag):
+    """-> previous setting (tests / A-B tools)"""
+    global _ON
+    prev, _ON = _ON, bool(flag)
+    return prev
+
+
+class domain:
+    """with detmode.domain("W"): ...   -- launches captured inside belong to that graph family"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _domain
+        self.prev, _domain = _domain, self.name
+
+    def __exit__(self, *a):
+        global _domain
+        _domain = self.prev
+
+
+def _key(like):
+    if like.is_cuda:
+        if torch.cuda.is_current_stream_capturing():
+            return (like.device.index, "graph", _domain or "M")
+        if _domain is not None:
+            return (like.device.index, "domain", _domain)
+        return (like.device.index, "stream", torch.cuda.current_stream(like.device).cuda_stream)
+    return ("cpu", _domain)
+
+
+def counters(like, n):
+    """-> int32 tensor of >= n zeroed arrival counters for a launch on `like`'s device and the current stream / graph family"""
+    if n > _CTR_CAP:
+        return torch.zeros(n, dtype=torch.int32, device=like.device)
+    key = _key(like)
+    c = _counters.get(key)
+    if c is None:
+        if like.is_cuda and torch.cuda.is_current_stream_capturing():
+            # first use of this family inside a capture: the buffer must outlive the graph's private pool -> allocate it outside
+            # the capture's allocator scope is not possible here, so it becomes part of the capture (zeroed by a captured fill on
+            # every replay, which is harmless: the kernels leave it zeroed anyway)
+            c = torch.zeros(_CTR_CAP, dtype=torch.int32, device=like.device)
+            return c
+        c = torch.zeros(_CTR_CAP, dtype=torch.int32, device=like.device)
+        _counters[key] = c
+    return c
+
+
+def prewarm(device, families=("M", "W")):
+    """allocate the graph families' counter blocks BEFORE a capture starts (graphed.py)"""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return
+    for f in families:
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), "graph", f)
+        if key not in _counters:
+            _counters[key] = torch.zeros(_CTR_CAP, dtype=torch.int32, device=dev)
+
+
+def new_plan():
+    buf = (ctypes.c_longlong * 4)()
+    return buf, ctypes.addressof(buf)
+
+
+def workspace(like, plan):
+    """plan = the four values a `*_det` entry point reported -> (ws tensor or None, ws_floats, counter tensor, n_ctr)"""
+    n_ctr, ws_floats = int(plan[2]), int(plan[3])
+    ws = torch.empty(ws_floats, dtype=torch.float32, device=like.device) if ws_floats > 0 else None
+    ctr = counters(like, max(n_ctr, 1))
+    return ws, ws_floats, ctr, max(n_ctr, 1)

@@ -38,6 +38,15 @@ def gemm(A, B, form=NT, bias=None, relu=False, out=None, accumulate=False, split
     else:
         out3 = out.unsqueeze(0) if out.dim() == 2 else out
         assert out3.is_contiguous() and tuple(out3.shape) == (b, M, N)
+    from . import detmode as _det
+    if _det.on():
+        args = (_lib.ptr(A3), _lib.ptr(B3), _lib.ptr(out3), _lib.ptr(bias), form, b, M, N, K, lda, ldb, N, A3.stride(0), B3.stride(0), M * N,
+                splits, int(relu), int(accumulate), tile, workgroups)
+        plan, addr = _det.new_plan()
+        L.call("omni_gemm_engine_det", *args, None, 0, None, 0, addr, _lib.stream_of(A))
+        ws, wsf, ctr, nctr = _det.workspace(A, plan)
+        L.call("omni_gemm_engine_det", *args, _lib.ptr(ws), wsf, _lib.ptr(ctr), nctr, None, _lib.stream_of(A))
+        return out3[0] if squeeze else out3
     if splits > 1 and not accumulate:
         out3.zero_()
     elif splits == BALANCED and not accumulate:

@@ -123,7 +123,15 @@ def gemm_batched_wgrad(V, dM, algo=0):
     K = dM.shape[2]
     L = _lib.check_device(V, dM)
     dU = torch.empty((B, K, C), dtype=torch.float32, device=V.device)
-    L.call("omni_gemm_batched_wgrad_algo", _lib.ptr(V), _lib.ptr(dM), _lib.ptr(dU), B, M, C, K, algo, _lib.stream_of(V))
+    from . import detmode as _det
+    if not _det.on():
+        L.call("omni_gemm_batched_wgrad_algo", _lib.ptr(V), _lib.ptr(dM), _lib.ptr(dU), B, M, C, K, algo, _lib.stream_of(V))
+        return dU
+    plan, addr = _det.new_plan()
+    L.call("omni_gemm_batched_wgrad_det", _lib.ptr(V), _lib.ptr(dM), _lib.ptr(dU), B, M, C, K, algo, None, 0, None, 0, addr, _lib.stream_of(V))
+    ws, wsf, ctr, nctr = _det.workspace(V, plan)
+    L.call("omni_gemm_batched_wgrad_det", _lib.ptr(V), _lib.ptr(dM), _lib.ptr(dU), B, M, C, K, int(plan[0]), _lib.ptr(ws), wsf, _lib.ptr(ctr), nctr,
+           None, _lib.stream_of(V))
     return dU
 
 

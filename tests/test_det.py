@@ -184,6 +184,12 @@ def _run_roi_align(dev):
     for d, f in zip(dfe, fr):
         fg = f.grad if f.grad is not None else torch.zeros_like(f)
         assert (d.cpu().permute(0, 3, 1, 2) - fg).abs().max() < 2e-5
+    # the owner-computes (deterministic) backward overwrites garbage and gives the same gradients
+    dfd = [torch.full_like(f, float("nan")) for f in fn]
+    det.roi_align_bwd_det(dfd, scales, rois.to(dev), bidx.to(dev), lv, P, dout.to(dev))
+    for d, f in zip(dfd, fr):
+        fg = f.grad if f.grad is not None else torch.zeros_like(f)
+        assert (d.cpu().permute(0, 3, 1, 2) - fg).abs().max() < 2e-5
     # two gradient tensors in one pass (the box head's for every ROI + the cube head's for the first `first` of every `per_image`)
     # == one pass over their sum; also with the first one absent
     per_image, first = 11, 4                                   # 33 ROIs = 3 blocks
@@ -201,6 +207,11 @@ def _run_roi_align(dev):
                           dout2=d2.to(dev), per_image=per_image, first=first)
         for a, b in zip(got2, want):
             assert (a - b).abs().max() <= 1e-5 * max(1.0, float(b.abs().max()))     # (atomics: summation order differs)
+        got3 = [torch.full_like(f, float("nan")) for f in fn]
+        det.roi_align_bwd_det(got3, scales, rois.to(dev), bidx.to(dev), lv, P, None if first_grad is None else first_grad.to(dev),
+                              dout2=d2.to(dev), per_image=per_image, first=first)
+        for a, b in zip(got3, want):
+            assert (a - b).abs().max() <= 1e-5 * max(1.0, float(b.abs().max()))
 
 
 def _run_roi_align_big(dev):
@@ -220,6 +231,9 @@ def _run_roi_align_big(dev):
     dfe = [torch.zeros(1, 150, 150, C, device=dev)]
     det.roi_align_bwd(dfe, [1.0], rois.to(dev), bidx, lv, P, dout.to(dev))
     assert (dfe[0].cpu().permute(0, 3, 1, 2) - fr.grad).abs().max() < 2e-5
+    dfd = [torch.full((1, 150, 150, C), float("nan"), device=dev)]          # ragged 8 x 8 tiles (150 = 18 * 8 + 6), a 147 px footprint
+    det.roi_align_bwd_det(dfd, [1.0], rois.to(dev), bidx, lv, P, dout.to(dev))
+    assert (dfd[0].cpu().permute(0, 3, 1, 2) - fr.grad).abs().max() < 2e-5
 
 
 def _run_box_loss(dev):
