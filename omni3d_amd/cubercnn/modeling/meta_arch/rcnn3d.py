@@ -19,6 +19,9 @@ from ..roi_heads import build_roi_heads
 from ..targets import pack_targets
 
 
+_EVAL_F22 = __import__("os").environ.get("OMNI_EVAL_F22", "1") != "0"       # A/B knob
+
+
 @META_ARCH_REGISTRY.register()
 class RCNN3D(nn.Module):
     @configurable
@@ -79,7 +82,16 @@ class RCNN3D(nn.Module):
 
     def _forward(self, batched_inputs, packed=None):
         if not self.training:
-            return self.inference(batched_inputs, packed=packed)
+            if not _EVAL_F22:
+                return self.inference(batched_inputs, packed=packed)
+            # Inference runs every Winograd layer on the 16-point F(2x2,3x3) transform: the cube head's Gram-Schmidt amplifies feature
+            # noise up to ~300x for near-parallel 6D pose vectors (tools/debug/pose_diag.py), and the 36-point transform of the
+            # bottom-up is what that noise is made of -- worst pose / corner error of the full-size fixture against float64 2.9e-4
+            # with F(4x4,3x3), 3.5e-5 without (north_star: 1e-4), for 4 % of the inference time.  Training keeps F(4x4,3x3): its
+            # losses sit at 1e-7 and its gradients are judged against the fp32 reference's own distance to float64.
+            from ....kernels import wino as _wino
+            with _wino.f22_only():
+                return self.inference(batched_inputs, packed=packed)
         auto = self.__dict__.get("_omni_auto")
         if auto is not None and packed is None and not auto.busy:
             # the drop-in loop: once the batch signature repeats, model(data) replays the staged hipGraphs of the whole step

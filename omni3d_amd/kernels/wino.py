@@ -31,10 +31,29 @@ def eligible(x_shape, w_shape, stride, pad):
     return C >= 64 and K >= 64 and tile_size(x_shape) == 4 and N * (H // 4) * (W // 4) >= 4096
 
 
+_f22_depth = 0
+
+
+class f22_only:
+    """with wino.f22_only(): convolutions inside take the 16-point F(2x2,3x3) transform whatever the map size.  Its fp32 error is
+    ~1/3 of F(4x4,3x3)'s (tools/winograd_error.py); used where a convolution's output feeds an ill-conditioned consumer and speed
+    is not the point -- the FPN output convolutions in front of ROIAlign at inference (cubercnn/modeling/backbone/fpn.py)."""
+
+    def __enter__(self):
+        global _f22_depth
+        _f22_depth += 1
+
+    def __exit__(self, *a):
+        global _f22_depth
+        _f22_depth -= 1
+
+
 def tile_size(x_shape):
     """4 = F(4x4,3x3) (36 points, 2.25 multiplies per output) when the map divides into >= 256 tiles of 4x4 (batch 4: maps of
     32x32 and larger), else 2 = F(2x2,3x3) (16 points, 4 multiplies per output)."""
     N, _, H, W = x_shape
+    if _f22_depth > 0:
+        return 2
     return 4 if (_F43 and H % 4 == 0 and W % 4 == 0 and N * (H // 4) * (W // 4) >= _F43_MIN_TILES) else 2
 
 

@@ -56,8 +56,9 @@ def _run(dev, name="dla34_small_infer"):
             r64 = {k: v[both] for k, v in r64.items()}
 
         def bounded(name, got, cap, scale=None):
-            """|HIP - fp64| <= max(cap, 3 x the reference's own fp32 distance to the fp64 value), never above 2 x cap
-            (cap = north_star's 1e-4, relative for values above 1).  The split-K / fc1 atomics reorder the fp32 sums from
+            """|HIP - fp64| <= max(cap, 3 x the reference's own fp32 distance to the fp64 value), never above max(2 x cap, 1.5 x that
+            distance) (cap = north_star's 1e-4, relative for values above 1; the second term only matters where the REFERENCE's own
+            fp32 run is above the bar -- the 6D pose of one detection of the small fixture, 1.9e-4).  The split-K / fc1 atomics reorder the fp32 sums from
             run to run: over repeated runs the worst element of pred_dimensions sits between 2e-5 and 1.1e-4 while the CPU
             fp32 reference is a steady 4.5e-5 from float64 (profiles/r02_parity_fp64_inference.txt) -- the MAX over all
             detections of an fp32 rounding error is what fluctuates, so the bar is tied to the measured conditioning."""
@@ -65,7 +66,7 @@ def _run(dev, name="dla34_small_infer"):
             den = (1.0 + r_64.abs()) if scale is None else scale
             e_hip, e_ref = float(((got - r_64).abs() / den).max()), float(((r32 - r_64).abs() / den).max())
             report.append("%-16s |hip-fp64| %.2e  |ref32-fp64| %.2e  cap %.0e" % (name, e_hip, e_ref, cap))
-            if not (e_hip <= max(cap, 3.0 * e_ref) and e_hip <= 2.0 * cap):
+            if not (e_hip <= max(cap, 3.0 * e_ref) and e_hip <= max(2.0 * cap, 1.5 * e_ref)):
                 bad.append(report[-1])
 
         ext = float(max(o["instances"].image_size))
@@ -75,12 +76,15 @@ def _run(dev, name="dla34_small_infer"):
         bounded("pred_center_cam", i.pred_center_cam, 1e-4)
         # projected 3D centres may lie far outside the image (|u| up to ~800 px here)
         bounded("pred_center_2D", i.pred_center_2D, 1e-4 * 4, scale=r64["pred_center_2D"].abs().clamp(min=ext))
-        # the Gram-Schmidt of a random-init 6D pose amplifies fp32 rounding of the head GEMMs: the REFERENCE in fp32 is
-        # itself 2e-4 .. 3.5e-4 from its float64 evaluation here, so the cap is 1e-3 and the 2x rule is the real bar
-        bounded("pred_pose", i.pred_pose, 1e-3)
+        # Round 4: north_star's 1e-4 here too (1e-3 before).  The Gram-Schmidt of a random-init 6D pose amplifies feature noise by
+        # up to ~300x (angle between the two pose vectors 3 degrees: tools/debug/pose_diag.py, profiles/r04_pose_diag.txt); the decode
+        # kernel evaluates the fp32 head outputs in float64 (arithmetic error 3e-8) and inference runs its Winograd layers on the
+        # 16-point transform, which brought the full-size fixture from 2.9e-4 to 3.5e-5.  Where the REFERENCE's fp32 run is itself
+        # above the bar (small fixture, 1.9e-4 / 3.1e-4) the 3x / 1.5x rule of `bounded` applies.
+        bounded("pred_pose", i.pred_pose, 1e-4)
         # corners = centre +- R dims / 2 cancel for the random-init head's cuboids of up to ~100 m around a centre a few metres
         # away, so the error of a corner is measured against the extent of ITS cuboid, not against the corner coordinate
-        bounded("pred_bbox3D", i.pred_bbox3D, 1e-3, scale=1.0 + r64["pred_bbox3D"].double().abs().amax(dim=(1, 2), keepdim=True))
+        bounded("pred_bbox3D", i.pred_bbox3D, 1e-4, scale=1.0 + r64["pred_bbox3D"].double().abs().amax(dim=(1, 2), keepdim=True))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir) and dev == "cuda":
         with open(os.path.join(out_dir, "inference_fp64_report.txt" if name == "dla34_small_infer" else name + "_fp64_report.txt"), "w") as f:
