@@ -194,6 +194,12 @@ int omni_upsample2_bwd_carry(const float* dout, const float* carry, long long ld
  * uint8 planar (N,3,H,W) -> fp32 NHWC (N,PH,PW,4), (v-mean)/std, channel 3 and padding = 0. */
 int omni_preprocess(const unsigned char* img, float* out, int N, int H, int W, int PH, int PW, float m0,
                     float m1, float m2, float s0, float s1, float s2, void* stream);
+/* The same for a batch staged into fixed-size slots: image_hw (N,2) device ints = the valid height / width of image n inside its
+ * H x W slot; everything outside is zero padding like the reference's ImageList.from_tensors of the real sizes
+ * (rcnn3d.py:46 -> detectron2 ImageList).  Lets one captured training step serve every batch of a size bucket
+ * (configs/Base.yaml:10-13 draws a new short edge per image; cubercnn/solver/autoreplay.py). */
+int omni_preprocess_masked(const unsigned char* img, const int* image_hw, float* out, int N, int H, int W, int PH, int PW,
+                           float m0, float m1, float m2, float s0, float s1, float s2, void* stream);
 
 /* ----------------------------------------------------------- index-exact selection kernels */
 

@@ -214,6 +214,10 @@ def run_train(args, world, rank):
             try:
                 d1, d10 = dropin_loop(30, 1), dropin_loop(30, 10)
                 res["dropin_loop_ms_per_step"] = d1["ms_per_step"]
+                try:
+                    res["dropin_loop_multiscale"] = dropin_loop_multiscale(fixed_ms=1e3 * dt / args.steps)
+                except Exception as e:  # noqa: BLE001
+                    res["dropin_loop_multiscale"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
                 res["dropin_loop"] = {"loop": "tools/train_synthetic.py == tools/train_net.py:176-285 body, new batch (pool of 4) every iteration, "
                                               "host-side target packing + H2D inside the timed region",
                                       "losses_read_every_iteration": d1, "losses_read_every_10th": d10,
@@ -272,6 +276,64 @@ def dropin_loop(iters=30, sync_every=1):
     return {"ms_per_step": 1e3 * dt / iters, "iterations": iters, "replayed_iterations": auto.replays if auto is not None else 0,
             "capture": "ok" if (auto is not None and auto.failed is None and auto.stepper is not None) else f"not replaying: {getattr(auto, 'failed', 'disabled')}",
             "losses_read_every": sync_every, "last_total_loss": red["total_loss"]}
+
+
+def dropin_loop_multiscale(iters=24, pool_size=8, fixed_ms=None):
+    """The same loop body on batches drawn like the reference's loader draws them (configs/Base.yaml:10-13: a new short edge per
+    image, cubercnn/data/dataset_mapper.py:17-58; synthetic.make_multiscale_batch): every batch has its own tuple of image shapes.
+    AutoReplay keys its captured steps by (batch size, padded height, padded width) -- ImageList pads to multiples of 64 anyway -- and
+    serves any image sizes of a bucket from one capture (images in masked slots, sizes as device data).  Reported: ms per iteration
+    once every bucket of the pool is captured, the buckets, and the fixed-shape replayed step scaled by padded pixels for comparison."""
+    from omni3d_amd import synthetic
+    from omni3d_amd.cubercnn.solver.guard import StepGuard
+    from omni3d_amd.d2.solver import build_lr_scheduler
+    cfg, model, opt, priors = build(1, seed=1)
+    sched = build_lr_scheduler(cfg, opt)
+    auto = model.__dict__.get("_omni_auto")
+    if auto is None:
+        return {"error": "AutoReplay disabled"}
+    pool = [synthetic.make_multiscale_batch(IMS_PER_GPU, 3000 + s, priors=priors) for s in range(pool_size)]
+    sigs = [auto.signature(b) for b in pool]
+    guard = None
+
+    def iteration(it):
+        nonlocal guard
+        loss_dict = model(pool[it % len(pool)])
+        losses = sum(loss_dict.values())
+        if guard is None:
+            guard = StepGuard(list(loss_dict), cfg.MODEL.STABILIZE, cfg.SOLVER.CHECKPOINT_PERIOD, losses.device)
+            opt.skip_flag = guard.skip
+        opt.zero_grad()
+        losses.backward()
+        opt.all_reduce_grads()
+        opt.check_nonfinite(guard.nonfinite_flag)
+        guard.update(loss_dict, sync=True)
+        opt.step()
+        sched.step()
+
+    it = 0
+    for _ in range((auto.warm + 2) * len(pool)):     # every bucket: its eager warm-up iterations, its capture, a first replay
+        iteration(it)
+        it += 1
+    _sync()
+    replays0, captures0 = auto.replays, auto.captures
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        iteration(it)
+        it += 1
+    _sync()
+    dt = time.perf_counter() - t0
+    px = [s[1] * s[2] for s in sigs]
+    mean_px = sum(px[(k + (auto.warm + 2) * len(pool)) % len(pool)] for k in range(iters)) / iters
+    out = {"ms_per_step": 1e3 * dt / iters, "iterations": iters, "pool": pool_size, "buckets": sorted(set(sigs)),
+           "image_shapes_of_first_batch": [tuple(b["image"].shape[-2:]) for b in pool[0]],
+           "replayed_in_timed_region": auto.replays - replays0, "captures_in_timed_region": auto.captures - captures0,
+           "captures_total": auto.captures, "capture": "ok" if auto.failed is None else f"not replaying: {auto.failed}",
+           "mean_padded_pixels_per_image": mean_px}
+    if fixed_ms is not None:
+        out["fixed_shape_step_scaled_by_pixels_ms"] = fixed_ms * mean_px / float(IMAGE_SIZE * IMAGE_SIZE)
+        out["vs_pixel_scaled_fixed_shape"] = out["ms_per_step"] / out["fixed_shape_step_scaled_by_pixels_ms"]
+    return out
 
 
 def run_infer(args, world, rank):

@@ -456,9 +456,11 @@ __global__ void __launch_bounds__(256) upsample2_bwd_kernel(const float* __restr
 
 // ---- image normalisation: uint8 planar (N,3,H,W) -> NHWC fp32 with 4 channels (4th = 0), the
 //      bottom/right padding up to (PH, PW) is zero AFTER normalisation (ImageList.from_tensors) ---
+// image_hw (nullable): device (N, 2) ints, the valid height / width of every image inside its H x W slot (a batch staged into
+// fixed-size slots -- the size-bucketed graph replay of cubercnn/solver/autoreplay.py); pixels outside are written as zero padding
 __global__ void __launch_bounds__(256) preprocess_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
                                                          int N, int H, int W, int PH, int PW, float m0, float m1,
-                                                         float m2, float s0, float s1, float s2) {
+                                                         float m2, float s0, float s1, float s2, const int* __restrict__ image_hw) {
     const long total = (long)N * PH * PW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int w = (int)(i % PW);
@@ -466,7 +468,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const unsigned char* __
         const int h = (int)(q % PH);
         const int n = (int)(q / PH);
         float4 v = f4(0.f);
-        if (h < H && w < W) {
+        const int vh = image_hw != nullptr ? min(H, image_hw[2 * n]) : H, vw = image_hw != nullptr ? min(W, image_hw[2 * n + 1]) : W;
+        if (h < vh && w < vw) {
             const unsigned char* b = img + ((long)n * 3 * H + h) * W + w;
             v.x = ((float)b[0] - m0) / s0;
             v.y = ((float)b[(long)H * W] - m1) / s1;
@@ -709,14 +712,19 @@ int omni_upsample2_bwd(const float* dout, float* dtop, int N, int H, int W, int 
 }
 
 // img uint8 (N,3,H,W) -> out fp32 NHWC (N,PH,PW,4): (v - mean)/std per channel, zero padded.
-int omni_preprocess(const unsigned char* img, float* out, int N, int H, int W, int PH, int PW, float m0, float m1,
-                    float m2, float s0, float s1, float s2, void* stream) {
+int omni_preprocess_masked(const unsigned char* img, const int* image_hw, float* out, int N, int H, int W, int PH, int PW, float m0,
+                           float m1, float m2, float s0, float s1, float s2, void* stream) {
     if (PH < H || PW < W) return OMNI_ERR_ARG;
     const long total = (long)N * PH * PW;
     if (total == 0) return OMNI_OK;
     hipLaunchKernelGGL(preprocess_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, img, out, N, H, W, PH,
-                       PW, m0, m1, m2, s0, s1, s2);
+                       PW, m0, m1, m2, s0, s1, s2, image_hw);
     return omni_launch_status();
+}
+
+int omni_preprocess(const unsigned char* img, float* out, int N, int H, int W, int PH, int PW, float m0, float m1,
+                    float m2, float s0, float s1, float s2, void* stream) {
+    return omni_preprocess_masked(img, nullptr, out, N, H, W, PH, PW, m0, m1, m2, s0, s1, s2, stream);
 }
 
 // dz = dy * (y > 0), n elements (n % 4 == 0).

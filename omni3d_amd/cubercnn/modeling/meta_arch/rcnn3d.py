@@ -51,9 +51,16 @@ class RCNN3D(nn.Module):
     def device(self):
         return self.pixel_mean.device
 
-    def preprocess_image(self, batched_inputs):
+    def preprocess_image(self, batched_inputs, slot_hw=None):
+        """slot_hw: device (B, 2) int32 -- the images sit in equal-size slots (the size-bucketed replay of solver/autoreplay.py) and
+        their real sizes are device data; the padding mask is then applied by the kernel, not by host-side slicing"""
         imgs = [x["image"] for x in batched_inputs]
         sizes = [(im.shape[-2], im.shape[-1]) for im in imgs]
+        if slot_hw is not None:
+            assert len(set(sizes)) == 1
+            batch = torch.stack(imgs).to(self.device, non_blocking=True)
+            x = bnpool.preprocess(batch, self._mean, self._std, self.backbone.size_divisibility, image_hw=slot_hw)
+            return ImageList(x, sizes)
         if len(set(sizes)) == 1:
             batch = torch.stack(imgs).to(self.device, non_blocking=True)
         else:   # ragged batch: pad the uint8 images on the host first (zero padding is re-zeroed after normalisation)
@@ -99,7 +106,7 @@ class RCNN3D(nn.Module):
             out = auto.forward(batched_inputs)
             if out is not None:
                 return out
-        images = self.preprocess_image(batched_inputs)
+        images = self.preprocess_image(batched_inputs, slot_hw=packed.image_hw if getattr(packed, "slotted", False) else None)
         packed_given = packed
         if packed is None:
             packed = self.prepack(batched_inputs)

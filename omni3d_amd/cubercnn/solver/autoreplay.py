@@ -23,12 +23,18 @@ reachable only from bench.py.  `AutoReplay` closes the gap without touching the 
     sum, a loss scale): the next `model(data)` then raises and names the remedy instead of training on wrong gradients;
   * a second `optimizer.zero_grad()` in the same iteration (the reference's "diverging: zero_grad, no step" branch,
     tools/train_net.py:245-247) clears the bucket for real;
-  * a different signature (another image size, another batch size, eval mode) falls back to eager launches and starts over.
+  * eval mode runs eager launches.
 
-Real Omni3D training resizes every image to a random short edge (configs/Base.yaml:10-13), so signatures repeat only within an
-aspect-ratio / scale bucket; the fixed-shape regime is the benchmark's (BASELINE.json configs[1]) and any fixed-resolution
-fine-tuning run.  OMNI_AUTO_REPLAY=0 switches the mechanism off."""
+Round 4: a cache of captured steps keyed by SIZE BUCKET.  Real Omni3D training resizes every image to a random short edge
+(configs/Base.yaml:10-13: 25 values from 256 to 640; cubercnn/data/dataset_mapper.py:17-58), so the exact tuple of image shapes of a
+batch almost never repeats -- but detectron2's ImageList pads every batch to multiples of 64 anyway, and everything behind the padded
+tensor already takes the real image sizes as DEVICE data (`packed.image_hw`).  The signature is therefore (batch size, padded
+height, padded width): the captured step holds its images in fixed-size slots of that shape, `model(data)` copies each new image
+into the corner of its slot, and the preprocessing kernel masks the rest with the sizes of THIS batch (omni_preprocess_masked).  Up to
+OMNI_AUTO_REPLAY_CACHE (16) captured steps are kept, least recently used evicted; a bucket is captured after `warm` eager iterations
+of its own.  OMNI_AUTO_REPLAY=0 switches the mechanism off."""
 import os
+from collections import OrderedDict
 
 import torch
 from torch.autograd import Function
@@ -37,6 +43,8 @@ from ... import functional as HF
 from ..modeling.targets import MAX_GT_PER_IMAGE, pack_targets
 
 ENABLED = os.environ.get("OMNI_AUTO_REPLAY", "1") != "0"
+CACHE = int(os.environ.get("OMNI_AUTO_REPLAY_CACHE", "16"))           # captured steps kept (a few GB of graph-private memory each)
+BUCKET = 64                                                           # ImageList's padding granularity (FPN size divisibility)
 ROW_FIELDS = ("gt", "gt_cls", "gt3d", "gtpose", "ign")           # (rows, ...) arrays indexed through gt_off / ign_off
 FIXED_FIELDS = ("gt_off", "ign_off", "Ks", "v2r", "ratio", "image_hw")
 
@@ -89,12 +97,14 @@ class AutoReplay:
     def __init__(self, model, optimizer, warm=2, graphs=None):
         self.model, self.opt, self.warm = model, optimizer, warm
         self.graphs = graphs                     # None: hipGraphs on a GPU, eager staged launches elsewhere (CPU tests)
-        self.sig, self.count, self.stepper, self.failed = None, 0, None, None
-        self.static_batch = self.static_packed = None
+        self.cache = OrderedDict()               # bucket -> captured step (stepper, static batch / targets, logged scalars)
+        self.counts = {}                         # bucket -> iterations seen
+        self.failed = None
         self.anchor = None
         self.bad = None                          # device float: != 0 when backward saw a non-unit upstream gradient
         self.bad_host, self.bad_event, self.bad_armed = None, None, False
         self.replays = 0
+        self.captures = 0
         self.holders = []                        # inner graphs of the eager iterations' loss dicts (see _Boundary)
         self._eager_anchor = None
         self.busy = False                        # True while a capture drives the model itself
@@ -103,7 +113,15 @@ class AutoReplay:
     # ---- signature / state machine -----------------------------------------------------------------------------------
     @staticmethod
     def signature(batch):
-        return (len(batch),) + tuple(tuple(b["image"].shape) for b in batch)
+        """(batch size, padded height, padded width): what every shape behind ImageList.from_tensors depends on"""
+        H = max(b["image"].shape[-2] for b in batch)
+        W = max(b["image"].shape[-1] for b in batch)
+        return (len(batch), -(-H // BUCKET) * BUCKET, -(-W // BUCKET) * BUCKET)
+
+    # (kept for callers / tests that look at the most recently used captured step)
+    @property
+    def stepper(self):
+        return next(reversed(self.cache.values()))["stepper"] if self.cache else None
 
     def forward(self, batched_inputs):
         """-> loss dict of a replayed step, or None (the caller runs the eager path)"""
@@ -111,21 +129,23 @@ class AutoReplay:
             return None
         self._raise_if_poisoned()
         sig = self.signature(batched_inputs)
-        if sig != self.sig:
-            self._drop()
-            self.sig, self.count = sig, 0
-        self.count += 1
-        if self.stepper is None:
-            if self.count <= self.warm:
+        self.counts[sig] = self.counts.get(sig, 0) + 1
+        entry = self.cache.get(sig)
+        if entry is None:
+            if self.counts[sig] <= self.warm:
                 return None
             try:
-                self._capture(batched_inputs)
+                entry = self._capture(batched_inputs, sig)
             except Exception as e:  # noqa: BLE001 -- capture refused: stay on eager launches, say why once
                 self._drop()
                 self.failed = f"{type(e).__name__}: {str(e)[:200]}"
                 import warnings
                 warnings.warn(f"omni3d_amd: staged-graph capture of the training step failed ({self.failed}); running eager launches")
                 return None
+            self.cache[sig] = entry
+            while len(self.cache) > max(CACHE, 1):
+                self.cache.popitem(last=False)            # least recently used: its graphs and their private pools are released
+        self.cache.move_to_end(sig)
         if getattr(self.opt, "_replay_state", None) is not None:
             # the previous replayed gradients were neither applied (step) nor dropped (second zero_grad): a loop that accumulates
             # over several forward passes.  The replay zeroes the bucket itself, so that pattern needs eager launches.
@@ -135,15 +155,15 @@ class AutoReplay:
             import warnings
             warnings.warn("omni3d_amd: gradient accumulation over several model(data) calls detected; staged-graph replay switched off")
             return None
-        self._stage(batched_inputs)
-        losses, total, pending = self.stepper()
+        self._stage(entry, batched_inputs)
+        losses, total, pending = entry["stepper"]()
         self.opt._replay_state = {"pending": pending, "zero_grads_seen": 0}
         self.replays += 1
         names = list(losses.keys())
         out = _Replayed.apply(self.anchor, self, *[losses[k].detach() for k in names])     # detached: nothing upstream of the node
         from ...d2.events import get_event_storage, has_event_storage
         if has_event_storage():                      # the logged scalars live in static tensors the replay refreshed
-            for m, saved in self._logs:
+            for m, saved in entry["logs"]:
                 m.pending_logs = dict(saved)
             self.model.flush_logs(get_event_storage())
         return HF.LossDict({k: out[i] for i, k in enumerate(names)})
@@ -174,63 +194,74 @@ class AutoReplay:
         gc.collect()
 
     def _drop(self):
-        if self.stepper is not None:
-            self.model.feature_cut = None
-            bu = getattr(getattr(self.model, "backbone", None), "bottom_up", None)
-            if bu is not None and hasattr(bu, "stage_cut"):
-                bu.stage_cut = None
-        self.stepper = self.static_batch = self.static_packed = None
+        """forget every captured step (a failure, or a loop the protocol does not cover)"""
+        self.cache.clear()
+        self.counts.clear()
+        self.model.feature_cut = None
+        bu = getattr(getattr(self.model, "backbone", None), "bottom_up", None)
+        if bu is not None and hasattr(bu, "stage_cut"):
+            bu.stage_cut = None
 
     # ---- capture -----------------------------------------------------------------------------------------------------
-    def _capture(self, batch):
+    def _capture(self, batch, sig):
         from .graphed import GraphedPipelined
         model, dev = self.model, self.model.device
-        B = len(batch)
+        B, Hb, Wb = sig
+        # the images' slots: every later batch of this bucket is copied into their corners
+        slots = torch.zeros((B, 3, Hb, Wb), dtype=batch[0]["image"].dtype, device=dev)
         sb = []
-        for b in batch:
+        for n, b in enumerate(batch):
             c = {k: v for k, v in b.items() if k not in ("image", "instances")}
-            c["image"] = b["image"].to(dev).clone()
+            h, w = b["image"].shape[-2:]
+            slots[n, :, :h, :w].copy_(b["image"], non_blocking=True)
+            c["image"] = slots[n]
             if "instances" in b:
                 c["instances"] = b["instances"]
             sb.append(c)
         self.release_eager_graphs()                      # no live eager graph (and its default-stream AccumulateGrad nodes) during capture
-        packed = model.prepack(batch)
+        packed = model.prepack(batch)                    # (real image sizes: packed.image_hw)
         cap = B * int(os.environ.get("OMNI_AUTO_REPLAY_ROWS", MAX_GT_PER_IMAGE))
         for f in ROW_FIELDS:                              # fixed capacity: any later batch's rows fit
             t = getattr(packed, f)
             pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             pad[: t.shape[0]] = t
             setattr(packed, f, pad)
-        self.static_batch, self.static_packed = sb, packed
+        packed.slotted = True                            # RCNN3D.preprocess_image masks the slots with packed.image_hw on the device
         graphs = self.graphs if self.graphs is not None else (dev.type == "cuda")
         # a capture is not a training step: its warm-up passes must not move the BatchNorm running statistics
         bufs = [(b, b.detach().clone()) for b in model.buffers()]
         self.busy = True
         try:
-            self.stepper = GraphedPipelined(model, self.opt, sb, packed, graphs=graphs)
+            stepper = GraphedPipelined(model, self.opt, sb, packed, graphs=graphs)
         finally:
             self.busy = False
             with torch.no_grad():
                 for b, saved in bufs:
                     b.copy_(saved)
-        self.anchor = getattr(model, "_omni_ddp_anchor", None)
+        if stepper.stages is not None:
+            stepper.uninstall()                          # replays need no cut points; eager iterations of other buckets run uncut
         if self.anchor is None:
-            self.anchor = torch.zeros(1, device=dev, requires_grad=True)
-        self.bad = torch.zeros(1, dtype=torch.float32, device=dev)
+            self.anchor = getattr(model, "_omni_ddp_anchor", None)
+            if self.anchor is None:
+                self.anchor = torch.zeros(1, device=dev, requires_grad=True)
+            self.bad = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.captures += 1
         # what the components would log this iteration (static tensors of the captured pass; flush_logs pops them)
-        self._logs = [(m, dict(m.pending_logs)) for m in (model.proposal_generator, model.roi_heads) if hasattr(m, "pending_logs")]
+        logs = [(m, dict(m.pending_logs)) for m in (model.proposal_generator, model.roi_heads) if hasattr(m, "pending_logs")]
+        return {"stepper": stepper, "batch": sb, "packed": packed, "slots": slots, "logs": logs}
 
-    def _stage(self, batch):
+    def _stage(self, entry, batch):
         """new data into the tensors the graphs were captured on"""
         dev = self.model.device
-        for s, b in zip(self.static_batch, batch):
-            s["image"].copy_(b["image"], non_blocking=True)
+        for n, (s_, b) in enumerate(zip(entry["batch"], batch)):
+            h, w = b["image"].shape[-2:]
+            entry["slots"][n, :, :h, :w].copy_(b["image"], non_blocking=True)     # (the rest of the slot is masked by image_hw)
             for k in ("K", "height", "width"):
                 if k in b:
-                    s[k] = b[k]
+                    s_[k] = b[k]
         sizes = [(b["image"].shape[-2], b["image"].shape[-1]) for b in batch]
         new = pack_targets(batch, sizes, getattr(self.model.roi_heads, "virtual_focal", 512.0), with_gt=True)
-        sp = self.static_packed
+        sp = entry["packed"]
         for f in ROW_FIELDS:
             src, dst = getattr(new, f), getattr(sp, f)
             n = src.shape[0]

@@ -281,10 +281,9 @@ class GraphedPipelined:
         self.model, self.optimizer, self.group = model, optimizer, group
         self.static_batch, self.static_packed = batch, packed
         self.cuts = StageCuts()
-        model.feature_cut = self.cuts
+        self._install()
         bottom_up = getattr(getattr(model, "backbone", None), "bottom_up", None)
         if bottom_up is not None and hasattr(type(bottom_up), "stage_cut"):
-            bottom_up.stage_cut = self.cuts
             import os
             if os.environ.get("OMNI_PIPE_CUTS") is not None:       # A/B knob: "" | "p2" | "p2,p3" | "p2,p3,p4" | "p2,p3,p4,p5"
                 bottom_up.stage_cut_at = tuple(x for x in os.environ["OMNI_PIPE_CUTS"].split(",") if x)
@@ -349,6 +348,21 @@ class GraphedPipelined:
             HF.side_take()
             HF.side_mode(prev_mode)
 
+    def _install(self):
+        """the model cuts its forward at THIS object's cut points (several captured steps may exist side by side -- one per size
+        bucket, solver/autoreplay.py -- and eager iterations in between run uncut: `uninstall` after a capture / an eager staged step)"""
+        self.model.feature_cut = self.cuts
+        bottom_up = getattr(getattr(self.model, "backbone", None), "bottom_up", None)
+        if bottom_up is not None and hasattr(type(bottom_up), "stage_cut"):
+            bottom_up.stage_cut = self.cuts
+
+    def uninstall(self):
+        if getattr(self.model, "feature_cut", None) is self.cuts:
+            self.model.feature_cut = None
+        bottom_up = getattr(getattr(self.model, "backbone", None), "bottom_up", None)
+        if bottom_up is not None and getattr(bottom_up, "stage_cut", None) is self.cuts:
+            bottom_up.stage_cut = None
+
     def _stage0(self):
         self.cuts.reset()
         self.optimizer.zero_grad()
@@ -369,7 +383,11 @@ class GraphedPipelined:
 
     def __call__(self):
         if self.stages is None:
-            losses, total, pending = self._eager()
+            self._install()
+            try:
+                losses, total, pending = self._eager()
+            finally:
+                self.uninstall()
             return losses, total, pending + self.optimizer.all_reduce_begin("late", self.group)
         main, side = torch.cuda.current_stream(), self.side
         pending, n = [], len(self.stages)

@@ -191,8 +191,9 @@ def upsample2_bwd(dout, carry=None):
     return dtop.permute(0, 3, 1, 2)
 
 
-def preprocess(images_u8, pixel_mean, pixel_std, size_divisibility=0):
-    """images (N,3,H,W) uint8 -> (N,4,PH,PW) CL fp32 normalised, zero padded (channel 3 = 0)."""
+def preprocess(images_u8, pixel_mean, pixel_std, size_divisibility=0, image_hw=None):
+    """images (N,3,H,W) uint8 -> (N,4,PH,PW) CL fp32 normalised, zero padded (channel 3 = 0).
+    image_hw (N,2) int32 on the device: valid size of every image inside its slot (the rest of the slot is padding)."""
     assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[1] == 3
     images_u8 = images_u8.contiguous()
     N, _, H, W = images_u8.shape
@@ -203,8 +204,13 @@ def preprocess(images_u8, pixel_mean, pixel_std, size_divisibility=0):
     L = _lib.check_device(images_u8)
     out = torch.empty((N, PH, PW, 4), dtype=torch.float32, device=images_u8.device)
     m, s = [float(v) for v in pixel_mean], [float(v) for v in pixel_std]
-    L.call("omni_preprocess", _lib.ptr(images_u8), _lib.ptr(out), N, H, W, PH, PW, m[0], m[1], m[2], s[0], s[1], s[2],
-           _lib.stream_of(images_u8))
+    if image_hw is not None:
+        assert image_hw.dtype == torch.int32 and tuple(image_hw.shape) == (N, 2) and image_hw.is_contiguous()
+        L.call("omni_preprocess_masked", _lib.ptr(images_u8), _lib.ptr(image_hw), _lib.ptr(out), N, H, W, PH, PW, m[0], m[1], m[2], s[0], s[1],
+               s[2], _lib.stream_of(images_u8))
+    else:
+        L.call("omni_preprocess", _lib.ptr(images_u8), _lib.ptr(out), N, H, W, PH, PW, m[0], m[1], m[2], s[0], s[1], s[2],
+               _lib.stream_of(images_u8))
     return out.permute(0, 3, 1, 2)
 
 

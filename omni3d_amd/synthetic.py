@@ -178,3 +178,31 @@ def write_omni3d_stats(root, category_names, category_ids=None):
         json.dump({"n_datasets": 1, "n_ims": 0, "n_anns": 0, "category_names": list(category_names),
                    "categories": [{"id": cid, "name": n} for cid, n in zip(category_ids, category_names)]}, f)
     return path
+
+
+# ---- batches shaped like the reference's real input regime ----------------------------------------------------------------------
+# configs/Base.yaml:10-13: INPUT.MIN_SIZE_TRAIN = 256, 272, ..., 640 (25 values), MAX_SIZE_TRAIN 4096; cubercnn/data/dataset_mapper.py
+# :17-58 resizes every image to a short edge drawn from that list.  Aspect ratios of the Omni3D sources: KITTI 1242 x 375, nuScenes
+# 1600 x 900, SUN RGB-D 730 x 530 / Hypersim 1024 x 768, Objectron 1440 x 1920 (portrait).
+MIN_SIZE_TRAIN = tuple(range(256, 641, 16))
+ASPECTS = ((375, 1242), (900, 1600), (530, 730), (768, 1024), (1920, 1440))
+
+
+def make_multiscale_batch(num_images, seed, priors=None, num_gt=8, max_long_edge=1344):
+    """`num_images` synthetic images, each with its own short edge (MIN_SIZE_TRAIN) and source aspect ratio, like one iteration of the
+    reference's loader; max_long_edge bounds the synthetic KITTI-shaped images (2120 px at short edge 640 would only make the
+    benchmark's buckets bigger, not different)"""
+    rs = np.random.RandomState(seed)
+    batch = []
+    for i in range(num_images):
+        short = int(MIN_SIZE_TRAIN[rs.randint(len(MIN_SIZE_TRAIN))])
+        ah, aw = ASPECTS[rs.randint(len(ASPECTS))]
+        if ah <= aw:
+            h, w = short, int(round(short * aw / ah))
+        else:
+            h, w = int(round(short * ah / aw)), short
+        if max(h, w) > max_long_edge:
+            sc = max_long_edge / max(h, w)
+            h, w = int(round(h * sc)), int(round(w * sc))
+        batch += make_batch(1, h, w, num_gt=num_gt, seed=seed * 131 + i, priors=priors)
+    return batch
