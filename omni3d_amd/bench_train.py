@@ -89,7 +89,7 @@ def run_train(args, world, rank):
     def eager_step():
         if getattr(model, "feature_cut", None) is not None and hasattr(graphed, "_eager"):    # staged backward installed
             losses, total, pending = graphed._eager()
-            opt.all_reduce_finish(pending + opt.all_reduce_begin("late"), defer_scale=True)
+            opt.all_reduce_finish(pending + graphed._late(graphed._eager_exchanged_all), defer_scale=True)
             return finish(losses, total)
         opt.zero_grad()
         losses = model(batch, packed)

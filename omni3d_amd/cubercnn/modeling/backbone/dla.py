@@ -249,6 +249,19 @@ class DLABackbone(Backbone):
     # (device timestamps of OMNI_PIPE_TIMING=1, profiles/r03_pipe_timing.log): 12.14 -> 12.06 ms / step
     stage_cut_at = ("stem", "p2", "p3")
 
+    def backward_stages(self):
+        """{module name: backward stage its parameters' gradients complete in} for the cut points of `stage_cut_at` (stage 0 = the
+        heads, 1 = FPN + everything above the topmost cut, counting up towards the input); read by solver/build.py to lay the
+        gradient bucket out stage by stage"""
+        order = [("base_layer", "stem"), ("level0", None), ("level1", None), ("level2", "p2"), ("level3", "p3"), ("level4", "p4"), ("level5", "p5")]
+        n_cuts = sum(1 for _, c in order if c in self.stage_cut_at)
+        out, seen = {}, 0
+        for name, c in order:
+            out[name] = 1 + n_cuts - seen       # modules before the first cut are the LAST stage
+            if c in self.stage_cut_at:
+                seen += 1
+        return out
+
     def forward(self, x):
         on = self.stage_cut is not None and self.training and torch.is_grad_enabled()
         cut = lambda name, t: self.stage_cut(t) if (on and name in self.stage_cut_at) else t      # noqa: E731

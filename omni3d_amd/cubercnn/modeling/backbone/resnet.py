@@ -124,6 +124,17 @@ class ResNet(Backbone):
     stage_cut = None      # solver/graphed.py GraphedPipelined: backward is cut between the stages (x -> detached copy of x)
     stage_cut_at = ("p2", "p3")
 
+    def backward_stages(self):
+        """{module name: backward stage} for the cut points of `stage_cut_at` (see DLA.backward_stages)"""
+        order = [("conv1", None), ("bn1", None), ("layer1", "p2"), ("layer2", "p3"), ("layer3", "p4"), ("layer4", "p5")]
+        n_cuts = sum(1 for _, c in order if c in self.stage_cut_at)
+        out, seen = {}, 0
+        for name, c in order:
+            out[name] = 1 + n_cuts - seen
+            if c in self.stage_cut_at:
+                seen += 1
+        return out
+
     def forward(self, x):
         w = self.conv1.weight
         if x.shape[1] != w.shape[1]:   # 3-channel stem weight against the 4-channel padded image

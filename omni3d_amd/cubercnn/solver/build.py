@@ -78,7 +78,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         layout = {}
         total = 0
         for key, items in classes.items():
-            items = sorted(items, key=lambda gp: bool(getattr(gp[1], "_omni_early_grad", False)))   # stable: [late | early]
+            items = sorted(items, key=lambda gp: -self._grad_stage(gp[1]))    # stable: [last backward stage | ... | stage 1 | heads]
             ids = {id(p) for _, p in items}
             entries, done = [], set()
             for g, p in items:
@@ -87,7 +87,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 tag = getattr(p, "_omni_fuse", None)
                 members = tag["members"] if tag is not None else None
                 if members is not None and all(id(m) in ids for m in members) and not any(id(m) in done for m in members) and \
-                        len({bool(getattr(m, "_omni_early_grad", False)) for m in members}) == 1:
+                        len({self._grad_stage(m) for m in members}) == 1:
                     gof = {id(pp): gg for gg, pp in items}
                     for m in members:
                         entries.append((gof[id(m)], m, m.numel(), tag))
@@ -112,11 +112,15 @@ class _FlatOptimizer(torch.optim.Optimizer):
         # backbone, tagged `_omni_early_grad` by build_optimizer) sit behind the late ones, so each class is
         # [late | early] and the data-parallel exchange can all-reduce the early ranges while the backbone is still
         # back-propagating (all_reduce_begin / all_reduce_finish).
-        self.early_ranges, self.late_ranges = [], []
+        # Round 4: one exchange range per BACKWARD STAGE and class (`_omni_grad_stage`, tagged by build_optimizer from the backbone's
+        # cut points: 0 = heads, 1 = FPN + the deepest levels, ... last = the first layer), ordered last stage first, so the
+        # gradients of stage k are all-reduced behind that stage's weight-gradient graph while the stages below still back-propagate
+        # (graphed.py); `early_ranges` (stage 0) / `late_ranges` (everything else) keep the two-phase interface.
+        self.stage_ranges = {}
         for key, (items, entries) in layout.items():
             start = off
-            mid = None
             fused_start = {}
+            cur_stage, cur_start = None, off
             for g, p, n, tag in entries:
                 if p is None:
                     if tag is not None:              # the padding closes a fused group: hand its members the fused views
@@ -125,8 +129,11 @@ class _FlatOptimizer(torch.optim.Optimizer):
                                                               tuple(m.data_ptr() for m in tag["members"]))
                     off += n
                     continue
-                if mid is None and getattr(p, "_omni_early_grad", False):
-                    mid = off
+                st = self._grad_stage(p)
+                if st != cur_stage:
+                    if cur_stage is not None and off > cur_start:
+                        self.stage_ranges.setdefault(cur_stage, []).append((cur_start, off))
+                    cur_stage, cur_start = st, off
                 if tag is not None and id(tag) not in fused_start:
                     fused_start[id(tag)] = off
                 pv = self._view_like(self.flat_param[off:off + n], p)
@@ -138,13 +145,19 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 p.grad = gv
                 self._slot[id(p)] = (off, n)
                 off += n
-            if mid is None:
-                mid = off
-            if mid > start:
-                self.late_ranges.append((start, mid))
-            if off > mid:
-                self.early_ranges.append((mid, off))
+            if cur_stage is not None and off > cur_start:
+                self.stage_ranges.setdefault(cur_stage, []).append((cur_start, off))
             self.segments.append((start, off, next(i for i, g in enumerate(self.param_groups) if g is items[0][0])))
+        self.n_stages = (max(self.stage_ranges) + 1) if self.stage_ranges else 1
+        self.early_ranges = list(self.stage_ranges.get(0, []))
+        self.late_ranges = [r for k in sorted(self.stage_ranges) if k > 0 for r in self.stage_ranges[k]]
+
+    @staticmethod
+    def _grad_stage(p):
+        st = getattr(p, "_omni_grad_stage", None)
+        if st is not None:
+            return int(st)
+        return 0 if getattr(p, "_omni_early_grad", False) else 1
 
     def set_direct_accumulate(self, flag):
         self._direct = bool(flag)
@@ -223,19 +236,39 @@ class _FlatOptimizer(torch.optim.Optimizer):
             return
         self.all_reduce_finish(self.all_reduce_begin("early", group) + self.all_reduce_begin("late", group), group)
 
+    EXCHANGE_CHUNK = 8 << 20        # elements per all-reduce call (32 MB): a stage's range is issued in pieces RCCL can pipeline
+
+    def exchange_chunks(self, stages):
+        """-> [(start, end)] of the given backward stages, stage by stage, class by class, cut into EXCHANGE_CHUNK pieces.  A function
+        of the bucket layout alone: every rank issues the same sequence whether it replays a captured step or runs eager launches."""
+        out = []
+        for k in stages:
+            for s, e in self.stage_ranges.get(k, []):
+                while s < e:
+                    out.append((s, min(e, s + self.EXCHANGE_CHUNK)))
+                    s += self.EXCHANGE_CHUNK
+        return out
+
     def all_reduce_begin(self, which, group=None):
-        """Starts the asynchronous all-reduce (sum) of the `which` in {"early", "late"} ranges of the flat gradient
-        bucket and returns the pending work handles.  "early" = every parameter outside the backbone: their gradients
-        are final once the heads have back-propagated (cubercnn/solver/graphed.py runs the backbone's backward after
-        this call), so RCCL moves ~61 % of the 191.6 MB while the backbone's dgrad/wgrad kernels run."""
+        """Starts the asynchronous all-reduce (sum) of a part of the flat gradient bucket and returns the pending work handles.
+        which: "early" = backward stage 0 (every parameter outside the backbone: final once the heads have back-propagated), "late" =
+        every other stage, an int k = stage k, ("from", k) = stages k, k + 1, ...  cubercnn/solver/graphed.py issues stage k behind
+        that stage's weight-gradient graph, so RCCL moves each stage's bytes while the stages below still back-propagate."""
         import torch.distributed as dist
         if getattr(self, "_exchange_muted", False):        # warm-up passes of a staged-graph capture (graphed.py): rank-local
             return []
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
             return []
         self._exchanged = True
-        ranges = self.early_ranges if which == "early" else self.late_ranges
-        return [(dist.all_reduce(self.flat_grad[s:e], group=group, async_op=True), s, e) for s, e in ranges]
+        if which == "early":
+            stages = [0]
+        elif which == "late":
+            stages = list(range(1, self.n_stages))
+        elif isinstance(which, tuple):
+            stages = list(range(int(which[1]), self.n_stages))
+        else:
+            stages = [int(which)]
+        return [(dist.all_reduce(self.flat_grad[s:e], group=group, async_op=True), s, e) for s, e in self.exchange_chunks(stages)]
 
     def all_reduce_finish(self, pending, group=None, defer_scale=False):
         """Waits for the handles of all_reduce_begin (stream-ordered for RCCL) and averages.  defer_scale=True leaves the
@@ -451,13 +484,34 @@ def fused_view(members, training):
     return pflat, gflat
 
 
+def grad_stage_map(model):
+    """parameter name -> backward stage in which its gradient completes (cubercnn/solver/graphed.py GraphedPipelined): 0 = everything
+    outside the backbone, 1 = FPN + the bottom-up levels above the last cut, 2, 3, ... = the pieces between the cuts going down, as
+    the bottom-up declares them (`backward_stages()`: {name prefix: stage}); a backbone without cut points is stage 1 as a whole."""
+    bu = getattr(getattr(model, "backbone", None), "bottom_up", None)
+    table = bu.backward_stages() if (bu is not None and hasattr(bu, "backward_stages")) else {}
+
+    def stage_of(name):
+        if not name.startswith("backbone."):
+            return 0
+        if name.startswith("backbone.bottom_up."):
+            rest = name[len("backbone.bottom_up."):]
+            for prefix, st in table.items():
+                if rest == prefix or rest.startswith(prefix + "."):
+                    return st
+        return 1
+    return stage_of
+
+
 def build_optimizer(cfg, model):
     params = _param_groups(cfg, model)
     tag_fused_groups(model.module if hasattr(model, "module") else model)
     # gradients of everything outside the backbone are complete before the backbone starts back-propagating
     inner = model.module if hasattr(model, "module") else model
+    stage_of = grad_stage_map(inner)
     for name, p in inner.named_parameters():
         p._omni_early_grad = not name.startswith("backbone.")
+        p._omni_grad_stage = stage_of(name)
     # tools/train_net.py:449-454 wraps the model in DistributedDataParallel BEFORE do_train builds the optimizer.  A wrapper that
     # reduces the gradients itself needs autograd's accumulation hooks (no direct accumulation) and makes the step's own exchange
     # redundant; a wrapper this package's build_model prepared (`_omni_owns_exchange`, cubercnn/solver/ddp.py) leaves the exchange
@@ -475,6 +529,8 @@ def build_optimizer(cfg, model):
                        decoupled=adamw, direct_accumulate=direct)
     else:
         raise ValueError("{} is not supported as an optimizer.".format(cfg.SOLVER.TYPE))
+    bu = getattr(getattr(inner, "backbone", None), "bottom_up", None)
+    opt.stage_cut_signature = tuple(getattr(bu, "stage_cut_at", ())) if bu is not None else ()     # what the ranges were laid out for
     opt.exchange_in_step = direct          # DDP's reducer already averaged: never all-reduce the bucket a second time
     if direct:
         from .autoreplay import attach

@@ -363,6 +363,21 @@ class GraphedPipelined:
         if bottom_up is not None and getattr(bottom_up, "stage_cut", None) is self.cuts:
             bottom_up.stage_cut = None
 
+    def _per_stage_exchange(self, n_graph_stages):
+        """One exchange per backward stage needs the gradient bucket laid out for exactly these cut points (build_optimizer tagged the
+        parameters from the bottom-up's `stage_cut_at`); anything else -- an A/B run with other cuts, a backbone without cut points --
+        falls back to two phases: heads behind stage 0, the rest after the last stage.  Either way the SEQUENCE of all-reduce calls
+        is the same (stage ranges in order, FlatOptimizer.exchange_chunks): ranks may mix the forms."""
+        opt = self.optimizer
+        bu = getattr(getattr(self.model, "backbone", None), "bottom_up", None)
+        sig = tuple(getattr(bu, "stage_cut_at", ())) if bu is not None else ()
+        return (getattr(opt, "n_stages", 2) == n_graph_stages and getattr(opt, "stage_cut_signature", None) == sig
+                and hasattr(opt, "stage_ranges"))
+
+    def _late(self, per_stage):
+        """what is left to exchange after the last stage: nothing when every stage issued its own ranges"""
+        return [] if per_stage else self.optimizer.all_reduce_begin("late", self.group)
+
     def _stage0(self):
         self.cuts.reset()
         self.optimizer.zero_grad()
@@ -375,10 +390,17 @@ class GraphedPipelined:
         """all stages with eager launches (weight gradients wherever functional.side_mode() puts them)
         -> (loss dict, total, pending early all-reduce handles)"""
         losses, total = self._stage0()
-        pending = self.optimizer.all_reduce_begin("early", self.group)
+        per_stage = self._per_stage_exchange(1 + len(self.cuts))
+        pending = self.optimizer.all_reduce_begin(0 if per_stage else "early", self.group)
+        k = 0
         while len(self.cuts):
             self.cuts.backward_last()
+            k += 1
+            if per_stage:
+                self.HF.side_join()                  # (eager form: the stage's weight gradients are complete)
+                pending += self.optimizer.all_reduce_begin(k, self.group)
         self.HF.side_join()
+        self._eager_exchanged_all = per_stage
         return losses, total, pending
 
     def __call__(self):
@@ -388,9 +410,10 @@ class GraphedPipelined:
                 losses, total, pending = self._eager()
             finally:
                 self.uninstall()
-            return losses, total, pending + self.optimizer.all_reduce_begin("late", self.group)
+            return losses, total, pending + self._late(self._eager_exchanged_all)
         main, side = torch.cuda.current_stream(), self.side
         pending, n = [], len(self.stages)
+        self._replay_per_stage = self._per_stage_exchange(n)
         ends = [None] * n
         timing = _PIPE_TIMING          # diagnostic (OMNI_PIPE_TIMING=1): device timestamps of every M_k / W_k end, see pipe_timing_report
         if timing:
@@ -401,7 +424,7 @@ class GraphedPipelined:
 
         def launch_w(k):                              # W_k starts when M_k has finished ...
             gw = self.stages[k][1]
-            if gw is None and k > 0:
+            if gw is None and k > 0 and not self._replay_per_stage:
                 return []
             side.wait_event(ends[k])
             with torch.cuda.stream(side):
@@ -413,7 +436,10 @@ class GraphedPipelined:
                         rec["host"].append(("W%d" % k, (time.perf_counter() - h0) * 1e6))
                         rec["w"][k] = torch.cuda.Event(enable_timing=True)
                         rec["w"][k].record(side)
-                # the heads' gradients are final after W_0: their all-reduce rides behind it on the side stream
+                # stage k's gradients are final after W_k: their all-reduce rides behind it on the side stream and overlaps the
+                # stages below (round 3: only the heads' ranges did, the backbone's 75 MB went out after the last stage)
+                if self._replay_per_stage:
+                    return self.optimizer.all_reduce_begin(k, self.group)
                 return self.optimizer.all_reduce_begin("early", self.group) if k == 0 else []
 
         # host order M_0, M_1, W_0, M_2, W_1, ...: the next critical-path graph is always queued on the main stream before the
@@ -446,4 +472,4 @@ class GraphedPipelined:
                     pending += launch_w(k - 1)
             pending += launch_w(n - 1)
         main.wait_stream(side)                        # ... and everything after the step waits for the last W
-        return self.losses, self.total, pending + self.optimizer.all_reduce_begin("late", self.group)
+        return self.losses, self.total, pending + self._late(self._replay_per_stage)

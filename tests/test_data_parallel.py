@@ -318,3 +318,158 @@ def test_script_ddp_wrapper_leaves_the_exchange_to_the_flat_bucket_world2(emu_li
     assert r[0]["replays"] == 2 and r[1]["replays"] == 2
     for k in range(world):
         assert r[k]["per_iter"] == [r[k]["bucket"]] * 3, (r[k]["per_iter"], r[k]["bucket"])      # one pass over the bucket per iteration
+
+
+# ---- round 4: one exchange range per backward stage -----------------------------------------------------------------------------
+def _make_staged_net():
+    """bottom_up.l0 | cut "a" | bottom_up.l1 -> features | cut | heads: three backward stages (heads, l1, l0)"""
+    from omni3d_amd.cubercnn.modeling.layers import BatchNorm2d, Conv2d, FlattenLinear, Linear
+
+    class BottomUp(torch.nn.Module):
+        stage_cut = None
+        stage_cut_at = ("a",)
+
+        def __init__(self):
+            super().__init__()
+            self.l0 = Conv2d(8, 16, 3, padding=1, bias=True)
+            self.bn0 = BatchNorm2d(16)
+            self.l1 = Conv2d(16, 16, 3, padding=1, bias=True)
+
+        def backward_stages(self):
+            return {"l0": 2, "bn0": 2, "l1": 1}
+
+        def forward(self, x):
+            x = self.bn0(self.l0(x, relu=True), relu=True)
+            if self.stage_cut is not None and self.training and torch.is_grad_enabled():
+                x = self.stage_cut(x)
+            return self.l1(x, relu=True)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Module()
+            self.backbone.bottom_up = BottomUp()
+            self.f = FlattenLinear(16, 4, 12)
+            self.l = Linear(12, 8)
+            self.feature_cut = None
+
+        def forward(self, x, packed=None):
+            feats = {"p": self.backbone.bottom_up(x)}
+            if self.feature_cut is not None:
+                feats = self.feature_cut(feats)
+            return {"loss": self.l(self.f(feats["p"], relu=True)).square().mean()}
+    torch.manual_seed(0)
+    return Net()
+
+
+def _staged_opt(net):
+    from omni3d_amd.cubercnn.solver.build import FlatSGD, grad_stage_map
+    stage_of = grad_stage_map(net)
+    for n, p in net.named_parameters():
+        p._omni_grad_stage = stage_of(n)
+    opt = FlatSGD([{"params": [p], "weight_decay": 0.0 if p.dim() == 1 else 1e-3} for p in net.parameters()], lr=0.1, momentum=0.9)
+    opt.stage_cut_signature = tuple(net.backbone.bottom_up.stage_cut_at)
+    return opt
+
+
+def _worker_staged(rank, world, port, out, mixed):
+    """mixed: rank 0 runs the staged step (an exchange behind every backward stage), rank 1 the plain loop whose step() exchanges the
+    whole bucket -- what a rank whose capture failed does (solver/autoreplay.py).  Same collective sequence, same weights."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_emulator()
+    from omni3d_amd.cubercnn.solver.graphed import GraphedPipelined
+    net = _make_staged_net()
+    opt = _staged_opt(net)
+    assert opt.n_stages == 3 and sorted(opt.stage_ranges) == [0, 1, 2]
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **kw):
+        calls.append(int(t.numel()))
+        return real(t, *a, **kw)
+    dist.all_reduce = counting
+    staged = (rank == 0) or not mixed
+    stepper = GraphedPipelined(net, opt, _shard(rank), None, graphs=False) if staged else None
+    if stepper is not None:
+        assert stepper._per_stage_exchange(3)
+    for _ in range(2):
+        if staged:
+            _, _, pending = stepper()
+            opt.all_reduce_finish(pending)
+        else:
+            opt.zero_grad()
+            net(_shard(rank))["loss"].backward()
+            opt.all_reduce_grads()
+        opt.step()
+    dist.all_reduce = real
+    torch.save({"p": {n: p.detach().clone() for n, p in net.named_parameters()}, "calls": calls}, os.path.join(out, f"st{int(mixed)}{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_per_stage_exchange_world2(emu_lib, tmp_path, mixed):
+    """three backward stages, one exchange per stage behind its backward: replicas bit-identical, equal to the plain loop, and the
+    sequence of all-reduce calls (sizes, order) is the same on a rank that runs the staged step and on one that does not"""
+    world = 2
+    mp.spawn(_worker_staged, args=(world, _free_port(), str(tmp_path), mixed), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"st{int(mixed)}{k}.pt")) for k in range(world)]
+    assert r[0]["calls"] == r[1]["calls"] and len(r[0]["calls"]) > 0
+    for n in r[0]["p"]:
+        assert torch.equal(r[0]["p"][n], r[1]["p"][n]), n
+    if not mixed:
+        mp.spawn(_worker_single_phase_staged, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+        sp = torch.load(os.path.join(tmp_path, "sps0.pt"))
+        for n in sp:
+            assert (r[0]["p"][n] - sp[n]).abs().max() <= 1e-6 * max(1.0, float(sp[n].abs().max())), n
+
+
+def _worker_single_phase_staged(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_emulator()
+    net = _make_staged_net()
+    opt = _staged_opt(net)
+    for _ in range(2):
+        opt.zero_grad()
+        net(_shard(rank))["loss"].backward()
+        opt.all_reduce_grads()
+        opt.step()
+    torch.save({n: p.detach().clone() for n, p in net.named_parameters()}, os.path.join(out, f"sps{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_stage_ranges_of_the_real_model():
+    """cubercnn_DLA34_FPN: five backward stages (heads | FPN + level 5, 4 | level 3 | level 2 .. 0 | first layer); the ranges tile the
+    bucket exactly once, every parameter sits in a range of its own stage, chunks are at most 32 MB, and what is left for after the
+    last stage is the first layer's few kB (the backbone's 75 MB used to go out after the last stage)"""
+    from oracle import make_golden as MG
+    from omni3d_amd import synthetic
+    from omni3d_amd.cubercnn.solver import build_optimizer
+    cfg = MG.product_cfg([])
+    model = MG.build_product_model(cfg, synthetic.make_priors(50), 3, device="cpu")
+    opt = build_optimizer(cfg, model)
+    assert opt.n_stages == 5 and opt.stage_cut_signature == ("stem", "p2", "p3")
+    covered = sorted(r for rs in opt.stage_ranges.values() for r in rs)
+    assert covered[0][0] == 0 and covered[-1][1] == opt.flat_grad.numel()
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    for n, p in model.named_parameters():
+        if id(p) not in opt._slot:
+            continue
+        off, cnt = opt._slot[id(p)]
+        st = p._omni_grad_stage
+        assert any(s <= off and off + cnt <= e for s, e in opt.stage_ranges[st]), (n, st)
+        if n.startswith("backbone.bottom_up.base_layer"):
+            assert st == 4
+        if n.startswith("backbone.fpn_") or n.startswith("backbone.bottom_up.level5") or n.startswith("backbone.bottom_up.level4"):
+            assert st == 1
+        if n.startswith("backbone.bottom_up.level3"):
+            assert st == 2
+        if n.startswith("roi_heads") or n.startswith("proposal_generator"):
+            assert st == 0
+    chunks = opt.exchange_chunks(range(opt.n_stages))
+    assert max(e - s for s, e in chunks) <= opt.EXCHANGE_CHUNK and sum(e - s for s, e in chunks) == opt.flat_grad.numel()
+    last = sum(e - s for s, e in opt.stage_ranges[4]) * 4
+    assert last < 10 * 2 ** 20, last                       # bytes whose exchange cannot overlap any backward work
+    by_stage = {k: sum(e - s for s, e in v) * 4 / 2 ** 20 for k, v in opt.stage_ranges.items()}
+    assert by_stage[0] > 100 and by_stage[1] > 40, by_stage   # MB: heads 117, FPN + level 5 / 4
