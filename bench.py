@@ -23,7 +23,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np
 import torch
@@ -150,7 +149,7 @@ IOU_PAIRS = int(os.environ.get("OMNI_BENCH_IOU_PAIRS", "100000"))      # BASELIN
 def run_iou3d(args, world, rank):
     """One step = one pass of box3d_overlap's work over 100k (dt, gt) pairs resident in HBM.
     Pairs are independent, so ranks shard them with no collective (weak scaling)."""
-    import boxgen
+    from omni3d_amd import boxgen
     from omni3d_amd.kernels import iou3d
     P = IOU_PAIRS
     rng = np.random.default_rng(1000 + rank)
@@ -203,7 +202,7 @@ def run_iou3d(args, world, rank):
     return res
 
 
-IOU_PMC = "r03_pmc_iou3d.csv"
+IOU_PMC = "r04_pmc_iou3d.csv" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_iou3d.csv")) else "r03_pmc_iou3d.csv"
 
 
 def cpu_baseline_iou3d(dt, gt, nsample=20000):
@@ -214,6 +213,7 @@ def cpu_baseline_iou3d(dt, gt, nsample=20000):
         return {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "skipped (OMNI_BENCH_SKIP_CPU=1)"}
     nsample = min(nsample, len(dt))
     cores = min(len(os.sched_getaffinity(0)), 64)          # OpenMP team of the all-cores leg (set before libgomp starts)
+    from omni3d_amd.profile_io import host_cores
     os.environ["OMP_NUM_THREADS"] = str(cores)
     orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
     Pt = ctypes.c_void_p
@@ -249,13 +249,28 @@ def cpu_baseline_iou3d(dt, gt, nsample=20000):
                                      ctypes.c_float(1e-8), o.ctypes.data_as(Pt))
     reps, el = timed(loop, 8.0)
     pyloop = npairs * reps / el
-    return {"value": single, "unit": "pairs/s", "cores": 1, "kind": "port",
+    return {"value": single, "unit": "pairs/s", "cores": 1, "kind": "port", "host": host_cores(),
             "sample": f"first {nsample} pairs of the same workload, oracle/iou_box3d_oracle.c, 1 thread, ~8 s",
             "openmp": {"value": omp, "cores": cores, "sample": f"same {nsample} pairs, #pragma omp parallel for, {cores} threads (the box's cgroup may grant fewer "
                                                                   "CPUs than it shows: the measured speed-up over 1 thread is what it is), ~5 s"},
             "python_loop": {"value": pyloop, "cores": 1,
                             "sample": f"{len(groups)} evaluator-shaped groups (<=100 dt x 1-8 gt, {npairs} pairs): torch.tensor + one "
                                       "box3d_overlap call per group like omni3d_evaluation.py:1339-1343, ~8 s"}}
+
+
+def extra_leg(argv, env):
+    """one more workload of this script in its own process (another model configuration is a module-level constant of bench_train);
+    -> the fields of its JSON line a reader needs, or the error"""
+    import subprocess
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "scaling", "config")
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1"] + argv, env=dict(os.environ, **env), capture_output=True,
+                             text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        r = json.loads(line)
+        return {k: r[k] for k in keep if k in r}
+    except Exception as e:  # noqa: BLE001 -- an extra leg must never take the measured line down with it
+        return {"value": None, "error": f"{type(e).__name__}: {str(e)[:200]}"}
 
 
 def main():
@@ -283,6 +298,13 @@ def main():
             if rank == 0:
                 res["iou3d"] = {k: io[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype",
                                                    "config", "roofline", "cpu_baseline")}
+            if world == 1 and DEVICE == "cuda" and os.environ.get("OMNI_BENCH_SKIP_EXTRA") != "1":
+                # the other two driver-visible numbers of the path -- inference on the same staged batch, and the
+                # training step of configs[3]'s model (cubercnn_ResNet34_FPN, N = 1, 10 steps) -- short legs in the same line
+                res["infer"] = extra_leg(["--workload", "infer", "--steps", "20", "--warmup", "3"], {})
+                res["resnet34"] = extra_leg(["--workload", "train", "--steps", "10", "--warmup", "3"],
+                                            {"OMNI_BENCH_CONFIG": "cubercnn_ResNet34_FPN.yaml", "OMNI_BENCH_SKIP_CPU": "1",
+                                             "OMNI_BENCH_SKIP_ROOFLINE": "1", "OMNI_BENCH_SKIP_DROPIN": "1"})
     observe_ranks(world, local, info)
     if rank == 0:
         res["n_gpus"] = world

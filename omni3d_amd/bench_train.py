@@ -382,10 +382,19 @@ def _time_launch(fn, iters):
     return a.elapsed_time(b) / iters
 
 
-def _table_shares(csv_name="r03_train_final_kernel_stats.csv"):
+def _latest(name):
+    """newest committed round of a profile artefact: profiles/r04_<name> if it exists, else r03_<name>"""
+    for r in ("r04", "r03"):
+        if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_{name}")):
+            return f"{r}_{name}"
+    return f"r04_{name}"
+
+
+def _table_shares(csv_name=None):
     """share of the summed kernel time per kernel symbol in the committed rocprofv3 table (+ its sha256) -> ({symbol: frac}, note)"""
     import csv
     import hashlib
+    csv_name = csv_name or _latest("train_final_kernel_stats.csv")
     path = os.path.join(ROOT, "profiles", csv_name)
     if not os.path.exists(path):
         return {}, None
@@ -409,7 +418,7 @@ def dominant_kernel_roofline(iters=20):
     to the 157.3 TFLOP/s fp32-MFMA peak is in the line (the step is a near tie between six MFMA symbols at 7-9 % each)."""
     from omni3d_amd.kernels import conv, wino
     from omni3d_amd.profile_io import profile_counters
-    PMC = "r03_pmc_families.csv"
+    PMC = _latest("pmc_families.csv")
     shares, table = _table_shares()
     B, C, H = IMS_PER_GPU, 256, 128
     x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
@@ -421,11 +430,13 @@ def dominant_kernel_roofline(iters=20):
     flops_direct = 2.0 * B * H * H * C * C * 9
     ms_wino = _time_launch(lambda: wino.conv3x3_fwd(x, w, tile=4), iters)
 
-    def fam(name, kernel, shape, fl, fn, pmc_key=None, grid=None, alg_bytes=None):
+    def fam(name, kernel, shape, fl, fn, pmc_key=None, grid=None, alg_bytes=None, per_step=None):
         t = _time_launch(fn, max(iters // 2, 5))
         sym = kernel.split("(")[0]
         r = {"family": name, "kernel": kernel, "shape": shape, "gflop": fl / 1e9, "kernel_ms": t, "tflops": fl / (t * 1e-3) / 1e12,
              "frac": fl / (t * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "share_of_kernel_time_in_table": shares.get(sym)}
+        if per_step is not None:
+            r["launches_per_step"] = per_step
         if alg_bytes is not None:
             r["algorithmic_bytes_per_launch"] = alg_bytes
         c = profile_counters(PMC, pmc_key or kernel.split("<")[0], grid)
@@ -452,16 +463,16 @@ def dominant_kernel_roofline(iters=20):
     fl4 = 2.0 * 36 * 256 * 256 * 256
     families = [
         fam("Winograd point GEMMs, 128x128 maps (FPN output / RPN conv at p2: 4 launches / step, the heaviest shape of this symbol)", "gemm_nt_pf_kernel<4>", "36x[4096x256]x[256x256]^T (3x3 256->256 @128x128)", flops,
-            lambda: wino.gemm_batched(V, U), grid=2359296, alg_bytes=4.0 * (2 * P * T * C + P * C * C)),
+            lambda: wino.gemm_batched(V, U), grid=2359296, alg_bytes=4.0 * (2 * P * T * C + P * C * C), per_step=4),
         fam("Winograd point GEMMs, small maps (DLA level 4: 18 launches / step)", "gemm_nt_pf_kernel<4>",
             "36x[256x256]x[256x256]^T (3x3 256->256 @32x32, F(4x4,3x3))", fl4, lambda: wino.gemm_batched(V4, U4), grid=147456,
-            alg_bytes=4.0 * (2 * 36 * 256 * 256 + 36 * 256 * 256)),
+            alg_bytes=4.0 * (2 * 36 * 256 * 256 + 36 * 256 * 256), per_step=18),
         fam("Winograd point GEMMs, small maps (DLA level 3: 14 launches / step)", "gemm_nt_pf_kernel<4>",
             "36x[1024x128]x[128x128]^T (3x3 128->128 @64x64, F(4x4,3x3))", fl3, lambda: wino.gemm_batched(V3, U3), grid=294912,
-            alg_bytes=4.0 * (2 * 36 * 1024 * 128 + 36 * 128 * 128)),
+            alg_bytes=4.0 * (2 * 36 * 1024 * 128 + 36 * 128 * 128), per_step=14),
         fam("Winograd point GEMMs, 64x64 maps (FPN / RPN p3)", "gemm_nt_pf_kernel<4>",
             "36x[1024x256]x[256x256]^T (3x3 256->256 @64x64, F(4x4,3x3))", 2.0 * 36 * 1024 * 256 * 256,
-            lambda: wino.gemm_batched(V5, U4), grid=589824, alg_bytes=4.0 * (2 * 36 * 1024 * 256 + 36 * 256 * 256)),
+            lambda: wino.gemm_batched(V5, U4), grid=589824, alg_bytes=4.0 * (2 * 36 * 1024 * 256 + 36 * 256 * 256), per_step=4),
         fam("Winograd weight-gradient GEMMs", "gemm_tn_pf_kernel<4>", "36x[256x4096]x[4096x256] (same layer)", flops,
             lambda: wino.gemm_batched_wgrad(V, dM), grid=147456),      # (PMC: the three weight-gradient shapes share the geometry
                                                                         #  576 workgroups -> one averaged row)
@@ -490,7 +501,16 @@ def dominant_kernel_roofline(iters=20):
     top = max(shares, key=shares.get) if shares else None
     head = next((f for f in families if top is not None and f["kernel"].split("(")[0] == top), families[0])
     traffic = head.get("pmc_traffic_bytes")
+    # `frac` is the symbol's BEST (and heaviest) shape; the same symbol over all of its shapes of a step, weighted
+    # by launches per step, and the launch-weighted mean over every family listed below
+    same = [f for f in families if f["kernel"] == head["kernel"] and f.get("launches_per_step")]
+    sym_w = (sum(f["gflop"] * f["launches_per_step"] for f in same) / max(sum(f["kernel_ms"] * f["launches_per_step"] for f in same), 1e-9)
+             / FP32_MFMA_PEAK_TF) if same else None
     return {"bound": "mfma",
+            "frac_symbol_weighted": sym_w,
+            "frac_symbol_weighted_note": "same kernel symbol over %d launches / step of %d shapes (flops x launches / time x launches of the "
+                                         "families below that carry `launches_per_step`); `frac` is its heaviest shape" % (
+                                             sum(f["launches_per_step"] for f in same), len(same)) if same else None,
             "kernel": f"{head['kernel']} on {head['shape']} [{head['family']}]"
                       + (f" -- tops {table} with {shares[top]:.1%} of the summed kernel time" if top == head["kernel"].split("(")[0] else ""),
             "achieved": head["tflops"], "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": head["frac"],

@@ -84,3 +84,26 @@ class ExecutedFlops:
             N, H, W, C, K, R = a[3:9]
             return 2.0 * N * H * W * K * R * R * C
         return 0.0
+
+
+def host_cores():
+    """what the box's host really offers (SURVEY.md 8d asks for the physical core count next to a CPU baseline): logical CPUs the
+    OS shows, CPUs this process may run on, physical cores (distinct (package, core id) pairs of /proc/cpuinfo) and sockets"""
+    import os
+    info = {"logical_cpus": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "physical_cores": None, "sockets": None, "model": None}
+    try:
+        cores, pk = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pk = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cores.add((pk, line.split(":")[1].strip()))
+            elif line.startswith("model name") and info["model"] is None:
+                info["model"] = line.split(":")[1].strip()
+        if cores:
+            info["physical_cores"] = len(cores)
+            info["sockets"] = len({c[0] for c in cores})
+    except OSError:
+        pass
+    return info

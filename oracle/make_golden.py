@@ -340,7 +340,7 @@ def main_evalfull(seed=5, images=40, cats=3):
     import numpy as np
     H.install()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import boxgen
+    from omni3d_amd import boxgen
     from cubercnn.evaluation.omni3d_evaluation import Omni3Deval
     from omni3d_amd.cubercnn.evaluation import AnnotationIndex          # duck-typed COCO API (4 methods), no arithmetic
     np.float = float                                                     # the reference still uses the alias numpy 2 removed (:1265)

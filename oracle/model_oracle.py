@@ -365,7 +365,12 @@ def time_training(priors, batches=(2, 4), size=512, warmup=3, timed=10, budget_s
         med = kept[len(kept) // 2]
         per_batch[images] = {"images_per_s": images / med, "median_s_per_iter": med, "warmup": warmup, "timed": len(kept)}
     head = per_batch[batches[-1]]          # the batch BASELINE's metric is quoted on (4 / GPU)
-    return {"value": head["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port",
+    try:
+        from omni3d_amd.profile_io import host_cores
+        host = host_cores()
+    except Exception:  # noqa: BLE001
+        host = None
+    return {"value": head["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port", "host": host,
             "by_batch": {str(k): v for k, v in per_batch.items()},
             "sample": f"oracle/model_oracle.py (plain-PyTorch CPU port of the reference path, pinned to fixtures written by the reference's own "
                       f"files), {size}x{size}, fwd+10 losses+bwd+SGD; `value` = batch {batches[-1]}: median of {head['timed']} timed iterations "
