@@ -14,7 +14,6 @@
 // backward scatter is a coalesced run of fp32 atomics.  Output is (R, P, P, C): with KRSC weights the
 // following fc1 is a PxP "valid" convolution whose reduction index is contiguous on both operands.
 #include <device_rt.h>
-#include "split_reduce.h"
 #pragma clang fp contract(off)
 
 namespace {
@@ -272,27 +271,25 @@ __global__ void __launch_bounds__(256) roi_align_bwd_sep_kernel(FeatLevels fl, c
 }
 
 // ---- deterministic backward (round 4): the OUTPUT owns the sum ------------------------------------------------------------
-// The scatter above is bound by ~1.2e8 fp32 atomics per step and the order in which they land -- hence the rounding of every
-// feature-gradient element that several ROIs touch -- changes from run to run.  Here one wave owns an 8 x 8 pixel tile of one
-// (level, image) and 64 channels (lane = channel, 64 accumulators in registers); the workgroup (4 waves = 4 channel groups of
-// the same tile) lists the ROIs of that image and level whose footprint meets the tile, IN ROI ORDER, and every wave adds their
-// contributions one after the other with the same separable arithmetic as the scatter kernel.  Each element of dfeat is written
-// exactly once (no zero-fill in front, no atomics), and the sum over ROIs always runs in ascending ROI index.
+// The scatter above is bound by ~7e7 fp32 atomics per step and the order in which they land -- hence the rounding of every
+// feature-gradient element that several ROIs touch -- changes from run to run.  Here the output owns the sum: a workgroup owns a
+// 16 x 8 pixel region of one (level, image) and lists the ROIs of that image and level whose footprint meets it, IN ROI ORDER;
+// each of its four waves owns an 8 x 4 pixel tile of the region across ALL channels (lane = 4 channels, 32 float4 accumulators in
+// registers) and adds the ROIs' contributions one after the other with the same separable arithmetic as the scatter kernel.  Each
+// element of dfeat is written exactly once (no zero-fill in front, no atomics); the sum over ROIs runs in ascending ROI index.
+// Measured first (one wave per 8 x 8 tile and 64 channels, one channel per lane): 0.65 ms against 0.29 ms for the scatter -- 49
+// four-byte-per-lane loads per (tile, ROI, channel group), 0.5 GB through 256-byte transactions, were 85 % of it (the ROIs of the
+// benchmark are ~10 x 6 pixels on p2 and touch ~5 tiles each).  Hence float4 lanes (1 KiB per load instruction) and loads only
+// for the bins that carry weight on this tile.
 struct GatherTiles {
-    int off[MAXL + 1];        // first tile of each level in the 1-D grid
-    int tx[MAXL], ty[MAXL];   // 8 x 8 tiles per image along x / y
+    int off[MAXL + 1];        // first region of each level in the 1-D grid
+    int tx[MAXL], ty[MAXL];   // regions per image along x / y
     int B;
 };
-constexpr int GT_TILE = 8, GT_MAXR = 4096;
-// GT_NSEG > 1: up to GT_NSEG workgroups share a tile with a long ROI list -- every one of them builds the same ordered list, takes a
-// contiguous chunk of it (>= GT_CHUNK ROIs each), and the partial tiles meet in a workspace slot per (tile, segment), summed in
-// segment order by the last arrival (the ordered-split scheme of split_reduce.h).  Measured on MI355X with 8 segments: 532 -> 1110 us
-// per step -- the kernel is bound by VALU issue (140 k (tile, ROI, channel group) jobs of ~1.7 k instructions), not by its tail, and
-// half of the tiles then pay 0.5 MB of slot traffic -- so the shipped configuration is one workgroup per tile.
-constexpr int GT_NSEG = 1, GT_CHUNK = 12;
+constexpr int GT_RW = 16, GT_RH = 8, GT_TW = 8, GT_TH = 4, GT_MAXR = 4096;
 
-// per ROI, once: (image << 8 | level, or -1 for an empty sampling grid), footprint rows Y0 | Y1 << 16, columns X0 | X1 << 16 -- what
-// every tile's list building compares against (10 k workgroups each recomputing 2048 footprints was most of the first version's time)
+// per ROI, once: (image << 8 | level, or -1 for an empty sampling grid), footprint rows Y0 | Y1 << 16, columns X0 | X1 << 16, sampling
+// grid gh | gw << 16 -- what every region's list building compares against -- and the ROI's start / bin size on its level
 template <int PP>
 __global__ void roi_footprint_kernel(FeatLevels fl, const float* __restrict__ rois, const int* __restrict__ batch_idx,
                                      const int* __restrict__ levels, int R, int4* __restrict__ fp, float4* __restrict__ par) {
@@ -313,41 +310,37 @@ __global__ void roi_footprint_kernel(FeatLevels fl, const float* __restrict__ ro
         o = make_int4((batch_idx[r] << 8) | l, Y0 | (Y1 << 16), X0 | (X1 << 16), gh | (gw << 16));
     }
     fp[r] = o;
-    par[2 * r] = make_float4(sw, sh, bin_w, bin_h);
-    par[2 * r + 1] = make_float4(gh > 0 ? bin_h / (float)gh : 0.f, gw > 0 ? bin_w / (float)gw : 0.f, (gh > 0 && gw > 0) ? 1.f / (float)(gh * gw) : 0.f, 0.f);
+    par[r] = make_float4(sw, sh, bin_w, bin_h);
 }
 
 template <int PP>
 __global__ void __launch_bounds__(256) roi_align_bwd_gather_kernel(FeatLevels fl, GatherTiles gt, const float* __restrict__ rois,
-                                                                   const int* __restrict__ batch_idx, const int* __restrict__ levels,
                                                                    int R, int C, const float* __restrict__ dout,
                                                                    const float* __restrict__ dout2, int per_image, int first,
-                                                                   float* __restrict__ ws, unsigned* __restrict__ ctr,
                                                                    const int4* __restrict__ fp, const float4* __restrict__ par) {
     __shared__ unsigned char s_hit[GT_MAXR];
     __shared__ unsigned short s_list[GT_MAXR];
     __shared__ int s_count;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // coarsest level first: its few tiles carry the longest ROI lists and should not be the launch's tail
-    const int tile_id = gt.off[MAXL] - 1 - (int)blockIdx.x / GT_NSEG, seg = (int)blockIdx.x % GT_NSEG;
+    // coarsest level first: its few regions carry the longest ROI lists and should not be the launch's tail
+    const int region = gt.off[MAXL] - 1 - (int)blockIdx.x;
     int l = 0;
-    while (l + 1 < fl.nlev && tile_id >= gt.off[l + 1]) ++l;
-    int t = tile_id - gt.off[l];
-    const int tix = t % gt.tx[l]; t /= gt.tx[l];
-    const int tiy = t % gt.ty[l];
+    while (l + 1 < fl.nlev && region >= gt.off[l + 1]) ++l;
+    int t = region - gt.off[l];
+    const int rix = t % gt.tx[l]; t /= gt.tx[l];
+    const int riy = t % gt.ty[l];
     const int n = t / gt.ty[l];
     const int H = fl.H[l], W = fl.W[l];
-    const float sc = fl.scale[l];
-    const int ty0 = tiy * GT_TILE, tx0 = tix * GT_TILE;
-    // -- 1. which ROIs touch this tile (every thread tests R / 256 precomputed footprints)
+    const int ry0 = riy * GT_RH, rx0 = rix * GT_RW;
+    // -- 1. which ROIs touch this region (every thread tests R / 256 precomputed footprints), compacted in ascending ROI index
     const int key = (n << 8) | l;
     for (int r = tid; r < R; r += 256) {
         const int4 f = fp[r];
         const int Y0 = f.y & 0xffff, Y1 = f.y >> 16, X0 = f.z & 0xffff, X1 = f.z >> 16;
-        s_hit[r] = (f.x == key && Y0 < ty0 + GT_TILE && Y1 >= ty0 && X0 < tx0 + GT_TILE && X1 >= tx0) ? 1 : 0;
+        s_hit[r] = (f.x == key && Y0 < ry0 + GT_RH && Y1 >= ry0 && X0 < rx0 + GT_RW && X1 >= rx0) ? 1 : 0;
     }
     __syncthreads();
-    if (wave == 0) {                                          // ordered compaction: ascending ROI index
+    if (wave == 0) {
         int count = 0;
         for (int base = 0; base < R; base += 64) {
             const int r = base + lane;
@@ -359,112 +352,98 @@ __global__ void __launch_bounds__(256) roi_align_bwd_gather_kernel(FeatLevels fl
         if (lane == 0) s_count = count;
     }
     __syncthreads();
-    const int total = s_count;
-    const int nseg = min(GT_NSEG, max(1, (total + GT_CHUNK - 1) / GT_CHUNK));
-    if (seg >= nseg) return;
-    const int q_begin = (int)((long)seg * total / nseg), count = (int)((long)(seg + 1) * total / nseg);
-    // From here on the four waves are independent (no workgroup barrier): each owns one 64-channel group of the tile.  The
-    // tile-local weight tables of a ROI live in two registers -- lane 8 * yy + ph holds WY[yy][ph], the summed y-weights of bin
-    // ph's samples on tile row yy (same for x) -- and reach the FMAs as wave-uniform scalars through v_readlane.
-    const int tr = lane >> 3, tb = lane & 7;                  // this lane's (tile row / column, bin) of the weight registers
-    {                                                         // wave = channel group (C <= 256; a wave past C idles but arrives)
-        const int c = wave * 64 + lane;
-        const bool cok = c < C;
-        float acc[GT_TILE * GT_TILE];
+    const int count = s_count;
+    // -- 2. from here on the four waves are independent: wave = one 8 x 4 tile of the region, lane = 4 channels.  The tile-local
+    // weights of a ROI live in two registers -- lane 8 * yy + ph holds WY[yy][ph], the summed y-weights of bin ph's samples on tile
+    // row yy; lane 8 * xx + pw the same for x -- and reach the FMAs as wave-uniform scalars through v_readlane.
+    const int ty0 = ry0 + GT_TH * (wave >> 1), tx0 = rx0 + GT_TW * (wave & 1);
+    const int tr = lane >> 3, tb = lane & 7;
+    const int c = 4 * lane;
+    const bool cok = c < C;
+    float4 acc[GT_TH * GT_TW];
 #pragma unroll
-        for (int i = 0; i < GT_TILE * GT_TILE; ++i) acc[i] = 0.f;
-        for (int q = q_begin; q < count; ++q) {
-            const int r = s_list[q];
-            // the 49 bin gradients of this lane's channel first: their latency covers the weight arithmetic below
-            const float* o = (dout != nullptr && cok) ? dout + (long)r * PP * PP * C + c : nullptr;
-            const float* o2 = nullptr;
-            if (dout2 != nullptr && cok) {
-                const int img = r / per_image, k = r - img * per_image;
-                if (k < first) o2 = dout2 + ((long)img * first + k) * PP * PP * C + c;
-            }
-            float g[PP][PP];
-#pragma unroll
-            for (int ph = 0; ph < PP; ++ph)
-#pragma unroll
-                for (int pw = 0; pw < PP; ++pw) {
-                    float v = o != nullptr ? o[(long)(ph * PP + pw) * C] : 0.f;
-                    if (o2 != nullptr) v += o2[(long)(ph * PP + pw) * C];
-                    g[ph][pw] = v;
-                }
-            // per-ROI constants from roi_footprint_kernel (same expressions as the scatter kernel: sample positions are bit-equal)
-            const float4 pa = par[2 * r], pb = par[2 * r + 1];
-            const float sw = pa.x, sh = pa.y, bin_w = pa.z, bin_h = pa.w;
-            const int ghw = fp[r].w, gh = ghw & 0xffff, gw = ghw >> 16;
-            float wyv = 0.f, wxv = 0.f;
-            if (tb < PP) {
+    for (int i = 0; i < GT_TH * GT_TW; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < count; ++q) {
+        const int r = s_list[q];
+        const int4 f = fp[r];
+        // (tile-level test first: a ROI of the region's list may miss this wave's tile altogether)
+        if ((f.y & 0xffff) >= ty0 + GT_TH || (f.y >> 16) < ty0 || (f.z & 0xffff) >= tx0 + GT_TW || (f.z >> 16) < tx0) continue;
+        const float4 pa = par[r];
+        const float sw = pa.x, sh = pa.y, bin_w = pa.z, bin_h = pa.w;
+        const int gh = f.w & 0xffff, gw = f.w >> 16;
+        float wyv = 0.f, wxv = 0.f;
+        if (tb < PP) {
+            if (tr < GT_TH)
                 for (int iy = 0; iy < gh; ++iy) {             // samples in ascending order, like the scatter kernel's table build
                     const Tap1 tp = make_tap1(sh + (float)tb * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh, H);
                     if (!tp.ok) continue;
                     if (tp.lo - ty0 == tr) wyv += tp.wlo;
                     if (tp.hi - ty0 == tr) wyv += tp.whi;
                 }
-                for (int ix = 0; ix < gw; ++ix) {
-                    const Tap1 tp = make_tap1(sw + (float)tb * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw, W);
-                    if (!tp.ok) continue;
-                    if (tp.lo - tx0 == tr) wxv += tp.wlo;
-                    if (tp.hi - tx0 == tr) wxv += tp.whi;
-                }
+            for (int ix = 0; ix < gw; ++ix) {
+                const Tap1 tp = make_tap1(sw + (float)tb * bin_w + ((float)ix + 0.5f) * bin_w / (float)gw, W);
+                if (!tp.ok) continue;
+                if (tp.lo - tx0 == tr) wxv += tp.wlo;
+                if (tp.hi - tx0 == tr) wxv += tp.whi;
             }
-            const float inv_count = pb.z;
-            // rows / columns of the tile this ROI has any weight on (a ROI usually covers part of the tile): one scalar test each
-            // instead of a test per (row, bin); inside an active row the arithmetic is branch-free
-            const unsigned long long ymask = __ballot(wyv != 0.f), xmask = __ballot(wxv != 0.f);
-            float wxs[GT_TILE][PP];
+        }
+        const unsigned long long ymask = __ballot(wyv != 0.f), xmask = __ballot(wxv != 0.f);
+        if (ymask == 0 || xmask == 0) continue;
+        // bins (rows ph / columns pw of the 7 x 7 grid) that carry weight on this tile
+        unsigned phm = 0, pwm = 0;
 #pragma unroll
-            for (int xx = 0; xx < GT_TILE; ++xx)
-#pragma unroll
-                for (int pw = 0; pw < PP; ++pw) wxs[xx][pw] = omni_readlane(wxv, xx * 8 + pw);       // wave-uniform (SGPRs)
-            {
+        for (int k = 0; k < 8; ++k) { phm |= (unsigned)(ymask >> (8 * k)) & 0x7fu; pwm |= (unsigned)(xmask >> (8 * k)) & 0x7fu; }
+        const float inv_count = 1.f / (float)(gh * gw);
+        const float* o = (dout != nullptr && cok) ? dout + (long)r * PP * PP * C + c : nullptr;
+        const float* o2 = nullptr;
+        if (dout2 != nullptr && cok) {
+            const int img = r / per_image, k = r - img * per_image;
+            if (k < first) o2 = dout2 + ((long)img * first + k) * PP * PP * C + c;
+        }
+        {
 #pragma clang fp contract(fast)
 #pragma unroll
-                for (int yy = 0; yy < GT_TILE; ++yy) {
-                    if (((ymask >> (8 * yy)) & 0x7fULL) == 0) continue;
-                    float rowT[PP];
+            for (int ph = 0; ph < PP; ++ph) {
+                if (!((phm >> ph) & 1u)) continue;
+                float4 g[PP];
 #pragma unroll
-                    for (int pw = 0; pw < PP; ++pw) rowT[pw] = 0.f;
+                for (int pw = 0; pw < PP; ++pw) {
+                    g[pw] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if ((pwm >> pw) & 1u) {
+                        if (o != nullptr) g[pw] = *reinterpret_cast<const float4*>(o + (long)(ph * PP + pw) * C);
+                        if (o2 != nullptr) {
+                            const float4 v2 = *reinterpret_cast<const float4*>(o2 + (long)(ph * PP + pw) * C);
+                            g[pw].x += v2.x; g[pw].y += v2.y; g[pw].z += v2.z; g[pw].w += v2.w;
+                        }
+                    }
+                }
+                // T[xx] = sum_pw WX[xx][pw] * g[ph][pw], then acc[yy][xx] += WY[yy][ph] / count * T[xx]
 #pragma unroll
-                    for (int ph = 0; ph < PP; ++ph) {
-                        const float w = omni_readlane(wyv, yy * 8 + ph) * inv_count;
+                for (int xx = 0; xx < GT_TW; ++xx) {
+                    if (((xmask >> (8 * xx)) & 0x7fULL) == 0) continue;
+                    float4 T = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int pw = 0; pw < PP; ++pw) rowT[pw] += w * g[ph][pw];
+                    for (int pw = 0; pw < PP; ++pw) {
+                        const float w = omni_readlane(wxv, xx * 8 + pw);
+                        T.x += w * g[pw].x; T.y += w * g[pw].y; T.z += w * g[pw].z; T.w += w * g[pw].w;
                     }
 #pragma unroll
-                    for (int xx = 0; xx < GT_TILE; ++xx) {
-                        if (((xmask >> (8 * xx)) & 0x7fULL) == 0) continue;
-                        float v = 0.f;
-#pragma unroll
-                        for (int pw = 0; pw < PP; ++pw) v += wxs[xx][pw] * rowT[pw];
-                        acc[yy * GT_TILE + xx] += v;
+                    for (int yy = 0; yy < GT_TH; ++yy) {
+                        const float w = omni_readlane(wyv, yy * 8 + ph) * inv_count;
+                        float4& a = acc[yy * GT_TW + xx];
+                        a.x += w * T.x; a.y += w * T.y; a.z += w * T.z; a.w += w * T.w;
                     }
                 }
             }
         }
-        if (nseg > 1) {
-            // partial tile of this segment -> slot (tile, segment); the last arrival adds the segments in order
-            float* slot = ws + ((long)tile_id * GT_NSEG) * (GT_TILE * GT_TILE * 256) + tid;
+    }
+    if (cok) {
+        float* feat = fl.f[l] + (long)n * H * W * C + c;
 #pragma unroll
-            for (int i = 0; i < GT_TILE * GT_TILE; ++i) OMNI_ST_AGENT(slot + ((long)seg * GT_TILE * GT_TILE + i) * 256, acc[i]);
-            if (!omni_split_arrive(ctr + tile_id, nseg)) return;
+        for (int yy = 0; yy < GT_TH; ++yy)
 #pragma unroll
-            for (int i = 0; i < GT_TILE * GT_TILE; ++i) acc[i] = 0.f;
-            for (int sg = 0; sg < nseg; ++sg) {
-#pragma unroll
-                for (int i = 0; i < GT_TILE * GT_TILE; ++i) acc[i] += OMNI_LD_AGENT(slot + ((long)sg * GT_TILE * GT_TILE + i) * 256);
-            }
-        }
-        if (cok) {
-            float* feat = fl.f[l] + (long)n * H * W * C + c;
-#pragma unroll
-            for (int yy = 0; yy < GT_TILE; ++yy)
-#pragma unroll
-                for (int xx = 0; xx < GT_TILE; ++xx)
-                    if (ty0 + yy < H && tx0 + xx < W) feat[((long)(ty0 + yy) * W + tx0 + xx) * C] = acc[yy * GT_TILE + xx];
-        }
+            for (int xx = 0; xx < GT_TW; ++xx)
+                if (ty0 + yy < H && tx0 + xx < W) *reinterpret_cast<float4*>(feat + ((long)(ty0 + yy) * W + tx0 + xx) * C) = acc[yy * GT_TW + xx];
     }
 }
 
@@ -525,37 +504,43 @@ static int roi_align_bwd_impl(const void* const* dlevel_ptrs, const int* level_h
     return omni_launch_status();
 }
 
-// Deterministic form of omni_roi_align_bwd2 (P == 7, R <= 4096, C <= 256, B images): dlevel_ptrs[l] (B, H_l, W_l, C) are
-// OVERWRITTEN -- every element exactly once, by the wave that owns its 8 x 8 tile, which adds the contributions of the ROIs in
-// ascending ROI index (long ROI lists: in up to 8 contiguous chunks whose partial tiles meet in `ws` and are added in chunk order;
-// ctr: n_ctr zeroed counters, left zeroed).  No zero-fill by the caller, no atomics on the gradients; two runs give bit-identical
-// feature gradients.  plan != NULL: plan[2] = counters, plan[3] = workspace floats needed; nothing is launched.
+// Deterministic form of omni_roi_align_bwd2 (P == 7, R <= 4096, C <= 256, B <= 255 images): dlevel_ptrs[l] (B, H_l, W_l, C) are
+// OVERWRITTEN -- every element exactly once, by the wave that owns its 8 x 4 tile, which adds the contributions of the ROIs in
+// ascending ROI index.  No zero-fill by the caller, no atomics; two runs give bit-identical feature gradients.  ws: scratch for
+// the per-ROI footprint records (plan != NULL: plan[3] = floats needed, nothing is launched); ctr / n_ctr are unused.
 int omni_roi_align_bwd_det(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev, int B,
                            const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, const float* dout,
                            const float* dout2, int per_image, int first, float* ws, long long ws_floats, int* ctr, int n_ctr,
                            long long* plan, void* stream) {
-    if (nlev <= 0 || nlev > MAXL || (C & 3) || C > 256 || P != 7 || B <= 0 || R < 0 || R > GT_MAXR || (dout == nullptr && dout2 == nullptr)) return OMNI_ERR_ARG;
+    (void)ctr; (void)n_ctr;
+    if (nlev <= 0 || nlev > MAXL || (C & 3) || C > 256 || P != 7 || B <= 0 || B > 255 || R < 0 || R > GT_MAXR || (dout == nullptr && dout2 == nullptr)) return OMNI_ERR_ARG;
     if (dout2 != nullptr && (per_image <= 0 || first < 0 || first > per_image || R % per_image != 0)) return OMNI_ERR_ARG;
     FeatLevels fl = make_feat(dlevel_ptrs, level_hw, level_scale, nlev);
     GatherTiles gt;
     int total = 0;
-    for (int l = 0; l < MAXL; ++l) { gt.off[l] = total; gt.tx[l] = gt.ty[l] = 1; if (l < nlev) { gt.tx[l] = (fl.W[l] + GT_TILE - 1) / GT_TILE; gt.ty[l] = (fl.H[l] + GT_TILE - 1) / GT_TILE; total += B * gt.tx[l] * gt.ty[l]; } }
-    gt.off[MAXL] = total;
+    for (int l = 0; l < MAXL; ++l) {
+        gt.off[l] = total;
+        gt.tx[l] = gt.ty[l] = 1;
+        if (l < nlev) {
+            if (fl.H[l] > 65535 || fl.W[l] > 65535) return OMNI_ERR_ARG;
+            gt.tx[l] = (fl.W[l] + GT_RW - 1) / GT_RW;
+            gt.ty[l] = (fl.H[l] + GT_RH - 1) / GT_RH;
+            total += B * gt.tx[l] * gt.ty[l];
+        }
+    }
     for (int l = nlev; l <= MAXL; ++l) gt.off[l] = total;
     gt.B = B;
-    const long long slots = (long long)total * GT_NSEG * GT_TILE * GT_TILE * 256;
-    const long long need = slots + 12LL * R;                  // + the per-ROI records: int4 footprint, 2 x float4 parameters
-    if (plan != nullptr) { plan[0] = plan[1] = 0; plan[2] = total; plan[3] = need; return OMNI_OK; }
+    const long long need = 8LL * R + 4;                       // per-ROI records: int4 footprint + float4 parameters
+    if (plan != nullptr) { plan[0] = plan[1] = plan[2] = 0; plan[3] = need; return OMNI_OK; }
     if (total == 0) return OMNI_OK;
-    if (ws == nullptr || ctr == nullptr || ws_floats < need || n_ctr < total) return OMNI_ERR_ARG;
-    int4* fp = reinterpret_cast<int4*>(ws + slots);           // (slots is a multiple of 4 floats: 16-byte aligned like ws)
-    float4* par = reinterpret_cast<float4*>(ws + slots + 4LL * R);
+    if (ws == nullptr || ws_floats < need) return OMNI_ERR_ARG;
+    int4* fp = reinterpret_cast<int4*>(ws);
+    float4* par = reinterpret_cast<float4*>(ws + 4LL * R);
     if (R > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_footprint_kernel<7>), dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, fl, rois, batch_idx,
                            levels, R, fp, par);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_bwd_gather_kernel<7>), dim3((unsigned)total * GT_NSEG), dim3(256), 0, (hipStream_t)stream, fl,
-                       gt, rois, batch_idx, levels, R, C, dout, dout2, per_image, first, ws, (unsigned*)ctr, (const int4*)fp,
-                       (const float4*)par);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_bwd_gather_kernel<7>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, fl, gt, rois, R,
+                       C, dout, dout2, per_image, first, (const int4*)fp, (const float4*)par);
     return omni_launch_status();
 }
 
