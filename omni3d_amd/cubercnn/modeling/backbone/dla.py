@@ -243,6 +243,7 @@ class DLABackbone(Backbone):
         self._out_feature_strides = {"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64}
         self._out_features = ["p2", "p3", "p4", "p5", "p6"]
 
+    fwd_split = None      # solver/graphed.py GraphedPipelined: callable run once between level 1 and level 2 while a step is captured
     stage_cut = None      # solver/graphed.py GraphedPipelined: backward is cut between the levels (x -> detached copy of x)
     # a cut at level k needs the cuts at all lower levels (see GraphedPipelined).  Measured optimum; "stem" (round 3): the main stream
     # used to wait 0.39 ms for the last weight-gradient graph after its own last kernel, 0.20 ms with the first layer as its own stage
@@ -268,6 +269,8 @@ class DLABackbone(Backbone):
         # ("stem": the first layer's backward -- a BatchNorm backward and a 0.33 ms weight gradient, nothing below it -- as a stage of
         # its own, so the weight gradients of level 2 .. level 0 run beside it instead of after it)
         x = self.level1(self.level0(cut("stem", self.base_layer(x))))
+        if self.fwd_split is not None:       # solver/graphed.py: the forward graph is cut here (no Winograd layer above this point)
+            self.fwd_split()
         p2 = cut("p2", self.level2(x))
         p3 = cut("p3", self.level3(p2))
         p4 = cut("p4", self.level4(p3))

@@ -322,14 +322,19 @@ class GraphedPipelined:
         try:
             stages, pool_m, pool_w = [], None, None
             self._held = []                 # closures + their inputs: kept for the lifetime of the graphs (see class docstring)
+            self.prologue = None
             while True:
                 gm = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gm, pool=pool_m, capture_error_mode="thread_local"), detmode.domain("M"):
-                    if not stages:
-                        self.losses, self.total = self._stage0()
-                    else:
-                        self.cuts.backward_last()
-                pool_m = gm.pool()
+                if not stages and self._split_forward(bottom_up):
+                    gm = self._capture_stage0_split(bottom_up)
+                    pool_m = gm.pool()
+                else:
+                    with torch.cuda.graph(gm, pool=pool_m, capture_error_mode="thread_local"), detmode.domain("M"):
+                        if not stages:
+                            self.losses, self.total = self._stage0()
+                        else:
+                            self.cuts.backward_last()
+                    pool_m = gm.pool()
                 fns, keep = HF.side_take()
                 gw = None
                 if fns:
@@ -347,6 +352,51 @@ class GraphedPipelined:
         finally:
             HF.side_take()
             HF.side_mode(prev_mode)
+
+    # ---- round 4: the head of the forward pass ---------------------------------------------------------------------------------
+    # The Winograd filter transforms of a pass (one launch, 260 MB moved, ~0.13 ms) sat at the very start of the critical path while
+    # the weight-gradient stream idles through all of forward.  Stage 0 is therefore captured as THREE graphs: P (the transforms,
+    # replayed on the side stream), M0a (zero_grad, preprocessing, stem, DLA level 0 / 1 -- no Winograd layer in there) and M0b
+    # (the rest of stage 0), which starts behind both.  The forward is cut by a callable the bottom-up runs between level 1 and 2.
+    # MEASURED and left OFF (OMNI_PIPE_PROLOGUE=1 enables it): 11.718 ms with and without.  The trace shows why: the head of M0a is
+    # itself HBM-bound (the 191 MB zero-fill of the gradient bucket 25 -> 81 us, preprocessing 8 -> 31 us beside the transform's 260 MB),
+    # so the first Winograd layer starts 7 us earlier, not 130 (profiles/r04_ab_prologue.log).
+    @staticmethod
+    def _split_forward(bottom_up):
+        import os
+        return (bottom_up is not None and hasattr(type(bottom_up), "fwd_split") and os.environ.get("OMNI_PIPE_PROLOGUE", "0") != "0")
+
+    def _capture_stage0_split(self, bottom_up):
+        from ...kernels import detmode
+        HF = self.HF
+        gp, ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(gp, capture_error_mode="thread_local"), detmode.domain("W"):
+            pre = HF.wino_pretransform(self.model)
+        self._held.append((pre,))
+        state = {"done": False}
+
+        def split():
+            if not state["done"]:
+                state["done"] = True
+                ga.capture_end()
+                gb.capture_begin(pool=pool, capture_error_mode="thread_local")
+        torch.cuda.synchronize()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        bottom_up.fwd_split = split
+        try:
+            with torch.cuda.stream(cap), detmode.domain("M"), HF.wino_preloaded(pre):
+                ga.capture_begin(pool=pool, capture_error_mode="thread_local")
+                self.losses, self.total = self._stage0()
+                if not state["done"]:
+                    raise RuntimeError("the forward pass never reached its split point")
+                gb.capture_end()
+        finally:
+            bottom_up.fwd_split = None
+        torch.cuda.current_stream().wait_stream(cap)
+        self.prologue = (gp, ga)
+        return gb
 
     def _install(self):
         """the model cuts its forward at THIS object's cut points (several captured steps may exist side by side -- one per size
@@ -421,6 +471,15 @@ class GraphedPipelined:
             rec = {"t0": torch.cuda.Event(enable_timing=True), "m": [], "w": [None] * n, "host": []}
             rec["t0"].record(main)
             self._timing.append(rec)
+        if self.prologue is not None:
+            # P on the side stream (behind whatever the main stream did last: the optimizer's update), M0a on the main stream;
+            # M0b -- stages[0] -- starts behind both
+            gp, ga = self.prologue
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                gp.replay()
+            ga.replay()
+            main.wait_stream(side)
 
         def launch_w(k):                              # W_k starts when M_k has finished ...
             gw = self.stages[k][1]

@@ -404,7 +404,37 @@ def rpn_head16(ts, w_obj, b_obj, w_del, b_del):
     return list(_RPNHead16.apply(w_obj, b_obj, w_del, b_del, *ts))
 
 
-_wino_scope = {"cache": None, "record": []}     # (weight address, shape) -> (U, U'), only while a model forward is running
+_wino_scope = {"cache": None, "record": [], "preloaded": None}     # (weight address, shape) -> (U, U'), only while a model forward is running
+
+
+def wino_pretransform(owner, kind="_omni_wino_plan_train"):
+    """every Winograd filter transform the next pass of `owner` will need (the plan its earlier passes left on it), as ONE launch
+    outside the pass -> {(weight address, shape, tile): (U, U')}.  solver/graphed.py captures this as its own little graph and replays
+    it on the idle weight-gradient stream beside the first layers of the forward pass (the transform moves 260 MB; it used to sit
+    at the head of the critical path).  Hand the result to `wino_preloaded` around the pass that should use it."""
+    plan = getattr(owner, kind, None) if _WINO_MULTI else None
+    out = {}
+    if not plan:
+        return out
+    items = [(w, True, flip, tile) for w, tile, flip in plan if w.is_contiguous(memory_format=CL)]
+    for k in range(0, len(items), wino.WEIGHTS_MULTI_MAX):
+        chunk = items[k:k + wino.WEIGHTS_MULTI_MAX]
+        for (w, _, _, tile), uu in zip(chunk, wino.transform_weights_multi(chunk)):
+            out[(w.data_ptr(), tuple(w.shape), tile)] = uu
+    return out
+
+
+class wino_preloaded:
+    """with wino_preloaded(d): the passes inside take their filter transforms from `d` (wino_pretransform) instead of launching them"""
+
+    def __init__(self, d):
+        self.d = d
+
+    def __enter__(self):
+        self.prev, _wino_scope["preloaded"] = _wino_scope["preloaded"], self.d
+
+    def __exit__(self, *a):
+        _wino_scope["preloaded"] = self.prev
 _WINO_MULTI = _os_environ_get("OMNI_WINO_WEIGHTS_MULTI", "1") != "0"          # A/B knob
 
 
@@ -423,7 +453,10 @@ class wino_weight_scope:
         _wino_scope["record"] = []
         self.kind = "_omni_wino_plan_train" if torch.is_grad_enabled() else "_omni_wino_plan_infer"
         plan = getattr(self.owner, self.kind, None) if (self.owner is not None and _WINO_MULTI) else None
-        if plan:
+        pre = _wino_scope["preloaded"]
+        if pre is not None and self.kind == "_omni_wino_plan_train":
+            cache.update(pre)
+        elif plan:
             items = [(w, True, flip, tile) for w, tile, flip in plan if w.is_contiguous(memory_format=CL)]
             for k in range(0, len(items), wino.WEIGHTS_MULTI_MAX):
                 chunk = items[k:k + wino.WEIGHTS_MULTI_MAX]

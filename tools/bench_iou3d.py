@@ -9,8 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import boxgen  # noqa: E402
+from omni3d_amd import boxgen  # noqa: E402
 from omni3d_amd.kernels import iou3d  # noqa: E402
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
