@@ -109,6 +109,7 @@ def _pack_proposal_list(proposals, image_sizes, device):
 @ROI_HEADS_REGISTRY.register()
 class ROIHeads3D(nn.Module):
     accepts_packed = True     # forward() also takes the ground truth pre-packed on the device (RCNN3D.prepack)
+    pool_cut = None           # solver/graphed.py: callable applied to the pooled (box, cube) features = a backward stage boundary
     @configurable
     def __init__(self, *, num_classes, batch_size_per_image, positive_fraction, proposal_iou_threshold, proposal_append_gt,
                  box_in_features, box_pooler, box_head, box_predictor, ignore_thresh, cube_head, cube_pooler, loss_w_3d,
@@ -235,6 +236,8 @@ class ROIHeads3D(nn.Module):
                 B, S = scls.shape
                 x_box, x_cube = self.box_pooler.forward_shared(feats, sboxes.reshape(B * S, 4), self._batch_index(B, S, sboxes.device),
                                                                S, self.fg_cap)
+                if self.pool_cut is not None and torch.is_grad_enabled():      # solver/graphed.py: backward stage boundary
+                    x_box, x_cube = self.pool_cut((x_box, x_cube))
             losses, cube_boxes = self._forward_box_train(feats, sboxes, scls, sgt, packed, x_box)
             losses.update(self._forward_cube_train(feats, cube_boxes, scls, sgt, packed, x_cube))
             return [], losses

@@ -490,17 +490,26 @@ def grad_stage_map(model):
     the bottom-up declares them (`backward_stages()`: {name prefix: stage}); a backbone without cut points is stage 1 as a whole."""
     bu = getattr(getattr(model, "backbone", None), "bottom_up", None)
     table = bu.backward_stages() if (bu is not None and hasattr(bu, "backward_stages")) else {}
+    # the cut at the pooled ROI features (graphed.py POOL_CUT) makes the FC heads stage 0 and everything whose gradient completes
+    # with ROIAlign's / the RPN's backward stage 1; the backbone's stages move down by one
+    shift = 1 if pool_cut_active(model) else 0
 
     def stage_of(name):
         if not name.startswith("backbone."):
-            return 0
+            return shift if (shift and not name.startswith("roi_heads.")) else 0
         if name.startswith("backbone.bottom_up."):
             rest = name[len("backbone.bottom_up."):]
             for prefix, st in table.items():
                 if rest == prefix or rest.startswith(prefix + "."):
-                    return st
-        return 1
+                    return st + shift
+        return 1 + shift
     return stage_of
+
+
+def pool_cut_active(model):
+    from .graphed import POOL_CUT
+    heads = getattr(model, "roi_heads", None)
+    return bool(POOL_CUT and heads is not None and hasattr(type(heads), "pool_cut") and hasattr(getattr(model, "proposal_generator", None), "forward"))
 
 
 def build_optimizer(cfg, model):
@@ -530,7 +539,7 @@ def build_optimizer(cfg, model):
     else:
         raise ValueError("{} is not supported as an optimizer.".format(cfg.SOLVER.TYPE))
     bu = getattr(getattr(inner, "backbone", None), "bottom_up", None)
-    opt.stage_cut_signature = tuple(getattr(bu, "stage_cut_at", ())) if bu is not None else ()     # what the ranges were laid out for
+    opt.stage_cut_signature = (tuple(getattr(bu, "stage_cut_at", ())) if bu is not None else ()) + (("pool",) if pool_cut_active(inner) else ())
     opt.exchange_in_step = direct          # DDP's reducer already averaged: never all-reduce the bucket a second time
     if direct:
         from .autoreplay import attach

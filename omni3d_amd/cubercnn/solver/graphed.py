@@ -56,6 +56,10 @@ def make_side_stream(device=None):
 
 SIDE_CUS_DEFAULT = 0            # 0 = no mask
 _PIPE_ORDER = __import__("os").environ.get("OMNI_PIPE_ORDER", "interleaved")
+# round 4: a cut at the pooled ROI features + the RPN losses deferred to that cut's stage, so stage 0 = forward + the FC heads'
+# backward and W_0 (the fc1-class weight gradients, 1.1 ms of work) runs beside ROIAlign's / the RPN's backward instead of beside
+# FPN + level 5 / 4 (A/B knob; the gradient bucket's stage layout follows it, solver/build.py)
+POOL_CUT = __import__("os").environ.get("OMNI_PIPE_POOL_CUT", "1") != "0"
 _PIPE_TIMING = __import__("os").environ.get("OMNI_PIPE_TIMING", "0") == "1"
 
 
@@ -225,24 +229,33 @@ class StageCuts:
         from ...functional import fanout
         if isinstance(x, dict):
             dst = {k: fanout(v.detach().requires_grad_(True)) for k, v in x.items()}
+        elif isinstance(x, (tuple, list)):
+            dst = tuple(None if v is None else fanout(v.detach().requires_grad_(True)) for v in x)
         else:
             dst = fanout(x.detach().requires_grad_(True))
-        self.cuts.append((x, dst))
+        self.cuts.append([x, dst, []])
         return dst
+
+    def attach_root(self, loss):
+        """a scalar whose backward is DEFERRED to the stage of the most recent cut (round 4: the RPN losses wait for the stage that
+        also runs ROIAlign's backward, so that stage 0 ends -- and its weight-gradient graph starts -- right behind the FC heads)"""
+        self.cuts[-1][2].append(loss)
 
     def reset(self):
         self.cuts.clear()
 
     def backward_last(self):
-        src, dst = self.cuts.pop()
+        src, dst, roots = self.cuts.pop()
         if isinstance(src, dict):
             pairs = [(src[k], _leaf_grad(dst[k])) for k in src]
+        elif isinstance(src, (tuple, list)):
+            pairs = [(a, _leaf_grad(b)) for a, b in zip(src, dst) if a is not None]
         else:
             pairs = [(src, _leaf_grad(dst))]
         pairs = [p for p in pairs if p[1] is not None]
         del src, dst
-        if pairs:
-            torch.autograd.backward([p[0] for p in pairs], [p[1] for p in pairs])
+        if pairs or roots:
+            torch.autograd.backward([p[0] for p in pairs] + list(roots), [p[1] for p in pairs] + [None] * len(roots))
 
 
 class GraphedPipelined:
@@ -405,8 +418,19 @@ class GraphedPipelined:
         bottom_up = getattr(getattr(self.model, "backbone", None), "bottom_up", None)
         if bottom_up is not None and hasattr(type(bottom_up), "stage_cut"):
             bottom_up.stage_cut = self.cuts
+        heads = getattr(self.model, "roi_heads", None)
+        if heads is not None and hasattr(type(heads), "pool_cut") and POOL_CUT:
+            heads.pool_cut = self._pool_cut
+
+    def _pool_cut(self, xs):
+        self._pool_cut_made = True
+        return self.cuts(xs)
+    _pool_cut_made = False
 
     def uninstall(self):
+        heads = getattr(self.model, "roi_heads", None)
+        if heads is not None and getattr(heads, "pool_cut", None) is not None and getattr(heads.pool_cut, "__self__", None) is self:
+            heads.pool_cut = None
         if getattr(self.model, "feature_cut", None) is self.cuts:
             self.model.feature_cut = None
         bottom_up = getattr(getattr(self.model, "backbone", None), "bottom_up", None)
@@ -421,6 +445,8 @@ class GraphedPipelined:
         opt = self.optimizer
         bu = getattr(getattr(self.model, "backbone", None), "bottom_up", None)
         sig = tuple(getattr(bu, "stage_cut_at", ())) if bu is not None else ()
+        if self._pool_cut_made:
+            sig = sig + ("pool",)
         return (getattr(opt, "n_stages", 2) == n_graph_stages and getattr(opt, "stage_cut_signature", None) == sig
                 and hasattr(opt, "stage_ranges"))
 
@@ -433,8 +459,29 @@ class GraphedPipelined:
         self.optimizer.zero_grad()
         losses = self.model(self.static_batch, self.static_packed)
         total = total_loss(losses)
-        total.backward()
+        first, deferred = self._split_losses(losses)
+        if deferred is None:
+            total.backward()
+        else:
+            # stage 0 back-propagates the ROI heads' losses only, down to the pooled ROI features; the RPN's two losses are the
+            # roots of the next stage together with ROIAlign's backward
+            self.cuts.attach_root(deferred)
+            first.backward()
         return losses, total.detach()
+
+    def _split_losses(self, losses):
+        """-> (sum of the losses whose backward belongs to stage 0, sum of the deferred ones or None)"""
+        heads = getattr(self.model, "roi_heads", None)
+        if heads is None or getattr(getattr(heads, "pool_cut", None), "__self__", None) is not self or not len(self.cuts) or not self._pool_cut_made:
+            return None, None
+        vecs = getattr(losses, "vectors", None)
+        if not vecs or sorted(n for _, names in vecs for n in names) != sorted(losses.keys()):
+            return None, None
+        late = [v for v, names in vecs if all(n.startswith("rpn/") for n in names)]
+        early = [v for v, names in vecs if not all(n.startswith("rpn/") for n in names)]
+        if not late or not early:
+            return None, None
+        return torch.cat(early).sum(), torch.cat(late).sum()
 
     def _eager(self):
         """all stages with eager launches (weight gradients wherever functional.side_mode() puts them)
