@@ -112,7 +112,7 @@ def run_train(args, world, rank):
         try:
             graphed = GraphedPipelined(model, opt, batch, packed, graphs=use_graph)
             graph_note = (f"{len(graphed.stages)} backward stages x (critical-path hipGraph on the main stream | weight-gradient hipGraph "
-                          "on a second stream), all-reduce of the heads' gradients behind stage 0" if use_graph
+                          "on a second stream), all-reduce of every backward stage's gradient range behind that stage's weight-gradient graph" if use_graph
                           else "eager staged backward, weight gradients on a second stream")
         except Exception as e:   # capture refused: same sequence with eager launches
             graphed = GraphedPipelined(model, opt, batch, packed, graphs=False)

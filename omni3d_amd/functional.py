@@ -659,6 +659,7 @@ class _BNReLUWinoConv(Function):
 # transform reads every activation 2.25 times (overlapping 6x6 windows) and now normalises it 2.25 times, with 8 more live registers
 # next to its 144-register tile -- that costs more than the 5 us bn_apply launch and the 2 x 4-17 MB it saves
 _BN_WINO_FUSE = _os_environ_get("OMNI_BN_WINO_FUSE", "0") != "0"      # A/B knob
+_BN_WINO_FUSE_MAX_PIX = int(_os_environ_get("OMNI_BN_WINO_FUSE_MAX_PIX", str(1 << 30)))     # ... only on maps of at most this many pixels
 
 
 def bn_relu_conv3x3(x, bn, conv_mod, want_stats):
@@ -669,7 +670,8 @@ def bn_relu_conv3x3(x, bn, conv_mod, want_stats):
     parts = getattr(x, "_omni_bn_partials", None)
     if (_BN_WINO_FUSE and _WINOGRAD and parts is not None and bn.training and torch.is_grad_enabled() and conv_mod.bias is None
             and conv_mod.stride[0] == 1 and conv_mod.padding[0] == 1 and w.requires_grad and x.requires_grad
-            and wino.eligible(x.shape, w.shape, 1, 1) and _BN_REMASK and w.is_contiguous(memory_format=CL)):
+            and wino.eligible(x.shape, w.shape, 1, 1) and _BN_REMASK and w.is_contiguous(memory_format=CL)
+            and x.shape[0] * x.shape[2] * x.shape[3] <= _BN_WINO_FUSE_MAX_PIX):
         y, p2 = _BNReLUWinoConv.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                                       bn.running_var if bn.track_running_stats else None, bn.eps, bn.momentum, parts, w, bool(want_stats))
         if bn.track_running_stats and bn.num_batches_tracked is not None and not bn.defer_counter:
