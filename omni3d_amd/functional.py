@@ -214,6 +214,22 @@ def side_join():
     _side["pending"].clear()
 
 
+def _relu_already_masked(dy):
+    """The fused RPN head's data gradient applies the ReLU mask of the convolution below it on the way out and says so with a tag on
+    the gradient tensor (`_omni_relu_masked` = the tensor's version counter at that moment).  The tag is only good while the tensor
+    is what the head wrote: if the convolution's output ever gets a second consumer, the autograd engine may accumulate that consumer's
+    (unmasked) gradient IN PLACE into the tagged tensor -- the version counter then differs, the sum can no longer be masked
+    correctly, and this raises instead of returning wrong gradients."""
+    tag = getattr(dy, "_omni_relu_masked", None)
+    if tag is None or tag is False:
+        return False
+    if tag is not True and dy._version != tag:
+        raise RuntimeError("omni3d_amd: the gradient of a convolution whose ReLU mask was applied by its consumer (fused RPN head) was "
+                           "modified in place afterwards -- a second consumer of that convolution's output; set OMNI_RPN_HEAD16=0")
+    return True
+
+
+
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, relu, want_stats=False):
@@ -238,7 +254,7 @@ class _Conv2d(Function):
     def backward(ctx, dy, _parts_grad=None):
         x, w, y = ctx.saved_tensors
         stride, pad, relu, has_bias = ctx.cfg
-        relu = relu and not getattr(dy, "_omni_relu_masked", False)       # (the consumer's data-gradient kernel applied the mask)
+        relu = relu and not _relu_already_masked(dy)       # (the consumer's data-gradient kernel applied the mask)
         dy = _cl(dy)
         if relu:   # elementwise on the NHWC views (same dense layout for dy and y)
             dy = bnpool.relu_bwd(dy.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
@@ -314,7 +330,7 @@ class _WinoConv3x3(Function):
     def backward(ctx, dy, _parts_grad=None):
         V, w, y, Uf = ctx.saved_tensors
         relu, has_bias = ctx.cfg
-        relu = relu and not getattr(dy, "_omni_relu_masked", False)       # (the consumer's data-gradient kernel applied the mask)
+        relu = relu and not _relu_already_masked(dy)       # (the consumer's data-gradient kernel applied the mask)
         dy = _cl(dy)
         if relu:
             dy = bnpool.relu_bwd(dy.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
@@ -380,7 +396,7 @@ class _RPNHead16(Function):
             dts = []
             for d in det.head16_dgrad(dys, tn, w_obj, w_del, relu_mask=True):
                 d = d.permute(0, 3, 1, 2)
-                d._omni_relu_masked = True           # read by _WinoConv3x3 / _Conv2d.backward: no second pass for the ReLU
+                d._omni_relu_masked = d._version           # read by _WinoConv3x3 / _Conv2d.backward: no second pass for the ReLU
                 dts.append(d)
         grads = (None, None, None, None)
         if any(ctx.needs_input_grad[:4]):
