@@ -530,6 +530,10 @@ int omni_wino_weights_multi(const void* const* g, const void* const* U, const vo
 int omni_wino_dy_in(const float* dy, float* dM, float* Vd, int N, int H, int W, int K, int tile, void* stream);
 int omni_wino_weights(const float* g, float* U /*nullable*/, float* U_flip /*nullable: U'*/, int K, int C, int tile, void* stream);
 int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate, int tile, void* stream);
+/* n <= 16 of them in one launch, each ADDED into its gradient view; sources naming the same dg (the RPN's shared convolution: one
+ * weight gradient per FPN level) are added in the order given, as the separate launches would */
+int omni_wino_dweights_multi(const void* const* dU, const void* const* dg, const int* K, const int* C, const int* tile, int n,
+                             void* stream);
 /* `batch` independent dense GEMMs in one launch (the 16 Winograd points):
  * fwd: out[b](M,K) = x[b](M,C) * w[b](K,C)^T;  wgrad: dw[b](K,C) = dy[b](M,K)^T * x[b](M,C) (overwrites dw). */
 int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch, int M, int C, int K, void* stream);
@@ -547,6 +551,14 @@ int omni_gemm_batched_wgrad_algo(const float* x, const float* dy, float* dw, int
 /* deterministic form (see omni_conv2d_fwd_det): the row splits of the Winograd-domain weight gradient meet in `ws` in split order */
 int omni_gemm_batched_wgrad_det(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, int algo, float* ws,
                                 long long ws_floats, int* ctr, int n_ctr, long long* plan, void* stream);
+/* n <= 16 such weight-gradient GEMMs of different shapes in ONE launch (round 4: all the Winograd layers whose data gradients a
+ * backward stage has produced; each alone is a latency-bound launch on 256 CUs).  Problem i: dw[i] (batch[i], K[i], C[i]) =
+ * dy[i] (batch[i], M[i], K[i])^T x[i] (batch[i], M[i], C[i]); tiles, row splits and (ctr != NULL) the ordered split reduction are
+ * those of omni_gemm_batched_wgrad_det(algo 2) on that problem alone -- bit-identical to n separate calls.  ws / ctr hold the
+ * problems' regions back to back; plan: [0] = 2, [1] = 0, [2] = counters, [3] = workspace floats of the whole call. */
+int omni_gemm_batched_wgrad_multi(const void* const* x, const void* const* dy, const void* const* dw, const int* batch, const int* M,
+                                  const int* C, const int* K, int n, float* ws, long long ws_floats, int* ctr, int n_ctr,
+                                  long long* plan, void* stream);
 
 /* Direct convolution for the full-resolution, few-channel DLA-34 stem layers (cubercnn/modeling/backbone/dla.py:241-247):
  * out (N,H,W,16) = conv(x (N,H,W,C), w (16,R,R,C)), stride 1, padding R/2; (C, R) = (4, 7) [base_layer, image padded

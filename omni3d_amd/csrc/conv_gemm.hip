@@ -892,16 +892,15 @@ __global__ void __launch_bounds__(256) gemm_nt_pf_kernel(GemmTP p) {
 // TN twin of gemm_nt_pf_kernel: out[b] (Kc x C) (+)= A[b]^T B[b] with A (M x Kc), B (M x C), the reduction running over the M
 // rows (Winograd-domain weight gradient dU = dM^T V of the small maps).  gridDim.y splits the rows (`rows_per_split`, a multiple
 // of 32 * PF); a split launch adds its partial tile atomically into a zeroed output, a single split stores it.
+// `item` = this workgroup's position in the (problem, split, tile) sequence of ONE batched GEMM, tile fastest
 template <int PF>
-__global__ void __launch_bounds__(256) gemm_tn_pf_kernel(GemmTP p, int rows_per_split, int splits) {
+__device__ __forceinline__ void gemm_tn_pf_body(const GemmTP& p, const int rows_per_split, const int splits, const int item) {
     constexpr int BM = 64, BN = 64, BK = 32, F4 = BM / 4, ROWS = 256 / F4, LI = BK / ROWS;      // 16 float4 per row, 16 rows per pass
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int c4 = tid % F4, lrow = tid / F4;
-    // 1-D grid over (problem, split, tile) items, tile fastest, one contiguous chunk per XCD (see gemm_nt_pf_kernel)
     const int tiles_m = (p.N + BM - 1) / BM, tiles = tiles_m * ((p.K + BN - 1) / BN);
-    const int item = xcd_chunked((int)blockIdx.x, (int)gridDim.x);
     const int prob = item / (tiles * splits), rem = item - prob * (tiles * splits);
     const int split = rem / tiles, tix = rem - split * tiles;
     const omni_rsrc_t ra_ = omni_make_rsrc(p.A + (long)prob * p.ab, (unsigned)p.M * (unsigned)p.N * 4u);   // p.N = Kc (A's width)
@@ -967,6 +966,39 @@ __global__ void __launch_bounds__(256) gemm_tn_pf_kernel(GemmTP p, int rows_per_
             else atomicAdd(o, acc[0][0][r]);
         }
     }
+}
+
+template <int PF>
+__global__ void __launch_bounds__(256) gemm_tn_pf_kernel(GemmTP p, int rows_per_split, int splits) {
+    // 1-D grid over (problem, split, tile) items, tile fastest, one contiguous chunk per XCD (see gemm_nt_pf_kernel)
+    gemm_tn_pf_body<PF>(p, rows_per_split, splits, xcd_chunked((int)blockIdx.x, (int)gridDim.x));
+}
+
+// Several batched TN GEMMs of DIFFERENT shapes in one launch: the Winograd-domain weight gradients of all the layers whose data
+// gradients one backward stage has produced (round 4).  They are independent of each other, and each alone is a latency-bound
+// launch on 256 CUs -- a level-4 layer is 36 x 16 tiles of 8 slabs, 2.25 workgroups per CU, one wave of work whose duration is a
+// workgroup's serial time (prologue, 8 slabs, ordered split sum) -- so a stage's worth of them back to back left the chip mostly waiting.
+// In one launch the workgroups of the next problem fill the CUs the moment those of the previous one retire.
+//   * ids [first[j], first[j] + roundup8(items[j])) belong to problem j; first[j] is a multiple of 8, so id % 8 -- the XCD the
+//     hardware hands the workgroup to -- is also the XCD index INSIDE the problem: each problem's items are cut into eight
+//     contiguous chunks, one per XCD (its tiles share the operand panels in that L2), and every XCD gets an eighth of every
+//     problem, whatever their relative cost (up to seven padding ids per problem exit at once);
+//   * per-problem arithmetic, split structure, workspace slots and counters are those of a launch of gemm_tn_pf_kernel on that
+//     problem alone: the results are bit-identical to separate launches.
+constexpr int TN_MULTI_MAX = 16;
+struct GemmTnMulti {
+    GemmTP p[TN_MULTI_MAX];
+    int rps[TN_MULTI_MAX], splits[TN_MULTI_MAX], items[TN_MULTI_MAX], first[TN_MULTI_MAX + 1];
+    int n;
+};
+template <int PF>
+__global__ void __launch_bounds__(256) gemm_tn_multi_kernel(GemmTnMulti t) {
+    const int id = (int)blockIdx.x;
+    int j = 0;
+    while (j + 1 < t.n && id >= t.first[j + 1]) ++j;
+    const int local = id - t.first[j];
+    if (local >= t.items[j]) return;
+    gemm_tn_pf_body<PF>(t.p[j], t.rps[j], t.splits[j], xcd_chunked(local, t.items[j]));
 }
 
 inline bool bad_geom(const ConvP& p) {
@@ -1349,6 +1381,18 @@ int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch,
 // with 2-4 slabs of buffer-load prefetch in flight (gemm_tn_pf_kernel)
 constexpr bool WGRAD64_DEEP_PREFETCH = true;    // gemm_tn_pf_kernel (profiles/r03_sweep_batched_gemm.log: 3-66 % faster on every Winograd weight-gradient shape)
 
+// 64x64 tiles of gemm_tn_pf_kernel: row splits of >= 8 slabs, aiming at >= 512 workgroups
+static inline void tn_pf_plan(int batch, int M, int C, int K, int& tiles, long& splits, int& rps) {
+    tiles = ((K + 63) / 64) * ((C + 63) / 64);
+    splits = (512 + (long)tiles * batch - 1) / ((long)tiles * batch);
+    const long max_splits = ((long)M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    rps = (int)(((long)M + splits - 1) / splits);
+    rps = (rps + 127) / 128 * 128;                                   // multiple of 32 * PF for PF = 4
+    splits = ((long)M + rps - 1) / rps;
+}
+
 static int gemm_batched_wgrad_impl(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, int algo, void* stream,
                                    const DetArgs& det) {
     if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3) || (K & 3) || algo < 0 || algo > 2) return OMNI_ERR_ARG;
@@ -1362,15 +1406,9 @@ static int gemm_batched_wgrad_impl(const float* x, const float* dy, float* dw, i
     if (algo == 2 && !fits) return OMNI_ERR_ARG;
     if (algo == 0) algo = (WGRAD64_DEEP_PREFETCH && fits) ? 2 : 1;
     if (algo == 2) {
-        const int tiles = ((K + 63) / 64) * ((C + 63) / 64);
-        // >= 8 slabs per split, aim at >= 512 workgroups
-        long splits = (512 + (long)tiles * batch - 1) / ((long)tiles * batch);
-        const long max_splits = ((long)M + 255) / 256;
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
-        int rps = (int)(((long)M + splits - 1) / splits);
-        rps = (rps + 127) / 128 * 128;                                   // multiple of 32 * PF for PF = 4
-        splits = ((long)M + rps - 1) / rps;
+        int tiles, rps;
+        long splits;
+        tn_pf_plan(batch, M, C, K, tiles, splits, rps);
         if (det.plan != nullptr) {
             det_plan(det, algo, (long)tiles * batch, splits, 64 * 64);
             return OMNI_OK;
@@ -1426,6 +1464,77 @@ int omni_gemm_batched_wgrad_algo(const float* x, const float* dy, float* dw, int
 int omni_gemm_batched_wgrad_det(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, int algo, float* ws,
                                 long long ws_floats, int* ctr, int n_ctr, long long* plan, void* stream) {
     return gemm_batched_wgrad_impl(x, dy, dw, batch, M, C, K, algo, stream, DetArgs{ws, ws_floats, (unsigned*)ctr, n_ctr, plan});
+}
+
+// n <= 16 independent batched weight-gradient GEMMs of different shapes in ONE launch (gemm_tn_multi_kernel).  Problem i:
+// dw[i][b] (K[i] x C[i]) = dy[i][b] (M[i] x K[i])^T x[i][b] (M[i] x C[i]), b < batch[i]; each with the tiles, row splits and (ctr !=
+// nullptr) ordered split reduction of omni_gemm_batched_wgrad_det(algo 2) on that problem alone -- the results are bit-identical
+// to n separate calls.  Workspace / counters: the problems' regions one after the other; plan (nullable) reports [0] = 2,
+// [1] = 0, [2] = counters, [3] = workspace floats of the whole call and returns without launching.
+int omni_gemm_batched_wgrad_multi(const void* const* x, const void* const* dy, const void* const* dw, const int* batch, const int* M,
+                                  const int* C, const int* K, int n, float* ws, long long ws_floats, int* ctr, int n_ctr,
+                                  long long* plan, void* stream) {
+    if (n <= 0 || n > TN_MULTI_MAX || x == nullptr || dy == nullptr || dw == nullptr) return OMNI_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    struct One { int i, tiles, rps; long splits, ws_off, ctr_off; };
+    One one[TN_MULTI_MAX];
+    long ws_need = 0, ctr_need = 0;
+    int live = 0;
+    for (int i = 0; i < n; ++i) {
+        if (batch[i] <= 0 || M[i] < 0 || C[i] <= 0 || K[i] <= 0 || (C[i] & 3) || (K[i] & 3) || dw[i] == nullptr ||
+            (M[i] > 0 && (x[i] == nullptr || dy[i] == nullptr)))
+            return OMNI_ERR_ARG;
+        if ((long)M[i] * C[i] * 4 >= (1L << 31) || (long)M[i] * K[i] * 4 >= (1L << 31)) return OMNI_ERR_ARG;
+        if (M[i] == 0) {
+            if (plan == nullptr) omni_memset_async((void*)dw[i], 0, sizeof(float) * (size_t)batch[i] * K[i] * C[i], st);
+            continue;
+        }
+        One& o = one[live++];
+        o.i = i;
+        tn_pf_plan(batch[i], M[i], C[i], K[i], o.tiles, o.splits, o.rps);
+        o.ws_off = ws_need;
+        o.ctr_off = ctr_need;
+        if (o.splits > 1) {
+            ws_need += omni_split_ws_floats((long)o.tiles * batch[i], o.splits, 64 * 64);
+            ctr_need += omni_split_counters((long)o.tiles * batch[i], o.splits);
+        }
+    }
+    if (plan != nullptr) {
+        plan[0] = 2; plan[1] = 0; plan[2] = ctr_need; plan[3] = ws_need;
+        return OMNI_OK;
+    }
+    if (live == 0) return OMNI_OK;
+    const bool ordered = ctr != nullptr;
+    if (ordered && ctr_need > 0 && (ws == nullptr || ws_floats < ws_need || n_ctr < ctr_need)) return OMNI_ERR_ARG;
+    // longest workgroups first (dispatch follows the id): the short ones fill the tail
+    for (int a = 1; a < live; ++a) {
+        const One v = one[a];
+        int b = a;
+        for (; b > 0 && one[b - 1].rps < v.rps; --b) one[b] = one[b - 1];
+        one[b] = v;
+    }
+    GemmTnMulti t;
+    t.n = live;
+    long first = 0;
+    for (int j = 0; j < live; ++j) {
+        const One& o = one[j];
+        const int i = o.i;
+        const bool split = o.splits > 1;
+        if (split && !ordered) omni_memset_async((void*)dw[i], 0, sizeof(float) * (size_t)batch[i] * K[i] * C[i], st);
+        t.p[j] = GemmTP{(const float*)dy[i], (const float*)x[i], (float*)dw[i], M[i], K[i], C[i], (long)M[i] * K[i], (long)M[i] * C[i],
+                        (long)K[i] * C[i], (split && ordered) ? ws + o.ws_off : nullptr, (split && ordered) ? (unsigned*)ctr + o.ctr_off : nullptr};
+        t.rps[j] = o.rps;
+        t.splits[j] = (int)o.splits;
+        const long items = (long)o.tiles * o.splits * batch[i];
+        if (items > 0x3fffffff) return OMNI_ERR_ARG;
+        t.items[j] = (int)items;
+        t.first[j] = (int)first;
+        first += (items + 7) / 8 * 8;
+        if (first > 0x7fffffff) return OMNI_ERR_ARG;
+    }
+    t.first[live] = (int)first;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_tn_multi_kernel<4>), dim3((unsigned)first), dim3(256), 0, st, t);
+    return omni_launch_status();
 }
 
 int omni_gemm_batched_wgrad(const float* x, const float* dy, float* dw, int batch, int M, int C, int K, void* stream) {

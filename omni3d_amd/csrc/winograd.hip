@@ -243,31 +243,42 @@ __global__ void __launch_bounds__(256) wino_w_kernel(const float* __restrict__ g
     wino_w_body(g, U, Uf, K, C, (int)blockIdx.x, s_t);
 }
 
+// v[r][s] = (G^T dU G)[r][s] of filter element i = k * C + c
+__device__ __forceinline__ void wino_dw_elem(const float* __restrict__ dU, long total, long i, float (&v)[3][3]) {
+#pragma clang fp contract(off)
+    float u[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) u[r][s] = dU[(long)(4 * r + s) * total + i];
+    float e[3][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {       // G^T dU
+        e[0][s] = u[0][s] + 0.5f * (u[1][s] + u[2][s]);
+        e[1][s] = 0.5f * (u[1][s] - u[2][s]);
+        e[2][s] = 0.5f * (u[1][s] + u[2][s]) + u[3][s];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {       // (.) G
+        v[r][0] = e[r][0] + 0.5f * (e[r][1] + e[r][2]);
+        v[r][1] = 0.5f * (e[r][1] - e[r][2]);
+        v[r][2] = 0.5f * (e[r][1] + e[r][2]) + e[r][3];
+    }
+}
+
 __global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dg, int K, int C,
                                                       int accumulate) {
+#pragma clang fp contract(off)
     const long total = (long)K * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C), k = (int)(i / C);
-        float u[4][4];
+        float v[3][3];
+        wino_dw_elem(dU, total, i, v);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) u[r][s] = dU[(long)(4 * r + s) * total + i];
-        float e[3][4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {       // G^T dU
-            e[0][s] = u[0][s] + 0.5f * (u[1][s] + u[2][s]);
-            e[1][s] = 0.5f * (u[1][s] - u[2][s]);
-            e[2][s] = 0.5f * (u[1][s] + u[2][s]) + u[3][s];
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {       // (.) G
-            const float v0 = e[r][0] + 0.5f * (e[r][1] + e[r][2]);
-            const float v1 = 0.5f * (e[r][1] - e[r][2]);
-            const float v2 = 0.5f * (e[r][1] + e[r][2]) + e[r][3];
+        for (int r = 0; r < 3; ++r) {
             float* o = dg + ((long)k * 9 + r * 3) * C + c;
-            if (accumulate) { o[0] += v0; o[C] += v1; o[2 * (long)C] += v2; }
-            else { o[0] = v0; o[C] = v1; o[2 * (long)C] = v2; }
+            if (accumulate) { o[0] += v[r][0]; o[C] += v[r][1]; o[2 * (long)C] += v[r][2]; }
+            else { o[0] = v[r][0]; o[C] = v[r][1]; o[2 * (long)C] = v[r][2]; }
         }
     }
 }
@@ -477,6 +488,7 @@ __device__ __forceinline__ void g6(const float (&g)[3], float (&a)[6]) {
     a[5] = g[2];
 }
 __device__ __forceinline__ void gt6(const float (&u)[6], float (&e)[3]) {      // e = G^T u (adjoint of g6)
+#pragma clang fp contract(off)      // one rounding per written operation: the chained form (wino_dw_multi_kernel) must equal the separate launches bit for bit
     e[0] = u[0] + (u[1] - u[2]) * (1.f / 3.f) - u[3] * (16.f / 15.f) + u[4] * (1.f / 15.f);
     e[1] = (u[1] + u[2]) * (1.f / 3.f) - u[3] * (8.f / 15.f) - u[4] * (2.f / 15.f);
     e[2] = (u[1] - u[2]) * (1.f / 3.f) + (u[4] - u[3]) * (4.f / 15.f) + u[5];
@@ -558,33 +570,82 @@ __global__ void __launch_bounds__(256) wino_w_multi_kernel(WinoWTable t) {
     else wino4_w_body(t.g[e], t.U[e], t.Uf[e], t.K[e], t.C[e], bid, s_t);
 }
 
+__device__ __forceinline__ void wino4_dw_elem(const float* __restrict__ dU, long total, long i, float (&v)[3][3]) {
+#pragma clang fp contract(off)
+    float e[3][6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        float col[6], o3[3];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) col[r] = dU[(long)(6 * r + s) * total + i];
+        gt6(col, o3);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) e[r][s] = o3[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) gt6(e[r], v[r]);
+}
+
 __global__ void __launch_bounds__(256) wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dg, int K, int C,
                                                        int accumulate) {
+#pragma clang fp contract(off)
     const long total = (long)K * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C), k = (int)(i / C);
-        float e[3][6];
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            float col[6], o3[3];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) col[r] = dU[(long)(6 * r + s) * total + i];
-            gt6(col, o3);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) e[r][s] = o3[r];
-        }
+        float v[3][3];
+        wino4_dw_elem(dU, total, i, v);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            float v[3];
-            gt6(e[r], v);
             float* o = dg + ((long)k * 9 + r * 3) * C + c;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                if (accumulate) o[(long)s * C] += v[s];
-                else o[(long)s * C] = v[s];
+                if (accumulate) o[(long)s * C] += v[r][s];
+                else o[(long)s * C] = v[r][s];
             }
         }
     }
+}
+
+// The transforms back of several layers' weight gradients in one launch, each ADDED into its gradient view (the tail of the
+// weight-gradient stream's batched launch, omni_gemm_batched_wgrad_multi).  Sources that add into the SAME view -- the RPN's shared
+// 3x3 convolution sees one weight gradient per FPN level -- are chained inside one thread, in the order they were given, so the
+// result is what the separate launches, one after the other, would have left.
+constexpr int WINO_DW_MAX = 16;
+struct WinoDwTable {
+    const float* dU[WINO_DW_MAX];        // sources, grouped by destination
+    int tile[WINO_DW_MAX];               // per source
+    float* dg[WINO_DW_MAX];              // per destination
+    int K[WINO_DW_MAX], C[WINO_DW_MAX], src0[WINO_DW_MAX + 1], wg0[WINO_DW_MAX + 1];
+    int n;
+};
+__global__ void __launch_bounds__(256) wino_dw_multi_kernel(WinoDwTable t) {
+#pragma clang fp contract(off)
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.wg0[e + 1]) ++e;
+    const int C = t.C[e];
+    const long total = (long)t.K[e] * C;
+    const long i = (long)((int)blockIdx.x - t.wg0[e]) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C), k = (int)(i / C);
+    float* o = t.dg[e] + (long)k * 9 * C + c;
+    float acc[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc[r][s] = o[(long)(r * 3 + s) * C];
+    for (int q = t.src0[e]; q < t.src0[e + 1]; ++q) {
+        float v[3][3];
+        if (t.tile[q] == 2) wino_dw_elem(t.dU[q], total, i, v);
+        else wino4_dw_elem(t.dU[q], total, i, v);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) acc[r][s] += v[r][s];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) o[(long)(r * 3 + s) * C] = acc[r][s];
 }
 
 // ---- backward: both transforms of dy in one pass ---------------------------------------------------------------------
@@ -833,6 +894,39 @@ int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate,
     if (K <= 0 || C <= 0 || (tile != 2 && tile != 4)) return OMNI_ERR_ARG;
     if (tile == 2) hipLaunchKernelGGL(wino_dw_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, dU, dg, K, C, accumulate);
     else hipLaunchKernelGGL(wino4_dw_kernel, dim3(ew_grid((long)K * C)), dim3(256), 0, (hipStream_t)stream, dU, dg, K, C, accumulate);
+    return omni_launch_status();
+}
+
+// dg[i] (K[i],3,3,C[i]) += G^T dU[i] G for n <= 16 sources in ONE launch; sources with the same dg (same K, C) are added in the order given
+int omni_wino_dweights_multi(const void* const* dU, const void* const* dg, const int* K, const int* C, const int* tile, int n, void* stream) {
+    if (n <= 0 || n > WINO_DW_MAX || dU == nullptr || dg == nullptr) return OMNI_ERR_ARG;
+    WinoDwTable t;
+    int dest[WINO_DW_MAX], nd = 0;             // dest[i] = destination entry of source i
+    for (int i = 0; i < n; ++i) {
+        if (K[i] <= 0 || C[i] <= 0 || (tile[i] != 2 && tile[i] != 4) || dU[i] == nullptr || dg[i] == nullptr) return OMNI_ERR_ARG;
+        int d = 0;
+        while (d < nd && t.dg[d] != (float*)dg[i]) ++d;
+        if (d == nd) {
+            t.dg[nd] = (float*)dg[i]; t.K[nd] = K[i]; t.C[nd] = C[i];
+            ++nd;
+        } else if (t.K[d] != K[i] || t.C[d] != C[i]) {
+            return OMNI_ERR_ARG;
+        }
+        dest[i] = d;
+    }
+    t.n = nd;
+    t.wg0[0] = 0;
+    int q = 0;
+    for (int d = 0; d < nd; ++d) {
+        t.src0[d] = q;
+        for (int i = 0; i < n; ++i)
+            if (dest[i] == d) { t.dU[q] = (const float*)dU[i]; t.tile[q] = tile[i]; ++q; }
+        const long wgs = ((long)t.K[d] * t.C[d] + 255) / 256;
+        if (t.wg0[d] + wgs > 0x7fffffff) return OMNI_ERR_ARG;
+        t.wg0[d + 1] = t.wg0[d] + (int)wgs;
+    }
+    t.src0[nd] = q;
+    hipLaunchKernelGGL(wino_dw_multi_kernel, dim3((unsigned)t.wg0[nd]), dim3(256), 0, (hipStream_t)stream, t);
     return omni_launch_status();
 }
 

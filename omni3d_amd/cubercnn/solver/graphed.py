@@ -330,7 +330,7 @@ class GraphedPipelined:
         HF.side_mode("collect")
         # deterministic split reductions (kernels/detmode.py): the critical-path graphs and the weight-gradient graphs replay
         # side by side, so each family gets its own block of arrival counters, allocated before the first capture starts
-        from ...kernels import detmode
+        from ...kernels import detmode, wino
         detmode.prewarm(torch.cuda.current_device())
         try:
             stages, pool_m, pool_w = [], None, None
@@ -352,8 +352,8 @@ class GraphedPipelined:
                 gw = None
                 if fns:
                     gw = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gw, pool=pool_w, capture_error_mode="thread_local"), detmode.domain("W"):
-                        for fn in fns:
+                    with torch.cuda.graph(gw, pool=pool_w, capture_error_mode="thread_local"), detmode.domain("W"), wino.batched_wgrads():
+                        for fn in fns:          # (the Winograd-domain GEMMs of the stage leave together when the context closes)
                             fn()
                     pool_w = gw.pool()
                 self._held.append((fns, keep))

@@ -154,6 +154,94 @@ def gemm_batched_wgrad(V, dM, algo=0):
     return dU
 
 
+WGRAD_MULTI_MAX = 16
+WGRAD_MULTI = _os.environ.get("OMNI_WGRAD_MULTI", "1") != "0"
+_deferred = None        # [(V, dM, dU, accum_into)] while a batched_wgrads() context is open
+
+
+def gemm_batched_wgrad_multi(problems):
+    """problems: [(V (B,M,C), dM (B,M,K))], <= 16, any mix of shapes -> [dU (B,K,C)], all in ONE launch (omni_gemm_batched_wgrad_multi);
+    bit-identical to gemm_batched_wgrad on each"""
+    import ctypes
+    from . import detmode as _det
+    n = len(problems)
+    assert 0 < n <= WGRAD_MULTI_MAX
+    L = _lib.check_device(*[t for pr in problems for t in pr])
+    outs = [torch.empty((V.shape[0], dM.shape[2], V.shape[2]), dtype=torch.float32, device=V.device) for V, dM in problems]
+    P = ctypes.c_void_p
+    arr = lambda vals: ctypes.cast((P * n)(*vals), P)                     # noqa: E731
+    ints = lambda vals: ctypes.cast((ctypes.c_int * n)(*vals), P)         # noqa: E731
+    head = (arr([V.data_ptr() for V, _ in problems]), arr([dM.data_ptr() for _, dM in problems]), arr([o.data_ptr() for o in outs]),
+            ints([V.shape[0] for V, _ in problems]), ints([V.shape[1] for V, _ in problems]), ints([V.shape[2] for V, _ in problems]),
+            ints([dM.shape[2] for _, dM in problems]), n)
+    V0 = problems[0][0]
+    if not _det.on():
+        L.call("omni_gemm_batched_wgrad_multi", *head, None, 0, None, 0, None, _lib.stream_of(V0))
+        return outs
+    plan, addr = _det.new_plan()
+    L.call("omni_gemm_batched_wgrad_multi", *head, None, 0, None, 0, addr, _lib.stream_of(V0))
+    ws, wsf, ctr, nctr = _det.workspace(V0, plan)
+    L.call("omni_gemm_batched_wgrad_multi", *head, _lib.ptr(ws), wsf, _lib.ptr(ctr), nctr, None, _lib.stream_of(V0))
+    return outs
+
+
+def _multi_fits(V, dM):
+    return V.shape[1] > 0 and V.shape[1] * V.shape[2] * 4 < (1 << 31) and dM.shape[1] * dM.shape[2] * 4 < (1 << 31)
+
+
+class batched_wgrads:
+    """Context of the weight-gradient stream: the Winograd-domain weight gradients issued inside through wgrad_into() are
+    collected, their GEMMs leave in launches of <= 16 problems when the context closes (csrc/conv_gemm.hip gemm_tn_multi_kernel),
+    then the transforms back add into the gradient views in the order of issue."""
+
+    def __enter__(self):
+        global _deferred
+        self.prev, _deferred = _deferred, []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _deferred
+        items, _deferred = _deferred, self.prev
+        if et is None:
+            for i in range(0, len(items), WGRAD_MULTI_MAX):
+                part = items[i:i + WGRAD_MULTI_MAX]
+                if len(part) == 1:
+                    dUs = [gemm_batched_wgrad(part[0][0], part[0][1])]
+                else:
+                    dUs = gemm_batched_wgrad_multi([(V, dM) for V, dM, _ in part])
+                transform_dweights_multi([(dU, into) for dU, (_, _, into) in zip(dUs, part)])
+        return False
+
+
+def transform_dweights_multi(items):
+    """items: [(dU (P,K,C), accum_into (K,C,3,3) CL gradient view)], <= 16: accum_into += the transform back of dU, all in one launch;
+    views named twice receive their sources in list order"""
+    import ctypes
+    n = len(items)
+    assert 0 < n <= WGRAD_MULTI_MAX
+    if n == 1:
+        return transform_dweights(*items[0])
+    L = _lib.check_device(*[dU for dU, _ in items])
+    gvs = [into.permute(0, 2, 3, 1) for _, into in items]
+    assert all(g.is_contiguous() for g in gvs)
+    P = ctypes.c_void_p
+    arr = lambda vals: ctypes.cast((P * n)(*vals), P)                     # noqa: E731
+    ints = lambda vals: ctypes.cast((ctypes.c_int * n)(*vals), P)         # noqa: E731
+    L.call("omni_wino_dweights_multi", arr([dU.data_ptr() for dU, _ in items]), arr([g.data_ptr() for g in gvs]),
+           ints([dU.shape[1] for dU, _ in items]), ints([dU.shape[2] for dU, _ in items]),
+           ints([2 if dU.shape[0] == 16 else 4 for dU, _ in items]), n, _lib.stream_of(items[0][0]))
+    return None
+
+
+def wgrad_into(V, dM, accum_into):
+    """accum_into (KRSC-contiguous gradient view) += the weight gradient of a Winograd layer: V its transformed input, dM its
+    transformed output gradient.  Inside batched_wgrads() the GEMM joins the context's launch."""
+    if _deferred is None or not WGRAD_MULTI or not _multi_fits(V, dM):
+        return transform_dweights(gemm_batched_wgrad(V, dM), accum_into)
+    _deferred.append((V, dM, accum_into))
+    return None
+
+
 def transform_output(Mt, shape, bias=None, relu=False, carry=None):
     """Mt (P,T,K) -> y (N,K,H,W) CL; shape = (N, H, W); the tile size follows from P.
     carry (data gradients): gradient fan-in, a logical (N,K,H,W) tensor in NHWC memory with any pixel pitch, added to the result"""
@@ -278,7 +366,7 @@ def conv3x3_backward(V, dy, w, U_flip, accum_into=None, side_run=None, bn_below=
     tile = 2 if V.shape[0] == 16 else 4
     dM, Vd = transform_dy_both(dy, tile)
     if side_run is not None and accum_into is not None:
-        dw = side_run(lambda: transform_dweights(gemm_batched_wgrad(V, dM), accum_into), (V, dM))
+        dw = side_run(lambda: wgrad_into(V, dM, accum_into), (V, dM))
     else:
         dw = None
     if U_flip is None:
@@ -299,4 +387,7 @@ def conv3x3_backward(V, dy, w, U_flip, accum_into=None, side_run=None, bn_below=
 
 
 def conv3x3_wgrad(V, dy, accum_into=None):
-    return transform_dweights(gemm_batched_wgrad(V, transform_dy(dy, 2 if V.shape[0] == 16 else 4)), accum_into)
+    dM = transform_dy(dy, 2 if V.shape[0] == 16 else 4)
+    if accum_into is not None:
+        return wgrad_into(V, dM, accum_into)
+    return transform_dweights(gemm_batched_wgrad(V, dM), None)

@@ -264,6 +264,54 @@ def _run_prefetch_gemm(dev):
         ref = torch.einsum("bmk,bmc->bkc", dM.cpu().double(), V.cpu().double())
         assert (dU.cpu().double() - ref).abs().max() <= 1e-4 * ref.abs().max(), (B, M, K, C)
         assert (dU - wino.gemm_batched_wgrad(V, dM, algo=1)).abs().max() <= 1e-5 * float(ref.abs().max())
+    # several problems of different shapes in one launch (gemm_tn_multi_kernel): bit-identical to one launch each -- ordered split
+    # reductions and atomic ones (single-split problems), item counts that are no multiple of 8, an empty problem
+    from omni3d_amd.kernels import detmode
+    shapes = ((3, 70, 72, 64), (2, 300, 136, 68), (2, 1024, 64, 128), (1, 128, 64, 64), (16, 600, 64, 64), (2, 0, 64, 64), (36, 40, 128, 64))
+    probs = [(torch.randn(B, M, C, generator=g).to(dev), torch.randn(B, M, K, generator=g).to(dev)) for B, M, K, C in shapes]
+    for flag in (True, False):
+        prev = detmode.set_enabled(flag)
+        try:
+            multi = wino.gemm_batched_wgrad_multi(probs)
+            for (V, dM), dU, shp in zip(probs, multi, shapes):
+                one = wino.gemm_batched_wgrad(V, dM)
+                if flag or shp[1] <= 256:
+                    assert torch.equal(dU, one), (flag, shp)
+                else:
+                    assert (dU - one).abs().max() <= 2e-5 * float(one.abs().max()), (flag, shp)
+        finally:
+            detmode.set_enabled(prev)
+    # the weight-gradient stream's context: the transforms back add into the gradient views after the common launch
+    cshapes = ((16, 600, 64, 64), (36, 40, 128, 64), (16, 300, 72, 68))
+    cprobs = [(torch.randn(B, M, C, generator=g).to(dev), torch.randn(B, M, K, generator=g).to(dev)) for B, M, K, C in cshapes]
+    start = [torch.randn(K, C, 3, 3, generator=g).to(dev).contiguous(memory_format=torch.channels_last) for _, _, K, C in cshapes]
+    want, got = [], []
+    for (V, dM), w0 in zip(cprobs, start):
+        t = w0.clone(memory_format=torch.channels_last)
+        wino.transform_dweights(wino.gemm_batched_wgrad(V, dM), t)
+        want.append(t)
+    with wino.batched_wgrads():
+        for (V, dM), w0 in zip(cprobs, start):
+            t = w0.clone(memory_format=torch.channels_last)
+            assert wino.wgrad_into(V, dM, t) is None
+            got.append(t)
+        assert torch.equal(got[0], start[0])          # nothing has been launched yet
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    # two sources into one view (the RPN's shared convolution over the FPN levels), F(2x2) and F(4x4) mixed
+    sh = ((16, 200, 64, 64), (36, 90, 64, 64), (16, 50, 64, 64))
+    sp = [(torch.randn(B, M, C, generator=g).to(dev), torch.randn(B, M, K, generator=g).to(dev)) for B, M, K, C in sh]
+    seq = start[0].clone(memory_format=torch.channels_last)
+    for V, dM in sp:
+        wino.transform_dweights(wino.gemm_batched_wgrad(V, dM), seq)
+    tog = start[0].clone(memory_format=torch.channels_last)
+    other = start[1].clone(memory_format=torch.channels_last)
+    with wino.batched_wgrads():
+        wino.wgrad_into(sp[0][0], sp[0][1], tog)
+        wino.wgrad_into(cprobs[1][0], cprobs[1][1], other)
+        wino.wgrad_into(sp[1][0], sp[1][1], tog)
+        wino.wgrad_into(sp[2][0], sp[2][1], tog)
+    assert torch.equal(seq, tog) and torch.equal(other, want[1])
 
 
 def test_persistent_gemm_emulated(emu_lib):
