@@ -568,10 +568,15 @@ int omni_stem_conv_fwd(const float* x, const float* w, float* out, int N, int H,
 /* Its weight gradient: dw (16,R,R,C) = (accumulate == 0) or += sum over pixels of dy (N,H,W,16) (x) x (N,H,W,C). */
 int omni_stem_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
                          int accumulate, void* stream);
-/* deterministic form (round 4): per-wave partial filter gradients in `ws` (plan != NULL: plan[3] = floats needed, nothing launched),
- * added in a fixed order by a second launch; same call site as omni_stem_conv_wgrad */
+/* deterministic form (round 4): per-workgroup partial filter gradients in `ws` (plan != NULL: plan[3] = floats needed, nothing
+ * launched), added in a fixed order by a second launch; same call site as omni_stem_conv_wgrad */
 int omni_stem_conv_wgrad_det(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
                              int accumulate, float* ws, long long ws_floats, long long* plan, void* stream);
+/* The stride-2 member of the family (round 4): dw (32,3,3,16) from x (N,H,W,16) and dy (N,H/2,W/2,32), H and W even -- the
+ * weight gradient of DLA-34's level1 convolution (cubercnn/modeling/backbone/dla.py:291-295; torch.nn.Conv2d backward).
+ * deterministic != 0: ws / plan as omni_stem_conv_wgrad_det; 0: fp32 atomics into dw. */
+int omni_stem_conv_s2_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
+                            int accumulate, int deterministic, float* ws, long long ws_floats, long long* plan, void* stream);
 
 /* Greedy detection <-> ground-truth matching of Omni3Deval.evaluateImg (cubercnn/evaluation/omni3d_evaluation.py:1433-1551,
  * 3D mode) for all (image, category) groups x A depth ranges x T IoU thresholds.  ious: ragged (D_g, G_g) matrices at

@@ -1381,6 +1381,17 @@ int omni_gemm_batched_fwd(const float* x, const float* w, float* out, int batch,
 // with 2-4 slabs of buffer-load prefetch in flight (gemm_tn_pf_kernel)
 constexpr bool WGRAD64_DEEP_PREFETCH = true;    // gemm_tn_pf_kernel (profiles/r03_sweep_batched_gemm.log: 3-66 % faster on every Winograd weight-gradient shape)
 
+// A/B knob (OMNI_WGRAD_LDS_PAD, bytes of unused dynamic LDS per workgroup): bounds how many weight-gradient workgroups a CU hosts, so
+// that workgroups of the critical-path stream always find registers / LDS free beside them
+static inline unsigned tn_lds_pad() {
+    static const unsigned pad = [] {
+        const char* e = getenv("OMNI_WGRAD_LDS_PAD");
+        const long v = e != nullptr ? atol(e) : 0;
+        return (unsigned)(v < 0 ? 0 : v > 32768 ? 32768 : v);
+    }();
+    return pad;
+}
+
 // 64x64 tiles of gemm_tn_pf_kernel: row splits of >= 8 slabs, aiming at >= 512 workgroups
 static inline void tn_pf_plan(int batch, int M, int C, int K, int& tiles, long& splits, int& rps) {
     tiles = ((K + 63) / 64) * ((C + 63) / 64);
@@ -1533,7 +1544,7 @@ int omni_gemm_batched_wgrad_multi(const void* const* x, const void* const* dy, c
         if (first > 0x7fffffff) return OMNI_ERR_ARG;
     }
     t.first[live] = (int)first;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_tn_multi_kernel<4>), dim3((unsigned)first), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_tn_multi_kernel<4>), dim3((unsigned)first), dim3(256), tn_lds_pad(), st, t);
     return omni_launch_status();
 }
 

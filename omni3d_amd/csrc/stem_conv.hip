@@ -138,31 +138,40 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
 }
 
 
-// ---- weight gradient: dW[k][r][s][c] += sum over output pixels of dy[pix][k] * x[pix + (r, s) - pad][c] -----------------
-// MFMA 16x16x4 with M = the 16 output channels, N = 16 columns of (tap, c) and the k dimension running over 4 consecutive
-// output pixels of a row: A[k][j] = dy[pix0 + j][k], B[j][col] = x[pix0 + j + tap(col)][c(col)].
-//   C = 16: one N block per tap (9 accumulator blocks);  C = 4: one block per 4 horizontally adjacent taps (rows of 7 taps
-//   padded to 8: 14 blocks) -- in both cases the 16 lanes of a k group read 16 consecutive floats of the LDS halo.
-// Persistent workgroups loop over 4 x 64 pixel tiles and keep the accumulators in registers; every wave adds its partial
-// filter gradient to dW with fp32 atomics at the end (dW is the flat gradient bucket or a zeroed buffer).
-template <int C, int R>
-// part != nullptr (deterministic mode, round 4): every wave stores its partial filter gradient as row (4 * blockIdx.x + wave) of
-// part[4 * gridDim.x][16 * R * R * C] instead; stem_wgrad_finalize_kernel adds the rows in a fixed order.
+// ---- weight gradient: dW[k][r][s][c] += sum over output pixels of dy[pix][k] * x[S * pix + (r, s) - pad][c] -------------
+// MFMA 16x16x4 with M = 16 output channels, N = 16 columns of (tap, c) and the k dimension running over 4 consecutive
+// output pixels of a row: A[k][j] = dy[pix0 + j][k], B[j][col] = x[S * (pix0 + j) + tap(col)][c(col)].
+//   C = 16: one N block per tap (9 accumulator blocks per 16 output channels);  C = 4: one block per 4 horizontally adjacent
+//   taps (rows of 7 taps padded to 8: 14 blocks) -- in both cases the 16 lanes of a k group read 16 consecutive floats of the
+//   LDS halo.
+// (C, R, S, K) = (4, 7, 1, 16) base_layer | (16, 3, 1, 16) level0 | (16, 3, 2, 32) level1 (round 4: the stride-2 layer ran on the
+//   implicit GEMM's 32 x 128 tiles cut 512 ways over the pixels, 197 us for 2.4 GFLOP and 100 MB).
+// Persistent workgroups loop over TH x TW output tiles and keep the accumulators in registers.  At the end the four waves add
+// their partial filter gradients in LDS, wave 0 first, and the workgroup either stores ONE partial row (part != nullptr:
+// deterministic mode, stem_wgrad_finalize_kernel adds the rows in a fixed order) or adds it to dw with fp32 atomics.
+template <int C, int R, int S, int K>
 __global__ void __launch_bounds__(256) stem_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                              float* __restrict__ dw, int N, int H, int W, int ldx, int lddy,
-                                                              float* __restrict__ part) {
-    constexpr int TH = 4, TW = 64, PAD = R / 2;
-    constexpr int HR = TH + R - 1, HC = TW + R - 1 + (C == 4 ? 1 : 0);
-    constexpr int NB = (C == 16) ? R * R : R * 2;            // accumulator blocks
-    __shared__ __attribute__((aligned(16))) float s_in[HR * HC * C];
-    __shared__ __attribute__((aligned(16))) float s_dy[TH * TW * 16];
+                                                              float* __restrict__ dw, int N, int H, int W, int OH, int OW, int ldx,
+                                                              int lddy, float* __restrict__ part) {
+    constexpr int TH = 4, TW = (S == 1) ? 64 : 32, PAD = R / 2, KB = K / 16, K4 = K / 4;
+    constexpr int HR = S * (TH - 1) + R, HC = S * (TW - 1) + R + (C == 4 ? 1 : 0);
+    constexpr int NB = (C == 16) ? R * R : R * 2;            // accumulator blocks per 16 output channels
+    constexpr int KD = R * R * C, E = K * KD;
+    constexpr int IN_FLOATS = HR * HC * C, DY_FLOATS = TH * TW * K;
+    static_assert(E <= IN_FLOATS + DY_FLOATS, "the filter gradient is summed over the waves in the tile buffers");
+    static_assert(C == 16 || S == 1, "the 4-channel form walks 4 adjacent taps per block");
+    __shared__ __attribute__((aligned(16))) float smem[IN_FLOATS + DY_FLOATS];
+    float* s_in = smem;
+    float* s_dy = smem + IN_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int tiles_x = (OW + TW - 1) / TW, tiles_y = (OH + TH - 1) / TH;
     const int tiles = N * tiles_y * tiles_x;
-    f32x4 acc[NB];
+    f32x4 acc[KB][NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[kb][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     constexpr int C4 = C / 4;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         int t = tile;
@@ -172,13 +181,13 @@ __global__ void __launch_bounds__(256) stem_conv_wgrad_kernel(const float* __res
         const int oy0 = ty * TH, ox0 = tx * TW;
         // all global loads of the tile before the first LDS store (see stem_conv_fwd_kernel); they are issued BEFORE the barrier
         // that frees the LDS tiles, so they fly while the other waves finish the previous tile's MFMAs
-        constexpr int NI = (HR * HC * C4 + 255) / 256, ND = (TH * TW * 4 + 255) / 256;
+        constexpr int NI = (HR * HC * C4 + 255) / 256, ND = (TH * TW * K4 + 255) / 256;
         float4 vi[NI], vd[ND];
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int i = tid + 256 * u;
             const int c4 = i % C4, cc = (i / C4) % HC, row = i / (C4 * HC);
-            const int iy = oy0 - PAD + row, ix = ox0 - PAD + cc;
+            const int iy = S * oy0 - PAD + row, ix = S * ox0 - PAD + cc;
             vi[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < HR * HC * C4 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
                 vi[u] = ld4(x + (((long)n * H + iy) * W + ix) * ldx + 4 * c4);
@@ -186,10 +195,10 @@ __global__ void __launch_bounds__(256) stem_conv_wgrad_kernel(const float* __res
 #pragma unroll
         for (int u = 0; u < ND; ++u) {
             const int i = tid + 256 * u;
-            const int k4 = i % 4, cc = (i / 4) % TW, row = i / (4 * TW);
+            const int k4 = i % K4, cc = (i / K4) % TW, row = i / (K4 * TW);
             const int oy = oy0 + row, ox = ox0 + cc;
             vd[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < TH * TW * 4 && oy < H && ox < W) vd[u] = ld4(dy + (((long)n * H + oy) * W + ox) * lddy + 4 * k4);
+            if (i < TH * TW * K4 && oy < OH && ox < OW) vd[u] = ld4(dy + (((long)n * OH + oy) * OW + ox) * lddy + 4 * k4);
         }
         __syncthreads();                                      // previous tile's LDS reads are done
 #pragma unroll
@@ -201,50 +210,69 @@ __global__ void __launch_bounds__(256) stem_conv_wgrad_kernel(const float* __res
 #pragma unroll
         for (int u = 0; u < ND; ++u) {
             const int i = tid + 256 * u;
-            const int k4 = i % 4, cc = (i / 4) % TW, row = i / (4 * TW);
-            if (i < TH * TW * 4) *reinterpret_cast<float4*>(s_dy + (row * TW + cc) * 16 + 4 * k4) = vd[u];
+            const int k4 = i % K4, cc = (i / K4) % TW, row = i / (K4 * TW);
+            if (i < TH * TW * K4) *reinterpret_cast<float4*>(s_dy + (row * TW + cc) * K + 4 * k4) = vd[u];
         }
         __syncthreads();
 #pragma unroll 1
         for (int p0 = 0; p0 < TW; p0 += 4) {                  // 4 output pixels of row `wave` per k group
-            const float a = s_dy[(wave * TW + p0 + g) * 16 + col];
+            float a[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) a[kb] = s_dy[(wave * TW + p0 + g) * K + kb * 16 + col];
             if (C == 16) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int sx = 0; sx < R; ++sx)
-                        acc[r * R + sx] = mfma_16x16x4(a, s_in[((wave + r) * HC + p0 + g + sx) * C + col], acc[r * R + sx]);
+                    for (int sx = 0; sx < R; ++sx) {
+                        const float b = s_in[((S * wave + r) * HC + S * (p0 + g) + sx) * C + col];
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb) acc[kb][r * R + sx] = mfma_16x16x4(a[kb], b, acc[kb][r * R + sx]);
+                    }
             } else {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int blk = 0; blk < 2; ++blk)
-                        acc[r * 2 + blk] = mfma_16x16x4(a, s_in[((wave + r) * HC + p0 + g + 4 * blk) * C + col], acc[r * 2 + blk]);
+                    for (int blk = 0; blk < 2; ++blk) {
+                        const float b = s_in[((wave + r) * HC + p0 + g + 4 * blk) * C + col];
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb) acc[kb][r * 2 + blk] = mfma_16x16x4(a[kb], b, acc[kb][r * 2 + blk]);
+                    }
             }
         }
     }
-    // D[row = 4g + i][col]: k = 4g + i;  C = 16: (tap = block, c = col);  C = 4: (s = 4 blk + col / 4, c = col % 4)
-    constexpr int KD = R * R * C;
+    // D[row = 4g + i][col]: k = 16 kb + 4g + i;  C = 16: (tap = block, c = col);  C = 4: (s = 4 blk + col / 4, c = col % 4).
+    // The four waves add into smem[E] one after the other (every element belongs to the same lane in each wave).
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        int off;
-        bool ok = true;
-        if (C == 16) {
-            off = b * C + col;
-        } else {
-            const int r = b >> 1, sx = 4 * (b & 1) + (col >> 2);
-            ok = sx < R;
-            off = (r * R + sx) * C + (col & 3);
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    int off;
+                    bool ok = true;
+                    if (C == 16) {
+                        off = b * C + col;
+                    } else {
+                        const int r = b >> 1, sx = 4 * (b & 1) + (col >> 2);
+                        ok = sx < R;
+                        off = (r * R + sx) * C + (col & 3);
+                    }
+                    if (!ok) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float* q = smem + (kb * 16 + 4 * g + i) * KD + off;
+                        *q = (w == 0) ? acc[kb][b][i] : *q + acc[kb][b][i];
+                    }
+                }
         }
-        if (!ok) continue;
-        if (part != nullptr) {
-            float* row = part + ((long)blockIdx.x * 4 + wave) * (16 * KD);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) row[(4 * g + i) * KD + off] = acc[b][i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(dw + (long)(4 * g + i) * KD + off, acc[b][i]);
-        }
+    }
+    __syncthreads();
+    if (part != nullptr) {
+        float* row = part + (long)blockIdx.x * E;
+        for (int e = tid; e < E; e += 256) row[e] = smem[e];
+    } else {
+        for (int e = tid; e < E; e += 256) atomicAdd(dw + e, smem[e]);
     }
 }
 
@@ -256,8 +284,18 @@ __global__ void __launch_bounds__(256) stem_wgrad_finalize_kernel(const float* _
     const int t = threadIdx.x, el = t & 3, rg = t >> 2;
     const int e = (int)blockIdx.x * 4 + el;
     double a = 0.0;
-    if (e < E)
-        for (int r = rg; r < rows; r += 64) a += (double)part[(long)r * E + e];
+    if (e < E) {
+        int r = rg;
+        for (; r + 192 < rows; r += 256) {       // four independent loads in flight: this loop is pure latency
+            const float v0 = part[(long)r * E + e], v1 = part[(long)(r + 64) * E + e], v2 = part[(long)(r + 128) * E + e],
+                        v3 = part[(long)(r + 192) * E + e];
+            a += (double)v0;
+            a += (double)v1;
+            a += (double)v2;
+            a += (double)v3;
+        }
+        for (; r < rows; r += 64) a += (double)part[(long)r * E + e];
+    }
     sm[t] = a;
     __syncthreads();
     for (int s = 128; s >= 4; s >>= 1) {
@@ -301,40 +339,56 @@ int omni_stem_conv_fwd_stats(const float* x, const float* w, float* out, int N, 
     return stem_fwd_impl(x, w, out, N, H, W, C, K, R, ldx, ldo, stats, stats_rows, nblk_out, stream);
 }
 
-// dw (16,R,R,C) (+)= sum_pix dy (N,H,W,16) x (N,H,W,C); accumulate == 0 zeroes dw first (atomic accumulation either way).
-static int stem_wgrad_impl(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
-                           int accumulate, float* ws, long long ws_floats, long long* plan, bool det, void* stream) {
-    if (N < 0 || H <= 0 || W <= 0 || K != 16 || ldx < C || lddy < K || (ldx & 3) || (lddy & 3)) return OMNI_ERR_ARG;
-    if (!((C == 4 && R == 7) || (C == 16 && R == 3))) return OMNI_ERR_ARG;
+// dw (K,R,R,C) (+)= sum_pix dy (N,OH,OW,K) x (N,H,W,C); accumulate == 0 zeroes dw first (atomic accumulation either way).
+// (C, R, stride, K) in {(4, 7, 1, 16), (16, 3, 1, 16), (16, 3, 2, 32)}; stride 2: H, W even, OH = H / 2.
+static int stem_wgrad_impl(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int stride, int ldx,
+                           int lddy, int accumulate, float* ws, long long ws_floats, long long* plan, bool det, void* stream) {
+    if (N < 0 || H <= 0 || W <= 0 || ldx < C || lddy < K || (ldx & 3) || (lddy & 3)) return OMNI_ERR_ARG;
+    const int form = (C == 4 && R == 7 && stride == 1 && K == 16) ? 0 : (C == 16 && R == 3 && stride == 1 && K == 16) ? 1
+                   : (C == 16 && R == 3 && stride == 2 && K == 32 && !(H & 1) && !(W & 1)) ? 2 : -1;
+    if (form < 0) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    long tiles = (long)N * ((H + 3) / 4) * ((W + 63) / 64);
-    const unsigned grid = (unsigned)(tiles < 768 ? tiles : 768);        // 3 resident workgroups per CU
+    const int OH = H / stride, OW = W / stride, TW = stride == 1 ? 64 : 32;
+    const long tiles = (long)N * ((OH + 3) / 4) * ((OW + TW - 1) / TW);
+    // <= 3 resident workgroups per CU, every one with the same number of tiles (+- 1)
+    const long per = (tiles + 767) / 768;
+    const unsigned grid = (unsigned)(tiles <= 768 ? tiles : (tiles + per - 1) / per);
     const int E = K * R * R * C;
-    if (plan != nullptr) { plan[0] = plan[1] = plan[2] = 0; plan[3] = (long long)grid * 4 * E; return OMNI_OK; }
-    if (det && N > 0 && (ws == nullptr || ws_floats < (long long)grid * 4 * E)) return OMNI_ERR_ARG;
+    if (plan != nullptr) { plan[0] = plan[1] = plan[2] = 0; plan[3] = (long long)grid * E; return OMNI_OK; }
+    if (det && N > 0 && (ws == nullptr || ws_floats < (long long)grid * E)) return OMNI_ERR_ARG;
     if (!accumulate && (!det || N == 0)) omni_memset_async(dw, 0, sizeof(float) * (size_t)E, st);
     if (N == 0) return OMNI_OK;
     float* part = det ? ws : nullptr;
-    if (C == 4)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<4, 7>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, ldx, lddy, part);
+    if (form == 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<4, 7, 1, 16>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, OH, OW, ldx, lddy, part);
+    else if (form == 1)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<16, 3, 1, 16>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, OH, OW, ldx, lddy, part);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<16, 3>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, ldx, lddy, part);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<16, 3, 2, 32>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, OH, OW, ldx, lddy, part);
     if (det)
-        hipLaunchKernelGGL(stem_wgrad_finalize_kernel, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, st, (const float*)part, (int)grid * 4, E, dw,
+        hipLaunchKernelGGL(stem_wgrad_finalize_kernel, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, st, (const float*)part, (int)grid, E, dw,
                            accumulate);
     return omni_launch_status();
 }
 
 int omni_stem_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
                          int accumulate, void* stream) {
-    return stem_wgrad_impl(x, dy, dw, N, H, W, C, K, R, ldx, lddy, accumulate, nullptr, 0, nullptr, false, stream);
+    return stem_wgrad_impl(x, dy, dw, N, H, W, C, K, R, 1, ldx, lddy, accumulate, nullptr, 0, nullptr, false, stream);
 }
 
-// deterministic form: per-wave partial filter gradients go to `ws` (ws_floats floats; plan != NULL: plan[3] = floats needed, no
+// deterministic form: per-workgroup partial filter gradients go to `ws` (ws_floats floats; plan != NULL: plan[3] = floats needed, no
 // launch) and a second launch adds them in a fixed order into dw (overwritten, or added to when accumulate != 0); no atomics
 int omni_stem_conv_wgrad_det(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
                              int accumulate, float* ws, long long ws_floats, long long* plan, void* stream) {
-    return stem_wgrad_impl(x, dy, dw, N, H, W, C, K, R, ldx, lddy, accumulate, ws, ws_floats, plan, true, stream);
+    return stem_wgrad_impl(x, dy, dw, N, H, W, C, K, R, 1, ldx, lddy, accumulate, ws, ws_floats, plan, true, stream);
+}
+
+// the stride-2 member of the family: dw (32,3,3,16) from x (N,H,W,16) and dy (N,H/2,W/2,32) (DLA-34 level1, dla.py:291-295).
+// deterministic != 0: as omni_stem_conv_wgrad_det (ws / plan); 0: fp32 atomics into dw, ws / plan unused
+int omni_stem_conv_s2_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
+                            int accumulate, int deterministic, float* ws, long long ws_floats, long long* plan, void* stream) {
+    return stem_wgrad_impl(x, dy, dw, N, H, W, C, K, R, 2, ldx, lddy, accumulate, ws, ws_floats, deterministic ? plan : nullptr,
+                           deterministic != 0, stream);
 }
 
 }  // extern "C"

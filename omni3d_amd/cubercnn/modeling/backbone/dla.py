@@ -254,7 +254,7 @@ class DLABackbone(Backbone):
         """{module name: backward stage its parameters' gradients complete in} for the cut points of `stage_cut_at` (stage 0 = the
         heads, 1 = FPN + everything above the topmost cut, counting up towards the input); read by solver/build.py to lay the
         gradient bucket out stage by stage"""
-        order = [("base_layer", "stem"), ("level0", None), ("level1", None), ("level2", "p2"), ("level3", "p3"), ("level4", "p4"), ("level5", "p5")]
+        order = [("base_layer", "stem"), ("level0", None), ("level1", "l1"), ("level2", "p2"), ("level3", "p3"), ("level4", "p4"), ("level5", "p5")]
         n_cuts = sum(1 for _, c in order if c in self.stage_cut_at)
         out, seen = {}, 0
         for name, c in order:
@@ -268,7 +268,7 @@ class DLABackbone(Backbone):
         cut = lambda name, t: self.stage_cut(t) if (on and name in self.stage_cut_at) else t      # noqa: E731
         # ("stem": the first layer's backward -- a BatchNorm backward and a 0.33 ms weight gradient, nothing below it -- as a stage of
         # its own, so the weight gradients of level 2 .. level 0 run beside it instead of after it)
-        x = self.level1(self.level0(cut("stem", self.base_layer(x))))
+        x = cut("l1", self.level1(self.level0(cut("stem", self.base_layer(x)))))
         if self.fwd_split is not None:       # solver/graphed.py: the forward graph is cut here (no Winograd layer above this point)
             self.fwd_split()
         p2 = cut("p2", self.level2(x))

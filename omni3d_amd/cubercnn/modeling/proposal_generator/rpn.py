@@ -199,7 +199,8 @@ class RPNWithIgnore(nn.Module):
         levels = self.rpn_head(feats)
         if self.training:
             assert targets is not None, "RPN requires ground truth in training!"
-            labels, matched_idx = self.label_and_sample_anchors(anchors, targets)
+            with HF.forked():        # (a parallel branch of the captured step, joined behind the proposals; eager: a no-op)
+                labels, matched_idx = self.label_and_sample_anchors(anchors, targets)
             losses = self.losses(levels, anchors, labels, matched_idx, targets)
             self.last_labels = labels
         else:
@@ -207,6 +208,7 @@ class RPNWithIgnore(nn.Module):
         image_hw = targets.image_hw if targets is not None else torch.tensor(
             [list(s) for s in images.image_sizes], dtype=torch.int32, device=anchors.device)
         prop, scores, count = self.predict_proposals(levels, anchors, hw_list, image_hw)
+        HF.join_branch()
         self.last = {"boxes": prop, "scores": scores, "count": count}
         if self.injected is not None and "proposals" in self.injected:
             # stage-wise parity tests: the second stage runs on a given proposal list (list of (n_i, 4) boxes in score

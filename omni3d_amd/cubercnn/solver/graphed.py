@@ -10,6 +10,8 @@ scan, SGD update: 3-4 launches) stays eager so schedulers keep working on host f
 The reference's loop is tools/train_net.py:do_train (:175-259); this object replaces its
 `loss_dict = model(data); losses.backward()` pair for a pre-staged batch.  New input data is fed by copying
 into the static tensors the graph was captured with (`static_batch` / `static_packed`)."""
+import os
+
 import torch
 
 from ...functional import total_loss
@@ -328,6 +330,12 @@ class GraphedPipelined:
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
         HF.side_mode("collect")
+        # forward branches (functional.set_branch_stream): the RPN's labelling + loss beside its proposal selection, inside M0.
+        # MEASURED and left OFF (OMNI_PIPE_BRANCH=1 enables it): M0 ends 0.10 ms earlier on the device, but hipGraphLaunch of a graph
+        # with a fork blocks the host for the length of a step on ROCm 7.2 (host time of the M0 launch 0.1 -> 11.9 ms), the later
+        # stages are enqueued late and the step takes 12.5 ms instead of 11.4 (profiles/r04_ab_branch.log)
+        self.branch = torch.cuda.Stream() if os.environ.get("OMNI_PIPE_BRANCH", "0") == "1" else None
+        prev_branch = HF.set_branch_stream(self.branch)
         # deterministic split reductions (kernels/detmode.py): the critical-path graphs and the weight-gradient graphs replay
         # side by side, so each family gets its own block of arrival counters, allocated before the first capture starts
         from ...kernels import detmode, wino
@@ -363,6 +371,7 @@ class GraphedPipelined:
                     break
             self.stages = stages
         finally:
+            HF.set_branch_stream(prev_branch)
             HF.side_take()
             HF.side_mode(prev_mode)
 

@@ -183,6 +183,8 @@ def _side_run(fn, keepalive):
     mode = _side["mode"]
     if mode == "inline" or (dev.type != "cuda" and mode != "collect"):
         return fn()
+    if _DEBUG_DROP_SIDE:           # timing experiment only (tools): the critical path alone, parameter gradients never computed
+        return None
     _side["queue"].append(fn)
     _side["pending"].extend(keepalive)
     if mode == "collect":
@@ -198,6 +200,49 @@ def _side_run(fn, keepalive):
     return None
 
 
+# ---- a second branch inside the forward pass (round 4) ------------------------------------------------------------------------------
+# The RPN's anchor labelling + sampling + loss forward (0.14 ms of latency-bound launches) and its proposal selection (top-k, decode,
+# NMS, top-k: 0.32 ms of them) both start from the head outputs and do not read each other.  While a step is being captured
+# (solver/graphed.py installs a stream) the first runs on that stream -- a parallel branch of the SAME hipGraph -- and the capturing
+# stream waits for it where the proposals are done.  Without an installed stream (eager steps, tests) nothing changes.
+_branch = {"stream": None, "open": False}
+
+
+def set_branch_stream(stream):
+    """-> the previous one; None switches the fork off"""
+    prev, _branch["stream"], _branch["open"] = _branch["stream"], stream, False
+    return prev
+
+
+class forked:
+    """with forked(): launches inside go to the branch stream (which first waits for everything the current stream has been given);
+    join_branch() makes the current stream wait for the branch.  Custom Functions enter it INSIDE forward(), so that autograd keeps
+    seeing the ambient stream and runs their backward there."""
+
+    def __enter__(self):
+        self.ctx = None
+        st = _branch["stream"]
+        if st is not None:
+            if not _branch["open"]:
+                st.wait_stream(torch.cuda.current_stream())
+                _branch["open"] = True
+            self.ctx = torch.cuda.stream(st)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+        return False
+
+
+def join_branch():
+    if _branch["open"]:
+        torch.cuda.current_stream().wait_stream(_branch["stream"])
+        _branch["open"] = False
+
+
+_DEBUG_DROP_SIDE = _environ.get("OMNI_DEBUG_DROP_SIDE", "0") == "1"
 BIAS_GRAD_SIDE = _environ.get("OMNI_BIAS_GRAD_SIDE", "1") != "0"
 
 
@@ -289,7 +334,7 @@ class _Conv2d(Function):
             # (measured: the stem weight-gradient kernel wins for the 16-channel layer, 0.13 vs 0.21 ms, not for the
             # 4-channel 7x7 layer, 0.26 vs 0.21 ms, which keeps the split-K implicit GEMM)
             def wgrad():
-                return (conv.stem_conv_wgrad(x, dy, w.shape[2], accum_into=gw) if (ctx.stem and w.shape[1] == 16)
+                return (conv.stem_conv_wgrad(x, dy, w.shape[2], accum_into=gw, stride=stride) if conv.stem_wgrad_eligible(x.shape, w.shape, stride, pad)
                         else conv.conv2d_wgrad(x, dy, (w.shape[2], w.shape[3]), stride, pad, accum_into=gw))
             dw = _side_run(wgrad, (x, dy)) if gw is not None else wgrad()
         db = None
@@ -1012,14 +1057,16 @@ class _RPNLoss(Function):
     @staticmethod
     def forward(ctx, anchors, labels, matched_idx, gt, gt_off, inv_norm, weights, plain, *levels):
         ctx.set_materialize_grads(False)      # no zero tensors for the non-differentiable side outputs
-        lv = [_cl(t).permute(0, 2, 3, 1) for t in levels]
-        pack = det.LevelPack(lv)
-        sums = det.rpn_loss_fwd(pack, anchors, labels, matched_idx, gt, gt_off, plain)
+        with forked():                        # (behind the labelling, beside the proposal selection: see set_branch_stream)
+            lv = [_cl(t).permute(0, 2, 3, 1) for t in levels]
+            pack = det.LevelPack(lv)
+            sums = det.rpn_loss_fwd(pack, anchors, labels, matched_idx, gt, gt_off, plain)
+            vec = sums[:2].float() * _coef((inv_norm * weights[0], inv_norm * weights[1]), sums.device)
         ctx.pack = pack
         ctx.save_for_backward(anchors, labels, matched_idx, gt, gt_off)
         ctx.inv_norm, ctx.weights, ctx.plain = inv_norm, weights, plain
         ctx.mark_non_differentiable(sums)
-        return sums[:2].float() * _coef((inv_norm * weights[0], inv_norm * weights[1]), sums.device), sums
+        return vec, sums
 
     @staticmethod
     def backward(ctx, g, _):

@@ -244,21 +244,46 @@ def stem_conv_fwd(x, w):
     return out.permute(0, 3, 1, 2)
 
 
-def stem_conv_wgrad(x, dy, R, accum_into=None):
-    """x (N,C,H,W) CL, dy (N,16,H,W) CL -> dw (16,C,R,R) CL; accum_into: KRSC-contiguous gradient view to ADD into."""
+_STEM_WGRAD_ALL = os.environ.get("OMNI_STEM_WGRAD_ALL", "1") != "0"       # A/B: 0 = only the 16 -> 16 stride-1 layer (rounds 2-3)
+
+
+def stem_wgrad_eligible(x_shape, w_shape, stride, pad):
+    """weight gradients served by stem_conv_wgrad_kernel: the two stride-1 stem layers and (16 -> 32, 3x3, stride 2) = DLA-34 level1.
+    The 4-channel 7x7 form only with the deterministic reductions on: its 3136-element filter gradient met 3072 waves' worth of
+    fp32 atomics (0.26 ms against the implicit GEMM's 0.21), the partial rows + fixed-order finalize do not"""
+    K, C, R, S = w_shape
+    if R != S or pad != R // 2 or x_shape[1] != C:
+        return False
+    if stride == 1:
+        return K == 16 and ((C, R) == (16, 3) or ((C, R) == (4, 7) and _det.on() and _STEM_WGRAD_ALL))
+    return _STEM_WGRAD_ALL and stride == 2 and (K, C, R) == (32, 16, 3) and x_shape[2] % 2 == 0 and x_shape[3] % 2 == 0
+
+
+def stem_conv_wgrad(x, dy, R, accum_into=None, stride=1):
+    """x (N,C,H,W) CL, dy (N,K,H/stride,W/stride) CL -> dw (K,C,R,R) CL; accum_into: KRSC-contiguous gradient view to ADD into."""
     xv, dv = _nhwc(x), _nhwc(dy)
     N, H, W, C = xv.shape
     K = dv.shape[3]
     L = _lib.check_device(xv, dv)
-    def launch(dst, acc):
-        if not _det.on():
+    on = _det.on()
+
+    def call(dst, acc, ws, wsf, plan):
+        if stride == 2:
+            L.call("omni_stem_conv_s2_wgrad", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dst), N, H, W, C, K, R, C, K, acc, int(on), ws, wsf, plan,
+                   _lib.stream_of(x))
+        elif on:
+            L.call("omni_stem_conv_wgrad_det", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dst), N, H, W, C, K, R, C, K, acc, ws, wsf, plan, _lib.stream_of(x))
+        else:
             L.call("omni_stem_conv_wgrad", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dst), N, H, W, C, K, R, C, K, acc, _lib.stream_of(x))
+
+    def launch(dst, acc):
+        if not on:
+            call(dst, acc, None, 0, None)
             return
         plan, addr = _det.new_plan()
-        L.call("omni_stem_conv_wgrad_det", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dst), N, H, W, C, K, R, C, K, acc, None, 0, addr, _lib.stream_of(x))
+        call(dst, acc, None, 0, addr)
         ws = torch.empty(max(int(plan[3]), 1), dtype=torch.float32, device=x.device)
-        L.call("omni_stem_conv_wgrad_det", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dst), N, H, W, C, K, R, C, K, acc, _lib.ptr(ws), int(plan[3]), None,
-               _lib.stream_of(x))
+        call(dst, acc, _lib.ptr(ws), int(plan[3]), None)
     if accum_into is not None:
         gv = accum_into.permute(0, 2, 3, 1)
         assert gv.is_contiguous() and tuple(gv.shape) == (K, R, R, C)

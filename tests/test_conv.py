@@ -354,15 +354,40 @@ def _run_stem(dev, N, H, W, C, R, seed=4):
     assert (acc.cpu() - 1.0 - dw_ref).abs().max() <= tol
 
 
+def _run_stem_s2_wgrad(dev, N, H, W, seed=7):
+    """the stride-2 member (DLA-34 level1, 16 -> 32): both reduction forms against torch's conv2d_weight"""
+    from omni3d_amd.kernels import conv, detmode
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, 16, H, W, generator=g)
+    dy = torch.randn(N, 32, H // 2, W // 2, generator=g)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last).to(dev)  # noqa: E731
+    assert conv.stem_wgrad_eligible(x.shape, (32, 16, 3, 3), 2, 1) and not conv.stem_wgrad_eligible((N, 16, H + 1, W), (32, 16, 3, 3), 2, 1)
+    dw_ref = torch.nn.grad.conv2d_weight(x, (32, 16, 3, 3), dy, stride=2, padding=1)
+    tol = 2e-6 * float(torch.nn.grad.conv2d_weight(x.abs(), (32, 16, 3, 3), dy.abs(), stride=2, padding=1).max())
+    for flag in (True, False):
+        prev = detmode.set_enabled(flag)
+        try:
+            dw = conv.stem_conv_wgrad(cl(x), cl(dy), 3, stride=2)
+            assert dw.shape == dw_ref.shape and (dw.cpu() - dw_ref).abs().max() <= tol, flag
+            acc = torch.ones(32, 16, 3, 3).contiguous(memory_format=torch.channels_last).to(dev)
+            conv.stem_conv_wgrad(cl(x), cl(dy), 3, accum_into=acc, stride=2)
+            assert (acc.cpu() - 1.0 - dw_ref).abs().max() <= tol, flag
+        finally:
+            detmode.set_enabled(prev)
+
+
 def test_stem_conv_emulated(emu_lib):
     _run_stem("cpu", 1, 6, 70, 16, 3)      # ragged tile in x and y
     _run_stem("cpu", 2, 5, 9, 4, 7)
+    _run_stem_s2_wgrad("cpu", 2, 10, 70)   # 5 x 35 outputs: ragged in both directions
 
 
 @pytest.mark.gpu
 def test_stem_conv_gpu(hip_lib):
     _run_stem("cuda", 2, 128, 192, 16, 3)
     _run_stem("cuda", 2, 130, 100, 4, 7)
+    _run_stem_s2_wgrad("cuda", 2, 132, 200)
+    _run_stem_s2_wgrad("cuda", 4, 512, 512)       # level1 at the benchmark's size: more tiles than persistent workgroups
 
 
 def _run_stem_autograd(dev):
