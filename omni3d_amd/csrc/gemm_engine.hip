@@ -39,12 +39,27 @@ struct GemmArgs {
     // balanced mode (BAL): every workgroup owns bal_r whole tiles, the remaining tiles (fewer than workgroups) are cut along the
     // reduction into bal_ts parts of bal_sps slabs, one part per workgroup (bal_tail_items of them)
     int bal_r, bal_ts, bal_sps, bal_tail_items;
+    // tile order (engine_tile): bands of `band` tile rows, inside a band tile row fastest -- the 32 workgroups of an XCD, which take 32
+    // consecutive tiles at a time, then cover a band x (32 / band) block of tiles and share both operand panels in that XCD's L2
+    int band;
     // deterministic mode: ws != nullptr -> the parts of a cut tile are stored to `ws` and summed in part order by
     // engine_cut_finalize_kernel (bias / ReLU / accumulate applied there)
     float* ws;
 };
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return mfma_32x32x2(a, b, c); }
+
+// linear tile index of one batch entry -> tile coordinates.  band == 1 is row-major (tile column fastest): 32 consecutive tiles are
+// then one tile row x 32 columns -- they share the A panel, and every B panel is fetched again for each of the tiles_m rows (fc1's
+// weight gradient: 103 MB of activations x 8 = the 930 MB of traffic behind 163 MB of operands in profiles/r03_pmc_families.csv).
+// With bands of 8 rows the same 32 tiles are an 8 x 4 block: A is fetched tiles_n / 4 times, B tiles_m / 8 times.
+__device__ __forceinline__ void engine_tile(int t, int tiles_m, int tiles_n, int band, int& tm, int& tn) {
+    const int per = band * tiles_n;
+    const int bnd = t / per, idx = t - bnd * per;
+    const int bm = min(band, tiles_m - bnd * band);
+    tn = idx / bm;
+    tm = bnd * band + (idx - tn * bm);
+}
 
 // Compile-time description of one k-chunk's issue order for the scheduler: SLOTS pairs of MFMAs, after each pair either one
 // DMA piece (slots 2, 5, 8, ... until the ND pieces of the chunk are placed) or the next few of the NR fragment reads.
@@ -119,8 +134,9 @@ __global__ void __launch_bounds__(256) gemm_engine_kernel(GemmArgs p) {
         } else {
             r = item;
         }
-        tn = r % p.tiles_n; r /= p.tiles_n;
-        tm = r % p.tiles_m; r /= p.tiles_m;
+        const int per_b = p.tiles_m * p.tiles_n;
+        engine_tile(r % per_b, p.tiles_m, p.tiles_n, p.band, tm, tn);
+        r /= per_b;
         b = r % p.batch;
         if (!BAL) {
             const int split = r / p.batch;
@@ -374,19 +390,20 @@ __global__ void __launch_bounds__(256) transpose2d_kernel(const float* __restric
 
 // Deterministic mode, second launch: C tile (=, or += when accumulate) sum over the parts of a cut tile in part order (+ bias)
 // (ReLU).  One workgroup per (cut tile, 8 accumulator registers): thread tid adds `parts` slot values per register, all loads of a
-// register independent.  first_tile: linear index (batch, tile row, tile column) of cut tile 0.
+// register independent.  first_tile: linear index (batch, then engine_tile order) of cut tile 0.
 template <int BM, int BN>
 __global__ void __launch_bounds__(256) engine_cut_finalize_kernel(const float* __restrict__ ws, int parts, long first_tile, int tiles_m,
                                                                   int tiles_n, float* __restrict__ C, const float* __restrict__ bias, int M,
-                                                                  int N, int ldc, long sc, int relu, int accumulate) {
+                                                                  int N, int ldc, long sc, int relu, int accumulate, int band) {
     constexpr int WN = BN / 64, NACC = BM * BN / 256, CH = NACC / 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     const long ct = (long)blockIdx.x / CH;
     const int r0 = ((int)blockIdx.x % CH) * 8;
-    long r = first_tile + ct;
-    const int tn = (int)(r % tiles_n); r /= tiles_n;
-    const int tm = (int)(r % tiles_m);
-    const long b = r / tiles_m;
+    const long r = first_tile + ct;
+    const long per_b = (long)tiles_m * tiles_n;
+    int tm, tn;
+    engine_tile((int)(r % per_b), tiles_m, tiles_n, band, tm, tn);      // (band: the order the kernel numbered the cut tiles in)
+    const long b = r / per_b;
     const float* slot = ws + ct * parts * (long)(BM * BN) + tid;
     float* o = C + b * sc;
 #pragma unroll
@@ -413,11 +430,22 @@ struct EngineDet {
     long long* plan;        // != nullptr: report {0, parts of a cut tile, counters, workspace floats} and do not launch
 };
 
+// tile rows per band (see engine_tile); OMNI_ENGINE_BAND overrides (1 = row-major, the order of rounds 2-3)
+static inline int engine_band(int tiles_m) {
+    static const int forced = [] {
+        const char* e = getenv("OMNI_ENGINE_BAND");
+        return e != nullptr ? atoi(e) : 0;
+    }();
+    int band = forced > 0 ? forced : 8;
+    if (band > tiles_m) band = tiles_m;
+    return band < 1 ? 1 : band;
+}
+
 template <int LA, int LB, int BM, int BN>
 int launch_engine(GemmArgs p, int workgroups, hipStream_t st, const EngineDet& det) {
     p.ws = nullptr;
     long fin_tiles = 0, fin_first = 0;
-    int fin_parts = 0;
+    int fin_parts = 0, fin_band = 1;
     auto bind = [&](long cut_tiles, long parts, long first) -> int {        // deterministic mode: slots for the cut tiles
         if (det.plan != nullptr) {
             det.plan[0] = 0; det.plan[1] = parts; det.plan[2] = 0;
@@ -434,10 +462,11 @@ int launch_engine(GemmArgs p, int workgroups, hipStream_t st, const EngineDet& d
         if (fin_tiles > 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(engine_cut_finalize_kernel<BM, BN>), dim3((unsigned)(fin_tiles * (BM * BN / 2048))), dim3(256), 0, st,
                                (const float*)p.ws, fin_parts, fin_first, p.tiles_m, p.tiles_n, p.C, p.bias, p.M, p.N, p.ldc, p.sc, p.relu,
-                               p.accumulate);
+                               p.accumulate, fin_band);
     };
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
+    p.band = engine_band(p.tiles_m);
     const int nk_total = (p.K + 31) / 32;
     const long tiles = (long)p.tiles_m * p.tiles_n * p.batch;
     if (p.splits == -1) {                                                       // balanced: whole tiles + one cut part per workgroup
@@ -453,6 +482,7 @@ int launch_engine(GemmArgs p, int workgroups, hipStream_t st, const EngineDet& d
             p.bal_tail_items = (int)left * p.bal_ts;
             const int rc = bind(left, p.bal_ts, tiles - left);
             if (rc != 0) return rc > 0 ? OMNI_OK : OMNI_ERR_ARG;
+            fin_band = p.band;                                                  // cut tiles are numbered in the kernel's tile order
             if (p.bal_ts > 1 && p.relu && p.ws == nullptr) return OMNI_ERR_ARG;    // cut tiles meet through atomics: no ReLU on them
             p.splits = 1;
             p.items = (int)tiles;
@@ -492,7 +522,7 @@ extern "C" {
 // splits > 1 or accumulate != 0: fp32 atomics into C (the caller zeroes C when it is not accumulating); bias / ReLU are
 // applied only on the non-atomic path (bias also on split 0 of an atomic one).
 // splits == -1: balanced.  With T tiles and W workgroups (W a multiple of 8), every workgroup computes T / W whole tiles and the
-// last T % W tiles (tile order: batch, then tile row, then tile column) are cut along the reduction into floor(W / (T % W)) parts
+// last T % W tiles (tile order: batch, then engine_tile's bands -- NOT row-major: zero all of C) are cut along the reduction into floor(W / (T % W)) parts
 // that are ADDED into C with atomics: the caller zeroes those tiles (or all of C) unless accumulating; no ReLU when tiles are cut.  All leading dimensions, M (MC operands), N
 // (MC operands) and K offsets in multiples of 4 floats; tensors < 2 GiB.
 static int gemm_engine_impl(const float* A, const float* B, float* C, const float* bias, int form, int batch, int M, int N, int K,

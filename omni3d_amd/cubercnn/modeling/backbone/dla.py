@@ -248,7 +248,9 @@ class DLABackbone(Backbone):
     # a cut at level k needs the cuts at all lower levels (see GraphedPipelined).  Measured optimum; "stem" (round 3): the main stream
     # used to wait 0.39 ms for the last weight-gradient graph after its own last kernel, 0.20 ms with the first layer as its own stage
     # (device timestamps of OMNI_PIPE_TIMING=1, profiles/r03_pipe_timing.log): 12.14 -> 12.06 ms / step
-    stage_cut_at = ("stem", "p2", "p3")
+    # "l1" (round 4, between level 1 and level 2): the weight gradients of level 2 start while level 1 / 0 are still in backward; the
+    # last weight-gradient graph shrinks to the two full-resolution layers: 11.37 -> 11.30 ms (profiles/r04_ab_cut_l1.log)
+    stage_cut_at = ("stem", "l1", "p2", "p3")
 
     def backward_stages(self):
         """{module name: backward stage its parameters' gradients complete in} for the cut points of `stage_cut_at` (stage 0 = the

@@ -357,6 +357,9 @@ class GraphedPipelined:
                             self.cuts.backward_last()
                     pool_m = gm.pool()
                 fns, keep = HF.side_take()
+                # (measured, profiles/r04_ab_w_shift.log: carrying the heads' weight gradients into the NEXT stage's graph frees M1
+                # -- 1.45 -> 0.79 ms, it is HBM-bound on the p2 maps and so is the fc1 weight gradient beside it -- and M2 pays it
+                # back, 1.73 -> 2.45 ms: the two streams share one throughput, where the weight gradients land does not matter)
                 gw = None
                 if fns:
                     gw = torch.cuda.CUDAGraph()

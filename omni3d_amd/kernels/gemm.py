@@ -12,7 +12,7 @@ def gemm(A, B, form=NT, bias=None, relu=False, out=None, accumulate=False, split
        NT: A (b, M, K), B (b, N, K) -> (b, M, N)      NN: A (b, M, K), B (b, K, N)      TN: A (b, K, M), B (b, K, N) -> (b, M, N)
     out: optional preallocated result (accumulate=True adds into it with fp32 atomics); splits > 1 zeroes `out` first unless
     accumulating.  splits = BALANCED (-1): whole tiles per workgroup plus one part of the left-over tiles each (csrc/gemm_engine.hip);
-    the left-over tiles are the last ones, so only the tile rows from the first of them on are zeroed."""
+    without the deterministic mode `out` is zeroed when tiles are cut (their parts meet through atomics)."""
     squeeze = A.dim() == 2
     A3, B3 = (A.unsqueeze(0), B.unsqueeze(0)) if squeeze else (A, B)
     assert A3.is_contiguous() and B3.is_contiguous() and A3.shape[0] == B3.shape[0]
@@ -53,13 +53,8 @@ def gemm(A, B, form=NT, bias=None, relu=False, out=None, accumulate=False, split
         W = workgroups or 256
         bm, bn = (256, 128) if tile == 1 else (128, 128)
         tm, tn = (M + bm - 1) // bm, (N + bn - 1) // bn
-        left = (b * tm * tn) % W
-        if left:
-            t0 = b * tm * tn - left                       # first cut tile -> (batch, tile row)
-            b0, r0 = divmod(t0 // tn, tm)
-            out3[b0, r0 * bm:].zero_()
-            if b0 + 1 < b:
-                out3[b0 + 1:].zero_()
+        if (b * tm * tn) % W:
+            out3.zero_()        # (the cut tiles are the last ones of the engine's banded tile order: not a suffix of rows)
     L.call("omni_gemm_engine", _lib.ptr(A3), _lib.ptr(B3), _lib.ptr(out3), _lib.ptr(bias), form, b, M, N, K, lda, ldb, N,
            A3.stride(0), B3.stride(0), M * N, splits, int(relu), int(accumulate), tile, workgroups, _lib.stream_of(A))
     return out3[0] if squeeze else out3

@@ -154,7 +154,7 @@ def gemm_batched_wgrad(V, dM, algo=0):
     return dU
 
 
-WGRAD_MULTI_MAX = 16
+WGRAD_MULTI_MAX = max(1, min(16, int(_os.environ.get("OMNI_WGRAD_MULTI_MAX", "16"))))      # problems per launch (A/B knob; the kernel takes <= 16)
 WGRAD_MULTI = _os.environ.get("OMNI_WGRAD_MULTI", "1") != "0"
 _deferred = None        # [(V, dM, dU, accum_into)] while a batched_wgrads() context is open
 

@@ -440,7 +440,7 @@ def _worker_single_phase_staged(rank, world, port, out):
 
 
 def test_stage_ranges_of_the_real_model():
-    """cubercnn_DLA34_FPN: six backward stages (FC heads | ROIAlign + RPN | FPN + level 5, 4 | level 3 | level 2 .. 0 | first layer);
+    """cubercnn_DLA34_FPN: seven backward stages (FC heads | ROIAlign + RPN | FPN + level 5, 4 | level 3 | level 2 | level 1, 0 | first layer);
     the ranges tile the bucket exactly once, every parameter sits in a range of its own stage, chunks are at most 32 MB, and what is
     left for after the last stage is the first layer's few kB (the backbone's 75 MB used to go out after the last stage)"""
     from oracle import make_golden as MG
@@ -449,11 +449,12 @@ def test_stage_ranges_of_the_real_model():
     cfg = MG.product_cfg([])
     model = MG.build_product_model(cfg, synthetic.make_priors(50), 3, device="cpu")
     opt = build_optimizer(cfg, model)
-    assert opt.n_stages == 6 and opt.stage_cut_signature == ("stem", "p2", "p3", "pool")
+    assert opt.n_stages == 7 and opt.stage_cut_signature == ("stem", "l1", "p2", "p3", "pool")
     covered = sorted(r for rs in opt.stage_ranges.values() for r in rs)
     assert covered[0][0] == 0 and covered[-1][1] == opt.flat_grad.numel()
     assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
-    want = (("backbone.bottom_up.base_layer", 5), ("backbone.bottom_up.level2", 4), ("backbone.bottom_up.level3", 3), ("backbone.fpn_", 2),
+    want = (("backbone.bottom_up.base_layer", 6), ("backbone.bottom_up.level0", 5), ("backbone.bottom_up.level1", 5),
+            ("backbone.bottom_up.level2", 4), ("backbone.bottom_up.level3", 3), ("backbone.fpn_", 2),
             ("backbone.bottom_up.level5", 2), ("backbone.bottom_up.level4", 2), ("proposal_generator", 1), ("roi_heads", 0))
     for n, p in model.named_parameters():
         if id(p) not in opt._slot:
@@ -466,7 +467,7 @@ def test_stage_ranges_of_the_real_model():
                 assert st == stage, (n, st, stage)
     chunks = opt.exchange_chunks(range(opt.n_stages))
     assert max(e - s for s, e in chunks) <= opt.EXCHANGE_CHUNK and sum(e - s for s, e in chunks) == opt.flat_grad.numel()
-    last = sum(e - s for s, e in opt.stage_ranges[5]) * 4
+    last = sum(e - s for s, e in opt.stage_ranges[6]) * 4
     assert last < 10 * 2 ** 20, last                       # bytes whose exchange cannot overlap any backward work
     by_stage = {k: sum(e - s for s, e in v) * 4 / 2 ** 20 for k, v in opt.stage_ranges.items()}
     assert by_stage[0] > 100 and by_stage[2] > 40, by_stage   # MB: FC heads 109, FPN + level 5 / 4 66

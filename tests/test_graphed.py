@@ -71,9 +71,9 @@ def test_pipelined_graphs_match_eager_while_the_weights_move(hip_lib):
     for g in opt.param_groups:
         g["lr"] = 2e-3                    # random-init weights: keep the four steps finite
     stepper = GraphedPipelined(model, opt, batch, packed)
-    # FC heads | ROIAlign + RPN | FPN + levels 5, 4 | level 3 | level 2 .. level 0 | first layer (its weight gradient runs on the main
+    # FC heads | ROIAlign + RPN | FPN + levels 5, 4 | level 3 | level 2 | level 1, 0 | first layer (its weight gradient runs on the main
     # stream: no W graph)
-    assert len(stepper.stages) == 6 and all(gw is not None for _, gw in stepper.stages[:-1])
+    assert len(stepper.stages) == 7 and all(gw is not None for _, gw in stepper.stages[:-1])
     names = {id(p): n for n, p in model.named_parameters()}
     prev_mode = HF.side_mode()
     try:
