@@ -389,16 +389,18 @@ __global__ void __launch_bounds__(256) transpose2d_kernel(const float* __restric
 }
 
 // Deterministic mode, second launch: C tile (=, or += when accumulate) sum over the parts of a cut tile in part order (+ bias)
-// (ReLU).  One workgroup per (cut tile, 8 accumulator registers): thread tid adds `parts` slot values per register, all loads of a
-// register independent.  first_tile: linear index (batch, then engine_tile order) of cut tile 0.
+// (ReLU).  One workgroup per (cut tile, FIN_REGS accumulator registers): thread tid adds `parts` slot values per register.  (Round 4:
+// 8 -> 2 registers per workgroup and four loads in flight: fc1's weight gradient has 16 cut tiles x 16 parts -- 128 workgroups walked
+// 128 dependent loads each, 143 us in the step.)  first_tile: linear index (batch, then engine_tile order) of cut tile 0.
+constexpr int FIN_REGS = 2;
 template <int BM, int BN>
 __global__ void __launch_bounds__(256) engine_cut_finalize_kernel(const float* __restrict__ ws, int parts, long first_tile, int tiles_m,
                                                                   int tiles_n, float* __restrict__ C, const float* __restrict__ bias, int M,
                                                                   int N, int ldc, long sc, int relu, int accumulate, int band) {
-    constexpr int WN = BN / 64, NACC = BM * BN / 256, CH = NACC / 8;
+    constexpr int WN = BN / 64, NACC = BM * BN / 256, CH = NACC / FIN_REGS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     const long ct = (long)blockIdx.x / CH;
-    const int r0 = ((int)blockIdx.x % CH) * 8;
+    const int r0 = ((int)blockIdx.x % CH) * FIN_REGS;
     const long r = first_tile + ct;
     const long per_b = (long)tiles_m * tiles_n;
     int tm, tn;
@@ -407,10 +409,19 @@ __global__ void __launch_bounds__(256) engine_cut_finalize_kernel(const float* _
     const float* slot = ws + ct * parts * (long)(BM * BN) + tid;
     float* o = C + b * sc;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < FIN_REGS; ++u) {
         const int reg = r0 + u, blk = reg >> 4, rr = reg & 15, i = blk / WN, j = blk % WN;
         float v = 0.f;
-        for (int q = 0; q < parts; ++q) v += slot[((long)q * NACC + reg) * 256];
+        int q = 0;
+        for (; q + 4 <= parts; q += 4) {      // four loads in flight, added in part order
+            const float t0 = slot[((long)q * NACC + reg) * 256], t1 = slot[((long)(q + 1) * NACC + reg) * 256],
+                        t2 = slot[((long)(q + 2) * NACC + reg) * 256], t3 = slot[((long)(q + 3) * NACC + reg) * 256];
+            v += t0;
+            v += t1;
+            v += t2;
+            v += t3;
+        }
+        for (; q < parts; ++q) v += slot[((long)q * NACC + reg) * 256];
         const int n = tn * BN + wn * (BN / 2) + j * 32 + l31;
         const int m = tm * BM + wm * (BM / 2) + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
         if (m < M && n < N) {
@@ -460,7 +471,7 @@ int launch_engine(GemmArgs p, int workgroups, hipStream_t st, const EngineDet& d
     };
     auto finalize = [&]() {
         if (fin_tiles > 0)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(engine_cut_finalize_kernel<BM, BN>), dim3((unsigned)(fin_tiles * (BM * BN / 2048))), dim3(256), 0, st,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(engine_cut_finalize_kernel<BM, BN>), dim3((unsigned)(fin_tiles * (BM * BN / (256 * FIN_REGS)))), dim3(256), 0, st,
                                (const float*)p.ws, fin_parts, fin_first, p.tiles_m, p.tiles_n, p.C, p.bias, p.M, p.N, p.ldc, p.sc, p.relu,
                                p.accumulate, fin_band);
     };

@@ -112,6 +112,9 @@ class FlattenLinear(nn.Module):
         return HF.linear(x2, w2, self.bias, relu, gview)
 
 
+PARAM_EPOCH = [0]        # bumped by every parameter update torch's version counters do not see (solver/build.py FlatOptimizer.step)
+
+
 class BatchNorm2d(nn.BatchNorm2d):
     # RCNN3D sets this and bumps every `num_batches_tracked` of the model with ONE multi-tensor add per step
     defer_counter = False
@@ -125,8 +128,18 @@ class BatchNorm2d(nn.BatchNorm2d):
                 self.num_batches_tracked += 1
             return y
         from ...kernels import bnpool
-        rstd = torch.rsqrt(self.running_var + self.eps)
-        scale = self.weight * rstd
-        scale_shift = torch.cat([scale, self.bias - self.running_mean * scale]).detach().contiguous()
+        # inference: (scale, shift) of the frozen statistics, built once per set of values (six ATen launches per layer and call
+        # otherwise: 234 of the 805 launches of an inference pass, profiles/r04_infer_trace_table.txt).  The key catches every write
+        # torch knows about (load_state_dict, copy_, in-place ops bump `_version`) and PARAM_EPOCH the ones it cannot see (the flat
+        # optimizers update parameters through raw pointers: FlatOptimizer.step bumps it)
+        key = (PARAM_EPOCH[0], self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
+               self.weight.data_ptr(), self.running_var.data_ptr())
+        cached = self.__dict__.get("_eval_scale_shift")
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                scale = self.weight * torch.rsqrt(self.running_var + self.eps)
+                cached = (key, torch.cat([scale, self.bias - self.running_mean * scale]).contiguous())
+            self.__dict__["_eval_scale_shift"] = cached
+        scale_shift = cached[1]
         return bnpool.bn_apply(x.contiguous(memory_format=CL), scale_shift,
                                residual.contiguous(memory_format=CL) if residual is not None else None, relu)

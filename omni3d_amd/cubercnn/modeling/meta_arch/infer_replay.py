@@ -1,0 +1,103 @@
+"""`model(batch)` in eval mode from a captured hipGraph (round 4).
+
+RCNN3D.inference (rcnn3d.py:79-112 of the reference) is ~570 launches of fixed shape for a given padded batch size -- backbone, RPN,
+box head, batched per-class NMS, cube head, fused decode -- followed by one device->host copy of the detection counts.  Issued
+eagerly the pass is bound by the host (10.5 ms per batch of four 512 x 512 images against 7 ms of kernel time).  Like the training
+step (solver/autoreplay.py) the device half is captured once per size bucket -- (batch size, padded height, padded width); the real
+image sizes are device data (`packed.image_hw`) -- and replayed: `model(batch)` copies the images into the corners of their slots,
+refreshes the intrinsics / ratios / sizes in the static `packed`, launches ONE graph and runs the host half (counts, Instances,
+postprocess) on its output tensors.  Results are the eager path's: the same kernels on the same values.
+
+Oracle-2D inputs, a caller-supplied `packed`, CPU tensors and OMNI_INFER_REPLAY=0 take the eager path; so does the first pass
+of every bucket (it also fills the per-shape caches -- anchors, batch indices -- a capture must not create)."""
+import os
+from collections import OrderedDict
+
+import torch
+
+from ..targets import pack_targets
+
+ENABLED = os.environ.get("OMNI_INFER_REPLAY", "1") != "0"
+CACHE = int(os.environ.get("OMNI_INFER_REPLAY_CACHE", "8"))
+FIELDS = ("Ks", "v2r", "ratio", "image_hw")          # what the inference pass reads of the packed batch description
+
+
+class InferReplay:
+    def __init__(self, model, warm=1):
+        self.model, self.warm = model, warm
+        self.cache, self.counts = OrderedDict(), {}
+        self.failed = None
+        self.replays = self.captures = 0
+
+    def run(self, batched_inputs, context):
+        """-> (raw device outputs, image sizes) of a replayed pass, or None (the caller runs the eager pass).  `context`: a callable
+        returning the context manager the eager pass runs its device half under (Winograd tile choice, filter-transform scope)"""
+        if not ENABLED or self.failed is not None or not batched_inputs:
+            return None
+        img0 = batched_inputs[0]["image"]
+        if self.model.device.type != "cuda" or any("oracle2D" in b for b in batched_inputs):
+            return None
+        from ...solver.autoreplay import AutoReplay
+        sig = AutoReplay.signature(batched_inputs) + (str(img0.dtype),)
+        self.counts[sig] = self.counts.get(sig, 0) + 1
+        entry = self.cache.get(sig)
+        if entry is None:
+            if self.counts[sig] <= self.warm:
+                return None
+            try:
+                entry = self._capture(batched_inputs, sig, context)
+            except Exception as e:  # noqa: BLE001 -- capture refused: eager launches from now on, say why once
+                self.failed = f"{type(e).__name__}: {str(e)[:200]}"
+                self.cache.clear()
+                import warnings
+                warnings.warn(f"omni3d_amd: hipGraph capture of the inference pass failed ({self.failed}); running eager launches")
+                return None
+            self.cache[sig] = entry
+            while len(self.cache) > max(CACHE, 1):
+                self.cache.popitem(last=False)
+        else:
+            self._stage(entry, batched_inputs)
+        self.cache.move_to_end(sig)
+        entry["graph"].replay()
+        self.replays += 1
+        sizes = [(b["image"].shape[-2], b["image"].shape[-1]) for b in batched_inputs]
+        # (copies: the results handed to the caller must not alias the tensors the next replay overwrites -- a few hundred KB)
+        return {k: v.clone() for k, v in entry["raw"].items()}, sizes
+
+    def _pack(self, batch):
+        sizes = [(b["image"].shape[-2], b["image"].shape[-1]) for b in batch]
+        return pack_targets(batch, sizes, getattr(self.model.roi_heads, "virtual_focal", 512.0), with_gt=False)
+
+    def _capture(self, batch, sig, context):
+        model, dev = self.model, self.model.device
+        B, Hb, Wb = sig[:3]
+        slots = torch.zeros((B, 3, Hb, Wb), dtype=batch[0]["image"].dtype, device=dev)
+        sb = []
+        for n, b in enumerate(batch):
+            c = {k: v for k, v in b.items() if k not in ("image", "instances")}
+            h, w = b["image"].shape[-2:]
+            slots[n, :, :h, :w].copy_(b["image"], non_blocking=True)
+            c["image"] = slots[n]
+            sb.append(c)
+        packed = self._pack(batch).to(dev)
+        packed.slotted = True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad(), context():
+            model._inference_device(sb, packed)               # per-shape caches (anchors, index vectors) exist before the capture
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"), torch.no_grad(), context():
+            raw = model._inference_device(sb, packed)
+        self.captures += 1
+        return {"graph": g, "raw": raw, "slots": slots, "batch": sb, "packed": packed}
+
+    def _stage(self, entry, batch):
+        dev = self.model.device
+        for n, b in enumerate(batch):
+            h, w = b["image"].shape[-2:]
+            entry["slots"][n, :, :h, :w].copy_(b["image"], non_blocking=True)       # (the rest of the slot is masked by image_hw)
+        new, sp = self._pack(batch), entry["packed"]
+        for f in FIELDS:
+            getattr(sp, f).copy_(getattr(new, f).to(dev, non_blocking=True), non_blocking=True)

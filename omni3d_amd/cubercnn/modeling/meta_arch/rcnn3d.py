@@ -157,9 +157,46 @@ class RCNN3D(nn.Module):
             if hasattr(m, "flush_logs"):       # (a reference-style component logs its scalars itself)
                 m.flush_logs(storage)
 
+    def _inference_device(self, batched_inputs, packed):
+        """the device half of inference() for this package's own components: fixed shapes, no host synchronisation"""
+        from ..roi_heads.inference import roi_heads_inference_device
+        images = self.preprocess_image(batched_inputs, slot_hw=packed.image_hw if getattr(packed, "slotted", False) else None)
+        features = self.backbone(images.tensor)
+        proposals, _ = self.proposal_generator(images, features, None, targets=packed)
+        return roi_heads_inference_device(self.roi_heads, [features[f] for f in self.roi_heads.in_features], proposals, packed)
+
+    def _replayed_inference(self, batched_inputs, do_postprocess):
+        """-> results of a pass replayed from its captured hipGraph, or None (meta_arch/infer_replay.py)"""
+        if not (self._all_packed() and getattr(self.roi_heads, "replayable_inference", False)):
+            return None
+        rep = self.__dict__.get("_omni_infer")
+        if rep is None:
+            from .infer_replay import InferReplay
+            rep = self.__dict__["_omni_infer"] = InferReplay(self)
+        import contextlib
+        from ....kernels import wino as _wino
+
+        def context():
+            st = contextlib.ExitStack()
+            st.enter_context(HF.wino_weight_scope(self))
+            if _EVAL_F22:
+                st.enter_context(_wino.f22_only())
+            return st
+        got = rep.run(batched_inputs, context)
+        if got is None:
+            return None
+        from ..roi_heads.inference import collect_detections, postprocess
+        raw, sizes = got
+        results = collect_detections(raw, sizes)
+        return postprocess(results, batched_inputs, sizes) if do_postprocess else results
+
     def inference(self, batched_inputs, detected_instances=None, do_postprocess=True, packed=None):
         assert not self.training
         from ..roi_heads.inference import postprocess
+        if packed is None and detected_instances is None:
+            out = self._replayed_inference(batched_inputs, do_postprocess)
+            if out is not None:
+                return out
         images = self.preprocess_image(batched_inputs)
         if packed is None:
             sizes = images.image_sizes

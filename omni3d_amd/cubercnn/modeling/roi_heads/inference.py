@@ -14,6 +14,12 @@ def roi_heads_inference(heads, images, feats, proposals, packed):
     """Whole batch, fixed shapes, ONE device->host copy (the per-image detection counts) at the very end: score / decode /
     clip / threshold (csrc/infer.hip), stable candidate sort (top-k kernel), per-class NMS as one problem per image, the
     DETECTIONS_PER_IMAGE best into fixed slots, then the cube head + fused decode on those slots."""
+    return collect_detections(roi_heads_inference_device(heads, feats, proposals, packed), images.image_sizes)
+
+
+@torch.no_grad()
+def roi_heads_inference_device(heads, feats, proposals, packed):
+    """the device half: fixed-shape tensors for the whole batch, no host synchronisation (capturable: meta_arch/infer_replay.py)"""
     K = heads.num_classes
     pred_boxes_all, count = proposals.boxes, proposals.count
     B, P = pred_boxes_all.shape[:2]
@@ -39,11 +45,18 @@ def roi_heads_inference(heads, images, feats, proposals, packed):
                                            heads.cube_mode, heads.clusters())
     final = (dscore.view(-1) * cube3d[:, 8]) ** 0.5                                               # roi_heads.py:800-801
     full = torch.gather(probs.view(B, P, K), 1, droi.long()[:, :, None].expand(-1, -1, K))        # scores of all classes per kept roi
-    counts = dcount.tolist()                                                                      # the one host sync
+    return {"dbox": dbox, "final": final, "full": full, "dcls": dcls, "verts": verts, "cube3d": cube3d, "pose": pose, "dcount": dcount}
+
+
+def collect_detections(raw, image_sizes):
+    """the host half: ONE synchronisation (the per-image detection counts), then list[Instances] of row slices of the batch tensors"""
+    dbox, final, full, dcls, verts, cube3d, pose = (raw[k] for k in ("dbox", "final", "full", "dcls", "verts", "cube3d", "pose"))
+    B, topk = dbox.shape[:2]
+    counts = raw["dcount"].tolist()                                                               # the one host sync
     per_image = []
     for n in range(B):
         k, o = counts[n], n * topk
-        inst = Instances(tuple(images.image_sizes[n]))
+        inst = Instances(tuple(image_sizes[n]))
         inst.pred_boxes = Boxes(dbox[n, :k])
         inst.scores = final[o:o + k]
         inst.scores_full = full[n, :k]
@@ -53,6 +66,7 @@ def roi_heads_inference(heads, images, feats, proposals, packed):
         inst.pred_center_2D = cube3d[o:o + k, 6:8]
         inst.pred_dimensions = cube3d[o:o + k, 3:6]
         inst.pred_pose = pose[o:o + k]
+        inst._omni_slots = (dbox, n, k)           # postprocess(): all images' boxes rescaled / clipped / tested in one pass
         per_image.append(inst)
     return per_image
 
@@ -100,6 +114,9 @@ def roi_heads_oracle2d(heads, images, feats, oracles, packed):
 def postprocess(instances, batched_inputs, image_sizes):
     """detectron2 GeneralizedRCNN._postprocess / detector_postprocess: rescale 2D boxes to the original
     resolution, clip, drop empty boxes; 3D fields pass through."""
+    slots = [getattr(res, "_omni_slots", None) for res in instances]
+    if slots and all(s is not None and s[0] is slots[0][0] and s[1] == n for n, s in enumerate(slots)):
+        return _postprocess_slots(instances, batched_inputs, image_sizes, slots[0][0])
     out = []
     for res, info, size in zip(instances, batched_inputs, image_sizes):
         H, W = info.get("height", size[0]), info.get("width", size[1])
@@ -111,4 +128,27 @@ def postprocess(instances, batched_inputs, image_sizes):
         b = torch.stack((b[:, 0].clamp(0, W), b[:, 1].clamp(0, H), b[:, 2].clamp(0, W), b[:, 3].clamp(0, H)), dim=1)
         r.pred_boxes = Boxes(b)
         out.append({"instances": r[r.pred_boxes.nonempty()]})
+    return out
+
+
+@torch.no_grad()
+def _postprocess_slots(instances, batched_inputs, image_sizes, dbox):
+    """postprocess() for the results of roi_heads_inference: their boxes are row slices of ONE (B, topk, 4) tensor, so the rescale,
+    the clip and the empty-box test run once for the batch (the same multiplications and clamps, in the same order), the mask comes
+    back in one copy, and an image whose boxes are all non-empty -- every image, normally -- keeps its fields as the views they are.
+    Per image the reference's form costs ~25 launches (boolean indexing of nine fields = nine nonzero + gather pairs)."""
+    B = dbox.shape[0]
+    HW = [(info.get("height", size[0]), info.get("width", size[1])) for info, size in zip(batched_inputs, image_sizes)]
+    sc = torch.tensor([[W / res.image_size[1], H / res.image_size[0]] * 2 for (H, W), res in zip(HW, instances)], dtype=torch.float32)
+    lim = torch.tensor([[W, H, W, H] for H, W in HW], dtype=torch.float32)
+    both = torch.stack([sc, lim]).to(dbox.device, non_blocking=True)               # one copy
+    b = torch.minimum((dbox * both[0][:, None, :]).clamp_(min=0), both[1][:, None, :])
+    ok = ((b[..., 2] - b[..., 0] > 0) & (b[..., 3] - b[..., 1] > 0)).cpu()
+    out = []
+    for n, (res, (H, W)) in enumerate(zip(instances, HW)):
+        k = res._omni_slots[2]
+        r = Instances((H, W), **res.get_fields())
+        r.pred_boxes = Boxes(b[n, :k])
+        keep = ok[n, :k]
+        out.append({"instances": r if bool(keep.all()) else r[keep.to(dbox.device)]})
     return out

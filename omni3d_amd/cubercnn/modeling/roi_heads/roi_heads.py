@@ -109,6 +109,7 @@ def _pack_proposal_list(proposals, image_sizes, device):
 @ROI_HEADS_REGISTRY.register()
 class ROIHeads3D(nn.Module):
     accepts_packed = True     # forward() also takes the ground truth pre-packed on the device (RCNN3D.prepack)
+    replayable_inference = True    # its eval pass is inference.roi_heads_inference_device + one host sync (meta_arch/infer_replay.py)
     pool_cut = None           # solver/graphed.py: callable applied to the pooled (box, cube) features = a backward stage boundary
     @configurable
     def __init__(self, *, num_classes, batch_size_per_image, positive_fraction, proposal_iou_threshold, proposal_append_gt,

@@ -311,6 +311,8 @@ class _FlatOptimizer(torch.optim.Optimizer):
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 self.all_reduce_grads()
         self._step_segments()
+        from ..modeling.layers import PARAM_EPOCH
+        PARAM_EPOCH[0] += 1                  # (inference-side caches of values derived from parameters: layers.BatchNorm2d)
         self.skip_flag = user_skip
         self._grad_scale = 1.0
         self._steps += 1

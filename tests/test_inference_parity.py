@@ -102,3 +102,69 @@ def test_inference_matches_reference_emulated(emu_lib, name):
 @pytest.mark.parametrize("name", FIXTURES + FULL_FIXTURES)
 def test_inference_matches_reference_gpu(hip_lib, name):
     _run("cuda", name)
+
+
+FIELDS_OUT = ("scores", "scores_full", "pred_classes", "pred_bbox3D", "pred_center_cam", "pred_center_2D", "pred_dimensions", "pred_pose")
+
+
+def _same_results(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        i, j = x["instances"], y["instances"]
+        assert len(i) == len(j) and i.image_size == j.image_size
+        assert torch.equal(i.pred_boxes.tensor, j.pred_boxes.tensor)
+        for f in FIELDS_OUT:
+            assert torch.equal(getattr(i, f), getattr(j, f)), f
+
+
+@pytest.mark.gpu
+def test_replayed_inference_equals_eager_gpu(hip_lib):
+    """meta_arch/infer_replay.py: `model(batch)` in eval mode from the captured hipGraph of its size bucket gives the eager pass's
+    results bit for bit -- also for a second batch of the bucket with other images, other (ragged) sizes and other intrinsics, which
+    must reach the static tensors -- and the batched postprocess equals the per-image form of the reference"""
+    from oracle import make_golden as MG
+    from omni3d_amd import synthetic
+    from omni3d_amd.cubercnn.modeling.meta_arch import infer_replay
+    from omni3d_amd.cubercnn.modeling.roi_heads import inference as INF
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "dla34_small_infer.pt"), weights_only=False)
+    spec = gold["spec"]
+    priors = synthetic.make_priors(50, bins=spec.get("prior_bins", 0))
+    model = MG.sharpen(MG.build_product_model(MG.product_cfg(spec["overrides"]), priors, spec["seed"])).to("cuda")
+    model.eval()
+    first = MG.infer_batch(spec, priors)
+    H, W = first[0]["image"].shape[-2:]
+    second = synthetic.make_batch(len(first), H, W, num_gt=4, seed=77, priors=priors)
+    second[0]["image"] = second[0]["image"][:, : H - 24, : W - 40].contiguous()          # ragged, same 64-pixel bucket
+    second[0]["height"], second[0]["width"] = H - 24, W - 40
+    second[-1]["K"] = [[700.0, 0.0, W / 2.0 + 3.0], [0.0, 700.0, H / 2.0 - 2.0], [0.0, 0.0, 1.0]]
+    for b in first + second:
+        b["image"] = b["image"].to("cuda")
+        b.pop("instances", None)
+    prev = infer_replay.ENABLED
+    try:
+        infer_replay.ENABLED = False
+        with torch.no_grad():
+            eager = [model(first), model(second)]
+        infer_replay.ENABLED = True
+        with torch.no_grad():
+            model(first)                                  # pass 1 of the bucket: eager, fills the per-shape caches
+            replayed = [model(first), model(second), model(first)]
+        rep = model.__dict__["_omni_infer"]
+        assert rep.failed is None and rep.captures == 1 and rep.replays == 3, (rep.failed, rep.captures, rep.replays)
+    finally:
+        infer_replay.ENABLED = prev
+    _same_results(eager[0], replayed[0])
+    _same_results(eager[1], replayed[1])
+    _same_results(eager[0], replayed[2])
+    assert sum(len(r["instances"]) for r in eager[0]) > 0
+    # the batched postprocess against the per-image form on the same raw results
+    with torch.no_grad():
+        res = model.inference(first, do_postprocess=False)
+    for r in res:
+        assert getattr(r, "_omni_slots", None) is not None
+    sizes = [(b["image"].shape[-2], b["image"].shape[-1]) for b in first]
+    fast = INF.postprocess(res, first, sizes)
+    for r in res:
+        r.__dict__.pop("_omni_slots")
+    slow = INF.postprocess(res, first, sizes)
+    _same_results(fast, slow)
