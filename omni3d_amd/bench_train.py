@@ -461,7 +461,14 @@ def dominant_kernel_roofline(iters=20):
     dM4 = torch.randn(36, 256, 256, device="cuda")
     V5 = torch.randn(36, 1024, 256, device="cuda")                                                   # FPN output / RPN conv at p3
     fl4 = 2.0 * 36 * 256 * 256 * 256
+    # the weight-gradient stream's launch of backward stage 2 (FPN output convolutions p2..p5, DLA level 5 and level 4): 14 problems
+    STAGE2 = [(36, 4096, 256, 256), (36, 1024, 256, 256), (36, 256, 256, 256), (16, 256, 256, 256)] + [(16, 256, 512, 512)] * 3 + [(36, 256, 256, 256)] * 7
+    multi = [(torch.randn(b, m, c, device="cuda"), torch.randn(b, m, k, device="cuda")) for b, m, k, c in STAGE2]
+    fl_multi = sum(2.0 * b * m * k * c for b, m, k, c in STAGE2)
     families = [
+        fam("Winograd weight-gradient GEMMs of one backward stage in ONE launch (round 4: 14 problems -- FPN p2..p5, DLA level 5, level 4)",
+            "gemm_tn_multi_kernel<4>", "36x[4096,256,256] + 36x[1024,256,256] + 16x[256,256,256] + 3 x 16x[256,512,512] + 8 x 36x[256,256,256]",
+            fl_multi, lambda: wino.gemm_batched_wgrad_multi(multi), grid=2326528),
         fam("Winograd point GEMMs, 128x128 maps (FPN output / RPN conv at p2: 4 launches / step, the heaviest shape of this symbol)", "gemm_nt_pf_kernel<4>", "36x[4096x256]x[256x256]^T (3x3 256->256 @128x128)", flops,
             lambda: wino.gemm_batched(V, U), grid=2359296, alg_bytes=4.0 * (2 * P * T * C + P * C * C), per_step=4),
         fam("Winograd point GEMMs, small maps (DLA level 4: 18 launches / step)", "gemm_nt_pf_kernel<4>",

@@ -28,6 +28,7 @@ class InferReplay:
         self.cache, self.counts = OrderedDict(), {}
         self.failed = None
         self.replays = self.captures = 0
+        self.digest, self._tensors = None, None
 
     def run(self, batched_inputs, context):
         """-> (raw device outputs, image sizes) of a replayed pass, or None (the caller runs the eager pass).  `context`: a callable
@@ -38,6 +39,14 @@ class InferReplay:
         if self.model.device.type != "cuda" or any("oracle2D" in b for b in batched_inputs):
             return None
         from ...solver.autoreplay import AutoReplay
+        # A captured pass reads the weights through their pointers (live), but values DERIVED from them outside the graph -- the
+        # cached eval-mode BatchNorm coefficients -- are baked in as the tensors they were at capture time: any parameter / buffer
+        # write since then (an optimizer step, load_state_dict) drops the captured passes
+        digest = self._digest()
+        if digest != self.digest:
+            self.cache.clear()
+            self.counts.clear()
+            self.digest = digest
         sig = AutoReplay.signature(batched_inputs) + (str(img0.dtype),)
         self.counts[sig] = self.counts.get(sig, 0) + 1
         entry = self.cache.get(sig)
@@ -63,6 +72,12 @@ class InferReplay:
         sizes = [(b["image"].shape[-2], b["image"].shape[-1]) for b in batched_inputs]
         # (copies: the results handed to the caller must not alias the tensors the next replay overwrites -- a few hundred KB)
         return {k: v.clone() for k, v in entry["raw"].items()}, sizes
+
+    def _digest(self):
+        from ..layers import PARAM_EPOCH
+        if self._tensors is None:
+            self._tensors = list(self.model.parameters()) + list(self.model.buffers())
+        return (PARAM_EPOCH[0], sum(t._version for t in self._tensors), len(self._tensors))
 
     def _pack(self, batch):
         sizes = [(b["image"].shape[-2], b["image"].shape[-1]) for b in batch]

@@ -175,6 +175,10 @@ def gemm_batched_wgrad_multi(problems):
             ints([V.shape[0] for V, _ in problems]), ints([V.shape[1] for V, _ in problems]), ints([V.shape[2] for V, _ in problems]),
             ints([dM.shape[2] for _, dM in problems]), n)
     V0 = problems[0][0]
+    if _os.environ.get("OMNI_WGRAD_MULTI_LOG") == "1":       # (tools: which problems a launch holds, for the in-step roofline figures)
+        gf = sum(2.0 * V.shape[0] * V.shape[1] * V.shape[2] * dM.shape[2] for V, dM in problems) / 1e9
+        print(f"gemm_tn_multi: {n} problems, {gf:.2f} GFLOP: " + " ".join(f"{V.shape[0]}x[{V.shape[1]}x{dM.shape[2]}x{V.shape[2]}]" for V, dM in problems),
+              flush=True)
     if not _det.on():
         L.call("omni_gemm_batched_wgrad_multi", *head, None, 0, None, 0, None, _lib.stream_of(V0))
         return outs

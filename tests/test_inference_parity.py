@@ -156,6 +156,20 @@ def test_replayed_inference_equals_eager_gpu(hip_lib):
     _same_results(eager[0], replayed[0])
     _same_results(eager[1], replayed[1])
     _same_results(eager[0], replayed[2])
+    # a parameter write drops the captured passes (they hold the BatchNorm coefficients of the old values)
+    with torch.no_grad():
+        bn = next(m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        bn.running_var.mul_(1.5)
+        moved = model(first)
+        assert rep.captures == 1 and len(rep.cache) == 0          # eager again (first pass of the bucket after the write)
+        infer_replay.ENABLED = False
+        want = model(first)
+        infer_replay.ENABLED = True
+        again = model(first)
+        assert rep.captures == 2
+        bn.running_var.div_(1.5)
+    _same_results(want, moved)
+    _same_results(want, again)
     assert sum(len(r["instances"]) for r in eager[0]) > 0
     # the batched postprocess against the per-image form on the same raw results
     with torch.no_grad():

@@ -52,5 +52,11 @@ bo, bd = torch.zeros(3, device="cuda", requires_grad=True), torch.zeros(12, devi
 for _ in range(reps):
     ys = F.rpn_head16(ts, wo, bo, wd, bd)
     torch.autograd.backward(ys, [torch.randn_like(y) for y in ys])
+# the weight-gradient stream's launch of backward stage 2: 14 Winograd-domain weight-gradient GEMMs in one launch (gemm_tn_multi_kernel)
+from omni3d_amd.kernels import wino
+STAGE2 = [(36, 4096, 256, 256), (36, 1024, 256, 256), (36, 256, 256, 256), (16, 256, 256, 256)] + [(16, 256, 512, 512)] * 3 + [(36, 256, 256, 256)] * 7
+multi = [(torch.randn(b, m, c, device="cuda"), torch.randn(b, m, k, device="cuda")) for b, m, k, c in STAGE2]
+for _ in range(reps):
+    wino.gemm_batched_wgrad_multi(multi)
 torch.cuda.synchronize()
 print("done")
