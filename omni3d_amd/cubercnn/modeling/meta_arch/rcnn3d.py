@@ -84,6 +84,15 @@ class RCNN3D(nn.Module):
         return pack_targets(batched_inputs, sizes, vf, with_gt=True).to(self.device)
 
     def forward(self, batched_inputs, packed=None):
+        auto = self.__dict__.get("_omni_auto") if self.training else None
+        if auto is not None and packed is None and not auto.busy:
+            # the drop-in loop: once the batch signature repeats, model(data) replays the staged hipGraphs of the whole step
+            # (cubercnn/solver/autoreplay.py); callers that pre-stage their batch (bench.py, GraphedPipelined) pass `packed`.
+            # (Asked BEFORE the filter-transform scope opens: a replayed step carries its own transforms, the scope's eager launch --
+            # 260 MB of traffic, 0.25 ms of host time -- would be thrown away)
+            out = auto.forward(batched_inputs)
+            if out is not None:
+                return out
         with HF.wino_weight_scope(self):   # every Winograd filter of the pass is transformed by one launch at its start
             return self._forward(batched_inputs, packed)
 
@@ -99,13 +108,7 @@ class RCNN3D(nn.Module):
             from ....kernels import wino as _wino
             with _wino.f22_only():
                 return self.inference(batched_inputs, packed=packed)
-        auto = self.__dict__.get("_omni_auto")
-        if auto is not None and packed is None and not auto.busy:
-            # the drop-in loop: once the batch signature repeats, model(data) replays the staged hipGraphs of the whole step
-            # (cubercnn/solver/autoreplay.py); callers that pre-stage their batch (bench.py, GraphedPipelined) pass `packed`
-            out = auto.forward(batched_inputs)
-            if out is not None:
-                return out
+        auto = self.__dict__.get("_omni_auto")         # (forward() has already asked it for a replay)
         images = self.preprocess_image(batched_inputs, slot_hw=packed.image_hw if getattr(packed, "slotted", False) else None)
         packed_given = packed
         if packed is None:

@@ -44,6 +44,10 @@ from ..modeling.targets import MAX_GT_PER_IMAGE, pack_targets
 
 ENABLED = os.environ.get("OMNI_AUTO_REPLAY", "1") != "0"
 CACHE = int(os.environ.get("OMNI_AUTO_REPLAY_CACHE", "16"))           # captured steps kept (a few GB of graph-private memory each)
+# A/B: stage new batches through pinned host buffers with stream-ordered copies.  MEASURED and left OFF: on this ROCm 7.2 host the 3 MB
+# of image slots take ~20 ms to cross from pinned memory (37.1 against 11.9 ms per iteration, profiles/r04_dropin_phases.log); the pageable
+# copies block the host until the previous step has drained, which costs 0.3 ms per iteration with the losses read every 1000th
+PINNED = os.environ.get("OMNI_AUTO_REPLAY_PINNED", "0") == "1"
 BUCKET = 64                                                           # ImageList's padding granularity (FPN size divisibility)
 ROW_FIELDS = ("gt", "gt_cls", "gt3d", "gtpose", "ign")           # (rows, ...) arrays indexed through gt_off / ign_off
 FIXED_FIELDS = ("gt_off", "ign_off", "Ks", "v2r", "ratio", "image_hw")
@@ -251,25 +255,59 @@ class AutoReplay:
         return {"stepper": stepper, "batch": sb, "packed": packed, "slots": slots, "logs": logs}
 
     def _stage(self, entry, batch):
-        """new data into the tensors the graphs were captured on"""
+        """new data into the tensors the graphs were captured on.  With OMNI_AUTO_REPLAY_PINNED=1 everything crosses PCIe from pinned
+        staging buffers (two sets per captured step, taken in turn, reused only after the copies that read a set have executed) with
+        stream-ordered copies, so that the host does not wait for the device here; see PINNED for why that is not the default."""
         dev = self.model.device
-        for n, (s_, b) in enumerate(zip(entry["batch"], batch)):
-            h, w = b["image"].shape[-2:]
-            entry["slots"][n, :, :h, :w].copy_(b["image"], non_blocking=True)     # (the rest of the slot is masked by image_hw)
-            for k in ("K", "height", "width"):
-                if k in b:
-                    s_[k] = b[k]
         sizes = [(b["image"].shape[-2], b["image"].shape[-1]) for b in batch]
         new = pack_targets(batch, sizes, getattr(self.model.roi_heads, "virtual_focal", 512.0), with_gt=True)
         sp = entry["packed"]
         for f in ROW_FIELDS:
+            if getattr(new, f).shape[0] > getattr(sp, f).shape[0]:
+                raise ValueError(f"{getattr(new, f).shape[0]} rows of {f} exceed the static capacity {getattr(sp, f).shape[0]}")
+        for s_, b in zip(entry["batch"], batch):
+            for k in ("K", "height", "width"):
+                if k in b:
+                    s_[k] = b[k]
+        pin = None
+        if dev.type == "cuda" and PINNED:
+            sets = entry.setdefault("pinned", [])
+            turn = entry["turn"] = (entry.get("turn", -1) + 1) % 2
+            if len(sets) <= turn:
+                st = {"img": torch.zeros(entry["slots"].shape, dtype=entry["slots"].dtype).pin_memory(), "event": None}
+                for f in ROW_FIELDS + FIXED_FIELDS:
+                    t = getattr(sp, f)
+                    st[f] = torch.zeros(t.shape, dtype=t.dtype).pin_memory()
+                sets.append(st)
+            pin = sets[turn]
+            if pin["event"] is not None:
+                pin["event"].synchronize()                      # its copies of two iterations ago have executed (normally long ago)
+        host_imgs = pin is not None and all(not b["image"].is_cuda for b in batch)
+        for n, b in enumerate(batch):
+            h, w = sizes[n]
+            if host_imgs:
+                pin["img"][n, :, :h, :w].copy_(b["image"])                            # host -> pinned (the rest of the slot is masked by image_hw)
+            else:
+                entry["slots"][n, :, :h, :w].copy_(b["image"], non_blocking=True)
+        if host_imgs:
+            entry["slots"].copy_(pin["img"], non_blocking=True)                       # ONE contiguous, asynchronous copy of all slots
+        for f in ROW_FIELDS + FIXED_FIELDS:
             src, dst = getattr(new, f), getattr(sp, f)
-            n = src.shape[0]
-            if n > dst.shape[0]:
-                raise ValueError(f"{n} rows of {f} exceed the static capacity {dst.shape[0]}")
-            dst[:n].copy_(src.to(dev, non_blocking=True), non_blocking=True)
-        for f in FIXED_FIELDS:
-            getattr(sp, f).copy_(getattr(new, f).to(dev, non_blocking=True), non_blocking=True)
+            n = src.shape[0] if f in ROW_FIELDS else None
+            if pin is not None:
+                if n is None:
+                    pin[f].copy_(src)
+                    dst.copy_(pin[f], non_blocking=True)
+                elif n > 0:
+                    pin[f][:n].copy_(src)
+                    dst[:n].copy_(pin[f][:n], non_blocking=True)
+            elif n is None:
+                dst.copy_(src.to(dev, non_blocking=True), non_blocking=True)
+            else:
+                dst[:n].copy_(src.to(dev, non_blocking=True), non_blocking=True)
+        if pin is not None:
+            pin["event"] = torch.cuda.Event()
+            pin["event"].record()
         sp.num_gt, sp.num_ign = new.num_gt, new.num_ign
 
     # ---- backward / step protocol --------------------------------------------------------------------------------------

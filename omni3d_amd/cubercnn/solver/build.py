@@ -207,19 +207,28 @@ class _FlatOptimizer(torch.optim.Optimizer):
         # the replay and step() detached the views but must not cost the slot its content; only optimizer.zero_grad()
         # called twice drops a replayed iteration
         replayed = getattr(self, "_replay_state", None) is not None
+        bound = self.__dict__.setdefault("_bound_views", {})       # id(p) -> the bucket view this method (or __init__) bound as p.grad
+        if self.__dict__.get("_bound_base") != self.flat_grad.data_ptr():
+            bound.clear()
+            self.__dict__["_bound_base"] = self.flat_grad.data_ptr()
         for g in self.param_groups:
             for p in g["params"]:
+                cur = p.grad
+                if cur is not None and cur is bound.get(id(p)):
+                    continue                                        # (identity: the common case costs no tensor call)
                 off, n = self._slot[id(p)]
                 want = self.flat_grad[off:off + n]
-                if p.grad is not None and p.grad.data_ptr() == want.data_ptr():
+                if cur is not None and cur.data_ptr() == want.data_ptr():
+                    bound[id(p)] = cur
                     continue
                 gv = self._view_like(want, p)
-                if p.grad is None:
+                if cur is None:
                     if not replayed:
                         gv.zero_()
                 else:
-                    gv.copy_(p.grad)
+                    gv.copy_(cur)
                 p.grad = gv
+                bound[id(p)] = gv
                 fixed += 1
         if fixed:
             self.set_direct_accumulate(self._direct)
