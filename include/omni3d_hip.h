@@ -528,6 +528,15 @@ int omni_wino_weights_multi(const void* const* g, const void* const* U, const vo
                             const int* tile, int n, void* stream);
 /* backward: dM (as omni_wino_dy) and V_dy (as omni_wino_in of dy) from one read of dy */
 int omni_wino_dy_in(const float* dy, float* dM, float* Vd, int N, int H, int W, int K, int tile, void* stream);
+/* Row-range forms (round 4): the Winograd-domain array is a row range of a wider (points, rows_total, channels) array holding the tiles
+ * of several tensors side by side -- the FPN levels under the RPN's shared 3x3 convolution (detectron2 StandardRPNHead.conv,
+ * configs/Base.yaml:49) -- so that ONE batched GEMM over rows_total rows serves all of them.  V / M / dM / Vd point at the tensor's
+ * first row; plane = rows_total * channels floats between point planes.  omni_wino_out_rows: carry != NULL selects the fan-in form of
+ * omni_wino_out_carry (no bias / ReLU then). */
+int omni_wino_in_rows(const float* x, float* V, int N, int H, int W, int C, int tile, long long plane, void* stream);
+int omni_wino_out_rows(const float* M, const float* bias /*nullable*/, const float* carry /*nullable*/, long long ldc, float* y, int N,
+                       int H, int W, int K, int relu, int tile, long long plane, void* stream);
+int omni_wino_dy_in_rows(const float* dy, float* dM, float* Vd, int N, int H, int W, int K, int tile, long long plane, void* stream);
 int omni_wino_weights(const float* g, float* U /*nullable*/, float* U_flip /*nullable: U'*/, int K, int C, int tile, void* stream);
 int omni_wino_dweights(const float* dU, float* dg, int K, int C, int accumulate, int tile, void* stream);
 /* n <= 16 of them in one launch, each ADDED into its gradient view; sources naming the same dg (the RPN's shared convolution: one

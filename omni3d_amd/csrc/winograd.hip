@@ -43,11 +43,14 @@ __device__ __forceinline__ float4 wino_ld(const float* __restrict__ p, bool ok, 
     return v;
 }
 
+// plane_in > 0: the (point, tile, channel) array is a row range of a wider one -- the tiles of several tensors side by side (the RPN's
+// shared convolution over the FPN levels, one GEMM for all of them) -- V points at this tensor's first row and the point planes are
+// plane_in floats apart; 0: the array of this tensor alone (planes T * C apart).  Same convention in the kernels below.
 __global__ void __launch_bounds__(256) wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W,
-                                                      int C, const float* __restrict__ affine, int relu) {
+                                                      int C, const float* __restrict__ affine, int relu, long plane_in) {
     const int C4 = C >> 2, TH = H >> 1, TW = W >> 1;
     const bool aff = affine != nullptr;
-    const long T = (long)N * TH * TW, total = T * C4, plane = T * C;
+    const long T = (long)N * TH * TW, total = T * C4, plane = plane_in > 0 ? plane_in : T * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         const long t = i / C4;
@@ -109,9 +112,9 @@ __device__ __forceinline__ void block_channel_stats(float4 sv, float4 sq, int K,
 
 __global__ void __launch_bounds__(256) wino_out_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                        float* __restrict__ y, int N, int H, int W, int K, int relu,
-                                                       float* __restrict__ stats, const float* __restrict__ carry, long ldc) {
+                                                       float* __restrict__ stats, const float* __restrict__ carry, long ldc, long plane_in) {
     const int K4 = K >> 2, TH = H >> 1, TW = W >> 1;
-    const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    const long T = (long)N * TH * TW, total = T * K4, plane = plane_in > 0 ? plane_in : T * K;
     float4 sv = z4(), sq = z4();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k4 = (int)(i % K4);
@@ -325,10 +328,10 @@ __device__ __forceinline__ void a6(const V (&y)[4], V (&u)[6]) {      // u = A y
 }
 
 __global__ void __launch_bounds__(256) wino4_in_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W,
-                                                       int C, const float* __restrict__ affine, int relu) {
+                                                       int C, const float* __restrict__ affine, int relu, long plane_in) {
     const int C4 = C >> 2, TH = H >> 2, TW = W >> 2;
     const bool aff = affine != nullptr;
-    const long T = (long)N * TH * TW, total = T * C4, plane = T * C;
+    const long T = (long)N * TH * TW, total = T * C4, plane = plane_in > 0 ? plane_in : T * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         const long t = i / C4;
@@ -375,9 +378,9 @@ struct BnBwdStats {
 __global__ void __launch_bounds__(256) wino4_out_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                         float* __restrict__ y, int N, int H, int W, int K, int relu,
                                                         float* __restrict__ stats, BnBwdStats bnb,
-                                                        const float* __restrict__ carry, long ldc) {
+                                                        const float* __restrict__ carry, long ldc, long plane_in) {
     const int K4 = K >> 2, TH = H >> 2, TW = W >> 2;
-    const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    const long T = (long)N * TH * TW, total = T * K4, plane = plane_in > 0 ? plane_in : T * K;
     float4 sv = z4(), sq = z4();
     float4 mu = z4(), rs = z4(), sc = z4(), sh = z4();
     if (bnb.x != nullptr) {            // (the statistics modes keep ONE channel group per thread: 256 % K4 == 0)
@@ -652,9 +655,9 @@ __global__ void __launch_bounds__(256) wino_dw_multi_kernel(WinoDwTable t) {
 // The data gradient needs V_dy = B^T dy B (the (tile+2)^2 window, like wino_in) and the weight gradient needs
 // dM = A dy A^T (the central tile x tile block of the same window): one kernel reads the window once and writes both.
 __global__ void __launch_bounds__(256) wino_dy_in_kernel(const float* __restrict__ dy, float* __restrict__ dM, float* __restrict__ Vd,
-                                                         int N, int H, int W, int K) {
+                                                         int N, int H, int W, int K, long plane_in) {
     const int K4 = K >> 2, TH = H >> 1, TW = W >> 1;
-    const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    const long T = (long)N * TH * TW, total = T * K4, plane = plane_in > 0 ? plane_in : T * K;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k4 = (int)(i % K4);
         const long t = i / K4;
@@ -709,9 +712,9 @@ __global__ void __launch_bounds__(256) wino_dy_in_kernel(const float* __restrict
 }
 
 __global__ void __launch_bounds__(256) wino4_dy_in_kernel(const float* __restrict__ dy, float* __restrict__ dM, float* __restrict__ Vd,
-                                                          int N, int H, int W, int K) {
+                                                          int N, int H, int W, int K, long plane_in) {
     const int K4 = K >> 2, TH = H >> 2, TW = W >> 2;
-    const long T = (long)N * TH * TW, total = T * K4, plane = T * K;
+    const long T = (long)N * TH * TW, total = T * K4, plane = plane_in > 0 ? plane_in : T * K;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k4 = (int)(i % K4);
         const long t = i / K4;
@@ -779,13 +782,27 @@ extern "C" {
 
 // omni_wino_in of relu?(x * scale + shift): affine = [scale (C) | shift (C)] of the BatchNorm between the convolution that wrote x and
 // this one (nullable: plain omni_wino_in) -- the normalised activation is consumed without ever being stored.
-int omni_wino_in_affine(const float* x, const float* affine, int relu, float* V, int N, int H, int W, int C, int tile, void* stream) {
+static int wino_in_impl(const float* x, const float* affine, int relu, float* V, int N, int H, int W, int C, int tile, long plane, void* stream) {
     if (bad(N, H, W, C) || (tile != 2 && tile != 4) || (H % tile) || (W % tile)) return OMNI_ERR_ARG;
-    const long total = (long)N * (H / tile) * (W / tile) * (C / 4);
+    const long tiles = (long)N * (H / tile) * (W / tile), total = tiles * (C / 4);
+    if (plane != 0 && plane < tiles * C) return OMNI_ERR_ARG;
     if (total == 0) return OMNI_OK;
-    if (tile == 2) hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C, affine, relu);
-    else hipLaunchKernelGGL(wino4_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C, affine, relu);
+    if (tile == 2) hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C, affine, relu, plane);
+    else hipLaunchKernelGGL(wino4_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C, affine, relu, plane);
     return omni_launch_status();
+}
+
+int omni_wino_in_affine(const float* x, const float* affine, int relu, float* V, int N, int H, int W, int C, int tile, void* stream) {
+    return wino_in_impl(x, affine, relu, V, N, H, W, C, tile, 0, stream);
+}
+
+// Row-range forms (round 4): the Winograd-domain array is a row range of a wider (points, rows_total, channels) array that holds the
+// tiles of SEVERAL tensors side by side -- the five FPN levels under the RPN's shared 3x3 convolution -- so that ONE batched GEMM
+// (omni_gemm_batched_fwd / _wgrad over rows_total rows) serves all of them.  V / Mt / dM / Vd point at the tensor's first row,
+// `plane` = rows_total * channels floats between point planes.
+int omni_wino_in_rows(const float* x, float* V, int N, int H, int W, int C, int tile, long long plane, void* stream) {
+    if (plane <= 0) return OMNI_ERR_ARG;
+    return wino_in_impl(x, nullptr, 0, V, N, H, W, C, tile, (long)plane, stream);
 }
 
 int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile, void* stream) {
@@ -794,10 +811,11 @@ int omni_wino_in(const float* x, float* V, int N, int H, int W, int C, int tile,
 
 static int wino_out_impl(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, float* stats,
                          int stats_rows, int* nblk_out, void* stream, BnBwdStats bnb = BnBwdStats{nullptr, nullptr, nullptr},
-                         const float* carry = nullptr, long ldc = 0) {
+                         const float* carry = nullptr, long ldc = 0, long plane = 0) {
     if (nblk_out) *nblk_out = 0;
     if (bad(N, H, W, K) || (tile != 2 && tile != 4) || (H % tile) || (W % tile)) return OMNI_ERR_ARG;
-    const long total = (long)N * (H / tile) * (W / tile) * (K / 4);
+    const long tiles = (long)N * (H / tile) * (W / tile), total = tiles * (K / 4);
+    if (plane != 0 && plane < tiles * K) return OMNI_ERR_ARG;
     if (total == 0) return OMNI_OK;
     int grid = ew_grid(total);
     // statistics: one partial row per workgroup; needs a fixed channel group per thread (256 % (K/4) == 0), raw outputs
@@ -809,10 +827,19 @@ static int wino_out_impl(const float* M, const float* bias, float* y, int N, int
     }
     if (st_ptr == nullptr) bnb = BnBwdStats{nullptr, nullptr, nullptr};
     if (tile == 2) hipLaunchKernelGGL(wino_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu, st_ptr,
-                                      carry, ldc);
+                                      carry, ldc, plane);
     else hipLaunchKernelGGL(wino4_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, bias, y, N, H, W, K, relu, st_ptr, bnb,
-                            carry, ldc);
+                            carry, ldc, plane);
     return omni_launch_status();
+}
+
+// row-range form of omni_wino_out (bias / ReLU) and of omni_wino_out_carry (carry != NULL: no bias, no ReLU); see omni_wino_in_rows
+int omni_wino_out_rows(const float* M, const float* bias, const float* carry, long long ldc, float* y, int N, int H, int W, int K, int relu,
+                       int tile, long long plane, void* stream) {
+    if (plane <= 0) return OMNI_ERR_ARG;
+    if (carry != nullptr && (bias != nullptr || relu || ldc < K || (ldc & 3) || (((unsigned long long)carry) & 15))) return OMNI_ERR_ARG;
+    return wino_out_impl(M, bias, y, N, H, W, K, relu, tile, nullptr, 0, nullptr, stream, BnBwdStats{nullptr, nullptr, nullptr}, carry,
+                         carry != nullptr ? (long)ldc : 0, (long)plane);
 }
 
 int omni_wino_out(const float* M, const float* bias, float* y, int N, int H, int W, int K, int relu, int tile, void* stream) {
@@ -852,13 +879,24 @@ int omni_wino_dy(const float* dy, float* dM, int N, int H, int W, int K, int til
     return omni_launch_status();
 }
 
-int omni_wino_dy_in(const float* dy, float* dM, float* Vd, int N, int H, int W, int K, int tile, void* stream) {
+static int wino_dy_in_impl(const float* dy, float* dM, float* Vd, int N, int H, int W, int K, int tile, long plane, void* stream) {
     if (bad(N, H, W, K) || (tile != 2 && tile != 4) || (H % tile) || (W % tile)) return OMNI_ERR_ARG;
-    const long total = (long)N * (H / tile) * (W / tile) * (K / 4);
+    const long tiles = (long)N * (H / tile) * (W / tile), total = tiles * (K / 4);
+    if (plane != 0 && plane < tiles * K) return OMNI_ERR_ARG;
     if (total == 0) return OMNI_OK;
-    if (tile == 2) hipLaunchKernelGGL(wino_dy_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, Vd, N, H, W, K);
-    else hipLaunchKernelGGL(wino4_dy_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, Vd, N, H, W, K);
+    if (tile == 2) hipLaunchKernelGGL(wino_dy_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, Vd, N, H, W, K, plane);
+    else hipLaunchKernelGGL(wino4_dy_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dM, Vd, N, H, W, K, plane);
     return omni_launch_status();
+}
+
+int omni_wino_dy_in(const float* dy, float* dM, float* Vd, int N, int H, int W, int K, int tile, void* stream) {
+    return wino_dy_in_impl(dy, dM, Vd, N, H, W, K, tile, 0, stream);
+}
+
+// row-range form (dM and Vd are row ranges of two arrays of the same extent; see omni_wino_in_rows)
+int omni_wino_dy_in_rows(const float* dy, float* dM, float* Vd, int N, int H, int W, int K, int tile, long long plane, void* stream) {
+    if (plane <= 0) return OMNI_ERR_ARG;
+    return wino_dy_in_impl(dy, dM, Vd, N, H, W, K, tile, (long)plane, stream);
 }
 
 int omni_wino_weights(const float* g, float* U, float* U_flip, int K, int C, int tile, void* stream) {

@@ -51,14 +51,23 @@ class StandardRPNHead(nn.Module):
         return {"in_channels": in_channels[0], "num_anchors": ag.num_anchors[0], "box_dim": ag.box_dim,
                 "conv_dims": cfg.MODEL.RPN.CONV_DIMS}
 
+    def _shared_conv(self, features):
+        """the shared 3x3 + ReLU over every level: one GEMM per direction for all levels when the maps allow it (functional.
+        _WinoConv3x3Levels), else one convolution per level"""
+        c = self.conv
+        on = HF._WINO_LEVELS == "1" or (HF._WINO_LEVELS == "infer" and not (self.training and torch.is_grad_enabled()))
+        if on and c.stride[0] == 1 and c.padding[0] == 1 and HF.conv3x3_levels_eligible(features, c.weight, 1, 1):
+            return HF.conv3x3_levels(features, c.weight, c.bias, relu=True)
+        return [c(x, relu=True) for x in features]
+
     def forward(self, features):
         wl, wd = self.objectness_logits.weight, self.anchor_deltas.weight
         if _FUSED_HEAD and HF.rpn_head16_eligible(features, wl, wd):
             # both 1x1 heads over every level: one HBM-bound launch per direction (csrc/rpn_head.hip)
-            return HF.rpn_head16([self.conv(x, relu=True) for x in features], wl, self.objectness_logits.bias, wd, self.anchor_deltas.bias)
+            return HF.rpn_head16(self._shared_conv(features), wl, self.objectness_logits.bias, wd, self.anchor_deltas.bias)
         w16 = torch.cat([wl, wd, wl.new_zeros(1, wl.shape[1], 1, 1)], dim=0)
         b16 = torch.cat([self.objectness_logits.bias, self.anchor_deltas.bias, wl.new_zeros(1)])
-        return [HF.conv2d(self.conv(x, relu=True), w16, b16, 1, 0) for x in features]   # (B,16,H,W) CL each
+        return [HF.conv2d(t, w16, b16, 1, 0) for t in self._shared_conv(features)]   # (B,16,H,W) CL each
 
 
 def build_rpn_head(cfg, input_shape):

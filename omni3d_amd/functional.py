@@ -427,6 +427,105 @@ class _WinoConv3x3(Function):
         return dx, dw, db, None, None
 
 
+class _WinoConv3x3Levels(Function):
+    """ONE 3x3 / stride 1 / pad 1 convolution (one filter, one bias) applied to several tensors -- detectron2's StandardRPNHead.conv
+    over the FPN levels p2..p6 (configs/Base.yaml:49) -- with the Winograd-domain tiles of all of them side by side in one array: one
+    batched GEMM per direction for all levels instead of one per level (the p4..p6 problems are 256 / 64 / 16 tile rows: alone each
+    is a latency-bound launch), ONE weight-gradient problem whose row reduction sums the levels, and the transforms of every level
+    reading / writing their row range of the shared arrays (csrc/winograd.hip, the *_rows entry points)."""
+
+    @staticmethod
+    def forward(ctx, w, bias, relu, *xs):
+        ctx.set_materialize_grads(False)
+        ctx.direct = (_direct_grad(w), _direct_grad(bias))
+        ctx.slots = [_slot_enter(x, ctx.needs_input_grad[3 + i]) for i, x in enumerate(xs)]
+        w_given = w
+        xs, w = [_cl(x) for x in xs], _cl(w)
+        shapes = [tuple(x.shape) for x in xs]
+        tile = wino.levels_tile(shapes)
+        assert tile in (2, 4), "conv3x3_levels_eligible() first"
+        offs, rows = wino.level_rows(shapes, tile)
+        need_flip = any(x.requires_grad for x in xs)
+        key = (w.data_ptr(), tuple(w.shape), tile)
+        cache = _wino_scope["cache"]
+        U, Uf = cache.get(key, (None, None)) if cache is not None else (None, None)
+        if U is None or (need_flip and Uf is None):
+            U, Uf = wino.transform_weights(w, True, need_flip or Uf is not None, tile)
+            if cache is not None:
+                cache[key] = (U, Uf)
+                if w is w_given:
+                    _wino_scope["record"].append((w, tile, bool(need_flip or Uf is not None)))
+        V = torch.empty(((tile + 2) ** 2, rows, w.shape[1]), dtype=torch.float32, device=w.device)
+        for x, o in zip(xs, offs):
+            wino.transform_input_rows(x, V, o, tile)
+        Mt = wino.gemm_batched(V, U)
+        ys = [wino.transform_output_rows(Mt, o, (sh[0], sh[2], sh[3]), bias, relu) for sh, o in zip(shapes, offs)]
+        ctx.save_for_backward(V, w, Uf if need_flip else None, *(ys if relu else []))
+        ctx.meta = (relu, bias is not None, tile, shapes, offs, rows)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        V, w, Uf, *ys = ctx.saved_tensors
+        relu, has_bias, tile, shapes, offs, rows = ctx.meta
+        K = w.shape[0]
+        gw, gb = ctx.direct
+        if gw is not None and not gw.is_contiguous(memory_format=CL):
+            gw = None
+        alloc = torch.zeros if any(d is None for d in dys) else torch.empty         # (a level without a gradient contributes zero rows)
+        dM = alloc((V.shape[0], rows, K), dtype=torch.float32, device=V.device)
+        Vd = alloc((V.shape[0], rows, K), dtype=torch.float32, device=V.device)
+        db = None
+        for l, dy in enumerate(dys):
+            if dy is None:
+                continue
+            masked = relu and _relu_already_masked(dy)       # (the consumer's data-gradient kernel applied the mask)
+            dy = _cl(dy)
+            if relu and not masked:
+                dy = bnpool.relu_bwd(dy.permute(0, 2, 3, 1), ys[l].permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            wino.transform_dy_in_rows(dy, dM, Vd, offs[l], tile)
+            if has_bias and ctx.needs_input_grad[1]:
+                part = _bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, K), gb)
+                if gb is None:
+                    db = part if db is None else db + part
+        dw = None
+        if ctx.needs_input_grad[0]:
+            if gw is not None:
+                _side_run(lambda: wino.wgrad_into(V, dM, gw), (V, dM))
+            else:
+                dw = wino.transform_dweights(wino.gemm_batched_wgrad(V, dM), None)
+        dxs = [None] * len(shapes)
+        if any(ctx.needs_input_grad[3:]):
+            if Uf is None:
+                Uf = wino.transform_weights(w, want_u=False, want_flip=True, tile=tile)[1]
+            Mx = wino.gemm_batched(Vd, Uf)
+            for l, (sh, o) in enumerate(zip(shapes, offs)):
+                if not ctx.needs_input_grad[3 + l]:
+                    continue
+
+                def dgrad(carry, sh=sh, o=o):
+                    ok = carry is not None and _carry_pitch(carry) is not None
+                    dx_ = wino.transform_output_rows(Mx, o, (sh[0], sh[2], sh[3]), carry=carry if ok else None)
+                    return dx_ if (ok or carry is None) else dx_ + carry
+                dxs[l] = _slot_deliver(ctx.slots[l], dgrad)
+        return (dw, db, None, *dxs)
+
+
+def conv3x3_levels_eligible(xs, w, stride=1, pad=1):
+    """several tensors under one 3x3 filter through the shared Winograd arrays (_WinoConv3x3Levels)?"""
+    if not (_WINOGRAD and len(xs) > 1 and w.shape[2] == 3 and w.shape[3] == 3 and stride == 1 and pad == 1):
+        return False
+    C, K = w.shape[1], w.shape[0]
+    if C % 32 or K % 32 or C < 128 or K < 128 or any(x.dim() != 4 or x.shape[1] != C or x.dtype != torch.float32 for x in xs):
+        return False
+    return wino.levels_tile([tuple(x.shape) for x in xs]) != 0
+
+
+def conv3x3_levels(xs, w, bias=None, relu=False):
+    """[conv2d(x, w, bias, 1, 1, relu) for x in xs] with one GEMM per direction for all of them (see _WinoConv3x3Levels)"""
+    return list(_WinoConv3x3Levels.apply(w, bias, bool(relu), *xs))
+
+
 class _RPNHead16(Function):
     """objectness_logits + anchor_deltas of detectron2's StandardRPNHead over all FPN levels (csrc/rpn_head.hip): ts = the per-level
     ReLU outputs of the shared 3x3 convolution, (B, 256, H, W) CL -> per-level (B, 16, H, W) CL [3 logits | 12 deltas | 0].
@@ -554,6 +653,11 @@ class wino_weight_scope:
 
 
 _WINOGRAD = _os_environ_get("OMNI_WINOGRAD", "1") != "0"
+# The RPN's shared 3x3 over all FPN levels through one GEMM per direction (conv3x3_levels).  MEASURED and left OFF for training
+# (profiles/r04_ab_wino_levels.log: 11.33-11.35 ms with, 11.25-11.34 without -- the p4..p6 GEMMs it absorbs are paid back by 36-point
+# transforms on the 16x16 / 8x8 maps and a third more rows in the p2 launch; inference: 623 against 616 images/s, but the smallest
+# levels change from the direct kernel to the transform and one reference-written inference fixture flips a detection on it).
+_WINO_LEVELS = _os_environ_get("OMNI_WINO_LEVELS", "0")               # "1" always | "0" never | "infer": eval mode only
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, want_stats=False):

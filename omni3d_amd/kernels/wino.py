@@ -88,6 +88,67 @@ def transform_input(x, tile=2, affine=None, relu=False):
     return V
 
 
+# ---- row-range forms: the tiles of several tensors side by side in one (P, rows_total, C) array, ONE batched GEMM for all of them ----
+def levels_tile(shapes):
+    """common tile size for the tensors of a shared convolution (the RPN's 3x3 over the FPN levels), or 0: the 36-point transform when
+    every map divides into 4x4 tiles and there are enough of them in total, else the 16-point one on even maps"""
+    if not shapes or any(H % 2 or W % 2 for _, _, H, W in shapes):
+        return 0
+    if _f22_depth == 0 and _F43 and all(H % 4 == 0 and W % 4 == 0 for _, _, H, W in shapes) \
+            and sum(N * (H // 4) * (W // 4) for N, _, H, W in shapes) >= _F43_MIN_TILES:
+        return 4
+    return 2 if sum(N * (H // 2) * (W // 2) for N, _, H, W in shapes) >= _MIN_TILES else 0
+
+
+def level_rows(shapes, tile):
+    """-> (first row of every tensor, total rows)"""
+    offs, tot = [], 0
+    for N, _, H, W in shapes:
+        offs.append(tot)
+        tot += N * (H // tile) * (W // tile)
+    return offs, tot
+
+
+def _row_ptr(A, row0):
+    return A.data_ptr() + 4 * row0 * A.shape[2]
+
+
+def transform_input_rows(x, V_all, row0, tile):
+    """x (N,C,H,W) CL -> rows [row0, row0 + T) of V_all (P, rows_total, C)"""
+    xv = _nhwc(x)
+    N, H, W, C = xv.shape
+    L = _lib.check_device(xv, V_all)
+    assert V_all.shape[0] == _points(tile) and V_all.shape[2] == C and row0 + N * (H // tile) * (W // tile) <= V_all.shape[1]
+    L.call("omni_wino_in_rows", _lib.ptr(xv), _row_ptr(V_all, row0), N, H, W, C, tile, V_all.shape[1] * C, _lib.stream_of(x))
+
+
+def transform_output_rows(Mt_all, row0, shape, bias=None, relu=False, carry=None):
+    """rows [row0, ...) of Mt_all (P, rows_total, K) -> y (N,K,H,W) CL (+ bias, ReLU | + carry: see transform_output)"""
+    tile = 2 if Mt_all.shape[0] == 16 else 4
+    N, H, W = shape
+    K = Mt_all.shape[2]
+    L = _lib.check_device(Mt_all, bias)
+    assert row0 + N * (H // tile) * (W // tile) <= Mt_all.shape[1]
+    y = torch.empty((N, H, W, K), dtype=torch.float32, device=Mt_all.device)
+    if carry is not None:
+        assert bias is None and not relu and tuple(carry.shape) == (N, K, H, W)
+    L.call("omni_wino_out_rows", _row_ptr(Mt_all, row0), _lib.ptr(bias), carry.data_ptr() if carry is not None else None,
+           carry.stride(3) if carry is not None else 0, _lib.ptr(y), N, H, W, K, int(relu), tile, Mt_all.shape[1] * K, _lib.stream_of(Mt_all))
+    return y.permute(0, 3, 1, 2)
+
+
+def transform_dy_in_rows(dy, dM_all, Vd_all, row0, tile):
+    """dy (N,K,H,W) CL -> rows [row0, ...) of dM_all and Vd_all (both (P, rows_total, K)): the weight gradient's and the data gradient's
+    transforms of dy from one read"""
+    dv = _nhwc(dy)
+    N, H, W, K = dv.shape
+    L = _lib.check_device(dv, dM_all, Vd_all)
+    assert dM_all.shape == Vd_all.shape and dM_all.shape[0] == _points(tile) and dM_all.shape[2] == K
+    assert row0 + N * (H // tile) * (W // tile) <= dM_all.shape[1]
+    L.call("omni_wino_dy_in_rows", _lib.ptr(dv), _row_ptr(dM_all, row0), _row_ptr(Vd_all, row0), N, H, W, K, tile, dM_all.shape[1] * K,
+           _lib.stream_of(dy))
+
+
 def transform_weights(w, want_u=True, want_flip=False, tile=2):
     """w (K,C,3,3) CL (KRSC) -> (U (16,K,C) or None, U' (16,C,K) or None); U' = transform of the rotated, channel-transposed
     filter (the data gradient's weights), produced by the same launch."""

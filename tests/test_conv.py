@@ -527,3 +527,62 @@ def test_bn_relu_winograd_fusion_emulated(emu_lib):
 @pytest.mark.gpu
 def test_bn_relu_winograd_fusion_gpu(hip_lib):
     _run_bn_relu_wino_fusion("cuda", [(4, 128, 64, 4), (4, 256, 32, 4), (4, 512, 16, 2), (4, 64, 128, 4)])
+
+
+# ---- one 3x3 filter over several tensors through shared Winograd arrays (functional._WinoConv3x3Levels) -------------------
+def _run_levels(dev, sizes, tile_expected, N=2, C=128, K=128, seed=3):
+    """the RPN's shared convolution over FPN levels.  (1) without ReLU against torch's conv2d on every level: outputs, input gradients
+    (level 0 has a second consumer), filter and bias gradients.  (2) with ReLU against the per-level path of the same kernels on the
+    levels that take the same transform there: a ReLU mask flips wherever an output is within rounding of zero, so only two paths with
+    the same arithmetic can be compared through it."""
+    from omni3d_amd import functional as HF
+    from omni3d_amd.kernels import wino
+    g = torch.Generator().manual_seed(seed)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)  # noqa: E731
+    xs = [torch.randn(N, C, h, w_, generator=g) for h, w_ in sizes]
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(K, generator=g) * 0.1
+    dys = [torch.randn(N, K, h, w_, generator=g) for h, w_ in sizes]
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = [F.conv2d(x, wr, br, padding=1) for x in xr]
+    torch.autograd.backward(ref + [(xr[0] * 0.5).sum()], dys + [torch.ones(())])                 # a second consumer of level 0
+    xd = [cl(x).to(dev).requires_grad_(True) for x in xs]
+    wd, bd = cl(w).to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    assert HF.conv3x3_levels_eligible(xd, wd) and wino.levels_tile([tuple(x.shape) for x in xd]) == tile_expected
+    with HF.wino_weight_scope():
+        ys = HF.conv3x3_levels(xd, wd, bd, relu=False)
+    torch.autograd.backward(ys + [(xd[0] * 0.5).sum()], [cl(d).to(dev) for d in dys] + [torch.ones((), device=dev)])
+    tol = 2e-3 if tile_expected == 4 else 5e-4
+    for y, r in zip(ys, ref):
+        assert (y.detach().cpu() - r.detach()).abs().max() <= tol * float(r.detach().abs().max())
+    for a, r in zip(xd, xr):
+        assert (a.grad.cpu() - r.grad).abs().max() <= tol * float(r.grad.abs().max())
+    assert (wd.grad.cpu() - wr.grad).abs().max() <= tol * float(wr.grad.abs().max())
+    assert (bd.grad.cpu() - br.grad).abs().max() <= 1e-4 * float(br.grad.abs().max())
+    # (2) ReLU: the same tensors through both forms
+    import contextlib
+    xa = [cl(x).to(dev).requires_grad_(True) for x in xs]
+    xb = [cl(x).to(dev).requires_grad_(True) for x in xs]
+    with HF.wino_weight_scope():
+        ya = HF.conv3x3_levels(xa, wd, bd, relu=True)
+    with (wino.f22_only() if tile_expected == 2 else contextlib.nullcontext()), HF.wino_weight_scope():
+        same = [l for l, x in enumerate(xb) if wino.eligible(tuple(x.shape), tuple(wd.shape), 1, 1) and wino.tile_size(tuple(x.shape)) == tile_expected]
+        yb = {l: HF.conv2d(xb[l], wd, bd, 1, 1, relu=True) for l in same}
+    assert same, "no level takes the same transform on the per-level path"
+    torch.autograd.backward(ya, [cl(d).to(dev) for d in dys])
+    torch.autograd.backward([yb[l] for l in same], [cl(dys[l]).to(dev) for l in same])
+    for l in same:
+        assert torch.equal(ya[l].detach(), yb[l].detach()), l                    # same arithmetic per output row
+        assert (xa[l].grad - xb[l].grad).abs().max() <= 1e-5 * float(xb[l].grad.abs().max()), l
+
+
+def test_wino_levels_emulated(emu_lib):
+    _run_levels("cpu", [(16, 24), (8, 12), (4, 8)], 2, N=4)      # 128 tiles of 4x4 are below the 36-point transform's floor: 16-point
+    _run_levels("cpu", [(32, 32), (16, 16), (8, 8), (4, 4)], 4, N=4)
+
+
+@pytest.mark.gpu
+def test_wino_levels_gpu(hip_lib):
+    _run_levels("cuda", [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)], 4, N=4, C=256, K=256)      # the benchmark's five levels
+    _run_levels("cuda", [(64, 96), (32, 48), (16, 24), (8, 12), (4, 6)], 2, N=2, C=256, K=256)         # p6 of 4 x 6: 16-point transform
