@@ -187,6 +187,7 @@ def linear_fwd(x, w, bias=None, relu=False):
 
 
 _DGRAD_NT = os.environ.get("OMNI_FC_DGRAD_NT", "1") != "0"
+_DGRAD_FORM = os.environ.get("OMNI_FC_DGRAD_FORM", "nn")            # "nn": the engine reads W as it is | "nt": transpose W first (rounds 2-3)
 _FC_BALANCED = os.environ.get("OMNI_FC_BALANCED", "1") != "0"
 _FC_WGRAD_ENGINE_MIN_ROWS = int(os.environ.get("OMNI_FC_WGRAD_ENGINE_MIN_ROWS", "1024"))
 # persistent workgroups of the fc1-class weight gradient (0 = one per CU): it runs on the weight-gradient stream BESIDE the critical path,
@@ -199,10 +200,13 @@ def linear_dgrad(dy, w):
     C = w.shape[1]
     L = _lib.check_device(dy, w)
     if _DGRAD_NT and M >= 512 and C >= 4096 and K >= 512 and (K % 32) == 0:
-        # fc1-class data gradient dX = dY W as the NT product dY (W^T)^T on the LDS-DMA engine: one pass over W to transpose it
-        # (51 MB for fc1) buys the engine's NT main loop (0.78 of the fp32-MFMA peak against 0.59 for the tile kernel's NN form)
+        # fc1-class data gradient dX = dY W on the LDS-DMA engine.  Round 4: its NN form reads W as it is (box head 494 us, cube head 160 us,
+        # same sums bit for bit); rounds 2-3 transposed W first (51 MB, two launches per step on the critical path) for the NT main
+        # loop: 540 / 175 us including the transpose (tools/exp/fc1_nn.py, profiles/r04_fc1_nn.log).  OMNI_FC_DGRAD_FORM=nt: the old form
         from . import gemm as _gemm
-        return _gemm.gemm(dy, _gemm.transpose2d(w), _gemm.NT, tile=2, splits=_gemm.BALANCED if _FC_BALANCED else 1)
+        if _DGRAD_FORM == "nt":
+            return _gemm.gemm(dy, _gemm.transpose2d(w), _gemm.NT, tile=2, splits=_gemm.BALANCED if _FC_BALANCED else 1)
+        return _gemm.gemm(dy, w, _gemm.NN, tile=2, splits=_gemm.BALANCED if _FC_BALANCED else 1)
     dx = torch.empty((M, C), dtype=torch.float32, device=dy.device)
     _dgrad_launch(L, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), M, 1, 1, C, K, 1, 1, 1, 0, K, C, 0, 0, 0, dy)
     return dx
