@@ -485,9 +485,9 @@ def dominant_kernel_roofline(iters=20):
                                                                         #  576 workgroups -> one averaged row)
         fam("FC forward (fc1-class)", "gemm_engine_kernel<0, 0, 128, 128, false>", "[2048x12544]x[1024x12544]^T box-head fc1 (128 tiles x 2 reduction halves = one round of 256 workgroups)",
             2.0 * 2048 * 12544 * 1024, lambda: conv.linear_fwd(x1, w1, None), pmc_key="gemm_engine_kernel<0, 0, 128, 128, false>", grid=65536),
-        fam("FC data gradient (transpose of W + the engine's NT form, balanced work split)", "gemm_engine_kernel<0, 0, 128, 128, true>",
-            "[2048x1024]x[12544x1024]^T box-head fc1 (incl. the 51 MB transpose; 1568 tiles = 6 per workgroup + 32 tiles cut in 8)",
-            2.0 * 2048 * 12544 * 1024, lambda: conv.linear_dgrad(dy1, w1), pmc_key="gemm_engine_kernel<0, 0, 128, 128, true>", grid=65536),
+        fam("FC data gradient (the engine's NN form reading W as it is, balanced work split)", "gemm_engine_kernel<0, 1, 128, 128, true>",
+            "[2048x1024]x[1024x12544] box-head fc1 (1568 tiles = 6 per workgroup + 32 tiles cut in 8)",
+            2.0 * 2048 * 12544 * 1024, lambda: conv.linear_dgrad(dy1, w1), pmc_key="gemm_engine_kernel<0, 1, 128, 128, true>", grid=65536),
         fam("FC weight gradient (engine TN form, balanced work split, accumulated into the gradient bucket)", "gemm_engine_kernel<1, 1, 128, 128, true>",
             "[1024x2048]x[2048x12544] box-head fc1 (784 tiles = 3 per workgroup + 16 tiles cut in 16)", 2.0 * 2048 * 12544 * 1024,
             lambda: conv.linear_wgrad(x1, dy1, accum_into=gacc1), pmc_key="gemm_engine_kernel<1, 1, 128, 128, true>", grid=65536),
