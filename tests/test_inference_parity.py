@@ -182,3 +182,31 @@ def test_replayed_inference_equals_eager_gpu(hip_lib):
         r.__dict__.pop("_omni_slots")
     slow = INF.postprocess(res, first, sizes)
     _same_results(fast, slow)
+
+
+def test_batched_postprocess_equals_per_image_form_cpu():
+    """roi_heads/inference.py:_postprocess_slots (one rescale / clip / empty-box pass for the batch) against the per-image form of
+    detectron2's detector_postprocess -- including an image whose clipped boxes are partly EMPTY (the boolean-indexing fallback) and an
+    image without detections"""
+    from omni3d_amd.cubercnn.modeling.roi_heads import inference as INF
+    g = torch.Generator().manual_seed(5)
+    B, topk, K = 3, 6, 4
+    dbox = torch.rand(B, topk, 4, generator=g) * 60.0
+    dbox[..., 2:] += dbox[..., :2] + 1.0
+    dbox[0, 1] = torch.tensor([70.0, 10.0, 90.0, 30.0])          # left of nothing: clipped to zero width at W = 64 -> dropped
+    dbox[0, 3] = torch.tensor([10.0, 80.0, 30.0, 95.0])          # below the image: zero height after the clip -> dropped
+    raw = {"dbox": dbox, "final": torch.rand(B * topk, generator=g), "full": torch.rand(B, topk, K, generator=g),
+           "dcls": torch.randint(0, K, (B, topk), generator=g, dtype=torch.int32), "verts": torch.rand(B * topk, 8, 3, generator=g),
+           "cube3d": torch.rand(B * topk, 9, generator=g), "pose": torch.rand(B * topk, 3, 3, generator=g),
+           "dcount": torch.tensor([5, 0, 6], dtype=torch.int32)}
+    sizes = [(64, 64), (48, 64), (64, 56)]
+    infos = [{"height": 128, "width": 128}, {"height": 48, "width": 64}, {"height": 96, "width": 84}]
+    res = INF.collect_detections(raw, sizes)
+    assert [len(r) for r in res] == [5, 0, 6] and all(getattr(r, "_omni_slots", None) is not None for r in res)
+    fast = INF.postprocess(res, infos, sizes)
+    for r in res:
+        r.__dict__.pop("_omni_slots")
+    slow = INF.postprocess(res, infos, sizes)
+    _same_results(fast, slow)
+    assert len(fast[0]["instances"]) == 3 and len(fast[1]["instances"]) == 0 and len(fast[2]["instances"]) == 6
+    assert fast[2]["instances"].image_size == (96, 84)
