@@ -137,7 +137,6 @@ def _postprocess_slots(instances, batched_inputs, image_sizes, dbox):
     the clip and the empty-box test run once for the batch (the same multiplications and clamps, in the same order), the mask comes
     back in one copy, and an image whose boxes are all non-empty -- every image, normally -- keeps its fields as the views they are.
     Per image the reference's form costs ~25 launches (boolean indexing of nine fields = nine nonzero + gather pairs)."""
-    B = dbox.shape[0]
     HW = [(info.get("height", size[0]), info.get("width", size[1])) for info, size in zip(batched_inputs, image_sizes)]
     sc = torch.tensor([[W / res.image_size[1], H / res.image_size[0]] * 2 for (H, W), res in zip(HW, instances)], dtype=torch.float32)
     lim = torch.tensor([[W, H, W, H] for H, W in HW], dtype=torch.float32)
