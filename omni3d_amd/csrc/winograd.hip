@@ -546,10 +546,102 @@ __device__ __forceinline__ void wino4_w_body(const float* __restrict__ g, float*
         }
     }
 }
+// The same transform on 32 x 32 (k, c) tiles (round 4): every store instruction of a wave covers two 128-byte runs instead of four
+// 64-byte ones -- this launch writes 260 MB per training step (36 planes of U and of U' for every 3x3 filter) and ran at 2.3 TB/s.
+// A thread owns four (k, c) pairs, k = k0 + tid / 32 + 8 j; U' goes through LDS one row of six points at a time ([6][32][33] floats).
+__device__ __forceinline__ void wino4_w_body32(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf, int K, int C,
+                                               int bid, float* __restrict__ smem) {
+    float (*s_t)[32][33] = reinterpret_cast<float (*)[32][33]>(smem);
+    const long total = (long)K * C;
+    const int tiles_c = (C + 31) / 32;
+    const int k0 = (bid / tiles_c) * 32, c0 = (bid % tiles_c) * 32;
+    const int kq = threadIdx.x >> 5, cc = threadIdx.x & 31;
+    const int c = c0 + cc;
+    float w[4][3][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + kq + 8 * j;
+        const bool ok = k < K && c < C;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) w[j][r][s] = ok ? g[((long)k * 9 + r * 3 + s) * C + c] : 0.f;
+    }
+    if (U != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + kq + 8 * j;
+            const bool ok = k < K && c < C;
+            float a[6][3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                float col[3], o6[6];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) col[r] = w[j][r][s];
+                g6(col, o6);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) a[r][s] = o6[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                float row[6];
+                g6(a[r], row);
+#pragma unroll
+                for (int s = 0; s < 6; ++s)
+                    if (ok) U[(long)(6 * r + s) * total + (long)k * C + c] = row[s];
+            }
+        }
+    }
+    if (Uf != nullptr) {
+        float a[4][6][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                float col[3], o6[6];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) col[r] = w[j][2 - r][2 - s];
+                g6(col, o6);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) a[j][r][s] = o6[r];
+            }
+        const int okk = k0 + cc;                     // transposed side: lanes run along k
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {                // (unrolled: `a` stays in registers)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float row[6];
+                float ar[3] = {a[j][r][0], a[j][r][1], a[j][r][2]};
+                g6(ar, row);
+#pragma unroll
+                for (int s = 0; s < 6; ++s) s_t[s][cc][kq + 8 * j] = row[s];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ol = kq + 8 * j, oc = c0 + ol;
+                if (oc < C && okk < K) {
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) Uf[(long)(6 * r + s) * total + (long)oc * K + okk] = s_t[s][ol][cc];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+// OMNI_WINO_W_TILE32=0: the 16 x 16 tiles of rounds 1-3 (A/B knob)
+static inline int wino4_w_tile32() {
+    static const int on = [] { const char* e = getenv("OMNI_WINO_W_TILE32"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
+    return on;
+}
+static inline int wino4_w_tiles(int K, int C) {
+    return wino4_w_tile32() ? ((K + 31) / 32) * ((C + 31) / 32) : ((K + 15) / 16) * ((C + 15) / 16);
+}
 __global__ void __launch_bounds__(256) wino4_w_kernel(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf,
-                                                      int K, int C) {
+                                                      int K, int C, int tile32) {
     __shared__ float s_t[36][16][17];
-    wino4_w_body(g, U, Uf, K, C, (int)blockIdx.x, s_t);
+    if (tile32) wino4_w_body32(g, U, Uf, K, C, (int)blockIdx.x, &s_t[0][0][0]);
+    else wino4_w_body(g, U, Uf, K, C, (int)blockIdx.x, s_t);
 }
 
 // Every filter of a forward pass in ONE launch: the weights are fixed for the duration of a step, so the ~20 transform launches of
@@ -562,7 +654,7 @@ struct WinoWTable {
     float* Uf[WINO_MULTI_MAX];
     int K[WINO_MULTI_MAX], C[WINO_MULTI_MAX], tile[WINO_MULTI_MAX];
     int wg0[WINO_MULTI_MAX + 1];
-    int n;
+    int n, tile32;
 };
 __global__ void __launch_bounds__(256) wino_w_multi_kernel(WinoWTable t) {
     __shared__ float s_t[36][16][17];
@@ -570,6 +662,7 @@ __global__ void __launch_bounds__(256) wino_w_multi_kernel(WinoWTable t) {
     while (e + 1 < t.n && (int)blockIdx.x >= t.wg0[e + 1]) ++e;
     const int bid = (int)blockIdx.x - t.wg0[e];
     if (t.tile[e] == 2) wino_w_body(t.g[e], t.U[e], t.Uf[e], t.K[e], t.C[e], bid, s_t);
+    else if (t.tile32) wino4_w_body32(t.g[e], t.U[e], t.Uf[e], t.K[e], t.C[e], bid, &s_t[0][0][0]);
     else wino4_w_body(t.g[e], t.U[e], t.Uf[e], t.K[e], t.C[e], bid, s_t);
 }
 
@@ -903,7 +996,8 @@ int omni_wino_weights(const float* g, float* U, float* U_flip, int K, int C, int
     if (K <= 0 || C <= 0 || (U == nullptr && U_flip == nullptr) || (tile != 2 && tile != 4)) return OMNI_ERR_ARG;
     const unsigned wt = (unsigned)(((K + 15) / 16) * ((C + 15) / 16));       // one 16 x 16 (k, c) tile per workgroup
     if (tile == 2) hipLaunchKernelGGL(wino_w_kernel, dim3(wt), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
-    else hipLaunchKernelGGL(wino4_w_kernel, dim3(wt), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
+    else hipLaunchKernelGGL(wino4_w_kernel, dim3((unsigned)wino4_w_tiles(K, C)), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C,
+                            wino4_w_tile32());
     return omni_launch_status();
 }
 
@@ -914,6 +1008,7 @@ int omni_wino_weights_multi(const void* const* g, const void* const* U, const vo
     if (n <= 0 || n > WINO_MULTI_MAX || g == nullptr || U == nullptr || U_flip == nullptr) return OMNI_ERR_ARG;
     WinoWTable t;
     t.n = n;
+    t.tile32 = wino4_w_tile32();
     t.wg0[0] = 0;
     for (int i = 0; i < n; ++i) {
         if (K[i] <= 0 || C[i] <= 0 || (U[i] == nullptr && U_flip[i] == nullptr) || (tile[i] != 2 && tile[i] != 4) || g[i] == nullptr)
@@ -922,7 +1017,7 @@ int omni_wino_weights_multi(const void* const* g, const void* const* U, const vo
         t.U[i] = (float*)U[i];
         t.Uf[i] = (float*)U_flip[i];
         t.K[i] = K[i]; t.C[i] = C[i]; t.tile[i] = tile[i];
-        t.wg0[i + 1] = t.wg0[i] + ((K[i] + 15) / 16) * ((C[i] + 15) / 16);
+        t.wg0[i + 1] = t.wg0[i] + (tile[i] == 4 ? wino4_w_tiles(K[i], C[i]) : ((K[i] + 15) / 16) * ((C[i] + 15) / 16));
     }
     hipLaunchKernelGGL(wino_w_multi_kernel, dim3((unsigned)t.wg0[n]), dim3(256), 0, (hipStream_t)stream, t);
     return omni_launch_status();
