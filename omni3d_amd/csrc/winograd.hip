@@ -187,6 +187,73 @@ __global__ void __launch_bounds__(256) wino_dy_kernel(const float* __restrict__ 
 // U[xi][k][c] = (G g G^T)[xi]; optionally also U'[xi][c][k], the transform of the 180-degree rotated, channel-transposed filter
 // (what the data gradient convolves dy with): rotating g permutes the rows of G g by pi = (3, 1, 2, 0), so
 // U'[4i + j][c][k] = U[4 pi(i) + pi(j)][k][c] -- no second pass over g.
+// 32 x 32 (k, c) tiles (round 4; see wino4_w_body32): a thread owns four (k, c) pairs, k = k0 + tid / 32 + 8 j; U' through LDS four
+// points at a time ([4][32][33] floats)
+__device__ __forceinline__ void wino_w_body32(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf, int K, int C,
+                                              int bid, float* __restrict__ smem) {
+    float (*s_t)[32][33] = reinterpret_cast<float (*)[32][33]>(smem);
+    const long total = (long)K * C;
+    const int tiles_c = (C + 31) / 32;
+    const int k0 = (bid / tiles_c) * 32, c0 = (bid % tiles_c) * 32;
+    const int kq = threadIdx.x >> 5, cc = threadIdx.x & 31;
+    const int c = c0 + cc;
+    float u[4][4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + kq + 8 * j;
+        const bool ok = k < K && c < C;
+        float w[3][3], a[4][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) w[r][s] = ok ? g[((long)k * 9 + r * 3 + s) * C + c] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {       // G g
+            a[0][s] = w[0][s];
+            a[1][s] = 0.5f * (w[0][s] + w[1][s] + w[2][s]);
+            a[2][s] = 0.5f * (w[0][s] - w[1][s] + w[2][s]);
+            a[3][s] = w[2][s];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {       // (.) G^T
+            u[j][r][0] = a[r][0];
+            u[j][r][1] = 0.5f * (a[r][0] + a[r][1] + a[r][2]);
+            u[j][r][2] = 0.5f * (a[r][0] - a[r][1] + a[r][2]);
+            u[j][r][3] = a[r][2];
+        }
+        if (U != nullptr && ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) U[(long)(4 * r + t) * total + (long)k * C + c] = u[j][r][t];
+        }
+    }
+    if (Uf != nullptr) {
+        const int okk = k0 + cc;                     // transposed side: lanes run along k
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pr = (r == 0) ? 3 : (r == 3) ? 0 : r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int pt = (t == 0) ? 3 : (t == 3) ? 0 : t;
+                    s_t[t][cc][kq + 8 * j] = u[j][pr][pt];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ol = kq + 8 * j, oc = c0 + ol;
+                if (oc < C && okk < K) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) Uf[(long)(4 * r + t) * total + (long)oc * K + okk] = s_t[t][ol][cc];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __device__ __forceinline__ void wino_w_body(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf, int K, int C,
                                             int bid, float (*s_t)[16][17]) {
     // one 16 (k) x 16 (c) tile per block (bid); U' goes through an LDS transpose (s_t: [16][16][17]) so that its rows (k contiguous)
@@ -241,9 +308,10 @@ __device__ __forceinline__ void wino_w_body(const float* __restrict__ g, float* 
     }
 }
 __global__ void __launch_bounds__(256) wino_w_kernel(const float* __restrict__ g, float* __restrict__ U, float* __restrict__ Uf,
-                                                     int K, int C) {
-    __shared__ float s_t[16][16][17];
-    wino_w_body(g, U, Uf, K, C, (int)blockIdx.x, s_t);
+                                                     int K, int C, int tile32) {
+    __shared__ float s_t[16][16][17];           // 17.4 KB >= the 32-tile form's [4][32][33]
+    if (tile32) wino_w_body32(g, U, Uf, K, C, (int)blockIdx.x, &s_t[0][0][0]);
+    else wino_w_body(g, U, Uf, K, C, (int)blockIdx.x, s_t);
 }
 
 // v[r][s] = (G^T dU G)[r][s] of filter element i = k * C + c
@@ -661,7 +729,8 @@ __global__ void __launch_bounds__(256) wino_w_multi_kernel(WinoWTable t) {
     int e = 0;
     while (e + 1 < t.n && (int)blockIdx.x >= t.wg0[e + 1]) ++e;
     const int bid = (int)blockIdx.x - t.wg0[e];
-    if (t.tile[e] == 2) wino_w_body(t.g[e], t.U[e], t.Uf[e], t.K[e], t.C[e], bid, s_t);
+    if (t.tile[e] == 2 && t.tile32) wino_w_body32(t.g[e], t.U[e], t.Uf[e], t.K[e], t.C[e], bid, &s_t[0][0][0]);
+    else if (t.tile[e] == 2) wino_w_body(t.g[e], t.U[e], t.Uf[e], t.K[e], t.C[e], bid, s_t);
     else if (t.tile32) wino4_w_body32(t.g[e], t.U[e], t.Uf[e], t.K[e], t.C[e], bid, &s_t[0][0][0]);
     else wino4_w_body(t.g[e], t.U[e], t.Uf[e], t.K[e], t.C[e], bid, s_t);
 }
@@ -994,10 +1063,9 @@ int omni_wino_dy_in_rows(const float* dy, float* dM, float* Vd, int N, int H, in
 
 int omni_wino_weights(const float* g, float* U, float* U_flip, int K, int C, int tile, void* stream) {
     if (K <= 0 || C <= 0 || (U == nullptr && U_flip == nullptr) || (tile != 2 && tile != 4)) return OMNI_ERR_ARG;
-    const unsigned wt = (unsigned)(((K + 15) / 16) * ((C + 15) / 16));       // one 16 x 16 (k, c) tile per workgroup
-    if (tile == 2) hipLaunchKernelGGL(wino_w_kernel, dim3(wt), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C);
-    else hipLaunchKernelGGL(wino4_w_kernel, dim3((unsigned)wino4_w_tiles(K, C)), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C,
-                            wino4_w_tile32());
+    const unsigned wt = (unsigned)wino4_w_tiles(K, C);       // one 32 x 32 (or, OMNI_WINO_W_TILE32=0, 16 x 16) (k, c) tile per workgroup
+    if (tile == 2) hipLaunchKernelGGL(wino_w_kernel, dim3(wt), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C, wino4_w_tile32());
+    else hipLaunchKernelGGL(wino4_w_kernel, dim3(wt), dim3(256), 0, (hipStream_t)stream, g, U, U_flip, K, C, wino4_w_tile32());
     return omni_launch_status();
 }
 
@@ -1017,7 +1085,7 @@ int omni_wino_weights_multi(const void* const* g, const void* const* U, const vo
         t.U[i] = (float*)U[i];
         t.Uf[i] = (float*)U_flip[i];
         t.K[i] = K[i]; t.C[i] = C[i]; t.tile[i] = tile[i];
-        t.wg0[i + 1] = t.wg0[i] + (tile[i] == 4 ? wino4_w_tiles(K[i], C[i]) : ((K[i] + 15) / 16) * ((C[i] + 15) / 16));
+        t.wg0[i + 1] = t.wg0[i] + wino4_w_tiles(K[i], C[i]);      // (both transforms take the same tile size)
     }
     hipLaunchKernelGGL(wino_w_multi_kernel, dim3((unsigned)t.wg0[n]), dim3(256), 0, (hipStream_t)stream, t);
     return omni_launch_status();
