@@ -23,8 +23,9 @@ FIELDS = ("Ks", "v2r", "ratio", "image_hw")          # what the inference pass r
 
 
 class InferReplay:
-    def __init__(self, model, warm=1):
+    def __init__(self, model, warm=1, graphs=None):
         self.model, self.warm = model, warm
+        self.graphs = graphs                 # None: hipGraphs on a GPU, nothing elsewhere; False: the same staging with eager launches (CPU tests)
         self.cache, self.counts = OrderedDict(), {}
         self.failed = None
         self.replays = self.captures = 0
@@ -36,7 +37,7 @@ class InferReplay:
         if not ENABLED or self.failed is not None or not batched_inputs:
             return None
         img0 = batched_inputs[0]["image"]
-        if self.model.device.type != "cuda" or any("oracle2D" in b for b in batched_inputs):
+        if (self.model.device.type != "cuda" and self.graphs is not False) or any("oracle2D" in b for b in batched_inputs):
             return None
         from ...solver.autoreplay import AutoReplay
         # A captured pass reads the weights through their pointers (live), but values DERIVED from them outside the graph -- the
@@ -67,7 +68,11 @@ class InferReplay:
         else:
             self._stage(entry, batched_inputs)
         self.cache.move_to_end(sig)
-        entry["graph"].replay()
+        if entry["graph"] is not None:
+            entry["graph"].replay()
+        else:
+            with torch.no_grad(), context():
+                entry["raw"] = self.model._inference_device(entry["batch"], entry["packed"])
         self.replays += 1
         sizes = [(b["image"].shape[-2], b["image"].shape[-1]) for b in batched_inputs]
         # (copies: the results handed to the caller must not alias the tensors the next replay overwrites -- a few hundred KB)
@@ -96,6 +101,9 @@ class InferReplay:
             sb.append(c)
         packed = self._pack(batch).to(dev)
         packed.slotted = True
+        if self.graphs is False or dev.type != "cuda":
+            self.captures += 1
+            return {"graph": None, "raw": None, "slots": slots, "batch": sb, "packed": packed}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad(), context():

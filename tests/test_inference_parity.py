@@ -210,3 +210,44 @@ def test_batched_postprocess_equals_per_image_form_cpu():
     _same_results(fast, slow)
     assert len(fast[0]["instances"]) == 3 and len(fast[1]["instances"]) == 0 and len(fast[2]["instances"]) == 6
     assert fast[2]["instances"].image_size == (96, 84)
+
+
+def test_replayed_inference_staging_emulated(emu_lib):
+    """InferReplay with graphs=False (the same slots / static packed description / digest logic, eager launches): a second batch of
+    the bucket with a ragged image and other intrinsics must reach the static tensors, results equal the plain eager pass, and a
+    parameter write drops the captured passes"""
+    from oracle import make_golden as MG
+    from omni3d_amd import synthetic
+    from omni3d_amd.cubercnn.modeling.meta_arch import infer_replay
+    LIGHT = ["MODEL.RPN.PRE_NMS_TOPK_TEST", 60, "MODEL.RPN.POST_NMS_TOPK_TEST", 20, "MODEL.DLA.TYPE", "dla46_c", "MODEL.FPN.OUT_CHANNELS", 32,
+             "MODEL.ROI_BOX_HEAD.FC_DIM", 64, "MODEL.ROI_CUBE_HEAD.FC_DIM", 64, "TEST.DETECTIONS_PER_IMAGE", 10]
+    priors = synthetic.make_priors(50)
+    model = MG.sharpen(MG.build_product_model(MG.product_cfg(LIGHT), priors, 11, device="cpu"))
+    model.eval()
+    first = synthetic.make_batch(2, 64, 64, num_gt=3, seed=5, priors=priors)
+    second = synthetic.make_batch(2, 64, 64, num_gt=3, seed=6, priors=priors)
+    second[1]["image"] = second[1]["image"][:, :40, :56].contiguous()
+    second[1]["height"], second[1]["width"] = 80, 112
+    second[0]["K"] = [[300.0, 0.0, 30.0], [0.0, 300.0, 34.0], [0.0, 0.0, 1.0]]
+    for b in first + second:
+        b.pop("instances", None)
+    prev = infer_replay.ENABLED
+    try:
+        infer_replay.ENABLED = False
+        with torch.no_grad():
+            eager = [model(first), model(second)]
+        infer_replay.ENABLED = True
+        rep = model.__dict__["_omni_infer"] = infer_replay.InferReplay(model, graphs=False)
+        with torch.no_grad():
+            model(first)
+            got = [model(first), model(second), model(first)]
+            assert rep.failed is None and rep.captures == 1 and rep.replays == 3, (rep.failed, rep.captures, rep.replays)
+            _same_results(eager[0], got[0])
+            _same_results(eager[1], got[1])
+            _same_results(eager[0], got[2])
+            assert sum(len(r["instances"]) for r in eager[0] + eager[1]) > 0
+            next(m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)).running_var.mul_(1.25)
+            model(first)
+            assert len(rep.cache) == 0 and rep.captures == 1
+    finally:
+        infer_replay.ENABLED = prev
