@@ -586,3 +586,67 @@ def test_wino_levels_emulated(emu_lib):
 def test_wino_levels_gpu(hip_lib):
     _run_levels("cuda", [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)], 4, N=4, C=256, K=256)      # the benchmark's five levels
     _run_levels("cuda", [(64, 96), (32, 48), (16, 24), (8, 12), (4, 6)], 2, N=2, C=256, K=256)         # p6 of 4 x 6: 16-point transform
+
+
+def test_collected_weight_gradients_emulated(emu_lib):
+    """what solver/graphed.py does with a backward stage's weight-gradient closures, without the graphs: in side_mode("collect") the
+    backward of Winograd / direct / linear layers only QUEUES its filter- and bias-gradient launches; run afterwards inside
+    wino.batched_wgrads() (the Winograd-domain GEMMs leave in one launch, a filter shared by two layers receives both gradients in issue
+    order) they must leave in the gradient views exactly what the inline mode leaves"""
+    from omni3d_amd import functional as HF
+    from omni3d_amd.kernels import wino
+    g = torch.Generator().manual_seed(12)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)  # noqa: E731
+
+    def build():
+        ws = [cl(torch.randn(128, 128, 3, 3, generator=torch.Generator().manual_seed(s)) * 0.05).requires_grad_(True) for s in (1, 2)]
+        bs = [torch.randn(128, generator=torch.Generator().manual_seed(9)).requires_grad_(True)]
+        lw = (torch.randn(64, 128, generator=torch.Generator().manual_seed(7)) * 0.05).requires_grad_(True)
+        for p in ws + bs + [lw]:
+            p.grad = torch.zeros_like(p)              # the optimizer's bucket views: backward ADDS into them
+            p._omni_direct_grad = True
+        return ws, bs, lw
+
+    xs = [cl(torch.randn(2, 128, 32, 16, generator=g)), cl(torch.randn(2, 128, 32, 32, generator=g))]       # 256 / 512 tiles: Winograd layers
+    dys = [cl(torch.randn(2, 128, 32, 16, generator=g)), cl(torch.randn(2, 128, 32, 32, generator=g)), cl(torch.randn(2, 128, 32, 16, generator=g))]
+    dl = torch.randn(2 * 32 * 16, 64, generator=g)
+    assert all(wino.eligible(tuple(x.shape), (128, 128, 3, 3), 1, 1) for x in xs)
+
+    def run(ws, bs, lw):
+        xa, xb = xs[0].clone().requires_grad_(True), xs[1].clone().requires_grad_(True)
+        with HF.wino_weight_scope():
+            y0 = HF.conv2d(xa, ws[0], bs[0], 1, 1, relu=True)            # filter 0 + bias on two tensors (the RPN's shared conv)
+            y1 = HF.conv2d(xb, ws[0], bs[0], 1, 1, relu=True)
+            y2 = HF.conv2d(xa, ws[1], None, 1, 1)
+            y3 = HF.linear(y2.permute(0, 2, 3, 1).reshape(-1, 128), lw, None)
+        torch.autograd.backward([y0, y1, y2, y3], [dys[0], dys[1], dys[2], dl])
+        return xa.grad, xb.grad
+
+    prev = HF.side_mode()
+    try:
+        HF.side_mode("inline")
+        ref_p = build()
+        ref_dx = run(*ref_p)
+        HF.side_mode("collect")
+        got_p = build()
+        got_dx = run(*got_p)
+        fns, keep = HF.side_take()
+        assert len(fns) >= 6                              # 3 filter gradients + 2 bias gradients + the linear layer's
+        assert all(float(p.grad.abs().max()) == 0.0 for p in got_p[0] + got_p[1] + [got_p[2]]), "collect mode must not launch them"
+        seen = []
+        real = wino.gemm_batched_wgrad_multi
+        wino.gemm_batched_wgrad_multi = lambda probs: (seen.append(len(probs)), real(probs))[1]
+        try:
+            with wino.batched_wgrads():
+                for fn in fns:
+                    fn()
+        finally:
+            wino.gemm_batched_wgrad_multi = real
+        assert seen == [3], seen                          # the three Winograd layers' GEMMs left in ONE launch
+    finally:
+        HF.side_take()
+        HF.side_mode(prev)
+    for a, b in zip(ref_dx, got_dx):
+        assert torch.equal(a, b)
+    for a, b in zip(ref_p[0] + ref_p[1] + [ref_p[2]], got_p[0] + got_p[1] + [got_p[2]]):
+        assert torch.equal(a.grad, b.grad)
