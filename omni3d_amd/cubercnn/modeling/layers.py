@@ -126,6 +126,8 @@ class BatchNorm2d(nn.BatchNorm2d):
                                     self.momentum)
             if self.track_running_stats and self.num_batches_tracked is not None and not self.defer_counter:
                 self.num_batches_tracked += 1
+            if self.track_running_stats:
+                PARAM_EPOCH[0] += 1          # the kernel moved the running statistics through raw pointers: eval-mode caches are stale
             return y
         from ...kernels import bnpool
         # inference: (scale, shift) of the frozen statistics, built once per set of values (six ATen launches per layer and call
