@@ -29,7 +29,7 @@ class InferReplay:
         self.cache, self.counts = OrderedDict(), {}
         self.failed = None
         self.replays = self.captures = 0
-        self.digest, self._tensors = None, None
+        self.digest, self._tensors, self._side = None, None, None
 
     def run(self, batched_inputs, context):
         """-> (raw device outputs, image sizes) of a replayed pass, or None (the caller runs the eager pass).  `context`: a callable
@@ -104,7 +104,9 @@ class InferReplay:
         if self.graphs is False or dev.type != "cuda":
             self.captures += 1
             return {"graph": None, "raw": None, "slots": slots, "batch": sb, "packed": packed}
-        side = torch.cuda.Stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()        # (one for all captures: per-stream state elsewhere -- arrival counters -- is keyed by it)
+        side = self._side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad(), context():
             model._inference_device(sb, packed)               # per-shape caches (anchors, index vectors) exist before the capture
