@@ -117,6 +117,21 @@ int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const flo
                 float* running_mean, float* running_var, float* mean_rstd, float* scale_shift, double* ws,
                 int P, int C, float eps, float momentum, int relu, void* stream);
 
+/* Round 5: the same forward / backward with every variant behind explicit arguments (the entry points above and the *_partials /
+ * *_carry forms below are these with defaults).  partial [nullable] = [nblk][2][C] statistics rows already written by the producer of x
+ * (forward) / of dy (backward); NULL = a reduction pass runs first (ws as above).  ldy / lddy / ldc: pixel pitches in floats of y, dy
+ * and res_carry (0 or C = dense; a DLA Root child, dla.py:171, is written into / read from its channel slice of the concatenated
+ * tensor).  fuse_rows: with <= fuse_rows partial rows and C % 16 == 0 the finalize is folded into the apply launch -- every workgroup
+ * owns 16 channels of a pixel chunk and sums the rows of those channels itself in the finalize kernel's order: same bits, one
+ * dependent launch less (0 = always the separate finalize launch). */
+int omni_bn_fwd_algo(const float* x, const float* partial, int nblk, const float* gamma, const float* beta, const float* residual,
+                     float* y, long long ldy, float* running_mean, float* running_var, float* mean_rstd, float* scale_shift,
+                     double* ws, int P, int C, float eps, float momentum, int relu, int fuse_rows, void* stream);
+int omni_bn_bwd_algo(const float* x, const float* dy, long long lddy, const float* y, const float* gamma, const float* mean_rstd,
+                     const float* partial, int nblk, float* dx, float* dres, const float* res_carry, long long ldc, float* dgamma,
+                     float* dbeta, double* ws, float* coef, int P, int C, int relu, int accumulate_param_grads, int fuse_rows,
+                     void* stream);
+
 /* eval-mode / frozen BatchNorm (solver/build.py:71-76 freeze_bn): y = relu?(x*scale+shift(+res)). */
 int omni_bn_apply(const float* x, const float* scale_shift, const float* residual, float* y, int P, int C,
                   int relu, void* stream);

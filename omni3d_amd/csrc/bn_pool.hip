@@ -194,22 +194,24 @@ __global__ void __launch_bounds__(256) bn_finalize_fwd_kernel(const float* __res
 }
 
 // y = relu?( x * scale + shift (+ residual) )
+// (ldy: pixel pitch of y in floats, 0 = dense; a Root child is written straight into its channel slice of the concatenated tensor)
 __device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const float* __restrict__ scale_shift,
                                               const float* __restrict__ residual, float* __restrict__ y,
-                                              long total4, int C, int relu) {
+                                              long total4, int C, int relu, long ldy = 0) {
     const int C4 = C >> 2;
+    const bool dense = ldy == 0 || ldy == C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % C4);
         float4 v = ld4(x + 4 * i) * ld4(scale_shift + 4 * col) + ld4(scale_shift + C + 4 * col);
         if (residual != nullptr) v = v + ld4(residual + 4 * i);
         if (relu) v = relu4(v);
-        st4(y + 4 * i, v);
+        st4(dense ? y + 4 * i : y + (i / C4) * ldy + 4 * col, v);
     }
 }
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale_shift,
                                                        const float* __restrict__ residual, float* __restrict__ y,
-                                                       long total4, int C, int relu) {
-    bn_apply_body(x, scale_shift, residual, y, total4, C, relu);
+                                                       long total4, int C, int relu, long ldy) {
+    bn_apply_body(x, scale_shift, residual, y, total4, C, relu, ldy);
 }
 
 // backward finalize: dgamma, dbeta out (or accumulated); coefficients for the apply pass:
@@ -261,6 +263,178 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dres, long total4, int C, int relu,
                                                            const float* __restrict__ res_carry, long ldc, long lddy) {
     bn_bwd_apply_body(x, dy, y, mean_rstd, coef, dx, dres, total4, C, relu, res_carry, ldc, lddy);
+}
+
+// ---- round 5: the finalize folded into the apply pass (channel-group ownership) ---------------------------------------------
+// The finalize launches were pure latency on the critical path (39 + 37 per DLA-34 step, a ~5 us slot each for a few hundred flops).
+// Here a workgroup of the APPLY pass owns GC = 16 channels (one 64-byte run per pixel) of a pixel chunk and first sums the partial
+// rows of exactly those channels itself: nblk x 128 bytes, every thread one or a few independent float4 loads -- one memory
+// round trip instead of a dependent launch.  Nothing meets across workgroups, so there is no counter, no fence and no order to
+// depend on; per channel the additions are colsum_fin's (same 4-row grouping, same tree over the 64 row groups), i.e. the
+// coefficients are BIT-IDENTICAL to the three-launch path.  The workgroups of pixel chunk 0 also write mean / rstd / scale /
+// shift / running statistics (forward) or dgamma / dbeta (backward).  Work items are walked in XCD-contiguous order: the
+// channel groups of one pixel chunk run on the same XCD, so every 128-byte line is used whole inside one L2.
+constexpr int GQ = 4, GC = 4 * GQ;
+static_assert(256 / GQ == FIN_RG, "colsum_fin_quads walks the partial rows in colsum_fin's 64 row groups");
+__device__ __forceinline__ void acc4(double (&a)[4], float4 v0, float4 v1, float4 v2, float4 v3) {
+    a[0] += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+    a[1] += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    a[2] += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+    a[3] += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+}
+// totals of the GC channels starting at c0 over the nblk partial rows; thread t < GC returns (s0, s1) of channel c0 + t
+__device__ __forceinline__ void colsum_fin_quads(const float* __restrict__ partial, int nblk, int C, int c0, double& s0, double& s1) {
+    __shared__ double sm0[256][4], sm1[256][4];
+    const int t = threadIdx.x, q = t % GQ, rg = t / GQ;
+    const float* base = partial + c0 + 4 * q;
+    const long st = (long)FIN_RG * 2 * C;
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    int blk = rg;
+#pragma unroll 2
+    for (; blk + 3 * FIN_RG < nblk; blk += 4 * FIN_RG) {
+        const float* p = base + (long)blk * 2 * C;
+        const float4 a0 = ld4(p), a1 = ld4(p + st), a2 = ld4(p + 2 * st), a3 = ld4(p + 3 * st);
+        const float4 b0 = ld4(p + C), b1 = ld4(p + st + C), b2 = ld4(p + 2 * st + C), b3 = ld4(p + 3 * st + C);
+        acc4(a, a0, a1, a2, a3);
+        acc4(b, b0, b1, b2, b3);
+    }
+    for (; blk < nblk; blk += FIN_RG) {
+        const float4 av = ld4(base + (long)blk * 2 * C), bv = ld4(base + (long)blk * 2 * C + C);
+        a[0] += (double)av.x; a[1] += (double)av.y; a[2] += (double)av.z; a[3] += (double)av.w;
+        b[0] += (double)bv.x; b[1] += (double)bv.y; b[2] += (double)bv.z; b[3] += (double)bv.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sm0[t][k] = a[k]; sm1[t][k] = b[k]; }
+    __syncthreads();
+    for (int half = FIN_RG / 2; half >= 1; half >>= 1) {
+        if (rg < half) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sm0[t][k] += sm0[t + half * GQ][k]; sm1[t][k] += sm1[t + half * GQ][k]; }
+        }
+        __syncthreads();
+    }
+    s0 = sm0[(t >> 2) & (GQ - 1)][t & 3];
+    s1 = sm1[(t >> 2) & (GQ - 1)][t & 3];
+}
+// work item of this workgroup: (channel group, pixel chunk), XCD-contiguous; false = nothing to do (grid rounded up to 8)
+__device__ __forceinline__ bool fin_item(int CG, int PC, int& cg, int& pc) {
+    const int nitems = CG * PC, per = (nitems + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (item >= nitems || (int)(blockIdx.x >> 3) >= per) return false;
+    cg = item % CG;
+    pc = item / CG;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) bn_fin_apply_kernel(const float* __restrict__ x, const float* __restrict__ partial, int nblk, int P,
+                                                           int C, float eps, float momentum, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ residual,
+                                                           float* __restrict__ y, long ldy, float* __restrict__ mean_rstd,
+                                                           float* __restrict__ scale_shift, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, int relu, int CG, int PC, int chunk) {
+    int cg, pc;
+    if (!fin_item(CG, PC, cg, pc)) return;
+    const int c0 = cg * GC, t = threadIdx.x;
+    __shared__ float s_ss[2 * GC];
+    double sx, sxx;
+    colsum_fin_quads(partial, nblk, C, c0, sx, sxx);
+    if (t < GC) {       // (the arithmetic of bn_finalize_fwd_group)
+        const int c = c0 + t;
+        const double mean = sx / P;
+        double var = sxx / P - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * rstd;
+        const float sh = beta[c] - (float)mean * sc;
+        s_ss[t] = sc;
+        s_ss[GC + t] = sh;
+        if (pc == 0) {
+            mean_rstd[c] = (float)mean;
+            mean_rstd[C + c] = rstd;
+            scale_shift[c] = sc;
+            scale_shift[C + c] = sh;
+            if (running_mean != nullptr) {
+                const double unbiased = P > 1 ? var * P / (P - 1) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+        }
+    }
+    __syncthreads();
+    const int col = t & (GQ - 1), prow = t >> 2;
+    const float4 sc = ld4(s_ss + 4 * col), sh = ld4(s_ss + GC + 4 * col);
+    const long pend = min((long)P, (long)(pc + 1) * chunk), coff = c0 + 4 * col;
+    long p = (long)pc * chunk + prow;
+    for (; p + 192 < pend; p += 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld4(x + (p + 64 * u) * C + coff) * sc + sh;
+        if (residual != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = v[u] + ld4(residual + (p + 64 * u) * C + coff);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) st4(y + (p + 64 * u) * ldy + coff, relu ? relu4(v[u]) : v[u]);
+    }
+    for (; p < pend; p += 64) {
+        float4 v = ld4(x + p * C + coff) * sc + sh;
+        if (residual != nullptr) v = v + ld4(residual + p * C + coff);
+        st4(y + p * ldy + coff, relu ? relu4(v) : v);
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_fin_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, long lddy,
+                                                               const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ partial,
+                                                               int nblk, int P, int C, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int accumulate, float* __restrict__ dx,
+                                                               float* __restrict__ dres, const float* __restrict__ res_carry, long ldc,
+                                                               int relu, int CG, int PC, int chunk) {
+    int cg, pc;
+    if (!fin_item(CG, PC, cg, pc)) return;
+    const int c0 = cg * GC, t = threadIdx.x;
+    __shared__ float s_cf[3 * GC];
+    double db, dg;
+    colsum_fin_quads(partial, nblk, C, c0, db, dg);
+    if (t < GC) {       // (the arithmetic of bn_finalize_bwd_group)
+        const int c = c0 + t;
+        if (pc == 0) {
+            dbeta[c] = accumulate ? dbeta[c] + (float)db : (float)db;
+            dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
+        }
+        s_cf[t] = gamma[c] * mean_rstd[C + c];
+        s_cf[GC + t] = (float)(db / P);
+        s_cf[2 * GC + t] = (float)(dg / P);
+    }
+    __syncthreads();
+    const int col = t & (GQ - 1), prow = t >> 2;
+    const long coff = c0 + 4 * col;
+    const float4 k0 = ld4(s_cf + 4 * col), k1 = ld4(s_cf + GC + 4 * col), k2 = ld4(s_cf + 2 * GC + 4 * col);
+    const float4 mu = ld4(mean_rstd + coff), rs = ld4(mean_rstd + C + coff);
+    float4 msc = f4(0.f), msh = f4(0.f);
+    if (relu == 2) { msc = ld4(y + coff); msh = ld4(y + C + coff); }       // y = (scale, shift): see bn_reduce_tile
+    const long pend = min((long)P, (long)(pc + 1) * chunk);
+    for (long p = (long)pc * chunk + prow; p < pend; p += 128) {
+        // two pixels per trip: up to 8 independent loads in flight per lane
+        const long p1 = p + 64;
+        const bool two = p1 < pend;
+        float4 g0 = ld4(dy + p * lddy + coff), g1 = two ? ld4(dy + p1 * lddy + coff) : f4(0.f);
+        const float4 x0 = ld4(x + p * C + coff), x1 = two ? ld4(x + p1 * C + coff) : f4(0.f);
+        if (relu == 1) {
+            g0 = mask4(g0, ld4(y + p * C + coff));
+            if (two) g1 = mask4(g1, ld4(y + p1 * C + coff));
+        } else if (relu == 2) {
+            g0 = mask4(g0, x0 * msc + msh);
+            g1 = mask4(g1, x1 * msc + msh);
+        }
+        if (dres != nullptr) {
+            st4(dres + p * C + coff, res_carry != nullptr ? g0 + ld4(res_carry + p * ldc + coff) : g0);
+            if (two) st4(dres + p1 * C + coff, res_carry != nullptr ? g1 + ld4(res_carry + p1 * ldc + coff) : g1);
+        }
+        const float4 h0 = (x0 - mu) * rs, h1 = (x1 - mu) * rs;
+        st4(dx + p * C + coff, k0 * (g0 - k1 - h0 * k2));
+        if (two) st4(dx + p1 * C + coff, k0 * (g1 - k1 - h1 * k2));
+    }
 }
 
 #ifndef OMNI_HIPEMU
@@ -513,23 +687,62 @@ inline int red_grid(int P, int C) {
 
 extern "C" {
 
+// pixel chunks of the fused finalize + apply launches: ~2 workgroups per CU over (channel groups x chunks), chunks of >= 64 pixels
+// that are multiples of 64 (one pixel per 4 lanes and trip)
+static inline void fin_geometry(int P, int C, int& CG, int& PC, int& chunk, int& grid) {
+    CG = C / GC;
+    long pc = 512 / CG;
+    const long maxpc = ((long)P + 63) / 64;
+    if (pc > maxpc) pc = maxpc;
+    if (pc < 1) pc = 1;
+    chunk = (int)((((long)P + pc - 1) / pc + 63) / 64 * 64);
+    PC = (int)(((long)P + chunk - 1) / chunk);
+    grid = (CG * PC + 7) / 8 * 8;
+}
+static inline bool fin_fusable(int C, int nblk, int fuse_rows) { return fuse_rows > 0 && nblk <= fuse_rows && (C % GC) == 0; }
+static const int BN_FUSE_ROWS_DEFAULT = 512;
+
 // Training-mode BatchNorm forward on NHWC x (P = N*H*W pixels, C channels, C % 4 == 0, C <= 4096).
-// ws: >= 2*C*258 doubles of scratch (sums + per-block partials).  mean_rstd (2C), scale_shift (2C) kept for backward.
+// partial [nullable]: [nblk][2][C] per-block sums / sums of squares already made by the PRODUCER of x (conv / Winograd / stem
+// epilogues); NULL: a statistics pass over x runs first (ws: >= 2*C*258 doubles of scratch).  ldy: pixel pitch of y in floats
+// (>= C, % 4 == 0; y 16-byte aligned).  mean_rstd (2C), scale_shift (2C) are kept for backward.
+// fuse_rows: the finalize is folded into the apply launch when there are <= fuse_rows partial rows and C % 16 == 0 (0 = never:
+// the round 1-4 finalize launch); both forms give the same bits.
+int omni_bn_fwd_algo(const float* x, const float* partial, int nblk, const float* gamma, const float* beta, const float* residual,
+                     float* y, long long ldy, float* running_mean, float* running_var, float* mean_rstd, float* scale_shift, double* ws,
+                     int P, int C, float eps, float momentum, int relu, int fuse_rows, void* stream) {
+    if (P <= 0 || C <= 0 || (C & 3) || C > 4096 || (partial != nullptr && nblk <= 0) || (partial == nullptr && ws == nullptr))
+        return OMNI_ERR_ARG;
+    if (ldy == 0) ldy = C;
+    if (ldy < C || (ldy & 3) || (((unsigned long long)y) & 15)) return OMNI_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (partial == nullptr) {
+        nblk = red_grid(P, C);
+        float* mine = reinterpret_cast<float*>(ws + 2 * C);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, x, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(mine), 0L);
+        partial = mine;
+    }
+    if (fin_fusable(C, nblk, fuse_rows)) {
+        int CG, PC, chunk, grid;
+        fin_geometry(P, C, CG, PC, chunk, grid);
+        hipLaunchKernelGGL(bn_fin_apply_kernel, dim3(grid), dim3(256), 0, st, x, partial, nblk, P, C, eps, momentum, gamma, beta, residual,
+                           y, (long)ldy, mean_rstd, scale_shift, running_mean, running_var, relu, CG, PC, chunk);
+        return omni_launch_status();
+    }
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, partial, nblk, P, C, eps, momentum, gamma,
+                       beta, mean_rstd, scale_shift, running_mean, running_var);
+    const long total4 = (long)P * (C >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, (const float*)scale_shift, residual, y, total4, C, relu,
+                       (long)ldy);
+    return omni_launch_status();
+}
+
 int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                 float* running_mean, float* running_var, float* mean_rstd, float* scale_shift, double* ws, int P, int C,
                 float eps, float momentum, int relu, void* stream) {
-    if (P <= 0 || C <= 0 || (C & 3) || C > 4096) return OMNI_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int nblk = red_grid(P, C);
-    float* partial = reinterpret_cast<float*>(ws + 2 * C);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<0>), dim3(nblk), dim3(256), 0, st, x, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, P, C, 0, reinterpret_cast<double*>(partial), 0L);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, (const float*)partial, nblk, P, C, eps,
-                       momentum, gamma, beta, mean_rstd, scale_shift, running_mean, running_var);
-    const long total4 = (long)P * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, (const float*)scale_shift, residual, y,
-                       total4, C, relu);
-    return omni_launch_status();
+    return omni_bn_fwd_algo(x, nullptr, 0, gamma, beta, residual, y, C, running_mean, running_var, mean_rstd, scale_shift, ws, P, C, eps,
+                            momentum, relu, BN_FUSE_ROWS_DEFAULT, stream);
 }
 
 // The same forward with the statistics pass already done by the PRODUCER of x (conv / Winograd / stem epilogues):
@@ -537,13 +750,9 @@ int omni_bn_fwd(const float* x, const float* gamma, const float* beta, const flo
 int omni_bn_fwd_partials(const float* x, const float* partial, int nblk, const float* gamma, const float* beta, const float* residual,
                          float* y, float* running_mean, float* running_var, float* mean_rstd, float* scale_shift, int P, int C,
                          float eps, float momentum, int relu, void* stream) {
-    if (P <= 0 || C <= 0 || (C & 3) || C > 4096 || nblk <= 0) return OMNI_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, partial, nblk, P, C, eps, momentum, gamma, beta,
-                       mean_rstd, scale_shift, running_mean, running_var);
-    const long total4 = (long)P * (C >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, (const float*)scale_shift, residual, y, total4, C, relu);
-    return omni_launch_status();
+    if (partial == nullptr) return OMNI_ERR_ARG;
+    return omni_bn_fwd_algo(x, partial, nblk, gamma, beta, residual, y, C, running_mean, running_var, mean_rstd, scale_shift, nullptr, P, C,
+                            eps, momentum, relu, BN_FUSE_ROWS_DEFAULT, stream);
 }
 
 // The finalize half of omni_bn_fwd_partials alone: batch statistics -> mean_rstd (2C), scale_shift (2C), running statistics updated.
@@ -563,7 +772,7 @@ int omni_bn_apply(const float* x, const float* scale_shift, const float* residua
     if (P <= 0 || C <= 0 || (C & 3)) return OMNI_ERR_ARG;
     const long total4 = (long)P * (C >> 2);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, scale_shift, residual,
-                       y, total4, C, relu);
+                       y, total4, C, relu, 0L);
     return omni_launch_status();
 }
 
@@ -573,25 +782,49 @@ static int bad_carry(const float* carry, long long ldc, int C) {
     return carry != nullptr && (ldc < C || (ldc & 3) || (((unsigned long long)carry) & 15));
 }
 
-// omni_bn_bwd with gradient fan-in on the residual: dres = (masked dy) + res_carry, res_carry [nullable] an NHWC tensor of the
-// same extent with pixel pitch ldc floats (what the other consumers of the residual tensor already contributed to its gradient);
-// dy with pixel pitch lddy floats (a channel slice of the DLA Root's concatenated gradient is read where it lies).
-int omni_bn_bwd_carry(const float* x, const float* dy, long long lddy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
-                      float* dres, const float* res_carry, long long ldc, float* dgamma, float* dbeta, double* ws, float* coef, int P,
-                      int C, int relu, int accumulate_param_grads, void* stream) {
+// Backward of omni_bn_fwd(_algo) with gradient fan-in on the residual: dres = (masked dy) + res_carry, res_carry [nullable] an NHWC
+// tensor of the same extent with pixel pitch ldc floats (what the other consumers of the residual tensor already contributed to its
+// gradient); dy with pixel pitch lddy floats (a channel slice of the DLA Root's concatenated gradient is read where it lies).
+// partial [nullable]: [nblk][2][C] reductions (sum dz, sum dz * xhat) already made by the kernel that produced dy
+// (omni_wino_out_bn_bwd_stats; dense dy, no carry); NULL: the reduction pass runs first (ws: >= 2*C*258 doubles).
+// fuse_rows: as omni_bn_fwd_algo (coef, 3C floats of scratch, is only touched by the unfused form).
+int omni_bn_bwd_algo(const float* x, const float* dy, long long lddy, const float* y, const float* gamma, const float* mean_rstd,
+                     const float* partial, int nblk, float* dx, float* dres, const float* res_carry, long long ldc, float* dgamma,
+                     float* dbeta, double* ws, float* coef, int P, int C, int relu, int accumulate_param_grads, int fuse_rows,
+                     void* stream) {
     if (P <= 0 || C <= 0 || (C & 3) || C > 4096 || relu < 0 || relu > 2 || (relu && y == nullptr)) return OMNI_ERR_ARG;
+    if (lddy == 0) lddy = C;
     if (bad_carry(res_carry, ldc, C) || (res_carry != nullptr && dres == nullptr) || bad_carry(dy, lddy, C)) return OMNI_ERR_ARG;
+    if ((partial != nullptr && (nblk <= 0 || res_carry != nullptr || lddy != C)) || (partial == nullptr && ws == nullptr)) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = red_grid(P, C);
-    float* partial = reinterpret_cast<float*>(ws + 2 * C);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<1>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean_rstd, P, C, relu,
-                       reinterpret_cast<double*>(partial), (long)lddy);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, (const float*)partial, nblk, P, C, gamma,
-                       mean_rstd, dgamma, dbeta, coef, accumulate_param_grads);
+    if (partial == nullptr) {
+        nblk = red_grid(P, C);
+        float* mine = reinterpret_cast<float*>(ws + 2 * C);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_reduce_kernel<1>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean_rstd, P, C, relu,
+                           reinterpret_cast<double*>(mine), (long)lddy);
+        partial = mine;
+    }
+    if (fin_fusable(C, nblk, fuse_rows)) {
+        int CG, PC, chunk, grid;
+        fin_geometry(P, C, CG, PC, chunk, grid);
+        hipLaunchKernelGGL(bn_fin_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, x, dy, (long)lddy, y, mean_rstd, gamma, partial, nblk, P, C,
+                           dgamma, dbeta, accumulate_param_grads, dx, dres, res_carry, (long)ldc, relu, CG, PC, chunk);
+        return omni_launch_status();
+    }
+    if (coef == nullptr) return OMNI_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, partial, nblk, P, C, gamma, mean_rstd,
+                       dgamma, dbeta, coef, accumulate_param_grads);
     const long total4 = (long)P * (C >> 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, dy, y, mean_rstd,
                        (const float*)coef, dx, dres, total4, C, relu, res_carry, (long)ldc, (long)lddy);
     return omni_launch_status();
+}
+
+int omni_bn_bwd_carry(const float* x, const float* dy, long long lddy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
+                      float* dres, const float* res_carry, long long ldc, float* dgamma, float* dbeta, double* ws, float* coef, int P,
+                      int C, int relu, int accumulate_param_grads, void* stream) {
+    return omni_bn_bwd_algo(x, dy, lddy, y, gamma, mean_rstd, nullptr, 0, dx, dres, res_carry, ldc, dgamma, dbeta, ws, coef, P, C, relu,
+                            accumulate_param_grads, BN_FUSE_ROWS_DEFAULT, stream);
 }
 
 int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd, float* dx,
@@ -605,14 +838,9 @@ int omni_bn_bwd(const float* x, const float* dy, const float* y, const float* ga
 int omni_bn_bwd_partials(const float* x, const float* dy, const float* y, const float* gamma, const float* mean_rstd,
                          const float* partial, int nblk, float* dx, float* dres, float* dgamma, float* dbeta, float* coef, int P,
                          int C, int relu, int accumulate_param_grads, void* stream) {
-    if (P <= 0 || C <= 0 || (C & 3) || C > 4096 || nblk <= 0 || relu < 0 || relu > 2 || (relu && y == nullptr)) return OMNI_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, st, partial, nblk, P, C, gamma, mean_rstd,
-                       dgamma, dbeta, coef, accumulate_param_grads);
-    const long total4 = (long)P * (C >> 2);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, x, dy, y, mean_rstd, (const float*)coef, dx, dres,
-                       total4, C, relu, (const float*)nullptr, 0L, 0L);
-    return omni_launch_status();
+    if (partial == nullptr) return OMNI_ERR_ARG;
+    return omni_bn_bwd_algo(x, dy, C, y, gamma, mean_rstd, partial, nblk, dx, dres, nullptr, 0, dgamma, dbeta, nullptr, coef, P, C, relu,
+                            accumulate_param_grads, BN_FUSE_ROWS_DEFAULT, stream);
 }
 
 int omni_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {

@@ -117,3 +117,4 @@ __device__ __forceinline__ void omni_barrier_lds() {
 #define OMNI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)                            /* nothing is scheduled across this point */
 #define OMNI_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)      /* 0x8 MFMA, 0x20 VMEM read, 0x100 DS read */
 #define OMNI_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+

@@ -1,5 +1,7 @@
 """Launchers for csrc/bn_pool.hip.  All tensors are logical NCHW in channels_last memory
 (physically NHWC), fp32, C % 4 == 0."""
+import os
+
 import torch
 
 from .. import lib as _lib
@@ -10,27 +12,44 @@ def _like_cl(shape_nhwc, ref):
     return torch.empty(shape_nhwc, dtype=torch.float32, device=ref.device)
 
 
-def bn_fwd(x, gamma, beta, running_mean, running_var, residual=None, relu=False, eps=1e-5, momentum=0.1, partials=None):
+# partial rows up to which the finalize is folded into the apply launch (omni_bn_fwd_algo / omni_bn_bwd_algo); 0 = the separate finalize
+# launch of rounds 1-4.  Read once: an A/B knob for bench runs, the tests and the driver leave it unset.
+FUSE_ROWS = int(os.environ.get("OMNI_BN_FUSE_ROWS", "512"))
+
+
+def _pitched_out(out, N, H, W, C):
+    """out: logical (N, C, H, W) view with channel stride 1 whose pixels are `ldy` floats apart (a channel slice of a wider NHWC tensor)
+    -> (tensor to return, address, ldy)"""
+    assert tuple(out.shape) == (N, C, H, W) and out.dtype == torch.float32 and out.stride(1) == 1, (out.shape, out.stride())
+    ldy = out.stride(3)
+    assert out.stride(2) == W * ldy and out.stride(0) == H * W * ldy and ldy >= C and ldy % 4 == 0 and out.data_ptr() % 16 == 0
+    return out, out.data_ptr(), ldy
+
+
+def bn_fwd(x, gamma, beta, running_mean, running_var, residual=None, relu=False, eps=1e-5, momentum=0.1, partials=None, out=None):
     """-> (y CL, mean_rstd (2C), scale_shift (2C)); running stats updated in place.  partials (nblk, 2C): per-block sums / sums
-    of squares of x already produced by the kernel that wrote x (conv / Winograd / stem epilogue): skips the statistics pass."""
+    of squares of x already produced by the kernel that wrote x (conv / Winograd / stem epilogue): skips the statistics pass.
+    out: where y goes -- a channel slice of a wider NHWC tensor (the DLA Root's concatenated input) -- instead of a new tensor."""
     xv = _nhwc(x)
     rv = _nhwc(residual) if residual is not None else None
     N, H, W, C = xv.shape
     L = _lib.check_device(xv, rv, gamma, beta, running_mean, running_var)
-    y = _like_cl((N, H, W, C), x)
+    if out is not None:
+        y, yaddr, ldy = _pitched_out(out, N, H, W, C)
+    else:
+        yv = _like_cl((N, H, W, C), x)
+        y, yaddr, ldy = yv.permute(0, 3, 1, 2), _lib.ptr(yv), C
     mean_rstd = torch.empty(2 * C, dtype=torch.float32, device=x.device)
     scale_shift = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    ws = None
     if partials is not None:
         assert partials.is_contiguous() and partials.shape[1] == 2 * C
-        L.call("omni_bn_fwd_partials", _lib.ptr(xv), _lib.ptr(partials), partials.shape[0], _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(rv),
-               _lib.ptr(y), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), N * H * W, C,
-               float(eps), float(momentum), int(relu), _lib.stream_of(x))
-        return y.permute(0, 3, 1, 2), mean_rstd, scale_shift
-    ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
-    L.call("omni_bn_fwd", _lib.ptr(xv), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(rv), _lib.ptr(y),
-           _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(mean_rstd), _lib.ptr(scale_shift), _lib.ptr(ws),
-           N * H * W, C, float(eps), float(momentum), int(relu), _lib.stream_of(x))
-    return y.permute(0, 3, 1, 2), mean_rstd, scale_shift
+    else:
+        ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
+    L.call("omni_bn_fwd_algo", _lib.ptr(xv), _lib.ptr(partials), partials.shape[0] if partials is not None else 0, _lib.ptr(gamma),
+           _lib.ptr(beta), _lib.ptr(rv), yaddr, ldy, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(mean_rstd),
+           _lib.ptr(scale_shift), _lib.ptr(ws), N * H * W, C, float(eps), float(momentum), int(relu), FUSE_ROWS, _lib.stream_of(x))
+    return y, mean_rstd, scale_shift
 
 
 def bn_finalize_fwd(x, gamma, beta, running_mean, running_var, partials, eps=1e-5, momentum=0.1):
@@ -85,26 +104,19 @@ def bn_bwd(x, dy, y, gamma, mean_rstd, relu=False, want_dres=False, accum_into=N
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     coef = torch.empty(3 * C, dtype=torch.float32, device=x.device)
+    ws = None
     if partials is not None:
         assert partials.is_contiguous() and partials.shape[1] == 2 * C and res_carry is None and not dy_pitched
-        L.call("omni_bn_bwd_partials", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(partials),
-               partials.shape[0], _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(coef), N * H * W, C, mode,
-               int(accum_into is not None), _lib.stream_of(x))
-        if accum_into is not None:
-            dgamma = dbeta = None
-        return dx.permute(0, 3, 1, 2), (dres.permute(0, 3, 1, 2) if want_dres else None), dgamma, dbeta
-    ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
+    else:
+        ws = torch.empty(2 * C * 258, dtype=torch.float64, device=x.device)
     if res_carry is not None or dy_pitched:
         assert tuple(dy.shape) == tuple(x.shape) and dy.stride(1) == 1
         if res_carry is not None:
             assert want_dres and tuple(res_carry.shape) == tuple(x.shape)
-        L.call("omni_bn_bwd_carry", _lib.ptr(xv), dy.data_ptr(), dy.stride(3), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd),
-               _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(res_carry), res_carry.stride(3) if res_carry is not None else 0, _lib.ptr(dgamma),
-               _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, mode, int(accum_into is not None), _lib.stream_of(x))
-    else:
-        L.call("omni_bn_bwd", _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(yv), _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(dx),
-               _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, mode,
-               int(accum_into is not None), _lib.stream_of(x))
+    L.call("omni_bn_bwd_algo", _lib.ptr(xv), dy.data_ptr() if dy_pitched else _lib.ptr(dyv), dy.stride(3) if dy_pitched else C, _lib.ptr(yv),
+           _lib.ptr(gamma), _lib.ptr(mean_rstd), _lib.ptr(partials), partials.shape[0] if partials is not None else 0, _lib.ptr(dx),
+           _lib.ptr(dres), _lib.ptr(res_carry), res_carry.stride(3) if res_carry is not None else 0, _lib.ptr(dgamma), _lib.ptr(dbeta),
+           _lib.ptr(ws), _lib.ptr(coef), N * H * W, C, mode, int(accum_into is not None), FUSE_ROWS, _lib.stream_of(x))
     if accum_into is not None:
         dgamma = dbeta = None
     return dx.permute(0, 3, 1, 2), (dres.permute(0, 3, 1, 2) if want_dres else None), dgamma, dbeta

@@ -193,6 +193,7 @@ _FC_WGRAD_ENGINE_MIN_ROWS = int(os.environ.get("OMNI_FC_WGRAD_ENGINE_MIN_ROWS", 
 # persistent workgroups of the fc1-class weight gradient (0 = one per CU): it runs on the weight-gradient stream BESIDE the critical path,
 # and a launch on fewer workgroups leaves CUs to the main stream for its whole (longer) duration (A/B knob)
 _FC_WGRAD_WGS = int(os.environ.get("OMNI_FC_WGRAD_WGS", "0"))
+_FC_WGRAD_SPLITS = int(os.environ.get("OMNI_FC_WGRAD_SPLITS", "-1"))      # -1 = balanced (gemm.BALANCED) | 1 = whole tiles only (A/B knob)
 
 
 def linear_dgrad(dy, w):
@@ -222,7 +223,7 @@ def linear_wgrad(x, dy, accum_into=None):
             # fc1-class weight gradient dW += dY^T X on the LDS-DMA engine's TN form with the balanced work split: 784 tiles of
             # 128 x 128 are 3.06 rounds of 256 workgroups -- the plain launch pays 4 (csrc/gemm_engine.hip, BAL)
             from . import gemm as _gemm
-            _gemm.gemm(dy, x, _gemm.TN, out=accum_into, accumulate=True, tile=2, splits=_gemm.BALANCED, workgroups=_FC_WGRAD_WGS)
+            _gemm.gemm(dy, x, _gemm.TN, out=accum_into, accumulate=True, tile=2, splits=_FC_WGRAD_SPLITS, workgroups=_FC_WGRAD_WGS)
             return None
         _wgrad_launch(L, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(accum_into), M, 1, 1, C, K, 1, 1, 1, 0, C, K, 1, 0, x)
         return None

@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libomni3d_hip.so")
+# OMNI_LIB_SUFFIX: an A/B build of the same sources next to the default library (csrc/Makefile SUFFIX=...); unset everywhere but in bench A/B runs
+LIB_PATH = os.path.join(_HERE, "libomni3d_hip" + os.environ.get("OMNI_LIB_SUFFIX", "") + ".so")
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
 _CODES = {"p": _P, "i": _I, "l": _L, "f": _F}

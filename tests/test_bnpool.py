@@ -272,3 +272,70 @@ def test_eval_coefficients_follow_the_running_statistics_emulated(emu_lib):
     with torch.no_grad():
         bn.weight.mul_(2.0); ref.weight.mul_(2.0)                                        # a write torch sees
     assert (bn(x) - ref(x)).abs().max() <= 1e-5
+
+
+def _fused_vs_three_launch(dev, N, C, H, W, relu, with_res, pitched):
+    """round 5: the finalize folded into the apply launch (omni_bn_fwd_algo / omni_bn_bwd_algo, fuse_rows > 0) against the separate
+    finalize launch (fuse_rows = 0) -- same summation order per channel, so every output must be the same BITS; `pitched`: y is written
+    into / dy is read from a channel slice of a wider NHWC tensor (the DLA Root's concatenated input, dla.py:171)"""
+    from omni3d_amd.kernels import bnpool
+    g = torch.Generator().manual_seed(N * 1000 + C + H)
+    x = _cl(torch.randn(N, C, H, W, generator=g) * 2 + 0.7).to(dev)
+    res = _cl(torch.randn(N, C, H, W, generator=g)).to(dev) if with_res else None
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    dy = _cl(torch.randn(N, C, H, W, generator=g)).to(dev)
+    carry = _cl(torch.randn(N, C, H, W, generator=g)).to(dev) if with_res else None
+    wide = C + 32
+    outs = []
+    for rows in (0, 4096):
+        bnpool.FUSE_ROWS = rows
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        out = None
+        if pitched:
+            big = torch.full((N, H, W, wide), 7.0, device=dev)
+            out = big.permute(0, 3, 1, 2)[:, 16:16 + C]
+        y, mean_rstd, scale_shift = bnpool.bn_fwd(x, gamma, beta, rm, rv, residual=res, relu=relu, out=out)
+        if pitched:
+            assert y.data_ptr() == out.data_ptr()
+            assert (big[..., :16] == 7.0).all() and (big[..., 16 + C:] == 7.0).all()
+            dyk = torch.zeros((N, H, W, wide), device=dev)
+            dyk[..., 8:8 + C] = dy.permute(0, 2, 3, 1)
+            dyk = dyk.permute(0, 3, 1, 2)[:, 8:8 + C]
+        else:
+            dyk = dy
+        remask = relu and not with_res
+        dx, dres, dgamma, dbeta = bnpool.bn_bwd(x, dyk, None if remask else (y.contiguous(memory_format=torch.channels_last) if relu else None),
+                                                gamma, mean_rstd, relu=relu, want_dres=with_res, scale_shift=scale_shift if remask else None,
+                                                res_carry=carry)
+        outs.append([y.clone(), mean_rstd, scale_shift, rm, rv, dx, dgamma, dbeta] + ([dres] if with_res else []))
+    bnpool.FUSE_ROWS = 512
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # and the values themselves against torch
+    xr = x.cpu().clone().requires_grad_(True)
+    rr = res.cpu().clone().requires_grad_(True) if with_res else None
+    z = F.batch_norm(xr, torch.zeros(C), torch.ones(C), gamma.cpu(), beta.cpu(), True, 0.1, 1e-5)
+    z = z + rr if with_res else z
+    yr = F.relu(z) if relu else z
+    yr.backward(dy.cpu())
+    assert (outs[1][0].cpu() - yr.detach()).abs().max() < 2e-5
+    assert (outs[1][5].cpu() - xr.grad).abs().max() < 5e-5
+    if with_res:
+        assert (outs[1][8].cpu() - (rr.grad + carry.cpu())).abs().max() < 1e-6
+
+
+FUSED_CASES = [(2, 16, 5, 7, True, False, False), (1, 64, 4, 4, True, True, True), (2, 32, 9, 9, False, False, True),
+               (1, 16, 70, 66, True, False, False),     # several pixel chunks with a ragged tail, > 256 partial rows in backward
+               (2, 48, 6, 10, True, True, False), (1, 128, 3, 5, False, True, True)]
+
+
+@pytest.mark.parametrize("cfg", FUSED_CASES)
+def test_bn_finalize_folded_into_apply_emulated(emu_lib, cfg):
+    _fused_vs_three_launch("cpu", *cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", FUSED_CASES + [(4, 128, 64, 64, True, True, False), (4, 256, 32, 32, True, False, True),
+                                               (4, 512, 16, 16, True, True, True), (4, 64, 128, 128, True, False, False)])
+def test_bn_finalize_folded_into_apply_gpu(hip_lib, cfg):
+    _fused_vs_three_launch("cuda", *cfg)

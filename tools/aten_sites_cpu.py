@@ -22,6 +22,11 @@ VIEWS = ("view", "reshape", "permute", "expand", "slice", "select", "t.default",
          "alias", "_unsafe_view", "empty", "new_empty", "split", "unbind", "is_", "size", "stride", "sym_", "_local_scalar", "lift_fresh", "contiguous")
 
 
+VIEWS_EXACT = {"view", "reshape", "permute", "expand", "slice", "select", "t", "transpose", "as_strided", "unsqueeze", "squeeze", "detach", "alias",
+               "_unsafe_view", "empty", "new_empty", "empty_like", "empty_strided", "split", "unbind", "size", "stride", "lift_fresh", "contiguous",
+               "narrow", "view_as", "expand_as", "unfold", "_reshape_alias", "split_with_sizes", "chunk", "numel", "dim", "storage_offset"}
+
+
 class Rec(TorchDispatchMode):
     def __init__(self):
         super().__init__()
@@ -29,7 +34,8 @@ class Rec(TorchDispatchMode):
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
-        if not any(v in name for v in VIEWS):
+        base = name.replace("aten.", "").split(".")[0]
+        if base not in VIEWS_EXACT and not base.startswith(("sym_", "is_", "_local_scalar")):
             site = "?"
             for fr in reversed(traceback.extract_stack()):
                 if "/omni3d_amd/" in fr.filename:
@@ -47,7 +53,7 @@ cfg = MG.product_cfg(LIGHT)
 model = MG.build_product_model(cfg, priors, 11, device="cpu")
 model.train()
 opt = build_optimizer(cfg, model)
-batch = synthetic.make_batch(1, 64, 64, num_gt=3, seed=40, priors=priors)
+batch = synthetic.make_batch(int(os.environ.get("ATEN_SITES_B", "2")), 64, 64, num_gt=3, seed=40, priors=priors)
 packed = model.prepack(batch)
 from omni3d_amd.d2.events import EventStorage
 with EventStorage(0):
@@ -58,7 +64,8 @@ with EventStorage(0):
     opt.zero_grad()
     with fwd:
         losses = model(batch, packed)
-        total = sum(losses.values())
+        from omni3d_amd.functional import total_loss
+        total = total_loss(losses)
     with bwd:
         total.backward()
 for title, rec in (("forward (+ loss sum)", fwd), ("backward", bwd)):
