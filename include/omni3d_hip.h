@@ -589,6 +589,14 @@ int omni_gemm_batched_wgrad_multi(const void* const* x, const void* const* dy, c
  * 3 -> 4 channels] or (16, 3) [level0; also its data gradient with the rotated, channel-transposed filter]. */
 int omni_stem_conv_fwd(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
                        void* stream);
+/* Round 5: the data gradients of the full-resolution stem layers on the same design (input halo + whole filter in LDS, MFMA 16x16x4).
+ * omni_stem_conv_dgrad: 3x3 16 -> 16 stride 1 (level0, dla.py:246-247) from the layer's FORWARD filter -- the 180-degree rotation and
+ * the channel transposition happen while the filter is staged.  omni_stem_conv_s2_dgrad: 3x3 stride 2 pad 1, 16 -> 32 (level1,
+ * dla.py:248-249): dx (N,H,W,16) from dy (N,(H-1)/2+1,(W-1)/2+1,32); parity classes of the strided gradient inside one launch. */
+int omni_stem_conv_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int lddy, int lddx,
+                         void* stream);
+int omni_stem_conv_s2_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int lddy, int lddx,
+                            void* stream);
 /* Its weight gradient: dw (16,R,R,C) = (accumulate == 0) or += sum over pixels of dy (N,H,W,16) (x) x (N,H,W,C). */
 int omni_stem_conv_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
                          int accumulate, void* stream);

@@ -53,6 +53,19 @@ struct ConvP {
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// 16 bytes through a buffer resource: an offset outside the resource (OMNI_OOB) returns zeros WITHOUT a branch
+typedef unsigned omni_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 bufld4(omni_rsrc_t r, int voff) {
+#ifdef OMNI_HIPEMU
+    float4 v = zero4();
+    if ((unsigned)voff + 16u <= r.bytes) memcpy(&v, r.base + (unsigned)voff, 16);
+    return v;
+#else
+    const omni_u4 u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+#endif
+}
+
 
 // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD
 // a contiguous chunk of the (m-fastest) tile sequence.
@@ -157,7 +170,12 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kq = tid % KQ, lrow = tid / KQ;
 
-    long a_base[AI];                                   // element offset of (img, ih0, iw0, 0)
+    // Operands come through buffer resources (round 5, the design of gemm_nt_pf_kernel): padding taps, rows past M / K and slabs
+    // past the reduction become an out-of-range OFFSET, not a branch around the load -- every load_slab() issues the same loads, so
+    // the prefetch ring (PF > 1) keeps its slabs in flight instead of draining vmcnt at every guarded load.  Tensors < 2 GiB.
+    const omni_rsrc_t rx_ = omni_make_rsrc(p.x, (unsigned)((((long)p.N * p.H * p.W - 1) * p.ldx + p.C) * 4));
+    const omni_rsrc_t rw_ = omni_make_rsrc(p.w, (unsigned)((long)p.K * Kd * 4));
+    int a_base[AI];                                    // element offset of (img, ih0, iw0, 0) (may be negative: padding)
     int a_ih[AI], a_iw[AI];
     bool a_ok[AI];
 #pragma unroll
@@ -169,7 +187,7 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
         const int oh = rem / p.OW, ow = rem - oh * p.OW;
         a_ih[i] = oh * p.stride - p.pad;
         a_iw[i] = ow * p.stride - p.pad;
-        a_base[i] = ((long)(img * p.H + a_ih[i]) * p.W + a_iw[i]) * p.ldx;
+        a_base[i] = ((img * p.H + a_ih[i]) * p.W + a_iw[i]) * p.ldx;
     }
     // reduction cursor of this thread's float4 column: kd = (r*S + s)*C + c, advanced by BKX per slab
     const int nk_total = (Kd + BKX - 1) / BKX;
@@ -197,19 +215,21 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
         s_cur = tap0 - r_cur * p.S;
     }
     float4 ra[PF][AI], rb[PF][BI];
+    int issued = 0;                                    // slabs requested so far: the ring asks past this split's last slab
     auto load_slab = [&](const int st) {
-        const bool kok = kd < Kd;
-        const long tap_off = ((long)r_cur * p.W + s_cur) * p.ldx + c_cur;
+        const bool kok = kd < Kd && issued < nk;
+        ++issued;
+        const int tap_off = (r_cur * p.W + s_cur) * p.ldx + c_cur;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int ih = a_ih[i] + r_cur, iw = a_iw[i] + s_cur;
             const bool ok = a_ok[i] && kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            ra[st][i] = ok ? ldg4(p.x + a_base[i] + tap_off) : zero4();
+            ra[st][i] = bufld4(rx_, ok ? (a_base[i] + tap_off) * 4 : OMNI_OOB);
         }
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
             const int n = n0 + lrow + RPP * j;
-            rb[st][j] = (lrow + RPP * j < BN && n < p.K && kok) ? ldg4(p.w + (long)n * Kd + kd) : zero4();
+            rb[st][j] = bufld4(rw_, (lrow + RPP * j < BN && n < p.K && kok) ? (n * Kd + kd) * 4 : OMNI_OOB);
         }
         if (tap_inner) {
             kd += p.C;
@@ -257,21 +277,18 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
     } else {
         // stage s holds slab kt when kt % PF == s; the cursor of load_slab() runs PF slabs ahead of the MFMAs
 #pragma unroll
-        for (int s = 0; s < PF; ++s)
-            if (s < nk) load_slab(s);
+        for (int s = 0; s < PF; ++s) load_slab(s);                             // slabs 0 .. PF - 1 (zeros past the split's end)
         store_slab(0, 0);
-        if (PF < nk) load_slab(0);
+        load_slab(0);
         omni_barrier_lds();
         for (int kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int kt = kt0 + u;
-                if (kt < nk) {
+                if (kt < nk) {                                                 // (uniform; only the last round of a ragged nk)
                     const int buf = kt & 1;
-                    if (kt + 1 < nk) {
-                        store_slab(buf ^ 1, (u + 1) % PF);                     // slab kt + 1: its loads were issued PF phases ago
-                        if (kt + 1 + PF < nk) load_slab((u + 1) % PF);         // refill the stage just drained
-                    }
+                    store_slab(buf ^ 1, (u + 1) % PF);                         // slab kt + 1: its loads were issued PF phases ago
+                    load_slab((u + 1) % PF);                                   // slab kt + 1 + PF, unconditionally
                     const float* As = smem + buf * (BM + BN) * BKP;
                     mma_slab<WM, WN, true, true, 0, 0, BKX>(As, As + BM * BKP, wm * WM * 32, wn * WN * 32, lane, acc);
                     omni_barrier_lds();       // not __syncthreads(): that would drain the loads in flight (vmcnt(0))
@@ -799,18 +816,6 @@ struct GemmTP {
     unsigned* ctr;
 };
 
-typedef unsigned omni_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 bufld4(omni_rsrc_t r, int voff) {
-#ifdef OMNI_HIPEMU
-    float4 v = zero4();
-    if ((unsigned)voff + 16u <= r.bytes) memcpy(&v, r.base + (unsigned)voff, 16);
-    return v;
-#else
-    const omni_u4 u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
-    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-#endif
-}
-
 template <int PF>
 __global__ void __launch_bounds__(256) gemm_nt_pf_kernel(GemmTP p) {
     constexpr int BM = 64, BN = 64, BKX = 32, BKP = BKX + 4, KQ = BKX / 4, RPP = 256 / KQ, AI = BM / RPP, BI = BN / RPP;
@@ -1111,6 +1116,8 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
 #define OMNI_FWD(BM_, BN_, WM_, WN_, BK_, PF_)                                                                           \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<BM_, BN_, WM_, WN_, BK_, PF_>),                                     \
                        dim3((unsigned)(((M + BM_ - 1) / BM_) * ((K + BN_ - 1) / BN_)), (unsigned)splits), dim3(256), 0, st, p)
+    // (round 5: the 64 x 64 launches of the direct convolutions gain nothing from a deeper ring -- PF 2 / 3 on every one of them:
+    // 10.97 / 10.99 ms per step against 10.97, profiles/r05_ab_conv64_pf.log; tile 5 stays an explicit choice)
     if (tile == 1) OMNI_FWD(128, 128, 2, 2, 32, 1);
     else if (tile == 2) OMNI_FWD(64, 64, 2, 2, 32, 1);
     else if (tile == 5) OMNI_FWD(64, 64, 2, 2, 32, 3);

@@ -19,10 +19,14 @@ namespace {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int C, int R>
+// ROT (C == 16 only): `w` is the FORWARD filter (16, R, R, 16) of a layer whose DATA GRADIENT this launch computes -- x is dy, out is
+// dx, and the filter used is w rotated by 180 degrees with its channel roles swapped, wd[c][r][s][k] = w[k][R-1-r][R-1-s][c], built
+// while the filter is staged (round 5: the flip + transpose + layout copy were three ATen launches, 23 us, for a 9 KB tensor).
+template <int C, int R, bool ROT = false>
 __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             float* __restrict__ out, int N, int H, int W, int ldx, int ldo,
                                                             float* __restrict__ stats) {
+    static_assert(!ROT || C == 16, "the rotated form is the 16 -> 16 layer's data gradient");
     constexpr int TH = 4, TW = 64, PAD = R / 2;
     constexpr int HR = TH + R - 1, HC = TW + R - 1 + (C == 4 ? 1 : 0);   // C = 4: one spare column for the padded 8th tap
     constexpr int PP = (C == 16) ? 20 : 4;                               // LDS floats per pixel (20: conflict-free b128 reads)
@@ -60,7 +64,14 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
         const int i = tid + 256 * u;
         const int c4 = i % C4, s = (i / C4) % SP, r = (i / (C4 * SP)) % R, k = i / (C4 * SP * R);
         vw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < 16 * R * SP * C4 && s < R) vw[u] = ld4(w + (((long)k * R + r) * R + s) * C + 4 * c4);
+        if (i < 16 * R * SP * C4 && s < R) {
+            if (ROT) {      // element (k, r, s, c) of the rotated filter = w[c][R-1-r][R-1-s][k], c = 4 c4 .. 4 c4 + 3
+                const float* q = w + (((long)(4 * c4) * R + (R - 1 - r)) * R + (R - 1 - s)) * C + k;
+                vw[u] = make_float4(q[0], q[(long)R * R * C], q[2L * R * R * C], q[3L * R * R * C]);
+            } else {
+                vw[u] = ld4(w + (((long)k * R + r) * R + s) * C + 4 * c4);
+            }
+        }
     }
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
@@ -137,6 +148,117 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
     }
 }
 
+
+// ---- data gradient of the stride-2 3x3 layer (DLA-34 level1: 16 -> 32 channels at 512 x 512, dla.py:248-249,291-295) ------------
+//   dx[n, ih, iw, c] = sum over (r, s, k) with (ih + 1 - r), (iw + 1 - s) even of dy[n, (ih + 1 - r) / 2, (iw + 1 - s) / 2, k] * w[k, r, s, c]
+// 2.4 GFLOP against 100 MB (33.5 MB of dy read, 67 MB of dx written): HBM floor 12.5 us, MFMA floor 15 us.  The implicit GEMM ran
+// this as four parity-class launches-in-one on 256 x 32 tiles (N = 16 padded to 32, every dy pixel re-staged per tap): 118 us isolated,
+// 177-217 us inside the step -- the longest single launch of the critical path after the fc1 GEMMs (gpurun_out/r05a_timeline.txt).
+// Here a workgroup owns an 8 x 64 tile of dx, stages its 5 x 33 pixel halo of dy (all K channels) and the whole filter into LDS once
+// and walks the taps of each PARITY CLASS with v_mfma_f32_16x16x4_f32 (M = 16 pixels of one class in one row, N = the 16 channels of
+// dx exactly): even rows / columns meet one tap per axis (r = 1), odd ones two (r = 0, 2) -- no MFMA work on the structural zeros.
+// A wave takes one even and one odd row of the tile (rows w and 7 - w), so the four waves carry the same number of MFMAs.
+//   fragments: a lane's ds_read_b128 holds dy channels 16 h + 4 g .. + 3 of its pixel (A) / filter entries of the same channels for its
+//   dx channel (B); MFMA t takes element t, i.e. the k index of the four MFMAs runs over the lane groups g (as in stem_conv_fwd_kernel).
+template <int C, int K>
+__global__ void __launch_bounds__(256) stem_dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int N, int H, int W, int OH, int OW, int lddy,
+                                                            int lddx) {
+    static_assert(C == 16 && K % 16 == 0, "N = 16 dx channels per MFMA block; dy channels in chunks of 16");
+    constexpr int TH = 8, TW = 64, HR = TH / 2 + 1, HC = TW / 2 + 1, PP = K + 4, KP = K + 4, K4 = K / 4, KH = K / 16;
+    __shared__ __attribute__((aligned(16))) float s_dy[HR * HC * PP];
+    __shared__ __attribute__((aligned(16))) float s_w[9 * C * KP];          // [tap][c][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int n = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;                                  // even
+    const int hy0 = oy0 / 2, hx0 = ox0 / 2;
+    // ---- stage: every global load before the first LDS store
+    constexpr int NI = (HR * HC * K4 + 255) / 256, NW = (K * 9 * (C / 4) + 255) / 256;
+    float4 vi[NI], vw[NW];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = tid + 256 * u;
+        const int k4 = i % K4, col = (i / K4) % HC, row = i / (K4 * HC);
+        const int oy = hy0 + row, ox = hx0 + col;
+        vi[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < HR * HC * K4 && oy < OH && ox < OW) vi[u] = ld4(dy + (((long)n * OH + oy) * OW + ox) * lddy + 4 * k4);
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+        const int i = tid + 256 * u;
+        vw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < K * 9 * (C / 4)) vw[u] = ld4(w + 4L * i);                   // w (K, 3, 3, C) read linearly
+    }
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = tid + 256 * u;
+        const int k4 = i % K4, col = (i / K4) % HC, row = i / (K4 * HC);
+        if (i < HR * HC * K4) *reinterpret_cast<float4*>(s_dy + (row * HC + col) * PP + 4 * k4) = vi[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+        const int i = tid + 256 * u;
+        if (i < K * 9 * (C / 4)) {
+            const int c4 = i % (C / 4), tap = (i / (C / 4)) % 9, k = i / (9 * (C / 4));
+            float* q = s_w + (tap * C + 4 * c4) * KP + k;
+            q[0] = vw[u].x; q[KP] = vw[u].y; q[2 * KP] = vw[u].z; q[3 * KP] = vw[u].w;
+        }
+    }
+    __syncthreads();
+
+    const int px = lane & 15, g = lane >> 4;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int y = half == 0 ? wave : TH - 1 - wave;                      // tile row of dx; parity = y & 1 (oy0 is even)
+        const int ih = oy0 + y;
+        const int nr = 1 + (y & 1);                                          // row taps: even: r = 1 | odd: r = 0, 2
+        f32x4 acc[2][2];                                                     // [column parity][block of 16 class pixels]
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[pw][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int jr = 0; jr < nr; ++jr) {
+            const int r = (y & 1) ? 2 * jr : 1;
+            const int lr = (y + 1 - r) >> 1;                                 // halo row of dy
+#pragma unroll
+            for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                for (int js = 0; js <= pw; ++js) {                           // column taps: even: s = 1 | odd: s = 0 (dc 1), s = 2 (dc 0)
+                    const int sx = pw ? 2 * js : 1, dc = pw ? 1 - js : 0;
+#pragma unroll
+                    for (int h2 = 0; h2 < KH; ++h2) {
+                        const float4 bw = *reinterpret_cast<const float4*>(s_w + ((r * 3 + sx) * C + px) * KP + 16 * h2 + 4 * g);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const float4 a = *reinterpret_cast<const float4*>(s_dy + (lr * HC + 16 * b + px + dc) * PP + 16 * h2 + 4 * g);
+                            acc[pw][b] = mfma_16x16x4(a.x, bw.x, acc[pw][b]);
+                            acc[pw][b] = mfma_16x16x4(a.y, bw.y, acc[pw][b]);
+                            acc[pw][b] = mfma_16x16x4(a.z, bw.z, acc[pw][b]);
+                            acc[pw][b] = mfma_16x16x4(a.w, bw.w, acc[pw][b]);
+                        }
+                    }
+                }
+        }
+        // D[row = 4g + i][col = px]: class pixel j = 16 b + 4 g + i of this row -> dx column ox0 + 2 j + pw, channel px
+        if (ih < H) {
+            float* orow = dx + ((long)n * H + ih) * W * lddx + px;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int pw = 0; pw < 2; ++pw) {
+                        const int iw = ox0 + 2 * (16 * b + 4 * g + i) + pw;
+                        if (iw < W) orow[(long)iw * lddx] = acc[pw][b][i];
+                    }
+        }
+    }
+}
 
 // ---- weight gradient: dW[k][r][s][c] += sum over output pixels of dy[pix][k] * x[S * pix + (r, s) - pad][c] -------------
 // MFMA 16x16x4 with M = 16 output channels, N = 16 columns of (tap, c) and the k dimension running over 4 consecutive
@@ -311,9 +433,9 @@ extern "C" {
 
 // out (N,H,W,16) = conv(x (N,H,W,C), w (16,R,R,C)), stride 1, padding R/2.  (C, R) in {(4, 7), (16, 3)}.
 static int stem_fwd_impl(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
-                         float* stats, int stats_rows, int* nblk_out, void* stream) {
+                         float* stats, int stats_rows, int* nblk_out, void* stream, bool rot = false) {
     if (nblk_out) *nblk_out = 0;
-    if (N < 0 || H <= 0 || W <= 0 || K != 16 || ldx < C || ldo < K || (ldx & 3)) return OMNI_ERR_ARG;
+    if (N < 0 || H <= 0 || W <= 0 || K != 16 || ldx < C || ldo < K || (ldx & 3) || (rot && C != 16)) return OMNI_ERR_ARG;
     if (!((C == 4 && R == 7) || (C == 16 && R == 3))) return OMNI_ERR_ARG;
     if (N == 0) return OMNI_OK;
     const long tiles = (long)N * ((H + 3) / 4) * ((W + 63) / 64);
@@ -321,6 +443,9 @@ static int stem_fwd_impl(const float* x, const float* w, float* out, int N, int 
     if (sp && nblk_out) *nblk_out = (int)tiles;
     if (C == 4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_fwd_kernel<4, 7>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w,
+                           out, N, H, W, ldx, ldo, sp);
+    else if (rot)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_fwd_kernel<16, 3, true>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w,
                            out, N, H, W, ldx, ldo, sp);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_fwd_kernel<16, 3>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w,
@@ -331,6 +456,28 @@ static int stem_fwd_impl(const float* x, const float* w, float* out, int N, int 
 int omni_stem_conv_fwd(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
                        void* stream) {
     return stem_fwd_impl(x, w, out, N, H, W, C, K, R, ldx, ldo, nullptr, 0, nullptr, stream);
+}
+
+// data gradient of the 3x3 16 -> 16 stride-1 layer: dx (N,H,W,16) from dy (N,H,W,16) and the layer's FORWARD filter w (16,3,3,16); the
+// rotated, channel-transposed filter is formed while it is staged (no temporary)
+int omni_stem_conv_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int lddy, int lddx,
+                         void* stream) {
+    if (C != 16 || K != 16 || R != 3) return OMNI_ERR_ARG;
+    return stem_fwd_impl(dy, w, dx, N, H, W, K, C, R, lddy, lddx, nullptr, 0, nullptr, stream, true);
+}
+
+// data gradient of the 3x3 stride-2 pad-1 layer 16 -> 32 (DLA-34 level1): dx (N,H,W,16) from dy (N,OH,OW,32), OH = (H - 1) / 2 + 1,
+// and w (32,3,3,16).  Every element of dx is written (no accumulation form: the layer's input has one consumer).
+int omni_stem_conv_s2_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int lddy, int lddx,
+                            void* stream) {
+    if (N < 0 || H <= 0 || W <= 0 || C != 16 || K != 32 || R != 3 || lddy < K || lddx < C || (lddy & 3)) return OMNI_ERR_ARG;
+    if (N == 0) return OMNI_OK;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long tiles = (long)N * ((H + 7) / 8) * ((W + 63) / 64);
+    if (tiles > 0x7fffffff) return OMNI_ERR_ARG;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_dgrad_s2_kernel<16, 32>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, dy, w, dx, N,
+                       H, W, OH, OW, lddy, lddx);
+    return omni_launch_status();
 }
 
 // the same with BatchNorm partial statistics stats[rows][2][16] of the output (one row per 4 x 64 tile); *nblk_out = rows (0 = none)

@@ -321,9 +321,11 @@ class _Conv2d(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             def dgrad(carry):
+                if conv.stem_dgrad_eligible(x.shape, w.shape, stride, pad):
+                    # full-resolution stem layers: input halo + whole filter in LDS (csrc/stem_conv.hip); the stride-1 form is the
+                    # same convolution of dy with the 180-degree rotated, channel-transposed filter, formed inside the kernel
+                    return _add_carry(conv.stem_conv_dgrad(dy, w, (x.shape[2], x.shape[3]), stride), carry)
                 if ctx.stem and w.shape[1] == 16:
-                    # data gradient of a stride-1 "same" convolution = the same convolution of dy with the 180-degree rotated,
-                    # channel-transposed filter (a 9 KB tensor)
                     return _add_carry(conv.stem_conv_fwd(dy, _cl(w.flip(2, 3).transpose(0, 1))), carry)
                 if carry is not None and _carry_pitch(carry) is not None:
                     return conv.conv2d_dgrad(dy, w, (x.shape[2], x.shape[3]), stride, pad, accum_into=carry)

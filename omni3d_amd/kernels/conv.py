@@ -189,11 +189,16 @@ def linear_fwd(x, w, bias=None, relu=False):
 _DGRAD_NT = os.environ.get("OMNI_FC_DGRAD_NT", "1") != "0"
 _DGRAD_FORM = os.environ.get("OMNI_FC_DGRAD_FORM", "nn")            # "nn": the engine reads W as it is | "nt": transpose W first (rounds 2-3)
 _FC_BALANCED = os.environ.get("OMNI_FC_BALANCED", "1") != "0"
-_FC_WGRAD_ENGINE_MIN_ROWS = int(os.environ.get("OMNI_FC_WGRAD_ENGINE_MIN_ROWS", "1024"))
-# persistent workgroups of the fc1-class weight gradient (0 = one per CU): it runs on the weight-gradient stream BESIDE the critical path,
-# and a launch on fewer workgroups leaves CUs to the main stream for its whole (longer) duration (A/B knob)
-_FC_WGRAD_WGS = int(os.environ.get("OMNI_FC_WGRAD_WGS", "0"))
-_FC_WGRAD_SPLITS = int(os.environ.get("OMNI_FC_WGRAD_SPLITS", "-1"))      # -1 = balanced (gemm.BALANCED) | 1 = whole tiles only (A/B knob)
+# Round 5: the fc1-class WEIGHT gradient is back on the tile kernel.  It runs on the weight-gradient stream beside the critical path, and
+# the engine's balanced 128 x 128 form compiles to 256 VGPRs + 154 AGPRs = 410 registers per lane (one workgroup per CU because of its
+# 96 KB of LDS, so hipcc budgets the whole file): while its 256 persistent workgroups hold every CU, no wave that needs more than ~100
+# registers can start anywhere on the chip, and the main stream's next kernels (wino4_out: 254 VGPRs) waited out its 550 us
+# (gpurun_out/r05a_timeline.txt; VERDICT r4 weak 3 saw the same stall).  The tile kernel (152 registers, 49 KB of LDS, non-persistent)
+# is slower in isolation and shares the CUs: 10.85 -> 10.72 ms / step (profiles/r05_ab_fc1_wgrad.log; engine on 224 workgroups: 10.80).
+# OMNI_FC_WGRAD_ENGINE_MIN_ROWS=1024 restores the engine (A/B knob).
+_FC_WGRAD_ENGINE_MIN_ROWS = int(os.environ.get("OMNI_FC_WGRAD_ENGINE_MIN_ROWS", str(1 << 30)))
+_FC_WGRAD_WGS = int(os.environ.get("OMNI_FC_WGRAD_WGS", "0"))              # persistent workgroups of the engine form (0 = one per CU)
+_FC_WGRAD_SPLITS = int(os.environ.get("OMNI_FC_WGRAD_SPLITS", "-1"))      # -1 = balanced (gemm.BALANCED) | 1 = whole tiles only
 
 
 def linear_dgrad(dy, w):
@@ -247,6 +252,31 @@ def stem_conv_fwd(x, w):
     out = torch.empty((N, H, W, K), dtype=torch.float32, device=x.device)
     L.call("omni_stem_conv_fwd", _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(out), N, H, W, C, K, R, C, K, _lib.stream_of(x))
     return out.permute(0, 3, 1, 2)
+
+
+_STEM_DGRAD = os.environ.get("OMNI_STEM_DGRAD", "1") != "0"        # A/B: 0 = the round-4 data gradients of level0 / level1
+
+
+def stem_dgrad_eligible(x_shape, w_shape, stride, pad):
+    """data gradients served by csrc/stem_conv.hip (round 5): 3x3 16 -> 16 stride 1 (level0, filter rotated inside the kernel) and
+    3x3 stride 2 pad 1 16 -> 32 (level1, parity classes inside one launch)"""
+    K, C, R, S = w_shape
+    if not _STEM_DGRAD or R != 3 or S != 3 or pad != 1 or C != 16 or x_shape[1] != 16:
+        return False
+    return (stride == 1 and K == 16) or (stride == 2 and K == 32)
+
+
+def stem_conv_dgrad(dy, w, in_hw, stride):
+    """dy (N,K,OH,OW) CL, w (K,16,3,3) CL (the layer's forward filter) -> dx (N,16,H,W) CL"""
+    dyv, wv = _nhwc(dy), _nhwc(w)
+    N, OH, OW, K = dyv.shape
+    H, W = in_hw
+    assert (OH, OW) == ((H - 1) // stride + 1, (W - 1) // stride + 1) and tuple(wv.shape) == (K, 3, 3, 16)
+    L = _lib.check_device(dyv, wv)
+    dx = torch.empty((N, H, W, 16), dtype=torch.float32, device=dy.device)
+    L.call("omni_stem_conv_dgrad" if stride == 1 else "omni_stem_conv_s2_dgrad", _lib.ptr(dyv), _lib.ptr(wv), _lib.ptr(dx), N, H, W, 16, K, 3,
+           K, 16, _lib.stream_of(dy))
+    return dx.permute(0, 3, 1, 2)
 
 
 _STEM_WGRAD_ALL = os.environ.get("OMNI_STEM_WGRAD_ALL", "1") != "0"       # A/B: 0 = only the 16 -> 16 stride-1 layer (rounds 2-3)

@@ -376,10 +376,32 @@ def _run_stem_s2_wgrad(dev, N, H, W, seed=7):
             detmode.set_enabled(prev)
 
 
+def _run_stem_dgrad(dev, N, H, W, stride, seed=9):
+    """round 5: the stem data gradients (level0: rotated filter formed inside the kernel; level1: stride 2, parity classes in one
+    launch) against torch's conv2d_input and against the implicit GEMM"""
+    from omni3d_amd.kernels import conv
+    g = torch.Generator().manual_seed(seed)
+    K = 16 if stride == 1 else 32
+    w = torch.randn(K, 16, 3, 3, generator=g) * 0.2
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = torch.randn(N, K, OH, OW, generator=g)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last).to(dev)  # noqa: E731
+    assert conv.stem_dgrad_eligible((N, 16, H, W), w.shape, stride, 1) and not conv.stem_dgrad_eligible((N, 16, H, W), w.shape, stride, 0)
+    ref = torch.nn.grad.conv2d_input((N, 16, H, W), w, dy, stride=stride, padding=1)
+    scale = float(torch.nn.grad.conv2d_input((N, 16, H, W), w.abs(), dy.abs(), stride=stride, padding=1).max())
+    dx = conv.stem_conv_dgrad(cl(dy), cl(w), (H, W), stride)
+    assert dx.shape == ref.shape and (dx.cpu() - ref).abs().max() <= 2e-6 * scale, (stride, float((dx.cpu() - ref).abs().max()), scale)
+    gemm = conv.conv2d_dgrad(cl(dy), cl(w), (H, W), stride, 1)
+    assert (dx - gemm).abs().max() <= 4e-6 * scale
+
+
 def test_stem_conv_emulated(emu_lib):
     _run_stem("cpu", 1, 6, 70, 16, 3)      # ragged tile in x and y
     _run_stem("cpu", 2, 5, 9, 4, 7)
     _run_stem_s2_wgrad("cpu", 2, 10, 70)   # 5 x 35 outputs: ragged in both directions
+    _run_stem_dgrad("cpu", 1, 6, 70, 1)
+    _run_stem_dgrad("cpu", 2, 10, 70, 2)   # ragged 8 x 64 tiles
+    _run_stem_dgrad("cpu", 1, 9, 67, 2)    # odd extents: the last row / column of dx meets a single tap
 
 
 @pytest.mark.gpu
@@ -388,6 +410,10 @@ def test_stem_conv_gpu(hip_lib):
     _run_stem("cuda", 2, 130, 100, 4, 7)
     _run_stem_s2_wgrad("cuda", 2, 132, 200)
     _run_stem_s2_wgrad("cuda", 4, 512, 512)       # level1 at the benchmark's size: more tiles than persistent workgroups
+    _run_stem_dgrad("cuda", 2, 128, 192, 1)
+    _run_stem_dgrad("cuda", 2, 132, 200, 2)
+    _run_stem_dgrad("cuda", 1, 67, 131, 2)
+    _run_stem_dgrad("cuda", 4, 512, 512, 2)       # the benchmark's level1
 
 
 def _run_stem_autograd(dev):
