@@ -197,7 +197,7 @@ BACKBONE_SMALL = (dict(SMALL, name="mnasnet_small", seed=24, config="cubercnn_mn
 
 
 FULL = dict(name="dla34_full", seed=6, images=4, height=512, width=512, num_gt=8, overrides=[])       # BASELINE configs[1]
-RESNET_FULL = dict(name="resnet34_full", seed=8, images=2, height=512, width=512, num_gt=8, overrides=[],
+RESNET_FULL = dict(name="resnet34_full", seed=8, images=4, height=512, width=512, num_gt=8, overrides=[],
                    config="cubercnn_ResNet34_FPN.yaml")                                                  # BASELINE configs[3] model
 
 

@@ -356,10 +356,10 @@ def test_training_step_ragged_batch_vs_cpu_oracle(hip_lib):
 
 @pytest.mark.gpu
 def test_training_step_fullsize_resnet34_vs_cpu_oracle(hip_lib):
-    """BASELINE configs[3] model at full size: cubercnn_ResNet34_FPN, 2 x 512x512."""
+    """BASELINE configs[3] model at full size and at the benchmarked batch: cubercnn_ResNet34_FPN, 4 x 512x512."""
     from omni3d_amd import synthetic
     priors = synthetic.make_priors(50)
-    _vs_cpu_oracle(synthetic.make_batch(2, 512, 512, num_gt=8, seed=23, priors=priors), report="resnet34_fp64_report.txt",
+    _vs_cpu_oracle(synthetic.make_batch(4, 512, 512, num_gt=8, seed=23, priors=priors), report="resnet34_fp64_report.txt",
                    config="cubercnn_ResNet34_FPN.yaml", backbone="resnet34")
 
 
