@@ -118,7 +118,7 @@ def max_over_ranks(x, world):
     return float(t.item())
 
 
-from omni3d_amd.profile_io import profile_counters  # noqa: E402
+from omni3d_amd.profile_io import latest_profile, profile_counters  # noqa: E402
 
 
 class _Timer:
@@ -175,7 +175,7 @@ def run_iou3d(args, world, rank):
     dt_s = max_over_ranks(time.perf_counter() - t0, world)
     kern_ms = float(np.mean([e.ms() for e in ev]))
     alg_bytes = P * (192 + 4)
-    pmc = profile_counters(IOU_PMC, "iou_box3d_kernel") or profile_counters("r02_pmc_iou3d.csv", "iou_box3d_kernel")
+    pmc = profile_counters(IOU_PMC, "iou_box3d_kernel")
     res = {
         "metric": "IoU3D box pairs/sec (box3d_overlap, 100k dt x gt pairs)", "value": P * world * args.steps / dt_s,
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -189,8 +189,12 @@ def run_iou3d(args, world, rank):
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": (pmc["FETCH_SIZE_x2_MB"] + pmc["WRITE_SIZE_MB"]) * 1e6 if pmc and pmc.get("FETCH_SIZE_x2_MB") and pmc.get("WRITE_SIZE_MB") else None,
                      "kernel_ms": kern_ms, "pairs_per_s_kernel": P / (kern_ms * 1e-3),
-                     "note": "196 B/pair algorithmic I/O; the kernel is VALU / branch bound, not HBM bound: `valu` is the issue-side "
-                             "utilisation (VALU-active share of the wave cycles) from the committed PMC pass",
+                     # the kernel's own figure: it is VALU-issue bound, so the number to push is the share of SIMD-cycles that have a VALU
+                     # instruction in flight (committed PMC pass; SQ_* in quad-cycles) -- `frac` above is only the schema's HBM sanity bound
+                     "kernel_bound": "valu-issue",
+                     "valu_busy_frac_of_simd_cycles": pmc.get("valu_busy_frac_of_simd_cycles") if pmc else None,
+                     "note": "196 B/pair algorithmic I/O; the kernel is VALU / branch bound, not HBM bound: `valu_busy_frac_of_simd_cycles` = "
+                             "SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) from the committed PMC pass in `valu`",
                      "valu": pmc},
     }
     if rank == 0:       # the CPU leg is reported at N = 1 only (the other ranks would wait on it)
@@ -202,7 +206,7 @@ def run_iou3d(args, world, rank):
     return res
 
 
-IOU_PMC = "r04_pmc_iou3d.csv" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_iou3d.csv")) else "r03_pmc_iou3d.csv"
+IOU_PMC = latest_profile("pmc_iou3d.csv")
 
 
 def cpu_baseline_iou3d(dt, gt, nsample=20000):

@@ -64,14 +64,7 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
         const int i = tid + 256 * u;
         const int c4 = i % C4, s = (i / C4) % SP, r = (i / (C4 * SP)) % R, k = i / (C4 * SP * R);
         vw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < 16 * R * SP * C4 && s < R) {
-            if (ROT) {      // element (k, r, s, c) of the rotated filter = w[c][R-1-r][R-1-s][k], c = 4 c4 .. 4 c4 + 3
-                const float* q = w + (((long)(4 * c4) * R + (R - 1 - r)) * R + (R - 1 - s)) * C + k;
-                vw[u] = make_float4(q[0], q[(long)R * R * C], q[2L * R * R * C], q[3L * R * R * C]);
-            } else {
-                vw[u] = ld4(w + (((long)k * R + r) * R + s) * C + 4 * c4);
-            }
-        }
+        if (i < 16 * R * SP * C4 && s < R) vw[u] = ld4(w + (((long)k * R + r) * R + s) * C + 4 * c4);     // (ROT too: w is read linearly)
     }
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
@@ -83,7 +76,14 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
     for (int u = 0; u < NW; ++u) {
         const int i = tid + 256 * u;
         const int c4 = i % C4, s = (i / C4) % SP, r = (i / (C4 * SP)) % R, k = i / (C4 * SP * R);
-        if (i < 16 * R * SP * C4) *reinterpret_cast<float4*>(s_w + k * KP + (r * SP + s) * C + 4 * c4) = vw[u];
+        if (i < 16 * R * SP * C4) {
+            if (ROT) {      // w[k][r][s][4 c4 + e] is element (row 4 c4 + e, tap (R-1-r, R-1-s), input channel k) of the rotated filter
+                float* q = s_w + (4 * c4) * KP + ((R - 1 - r) * SP + (R - 1 - s)) * C + k;
+                q[0] = vw[u].x; q[KP] = vw[u].y; q[2 * KP] = vw[u].z; q[3 * KP] = vw[u].w;
+            } else {
+                *reinterpret_cast<float4*>(s_w + k * KP + (r * SP + s) * C + 4 * c4) = vw[u];
+            }
+        }
     }
     __syncthreads();
 

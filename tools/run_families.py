@@ -23,6 +23,8 @@ CONVS = [  # name, H, C, K, R, stride
     ("l3 root 1x1 448->128 @64", 64, 448, 128, 1, 1),
     ("l4 root 1x1 896->256 @32", 32, 896, 256, 1, 1),
     ("fpn lat 1x1 64->256 @128", 128, 64, 256, 1, 1),
+    ("level1 3x3s2 16->32 @512", 512, 16, 32, 3, 2),       # round 5: stem_dgrad_s2_kernel / stem_conv_wgrad_kernel<16, 3, 2, 32>
+    ("level0 3x3 16->16 @512", 512, 16, 16, 3, 1),
 ]
 LINEARS = [("fc1 2048x12544->1024", 2048, 12544, 1024), ("fc2 2048x1024->1024", 2048, 1024, 1024),
            ("cube fc1 512x12544->1024", 512, 12544, 1024)]
