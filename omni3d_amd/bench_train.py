@@ -108,6 +108,10 @@ def run_train(args, world, rank):
     graphed, graph_note = None, "eager (OMNI_BENCH_GRAPH=0)"
     from omni3d_amd.cubercnn.solver.graphed import GraphedForwardBackward, GraphedPipelined, GraphedTwoPhase
     pipelined = os.environ.get("OMNI_BENCH_PIPELINE", "1") != "0" and os.environ.get("OMNI_BENCH_TWO_PHASE") != "1"
+    if world > 1 and DEVICE == "cuda":
+        from omni3d_amd.cubercnn.solver import graphed as _graphed_mod
+        _graphed_mod.set_pipe_timing(True)       # per-stage device timestamps + exposed exchange time in every N > 1 line
+        opt.exchange_timing = True
     if pipelined:
         try:
             graphed = GraphedPipelined(model, opt, batch, packed, graphs=use_graph)
@@ -175,6 +179,12 @@ def run_train(args, world, rank):
         import sys
         from omni3d_amd.cubercnn.solver.graphed import pipe_timing_report
         print("pipe timing: " + pipe_timing_report(graphed), file=sys.stderr)
+    exchange = None
+    if world > 1:        # what a bad scaling curve would have to be explained with
+        from omni3d_amd.cubercnn.solver.graphed import pipe_timing_table
+        exchange = opt.exchange_report() or {}
+        exchange["stage_timeline"] = pipe_timing_table(graphed) if getattr(graphed, "_timing", None) else None
+        exchange["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_", "OMNI_EXCHANGE", "TORCH_NCCL"))}
     final_losses = [float(v) for v in torch.stack(loss_log[-args.steps:]).cpu()]
     ims = IMS_PER_GPU * world * args.steps / dt
     step_tf = TRAIN_GFLOP_PER_IMAGE * 1e9 * IMS_PER_GPU * args.steps / dt / 1e12   # per GPU (the per-image figure is for 512 x 512)
@@ -199,6 +209,8 @@ def run_train(args, world, rank):
         "skipped_steps": int(torch.stack(skipped_log[-args.steps:]).sum().item()),
         "guard": "rolling-loss divergence test + NaN/Inf gradient scan + retry decision on the device, one 12-float all-reduce/step",
     }
+    if exchange is not None:
+        res["exchange"] = exchange
     if NONSTANDARD:
         res["nonstandard"] = {"ims_per_gpu": IMS_PER_GPU, "image_size": IMAGE_SIZE, "overrides": OVERRIDES, "device": DEVICE,
                               "note": "not BASELINE.json's configuration: functional check only"}
@@ -218,6 +230,11 @@ def run_train(args, world, rank):
                     res["dropin_loop_multiscale"] = dropin_loop_multiscale(fixed_ms=1e3 * dt / args.steps)
                 except Exception as e:  # noqa: BLE001
                     res["dropin_loop_multiscale"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+                if os.environ.get("OMNI_BENCH_SKIP_STREAM") != "1":
+                    try:
+                        res["dropin_loop_multiscale_stream"] = dropin_loop_multiscale_stream(fixed_ms=1e3 * dt / args.steps)
+                    except Exception as e:  # noqa: BLE001
+                        res["dropin_loop_multiscale_stream"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
                 res["dropin_loop"] = {"loop": "tools/train_synthetic.py == tools/train_net.py:176-285 body, new batch (pool of 4) every iteration, "
                                               "host-side target packing + H2D inside the timed region",
                                       "losses_read_every_iteration": d1, "losses_read_every_10th": d10,
@@ -333,6 +350,58 @@ def dropin_loop_multiscale(iters=24, pool_size=8, fixed_ms=None):
     if fixed_ms is not None:
         out["fixed_shape_step_scaled_by_pixels_ms"] = fixed_ms * mean_px / float(IMAGE_SIZE * IMAGE_SIZE)
         out["vs_pixel_scaled_fixed_shape"] = out["ms_per_step"] / out["fixed_shape_step_scaled_by_pixels_ms"]
+    return out
+
+
+def dropin_loop_multiscale_stream(iters=200, fixed_ms=None):
+    """the same loop on a NON-RECYCLED stream -- `iters` freshly drawn batches (generated before the clock starts,
+    never repeated), a cold cache: the timed region contains the eager warm-up iterations of every new size bucket, its capture, the
+    evictions of the 16-entry cache and whatever the thrash guard decides (cubercnn/solver/autoreplay.py).  Reported: the cache's own
+    statistics, the time per iteration over the WHOLE region and over its last quarter (steady state)."""
+    from omni3d_amd import synthetic
+    from omni3d_amd.cubercnn.solver.guard import StepGuard
+    from omni3d_amd.d2.solver import build_lr_scheduler
+    import warnings
+    cfg, model, opt, priors = build(1, seed=2)
+    sched = build_lr_scheduler(cfg, opt)
+    auto = model.__dict__.get("_omni_auto")
+    if auto is None:
+        return {"error": "AutoReplay disabled"}
+    stream = [synthetic.make_multiscale_batch(IMS_PER_GPU, 7000 + s, priors=priors) for s in range(iters)]
+    guard = None
+    marks = []
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        _sync()
+        t0 = time.perf_counter()
+        for it, batch in enumerate(stream):
+            loss_dict = model(batch)
+            losses = sum(loss_dict.values())
+            if guard is None:
+                guard = StepGuard(list(loss_dict), cfg.MODEL.STABILIZE, cfg.SOLVER.CHECKPOINT_PERIOD, losses.device)
+                opt.skip_flag = guard.skip
+            opt.zero_grad()
+            losses.backward()
+            opt.all_reduce_grads()
+            opt.check_nonfinite(guard.nonfinite_flag)
+            guard.update(loss_dict, sync=True)
+            opt.step()
+            sched.step()
+            if it + 1 == iters - iters // 4:
+                _sync()
+                marks.append((time.perf_counter(), auto.replays))
+        _sync()
+        t1 = time.perf_counter()
+    st = auto.stats()
+    px = [s_[1] * s_[2] for s_ in (auto.signature(b) for b in stream)]
+    out = {"iterations": iters, "ms_per_iteration_whole_region": 1e3 * (t1 - t0) / iters,
+           "ms_per_iteration_last_quarter": 1e3 * (t1 - marks[0][0]) / (iters // 4) if marks else None,
+           "replayed_in_last_quarter": (auto.replays - marks[0][1]) if marks else None, "last_quarter_iterations": iters // 4,
+           "cache_entries": len(auto.cache), "stats": st, "capture": "ok" if auto.failed is None else f"not replaying: {auto.failed}",
+           "guard_warnings": [str(r.message)[:160] for r in rec if "omni3d_amd" in str(r.message)],
+           "mean_padded_pixels_per_image": sum(px) / len(px)}
+    if fixed_ms is not None:
+        out["fixed_shape_step_scaled_by_pixels_ms"] = fixed_ms * out["mean_padded_pixels_per_image"] / float(IMAGE_SIZE * IMAGE_SIZE)
     return out
 
 

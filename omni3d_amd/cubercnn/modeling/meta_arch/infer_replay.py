@@ -39,7 +39,6 @@ class InferReplay:
         img0 = batched_inputs[0]["image"]
         if (self.model.device.type != "cuda" and self.graphs is not False) or any("oracle2D" in b for b in batched_inputs):
             return None
-        from ...solver.autoreplay import AutoReplay
         # A captured pass reads the weights through their pointers (live), but values DERIVED from them outside the graph -- the
         # cached eval-mode BatchNorm coefficients -- are baked in as the tensors they were at capture time: any parameter / buffer
         # write since then (an optimizer step, load_state_dict) drops the captured passes
@@ -48,7 +47,7 @@ class InferReplay:
             self.cache.clear()
             self.counts.clear()
             self.digest = digest
-        sig = AutoReplay.signature(batched_inputs) + (str(img0.dtype),)
+        sig = self.signature(batched_inputs) + (str(img0.dtype),)
         self.counts[sig] = self.counts.get(sig, 0) + 1
         entry = self.cache.get(sig)
         if entry is None:
@@ -78,11 +77,33 @@ class InferReplay:
         # (copies: the results handed to the caller must not alias the tensors the next replay overwrites -- a few hundred KB)
         return {k: v.clone() for k, v in entry["raw"].items()}, sizes
 
+    def signature(self, batch):
+        """(batch size, padded height, padded width) on the grid the EAGER pass pads to (`backbone.size_divisibility`, 64 for the
+        reference's configurations): a replayed pass sees the tensor an eager pass would have built"""
+        from ...solver.autoreplay import AutoReplay
+        g = AutoReplay._model_bucket(self.model)
+        H = max(b["image"].shape[-2] for b in batch)
+        W = max(b["image"].shape[-1] for b in batch)
+        return (len(batch), -(-H // g) * g, -(-W // g) * g)
+
     def _digest(self):
+        """changes whenever a captured pass could be stale: a write torch knows about (`_version`), one it cannot see (PARAM_EPOCH:
+        the flat optimizers and replayed training steps move values through raw pointers), or a parameter / buffer whose STORAGE was
+        replaced (`model.to()`, `.double()`: the graph would keep reading the freed allocation) -- ADVICE r4"""
         from ..layers import PARAM_EPOCH
         if self._tensors is None:
             self._tensors = list(self.model.parameters()) + list(self.model.buffers())
-        return (PARAM_EPOCH[0], sum(t._version for t in self._tensors), len(self._tensors))
+            if "_apply" not in self.model.__dict__:         # `model.to()` / `.double()` / `.cuda()` REPLACE the buffer objects: re-list after them
+                inner, me = self.model._apply, self
+
+                def _apply(fn, *a, **k):
+                    out = inner(fn, *a, **k)
+                    PARAM_EPOCH[0] += 1
+                    me._tensors = None
+                    return out
+                self.model.__dict__["_apply"] = _apply
+        tensors = self._tensors
+        return (PARAM_EPOCH[0], sum(t._version for t in tensors), len(tensors), hash(tuple(t.data_ptr() for t in tensors)))
 
     def _pack(self, batch):
         sizes = [(b["image"].shape[-2], b["image"].shape[-1]) for b in batch]
@@ -104,6 +125,9 @@ class InferReplay:
         if self.graphs is False or dev.type != "cuda":
             self.captures += 1
             return {"graph": None, "raw": None, "slots": slots, "batch": sb, "packed": packed}
+        from ....kernels import detmode
+        detmode.prewarm(dev, ("M",))                # the graph family's arrival counters exist BEFORE the capture: a first use inside it would
+                                                    # put a 256 KB zero-fill node (and pool memory) behind every deterministic launch
         if self._side is None:
             self._side = torch.cuda.Stream()        # (one for all captures: per-stream state elsewhere -- arrival counters -- is keyed by it)
         side = self._side

@@ -49,6 +49,19 @@ CACHE = int(os.environ.get("OMNI_AUTO_REPLAY_CACHE", "16"))           # captured
 # copies block the host until the previous step has drained, which costs 0.3 ms per iteration with the losses read every 1000th
 PINNED = os.environ.get("OMNI_AUTO_REPLAY_PINNED", "0") == "1"
 BUCKET = 64                                                           # ImageList's padding granularity (FPN size divisibility)
+# Thrash guard (round 5): real Omni3D training draws 25 short edges x the datasets' aspect ratios -- far more padded
+# (height, width) pairs than the cache holds.  A capture costs several eager steps (three muted warm-up passes + seven captured
+# stages) and stalls the peer ranks that wait in their all-reduce, so a cache that keeps evicting what it is about to need is worse
+# than no cache.  Watched over a sliding window of GUARD_WINDOW training iterations:
+#   level 0  buckets of 64 x 64 (what the eager pass pads to: replay and eager see the same tensor);
+#   level 1  (captures + iterations of not-yet-captured buckets exceed GUARD_MISS of the window) extents above COARSE_ABOVE are rounded
+#            up to COARSE (128): fewer, slightly larger buckets -- the images sit in larger zero-padded slots, which the model treats
+#            like a batch whose largest image is that much larger;
+#   level 2  (still thrashing a window later) no NEW bucket is captured any more: cached buckets replay, everything else runs eager.
+# One warning per escalation.  An evicted bucket has to earn its `warm` eager iterations again (its counter is reset).
+GUARD_WINDOW = int(os.environ.get("OMNI_AUTO_REPLAY_WINDOW", "64"))
+GUARD_MISS = float(os.environ.get("OMNI_AUTO_REPLAY_MISS", "0.25"))
+COARSE, COARSE_ABOVE = int(os.environ.get("OMNI_AUTO_REPLAY_COARSE", "128")), int(os.environ.get("OMNI_AUTO_REPLAY_COARSE_ABOVE", "512"))
 ROW_FIELDS = ("gt", "gt_cls", "gt3d", "gtpose", "ign")           # (rows, ...) arrays indexed through gt_off / ign_off
 FIXED_FIELDS = ("gt_off", "ign_off", "Ks", "v2r", "ratio", "image_hw")
 
@@ -109,6 +122,15 @@ class AutoReplay:
         self.bad_host, self.bad_event, self.bad_armed = None, None, False
         self.replays = 0
         self.captures = 0
+        self.evictions = 0
+        self.recaptures = 0                      # captures of a bucket that had been captured (and evicted) before
+        self.eager_iters = 0                     # training iterations this object sent down the eager path
+        self.ever = set()                        # buckets captured at least once
+        self.level = 0                           # thrash-guard level (see GUARD_WINDOW)
+        self.window = []                         # last GUARD_WINDOW iterations: True = replay of a cached bucket, False = miss
+        self.level_at = 0                        # iteration count at the last escalation
+        self.iters = 0
+        self.granularity = self._model_bucket(model)
         self.holders = []                        # inner graphs of the eager iterations' loss dicts (see _Boundary)
         self._eager_anchor = None
         self.busy = False                        # True while a capture drives the model itself
@@ -116,11 +138,54 @@ class AutoReplay:
 
     # ---- signature / state machine -----------------------------------------------------------------------------------
     @staticmethod
-    def signature(batch):
+    def _model_bucket(model):
+        """padding granularity of the eager pass: `backbone.size_divisibility` (ImageList.from_tensors); a replayed pass must see the
+        same padded tensor as an eager one, so the bucket grid is that value (64 for every FPN-with-p6 configuration of the reference)"""
+        div = int(getattr(getattr(model, "backbone", None), "size_divisibility", 0) or 0)
+        return div if div > 0 else BUCKET
+
+    def signature(self, batch):
         """(batch size, padded height, padded width): what every shape behind ImageList.from_tensors depends on"""
         H = max(b["image"].shape[-2] for b in batch)
         W = max(b["image"].shape[-1] for b in batch)
-        return (len(batch), -(-H // BUCKET) * BUCKET, -(-W // BUCKET) * BUCKET)
+        g = self.granularity
+
+        def up(v):
+            q = -(-v // g) * g
+            if self.level >= 1 and q > COARSE_ABOVE and COARSE % g == 0:
+                q = -(-v // COARSE) * COARSE
+            return q
+        return (len(batch), up(H), up(W))
+
+    def stats(self):
+        """what the cache did so far (bench.py `dropin_loop_multiscale`, tests)"""
+        n = max(self.iters, 1)
+        return {"iterations": self.iters, "replays": self.replays, "eager": self.eager_iters, "captures": self.captures, "recaptures": self.recaptures,
+                "evictions": self.evictions, "buckets_seen": len(self.counts) + len([k for k in self.ever if k not in self.counts]),
+                "buckets_cached": len(self.cache), "hit_rate": self.replays / n, "guard_level": self.level, "bucket_granularity": self.granularity}
+
+    def _note(self, hit):
+        """sliding-window bookkeeping of the thrash guard; escalates at most once per window"""
+        self.iters += 1
+        self.window.append(bool(hit))
+        if len(self.window) > GUARD_WINDOW:
+            self.window.pop(0)
+        if self.level >= 2 or len(self.window) < GUARD_WINDOW or self.iters - self.level_at < GUARD_WINDOW:
+            return
+        if len(self.cache) < max(CACHE, 1) and self.evictions == 0:
+            return                                # still filling the cache for the first time: misses are warm-up, not thrash
+        miss = 1.0 - sum(self.window) / len(self.window)
+        if miss <= GUARD_MISS:
+            return
+        import warnings
+        self.level += 1
+        self.level_at = self.iters
+        if self.level == 1:
+            warnings.warn(f"omni3d_amd: {miss:.0%} of the last {GUARD_WINDOW} iterations missed the {CACHE}-entry cache of captured training "
+                          f"steps ({len(self.counts)} size buckets seen): rounding extents above {COARSE_ABOVE} up to {COARSE} from now on")
+        else:
+            warnings.warn(f"omni3d_amd: the captured-step cache still misses {miss:.0%} of the iterations; no new size bucket is captured "
+                          "any more (cached buckets replay, the rest runs eager launches).  OMNI_AUTO_REPLAY_CACHE raises the cache size")
 
     # (kept for callers / tests that look at the most recently used captured step)
     @property
@@ -135,8 +200,10 @@ class AutoReplay:
         sig = self.signature(batched_inputs)
         self.counts[sig] = self.counts.get(sig, 0) + 1
         entry = self.cache.get(sig)
+        self._note(entry is not None)
         if entry is None:
-            if self.counts[sig] <= self.warm:
+            if self.counts[sig] <= self.warm or self.level >= 2:
+                self.eager_iters += 1
                 return None
             try:
                 entry = self._capture(batched_inputs, sig)
@@ -146,9 +213,14 @@ class AutoReplay:
                 import warnings
                 warnings.warn(f"omni3d_amd: staged-graph capture of the training step failed ({self.failed}); running eager launches")
                 return None
+            if sig in self.ever:
+                self.recaptures += 1
+            self.ever.add(sig)
             self.cache[sig] = entry
             while len(self.cache) > max(CACHE, 1):
-                self.cache.popitem(last=False)            # least recently used: its graphs and their private pools are released
+                old_sig, _ = self.cache.popitem(last=False)   # least recently used: its graphs and their private pools are released
+                self.counts.pop(old_sig, None)                # ... and it has to earn its warm-up iterations again
+                self.evictions += 1
         self.cache.move_to_end(sig)
         if getattr(self.opt, "_replay_state", None) is not None:
             # the previous replayed gradients were neither applied (step) nor dropped (second zero_grad): a loop that accumulates
@@ -163,6 +235,9 @@ class AutoReplay:
         losses, total, pending = entry["stepper"]()
         self.opt._replay_state = {"pending": pending, "zero_grads_seen": 0}
         self.replays += 1
+        from ..modeling.layers import PARAM_EPOCH
+        PARAM_EPOCH[0] += 1      # the replay moved the BatchNorm running statistics through raw pointers: eval-mode caches (layers.py, InferReplay)
+                                 # are stale even if this iteration's update is dropped
         names = list(losses.keys())
         out = _Replayed.apply(self.anchor, self, *[losses[k].detach() for k in names])     # detached: nothing upstream of the node
         from ...d2.events import get_event_storage, has_event_storage

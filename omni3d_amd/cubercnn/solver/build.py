@@ -9,6 +9,8 @@ bucket (`param.grad` are views, so the training script's per-parameter NaN scan 
 still works), and `step()` is one fused kernel per group.  The flat gradient bucket is also what the
 data-parallel all-reduce operates on (one RCCL call, no per-tensor launches), and a fused non-finite scan of
 it can gate the step on the device."""
+import os
+
 import torch
 
 from ...kernels import det
@@ -245,11 +247,26 @@ class _FlatOptimizer(torch.optim.Optimizer):
             return
         self.all_reduce_finish(self.all_reduce_begin("early", group) + self.all_reduce_begin("late", group), group)
 
-    EXCHANGE_CHUNK = 8 << 20        # elements per all-reduce call (32 MB): a stage's range is issued in pieces RCCL can pipeline
+    # elements per all-reduce call (default 32 MB): a stage's range is issued in pieces RCCL can pipeline.  OMNI_EXCHANGE_CHUNK_MB and
+    # OMNI_EXCHANGE_MERGE_FROM are the two knobs the first multi-GPU run may want to sweep: xGMI rings are per-link
+    # bound, so the best piece size is a property of the node, and the last stages' ranges are tiny (0.5 / 0.03 / 0.01 MB: pure latency) --
+    # MERGE_FROM = k sends the ranges of stages k, k + 1, ... together behind the LAST stage instead of one call sequence per stage.
+    # Both must be the same on every rank (they are part of the call sequence); the defaults are the round-4 behaviour.
+    EXCHANGE_CHUNK = max(1, int(float(os.environ.get("OMNI_EXCHANGE_CHUNK_MB", "32")) * (1 << 18)))
+    EXCHANGE_MERGE_FROM = int(os.environ.get("OMNI_EXCHANGE_MERGE_FROM", "-1"))
+    exchange_timing = False         # bench.py, N > 1: device-side events around the waits of all_reduce_finish (exchange_report)
+
+    def exchange_stages(self, k):
+        """backward stages whose ranges go out behind stage k (see EXCHANGE_MERGE_FROM)"""
+        m, last = self.EXCHANGE_MERGE_FROM, self.n_stages - 1
+        if m < 0 or m >= last or k < m:
+            return [k]
+        return list(range(m, self.n_stages)) if k == last else []
 
     def exchange_chunks(self, stages):
         """-> [(start, end)] of the given backward stages, stage by stage, class by class, cut into EXCHANGE_CHUNK pieces.  A function
-        of the bucket layout alone: every rank issues the same sequence whether it replays a captured step or runs eager launches."""
+        of the bucket layout (and the two environment knobs) alone: every rank issues the same sequence whether it replays a captured
+        step or runs eager launches."""
         out = []
         for k in stages:
             for s, e in self.stage_ranges.get(k, []):
@@ -276,7 +293,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         elif isinstance(which, tuple):
             stages = list(range(int(which[1]), self.n_stages))
         else:
-            stages = [int(which)]
+            stages = self.exchange_stages(int(which))
         return [(dist.all_reduce(self.flat_grad[s:e], group=group, async_op=True), s, e) for s, e in self.exchange_chunks(stages)]
 
     def all_reduce_finish(self, pending, group=None, defer_scale=False):
@@ -287,12 +304,32 @@ class _FlatOptimizer(torch.optim.Optimizer):
         if not pending:
             return
         scale = 1.0 / dist.get_world_size(group)
+        timed = self.exchange_timing and self.flat_grad.is_cuda
+        if timed:       # how long the consuming stream really waits for the exchange = the part of it that did NOT overlap with backward
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for work, s, e in pending:
             work.wait()
             if not defer_scale:
                 self.flat_grad[s:e].mul_(scale)
+        if timed:
+            ev[1].record()
+            self._exchange_events = (getattr(self, "_exchange_events", []) + [(ev, len(pending), sum(e - s for _, s, e in pending))])[-64:]
         if defer_scale:
             self._grad_scale = scale
+
+    def exchange_report(self, last=20):
+        """-> what the timed steps' exchanges looked like from the consuming stream (None if nothing was timed)"""
+        evs = getattr(self, "_exchange_events", [])[-last:]
+        if not evs:
+            return None
+        torch.cuda.synchronize()
+        return {"exposed_ms": sum(a.elapsed_time(b) for (a, b), _, _ in evs) / len(evs), "steps": len(evs),
+                "all_reduce_calls_per_step": evs[-1][1], "bytes_per_step": 4 * evs[-1][2], "chunk_mb": self.EXCHANGE_CHUNK / (1 << 18),
+                "merge_from_stage": self.EXCHANGE_MERGE_FROM,
+                "stage_range_mb": {k: round(4 * sum(e - s for s, e in v) / 1e6, 3) for k, v in sorted(getattr(self, "stage_ranges", {}).items())},
+                "note": "exposed_ms: device time between the events around the waits of all_reduce_finish -- the share of the exchange that "
+                        "backward did not hide"}
 
     @torch.no_grad()
     def check_nonfinite(self, flag):

@@ -65,6 +65,13 @@ POOL_CUT = __import__("os").environ.get("OMNI_PIPE_POOL_CUT", "1") != "0"
 _PIPE_TIMING = __import__("os").environ.get("OMNI_PIPE_TIMING", "0") == "1"
 
 
+def set_pipe_timing(flag):
+    """bench.py turns the device timestamps on for every N > 1 run: the first multi-GPU curve should say WHERE a step spends its time
+    (per stage: end of the critical-path graph M_k, of the weight-gradient graph W_k, of stage k's all-reduce X_k)"""
+    global _PIPE_TIMING
+    _PIPE_TIMING = bool(flag)
+
+
 def pipe_timing_report(graphed, last=10):
     """OMNI_PIPE_TIMING=1: mean over the last steps of, per stage, when M_k / W_k ended on the device (ms after the step's first
     launch) and how long the host spent inside each graph launch (us) -- without a profiler attached"""
@@ -77,13 +84,31 @@ def pipe_timing_report(graphed, last=10):
     for k in range(n):
         m = sum(r["t0"].elapsed_time(r["m"][k]) for r in recs) / len(recs)
         w = [r["t0"].elapsed_time(r["w"][k]) for r in recs if r["w"][k] is not None]
-        out.append("M%d end %.3f ms%s" % (k, m, (", W%d end %.3f ms" % (k, sum(w) / len(w))) if w else ""))
+        x = [r["t0"].elapsed_time(r["x"][k]) for r in recs if r.get("x") and r["x"][k] is not None]
+        out.append("M%d end %.3f ms%s%s" % (k, m, (", W%d end %.3f ms" % (k, sum(w) / len(w))) if w else "",
+                                            (", X%d end %.3f ms" % (k, sum(x) / len(x))) if x else ""))
     host = {}
     for r in recs:
         for name, us in r["host"]:
             host.setdefault(name, []).append(us)
     out.append("host us per launch: " + ", ".join("%s %.0f" % (k, sum(v) / len(v)) for k, v in host.items()))
     return " | ".join(out)
+
+
+def pipe_timing_table(graphed, last=10):
+    """the same as numbers: {"M_end_ms": [...], "W_end_ms": [...], "X_end_ms": [...]} (None where a stage has no such part)"""
+    torch.cuda.synchronize()
+    recs = getattr(graphed, "_timing", [])[-last:]
+    if not recs:
+        return None
+
+    def mean(key, k):
+        v = [r["t0"].elapsed_time(r[key][k]) for r in recs if r.get(key) and r[key][k] is not None]
+        return sum(v) / len(v) if v else None
+    n = len(recs[0]["m"])
+    return {"M_end_ms": [mean("m", k) for k in range(n)], "W_end_ms": [mean("w", k) for k in range(n)], "X_end_ms": [mean("x", k) for k in range(n)],
+            "steps": len(recs), "note": "device timestamps after the step's first launch: end of stage k's critical-path graph (M), of its "
+                                        "weight-gradient graph (W) and of the all-reduce calls issued behind it (X)"}
 _MASKED_STREAMS = []
 
 
@@ -527,7 +552,7 @@ class GraphedPipelined:
         timing = _PIPE_TIMING          # diagnostic (OMNI_PIPE_TIMING=1): device timestamps of every M_k / W_k end, see pipe_timing_report
         if timing:
             import time
-            rec = {"t0": torch.cuda.Event(enable_timing=True), "m": [], "w": [None] * n, "host": []}
+            rec = {"t0": torch.cuda.Event(enable_timing=True), "m": [], "w": [None] * n, "x": [None] * n, "host": []}
             rec["t0"].record(main)
             self._timing.append(rec)
         if self.prologue is not None:
@@ -557,8 +582,20 @@ class GraphedPipelined:
                 # stage k's gradients are final after W_k: their all-reduce rides behind it on the side stream and overlaps the
                 # stages below (round 3: only the heads' ranges did, the backbone's 75 MB went out after the last stage)
                 if self._replay_per_stage:
-                    return self.optimizer.all_reduce_begin(k, self.group)
-                return self.optimizer.all_reduce_begin("early", self.group) if k == 0 else []
+                    handles = self.optimizer.all_reduce_begin(k, self.group)
+                else:
+                    handles = self.optimizer.all_reduce_begin("early", self.group) if k == 0 else []
+                if timing and handles:
+                    # when did stage k's exchange finish?  A probe stream waits for the collectives (work.wait() is a stream-level
+                    # wait for RCCL) and records -- neither the main nor the weight-gradient stream is held up by the measurement
+                    if getattr(self, "_probe", None) is None:
+                        self._probe = torch.cuda.Stream()
+                    with torch.cuda.stream(self._probe):
+                        for h in handles:
+                            h[0].wait()
+                        rec["x"][k] = torch.cuda.Event(enable_timing=True)
+                        rec["x"][k].record(self._probe)
+                return handles
 
         # host order M_0, M_1, W_0, M_2, W_1, ...: the next critical-path graph is always queued on the main stream before the
         # side-stream launch that depends on an event (measured: a graph launch behind a cross-stream event delays every

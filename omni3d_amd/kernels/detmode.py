@@ -77,6 +77,18 @@ def counters(like, n):
     return c
 
 
+def nonzero_counters():
+    """-> [(key, non-zero entries)] over every persistent arrival-counter block (host sync: tests and OMNI_DET_SELFCHECK only).  The
+    deterministic split reductions rely on every counter being zero on entry and leave it zero on exit (csrc/split_reduce.h); a launch
+    that faulted, or whose plan and launch calls disagreed on the split count, would leave one behind and silently corrupt every
+    later reduction of that stream / graph family.  tests/test_determinism.py asserts this list is empty after full
+    training steps; OMNI_DET_SELFCHECK=1 checks the block a launch is about to use and raises."""
+    return [(k, int((c != 0).sum())) for k, c in _counters.items() if bool((c != 0).any())]
+
+
+_SELFCHECK = os.environ.get("OMNI_DET_SELFCHECK", "0") == "1"
+
+
 def prewarm(device, families=("M", "W")):
     """allocate the graph families' counter blocks BEFORE a capture starts (graphed.py)"""
     dev = torch.device(device)
@@ -97,5 +109,14 @@ def workspace(like, plan):
     """plan = the four values a `*_det` entry point reported -> (ws tensor or None, ws_floats, counter tensor, n_ctr)"""
     n_ctr, ws_floats = int(plan[2]), int(plan[3])
     ws = torch.empty(ws_floats, dtype=torch.float32, device=like.device) if ws_floats > 0 else None
+    if n_ctr <= 0 and ws_floats <= 0:
+        # no split: the launch needs neither slots nor counters, only a non-null `ctr` to select the deterministic entry's behaviour --
+        # any already-existing block will do, and nothing is allocated (inside a capture: no extra fill node)
+        existing = _counters.get(_key(like))
+        if existing is not None:
+            return None, 0, existing, 1
     ctr = counters(like, max(n_ctr, 1))
+    if _SELFCHECK and like.is_cuda and not torch.cuda.is_current_stream_capturing() and bool((ctr != 0).any()):
+        raise RuntimeError("omni3d_amd: arrival counters of a deterministic reduction are not zero on entry (an earlier launch of this "
+                           f"stream faulted or was planned with another split count): {int((ctr != 0).sum())} entries")
     return ws, ws_floats, ctr, max(n_ctr, 1)

@@ -211,3 +211,74 @@ def test_reference_loop_full_size_replay_equals_eager_gpu(hip_lib):
     for (na, ba), (nb, bb) in zip(model_a.named_buffers(), model_b.named_buffers()):
         if ba.dtype.is_floating_point and ba.numel():
             assert (ba - bb).abs().max() <= 1e-3 * max(1.0, float(bb.abs().max())), na
+
+
+def test_thrash_guard_escalates_and_freezes(monkeypatch):
+    """more size buckets than cache entries.  The capture itself is stubbed -- this is the cache's state machine: an
+    evicted bucket must earn its warm-up again, a window of mostly-missing iterations first coarsens the buckets above the threshold,
+    then stops capturing new ones; cached buckets keep replaying, everything else goes down the eager path; one warning per level."""
+    import warnings
+
+    from omni3d_amd.cubercnn.solver import autoreplay as AR
+
+    class _Opt:
+        _replay_state = None
+
+    class _Model:
+        training = True
+        device = torch.device("cpu")
+        feature_cut = None
+
+        def flush_logs(self, storage):
+            pass
+
+    monkeypatch.setattr(AR, "CACHE", 4)
+    monkeypatch.setattr(AR, "GUARD_WINDOW", 16)
+    monkeypatch.setattr(AR, "GUARD_MISS", 0.25)
+    monkeypatch.setattr(AR, "COARSE", 128)
+    monkeypatch.setattr(AR, "COARSE_ABOVE", 256)
+    auto = AR.AutoReplay(_Model(), _Opt(), warm=1)
+    assert auto.granularity == 64
+    captured = []
+
+    def fake_capture(batch, sig):
+        captured.append(sig)
+        auto.captures += 1
+        auto.anchor = torch.zeros(1, requires_grad=True)
+        return {"stepper": lambda: ({"l": torch.zeros(())}, torch.zeros(()), None), "logs": []}
+    monkeypatch.setattr(auto, "_capture", fake_capture)
+    monkeypatch.setattr(auto, "_stage", lambda entry, batch: None)
+
+    def it(h, w):
+        out = auto.forward([{"image": torch.zeros(3, h, w, dtype=torch.uint8)}])
+        auto.opt._replay_state = None        # the loop's optimizer.step()
+        return out is not None
+
+    # steady state inside the cache: 3 buckets, each captured once, then hits only
+    for _ in range(6):
+        for w in (64, 128, 192):
+            it(64, w)
+    assert auto.captures == 3 and auto.evictions == 0 and auto.level == 0 and auto.stats()["hit_rate"] > 0.6
+    # twelve buckets in rotation on a 4-entry cache: evictions reset the counters, the guard escalates twice, captures stop
+    widths = [64 * k for k in range(1, 13)]
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for _ in range(12):
+            for w in widths:
+                it(320, w)
+    msgs = [str(r.message) for r in rec if "omni3d_amd" in str(r.message)]
+    assert len(msgs) == 2 and "rounding extents" in msgs[0] and "no new size bucket" in msgs[1], msgs
+    st = auto.stats()
+    assert auto.level == 2 and st["evictions"] > 0 and st["recaptures"] >= 0 and st["guard_level"] == 2
+    frozen = auto.captures
+    # level 1 merged the extents above 256 into 128-wide buckets: 320 -> 384 high, widths 320 / 384 share one bucket
+    assert auto.signature([{"image": torch.zeros(3, 320, 320)}]) == auto.signature([{"image": torch.zeros(3, 330, 384)}]) == (1, 384, 384)
+    assert auto.signature([{"image": torch.zeros(3, 64, 200)}]) == (1, 64, 256)          # below the threshold: the eager grid
+    for _ in range(3):
+        for w in widths:
+            it(320, w)
+    assert auto.captures == frozen                                                    # nothing new is captured ...
+    cached = next(iter(auto.cache))
+    before = auto.replays
+    assert it(cached[1], cached[2]) and auto.replays == before + 1                    # ... cached buckets still replay
+    assert auto.stats()["eager"] > 0

@@ -374,13 +374,18 @@ def _staged_opt(net):
 
 def _worker_staged(rank, world, port, out, mixed):
     """mixed: rank 0 runs the staged step (an exchange behind every backward stage), rank 1 the plain loop whose step() exchanges the
-    whole bucket -- what a rank whose capture failed does (solver/autoreplay.py).  Same collective sequence, same weights."""
+    whole bucket -- what a rank whose capture failed does (solver/autoreplay.py).  Same collective sequence, same weights.
+    mixed == 2: the same with the round-5 knobs (OMNI_EXCHANGE_MERGE_FROM / OMNI_EXCHANGE_CHUNK_MB): stages >= 1 go out together behind
+    the last stage, in 4 KB pieces -- still one sequence on both ranks."""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _install_emulator()
     from omni3d_amd.cubercnn.solver.graphed import GraphedPipelined
     net = _make_staged_net()
     opt = _staged_opt(net)
+    if mixed == 2:
+        type(opt).EXCHANGE_MERGE_FROM, type(opt).EXCHANGE_CHUNK = 1, 1024
+        assert opt.exchange_stages(0) == [0] and opt.exchange_stages(1) == [] and opt.exchange_stages(2) == [1, 2]
     assert opt.n_stages == 3 and sorted(opt.stage_ranges) == [0, 1, 2]
     calls = []
     real = dist.all_reduce
@@ -407,7 +412,7 @@ def _worker_staged(rank, world, port, out, mixed):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("mixed", [False, True, 2])
 def test_per_stage_exchange_world2(emu_lib, tmp_path, mixed):
     """three backward stages, one exchange per stage behind its backward: replicas bit-identical, equal to the plain loop, and the
     sequence of all-reduce calls (sizes, order) is the same on a rank that runs the staged step and on one that does not"""
@@ -415,6 +420,8 @@ def test_per_stage_exchange_world2(emu_lib, tmp_path, mixed):
     mp.spawn(_worker_staged, args=(world, _free_port(), str(tmp_path), mixed), nprocs=world, join=True)
     r = [torch.load(os.path.join(tmp_path, f"st{int(mixed)}{k}.pt")) for k in range(world)]
     assert r[0]["calls"] == r[1]["calls"] and len(r[0]["calls"]) > 0
+    if mixed == 2:
+        assert max(r[0]["calls"]) <= 1024          # the chunk knob is honoured
     for n in r[0]["p"]:
         assert torch.equal(r[0]["p"][n], r[1]["p"][n]), n
     if not mixed:

@@ -155,3 +155,5 @@ def test_training_step_is_bit_identical_run_to_run_gpu(hip_lib, name):
         assert set(g0) == set(gi)
         bad = [n for n in g0 if not torch.equal(g0[n], gi[n])]
         assert not bad, (len(bad), bad[:8])
+    # every arrival counter the three steps used is back at zero (csrc/split_reduce.h: the protocol's invariant)
+    assert detmode.nonzero_counters() == []
