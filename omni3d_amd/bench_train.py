@@ -310,7 +310,7 @@ def dropin_loop_multiscale(iters=24, pool_size=8, fixed_ms=None):
     if auto is None:
         return {"error": "AutoReplay disabled"}
     pool = [synthetic.make_multiscale_batch(IMS_PER_GPU, 3000 + s, priors=priors) for s in range(pool_size)]
-    sigs = [auto.signature(b) for b in pool]
+    sigs = [auto.signature(b, record=False) for b in pool]
     guard = None
 
     def iteration(it):
@@ -353,7 +353,7 @@ def dropin_loop_multiscale(iters=24, pool_size=8, fixed_ms=None):
     return out
 
 
-def dropin_loop_multiscale_stream(iters=200, fixed_ms=None):
+def dropin_loop_multiscale_stream(iters=320, fixed_ms=None):
     """the same loop on a NON-RECYCLED stream -- `iters` freshly drawn batches (generated before the clock starts,
     never repeated), a cold cache: the timed region contains the eager warm-up iterations of every new size bucket, its capture, the
     evictions of the 16-entry cache and whatever the thrash guard decides (cubercnn/solver/autoreplay.py).  Reported: the cache's own
@@ -393,7 +393,7 @@ def dropin_loop_multiscale_stream(iters=200, fixed_ms=None):
         _sync()
         t1 = time.perf_counter()
     st = auto.stats()
-    px = [s_[1] * s_[2] for s_ in (auto.signature(b) for b in stream)]
+    px = [s_[1] * s_[2] for s_ in (auto.signature(b, record=False) for b in stream)]
     out = {"iterations": iters, "ms_per_iteration_whole_region": 1e3 * (t1 - t0) / iters,
            "ms_per_iteration_last_quarter": 1e3 * (t1 - marks[0][0]) / (iters // 4) if marks else None,
            "replayed_in_last_quarter": (auto.replays - marks[0][1]) if marks else None, "last_quarter_iterations": iters // 4,
@@ -525,7 +525,7 @@ def dominant_kernel_roofline(iters=20):
         # the same (kernel, grid) INSIDE the step, beside the other stream's work: average duration in the committed table of one
         # replayed step (in-step fractions next to the isolated ones).  step_gflop: flops of the AVERAGE launch of
         # that row when it mixes shapes (the two fc1 weight gradients share a grid)
-        row = step_rows.get((sym[:60], step_grid if step_grid is not None else f"{grid}x1x1"))
+        row = None if step_grid is False else step_rows.get((sym[:60], step_grid if step_grid is not None else f"{grid}x1x1"))
         if row is not None:
             gf = step_gflop if step_gflop is not None else fl / 1e9
             r["in_step"] = {"launches_per_step": row[0], "avg_us": row[1], "tflops": gf * 1e9 / (row[1] * 1e-6) / 1e12,
@@ -577,25 +577,26 @@ def dominant_kernel_roofline(iters=20):
             "36x[1024x256]x[256x256]^T (3x3 256->256 @64x64, F(4x4,3x3))", 2.0 * 36 * 1024 * 256 * 256,
             lambda: wino.gemm_batched(V5, U4), grid=589824, alg_bytes=4.0 * (2 * 36 * 1024 * 256 + 36 * 256 * 256), per_step=4),
         fam("Winograd weight-gradient GEMMs", "gemm_tn_pf_kernel<4>", "36x[256x4096]x[4096x256] (same layer)", flops,
-            lambda: wino.gemm_batched_wgrad(V, dM), grid=147456),      # (PMC: the three weight-gradient shapes share the geometry
+            lambda: wino.gemm_batched_wgrad(V, dM), grid=147456, step_grid=False),      # (PMC: the three weight-gradient shapes share the geometry
                                                                         #  576 workgroups -> one averaged row)
         fam("FC forward (fc1-class)", "gemm_engine_kernel<0, 0, 128, 128, false>", "[2048x12544]x[1024x12544]^T box-head fc1 (128 tiles x 2 reduction halves = one round of 256 workgroups)",
             2.0 * 2048 * 12544 * 1024, lambda: conv.linear_fwd(x1, w1, None), pmc_key="gemm_engine_kernel<0, 0, 128, 128, false>", grid=65536),
         fam("FC data gradient (the engine's NN form reading W as it is, balanced work split)", "gemm_engine_kernel<0, 1, 128, 128, true>",
             "[2048x1024]x[1024x12544] box-head fc1 (1568 tiles = 6 per workgroup + 32 tiles cut in 8)",
-            2.0 * 2048 * 12544 * 1024, lambda: conv.linear_dgrad(dy1, w1), pmc_key="gemm_engine_kernel<0, 1, 128, 128, true>", grid=65536),
+            2.0 * 2048 * 12544 * 1024, lambda: conv.linear_dgrad(dy1, w1), pmc_key="gemm_engine_kernel<0, 1, 128, 128, true>", grid=65536,
+            step_gflop=(2.0 * (2048 + 512) * 12544 * 1024) / 2 / 1e9),       # (in the step: the box head's and the cube head's launch, averaged)
         fam("FC weight gradient (round 5: the 128x64 tile kernel on the weight-gradient stream -- the engine's balanced form held 410 registers "
             "per lane on every CU and stalled the main stream, kernels/conv.py; accumulated into the gradient bucket; in the step the row averages "
             "the box head's 2048-row and the cube head's 512-row launch)", "conv_wgrad_kernel<128, 64, 2, 2, 32>",
             "[1024x2048]x[2048x12544] box-head fc1 (8 x 196 tiles)", 2.0 * 2048 * 12544 * 1024,
             lambda: conv.linear_wgrad(x1, dy1, accum_into=gacc1), grid=401408, per_step=2, step_gflop=(2.0 * (2048 + 512) * 12544 * 1024) / 2 / 1e9),
         fam("Winograd weight-gradient GEMMs, small maps", "gemm_tn_pf_kernel<4>", "36x[128x1024]x[1024x128] (DLA level 3)", fl3,
-            lambda: wino.gemm_batched_wgrad(V3, dM3), grid=147456),
+            lambda: wino.gemm_batched_wgrad(V3, dM3), grid=147456, step_grid=False),
         fam("Winograd weight-gradient GEMMs, small maps (DLA level 4)", "gemm_tn_pf_kernel<4>", "36x[256x256]x[256x256] (DLA level 4)", fl4,
-            lambda: wino.gemm_batched_wgrad(V4, dM4), grid=147456),
+            lambda: wino.gemm_batched_wgrad(V4, dM4), grid=147456, step_grid=False),
         fam("direct conv 64x64 tiles (23 launches / step: the stride-2 3x3 and the 1x1 root / projection / lateral layers)", "conv_fwd_kernel<64, 64, 2, 2, 32, 1>",
             "3x3/s2 64->128 @128x128 (DLA level 3 entry)", 2.0 * B * 64 * 64 * 128 * 64 * 9,
-            lambda: conv.conv2d_fwd(xs, ws, None, 2, 1), grid=131072, per_step=23),
+            lambda: conv.conv2d_fwd(xs, ws, None, 2, 1), grid=131072, per_step=23, step_grid=False),     # (six shapes share this grid in the step)
         fam("direct dgrad 64x64 tiles (20 launches / step)", "conv_dgrad_kernel<64, 64, 2, 2, 32>", "3x3/s2 64->128 @128x128 (four parity classes in grid.z)",
             2.0 * B * 64 * 64 * 128 * 64 * 9, lambda: conv.conv2d_dgrad(dys, ws, (128, 128), 2, 1), grid=131072, step_grid="32768x1x4", per_step=20),
         fam("direct wgrad 128x64 tiles (VERDICT r4 missing 2: the #2 symbol of the round-4 table; 23 launches / step on the weight-gradient stream)",

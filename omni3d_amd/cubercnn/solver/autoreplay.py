@@ -49,19 +49,25 @@ CACHE = int(os.environ.get("OMNI_AUTO_REPLAY_CACHE", "16"))           # captured
 # copies block the host until the previous step has drained, which costs 0.3 ms per iteration with the losses read every 1000th
 PINNED = os.environ.get("OMNI_AUTO_REPLAY_PINNED", "0") == "1"
 BUCKET = 64                                                           # ImageList's padding granularity (FPN size divisibility)
-# Thrash guard (round 5): real Omni3D training draws 25 short edges x the datasets' aspect ratios -- far more padded
-# (height, width) pairs than the cache holds.  A capture costs several eager steps (three muted warm-up passes + seven captured
-# stages) and stalls the peer ranks that wait in their all-reduce, so a cache that keeps evicting what it is about to need is worse
-# than no cache.  Watched over a sliding window of GUARD_WINDOW training iterations:
-#   level 0  buckets of 64 x 64 (what the eager pass pads to: replay and eager see the same tensor);
-#   level 1  (captures + iterations of not-yet-captured buckets exceed GUARD_MISS of the window) extents above COARSE_ABOVE are rounded
-#            up to COARSE (128): fewer, slightly larger buckets -- the images sit in larger zero-padded slots, which the model treats
-#            like a batch whose largest image is that much larger;
-#   level 2  (still thrashing a window later) no NEW bucket is captured any more: cached buckets replay, everything else runs eager.
-# One warning per escalation.  An evicted bucket has to earn its `warm` eager iterations again (its counter is reset).
-GUARD_WINDOW = int(os.environ.get("OMNI_AUTO_REPLAY_WINDOW", "64"))
+# Thrash guard (round 5): real Omni3D training draws 25 short edges x the datasets' aspect ratios -- 66 padded (height,
+# width) pairs in 200 iterations of the synthetic Omni3D-shaped stream (bench.py `dropin_loop_multiscale_stream`), far more than the
+# cache holds.  A capture costs several eager steps (three muted warm-up passes + seven captured stages), stalls the peer ranks that
+# wait in their all-reduce, and an eager iteration on a never-seen shape is ~15x a replayed one: a cache that keeps evicting what it
+# is about to need is worse than no cache, and a coarser grid that FITS the cache is far better than either -- the images sit in
+# larger zero-padded slots (masked on the device with their real sizes), which the model treats like a batch whose largest image is
+# that much larger.  Watched over a sliding window of GUARD_WINDOW training iterations; whenever the share of iterations that did
+# not replay a cached bucket exceeds GUARD_MISS the guard moves one level up (at most once per window, one warning each):
+#   level 0  buckets on the grid the eager pass pads to (64: replay and eager see the same tensor);
+#   level k  extents above GRID_ABOVE rounded up to GRIDS[k - 1] (128, 256: at most ~3 x 6 buckets for Base.yaml's sizes).  The guard
+#            does not climb one grid per window: it replays the extents of the last iterations under every candidate grid and takes
+#            the FINEST one whose bucket count fits three quarters of the cache (measured on the 200-iteration stream: stepping
+#            128 -> 256 one window at a time was still missing half the iterations when the run ended);
+#   last     no NEW bucket is captured any more: cached buckets replay, everything else runs eager launches.
+# An evicted bucket has to earn its `warm` eager iterations again (its counter is reset).
+GUARD_WINDOW = int(os.environ.get("OMNI_AUTO_REPLAY_WINDOW", "48"))
 GUARD_MISS = float(os.environ.get("OMNI_AUTO_REPLAY_MISS", "0.25"))
-COARSE, COARSE_ABOVE = int(os.environ.get("OMNI_AUTO_REPLAY_COARSE", "128")), int(os.environ.get("OMNI_AUTO_REPLAY_COARSE_ABOVE", "512"))
+GRIDS = tuple(int(v) for v in os.environ.get("OMNI_AUTO_REPLAY_GRIDS", "128,256").split(",") if v)
+GRID_ABOVE = int(os.environ.get("OMNI_AUTO_REPLAY_GRID_ABOVE", "256"))
 ROW_FIELDS = ("gt", "gt_cls", "gt3d", "gtpose", "ign")           # (rows, ...) arrays indexed through gt_off / ign_off
 FIXED_FIELDS = ("gt_off", "ign_off", "Ks", "v2r", "ratio", "image_hw")
 
@@ -131,6 +137,8 @@ class AutoReplay:
         self.level_at = 0                        # iteration count at the last escalation
         self.iters = 0
         self.granularity = self._model_bucket(model)
+        self.extents = []                        # (batch size, max height, max width) of the recent iterations (see _note)
+        self.evictions_at_level = 0
         self.holders = []                        # inner graphs of the eager iterations' loss dicts (see _Boundary)
         self._eager_anchor = None
         self.busy = False                        # True while a capture drives the model itself
@@ -144,18 +152,28 @@ class AutoReplay:
         div = int(getattr(getattr(model, "backbone", None), "size_divisibility", 0) or 0)
         return div if div > 0 else BUCKET
 
-    def signature(self, batch):
+    def signature(self, batch, record=True):
         """(batch size, padded height, padded width): what every shape behind ImageList.from_tensors depends on"""
         H = max(b["image"].shape[-2] for b in batch)
         W = max(b["image"].shape[-1] for b in batch)
+        if not record:
+            return self._bucket(len(batch), H, W, self.level)
+
+        self.extents.append((len(batch), H, W))
+        if len(self.extents) > 4 * GUARD_WINDOW:
+            del self.extents[: len(self.extents) - 4 * GUARD_WINDOW]
+        return self._bucket(len(batch), H, W, self.level)
+
+    def _bucket(self, B, H, W, level):
         g = self.granularity
+        coarse = GRIDS[min(level, len(GRIDS)) - 1] if (level >= 1 and GRIDS) else 0
 
         def up(v):
             q = -(-v // g) * g
-            if self.level >= 1 and q > COARSE_ABOVE and COARSE % g == 0:
-                q = -(-v // COARSE) * COARSE
+            if coarse and q > GRID_ABOVE and coarse % g == 0:
+                q = -(-v // coarse) * coarse
             return q
-        return (len(batch), up(H), up(W))
+        return (B, up(H), up(W))
 
     def stats(self):
         """what the cache did so far (bench.py `dropin_loop_multiscale`, tests)"""
@@ -170,19 +188,31 @@ class AutoReplay:
         self.window.append(bool(hit))
         if len(self.window) > GUARD_WINDOW:
             self.window.pop(0)
-        if self.level >= 2 or len(self.window) < GUARD_WINDOW or self.iters - self.level_at < GUARD_WINDOW:
+        if self.level > len(GRIDS) or len(self.window) < GUARD_WINDOW or self.iters - self.level_at < GUARD_WINDOW:
             return
-        if len(self.cache) < max(CACHE, 1) and self.evictions == 0:
-            return                                # still filling the cache for the first time: misses are warm-up, not thrash
+        if len(self.cache) < max(CACHE, 1) and self.evictions == self.evictions_at_level:
+            return                                # still filling the cache (for the first time on this grid): misses are warm-up, not thrash
         miss = 1.0 - sum(self.window) / len(self.window)
         if miss <= GUARD_MISS:
             return
         import warnings
-        self.level += 1
+        seen = len(self.counts)
+        # the finest grid above the current one under which the recent extents fit 3/4 of the cache; none does: the coarsest, then freeze
+        nxt = self.level + 1
+        while nxt < len(GRIDS) and len({self._bucket(*e, nxt) for e in self.extents}) > 0.75 * max(CACHE, 1):
+            nxt += 1
+        self.level = nxt
         self.level_at = self.iters
-        if self.level == 1:
+        if self.level <= len(GRIDS):
+            # the buckets of the finer grid will not be asked for again: release their graphs, and let the new grid fill the cache like
+            # a fresh start (misses while it fills are warm-up, not thrash: see the test above)
+            self.cache.clear()
+            self.counts.clear()
+            self.window.clear()
+            self.evictions_at_level = self.evictions
+        if self.level <= len(GRIDS):
             warnings.warn(f"omni3d_amd: {miss:.0%} of the last {GUARD_WINDOW} iterations missed the {CACHE}-entry cache of captured training "
-                          f"steps ({len(self.counts)} size buckets seen): rounding extents above {COARSE_ABOVE} up to {COARSE} from now on")
+                          f"steps ({seen} size buckets seen): rounding extents above {GRID_ABOVE} up to {GRIDS[self.level - 1]} from now on")
         else:
             warnings.warn(f"omni3d_amd: the captured-step cache still misses {miss:.0%} of the iterations; no new size bucket is captured "
                           "any more (cached buckets replay, the rest runs eager launches).  OMNI_AUTO_REPLAY_CACHE raises the cache size")
@@ -198,11 +228,15 @@ class AutoReplay:
             return None
         self._raise_if_poisoned()
         sig = self.signature(batched_inputs)
-        self.counts[sig] = self.counts.get(sig, 0) + 1
         entry = self.cache.get(sig)
+        level = self.level
         self._note(entry is not None)
+        if self.level != level:                  # the guard changed the grid (and emptied the cache): this batch's bucket on the new one
+            sig = self.signature(batched_inputs, record=False)
+            entry = self.cache.get(sig)
+        self.counts[sig] = self.counts.get(sig, 0) + 1
         if entry is None:
-            if self.counts[sig] <= self.warm or self.level >= 2:
+            if self.counts[sig] <= self.warm or self.level > len(GRIDS):
                 self.eager_iters += 1
                 return None
             try:

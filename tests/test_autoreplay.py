@@ -235,8 +235,8 @@ def test_thrash_guard_escalates_and_freezes(monkeypatch):
     monkeypatch.setattr(AR, "CACHE", 4)
     monkeypatch.setattr(AR, "GUARD_WINDOW", 16)
     monkeypatch.setattr(AR, "GUARD_MISS", 0.25)
-    monkeypatch.setattr(AR, "COARSE", 128)
-    monkeypatch.setattr(AR, "COARSE_ABOVE", 256)
+    monkeypatch.setattr(AR, "GRIDS", (128,))
+    monkeypatch.setattr(AR, "GRID_ABOVE", 256)
     auto = AR.AutoReplay(_Model(), _Opt(), warm=1)
     assert auto.granularity == 64
     captured = []
