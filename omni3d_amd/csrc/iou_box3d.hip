@@ -19,6 +19,14 @@
 #include <device_rt.h>
 #pragma clang fp contract(off)
 
+#if defined(OMNI_HIPEMU) && defined(IOU_DEBUG_HIST)
+// (host-emulator instrumentation of tools/iou3d_list_sizes.py: sizes of the joint triangle list entering each plane pass / the dedupe
+// phase, and the rounds of the clipping code all waves execute)
+int g_iou_hist[7][128], g_iou_rounds[2];
+extern "C" int* omni_debug_iou_hist() { return &g_iou_hist[0][0]; }
+extern "C" int* omni_debug_iou_rounds() { return g_iou_rounds; }
+#endif
+
 namespace {
 
 constexpr float K_EPS = 1e-8f;
@@ -244,7 +252,13 @@ __device__ __forceinline__ void iou_pair_body(PairLds<CAPT>& L, const bool act, 
         float* dst = L.tri[cur ^ 1];
         int base = 0, newA = 0;
         const int nmax = group_max(n);
+#if defined(OMNI_HIPEMU) && defined(IOU_DEBUG_HIST)
+        if (act && sl == 0) ++g_iou_hist[f][n < 127 ? n : 127];
+#endif
         for (int i0 = 0; i0 < nmax; i0 += SUB) {
+#if defined(OMNI_HIPEMU) && defined(IOU_DEBUG_HIST)
+            if (lane == 0) ++g_iou_rounds[0];
+#endif
             const int i = i0 + sl;
             int cnt = 0;
             Tri o0, o1;
@@ -271,6 +285,9 @@ __device__ __forceinline__ void iou_pair_body(PairLds<CAPT>& L, const bool act, 
         cur ^= 1;
         __syncthreads();
     }
+#if defined(OMNI_HIPEMU) && defined(IOU_DEBUG_HIST)
+    if (act && sl == 0) ++g_iou_hist[6][n < 127 ? n : 127];
+#endif
     const float* T = L.tri[cur];
     float* aux = L.tri[cur ^ 1];                 // spare list: normals | areas | keep flags of the dedupe phase
     float* nrm = aux;

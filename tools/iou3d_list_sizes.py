@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Sizes of the joint triangle list of the IoU3D kernel entering each of its six plane passes and its dedupe phase, on the bench
+workload's pair distribution: an instrumented HOST-EMULATOR build of csrc/iou_box3d.hip (-DIOU_DEBUG_HIST), no GPU needed.
+The kernel runs 32 lanes per pair, so a list longer than 32 costs a second, sparsely filled round of the whole clipping code."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from omni3d_amd import boxgen  # noqa: E402
+
+emu = os.path.join(ROOT, "tests", "hipemu")
+cxx = "/opt/rocm/lib/llvm/bin/clang++"
+subprocess.check_call(["make", "-s", "-C", emu, "-j8"])
+subprocess.check_call([cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-I" + emu, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "omni3d_amd", "csrc"),
+                       "-Wno-unused-function", "-Wno-unknown-pragmas", "-fno-strict-aliasing", "-DIOU_DEBUG_HIST", "-c",
+                       os.path.join(ROOT, "omni3d_amd", "csrc", "iou_box3d.hip"), "-o", "/tmp/iou_dbg.o"])
+subprocess.check_call([cxx, "-shared", "-fPIC", "-o", "/tmp/libiou_dbg.so", "/tmp/iou_dbg.o", os.path.join(emu, "_build", "hipemu.o")])
+lib = ctypes.CDLL("/tmp/libiou_dbg.so")
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
+dt, gt, _ = boxgen.omni3d_like_pairs(np.random.default_rng(1000), P)
+d, g = np.ascontiguousarray(dt, dtype=np.float32), np.ascontiguousarray(gt, dtype=np.float32)
+ar = np.arange(P, dtype=np.int32)
+vol, iou, ov = np.zeros(P, np.float32), np.zeros(P, np.float32), np.zeros(1, np.int32)
+lib.omni_debug_iou_rounds.restype = ctypes.POINTER(ctypes.c_int)
+lib.omni_debug_iou_hist.restype = ctypes.POINTER(ctypes.c_int)
+f = lib.omni_iou_box3d_pairs_algo
+f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_longlong] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p]
+rounds = {}
+for variant in (1064, 1032):       # one pair per wave | two pairs per wave (the production form: joint plane passes since round 5)
+    lib.omni_debug_iou_rounds()[0] = 0
+    ctypes.memset(lib.omni_debug_iou_hist(), 0, 7 * 128 * 4)
+    rc = f(d.ctypes.data, g.ctypes.data, ar.ctypes.data, ar.ctypes.data, P, None, vol.ctypes.data, iou.ctypes.data, ov.ctypes.data, variant, None)
+    rounds[variant] = lib.omni_debug_iou_rounds()[0]
+h = np.ctypeslib.as_array(lib.omni_debug_iou_hist(), shape=(7, 128)).copy()
+print("rounds of the clipping code (all waves, all six passes):", rounds)
+print(f"rc {rc}; {P} pairs, {int(h[0].sum())} reach the clipping passes, {int((iou > 0).sum())} with IoU > 0")
+n = np.arange(128)
+for k in range(7):
+    c = h[k]
+    tot = max(c.sum(), 1)
+    cum = np.cumsum(c) / tot
+    print(f"{'entering pass %d' % k if k < 6 else 'after pass 5  '}: mean {float((c * n).sum() / tot):5.1f}  P(n = 0) {c[0] / tot:.2f}  P(n > 32) {c[33:].sum() / tot:.2f}  "
+          f"P(n > 48) {c[49:].sum() / tot:.2f}  P(n > 64) {c[65:].sum() / tot:.2f}  median {int(np.searchsorted(cum, 0.5))}  p90 {int(np.searchsorted(cum, 0.9))}")
