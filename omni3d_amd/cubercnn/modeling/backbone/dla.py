@@ -32,7 +32,7 @@ class ConvBNReLU(nn.Sequential):
         conv, bn = self[0], self[1]
         w = conv.weight
         if x.shape[1] != w.shape[1]:   # 3-channel stem weight against the 4-channel padded image
-            w = torch.cat([w, w.new_zeros(w.shape[0], x.shape[1] - w.shape[1], w.shape[2], w.shape[3])], dim=1)
+            w = HF.pad_input_channels(w, x.shape[1], self.__dict__.setdefault("_w_pad", {}))
         return bn(HF.conv2d(x, w, None, conv.stride[0], conv.padding[0], False, bn.training and torch.is_grad_enabled()), relu=True)
 
 

@@ -138,7 +138,7 @@ class ResNet(Backbone):
     def forward(self, x):
         w = self.conv1.weight
         if x.shape[1] != w.shape[1]:   # 3-channel stem weight against the 4-channel padded image
-            w = torch.cat([w, w.new_zeros(w.shape[0], x.shape[1] - w.shape[1], w.shape[2], w.shape[3])], dim=1)
+            w = HF.pad_input_channels(w, x.shape[1], self.__dict__.setdefault("_w_pad", {}))
         x = self.bn1(HF.conv2d(x, w, None, 2, 3, False, self.bn1.training and torch.is_grad_enabled()), relu=True)
         x = HF.max_pool3s2(x)
         on = self.stage_cut is not None and self.training and torch.is_grad_enabled()

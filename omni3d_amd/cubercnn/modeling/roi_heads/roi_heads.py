@@ -245,6 +245,14 @@ class ROIHeads3D(nn.Module):
         from .inference import roi_heads_inference
         return roi_heads_inference(self, images, feats, proposals, packed), {}
 
+    def _gt_rows(self, sgt):
+        """matched ground-truth row per sampled ROI with the background marker (-1) clamped to row 0, computed ONCE per step for the box
+        and the cube losses (two launches less)"""
+        memo = self.__dict__.get("_gt_rows_memo")
+        if memo is None or memo[0] is not sgt:
+            memo = self.__dict__["_gt_rows_memo"] = (sgt, sgt.clamp(min=0))
+        return memo[1]
+
     def _batch_index(self, B, per_image, device):
         cache = self.__dict__.setdefault("_bidx_cache", {})
         key = (B, per_image, str(device))
@@ -259,7 +267,7 @@ class ROIHeads3D(nn.Module):
         if x is None:
             x = self.box_pooler(feats, rois, self._batch_index(B, S, rois.device))
         pred = self.box_predictor(self.box_head(x))
-        losses = self.box_predictor.losses(pred, scls.reshape(-1), rois, packed, sgt.reshape(-1).clamp(min=0))
+        losses = self.box_predictor.losses(pred, scls.reshape(-1), rois, packed, self._gt_rows(sgt).reshape(-1))
         if self.train_on_pred_boxes:      # roi_heads.py:283-289: the 3D head trains on the (detached) 2D predictions of the GT classes
             with torch.no_grad():
                 sboxes = det.box_decode_gt_class(pred.detach().contiguous(), self.num_classes, scls.reshape(-1).contiguous(), rois.contiguous(),
@@ -287,7 +295,7 @@ class ROIHeads3D(nn.Module):
         Fc = self.fg_cap
         rois = sboxes[:, :Fc].reshape(B * Fc, 4).contiguous()
         cls = scls[:, :Fc].reshape(-1).contiguous()
-        gt_row = sgt[:, :Fc].reshape(-1).clamp(min=0).contiguous()
+        gt_row = self._gt_rows(sgt)[:, :Fc].reshape(-1).contiguous()
         bidx = self._batch_index(B, Fc, rois.device)
         if x is None:
             x = self.cube_pooler(feats, self.scale_proposals(rois), bidx)

@@ -862,10 +862,12 @@ def bn_relu_conv3x3(x, bn, conv_mod, want_stats):
 
 
 _BN_REMASK = _os_environ_get("OMNI_BN_REMASK", "1") != "0"     # A/B knob
-# backward reductions from the data-gradient transform above the layer (wino.transform_output_bn_bwd).  OFF by default: measured
-# neutral on the DLA-34 step (317.9 / 316.2 images/s with, 316.3 without): the transform of a 32x32 / 64x64 map runs on 128-256
-# workgroups and gets 2-3x longer with the extra x reads, which is what the saved reduction launch was worth
-_BN_BWD_FUSE = _os_environ_get("OMNI_BN_BWD_FUSE", "0") != "0"
+# backward reductions from the data-gradient transform above the layer (wino.transform_output_bn_bwd): the F(4x4) output transform that
+# writes a BatchNorm's output gradient also emits that layer's (sum dz, sum dz * xhat) partial rows, so its backward is ONE launch
+# (finalize folded into the apply pass, csrc/bn_pool.hip) instead of a reduction pass + apply.  Round 3 measured it neutral with the
+# separate finalize launch (317.9 / 316.2 images/s with, 316.3 without); round 5, without that launch: 10.905 -> 10.877 ms per step
+# (profiles/r05_ab_bn_fuse.log) -- on by default, OMNI_BN_BWD_FUSE=0 restores the reduction pass.
+_BN_BWD_FUSE = _os_environ_get("OMNI_BN_BWD_FUSE", "1") != "0"
 
 
 class _BatchNorm(Function):
@@ -1003,6 +1005,29 @@ class _CatChannels(Function):
             off += c
             outs.append(_slot_deliver(slot, lambda carry, piece=piece: _add_carry(piece, carry)) if ctx.needs_input_grad[i] else None)
         return tuple(outs)
+
+
+class _PadInputChannels(Function):
+    """(K, C, R, S) filter -> (K, C4, R, S) with zero input channels appended: the 3-channel stem filter against the image padded to
+    4 channels (dla.py:241-245).  The padded copy lives in a persistent buffer whose extra channels stay zero, so a step pays one
+    strided copy instead of a zero-fill + concatenation, and the backward is a view (round 5)."""
+
+    @staticmethod
+    def forward(ctx, w, c4, holder):
+        buf = holder.get("buf")
+        if buf is None or buf.shape[0] != w.shape[0] or buf.shape[1] != c4 or buf.device != w.device or buf.dtype != w.dtype:
+            buf = holder["buf"] = torch.zeros((w.shape[0], c4, w.shape[2], w.shape[3]), dtype=w.dtype, device=w.device).contiguous(memory_format=CL)
+        buf[:, : w.shape[1]].copy_(w)
+        ctx.c = w.shape[1]
+        return buf.detach()          # (a fresh alias per call: the buffer object itself never carries an autograd node)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, : ctx.c], None, None
+
+
+def pad_input_channels(w, c4, holder):
+    return _PadInputChannels.apply(w, c4, holder)
 
 
 def cat_channels(xs):
@@ -1149,11 +1174,31 @@ class LossDict(dict):
             self.vectors += other.vectors
 
 
+class _SumVectors(Function):
+    """sum of all elements of a few small vectors.  Its backward hands every vector ONE contiguous gradient (slices of a single
+    broadcast of the upstream scalar): autograd's own `cat(...).sum()` delivers stride-0 views, and each loss function then paid a
+    copy launch to make its gradient addressable by a kernel (three launches per step, round 5)."""
+
+    @staticmethod
+    def forward(ctx, *vecs):
+        ctx.sizes = [int(v.numel()) for v in vecs]
+        return torch.cat([v.reshape(-1) for v in vecs]).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        flat = g.reshape(1).expand(sum(ctx.sizes)).contiguous()
+        out, off = [], 0
+        for n in ctx.sizes:
+            out.append(flat[off:off + n])
+            off += n
+        return tuple(out)
+
+
 def total_loss(losses):
     """== sum(losses.values()) (up to fp32 summation order)"""
     vecs = getattr(losses, "vectors", None)
     if vecs and sorted(n for _, names in vecs for n in names) == sorted(losses.keys()):
-        return torch.cat([v for v, _ in vecs]).sum()
+        return _SumVectors.apply(*[v for v, _ in vecs])
     return sum(losses.values())
 
 
