@@ -193,6 +193,7 @@ def run_iou3d(args, world, rank):
                      # instruction in flight (committed PMC pass; SQ_* in quad-cycles) -- `frac` above is only the schema's HBM sanity bound
                      "kernel_bound": "valu-issue",
                      "valu_busy_frac_of_simd_cycles": pmc.get("valu_busy_frac_of_simd_cycles") if pmc else None,
+                     "valu_lane_utilisation": pmc.get("valu_lane_utilisation") if pmc else None,
                      "note": "196 B/pair algorithmic I/O; the kernel is VALU / branch bound, not HBM bound: `valu_busy_frac_of_simd_cycles` = "
                              "SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) from the committed PMC pass in `valu`",
                      "valu": pmc},

@@ -114,38 +114,58 @@ __device__ __forceinline__ V3 plane_edge_intersection(V3 pc, V3 normal, V3 p0, V
 // clip one triangle by one face plane; returns 0..2 triangles in o0/o1
 __device__ __forceinline__ int clip_tri(const V3* pv, V3 pc, V3 normal, const Tri& t, Tri& o0, Tri& o1) {
     V3 v0 = t.v[0], v1 = t.v[1], v2 = t.v[2];
-    bool in0 = vdot(vsub(v0, pc), normal) >= 0.0f;
-    bool in1 = vdot(vsub(v1, pc), normal) >= 0.0f;
-    bool in2 = vdot(vsub(v2, pc), normal) >= 0.0f;
-    // coplanar triangle is kept as is
-    V3 nt = tri_normal(t);
-    bool check1 = fabsf(vdot(nt, normal)) > 1.0f - D_EPS;
+    const float d0 = vdot(vsub(v0, pc), normal), d1 = vdot(vsub(v1, pc), normal), d2 = vdot(vsub(v2, pc), normal);
+    bool in0 = d0 >= 0.0f;
+    bool in1 = d1 >= 0.0f;
+    bool in2 = d2 >= 0.0f;
+    // coplanar triangle is kept as is.  The test starts with |nt . normal| > 1 - 1e-3, i.e. the triangle within 2.56 degrees of the plane:
+    // then the plane distances of its vertices differ by at most sin(2.56 deg) = 0.0447 of its longest edge.  Round 5: a triangle whose
+    // distances spread over MORE than 0.05 of the longest edge cannot pass that test, and its normal (three cross products, four
+    // square roots, three divisions: a third of this function) is not computed at all -- most triangles in four of the six passes of
+    // a yaw-rotated box pair; a wave skips the code when none of its lanes needs it.  Conservative (12 % margin, NaNs take the full
+    // test), so every decision is the one the full test makes.
+    const float spread = fmaxf(d0, fmaxf(d1, d2)) - fminf(d0, fminf(d1, d2));
+    const V3 e01 = vsub(v1, v0), e02 = vsub(v2, v0), e12 = vsub(v2, v1);
+    const float l2 = fmaxf(vdot(e01, e01), fmaxf(vdot(e02, e02), vdot(e12, e12)));
+    const bool maybe_parallel = !(spread * spread > 0.0025f * l2);
     bool coplanar = false;
-    if (check1) {
-        V3 d = argmax_dir<4>(t, pv);
-        coplanar = (fabsf(vdot(d, normal)) < D_EPS) || (fabsf(vdot(nt, d)) < D_EPS);
+    if (maybe_parallel) {
+        V3 nt = tri_normal(t);
+        bool check1 = fabsf(vdot(nt, normal)) > 1.0f - D_EPS;
+        if (check1) {
+            V3 d = argmax_dir<4>(t, pv);
+            coplanar = (fabsf(vdot(d, normal)) < D_EPS) || (fabsf(vdot(nt, d)) < D_EPS);
+        }
     }
     if (coplanar || (in0 && in1 && in2)) { o0 = t; return 1; }
     if (!in0 && !in1 && !in2) return 0;
-    int nin = (int)in0 + (int)in1 + (int)in2;
+    const int nin = (int)in0 + (int)in1 + (int)in2;
+    // Two vertices inside: the edges (vi1, vout) and (vi2, vout) are cut; one inside: (vin, vo1) and (vin, vo2).  Both cases are TWO
+    // calls of plane_edge_intersection: the operands are selected first and the calls are shared (round 5) -- the lanes of a wave that
+    // take different cases no longer execute the ~130-instruction intersection code twice with complementary halves masked off.
+    // Same operands into the same function: the same floats.
+    V3 a1, b1, a2, b2;
     if (nin == 2) {
         V3 vout, vi1, vi2;
         if (!in2) { vout = v2; vi1 = v0; vi2 = v1; }
         else if (!in1) { vout = v1; vi1 = v0; vi2 = v2; }
         else { vout = v0; vi1 = v1; vi2 = v2; }
-        V3 p1 = plane_edge_intersection(pc, normal, vi1, vout);
-        V3 p2 = plane_edge_intersection(pc, normal, vi2, vout);
-        o0.v[0] = vi1; o0.v[1] = p1; o0.v[2] = vi2;
-        o1.v[0] = vi2; o1.v[1] = p1; o1.v[2] = p2;
+        a1 = vi1; b1 = vout; a2 = vi2; b2 = vout;
+    } else {
+        V3 vin, vo1, vo2;
+        if (in0) { vin = v0; vo1 = v1; vo2 = v2; }
+        else if (in2) { vin = v2; vo1 = v0; vo2 = v1; }
+        else { vin = v1; vo1 = v0; vo2 = v2; }
+        a1 = vin; b1 = vo1; a2 = vin; b2 = vo2;
+    }
+    const V3 p1 = plane_edge_intersection(pc, normal, a1, b1);
+    const V3 p2 = plane_edge_intersection(pc, normal, a2, b2);
+    if (nin == 2) {
+        o0.v[0] = a1; o0.v[1] = p1; o0.v[2] = a2;
+        o1.v[0] = a2; o1.v[1] = p1; o1.v[2] = p2;
         return 2;
     }
-    V3 vin, vo1, vo2;
-    if (in0) { vin = v0; vo1 = v1; vo2 = v2; }
-    else if (in2) { vin = v2; vo1 = v0; vo2 = v1; }
-    else { vin = v1; vo1 = v0; vo2 = v2; }
-    V3 p1 = plane_edge_intersection(pc, normal, vin, vo1);
-    V3 p2 = plane_edge_intersection(pc, normal, vin, vo2);
-    o0.v[0] = vin; o0.v[1] = p1; o0.v[2] = p2;
+    o0.v[0] = a1; o0.v[1] = p1; o0.v[2] = p2;
     return 1;
 }
 
@@ -218,7 +238,31 @@ __device__ __forceinline__ void iou_pair_body(PairLds<CAPT>& L, const bool act, 
         if (vdot(vsub(ctr, pc), n) < 0.0f) n = vscale(n, -1.0f);
         stv(L.pc[bx][f], pc);
         stv(L.pn[bx][f], n);
-    } else if (act && sl < 14) {
+    }
+    if (SUB >= 32) {
+        // box volumes (round 5): one tetrahedron per sub-lane (24 of them) instead of two lanes walking twelve each -- 360 VALU
+        // instructions with 2 of 32 lanes active were 3 % lane utilisation (profiles/r05_pmc_iou3d.csv: 0.32 over the whole kernel).
+        // The twelve terms of a box are then added in the ORACLE's order (t = 0, 1, ..., 11) by one lane, so the volume is the same float.
+        float term = 0.f;
+        if (act && sl < 24) {
+            const int bx = sl / 12, t = sl % 12;
+            const float* B = L.box[bx];
+            V3 ctr = mk(0.f, 0.f, 0.f);
+            for (int q = 0; q < 8; ++q) { ctr.x += B[3 * q]; ctr.y += B[3 * q + 1]; ctr.z += B[3 * q + 2]; }
+            ctr = vdiv(ctr, 8.0f);
+            V3 a = vsub(ldv(B + 3 * c_box_tris[t][0]), ctr);
+            V3 b = vsub(ldv(B + 3 * c_box_tris[t][1]), ctr);
+            V3 c = vsub(ldv(B + 3 * c_box_tris[t][2]), ctr);
+            term = fabsf(vdot(a, vcross(b, c))) / 6.0f;
+        }
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            v0 += __shfl(term, shift + t, 64);
+            v1 += __shfl(term, shift + 12 + t, 64);
+        }
+        if (act && sl == 0) { L.vol[0] = v0; L.vol[1] = v1; }
+    } else if (act && sl >= 12 && sl < 14) {
         const int bx = sl - 12;
         const float* B = L.box[bx];
         V3 ctr = mk(0.f, 0.f, 0.f);
@@ -533,6 +577,7 @@ __global__ void box3d_validity_kernel(const float* __restrict__ boxes, int N, fl
 // with the full 160-triangle lists), marked pairs redone at full capacity by the retry pass
 constexpr int IOU_VARIANT = 1032;      // (set from tools/bench_iou3d.py: profiles/r03_iou3d_variants*.log)
 
+// (round 5 re-measured on the 100 k-pair workload: 4 / 8 / 16 / 32 / 64 pairs per wave -> 0.640 / 0.585 / 0.544 / 0.659 / 0.746 ms)
 inline int iou_chunk(long long npairs) { return npairs >= 262144 ? 64 : npairs >= 131072 ? 32 : 16; }
 
 inline int iou_grid(long long npairs) {

@@ -28,7 +28,7 @@ def profile_counters(csv_name, kernel_substr, grid=None):
             return None
     out = {"source": f"profiles/{csv_name}", "sha256_16": digest, "kernel": r["kernel"], "grid": int(float(r["grid"]))}
     for k in ("FETCH_SIZE_x2_MB", "WRITE_SIZE_MB", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
-              "SQ_INSTS_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "mfma_flop"):
+              "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "mfma_flop"):
         out[k] = f(k)
     # cycle-based (DVFS-independent) MFMA utilisation: busy SIMD-cycles / (GUI-active cycles per XCD x 1024 SIMDs); GRBM_GUI_ACTIVE is
     # summed over the 8 XCDs on gfx950 (profiles/README.md)
@@ -40,6 +40,9 @@ def profile_counters(csv_name, kernel_substr, grid=None):
     # the figure of merit of a VALU-issue-bound kernel (IoU3D), as VERDICT r4 recomputed it from the committed counters
     if out["SQ_ACTIVE_INST_VALU"] and out["GRBM_GUI_ACTIVE"]:
         out["valu_busy_frac_of_simd_cycles"] = out["SQ_ACTIVE_INST_VALU"] * 4.0 / (out["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    # average share of a wave's 64 lanes that are active in a VALU instruction (thread-cycles per instruction / 64)
+    if out.get("SQ_THREAD_CYCLES_VALU") and out["SQ_INSTS_VALU"]:
+        out["valu_lane_utilisation"] = out["SQ_THREAD_CYCLES_VALU"] / (64.0 * out["SQ_INSTS_VALU"])
     return out
 
 

@@ -25,6 +25,8 @@ GROUPS = [
      "SQ_INSTS_MFMA", "SQ_WAVES"],
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
+    # lane utilisation of the VALU: thread-cycles the VALU spent on ACTIVE lanes against the instruction count
+    ["SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"],
 ]
 
 
