@@ -62,15 +62,20 @@ __device__ __forceinline__ void sttri(float* p, const Tri& t) { stv(p, t.v[0]); 
 __device__ __forceinline__ V3 tri_normal(const Tri& t) {
     V3 ctr = vdiv(vadd(vadd(t.v[0], t.v[1]), t.v[2]), 3.0f);
     V3 a0 = vsub(t.v[0], ctr), a1 = vsub(t.v[1], ctr), a2 = vsub(t.v[2], ctr);
+    // first maximum of the three cross-product norms wins (the comparison chain of the sequential form, NaNs included); the winner's
+    // normal is then computed ONCE -- the sequential form normalised inside every taken branch, and in a wave all three branches are
+    // taken by some lane (round 5: two get_normal bodies less per call, same operands into the one that remains)
     float best = -1.0f;
-    V3 n = mk(0.f, 0.f, 0.f);
-    float d01 = vnorm(vcross(a0, a1));
-    if (d01 > best) { best = d01; n = get_normal(a0, a1); }
-    float d02 = vnorm(vcross(a0, a2));
-    if (d02 > best) { best = d02; n = get_normal(a0, a2); }
-    float d12 = vnorm(vcross(a1, a2));
-    if (d12 > best) { best = d12; n = get_normal(a1, a2); }
-    return n;
+    int sel = -1;
+    const float d01 = vnorm(vcross(a0, a1));
+    if (d01 > best) { best = d01; sel = 0; }
+    const float d02 = vnorm(vcross(a0, a2));
+    if (d02 > best) { best = d02; sel = 1; }
+    const float d12 = vnorm(vcross(a1, a2));
+    if (d12 > best) { best = d12; sel = 2; }
+    if (sel < 0) return mk(0.f, 0.f, 0.f);
+    const V3 p = sel == 2 ? a1 : a0, q = sel == 0 ? a1 : a2;
+    return get_normal(p, q);
 }
 __device__ __forceinline__ float tri_area(const Tri& t) {
     return vnorm(vcross(vsub(t.v[1], t.v[0]), vsub(t.v[2], t.v[0]))) / 2.0f;
@@ -226,15 +231,17 @@ __device__ __forceinline__ void iou_pair_body(PairLds<CAPT>& L, const bool act, 
         for (int k = 0; k < 4; ++k) q[k] = ldv(B + 3 * c_box_planes[f][k]);
         V3 pc = vdiv(vadd(vadd(vadd(q[0], q[1]), q[2]), q[3]), 4.0f);
         float best = -1.0f;
-        V3 n = mk(0.f, 0.f, 0.f);
+        V3 ba = mk(0.f, 0.f, 0.f), bb = mk(0.f, 0.f, 0.f);
+        bool any = false;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = i + 1; j < 4; ++j) {
                 V3 a = vsub(q[i], pc), b = vsub(q[j], pc);
                 float d = vnorm(vcross(a, b));
-                if (d > best) { best = d; n = get_normal(a, b); }
+                if (d > best) { best = d; ba = a; bb = b; any = true; }      // (the winner's normal is computed once, below)
             }
+        V3 n = any ? get_normal(ba, bb) : mk(0.f, 0.f, 0.f);
         if (vdot(vsub(ctr, pc), n) < 0.0f) n = vscale(n, -1.0f);
         stv(L.pc[bx][f], pc);
         stv(L.pn[bx][f], n);
