@@ -126,13 +126,13 @@ class Boxes:
 
 def pairwise_iou(boxes1: Boxes, boxes2: Boxes):
     """(N,4) x (M,4) -> (N,M) IoU; `inter > 0 ? inter / (a1 + a2 - inter) : 0` [detectron2]."""
-    from ..kernels import boxes as kboxes
+    from ..kernels import det as kboxes
     return kboxes.pairwise_iou(boxes1.tensor, boxes2.tensor, mode="iou")
 
 
 def pairwise_ioa(boxes1: Boxes, boxes2: Boxes):
     """(N,4) x (M,4) -> (N,M) intersection over area(boxes2) [detectron2]."""
-    from ..kernels import boxes as kboxes
+    from ..kernels import det as kboxes
     return kboxes.pairwise_iou(boxes1.tensor, boxes2.tensor, mode="ioa")
 
 

@@ -49,9 +49,9 @@ def gemm(A, B, form=NT, bias=None, relu=False, out=None, accumulate=False, split
         return out3[0] if squeeze else out3
     if splits > 1 and not accumulate:
         out3.zero_()
-    elif splits == BALANCED and not accumulate:
+    elif splits == BALANCED and not accumulate and tile == 2:      # (tile 1 has no balanced form: the launcher runs whole tiles)
         W = workgroups or 256
-        bm, bn = (256, 128) if tile == 1 else (128, 128)
+        bm, bn = (128, 128)
         tm, tn = (M + bm - 1) // bm, (N + bn - 1) // bn
         if (b * tm * tn) % W:
             out3.zero_()        # (the cut tiles are the last ones of the engine's banded tile order: not a suffix of rows)

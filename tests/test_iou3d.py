@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-import boxgen
+from omni3d_amd import boxgen
 from test_iou3d_oracle import oracle_iou, oracle_overlap
 
 TOL = 1e-5  # fp32; north_star bar for IoU3D is 1e-4

@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 import pytest
 
-import boxgen
+from omni3d_amd import boxgen
 import exact_iou3d
 
 P = ctypes.c_void_p
