@@ -104,14 +104,23 @@ __device__ __forceinline__ V3 argmax_dir(const Tri& t, const V3* other) {
 }
 
 __device__ __forceinline__ V3 plane_edge_intersection(V3 pc, V3 normal, V3 p0, V3 p1) {
-    V3 direc = vsub(p1, p0);
-    direc = vdiv(direc, fmaxf(vnorm(direc), K_EPS));
+    const V3 e = vsub(p1, p0);
+    // The edge is cut unless it runs within asin(1e-3) of the plane: |dot(e / max(|e|, 1e-8), normal)| >= 1e-3.  Round 5: that test
+    // needs a square root and three divisions and is true for almost every edge -- an edge with (e . n)^2 > (1.015e-3)^2 |e|^2 and
+    // |e|^2 >= 1e-15 passes it whatever the rounding of the normalisation (1.5 % margin against ~1e-6), so the normalised form is only
+    // evaluated for the rest, and a wave skips it when none of its lanes has such an edge.  Same decision, same intersection point.
+    const float bot = vdot(e, normal);
+    const float len2 = vdot(e, e);
+    bool cut = bot * bot > 1.030225e-6f * len2 && len2 >= 1e-15f;
+    if (!cut) {
+        const V3 direc = vdiv(e, fmaxf(vnorm(e), K_EPS));
+        cut = fabsf(vdot(direc, normal)) >= D_EPS;
+    }
     V3 p = vdiv(vadd(p1, p0), 2.0f);
-    if (fabsf(vdot(direc, normal)) >= D_EPS) {
+    if (cut) {
         float top = -1.0f * vdot(vsub(p0, pc), normal);
-        float bot = vdot(vsub(p1, p0), normal);
         float a = top / bot;
-        p = vadd(p0, vscale(vsub(p1, p0), a));
+        p = vadd(p0, vscale(e, a));
     }
     return p;
 }
