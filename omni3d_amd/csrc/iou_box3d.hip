@@ -23,6 +23,8 @@
 // (host-emulator instrumentation of tools/iou3d_list_sizes.py: sizes of the joint triangle list entering each plane pass / the dedupe
 // phase, and the rounds of the clipping code all waves execute)
 int g_iou_hist[7][128], g_iou_rounds[2];
+long g_iou_phase[4][2];      // [rounds | with the normal | with the coplanarity test | with the intersection code][executions, active lanes]
+extern "C" long* omni_debug_iou_phase() { return &g_iou_phase[0][0]; }
 extern "C" int* omni_debug_iou_hist() { return &g_iou_hist[0][0]; }
 extern "C" int* omni_debug_iou_rounds() { return g_iou_rounds; }
 #endif
@@ -126,6 +128,12 @@ __device__ __forceinline__ V3 plane_edge_intersection(V3 pc, V3 normal, V3 p0, V
 }
 
 // clip one triangle by one face plane; returns 0..2 triangles in o0/o1
+#if defined(OMNI_HIPEMU) && defined(IOU_DEBUG_HIST)
+static int g_clip_dbg[64];      // per lane, bits of its last clip_tri call: 1 normal needed | 2 coplanarity test | 4 clipped
+#define IOU_DBG(b) (g_clip_dbg[threadIdx.x & 63] |= (b))
+#else
+#define IOU_DBG(b) ((void)0)
+#endif
 __device__ __forceinline__ int clip_tri(const V3* pv, V3 pc, V3 normal, const Tri& t, Tri& o0, Tri& o1) {
     V3 v0 = t.v[0], v1 = t.v[1], v2 = t.v[2];
     const float d0 = vdot(vsub(v0, pc), normal), d1 = vdot(vsub(v1, pc), normal), d2 = vdot(vsub(v2, pc), normal);
@@ -144,9 +152,11 @@ __device__ __forceinline__ int clip_tri(const V3* pv, V3 pc, V3 normal, const Tr
     const bool maybe_parallel = !(spread * spread > 0.0025f * l2);
     bool coplanar = false;
     if (maybe_parallel) {
+        IOU_DBG(1);
         V3 nt = tri_normal(t);
         bool check1 = fabsf(vdot(nt, normal)) > 1.0f - D_EPS;
         if (check1) {
+            IOU_DBG(2);
             V3 d = argmax_dir<4>(t, pv);
             coplanar = (fabsf(vdot(d, normal)) < D_EPS) || (fabsf(vdot(nt, d)) < D_EPS);
         }
@@ -172,6 +182,7 @@ __device__ __forceinline__ int clip_tri(const V3* pv, V3 pc, V3 normal, const Tr
         else { vin = v1; vo1 = v0; vo2 = v2; }
         a1 = vin; b1 = vo1; a2 = vin; b2 = vo2;
     }
+    IOU_DBG(4);
     const V3 p1 = plane_edge_intersection(pc, normal, a1, b1);
     const V3 p2 = plane_edge_intersection(pc, normal, a2, b2);
     if (nin == 2) {
@@ -322,6 +333,9 @@ __device__ __forceinline__ void iou_pair_body(PairLds<CAPT>& L, const bool act, 
             const int i = i0 + sl;
             int cnt = 0;
             Tri o0, o1;
+#if defined(OMNI_HIPEMU) && defined(IOU_DEBUG_HIST)
+            g_clip_dbg[lane] = 0;
+#endif
             if (i < n) {
                 const int other = (i < nA) ? 1 : 0;  // plane set of the other box
                 V3 pv[4];
@@ -330,6 +344,17 @@ __device__ __forceinline__ void iou_pair_body(PairLds<CAPT>& L, const bool act, 
                 Tri t = ldtri(src + i * 9);
                 cnt = clip_tri(pv, ldv(L.pc[other][f]), ldv(L.pn[other][f]), t, o0, o1);
             }
+#if defined(OMNI_HIPEMU) && defined(IOU_DEBUG_HIST)
+            {   // how often does a ROUND (the whole wave) execute the normal / the coplanarity test / the intersection code, with how many lanes
+                const unsigned long long q1 = __ballot(g_clip_dbg[lane] & 1), q2 = __ballot(g_clip_dbg[lane] & 2), q4 = __ballot(g_clip_dbg[lane] & 4), qa = __ballot(i < n);
+                if (lane == 0) {
+                    g_iou_phase[0][0] += 1; g_iou_phase[0][1] += __popcll(qa);
+                    if (q1) { g_iou_phase[1][0] += 1; g_iou_phase[1][1] += __popcll(q1); }
+                    if (q2) { g_iou_phase[2][0] += 1; g_iou_phase[2][1] += __popcll(q2); }
+                    if (q4) { g_iou_phase[3][0] += 1; g_iou_phase[3][1] += __popcll(q4); }
+                }
+            }
+#endif
             const unsigned long long b1m = (__ballot(cnt >= 1) >> shift) & sub_all, b2m = (__ballot(cnt == 2) >> shift) & sub_all;
             const int off = base + __popcll(b1m & sub_lt) + __popcll(b2m & sub_lt);
             if (cnt >= 1) { if (off < CAPT) sttri(dst + off * 9, o0); else over = true; }

@@ -28,16 +28,21 @@ ar = np.arange(P, dtype=np.int32)
 vol, iou, ov = np.zeros(P, np.float32), np.zeros(P, np.float32), np.zeros(1, np.int32)
 lib.omni_debug_iou_rounds.restype = ctypes.POINTER(ctypes.c_int)
 lib.omni_debug_iou_hist.restype = ctypes.POINTER(ctypes.c_int)
+lib.omni_debug_iou_phase.restype = ctypes.POINTER(ctypes.c_long)
 f = lib.omni_iou_box3d_pairs_algo
 f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_longlong] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p]
 rounds = {}
 for variant in (1064, 1032):       # one pair per wave | two pairs per wave (the production form: joint plane passes since round 5)
     lib.omni_debug_iou_rounds()[0] = 0
     ctypes.memset(lib.omni_debug_iou_hist(), 0, 7 * 128 * 4)
+    ctypes.memset(lib.omni_debug_iou_phase(), 0, 8 * 8)
     rc = f(d.ctypes.data, g.ctypes.data, ar.ctypes.data, ar.ctypes.data, P, None, vol.ctypes.data, iou.ctypes.data, ov.ctypes.data, variant, None)
     rounds[variant] = lib.omni_debug_iou_rounds()[0]
 h = np.ctypeslib.as_array(lib.omni_debug_iou_hist(), shape=(7, 128)).copy()
 print("rounds of the clipping code (all waves, all six passes):", rounds)
+ph = np.ctypeslib.as_array(lib.omni_debug_iou_phase(), shape=(4, 2)).copy()
+for name, (ex, lanes) in zip(("clip_tri rounds", "  ... computing triangle normals", "  ... running the coplanarity test (argmax_dir)", "  ... running the intersection code"), ph):
+    print(f"{name:50s} {int(ex):7d} executions ({ex / max(ph[0][0], 1):.2f} of the rounds), {lanes / max(ex, 1):5.1f} of 64 lanes active")
 print(f"rc {rc}; {P} pairs, {int(h[0].sum())} reach the clipping passes, {int((iou > 0).sum())} with IoU > 0")
 n = np.arange(128)
 for k in range(7):
