@@ -157,3 +157,33 @@ def test_training_step_is_bit_identical_run_to_run_gpu(hip_lib, name):
         assert not bad, (len(bad), bad[:8])
     # every arrival counter the three steps used is back at zero (csrc/split_reduce.h: the protocol's invariant)
     assert detmode.nonzero_counters() == []
+
+
+@pytest.mark.gpu
+def test_split_reduce_memory_ordering_litmus_gpu(hip_lib):
+    """csrc/split_reduce.h publishes a split's partial tile with agent-scope (sc1) stores, waits for them (s_waitcnt
+    vmcnt(0)), takes a ticket with a relaxed atomic and lets the LAST arrival read every slot -- ordering by control dependency, no
+    release / acquire fences.  The litmus: many-way split reductions whose splits land on different XCDs (different, non-coherent
+    L2s), hammered 300 times each; a slot read that overtook its store would show up as a result that differs from the first run
+    (the sum is order-fixed, so ANY difference is a stale read) or as a counter left behind."""
+    from omni3d_amd.kernels import conv, detmode
+    assert detmode.on()
+    g = torch.Generator().manual_seed(11)
+    cases = [  # few tiles, deep reductions: every tile is met by 8-32 workgroups
+        ((2, 512, 8, 8), (256, 512, 3, 3), 1, 1, 16),       # 2 x 4 tiles x 16 splits
+        ((1, 256, 6, 6), (64, 256, 3, 3), 1, 1, 32),        # one row of tiles x 32 splits: the two-level (grouped) reduction
+        ((4, 128, 16, 16), (128, 128, 1, 1), 1, 0, 4),
+    ]
+    for xs, ws, stride, pad, splits in cases:
+        x = _cl(torch.randn(*xs, generator=g)).cuda()
+        w = _cl(torch.randn(*ws, generator=g) * 0.05).cuda()
+        dy = _cl(torch.randn(xs[0], ws[0], xs[2], xs[3], generator=g)).cuda()
+        ref_f = conv.conv2d_fwd(x, w, None, stride, pad, tile=2, splits=splits).clone()
+        ref_d = conv.conv2d_dgrad(dy, w, (xs[2], xs[3]), stride, pad, tile=2, splits=splits).clone()
+        ref_w = conv.conv2d_wgrad(x, dy, (ws[2], ws[3]), stride, pad).clone()
+        for it in range(300):
+            assert torch.equal(conv.conv2d_fwd(x, w, None, stride, pad, tile=2, splits=splits), ref_f), (xs, "fwd", it)
+            assert torch.equal(conv.conv2d_dgrad(dy, w, (xs[2], xs[3]), stride, pad, tile=2, splits=splits), ref_d), (xs, "dgrad", it)
+            assert torch.equal(conv.conv2d_wgrad(x, dy, (ws[2], ws[3]), stride, pad), ref_w), (xs, "wgrad", it)
+    torch.cuda.synchronize()
+    assert detmode.nonzero_counters() == []

@@ -18,7 +18,7 @@ d, g = torch.from_numpy(dt).cuda(), torch.from_numpy(gt).cuda()
 ar = torch.arange(P, dtype=torch.int32, device="cuda")
 valid, _ = iou3d.box3d_validity(d)
 ref = None
-for lanes in (64, 32, 1064, 1032, 2064, 2032, 3032):
+for lanes in (64, 32, 16, 1064, 1032, 1016, 2064, 2032, 3032):
     for _ in range(3):
         out = iou3d.iou_box3d_pairs(d, g, ar, ar, valid1=valid, lanes_per_pair=lanes)[1]
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
