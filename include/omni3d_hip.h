@@ -350,9 +350,10 @@ int omni_roi_align_bwd(const void* const* dlevel_ptrs, const int* level_hw, cons
 int omni_roi_align_bwd2(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
                         const float* rois, const int* batch_idx, const int* levels, int R, int P, int C,
                         const float* dout, const float* dout2, int per_image, int first, void* stream);
-/* Deterministic form (round 4; P == 7, R <= 4096, B = images): the OUTPUT owns the sum -- one wave per 8 x 8 pixel tile of a
- * (level, image) and 64 channels adds the contributions of the ROIs that touch the tile in ascending ROI index and writes every
- * element of dlevel_ptrs[l] exactly once (OVERWRITES: no zero-fill by the caller), no atomics: two runs are bit-identical.
+/* Deterministic form (round 4; P == 7, R <= 4096, B = images): the OUTPUT owns the sum -- one workgroup per 8 x 4 pixel tile of a
+ * (level, image), all channels: its four waves deal out the ROIs that touch the tile (wave s: entries s, s + 4, ... of the list in
+ * ascending ROI index) and meet in wave order, so an element's value depends on the inputs alone; every element of dlevel_ptrs[l]
+ * is written exactly once (OVERWRITES: no zero-fill by the caller), no atomics: two runs are bit-identical.
  * C <= 256, B <= 255.  ws: scratch for per-ROI footprint records (plan != NULL: plan[3] = floats needed, nothing is launched);
  * ctr / n_ctr are not used by this kernel.  Same call site and gradient arguments as omni_roi_align_bwd2. */
 int omni_roi_align_bwd_det(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev, int B,

@@ -272,21 +272,27 @@ __global__ void __launch_bounds__(256) roi_align_bwd_sep_kernel(FeatLevels fl, c
 
 // ---- deterministic backward (round 4): the OUTPUT owns the sum ------------------------------------------------------------
 // The scatter above is bound by ~7e7 fp32 atomics per step and the order in which they land -- hence the rounding of every
-// feature-gradient element that several ROIs touch -- changes from run to run.  Here the output owns the sum: a workgroup owns a
-// 16 x 8 pixel region of one (level, image) and lists the ROIs of that image and level whose footprint meets it, IN ROI ORDER;
-// each of its four waves owns an 8 x 4 pixel tile of the region across ALL channels (lane = 4 channels, 32 float4 accumulators in
-// registers) and adds the ROIs' contributions one after the other with the same separable arithmetic as the scatter kernel.  Each
-// element of dfeat is written exactly once (no zero-fill in front, no atomics); the sum over ROIs runs in ascending ROI index.
-// Measured first (one wave per 8 x 8 tile and 64 channels, one channel per lane): 0.65 ms against 0.29 ms for the scatter -- 49
-// four-byte-per-lane loads per (tile, ROI, channel group), 0.5 GB through 256-byte transactions, were 85 % of it (the ROIs of the
-// benchmark are ~10 x 6 pixels on p2 and touch ~5 tiles each).  Hence float4 lanes (1 KiB per load instruction) and loads only
-// for the bins that carry weight on this tile.
+// feature-gradient element that several ROIs touch -- changes from run to run.  Here the output owns the sum: a workgroup owns an
+// 8 x 4 pixel tile of one (level, image) across ALL channels (lane = 4 channels, 32 float4 accumulators in registers) and lists the
+// ROIs of that image and level whose footprint meets the tile, IN ROI ORDER.  Each element of dfeat is written exactly once (no
+// zero-fill in front, no atomics) and its value depends on the inputs alone.
+// Round 4 gave every wave of a workgroup its own tile and let it walk the whole list: the launch was bound by its LONGEST list (the
+// benchmark's 2048 ROIs sit almost all on p2, ~10 x 6 pixels each; (8 x 4 tile, ROI) lists: mean 5.9, 90th percentile 16, longest
+// 50, tools/debug/roi_bwd_probe.py) times ~5 us per entry -- up to seven rounds of dependent loads, one per bin row, more where a
+// ROI carries the cube head's gradient as well and every bin's second load met its first in an add.  Round 5: the four waves of a
+// workgroup SHARE one tile and deal its list out (wave s takes entries s, s + 4, ...: chains of <= 13), then meet through LDS in
+// wave order -- the sum of an element is ((S0 + S1) + S2) + S3 with S_s the ascending-ROI sum of wave s, a function of the ROI set
+// alone; a bin row's loads (7 from each gradient tensor) are issued as one block before anything waits.  Alone on the device: 272
+// -> 136 us (tools/debug/roi_bwd_probe.py); in the two-stream step 10.81 -> 10.77 ms only -- the chain-bound form left most of the
+// machine to the weight-gradient stream beside it (profiles/r05_ab_roi_gather.log).
 struct GatherTiles {
-    int off[MAXL + 1];        // first region of each level in the 1-D grid
-    int tx[MAXL], ty[MAXL];   // regions per image along x / y
+    int off[MAXL + 1];        // first patch of each level (a patch = GT_PW x GT_PH tiles = 32 x 32 pixels of one image)
+    int px[MAXL], py[MAXL];   // patches per image along x / y
+    int tx[MAXL], ty[MAXL];   // tiles per image along x / y
     int B;
 };
-constexpr int GT_RW = 16, GT_RH = 8, GT_TW = 8, GT_TH = 4, GT_MAXR = 4096;
+constexpr int GT_TW = 8, GT_TH = 4, GT_SLICES = 4, GT_MAXR = 4096;
+constexpr int GT_PW = 4, GT_PH = 8, GT_PT = GT_PW * GT_PH;     // tiles per patch
 
 // per ROI, once: (image << 8 | level, or -1 for an empty sampling grid), footprint rows Y0 | Y1 << 16, columns X0 | X1 << 16, sampling
 // grid gh | gw << 16 -- what every region's list building compares against -- and the ROI's start / bin size on its level
@@ -321,23 +327,30 @@ __global__ void __launch_bounds__(256) roi_align_bwd_gather_kernel(FeatLevels fl
     __shared__ unsigned char s_hit[GT_MAXR];
     __shared__ unsigned short s_list[GT_MAXR];
     __shared__ int s_count;
+    __shared__ float4 s_acc[GT_TH * GT_TW][64];         // one wave's accumulators on their way to wave 0
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // coarsest level first: its few regions carry the longest ROI lists and should not be the launch's tail
-    const int region = gt.off[MAXL] - 1 - (int)blockIdx.x;
+    // workgroup -> tile: the tiles that meet one ROI are neighbours and read the same bins, and an XCD's L2 only helps the workgroups
+    // of that XCD (blockIdx % 8) -- so a 32 x 32 pixel patch of tiles goes to ONE XCD, as 32 consecutive workgroups of it, and the
+    // patches go round the XCDs (ROI density varies over the image; neighbouring patches on different XCDs level that out)
+    const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    const int patch = (j / GT_PT) * 8 + xcd, tin = j % GT_PT;
+    if (patch >= gt.off[MAXL]) return;
     int l = 0;
-    while (l + 1 < fl.nlev && region >= gt.off[l + 1]) ++l;
-    int t = region - gt.off[l];
-    const int rix = t % gt.tx[l]; t /= gt.tx[l];
-    const int riy = t % gt.ty[l];
-    const int n = t / gt.ty[l];
+    while (l + 1 < fl.nlev && patch >= gt.off[l + 1]) ++l;
+    int t = patch - gt.off[l];
+    const int pix = t % gt.px[l]; t /= gt.px[l];
+    const int piy = t % gt.py[l];
+    const int n = t / gt.py[l];
+    const int tix = pix * GT_PW + tin % GT_PW, tiy = piy * GT_PH + tin / GT_PW;
+    if (tix >= gt.tx[l] || tiy >= gt.ty[l]) return;
     const int H = fl.H[l], W = fl.W[l];
-    const int ry0 = riy * GT_RH, rx0 = rix * GT_RW;
-    // -- 1. which ROIs touch this region (every thread tests R / 256 precomputed footprints), compacted in ascending ROI index
+    const int ty0 = tiy * GT_TH, tx0 = tix * GT_TW;
+    // -- 1. which ROIs touch this tile (every thread tests R / 256 precomputed footprints), compacted in ascending ROI index
     const int key = (n << 8) | l;
     for (int r = tid; r < R; r += 256) {
         const int4 f = fp[r];
         const int Y0 = f.y & 0xffff, Y1 = f.y >> 16, X0 = f.z & 0xffff, X1 = f.z >> 16;
-        s_hit[r] = (f.x == key && Y0 < ry0 + GT_RH && Y1 >= ry0 && X0 < rx0 + GT_RW && X1 >= rx0) ? 1 : 0;
+        s_hit[r] = (f.x == key && Y0 < ty0 + GT_TH && Y1 >= ty0 && X0 < tx0 + GT_TW && X1 >= tx0) ? 1 : 0;
     }
     __syncthreads();
     if (wave == 0) {
@@ -353,21 +366,19 @@ __global__ void __launch_bounds__(256) roi_align_bwd_gather_kernel(FeatLevels fl
     }
     __syncthreads();
     const int count = s_count;
-    // -- 2. from here on the four waves are independent: wave = one 8 x 4 tile of the region, lane = 4 channels.  The tile-local
-    // weights of a ROI live in two registers -- lane 8 * yy + ph holds WY[yy][ph], the summed y-weights of bin ph's samples on tile
-    // row yy; lane 8 * xx + pw the same for x -- and reach the FMAs as wave-uniform scalars through v_readlane.
-    const int ty0 = ry0 + GT_TH * (wave >> 1), tx0 = rx0 + GT_TW * (wave & 1);
+    // -- 2. the four waves deal the list out: wave s adds entries s, s + GT_SLICES, ... (ascending) into its own accumulators; lane =
+    // 4 channels.  The tile-local weights of a ROI live in two registers -- lane 8 * yy + ph holds WY[yy][ph], the summed y-weights
+    // of bin ph's samples on tile row yy; lane 8 * xx + pw the same for x -- and reach the FMAs as wave-uniform scalars through
+    // v_readlane.
     const int tr = lane >> 3, tb = lane & 7;
     const int c = 4 * lane;
     const bool cok = c < C;
     float4 acc[GT_TH * GT_TW];
 #pragma unroll
     for (int i = 0; i < GT_TH * GT_TW; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int q = 0; q < count; ++q) {
+    for (int q = wave; q < count; q += GT_SLICES) {
         const int r = s_list[q];
         const int4 f = fp[r];
-        // (tile-level test first: a ROI of the region's list may miss this wave's tile altogether)
-        if ((f.y & 0xffff) >= ty0 + GT_TH || (f.y >> 16) < ty0 || (f.z & 0xffff) >= tx0 + GT_TW || (f.z >> 16) < tx0) continue;
         const float4 pa = par[r];
         const float sw = pa.x, sh = pa.y, bin_w = pa.z, bin_h = pa.w;
         const int gh = f.w & 0xffff, gw = f.w >> 16;
@@ -389,14 +400,14 @@ __global__ void __launch_bounds__(256) roi_align_bwd_gather_kernel(FeatLevels fl
         }
         const unsigned long long ymask = __ballot(wyv != 0.f), xmask = __ballot(wxv != 0.f);
         if (ymask == 0 || xmask == 0) continue;
-        // bins (rows ph / columns pw of the 7 x 7 grid) that carry weight on this tile
-        unsigned phm = 0, pwm = 0;
+        // bin rows ph of the 7 x 7 grid that carry weight on this tile
+        unsigned phm = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { phm |= (unsigned)(ymask >> (8 * k)) & 0x7fu; pwm |= (unsigned)(xmask >> (8 * k)) & 0x7fu; }
+        for (int k = 0; k < 8; ++k) phm |= (unsigned)(ymask >> (8 * k)) & 0x7fu;
         const float inv_count = 1.f / (float)(gh * gw);
-        const float* o = (dout != nullptr && cok) ? dout + (long)r * PP * PP * C + c : nullptr;
-        const float* o2 = nullptr;
-        if (dout2 != nullptr && cok) {
+        const float* o = dout != nullptr ? dout + (long)r * PP * PP * C + c : nullptr;           // (wave-uniform tests: the lanes
+        const float* o2 = nullptr;                                                               //  past C are masked at the loads)
+        if (dout2 != nullptr) {
             const int img = r / per_image, k = r - img * per_image;
             if (k < first) o2 = dout2 + ((long)img * first + k) * PP * PP * C + c;
         }
@@ -405,17 +416,22 @@ __global__ void __launch_bounds__(256) roi_align_bwd_gather_kernel(FeatLevels fl
 #pragma unroll
             for (int ph = 0; ph < PP; ++ph) {
                 if (!((phm >> ph) & 1u)) continue;
-                float4 g[PP];
+                // the whole bin row of both gradient tensors as one block of loads (a bin without weight on this tile costs a load,
+                // not a round trip: its weights are zero)
+                float4 g[PP], g2[PP];
 #pragma unroll
-                for (int pw = 0; pw < PP; ++pw) {
-                    g[pw] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if ((pwm >> pw) & 1u) {
-                        if (o != nullptr) g[pw] = *reinterpret_cast<const float4*>(o + (long)(ph * PP + pw) * C);
-                        if (o2 != nullptr) {
-                            const float4 v2 = *reinterpret_cast<const float4*>(o2 + (long)(ph * PP + pw) * C);
-                            g[pw].x += v2.x; g[pw].y += v2.y; g[pw].z += v2.z; g[pw].w += v2.w;
-                        }
-                    }
+                for (int pw = 0; pw < PP; ++pw) g[pw] = g2[pw] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (o != nullptr && cok) {
+#pragma unroll
+                    for (int pw = 0; pw < PP; ++pw) g[pw] = *reinterpret_cast<const float4*>(o + (long)(ph * PP + pw) * C);
+                }
+                if (o2 != nullptr && cok) {
+#pragma unroll
+                    for (int pw = 0; pw < PP; ++pw) g2[pw] = *reinterpret_cast<const float4*>(o2 + (long)(ph * PP + pw) * C);
+                }
+                if (o2 != nullptr) {
+#pragma unroll
+                    for (int pw = 0; pw < PP; ++pw) { g[pw].x += g2[pw].x; g[pw].y += g2[pw].y; g[pw].z += g2[pw].z; g[pw].w += g2[pw].w; }
                 }
                 // T[xx] = sum_pw WX[xx][pw] * g[ph][pw], then acc[yy][xx] += WY[yy][ph] / count * T[xx]
 #pragma unroll
@@ -437,7 +453,24 @@ __global__ void __launch_bounds__(256) roi_align_bwd_gather_kernel(FeatLevels fl
             }
         }
     }
-    if (cok) {
+    // -- 3. the waves meet in wave order: ((S0 + S1) + S2) + S3
+    for (int s = 1; s < GT_SLICES; ++s) {
+        if (count <= s) break;                                  // (workgroup-uniform: wave s had no entry, nor has any later one)
+        if (s > 1) __syncthreads();                             // wave 0 has read the previous wave's values
+        if (wave == s) {
+#pragma unroll
+            for (int i = 0; i < GT_TH * GT_TW; ++i) s_acc[i][lane] = acc[i];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < GT_TH * GT_TW; ++i) {
+                const float4 v = s_acc[i][lane];
+                acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+            }
+        }
+    }
+    if (wave == 0 && cok) {
         float* feat = fl.f[l] + (long)n * H * W * C + c;
 #pragma unroll
         for (int yy = 0; yy < GT_TH; ++yy)
@@ -505,8 +538,8 @@ static int roi_align_bwd_impl(const void* const* dlevel_ptrs, const int* level_h
 }
 
 // Deterministic form of omni_roi_align_bwd2 (P == 7, R <= 4096, C <= 256, B <= 255 images): dlevel_ptrs[l] (B, H_l, W_l, C) are
-// OVERWRITTEN -- every element exactly once, by the wave that owns its 8 x 4 tile, which adds the contributions of the ROIs in
-// ascending ROI index.  No zero-fill by the caller, no atomics; two runs give bit-identical feature gradients.  ws: scratch for
+// OVERWRITTEN -- every element exactly once, by the workgroup that owns its 8 x 4 tile (four waves deal out the tile's ROIs in
+// ascending ROI index and meet in wave order).  No zero-fill by the caller, no atomics; two runs give bit-identical feature gradients.  ws: scratch for
 // the per-ROI footprint records (plan != NULL: plan[3] = floats needed, nothing is launched); ctr / n_ctr are unused.
 int omni_roi_align_bwd_det(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev, int B,
                            const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, const float* dout,
@@ -517,15 +550,19 @@ int omni_roi_align_bwd_det(const void* const* dlevel_ptrs, const int* level_hw, 
     if (dout2 != nullptr && (per_image <= 0 || first < 0 || first > per_image || R % per_image != 0)) return OMNI_ERR_ARG;
     FeatLevels fl = make_feat(dlevel_ptrs, level_hw, level_scale, nlev);
     GatherTiles gt;
-    int total = 0;
+    int total = 0;                                            // patches
     for (int l = 0; l < MAXL; ++l) {
         gt.off[l] = total;
-        gt.tx[l] = gt.ty[l] = 1;
+        gt.tx[l] = gt.ty[l] = gt.px[l] = gt.py[l] = 1;
         if (l < nlev) {
             if (fl.H[l] > 65535 || fl.W[l] > 65535) return OMNI_ERR_ARG;
-            gt.tx[l] = (fl.W[l] + GT_RW - 1) / GT_RW;
-            gt.ty[l] = (fl.H[l] + GT_RH - 1) / GT_RH;
-            total += B * gt.tx[l] * gt.ty[l];
+            gt.tx[l] = (fl.W[l] + GT_TW - 1) / GT_TW;
+            gt.ty[l] = (fl.H[l] + GT_TH - 1) / GT_TH;
+            gt.px[l] = (gt.tx[l] + GT_PW - 1) / GT_PW;
+            gt.py[l] = (gt.ty[l] + GT_PH - 1) / GT_PH;
+            const long patches = (long)B * gt.px[l] * gt.py[l];
+            if (total + patches > (1L << 22)) return OMNI_ERR_ARG;
+            total += (int)patches;
         }
     }
     for (int l = nlev; l <= MAXL; ++l) gt.off[l] = total;
@@ -539,7 +576,7 @@ int omni_roi_align_bwd_det(const void* const* dlevel_ptrs, const int* level_hw, 
     if (R > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_footprint_kernel<7>), dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, fl, rois, batch_idx,
                            levels, R, fp, par);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_bwd_gather_kernel<7>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, fl, gt, rois, R,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_bwd_gather_kernel<7>), dim3((unsigned)((total + 7) / 8 * 8 * GT_PT)), dim3(256), 0, (hipStream_t)stream, fl, gt, rois, R,
                        C, dout, dout2, per_image, first, (const int4*)fp, (const float4*)par);
     return omni_launch_status();
 }

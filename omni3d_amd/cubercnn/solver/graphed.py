@@ -14,7 +14,20 @@ import os
 
 import torch
 
-from ...functional import total_loss
+from ...functional import sum_vectors, total_loss
+
+
+_units = {}
+
+
+def _unit(t):
+    """the gradient a scalar loss root starts from, built once per device: `t.backward()` without it launches a fill for
+    ones_like(t) in every step"""
+    key = (str(t.device), t.dtype)
+    one = _units.get(key)
+    if one is None:
+        one = _units[key] = torch.ones((), dtype=t.dtype, device=t.device)
+    return one
 
 
 def _leaf_grad(t):
@@ -177,7 +190,7 @@ class GraphedTwoPhase:
         self.optimizer.zero_grad()
         losses = self.model(self.static_batch, self.static_packed)
         total = total_loss(losses)             # == sum(losses.values()), two launches
-        total.backward()
+        total.backward(_unit(total))
         return losses, total.detach()
 
     def _phase_b(self):
@@ -228,7 +241,7 @@ class GraphedForwardBackward:
         self.optimizer.zero_grad()
         losses = self.model(self.static_batch, self.static_packed)
         total = total_loss(losses)             # == sum(losses.values()), two launches
-        total.backward()
+        total.backward(_unit(total))
         return losses, total.detach()
 
     def __call__(self):
@@ -282,7 +295,7 @@ class StageCuts:
         pairs = [p for p in pairs if p[1] is not None]
         del src, dst
         if pairs or roots:
-            torch.autograd.backward([p[0] for p in pairs] + list(roots), [p[1] for p in pairs] + [None] * len(roots))
+            torch.autograd.backward([p[0] for p in pairs] + list(roots), [p[1] for p in pairs] + [_unit(r) for r in roots])
 
 
 class GraphedPipelined:
@@ -495,16 +508,19 @@ class GraphedPipelined:
         self.cuts.reset()
         self.optimizer.zero_grad()
         losses = self.model(self.static_batch, self.static_packed)
-        total = total_loss(losses)
         first, deferred = self._split_losses(losses)
         if deferred is None:
-            total.backward()
-        else:
-            # stage 0 back-propagates the ROI heads' losses only, down to the pooled ROI features; the RPN's two losses are the
-            # roots of the next stage together with ROIAlign's backward
-            self.cuts.attach_root(deferred)
-            first.backward()
-        return losses, total.detach()
+            total = total_loss(losses)
+            total.backward(_unit(total))
+            return losses, total.detach()
+        # stage 0 back-propagates the ROI heads' losses only, down to the pooled ROI features; the RPN's two losses are the
+        # roots of the next stage together with ROIAlign's backward.  (The reported total is the sum of the two partial sums: one
+        # add instead of a second concatenate + reduce over all vectors.)
+        with torch.no_grad():
+            total = first + deferred
+        self.cuts.attach_root(deferred)
+        first.backward(_unit(first))
+        return losses, total
 
     def _split_losses(self, losses):
         """-> (sum of the losses whose backward belongs to stage 0, sum of the deferred ones or None)"""
@@ -518,7 +534,7 @@ class GraphedPipelined:
         early = [v for v, names in vecs if not all(n.startswith("rpn/") for n in names)]
         if not late or not early:
             return None, None
-        return torch.cat(early).sum(), torch.cat(late).sum()
+        return sum_vectors(early), sum_vectors(late)
 
     def _eager(self):
         """all stages with eager launches (weight gradients wherever functional.side_mode() puts them)

@@ -1150,13 +1150,25 @@ def _scalar(t):
 _coef_cache = {}
 
 
-def _coef(values, device):
+def _coef(values, device, dtype=torch.float32):
     """small constant vector on the device, built once (before any hipGraph capture: the warm-up steps run first)"""
-    key = (tuple(float(v) for v in values), str(device))
+    key = (tuple(float(v) for v in values), str(device), dtype)
     t = _coef_cache.get(key)
     if t is None:
-        t = _coef_cache[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+        t = _coef_cache[key] = torch.tensor(key[0], dtype=dtype, device=device)
     return t
+
+
+def _scalar_grads(g, n):
+    """the n one-element gradient tensors a loss kernel reads, from the gradient of its n-vector WITHOUT a copy launch where the
+    vector's gradient is one broadcast scalar (stride 0: what `_SumVectors` and autograd's own sum hand down)"""
+    if g.dtype != torch.float32:
+        g = g.float()
+    if g.dim() == 1 and g.stride(0) == 0:
+        one = g.as_strided((1,), (1,))
+        return (one,) * n
+    g = g.contiguous()
+    return tuple(g[k:k + 1] for k in range(n))
 
 
 class LossDict(dict):
@@ -1175,23 +1187,25 @@ class LossDict(dict):
 
 
 class _SumVectors(Function):
-    """sum of all elements of a few small vectors.  Its backward hands every vector ONE contiguous gradient (slices of a single
-    broadcast of the upstream scalar): autograd's own `cat(...).sum()` delivers stride-0 views, and each loss function then paid a
-    copy launch to make its gradient addressable by a kernel (three launches per step, round 5)."""
+    """sum of all elements of a few small vectors (one launch for one vector, two for several).  Its backward hands every vector the
+    upstream scalar as a stride-0 view -- no launch; the loss functions read it as the one scalar it is (`_scalar_grads`)."""
 
     @staticmethod
     def forward(ctx, *vecs):
         ctx.sizes = [int(v.numel()) for v in vecs]
+        if len(vecs) == 1:
+            return vecs[0].sum()
         return torch.cat([v.reshape(-1) for v in vecs]).sum()
 
     @staticmethod
     def backward(ctx, g):
-        flat = g.reshape(1).expand(sum(ctx.sizes)).contiguous()
-        out, off = [], 0
-        for n in ctx.sizes:
-            out.append(flat[off:off + n])
-            off += n
-        return tuple(out)
+        g = g.reshape(1)
+        return tuple(g.expand(n) for n in ctx.sizes)
+
+
+def sum_vectors(vecs):
+    """scalar sum of a list of small loss vectors (differentiable)"""
+    return _SumVectors.apply(*vecs)
 
 
 def total_loss(losses):
@@ -1212,7 +1226,9 @@ class _RPNLoss(Function):
             lv = [_cl(t).permute(0, 2, 3, 1) for t in levels]
             pack = det.LevelPack(lv)
             sums = det.rpn_loss_fwd(pack, anchors, labels, matched_idx, gt, gt_off, plain)
-            vec = sums[:2].float() * _coef((inv_norm * weights[0], inv_norm * weights[1]), sums.device)
+            # (fp64 sums x fp64 coefficients, rounded once into the fp32 loss vector: one launch)
+            vec = torch.mul(sums[:2], _coef((inv_norm * weights[0], inv_norm * weights[1]), sums.device, torch.float64),
+                            out=torch.empty(2, dtype=torch.float32, device=sums.device))
         ctx.pack = pack
         ctx.save_for_backward(anchors, labels, matched_idx, gt, gt_off)
         ctx.inv_norm, ctx.weights, ctx.plain = inv_norm, weights, plain
@@ -1222,10 +1238,10 @@ class _RPNLoss(Function):
     @staticmethod
     def backward(ctx, g, _):
         anchors, labels, matched_idx, gt, gt_off = ctx.saved_tensors
-        g = g.contiguous().float()
         if ctx.weights != (1.0, 1.0):
-            g = g * _coef(ctx.weights, g.device)
-        grads = det.rpn_loss_bwd(ctx.pack, anchors, labels, matched_idx, gt, gt_off, g[0:1], g[1:2], ctx.inv_norm, ctx.plain)
+            g = g.float() * _coef(ctx.weights, g.device)
+        g_cls, g_loc = _scalar_grads(g, 2)
+        grads = det.rpn_loss_bwd(ctx.pack, anchors, labels, matched_idx, gt, gt_off, g_cls, g_loc, ctx.inv_norm, ctx.plain)
         return (None,) * 8 + tuple(t.permute(0, 3, 1, 2) for t in grads)
 
 
@@ -1245,8 +1261,8 @@ class _BoxLoss(Function):
         ctx.save_for_backward(pred, cls, prop, gt, gt_row, sums)
         ctx.meta = (K, weights, loss_w)
         ctx.mark_non_differentiable(sums)
-        s = sums[:3].float()
-        vec = s[:2] / s[2:3].clamp(min=1.0)
+        # (fp64 sums / fp64 count, rounded once into the fp32 loss vector: two launches)
+        vec = torch.div(sums[:2], sums[2:3].clamp(min=1.0), out=torch.empty(2, dtype=torch.float32, device=sums.device))
         if loss_w != (1.0, 1.0):
             vec = vec * _coef(loss_w, vec.device)
         return vec, sums
@@ -1255,10 +1271,10 @@ class _BoxLoss(Function):
     def backward(ctx, g, _):
         pred, cls, prop, gt, gt_row, sums = ctx.saved_tensors
         K, weights, loss_w = ctx.meta
-        g = g.contiguous().float()
         if loss_w != (1.0, 1.0):
-            g = g * _coef(loss_w, g.device)
-        return (det.box_loss_bwd(pred, K, cls, prop, gt, gt_row, sums, g[0:1], g[1:2], weights),) + (None,) * 7
+            g = g.float() * _coef(loss_w, g.device)
+        g_cls, g_reg = _scalar_grads(g, 2)
+        return (det.box_loss_bwd(pred, K, cls, prop, gt, gt_row, sums, g_cls, g_reg, weights),) + (None,) * 7
 
 
 def box_loss(pred, K, cls, prop, gt, gt_row, weights=(10.0, 10.0, 5.0, 5.0), loss_w=(1.0, 1.0)):
@@ -1283,7 +1299,9 @@ class _CubeLoss(Function):
     def backward(ctx, g, _):
         vals, jac, red, cls, boxes = ctx.saved_tensors
         F_, K, ldh, mode, coef, clusters = ctx.meta
-        gk = g.contiguous().float() * _coef(coef, g.device)
+        gk = g.float() * _coef(coef, g.device)             # (a broadcast scalar x 6 coefficients -> a contiguous 6-vector: one launch)
+        if not gk.is_contiguous():
+            gk = gk.contiguous()
         dhead = det.cube_loss_bwd(vals, jac, red, gk, cls, boxes, F_, K, ldh, mode, clusters)
         return (dhead,) + (None,) * 14
 
