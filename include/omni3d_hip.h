@@ -99,12 +99,29 @@ int omni_conv2d_fwd_det(const float* x, const float* w, const float* bias, float
                         int R, int S, int stride, int pad, int ldx, int ldo, int relu, int tile, int splits, float* stats,
                         int stats_rows, int* nblk_out, float* ws, long long ws_floats, int* ctr, int n_ctr, long long* plan,
                         void* stream);
+
+/* omni_conv2d_fwd_det for an input that is the channel concatenation of nsrc <= 6 dense NHWC tensors xs[s] (N, H, W, cs[s]),
+ * cs[s] % 32 == 0, WITHOUT forming the concatenation: conv1x1(torch.cat(children, 1)) of the DLA Root
+ * (cubercnn/modeling/backbone/dla.py:166-172).  1 x 1, stride 1, no padding; out (N, H, W, K) with pixel pitch ldo.  Same tiles,
+ * splits, epilogues and bit-identical results as the single-tensor entry on the concatenated input.  xs / cs are HOST arrays.
+ * ctr == NULL && plan == NULL: non-deterministic form (split reductions meet through atomics). */
+int omni_conv2d_fwd_multi_det(const void* const* xs, const int* cs, int nsrc, const float* w, const float* bias, float* out, int N, int H,
+                              int W, int K, int ldo, int relu, int tile, int splits_req, float* stats, int stats_rows, int* nblk_out,
+                              float* ws, long long ws_floats, int* ctr, int n_ctr, long long* plan, void* stream);
 int omni_conv2d_dgrad_det(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int R, int S,
                           int stride, int pad, int lddy, int lddx, int accumulate, int tile, int splits, float* ws,
                           long long ws_floats, int* ctr, int n_ctr, long long* plan, void* stream);
 int omni_conv2d_wgrad_det(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
                           int stride, int pad, int ldx, int lddy, int accumulate, int tile, float* ws, long long ws_floats,
                           int* ctr, int n_ctr, long long* plan, void* stream);
+
+/* omni_conv2d_wgrad_det for an input that is the channel concatenation of nsrc <= 6 dense NHWC tensors (omni_conv2d_fwd_multi_det):
+ * dw (K, 1, 1, sum cs) = dy^T x of the DLA Root's 1 x 1 convolution (dla.py:166-172) without the concatenated copy; cs[s] % 4 == 0,
+ * xs / cs HOST arrays, dy (N, H, W, K) with pixel pitch lddy.  Bit-identical to the single-tensor entry on the concatenated input.
+ * ctr == NULL && plan == NULL: non-deterministic form. */
+int omni_conv2d_wgrad_multi_det(const void* const* xs, const int* cs, int nsrc, const float* dy, float* dw, int N, int H, int W, int K,
+                                int lddy, int accumulate, int tile, float* ws, long long ws_floats, int* ctr, int n_ctr, long long* plan,
+                                void* stream);
 
 /* ------------------------------------------------------- BatchNorm / pooling / FPN (NHWC) */
 

@@ -29,6 +29,7 @@
 
 namespace {
 
+constexpr int OMNI_MAX_SRC = 6;
 struct ConvP {
     const float* x;   // fwd: input NHWC (pitch ldx) | dgrad: dY NHWC (pitch ldx) | wgrad: input NHWC
     const float* w;   // fwd/dgrad: weights KRSC    | wgrad: dY (pitch ldw)
@@ -48,6 +49,12 @@ struct ConvP {
     // read-modify-write (every output element has exactly one owner per launch) instead of atomics
     float* ws;
     unsigned* ctr;
+    // multi-source input (round 5, the DLA Root): nsrc > 0 asks the 1 x 1 / stride 1 forward kernel (PF == 1) to read the input
+    // channels [coff[s], coff[s + 1]) from the dense NHWC tensor xs[s] (pitch = its own channel count) -- torch.cat(xs, 1) is never
+    // formed.  Every coff[s] is a multiple of the slab depth, so a slab has one source.
+    const float* xs[OMNI_MAX_SRC];
+    int coff[OMNI_MAX_SRC + 1];
+    int nsrc;
 };
 
 
@@ -219,6 +226,27 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvP p) {
     auto load_slab = [&](const int st) {
         const bool kok = kd < Kd && issued < nk;
         ++issued;
+        if constexpr (PF == 1) {
+            if (p.nsrc > 0) {                          // (uniform) 1 x 1 convolution over the channel concatenation of p.xs[]
+                const int c0 = (kt_begin + issued - 1) * BKX;                  // first channel of this slab: picks its source
+                const float* src = p.xs[0];
+                int lo = 0, hi = p.coff[1];
+#pragma unroll
+                for (int q = 1; q < OMNI_MAX_SRC; ++q)
+                    if (q < p.nsrc && c0 >= p.coff[q]) { src = p.xs[q]; lo = p.coff[q]; hi = p.coff[q + 1]; }
+                const int cs = hi - lo, cl = kd - lo;
+#pragma unroll
+                for (int i = 0; i < AI; ++i)
+                    ra[st][i] = (a_ok[i] && kok) ? ldg4(src + (long)(m0 + lrow + RPP * i) * cs + cl) : zero4();
+#pragma unroll
+                for (int j = 0; j < BI; ++j) {
+                    const int n = n0 + lrow + RPP * j;
+                    rb[st][j] = bufld4(rw_, (lrow + RPP * j < BN && n < p.K && kok) ? (n * Kd + kd) * 4 : OMNI_OOB);
+                }
+                kd += BKX;
+                return;
+            }
+        }
         const int tap_off = (r_cur * p.W + s_cur) * p.ldx + c_cur;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
@@ -594,6 +622,19 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
     const int br = tap / p.S - p.pad, bs = tap - (tap / p.S) * p.S - p.pad;   // tap offset minus padding
     const int am = m0 + am4 * 4;
     const bool m_ok = am < p.K;
+    // multi-source input (1 x 1 filter over the channel concatenation of p.xs[], see ConvP): this thread's four channels live in ONE
+    // of the sources (every width is a multiple of 4), whatever the tile straddles
+    const float* xsrc = p.x;
+    int xld = p.ldx, bcl = bc;
+    if (p.nsrc > 0) {
+        int lo = 0, hi = p.coff[1];
+        xsrc = p.xs[0];
+#pragma unroll
+        for (int q = 1; q < OMNI_MAX_SRC; ++q)
+            if (q < p.nsrc && nn >= p.coff[q]) { xsrc = p.xs[q]; lo = p.coff[q]; hi = p.coff[q + 1]; }
+        xld = hi - lo;
+        bcl = nn - lo;
+    }
 
     // pixel cursors (img, oh, ow) of this thread's BI rows of the NEXT slab to load; one slab advances them by
     // BK pixels = d_img images + d_oh rows + d_ow columns (precomputed, carries resolved with two compares)
@@ -624,7 +665,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
         for (int j = 0; j < BI; ++j) {
             const int ih = b_oh[j] * p.stride + br, iw = b_ow[j] * p.stride + bs;
             const bool ok = n_ok && b_pix[j] < p_end && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            rb[j] = ok ? ldg4(p.x + ((long)(b_img[j] * p.H + ih) * p.W + iw) * p.ldx + bc) : zero4();
+            rb[j] = ok ? ldg4(xsrc + ((long)(b_img[j] * p.H + ih) * p.W + iw) * xld + bcl) : zero4();
             b_pix[j] += BK;
             b_ow[j] += d_ow;
             if (b_ow[j] >= p.OW) { b_ow[j] -= p.OW; ++b_oh[j]; }
@@ -1051,15 +1092,37 @@ static inline void det_plan(const DetArgs& d, long tile, long tiles, long splits
     d.plan[3] = splits > 1 ? omni_split_ws_floats(tiles, splits, tile_elems) : 0;
 }
 
+struct MultiSrc {
+    const void* const* xs;    // nsrc dense NHWC tensors (N, H, W, cs[s])
+    const int* cs;
+    int nsrc;
+};
+
 static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, float* out, int N, int H, int W, int C, int K,
                            int R, int S, int stride, int pad, int ldx, int ldo, int relu, int tile, int splits_req, float* stats,
-                           int stats_rows, int* nblk_out, void* stream, const DetArgs& det = DetArgs{nullptr, 0, nullptr, 0, nullptr}) {
+                           int stats_rows, int* nblk_out, void* stream, const DetArgs& det = DetArgs{nullptr, 0, nullptr, 0, nullptr},
+                           const MultiSrc* ms = nullptr) {
     ConvP p{x, w, bias, out, N, H, W, C, (H + 2 * pad - R) / stride + 1, (W + 2 * pad - S) / stride + 1, K,
             R, S, stride, pad, ldx, ldo, 0, relu, 0, 1};
     p.stats = nullptr;
     p.ws = nullptr;
     p.ctr = nullptr;
+    p.nsrc = 0;
     if (nblk_out) *nblk_out = 0;
+    if (ms != nullptr) {      // the input is the channel concatenation of ms->xs[]: 1 x 1 / stride 1, every width a multiple of 32
+        if (ms->nsrc < 1 || ms->nsrc > OMNI_MAX_SRC || R != 1 || S != 1 || stride != 1 || pad != 0 || tile == 5) return OMNI_ERR_ARG;
+        p.coff[0] = 0;
+        for (int q = 0; q < OMNI_MAX_SRC; ++q) {
+            const bool live = q < ms->nsrc;
+            if (live && (ms->xs[q] == nullptr || ms->cs[q] <= 0 || (ms->cs[q] % 32) != 0)) return OMNI_ERR_ARG;
+            p.xs[q] = live ? (const float*)ms->xs[q] : nullptr;
+            p.coff[q + 1] = p.coff[q] + (live ? ms->cs[q] : 0);
+            if (live && (long)N * H * W * ms->cs[q] >= (1L << 31)) return OMNI_ERR_ARG;
+        }
+        if (p.coff[ms->nsrc] != C || ldx != C) return OMNI_ERR_ARG;
+        p.nsrc = ms->nsrc;
+        p.x = p.xs[0];
+    }
     if (bad_geom(p) || (ldx & 3) || ldx < C || ldo < K || tile < 0 || tile > 5 || splits_req < 0) return OMNI_ERR_ARG;
     if (splits_req > 1 && ldo != K) return OMNI_ERR_ARG;
     const long M = (long)N * p.OH * p.OW;
@@ -1155,6 +1218,23 @@ int omni_conv2d_fwd_det(const float* x, const float* w, const float* bias, float
                         int* nblk_out, float* ws, long long ws_floats, int* ctr, int n_ctr, long long* plan, void* stream) {
     return conv2d_fwd_impl(x, w, bias, out, N, H, W, C, K, R, S, stride, pad, ldx, ldo, relu, tile, splits_req, stats, stats_rows, nblk_out,
                            stream, DetArgs{ws, ws_floats, (unsigned*)ctr, n_ctr, plan});
+}
+
+// The same for an input that is the channel concatenation of nsrc <= 6 dense NHWC tensors xs[s] (N, H, W, cs[s]), cs[s] % 32 == 0
+// -- the DLA Root's conv1x1(torch.cat(children, 1)) (dla.py:166-172) WITHOUT the concatenated copy: a reduction slab reads its
+// channels from the source that holds them.  1 x 1, stride 1, no padding; same tiles, splits, epilogues (bias / ReLU / BatchNorm
+// statistics) and bit-identical results as omni_conv2d_fwd_det on the concatenated tensor.  ctr == NULL && plan == NULL: the
+// non-deterministic form (a split reduction then meets through atomics in a zeroed output).
+int omni_conv2d_fwd_multi_det(const void* const* xs, const int* cs, int nsrc, const float* w, const float* bias, float* out, int N, int H,
+                              int W, int K, int ldo, int relu, int tile, int splits_req, float* stats, int stats_rows, int* nblk_out,
+                              float* ws, long long ws_floats, int* ctr, int n_ctr, long long* plan, void* stream) {
+    if (xs == nullptr || cs == nullptr || nsrc < 1 || nsrc > OMNI_MAX_SRC) return OMNI_ERR_ARG;
+    long C = 0;
+    for (int q = 0; q < nsrc; ++q) C += cs[q] > 0 ? cs[q] : 0;
+    if (C <= 0 || C > (1 << 20)) return OMNI_ERR_ARG;
+    const MultiSrc ms{xs, cs, nsrc};
+    return conv2d_fwd_impl((const float*)xs[0], w, bias, out, N, H, W, (int)C, K, 1, 1, 1, 0, (int)C, ldo, relu, tile, splits_req, stats, stats_rows,
+                           nblk_out, stream, DetArgs{ws, ws_floats, (unsigned*)ctr, n_ctr, plan}, &ms);
 }
 
 // Tile choice: 128x128 when that already fills the 256 CUs, otherwise 64x64 (4x the workgroups); when even
@@ -1256,7 +1336,8 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
 // directly in the flat gradient bucket without an extra add kernel per parameter.
 // tile: 0 auto | 1 = 128x128 | 2 = 64x64 | 3 = 128x64 | 4 = 32x128 (BM over K, BN over the (r, s, c) extent)
 static int conv2d_wgrad_impl(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
-                             int stride, int pad, int ldx, int lddy, int accumulate, int tile, void* stream, const DetArgs& det) {
+                             int stride, int pad, int ldx, int lddy, int accumulate, int tile, void* stream, const DetArgs& det,
+                             const MultiSrc* ms = nullptr) {
     // tile + 16: the same tile with the XCD-contiguous workgroup order; tile + 32: with the plain order; 0..4: the launcher decides
     int xcd_order = -1;
     if (tile >= 32) { xcd_order = 0; tile -= 32; }
@@ -1267,6 +1348,20 @@ static int conv2d_wgrad_impl(const float* x, const float* dy, float* dw, int N, 
     p.stats = nullptr;
     p.ws = nullptr;
     p.ctr = nullptr;
+    p.nsrc = 0;
+    if (ms != nullptr) {      // x is the channel concatenation of ms->xs[]: 1 x 1 / stride 1
+        if (ms->nsrc < 1 || ms->nsrc > OMNI_MAX_SRC || R != 1 || S != 1 || stride != 1 || pad != 0) return OMNI_ERR_ARG;
+        p.coff[0] = 0;
+        for (int q = 0; q < OMNI_MAX_SRC; ++q) {
+            const bool live = q < ms->nsrc;
+            if (live && (ms->xs[q] == nullptr || ms->cs[q] <= 0 || (ms->cs[q] & 3))) return OMNI_ERR_ARG;
+            p.xs[q] = live ? (const float*)ms->xs[q] : nullptr;
+            p.coff[q + 1] = p.coff[q] + (live ? ms->cs[q] : 0);
+        }
+        if (p.coff[ms->nsrc] != C || ldx != C) return OMNI_ERR_ARG;
+        p.nsrc = ms->nsrc;
+        p.x = p.xs[0];
+    }
     if (bad_geom(p) || (K & 3) || (ldx & 3) || (lddy & 3) || ldx < C || lddy < K) return OMNI_ERR_ARG;
     const long P = (long)N * p.OH * p.OW;
     const int Nn = R * S * C;
@@ -1331,6 +1426,20 @@ int omni_conv2d_wgrad_det(const float* x, const float* dy, float* dw, int N, int
                           void* stream) {
     return conv2d_wgrad_impl(x, dy, dw, N, H, W, C, K, R, S, stride, pad, ldx, lddy, accumulate, tile, stream,
                              DetArgs{ws, ws_floats, (unsigned*)ctr, n_ctr, plan});
+}
+
+// omni_conv2d_wgrad_det for an input that is the channel concatenation of nsrc <= 6 dense NHWC tensors (see omni_conv2d_fwd_multi_det):
+// dw (K, 1, 1, sum cs) = dy^T x without the concatenated copy; cs[s] % 4 == 0.  ctr == NULL && plan == NULL: non-deterministic form.
+int omni_conv2d_wgrad_multi_det(const void* const* xs, const int* cs, int nsrc, const float* dy, float* dw, int N, int H, int W, int K,
+                                int lddy, int accumulate, int tile, float* ws, long long ws_floats, int* ctr, int n_ctr, long long* plan,
+                                void* stream) {
+    if (xs == nullptr || cs == nullptr || nsrc < 1 || nsrc > OMNI_MAX_SRC) return OMNI_ERR_ARG;
+    long C = 0;
+    for (int q = 0; q < nsrc; ++q) C += cs[q] > 0 ? cs[q] : 0;
+    if (C <= 0 || C > (1 << 20)) return OMNI_ERR_ARG;
+    const MultiSrc ms{xs, cs, nsrc};
+    return conv2d_wgrad_impl((const float*)xs[0], dy, dw, N, H, W, (int)C, K, 1, 1, 1, 0, (int)C, lddy, accumulate, tile, stream,
+                             DetArgs{ws, ws_floats, (unsigned*)ctr, n_ctr, plan}, &ms);
 }
 
 int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,

@@ -14,10 +14,12 @@ import torch
 from torch import nn
 
 from .... import functional as HF
+from ....kernels import conv as kconv
 from ..layers import BatchNorm2d, Conv2d, GroupedConv2d
 from ..registries import BACKBONE_REGISTRY
 from .fpn import FPN, Backbone
 
+_ROOT_MULTI_SRC = os.environ.get("OMNI_ROOT_MULTI_SRC", "1") != "0"     # A/B knob: 0 = Root concatenates its children (rounds 1-4)
 _SHARE_POOL = os.environ.get("OMNI_DLA_SHARE_POOL", "1") != "0"      # A/B knob: nested trees pool their common input once
 
 
@@ -114,8 +116,15 @@ class Root(nn.Module):
         self.residual = residual
 
     def forward(self, *x):
-        # (the concatenation hands each child its slice of the gradient through the child's fan-in slot, see functional.fanout)
-        y = self.conv(HF.cat_channels(x) if (self.training and torch.is_grad_enabled()) else torch.cat(x, 1))
+        conv = self.conv
+        if _ROOT_MULTI_SRC and conv.kernel_size == (1, 1) and conv.bias is None and kconv.multi_src_eligible(x, conv.weight):
+            # the 1 x 1 convolution reads its reduction slabs from the children directly: torch.cat(x, 1) is never formed (six
+            # copies of 7-16 us on the critical path of the 4 x 512 x 512 step, and as many in an inference pass)
+            want_stats = self.training and torch.is_grad_enabled()
+            y = HF.cat_conv1x1(x, conv.weight, want_stats)
+        else:
+            # (the concatenation hands each child its slice of the gradient through the child's fan-in slot, see functional.fanout)
+            y = conv(HF.cat_channels(x) if (self.training and torch.is_grad_enabled()) else torch.cat(x, 1))
         return self.bn(y, residual=x[0] if self.residual else None, relu=True)
 
 

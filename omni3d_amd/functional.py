@@ -1007,6 +1007,59 @@ class _CatChannels(Function):
         return tuple(outs)
 
 
+class _CatConv1x1(Function):
+    """conv1x1(torch.cat(xs, 1)) of the DLA Root (dla.py:166-172) without the concatenated copy in the forward pass: the kernel reads
+    every reduction slab from the child that holds its channels (csrc/conv_gemm.hip, ConvP::xs), with the BatchNorm statistics in
+    its epilogue like any conv -> BatchNorm pair.  Backward: ONE data gradient of the concatenated input whose channel slices --
+    strided views -- go to the children through their fan-in slots exactly as `_CatChannels` hands them over; the weight gradient
+    reads the children in place as well.  Bit-identical to `_Conv2d(_CatChannels(xs))`."""
+
+    @staticmethod
+    def forward(ctx, w, want_stats, *xs):
+        ctx.set_materialize_grads(False)
+        ctx.direct = _direct_grad(w)
+        ctx.slots = [_slot_enter(x, ctx.needs_input_grad[2 + i]) for i, x in enumerate(xs)]
+        xs = [_cl(x) for x in xs]
+        w = _cl(w)
+        y, parts = conv.conv1x1_multi_fwd(xs, w, want_stats=want_stats)
+        ctx.save_for_backward(w, *xs)
+        parts = _parts_out(parts, y)
+        ctx.mark_non_differentiable(parts)
+        return y, parts
+
+    @staticmethod
+    def backward(ctx, dy, _parts_grad=None):
+        w, *xs = ctx.saved_tensors
+        dy = _cl(dy)
+        gw = ctx.direct
+        if gw is not None and not gw.is_contiguous(memory_format=CL):
+            gw = None
+        outs = [None] * len(xs)
+        if any(ctx.needs_input_grad[2:]):
+            g = conv.conv2d_dgrad(dy, w, (dy.shape[2], dy.shape[3]), 1, 0)
+            off = 0
+            for i, (slot, x) in enumerate(zip(ctx.slots, xs)):
+                piece = g[:, off:off + x.shape[1]]
+                off += x.shape[1]
+                if ctx.needs_input_grad[2 + i]:
+                    outs[i] = _slot_deliver(slot, lambda carry, piece=piece: _add_carry(piece, carry))
+        dw = None
+        if ctx.needs_input_grad[0]:
+            def wgrad():
+                return conv.conv1x1_multi_wgrad(xs, dy, accum_into=gw)
+            dw = _side_run(wgrad, (*xs, dy)) if gw is not None else wgrad()
+        return (dw, None) + tuple(outs)
+
+
+def cat_conv1x1(xs, w, want_stats=False):
+    """conv2d(torch.cat(xs, 1), w) for a 1 x 1, stride-1, bias-free convolution (see `_CatConv1x1`); the caller checked
+    `conv.multi_src_eligible(xs, w)`"""
+    y, parts = _CatConv1x1.apply(w, want_stats, *xs)
+    if parts.shape[0] > 0:
+        y._omni_bn_partials = parts
+    return y
+
+
 class _PadInputChannels(Function):
     """(K, C, R, S) filter -> (K, C4, R, S) with zero input channels appended: the 3-channel stem filter against the image padded to
     4 channels (dla.py:241-245).  The padded copy lives in a persistent buffer whose extra channels stay zero, so a step pays one

@@ -110,6 +110,50 @@ def conv2d_fwd_stats(x, w, stride=1, pad=0):
     return out.permute(0, 3, 1, 2), (stats[:cell.value] if cell.value > 0 else None)
 
 
+MULTI_SRC_MAX = 6
+
+
+def multi_src_eligible(xs, w):
+    """omni_conv2d_fwd_multi_det serves: a 1 x 1 filter over 2..6 same-sized maps whose channel counts are multiples of 32"""
+    if not (2 <= len(xs) <= MULTI_SRC_MAX) or w.dim() != 4 or w.shape[2] != 1 or w.shape[3] != 1:
+        return False
+    n, _, h, wd = xs[0].shape
+    if any(x.dim() != 4 or x.shape[0] != n or x.shape[2] != h or x.shape[3] != wd or x.shape[1] % 32 or x.dtype != torch.float32 for x in xs):
+        return False
+    return sum(x.shape[1] for x in xs) == w.shape[1] and n * h * wd * max(x.shape[1] for x in xs) < (1 << 31)
+
+
+def conv1x1_multi_fwd(xs, w, bias=None, relu=False, want_stats=False, tile=0, splits=0):
+    """conv2d_fwd(torch.cat(xs, 1), w) for a 1 x 1 filter WITHOUT the concatenated copy (the DLA Root, dla.py:166-172): every
+    reduction slab reads its channels from the map that holds them; bit-identical to the single-tensor call.
+    -> (y (N,K,H,W) CL, BatchNorm partial statistics (nblk, 2K) or None)"""
+    import ctypes
+    xv = [_nhwc(x) for x in xs]
+    wv = _nhwc(w)
+    N, H, W, _ = xv[0].shape
+    K = wv.shape[0]
+    L = _lib.check_device(*xv, wv, bias)
+    out = torch.empty((N, H, W, K), dtype=torch.float32, device=xv[0].device)
+    n = len(xv)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in xv])
+    cs = (ctypes.c_int * n)(*[int(t.shape[3]) for t in xv])
+    pa, ca = ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(cs, ctypes.c_void_p)
+    stats = _stats_buf(K, out.device) if want_stats and bias is None and not relu else None
+    cell, addr = _nblk_cell()
+    st = _lib.stream_of(xv[0])
+    head = (pa, ca, n, _lib.ptr(wv), _lib.ptr(bias), _lib.ptr(out), N, H, W, K, K, int(relu))
+    if not _det.on():
+        L.call("omni_conv2d_fwd_multi_det", *head, tile, splits, _lib.ptr(stats), STATS_ROWS if stats is not None else 0, addr, None, 0, None, 0,
+               None, st)
+    else:
+        plan, paddr = _det.new_plan()
+        L.call("omni_conv2d_fwd_multi_det", *head, tile, splits, None, 0, None, None, 0, None, 0, paddr, st)
+        ws, wsf, ctr, nctr = _det.workspace(xv[0], plan)
+        L.call("omni_conv2d_fwd_multi_det", *head, int(plan[0]), int(plan[1]), _lib.ptr(stats), STATS_ROWS if stats is not None else 0, addr,
+               _lib.ptr(ws), wsf, _lib.ptr(ctr), nctr, None, st)
+    return out.permute(0, 3, 1, 2), (stats[:cell.value] if stats is not None and cell.value > 0 else None)
+
+
 def stem_conv_fwd_stats(x, w):
     xv, wv = _nhwc(x), _nhwc(w)
     N, H, W, C = xv.shape
@@ -159,6 +203,36 @@ def conv2d_wgrad(x, dy, ksize, stride=1, pad=0, accum_into=None, tile=0):
     dw = torch.empty((K, R, S, C), dtype=torch.float32, device=x.device)
     _wgrad_launch(L, _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, K, R, S, stride, pad, C, K, 0, tile, x)
     return dw.permute(0, 3, 1, 2)
+
+
+def conv1x1_multi_wgrad(xs, dy, accum_into=None, tile=0):
+    """conv2d_wgrad(torch.cat(xs, 1), dy, (1, 1)) without the concatenated copy (omni_conv2d_wgrad_multi_det); same contract"""
+    import ctypes
+    xv = [_nhwc(x) for x in xs]
+    dyv = _nhwc(dy)
+    N, H, W, K = dyv.shape
+    C = sum(int(t.shape[3]) for t in xv)
+    L = _lib.check_device(*xv, dyv)
+    n = len(xv)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in xv])
+    cs = (ctypes.c_int * n)(*[int(t.shape[3]) for t in xv])
+    pa, ca = ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(cs, ctypes.c_void_p)
+    if accum_into is not None:
+        tgt = accum_into.permute(0, 2, 3, 1)
+        assert tgt.is_contiguous() and tgt.shape == (K, 1, 1, C)
+        dw, acc = tgt, 1
+    else:
+        dw, acc = torch.empty((K, 1, 1, C), dtype=torch.float32, device=dyv.device), 0
+    st = _lib.stream_of(dyv)
+    head = (pa, ca, n, _lib.ptr(dyv), _lib.ptr(dw), N, H, W, K, K, acc, tile)
+    if not _det.on():
+        L.call("omni_conv2d_wgrad_multi_det", *head, None, 0, None, 0, None, st)
+    else:
+        plan, paddr = _det.new_plan()
+        L.call("omni_conv2d_wgrad_multi_det", *head, None, 0, None, 0, paddr, st)
+        ws, wsf, ctr, nctr = _det.workspace(dyv, plan)
+        L.call("omni_conv2d_wgrad_multi_det", *head, _lib.ptr(ws), wsf, _lib.ptr(ctr), nctr, None, st)
+    return None if accum_into is not None else dw.permute(0, 3, 1, 2)
 
 
 def _engine_eligible(M, C, K):

@@ -676,3 +676,81 @@ def test_collected_weight_gradients_emulated(emu_lib):
         assert torch.equal(a, b)
     for a, b in zip(ref_p[0] + ref_p[1] + [ref_p[2]], got_p[0] + got_p[1] + [got_p[2]]):
         assert torch.equal(a.grad, b.grad)
+
+
+def _run_multi_src(dev, cases):
+    """round 5: the DLA Root's conv1x1(torch.cat(children, 1)) with the children read in place (omni_conv2d_fwd_multi_det) is
+    BIT-identical to the single-tensor call on the concatenated copy -- output, BatchNorm statistics, every tile / split choice --
+    and the autograd function hands back the same gradients as concatenate + conv2d"""
+    from omni3d_amd import functional as HF
+    from omni3d_amd.kernels import conv
+    g = torch.Generator().manual_seed(21)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last).to(dev)  # noqa: E731
+    for (N, H, W, cs, K, tile, splits) in cases:
+        xs = [cl(torch.randn(N, c, H, W, generator=g)) for c in cs]
+        w = cl(torch.randn(K, sum(cs), 1, 1, generator=g) * 0.05)
+        assert conv.multi_src_eligible(xs, w)
+        cat = cl(torch.cat(xs, 1))
+        y, parts = conv.conv1x1_multi_fwd(xs, w, want_stats=True, tile=tile, splits=splits)
+        if tile == 0 and splits == 0:
+            y0, parts0 = conv.conv2d_fwd_stats(cat, w, 1, 0)
+            assert (parts is None) == (parts0 is None)
+            if parts is not None:
+                assert torch.equal(parts, parts0)
+        else:
+            y0 = conv.conv2d_fwd(cat, w, None, 1, 0, tile=tile, splits=splits)
+        assert torch.equal(y, y0), (cs, tile, splits, float((y - y0).abs().max()))
+        ref = F.conv2d(torch.cat([x.cpu() for x in xs], 1), w.cpu())
+        assert (y.cpu() - ref).abs().max() <= 2e-5 * float(ref.abs().max())
+        b = torch.randn(K, generator=g).to(dev)
+        yb, _ = conv.conv1x1_multi_fwd(xs, w, bias=b, relu=True)
+        assert torch.equal(yb, conv.conv2d_fwd(cat, w, b, 1, 0, relu=True))
+        if tile == 0:       # the weight gradient reads the children in place as well
+            dy = cl(torch.randn(N, K, H, W, generator=g))
+            assert torch.equal(conv.conv1x1_multi_wgrad(xs, dy), conv.conv2d_wgrad(cat, dy, (1, 1), 1, 0))
+            into = cl(torch.randn(K, sum(cs), 1, 1, generator=g))
+            into2 = into.clone(memory_format=torch.channels_last)
+            conv.conv1x1_multi_wgrad(xs, dy, accum_into=into)
+            conv.conv2d_wgrad(cat, dy, (1, 1), 1, 0, accum_into=into2)
+            assert torch.equal(into, into2)
+    # not served: a width that is not a multiple of 32, a 3 x 3 filter, a single input
+    assert not conv.multi_src_eligible([xs[0], xs[0][:, :16]], torch.zeros(8, xs[0].shape[1] + 16, 1, 1))
+    assert not conv.multi_src_eligible(xs, torch.zeros(8, sum(cs), 3, 3)) and not conv.multi_src_eligible(xs[:1], torch.zeros(8, cs[0], 1, 1))
+    # autograd: gradients of the children (one of them with a second consumer: the fan-in slot) and of the filter
+    N, H, W, cs, K = 2, 9, 11, (64, 32, 64), 48
+    base = [torch.randn(N, c, H, W, generator=g) for c in cs]
+    w0 = torch.randn(K, sum(cs), 1, 1, generator=g) * 0.05
+    dy = cl(torch.randn(N, K, H, W, generator=g))
+    grads = []
+    for multi in (True, False):
+        leaves = [cl(t.clone()).requires_grad_(True) for t in base]
+        wk = cl(w0.clone()).requires_grad_(True)      # (clone: a 1 x 1 filter is channels_last as it is -- `cl` alone hands back w0 itself)
+        xs = [HF.fanout(t * 1.0) if i == 0 else t * 1.0 for i, t in enumerate(leaves)]
+        y = HF.cat_conv1x1(xs, wk) if multi else HF.conv2d(HF.cat_channels(xs), wk, None, 1, 0)
+        extra = HF.conv2d(xs[0], cl(torch.ones(8, cs[0], 1, 1) * 0.01), None, 1, 0).sum()      # the second consumer of the first child
+        (y * dy).sum().add(extra).backward()
+        HF.side_join()
+        grads.append([t.grad.clone() for t in leaves] + [wk.grad.clone()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    ref_leaves = [t.clone().requires_grad_(True) for t in base]
+    wr = w0.clone().requires_grad_(True)
+    (F.conv2d(torch.cat(ref_leaves, 1), wr) * dy.cpu()).sum().add(F.conv2d(ref_leaves[0], torch.ones(8, cs[0], 1, 1) * 0.01).sum()).backward()
+    for a, r in zip(grads[0], [t.grad for t in ref_leaves] + [wr.grad]):
+        assert (a.cpu() - r).abs().max() <= 1e-4 * max(float(r.abs().max()), 1.0)
+
+
+MULTI_SRC_SMALL = [(2, 9, 11, (64, 64), 64, 0, 0), (1, 8, 8, (128, 128, 64, 128), 128, 0, 0), (2, 4, 4, (256, 256, 128, 256), 256, 0, 0),
+                   (1, 6, 7, (32, 96, 32, 64, 32, 32), 40, 2, 3), (2, 5, 5, (64, 32), 72, 3, 1), (1, 16, 16, (64, 64), 128, 1, 2), (1, 5, 9, (32, 32), 16, 4, 1)]
+
+
+def test_conv1x1_multi_source_emulated(emu_lib):
+    _run_multi_src("cpu", MULTI_SRC_SMALL)
+
+
+@pytest.mark.gpu
+def test_conv1x1_multi_source_gpu(hip_lib):
+    # the six Roots of DLA-34 at the benchmark's size (4 x 512 x 512) + the small cases
+    _run_multi_src("cuda", [(4, 128, 128, (64, 64), 64, 0, 0), (4, 64, 64, (128, 128), 128, 0, 0), (4, 64, 64, (128, 128, 64, 128), 128, 0, 0),
+                            (4, 32, 32, (256, 256), 256, 0, 0), (4, 32, 32, (256, 256, 128, 256), 256, 0, 0), (4, 16, 16, (512, 512, 256), 512, 0, 0)]
+                   + MULTI_SRC_SMALL)
