@@ -32,6 +32,7 @@ for r in rows[lo:]:
 PY
 [ -s $OUT/${TAG}_trace_tail.csv ] && python tools/trace_timeline.py $OUT/${TAG}_trace_tail.csv $OUT/${TAG}_timeline.txt && head -3 $OUT/${TAG}_timeline.txt
 find $OUT/${TAG}_prof -name '*kernel_trace.csv' -delete
+if [ "${SKIP_PMC:-0}" = "0" ]; then
 timeout 600 python tools/pmc_run.py $OUT/${TAG}_pmc $OUT/${TAG}_pmc_families.csv -- python $REPO/tools/run_families.py > $OUT/${TAG}_pmc.log 2>&1
 tail -3 $OUT/${TAG}_pmc.log | cut -c1-200
 [ -s $OUT/${TAG}_pmc_families.csv ] && cp $OUT/${TAG}_pmc_families.csv profiles/r05_pmc_families.csv
@@ -40,6 +41,7 @@ OMNI_BENCH_SKIP_CPU=1 timeout 600 python tools/pmc_run.py $OUT/${TAG}_pmc_iou3d 
 tail -3 $OUT/${TAG}_pmc_iou3d.log | cut -c1-200
 [ -s $OUT/${TAG}_pmc_iou3d.csv ] && cp $OUT/${TAG}_pmc_iou3d.csv profiles/r05_pmc_iou3d.csv
 find $OUT/${TAG}_pmc_iou3d -name '*kernel_trace.csv' -delete; find $OUT/${TAG}_pmc_iou3d -name '*counter_collection.csv' -delete
+fi   # (SKIP_PMC=1: the committed profiles/r05_pmc_*.csv of this round stay -- same kernels, see profiles/README.md)
 OMNI_PIPE_TIMING=1 OMNI_BENCH_SKIP_CPU=1 OMNI_BENCH_SKIP_ROOFLINE=1 timeout 300 python bench.py --workload train --steps 30 --warmup 5 2>&1 | grep -E "pipe timing" > $OUT/${TAG}_pipe_timing.log
 timeout 1500 python bench.py > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.log
