@@ -713,6 +713,22 @@ def _run_multi_src(dev, cases):
             conv.conv1x1_multi_wgrad(xs, dy, accum_into=into)
             conv.conv2d_wgrad(cat, dy, (1, 1), 1, 0, accum_into=into2)
             assert torch.equal(into, into2)
+    # the non-deterministic form (split reductions meet through atomics): same sums up to their order
+    from omni3d_amd.kernels import detmode
+    prev = detmode.set_enabled(False)
+    try:
+        N, H, W, cs, K = 2, 4, 4, (256, 256, 128, 256), 256
+        xs = [cl(torch.randn(N, c, H, W, generator=g)) for c in cs]
+        w = cl(torch.randn(K, sum(cs), 1, 1, generator=g) * 0.05)
+        cat = cl(torch.cat(xs, 1))
+        y, _ = conv.conv1x1_multi_fwd(xs, w, want_stats=True)
+        y0 = conv.conv2d_fwd(cat, w, None, 1, 0)
+        assert (y - y0).abs().max() <= 2e-5 * float(y0.abs().max())
+        dy = cl(torch.randn(N, K, H, W, generator=g))
+        d, d0 = conv.conv1x1_multi_wgrad(xs, dy), conv.conv2d_wgrad(cat, dy, (1, 1), 1, 0)
+        assert (d - d0).abs().max() <= 2e-5 * float(d0.abs().max())
+    finally:
+        detmode.set_enabled(prev)
     # not served: a width that is not a multiple of 32, a 3 x 3 filter, a single input
     assert not conv.multi_src_eligible([xs[0], xs[0][:, :16]], torch.zeros(8, xs[0].shape[1] + 16, 1, 1))
     assert not conv.multi_src_eligible(xs, torch.zeros(8, sum(cs), 3, 3)) and not conv.multi_src_eligible(xs[:1], torch.zeros(8, cs[0], 1, 1))
