@@ -156,25 +156,70 @@ def run_train(args, world, rank):
             eager_step()
         executed_flops = counter.flops
 
+    # Conditioning: a fixed number of UNTIMED steps before the warm-up so that every timed window sees the device in
+    # the power / clock state of sustained training, not the first 0.3 s after idle (fixed count: every rank issues the same collectives)
+    n_cond = int(os.environ.get("OMNI_BENCH_CONDITION_STEPS", "150" if DEVICE == "cuda" else "0"))
+    from omni3d_amd.profile_io import GpuState
+    gpu = GpuState(torch.cuda.current_device()) if DEVICE == "cuda" else None
+    state = {"idle": gpu.sample() if gpu else None}
+    for i in range(n_cond):
+        step()
+        if i % 16 == 15:
+            _sync()                              # (keeps the host at most 16 steps ahead)
     for _ in range(args.warmup):
         step()
-    _sync()
-    if world > 1:
-        dist.barrier()
-    _sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_enqueue = time.perf_counter() - t0       # host time to enqueue the K steps (diagnostic: < dt means GPU-bound)
-    _sync()
-    if world > 1:
-        dist.barrier()
-    _sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=DEVICE)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # WINDOWS back-to-back windows of exactly `--steps` steps, each bracketed by synchronize + barrier on both sides and reduced with
+    # MAX over the ranks; the line's `ms_per_step` / `value` are the MEDIAN window (min / max beside it).  Between the enqueue of a
+    # window and its synchronize the device is still busy: that is when clocks / power / temperature are read.
+    n_win = max(1, int(os.environ.get("OMNI_BENCH_WINDOWS", "5")))
+    windows, enqueue, under_load = [], [], []
+    for _ in range(n_win):
+        _sync()
+        if world > 1:
+            dist.barrier()
+        _sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        enqueue.append(time.perf_counter() - t0)   # host time to enqueue the K steps (diagnostic: < dt means GPU-bound)
+        if gpu:
+            under_load.append(gpu.sample())
+        _sync()
+        if world > 1:
+            dist.barrier()
+        _sync()
+        w_dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([w_dt], dtype=torch.float64, device=DEVICE)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w_dt = float(t.item())
+        windows.append(w_dt)
+    order = sorted(range(n_win), key=lambda i: windows[i])
+    mid = order[(n_win - 1) // 2]                  # the median window (lower median for an even count)
+    dt, t_enqueue = windows[mid], enqueue[mid]
+    state["under_load"] = under_load[mid] if under_load else None
+    state["under_load_all_windows"] = under_load
+    state["neighbours"] = gpu.neighbours() if gpu else None
+    state["pci_address"] = gpu.address if gpu else None
+    # one more window of the same length WITH the per-stage device timestamps (end of every critical-path graph M_k and of every
+    # weight-gradient graph W_k after the step's first launch): never part of the measured windows
+    stage_ends = None
+    if DEVICE == "cuda" and getattr(graphed, "stages", None) and os.environ.get("OMNI_BENCH_SKIP_STAGE_ENDS") != "1":
+        from omni3d_amd.cubercnn.solver import graphed as _gm
+        was = _gm._PIPE_TIMING
+        _gm.set_pipe_timing(True)
+        _sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        _sync()
+        t_win = time.perf_counter() - t1
+        tab = _gm.pipe_timing_table(graphed, last=args.steps)
+        _gm.set_pipe_timing(was)
+        if tab:
+            stage_ends = {"M_end_ms": [None if v is None else round(v, 3) for v in tab["M_end_ms"]],
+                          "W_end_ms": [None if v is None else round(v, 3) for v in tab["W_end_ms"]],
+                          "window_ms_per_step": round(1e3 * t_win / args.steps, 4)}
     if os.environ.get("OMNI_PIPE_TIMING") == "1" and getattr(graphed, "_timing", None):
         import sys
         from omni3d_amd.cubercnn.solver.graphed import pipe_timing_report
@@ -197,6 +242,12 @@ def run_train(args, world, rank):
                    "global_batch": IMS_PER_GPU * world, "image": f"{IMAGE_SIZE}x{IMAGE_SIZE}",
                    "parallelism": f"dp{world} (flat-bucket RCCL all-reduce)"},
         "host_enqueue_ms_per_step": 1e3 * t_enqueue / args.steps,
+        "windows": {"ms_per_step": [round(1e3 * w / args.steps, 4) for w in windows], "min": 1e3 * min(windows) / args.steps,
+                    "median": 1e3 * dt / args.steps, "max": 1e3 * max(windows) / args.steps,
+                    "value_is": f"median of {n_win} back-to-back windows of {args.steps} steps, each bracketed by synchronize + barrier, MAX over ranks",
+                    "conditioning_steps_before_warmup": n_cond},
+        "gpu_state": state,
+        "stage_ends": stage_ends,
         "launch_mode": graph_note,
         "step_mfma_frac": step_tf / FP32_MFMA_PEAK_TF,
         "step_algorithmic_tflops_per_gpu": step_tf,

@@ -46,8 +46,8 @@ def profile_counters(csv_name, kernel_substr, grid=None):
     return out
 
 
-def latest_profile(name, rounds=("r05", "r04", "r03", "r02")):
-    """newest committed round of a profile artefact: profiles/r05_<name> if it exists, else r04_<name>, ..."""
+def latest_profile(name, rounds=("r06", "r05", "r04", "r03", "r02")):
+    """newest committed round of a profile artefact: profiles/r06_<name> if it exists, else r05_<name>, ..."""
     for r in rounds:
         if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_{name}")):
             return f"{r}_{name}"
@@ -192,3 +192,64 @@ def host_cores():
     except OSError:
         pass
     return info
+
+
+class GpuState:
+    """Clock / power / temperature of the device a rank runs on, read from the amdgpu hwmon files of ITS PCI function (the GPU box
+    is one tenant of an 8-GPU host: /sys/class/drm shows every card, torch's device properties say which one is ours).  A read is
+    four small files (~50 us): `sample()` between the enqueue of a timed window and its synchronize sees the device UNDER the load,
+    which is what a step-time difference between two boxes has to be explained with.  `neighbours()`:
+    how many of the host's other GPUs are clocked up, and their summed power -- the other tenants share the host's CPUs."""
+
+    FILES = (("sclk_mhz", "freq1_input", 1e-6), ("mclk_mhz", "freq2_input", 1e-6), ("power_w", "power1_input", 1e-6),
+             ("temp_junction_c", "temp2_input", 1e-3), ("temp_mem_c", "temp3_input", 1e-3))
+
+    def __init__(self, index=0):
+        self.dir, self.hwmon, self.address = None, None, None
+        try:
+            import glob
+            import torch
+            p = torch.cuda.get_device_properties(index)
+            self.address = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            d = os.path.join("/sys/bus/pci/devices", self.address)
+            hw = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*")))
+            if hw:
+                self.dir, self.hwmon = d, hw[0]
+        except Exception:  # noqa: BLE001 -- no GPU / no sysfs: every sample is None
+            pass
+
+    @staticmethod
+    def _read(path, scale):
+        try:
+            with open(path) as f:
+                return round(float(f.read().split()[0]) * scale, 1)
+        except (OSError, ValueError, IndexError):
+            return None
+
+    def sample(self):
+        if self.hwmon is None:
+            return None
+        out = {k: self._read(os.path.join(self.hwmon, f), s) for k, f, s in self.FILES}
+        out["busy_pct"] = self._read(os.path.join(self.dir, "gpu_busy_percent"), 1.0)
+        return out
+
+    def neighbours(self):
+        """the host's OTHER GPUs: count, how many run above 1 GHz right now, their summed socket power"""
+        if self.hwmon is None:
+            return None
+        import glob
+        n = up = 0
+        watts = 0.0
+        for hw in glob.glob("/sys/bus/pci/devices/*/hwmon/hwmon*"):
+            if hw == self.hwmon:
+                continue
+            try:
+                if open(os.path.join(hw, "name")).read().strip() != "amdgpu":
+                    continue
+            except OSError:
+                continue
+            n += 1
+            f = self._read(os.path.join(hw, "freq1_input"), 1e-6)
+            up += 1 if (f or 0) > 1000 else 0
+            watts += self._read(os.path.join(hw, "power1_input"), 1e-6) or 0.0
+        return {"other_gpus": n, "clocked_up": up, "power_w_sum": round(watts, 0)}
