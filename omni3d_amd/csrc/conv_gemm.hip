@@ -1117,7 +1117,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
             if (live && (ms->xs[q] == nullptr || ms->cs[q] <= 0 || (ms->cs[q] % 32) != 0)) return OMNI_ERR_ARG;
             p.xs[q] = live ? (const float*)ms->xs[q] : nullptr;
             p.coff[q + 1] = p.coff[q] + (live ? ms->cs[q] : 0);
-            if (live && (long)N * H * W * ms->cs[q] >= (1L << 31)) return OMNI_ERR_ARG;
+            if (live && (long)N * H * W * ms->cs[q] * 4 >= (1L << 31)) return OMNI_ERR_ARG;
         }
         if (p.coff[ms->nsrc] != C || ldx != C) return OMNI_ERR_ARG;
         p.nsrc = ms->nsrc;
@@ -1129,6 +1129,10 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, fl
     if (M == 0) return OMNI_OK;
     hipStream_t st = (hipStream_t)stream;
     const long Kd = (long)R * S * C;
+    // conv_fwd_kernel addresses x and w through buffer resources with 32-bit BYTE offsets (OMNI_OOB = 0x80000000 marks a lane as
+    // out of range): an operand of 2 GiB or more would wrap into the resource and read wrong data silently -- refuse it
+    if (ms == nullptr && (((long)N * H * W - 1) * ldx + C) * 4 >= (1L << 31)) return OMNI_ERR_ARG;
+    if ((long)K * Kd * 4 >= (1L << 31)) return OMNI_ERR_ARG;
     const long nslab = (Kd + 31) / 32;
     const long t128 = ((M + 127) / 128) * ((K + 127) / 128);
     const long t64 = ((M + 63) / 64) * ((K + 63) / 64);

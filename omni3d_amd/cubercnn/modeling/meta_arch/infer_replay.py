@@ -91,17 +91,10 @@ class InferReplay:
         the flat optimizers and replayed training steps move values through raw pointers), or a parameter / buffer whose STORAGE was
         replaced (`model.to()`, `.double()`: the graph would keep reading the freed allocation) -- ADVICE r4"""
         from ..layers import PARAM_EPOCH
-        if self._tensors is None:
-            self._tensors = list(self.model.parameters()) + list(self.model.buffers())
-            if "_apply" not in self.model.__dict__:         # `model.to()` / `.double()` / `.cuda()` REPLACE the buffer objects: re-list after them
-                inner, me = self.model._apply, self
-
-                def _apply(fn, *a, **k):
-                    out = inner(fn, *a, **k)
-                    PARAM_EPOCH[0] += 1
-                    me._tensors = None
-                    return out
-                self.model.__dict__["_apply"] = _apply
+        # re-listed on every call (~0.2 ms for the 330 tensors of the model): `model.to()` / `.double()` / `.cuda()` REPLACE parameter
+        # and buffer objects, and a hook on `_apply` stored in the instance dict broke torch.save(model) and made a deepcopy of the
+        # model move the ORIGINAL's tensors (ADVICE r5) -- the data_ptr hash below sees a replaced storage without any hook
+        self._tensors = list(self.model.parameters()) + list(self.model.buffers())
         tensors = self._tensors
         return (PARAM_EPOCH[0], sum(t._version for t in tensors), len(tensors), hash(tuple(t.data_ptr() for t in tensors)))
 

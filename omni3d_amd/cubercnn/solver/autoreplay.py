@@ -43,7 +43,12 @@ from ... import functional as HF
 from ..modeling.targets import MAX_GT_PER_IMAGE, pack_targets
 
 ENABLED = os.environ.get("OMNI_AUTO_REPLAY", "1") != "0"
-CACHE = int(os.environ.get("OMNI_AUTO_REPLAY_CACHE", "16"))           # captured steps kept (a few GB of graph-private memory each)
+# captured steps kept.  Round 6: 64 by default (was 16) AND bounded by memory -- a capture is refused room before it starts if the
+# device has less than RESERVE_GB + 1.5 x the largest captured step free; least recently used buckets go first.  MI355X has 288 GB:
+# the ~70 size buckets of the reference's loader (Base.yaml's 25 short edges x the datasets' aspect ratios on the 64 grid) fit, so
+# the DEFAULT keeps the eager pass's padding grid and a replayed iteration is the same computation as an eager one.
+CACHE = int(os.environ.get("OMNI_AUTO_REPLAY_CACHE", "64"))
+RESERVE_GB = float(os.environ.get("OMNI_AUTO_REPLAY_RESERVE_GB", "24"))
 # A/B: stage new batches through pinned host buffers with stream-ordered copies.  MEASURED and left OFF: on this ROCm 7.2 host the 3 MB
 # of image slots take ~20 ms to cross from pinned memory (37.1 against 11.9 ms per iteration, profiles/r04_dropin_phases.log); the pageable
 # copies block the host until the previous step has drained, which costs 0.3 ms per iteration with the losses read every 1000th
@@ -58,7 +63,7 @@ BUCKET = 64                                                           # ImageLis
 # that much larger.  Watched over a sliding window of GUARD_WINDOW training iterations; whenever the share of iterations that did
 # not replay a cached bucket exceeds GUARD_MISS the guard moves one level up (at most once per window, one warning each):
 #   level 0  buckets on the grid the eager pass pads to (64: replay and eager see the same tensor);
-#   level k  extents above GRID_ABOVE rounded up to GRIDS[k - 1] (128, 256: at most ~3 x 6 buckets for Base.yaml's sizes).  The guard
+#   level k  (only with OMNI_AUTO_REPLAY_GRIDS set, see GRIDS) extents above GRID_ABOVE rounded up to GRIDS[k - 1].  The guard
 #            does not climb one grid per window: it replays the extents of the last iterations under every candidate grid and takes
 #            the FINEST one whose bucket count fits three quarters of the cache (measured on the 200-iteration stream: stepping
 #            128 -> 256 one window at a time was still missing half the iterations when the run ended);
@@ -66,7 +71,12 @@ BUCKET = 64                                                           # ImageLis
 # An evicted bucket has to earn its `warm` eager iterations again (its counter is reset).
 GUARD_WINDOW = int(os.environ.get("OMNI_AUTO_REPLAY_WINDOW", "48"))
 GUARD_MISS = float(os.environ.get("OMNI_AUTO_REPLAY_MISS", "0.25"))
-GRIDS = tuple(int(v) for v in os.environ.get("OMNI_AUTO_REPLAY_GRIDS", "128,256").split(",") if v)
+# Coarser bucket grids are OPT-IN since round 6: a slot padded to a 128 / 256 grid is NOT the tensor the eager pass
+# or the reference builds (ImageList pads to size_divisibility = 64 of the batch maximum) -- BatchNorm's batch statistics then include
+# the extra zero padding and the RPN samples among additional all-negative anchors, so replayed iterations would differ numerically
+# from eager ones of the same run and from the reference.  OMNI_AUTO_REPLAY_GRIDS=128,256 trades that parity for a higher hit rate;
+# without it the guard's only escalation is "no new captures".
+GRIDS = tuple(int(v) for v in os.environ.get("OMNI_AUTO_REPLAY_GRIDS", "").split(",") if v)
 GRID_ABOVE = int(os.environ.get("OMNI_AUTO_REPLAY_GRID_ABOVE", "256"))
 ROW_FIELDS = ("gt", "gt_cls", "gt3d", "gtpose", "ign")           # (rows, ...) arrays indexed through gt_off / ign_off
 FIXED_FIELDS = ("gt_off", "ign_off", "Ks", "v2r", "ratio", "image_hw")
@@ -180,7 +190,8 @@ class AutoReplay:
         n = max(self.iters, 1)
         return {"iterations": self.iters, "replays": self.replays, "eager": self.eager_iters, "captures": self.captures, "recaptures": self.recaptures,
                 "evictions": self.evictions, "buckets_seen": len(self.counts) + len([k for k in self.ever if k not in self.counts]),
-                "buckets_cached": len(self.cache), "hit_rate": self.replays / n, "guard_level": self.level, "bucket_granularity": self.granularity}
+                "buckets_cached": len(self.cache), "hit_rate": self.replays / n, "guard_level": self.level, "bucket_granularity": self.granularity,
+                "cached_gb": round(sum(e.get("bytes", 0) for e in self.cache.values()) / (1 << 30), 2)}
 
     def _note(self, hit):
         """sliding-window bookkeeping of the thrash guard; escalates at most once per window"""
@@ -240,6 +251,7 @@ class AutoReplay:
                 self.eager_iters += 1
                 return None
             try:
+                self._make_room()
                 entry = self._capture(batched_inputs, sig)
             except Exception as e:  # noqa: BLE001 -- capture refused: stay on eager launches, say why once
                 self._drop()
@@ -316,6 +328,28 @@ class AutoReplay:
             bu.stage_cut = None
 
     # ---- capture -----------------------------------------------------------------------------------------------------
+    def _free_bytes(self):
+        """device memory a new capture's private pools can still get from the driver (blocks cached in OTHER graphs' pools are not
+        available to it; the general pool's cached blocks are handed back first if the figure is short)"""
+        return torch.cuda.mem_get_info()[0]
+
+    def _make_room(self):
+        """memory bound of the cache: least recently used captured steps are released until RESERVE_GB + 1.5 x the largest captured
+        step so far is free (their graphs' private pools go back to the allocator)"""
+        if self.model.device.type != "cuda" or not self.cache:
+            return
+        need = RESERVE_GB * (1 << 30) + 1.5 * max((e.get("bytes", 0) for e in self.cache.values()), default=0)
+        if self._free_bytes() < need:
+            torch.cuda.empty_cache()
+        while self.cache and self._free_bytes() < need:
+            old_sig, old = self.cache.popitem(last=False)
+            self.counts.pop(old_sig, None)
+            self.evictions += 1
+            del old
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+
     def _capture(self, batch, sig):
         from .graphed import GraphedPipelined
         model, dev = self.model, self.model.device
@@ -341,6 +375,7 @@ class AutoReplay:
             setattr(packed, f, pad)
         packed.slotted = True                            # RCNN3D.preprocess_image masks the slots with packed.image_hw on the device
         graphs = self.graphs if self.graphs is not None else (dev.type == "cuda")
+        mem0 = torch.cuda.memory_reserved() if dev.type == "cuda" else 0
         # a capture is not a training step: its warm-up passes must not move the BatchNorm running statistics
         bufs = [(b, b.detach().clone()) for b in model.buffers()]
         self.busy = True
@@ -361,7 +396,8 @@ class AutoReplay:
         self.captures += 1
         # what the components would log this iteration (static tensors of the captured pass; flush_logs pops them)
         logs = [(m, dict(m.pending_logs)) for m in (model.proposal_generator, model.roi_heads) if hasattr(m, "pending_logs")]
-        return {"stepper": stepper, "batch": sb, "packed": packed, "slots": slots, "logs": logs}
+        return {"stepper": stepper, "batch": sb, "packed": packed, "slots": slots, "logs": logs,
+                "bytes": max(0, torch.cuda.memory_reserved() - mem0) if dev.type == "cuda" else 0}
 
     def _stage(self, entry, batch):
         """new data into the tensors the graphs were captured on.  With OMNI_AUTO_REPLAY_PINNED=1 everything crosses PCIe from pinned

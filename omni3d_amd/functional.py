@@ -1067,12 +1067,26 @@ class _PadInputChannels(Function):
 
     @staticmethod
     def forward(ctx, w, c4, holder):
+        import weakref
         buf = holder.get("buf")
         if buf is None or buf.shape[0] != w.shape[0] or buf.shape[1] != c4 or buf.device != w.device or buf.dtype != w.dtype:
             buf = holder["buf"] = torch.zeros((w.shape[0], c4, w.shape[2], w.shape[3]), dtype=w.dtype, device=w.device).contiguous(memory_format=CL)
+        last = holder.get("last")
+        if torch.is_grad_enabled() and last is not None and last() is not None and not torch.cuda.is_current_stream_capturing():
+            # the alias handed out by an EARLIER grad-mode forward is still alive -- a convolution saved it for a backward that has not
+            # run yet (forward, forward, backward, backward; two model calls under one loss).  Writing the buffer now would bump its
+            # version under that saved tensor: this call gets a padded tensor of its own instead.  Captured steps never
+            # take this branch: a capture owns one forward and one backward.
+            out = torch.zeros_like(buf)
+            out[:, : w.shape[1]].copy_(w)
+            ctx.c = w.shape[1]
+            return out
         buf[:, : w.shape[1]].copy_(w)
         ctx.c = w.shape[1]
-        return buf.detach()          # (a fresh alias per call: the buffer object itself never carries an autograd node)
+        out = buf.detach()           # (a fresh alias per call: the buffer object itself never carries an autograd node)
+        if torch.is_grad_enabled():
+            holder["last"] = weakref.ref(out)
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -1245,15 +1259,16 @@ class _SumVectors(Function):
 
     @staticmethod
     def forward(ctx, *vecs):
-        ctx.sizes = [int(v.numel()) for v in vecs]
+        ctx.shapes = [tuple(v.shape) for v in vecs]
         if len(vecs) == 1:
             return vecs[0].sum()
         return torch.cat([v.reshape(-1) for v in vecs]).sum()
 
     @staticmethod
     def backward(ctx, g):
-        g = g.reshape(1)
-        return tuple(g.expand(n) for n in ctx.sizes)
+        # (stride-0 views in the SHAPE of every input: a vector that is not 1-D gets a gradient of its own shape)
+        g = g.reshape(())
+        return tuple(g.expand(sh) for sh in ctx.shapes)
 
 
 def sum_vectors(vecs):
