@@ -232,6 +232,10 @@ int omni_preprocess(const unsigned char* img, float* out, int N, int H, int W, i
  * (configs/Base.yaml:10-13 draws a new short edge per image; cubercnn/solver/autoreplay.py). */
 int omni_preprocess_masked(const unsigned char* img, const int* image_hw, float* out, int N, int H, int W, int PH, int PW,
                            float m0, float m1, float m2, float s0, float s1, float s2, void* stream);
+/* Round 6: the same from N <= 64 SEPARATE images (imgs: HOST array of N device pointers to planar uint8 (3, H, W) images) -- the
+ * `torch.stack` of ImageList.from_tensors folded into the read; image_hw nullable. */
+int omni_preprocess_multi(const void* const* imgs, const int* image_hw, float* out, int N, int H, int W, int PH, int PW, float m0,
+                          float m1, float m2, float s0, float s1, float s2, void* stream);
 
 /* ----------------------------------------------------------- index-exact selection kernels */
 
@@ -346,6 +350,21 @@ int omni_roi_sample(const float* prop_boxes, const int* prop_count, int B, int p
                     float iou_thr, float ignore_thresh, float eps, int num_classes, int batch_per_image,
                     int nfg_max, int append_gt, float* out_boxes, int* out_cls, int* out_gt, float* out_iou,
                     int* out_counts, void* stream);
+/* Round 6 forms of the two subsampling steps: expo == NULL draws the Exp(1) variates INSIDE the kernel (csrc/philox.h: Philox4x32-10
+ * keyed by draw_state[0] = seed, counter (element, row, draw_state[1]); the last workgroup to take its ticket advances
+ * draw_state[1]; ticket: one zeroed int32) -- replaces `Tensor.exponential_()` + torch's graph-safe generator bookkeeping, six
+ * launches per step for the randomness of detectron2 `subsample_labels` (rpn.py:41-127 / roi_heads.py:862-929 call sites).
+ * omni_roi_sample_draw also emits out_row (out_gt with -1 -> 0, the `clamp(min=0)` of the loss call sites) and contiguous copies
+ * of the first `first` slots per image (the cube head's ROIs: roi_heads.py:341-362). */
+int omni_rpn_match_draw(const float* anchors, int A, const float* gt, const int* gt_off, int B, int G, float thr_lo,
+                        float thr_hi, int l0, int l1, int l2, int allow_low_quality, const float* expo, long long* draw_state,
+                        int* ticket, float eps, float* matched_val, int* matched_idx, signed char* match_label, int* gt_best_bits,
+                        int* gt_best_idx, float* key_pos, float* key_neg, void* stream);
+int omni_roi_sample_draw(const float* prop_boxes, const int* prop_count, int B, int pmax, const float* gt, const int* gt_cls,
+                         const int* gt_off, const float* ign, const int* ign_off, const float* expo, long long* draw_state, int* ticket,
+                         float iou_thr, float ignore_thresh, float eps, int num_classes, int batch_per_image, int nfg_max,
+                         int append_gt, float* out_boxes, int* out_cls, int* out_gt, float* out_iou, int* out_counts, int* out_row,
+                         int first, float* first_boxes, int* first_cls, int* first_row, void* stream);
 
 /* ----------------------------------------------------------------------------- ROIAlign */
 
@@ -359,6 +378,11 @@ int omni_roi_levels(const float* rois, int R, int min_level, int max_level, floa
 int omni_roi_align_fwd(const void* const* level_ptrs, const int* level_hw, const float* level_scale, int nlev,
                        const float* rois, const int* batch_idx, const int* levels, int R, int P, int C,
                        float* out, void* stream);
+/* Round 6: forward that also writes the first `first` ROIs of every block of `per_image` to out2 ((R / per_image) * first, P, P, C) --
+ * the box head's and the cube head's pooled features in one pass (roi_heads.py:166-171, 267, 362), no slice copy. */
+int omni_roi_align_fwd2(const void* const* level_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                        const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, float* out,
+                        float* out2, int per_image, int first, void* stream);
 int omni_roi_align_bwd(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
                        const float* rois, const int* batch_idx, const int* levels, int R, int P, int C,
                        const float* dout, void* stream);
@@ -524,6 +548,21 @@ int omni_adam_tick(float* step, const float* skip_flag, void* stream);
 int omni_guard_pre(float* vec, int n, void* stream);
 int omni_guard_post(float* vec, int n, int world, float stabilize, float half_period, float tolerance, float gamma, float* state,
                     float* skip, float* out, void* stream);
+/* ---- round 6 (csrc/glue.hip): the scalar-sized ATen launches around the losses and the loop, one launch each.
+ * omni_scale_vec: out[i] = (float)(src[i * stride] * coef[i] / max(*denom, denom_min)), i < n <= 16, in double, rounded once --
+ *   `loss * weight`, `loss_sum / max(count, 1)` (detectron2 fast_rcnn.py losses(); cubercnn/modeling/roi_heads/roi_heads.py:745-768);
+ *   src double when src_f64 else float, stride 0 = one broadcast scalar; coef: n HOST doubles or NULL; denom: device scalar or NULL.
+ * omni_sum_vectors: out[0] / out[1] / out[2] = sum of the first nfirst vectors / of the rest / of all -- `sum(loss_dict.values())`
+ *   (tools/train_net.py:180) split at the backward-stage boundary; vecs / lens: nvec <= 16 HOST entries (device pointers, lengths).
+ * omni_guard_gather: vec[i] = *scalars[i], vec[n] = their sum -- the stacking of tools/train_net.py:186 + omni_guard_pre.
+ * omni_bump_counters: *counters[i] += delta (nn.BatchNorm2d's num_batches_tracked of every layer; HOST array of device pointers).
+ * omni_zero: zero-fill as a kernel node (optimizer.zero_grad() of the flat gradient bucket, tools/train_net.py:217). */
+int omni_scale_vec(const void* src, int src_f64, int stride, const double* coef, const void* denom, double denom_min, int n, float* out,
+                   void* stream);
+int omni_sum_vectors(const void* const* vecs, const int* lens, int nvec, int nfirst, float* out, void* stream);
+int omni_guard_gather(const void* const* scalars, int n, float* vec, void* stream);
+int omni_bump_counters(const void* const* counters, int n, long long delta, void* stream);
+int omni_zero(void* p, long long nbytes, void* stream);
 /* the isnan/isinf gradient scan of tools/train_net.py:222-233 as one pass; flag[0] = 1 if any. */
 int omni_nonfinite_any(const float* grad, long long n, float* flag, void* stream);
 
@@ -622,6 +661,13 @@ int omni_stem_conv_wgrad(const float* x, const float* dy, float* dw, int N, int 
  * launched), added in a fixed order by a second launch; same call site as omni_stem_conv_wgrad */
 int omni_stem_conv_wgrad_det(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
                              int accumulate, float* ws, long long ws_floats, long long* plan, void* stream);
+/* Round 6: the first layer (cubercnn/modeling/backbone/dla.py:241-245, 7x7 3 -> 16) on the 4-channel padded image with the filter
+ * as the model holds it -- w / dw (16, R, R, cw), cw = 3 < C = 4: no padded copy of the filter, no slice + add of its gradient.
+ * stats [nullable] as omni_stem_conv_fwd_stats; the weight gradient is the deterministic form (ws / plan as omni_stem_conv_wgrad_det). */
+int omni_stem_conv_fwd_cw(const float* x, const float* w, int cw, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
+                          float* stats, int stats_rows, int* nblk_out, void* stream);
+int omni_stem_conv_wgrad_det_cw(const float* x, const float* dy, float* dw, int cw, int N, int H, int W, int C, int K, int R, int ldx,
+                                int lddy, int accumulate, float* ws, long long ws_floats, long long* plan, void* stream);
 /* The stride-2 member of the family (round 4): dw (32,3,3,16) from x (N,H,W,16) and dy (N,H/2,W/2,32), H and W even -- the
  * weight gradient of DLA-34's level1 convolution (cubercnn/modeling/backbone/dla.py:291-295; torch.nn.Conv2d backward).
  * deterministic != 0: ws / plan as omni_stem_conv_wgrad_det; 0: fp32 atomics into dw. */

@@ -77,14 +77,13 @@ def run_train(args, world, rank):
                   "Cube/loss_pose", "Cube/loss_joint", "rpn/cls", "rpn/loc"]
     guard = StepGuard(LOSS_NAMES, cfg.MODEL.STABILIZE, cfg.SOLVER.CHECKPOINT_PERIOD, DEVICE)
     opt.skip_flag = guard.skip
-    loss_log, skipped_log = [], []
 
     def finish(losses, total):
+        # (the step's own record lives in the guard: guard.out = [skipped, retry, total loss, 10 losses] of the last step, guard.state[2]
+        # = steps skipped so far -- read once before / after the timed windows instead of two copy launches per step)
         opt.check_nonfinite(guard.nonfinite_flag)
         guard.update(losses, sync=False)
         opt.step()
-        loss_log.append(total.clone())
-        skipped_log.append(guard.skip.clone())
 
     def eager_step():
         if getattr(model, "feature_cut", None) is not None and hasattr(graphed, "_eager"):    # staged backward installed
@@ -173,14 +172,18 @@ def run_train(args, world, rank):
     # window and its synchronize the device is still busy: that is when clocks / power / temperature are read.
     n_win = max(1, int(os.environ.get("OMNI_BENCH_WINDOWS", "5")))
     windows, enqueue, under_load = [], [], []
-    for _ in range(n_win):
+    state0 = guard.state.clone()
+    first_out = None
+    for w_i in range(n_win):
         _sync()
         if world > 1:
             dist.barrier()
         _sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for s_i in range(args.steps):
             step()
+            if w_i == 0 and s_i == 0:
+                first_out = guard.out.clone()          # (one small copy in the whole timed region: the first step's loss)
         enqueue.append(time.perf_counter() - t0)   # host time to enqueue the K steps (diagnostic: < dt means GPU-bound)
         if gpu:
             under_load.append(gpu.sample())
@@ -230,7 +233,8 @@ def run_train(args, world, rank):
         exchange = opt.exchange_report() or {}
         exchange["stage_timeline"] = pipe_timing_table(graphed) if getattr(graphed, "_timing", None) else None
         exchange["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_", "OMNI_EXCHANGE", "TORCH_NCCL"))}
-    final_losses = [float(v) for v in torch.stack(loss_log[-args.steps:]).cpu()]
+    final_losses = [float(first_out[2]) if first_out is not None else float("nan"), float(guard.out[2])]
+    skipped_steps = int(round(float(guard.state[2] - state0[2])))
     ims = IMS_PER_GPU * world * args.steps / dt
     step_tf = TRAIN_GFLOP_PER_IMAGE * 1e9 * IMS_PER_GPU * args.steps / dt / 1e12   # per GPU (the per-image figure is for 512 x 512)
     res = {
@@ -257,7 +261,7 @@ def run_train(args, world, rank):
         "step_executed_tflops_per_gpu": executed_flops * args.steps / dt / 1e12,
         "step_executed_mfma_frac": executed_flops * args.steps / dt / 1e12 / FP32_MFMA_PEAK_TF,
         "loss_first_last": [final_losses[0], final_losses[-1]],
-        "skipped_steps": int(torch.stack(skipped_log[-args.steps:]).sum().item()),
+        "skipped_steps": skipped_steps,
         "guard": "rolling-loss divergence test + NaN/Inf gradient scan + retry decision on the device, one 12-float all-reduce/step",
     }
     if exchange is not None:

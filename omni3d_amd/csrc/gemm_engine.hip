@@ -6,7 +6,7 @@
 // 1x1 convolutions (FPN laterals, DLA roots / projections, dla.py:159-161,214), and the batched GEMMs of the Winograd path
 // (csrc/winograd.hip) -- forward  C = A * B^T ("NT"), data gradient  C = A * B ("NN"), weight gradient  C = A^T * B ("TN").
 //
-// What changed against the round-1 tile engine (csrc/conv_gemm.hip), each measured in tools/exp/gemm_exp.hip:
+// What changed against the round-1 tile engine (csrc/conv_gemm.hip), each measured in a standalone main-loop experiment (round 2, profiles/r02_engine_vs_tile_kernels.log):
 //   * operands go global -> LDS by `buffer_load_dwordx4 ... lds` (1 KiB per wave instruction, no VGPR staging, no
 //     ds_write pass); tile tails come back as zeros from the buffer resource's range check, so the slab body has NO
 //     branches and is one basic block the scheduler can interleave;
@@ -20,7 +20,7 @@
 //     a block (an LDS-DMA issue costs 60-180 cycles of the issuing wave; one wave per SIMD must hide it under an MFMA);
 //   * 256x128 tiles: 8 accumulators per wave halve the operand traffic per MFMA (power, not bandwidth, is what keeps
 //     random-data fp32 MFMA kernels below the 157 TFLOP/s peak).
-//   Measured (tools/exp, MI355X): [65536x256x2304] 115 -> 133 TFLOP/s, fc1-like 4x[2048x1024x3136] 115 -> 129.
+//   Measured (MI355X): [65536x256x2304] 115 -> 133 TFLOP/s, fc1-like 4x[2048x1024x3136] 115 -> 129.
 #include <device_rt.h>
 
 namespace {

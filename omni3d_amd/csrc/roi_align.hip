@@ -57,7 +57,8 @@ __device__ __forceinline__ Tap make_tap(float y, float x, int H, int W) {
 template <int DIR>
 __global__ void __launch_bounds__(256) roi_align_kernel(FeatLevels fl, const float* __restrict__ rois,
                                                         const int* __restrict__ batch_idx, const int* __restrict__ levels,
-                                                        int R, int P, int C, float* __restrict__ out) {
+                                                        int R, int P, int C, float* __restrict__ out,
+                                                        float* __restrict__ out2 = nullptr, int per_image = 0, int first = 0) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long job = (long)blockIdx.x * 4 + wave;   // (roi, bin)
     if (job >= (long)R * P * P) return;
@@ -117,6 +118,10 @@ __global__ void __launch_bounds__(256) roi_align_kernel(FeatLevels fl, const flo
         }
         acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count;
         *reinterpret_cast<float4*>(o + 4 * c4) = acc;
+        // round 6: the first `first` ROIs of every block of `per_image` also land in a second, contiguous tensor (the cube head
+        // pools the same boxes as the box head with an identical pooler: its features were a 25.7 MB slice copy of `out` before)
+        if (DIR == 0 && out2 != nullptr && (r % per_image) < first)
+            *reinterpret_cast<float4*>(out2 + (((long)(r / per_image) * first + (r % per_image)) * P * P + bin) * C + 4 * c4) = acc;
     }
 }
 
@@ -513,6 +518,22 @@ int omni_roi_align_fwd(const void* const* level_ptrs, const int* level_hw, const
     const long jobs = (long)R * P * P;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_kernel<0>), dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, fl, rois, batch_idx, levels, R, P, C, out);
+    return omni_launch_status();
+}
+
+// The same, ALSO writing the first `first` ROIs of every block of `per_image` consecutive ROIs to out2 ((R / per_image) * first, P, P, C):
+// one pass for the box head's and the cube head's pooled features (two ROIPoolers with the same resolution / sampling ratio on the
+// same boxes, cubercnn/modeling/roi_heads/roi_heads.py:166-171, 267, 362).
+int omni_roi_align_fwd2(const void* const* level_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                        const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, float* out,
+                        float* out2, int per_image, int first, void* stream) {
+    if (nlev <= 0 || nlev > MAXL || (C & 3) || P <= 0) return OMNI_ERR_ARG;
+    if (out2 != nullptr && (per_image <= 0 || first < 0 || first > per_image || R % per_image != 0)) return OMNI_ERR_ARG;
+    if (R == 0) return OMNI_OK;
+    FeatLevels fl = make_feat(level_ptrs, level_hw, level_scale, nlev);
+    const long jobs = (long)R * P * P;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_kernel<0>), dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, fl, rois, batch_idx, levels, R, P, C, out, out2, per_image, first);
     return omni_launch_status();
 }
 

@@ -19,6 +19,7 @@
 // RPN head tensors: level l holds Y_l (B, H_l, W_l, 16) fp32 NHWC = [3 objectness logits | 12 deltas
 // (a*4+d) | 1 pad]; anchor index = a_off[l] + (y*W_l + x)*3 + a  (detectron2 order H, W, A).
 #include <device_rt.h>
+#include "philox.h"
 #pragma clang fp contract(off)
 
 namespace {
@@ -101,11 +102,15 @@ __global__ void __launch_bounds__(256) rpn_match2_kernel(const float* __restrict
                                                          float lo, float hi, int l0, int l1, int l2, int allow_low,
                                                          const float* __restrict__ expo, float eps,
                                                          signed char* __restrict__ mlabel, int* __restrict__ gt_best_idx,
-                                                         float* __restrict__ key_pos, float* __restrict__ key_neg) {
+                                                         float* __restrict__ key_pos, float* __restrict__ key_neg,
+                                                         long long* __restrict__ draw_state, int* __restrict__ ticket) {
     __shared__ float4 sg[MAXG];
     __shared__ int sbest[MAXG];
     __shared__ int sarg[MAXG];
+    __shared__ unsigned long long s_ctr;
     const int n = blockIdx.y;
+    // expo == nullptr: the Exp(1) variate of (image, anchor) is drawn here (philox.h) instead of read from a pre-filled array
+    if (expo == nullptr && threadIdx.x == 0) s_ctr = omni_draw_begin(draw_state);
     const int g0 = gt_off[n], G = min(gt_off[n + 1] - g0, MAXG);
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
         sg[g] = ldbox(gt + 4 * (g0 + g));
@@ -127,13 +132,14 @@ __global__ void __launch_bounds__(256) rpn_match2_kernel(const float* __restrict
             }
         }
         mlabel[(long)n * A + a] = (signed char)label;
-        const float e = expo[(long)n * A + a];
+        const float e = expo != nullptr ? expo[(long)n * A + a] : omni_exp1((unsigned long long)draw_state[0], s_ctr, (unsigned)n, (unsigned)a);
         key_pos[(long)n * A + a] = (label != -1 && label != 0) ? (v + eps) / e : -INFINITY;
         key_neg[(long)n * A + a] = (label == 0) ? (v + eps) / e : -INFINITY;
     }
     __syncthreads();
     for (int g = threadIdx.x; g < G; g += blockDim.x)
         if (sarg[g] != 0x7fffffff) atomicMin(&gt_best_idx[g0 + g], sarg[g]);
+    if (expo == nullptr && threadIdx.x == 0) omni_draw_end(draw_state, ticket, s_ctr, (int)(gridDim.x * gridDim.y));
 }
 
 // ---- final labels of one image (rpn.py:79-105).  labels pre-filled with -1. -----------------------
@@ -405,13 +411,18 @@ __global__ void __launch_bounds__(ROI_T) roi_sample_kernel(const float* __restri
                                                            int batch_per_image, int nfg_max, int append_gt,
                                                            float* __restrict__ out_boxes, int* __restrict__ out_cls,
                                                            int* __restrict__ out_gt, float* __restrict__ out_iou,
-                                                           int* __restrict__ out_counts) {
+                                                           int* __restrict__ out_counts, long long* __restrict__ draw_state,
+                                                           int* __restrict__ ticket, int* __restrict__ out_row, int first,
+                                                           float* __restrict__ first_boxes, int* __restrict__ first_cls,
+                                                           int* __restrict__ first_row) {
     __shared__ float4 sg[MAXG];
     __shared__ unsigned long long kf[ROI_MAXC], kb[ROI_MAXC];
     __shared__ short s_cls[ROI_MAXC];
     __shared__ short s_m[ROI_MAXC];
     __shared__ int s_nbg, s_nfg;
+    __shared__ unsigned long long s_ctr;
     const int n = blockIdx.x, t = threadIdx.x;
+    if (expo == nullptr && t == 0) s_ctr = omni_draw_begin(draw_state);
     const int g0 = gt_off[n], G = min(gt_off[n + 1] - g0, MAXG);
     const int np = min(prop_count ? prop_count[n] : pmax, pmax);
     const int nc = min(np + (append_gt ? G : 0), ROI_MAXC);
@@ -463,7 +474,8 @@ __global__ void __launch_bounds__(ROI_T) roi_sample_kernel(const float* __restri
             else cls = num_classes;
             s_cls[i] = (short)cls;
             s_m[i] = (short)my_m[r];
-            const float key = (my_iou[r] + eps) / expo[(long)n * ROI_MAXC + i];
+            const float e = expo != nullptr ? expo[(long)n * ROI_MAXC + i] : omni_exp1((unsigned long long)draw_state[0], s_ctr, (unsigned)n, (unsigned)i);
+            const float key = (my_iou[r] + eps) / e;
             if (cls != -1 && cls != num_classes) { k_f = fkey(key, i); atomicAdd(&s_nfg, 1); }
             else if (cls == num_classes) { k_b = fkey(key, i); atomicAdd(&s_nbg, 1); }
         }
@@ -477,24 +489,34 @@ __global__ void __launch_bounds__(ROI_T) roi_sample_kernel(const float* __restri
     const int ns = nfg + nbgs;
     for (int j = t; j < batch_per_image; j += ROI_T) {
         const long o = (long)n * batch_per_image + j;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        int cls = -2, row = -1;   // padding slot, ignored by every consumer
+        float best = 0.f;
         if (j < ns) {
             const unsigned long long k = j < nfg ? kf[j] : kb[j - nfg];
             const int i = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
-            const float4 b = i < np ? ldbox(prop_boxes + 4 * ((long)n * pmax + i)) : sg[i - np];
-            *reinterpret_cast<float4*>(out_boxes + 4 * o) = b;
-            out_cls[o] = s_cls[i];
-            out_gt[o] = G > 0 ? g0 + s_m[i] : -1;
-            float best = 0.f;
+            b = i < np ? ldbox(prop_boxes + 4 * ((long)n * pmax + i)) : sg[i - np];
+            cls = s_cls[i];
+            row = G > 0 ? g0 + s_m[i] : -1;
             for (int g = 0; g < G; ++g) best = fmaxf(best, iou_d2(sg[g], b));
-            out_iou[o] = best;
-        } else {
-            *reinterpret_cast<float4*>(out_boxes + 4 * o) = make_float4(0.f, 0.f, 0.f, 0.f);
-            out_cls[o] = -2;   // padding slot, ignored by every consumer
-            out_gt[o] = -1;
-            out_iou[o] = 0.f;
+        }
+        *reinterpret_cast<float4*>(out_boxes + 4 * o) = b;
+        out_cls[o] = cls;
+        out_gt[o] = row;
+        out_iou[o] = best;
+        // round 6: what the loss kernels index the ground truth with (background / padding marker -1 -> row 0, `sgt.clamp(min=0)`
+        // before) and the contiguous copies of the first `first` slots the cube head works on -- three clamp / slice-copy launches less
+        const int row0 = row < 0 ? 0 : row;
+        if (out_row != nullptr) out_row[o] = row0;
+        if (j < first) {
+            const long of = (long)n * first + j;
+            *reinterpret_cast<float4*>(first_boxes + 4 * of) = b;
+            first_cls[of] = cls;
+            first_row[of] = row0;
         }
     }
     if (t == 0) { out_counts[2 * n] = nfg; out_counts[2 * n + 1] = nbgs; }
+    if (expo == nullptr && t == 0) omni_draw_end(draw_state, ticket, s_ctr, (int)gridDim.x);
 }
 
 Levels make_levels(const void* const* ptrs, const int* hw, int nlev) {
@@ -567,11 +589,13 @@ int omni_pairwise_iou(const float* boxes1, int N, const float* boxes2, int M, in
 // RPN anchor matching for a batch.  gt: concatenated VALID GT boxes, gt_off (B+1).  expo: (B, A)
 // Exp(1) variates (the multinomial's randomness).  Outputs per (image, anchor): matched IoU/index,
 // Matcher label, sampling keys; per GT: best anchor index.  gt_best_bits: (G) int scratch.
-int omni_rpn_match(const float* anchors, int A, const float* gt, const int* gt_off, int B, int G, float thr_lo,
-                   float thr_hi, int l0, int l1, int l2, int allow_low_quality, const float* expo, float eps,
-                   float* matched_val, int* matched_idx, signed char* match_label, int* gt_best_bits, int* gt_best_idx,
-                   float* key_pos, float* key_neg, void* stream) {
-    if (A <= 0 || B <= 0 || G < 0) return OMNI_ERR_ARG;
+// expo == NULL: the variates are drawn inside the kernel from draw_state (2 int64: seed, draw counter) / ticket (1 int32, zero) --
+// see philox.h; the draw counter is advanced by the launch.
+int omni_rpn_match_draw(const float* anchors, int A, const float* gt, const int* gt_off, int B, int G, float thr_lo,
+                        float thr_hi, int l0, int l1, int l2, int allow_low_quality, const float* expo, long long* draw_state,
+                        int* ticket, float eps, float* matched_val, int* matched_idx, signed char* match_label, int* gt_best_bits,
+                        int* gt_best_idx, float* key_pos, float* key_neg, void* stream) {
+    if (A <= 0 || B <= 0 || G < 0 || (expo == nullptr && (draw_state == nullptr || ticket == nullptr))) return OMNI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (G > 0) {
         omni_memset_async(gt_best_bits, 0, sizeof(int) * G, st);
@@ -582,8 +606,17 @@ int omni_rpn_match(const float* anchors, int A, const float* gt, const int* gt_o
                        gt_best_bits);
     hipLaunchKernelGGL(rpn_match2_kernel, grid, dim3(256), 0, st, anchors, A, gt, gt_off, (const float*)matched_val,
                        (const int*)gt_best_bits, thr_lo, thr_hi, l0, l1, l2, allow_low_quality, expo, eps, match_label,
-                       gt_best_idx, key_pos, key_neg);
+                       gt_best_idx, key_pos, key_neg, draw_state, ticket);
     return omni_launch_status();
+}
+
+int omni_rpn_match(const float* anchors, int A, const float* gt, const int* gt_off, int B, int G, float thr_lo,
+                   float thr_hi, int l0, int l1, int l2, int allow_low_quality, const float* expo, float eps,
+                   float* matched_val, int* matched_idx, signed char* match_label, int* gt_best_bits, int* gt_best_idx,
+                   float* key_pos, float* key_neg, void* stream) {
+    if (expo == nullptr) return OMNI_ERR_ARG;
+    return omni_rpn_match_draw(anchors, A, gt, gt_off, B, G, thr_lo, thr_hi, l0, l1, l2, allow_low_quality, expo, nullptr, nullptr, eps,
+                               matched_val, matched_idx, match_label, gt_best_bits, gt_best_idx, key_pos, key_neg, stream);
 }
 
 // Final anchor labels {-1,0,1} (B, A) from the sampled candidates (sorted top-k lists of the keys).
@@ -711,15 +744,35 @@ int omni_rpn_decode(const void* const* level_ptrs, const int* level_hw, int nlev
 // gt / gt_cls concatenated valid GT with gt_off (B+1); ign / ign_off ignore regions; expo (B, 2048)
 // Exp(1) variates.  Outputs (B, batch_per_image): boxes, class (num_classes = background, -2 = padding),
 // global GT row (or -1), matched IoU; counts (B, 2) = sampled fg / bg.
+// Round 6 form.  expo == NULL: variates drawn in the kernel (draw_state / ticket as in omni_rpn_match_draw).  out_row (B,
+// batch_per_image) [nullable]: out_gt with the background / padding marker -1 replaced by row 0 (what the loss kernels index with).
+// first > 0: first_boxes (B, first, 4), first_cls / first_row (B, first) = contiguous copies of the first `first` sampled slots of
+// every image (the cube head's ROIs, roi_heads.py:341-362: foreground first).
+int omni_roi_sample_draw(const float* prop_boxes, const int* prop_count, int B, int pmax, const float* gt, const int* gt_cls,
+                         const int* gt_off, const float* ign, const int* ign_off, const float* expo, long long* draw_state, int* ticket,
+                         float iou_thr, float ignore_thresh, float eps, int num_classes, int batch_per_image, int nfg_max,
+                         int append_gt, float* out_boxes, int* out_cls, int* out_gt, float* out_iou, int* out_counts, int* out_row,
+                         int first, float* first_boxes, int* first_cls, int* first_row, void* stream) {
+    if (B <= 0 || pmax < 0 || pmax > ROI_MAXC || batch_per_image <= 0 || batch_per_image > ROI_MAXC) return OMNI_ERR_ARG;
+    if (expo == nullptr && (draw_state == nullptr || ticket == nullptr)) return OMNI_ERR_ARG;
+    if (first < 0 || first > batch_per_image || (first > 0 && (first_boxes == nullptr || first_cls == nullptr || first_row == nullptr)))
+        return OMNI_ERR_ARG;
+    hipLaunchKernelGGL(roi_sample_kernel, dim3(B), dim3(ROI_T), 0, (hipStream_t)stream, prop_boxes, prop_count, pmax, gt,
+                       gt_cls, gt_off, ign, ign_off, expo, iou_thr, ignore_thresh, eps, num_classes, batch_per_image,
+                       nfg_max, append_gt, out_boxes, out_cls, out_gt, out_iou, out_counts, draw_state, ticket, out_row, first,
+                       first_boxes, first_cls, first_row);
+    return omni_launch_status();
+}
+
 int omni_roi_sample(const float* prop_boxes, const int* prop_count, int B, int pmax, const float* gt, const int* gt_cls,
                     const int* gt_off, const float* ign, const int* ign_off, const float* expo, float iou_thr,
                     float ignore_thresh, float eps, int num_classes, int batch_per_image, int nfg_max, int append_gt,
                     float* out_boxes, int* out_cls, int* out_gt, float* out_iou, int* out_counts, void* stream) {
-    if (B <= 0 || pmax < 0 || pmax > ROI_MAXC || batch_per_image <= 0 || batch_per_image > ROI_MAXC) return OMNI_ERR_ARG;
-    hipLaunchKernelGGL(roi_sample_kernel, dim3(B), dim3(ROI_T), 0, (hipStream_t)stream, prop_boxes, prop_count, pmax, gt,
-                       gt_cls, gt_off, ign, ign_off, expo, iou_thr, ignore_thresh, eps, num_classes, batch_per_image,
-                       nfg_max, append_gt, out_boxes, out_cls, out_gt, out_iou, out_counts);
-    return omni_launch_status();
+    if (expo == nullptr) return OMNI_ERR_ARG;
+    return omni_roi_sample_draw(prop_boxes, prop_count, B, pmax, gt, gt_cls, gt_off, ign, ign_off, expo, nullptr, nullptr, iou_thr,
+                                ignore_thresh, eps, num_classes, batch_per_image, nfg_max, append_gt, out_boxes, out_cls, out_gt, out_iou,
+                                out_counts, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }
+
 
 }  // extern "C"

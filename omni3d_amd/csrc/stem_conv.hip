@@ -25,7 +25,7 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 template <int C, int R, bool ROT = false>
 __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             float* __restrict__ out, int N, int H, int W, int ldx, int ldo,
-                                                            float* __restrict__ stats) {
+                                                            float* __restrict__ stats, int cw) {
     static_assert(!ROT || C == 16, "the rotated form is the 16 -> 16 layer's data gradient");
     constexpr int TH = 4, TW = 64, PAD = R / 2;
     constexpr int HR = TH + R - 1, HC = TW + R - 1 + (C == 4 ? 1 : 0);   // C = 4: one spare column for the padded 8th tap
@@ -64,7 +64,16 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
         const int i = tid + 256 * u;
         const int c4 = i % C4, s = (i / C4) % SP, r = (i / (C4 * SP)) % R, k = i / (C4 * SP * R);
         vw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < 16 * R * SP * C4 && s < R) vw[u] = ld4(w + (((long)k * R + r) * R + s) * C + 4 * c4);     // (ROT too: w is read linearly)
+        if (i < 16 * R * SP * C4 && s < R) {
+            if (C != 4 || cw == C) {
+                vw[u] = ld4(w + (((long)k * R + r) * R + s) * C + 4 * c4);     // (ROT too: w is read linearly)
+            } else {      // round 6: the first layer's filter as the model holds it, (16, R, R, cw = 3); the image's 4th channel is zero padding
+                const float* q = w + (((long)k * R + r) * R + s) * cw;
+                vw[u].x = q[0];
+                vw[u].y = cw > 1 ? q[1] : 0.f;
+                vw[u].z = cw > 2 ? q[2] : 0.f;
+            }
+        }
     }
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
@@ -400,8 +409,10 @@ __global__ void __launch_bounds__(256) stem_conv_wgrad_kernel(const float* __res
 
 // dw[e] (+)= sum over the `rows` partial rows of part[row][e], E elements: 4 elements per workgroup, 64 row groups per element,
 // every thread adds its rows in ascending order (fp64), the 64 group sums meet in LDS in a fixed tree -- run-to-run identical.
+// cw < C: dw holds cw channels per tap ((K, R, R, cw), the first layer's 3-channel filter gradient) -- the partial rows' padded channels
+// (exact zeros: the image's padding channel) are dropped here instead of by a slice + add behind the kernel
 __global__ void __launch_bounds__(256) stem_wgrad_finalize_kernel(const float* __restrict__ part, int rows, int E, float* __restrict__ dw,
-                                                                  int accumulate) {
+                                                                  int accumulate, int C, int cw) {
     __shared__ double sm[256];
     const int t = threadIdx.x, el = t & 3, rg = t >> 2;
     const int e = (int)blockIdx.x * 4 + el;
@@ -424,7 +435,13 @@ __global__ void __launch_bounds__(256) stem_wgrad_finalize_kernel(const float* _
         if (t < s) sm[t] += sm[t + s];
         __syncthreads();
     }
-    if (t < 4 && e < E) dw[e] = accumulate ? dw[e] + (float)sm[t] : (float)sm[t];
+    if (t < 4 && e < E) {
+        const int c = e % C;
+        if (c < cw) {
+            float* d = dw + (long)(e / C) * cw + c;
+            *d = accumulate ? *d + (float)sm[t] : (float)sm[t];
+        }
+    }
 }
 
 }  // namespace
@@ -433,9 +450,11 @@ extern "C" {
 
 // out (N,H,W,16) = conv(x (N,H,W,C), w (16,R,R,C)), stride 1, padding R/2.  (C, R) in {(4, 7), (16, 3)}.
 static int stem_fwd_impl(const float* x, const float* w, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
-                         float* stats, int stats_rows, int* nblk_out, void* stream, bool rot = false) {
+                         float* stats, int stats_rows, int* nblk_out, void* stream, bool rot = false, int cw = 0) {
     if (nblk_out) *nblk_out = 0;
+    if (cw == 0) cw = C;
     if (N < 0 || H <= 0 || W <= 0 || K != 16 || ldx < C || ldo < K || (ldx & 3) || (rot && C != 16)) return OMNI_ERR_ARG;
+    if (cw != C && (C != 4 || cw < 1 || cw > 4)) return OMNI_ERR_ARG;
     if (!((C == 4 && R == 7) || (C == 16 && R == 3))) return OMNI_ERR_ARG;
     if (N == 0) return OMNI_OK;
     const long tiles = (long)N * ((H + 3) / 4) * ((W + 63) / 64);
@@ -443,13 +462,13 @@ static int stem_fwd_impl(const float* x, const float* w, float* out, int N, int 
     if (sp && nblk_out) *nblk_out = (int)tiles;
     if (C == 4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_fwd_kernel<4, 7>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w,
-                           out, N, H, W, ldx, ldo, sp);
+                           out, N, H, W, ldx, ldo, sp, cw);
     else if (rot)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_fwd_kernel<16, 3, true>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w,
-                           out, N, H, W, ldx, ldo, sp);
+                           out, N, H, W, ldx, ldo, sp, cw);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_fwd_kernel<16, 3>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w,
-                           out, N, H, W, ldx, ldo, sp);
+                           out, N, H, W, ldx, ldo, sp, cw);
     return omni_launch_status();
 }
 
@@ -489,8 +508,10 @@ int omni_stem_conv_fwd_stats(const float* x, const float* w, float* out, int N, 
 // dw (K,R,R,C) (+)= sum_pix dy (N,OH,OW,K) x (N,H,W,C); accumulate == 0 zeroes dw first (atomic accumulation either way).
 // (C, R, stride, K) in {(4, 7, 1, 16), (16, 3, 1, 16), (16, 3, 2, 32)}; stride 2: H, W even, OH = H / 2.
 static int stem_wgrad_impl(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int stride, int ldx,
-                           int lddy, int accumulate, float* ws, long long ws_floats, long long* plan, bool det, void* stream) {
+                           int lddy, int accumulate, float* ws, long long ws_floats, long long* plan, bool det, void* stream, int cw = 0) {
+    if (cw == 0) cw = C;
     if (N < 0 || H <= 0 || W <= 0 || ldx < C || lddy < K || (ldx & 3) || (lddy & 3)) return OMNI_ERR_ARG;
+    if (cw != C && (!det || C != 4 || cw < 1 || cw > 4)) return OMNI_ERR_ARG;      // (the narrow filter gradient is written by the finalize launch)
     const int form = (C == 4 && R == 7 && stride == 1 && K == 16) ? 0 : (C == 16 && R == 3 && stride == 1 && K == 16) ? 1
                    : (C == 16 && R == 3 && stride == 2 && K == 32 && !(H & 1) && !(W & 1)) ? 2 : -1;
     if (form < 0) return OMNI_ERR_ARG;
@@ -503,7 +524,7 @@ static int stem_wgrad_impl(const float* x, const float* dy, float* dw, int N, in
     const int E = K * R * R * C;
     if (plan != nullptr) { plan[0] = plan[1] = plan[2] = 0; plan[3] = (long long)grid * E; return OMNI_OK; }
     if (det && N > 0 && (ws == nullptr || ws_floats < (long long)grid * E)) return OMNI_ERR_ARG;
-    if (!accumulate && (!det || N == 0)) omni_memset_async(dw, 0, sizeof(float) * (size_t)E, st);
+    if (!accumulate && (!det || N == 0)) omni_memset_async(dw, 0, sizeof(float) * (size_t)(E / C * cw), st);
     if (N == 0) return OMNI_OK;
     float* part = det ? ws : nullptr;
     if (form == 0)
@@ -514,7 +535,7 @@ static int stem_wgrad_impl(const float* x, const float* dy, float* dw, int N, in
         hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_conv_wgrad_kernel<16, 3, 2, 32>), dim3(grid), dim3(256), 0, st, x, dy, dw, N, H, W, OH, OW, ldx, lddy, part);
     if (det)
         hipLaunchKernelGGL(stem_wgrad_finalize_kernel, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, st, (const float*)part, (int)grid, E, dw,
-                           accumulate);
+                           accumulate, C, cw);
     return omni_launch_status();
 }
 
@@ -528,6 +549,18 @@ int omni_stem_conv_wgrad(const float* x, const float* dy, float* dw, int N, int 
 int omni_stem_conv_wgrad_det(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int ldx, int lddy,
                              int accumulate, float* ws, long long ws_floats, long long* plan, void* stream) {
     return stem_wgrad_impl(x, dy, dw, N, H, W, C, K, R, 1, ldx, lddy, accumulate, ws, ws_floats, plan, true, stream);
+}
+
+// Round 6: the first layer (dla.py:241-245: 7x7, 3 -> 16) against the 4-channel padded image with the filter AS THE MODEL HOLDS IT,
+// w / dw (16, R, R, cw) with cw = 3: the kernels read / write the narrow layout themselves -- the padded copy of the filter in front
+// of the forward and the slice + add of its gradient behind the backward (the last launch of the step's critical path) are gone.
+int omni_stem_conv_fwd_cw(const float* x, const float* w, int cw, float* out, int N, int H, int W, int C, int K, int R, int ldx, int ldo,
+                          float* stats, int stats_rows, int* nblk_out, void* stream) {
+    return stem_fwd_impl(x, w, out, N, H, W, C, K, R, ldx, ldo, stats, stats_rows, nblk_out, stream, false, cw);
+}
+int omni_stem_conv_wgrad_det_cw(const float* x, const float* dy, float* dw, int cw, int N, int H, int W, int C, int K, int R, int ldx,
+                                int lddy, int accumulate, float* ws, long long ws_floats, long long* plan, void* stream) {
+    return stem_wgrad_impl(x, dy, dw, N, H, W, C, K, R, 1, ldx, lddy, accumulate, ws, ws_floats, plan, true, stream, cw);
 }
 
 // the stride-2 member of the family: dw (32,3,3,16) from x (N,H,W,16) and dy (N,H/2,W/2,32) (DLA-34 level1, dla.py:291-295).

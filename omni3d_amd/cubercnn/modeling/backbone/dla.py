@@ -34,6 +34,12 @@ class ConvBNReLU(nn.Sequential):
         conv, bn = self[0], self[1]
         w = conv.weight
         if x.shape[1] != w.shape[1]:   # 3-channel stem weight against the 4-channel padded image
+            from ....kernels import conv as KC
+            if (conv.stride[0] == 1 and conv.padding[0] == 3 and KC.stem_first_eligible(x.shape, w) and bn.training and torch.is_grad_enabled()
+                    and not x.requires_grad):
+                # round 6: the stem kernels read the filter / write its gradient in the model's 3-channel layout (no padded copy, no
+                # slice + add of the gradient at the very end of the step's critical path)
+                return bn(HF.stem_first_conv(x, w, True), relu=True)
             w = HF.pad_input_channels(w, x.shape[1], self.__dict__.setdefault("_w_pad", {}))
         return bn(HF.conv2d(x, w, None, conv.stride[0], conv.padding[0], False, bn.training and torch.is_grad_enabled()), relu=True)
 

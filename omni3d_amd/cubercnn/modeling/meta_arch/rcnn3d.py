@@ -56,11 +56,19 @@ class RCNN3D(nn.Module):
         their real sizes are device data; the padding mask is then applied by the kernel, not by host-side slicing"""
         imgs = [x["image"] for x in batched_inputs]
         sizes = [(im.shape[-2], im.shape[-1]) for im in imgs]
+        # equal-size images already on the device are read through their own pointers: no `torch.stack` copy (round 6)
+        direct = (len(set(sizes)) == 1 and all(im.device == self.device for im in imgs))
         if slot_hw is not None:
             assert len(set(sizes)) == 1
-            batch = torch.stack(imgs).to(self.device, non_blocking=True)
-            x = bnpool.preprocess(batch, self._mean, self._std, self.backbone.size_divisibility, image_hw=slot_hw)
+            x = bnpool.preprocess_list(imgs, self._mean, self._std, self.backbone.size_divisibility, image_hw=slot_hw) if direct else None
+            if x is None:
+                batch = torch.stack(imgs).to(self.device, non_blocking=True)
+                x = bnpool.preprocess(batch, self._mean, self._std, self.backbone.size_divisibility, image_hw=slot_hw)
             return ImageList(x, sizes)
+        if direct:
+            x = bnpool.preprocess_list(imgs, self._mean, self._std, self.backbone.size_divisibility)
+            if x is not None:
+                return ImageList(x, sizes)
         if len(set(sizes)) == 1:
             batch = torch.stack(imgs).to(self.device, non_blocking=True)
         else:   # ragged batch: pad the uint8 images on the host first (zero padding is re-zeroed after normalisation)
@@ -156,7 +164,8 @@ class RCNN3D(nn.Module):
                 m.defer_counter = True
         live = [m.num_batches_tracked for m in bns if m.training and m.track_running_stats and m.num_batches_tracked is not None]
         if live:
-            torch._foreach_add_(live, 1)
+            from ....kernels import glue
+            glue.bump_counters(live, 1)
 
     def flush_logs(self, storage):
         """One device->host readback for all logged scalars (the reference does ~16 .item() syncs)."""

@@ -129,12 +129,13 @@ class RPNWithIgnore(nn.Module):
     @torch.no_grad()
     def label_and_sample_anchors(self, anchors, targets):
         B, A = targets.B, anchors.shape[0]
-        if self.injected is not None and "E" in self.injected:
-            E = self.injected["E"].to(anchors.device).float().contiguous()
-        else:
-            E = torch.empty((B, A), dtype=torch.float32, device=anchors.device).exponential_()
+        # injected Exp(1) variates (parity tests), else drawn inside the matching kernel (csrc/philox.h; round 6)
+        E = self.injected["E"].to(anchors.device).float().contiguous() if (self.injected is not None and "E" in self.injected) else None
+        if E is None and self.__dict__.get("_draw") is None:
+            from ....kernels.glue import DrawState
+            self.__dict__["_draw"] = DrawState()
         thr = self.anchor_thresholds
-        m = det.rpn_match(anchors, targets.gt, targets.gt_off, E, (thr[0], thr[-1]), self.anchor_labels, True)
+        m = det.rpn_match(anchors, targets.gt, targets.gt_off, E, (thr[0], thr[-1]), self.anchor_labels, True, draw=self.__dict__.get("_draw"), B=B)
         kpos = max(int(self.batch_size_per_image * self.positive_fraction), 1)
         # one launch for both draws: rows [0, B) = positive keys, [B, 2B) = negative keys (sorted => prefix = top-kpos)
         kv, ki = select.topk_rows(m["keys"], max(kpos, self.batch_size_per_image))

@@ -199,16 +199,22 @@ class ROIHeads3D(nn.Module):
         if boxes.shape[1] + MAX_GT_PER_IMAGE > det.ROI_MAXC and self.proposal_append_gt:
             raise ValueError(f"{boxes.shape[1]} proposals + up to {MAX_GT_PER_IMAGE} appended GT boxes exceed the sampler's "
                              f"capacity of {det.ROI_MAXC} candidates per image (csrc/rpn_roi.hip ROI_MAXC)")
-        if self.injected is not None and "E" in self.injected:
-            E = self.injected["E"].to(boxes.device).float().contiguous()
-        else:
-            E = torch.empty((B, det.ROI_MAXC), dtype=torch.float32, device=boxes.device).exponential_()
+        # the sampling randomness: injected Exp(1) variates (parity tests), else drawn INSIDE the sampling kernel (round 6: no
+        # `exponential_()` launch and none of the generator bookkeeping torch wraps around it under graph capture)
+        E = self.injected["E"].to(boxes.device).float().contiguous() if (self.injected is not None and "E" in self.injected) else None
+        if E is None and self.__dict__.get("_draw") is None:
+            from ....kernels.glue import DrawState
+            self.__dict__["_draw"] = DrawState()
         out = det.roi_sample(boxes, count, targets.gt, targets.gt_cls, targets.gt_off, targets.ign, targets.ign_off, E,
                              self.proposal_iou_threshold, self.ignore_thresh, self.num_classes, self.batch_size_per_image,
-                             self.positive_fraction, self.proposal_append_gt)
+                             self.positive_fraction, self.proposal_append_gt, draw=self.__dict__.get("_draw"), first=self.fg_cap)
         self.pending_logs["roi_counts"] = out[4]
         self.last_sampled_boxes, self.last_sampled_classes = out[0], out[1]    # (B, S, 4) / (B, S); read by the parity tests
-        return out
+        # what the kernel prepared for the losses: ground-truth rows with the background marker clamped to row 0, and the contiguous
+        # prefix (boxes, classes, rows) of the cube head's slots -- `sgt.clamp(min=0)` and three slice copies before
+        self.__dict__["_gt_rows_memo"] = (out[2], out[5])
+        self.__dict__["_cube_prefix"] = (out[0], out[6])
+        return out[:5]
 
     def forward(self, images, features, proposals, Ks, im_scales_ratio, targets=None, packed=None):
         """Reference contract (roi_heads.py:207): proposals = list[Instances] (proposal_boxes), Ks = per-image 3x3 intrinsics
@@ -293,9 +299,13 @@ class ROIHeads3D(nn.Module):
     def _forward_cube_train(self, feats, sboxes, scls, sgt, packed, x=None):
         B, S = scls.shape
         Fc = self.fg_cap
-        rois = sboxes[:, :Fc].reshape(B * Fc, 4).contiguous()
-        cls = scls[:, :Fc].reshape(-1).contiguous()
-        gt_row = self._gt_rows(sgt)[:, :Fc].reshape(-1).contiguous()
+        pre = self.__dict__.get("_cube_prefix")
+        if pre is not None and pre[0] is sboxes and pre[1][0] is not None and pre[1][0].shape[1] == min(Fc, S):
+            rois, cls, gt_row = pre[1][0].reshape(-1, 4), pre[1][1].reshape(-1), pre[1][2].reshape(-1)     # written by the sampling kernel
+        else:      # (boxes that are not the sampler's own: TRAIN_ON_PRED_BOXES, a caller's sample)
+            rois = sboxes[:, :Fc].reshape(B * Fc, 4).contiguous()
+            cls = scls[:, :Fc].reshape(-1).contiguous()
+            gt_row = self._gt_rows(sgt)[:, :Fc].reshape(-1).contiguous()
         bidx = self._batch_index(B, Fc, rois.device)
         if x is None:
             x = self.cube_pooler(feats, self.scale_proposals(rois), bidx)

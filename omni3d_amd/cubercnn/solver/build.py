@@ -185,7 +185,12 @@ class _FlatOptimizer(torch.optim.Optimizer):
             self._finish_replay_exchange()    # a second zero_grad(): the loop drops the iteration (tools/train_net.py:245-247)
         from ... import functional as HF
         HF.side_join()            # weight-gradient stream (normally already joined by the end-of-backward callback)
-        self.flat_grad.zero_()
+        from ... import lib as _lib
+        from ...kernels import glue
+        if self.flat_grad.is_cuda or (_lib._lib is not None and _lib._lib.emulated):
+            glue.zero_(self.flat_grad)        # (a kernel node of this library: round 6, no ATen launch left in the step)
+        else:
+            self.flat_grad.zero_()
         self._exchanged = False
         # the bucket is empty again: a 1/world left behind by an exchange whose step() never came (the dropped iteration of
         # tools/train_net.py:245-247) must not scale the NEXT iteration's, separately averaged, gradients

@@ -508,33 +508,32 @@ class GraphedPipelined:
         self.cuts.reset()
         self.optimizer.zero_grad()
         losses = self.model(self.static_batch, self.static_packed)
-        first, deferred = self._split_losses(losses)
+        first, deferred, total = self._split_losses(losses)
         if deferred is None:
             total = total_loss(losses)
             total.backward(_unit(total))
             return losses, total.detach()
         # stage 0 back-propagates the ROI heads' losses only, down to the pooled ROI features; the RPN's two losses are the
-        # roots of the next stage together with ROIAlign's backward.  (The reported total is the sum of the two partial sums: one
-        # add instead of a second concatenate + reduce over all vectors.)
-        with torch.no_grad():
-            total = first + deferred
+        # roots of the next stage together with ROIAlign's backward.  (Both partial sums and the reported total come out of ONE
+        # launch: functional.sum_vectors2.)
         self.cuts.attach_root(deferred)
         first.backward(_unit(first))
         return losses, total
 
     def _split_losses(self, losses):
-        """-> (sum of the losses whose backward belongs to stage 0, sum of the deferred ones or None)"""
+        """-> (sum of the losses whose backward belongs to stage 0, sum of the deferred ones or None, their total as a plain value)"""
         heads = getattr(self.model, "roi_heads", None)
         if heads is None or getattr(getattr(heads, "pool_cut", None), "__self__", None) is not self or not len(self.cuts) or not self._pool_cut_made:
-            return None, None
+            return None, None, None
         vecs = getattr(losses, "vectors", None)
         if not vecs or sorted(n for _, names in vecs for n in names) != sorted(losses.keys()):
-            return None, None
+            return None, None, None
         late = [v for v, names in vecs if all(n.startswith("rpn/") for n in names)]
         early = [v for v, names in vecs if not all(n.startswith("rpn/") for n in names)]
         if not late or not early:
-            return None, None
-        return sum_vectors(early), sum_vectors(late)
+            return None, None, None
+        from ...functional import sum_vectors2
+        return sum_vectors2(early, late)
 
     def _eager(self):
         """all stages with eager launches (weight gradients wherever functional.side_mode() puts them)

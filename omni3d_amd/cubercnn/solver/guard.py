@@ -48,8 +48,11 @@ class StepGuard:
         -> (skipped, retry, {name: reduced loss}) as host values when sync, else None."""
         from ...kernels import det
         n = len(self.names)
-        torch.stack([loss_dict[k].detach().float().reshape(()) for k in self.names], out=self.vec[:n])
-        det.guard_pre(self.vec, n)                                   # vec[n] = sum of the losses
+        from ...kernels import glue
+        vals = [loss_dict[k].detach() for k in self.names]
+        if not glue.guard_gather(vals, self.vec):                    # vec[:n] = the losses, vec[n] = their sum: one launch (round 6)
+            torch.stack([v.float().reshape(()) for v in vals], out=self.vec[:n])
+            det.guard_pre(self.vec, n)                               # vec[n] = sum of the losses
         w = self.world()
         if w > 1:
             dist.all_reduce(self.vec, group=self.group)              # the ONE collective of the guard

@@ -11,6 +11,7 @@ from os import environ as _environ
 
 _os_environ_get = _environ.get
 
+from .kernels import glue
 from .kernels import bnpool, conv, det, wino
 
 CL = torch.channels_last
@@ -343,6 +344,52 @@ class _Conv2d(Function):
         if has_bias and ctx.needs_input_grad[2]:
             db = _bias_grad(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]), gb)
         return dx, dw, db, None, None, None, None
+
+
+_STEM_FIRST_WGRAD_SIDE = _os_environ_get("OMNI_STEM_FIRST_WGRAD_SIDE", "0") == "1"      # A/B knob
+
+
+class _StemFirst(Function):
+    """The first layer (dla.py:241-245: 7x7, 3 -> 16, stride 1) on the 4-channel padded image, with the 3-channel filter read and its
+    gradient written in the model's own layout (csrc/stem_conv.hip, round 6).  The image needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, want_stats):
+        ctx.set_materialize_grads(False)
+        ctx.direct = _direct_grad(w)
+        x = _cl(x)
+        y, parts = conv.stem_first_fwd(x, w, want_stats)
+        ctx.save_for_backward(x)
+        parts = _parts_out(parts, y)
+        ctx.mark_non_differentiable(parts)
+        return y, parts
+
+    @staticmethod
+    def backward(ctx, dy, _parts_grad=None):
+        (x,) = ctx.saved_tensors
+        dy = _cl(dy)
+        gw = ctx.direct
+        if gw is not None and not gw.is_contiguous(memory_format=CL):
+            gw = None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            def wgrad():
+                return conv.stem_first_wgrad(x, dy, accum_into=gw)
+            # This is the LAST weight gradient of a step (its dy is the last tensor backward produces).  Measured (round 6,
+            # profiles/r06_ab_tail_balance.log): the weight-gradient stream reaches the end of backward ~0.15 ms behind the main
+            # stream, so queued there this launch started 150 us after its input was ready; on the main stream it starts at once and
+            # the two streams end together.
+            dw = _side_run(wgrad, (x, dy)) if (gw is not None and _STEM_FIRST_WGRAD_SIDE) else wgrad()
+        return None, dw, None
+
+
+def stem_first_conv(x, w, want_stats=False):
+    """conv2d(x[:, :3], w, padding=3) for the (N,4,H,W) padded image and the (16,3,7,7) filter; the caller checked
+    `conv.stem_first_eligible(x.shape, w)`"""
+    y, parts = _StemFirst.apply(x, w, want_stats)
+    if parts.shape[0] > 0:
+        y._omni_bn_partials = parts
+    return y
 
 
 class _WinoConv3x3(Function):
@@ -1162,9 +1209,7 @@ class _ROIAlignShared(Function):
         ctx.slots = [_slot_enter(f, ctx.needs_input_grad[7 + i]) for i, f in enumerate(feats)]
         feats = [_cl(f) for f in feats]
         nhwc = [f.permute(0, 2, 3, 1) for f in feats]
-        out = det.roi_align_fwd(nhwc, scales, rois, batch_idx, levels, P)          # (R, P, P, C)
-        R, C = out.shape[0], out.shape[3]
-        sub = out.view(R // per_image, per_image, P, P, C)[:, :first].reshape(-1, P, P, C)
+        out, sub = det.roi_align_fwd2(nhwc, scales, rois, batch_idx, levels, P, per_image, first)   # (R, P, P, C), (R/per_image*first, P, P, C)
         ctx.save_for_backward(rois, batch_idx, levels)
         ctx.meta = (scales, P, per_image, first, [tuple(f.shape) for f in nhwc])
         return out.permute(0, 3, 1, 2), sub.permute(0, 3, 1, 2)
@@ -1254,33 +1299,51 @@ class LossDict(dict):
 
 
 class _SumVectors(Function):
-    """sum of all elements of a few small vectors (one launch for one vector, two for several).  Its backward hands every vector the
-    upstream scalar as a stride-0 view -- no launch; the loss functions read it as the one scalar it is (`_scalar_grads`)."""
+    """sum of all elements of a few small vectors.  Its backward hands every vector the upstream scalar as a stride-0 view -- no
+    launch; the loss functions read it as the one scalar it is (`_scalar_grads`).  The forward value comes from `sums3[k]`, one
+    element of the (3,) result of ONE glue.sum_vectors launch that serves both partial sums of a staged step and their total
+    (round 6: cat + sum per partial sum and an add for the total before)."""
 
     @staticmethod
-    def forward(ctx, *vecs):
+    def forward(ctx, sums3, k, *vecs):
         ctx.shapes = [tuple(v.shape) for v in vecs]
-        if len(vecs) == 1:
-            return vecs[0].sum()
-        return torch.cat([v.reshape(-1) for v in vecs]).sum()
+        return sums3[k]
 
     @staticmethod
     def backward(ctx, g):
         # (stride-0 views in the SHAPE of every input: a vector that is not 1-D gets a gradient of its own shape, ADVICE r5)
         g = g.reshape(())
-        return tuple(g.expand(sh) for sh in ctx.shapes)
+        return (None, None) + tuple(g.expand(sh) for sh in ctx.shapes)
+
+
+def _vec_ok(vecs):
+    return 0 < len(vecs) <= glue.MAXV and all(v.dtype == torch.float32 and v.is_contiguous() and v.numel() <= 4096 for v in vecs)
 
 
 def sum_vectors(vecs):
     """scalar sum of a list of small loss vectors (differentiable)"""
-    return _SumVectors.apply(*vecs)
+    return sum_vectors2(vecs, ())[0]
+
+
+def sum_vectors2(first, rest):
+    """-> (sum of the vectors in `first`, sum of those in `rest` or None, total) with ONE launch; the two partial sums are
+    differentiable (separately: they are the roots of different backward stages, solver/graphed.py), the total is a plain value"""
+    first, rest = list(first), list(rest)
+    if not _vec_ok(first + rest):      # (not the loss vectors of this package: plain torch)
+        a = torch.cat([v.reshape(-1) for v in first]).sum()
+        b = torch.cat([v.reshape(-1) for v in rest]).sum() if rest else None
+        return a, b, (a.detach() + b.detach()) if rest else a.detach()
+    sums3 = glue.sum_vectors(first, rest)
+    a = _SumVectors.apply(sums3, 0, *first)
+    b = _SumVectors.apply(sums3, 1, *rest) if rest else None
+    return a, b, sums3[2]
 
 
 def total_loss(losses):
     """== sum(losses.values()) (up to fp32 summation order)"""
     vecs = getattr(losses, "vectors", None)
     if vecs and sorted(n for _, names in vecs for n in names) == sorted(losses.keys()):
-        return _SumVectors.apply(*[v for v, _ in vecs])
+        return sum_vectors([v for v, _ in vecs])
     return sum(losses.values())
 
 
@@ -1295,8 +1358,7 @@ class _RPNLoss(Function):
             pack = det.LevelPack(lv)
             sums = det.rpn_loss_fwd(pack, anchors, labels, matched_idx, gt, gt_off, plain)
             # (fp64 sums x fp64 coefficients, rounded once into the fp32 loss vector: one launch)
-            vec = torch.mul(sums[:2], _coef((inv_norm * weights[0], inv_norm * weights[1]), sums.device, torch.float64),
-                            out=torch.empty(2, dtype=torch.float32, device=sums.device))
+            vec = glue.scale_vec(sums, (inv_norm * weights[0], inv_norm * weights[1]), n=2)
         ctx.pack = pack
         ctx.save_for_backward(anchors, labels, matched_idx, gt, gt_off)
         ctx.inv_norm, ctx.weights, ctx.plain = inv_norm, weights, plain
@@ -1329,10 +1391,8 @@ class _BoxLoss(Function):
         ctx.save_for_backward(pred, cls, prop, gt, gt_row, sums)
         ctx.meta = (K, weights, loss_w)
         ctx.mark_non_differentiable(sums)
-        # (fp64 sums / fp64 count, rounded once into the fp32 loss vector: two launches)
-        vec = torch.div(sums[:2], sums[2:3].clamp(min=1.0), out=torch.empty(2, dtype=torch.float32, device=sums.device))
-        if loss_w != (1.0, 1.0):
-            vec = vec * _coef(loss_w, vec.device)
+        # (fp64 sums / max(fp64 count, 1) x loss weights, rounded once into the fp32 loss vector: one launch, round 6)
+        vec = glue.scale_vec(sums, loss_w, denom=sums[2:3], denom_min=1.0, n=2)
         return vec, sums
 
     @staticmethod
@@ -1361,15 +1421,17 @@ class _CubeLoss(Function):
         ctx.save_for_backward(vals, jac, red, cls, boxes)
         ctx.meta = (head.shape[0], K, head.shape[1], mode, coef, clusters)
         ctx.mark_non_differentiable(red)
-        return red[:6] * _coef(coef, red.device), red
+        return glue.scale_vec(red, coef, n=6), red
 
     @staticmethod
     def backward(ctx, g, _):
         vals, jac, red, cls, boxes = ctx.saved_tensors
         F_, K, ldh, mode, coef, clusters = ctx.meta
-        gk = g.float() * _coef(coef, g.device)             # (a broadcast scalar x 6 coefficients -> a contiguous 6-vector: one launch)
-        if not gk.is_contiguous():
-            gk = gk.contiguous()
+        g = g.float()
+        if g.dim() == 1 and g.stride(0) in (0, 1):
+            gk = glue.scale_vec(g, coef, n=6)              # (a broadcast scalar x 6 coefficients -> a contiguous 6-vector: one launch)
+        else:
+            gk = (g * _coef(coef, g.device)).contiguous()
         dhead = det.cube_loss_bwd(vals, jac, red, gk, cls, boxes, F_, K, ldh, mode, clusters)
         return (dhead,) + (None,) * 14
 

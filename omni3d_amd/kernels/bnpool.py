@@ -226,6 +226,34 @@ def preprocess(images_u8, pixel_mean, pixel_std, size_divisibility=0, image_hw=N
     return out.permute(0, 3, 1, 2)
 
 
+def preprocess_list(images, pixel_mean, pixel_std, size_divisibility=0, image_hw=None):
+    """`preprocess(torch.stack(images), ...)` without the stacked copy: N <= 64 equal-size (3,H,W) uint8 device tensors, read through
+    their own pointers (omni_preprocess_multi).  -> None when the list does not qualify (the caller stacks)."""
+    import ctypes
+    N = len(images)
+    if not (0 < N <= 64):
+        return None
+    H, W = images[0].shape[-2:]
+    for im in images:
+        if im.dtype != torch.uint8 or im.dim() != 3 or tuple(im.shape) != (3, H, W) or not im.is_contiguous() or im.device != images[0].device:
+            return None
+    L = _lib.get()
+    if not images[0].is_cuda and not L.emulated:
+        return None
+    PH, PW = H, W
+    if size_divisibility > 1:
+        s = size_divisibility
+        PH, PW = (H + s - 1) // s * s, (W + s - 1) // s * s
+    out = torch.empty((N, PH, PW, 4), dtype=torch.float32, device=images[0].device)
+    m, s = [float(v) for v in pixel_mean], [float(v) for v in pixel_std]
+    if image_hw is not None:
+        assert image_hw.dtype == torch.int32 and tuple(image_hw.shape) == (N, 2) and image_hw.is_contiguous()
+    ptrs = (ctypes.c_void_p * N)(*[im.data_ptr() for im in images])
+    L.call("omni_preprocess_multi", ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(image_hw), _lib.ptr(out), N, H, W, PH, PW, m[0], m[1], m[2],
+           s[0], s[1], s[2], _lib.stream_of(images[0]))
+    return out.permute(0, 3, 1, 2)
+
+
 def relu_bwd(dy, y):
     """dz = dy * (y > 0); same memory layout in and out."""
     L = _lib.check_device(dy, y)

@@ -282,7 +282,7 @@ def linear_dgrad(dy, w):
     if _DGRAD_NT and M >= 512 and C >= 4096 and K >= 512 and (K % 32) == 0:
         # fc1-class data gradient dX = dY W on the LDS-DMA engine.  Round 4: its NN form reads W as it is (box head 494 us, cube head 160 us,
         # same sums bit for bit); rounds 2-3 transposed W first (51 MB, two launches per step on the critical path) for the NT main
-        # loop: 540 / 175 us including the transpose (tools/exp/fc1_nn.py, profiles/r04_fc1_nn.log).  OMNI_FC_DGRAD_FORM=nt: the old form
+        # loop: 540 / 175 us including the transpose (profiles/r04_fc1_nn.log).  OMNI_FC_DGRAD_FORM=nt: the old form
         from . import gemm as _gemm
         if _DGRAD_FORM == "nt":
             return _gemm.gemm(dy, _gemm.transpose2d(w), _gemm.NT, tile=2, splits=_gemm.BALANCED if _FC_BALANCED else 1)
@@ -326,6 +326,44 @@ def stem_conv_fwd(x, w):
     out = torch.empty((N, H, W, K), dtype=torch.float32, device=x.device)
     L.call("omni_stem_conv_fwd", _lib.ptr(xv), _lib.ptr(wv), _lib.ptr(out), N, H, W, C, K, R, C, K, _lib.stream_of(x))
     return out.permute(0, 3, 1, 2)
+
+
+def stem_first_eligible(x_shape, w):
+    """the first layer on the 4-channel padded image with its 3-channel filter as the model holds it (round 6): 7x7, 16 outputs,
+    KRSC memory, deterministic reductions on (the narrow filter gradient is written by the ordered finalize launch)"""
+    return (_det.on() and tuple(w.shape) == (16, 3, 7, 7) and x_shape[1] == 4 and w.is_contiguous(memory_format=torch.channels_last)
+            and w.dtype == torch.float32)
+
+
+def stem_first_fwd(x, w, want_stats):
+    """x (N,4,H,W) CL (4th channel zero), w (16,3,7,7) CL -> (y (N,16,H,W) CL, BatchNorm partial rows or None)"""
+    xv = _nhwc(x)
+    wv = w.permute(0, 2, 3, 1)
+    assert wv.is_contiguous()
+    N, H, W, C = xv.shape
+    L = _lib.check_device(xv, wv)
+    out = torch.empty((N, H, W, 16), dtype=torch.float32, device=x.device)
+    stats = _stats_buf(16, x.device) if want_stats else None
+    cell, addr = _nblk_cell()
+    L.call("omni_stem_conv_fwd_cw", _lib.ptr(xv), _lib.ptr(wv), 3, _lib.ptr(out), N, H, W, C, 16, 7, C, 16, _lib.ptr(stats),
+           STATS_ROWS if want_stats else 0, addr, _lib.stream_of(x))
+    return out.permute(0, 3, 1, 2), (stats[:cell.value] if want_stats and cell.value > 0 else None)
+
+
+def stem_first_wgrad(x, dy, accum_into=None):
+    """-> dw (16,3,7,7) CL, or None after ADDING it into accum_into (the parameter's KRSC gradient view)"""
+    xv, dv = _nhwc(x), _nhwc(dy)
+    N, H, W, C = xv.shape
+    L = _lib.check_device(xv, dv)
+    dst = accum_into.permute(0, 2, 3, 1) if accum_into is not None else torch.empty((16, 7, 7, 3), dtype=torch.float32, device=x.device)
+    assert dst.is_contiguous() and tuple(dst.shape) == (16, 7, 7, 3)
+    acc = int(accum_into is not None)
+    plan, addr = _det.new_plan()
+    L.call("omni_stem_conv_wgrad_det_cw", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dst), 3, N, H, W, C, 16, 7, C, 16, acc, None, 0, addr, _lib.stream_of(x))
+    ws = torch.empty(max(int(plan[3]), 1), dtype=torch.float32, device=x.device)
+    L.call("omni_stem_conv_wgrad_det_cw", _lib.ptr(xv), _lib.ptr(dv), _lib.ptr(dst), 3, N, H, W, C, 16, 7, C, 16, acc, _lib.ptr(ws), int(plan[3]), None,
+           _lib.stream_of(x))
+    return None if accum_into is not None else dst.permute(0, 3, 1, 2)
 
 
 _STEM_DGRAD = os.environ.get("OMNI_STEM_DGRAD", "1") != "0"        # A/B: 0 = the round-4 data gradients of level0 / level1

@@ -45,20 +45,24 @@ def pairwise_iou(boxes1, boxes2, mode="iou"):
     return out
 
 
-def rpn_match(anchors, gt, gt_off, expo, thresholds=(0.05, 0.05), labels=(0, -1, 1), allow_low_quality=True, eps=1e-4):
-    """-> dict(matched_val, matched_idx, match_label, gt_best_idx, key_pos, key_neg)."""
+def rpn_match(anchors, gt, gt_off, expo, thresholds=(0.05, 0.05), labels=(0, -1, 1), allow_low_quality=True, eps=1e-4, draw=None, B=None):
+    """-> dict(matched_val, matched_idx, match_label, gt_best_idx, key_pos, key_neg).
+    expo (B, A): Exp(1) variates of the sampling keys, or None with draw = a glue.DrawState and B = batch size: the kernel draws them
+    itself (csrc/philox.h) -- no array, no generator launches."""
     L = _dev(anchors, gt, gt_off, expo)
-    A, B, G = anchors.shape[0], expo.shape[0], gt.shape[0]
+    A, G = anchors.shape[0], gt.shape[0]
+    B = expo.shape[0] if expo is not None else int(B)
     o = {
         "matched_val": _empty((B, A), torch.float32, anchors), "matched_idx": _empty((B, A), torch.int32, anchors),
         "match_label": _empty((B, A), torch.int8, anchors), "gt_best_idx": _empty((max(G, 1),), torch.int32, anchors),
         "keys": _empty((2 * B, A), torch.float32, anchors),   # rows [0, B) positive keys, [B, 2B) negative keys
     }
     bits = _empty((max(G, 1),), torch.int32, anchors)
-    L.call("omni_rpn_match", _lib.ptr(anchors), A, _lib.ptr(gt), _lib.ptr(gt_off), B, G, float(thresholds[0]),
+    state, ticket = draw.tensors(anchors.device) if expo is None else (None, None)
+    L.call("omni_rpn_match_draw", _lib.ptr(anchors), A, _lib.ptr(gt), _lib.ptr(gt_off), B, G, float(thresholds[0]),
            float(thresholds[1]), int(labels[0]), int(labels[1]), int(labels[2]), int(allow_low_quality), _lib.ptr(expo),
-           float(eps), _lib.ptr(o["matched_val"]), _lib.ptr(o["matched_idx"]), _lib.ptr(o["match_label"]), _lib.ptr(bits),
-           _lib.ptr(o["gt_best_idx"]), _lib.ptr(o["keys"][:B]), _lib.ptr(o["keys"][B:]), _lib.stream_of(anchors))
+           _lib.ptr(state), _lib.ptr(ticket), float(eps), _lib.ptr(o["matched_val"]), _lib.ptr(o["matched_idx"]), _lib.ptr(o["match_label"]),
+           _lib.ptr(bits), _lib.ptr(o["gt_best_idx"]), _lib.ptr(o["keys"][:B]), _lib.ptr(o["keys"][B:]), _lib.stream_of(anchors))
     o["key_pos"], o["key_neg"] = o["keys"][:B], o["keys"][B:]
     return o
 
@@ -204,20 +208,30 @@ ROI_MAXC = 2048
 
 
 def roi_sample(prop_boxes, prop_count, gt, gt_cls, gt_off, ign, ign_off, expo, iou_thr, ignore_thresh, num_classes,
-               batch_per_image, positive_fraction, append_gt=True, eps=1e-4):
+               batch_per_image, positive_fraction, append_gt=True, eps=1e-4, draw=None, first=0):
+    """-> (boxes, cls, gt row, iou, counts) of the sampled ROIs, + (rows clamped to >= 0,) + the contiguous copies (boxes, cls, clamped
+    rows) of the first `first` slots per image when first > 0.  expo (B, ROI_MAXC) Exp(1) variates, or None with draw = a
+    glue.DrawState: drawn inside the kernel (csrc/philox.h)."""
     L = _dev(prop_boxes, prop_count, gt, gt_cls, gt_off, ign, ign_off, expo)
     B, pmax = prop_boxes.shape[0], prop_boxes.shape[1]
-    assert expo.shape == (B, ROI_MAXC)
+    assert expo is None or expo.shape == (B, ROI_MAXC)
     o_boxes = _empty((B, batch_per_image, 4), torch.float32, prop_boxes)
     o_cls = _empty((B, batch_per_image), torch.int32, prop_boxes)
     o_gt = _empty((B, batch_per_image), torch.int32, prop_boxes)
     o_iou = _empty((B, batch_per_image), torch.float32, prop_boxes)
     o_cnt = _empty((B, 2), torch.int32, prop_boxes)
-    L.call("omni_roi_sample", _lib.ptr(prop_boxes), _lib.ptr(prop_count), B, pmax, _lib.ptr(gt), _lib.ptr(gt_cls),
-           _lib.ptr(gt_off), _lib.ptr(ign), _lib.ptr(ign_off), _lib.ptr(expo), float(iou_thr), float(ignore_thresh),
-           float(eps), int(num_classes), int(batch_per_image), int(batch_per_image * positive_fraction), int(append_gt),
-           _lib.ptr(o_boxes), _lib.ptr(o_cls), _lib.ptr(o_gt), _lib.ptr(o_iou), _lib.ptr(o_cnt), _lib.stream_of(prop_boxes))
-    return o_boxes, o_cls, o_gt, o_iou, o_cnt
+    o_row = _empty((B, batch_per_image), torch.int32, prop_boxes)
+    first = int(min(first, batch_per_image))
+    f_boxes = _empty((B, first, 4), torch.float32, prop_boxes) if first > 0 else None
+    f_cls = _empty((B, first), torch.int32, prop_boxes) if first > 0 else None
+    f_row = _empty((B, first), torch.int32, prop_boxes) if first > 0 else None
+    state, ticket = draw.tensors(prop_boxes.device) if expo is None else (None, None)
+    L.call("omni_roi_sample_draw", _lib.ptr(prop_boxes), _lib.ptr(prop_count), B, pmax, _lib.ptr(gt), _lib.ptr(gt_cls),
+           _lib.ptr(gt_off), _lib.ptr(ign), _lib.ptr(ign_off), _lib.ptr(expo), _lib.ptr(state), _lib.ptr(ticket), float(iou_thr),
+           float(ignore_thresh), float(eps), int(num_classes), int(batch_per_image), int(batch_per_image * positive_fraction),
+           int(append_gt), _lib.ptr(o_boxes), _lib.ptr(o_cls), _lib.ptr(o_gt), _lib.ptr(o_iou), _lib.ptr(o_cnt), _lib.ptr(o_row), first,
+           _lib.ptr(f_boxes), _lib.ptr(f_cls), _lib.ptr(f_row), _lib.stream_of(prop_boxes))
+    return o_boxes, o_cls, o_gt, o_iou, o_cnt, o_row, (f_boxes, f_cls, f_row)
 
 
 def roi_levels(rois, min_level=2, max_level=6, canonical_size=224.0, canonical_level=4):
@@ -245,6 +259,18 @@ def roi_align_fwd(feats_nhwc, scales, rois, batch_idx, levels, P):
     L.call("omni_roi_align_fwd", *a, _lib.ptr(rois), _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, _lib.ptr(out),
            _lib.stream_of(rois))
     return out
+
+
+def roi_align_fwd2(feats_nhwc, scales, rois, batch_idx, levels, P, per_image, first):
+    """-> (out (R, P, P, C), out2 ((R // per_image) * first, P, P, C) = the first `first` ROIs of every block of `per_image`), one pass"""
+    L = _dev(rois, batch_idx, levels, *feats_nhwc)
+    R, C = rois.shape[0], feats_nhwc[0].shape[3]
+    out = _empty((R, P, P, C), torch.float32, rois)
+    out2 = _empty(((R // per_image) * first, P, P, C), torch.float32, rois)
+    keep, a = _feat_args(feats_nhwc, scales)
+    L.call("omni_roi_align_fwd2", *a, _lib.ptr(rois), _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, _lib.ptr(out), _lib.ptr(out2),
+           int(per_image), int(first), _lib.stream_of(rois))
+    return out, out2
 
 
 def roi_align_bwd_deterministic(P, R, C=256):

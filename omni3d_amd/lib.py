@@ -14,14 +14,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OMNI_LIB_SUFFIX: an A/B build of the same sources next to the default library (csrc/Makefile SUFFIX=...); unset everywhere but in bench A/B runs
 LIB_PATH = os.path.join(_HERE, "libomni3d_hip" + os.environ.get("OMNI_LIB_SUFFIX", "") + ".so")
 
-_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
-_CODES = {"p": _P, "i": _I, "l": _L, "f": _F}
+_P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_double
+_CODES = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D}
 
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "omni3d_hip.h")
 
 
 def parse_header(path=HEADER_PATH):
-    """name -> argument codes ('p' pointer, 'i' int, 'l' long long, 'f' float) for every
+    """name -> argument codes ('p' pointer, 'i' int, 'l' long long, 'f' float, 'd' double) for every
     `int omni_*(...)` declared in include/omni3d_hip.h -- the single source of truth of the ABI."""
     import re
     text = open(path).read()
@@ -37,6 +37,8 @@ def parse_header(path=HEADER_PATH):
                 codes += "l"
             elif a.startswith("float"):
                 codes += "f"
+            elif a.startswith("double"):
+                codes += "d"
             elif a.startswith("int"):
                 codes += "i"
             else:

@@ -142,7 +142,7 @@ def _run_roi_sample(dev, crowded=0):
     pcount = torch.tensor([pmax, 250], dtype=torch.int32)
     E = torch.empty(B, det.ROI_MAXC).exponential_(generator=g)
     gt_off, ign_off = _offsets(gts), _offsets(igns)
-    ob, oc, og, oi, cnt = det.roi_sample(props.to(dev), pcount.to(dev), torch.cat(gts).to(dev), torch.cat(gcls).int().to(dev),
+    ob, oc, og, oi, cnt, orow, ofirst = det.roi_sample(props.to(dev), pcount.to(dev), torch.cat(gts).to(dev), torch.cat(gcls).int().to(dev),
                                          gt_off.to(dev), torch.cat(igns).to(dev), ign_off.to(dev), E.to(dev), 0.5, 0.5, Kc, 128, 0.25)
     for n in range(B):
         rb, rc, rm, rs = O.roi_label_and_sample(props[n, : pcount[n]], gts[n], gcls[n], igns[n], E[n], num_classes=Kc,
@@ -153,6 +153,72 @@ def _run_roi_sample(dev, crowded=0):
         assert torch.equal(oc[n, :ns].cpu().long(), rc)
         assert torch.equal(og[n, :ns].cpu().long() - int(gt_off[n]), rm)
         assert (oc[n, ns:] == -2).all()
+    # round 6: the rows the loss kernels index with (`clamp(min=0)` of the matched rows) and the cube head's contiguous prefix
+    assert torch.equal(orow.cpu(), og.cpu().clamp(min=0)) and ofirst == (None, None, None)
+    out = det.roi_sample(props.to(dev), pcount.to(dev), torch.cat(gts).to(dev), torch.cat(gcls).int().to(dev), gt_off.to(dev),
+                         torch.cat(igns).to(dev), ign_off.to(dev), E.to(dev), 0.5, 0.5, Kc, 128, 0.25, first=32)
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(out[:6], (ob, oc, og, oi, cnt, orow)))
+    fb, fc, fr = out[6]
+    assert torch.equal(fb.cpu(), ob[:, :32].cpu()) and torch.equal(fc.cpu(), oc[:, :32].cpu()) and torch.equal(fr.cpu(), orow[:, :32].cpu())
+    # in-kernel draws (csrc/philox.h): E = None + a DrawState.  The sample is a valid one (same counts: they do not depend on the
+    # variates), repeats exactly from the same (seed, counter), differs from the next draw, and the kernel advances the counter
+    from omni3d_amd.kernels.glue import DrawState
+    args = (props.to(dev), pcount.to(dev), torch.cat(gts).to(dev), torch.cat(gcls).int().to(dev), gt_off.to(dev), torch.cat(igns).to(dev),
+            ign_off.to(dev), None, 0.5, 0.5, Kc, 128, 0.25)
+    torch.manual_seed(5)
+    d1 = DrawState()
+    a1 = det.roi_sample(*args, draw=d1)
+    a2 = det.roi_sample(*args, draw=d1)
+    assert d1.state.cpu().tolist()[1] == 2 and int(d1.ticket.cpu()) == 0
+    torch.manual_seed(5)
+    d2 = DrawState()
+    b1 = det.roi_sample(*args, draw=d2)
+    assert torch.equal(a1[4].cpu(), cnt.cpu()) and torch.equal(a2[4].cpu(), cnt.cpu())
+    assert torch.equal(a1[0].cpu(), b1[0].cpu()) and torch.equal(a1[1].cpu(), b1[1].cpu())          # same seed, same counter
+    assert not torch.equal(a1[0].cpu(), a2[0].cpu())                                                   # next draw: another sample
+    for n in range(B):      # every sampled box is one of the candidates, foreground slots carry foreground classes
+        ns = int(a1[4][n].sum())
+        cand = torch.cat([props[n, : pcount[n]], gts[n]])
+        assert all((cand == a1[0][n, j].cpu()).all(1).any() for j in range(ns))
+        assert (a1[1][n, : int(a1[4][n, 0])].cpu() < Kc).all() and (a1[1][n, int(a1[4][n, 0]): ns].cpu() == Kc).all()
+
+
+def _run_philox(dev):
+    """the variates themselves: Exp(1) -- mean 1, variance 1, the right tail -- through the RPN matcher's sampling keys"""
+    from omni3d_amd.kernels import det
+    from omni3d_amd.kernels.glue import DrawState
+    g = torch.Generator().manual_seed(3)
+    A = 60000
+    anchors = _rand_boxes(g, A, 400, 400, 8, 64)
+    gt = torch.tensor([[10.0, 10, 50, 60]])
+    gt_off = torch.tensor([0, 1, 1], dtype=torch.int32)       # image 0: one box, image 1: none (every anchor is a negative)
+    torch.manual_seed(11)
+    d = DrawState()
+    m = det.rpn_match(anchors.to(dev), gt.to(dev), gt_off.to(dev), None, draw=d, B=2)
+    keys = m["key_neg"][1].cpu().double()                      # (0 + eps) / e for every anchor of the empty image
+    e = 1e-4 / keys
+    assert torch.isfinite(e).all() and (e > 0).all()
+    assert abs(float(e.mean()) - 1.0) < 0.02 and abs(float(e.var()) - 1.0) < 0.05
+    for q, want in ((1.0, 0.3679), (2.0, 0.1353), (4.0, 0.0183)):
+        assert abs(float((e > q).double().mean()) - want) < 0.01
+    m2 = det.rpn_match(anchors.to(dev), gt.to(dev), gt_off.to(dev), None, draw=d, B=2)
+    e2 = 1e-4 / m2["key_neg"][1].cpu().double()
+    assert abs(float(((e - 1) * (e2 - 1)).mean())) < 0.02     # consecutive draws are uncorrelated
+    assert d.state.cpu().tolist()[1] == 2 and int(d.ticket.cpu()) == 0
+    # the two images of one draw are different streams
+    lab = m["match_label"][0].cpu()
+    e0 = (m["matched_val"][0].cpu().double() + 1e-4) / torch.where(lab == 0, m["key_neg"][0].cpu().double(), torch.full((A,), float("nan"), dtype=torch.float64))
+    ok = lab == 0
+    assert abs(float(((e0[ok] - 1) * (e[ok] - 1)).mean())) < 0.03
+
+
+def test_philox_draws_emulated(emu_lib):
+    _run_philox("cpu")
+
+
+@pytest.mark.gpu
+def test_philox_draws_gpu(hip_lib):
+    _run_philox("cuda")
 
 
 def _run_roi_align(dev):
@@ -194,6 +260,10 @@ def _run_roi_align(dev):
     # == one pass over their sum; also with the first one absent
     per_image, first = 11, 4                                   # 33 ROIs = 3 blocks
     assert R == 3 * per_image
+    # forward with the prefix written to a second tensor in the same pass (round 6) == the slice of the full output, bit for bit
+    o1, o2 = det.roi_align_fwd2(fn, scales, rois.to(dev), bidx.to(dev), lv, P, per_image, first)
+    assert torch.equal(o1.cpu(), out.cpu())
+    assert torch.equal(o2.cpu(), out.cpu().view(3, per_image, P, P, C)[:, :first].reshape(-1, P, P, C))
     d2 = torch.randn((R // per_image) * first, P, P, C, generator=g)
     merged = dout.clone()
     merged.view(-1, per_image, P, P, C)[:, :first] += d2.view(-1, first, P, P, C)

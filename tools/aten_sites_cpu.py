@@ -1,6 +1,6 @@
 """Which Python lines issue the small ATen ops of one training step?  Runs the step on the CPU under the host emulator with a
 TorchDispatchMode that records every aten op that would be a device launch, together with the innermost frame inside this repo (the
-torch profiler has no Python stacks in this image).  usage: python tools/aten_sites_cpu.py [forward|backward]"""
+torch profiler has no Python stacks in this image).  usage: python tools/aten_sites_cpu.py"""
 import os
 import sys
 import traceback
@@ -41,7 +41,10 @@ class Rec(TorchDispatchMode):
                 if "/omni3d_amd/" in fr.filename:
                     site = f"{os.path.relpath(fr.filename, ROOT)}:{fr.lineno} {fr.name}"
                     break
-            self.sites[(site, name.replace("aten.", ""))] += 1
+            def sh(a):
+                return (str(a.dtype).replace("torch.", "") + str(tuple(a.shape))) if isinstance(a, torch.Tensor) else None
+            shapes = ",".join(x for x in (sh(a) for a in args[:3]) if x)
+            self.sites[(site, name.replace("aten.", "") + "  " + shapes[:70])] += 1
         return func(*args, **(kwargs or {}))
 
 
@@ -56,19 +59,36 @@ opt = build_optimizer(cfg, model)
 batch = synthetic.make_batch(int(os.environ.get("ATEN_SITES_B", "2")), 64, 64, num_gt=3, seed=40, priors=priors)
 packed = model.prepack(batch)
 from omni3d_amd.d2.events import EventStorage
+from omni3d_amd.cubercnn.solver.graphed import GraphedPipelined
+from omni3d_amd.cubercnn.solver.guard import StepGuard
+from omni3d_amd.functional import total_loss
+
+# the step bench.py times (omni3d_amd/bench_train.py): staged stepper (eager launches here) + non-finite scan + guard + fused update
 with EventStorage(0):
+    stepper = GraphedPipelined(model, opt, batch, packed, graphs=False)
+    names = None
+    guard = None
+
+    def finish(losses, total):
+        global guard
+        if guard is None:
+            guard = StepGuard(list(losses), cfg.MODEL.STABILIZE, cfg.SOLVER.CHECKPOINT_PERIOD, "cpu")
+            opt.skip_flag = guard.skip
+        opt.check_nonfinite(guard.nonfinite_flag)
+        guard.update(losses, sync=False)
+        opt.step()
+
     for _ in range(2):
-        opt.zero_grad()
-        sum(model(batch, packed).values()).backward()
-    fwd, bwd = Rec(), Rec()
-    opt.zero_grad()
-    with fwd:
-        losses = model(batch, packed)
-        from omni3d_amd.functional import total_loss
-        total = total_loss(losses)
-    with bwd:
-        total.backward()
-for title, rec in (("forward (+ loss sum)", fwd), ("backward", bwd)):
+        losses, total, pending = stepper()
+        opt.all_reduce_finish(pending, defer_scale=True)
+        finish(losses, total)
+    a, b = Rec(), Rec()
+    with a:
+        losses, total, pending = stepper()
+    with b:
+        opt.all_reduce_finish(pending, defer_scale=True)
+        finish(losses, total)
+for title, rec in (("staged forward + backward (what the seven stage graphs capture)", a), ("all_reduce_finish + non-finite scan + guard + update", b)):
     print(f"== {title}: {sum(rec.sites.values())} non-view aten ops")
     for (site, op), n in sorted(rec.sites.items(), key=lambda kv: (kv[0][0], kv[0][1])):
-        print(f"{n:3d}  {op:34s} {site}")
+        print(f"{n:3d}  {op:100s} {site}")

@@ -12,12 +12,12 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-OMNI_BENCH_SKIP_CPU=1 OMNI_BENCH_SKIP_ROOFLINE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o train -- python $REPO/bench.py --workload train --steps 10 --warmup 3 > $OUT/${TAG}_prof.log 2>&1
+OMNI_BENCH_CONDITION_STEPS=0 OMNI_BENCH_WINDOWS=1 OMNI_BENCH_SKIP_STAGE_ENDS=1 OMNI_BENCH_SKIP_CPU=1 OMNI_BENCH_SKIP_ROOFLINE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o train -- python $REPO/bench.py --workload train --steps 10 --warmup 3 > $OUT/${TAG}_prof.log 2>&1
 cd $REPO
 f=$(find $OUT/${TAG}_prof -name 'train_kernel_stats.csv' | head -1)
-[ -n "$f" ] && cp $f $OUT/${TAG}_kernel_stats.csv && cp $f profiles/r05_train_final_kernel_stats.csv && head -12 $f | cut -c1-150
+[ -n "$f" ] && cp $f $OUT/${TAG}_kernel_stats.csv && cp $f profiles/r06_train_final_kernel_stats.csv && head -12 $f | cut -c1-150
 t=$(find $OUT/${TAG}_prof -name 'train_kernel_trace.csv' | head -1)
-[ -n "$t" ] && python tools/trace_table.py $t 17 200 > $OUT/${TAG}_trace_table.txt && cp $OUT/${TAG}_trace_table.txt profiles/r05_trace_table_final.txt && head -3 $OUT/${TAG}_trace_table.txt
+[ -n "$t" ] && python tools/trace_table.py $t 17 200 > $OUT/${TAG}_trace_table.txt && cp $OUT/${TAG}_trace_table.txt profiles/r06_trace_table_final.txt && head -3 $OUT/${TAG}_trace_table.txt
 [ -n "$t" ] && python - "$t" $OUT/${TAG}_trace_tail.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -35,13 +35,13 @@ find $OUT/${TAG}_prof -name '*kernel_trace.csv' -delete
 if [ "${SKIP_PMC:-0}" = "0" ]; then
 timeout 600 python tools/pmc_run.py $OUT/${TAG}_pmc $OUT/${TAG}_pmc_families.csv -- python $REPO/tools/run_families.py > $OUT/${TAG}_pmc.log 2>&1
 tail -3 $OUT/${TAG}_pmc.log | cut -c1-200
-[ -s $OUT/${TAG}_pmc_families.csv ] && cp $OUT/${TAG}_pmc_families.csv profiles/r05_pmc_families.csv
+[ -s $OUT/${TAG}_pmc_families.csv ] && cp $OUT/${TAG}_pmc_families.csv profiles/r06_pmc_families.csv
 find $OUT/${TAG}_pmc -name '*kernel_trace.csv' -delete; find $OUT/${TAG}_pmc -name '*counter_collection.csv' -delete
 OMNI_BENCH_SKIP_CPU=1 timeout 600 python tools/pmc_run.py $OUT/${TAG}_pmc_iou3d $OUT/${TAG}_pmc_iou3d.csv --filter "iou_box3d|box3d_validity" -- python $REPO/bench.py --workload iou3d --steps 3 --warmup 1 > $OUT/${TAG}_pmc_iou3d.log 2>&1
 tail -3 $OUT/${TAG}_pmc_iou3d.log | cut -c1-200
-[ -s $OUT/${TAG}_pmc_iou3d.csv ] && cp $OUT/${TAG}_pmc_iou3d.csv profiles/r05_pmc_iou3d.csv
+[ -s $OUT/${TAG}_pmc_iou3d.csv ] && cp $OUT/${TAG}_pmc_iou3d.csv profiles/r06_pmc_iou3d.csv
 find $OUT/${TAG}_pmc_iou3d -name '*kernel_trace.csv' -delete; find $OUT/${TAG}_pmc_iou3d -name '*counter_collection.csv' -delete
-fi   # (SKIP_PMC=1: the committed profiles/r05_pmc_*.csv of this round stay -- same kernels, see profiles/README.md)
+fi   # (SKIP_PMC=1: the committed profiles/r06_pmc_*.csv of this round stay -- same kernels, see profiles/README.md)
 OMNI_PIPE_TIMING=1 OMNI_BENCH_SKIP_CPU=1 OMNI_BENCH_SKIP_ROOFLINE=1 timeout 300 python bench.py --workload train --steps 30 --warmup 5 2>&1 | grep -E "pipe timing" > $OUT/${TAG}_pipe_timing.log
 timeout 1500 python bench.py > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.log

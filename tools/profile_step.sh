@@ -1,11 +1,11 @@
 #!/bin/bash
-# usage: tools/_gpu_prof.sh <tag>  -> gpurun_out/<tag>_trace_table.txt, <tag>_trace_tail.csv (last 3 steps), <tag>_pipe.log
+# usage: tools/profile_step.sh <tag>  -> gpurun_out/<tag>_trace_table.txt, <tag>_trace_tail.csv (last 3 steps), <tag>_pipe.log
 set -u
 TAG=${1:-r04x}
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 OMNI_PIPE_TIMING=1 OMNI_BENCH_SKIP_CPU=1 OMNI_BENCH_SKIP_ROOFLINE=1 timeout 300 python bench.py --workload train --steps 30 --warmup 5 2>&1 | grep -E "pipe timing|images/sec" | cut -c1-400 > $OUT/${TAG}_pipe.log; cat $OUT/${TAG}_pipe.log | cut -c1-330
 cd /tmp
-OMNI_BENCH_SKIP_CPU=1 OMNI_BENCH_SKIP_ROOFLINE=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o train -- python $REPO/bench.py --workload train --steps 10 --warmup 3 > $OUT/${TAG}_prof.log 2>&1
+OMNI_BENCH_CONDITION_STEPS=0 OMNI_BENCH_WINDOWS=1 OMNI_BENCH_SKIP_STAGE_ENDS=1 OMNI_BENCH_SKIP_CPU=1 OMNI_BENCH_SKIP_ROOFLINE=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o train -- python $REPO/bench.py --workload train --steps 10 --warmup 3 > $OUT/${TAG}_prof.log 2>&1
 cd $REPO
 t=$(find $OUT/${TAG}_prof -name 'train_kernel_trace.csv' | head -1)
 [ -n "$t" ] && python tools/trace_table.py $t 17 200 > $OUT/${TAG}_trace_table.txt

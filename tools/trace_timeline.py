@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Timeline of ONE replayed training step from a rocprofv3 kernel trace tail (tools/_gpu_prof.sh): every kernel of the main queue
+"""Timeline of ONE replayed training step from a rocprofv3 kernel trace tail (tools/profile_step.sh): every kernel of the main queue
 and of the weight-gradient queue with its start offset and duration, plus per-phase sums.  usage: trace_timeline.py <tail.csv> [out]"""
 import csv
 import sys
