@@ -115,6 +115,16 @@ int omni_conv2d_wgrad_det(const float* x, const float* dy, float* dw, int N, int
                           int stride, int pad, int ldx, int lddy, int accumulate, int tile, float* ws, long long ws_floats,
                           int* ctr, int n_ctr, long long* plan, void* stream);
 
+/* Round 6: n <= 64 direct weight gradients (nn.Conv2d backward of the 1 x 1 roots / projections / laterals and the stride-2 3 x 3
+ * layers, cubercnn/modeling/backbone/dla.py:43-51, 159-172, 205-214; detectron2 FPN laterals) in as few launches as their tile shapes
+ * allow -- normally one per backward stage.  Dense tensors (ldx = C, lddy = K), square filters; arrays are HOST arrays of n entries.
+ * nsrc[i] > 0: x of problem i is the channel concatenation of xs[i * 6 + s] (widths cs[i * 6 + s]), as omni_conv2d_wgrad_multi_det.
+ * Deterministic form (ctr != NULL): every problem keeps the split structure of its own omni_conv2d_wgrad_det launch -- bit-identical
+ * results; plan != NULL: plan[2] = counters, plan[3] = workspace floats needed, nothing is launched. */
+int omni_conv2d_wgrad_batch_det(const void* const* x, const void* const* dy, const void* const* dw, const int* N, const int* H, const int* W,
+                                const int* C, const int* K, const int* R, const int* stride, const int* pad, const int* accumulate,
+                                const void* const* xs, const int* cs, const int* nsrc, int n, float* ws, long long ws_floats, int* ctr,
+                                int n_ctr, long long* plan, void* stream);
 /* omni_conv2d_wgrad_det for an input that is the channel concatenation of nsrc <= 6 dense NHWC tensors (omni_conv2d_fwd_multi_det):
  * dw (K, 1, 1, sum cs) = dy^T x of the DLA Root's 1 x 1 convolution (dla.py:166-172) without the concatenated copy; cs[s] % 4 == 0,
  * xs / cs HOST arrays, dy (N, H, W, K) with pixel pitch lddy.  Bit-identical to the single-tensor entry on the concatenated input.

@@ -65,6 +65,9 @@ def stage_batch(model, priors, rank, n=IMS_PER_GPU, size=IMAGE_SIZE):
 
 
 def run_train(args, world, rank):
+    main_prio = int(os.environ.get("OMNI_MAIN_PRIORITY", "0"))
+    if main_prio != 0 and DEVICE == "cuda":       # A/B knob: the critical path on a high-priority stream (torch: -1 = high)
+        torch.cuda.set_stream(torch.cuda.Stream(priority=main_prio))
     cfg, model, opt, priors = build(world)
     if world > 1:
         dist.broadcast(opt.flat_param, src=0)

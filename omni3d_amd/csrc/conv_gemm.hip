@@ -592,25 +592,26 @@ __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
 //   Each thread owns one (tap, c) float4 column of B and walks its BI pixel rows with incremental
 //   (oh, ow, offset) cursors -- no integer division inside the slab loop.
 // =================================================================================================
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK = 32>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_split) {
+// The body takes its place in the launch as arguments (bx / by / bz of gx / gy workgroups) so that ONE launch can carry several
+// problems (conv_wgrad_multi_kernel below: a workgroup looks its problem up and runs this body with that problem's coordinates).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
+__device__ __forceinline__ void conv_wgrad_body(ConvP& p, int pix_per_split, int bx, int by, int bz, int gx, int gy, float* smem) {
     constexpr int WM = BM / (32 * WAVES_M), WN = BN / (32 * WAVES_N);
     constexpr int AF4 = BM / 4, AROWS = 256 / AF4, AI = BK / AROWS;
     constexpr int BF4 = BN / 4, BROWS = 256 / BF4, BI = BK / BROWS;
     static_assert(AROWS * AI == BK && BROWS * BI == BK && WAVES_M * WAVES_N == 4, "tile mapping");
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
-    p.x += (long)blockIdx.z * p.xb;       // batched GEMM (Winograd): problem blockIdx.z
-    p.w += (long)blockIdx.z * p.wb;
-    p.out += (long)blockIdx.z * p.ob;
+    p.x += (long)bz * p.xb;       // batched GEMM (Winograd): problem bz
+    p.w += (long)bz * p.wb;
+    p.out += (long)bz * p.ob;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int P = p.N * p.OH * p.OW, Nn = p.R * p.S * p.C;
     const int tiles_m = (p.K + BM - 1) / BM;
     // p.relu (unused by a weight gradient) = XCD-contiguous tile order: the tiles_m workgroups that share an x panel run on ONE
     // XCD instead of one on each (fc1: 8 tiles per 2048 x 64 panel, exactly one per XCD in the plain order)
-    const int bid = p.relu ? xcd_chunked((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int bid = p.relu ? xcd_chunked(bx, gx) : bx;
     const int m0 = (bid % tiles_m) * BM, n0 = (bid / tiles_m) * BN;
-    const int p_begin = blockIdx.y * pix_per_split;
+    const int p_begin = by * pix_per_split;
     const int p_end = (p_begin + pix_per_split < P) ? p_begin + pix_per_split : P;
     const int am4 = tid % AF4, arow = tid / AF4;
     const int bn4 = tid % BF4, brow = tid / BF4;
@@ -686,7 +687,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
     f32x16 acc[WM][WN];
     zero_acc<WM, WN>(acc);
     const int nk = (p_end - p_begin + BK - 1) / BK;
-    const bool det = p.ctr != nullptr && gridDim.y > 1;
+    const bool det = p.ctr != nullptr && gy > 1;
     if (nk <= 0 && !det) return;
     if (nk > 0) {
         load_slab();
@@ -702,9 +703,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
         __syncthreads();
     }
     const int l31 = lane & 31, h = lane >> 5;
-    if (det && !omni_split_reduce<WM, WN>(p.ws, p.ctr, (long)blockIdx.z * gridDim.x + blockIdx.x, (int)blockIdx.y, (int)gridDim.y, acc))
+    if (det && !omni_split_reduce<WM, WN>(p.ws, p.ctr, (long)bz * gx + bx, by, gy, acc))
         return;
-    const bool single = gridDim.y == 1 && !p.accumulate;
+    const bool single = gy == 1 && !p.accumulate;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -723,6 +724,38 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
             }
         }
 }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK = 32>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_split) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    conv_wgrad_body<BM, BN, WAVES_M, WAVES_N, BK>(p, pix_per_split, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x,
+                                                  (int)gridDim.y, smem);
+}
+
+// Round 6: the direct weight gradients of one backward stage in ONE launch (the Winograd-domain ones have had
+// gemm_tn_multi_kernel since round 4: 0.23 -> 0.66 of peak inside the step).  The 23 direct launches of a step -- 1 x 1 roots,
+// projections and laterals, stride-2 3 x 3 layers: 1-2.4 GFLOP each -- ran at 0.23-0.30 of peak inside the step: every launch ramps up
+// and drains on its own while the weight-gradient stream shares the chip with the critical path.  Here problem q owns the workgroups
+// [first[q], first[q + 1]) of a 1-D grid, local index l -> (tile l % tiles[q], split l / tiles[q]); arithmetic, split structure,
+// workspace slots and counters of every problem are exactly those of its own launch of conv_wgrad_kernel (bit-identical results).
+constexpr int WGRAD_MULTI_MAX = 12;      // 12 x sizeof(ConvP) + the index arrays stay below the 4 KB of kernel arguments
+struct ConvWMulti {
+    ConvP p[WGRAD_MULTI_MAX];
+    int pps[WGRAD_MULTI_MAX], tiles[WGRAD_MULTI_MAX], splits[WGRAD_MULTI_MAX], first[WGRAD_MULTI_MAX + 1];
+    int n;
+};
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK = 32>
+__global__ void __launch_bounds__(256) conv_wgrad_multi_kernel(ConvWMulti m) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < WGRAD_MULTI_MAX; ++i)
+        if (i < m.n && (int)blockIdx.x >= m.first[i]) q = i;
+    const int l = (int)blockIdx.x - m.first[q];
+    ConvP p = m.p[q];
+    conv_wgrad_body<BM, BN, WAVES_M, WAVES_N, BK>(p, m.pps[q], l % m.tiles[q], l / m.tiles[q], 0, m.tiles[q], m.splits[q], smem);
+}
+
 
 // =================================================================================================
 // Persistent batched GEMM  out[b] (M x N) = A[b] (M x K) * B[b] (N x K)^T   (the 16 Winograd-point GEMMs, K = channels)
@@ -1339,6 +1372,37 @@ int omni_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, 
 // reduction is split); accumulate != 0: the result is atomically ADDED to dw -- this is how weight gradients land
 // directly in the flat gradient bucket without an extra add kernel per parameter.
 // tile: 0 auto | 1 = 128x128 | 2 = 64x64 | 3 = 128x64 | 4 = 32x128 (BM over K, BN over the (r, s, c) extent)
+// tile shape, tile count, reduction split and pixels per split of a weight-gradient launch: a function of the problem alone, shared by
+// the single-problem launcher and the multi-problem one (which keeps every problem's structure, hence its bits)
+struct WgradGeom {
+    int bm, bn, tiles, pps;
+    long splits;
+};
+static inline WgradGeom wgrad_geom(int K, int Nn, long P, int tile) {
+    constexpr int WBK = 32;
+    // tile: 128x128 for wide layers, 128x64 when the (tap, c) extent is only 64 wide, 64x64 for K <= 64,
+    // 32x128 for the <= 32-channel stem layers (a 64-row tile would spend >= half its MFMAs on padding)
+    WgradGeom g;
+    if (tile == 1) { g.bm = 128; g.bn = 128; }
+    else if (tile == 2) { g.bm = 64; g.bn = 64; }
+    else if (tile == 3) { g.bm = 128; g.bn = 64; }
+    else if (tile == 4) { g.bm = 32; g.bn = 128; }
+    else if (K > 64) { g.bm = 128; g.bn = (Nn > 64 && P >= 32768) ? 128 : 64; }
+    else if (K > 32) { g.bm = 64; g.bn = 64; }
+    else { g.bm = 32; g.bn = 128; }
+    g.tiles = ((K + g.bm - 1) / g.bm) * ((Nn + g.bn - 1) / g.bn);
+    // aim at ~1024 workgroups, at least 256 pixels (8 slabs) per split
+    long splits = (1024 + g.tiles - 1) / g.tiles;
+    const long max_splits = (P + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int pps = (int)((P + splits - 1) / splits);
+    pps = (pps + WBK - 1) / WBK * WBK;
+    g.pps = pps;
+    g.splits = (P + pps - 1) / pps;
+    return g;
+}
+
 static int conv2d_wgrad_impl(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, int ldx, int lddy, int accumulate, int tile, void* stream, const DetArgs& det,
                              const MultiSrc* ms = nullptr) {
@@ -1375,25 +1439,9 @@ static int conv2d_wgrad_impl(const float* x, const float* dy, float* dw, int N, 
         return OMNI_OK;
     }
     constexpr int WBK = 32;
-    // tile: 128x128 for wide layers, 128x64 when the (tap, c) extent is only 64 wide, 64x64 for K <= 64,
-    // 32x128 for the <= 32-channel stem layers (a 64-row tile would spend >= half its MFMAs on padding)
-    int bm, bn;
-    if (tile == 1) { bm = 128; bn = 128; }
-    else if (tile == 2) { bm = 64; bn = 64; }
-    else if (tile == 3) { bm = 128; bn = 64; }
-    else if (tile == 4) { bm = 32; bn = 128; }
-    else if (K > 64) { bm = 128; bn = (Nn > 64 && P >= 32768) ? 128 : 64; }
-    else if (K > 32) { bm = 64; bn = 64; }
-    else { bm = 32; bn = 128; }
-    const int tiles = ((K + bm - 1) / bm) * ((Nn + bn - 1) / bn);
-    // aim at ~1024 workgroups, at least 256 pixels (8 slabs) per split
-    long splits = (1024 + tiles - 1) / tiles;
-    long max_splits = (P + 255) / 256;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int pps = (int)((P + splits - 1) / splits);
-    pps = (pps + WBK - 1) / WBK * WBK;
-    splits = (P + pps - 1) / pps;
+    const WgradGeom geo = wgrad_geom(K, Nn, P, tile);
+    const int bm = geo.bm, bn = geo.bn, tiles = geo.tiles, pps = geo.pps;
+    const long splits = geo.splits;
     if (det.plan != nullptr) {
         det_plan(det, tile, tiles, splits, (long)bm * bn);
         return OMNI_OK;
@@ -1430,6 +1478,115 @@ int omni_conv2d_wgrad_det(const float* x, const float* dy, float* dw, int N, int
                           void* stream) {
     return conv2d_wgrad_impl(x, dy, dw, N, H, W, C, K, R, S, stride, pad, ldx, lddy, accumulate, tile, stream,
                              DetArgs{ws, ws_floats, (unsigned*)ctr, n_ctr, plan});
+}
+
+// Round 6: n direct weight gradients (dense tensors: ldx = C, lddy = K; square filters) in as few launches as their tile shapes allow
+// -- normally ONE (conv_wgrad_multi_kernel; <= 12 problems per launch, problems of another tile shape go to a launch of their own).
+// Problem i: dw[i] (K, R, R, C) (+)= dy[i] (N, OH, OW, K)^T x[i] (N, H, W, C); nsrc[i] > 0: x is the channel concatenation of the
+// nsrc[i] tensors xs[i * 6 + s] of widths cs[i * 6 + s] (1 x 1 / stride 1, as omni_conv2d_wgrad_multi_det).  Deterministic form only
+// (ctr != NULL): every problem keeps the split structure, workspace layout and counters of its own omni_conv2d_wgrad_det launch
+// (bit-identical results), at offsets inside ws / ctr; plan != NULL: plan[2] = counters, plan[3] = workspace floats, nothing launched.
+int omni_conv2d_wgrad_batch_det(const void* const* x, const void* const* dy, const void* const* dw, const int* N, const int* H, const int* W,
+                                const int* C, const int* K, const int* R, const int* stride, const int* pad, const int* accumulate,
+                                const void* const* xs, const int* cs, const int* nsrc, int n, float* ws, long long ws_floats, int* ctr,
+                                int n_ctr, long long* plan, void* stream) {
+    if (n <= 0 || n > 64 || x == nullptr || dy == nullptr || dw == nullptr) return OMNI_ERR_ARG;
+    if (plan == nullptr && ctr == nullptr) return OMNI_ERR_ARG;
+    struct One { ConvP p; WgradGeom g; long ws_off; int ctr_off; long work; };
+    One one[64];
+    long ws_need = 0;
+    long ctr_need = 1;        // (counter 0: the unsplit accumulating launches' marker, see omni_conv2d_wgrad_det)
+    int live = 0;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n; ++i) {
+        const int S = R[i];
+        ConvP p{(const float*)x[i], (const float*)dy[i], nullptr, (float*)dw[i], N[i], H[i], W[i], C[i], (H[i] + 2 * pad[i] - R[i]) / stride[i] + 1,
+                (W[i] + 2 * pad[i] - S) / stride[i] + 1, K[i], R[i], S, stride[i], pad[i], C[i], 0, K[i], 0, accumulate[i], 1};
+        p.stats = nullptr; p.ws = nullptr; p.ctr = nullptr; p.nsrc = 0;
+        p.xb = p.wb = p.ob = 0;
+        const int ns = nsrc != nullptr ? nsrc[i] : 0;
+        if (ns > 0) {
+            if (ns > OMNI_MAX_SRC || xs == nullptr || cs == nullptr || R[i] != 1 || stride[i] != 1 || pad[i] != 0) return OMNI_ERR_ARG;
+            p.coff[0] = 0;
+            for (int q = 0; q < OMNI_MAX_SRC; ++q) {
+                const bool ok = q < ns;
+                const int c = ok ? cs[i * OMNI_MAX_SRC + q] : 0;
+                if (ok && (xs[i * OMNI_MAX_SRC + q] == nullptr || c <= 0 || (c & 3))) return OMNI_ERR_ARG;
+                p.xs[q] = ok ? (const float*)xs[i * OMNI_MAX_SRC + q] : nullptr;
+                p.coff[q + 1] = p.coff[q] + c;
+            }
+            if (p.coff[ns] != C[i]) return OMNI_ERR_ARG;
+            p.nsrc = ns;
+            p.x = p.xs[0];
+        } else {
+            for (int q = 0; q < OMNI_MAX_SRC; ++q) { p.xs[q] = nullptr; p.coff[q] = 0; }
+            p.coff[OMNI_MAX_SRC] = 0;
+        }
+        if (p.x == nullptr || p.w == nullptr || p.out == nullptr || bad_geom(p) || (K[i] & 3) || (C[i] & 3)) return OMNI_ERR_ARG;
+        const long P = (long)N[i] * p.OH * p.OW;
+        const int Nn = R[i] * S * C[i];
+        if (P == 0) {
+            if (plan == nullptr && !accumulate[i]) omni_memset_async((void*)dw[i], 0, sizeof(float) * (size_t)K[i] * Nn, st);
+            continue;
+        }
+        One& o = one[live++];
+        o.p = p;
+        o.g = wgrad_geom(K[i], Nn, P, 0);
+        o.ws_off = ws_need;
+        o.ctr_off = (int)ctr_need;
+        o.work = (long)o.g.pps;
+        if (o.g.splits > 1) {
+            ws_need += omni_split_ws_floats(o.g.tiles, o.g.splits, (long)o.g.bm * o.g.bn);
+            ctr_need += omni_split_counters(o.g.tiles, o.g.splits);
+        }
+    }
+    if (plan != nullptr) { plan[0] = 0; plan[1] = 0; plan[2] = ctr_need; plan[3] = ws_need; return OMNI_OK; }
+    if (live == 0) return OMNI_OK;
+    if (n_ctr < ctr_need || (ws_need > 0 && (ws == nullptr || ws_floats < ws_need))) return OMNI_ERR_ARG;
+    // longest workgroups first (dispatch follows the id): the short ones fill the tail
+    for (int a = 1; a < live; ++a) {
+        const One v = one[a];
+        int b = a;
+        for (; b > 0 && one[b - 1].work < v.work; --b) one[b] = one[b - 1];
+        one[b] = v;
+    }
+    static const int shapes[4][2] = {{128, 128}, {128, 64}, {64, 64}, {32, 128}};
+    for (int sh = 0; sh < 4; ++sh) {
+        int j0 = 0;
+        while (true) {
+            ConvWMulti m;
+            m.n = 0;
+            long first = 0;
+            int j = j0;
+            for (; j < live && m.n < WGRAD_MULTI_MAX; ++j) {
+                One& o = one[j];
+                if (o.g.bm != shapes[sh][0] || o.g.bn != shapes[sh][1]) continue;
+                const long blocks = (long)o.g.tiles * o.g.splits;
+                if (first + blocks > 0x7fffffff) return OMNI_ERR_ARG;
+                o.p.ws = o.g.splits > 1 ? ws + o.ws_off : ws;
+                o.p.ctr = (unsigned*)ctr + (o.g.splits > 1 ? o.ctr_off : 0);
+                o.p.relu = 0;
+                m.p[m.n] = o.p;
+                m.pps[m.n] = o.g.pps;
+                m.tiles[m.n] = o.g.tiles;
+                m.splits[m.n] = (int)o.g.splits;
+                m.first[m.n] = (int)first;
+                first += blocks;
+                ++m.n;
+            }
+            j0 = j;
+            if (m.n == 0) break;
+            for (int q = m.n; q <= WGRAD_MULTI_MAX; ++q) m.first[q] = (int)first;
+            for (int q = m.n; q < WGRAD_MULTI_MAX; ++q) { m.pps[q] = 32; m.tiles[q] = 1; m.splits[q] = 1; m.p[q] = m.p[0]; }
+            constexpr int WBK = 32;
+            if (sh == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_multi_kernel<128, 128, 2, 2, WBK>), dim3((unsigned)first), dim3(256), 0, st, m);
+            else if (sh == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_multi_kernel<128, 64, 2, 2, WBK>), dim3((unsigned)first), dim3(256), 0, st, m);
+            else if (sh == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_multi_kernel<64, 64, 2, 2, WBK>), dim3((unsigned)first), dim3(256), 0, st, m);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_multi_kernel<32, 128, 1, 4, WBK>), dim3((unsigned)first), dim3(256), 0, st, m);
+            if (j0 >= live) break;
+        }
+    }
+    return omni_launch_status();
 }
 
 // omni_conv2d_wgrad_det for an input that is the channel concatenation of nsrc <= 6 dense NHWC tensors (see omni_conv2d_fwd_multi_det):

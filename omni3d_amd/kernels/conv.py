@@ -198,11 +198,80 @@ def conv2d_wgrad(x, dy, ksize, stride=1, pad=0, accum_into=None, tile=0):
     if accum_into is not None:
         tgt = accum_into.permute(0, 2, 3, 1)
         assert tgt.is_contiguous() and tgt.shape == (K, R, S, C)
+        if tile == 0 and R == S and _defer_direct((xv, dyv, tgt, N, H, W, C, K, R, stride, pad, None)):
+            return None           # (inside wino.batched_wgrads(): leaves with the stage's other direct weight gradients in one launch)
         _wgrad_launch(L, _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(tgt), N, H, W, C, K, R, S, stride, pad, C, K, 1, tile, x)
         return None
     dw = torch.empty((K, R, S, C), dtype=torch.float32, device=x.device)
     _wgrad_launch(L, _lib.ptr(xv), _lib.ptr(dyv), _lib.ptr(dw), N, H, W, C, K, R, S, stride, pad, C, K, 0, tile, x)
     return dw.permute(0, 3, 1, 2)
+
+
+# The stage's direct weight gradients in ONE launch.  MEASURED and left OFF (OMNI_WGRAD_BATCH=1 enables it):
+# 10.85 / 10.84 ms with it against 10.83 / 10.80 ms without on one box (profiles/r06_ab_wgrad_batch.log) -- unlike the Winograd-domain
+# GEMMs (0.23 -> 0.66 of peak from the same move in round 4) these launches are not short of workgroups: each already spreads ~1024
+# of them over a split reduction, and what holds them at 0.25 of peak is the operand path of the 128 x 64 tile (PMC: MFMA-busy 0.26),
+# which a shared launch does not change.  Results are bit-identical either way (tests/test_conv.py::test_wgrad_batch_*).
+WGRAD_BATCH = os.environ.get("OMNI_WGRAD_BATCH", "0") == "1"
+_direct_deferred = None        # list while wino.batched_wgrads() is open (the weight-gradient stream's capture of one backward stage)
+
+
+def _defer_direct(item):
+    """queue an accumulating direct weight gradient (x, dy, dw view, N, H, W, C, K, R, stride, pad, sources or None) for the
+    stage's multi-problem launch; False = not inside the context (or switched off): the caller launches it itself"""
+    if _direct_deferred is None or not WGRAD_BATCH or not _det.on():
+        return False
+    _direct_deferred.append(item)
+    return True
+
+
+def open_direct_batch():
+    global _direct_deferred
+    prev, _direct_deferred = _direct_deferred, []
+    return prev
+
+
+def close_direct_batch(prev, launch=True):
+    """launch what was queued (omni_conv2d_wgrad_batch_det) and restore the enclosing state"""
+    global _direct_deferred
+    items, _direct_deferred = _direct_deferred, prev
+    if launch and items:
+        conv2d_wgrad_batch(items)
+
+
+def conv2d_wgrad_batch(items):
+    """items: [(x NHWC, dy NHWC, dw KRSC view to ADD into, N, H, W, C, K, R, stride, pad, [source NHWC tensors] or None)] -> every dw
+    += its weight gradient, in one launch per tile shape (csrc/conv_gemm.hip conv_wgrad_multi_kernel); bit-identical to
+    conv2d_wgrad(accum_into=...) / conv1x1_multi_wgrad(accum_into=...) on each.  Two items that add into the same view never share a
+    launch (their order would be the hardware's): the second one starts a new batch."""
+    import ctypes
+    batch, seen, rest = [], set(), []
+    for it in items:
+        (rest if it[2].data_ptr() in seen else batch).append(it)
+        seen.add(it[2].data_ptr())
+    n = len(batch)
+    L = _lib.check_device(*[t for it in batch for t in it[:3]])
+    P = ctypes.c_void_p
+    arr = lambda vals: ctypes.cast((P * len(vals))(*vals), P)                     # noqa: E731
+    ints = lambda vals: ctypes.cast((ctypes.c_int * len(vals))(*[int(v) for v in vals]), P)         # noqa: E731
+    xs_flat, cs_flat, nsrc = [], [], []
+    for it in batch:
+        src = it[11] or []
+        nsrc.append(len(src))
+        xs_flat += [t.data_ptr() for t in src] + [0] * (6 - len(src))
+        cs_flat += [int(t.shape[3]) for t in src] + [0] * (6 - len(src))
+    head = (arr([it[0].data_ptr() for it in batch]), arr([it[1].data_ptr() for it in batch]), arr([it[2].data_ptr() for it in batch]),
+            ints([it[3] for it in batch]), ints([it[4] for it in batch]), ints([it[5] for it in batch]), ints([it[6] for it in batch]),
+            ints([it[7] for it in batch]), ints([it[8] for it in batch]), ints([it[9] for it in batch]), ints([it[10] for it in batch]),
+            ints([1] * n), arr(xs_flat), ints(cs_flat), ints(nsrc), n)
+    like = batch[0][1]
+    st = _lib.stream_of(like)
+    plan, paddr = _det.new_plan()
+    L.call("omni_conv2d_wgrad_batch_det", *head, None, 0, None, 0, paddr, st)
+    ws, wsf, ctr, nctr = _det.workspace(like, plan)
+    L.call("omni_conv2d_wgrad_batch_det", *head, _lib.ptr(ws), wsf, _lib.ptr(ctr), nctr, None, st)
+    if rest:
+        conv2d_wgrad_batch(rest)
 
 
 def conv1x1_multi_wgrad(xs, dy, accum_into=None, tile=0):
@@ -220,6 +289,8 @@ def conv1x1_multi_wgrad(xs, dy, accum_into=None, tile=0):
     if accum_into is not None:
         tgt = accum_into.permute(0, 2, 3, 1)
         assert tgt.is_contiguous() and tgt.shape == (K, 1, 1, C)
+        if tile == 0 and n <= 6 and _defer_direct((xv[0], dyv, tgt, N, H, W, C, K, 1, 1, 0, xv)):
+            return None
         dw, acc = tgt, 1
     else:
         dw, acc = torch.empty((K, 1, 1, C), dtype=torch.float32, device=dyv.device), 0

@@ -262,11 +262,15 @@ class batched_wgrads:
     def __enter__(self):
         global _deferred
         self.prev, _deferred = _deferred, []
+        from . import conv as _conv
+        self.prev_direct = _conv.open_direct_batch()       # round 6: the stage's DIRECT weight gradients leave in one launch too
         return self
 
     def __exit__(self, et, ev, tb):
         global _deferred
         items, _deferred = _deferred, self.prev
+        from . import conv as _conv
+        _conv.close_direct_batch(self.prev_direct, launch=et is None)
         if et is None:
             for i in range(0, len(items), WGRAD_MULTI_MAX):
                 part = items[i:i + WGRAD_MULTI_MAX]

@@ -770,3 +770,57 @@ def test_conv1x1_multi_source_gpu(hip_lib):
     _run_multi_src("cuda", [(4, 128, 128, (64, 64), 64, 0, 0), (4, 64, 64, (128, 128), 128, 0, 0), (4, 64, 64, (128, 128, 64, 128), 128, 0, 0),
                             (4, 32, 32, (256, 256), 256, 0, 0), (4, 32, 32, (256, 256, 128, 256), 256, 0, 0), (4, 16, 16, (512, 512, 256), 512, 0, 0)]
                    + MULTI_SRC_SMALL)
+
+
+def _run_wgrad_batch(dev, big=False):
+    """round 6: the direct weight gradients of a backward stage in one launch (conv_wgrad_multi_kernel) are bit-identical to their own
+    launches -- 1 x 1, stride-2 3 x 3, the DLA Root's multi-source 1 x 1, mixed tile shapes, two problems adding into one view"""
+    from omni3d_amd.kernels import conv, wino
+    g = torch.Generator().manual_seed(21)
+    CL = torch.channels_last
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g).contiguous(memory_format=CL).to(dev)
+    s = 4 if big else 1
+    # (N, C, H, W, K, R, stride, pad)
+    cases = [(2, 64, 16 * s, 16 * s, 128, 1, 1, 0), (2, 32, 16 * s, 16 * s, 64, 3, 2, 1), (1, 128, 8 * s, 8 * s, 256, 1, 1, 0),
+             (2, 64, 12 * s, 12 * s, 64, 3, 2, 1), (2, 16, 16 * s, 16 * s, 32, 3, 2, 1), (1, 256, 8 * s, 8 * s, 256, 1, 1, 0)]
+    probs = []
+    for N, C, H, W, K, R, st, pad in cases:
+        OH = (H + 2 * pad - R) // st + 1
+        probs.append((rnd(N, C, H, W), rnd(N, K, OH, OH), (R, R), st, pad))
+    xs = [rnd(2, 32, 8 * s, 8 * s), rnd(2, 64, 8 * s, 8 * s), rnd(2, 32, 8 * s, 8 * s)]
+    dy_ms = rnd(2, 64, 8 * s, 8 * s)
+
+    def grads():
+        return ([torch.full((dy.shape[1], x.shape[1], k[0], k[1]), 0.5).contiguous(memory_format=CL).to(dev) for x, dy, k, _, _ in probs]
+                + [torch.full((64, 128, 1, 1), 0.25).contiguous(memory_format=CL).to(dev)])
+
+    def issue(into):
+        for (x, dy, k, st, pad), gw in zip(probs, into):
+            conv.conv2d_wgrad(x, dy, k, st, pad, accum_into=gw)
+        conv.conv1x1_multi_wgrad(xs, dy_ms, accum_into=into[-1])
+        conv.conv2d_wgrad(probs[0][0], probs[0][1], probs[0][2], probs[0][3], probs[0][4], accum_into=into[0])       # the same view once more
+    one = grads()
+    issue(one)                                   # every problem its own launch
+    many = grads()
+    prev, conv.WGRAD_BATCH = conv.WGRAD_BATCH, True          # (measured neutral in the step and left off by default: kernels/conv.py)
+    with wino.batched_wgrads():                  # the weight-gradient stream's context: everything leaves when it closes
+        issue(many)
+        assert all(torch.equal(a, b) for a, b in zip(many, grads()))          # nothing launched yet
+    conv.WGRAD_BATCH = prev
+    for a, b in zip(one, many):
+        assert torch.equal(a.cpu(), b.cpu())
+    # and against the plain sum: dw of a fresh buffer
+    ref0 = conv.conv2d_wgrad(probs[1][0], probs[1][1], probs[1][2], probs[1][3], probs[1][4])
+    assert (many[1].cpu() - 0.5 - ref0.cpu()).abs().max() <= 1e-4 * float(ref0.abs().max())
+
+
+def test_wgrad_batch_emulated(emu_lib):
+    _run_wgrad_batch("cpu")
+
+
+@pytest.mark.gpu
+def test_wgrad_batch_gpu(hip_lib):
+    _run_wgrad_batch("cuda")
+    _run_wgrad_batch("cuda", big=True)
