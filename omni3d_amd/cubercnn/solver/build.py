@@ -258,23 +258,65 @@ class _FlatOptimizer(torch.optim.Optimizer):
     # MERGE_FROM = k sends the ranges of stages k, k + 1, ... together behind the LAST stage instead of one call sequence per stage.
     # Both must be the same on every rank (they are part of the call sequence); the defaults are the round-4 behaviour.
     EXCHANGE_CHUNK = max(1, int(float(os.environ.get("OMNI_EXCHANGE_CHUNK_MB", "32")) * (1 << 18)))
-    EXCHANGE_MERGE_FROM = int(os.environ.get("OMNI_EXCHANGE_MERGE_FROM", "-1"))
+    # Round 6 default "auto" (-2): the trailing stages whose ranges together stay below EXCHANGE_TAIL_MB (2 MB: DLA-34's stages 4-6 hold
+    # 0.5 / 0.03 / 0.01 MB -- three latency-bound call sequences at the very end of backward) leave as ONE sequence behind the last
+    # stage, adjacent ranges coalesced into one call; -1 = one sequence per stage (rounds 4-5), k >= 0 = merge from stage k.
+    EXCHANGE_MERGE_FROM = int(os.environ.get("OMNI_EXCHANGE_MERGE_FROM", "-2"))
+    EXCHANGE_TAIL_MB = float(os.environ.get("OMNI_EXCHANGE_TAIL_MB", "2"))
     exchange_timing = False         # bench.py, N > 1: device-side events around the waits of all_reduce_finish (exchange_report)
 
     def exchange_stages(self, k):
         """backward stages whose ranges go out behind stage k (see EXCHANGE_MERGE_FROM)"""
-        m, last = self.EXCHANGE_MERGE_FROM, self.n_stages - 1
+        m, last = self.merge_from(), self.n_stages - 1
         if m < 0 or m >= last or k < m:
             return [k]
         return list(range(m, self.n_stages)) if k == last else []
+
+    def merge_from(self):
+        """the stage from which the ranges leave together behind the last stage (-1: none); a function of the bucket layout and the
+        environment knobs alone -- the same on every rank"""
+        m = self.EXCHANGE_MERGE_FROM
+        if m != -2:
+            return m
+        cached = self.__dict__.get("_merge_from_auto")
+        if cached is None:
+            limit, tail, k = self.EXCHANGE_TAIL_MB * (1 << 18), 0, self.n_stages
+            while k > 1:        # (stage 0, the heads, is never part of the tail)
+                size = sum(e - s for s, e in self.stage_ranges.get(k - 1, []))
+                if tail + size > limit:
+                    break
+                tail += size
+                k -= 1
+            cached = self.__dict__["_merge_from_auto"] = k if k < self.n_stages - 1 else -1
+        return cached
 
     def exchange_chunks(self, stages):
         """-> [(start, end)] of the given backward stages, stage by stage, class by class, cut into EXCHANGE_CHUNK pieces.  A function
         of the bucket layout (and the two environment knobs) alone: every rank issues the same sequence whether it replays a captured
         step or runs eager launches."""
+        # The call boundaries must not depend on HOW a rank got here (stage by stage behind its weight-gradient graphs, or "early" +
+        # "late" from an eager step): stages below the merge point are always sequences of their own; the stages from the merge point
+        # on form ONE group whose ranges are coalesced where they touch in the bucket -- whenever all of them are asked for together,
+        # which is the only way either form asks for them.
+        m = self.merge_from()
+        tail = [k for k in stages if m >= 0 and k >= m]
+        groups = [[k] for k in stages if not (m >= 0 and k >= m)]
+        if tail:
+            groups.append(tail if tail == list(range(m, self.n_stages)) else None)
+            if groups[-1] is None:
+                groups = groups[:-1] + [[k] for k in tail]
         out = []
-        for k in stages:
-            for s, e in self.stage_ranges.get(k, []):
+        for grp in groups:
+            ranges = [r for k in grp for r in self.stage_ranges.get(k, [])]
+            if len(grp) > 1:
+                merged = []
+                for s, e in sorted(ranges):
+                    if merged and merged[-1][1] == s:
+                        merged[-1] = (merged[-1][0], e)
+                    else:
+                        merged.append((s, e))
+                ranges = merged
+            for s, e in ranges:
                 while s < e:
                     out.append((s, min(e, s + self.EXCHANGE_CHUNK)))
                     s += self.EXCHANGE_CHUNK
@@ -331,7 +373,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         torch.cuda.synchronize()
         return {"exposed_ms": sum(a.elapsed_time(b) for (a, b), _, _ in evs) / len(evs), "steps": len(evs),
                 "all_reduce_calls_per_step": evs[-1][1], "bytes_per_step": 4 * evs[-1][2], "chunk_mb": self.EXCHANGE_CHUNK / (1 << 18),
-                "merge_from_stage": self.EXCHANGE_MERGE_FROM,
+                "merge_from_stage": self.merge_from(),
                 "stage_range_mb": {k: round(4 * sum(e - s for s, e in v) / 1e6, 3) for k, v in sorted(getattr(self, "stage_ranges", {}).items())},
                 "note": "exposed_ms: device time between the events around the waits of all_reduce_finish -- the share of the exchange that "
                         "backward did not hide"}

@@ -3,8 +3,17 @@ import torch
 
 from .. import lib as _lib
 
+import os
+
 NT, NN, TN = 0, 1, 2
 BALANCED = -1
+# Multi-GPU readiness: the engine's launches are PERSISTENT -- one workgroup per CU for the whole GEMM (0.34-0.47 ms
+# for the fc1-class ones) -- and a collective's kernel cannot start on a CU whose LDS / wave slots such a workgroup holds.  In the
+# staged step every engine launch sits in stage 0, before the first exchange is issued (solver/graphed.py: stage k's ranges leave
+# behind W_k), so nothing should collide; if an 8-GPU profile shows RCCL kernels queueing behind them anyway, OMNI_ENGINE_WGS=240
+# leaves 16 CUs free (a multiple of 8: the balanced split needs one).  It is NOT the default: the balanced split cuts its left-over
+# tiles by the workgroup count, so another count is another fp32 summation order, and no run over RCCL has shown the need.
+ENGINE_WGS = int(os.environ.get("OMNI_ENGINE_WGS", "0"))
 
 
 def gemm(A, B, form=NT, bias=None, relu=False, out=None, accumulate=False, splits=1, tile=1, workgroups=0):
@@ -13,6 +22,7 @@ def gemm(A, B, form=NT, bias=None, relu=False, out=None, accumulate=False, split
     out: optional preallocated result (accumulate=True adds into it with fp32 atomics); splits > 1 zeroes `out` first unless
     accumulating.  splits = BALANCED (-1): whole tiles per workgroup plus one part of the left-over tiles each (csrc/gemm_engine.hip);
     without the deterministic mode `out` is zeroed when tiles are cut (their parts meet through atomics)."""
+    workgroups = workgroups or ENGINE_WGS
     squeeze = A.dim() == 2
     A3, B3 = (A.unsqueeze(0), B.unsqueeze(0)) if squeeze else (A, B)
     assert A3.is_contiguous() and B3.is_contiguous() and A3.shape[0] == B3.shape[0]

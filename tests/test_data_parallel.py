@@ -478,3 +478,31 @@ def test_stage_ranges_of_the_real_model():
     assert last < 10 * 2 ** 20, last                       # bytes whose exchange cannot overlap any backward work
     by_stage = {k: sum(e - s for s, e in v) * 4 / 2 ** 20 for k, v in opt.stage_ranges.items()}
     assert by_stage[0] > 100 and by_stage[2] > 40, by_stage   # MB: FC heads 109, FPN + level 5 / 4 66
+
+
+def test_exchange_tail_is_one_sequence_and_forms_agree():
+    """the tiny ranges of the last backward stages (DLA-34: 0.5 / 0.03 / 0.01 MB) leave as ONE call sequence behind
+    the last stage (default OMNI_EXCHANGE_MERGE_FROM=auto), touching ranges as one call -- and the sequence of (start, end) calls is the
+    same whether a rank issues it stage by stage (staged replay) or as "early" + "late" (an eager step)."""
+    import os
+    os.environ.setdefault("OMNI_BENCH_DEVICE", "cpu")
+    from omni3d_amd import bench_train as BT
+    cfg, model, opt, _ = BT.build(1, device="cpu")
+    assert opt.n_stages == 7
+    mb = {k: 4 * sum(e - s for s, e in v) / 1e6 for k, v in opt.stage_ranges.items()}
+    m = opt.merge_from()
+    assert m == 4 and sum(mb[k] for k in range(m, 7)) < 2.0 and mb[3] > 2.0, (m, mb)
+    per_stage = [c for k in range(7) for c in opt.exchange_chunks(opt.exchange_stages(k))]
+    two_phase = opt.exchange_chunks([0]) + opt.exchange_chunks(list(range(1, 7)))
+    assert per_stage == two_phase
+    tail = opt.exchange_chunks(list(range(m, 7)))
+    assert len(tail) <= 2 and sum(e - s for s, e in tail) == sum(e - s for k in range(m, 7) for s, e in opt.stage_ranges[k])      # one call per weight-decay class
+    assert opt.exchange_stages(4) == [] and opt.exchange_stages(5) == [] and opt.exchange_stages(6) == [4, 5, 6]
+    covered = sorted(per_stage)
+    assert covered[0][0] == 0 and all(a[1] == b[0] for a, b in zip(covered, covered[1:])) and covered[-1][1] == opt.flat_grad.numel()
+    # the round-4/5 behaviour stays reachable
+    type(opt).EXCHANGE_MERGE_FROM = -1
+    try:
+        assert opt.merge_from() == -1 and opt.exchange_stages(5) == [5]
+    finally:
+        type(opt).EXCHANGE_MERGE_FROM = -2
