@@ -217,7 +217,8 @@ def cpu_baseline_iou3d(dt, gt, nsample=20000):
     if os.environ.get("OMNI_BENCH_SKIP_CPU") == "1":       # profiling runs: do not spend GPU-box minutes on the CPU leg
         return {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "skipped (OMNI_BENCH_SKIP_CPU=1)"}
     nsample = min(nsample, len(dt))
-    cores = min(len(os.sched_getaffinity(0)), 64)          # OpenMP team of the all-cores leg (set before libgomp starts)
+    from omni3d_amd import cpu_quota
+    cores = min(cpu_quota() or len(os.sched_getaffinity(0)), 64)          # OpenMP team of the all-cores leg (set before libgomp starts): what the cgroup grants
     from omni3d_amd.profile_io import host_cores
     os.environ["OMP_NUM_THREADS"] = str(cores)
     orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
@@ -373,14 +374,15 @@ def compact_line(res, detail):
         ms = res.get("dropin_loop_multiscale_stream") or {}
         if ms.get("ms_per_iteration_whole_region") is not None:
             line["dropin_loop"]["multiscale_stream"] = _pick(ms, ("iterations", "ms_per_iteration_whole_region", "ms_per_iteration_last_quarter",
-                                                                   "fixed_shape_step_scaled_by_pixels_ms", "hit_rate", "eager_new_shape_ms"))
+                                                                   "fixed_shape_step_scaled_by_pixels_ms", "whole_region_vs_pixel_scaled_fixed_shape", "hit_rate", "eager_new_shape_ms",
+                                                                   "capture_ms", "replay_ms"))
     if "nonstandard" in res:
         line["nonstandard"] = _pick(res["nonstandard"], ("ims_per_gpu", "image_size", "device"))
     ex = res.get("exchange")
     if isinstance(ex, dict):       # N > 1: two numbers, the rest (per-call table, stage timeline, env) in the detail file
         line["exchange"] = _pick(ex, ("exposed_ms", "all_reduce_calls_per_step", "bytes_per_step", "chunk_mb", "merge_from_stage"))
     la = res.get("launch") or {}
-    line["launch"] = _pick(la, ("backend", "device", "ranks_observed", "one_gpu_per_rank"))
+    line["launch"] = _pick(la, ("backend", "device", "ranks_observed", "one_gpu_per_rank", "host_threads"))
     line["detail"] = detail
     line = _r(line)
     dropped = []
@@ -405,6 +407,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     world, rank, local, info = setup_dist(args.gpus)
+    from omni3d_amd import cpu_quota, respect_cpu_quota
+    info["host_threads"] = {"torch_intra_op": respect_cpu_quota(), "cgroup_cpu_quota": cpu_quota(), "cpus_shown": os.cpu_count()}
     workload = args.workload or DEFAULT_WORKLOAD
     if workload == "iou3d":
         res = run_iou3d(args, world, rank)

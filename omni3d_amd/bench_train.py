@@ -414,7 +414,7 @@ def dropin_loop_multiscale(iters=24, pool_size=8, fixed_ms=None):
 def dropin_loop_multiscale_stream(iters=320, fixed_ms=None):
     """the same loop on a NON-RECYCLED stream -- `iters` freshly drawn batches (generated before the clock starts,
     never repeated), a cold cache: the timed region contains the eager warm-up iterations of every new size bucket, its capture, the
-    evictions of the 16-entry cache and whatever the thrash guard decides (cubercnn/solver/autoreplay.py).  Reported: the cache's own
+    evictions of the memory-bounded 64-entry cache and whatever the thrash guard decides (cubercnn/solver/autoreplay.py).  Reported: the cache's own
     statistics, the time per iteration over the WHOLE region and over its last quarter (steady state)."""
     from omni3d_amd import synthetic
     from omni3d_amd.cubercnn.solver.guard import StepGuard
@@ -432,7 +432,9 @@ def dropin_loop_multiscale_stream(iters=320, fixed_ms=None):
         warnings.simplefilter("always")
         _sync()
         t0 = time.perf_counter()
+        kinds, t_prev = {"eager": [], "capture": [], "replay": []}, time.perf_counter()
         for it, batch in enumerate(stream):
+            cap0, rep0 = auto.captures, auto.replays
             loss_dict = model(batch)
             losses = sum(loss_dict.values())
             if guard is None:
@@ -445,9 +447,14 @@ def dropin_loop_multiscale_stream(iters=320, fixed_ms=None):
             guard.update(loss_dict, sync=True)
             opt.step()
             sched.step()
+            # (per-iteration wall time by kind: the loss read-back above is the iteration's synchronisation point)
+            t_now = time.perf_counter()
+            kinds["capture" if auto.captures > cap0 else "replay" if auto.replays > rep0 else "eager"].append(1e3 * (t_now - t_prev))
+            t_prev = t_now
             if it + 1 == iters - iters // 4:
                 _sync()
                 marks.append((time.perf_counter(), auto.replays))
+                t_prev = time.perf_counter()
         _sync()
         t1 = time.perf_counter()
     st = auto.stats()
@@ -458,8 +465,18 @@ def dropin_loop_multiscale_stream(iters=320, fixed_ms=None):
            "cache_entries": len(auto.cache), "stats": st, "capture": "ok" if auto.failed is None else f"not replaying: {auto.failed}",
            "guard_warnings": [str(r.message)[:160] for r in rec if "omni3d_amd" in str(r.message)],
            "mean_padded_pixels_per_image": sum(px) / len(px)}
+
+    def med(v):
+        v = sorted(v)
+        return v[len(v) // 2] if v else None
+    out["hit_rate"] = st.get("hit_rate")
+    out["eager_new_shape_ms"] = med(kinds["eager"])          # an iteration on a bucket that is not captured yet (eager launches)
+    out["capture_ms"] = med(kinds["capture"])
+    out["replay_ms"] = med(kinds["replay"])
+    out["iterations_by_kind"] = {k: len(v) for k, v in kinds.items()}
     if fixed_ms is not None:
         out["fixed_shape_step_scaled_by_pixels_ms"] = fixed_ms * out["mean_padded_pixels_per_image"] / float(IMAGE_SIZE * IMAGE_SIZE)
+        out["whole_region_vs_pixel_scaled_fixed_shape"] = out["ms_per_iteration_whole_region"] / out["fixed_shape_step_scaled_by_pixels_ms"]
     return out
 
 

@@ -51,7 +51,7 @@ class RCNN3D(nn.Module):
     def device(self):
         return self.pixel_mean.device
 
-    def preprocess_image(self, batched_inputs, slot_hw=None):
+    def preprocess_image(self, batched_inputs, slot_hw=None, hw_dev=None):
         """slot_hw: device (B, 2) int32 -- the images sit in equal-size slots (the size-bucketed replay of solver/autoreplay.py) and
         their real sizes are device data; the padding mask is then applied by the kernel, not by host-side slicing"""
         imgs = [x["image"] for x in batched_inputs]
@@ -69,6 +69,17 @@ class RCNN3D(nn.Module):
             x = bnpool.preprocess_list(imgs, self._mean, self._std, self.backbone.size_divisibility)
             if x is not None:
                 return ImageList(x, sizes)
+        if len(set(sizes)) != 1 and hw_dev is not None and self.device.type == "cuda":
+            # ragged batch, sizes already on the device (packed.image_hw): every image is copied into the corner of an UNINITIALISED
+            # device slot and the kernel masks the rest (round 6).  The host-side form below zero-fills and slice-copies a 14 MB CPU
+            # tensor with torch's intra-op thread pool on every iteration -- the op that woke 128 threads under a 16-CPU cgroup quota
+            # (omni3d_amd.respect_cpu_quota) -- and re-zeroes the padding with 2 launches per image afterwards.
+            H, W = max(s_[0] for s_ in sizes), max(s_[1] for s_ in sizes)
+            slots = torch.empty((len(imgs), 3, H, W), dtype=torch.uint8, device=self.device)
+            for n, im in enumerate(imgs):
+                slots[n, :, : im.shape[-2], : im.shape[-1]].copy_(im, non_blocking=True)
+            x = bnpool.preprocess(slots, self._mean, self._std, self.backbone.size_divisibility, image_hw=hw_dev)
+            return ImageList(x, sizes)
         if len(set(sizes)) == 1:
             batch = torch.stack(imgs).to(self.device, non_blocking=True)
         else:   # ragged batch: pad the uint8 images on the host first (zero padding is re-zeroed after normalisation)
@@ -121,10 +132,11 @@ class RCNN3D(nn.Module):
             with _wino.f22_only():
                 return self.inference(batched_inputs, packed=packed, _replay_tried=True)
         auto = self.__dict__.get("_omni_auto")         # (forward() has already asked it for a replay)
-        images = self.preprocess_image(batched_inputs, slot_hw=packed.image_hw if getattr(packed, "slotted", False) else None)
         packed_given = packed
         if packed is None:
             packed = self.prepack(batched_inputs)
+        images = self.preprocess_image(batched_inputs, slot_hw=packed.image_hw if getattr(packed, "slotted", False) else None,
+                                       hw_dev=getattr(packed, "image_hw", None))
         features = self.backbone(images.tensor)
         if getattr(self, "feature_cut", None) is not None:   # data-parallel two-phase backward (solver/graphed.py)
             features = self.feature_cut(features)

@@ -43,12 +43,17 @@ from ... import functional as HF
 from ..modeling.targets import MAX_GT_PER_IMAGE, pack_targets
 
 ENABLED = os.environ.get("OMNI_AUTO_REPLAY", "1") != "0"
-# captured steps kept.  Round 6: 64 by default (was 16) AND bounded by memory -- a capture is refused room before it starts if the
+# captured steps kept.  Round 6: 128 by default (was 16) AND bounded by memory -- a capture is refused room before it starts if the
 # device has less than RESERVE_GB + 1.5 x the largest captured step free; least recently used buckets go first.  MI355X has 288 GB:
 # the ~70 size buckets of the reference's loader (Base.yaml's 25 short edges x the datasets' aspect ratios on the 64 grid) fit, so
 # the DEFAULT keeps the eager pass's padding grid and a replayed iteration is the same computation as an eager one.
-CACHE = int(os.environ.get("OMNI_AUTO_REPLAY_CACHE", "64"))
+CACHE = int(os.environ.get("OMNI_AUTO_REPLAY_CACHE", "128"))
 RESERVE_GB = float(os.environ.get("OMNI_AUTO_REPLAY_RESERVE_GB", "24"))
+# One pair of graph-private memory pools for ALL captured steps (round 6).  Measured before: 26 buckets = 130 GB of graph-private memory
+# (5 GB each), the 288 GB device full after ~45 -- far fewer than the 82 buckets 320 batches of the reference-shaped stream touch.
+# Steps never overlap in time and a step reads only what it wrote itself, so their activations can share addresses (graphed.py).
+SHARE_POOLS = os.environ.get("OMNI_AUTO_REPLAY_SHARE_POOLS", "1") != "0"
+TRIM_GB = float(os.environ.get("OMNI_AUTO_REPLAY_TRIM_GB", "48"))        # reserved-but-unallocated memory above which a capture ends with empty_cache()
 # A/B: stage new batches through pinned host buffers with stream-ordered copies.  MEASURED and left OFF: on this ROCm 7.2 host the 3 MB
 # of image slots take ~20 ms to cross from pinned memory (37.1 against 11.9 ms per iteration, profiles/r04_dropin_phases.log); the pageable
 # copies block the host until the previous step has drained, which costs 0.3 ms per iteration with the losses read every 1000th
@@ -127,7 +132,10 @@ class _Boundary(Function):
 
 
 class AutoReplay:
-    def __init__(self, model, optimizer, warm=2, graphs=None):
+    def __init__(self, model, optimizer, warm=None, graphs=None):
+        # eager iterations a size bucket runs before it is captured.  Round 6: 1 (was 2) -- with a cache that holds every bucket of the
+        # reference's loader a capture is never wasted on a shape that will not come back, and every eager iteration saved is one replayed
+        warm = int(os.environ.get("OMNI_AUTO_REPLAY_WARM", "1")) if warm is None else warm
         self.model, self.opt, self.warm = model, optimizer, warm
         self.graphs = graphs                     # None: hipGraphs on a GPU, eager staged launches elsewhere (CPU tests)
         self.cache = OrderedDict()               # bucket -> captured step (stepper, static batch / targets, logged scalars)
@@ -150,6 +158,7 @@ class AutoReplay:
         self.extents = []                        # (batch size, max height, max width) of the recent iterations (see _note)
         self.evictions_at_level = 0
         self.holders = []                        # inner graphs of the eager iterations' loss dicts (see _Boundary)
+        self.pools = None                        # (M pool, W pool) shared by the captured steps of every bucket (SHARE_POOLS)
         self._eager_anchor = None
         self.busy = False                        # True while a capture drives the model itself
         optimizer._auto = self
@@ -218,6 +227,7 @@ class AutoReplay:
             # the buckets of the finer grid will not be asked for again: release their graphs, and let the new grid fill the cache like
             # a fresh start (misses while it fills are warm-up, not thrash: see the test above)
             self.cache.clear()
+            self.pools = None
             self.counts.clear()
             self.window.clear()
             self.evictions_at_level = self.evictions
@@ -316,11 +326,15 @@ class AutoReplay:
         for h in self.holders:
             h["inner"] = None
         self.holders = []
-        gc.collect()
+        # The graphs die by reference count when the holders let go; the collector is the safety net for a cycle through one of them.
+        # Only the young generations: the holders are at most four iterations old, and a FULL collection walks the whole heap of the
+        # training process (dataset dicts, loader state) -- measured 83 ms of a 210 ms capture (round 6, OMNI_AUTO_REPLAY_TIMING=1).
+        gc.collect() if os.environ.get("OMNI_AUTO_REPLAY_FULL_GC") == "1" else gc.collect(1)
 
     def _drop(self):
         """forget every captured step (a failure, or a loop the protocol does not cover)"""
         self.cache.clear()
+        self.pools = None
         self.counts.clear()
         self.model.feature_cut = None
         bu = getattr(getattr(self.model, "backbone", None), "bottom_up", None)
@@ -346,6 +360,8 @@ class AutoReplay:
             self.counts.pop(old_sig, None)
             self.evictions += 1
             del old
+            if not self.cache:
+                self.pools = None
             import gc
             gc.collect()
             torch.cuda.empty_cache()
@@ -365,7 +381,10 @@ class AutoReplay:
             if "instances" in b:
                 c["instances"] = b["instances"]
             sb.append(c)
+        import time as _time
+        _t = [_time.perf_counter()]
         self.release_eager_graphs()                      # no live eager graph (and its default-stream AccumulateGrad nodes) during capture
+        _t.append(_time.perf_counter())
         packed = model.prepack(batch)                    # (real image sizes: packed.image_hw)
         cap = B * int(os.environ.get("OMNI_AUTO_REPLAY_ROWS", MAX_GT_PER_IMAGE))
         for f in ROW_FIELDS:                              # fixed capacity: any later batch's rows fit
@@ -380,14 +399,32 @@ class AutoReplay:
         bufs = [(b, b.detach().clone()) for b in model.buffers()]
         self.busy = True
         try:
-            stepper = GraphedPipelined(model, self.opt, sb, packed, graphs=graphs)
+            # (one muted warm-up pass inside the capture instead of three: the bucket's eager iterations have already built every
+            # lazily-made constant of this shape; OMNI_AUTO_REPLAY_CAPTURE_WARMUP restores more)
+            stepper = GraphedPipelined(model, self.opt, sb, packed, graphs=graphs, warmup=int(os.environ.get("OMNI_AUTO_REPLAY_CAPTURE_WARMUP", "1")),
+                                       pools=self.pools if SHARE_POOLS else None)
         finally:
             self.busy = False
             with torch.no_grad():
                 for b, saved in bufs:
                     b.copy_(saved)
+        _t.append(_time.perf_counter())
+        if os.environ.get("OMNI_AUTO_REPLAY_TIMING") == "1":
+            print("capture %s: release+gc %.1f ms, stage+capture %.1f ms (%s)" % (sig, 1e3 * (_t[1] - _t[0]), 1e3 * (_t[2] - _t[1]),
+                  ", ".join("%s %.1f" % kv for kv in getattr(stepper, "phase_ms", {}).items())), flush=True)
         if stepper.stages is not None:
             stepper.uninstall()                          # replays need no cut points; eager iterations of other buckets run uncut
+            if SHARE_POOLS:
+                # every bucket's graphs allocate from ONE pair of private pools (graphed.py `pools`): this step's intermediates are
+                # released to them now, so the next bucket's capture reuses that memory instead of reserving its own ~5 GB
+                stepper.release_intermediates()
+                self.pools = stepper.pools
+                # segments of the shared pools that this capture left completely unused go back to the driver -- ONCE per captured step
+                # (torch's own capture context did it in front of each of the 14 stage captures; without it at all the pools'
+                # reserved memory grew to 222 GB over 47 buckets of different tensor sizes: profiles/r06_new_shape_*.txt)
+                # -- and only when the slack is worth a trip to the driver: hipFree of several GB takes 0.2-2 s (measured per capture)
+                if torch.cuda.memory_reserved() - torch.cuda.memory_allocated() > TRIM_GB * (1 << 30):
+                    torch.cuda.empty_cache()
         if self.anchor is None:
             self.anchor = getattr(model, "_omni_ddp_anchor", None)
             if self.anchor is None:

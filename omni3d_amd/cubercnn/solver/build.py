@@ -608,6 +608,8 @@ def pool_cut_active(model):
 
 
 def build_optimizer(cfg, model):
+    from ... import respect_cpu_quota
+    respect_cpu_quota()       # (the loop's host side must not wake more threads than the container may run: omni3d_amd/__init__.py)
     params = _param_groups(cfg, model)
     tag_fused_groups(model.module if hasattr(model, "module") else model)
     # gradients of everything outside the backbone are complete before the backbone starts back-propagating

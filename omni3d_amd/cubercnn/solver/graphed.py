@@ -39,6 +39,43 @@ def _leaf_grad(t):
     return left if t.grad is None else t.grad + left
 
 
+class lean_capture:
+    """`torch.cuda.graph(g, pool=...)` without what its __enter__ adds in front of EVERY capture: torch.cuda.synchronize(), a full
+    gc.collect() and torch.cuda.empty_cache().  A staged step is 14 captures; with one step captured per size bucket
+    (solver/autoreplay.py) the empty_cache handed the eager path's cached blocks back to the driver 14 times per new bucket and the
+    next eager iteration bought them again with hipMalloc (measured, round 6: -4 .. -15 GB of reserved memory per capture, single
+    iterations of 0.4-2.7 s, profiles/r06_new_shape_*.txt).  The caller synchronises and collects ONCE before its first capture.
+    OMNI_GRAPH_TORCH_CTX=1 restores torch's context manager."""
+    _stream = None
+
+    def __init__(self, graph, pool=None):
+        self.graph, self.pool = graph, pool
+        self.torch_ctx = torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local") if _TORCH_CTX else None
+
+    def __enter__(self):
+        if self.torch_ctx is not None:
+            return self.torch_ctx.__enter__()
+        if lean_capture._stream is None:
+            lean_capture._stream = torch.cuda.Stream()
+        self.stream = lean_capture._stream
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        kw = {"pool": self.pool} if self.pool is not None else {}
+        self.graph.capture_begin(capture_error_mode="thread_local", **kw)
+
+    def __exit__(self, *exc):
+        if self.torch_ctx is not None:
+            return self.torch_ctx.__exit__(*exc)
+        self.graph.capture_end()
+        self.ctx.__exit__(*exc)
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return False
+
+
+_TORCH_CTX = __import__("os").environ.get("OMNI_GRAPH_TORCH_CTX", "0") == "1"
+
+
 def make_side_stream(device=None):
     """The weight-gradient stream.  The critical path runs on the main stream and is ~92 % busy (rocprofv3 trace, queue 1: 11.4 of
     12.4 ms); whatever the side stream runs beside it competes for the same CUs, and a PERSISTENT side kernel (the fc1-class weight
@@ -328,11 +365,18 @@ class GraphedPipelined:
     inline), which is what the CPU / gloo tests exercise.
     `__call__` -> (loss dict, total, pending all-reduce handles)."""
 
-    def __init__(self, model, optimizer, batch, packed, warmup=3, graphs=True, group=None):
+    def __init__(self, model, optimizer, batch, packed, warmup=3, graphs=True, group=None, pools=None):
         from ... import functional as HF
         self.HF = HF
         self.model, self.optimizer, self.group = model, optimizer, group
         self.static_batch, self.static_packed = batch, packed
+        # pools: (M pool, W pool) of an EARLIER captured step of the same process whose memory this one may share (round 6,
+        # solver/autoreplay.py: one captured step per size bucket).  Two steps never run at the same time -- every step ends with the
+        # main stream waiting for the weight-gradient stream -- and a step reads nothing it has not written itself in the same replay
+        # except its static inputs and outputs (allocated outside / still referenced), so the buckets' activations can live in the
+        # same memory: ~5 GB per bucket before, the largest bucket's footprint in total now.  `release_intermediates()` is what makes
+        # a finished capture's memory available to the next one.
+        self.pools = pools
         self.cuts = StageCuts()
         self._install()
         bottom_up = getattr(getattr(model, "backbone", None), "bottom_up", None)
@@ -355,6 +399,8 @@ class GraphedPipelined:
         # (autoreplay.py), so a capture's warm-up steps on one rank would pair their all-reduces with another rank's real gradient
         # exchange -- a hang or silently mixed gradients.  The warm-up gradients are thrown away anyway; nothing in a capture
         # talks to another rank, and the replayed step's own exchange is the same (early, late) sequence as an eager step's.
+        import time as _time
+        _t0 = _time.perf_counter()
         muted = getattr(self.optimizer, "_exchange_muted", False)
         self.optimizer._exchange_muted = True
         try:
@@ -367,6 +413,7 @@ class GraphedPipelined:
             self.optimizer._exchange_muted = muted
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
+        _t1 = _time.perf_counter()
         HF.side_mode("collect")
         # forward branches (functional.set_branch_stream): the RPN's labelling + loss beside its proposal selection, inside M0.
         # MEASURED and left OFF (OMNI_PIPE_BRANCH=1 enables it): M0 ends 0.10 ms earlier on the device, but hipGraphLaunch of a graph
@@ -379,7 +426,8 @@ class GraphedPipelined:
         from ...kernels import detmode, wino
         detmode.prewarm(torch.cuda.current_device())
         try:
-            stages, pool_m, pool_w = [], None, None
+            stages = []
+            pool_m, pool_w = self.pools if self.pools is not None else (None, None)
             self._held = []                 # closures + their inputs: kept for the lifetime of the graphs (see class docstring)
             self.prologue = None
             while True:
@@ -388,7 +436,7 @@ class GraphedPipelined:
                     gm = self._capture_stage0_split(bottom_up)
                     pool_m = gm.pool()
                 else:
-                    with torch.cuda.graph(gm, pool=pool_m, capture_error_mode="thread_local"), detmode.domain("M"):
+                    with lean_capture(gm, pool_m), detmode.domain("M"):
                         if not stages:
                             self.losses, self.total = self._stage0()
                         else:
@@ -401,7 +449,7 @@ class GraphedPipelined:
                 gw = None
                 if fns:
                     gw = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gw, pool=pool_w, capture_error_mode="thread_local"), detmode.domain("W"), wino.batched_wgrads():
+                    with lean_capture(gw, pool_w), detmode.domain("W"), wino.batched_wgrads():
                         for fn in fns:          # (the Winograd-domain GEMMs of the stage leave together when the context closes)
                             fn()
                     pool_w = gw.pool()
@@ -411,10 +459,20 @@ class GraphedPipelined:
                 if len(self.cuts) == 0:
                     break
             self.stages = stages
+            self.pools = (pool_m, pool_w)
+            self.phase_ms = {"warmup": 1e3 * (_t1 - _t0), "capture": 1e3 * (_time.perf_counter() - _t1)}      # (diagnostic: autoreplay's OMNI_AUTO_REPLAY_TIMING)
         finally:
             HF.set_branch_stream(prev_branch)
             HF.side_take()
             HF.side_mode(prev_mode)
+
+    def release_intermediates(self):
+        """Drop the references that pinned this step's intermediate tensors (the weight-gradient closures and their inputs) while its
+        stages were being captured -- they had to outlive the capture of the LATER stages of the same step, whose graphs run beside the
+        weight-gradient graphs that read them.  The graphs keep using the addresses; the blocks return to the graphs' private pools,
+        where only a later capture INTO THE SAME POOLS (another size bucket's step, see `pools`) can be given them.  The loss tensors,
+        logged scalars and static inputs stay referenced by their owners."""
+        self._held = None
 
     # ---- round 4: the head of the forward pass ---------------------------------------------------------------------------------
     # The Winograd filter transforms of a pass (one launch, 260 MB moved, ~0.13 ms) sat at the very start of the critical path while

@@ -334,6 +334,12 @@ def time_training(priors, batches=(2, 4), size=512, warmup=3, timed=10, budget_s
     import os
     from omni3d_amd import synthetic
     cores = min(os.cpu_count() or 1, 32)   # more intra-op threads than this only adds contention on big hosts
+    try:    # (the container's CFS quota, not the host's core count, is what the threads can really use: 16 CPUs on the GPU boxes)
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(p))))
+    except (OSError, ValueError):
+        pass
     torch.set_num_threads(cores)
     t_leg = time.perf_counter()
     per_batch = {}
