@@ -115,6 +115,13 @@ int omni_conv2d_wgrad_det(const float* x, const float* dy, float* dw, int N, int
                           int stride, int pad, int ldx, int lddy, int accumulate, int tile, float* ws, long long ws_floats,
                           int* ctr, int n_ctr, long long* plan, void* stream);
 
+/* Round 6 (csrc/dgrad_s2.hip): data gradient of the 3x3 / stride-2 / pad-1 convolutions that open every DLA level and ResNet stage
+ * (cubercnn/modeling/backbone/dla.py:43-51, 186-215; autograd of nn.Conv2d).  dx (N, H, W, C) [pixel pitch lddx] (=, or += when
+ * accumulate != 0: a gradient fan-in target) from dy (N, (H-1)/2+1, (W-1)/2+1, K) [pitch lddy] and w (K, 3, 3, C); C, K multiples
+ * of 32.  One workgroup computes all four parity classes of a 16 x 16 dx tile from one staged dy tile: dy is read once, every dx
+ * element written once by its owner -- deterministic, no atomics, no zero-fill. */
+int omni_conv2d_s2_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int K, int lddy, int lddx,
+                         int accumulate, void* stream);
 /* Round 6: n <= 64 direct weight gradients (nn.Conv2d backward of the 1 x 1 roots / projections / laterals and the stride-2 3 x 3
  * layers, cubercnn/modeling/backbone/dla.py:43-51, 159-172, 205-214; detectron2 FPN laterals) in as few launches as their tile shapes
  * allow -- normally one per backward stage.  Dense tensors (ldx = C, lddy = K), square filters; arrays are HOST arrays of n entries.

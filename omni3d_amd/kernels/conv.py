@@ -167,6 +167,20 @@ def stem_conv_fwd_stats(x, w):
     return out.permute(0, 3, 1, 2), (stats[:cell.value] if cell.value > 0 else None)
 
 
+_S2_DGRAD = os.environ.get("OMNI_S2_DGRAD", "1") != "0"            # A/B knob: 0 = the generic kernel's four grid.z parity classes
+_S2_DGRAD_MIN_WGS = int(os.environ.get("OMNI_S2_DGRAD_MIN_WGS", "192"))
+
+
+def s2_dgrad_eligible(N, H, W, C, K, R, S, stride, pad):
+    """3x3 / stride 2 / pad 1 with channel counts in multiples of 32, and enough 8 x 8 dy tiles (x 64-channel groups) to fill the chip:
+    the small-map layers (DLA level 4 / 5 entries at 512 x 512 input: 64 and 16 tiles) stay on the split-K form of the generic kernel"""
+    if not _S2_DGRAD or (R, S, stride, pad) != (3, 3, 2, 1) or (C % 32) or (K % 32):
+        return False
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    wgs = N * ((OH + 7) // 8) * ((OW + 7) // 8) * (C // 64 if C % 64 == 0 else C // 32)
+    return wgs >= _S2_DGRAD_MIN_WGS
+
+
 def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, tile=0, splits=0, accum_into=None):
     """dy (N,K,OH,OW) CL, w (K,C,R,S) CL -> dx (N,C,H,W) CL.
     accum_into: gradient fan-in target (logical (N,C,H,W), NHWC memory with any pixel pitch -- functional._carry_pitch): the result
@@ -177,6 +191,16 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=0, tile=0, splits=0, accum_into=Non
     assert K == K2
     H, W = in_hw
     L = _lib.check_device(dyv, wv)
+    if tile == 0 and splits == 0 and s2_dgrad_eligible(N, H, W, C, K, R, S, stride, pad):
+        # round 6: all four parity classes of a dx tile from one staged dy tile (csrc/dgrad_s2.hip)
+        if accum_into is not None:
+            assert tuple(accum_into.shape) == (N, C, H, W) and accum_into.stride(1) == 1
+            L.call("omni_conv2d_s2_dgrad", _lib.ptr(dyv), _lib.ptr(wv), accum_into.data_ptr(), N, H, W, C, K, K, accum_into.stride(3), 1,
+                   _lib.stream_of(dy))
+            return accum_into
+        dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+        L.call("omni_conv2d_s2_dgrad", _lib.ptr(dyv), _lib.ptr(wv), _lib.ptr(dx), N, H, W, C, K, K, C, 0, _lib.stream_of(dy))
+        return dx.permute(0, 3, 1, 2)
     if accum_into is not None:
         assert tuple(accum_into.shape) == (N, C, H, W) and accum_into.stride(1) == 1
         _dgrad_launch(L, _lib.ptr(dyv), _lib.ptr(wv), accum_into.data_ptr(), N, H, W, C, K, R, S, stride, pad, K, accum_into.stride(3), 1,

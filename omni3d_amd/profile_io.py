@@ -102,7 +102,7 @@ def abi_signatures():
 
 
 def flop_class(name):
-    """how `executed_flops` prices an entry point: 'conv' | 'conv_multi' | 'conv_batch' | 'grouped' | 'stem' | 'gemm_batched' | 'gemm_batched_multi' | 'engine' |
+    """how `executed_flops` prices an entry point: 'conv' | 'conv_multi' | 'conv_batch' | 'conv_s2' | 'grouped' | 'stem' | 'gemm_batched' | 'gemm_batched_multi' | 'engine' |
     'head16' (MFMA launchers), 'valu' (matches the MFMA name pattern but has no MFMA in it), None (not an MFMA launcher).
     tests/test_profile_io.py asserts that every header entry matching conv|gemm|stem|head16 gets a class -- VERDICT r4 weak 8: the
     counter did not know the *_det / *_multi / *_s2 entries the default path had moved to and reported a third of the executed flops."""
@@ -127,6 +127,8 @@ def flop_class(name):
         return "conv_multi"
     if name == "omni_conv2d_wgrad_batch_det":
         return "conv_batch"
+    if name == "omni_conv2d_s2_dgrad":
+        return "conv_s2"
     if name.startswith("omni_conv2d"):
         return "conv"
     return None
@@ -156,6 +158,8 @@ def executed_flops(name, a):
         return 2.0 * v["N"] * OH * OW * v["K"] * v["R"] * v["S"] * v["C"] / (v["groups"] if cls == "grouped" else 1)
     if cls == "conv_multi":       # 1 x 1 convolution over the concatenation of nsrc maps
         return 2.0 * v["N"] * v["H"] * v["W"] * v["K"] * sum(_host_ints(v["cs"], v["nsrc"], ctypes.c_int))
+    if cls == "conv_s2":          # 3x3 / stride 2 / pad 1 data gradient
+        return 2.0 * v["N"] * ((v["H"] - 1) // 2 + 1) * ((v["W"] - 1) // 2 + 1) * v["K"] * 9 * v["C"]
     if cls == "conv_batch":       # n direct weight gradients in one call (host arrays of per-problem sizes)
         n = v["n"]
         cols = [_host_ints(v[k], n, ctypes.c_int) for k in ("N", "H", "W", "C", "K", "R", "stride", "pad")]

@@ -824,3 +824,52 @@ def test_wgrad_batch_emulated(emu_lib):
 def test_wgrad_batch_gpu(hip_lib):
     _run_wgrad_batch("cuda")
     _run_wgrad_batch("cuda", big=True)
+
+
+def _run_s2_dgrad(dev, cases):
+    """round 6 (csrc/dgrad_s2.hip): the fused four-class data gradient of the 3x3 / stride-2 / pad-1 convolutions against autograd of
+    F.conv2d (fp32 accumulation order differs: 1e-5 relative to the largest element), with and without a fan-in target, odd sizes,
+    ragged edges, both channel-tile forms; two runs are bit-identical"""
+    import torch.nn.functional as F
+    from omni3d_amd.kernels import conv
+    g = torch.Generator().manual_seed(33)
+    CL = torch.channels_last
+    for N, C, H, W, K in cases:
+        x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+        w = (torch.randn(K, C, 3, 3, generator=g) * 0.1)
+        y = F.conv2d(x, w, None, 2, 1)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        ref = x.grad
+        prev, conv._S2_DGRAD_MIN_WGS = conv._S2_DGRAD_MIN_WGS, 1
+        try:
+            dyd, wd = dy.contiguous(memory_format=CL).to(dev), w.contiguous(memory_format=CL).to(dev)
+            got = conv.conv2d_dgrad(dyd, wd, (H, W), 2, 1)
+            again = conv.conv2d_dgrad(dyd, wd, (H, W), 2, 1)
+            carry = torch.randn(N, C, H, W, generator=g).contiguous(memory_format=CL).to(dev)
+            base = carry.clone()
+            out = conv.conv2d_dgrad(dyd, wd, (H, W), 2, 1, accum_into=carry)
+        finally:
+            conv._S2_DGRAD_MIN_WGS = prev
+        tol = 2e-5 * max(float(ref.abs().max()), 1.0)
+        assert (got.cpu() - ref).abs().max() <= tol, (N, C, H, W, K, float((got.cpu() - ref).abs().max()))
+        assert torch.equal(got, again)
+        assert out.data_ptr() == carry.data_ptr() and (out.cpu() - base.cpu() - ref).abs().max() <= tol
+        # and the generic kernel (the A/B partner) agrees
+        prev, conv._S2_DGRAD = conv._S2_DGRAD, False
+        try:
+            old = conv.conv2d_dgrad(dyd, wd, (H, W), 2, 1)
+        finally:
+            conv._S2_DGRAD = prev
+        assert (old.cpu() - got.cpu()).abs().max() <= tol
+
+
+def test_s2_dgrad_emulated(emu_lib):
+    _run_s2_dgrad("cpu", [(1, 32, 16, 16, 32), (2, 64, 17, 15, 64), (1, 32, 30, 34, 64), (1, 128, 9, 16, 32)])
+
+
+@pytest.mark.gpu
+def test_s2_dgrad_gpu(hip_lib):
+    # DLA-34's level 2 / level 3 entries at the benchmark's size, ResNet-34's stage entries, and the small ragged cases
+    _run_s2_dgrad("cuda", [(4, 32, 256, 256, 64), (4, 64, 128, 128, 128), (4, 128, 64, 64, 256),
+                           (1, 32, 16, 16, 32), (2, 64, 17, 15, 64), (1, 32, 30, 34, 64), (1, 128, 9, 16, 32)])
