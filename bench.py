@@ -376,6 +376,12 @@ def compact_line(res, detail):
             line["dropin_loop"]["multiscale_stream"] = _pick(ms, ("iterations", "ms_per_iteration_whole_region", "ms_per_iteration_last_quarter",
                                                                    "fixed_shape_step_scaled_by_pixels_ms", "whole_region_vs_pixel_scaled_fixed_shape", "hit_rate", "eager_new_shape_ms",
                                                                    "capture_ms", "replay_ms"))
+    sp = res.get("bf16_split")
+    if isinstance(sp, dict) and sp.get("rows"):        # the opt-in experiment: one row, four numbers (the rest in the detail file)
+        r0 = sp["rows"][0]
+        line["bf16_split_experiment"] = {"shape": r0["shape"], "fp32_mfma_ms": r0["fp32_mfma"]["kernel_ms"], "split6_ms": r0["split6"]["kernel_ms"],
+                                         "split3_ms": r0["split3"]["kernel_ms"], "split6_err_over_fp32_err": r0["split6_err_over_fp32_err"],
+                                         "split3_err_over_fp32_err": r0["split3_err_over_fp32_err"], "on_measured_path": False}
     if "nonstandard" in res:
         line["nonstandard"] = _pick(res["nonstandard"], ("ims_per_gpu", "image_size", "device"))
     ex = res.get("exchange")
@@ -386,7 +392,7 @@ def compact_line(res, detail):
     line["detail"] = detail
     line = _r(line)
     dropped = []
-    for k in ("launch_mode", "nonstandard", "stage_ends", "exchange", "dropin_loop", "resnet34", "infer", "gpu_state", "windows"):
+    for k in ("launch_mode", "bf16_split_experiment", "nonstandard", "stage_ends", "exchange", "dropin_loop", "resnet34", "infer", "gpu_state", "windows"):
         if len(json.dumps(line)) <= LINE_CAP:
             break
         if k in line:

@@ -115,6 +115,11 @@ int omni_conv2d_wgrad_det(const float* x, const float* dy, float* dw, int N, int
                           int stride, int pad, int ldx, int lddy, int accumulate, int tile, float* ws, long long ws_floats,
                           int* ctr, int n_ctr, long long* plan, void* stream);
 
+/* OPT-IN EXPERIMENT, round 6 (csrc/gemm_split.hip; SURVEY.md section 7 "3 x bf16 split"): the batched NT GEMM of omni_gemm_batched
+ * -- out[b] (M x N) = A[b] (M x K) B[b] (N x K)^T, fp32 in / out, K % 32 == 0 -- on the bf16 matrix cores from an error-free split of
+ * the operands into 2 (terms = 3 products) or 3 (terms = 6) bf16 planes, fp32 accumulation.  Never selected by default: the measured
+ * path multiplies fp32 operands (v_mfma_f32_32x32x2_f32). */
+int omni_gemm_batched_split(const float* A, const float* B, float* out, int batch, int M, int N, int K, int terms, void* stream);
 /* Round 6 (csrc/dgrad_s2.hip): data gradient of the 3x3 / stride-2 / pad-1 convolutions that open every DLA level and ResNet stage
  * (cubercnn/modeling/backbone/dla.py:43-51, 186-215; autograd of nn.Conv2d).  dx (N, H, W, C) [pixel pitch lddx] (=, or += when
  * accumulate != 0: a gradient fan-in target) from dy (N, (H-1)/2+1, (W-1)/2+1, K) [pitch lddy] and w (K, 3, 3, C); C, K multiples

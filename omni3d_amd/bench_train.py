@@ -279,6 +279,10 @@ def run_train(args, world, rank):
     elif rank == 0:
         res["roofline"] = dominant_kernel_roofline()
         res["hbm_bound_kernels"] = hbm_bound_kernels(opt)
+        try:
+            res["bf16_split"] = bf16_split_experiment()
+        except Exception as e:  # noqa: BLE001 -- an experiment must never take the measured line down with it
+            res["bf16_split"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         if world == 1 and os.environ.get("OMNI_BENCH_SKIP_DROPIN") != "1":
             # the drop-in loop (north_star: "tools/train_net.py drops in unchanged"): same step, reached from inside model(data)
             try:
@@ -710,6 +714,36 @@ def dominant_kernel_roofline(iters=20):
             "kernel_ms": head["kernel_ms"], "flops_per_launch": head["gflop"] * 1e9, "operands": "fp32 (v_mfma_f32_32x32x2_f32)",
             "table": table, "layer_ms_winograd_vs_direct_3x3_256_at_128": [ms_wino, ms_direct],
             "families": families}
+
+
+def bf16_split_experiment(iters=20):
+    """VERDICT r5 item 8 / SURVEY.md section 7: the OPT-IN bf16-split form of the Winograd point GEMM (csrc/gemm_split.hip) next to the
+    product's fp32-MFMA kernel on the same inputs -- time, fp32-equivalent rate and error against float64 (four of the 36 points).
+    A separate object with its own `operands` strings and its own peak; the measured line never uses it."""
+    from omni3d_amd.kernels import wino
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rows = []
+    for name, B, M, K, C in (("p2 point GEMM 36x[4096x256]x[256x256]^T", 36, 4096, 256, 256), ("DLA level 3 36x[1024x128]x[128x128]^T", 36, 1024, 128, 128)):
+        V = torch.randn(B, M, C, device="cuda", generator=g)
+        U = torch.randn(B, K, C, device="cuda", generator=g) * 0.05
+        ref = torch.bmm(V[:4].double(), U[:4].double().transpose(1, 2))
+        scale = float(ref.abs().max())
+        fl = 2.0 * B * M * K * C
+        row = {"shape": name, "gflop": fl / 1e9}
+        for key, fn, operands, peak in (
+                ("fp32_mfma", lambda: wino.gemm_batched(V, U), "fp32 (v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TF),
+                ("split6", lambda: wino.gemm_batched_split(V, U, 6), "3 bf16 planes per fp32 operand, 6 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate", 2500.0 / 6),
+                ("split3", lambda: wino.gemm_batched_split(V, U, 3), "2 bf16 planes per fp32 operand, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate", 2500.0 / 3)):
+            out = fn()
+            err = float((out[:4].double() - ref).abs().max()) / scale
+            ms = _time_launch(fn, iters)
+            row[key] = {"kernel_ms": ms, "tflops_fp32_equivalent": fl / ms / 1e9, "peak_fp32_equivalent": peak, "operands": operands,
+                        "max_err_vs_fp64_over_max_ref": err}
+        row["split6_err_over_fp32_err"] = row["split6"]["max_err_vs_fp64_over_max_ref"] / max(row["fp32_mfma"]["max_err_vs_fp64_over_max_ref"], 1e-30)
+        row["split3_err_over_fp32_err"] = row["split3"]["max_err_vs_fp64_over_max_ref"] / max(row["fp32_mfma"]["max_err_vs_fp64_over_max_ref"], 1e-30)
+        rows.append(row)
+    return {"note": "opt-in experiment (OMNI_GEMM_SPLIT): never part of the measured step; accepted as admissible only where its error is <= the "
+                    "fp32-MFMA kernel's on the same inputs", "rows": rows}
 
 
 def hbm_bound_kernels(opt, iters=10):

@@ -187,12 +187,30 @@ def transform_weights_multi(items):
     return outs
 
 
+# OMNI_GEMM_SPLIT=3 | 6: the point GEMMs of the Winograd forward / data-gradient path on the bf16 matrix cores from an error-free
+# operand split (an experiment with its own bench object and its own error report; 0 = the product's fp32-MFMA path)
+GEMM_SPLIT = int(_os.environ.get("OMNI_GEMM_SPLIT", "0"))
+
+
+def gemm_batched_split(V, U, terms):
+    """V (B,M,C), U (B,K,C) -> (B,M,K) through the bf16 split with `terms` in (3, 6) products per fp32 product"""
+    B, M, C = V.shape
+    K = U.shape[1]
+    L = _lib.check_device(V, U)
+    out = torch.empty((B, M, K), dtype=torch.float32, device=V.device)
+    L.call("omni_gemm_batched_split", _lib.ptr(V), _lib.ptr(U), _lib.ptr(out), B, M, K, C, int(terms), _lib.stream_of(V))
+    return out
+
+
 def gemm_batched(V, U, algo=0, workgroups=0):
     """V (B,M,C), U (B,K,C) -> (B,M,K).  algo / workgroups: see omni_gemm_batched_fwd_algo (0 = the launcher's choice)."""
     B, M, C = V.shape
     K = U.shape[1]
     L = _lib.check_device(V, U)
     out = torch.empty((B, M, K), dtype=torch.float32, device=V.device)
+    if GEMM_SPLIT in (3, 6) and C % 32 == 0 and algo == 0:      # OPT-IN experiment (csrc/gemm_split.hip): never the default, never the measured line
+        L.call("omni_gemm_batched_split", _lib.ptr(V), _lib.ptr(U), _lib.ptr(out), B, M, K, C, GEMM_SPLIT, _lib.stream_of(V))
+        return out
     L.call("omni_gemm_batched_fwd_algo", _lib.ptr(V), _lib.ptr(U), _lib.ptr(out), B, M, C, K, algo, workgroups, _lib.stream_of(V))
     return out
 

@@ -173,6 +173,8 @@ def executed_flops(name, a):
         OH, OW = (v["H"] - 1) // stride + 1, (v["W"] - 1) // stride + 1
         return 2.0 * v["N"] * OH * OW * v["K"] * v["R"] * v["R"] * v["C"]
     if cls == "gemm_batched":
+        if "N" in v and "C" not in v:          # omni_gemm_batched_split (M x N x K naming)
+            return 2.0 * v["batch"] * v["M"] * v["N"] * v["K"]
         return 2.0 * v["batch"] * v["M"] * v["C"] * v["K"]
     if cls == "gemm_batched_multi":
         n = v["n"]

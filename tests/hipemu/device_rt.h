@@ -222,6 +222,32 @@ static inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return d;
 }
 
+// v_mfma_f32_32x32x16_bf16 (csrc/gemm_split.hip, the opt-in bf16-split experiment): lane l holds 8 bf16 of row / column l & 31 for
+// k = 8 * (l >> 5) + [0, 8); products are exact in fp32, accumulated in fp32 in k order
+static inline f32x16 mfma_bf16_32x32x16(const unsigned short* a, const unsigned short* b, f32x16 c) {
+    unsigned short* s = (unsigned short*)hipemu::wave_scratch();
+    int lane = hipemu::g.lane;
+    for (int e = 0; e < 8; ++e) { s[lane * 32 + e] = a[e]; s[lane * 32 + 8 + e] = b[e]; }
+    hipemu::wave_sync();
+    int j = lane & 31, hi = lane >> 5;
+    f32x16 d;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int g = 0; g < 2; ++g)
+            for (int e = 0; e < 8; ++e) {
+                unsigned ua = (unsigned)s[(i + 32 * g) * 32 + e] << 16, ub = (unsigned)s[(j + 32 * g) * 32 + 8 + e] << 16;
+                float fa, fb;
+                memcpy(&fa, &ua, 4);
+                memcpy(&fb, &ub, 4);
+                acc = fmaf(fa, fb, acc);
+            }
+        d[r] = acc;
+    }
+    hipemu::wave_sync();
+    return d;
+}
+
 // ---- LDS-DMA / scheduling primitives of csrc/gemm_engine.hip, emulated synchronously -----------------------------------
 struct omni_rsrc_t { const char* base; unsigned bytes; };
 static inline omni_rsrc_t omni_make_rsrc(const void* p, unsigned bytes) { return {(const char*)p, bytes}; }
