@@ -169,12 +169,19 @@ def stem_conv_fwd_stats(x, w):
 
 _S2_DGRAD = os.environ.get("OMNI_S2_DGRAD", "1") != "0"            # A/B knob: 0 = the generic kernel's four grid.z parity classes
 _S2_DGRAD_MIN_WGS = int(os.environ.get("OMNI_S2_DGRAD_MIN_WGS", "192"))
+# the 32-channel form (DLA level 2's entry, 32 -> 64 at 256 x 256): 35 us alone against the generic kernel's 56; INSIDE the step its own
+# row reads 128 us against 84 (profiles/r06_trace_table_final.txt: end of backward, beside the busiest stretch of the weight-gradient
+# stream) and the STEP is still the shorter one with it: 10.753 / 10.756 ms against 10.772 / 10.766 without (profiles/r06_ab_s2_dgrad_c32.log)
+# -- what it leaves to the other stream counts too.  OMNI_S2_DGRAD_C32=0 switches this form off.
+_S2_DGRAD_C32 = os.environ.get("OMNI_S2_DGRAD_C32", "1") != "0"
 
 
 def s2_dgrad_eligible(N, H, W, C, K, R, S, stride, pad):
     """3x3 / stride 2 / pad 1 with channel counts in multiples of 32, and enough 8 x 8 dy tiles (x 64-channel groups) to fill the chip:
     the small-map layers (DLA level 4 / 5 entries at 512 x 512 input: 64 and 16 tiles) stay on the split-K form of the generic kernel"""
     if not _S2_DGRAD or (R, S, stride, pad) != (3, 3, 2, 1) or (C % 32) or (K % 32):
+        return False
+    if C % 64 and not _S2_DGRAD_C32:
         return False
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     wgs = N * ((OH + 7) // 8) * ((OW + 7) // 8) * (C // 64 if C % 64 == 0 else C // 32)

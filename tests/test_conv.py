@@ -842,6 +842,7 @@ def _run_s2_dgrad(dev, cases):
         y.backward(dy)
         ref = x.grad
         prev, conv._S2_DGRAD_MIN_WGS = conv._S2_DGRAD_MIN_WGS, 1
+        prev32, conv._S2_DGRAD_C32 = conv._S2_DGRAD_C32, True
         try:
             dyd, wd = dy.contiguous(memory_format=CL).to(dev), w.contiguous(memory_format=CL).to(dev)
             got = conv.conv2d_dgrad(dyd, wd, (H, W), 2, 1)
@@ -850,7 +851,7 @@ def _run_s2_dgrad(dev, cases):
             base = carry.clone()
             out = conv.conv2d_dgrad(dyd, wd, (H, W), 2, 1, accum_into=carry)
         finally:
-            conv._S2_DGRAD_MIN_WGS = prev
+            conv._S2_DGRAD_MIN_WGS, conv._S2_DGRAD_C32 = prev, prev32
         tol = 2e-5 * max(float(ref.abs().max()), 1.0)
         assert (got.cpu() - ref).abs().max() <= tol, (N, C, H, W, K, float((got.cpu() - ref).abs().max()))
         assert torch.equal(got, again)

@@ -44,4 +44,5 @@ find $OUT/${TAG}_pmc_iou3d -name '*kernel_trace.csv' -delete; find $OUT/${TAG}_p
 fi   # (SKIP_PMC=1: the committed profiles/r06_pmc_*.csv of this round stay -- same kernels, see profiles/README.md)
 OMNI_PIPE_TIMING=1 OMNI_BENCH_SKIP_CPU=1 OMNI_BENCH_SKIP_ROOFLINE=1 timeout 300 python bench.py --workload train --steps 30 --warmup 5 2>&1 | grep -E "pipe timing" > $OUT/${TAG}_pipe_timing.log
 timeout 1500 python bench.py > $OUT/${TAG}_bench.log 2> $OUT/${TAG}_bench.err
+cp bench_detail.json $OUT/${TAG}_bench_detail.json 2>/dev/null
 tail -c 600 $OUT/${TAG}_bench.log

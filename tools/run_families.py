@@ -19,7 +19,8 @@ CONVS = [  # name, H, C, K, R, stride
     ("l3 3x3 128->128 @64", 64, 128, 128, 3, 1),
     ("l4 3x3 256->256 @32", 32, 256, 256, 3, 1),
     ("l5 3x3 512->512 @16", 16, 512, 512, 3, 1),
-    ("l3 3x3s2 64->128 @128", 128, 64, 128, 3, 2),
+    ("l3 3x3s2 64->128 @128", 128, 64, 128, 3, 2),          # round 6: data gradient on dgrad_s2_kernel<64> (all four parity classes per workgroup)
+    ("l2 3x3s2 32->64 @256", 256, 32, 64, 3, 2),            # round 6: dgrad_s2_kernel<32>
     ("l3 root 1x1 448->128 @64", 64, 448, 128, 1, 1),
     ("l4 root 1x1 896->256 @32", 32, 896, 256, 1, 1),
     ("fpn lat 1x1 64->256 @128", 128, 64, 256, 1, 1),
