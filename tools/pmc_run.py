@@ -44,7 +44,7 @@ def main():
     sep = argv.index("--")
     head, cmd = argv[:sep], argv[sep + 1:]
     outdir, summary = head[0], head[1]
-    filt = re.compile(head[head.index("--filter") + 1]) if "--filter" in head else re.compile(r"omni|conv_|gemm_|wino|bn_|stem_|iou_|head16")
+    filt = re.compile(head[head.index("--filter") + 1]) if "--filter" in head else re.compile(r"omni|conv_|gemm_|wino|bn_|stem_|iou_|head16|dgrad_|roi_align")
     names = available()
     os.makedirs(outdir, exist_ok=True)
     acc = defaultdict(lambda: defaultdict(list))
