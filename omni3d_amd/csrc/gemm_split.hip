@@ -22,6 +22,10 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+#ifndef OMNI_HIPEMU
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#endif
 
 __device__ __forceinline__ unsigned short bf16_rne(float x) {
     unsigned u = __float_as_uint(x);
@@ -35,6 +39,7 @@ struct SplitP {
     const float* B;
     float* out;
     int batch, M, N, K;
+    int dbg;        // tools/bench_gemm_split.py only: 1 = skip the MFMA phase, 2 = fetch only the first slab (what bounds the kernel?)
 };
 
 constexpr int SBM = 128, SBN = 128, SBK = 32, SROW = SBK + 8;        // bf16 elements per LDS row (80 bytes)
@@ -66,6 +71,7 @@ __global__ void __launch_bounds__(256) gemm_nt_split_kernel(SplitP p) {
         }
     };
     auto split_store = [&](unsigned short (*plane)[SBM * SROW], int row, const float4& v) {
+#ifdef OMNI_HIPEMU
         float x[4] = {v.x, v.y, v.z, v.w};
         us4 h, l, l2;
 #pragma unroll
@@ -79,6 +85,19 @@ __global__ void __launch_bounds__(256) gemm_nt_split_kernel(SplitP p) {
         *reinterpret_cast<us4*>(&plane[0][row * SROW + 4 * kq]) = h;
         *reinterpret_cast<us4*>(&plane[1][row * SROW + 4 * kq]) = l;
         if (PL == 3) *reinterpret_cast<us4*>(&plane[2][row * SROW + 4 * kq]) = l2;
+#else
+        // v_cvt_pk_bf16_f32 (round-to-nearest-even, two values per instruction); the residuals are exact fp32 differences
+        const f32x4v x = {v.x, v.y, v.z, v.w};
+        const bf16x4 h = __builtin_convertvector(x, bf16x4);
+        const f32x4v r1 = x - __builtin_convertvector(h, f32x4v);
+        const bf16x4 l = __builtin_convertvector(r1, bf16x4);
+        *reinterpret_cast<bf16x4*>(&plane[0][row * SROW + 4 * kq]) = h;
+        *reinterpret_cast<bf16x4*>(&plane[1][row * SROW + 4 * kq]) = l;
+        if (PL == 3) {
+            const f32x4v r2 = r1 - __builtin_convertvector(l, f32x4v);
+            *reinterpret_cast<bf16x4*>(&plane[2][row * SROW + 4 * kq]) = __builtin_convertvector(r2, bf16x4);
+        }
+#endif
     };
     auto store_slab = [&]() {
 #pragma unroll
@@ -100,39 +119,52 @@ __global__ void __launch_bounds__(256) gemm_nt_split_kernel(SplitP p) {
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
 
     const int l31 = lane & 31, kh = lane >> 5;
-    auto mma = [&](f32x16& c, const unsigned short* a, const unsigned short* b) {
-#ifdef OMNI_HIPEMU
-        c = mfma_bf16_32x32x16(a, b, c);
-#else
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(a), *reinterpret_cast<const bf16x8*>(b), c, 0, 0, 0);
-#endif
-    };
-
     const int nk = p.K / SBK;
     load_slab(0);
     for (int kt = 0; kt < nk; ++kt) {
         store_slab();
         __syncthreads();
-        if (kt + 1 < nk) load_slab((kt + 1) * SBK);
+        if (kt + 1 < nk && !(p.dbg & 2)) load_slab((kt + 1) * SBK);
+        if (!(p.dbg & 1))
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {                               // two k-steps of 16 per slab; this lane: k = 16 ks + 8 kh + [0, 8)
             const int ko = 16 * ks + 8 * kh;
+            // every fragment is read from LDS ONCE per k-step (2 row blocks x PL planes per operand), then feeds 2 x 2 x TERMS MFMAs
+            const unsigned short* fa[2][PL];
+            const unsigned short* fb[2][PL];
+#ifndef OMNI_HIPEMU
+            bf16x8 va[2][PL], vb[2][PL];
+#endif
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ar = (wm * 64 + i * 32 + l31) * SROW + ko;
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) {
+                    fa[i][pl] = &s_a[pl][(wm * 64 + i * 32 + l31) * SROW + ko];
+                    fb[i][pl] = &s_b[pl][(wn * 64 + i * 32 + l31) * SROW + ko];
+#ifndef OMNI_HIPEMU
+                    va[i][pl] = *reinterpret_cast<const bf16x8*>(fa[i][pl]);
+                    vb[i][pl] = *reinterpret_cast<const bf16x8*>(fb[i][pl]);
+#endif
+                }
+#ifdef OMNI_HIPEMU
+#define OMNI_MMA(c, i, pa, j, pb) c = mfma_bf16_32x32x16(fa[i][pa], fb[j][pb], c)
+#else
+#define OMNI_MMA(c, i, pa, j, pb) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[i][pa], vb[j][pb], c, 0, 0, 0)
+#endif
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int br = (wn * 64 + j * 32 + l31) * SROW + ko;
-                                        if (TERMS == 6) {
-                        mma(cor[i][j], &s_a[1][ar], &s_b[1][br]);      // lo lo
-                        mma(cor[i][j], &s_a[0][ar], &s_b[2][br]);      // hi lo2
-                        mma(cor[i][j], &s_a[2][ar], &s_b[0][br]);      // lo2 hi
+                    if (TERMS == 6) {
+                        OMNI_MMA(cor[i][j], i, 1, j, 1);               // lo lo
+                        OMNI_MMA(cor[i][j], i, 0, j, PL - 1);          // hi lo2
+                        OMNI_MMA(cor[i][j], i, PL - 1, j, 0);          // lo2 hi
                     }
-                    mma(cor[i][j], &s_a[0][ar], &s_b[1][br]);          // hi lo
-                    mma(cor[i][j], &s_a[1][ar], &s_b[0][br]);          // lo hi
-                    mma(acc[i][j], &s_a[0][ar], &s_b[0][br]);          // hi hi
+                    OMNI_MMA(cor[i][j], i, 0, j, 1);                   // hi lo
+                    OMNI_MMA(cor[i][j], i, 1, j, 0);                   // lo hi
+                    OMNI_MMA(acc[i][j], i, 0, j, 0);                   // hi hi
                 }
-            }
+#undef OMNI_MMA
         }
         __syncthreads();
     }
@@ -156,12 +188,14 @@ extern "C" {
 // out[b] (M x N) = A[b] (M x K) B[b] (N x K)^T for b < batch, dense fp32 operands (K % 32 == 0), through the bf16 split described at the
 // top of csrc/gemm_split.hip.  terms: 3 or 6.  EXPERIMENT: not on the product's default path (kernels/wino.py OMNI_GEMM_SPLIT).
 int omni_gemm_batched_split(const float* A, const float* B, float* out, int batch, int M, int N, int K, int terms, void* stream) {
+    const int dbg = terms / 10;
+    terms %= 10;
     if (A == nullptr || B == nullptr || out == nullptr || batch < 0 || M < 0 || N < 0 || K <= 0 || (K & 31) || (terms != 3 && terms != 6))
         return OMNI_ERR_ARG;
     const long items = (long)batch * ((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
     if (items == 0) return OMNI_OK;
     if (items > 0x7fffffff) return OMNI_ERR_ARG;
-    SplitP p{A, B, out, batch, M, N, K};
+    SplitP p{A, B, out, batch, M, N, K, dbg};
     if (terms == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_nt_split_kernel<3>), dim3((unsigned)items), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_nt_split_kernel<6>), dim3((unsigned)items), dim3(256), 0, (hipStream_t)stream, p);
     return omni_launch_status();
