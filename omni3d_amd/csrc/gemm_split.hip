@@ -39,20 +39,28 @@ struct SplitP {
     const float* B;
     float* out;
     int batch, M, N, K;
-    int dbg;        // tools/bench_gemm_split.py only: 1 = skip the MFMA phase, 2 = fetch only the first slab (what bounds the kernel?)
 };
 
 constexpr int SBM = 128, SBN = 128, SBK = 32, SROW = SBK + 8;        // bf16 elements per LDS row (80 bytes)
 
 template <int TERMS>
-__global__ void __launch_bounds__(256) gemm_nt_split_kernel(SplitP p) {
+__global__ void __launch_bounds__(256) OMNI_WAVES_PER_EU(2) gemm_nt_split_kernel(SplitP p) {
     constexpr int PL = TERMS == 3 ? 2 : 3;                           // bf16 planes per operand
     __shared__ __attribute__((aligned(16))) unsigned short s_a[PL][SBM * SROW];
     __shared__ __attribute__((aligned(16))) unsigned short s_b[PL][SBN * SROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_m = (p.M + SBM - 1) / SBM, tiles_n = (p.N + SBN - 1) / SBN, per = tiles_m * tiles_n;
-    const int item = (int)blockIdx.x;
+    // one contiguous chunk of the (problem, tile) sequence per XCD (workgroup ids go round-robin over the 8 XCDs): the column tiles
+    // that re-read an A panel share an L2 (PMC before: 340 MB fetched for 161 MB of operands)
+    int item = (int)blockIdx.x;
+    {
+        const int total = (int)gridDim.x;
+        if (total >= 8) {
+            const int q = total / 8, r = total % 8, xcd = item % 8, k = item / 8;
+            item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        }
+    }
     const int prob = item / per, tix = item - prob * per;
     const int m0 = (tix / tiles_n) * SBM, n0 = (tix % tiles_n) * SBN;
     const float* A = p.A + (long)prob * p.M * p.K;
@@ -124,46 +132,56 @@ __global__ void __launch_bounds__(256) gemm_nt_split_kernel(SplitP p) {
     for (int kt = 0; kt < nk; ++kt) {
         store_slab();
         __syncthreads();
-        if (kt + 1 < nk && !(p.dbg & 2)) load_slab((kt + 1) * SBK);
-        if (!(p.dbg & 1))
+        if (kt + 1 < nk) load_slab((kt + 1) * SBK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {                               // two k-steps of 16 per slab; this lane: k = 16 ks + 8 kh + [0, 8)
             const int ko = 16 * ks + 8 * kh;
-            // every fragment is read from LDS ONCE per k-step (2 row blocks x PL planes per operand), then feeds 2 x 2 x TERMS MFMAs
-            const unsigned short* fa[2][PL];
+            // B fragments of both column blocks are read once per k-step, A fragments once per row block: 9 fragments live at a time
+            // (with all 12 live beside the 128 accumulator registers the compiler shuttled the accumulators between VGPRs and AGPRs
+            // around every MFMA: 512 copies per slab, round 6 ISA / PMC: SQ_INSTS_VALU 3.6x the fp32 kernel's)
             const unsigned short* fb[2][PL];
 #ifndef OMNI_HIPEMU
-            bf16x8 va[2][PL], vb[2][PL];
+            bf16x8 vb[2][PL];
 #endif
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int pl = 0; pl < PL; ++pl) {
-                    fa[i][pl] = &s_a[pl][(wm * 64 + i * 32 + l31) * SROW + ko];
-                    fb[i][pl] = &s_b[pl][(wn * 64 + i * 32 + l31) * SROW + ko];
+                    fb[j][pl] = &s_b[pl][(wn * 64 + j * 32 + l31) * SROW + ko];
 #ifndef OMNI_HIPEMU
-                    va[i][pl] = *reinterpret_cast<const bf16x8*>(fa[i][pl]);
-                    vb[i][pl] = *reinterpret_cast<const bf16x8*>(fb[i][pl]);
+                    vb[j][pl] = *reinterpret_cast<const bf16x8*>(fb[j][pl]);
 #endif
                 }
 #ifdef OMNI_HIPEMU
-#define OMNI_MMA(c, i, pa, j, pb) c = mfma_bf16_32x32x16(fa[i][pa], fb[j][pb], c)
+#define OMNI_MMA(c, pa, j, pb) c = mfma_bf16_32x32x16(fa[pa], fb[j][pb], c)
 #else
-#define OMNI_MMA(c, i, pa, j, pb) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[i][pa], vb[j][pb], c, 0, 0, 0)
+#define OMNI_MMA(c, pa, j, pb) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[pa], vb[j][pb], c, 0, 0, 0)
 #endif
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                const unsigned short* fa[PL];
+#ifndef OMNI_HIPEMU
+                bf16x8 va[PL];
+#endif
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) {
+                    fa[pl] = &s_a[pl][(wm * 64 + i * 32 + l31) * SROW + ko];
+#ifndef OMNI_HIPEMU
+                    va[pl] = *reinterpret_cast<const bf16x8*>(fa[pl]);
+#endif
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (TERMS == 6) {
-                        OMNI_MMA(cor[i][j], i, 1, j, 1);               // lo lo
-                        OMNI_MMA(cor[i][j], i, 0, j, PL - 1);          // hi lo2
-                        OMNI_MMA(cor[i][j], i, PL - 1, j, 0);          // lo2 hi
+                        OMNI_MMA(cor[i][j], 1, j, 1);                  // lo lo
+                        OMNI_MMA(cor[i][j], 0, j, PL - 1);             // hi lo2
+                        OMNI_MMA(cor[i][j], PL - 1, j, 0);             // lo2 hi
                     }
-                    OMNI_MMA(cor[i][j], i, 0, j, 1);                   // hi lo
-                    OMNI_MMA(cor[i][j], i, 1, j, 0);                   // lo hi
-                    OMNI_MMA(acc[i][j], i, 0, j, 0);                   // hi hi
+                    OMNI_MMA(cor[i][j], 0, j, 1);                      // hi lo
+                    OMNI_MMA(cor[i][j], 1, j, 0);                      // lo hi
+                    OMNI_MMA(acc[i][j], 0, j, 0);                      // hi hi
                 }
+            }
 #undef OMNI_MMA
         }
         __syncthreads();
@@ -188,14 +206,12 @@ extern "C" {
 // out[b] (M x N) = A[b] (M x K) B[b] (N x K)^T for b < batch, dense fp32 operands (K % 32 == 0), through the bf16 split described at the
 // top of csrc/gemm_split.hip.  terms: 3 or 6.  EXPERIMENT: not on the product's default path (kernels/wino.py OMNI_GEMM_SPLIT).
 int omni_gemm_batched_split(const float* A, const float* B, float* out, int batch, int M, int N, int K, int terms, void* stream) {
-    const int dbg = terms / 10;
-    terms %= 10;
     if (A == nullptr || B == nullptr || out == nullptr || batch < 0 || M < 0 || N < 0 || K <= 0 || (K & 31) || (terms != 3 && terms != 6))
         return OMNI_ERR_ARG;
     const long items = (long)batch * ((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
     if (items == 0) return OMNI_OK;
     if (items > 0x7fffffff) return OMNI_ERR_ARG;
-    SplitP p{A, B, out, batch, M, N, K, dbg};
+    SplitP p{A, B, out, batch, M, N, K};
     if (terms == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_nt_split_kernel<3>), dim3((unsigned)items), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_nt_split_kernel<6>), dim3((unsigned)items), dim3(256), 0, (hipStream_t)stream, p);
     return omni_launch_status();
