@@ -52,7 +52,8 @@ def spawn_ranks(ngpus):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // ngpus)))
+    from omni3d_amd import cpu_quota
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (cpu_quota() or os.cpu_count() or 1) // ngpus)))      # (what the cgroup grants, shared by the ranks)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
