@@ -367,7 +367,7 @@ def compact_line(res, detail):
                                                 "valu_busy_frac_of_simd_cycles", "valu_lane_utilisation")),
                          "cpu_baseline": dict(_pick(c3, ("value", "unit", "cores", "kind")), sample=str(c3.get("sample", ""))[:120],
                                               openmp_value=(c3.get("openmp") or {}).get("value"), openmp_cores=(c3.get("openmp") or {}).get("cores"))}
-    for leg in ("infer", "resnet34"):
+    for leg in ("infer", "resnet34", "train_split6"):
         if isinstance(res.get(leg), dict):
             line[leg] = _pick(res[leg], ("value", "unit", "ms_per_step", "error"))
     if res.get("dropin_loop_ms_per_step") is not None:
@@ -393,7 +393,7 @@ def compact_line(res, detail):
     line["detail"] = detail
     line = _r(line)
     dropped = []
-    for k in ("launch_mode", "bf16_split_experiment", "nonstandard", "stage_ends", "exchange", "dropin_loop", "resnet34", "infer", "gpu_state", "windows"):
+    for k in ("launch_mode", "bf16_split_experiment", "nonstandard", "train_split6", "stage_ends", "exchange", "dropin_loop", "resnet34", "infer", "gpu_state", "windows"):
         if len(json.dumps(line)) <= LINE_CAP:
             break
         if k in line:
@@ -435,6 +435,14 @@ def main():
                 # the other two driver-visible numbers of the path -- inference on the same staged batch, and the
                 # training step of configs[3]'s model (cubercnn_ResNet34_FPN, N = 1, 10 steps) -- short legs in the same line
                 res["infer"] = extra_leg(["--workload", "infer", "--steps", "20", "--warmup", "3"], {})
+                # the opt-in 6-term bf16-split form of the large-map point GEMMs (csrc/gemm_split.hip): its OWN number, never `value`
+                res["train_split6"] = extra_leg(["--workload", "train", "--steps", "20", "--warmup", "3"],
+                                                {"OMNI_GEMM_SPLIT": "6", "OMNI_BENCH_SKIP_CPU": "1", "OMNI_BENCH_SKIP_ROOFLINE": "1",
+                                                 "OMNI_BENCH_SKIP_DROPIN": "1", "OMNI_BENCH_WINDOWS": "3", "OMNI_BENCH_CONDITION_STEPS": "50"})
+                if isinstance(res["train_split6"], dict) and res["train_split6"].get("value"):
+                    res["train_split6"]["operands"] = ("point GEMMs with >= 1024 Winograd tiles: fp32 operands split into 3 bf16 planes, 6 x "
+                                                       "v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation (0.3x the fp32-MFMA kernel's error "
+                                                       "vs float64); everything else as in the measured line")
                 res["resnet34"] = extra_leg(["--workload", "train", "--steps", "10", "--warmup", "3"],
                                             {"OMNI_BENCH_CONFIG": "cubercnn_ResNet34_FPN.yaml", "OMNI_BENCH_SKIP_CPU": "1",
                                              "OMNI_BENCH_SKIP_ROOFLINE": "1", "OMNI_BENCH_SKIP_DROPIN": "1"})

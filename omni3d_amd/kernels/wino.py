@@ -190,6 +190,10 @@ def transform_weights_multi(items):
 # OMNI_GEMM_SPLIT=3 | 6: the point GEMMs of the Winograd forward / data-gradient path on the bf16 matrix cores from an error-free
 # operand split (an experiment with its own bench object and its own error report; 0 = the product's fp32-MFMA path)
 GEMM_SPLIT = int(_os.environ.get("OMNI_GEMM_SPLIT", "0"))
+# only problems with at least this many rows (Winograd tiles) take the split form: on the 64 x 64 and 128 x 128 maps the 6-term kernel is
+# 1.17-1.5x faster than the fp32-MFMA one, on the small maps it is not (profiles/r06_bench_gemm_split.log); step: 10.62-10.64 ms with
+# 1024, 10.73-10.74 with 0, 10.80-10.83 without the split (profiles/r06_ab_gemm_split_minm.log)
+GEMM_SPLIT_MIN_M = int(_os.environ.get("OMNI_GEMM_SPLIT_MIN_M", "1024"))
 
 
 def gemm_batched_split(V, U, terms):
@@ -208,7 +212,7 @@ def gemm_batched(V, U, algo=0, workgroups=0):
     K = U.shape[1]
     L = _lib.check_device(V, U)
     out = torch.empty((B, M, K), dtype=torch.float32, device=V.device)
-    if GEMM_SPLIT in (3, 6) and C % 32 == 0 and algo == 0:      # OPT-IN experiment (csrc/gemm_split.hip): never the default, never the measured line
+    if GEMM_SPLIT in (3, 6) and C % 32 == 0 and algo == 0 and M >= GEMM_SPLIT_MIN_M:      # OPT-IN experiment (csrc/gemm_split.hip): never the default, never the measured line
         L.call("omni_gemm_batched_split", _lib.ptr(V), _lib.ptr(U), _lib.ptr(out), B, M, K, C, GEMM_SPLIT, _lib.stream_of(V))
         return out
     L.call("omni_gemm_batched_fwd_algo", _lib.ptr(V), _lib.ptr(U), _lib.ptr(out), B, M, C, K, algo, workgroups, _lib.stream_of(V))
