@@ -230,6 +230,8 @@ def _run_step_on_off(dev, name):
     return worst
 
 
+@pytest.mark.skipif(__import__("os").environ.get("OMNI_SLOW") != "1", reason="2.7 min under the host emulator (two emulated model steps); set OMNI_SLOW=1 "
+                    "(the GPU variant is the gate, the fan-in kernels keep their own emulated tests above)")
 def test_training_step_fanin_on_off_emulated(emu_lib):
     _run_step_on_off("cpu", "dla34_tiny")
 
