@@ -87,6 +87,12 @@ class DrawState:
     def tensors(self, device):
         if self.state is None or self.state.device != torch.device(device):
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())      # host generator: follows torch.manual_seed
+            try:        # ranks of a data-parallel job that seeded alike (bench.py, the reference's `seed_all_rng(seed + rank)` aside) must
+                import torch.distributed as dist          # not subsample their shards with the SAME variates
+                if dist.is_available() and dist.is_initialized():
+                    seed = (seed ^ ((dist.get_rank() + 1) * 0x9E3779B97F4A7C15)) & (2 ** 62 - 1)
+            except Exception:  # noqa: BLE001
+                pass
             self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
             self.ticket = torch.zeros(1, dtype=torch.int32, device=device)
         return self.state, self.ticket
