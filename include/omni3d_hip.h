@@ -400,6 +400,16 @@ int omni_roi_levels(const float* rois, int R, int min_level, int max_level, floa
 int omni_roi_align_fwd(const void* const* level_ptrs, const int* level_hw, const float* level_scale, int nlev,
                        const float* rois, const int* batch_idx, const int* levels, int R, int P, int C,
                        float* out, void* stream);
+/* Round 6: torchvision roi_align with its `aligned` switch exposed: aligned = 0 is detectron2's POOLER_TYPE "ROIAlign" (no half-pixel
+ * shift, ROI sides of at least one pixel), 1 = "ROIAlignV2" (cubercnn/modeling/roi_heads/roi_heads.py:166-171 passes
+ * MODEL.ROI_BOX_HEAD.POOLER_TYPE / MODEL.ROI_CUBE_HEAD.POOLER_TYPE through to detectron2's ROIPooler).  Any P; the backward adds into
+ * dlevel_ptrs with fp32 atomics (the caller zeroes them). */
+int omni_roi_align_fwd_mode(const void* const* level_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                            const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, int aligned, float* out,
+                            void* stream);
+int omni_roi_align_bwd_mode(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                            const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, int aligned,
+                            const float* dout, void* stream);
 /* Round 6: forward that also writes the first `first` ROIs of every block of `per_image` to out2 ((R / per_image) * first, P, P, C) --
  * the box head's and the cube head's pooled features in one pass (roi_heads.py:166-171, 267, 362), no slice copy. */
 int omni_roi_align_fwd2(const void* const* level_ptrs, const int* level_hw, const float* level_scale, int nlev,

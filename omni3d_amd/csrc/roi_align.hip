@@ -58,7 +58,7 @@ template <int DIR>
 __global__ void __launch_bounds__(256) roi_align_kernel(FeatLevels fl, const float* __restrict__ rois,
                                                         const int* __restrict__ batch_idx, const int* __restrict__ levels,
                                                         int R, int P, int C, float* __restrict__ out,
-                                                        float* __restrict__ out2 = nullptr, int per_image = 0, int first = 0) {
+                                                        float* __restrict__ out2 = nullptr, int per_image = 0, int first = 0, int aligned = 1) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long job = (long)blockIdx.x * 4 + wave;   // (roi, bin)
     if (job >= (long)R * P * P) return;
@@ -67,9 +67,13 @@ __global__ void __launch_bounds__(256) roi_align_kernel(FeatLevels fl, const flo
     const int l = levels[r];
     const int H = fl.H[l], W = fl.W[l];
     const float sc = fl.scale[l];
-    const float sw = rois[4 * r + 0] * sc - 0.5f, sh = rois[4 * r + 1] * sc - 0.5f;
-    const float ew = rois[4 * r + 2] * sc - 0.5f, eh = rois[4 * r + 3] * sc - 0.5f;
-    const float rw = ew - sw, rh = eh - sh;
+    // aligned (detectron2 "ROIAlignV2"): pixel-centre shift of half a pixel; otherwise ("ROIAlign", round 6) torchvision's legacy
+    // form: no shift and a ROI of at least one pixel per side
+    const float off = aligned ? 0.5f : 0.f;
+    const float sw = rois[4 * r + 0] * sc - off, sh = rois[4 * r + 1] * sc - off;
+    const float ew = rois[4 * r + 2] * sc - off, eh = rois[4 * r + 3] * sc - off;
+    float rw = ew - sw, rh = eh - sh;
+    if (!aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
     const float bin_h = rh / (float)P, bin_w = rw / (float)P;
     const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
     const float count = (float)max(gh * gw, 1);
@@ -534,6 +538,32 @@ int omni_roi_align_fwd2(const void* const* level_ptrs, const int* level_hw, cons
     const long jobs = (long)R * P * P;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_kernel<0>), dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, fl, rois, batch_idx, levels, R, P, C, out, out2, per_image, first);
+    return omni_launch_status();
+}
+
+// Round 6: the two general-resolution kernels with the `aligned` switch of torchvision's roi_align exposed -- aligned = 0 is
+// detectron2's POOLER_TYPE "ROIAlign" (cubercnn/modeling/roi_heads/roi_heads.py:166-171 passes the config key through).  The
+// backward is the atomic form (caller zeroes dlevel_ptrs): the owner-computes kernels serve the aligned form only.
+int omni_roi_align_fwd_mode(const void* const* level_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                            const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, int aligned, float* out,
+                            void* stream) {
+    if (nlev <= 0 || nlev > MAXL || (C & 3) || P <= 0) return OMNI_ERR_ARG;
+    if (R == 0) return OMNI_OK;
+    FeatLevels fl = make_feat(level_ptrs, level_hw, level_scale, nlev);
+    const long jobs = (long)R * P * P;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_kernel<0>), dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, fl, rois, batch_idx, levels, R, P, C, out, (float*)nullptr, 0, 0, aligned != 0);
+    return omni_launch_status();
+}
+int omni_roi_align_bwd_mode(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
+                            const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, int aligned,
+                            const float* dout, void* stream) {
+    if (nlev <= 0 || nlev > MAXL || (C & 3) || P <= 0 || dout == nullptr) return OMNI_ERR_ARG;
+    if (R == 0) return OMNI_OK;
+    FeatLevels fl = make_feat(dlevel_ptrs, level_hw, level_scale, nlev);
+    const long jobs = (long)R * P * P;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_kernel<1>), dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, fl, rois, batch_idx, levels, R, P, C, const_cast<float*>(dout), (float*)nullptr, 0, 0, aligned != 0);
     return omni_launch_status();
 }
 

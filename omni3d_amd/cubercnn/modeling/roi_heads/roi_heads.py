@@ -68,8 +68,12 @@ class ROIPooler(nn.Module):
     def __init__(self, output_size, scales, sampling_ratio, pooler_type, canonical_box_size=224, canonical_level=4):
         super().__init__()
         import math
-        if pooler_type != "ROIAlignV2" or sampling_ratio != 0:
-            raise NotImplementedError("MI355X hot path: ROIAlignV2 with adaptive sampling (POOLER_SAMPLING_RATIO 0)")
+        # POOLER_TYPE is passed through by the reference (roi_heads.py:166-171).  "ROIAlignV2" is every released configuration;
+        # "ROIAlign" (no half-pixel shift) runs on the general kernels since round 6; "ROIPool" / "ROIAlignRotated" are other operators.
+        if pooler_type not in ("ROIAlignV2", "ROIAlign") or sampling_ratio != 0:
+            raise NotImplementedError(f"MI355X hot path: POOLER_TYPE ROIAlignV2 / ROIAlign with adaptive sampling (POOLER_SAMPLING_RATIO 0); got "
+                                      f"{pooler_type!r} / {sampling_ratio}")
+        self.aligned = pooler_type == "ROIAlignV2"
         self.output_size = output_size if isinstance(output_size, int) else output_size[0]
         self.scales = tuple(scales)
         self.min_level = int(round(-math.log2(scales[0])))
@@ -78,10 +82,13 @@ class ROIPooler(nn.Module):
 
     def forward(self, feats, rois, batch_idx):
         levels = det.roi_levels(rois, self.min_level, self.max_level, float(self.canonical_box_size), self.canonical_level)
+        if not self.aligned:
+            return HF.roi_align_legacy(feats, self.scales, rois, batch_idx, levels, self.output_size)
         return HF.roi_align(feats, self.scales, rois, batch_idx, levels, self.output_size)
 
     def same_as(self, other):
-        return (self.output_size, self.scales, self.canonical_box_size, self.canonical_level) == \
+        """True when one shared pooling pass can serve both poolers (the aligned form only has the shared kernels)"""
+        return self.aligned and other.aligned and (self.output_size, self.scales, self.canonical_box_size, self.canonical_level) == \
             (other.output_size, other.scales, other.canonical_box_size, other.canonical_level)
 
     def forward_shared(self, feats, rois, batch_idx, per_image, first):

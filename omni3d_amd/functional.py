@@ -1196,6 +1196,34 @@ def roi_align(feats, scales, rois, batch_idx, levels, P):
     return _ROIAlign.apply(rois, batch_idx, levels, tuple(scales), P, *feats)
 
 
+class _ROIAlignLegacy(Function):
+    """POOLER_TYPE "ROIAlign" (torchvision roi_align with aligned=False: no half-pixel shift, ROI sides >= 1 pixel), round 6: the general
+    forward kernel and its atomic backward with the switch exposed (omni_roi_align_fwd_mode / _bwd_mode)."""
+
+    @staticmethod
+    def forward(ctx, rois, batch_idx, levels, scales, P, *feats):
+        ctx.slots = [_slot_enter(f, ctx.needs_input_grad[5 + i]) for i, f in enumerate(feats)]
+        feats = [_cl(f) for f in feats]
+        nhwc = [f.permute(0, 2, 3, 1) for f in feats]
+        out = det.roi_align_fwd_mode(nhwc, scales, rois, batch_idx, levels, P, False)
+        ctx.save_for_backward(rois, batch_idx, levels)
+        ctx.meta = (scales, P, [tuple(f.shape) for f in nhwc])
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        rois, batch_idx, levels = ctx.saved_tensors
+        scales, P, shapes = ctx.meta
+        dfe = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
+        det.roi_align_bwd_mode(dfe, scales, rois, batch_idx, levels, P, False, _cl(dout).permute(0, 2, 3, 1).contiguous())
+        return (None, None, None, None, None) + tuple(_slot_deliver(slot, lambda carry, d=d: _add_carry(d.permute(0, 3, 1, 2), carry))
+                                                      for slot, d in zip(ctx.slots, dfe))
+
+
+def roi_align_legacy(feats, scales, rois, batch_idx, levels, P):
+    return _ROIAlignLegacy.apply(rois, batch_idx, levels, tuple(scales), P, *feats)
+
+
 class _ROIAlignShared(Function):
     """Training: the cube head pools the SAME sampled boxes as the box head with an identical pooler (the reference builds
     two ROIPoolers with the same resolution / sampling ratio / type, roi_heads.py:166-171, and calls them on the same

@@ -261,6 +261,26 @@ def roi_align_fwd(feats_nhwc, scales, rois, batch_idx, levels, P):
     return out
 
 
+def roi_align_fwd_mode(feats_nhwc, scales, rois, batch_idx, levels, P, aligned):
+    """roi_align_fwd with torchvision's `aligned` switch (False = detectron2 POOLER_TYPE "ROIAlign")"""
+    L = _dev(rois, batch_idx, levels, *feats_nhwc)
+    R, C = rois.shape[0], feats_nhwc[0].shape[3]
+    out = _empty((R, P, P, C), torch.float32, rois)
+    keep, a = _feat_args(feats_nhwc, scales)
+    L.call("omni_roi_align_fwd_mode", *a, _lib.ptr(rois), _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, int(bool(aligned)), _lib.ptr(out),
+           _lib.stream_of(rois))
+    return out
+
+
+def roi_align_bwd_mode(dfeats_nhwc, scales, rois, batch_idx, levels, P, aligned, dout):
+    """atomic backward of roi_align_fwd_mode into ZEROED dfeats"""
+    L = _dev(rois, batch_idx, levels, dout, *dfeats_nhwc)
+    R, C = rois.shape[0], dfeats_nhwc[0].shape[3]
+    keep, a = _feat_args(dfeats_nhwc, scales)
+    L.call("omni_roi_align_bwd_mode", *a, _lib.ptr(rois), _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, int(bool(aligned)), _lib.ptr(dout),
+           _lib.stream_of(rois))
+
+
 def roi_align_fwd2(feats_nhwc, scales, rois, batch_idx, levels, P, per_image, first):
     """-> (out (R, P, P, C), out2 ((R // per_image) * first, P, P, C) = the first `first` ROIs of every block of `per_image`), one pass"""
     L = _dev(rois, batch_idx, levels, *feats_nhwc)

@@ -608,3 +608,51 @@ def test_box_head_num_fc_emulated(emu_lib, num_fc):
     for n, p in prod.named_parameters():
         g = p.grad.contiguous(memory_format=torch.contiguous_format).reshape(rg[n].grad.shape)
         assert (g - rg[n].grad).abs().max() < 1e-4 * max(1.0, float(rg[n].grad.abs().max())), n
+
+
+def _run_roi_align_legacy(dev):
+    """POOLER_TYPE "ROIAlign" (round 6): torchvision roi_align with aligned=False -- no half-pixel shift, ROI sides of at least one pixel --
+    forward and backward of the product's pooler against the restated torchvision op, level by level like detectron2's ROIPooler"""
+    from omni3d_amd.cubercnn.modeling.roi_heads.roi_heads import ROIPooler
+    from omni3d_amd.kernels import det
+    g = torch.Generator().manual_seed(19)
+    B, C, P = 2, 8, 7
+    hw = [(32, 32), (16, 16), (8, 8)]
+    scales = [1 / 4, 1 / 8, 1 / 16]
+    feats = [torch.randn(B, C, h, w, generator=g) for h, w in hw]
+    rois = torch.cat([_rand_boxes(g, 30, 128, 128, 6, 120), torch.tensor([[-20.0, -20, 30, 30], [100, 100, 160, 170], [5, 5, 5.5, 5.2], [40, 40, 40, 40]])])
+    R = rois.shape[0]
+    bidx = torch.randint(0, B, (R,), generator=g).int()
+    lv = U.assign_boxes_to_levels([Boxes(rois)], 2, 4, 56, 3)
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    ref = torch.zeros(R, C, P, P)
+    for level, scale in enumerate(scales):
+        inds = torch.where(lv == level)[0]
+        if inds.numel():
+            fmt = torch.cat([bidx[inds, None].float(), rois[inds]], dim=1)
+            ref = ref.index_put((inds,), U.roi_align(fr[level], fmt, P, scale, 0, False))
+    pool = ROIPooler(P, scales, 0, "ROIAlign", canonical_box_size=56, canonical_level=3)
+    assert not pool.aligned and not pool.same_as(pool)
+    fd = [f.clone().contiguous(memory_format=torch.channels_last).to(dev).requires_grad_(True) for f in feats]
+    got = pool(fd, rois.to(dev), bidx.to(dev))
+    assert (got.detach().cpu() - ref.detach()).abs().max() < 1e-5
+    # the aligned form differs visibly on the same boxes (the test would not notice a silently ignored flag otherwise)
+    al = ROIPooler(P, scales, 0, "ROIAlignV2", canonical_box_size=56, canonical_level=3)(fd, rois.to(dev), bidx.to(dev))
+    assert (al.detach().cpu() - ref.detach()).abs().max() > 1e-2
+    dout = torch.randn(R, C, P, P, generator=g)
+    ref.backward(dout)
+    got.backward(dout.to(dev))
+    for d, f in zip(fd, fr):
+        fg = f.grad if f.grad is not None else torch.zeros_like(f)
+        assert (d.grad.cpu() - fg).abs().max() < 5e-5
+    with pytest.raises(NotImplementedError):
+        ROIPooler(P, scales, 0, "ROIPool")
+
+
+def test_roi_align_legacy_pooler_emulated(emu_lib):
+    _run_roi_align_legacy("cpu")
+
+
+@pytest.mark.gpu
+def test_roi_align_legacy_pooler_gpu(hip_lib):
+    _run_roi_align_legacy("cuda")
