@@ -53,6 +53,11 @@ RESERVE_GB = float(os.environ.get("OMNI_AUTO_REPLAY_RESERVE_GB", "24"))
 # (5 GB each), the 288 GB device full after ~45 -- far fewer than the 82 buckets 320 batches of the reference-shaped stream touch.
 # Steps never overlap in time and a step reads only what it wrote itself, so their activations can share addresses (graphed.py).
 SHARE_POOLS = os.environ.get("OMNI_AUTO_REPLAY_SHARE_POOLS", "1") != "0"
+# The shared pools start as two ARENAS: one big block reserved in each (critical-path pool, weight-gradient pool) before the first capture,
+# so that every later capture carves its tensors out of memory the pools already own (freed neighbours coalesce inside a segment)
+# instead of buying ~6 GB of new segments per bucket from the driver and handing them back in 0.2-0.9 s trims (round 6:
+# 38.6 ms per iteration alone but 41-62 ms inside bench.py, where the allocator's state differed).  "0,0" switches the arenas off.
+ARENA_GB = tuple(float(v) for v in os.environ.get("OMNI_AUTO_REPLAY_ARENA_GB", "20,6").split(","))
 TRIM_GB = float(os.environ.get("OMNI_AUTO_REPLAY_TRIM_GB", "48"))        # reserved-but-unallocated memory above which a capture ends with empty_cache()
 # A/B: stage new batches through pinned host buffers with stream-ordered copies.  MEASURED and left OFF: on this ROCm 7.2 host the 3 MB
 # of image slots take ~20 ms to cross from pinned memory (37.1 against 11.9 ms per iteration, profiles/r04_dropin_phases.log); the pageable
@@ -335,6 +340,7 @@ class AutoReplay:
         """forget every captured step (a failure, or a loop the protocol does not cover)"""
         self.cache.clear()
         self.pools = None
+        self._arena_graphs = None
         self.counts.clear()
         self.model.feature_cut = None
         bu = getattr(getattr(self.model, "backbone", None), "bottom_up", None)
@@ -366,6 +372,25 @@ class AutoReplay:
             gc.collect()
             torch.cuda.empty_cache()
 
+    def _make_arenas(self, dev):
+        """two graph-private pools, each holding one big FREE block: a dummy capture allocates it inside the pool and lets it go again"""
+        from .graphed import lean_capture
+        pools, keep = [], []
+        torch.cuda.synchronize()
+        for gb in ARENA_GB[:2]:
+            pool = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            free = torch.cuda.mem_get_info()[0]
+            n = int(min(gb * (1 << 30), max(free - RESERVE_GB * (1 << 30), 0)))
+            with lean_capture(g, pool):
+                t = torch.empty(max(n, 1 << 20), dtype=torch.uint8, device=dev)
+                t[:256].zero_()                     # (a capture must hold a node)
+                del t
+            pools.append(pool)
+            keep.append(g)                          # the pool lives as long as a graph captured into it does
+        self.pools = tuple(pools)
+        self._arena_graphs = keep
+
     def _capture(self, batch, sig):
         from .graphed import GraphedPipelined
         model, dev = self.model, self.model.device
@@ -395,6 +420,8 @@ class AutoReplay:
         packed.slotted = True                            # RCNN3D.preprocess_image masks the slots with packed.image_hw on the device
         graphs = self.graphs if self.graphs is not None else (dev.type == "cuda")
         mem0 = torch.cuda.memory_reserved() if dev.type == "cuda" else 0
+        if graphs and SHARE_POOLS and self.pools is None and dev.type == "cuda" and max(ARENA_GB) > 0:
+            self._make_arenas(dev)
         # a capture is not a training step: its warm-up passes must not move the BatchNorm running statistics
         bufs = [(b, b.detach().clone()) for b in model.buffers()]
         self.busy = True
