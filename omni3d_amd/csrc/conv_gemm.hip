@@ -888,6 +888,9 @@ struct GemmTP {
     long ab, bb, ob;       // element strides between the gridDim.z problems
     float* ws;             // deterministic split reduction (split_reduce.h); ctr == nullptr: fp32 atomics
     unsigned* ctr;
+    int batch = 0;         // number of problems (read by the persistent form only: the others take it from the grid)
+    int nt_out = 0;        // 1: `nt` stores for out (outputs far larger than the 32 MB of L2 that the consumer streams from HBM anyway:
+                           // tools/probes/probe_gemm_nt.hip -- the p2 point GEMM 176 -> 170 us; smaller outputs stay L2-resident for the consumer)
 };
 
 template <int PF>
@@ -961,10 +964,136 @@ __global__ void __launch_bounds__(256) gemm_nt_pf_kernel(GemmTP p) {
     }
     const int l31 = lane & 31, h = lane >> 5;
     const int n = n0 + wn * 32 + l31;
+    if (p.nt_out) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < p.M && n < p.N) __builtin_nontemporal_store(acc[0][0][r], out + (long)m * p.N + n);
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < p.M && n < p.N) out[(long)m * p.N + n] = acc[0][0][r];
+    }
+}
+
+// Persistent form of gemm_nt_pf_kernel for launches of MANY tiles (the 128x128-map point GEMMs: 9216 tiles = 9 rounds of the
+// 1024 resident workgroups).  PMC on the one-tile-per-workgroup form showed 3.48 of 4 waves per SIMD resident on average and the MFMA
+// pipe idle 28 % of the time: every tile pays a workgroup launch and a prologue whose first slab comes from HBM with nothing to
+// overlap it.  Here gridDim.x workgroups (a multiple of 8) each walk their XCD's chunk of the (problem, tile) sequence with a
+// stride of gridDim.x / 8, and the slab stream runs THROUGH the tile boundaries: the load cursor (item, koff) is PF slabs ahead
+// of the MFMAs, so the first slabs of the next tile are in flight while the last ones of this tile multiply; a tile ends with its
+// 16 stores and a zeroed accumulator, nothing else.  Same tiles, same slab order, same MFMA chain per output element as
+// gemm_nt_pf_kernel: results are bit-identical.  One resource over ALL problems (offsets carry prob * stride; the launcher checks
+// batch * stride * 4 < 2 GiB), so no descriptor changes inside the loop.
+template <int PF>
+__global__ void __launch_bounds__(256) gemm_nt_pfp_kernel(GemmTP p) {
+    constexpr int BM = 64, BN = 64, BKX = 32, BKP = BKX + 4, KQ = BKX / 4, RPP = 256 / KQ, AI = BM / RPP, BI = BN / RPP;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * BKP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kq = tid % KQ, lrow = tid / KQ;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, per_problem = tiles_m * tiles_n;
+    const int total = per_problem * p.batch;
+    // this XCD's contiguous chunk of the item sequence (xcd_chunked's split), walked by its gridDim.x / 8 workgroups in rounds
+    const int x8 = (int)blockIdx.x & 7, stride = (int)gridDim.x >> 3;
+    const int q8 = total / 8, r8 = total % 8;
+    const int first = x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8;
+    const int last = first + q8 + (x8 < r8 ? 1 : 0);
+    int cp_item = first + ((int)blockIdx.x >> 3);
+    if (cp_item >= last) return;
+    const omni_rsrc_t ra_ = omni_make_rsrc(p.A, (unsigned)((long)p.batch * p.ab * 4));
+    const omni_rsrc_t rb_ = omni_make_rsrc(p.B, (unsigned)((long)p.batch * p.bb * 4));
+    const int k_end = p.K * 4;                      // bytes per row
+    int a_off[AI], b_off[BI];
+    int ld_item = cp_item, koff = 0;                // load cursor: the slab the NEXT load_slab() fetches
+    auto set_load_item = [&]() {
+        const bool ok = ld_item < last;
+        const int prob = ld_item / per_problem, tix = ld_item - prob * per_problem;
+        const int tile_m = tix / tiles_n, tile_n = tix - tile_m * tiles_n;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int m = tile_m * BM + lrow + RPP * i;
+            a_off[i] = (ok && m < p.M) ? (int)(((long)prob * p.ab + (long)m * p.K + kq * 4) * 4) : OMNI_OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const int n = tile_n * BN + lrow + RPP * j;
+            b_off[j] = (ok && n < p.N) ? (int)(((long)prob * p.bb + (long)n * p.K + kq * 4) * 4) : OMNI_OOB;
+        }
+    };
+    set_load_item();
+    float4 ra[PF][AI], rb[PF][BI];
+    auto load_slab = [&](const int st) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) ra[st][i] = bufld4(ra_, a_off[i] + koff);      // OMNI_OOB + koff stays out of range (koff < 2^30)
+#pragma unroll
+        for (int j = 0; j < BI; ++j) rb[st][j] = bufld4(rb_, b_off[j] + koff);
+        koff += BKX * 4;
+    };
+    // the reduction depth is a multiple of PF slabs, so a tile's last slab is always fetched at the same place of the unrolled
+    // body (u == PF - 2) and after the PF loads of the prologue: the only two places that look for the end of the row
+    auto next_tile_if_row_done = [&]() {
+        if (koff == k_end) {                        // wave-uniform: on to the first slab of this workgroup's next tile
+            koff = 0;
+            ld_item += stride;
+            set_load_item();
+        }
+    };
+    auto store_slab = [&](int buf, const int st) {
+        float* As = smem + buf * (BM + BN) * BKP;
+        float* Bs = As + BM * BKP;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<float4*>(As + (lrow + RPP * i) * BKP + kq * 4) = ra[st][i];
+#pragma unroll
+        for (int j = 0; j < BI; ++j) *reinterpret_cast<float4*>(Bs + (lrow + RPP * j) * BKP + kq * 4) = rb[st][j];
+    };
+    f32x16 acc[1][1];
+    zero_acc<1, 1>(acc);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) load_slab(s);
+    next_tile_if_row_done();
+    store_slab(0, 0);
+    load_slab(0);
+    omni_barrier_lds();
+    const int nk = p.K / BKX;                       // multiple of PF (launcher): stage and buffer parity carry over the tiles
+    const int l31 = lane & 31, h = lane >> 5;
+    for (; cp_item < last; cp_item += stride) {
+        for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int buf = u & 1;              // nk and PF even
+                store_slab(buf ^ 1, (u + 1) % PF);
+                load_slab((u + 1) % PF);
+                if (u == PF - 2) next_tile_if_row_done();
+                const float* As = smem + buf * (BM + BN) * BKP;
+                mma_slab<1, 1, true, true, 0, 0, BKX>(As, As + BM * BKP, wm * 32, wn * 32, lane, acc);
+                omni_barrier_lds();
+            }
+        }
+        const int prob = cp_item / per_problem, tix = cp_item - prob * per_problem;
+        const int tile_m = tix / tiles_n, tile_n = tix - tile_m * tiles_n;
+        float* out = p.out + (long)prob * p.ob;
+        const int n = tile_n * BN + wn * 32 + l31;
+        const int mb = tile_m * BM + wm * 32 + 4 * h;
+        if (tile_m * BM + BM <= p.M && tile_n * BN + BN <= p.N) {
+            if (p.nt_out) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(acc[0][0][r], out + (long)(mb + (r & 3) + 8 * (r >> 2)) * p.N + n);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[(long)(mb + (r & 3) + 8 * (r >> 2)) * p.N + n] = acc[0][0][r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < p.M && n < p.N) out[(long)m * p.N + n] = acc[0][0][r];
+            }
+        }
+        zero_acc<1, 1>(acc);
     }
 }
 
@@ -1612,16 +1741,18 @@ int omni_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int H, 
 // out[b] (M x K) = x[b] (M x C) * w[b] (K x C)^T
 // algo: 0 auto | 1 = persistent 128x128 workgroups walking the (problem, tile) list (`workgroups` of them, 0 = 512; needs
 // C % 32 == 0) | 2 = one 128x128 tile per workgroup | 3 = one 64x64 tile per workgroup | 4 = 64x64 tiles with 2-4 slabs of
-// buffer-load prefetch in flight (gemm_nt_pf_kernel; needs C % 64 == 0)
+// buffer-load prefetch in flight (gemm_nt_pf_kernel; needs C % 64 == 0) | 5 = algo 4's tiles walked by `workgroups` persistent
+// workgroups (0 = 1024, a multiple of 8) with the slab stream running through the tile boundaries (gemm_nt_pfp_kernel)
 int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int batch, int M, int C, int K, int algo, int workgroups,
                                void* stream) {
-    if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3) || algo < 0 || algo > 4 || workgroups < 0) return OMNI_ERR_ARG;
-    if (algo == 1 && ((C % 32) != 0 || (workgroups & 7))) return OMNI_ERR_ARG;
+    if (batch <= 0 || M < 0 || C <= 0 || K <= 0 || (C & 3) || algo < 0 || algo > 5 || workgroups < 0) return OMNI_ERR_ARG;
+    if ((algo == 1 || algo == 5) && ((C % 32) != 0 || (workgroups & 7))) return OMNI_ERR_ARG;
     if (M == 0) return OMNI_OK;
     ConvP p{x, w, nullptr, out, M, 1, 1, C, 1, 1, K, 1, 1, 1, 0, C, K, 0, 0, 0, 1, (long)M * C, (long)K * C, (long)M * K};
     const long t128 = (((long)M + 127) / 128) * ((K + 127) / 128);
     // measured per shape (tools/sweep_batched_gemm.py, hipGraph replay): the persistent kernel from 1024 128x128 tiles up, 64x64 tiles
     // below (36x[1024x256]x[256x256]^T: 60 us against 76 us with one 128x128 tile per workgroup)
+    const bool auto_choice = algo == 0;
     if (algo == 0) algo = (K > 64 && (C % 32) == 0 && t128 * batch >= 1024 && !(FWD64_DEEP_PREFETCH && (C % 64) == 0)) ? 1 : 3;
     if (algo == 1) {
         // >= 2 items per resident workgroup: persistent kernel with the prefetch carried across items
@@ -1630,6 +1761,28 @@ int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int b
         return omni_launch_status();
     }
     if (algo == 3 && FWD64_DEEP_PREFETCH && (C % 64) == 0 && (long)M * C * 4 < (1L << 31) && (long)K * C * 4 < (1L << 31)) algo = 4;
+    // many-tile launches: the persistent form from OMNI_GEMM_PERSIST_MIN_ITEMS 64x64 tiles up (A/B knob; 0 = never)
+    static const long persist_min = [] { const char* e = getenv("OMNI_GEMM_PERSIST_MIN_ITEMS"); return e ? atol(e) : 0L; }();
+    static const int persist_wgs = [] { const char* e = getenv("OMNI_GEMM_PERSIST_WGS"); return e ? atoi(e) : 0; }();
+    // outputs of at least this many MB leave through `nt` stores (A/B knob; 0 = never)
+    static const long nt_min_mb = [] { const char* e = getenv("OMNI_GEMM_NT_OUT_MIN_MB"); return e ? atol(e) : 0L; }();
+    const int nt_out = (nt_min_mb > 0 && (long)batch * M * K * 4 >= nt_min_mb * (1L << 20)) ? 1 : 0;
+    if (algo == 4 && auto_choice && persist_min > 0 && (((long)M + 63) / 64) * ((K + 63) / 64) * batch >= persist_min &&
+        (long)batch * M * C * 4 < (1L << 31) && (long)batch * K * C * 4 < (1L << 31) && (persist_wgs & 7) == 0) {
+        algo = 5;
+        workgroups = persist_wgs;
+    }
+    if (algo == 5) {
+        const long items = (((long)M + 63) / 64) * ((K + 63) / 64) * batch;
+        if ((C % 64) != 0 || (long)batch * M * C * 4 >= (1L << 31) || (long)batch * K * C * 4 >= (1L << 31) || items > 0x7fffffff)
+            return OMNI_ERR_ARG;
+        GemmTP g{x, w, out, M, K, C, (long)M * C, (long)K * C, (long)M * K, nullptr, nullptr, batch, nt_out};
+        long wgs = workgroups ? workgroups : 1024;
+        if (wgs > items) wgs = (items + 7) / 8 * 8;
+        if ((C % 128) == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_nt_pfp_kernel<4>), dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_nt_pfp_kernel<2>), dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, g);
+        return omni_launch_status();
+    }
     if (algo == 2)   // else 64x64 tiles: 4x the workgroups (measured on the 256ch @32x32 layers)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_fwd_kernel<128, 128, 2, 2, 32>), dim3((unsigned)t128, 1, (unsigned)batch), dim3(256), 0,
                            (hipStream_t)stream, p);
@@ -1639,7 +1792,7 @@ int omni_gemm_batched_fwd_algo(const float* x, const float* w, float* out, int b
                            (hipStream_t)stream, p);
     else {           // 64x64 tiles, PF slabs of buffer-load prefetch in flight (gemm_nt_pf_kernel)
         if ((C % 64) != 0 || (long)M * C * 4 >= (1L << 31) || (long)K * C * 4 >= (1L << 31)) return OMNI_ERR_ARG;
-        GemmTP g{x, w, out, M, K, C, (long)M * C, (long)K * C, (long)M * K, nullptr, nullptr};
+        GemmTP g{x, w, out, M, K, C, (long)M * C, (long)K * C, (long)M * K, nullptr, nullptr, batch, nt_out};
         const long wgs = (((long)M + 63) / 64) * ((K + 63) / 64) * batch;
         if (wgs > 0x7fffffff) return OMNI_ERR_ARG;
         const dim3 grid((unsigned)wgs);

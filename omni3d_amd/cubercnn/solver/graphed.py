@@ -365,6 +365,8 @@ class GraphedPipelined:
     inline), which is what the CPU / gloo tests exercise.
     `__call__` -> (loss dict, total, pending all-reduce handles)."""
 
+    _warm_stream = None
+
     def __init__(self, model, optimizer, batch, packed, warmup=3, graphs=True, group=None, pools=None):
         from ... import functional as HF
         self.HF = HF
@@ -392,7 +394,12 @@ class GraphedPipelined:
         self.side = make_side_stream()
         prev_mode = HF.side_mode()
         HF.side_mode("inline")
-        warm = torch.cuda.Stream()
+        # ONE warm-up stream per process: torch's caching allocator binds a block to the stream it was allocated on, so a fresh stream per
+        # captured step (one per size bucket under AutoReplay) left ~5 GB of cached blocks behind that no later stream could reuse -- the
+        # reserved memory grew by that much per capture until a 0.2-2.5 s empty_cache() handed it back (round 6)
+        if GraphedPipelined._warm_stream is None:
+            GraphedPipelined._warm_stream = torch.cuda.Stream()
+        warm = GraphedPipelined._warm_stream
         warm.wait_stream(torch.cuda.current_stream())
         # Warm-up off the capture: allocator pools, lazily built constants.  WITHOUT collectives: under the
         # reference's loader every rank decides for itself when its batch signature has repeated often enough to capture

@@ -254,8 +254,20 @@ def _run_prefetch_gemm(dev):
         ref = torch.einsum("bmc,bkc->bmk", V.cpu().double(), U.cpu().double())
         assert (out.cpu().double() - ref).abs().max() <= 1e-4 * ref.abs().max(), (B, M, K, C)
         assert torch.equal(out, wino.gemm_batched(V, U, algo=3)), (B, M, K, C)
+        # the persistent form (gemm_nt_pfp_kernel, slab stream running through the tile boundaries): 8 workgroups = one per XCD
+        # chunk walking several tiles each, 16 = two per chunk, 1024 = more workgroups than tiles (clamped); bit-identical
+        for wgs in (8, 16, 1024):
+            assert torch.equal(out, wino.gemm_batched(V, U, algo=5, workgroups=wgs)), (B, M, K, C, wgs)
+    g5 = torch.Generator().manual_seed(10)
+    V, U = torch.randn(5, 200, 128, generator=g5).to(dev), torch.randn(5, 100, 128, generator=g5).to(dev)   # 5 x 4 x 2 = 40 tiles: ragged chunks (40 % 8 == 0), K = PF slabs
+    assert torch.equal(wino.gemm_batched(V, U, algo=4), wino.gemm_batched(V, U, algo=5, workgroups=8))
+    V, U = torch.randn(3, 130, 256, generator=g5).to(dev), torch.randn(3, 64, 256, generator=g5).to(dev)    # 9 tiles over 8 chunks: one chunk holds two
+    assert torch.equal(wino.gemm_batched(V, U, algo=4), wino.gemm_batched(V, U, algo=5, workgroups=8))
+    assert torch.equal(wino.gemm_batched(V, U, algo=4), wino.gemm_batched(V, U, algo=5, workgroups=0))
     with pytest.raises(Exception):
         wino.gemm_batched(torch.randn(1, 64, 32).to(dev), torch.randn(1, 64, 32).to(dev), algo=4)     # C % 64 != 0: refused, not mangled
+    with pytest.raises(Exception):
+        wino.gemm_batched(V, U, algo=5, workgroups=12)                                                # not a multiple of 8
     # TN twin (Winograd-domain weight gradient): ragged row counts (a last slab of 6 rows, a split that gets fewer rows), ragged tiles
     for B, M, K, C in ((3, 70, 72, 64), (2, 300, 136, 68), (2, 1024, 64, 128), (1, 128, 64, 64)):
         V = torch.randn(B, M, C, generator=g).to(dev)

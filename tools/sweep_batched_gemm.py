@@ -32,13 +32,19 @@ for (P, M, C, K) in SHAPES:
     V, U = torch.randn(P, M, C, device="cuda"), torch.randn(P, K, C, device="cuda")
     gf = 2.0 * P * M * C * K / 1e9
     res = []
-    for algo, wg in ((0, 0), (1, 512), (2, 0), (3, 0), (4, 0)):
+    for algo, wg in ((0, 0), (1, 512), (3, 0), (4, 0), (5, 1024), (5, 768), (5, 512)):
         try:
             t = timeit(lambda: wino.gemm_batched(V, U, algo, wg))
             res.append(f"a{algo}/{wg}: {t:6.1f}us {gf / t * 1e3:5.1f}TF")
         except Exception as e:
             res.append(f"a{algo}/{wg}: err")
     print(f"{str((P, M, C, K)):24s} {gf:6.2f} GF | " + " | ".join(res), flush=True)
+    ref = wino.gemm_batched(V, U, 4, 0)
+    for wg in (1024, 768, 512, 8):
+        if not torch.equal(wino.gemm_batched(V, U, 5, wg), ref):
+            print("   !! algo 5 /", wg, "differs from algo 4", flush=True)
+    if os.environ.get("SWEEP_WGRAD", "0") != "1":
+        continue
     dM = torch.randn(P, M, K, device="cuda")
     res = []
     for algo in (1, 2):
