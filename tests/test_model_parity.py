@@ -186,6 +186,70 @@ def test_training_step_matches_reference_gpu(hip_lib, name):
     _run("cuda", name)
 
 
+def _run_uninjected(dev, name, report=None):
+    """The same step WITHOUT handing the second stage the reference's proposal list: first and second stage run
+    end to end on the product's own proposals; only the sampling variates stay injected (the reference draws them from torch's
+    generator).  A near-tie flip in the first stage re-deals the variates of every later proposal index, so the sampled ROI set
+    may differ in some (equally valid) background boxes -- this test MEASURES how far the ten losses move because of that and
+    bounds it: the anchor labels stay exact, the sampled sets overlap in >= 95 % of the boxes, every loss within 5e-4 (relative for
+    values above 1) of the reference's.  Measured on MI355X (profiles/r06_parity_uninjected_*.txt): 2 x 128 x 128 -- no flip, all
+    ten losses <= 2.2e-7; 4 x 512 x 512 (BASELINE configs[1]) -- 4 of 4000 proposals on one side only, 2012 of 2048 sampled ROIs
+    shared, worst loss BoxHead/loss_cls 6.7e-5, the other nine <= 9e-8: north_star's 1e-4 holds end to end without the injection."""
+    from oracle import make_golden as MG
+    from omni3d_amd import synthetic
+    from omni3d_amd.d2.events import EventStorage
+    gold = torch.load(_gold(name), weights_only=False)
+    spec = gold["spec"]
+    priors = synthetic.make_priors(50, bins=spec.get("prior_bins", 0))
+    model = MG.build_product_model(MG.product_cfg(spec["overrides"], spec.get("config", "cubercnn_DLA34_FPN.yaml")), priors, spec["seed"], device=dev)
+    batch = synthetic.make_batch(spec["images"], spec["height"], spec["width"], num_gt=spec["num_gt"], seed=spec["seed"], priors=priors)
+    E = MG.variates(spec, gold["rpn_labels"].shape[1])
+    model.proposal_generator.injected = {"E": E["rpn"]}            # no "proposals": the second stage sees the product's own list
+    model.roi_heads.injected = {"E": E["roi"]}
+    model.train()
+    with EventStorage(0):
+        losses = model(batch)
+        sum(losses.values()).backward()
+    assert torch.equal(model.proposal_generator.last_labels.cpu(), gold["rpn_labels"])
+    own, cnt = model.proposal_generator.last["boxes"].cpu(), model.proposal_generator.last["count"].tolist()
+    lines, flips, rank_same = [], 0, 0
+    for n, want in enumerate(gold["proposals"]):
+        got = own[n, :cnt[n]]
+        d = (got[:, None, :] - want[None, :, :]).abs().amax(dim=2)
+        flips += int((d.min(dim=0).values > 1e-2).sum()) + int((d.min(dim=1).values > 1e-2).sum())
+        m = min(len(got), len(want))
+        rank_same += int(((got[:m] - want[:m]).abs().amax(dim=1) <= 1e-2).sum())
+    total = sum(len(w) for w in gold["proposals"])
+    lines.append("proposals: %d in the reference's lists, %d present on one side only, %d at the same rank" % (total, flips, rank_same))
+    shared = n_ref = 0
+    for got, cls, want in zip(model.roi_heads.last_sampled_boxes.cpu(), model.roi_heads.last_sampled_classes.cpu(), gold["roi_boxes"]):
+        got = got[cls >= 0]
+        d = (got[:, None, :] - want[None, :, :]).abs().amax(dim=2)
+        shared += int((d.min(dim=0).values <= 1e-3).sum())
+        n_ref += len(want)
+    lines.append("sampled ROIs: %d of the reference's %d also sampled by the product" % (shared, n_ref))
+    worst = 0.0
+    for k, v in gold["losses"].items():
+        got = float(losses[k].detach())
+        rel = abs(got - v) / max(1.0, abs(v))
+        worst = max(worst, rel)
+        lines.append("loss %-24s reference %.7g  product %.7g  |diff| %.2e" % (k, v, got, rel))
+    out = os.path.join(ROOT, "gpurun_out")
+    if report and os.path.isdir(out):
+        with open(os.path.join(out, report), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    assert shared >= 0.95 * n_ref, lines[1]
+    assert worst <= 5e-4, lines
+    return flips, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dla34_small", "dla34_full"])
+def test_training_step_uninjected_gpu(hip_lib, name):
+    _run_uninjected("cuda", name, report="uninjected_%s.txt" % name)
+
+
 # ---- fp64-bounded three-way comparison --------------------------------------------------------------------------------
 # north_star bar: fp32 outputs within 1e-4.  Gradients of a random-init 60-layer BatchNorm network are ill-conditioned, and
 # instead of asserting that, these tests MEASURE it: the same CPU oracle is evaluated a second time in float64 (same weights,
