@@ -410,6 +410,14 @@ int omni_roi_align_fwd_mode(const void* const* level_ptrs, const int* level_hw, 
 int omni_roi_align_bwd_mode(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev,
                             const float* rois, const int* batch_idx, const int* levels, int R, int P, int C, int aligned,
                             const float* dout, void* stream);
+/* Round 6: POOLER_TYPE "ROIPool" = torchvision.ops.roi_pool as detectron2's ROIPooler applies it level by level (the reference passes
+ * MODEL.ROI_BOX_HEAD.POOLER_TYPE / MODEL.ROI_CUBE_HEAD.POOLER_TYPE through: cubercnn/modeling/roi_heads/roi_heads.py:166-171).
+ * out and argmax (R, P, P, C); argmax = h * W + w of the first maximum inside the ROI's image and level, -1 for an empty bin (out 0).
+ * The backward adds dout at the argmax pixels with fp32 atomics (the caller zeroes dlevel_ptrs). */
+int omni_roi_pool_fwd(const void* const* level_ptrs, const int* level_hw, const float* level_scale, int nlev, const float* rois,
+                      const int* batch_idx, const int* levels, int R, int P, int C, float* out, int* argmax, void* stream);
+int omni_roi_pool_bwd(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev, const int* batch_idx,
+                      const int* levels, int R, int P, int C, const float* dout, const int* argmax, void* stream);
 /* Round 6: forward that also writes the first `first` ROIs of every block of `per_image` to out2 ((R / per_image) * first, P, P, C) --
  * the box head's and the cube head's pooled features in one pass (roi_heads.py:166-171, 267, 362), no slice copy. */
 int omni_roi_align_fwd2(const void* const* level_ptrs, const int* level_hw, const float* level_scale, int nlev,

@@ -497,6 +497,66 @@ FeatLevels make_feat(const void* const* ptrs, const int* hw, const float* scales
     return fl;
 }
 
+// ---- POOLER_TYPE "ROIPool" (round 6) ------------------------------------------------------------------------------------------------
+// torchvision.ops.roi_pool, the operator detectron2's ROIPooler builds for POOLER_TYPE "ROIPool" (cubercnn/modeling/roi_heads/
+// roi_heads.py:166-171 passes MODEL.ROI_BOX_HEAD.POOLER_TYPE / MODEL.ROI_CUBE_HEAD.POOLER_TYPE through): ROI corners rounded to whole
+// feature pixels (round half away from zero), a ROI of at least 1 x 1, bin (ph, pw) = rows [floor(ph * bh), ceil((ph + 1) * bh)) and
+// the same for columns (bh = roi_height / P in fp32), shifted by the ROI start and clipped to the map; the maximum over the bin
+// (strictly-greater scan in row-major order, so the FIRST maximum wins), an empty bin gives 0 with argmax -1.  The backward hands a
+// bin's gradient to its argmax pixel (fp32 atomics into zeroed maps: overlapping ROIs share pixels).
+// One wave per (roi, bin); lane l owns channels 4l .. 4l+3 (+256 per round): a wave instruction reads one pixel's 1 KB run.
+template <int DIR>
+__global__ void __launch_bounds__(256) roi_pool_kernel(FeatLevels fl, const float* __restrict__ rois, const int* __restrict__ batch_idx,
+                                                       const int* __restrict__ levels, int R, int P, int C, float* __restrict__ out,
+                                                       int* __restrict__ argmax) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long job = (long)blockIdx.x * 4 + wave;   // (roi, bin)
+    if (job >= (long)R * P * P) return;
+    const int r = (int)(job / (P * P)), bin = (int)(job % (P * P));
+    const int ph = bin / P, pw = bin % P;
+    const int l = levels[r];
+    const int H = fl.H[l], W = fl.W[l];
+    float* feat = fl.f[l] + (long)batch_idx[r] * H * W * C;
+    const int C4 = C >> 2;
+    if (DIR == 1) {
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            const float4 g = *reinterpret_cast<const float4*>(out + job * C + 4 * c4);
+            const int4 a = *reinterpret_cast<const int4*>(argmax + job * C + 4 * c4);
+            if (a.x >= 0) atomicAdd(feat + (long)a.x * C + 4 * c4 + 0, g.x);
+            if (a.y >= 0) atomicAdd(feat + (long)a.y * C + 4 * c4 + 1, g.y);
+            if (a.z >= 0) atomicAdd(feat + (long)a.z * C + 4 * c4 + 2, g.z);
+            if (a.w >= 0) atomicAdd(feat + (long)a.w * C + 4 * c4 + 3, g.w);
+        }
+        return;
+    }
+    const float sc = fl.scale[l];
+    const int rsw = (int)roundf(rois[4 * r + 0] * sc), rsh = (int)roundf(rois[4 * r + 1] * sc);
+    const int rew = (int)roundf(rois[4 * r + 2] * sc), reh = (int)roundf(rois[4 * r + 3] * sc);
+    const int rw = max(rew - rsw + 1, 1), rh = max(reh - rsh + 1, 1);     // malformed ROIs are 1 x 1
+    const float bh = (float)rh / (float)P, bw = (float)rw / (float)P;
+    int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
+    int ws = (int)floorf((float)pw * bw), we = (int)ceilf((float)(pw + 1) * bw);
+    hs = min(max(hs + rsh, 0), H); he = min(max(he + rsh, 0), H);
+    ws = min(max(ws + rsw, 0), W); we = min(max(we + rsw, 0), W);
+    const bool empty = he <= hs || we <= ws;
+    for (int c4 = lane; c4 < C4; c4 += 64) {
+        const float init = empty ? 0.f : -3.402823466e+38f;
+        float4 m = make_float4(init, init, init, init);
+        int4 a = make_int4(-1, -1, -1, -1);
+        for (int h = hs; h < he; ++h)
+            for (int w = ws; w < we; ++w) {
+                const int idx = h * W + w;
+                const float4 v = *reinterpret_cast<const float4*>(feat + (long)idx * C + 4 * c4);
+                if (v.x > m.x) { m.x = v.x; a.x = idx; }
+                if (v.y > m.y) { m.y = v.y; a.y = idx; }
+                if (v.z > m.z) { m.z = v.z; a.z = idx; }
+                if (v.w > m.w) { m.w = v.w; a.w = idx; }
+            }
+        *reinterpret_cast<float4*>(out + job * C + 4 * c4) = m;
+        *reinterpret_cast<int4*>(argmax + job * C + 4 * c4) = a;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -564,6 +624,29 @@ int omni_roi_align_bwd_mode(const void* const* dlevel_ptrs, const int* level_hw,
     const long jobs = (long)R * P * P;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_align_kernel<1>), dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, fl, rois, batch_idx, levels, R, P, C, const_cast<float*>(dout), (float*)nullptr, 0, 0, aligned != 0);
+    return omni_launch_status();
+}
+
+// out (R, P, P, C) and argmax (R, P, P, C) int32 = h * W + w of the winning pixel in the ROI's image and level, -1 for an empty bin
+int omni_roi_pool_fwd(const void* const* level_ptrs, const int* level_hw, const float* level_scale, int nlev, const float* rois,
+                      const int* batch_idx, const int* levels, int R, int P, int C, float* out, int* argmax, void* stream) {
+    if (nlev <= 0 || nlev > MAXL || (C & 3) || P <= 0 || out == nullptr || argmax == nullptr) return OMNI_ERR_ARG;
+    if (R == 0) return OMNI_OK;
+    FeatLevels fl = make_feat(level_ptrs, level_hw, level_scale, nlev);
+    const long jobs = (long)R * P * P;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_kernel<0>), dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, fl, rois,
+                       batch_idx, levels, R, P, C, out, argmax);
+    return omni_launch_status();
+}
+// dlevel_ptrs[l] += the gradient of every bin at its argmax pixel (fp32 atomics; the caller zeroes the maps)
+int omni_roi_pool_bwd(const void* const* dlevel_ptrs, const int* level_hw, const float* level_scale, int nlev, const int* batch_idx,
+                      const int* levels, int R, int P, int C, const float* dout, const int* argmax, void* stream) {
+    if (nlev <= 0 || nlev > MAXL || (C & 3) || P <= 0 || dout == nullptr || argmax == nullptr) return OMNI_ERR_ARG;
+    if (R == 0) return OMNI_OK;
+    FeatLevels fl = make_feat(dlevel_ptrs, level_hw, level_scale, nlev);
+    const long jobs = (long)R * P * P;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_kernel<1>), dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, fl,
+                       (const float*)nullptr, batch_idx, levels, R, P, C, const_cast<float*>(dout), const_cast<int*>(argmax));
     return omni_launch_status();
 }
 

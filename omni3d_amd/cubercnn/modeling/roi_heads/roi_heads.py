@@ -69,11 +69,13 @@ class ROIPooler(nn.Module):
         super().__init__()
         import math
         # POOLER_TYPE is passed through by the reference (roi_heads.py:166-171).  "ROIAlignV2" is every released configuration;
-        # "ROIAlign" (no half-pixel shift) runs on the general kernels since round 6; "ROIPool" / "ROIAlignRotated" are other operators.
-        if pooler_type not in ("ROIAlignV2", "ROIAlign") or sampling_ratio != 0:
-            raise NotImplementedError(f"MI355X hot path: POOLER_TYPE ROIAlignV2 / ROIAlign with adaptive sampling (POOLER_SAMPLING_RATIO 0); got "
-                                      f"{pooler_type!r} / {sampling_ratio}")
+        # "ROIAlign" (no half-pixel shift) and "ROIPool" (torchvision roi_pool; it has no sampling ratio) run on the general kernels since
+        # round 6; "ROIAlignRotated" takes RotatedBoxes (five numbers per box), which this model's proposals are not.
+        if pooler_type not in ("ROIAlignV2", "ROIAlign", "ROIPool") or (sampling_ratio != 0 and pooler_type != "ROIPool"):
+            raise NotImplementedError(f"MI355X hot path: POOLER_TYPE ROIAlignV2 / ROIAlign with adaptive sampling (POOLER_SAMPLING_RATIO 0) or "
+                                      f"ROIPool; got {pooler_type!r} / {sampling_ratio}")
         self.aligned = pooler_type == "ROIAlignV2"
+        self.max_pool = pooler_type == "ROIPool"
         self.output_size = output_size if isinstance(output_size, int) else output_size[0]
         self.scales = tuple(scales)
         self.min_level = int(round(-math.log2(scales[0])))
@@ -82,6 +84,8 @@ class ROIPooler(nn.Module):
 
     def forward(self, feats, rois, batch_idx):
         levels = det.roi_levels(rois, self.min_level, self.max_level, float(self.canonical_box_size), self.canonical_level)
+        if self.max_pool:
+            return HF.roi_pool(feats, self.scales, rois, batch_idx, levels, self.output_size)
         if not self.aligned:
             return HF.roi_align_legacy(feats, self.scales, rois, batch_idx, levels, self.output_size)
         return HF.roi_align(feats, self.scales, rois, batch_idx, levels, self.output_size)

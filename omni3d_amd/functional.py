@@ -1224,6 +1224,34 @@ def roi_align_legacy(feats, scales, rois, batch_idx, levels, P):
     return _ROIAlignLegacy.apply(rois, batch_idx, levels, tuple(scales), P, *feats)
 
 
+class _ROIPool(Function):
+    """POOLER_TYPE "ROIPool" (torchvision roi_pool: whole-pixel ROI corners, maximum over each bin, gradient to the argmax pixel),
+    round 6: omni_roi_pool_fwd / _bwd (csrc/roi_align.hip)."""
+
+    @staticmethod
+    def forward(ctx, rois, batch_idx, levels, scales, P, *feats):
+        ctx.slots = [_slot_enter(f, ctx.needs_input_grad[5 + i]) for i, f in enumerate(feats)]
+        feats = [_cl(f) for f in feats]
+        nhwc = [f.permute(0, 2, 3, 1) for f in feats]
+        out, arg = det.roi_pool_fwd(nhwc, scales, rois, batch_idx, levels, P)
+        ctx.save_for_backward(batch_idx, levels, arg)
+        ctx.meta = (scales, P, [tuple(f.shape) for f in nhwc])
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        batch_idx, levels, arg = ctx.saved_tensors
+        scales, P, shapes = ctx.meta
+        dfe = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in shapes]
+        det.roi_pool_bwd(dfe, scales, batch_idx, levels, P, _cl(dout).permute(0, 2, 3, 1).contiguous(), arg)
+        return (None, None, None, None, None) + tuple(_slot_deliver(slot, lambda carry, d=d: _add_carry(d.permute(0, 3, 1, 2), carry))
+                                                      for slot, d in zip(ctx.slots, dfe))
+
+
+def roi_pool(feats, scales, rois, batch_idx, levels, P):
+    return _ROIPool.apply(rois, batch_idx, levels, tuple(scales), P, *feats)
+
+
 class _ROIAlignShared(Function):
     """Training: the cube head pools the SAME sampled boxes as the box head with an identical pooler (the reference builds
     two ROIPoolers with the same resolution / sampling ratio / type, roi_heads.py:166-171, and calls them on the same

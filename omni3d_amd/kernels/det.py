@@ -281,6 +281,26 @@ def roi_align_bwd_mode(dfeats_nhwc, scales, rois, batch_idx, levels, P, aligned,
            _lib.stream_of(rois))
 
 
+def roi_pool_fwd(feats_nhwc, scales, rois, batch_idx, levels, P):
+    """torchvision roi_pool level by level (detectron2 POOLER_TYPE "ROIPool") -> (out (R, P, P, C), argmax (R, P, P, C) int32)"""
+    L = _dev(rois, batch_idx, levels, *feats_nhwc)
+    R, C = rois.shape[0], feats_nhwc[0].shape[3]
+    out = _empty((R, P, P, C), torch.float32, rois)
+    arg = _empty((R, P, P, C), torch.int32, rois)
+    keep, a = _feat_args(feats_nhwc, scales)
+    L.call("omni_roi_pool_fwd", *a, _lib.ptr(rois), _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, _lib.ptr(out), _lib.ptr(arg),
+           _lib.stream_of(rois))
+    return out, arg
+
+
+def roi_pool_bwd(dfeats_nhwc, scales, batch_idx, levels, P, dout, argmax):
+    """dout lands on the argmax pixels: fp32 atomics into ZEROED dfeats"""
+    L = _dev(batch_idx, levels, dout, argmax, *dfeats_nhwc)
+    R, C = dout.shape[0], dfeats_nhwc[0].shape[3]
+    keep, a = _feat_args(dfeats_nhwc, scales)
+    L.call("omni_roi_pool_bwd", *a, _lib.ptr(batch_idx), _lib.ptr(levels), R, P, C, _lib.ptr(dout), _lib.ptr(argmax), _lib.stream_of(dout))
+
+
 def roi_align_fwd2(feats_nhwc, scales, rois, batch_idx, levels, P, per_image, first):
     """-> (out (R, P, P, C), out2 ((R // per_image) * first, P, P, C) = the first `first` ROIs of every block of `per_image`), one pass"""
     L = _dev(rois, batch_idx, levels, *feats_nhwc)

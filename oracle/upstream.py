@@ -607,6 +607,46 @@ def roi_align(input, rois, output_size, spatial_scale, sampling_ratio=0, aligned
     return out
 
 
+def roi_pool(input, rois, output_size, spatial_scale):
+    """torchvision.ops.roi_pool restated (detectron2 POOLER_TYPE "ROIPool" builds RoIPool(output_size, spatial_scale) per level).
+    input (N,C,H,W), rois (K,5) = [batch, x1, y1, x2, y2] -> (K,C,P,P), differentiable w.r.t. input.  Follows the published kernel:
+    ROI corners rounded to whole pixels with C round() (half away from zero), a ROI of at least 1 x 1 (roi_end - roi_start + 1),
+    bin (ph, pw) = rows [floor(ph * bh), ceil((ph + 1) * bh)) + roi_start clipped to [0, H] (bh = roi_height / P in float32), same for
+    columns; strictly-greater scan in row-major order (the FIRST maximum), an empty bin is 0 and passes no gradient."""
+    P = output_size if isinstance(output_size, int) else output_size[0]
+    N, C, H, W = input.shape
+    K = rois.shape[0]
+    rows = []
+
+    def c_round(v):          # C round(): half away from zero (torch.round is half to even)
+        v = float(v)
+        return int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)
+    scale32 = torch.tensor(spatial_scale, dtype=torch.float32)
+    for k in range(K):
+        b = int(rois[k, 0])
+        rsw, rsh, rew, reh = (c_round(rois[k, i].float() * scale32) for i in (1, 2, 3, 4))       # (the kernel's arithmetic is float32)
+        rw, rh = max(rew - rsw + 1, 1), max(reh - rsh + 1, 1)
+        bh = torch.tensor(float(rh), dtype=torch.float32) / torch.tensor(float(P), dtype=torch.float32)
+        bw = torch.tensor(float(rw), dtype=torch.float32) / torch.tensor(float(P), dtype=torch.float32)
+        bins = []
+        for ph in range(P):
+            for pw in range(P):
+                hs = int(torch.floor(torch.tensor(float(ph), dtype=torch.float32) * bh)) + rsh
+                he = int(torch.ceil(torch.tensor(float(ph + 1), dtype=torch.float32) * bh)) + rsh
+                ws = int(torch.floor(torch.tensor(float(pw), dtype=torch.float32) * bw)) + rsw
+                we = int(torch.ceil(torch.tensor(float(pw + 1), dtype=torch.float32) * bw)) + rsw
+                hs, he = min(max(hs, 0), H), min(max(he, 0), H)
+                ws, we = min(max(ws, 0), W), min(max(we, 0), W)
+                if he <= hs or we <= ws:
+                    bins.append(input.new_zeros((C,)))
+                    continue
+                region = input[b, :, hs:he, ws:we].reshape(C, -1)
+                idx = region.argmax(dim=1, keepdim=True)             # first occurrence of the maximum (row-major scan)
+                bins.append(region.gather(1, idx)[:, 0])
+        rows.append(torch.stack(bins, dim=1).reshape(C, P, P))
+    return torch.stack(rows) if rows else input.new_zeros((0, C, P, P))
+
+
 def assign_boxes_to_levels(box_lists, min_level, max_level, canonical_box_size, canonical_level):
     box_sizes = torch.sqrt(cat([boxes.area() for boxes in box_lists]))
     level_assignments = torch.floor(canonical_level + torch.log2(box_sizes / canonical_box_size + 1e-8))

@@ -646,7 +646,7 @@ def _run_roi_align_legacy(dev):
         fg = f.grad if f.grad is not None else torch.zeros_like(f)
         assert (d.grad.cpu() - fg).abs().max() < 5e-5
     with pytest.raises(NotImplementedError):
-        ROIPooler(P, scales, 0, "ROIPool")
+        ROIPooler(P, scales, 0, "ROIAlignRotated")
 
 
 def test_roi_align_legacy_pooler_emulated(emu_lib):
@@ -656,3 +656,50 @@ def test_roi_align_legacy_pooler_emulated(emu_lib):
 @pytest.mark.gpu
 def test_roi_align_legacy_pooler_gpu(hip_lib):
     _run_roi_align_legacy("cuda")
+
+
+def _run_roi_pool(dev):
+    """POOLER_TYPE "ROIPool" (round 6): torchvision roi_pool level by level like detectron2's ROIPooler -- forward, argmax routing of the
+    gradient (overlapping ROIs add), whole-pixel rounding (x.5 corners), ROIs partly / wholly outside the map (empty bins: 0, no
+    gradient), a degenerate ROI (forced to 1 x 1), bins narrower than a pixel (P larger than the ROI: neighbouring bins share a pixel)"""
+    from omni3d_amd.cubercnn.modeling.roi_heads.roi_heads import ROIPooler
+    g = torch.Generator().manual_seed(23)
+    B, C = 2, 8
+    hw = [(32, 32), (16, 16), (8, 8)]
+    scales = [1 / 4, 1 / 8, 1 / 16]
+    feats = [torch.randn(B, C, h, w, generator=g) for h, w in hw]
+    rois = torch.cat([_rand_boxes(g, 30, 128, 128, 6, 120),
+                      torch.tensor([[-20.0, -20, 30, 30], [100, 100, 160, 170], [5, 5, 5.5, 5.2], [40, 40, 40, 40], [2, 2, 10, 10], [6, 10, 18, 22],
+                                    [200, 200, 260, 260], [-50, -50, -10, -10], [0, 0, 127, 127]])])
+    R = rois.shape[0]
+    bidx = torch.randint(0, B, (R,), generator=g).int()
+    lv = U.assign_boxes_to_levels([Boxes(rois)], 2, 4, 56, 3)
+    for P in (7, 3):
+        fr = [f.clone().requires_grad_(True) for f in feats]
+        ref = torch.zeros(R, C, P, P)
+        for level, scale in enumerate(scales):
+            inds = torch.where(lv == level)[0]
+            if inds.numel():
+                fmt = torch.cat([bidx[inds, None].float(), rois[inds]], dim=1)
+                ref = ref.index_put((inds,), U.roi_pool(fr[level], fmt, P, scale))
+        pool = ROIPooler(P, scales, 2, "ROIPool", canonical_box_size=56, canonical_level=3)       # (roi_pool has no sampling ratio: any value passes)
+        assert pool.max_pool and not pool.same_as(pool)
+        fd = [f.clone().contiguous(memory_format=torch.channels_last).to(dev).requires_grad_(True) for f in feats]
+        got = pool(fd, rois.to(dev), bidx.to(dev))
+        assert torch.equal(got.detach().cpu(), ref.detach()), P               # a maximum is a copy: exact
+        assert bool((ref.detach().reshape(R, -1).abs().sum(1) == 0).any())    # (the wholly-outside ROIs really are empty)
+        dout = torch.randn(R, C, P, P, generator=g)
+        ref.backward(dout)
+        got.backward(dout.to(dev))
+        for d, f in zip(fd, fr):
+            fg = f.grad if f.grad is not None else torch.zeros_like(f)
+            assert (d.grad.cpu() - fg).abs().max() < 1e-5, P                  # (sums of a few gradients per pixel: order differs)
+
+
+def test_roi_pool_pooler_emulated(emu_lib):
+    _run_roi_pool("cpu")
+
+
+@pytest.mark.gpu
+def test_roi_pool_pooler_gpu(hip_lib):
+    _run_roi_pool("cuda")
