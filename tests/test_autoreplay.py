@@ -301,6 +301,14 @@ def test_buckets_share_graph_memory_gpu(hip_lib, monkeypatch):
     shapes = [(192, 256), (128, 128), (256, 320)]
 
     def run(share):
+        # leftovers of earlier tests / of the other run (dead graph pools with their 26 GB arenas, cached blocks) go back to the driver
+        # first: otherwise they are released whenever the collector gets to them, possibly by the trim at the end of the FIRST capture
+        # below, which also drops the cached blocks the second capture's warm-up pass would have reused (seen once on a GPU box:
+        # grew_shared [-33328, 450, 304] MB)
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
         monkeypatch.setattr(AR, "SHARE_POOLS", share)
         model, opt, _ = _build("cuda", small, 128)
         model.proposal_generator.injected = None             # in-kernel draws: the state advances on the device, replayed or not
