@@ -209,8 +209,16 @@ class RPNWithIgnore(nn.Module):
         levels = self.rpn_head(feats)
         if self.training:
             assert targets is not None, "RPN requires ground truth in training!"
-            with HF.forked():        # (a parallel branch of the captured step, joined behind the proposals; eager: a no-op)
-                labels, matched_idx = self.label_and_sample_anchors(anchors, targets)
+            self.__dict__["_last_hw_list"] = hw_list
+            hook = self.__dict__.get("_label_split")
+            if hook is not None:
+                # a step being captured in pipelined form (solver/graphed.py, OMNI_PIPE_LABELS): anchor labelling + sampling read only
+                # the anchors and the ground truth, so they were captured as a graph of their own that replays on the idle
+                # weight-gradient stream beside the bottom-up; the critical-path graph is cut HERE and its second half starts behind both
+                labels, matched_idx = hook()
+            else:
+                with HF.forked():        # (a parallel branch of the captured step, joined behind the proposals; eager: a no-op)
+                    labels, matched_idx = self.label_and_sample_anchors(anchors, targets)
             losses = self.losses(levels, anchors, labels, matched_idx, targets)
             self.last_labels = labels
         else:

@@ -74,6 +74,7 @@ class lean_capture:
 
 
 _TORCH_CTX = __import__("os").environ.get("OMNI_GRAPH_TORCH_CTX", "0") == "1"
+_GRAPH_DUMP = __import__("os").environ.get("OMNI_GRAPH_DUMP", "")
 
 
 def make_side_stream(device=None):
@@ -442,13 +443,21 @@ class GraphedPipelined:
                 if not stages and self._split_forward(bottom_up):
                     gm = self._capture_stage0_split(bottom_up)
                     pool_m = gm.pool()
+                elif not stages and self._split_labels():
+                    gm, pool_w = self._capture_stage0_labels(pool_m, pool_w)
+                    pool_m = gm.pool()
                 else:
+                    if _GRAPH_DUMP:
+                        gm.enable_debug_mode()
                     with lean_capture(gm, pool_m), detmode.domain("M"):
                         if not stages:
                             self.losses, self.total = self._stage0()
                         else:
                             self.cuts.backward_last()
                     pool_m = gm.pool()
+                    if _GRAPH_DUMP:                 # diagnostic (OMNI_GRAPH_DUMP=dir): the node list of every critical-path graph as a dot file
+                        os.makedirs(_GRAPH_DUMP, exist_ok=True)
+                        gm.debug_dump(os.path.join(_GRAPH_DUMP, "M%d.dot" % len(stages)))
                 fns, keep = HF.side_take()
                 # (measured, profiles/r04_ab_w_shift.log: carrying the heads' weight gradients into the NEXT stage's graph frees M1
                 # -- 1.45 -> 0.79 ms, it is HBM-bound on the p2 maps and so is the fc1 weight gradient beside it -- and M2 pays it
@@ -525,6 +534,53 @@ class GraphedPipelined:
         torch.cuda.current_stream().wait_stream(cap)
         self.prologue = (gp, ga)
         return gb
+
+    # Round 6: the RPN's anchor labelling + sampling (rpn_match1 / rpn_match2 / top-k of the sampling keys / rpn_finalize: four
+    # latency-bound launches, ~0.12 ms with the device otherwise idle) read the anchors and the ground truth only -- nothing the network
+    # computes.  Stage 0 is captured as THREE graphs: L (those four launches; replayed on the weight-gradient stream, which idles through
+    # all of forward), M0a (zero_grad .. RPN head) and M0b (losses, proposals, ROI heads, the heads' backward), which starts behind both.
+    # Unlike the filter-transform prologue above, L moves no memory to speak of: it hides completely.  OMNI_PIPE_LABELS=0 switches it off.
+    def _split_labels(self):
+        import os
+        rpn = getattr(self.model, "proposal_generator", None)
+        return (os.environ.get("OMNI_PIPE_LABELS", "1") != "0" and rpn is not None and hasattr(rpn, "label_and_sample_anchors")
+                and rpn.__dict__.get("_last_hw_list") is not None and getattr(rpn, "injected", None) is None and self.static_packed is not None)
+
+    def _capture_stage0_labels(self, pool_m, pool_w):
+        from ...kernels import detmode
+        rpn = self.model.proposal_generator
+        dev = next(self.model.parameters()).device
+        anchors = rpn.anchor_generator.grid(rpn.__dict__["_last_hw_list"], dev)       # (cached by the warm-up pass)
+        gl, ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with lean_capture(gl, pool_w), detmode.domain("W"):
+            pre = rpn.label_and_sample_anchors(anchors, self.static_packed)
+        self._held.append((pre, anchors))
+        state = {"done": False}
+
+        def split():
+            if not state["done"]:
+                state["done"] = True
+                ga.capture_end()
+                gb.capture_begin(pool=ga.pool(), capture_error_mode="thread_local")
+            return pre
+        if lean_capture._stream is None:
+            lean_capture._stream = torch.cuda.Stream()
+        cap = lean_capture._stream
+        cap.wait_stream(torch.cuda.current_stream())
+        rpn.__dict__["_label_split"] = split
+        try:
+            with torch.cuda.stream(cap), detmode.domain("M"):
+                kw = {"pool": pool_m} if pool_m is not None else {}
+                ga.capture_begin(capture_error_mode="thread_local", **kw)
+                self.losses, self.total = self._stage0()
+                if not state["done"]:
+                    raise RuntimeError("the forward pass never asked for the anchor labels")
+                gb.capture_end()
+        finally:
+            rpn.__dict__.pop("_label_split", None)
+        torch.cuda.current_stream().wait_stream(cap)
+        self.prologue = (gl, ga)
+        return gb, gl.pool()
 
     def _install(self):
         """the model cuts its forward at THIS object's cut points (several captured steps may exist side by side -- one per size
