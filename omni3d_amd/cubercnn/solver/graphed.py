@@ -77,6 +77,51 @@ _TORCH_CTX = __import__("os").environ.get("OMNI_GRAPH_TORCH_CTX", "0") == "1"
 _GRAPH_DUMP = __import__("os").environ.get("OMNI_GRAPH_DUMP", "")
 
 
+class DeviceEvent:
+    """A HIP event for DEVICE-side ordering only: hipEventDisableTiming | hipEventDisableSystemFence.  torch.cuda.Event (and
+    Stream.wait_stream, which records one) creates its events with hipEventDisableTiming alone, and recording such an event ends with a
+    system-scope release -- "cache writeback and invalidation, and the performance impact of those actions on the execution of
+    following work" (hip_runtime_api.h).  The stage-end events of a replayed step are recorded on the critical-path stream after EVERY
+    M_k while the weight-gradient stream keeps the L2s full of dirty lines; nobody on the host reads anything at those points.
+    Recorded / waited on through the HIP runtime torch already has loaded; one object per use site, re-recorded every step."""
+    _hip = None
+    FLAGS = 0x2 | 0x20000000          # hipEventDisableTiming | hipEventDisableSystemFence
+
+    def __init__(self):
+        import ctypes
+        if DeviceEvent._hip is None:
+            DeviceEvent._hip = ctypes.CDLL("libamdhip64.so")
+        self._ct = ctypes
+        self.ev = ctypes.c_void_p()
+        rc = DeviceEvent._hip.hipEventCreateWithFlags(ctypes.byref(self.ev), ctypes.c_uint(DeviceEvent.FLAGS))
+        if rc != 0:
+            raise RuntimeError("hipEventCreateWithFlags failed: %d" % rc)
+
+    def record(self, stream):
+        rc = DeviceEvent._hip.hipEventRecord(self.ev, self._ct.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError("hipEventRecord failed: %d" % rc)
+
+    def wait(self, stream):
+        """`stream` waits for the work this event was last recorded behind"""
+        rc = DeviceEvent._hip.hipStreamWaitEvent(self._ct.c_void_p(stream.cuda_stream), self.ev, self._ct.c_uint(0))
+        if rc != 0:
+            raise RuntimeError("hipStreamWaitEvent failed: %d" % rc)
+
+    def __del__(self):
+        try:
+            if self.ev:
+                DeviceEvent._hip.hipEventDestroy(self.ev)
+        except Exception:
+            pass
+
+
+# MEASURED and left OFF (profiles/r06_ab_device_events.log): 10.80-10.81 ms with device-only events against 10.74-10.77 with torch's --
+# the system-scope release is not what stretches the one stage boundary at which the weight-gradient queue is busy (~140 us instead of
+# ~14, profiles/r06_ab_labels_cuts_gaps.log), and the fence-free markers are no cheaper for the command processor.
+_PIPE_EVENTS = __import__("os").environ.get("OMNI_PIPE_EVENTS", "torch")      # "torch" | "device"
+
+
 def make_side_stream(device=None):
     """The weight-gradient stream.  The critical path runs on the main stream and is ~92 % busy (rocprofv3 trace, queue 1: 11.4 of
     12.4 ms); whatever the side stream runs beside it competes for the same CUs, and a PERSISTENT side kernel (the fc1-class weight
@@ -691,21 +736,36 @@ class GraphedPipelined:
             rec = {"t0": torch.cuda.Event(enable_timing=True), "m": [], "w": [None] * n, "x": [None] * n, "host": []}
             rec["t0"].record(main)
             self._timing.append(rec)
+        dev_ev = _PIPE_EVENTS == "device" and not timing
+        if dev_ev and getattr(self, "_dev_events", None) is None:
+            self._dev_events = [DeviceEvent() for _ in range(n + 3)]            # stage ends, prologue fork / join, end of step
+
+        def order(after, before, slot):
+            """stream `after` waits for what `before` has been given so far (device-side ordering only)"""
+            if dev_ev:
+                e = self._dev_events[slot]
+                e.record(before)
+                e.wait(after)
+            else:
+                after.wait_stream(before)
         if self.prologue is not None:
             # P on the side stream (behind whatever the main stream did last: the optimizer's update), M0a on the main stream;
             # M0b -- stages[0] -- starts behind both
             gp, ga = self.prologue
-            side.wait_stream(main)
+            order(side, main, n)
             with torch.cuda.stream(side):
                 gp.replay()
             ga.replay()
-            main.wait_stream(side)
+            order(main, side, n + 1)
 
         def launch_w(k):                              # W_k starts when M_k has finished ...
             gw = self.stages[k][1]
             if gw is None and k > 0 and not self._replay_per_stage:
                 return []
-            side.wait_event(ends[k])
+            if dev_ev:
+                ends[k].wait(side)
+            else:
+                side.wait_event(ends[k])
             with torch.cuda.stream(side):
                 if gw is not None:
                     if timing:
@@ -750,17 +810,17 @@ class GraphedPipelined:
         elif _PIPE_ORDER == "mfirst":               # A/B: every critical-path graph first, then the weight-gradient graphs behind their events
             for k in range(n):
                 self.stages[k][0].replay()
-                ends[k] = torch.cuda.Event()
+                ends[k] = self._dev_events[k] if dev_ev else torch.cuda.Event()
                 ends[k].record(main)
             for k in range(n):
                 pending += launch_w(k)
         else:
             for k in range(n):
                 self.stages[k][0].replay()
-                ends[k] = torch.cuda.Event()
+                ends[k] = self._dev_events[k] if dev_ev else torch.cuda.Event()
                 ends[k].record(main)
                 if k >= 1:
                     pending += launch_w(k - 1)
             pending += launch_w(n - 1)
-        main.wait_stream(side)                        # ... and everything after the step waits for the last W
+        order(main, side, n + 2)                      # ... and everything after the step waits for the last W
         return self.losses, self.total, pending + self._late(self._replay_per_stage)
