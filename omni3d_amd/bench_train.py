@@ -674,11 +674,12 @@ def dominant_kernel_roofline(iters=20):
             "[2048x1024]x[1024x12544] box-head fc1 (1568 tiles = 6 per workgroup + 32 tiles cut in 8)",
             2.0 * 2048 * 12544 * 1024, lambda: conv.linear_dgrad(dy1, w1), pmc_key="gemm_engine_kernel<0, 1, 128, 128, true>", grid=65536,
             step_gflop=(2.0 * (2048 + 512) * 12544 * 1024) / 2 / 1e9),       # (in the step: the box head's and the cube head's launch, averaged)
-        fam("FC weight gradient (round 5: the 128x64 tile kernel on the weight-gradient stream -- the engine's balanced form held 410 registers "
-            "per lane on every CU and stalled the main stream, kernels/conv.py; accumulated into the gradient bucket; in the step the row averages "
-            "the box head's 2048-row and the cube head's 512-row launch)", "conv_wgrad_kernel<128, 64, 2, 2, 32>",
-            "[1024x2048]x[2048x12544] box-head fc1 (8 x 196 tiles)", 2.0 * 2048 * 12544 * 1024,
-            lambda: conv.linear_wgrad(x1, dy1, accum_into=gacc1), grid=401408, per_step=2, step_gflop=(2.0 * (2048 + 512) * 12544 * 1024) / 2 / 1e9),
+        fam("FC weight gradient (round 5: a tile kernel on the weight-gradient stream -- the engine's balanced form held 410 registers "
+            "per lane on every CU and stalled the main stream, kernels/conv.py; late round 6: 64x64 tiles, 3136 of them end together where "
+            "1568 of 128x64 left a third round of 32 workgroups; accumulated into the gradient bucket; in the step the row averages "
+            "the box head's 2048-row and the cube head's 512-row launch)", "conv_wgrad_kernel<64, 64, 2, 2, 32>",
+            "[1024x2048]x[2048x12544] box-head fc1 (16 x 196 tiles)", 2.0 * 2048 * 12544 * 1024,
+            lambda: conv.linear_wgrad(x1, dy1, accum_into=gacc1), grid=802816, per_step=2, step_gflop=(2.0 * (2048 + 512) * 12544 * 1024) / 2 / 1e9),
         fam("Winograd weight-gradient GEMMs, small maps", "gemm_tn_pf_kernel<4>", "36x[128x1024]x[1024x128] (DLA level 3)", fl3,
             lambda: wino.gemm_batched_wgrad(V3, dM3), grid=147456, step_grid=False),
         fam("Winograd weight-gradient GEMMs, small maps (DLA level 4)", "gemm_tn_pf_kernel<4>", "36x[256x256]x[256x256] (DLA level 4)", fl4,

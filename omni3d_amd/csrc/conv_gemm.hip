@@ -1507,6 +1507,14 @@ struct WgradGeom {
     int bm, bn, tiles, pps;
     long splits;
 };
+// fc1-class weight gradients ([1024 x 2048]^T [2048 x 12544]: few "pixels", a very wide (tap, c) extent): 8 x 196 = 1568 tiles of
+// 128 x 64 are 2.04 rounds of the 768 resident workgroups -- a third round of 32 workgroups costs ~100 us; 3136 tiles of 64 x 64 at four
+// per CU end together: 589 -> 534 us (0.57 -> 0.63 of peak), the cube head's 512-ROI launch 157 -> 142 us (tools/probes/fc_wgrad_tiles.py,
+// profiles/r06_fc_wgrad_tiles.log).  Same slab order per output element.  OMNI_WGRAD_FC_TILE64=0: the 128 x 64 tile.
+static inline bool wgrad_fc_tile64() {
+    static const bool on = [] { const char* e = getenv("OMNI_WGRAD_FC_TILE64"); return e == nullptr || atoi(e) != 0; }();
+    return on;
+}
 static inline WgradGeom wgrad_geom(int K, int Nn, long P, int tile) {
     constexpr int WBK = 32;
     // tile: 128x128 for wide layers, 128x64 when the (tap, c) extent is only 64 wide, 64x64 for K <= 64,
@@ -1516,6 +1524,7 @@ static inline WgradGeom wgrad_geom(int K, int Nn, long P, int tile) {
     else if (tile == 2) { g.bm = 64; g.bn = 64; }
     else if (tile == 3) { g.bm = 128; g.bn = 64; }
     else if (tile == 4) { g.bm = 32; g.bn = 128; }
+    else if (K > 64 && Nn >= 4096 && P <= 4096 && wgrad_fc_tile64()) { g.bm = 64; g.bn = 64; }      // fc1-class: see wgrad_fc_tile64()
     else if (K > 64) { g.bm = 128; g.bn = (Nn > 64 && P >= 32768) ? 128 : 64; }
     else if (K > 32) { g.bm = 64; g.bn = 64; }
     else { g.bm = 32; g.bn = 128; }
