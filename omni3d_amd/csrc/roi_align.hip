@@ -287,12 +287,12 @@ __global__ void __launch_bounds__(256) roi_align_bwd_sep_kernel(FeatLevels fl, c
 // zero-fill in front, no atomics) and its value depends on the inputs alone.
 // Round 4 gave every wave of a workgroup its own tile and let it walk the whole list: the launch was bound by its LONGEST list (the
 // benchmark's 2048 ROIs sit almost all on p2, ~10 x 6 pixels each; (8 x 4 tile, ROI) lists: mean 5.9, 90th percentile 16, longest
-// 50, tools/debug/roi_bwd_probe.py) times ~5 us per entry -- up to seven rounds of dependent loads, one per bin row, more where a
+// 50, tools/probes/roi_bwd_probe.py) times ~5 us per entry -- up to seven rounds of dependent loads, one per bin row, more where a
 // ROI carries the cube head's gradient as well and every bin's second load met its first in an add.  Round 5: the four waves of a
 // workgroup SHARE one tile and deal its list out (wave s takes entries s, s + 4, ...: chains of <= 13), then meet through LDS in
 // wave order -- the sum of an element is ((S0 + S1) + S2) + S3 with S_s the ascending-ROI sum of wave s, a function of the ROI set
 // alone; a bin row's loads (7 from each gradient tensor) are issued as one block before anything waits.  Alone on the device: 272
-// -> 136 us (tools/debug/roi_bwd_probe.py); in the two-stream step 10.81 -> 10.77 ms only -- the chain-bound form left most of the
+// -> 136 us (tools/probes/roi_bwd_probe.py); in the two-stream step 10.81 -> 10.77 ms only -- the chain-bound form left most of the
 // machine to the weight-gradient stream beside it (profiles/r05_ab_roi_gather.log).
 struct GatherTiles {
     int off[MAXL + 1];        // first patch of each level (a patch = GT_PW x GT_PH tiles = 32 x 32 pixels of one image)

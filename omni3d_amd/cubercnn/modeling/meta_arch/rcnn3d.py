@@ -124,7 +124,7 @@ class RCNN3D(nn.Module):
             if not _EVAL_F22:
                 return self.inference(batched_inputs, packed=packed, _replay_tried=True)
             # Inference runs every Winograd layer on the 16-point F(2x2,3x3) transform: the cube head's Gram-Schmidt amplifies feature
-            # noise up to ~300x for near-parallel 6D pose vectors (tools/debug/pose_diag.py), and the 36-point transform of the
+            # noise up to ~300x for near-parallel 6D pose vectors (tools/probes/pose_diag.py), and the 36-point transform of the
             # bottom-up is what that noise is made of -- worst pose / corner error of the full-size fixture against float64 2.9e-4
             # with F(4x4,3x3), 3.5e-5 without (north_star: 1e-4), for 4 % of the inference time.  Training keeps F(4x4,3x3): its
             # losses sit at 1e-7 and its gradients are judged against the fp32 reference's own distance to float64.

@@ -114,7 +114,7 @@ class _Boundary(Function):
     nodes alive, and those are bound to the stream they were created on -- the default stream of an eager iteration.  A later
     hipGraph capture that meets such a node makes the autograd engine synchronise the capture stream with the default stream,
     which is illegal inside a capture (torch warns: "AccumulateGrad node's stream does not match ... may break CUDA graph capture";
-    on ROCm 7.2 capture_end segfaults: tools/debug/capture_matrix.py, profiles/r03_capture_matrix.txt).  With the boundary the loop
+    on ROCm 7.2 capture_end segfaults: tools/probes/capture_matrix.py, profiles/r03_capture_matrix.txt).  With the boundary the loop
     only ever holds this node; `release()` drops the inner graph before a capture, whatever the loop still references."""
 
     @staticmethod

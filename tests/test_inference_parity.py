@@ -77,7 +77,7 @@ def _run(dev, name="dla34_small_infer"):
         # projected 3D centres may lie far outside the image (|u| up to ~800 px here); round 6: north_star's 1e-4 (4e-4 before; measured <= 2.1e-5)
         bounded("pred_center_2D", i.pred_center_2D, 1e-4, scale=r64["pred_center_2D"].abs().clamp(min=ext))
         # Round 4: north_star's 1e-4 here too (1e-3 before).  The Gram-Schmidt of a random-init 6D pose amplifies feature noise by
-        # up to ~300x (angle between the two pose vectors 3 degrees: tools/debug/pose_diag.py, profiles/r04_pose_diag.txt); the decode
+        # up to ~300x (angle between the two pose vectors 3 degrees: tools/probes/pose_diag.py, profiles/r04_pose_diag.txt); the decode
         # kernel evaluates the fp32 head outputs in float64 (arithmetic error 3e-8) and inference runs its Winograd layers on the
         # 16-point transform, which brought the full-size fixture from 2.9e-4 to 3.5e-5.  Where the REFERENCE's fp32 run is itself
         # above the bar (small fixture, 1.9e-4 / 3.1e-4) the 3x / 1.5x rule of `bounded` applies.

@@ -283,7 +283,7 @@ GRAD_CAP_BACKBONE_TINY = 3e-2
 # Element-wise check of the recorded 64-element gradient heads (max |HIP - reference| over the largest reference element): a far
 # noisier quantity than a tensor norm, and it is NOT the same from run to run -- the production kernels sum split-K / statistics
 # partials with atomics, and a last-bit difference in an activation flips ReLU / max-pool decisions further up.  Ten repetitions
-# of each fixture on MI355X (tools/debug/grad_repeat.py, profiles/r03_grad_run_to_run_spread.txt): dla34_full base_layer.0.weight
+# of each fixture on MI355X (tools/probes/grad_repeat.py, profiles/r03_grad_run_to_run_spread.txt): dla34_full base_layer.0.weight
 # 1.38 .. 2.35 % (continuous), dla34_small 0.7 / 1.04 % (two modes), the 1 x 64 x 64 plumbing fixture dla34_tiny_head_entangled
 # 0.2 / 0.5 / 4.9 % (three modes: its deepest maps are 2 x 2, one flipped decision is a visible share of the gradient).  Caps:
 # 3 % (1.3 x the worst of the ten full-size runs), 6 % for the 1 x 64 x 64 fixtures; a wrong kernel is O(100 %) here.

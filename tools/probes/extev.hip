@@ -4,7 +4,7 @@
 // capture mode -- but the HIP runtime bundled with torch 2.10.0+rocm7.0 (the one a Python process gets) rejects the same call with
 // hipErrorInvalidValue, and torch.cuda.Event(external=True) raises "External events are disallowed in rocm".  So the critical
 // path of the training step cannot be ONE graph with mid-graph events; GraphedPipelined uses one graph per backward stage.
-//   hipcc --offload-arch=gfx950 -O2 -o extev tools/debug/extev.hip && ./extev [variant bits: 1 non-blocking stream, 2 global mode, 4 relaxed, 8 fork/join]
+//   hipcc --offload-arch=gfx950 -O2 -o extev tools/probes/extev.hip && ./extev [variant bits: 1 non-blocking stream, 2 global mode, 4 relaxed, 8 fork/join]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

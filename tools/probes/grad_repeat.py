@@ -2,7 +2,7 @@
 """Run-to-run spread of the gradient check of tests/test_model_parity.py::test_training_step_matches_reference_gpu on the GPU:
 the training step of a fixture is repeated N times in its production configuration (split-K / statistics atomics included) and
 the worst element-wise error of the recorded 64-element gradient heads (relative to the largest reference element, as the test
-measures it) is printed per run for the worst parameters.  Usage: python tools/debug/grad_repeat.py <fixture> [runs]"""
+measures it) is printed per run for the worst parameters.  Usage: python tools/probes/grad_repeat.py <fixture> [runs]"""
 import os
 import sys
 

@@ -7,7 +7,7 @@ detections furthest from the reference's float64 run prints
     perturbation of the head row (finite differences in float64),
 so that "the decode is ill-conditioned" and "the decode amplifies upstream fp32 noise" can be told apart.
 
-    python tools/debug/pose_diag.py [out.txt]      (GPU box)
+    python tools/probes/pose_diag.py [out.txt]      (GPU box)
 """
 import os
 import sys
