@@ -447,8 +447,10 @@ def dropin_loop_multiscale_stream(iters=320, fixed_ms=None):
         _sync()
         t0 = time.perf_counter()
         kinds, t_prev = {"eager": [], "capture": [], "replay": []}, time.perf_counter()
+        slow = []
         for it, batch in enumerate(stream):
             cap0, rep0 = auto.captures, auto.replays
+            r0 = torch.cuda.memory_reserved() if DEVICE == "cuda" else 0
             loss_dict = model(batch)
             losses = sum(loss_dict.values())
             if guard is None:
@@ -463,7 +465,12 @@ def dropin_loop_multiscale_stream(iters=320, fixed_ms=None):
             sched.step()
             # (per-iteration wall time by kind: the loss read-back above is the iteration's synchronisation point)
             t_now = time.perf_counter()
-            kinds["capture" if auto.captures > cap0 else "replay" if auto.replays > rep0 else "eager"].append(1e3 * (t_now - t_prev))
+            kind = "capture" if auto.captures > cap0 else "replay" if auto.replays > rep0 else "eager"
+            kinds[kind].append(1e3 * (t_now - t_prev))
+            # (diagnostic: the iterations that took > 150 ms with what the caching allocator did during them -- a run whose region is slow
+            # says which kind of iteration and whether memory was bought from / handed back to the driver)
+            if 1e3 * (t_now - t_prev) > 150.0:
+                slow.append([it, kind, round(1e3 * (t_now - t_prev), 1), round(((torch.cuda.memory_reserved() if DEVICE == "cuda" else 0) - r0) / 2 ** 20)])
             t_prev = t_now
             if it + 1 == iters - iters // 4:
                 _sync()
@@ -478,7 +485,8 @@ def dropin_loop_multiscale_stream(iters=320, fixed_ms=None):
            "replayed_in_last_quarter": (auto.replays - marks[0][1]) if marks else None, "last_quarter_iterations": iters // 4,
            "cache_entries": len(auto.cache), "stats": st, "capture": "ok" if auto.failed is None else f"not replaying: {auto.failed}",
            "guard_warnings": [str(r.message)[:160] for r in rec if "omni3d_amd" in str(r.message)],
-           "mean_padded_pixels_per_image": sum(px) / len(px)}
+           "mean_padded_pixels_per_image": sum(px) / len(px),
+           "slow_iterations_it_kind_ms_reservedMiB": slow[:24], "slow_iterations_total_ms": round(sum(r[2] for r in slow), 1)}
 
     def med(v):
         v = sorted(v)

@@ -58,7 +58,10 @@ SHARE_POOLS = os.environ.get("OMNI_AUTO_REPLAY_SHARE_POOLS", "1") != "0"
 # instead of buying ~6 GB of new segments per bucket from the driver and handing them back in 0.2-0.9 s trims (round 6:
 # 38.6 ms per iteration alone but 41-62 ms inside bench.py, where the allocator's state differed).  "0,0" switches the arenas off.
 ARENA_GB = tuple(float(v) for v in os.environ.get("OMNI_AUTO_REPLAY_ARENA_GB", "20,6").split(","))
-TRIM_GB = float(os.environ.get("OMNI_AUTO_REPLAY_TRIM_GB", "48"))        # reserved-but-unallocated memory above which a capture ends with empty_cache()
+TRIM_GB = float(os.environ.get("OMNI_AUTO_REPLAY_TRIM_GB", "48"))        # reserved-but-unallocated memory above which a capture ends with empty_cache() ...
+TRIM_FREE_GB = float(os.environ.get("OMNI_AUTO_REPLAY_TRIM_FREE_GB", "64"))   # ... but only once the DEVICE has less than this left: a trim is a 0.2-2 s
+#   hipFree, and on a 288 GB device whose loop holds ~100 GB the slack is not needed by anybody (one of four bench.py runs of the final
+#   head took 38.5 instead of 28.5 ms per iteration over the multi-scale region: ~1 s of stalls in its last quarter alone)
 # A/B: stage new batches through pinned host buffers with stream-ordered copies.  MEASURED and left OFF: on this ROCm 7.2 host the 3 MB
 # of image slots take ~20 ms to cross from pinned memory (37.1 against 11.9 ms per iteration, profiles/r04_dropin_phases.log); the pageable
 # copies block the host until the previous step has drained, which costs 0.3 ms per iteration with the losses read every 1000th
@@ -450,7 +453,8 @@ class AutoReplay:
                 # (torch's own capture context did it in front of each of the 14 stage captures; without it at all the pools'
                 # reserved memory grew to 222 GB over 47 buckets of different tensor sizes: profiles/r06_new_shape_*.txt)
                 # -- and only when the slack is worth a trip to the driver: hipFree of several GB takes 0.2-2 s (measured per capture)
-                if torch.cuda.memory_reserved() - torch.cuda.memory_allocated() > TRIM_GB * (1 << 30):
+                if (torch.cuda.memory_reserved() - torch.cuda.memory_allocated() > TRIM_GB * (1 << 30)
+                        and torch.cuda.mem_get_info()[0] < TRIM_FREE_GB * (1 << 30)):
                     torch.cuda.empty_cache()
         if self.anchor is None:
             self.anchor = getattr(model, "_omni_ddp_anchor", None)

@@ -122,6 +122,23 @@ class DeviceEvent:
 _PIPE_EVENTS = __import__("os").environ.get("OMNI_PIPE_EVENTS", "torch")      # "torch" | "device"
 
 
+_W_CHUNKS = int(__import__("os").environ.get("OMNI_PIPE_W_CHUNKS", "1"))
+
+
+class _GraphSeq:
+    """several graphs replayed back to back (OMNI_PIPE_W_CHUNKS)"""
+
+    def __init__(self):
+        self.graphs = []
+
+    def replay(self):
+        for g in self.graphs:
+            g.replay()
+
+    def pool(self):
+        return self.graphs[-1].pool()
+
+
 def make_side_stream(device=None):
     """The weight-gradient stream.  The critical path runs on the main stream and is ~92 % busy (rocprofv3 trace, queue 1: 11.4 of
     12.4 ms); whatever the side stream runs beside it competes for the same CUs, and a PERSISTENT side kernel (the fc1-class weight
@@ -508,7 +525,19 @@ class GraphedPipelined:
                 # -- 1.45 -> 0.79 ms, it is HBM-bound on the p2 maps and so is the fc1 weight gradient beside it -- and M2 pays it
                 # back, 1.73 -> 2.45 ms: the two streams share one throughput, where the weight gradients land does not matter)
                 gw = None
-                if fns:
+                if fns and _W_CHUNKS > 1:
+                    # A/B (OMNI_PIPE_W_CHUNKS=n): the stage's weight gradients as n graphs replayed one after the other -- more graph
+                    # boundaries on the weight-gradient queue, at which the command processor looks at the critical-path queue again
+                    gw = _GraphSeq()
+                    per = -(-len(fns) // _W_CHUNKS)
+                    for c0 in range(0, len(fns), per):
+                        g1 = torch.cuda.CUDAGraph()
+                        with lean_capture(g1, pool_w), detmode.domain("W"), wino.batched_wgrads():
+                            for fn in fns[c0:c0 + per]:
+                                fn()
+                        pool_w = g1.pool()
+                        gw.graphs.append(g1)
+                elif fns:
                     gw = torch.cuda.CUDAGraph()
                     with lean_capture(gw, pool_w), detmode.domain("W"), wino.batched_wgrads():
                         for fn in fns:          # (the Winograd-domain GEMMs of the stage leave together when the context closes)
