@@ -404,7 +404,11 @@ __global__ void __launch_bounds__(256) relu_inplace_kernel(float* __restrict__ y
 //   Rc x Sc tap subset: oh = ihc + oh_off - jr.  No MFMA work is spent on the structurally-zero taps
 //   (a 3x3/s2 dgrad does 9/4 taps per pixel instead of 9).  stride 1 is the single class (0, 0).
 // =================================================================================================
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BKX = 32>
+// PF >= 2 (late round 6): the operand path of gemm_nt_pf_kernel -- PF slabs of buffer loads in flight per thread, issued
+// unconditionally (padding taps, rows past M, slabs past this split's range get the out-of-range offset and come back as zeros), LDS
+// handed over behind an lgkmcnt-only barrier; the slab loop runs to a multiple of PF with zero slabs.  Same slab order and MFMA chain:
+// bit-identical to PF = 1 (the classic double buffer with guarded loads, kept for tensors a 32-bit byte offset does not reach).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BKX = 32, int PF = 1>
 __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
     constexpr int WM = BM / (32 * WAVES_M), WN = BN / (32 * WAVES_N);
     constexpr int BKP = BKX + 4, KQ = BKX / 4, RPP = 256 / KQ;
@@ -480,21 +484,28 @@ __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
         }
     }
     const int cb = n0 + bn4 * 4;
-    float4 ra[AI], rb[BI];
-    auto load_slab = [&]() {
-        const bool kok = kd < Kd;
+    float4 ra[PF][AI], rb[PF][BI];
+    const omni_rsrc_t rx_ = omni_make_rsrc(p.x, PF > 1 ? (unsigned)((long)p.N * p.OH * p.OW * p.ldx * 4) : 0u);
+    const omni_rsrc_t rw_ = omni_make_rsrc(p.w, PF > 1 ? (unsigned)((long)p.K * RSC * 4) : 0u);
+    int ld_cnt = 0;                                 // slabs fetched so far (PF > 1: a slab past this split's range loads zeros)
+    auto load_slab = [&](const int sg) {
+        const bool in_range = PF == 1 || ld_cnt < nk;       // (a slab past this split's range: zeros for both operands)
+        const bool kok = kd < Kd && in_range;
+        ++ld_cnt;
         const long tap_off = -((long)jr_cur * p.OW + js_cur) * p.ldx + k_cur;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int oh = a_oh[i] - jr_cur, ow = a_ow[i] - js_cur;
             const bool ok = a_ok[i] && kok && (unsigned)oh < (unsigned)p.OH && (unsigned)ow < (unsigned)p.OW;
-            ra[i] = ok ? ldg4(p.x + a_base[i] + tap_off) : zero4();
+            if (PF > 1) ra[sg][i] = bufld4(rx_, ok ? (int)((a_base[i] + tap_off) * 4) : OMNI_OOB);
+            else ra[sg][i] = ok ? ldg4(p.x + a_base[i] + tap_off) : zero4();
         }
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
-            const bool ok = (brow + BROWS * j < BKX) && kdb[j] < Kd && cb < p.C;
+            const bool ok = (brow + BROWS * j < BKX) && kdb[j] < Kd && cb < p.C && in_range;
             const int tap = (r0 + st * jrb[j]) * p.S + s0 + st * jsb[j];
-            rb[j] = ok ? ldg4(p.w + (long)kb[j] * RSC + (long)tap * p.C + cb) : zero4();
+            if (PF > 1) rb[sg][j] = bufld4(rw_, ok ? (int)(((long)kb[j] * RSC + (long)tap * p.C + cb) * 4) : OMNI_OOB);
+            else rb[sg][j] = ok ? ldg4(p.w + (long)kb[j] * RSC + (long)tap * p.C + cb) : zero4();
             if (tap_inner) {
                 if (++jsb[j] == Sc) {
                     jsb[j] = 0;
@@ -523,15 +534,15 @@ __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
             }
         }
     };
-    auto store_slab = [&](int buf) {
+    auto store_slab = [&](int buf, const int sg) {
         float* As = smem + buf * (BM * BKP + BKX * BN);
         float* Bs = As + BM * BKP;
 #pragma unroll
         for (int i = 0; i < AI; ++i)
-            if (lrow + RPP * i < BM) *reinterpret_cast<float4*>(As + (lrow + RPP * i) * BKP + kq * 4) = ra[i];
+            if (lrow + RPP * i < BM) *reinterpret_cast<float4*>(As + (lrow + RPP * i) * BKP + kq * 4) = ra[sg][i];
 #pragma unroll
         for (int j = 0; j < BI; ++j)
-            if (brow + BROWS * j < BKX) *reinterpret_cast<float4*>(Bs + (brow + BROWS * j) * BN + bn4 * 4) = rb[j];
+            if (brow + BROWS * j < BKX) *reinterpret_cast<float4*>(Bs + (brow + BROWS * j) * BN + bn4 * 4) = rb[sg][j];
     };
 
     f32x16 acc[WM][WN];
@@ -543,16 +554,33 @@ __global__ void __launch_bounds__(256) conv_dgrad_kernel(ConvP p) {
         // A split launch pre-zeroes dx and an accumulating one adds nothing; otherwise fall through and store zeros
         // (a deterministic split arrives with its zeros: the last arrival writes the tile).
         if (split || (p.accumulate && !det)) return;
+    } else if (PF > 1) {
+#pragma unroll
+        for (int sg = 0; sg < PF; ++sg) load_slab(sg);      // slabs 0 .. PF-1
+        store_slab(0, 0);
+        load_slab(0);                                       // slab PF
+        omni_barrier_lds();
+        for (int kt0 = 0; kt0 < nk; kt0 += PF) {            // (the last round may run into zero slabs)
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int buf = (kt0 + u) & 1;
+                store_slab(buf ^ 1, (u + 1) % PF);
+                load_slab((u + 1) % PF);
+                const float* As = smem + buf * (BM * BKP + BKX * BN);
+                mma_slab<WM, WN, true, false, 0, BN, BKX>(As, As + BM * BKP, wm * WM * 32, wn * WN * 32, lane, acc);
+                omni_barrier_lds();
+            }
+        }
     } else {
-        load_slab();
-        store_slab(0);
+        load_slab(0);
+        store_slab(0, 0);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
-            if (kt + 1 < nk) load_slab();
+            if (kt + 1 < nk) load_slab(0);
             const float* As = smem + buf * (BM * BKP + BKX * BN);
             mma_slab<WM, WN, true, false, 0, BN, BKX>(As, As + BM * BKP, wm * WM * 32, wn * WN * 32, lane, acc);
-            if (kt + 1 < nk) store_slab(buf ^ 1);
+            if (kt + 1 < nk) store_slab(buf ^ 1, 0);
             __syncthreads();
         }
     }
@@ -730,6 +758,132 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(ConvP p, int pix_per_sp
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
     conv_wgrad_body<BM, BN, WAVES_M, WAVES_N, BK>(p, pix_per_split, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x,
                                                   (int)gridDim.y, smem);
+}
+
+// Late round 6: the same weight gradient with the operand path of gemm_nt_pf_kernel / gemm_tn_pf_kernel -- PF slabs of buffer loads in
+// flight per thread, issued unconditionally (pixels past the split, padding taps and columns past K / R*S*C get the out-of-range
+// offset and come back as zeros, so the wait-count insertion keeps vmcnt(N) instead of draining at every guarded load), LDS handed
+// over behind an lgkmcnt-only barrier.  conv_wgrad_body above waits for every slab's loads before its MFMAs can start (PMC: MFMA-busy
+// 0.25 on the direct weight gradients).  Same slab order, same MFMA chain per output element: bit-identical; the reduction is padded
+// to a multiple of PF slabs with zero slabs.  Single-source problems whose tensors stay below 2 GiB (the launcher checks).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int PF>
+__device__ __forceinline__ void conv_wgrad_body_pf(ConvP& p, int pix_per_split, int bx, int by, int gx, int gy, float* smem) {
+    constexpr int WM = BM / (32 * WAVES_M), WN = BN / (32 * WAVES_N);
+    constexpr int AF4 = BM / 4, AROWS = 256 / AF4, AI = BK / AROWS;
+    constexpr int BF4 = BN / 4, BROWS = 256 / BF4, BI = BK / BROWS;
+    static_assert(AROWS * AI == BK && BROWS * BI == BK && WAVES_M * WAVES_N == 4, "tile mapping");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int P = p.N * p.OH * p.OW, Nn = p.R * p.S * p.C;
+    const int tiles_m = (p.K + BM - 1) / BM;
+    const int bid = p.relu ? xcd_chunked(bx, gx) : bx;
+    const int m0 = (bid % tiles_m) * BM, n0 = (bid / tiles_m) * BN;
+    const int p_begin = by * pix_per_split;
+    const int p_end = (p_begin + pix_per_split < P) ? p_begin + pix_per_split : P;
+    const int am4 = tid % AF4, arow = tid / AF4;
+    const int bn4 = tid % BF4, brow = tid / BF4;
+    const int nn = n0 + bn4 * 4;
+    const bool n_ok = nn < Nn;
+    const int tap = n_ok ? nn / p.C : 0;
+    const int bc = nn - tap * p.C;
+    const int br = tap / p.S - p.pad, bs = tap - (tap / p.S) * p.S - p.pad;
+    const int am = m0 + am4 * 4;
+    const bool m_ok = am < p.K;
+    const omni_rsrc_t ra_ = omni_make_rsrc(p.w, (unsigned)((long)P * p.ldw * 4));
+    const omni_rsrc_t rb_ = omni_make_rsrc(p.x, (unsigned)((long)p.N * p.H * p.W * p.ldx * 4));
+    int b_pix[BI], b_img[BI], b_oh[BI], b_ow[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int pix = p_begin + brow + BROWS * j;
+        const int pp = pix < P ? pix : 0;
+        const int img = pp / (p.OH * p.OW), rem = pp - img * (p.OH * p.OW);
+        b_pix[j] = pix;
+        b_img[j] = img;
+        b_oh[j] = rem / p.OW;
+        b_ow[j] = rem - b_oh[j] * p.OW;
+    }
+    const int d_img = BK / (p.OH * p.OW), d_rem = BK - d_img * (p.OH * p.OW);
+    const int d_oh = d_rem / p.OW, d_ow = d_rem - d_oh * p.OW;
+    int a_off = ((p_begin + arow) * p.ldw + am) * 4;          // byte offset of this thread's first dy row of the NEXT slab
+    int a_pix = p_begin + arow;
+    const int a_row = AROWS * p.ldw * 4, a_slab = BK * p.ldw * 4;
+
+    float4 ra[PF][AI], rb[PF][BI];
+    auto load_slab = [&](const int st) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) ra[st][i] = bufld4(ra_, (m_ok && a_pix + AROWS * i < p_end) ? a_off + a_row * i : OMNI_OOB);
+        a_off += a_slab;
+        a_pix += BK;
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const int ih = b_oh[j] * p.stride + br, iw = b_ow[j] * p.stride + bs;
+            const bool ok = n_ok && b_pix[j] < p_end && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            rb[st][j] = bufld4(rb_, ok ? (((b_img[j] * p.H + ih) * p.W + iw) * p.ldx + bc) * 4 : OMNI_OOB);
+            b_pix[j] += BK;
+            b_ow[j] += d_ow;
+            if (b_ow[j] >= p.OW) { b_ow[j] -= p.OW; ++b_oh[j]; }
+            b_oh[j] += d_oh;
+            if (b_oh[j] >= p.OH) { b_oh[j] -= p.OH; ++b_img[j]; }
+            b_img[j] += d_img;
+        }
+    };
+    auto store_slab = [&](int buf, const int st) {
+        float* As = smem + buf * BK * (BM + BN);
+        float* Bs = As + BK * BM;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<float4*>(As + (arow + AROWS * i) * BM + am4 * 4) = ra[st][i];
+#pragma unroll
+        for (int j = 0; j < BI; ++j) *reinterpret_cast<float4*>(Bs + (brow + BROWS * j) * BN + bn4 * 4) = rb[st][j];
+    };
+
+    f32x16 acc[WM][WN];
+    zero_acc<WM, WN>(acc);
+    const int nk = (p_end - p_begin + BK - 1) / BK;
+    const bool det = p.ctr != nullptr && gy > 1;
+    if (nk <= 0 && !det) return;
+    if (nk > 0) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) load_slab(s);          // slabs 0 .. PF-1 (slabs past the split: zeros)
+        store_slab(0, 0);
+        load_slab(0);                                       // slab PF
+        omni_barrier_lds();
+        for (int kt0 = 0; kt0 < nk; kt0 += PF) {            // (the last round may run into zero slabs: they add nothing)
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int buf = (kt0 + u) & 1;
+                store_slab(buf ^ 1, (u + 1) % PF);
+                load_slab((u + 1) % PF);
+                const float* As = smem + buf * BK * (BM + BN);
+                mma_slab<WM, WN, false, false, BM, BN, BK>(As, As + BK * BM, wm * WM * 32, wn * WN * 32, lane, acc);
+                omni_barrier_lds();
+            }
+        }
+    }
+    const int l31 = lane & 31, h = lane >> 5;
+    if (det && !omni_split_reduce<WM, WN>(p.ws, p.ctr, (long)bx, by, gy, acc))
+        return;
+    const bool single = gy == 1 && !p.accumulate;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + (wn * WN + j) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.K && n < Nn) {
+                    float* o = p.out + (long)m * Nn + n;
+                    if (single || (det && !p.accumulate)) *o = acc[i][j][r];
+                    else atomicAdd(o, acc[i][j][r]);
+                }
+            }
+        }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int PF>
+__global__ void __launch_bounds__(256) conv_wgrad_pf_kernel(ConvP p, int pix_per_split) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    conv_wgrad_body_pf<BM, BN, WAVES_M, WAVES_N, BK, PF>(p, pix_per_split, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, smem);
 }
 
 // Round 6: the direct weight gradients of one backward stage in ONE launch (the Winograd-domain ones have had
@@ -1465,6 +1619,19 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, float* dx, int N, 
         p.ctr = det.ctr;
     }
     if (splits > 1 && !accumulate && !ordered) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, st);
+    // deep-prefetch form (PF = 2) when a 32-bit byte offset reaches both operands; OMNI_DGRAD_PF=0: the classic body (A/B knob)
+    static const int dgrad_pf = [] { const char* e = getenv("OMNI_DGRAD_PF"); return e ? atoi(e) : 2; }();
+    const bool dpf_ok = dgrad_pf >= 2 && (long)N * p.OH * p.OW * lddy * 4 < (1L << 31) && (long)K * R * S * C * 4 < (1L << 31);
+#define OMNI_DGRAD_PF(BM_, BN_, WM_, WN_, BK_)                                                                           \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<BM_, BN_, WM_, WN_, BK_, 2>),                                     \
+                       dim3((unsigned)(((M + BM_ - 1) / BM_) * ((C + BN_ - 1) / BN_)), (unsigned)splits, ncls), dim3(256), 0, st, p)
+    if (dpf_ok && tile >= 1 && tile <= 3) {
+        if (tile == 1) OMNI_DGRAD_PF(128, 128, 2, 2, 32);
+        else if (tile == 2) OMNI_DGRAD_PF(64, 64, 2, 2, 32);
+        else OMNI_DGRAD_PF(128, 64, 2, 2, 32);
+        return omni_launch_status();
+    }
+#undef OMNI_DGRAD_PF
 #define OMNI_DGRAD(BM_, BN_, WM_, WN_, BK_)                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<BM_, BN_, WM_, WN_, BK_>),                                        \
                        dim3((unsigned)(((M + BM_ - 1) / BM_) * ((C + BN_ - 1) / BN_)), (unsigned)splits, ncls), dim3(256), 0, st, p)
@@ -1593,6 +1760,21 @@ static int conv2d_wgrad_impl(const float* x, const float* dy, float* dw, int N, 
     if (splits > 1 && !accumulate && !ordered) omni_memset_async(dw, 0, sizeof(float) * (size_t)K * Nn, (hipStream_t)stream);
     if (xcd_order < 0) xcd_order = (WGRAD_XCD_ORDER_FC && R == 1 && S == 1 && H == 1 && W == 1 && splits == 1) ? 1 : 0;
     p.relu = xcd_order;
+    // deep-prefetch form (conv_wgrad_pf_kernel): single-source problems whose operands a 32-bit buffer offset reaches
+    static const int wgrad_pf = [] { const char* e = getenv("OMNI_WGRAD_PF"); return e ? atoi(e) : 2; }();      // A/B knob: 0 = the classic body
+    const bool pf_ok = wgrad_pf >= 2 && ms == nullptr && (long)P * lddy * 4 < (1L << 31) && (long)N * H * W * ldx * 4 < (1L << 31);
+#define OMNI_WGRAD_PF(BM_, BN_, WM_, WN_, PF_)                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pf_kernel<BM_, BN_, WM_, WN_, WBK, PF_>), dim3(tiles, (unsigned)splits), dim3(256), 0, \
+                       (hipStream_t)stream, p, pps)
+    if (pf_ok) {
+        // (wgrad_pf == 3, A/B: three slabs in flight on the tiles whose registers allow it without losing a wave per SIMD)
+        if (bm == 128 && bn == 128) OMNI_WGRAD_PF(128, 128, 2, 2, 2);
+        else if (bm == 128) OMNI_WGRAD_PF(128, 64, 2, 2, 2);
+        else if (bm == 64) { if (wgrad_pf >= 3) OMNI_WGRAD_PF(64, 64, 2, 2, 3); else OMNI_WGRAD_PF(64, 64, 2, 2, 2); }
+        else { if (wgrad_pf >= 3) OMNI_WGRAD_PF(32, 128, 1, 4, 3); else OMNI_WGRAD_PF(32, 128, 1, 4, 2); }
+        return omni_launch_status();
+    }
+#undef OMNI_WGRAD_PF
 #define OMNI_WGRAD(BM_, BN_, WM_, WN_)                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_kernel<BM_, BN_, WM_, WN_, WBK>), dim3(tiles, (unsigned)splits), dim3(256), 0, \
                        (hipStream_t)stream, p, pps)
