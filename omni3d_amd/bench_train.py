@@ -685,7 +685,7 @@ def dominant_kernel_roofline(iters=20):
         fam("FC weight gradient (round 5: a tile kernel on the weight-gradient stream -- the engine's balanced form held 410 registers "
             "per lane on every CU and stalled the main stream, kernels/conv.py; late round 6: 64x64 tiles, 3136 of them end together where "
             "1568 of 128x64 left a third round of 32 workgroups; accumulated into the gradient bucket; in the step the row averages "
-            "the box head's 2048-row and the cube head's 512-row launch)", "conv_wgrad_kernel<64, 64, 2, 2, 32>",
+            "the box head's 2048-row and the cube head's 512-row launch; deep-prefetch operand path since late round 6)", "conv_wgrad_pf_kernel<64, 64, 2, 2, 32, 2>",
             "[1024x2048]x[2048x12544] box-head fc1 (16 x 196 tiles)", 2.0 * 2048 * 12544 * 1024,
             lambda: conv.linear_wgrad(x1, dy1, accum_into=gacc1), grid=802816, per_step=2, step_gflop=(2.0 * (2048 + 512) * 12544 * 1024) / 2 / 1e9),
         fam("Winograd weight-gradient GEMMs, small maps", "gemm_tn_pf_kernel<4>", "36x[128x1024]x[1024x128] (DLA level 3)", fl3,
@@ -700,7 +700,7 @@ def dominant_kernel_roofline(iters=20):
             2.0 * B * 64 * 64 * 128 * 64 * 9, lambda: conv.conv2d_dgrad(dys, ws, (128, 128), 2, 1), grid=65536, step_grid="65536x1x1", per_step=1,
             alg_bytes=4.0 * (B * 64 * 64 * 128 + B * 128 * 128 * 64 + 128 * 9 * 64)),
         fam("direct wgrad 128x64 tiles (VERDICT r4 missing 2: the #2 symbol of the round-4 table; 23 launches / step on the weight-gradient stream)",
-            "conv_wgrad_kernel<128, 64, 2, 2, 32>", "3x3/s2 64->128 @128x128: [128 x 65536]x[65536 x 576], 9 tiles x 64 pixel splits",
+            "conv_wgrad_pf_kernel<128, 64, 2, 2, 32, 2>", "3x3/s2 64->128 @128x128: [128 x 65536]x[65536 x 576], 9 tiles x 64 pixel splits",
             2.0 * B * 64 * 64 * 128 * 64 * 9, lambda: conv.conv2d_wgrad(xs, dys, (3, 3), 2, 1, accum_into=gws), grid=2304 * 64, step_grid="2304x64x1", per_step=23),
         fam("stem data gradient, stride 2 (round 5, MFMA 16x16x4: 2.4 GFLOP against 100 MB -- HBM floor 12.5 us, MFMA floor 15 us)", "stem_dgrad_s2_kernel<16, 32>",
             "3x3/s2 16->32 @512x512 (DLA level1), dx from dy", 2.0 * B * 256 * 256 * 32 * 16 * 9,
