@@ -880,10 +880,24 @@ __device__ __forceinline__ void conv_wgrad_body_pf(ConvP& p, int pix_per_split, 
         }
 }
 
+// xcd_splits: every tile of ONE pixel split reads the same dy rows (all (tap, c) tiles) and the same x pixels (all K tiles), but in the
+// launch order (tile fastest, workgroup ids round-robin over the 8 XCDs) the tiles of a split land on eight different L2s and each
+// fetches that range for itself (PMC, 3x3/s2 64->128: 145 MB fetched for 25 MB of operands).  With the flag the first 8 * (splits / 8)
+// splits are dealt out so that XCD q runs splits q, q + 8, ... with all their tiles; the remaining splits keep the plain order.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int PF>
-__global__ void __launch_bounds__(256) conv_wgrad_pf_kernel(ConvP p, int pix_per_split) {
+__global__ void __launch_bounds__(256) conv_wgrad_pf_kernel(ConvP p, int pix_per_split, int xcd_splits) {
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
-    conv_wgrad_body_pf<BM, BN, WAVES_M, WAVES_N, BK, PF>(p, pix_per_split, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, smem);
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+    if (xcd_splits) {
+        const int lin = by * gx + bx, gy8 = gy & ~7;
+        if (lin < gx * gy8) {
+            const int q = lin & 7, k = lin >> 3;
+            by = q + 8 * (k / gx);
+            bx = k - (k / gx) * gx;
+        }
+    }
+    conv_wgrad_body_pf<BM, BN, WAVES_M, WAVES_N, BK, PF>(p, pix_per_split, bx, by, gx, gy, smem);
 }
 
 // Round 6: the direct weight gradients of one backward stage in ONE launch (the Winograd-domain ones have had
@@ -1763,9 +1777,13 @@ static int conv2d_wgrad_impl(const float* x, const float* dy, float* dw, int N, 
     // deep-prefetch form (conv_wgrad_pf_kernel): single-source problems whose operands a 32-bit buffer offset reaches
     static const int wgrad_pf = [] { const char* e = getenv("OMNI_WGRAD_PF"); return e ? atoi(e) : 2; }();      // A/B knob: 0 = the classic body
     const bool pf_ok = wgrad_pf >= 2 && ms == nullptr && (long)P * lddy * 4 < (1L << 31) && (long)N * H * W * ldx * 4 < (1L << 31);
+    // MEASURED and left OFF (profiles/r06_ab_wgrad_xcd_splits.log): 10.66-10.68 ms with, 10.66-10.68 without; the 3x3/s2 64->128 launch
+    // 52 us either way -- the re-fetched ranges come out of the memory-side cache, not HBM
+    static const int wgrad_xcd_splits = [] { const char* e = getenv("OMNI_WGRAD_XCD_SPLITS"); return e ? atoi(e) : 0; }();      // A/B knob
+    const int xcd_splits = (wgrad_xcd_splits && splits >= 8 && tiles > 1) ? 1 : 0;
 #define OMNI_WGRAD_PF(BM_, BN_, WM_, WN_, PF_)                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_pf_kernel<BM_, BN_, WM_, WN_, WBK, PF_>), dim3(tiles, (unsigned)splits), dim3(256), 0, \
-                       (hipStream_t)stream, p, pps)
+                       (hipStream_t)stream, p, pps, xcd_splits)
     if (pf_ok) {
         // (wgrad_pf == 3, A/B: three slabs in flight on the tiles whose registers allow it without losing a wave per SIMD)
         if (bm == 128 && bn == 128) OMNI_WGRAD_PF(128, 128, 2, 2, 2);

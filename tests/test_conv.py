@@ -17,6 +17,7 @@ CASES = [
     (1, 7, 6, 16, 24, 1, 2, 0),     # 1x1/s2 (ResNet downsample): three of the four dgrad classes have no taps -> zeros
     (1, 12, 10, 4, 16, 7, 2, 3),    # 7x7/s2 ResNet stem
     (2, 5, 6, 16, 72, 3, 1, 1),     # wgrad 128x128 tile (K > 64, R*S*C > 64), pixel cursor wrapping rows and images
+    (2, 32, 40, 64, 128, 3, 1, 1),  # wgrad: 9 tiles x 10 pixel splits (with OMNI_WGRAD_XCD_SPLITS=1: 8 of them dealt out per XCD, 2 in the plain order)
 ]
 
 
