@@ -1635,7 +1635,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, float* dx, int N, 
     if (splits > 1 && !accumulate && !ordered) omni_memset_async(dx, 0, sizeof(float) * (size_t)N * H * W * C, st);
     // deep-prefetch form (PF = 2) when a 32-bit byte offset reaches both operands; OMNI_DGRAD_PF=0: the classic body (A/B knob)
     static const int dgrad_pf = [] { const char* e = getenv("OMNI_DGRAD_PF"); return e ? atoi(e) : 2; }();
-    const bool dpf_ok = dgrad_pf >= 2 && (long)N * p.OH * p.OW * lddy * 4 < (1L << 31) && (long)K * R * S * C * 4 < (1L << 31);
+    const bool dpf_ok = dgrad_pf >= 2 && (long)N * p.OH * p.OW * lddy * 4 < (1L << 31) - (1L << 24) && (long)K * R * S * C * 4 < (1L << 31) - (1L << 24);
 #define OMNI_DGRAD_PF(BM_, BN_, WM_, WN_, BK_)                                                                           \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dgrad_kernel<BM_, BN_, WM_, WN_, BK_, 2>),                                     \
                        dim3((unsigned)(((M + BM_ - 1) / BM_) * ((C + BN_ - 1) / BN_)), (unsigned)splits, ncls), dim3(256), 0, st, p)
@@ -1776,7 +1776,8 @@ static int conv2d_wgrad_impl(const float* x, const float* dy, float* dw, int N, 
     p.relu = xcd_order;
     // deep-prefetch form (conv_wgrad_pf_kernel): single-source problems whose operands a 32-bit buffer offset reaches
     static const int wgrad_pf = [] { const char* e = getenv("OMNI_WGRAD_PF"); return e ? atoi(e) : 2; }();      // A/B knob: 0 = the classic body
-    const bool pf_ok = wgrad_pf >= 2 && ms == nullptr && (long)P * lddy * 4 < (1L << 31) && (long)N * H * W * ldx * 4 < (1L << 31);
+    // (16 MiB of head-room: the byte cursors run up to PF slabs past the last pixel before their loads are masked)
+    const bool pf_ok = wgrad_pf >= 2 && ms == nullptr && (long)P * lddy * 4 < (1L << 31) - (1L << 24) && (long)N * H * W * ldx * 4 < (1L << 31) - (1L << 24);
     // MEASURED and left OFF (profiles/r06_ab_wgrad_xcd_splits.log): 10.66-10.68 ms with, 10.66-10.68 without; the 3x3/s2 64->128 launch
     // 52 us either way -- the re-fetched ranges come out of the memory-side cache, not HBM
     static const int wgrad_xcd_splits = [] { const char* e = getenv("OMNI_WGRAD_XCD_SPLITS"); return e ? atoi(e) : 0; }();      // A/B knob
