@@ -21,6 +21,7 @@ from .fpn import FPN, Backbone
 
 _ROOT_MULTI_SRC = os.environ.get("OMNI_ROOT_MULTI_SRC", "1") != "0"     # A/B knob: 0 = Root concatenates its children (rounds 1-4)
 _SHARE_POOL = os.environ.get("OMNI_DLA_SHARE_POOL", "1") != "0"      # A/B knob: nested trees pool their common input once
+_SIDE_STATS = os.environ.get("OMNI_DLA_SIDE_STATS", "1") != "0"      # A/B knob: statistics-only projections of nested trees on the weight-gradient stream
 
 
 class ConvBNReLU(nn.Sequential):
@@ -176,8 +177,18 @@ class Tree(nn.Module):
         if self.levels > 1 and self.project is not None:
             # a nested Tree recomputes `residual` from its own projection and drops this one (dla.py:208-213 of the reference):
             # run it for its BatchNorm's running statistics only -- no autograd graph, no saved activations
-            with torch.no_grad():
-                self.project(bottom.detach())
+            if _SIDE_STATS and HF.side_mode() == "collect":
+                # a step being captured: nothing in the step reads that BatchNorm's running statistics, so the 1 x 1 convolution + statistics
+                # leave the critical path and replay in the stage's weight-gradient graph (late round 6; OMNI_DLA_SIDE_STATS=0: inline)
+                src = bottom.detach()
+
+                def stats_only(src=src):
+                    with torch.no_grad():
+                        self.project(src)
+                HF._side_run(stats_only, (src,))
+            else:
+                with torch.no_grad():
+                    self.project(bottom.detach())
             residual = None
         else:
             residual = self.project(bottom) if self.project is not None else bottom
